@@ -1,0 +1,288 @@
+/* bath_oracle.h -- CPU restatement of the bathsearch DP hot path (TEST INFRASTRUCTURE ONLY).
+ *
+ * This directory is the parity ORACLE for bath_amd. It is a plain-C, scalar restatement of the
+ * reference algorithms (TravisWheelerLab/BATH, /root/reference/src). Nothing in the shipped
+ * product (bath_amd/, include/) may call into it; only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py do.
+ *
+ * PINNING STATUS (see DESIGN.md "Oracle"):
+ *   The reference cannot be built in this image (it needs the un-vendored easel library,
+ *   INSTALL:7-8), so there is no oracle/_ref. The oracle is pinned against the only golden
+ *   vectors the reference tree holds for this path: the pipeline counters and hit tables recorded
+ *   in the tutorial .out and .tbl files (tests/golden/), plus the reference unit tests' identities
+ *   (MSV == GViterbi(SameAsMF), Fwd == Bwd, parser == full).  Pieces that live in easel
+ *   (alphabets, esl_gencode ORF finder, esl_hmm_Forward, gumbel/exp tails) are restated from the
+ *   published easel algorithms and are pinned only through those end-to-end counters.
+ *
+ * Every function cites the reference file:line it follows.
+ */
+#ifndef BATH_ORACLE_H
+#define BATH_ORACLE_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* easel status codes the kernels return (easel.h; used at p7_pipeline.c:1471, msvfilter.c:179) */
+#define BO_OK         0
+#define BO_FAIL       1
+#define BO_EMEM       5
+#define BO_EFORMAT    7
+#define BO_EINVAL    11
+#define BO_ERANGE    16
+#define BO_ENORESULT 19
+
+#define BO_K_AMINO   20
+#define BO_KP_AMINO  29
+#define BO_K_DNA      4
+#define BO_KP_DNA    18
+#define BO_DSQ_SENTINEL 255
+
+/* evparam indices, hmmer.h:67 */
+enum { BO_MMU = 0, BO_MLAMBDA, BO_VMU, BO_VLAMBDA, BO_FTAU, BO_FLAMBDA, BO_FTAUFS3, BO_FTAUFS5, BO_NEVPARAM };
+
+/* generic transition order, hmmer.h:221-231 */
+enum { BO_MM = 0, BO_IM, BO_DM, BO_BM, BO_MD, BO_DD, BO_MI, BO_II, BO_NTRANS };
+/* hmm file transition order, p7_hmmfile.c:1615 / hmmer.h p7H_* */
+enum { BO_H_MM = 0, BO_H_MI, BO_H_MD, BO_H_IM, BO_H_II, BO_H_DM, BO_H_DD, BO_H_NTRANS };
+/* special states, hmmer.h:202-218 */
+enum { BO_XE = 0, BO_XN, BO_XJ, BO_XC };
+enum { BO_LOOP = 0, BO_MOVE };
+/* generic DP special cells xmx[i*5+s], hmmer.h:621-628 */
+enum { BO_GE = 0, BO_GN, BO_GJ, BO_GB, BO_GC, BO_NXCELLS };
+/* generic DP main cells, hmmer.h:604-619 */
+enum { BO_GD = 0, BO_GI = 1, BO_GM = 2, BO_NSCELLS = 3, BO_NSCELLS_FS = 8 };
+
+#define BO_MAXCODONS5 1367
+#define BO_MAXCODONS3 338
+#define BO_DEGEN5_C   1364
+#define BO_DEGEN5_QC1 1365
+#define BO_DEGEN5_QC2 1366
+#define BO_DEGEN3_C   336
+#define BO_DEGEN3_QC1 337
+
+/* ---------- core HMM (p7_hmm.c / hmmer.h P7_HMM) ---------- */
+typedef struct {
+  int    M;
+  int    max_length;
+  int    ct;                       /* NCBI codon table id                      */
+  float  fsprob;                   /* FRAMESHIFT PROB                          */
+  float *t;                        /* [ (M+1) * 7 ]   p7H order                */
+  float *mat;                      /* [ (M+1) * 20 ]                           */
+  float *ins;                      /* [ (M+1) * 20 ]                           */
+  float  compo[BO_K_AMINO];
+  float  evparam[BO_NEVPARAM];
+  char   name[128];
+  char   acc[64];
+  char  *consensus;                /* [M+2] */
+} bo_hmm;
+
+/* ---------- generic profile (hmmer.h:338 P7_PROFILE) ---------- */
+typedef struct {
+  int    M, L, max_length;
+  float  nj;
+  float *tsc;                      /* [ (M+1)*8 ]  (k=0..M-1 used; row M zeroed/-inf as reference leaves it) */
+  float *rsc;                      /* [Kp][ (M+1)*2 ]  MSC at [x][k*2], ISC at [x][k*2+1]                   */
+  float  xsc[4][2];
+  float  evparam[BO_NEVPARAM];
+  float  compo[BO_K_AMINO];
+} bo_profile;
+
+/* ---------- frameshift profile (hmmer.h:371 P7_FS_PROFILE) ---------- */
+typedef struct {
+  int    M, L, max_length, codon_lengths, maxcodons;
+  float  nj, fsprob;
+  float *tsc;                      /* [ (M+1)*8 ] */
+  float *rsc;                      /* [ (maxcodons+Kp) * (M+1) ]  row-major rsc[c][k] */
+  uint8_t *codons;                 /* [ (M+1) * maxcodons ]  best amino per (k,codon)  */
+  uint8_t *indel_pos;              /* [ (M+1) * maxcodons ]                             */
+  float  xsc[4][2];
+  float  evparam[BO_NEVPARAM];
+  float  compo[BO_K_AMINO];
+} bo_fs_profile;
+
+/* ---------- "optimized profile" scores, UNSTRIPED (impl_sse.h:75 P7_OPROFILE) ---------- */
+typedef struct {
+  int      M, L, max_length;
+  float    nj;
+  /* MSV */
+  uint8_t *rb;                     /* [Kp][M+1] biased byte costs (k=1..M; [x][0] = 255)          */
+  uint8_t  tbm_b, tec_b, tjb_b, base_b, bias_b;
+  float    scale_b;
+  /* Viterbi */
+  int16_t *rw;                     /* [Kp][M+1] word scores                                       */
+  int16_t *tw;                     /* [M+1][8] in generic order MM,IM,DM,BM,MD,DD,MI,II; value for
+                                      "transition out of/into node k" exactly as the striped twv holds */
+  int16_t  xw[4][2];
+  float    scale_w;
+  int16_t  base_w, ddbound_w;
+  /* Forward (odds ratios) */
+  float   *rf;                     /* [Kp][M+1] */
+  float   *tf;                     /* [M+1][8]  */
+  float    xf[4][2];
+  float    evparam[BO_NEVPARAM];
+  float    compo[BO_K_AMINO];
+} bo_oprofile;
+
+/* ---------- background (p7_bg.c) ---------- */
+typedef struct {
+  float f[BO_K_AMINO];
+  float p1;
+  /* 2-state filter HMM (esl_hmm) */
+  float t[2][3];
+  float e[2][BO_K_AMINO];
+  float eo[BO_KP_AMINO][2];
+  float pi[3];
+} bo_bg;
+
+/* ---------- score data (p7_scoredata.c) ---------- */
+typedef struct {
+  int      M;
+  uint8_t *ssv_scores;             /* [(M+1)*Kp] */
+  float   *prefix_lengths;         /* [M+1] */
+  float   *suffix_lengths;         /* [M+1] */
+} bo_scoredata;
+
+typedef struct {                   /* hmmer.h P7_HMM_WINDOW (fields used on the path) */
+  int32_t id, n, k, length;
+  float   score;
+} bo_window;
+
+typedef struct { bo_window *w; int count, size; } bo_windowlist;
+
+/* ---------- ORFs (esl_gencode_Process*, easel; bathsearch.c:384-392) ---------- */
+typedef struct {
+  int32_t start, end;              /* 1-based nt coords on the CURRENT strand's sequence; start<end */
+  int32_t n;                       /* aa length                                                    */
+  int32_t frame;                   /* 0..2                                                         */
+  int64_t off;                     /* offset of dsq[1] in the aa pool (sentinel at off-1... see .c) */
+} bo_orf;
+
+typedef struct { bo_orf *orf; int count, size; uint8_t *aa; int64_t aa_n, aa_size; } bo_orfblock;
+
+/* ============ alphabet / genetic code  (abc.c) ============ */
+int  bo_amino_digitize(char c);                 /* -1 if not in alphabet */
+int  bo_dna_digitize(char c);
+extern const char bo_amino_syms[];              /* "ACDEFGHIKLMNPQRSTVWY-BJZOUX*~" */
+extern const char bo_dna_syms[];                /* "ACGT-RYMKSWHBVDN*~"            */
+int  bo_amino_degen(int x, int y);              /* does degenerate x include canonical y */
+int  bo_dna_degen(int x, int y);
+uint8_t bo_dna_complement(uint8_t x);
+int  bo_gencode_basic(int ct, uint8_t basic[64]);              /* 16*n1+4*n2+n3 -> amino code */
+uint8_t bo_gencode_translate(const uint8_t basic[64], const uint8_t *codon3); /* esl_gencode_GetTranslation */
+void bo_revcomp(const uint8_t *dsq, int n, uint8_t *out);      /* dsq,out 1-based with sentinels */
+
+/* ============ hmm file (hmmfile.c) ============ */
+int  bo_hmmfile_read(const char *path, int index, bo_hmm **ret);  /* index-th model in file */
+int  bo_hmmfile_count(const char *path);
+void bo_hmm_free(bo_hmm *h);
+
+/* ============ profiles (profile.c) ============ */
+void bo_bg_create(bo_bg *bg);                                    /* p7_bg.c:44 */
+void bo_bg_setlength(bo_bg *bg, int L);                          /* p7_bg.c:189 */
+void bo_bg_setfilter(bo_bg *bg, int M, const float *compo);      /* p7_bg.c:449 */
+float bo_bg_nullone(const bo_bg *bg, int L);                     /* p7_bg.c:356 */
+float bo_bg_fs_nullone(const bo_bg *bg, int aminoL);             /* p7_bg.c:377 */
+float bo_bg_filterscore(const bo_bg *bg, const uint8_t *dsq, int L);  /* p7_bg.c:491 */
+float bo_bg_fs_filterscore(const bo_bg *bg, const uint8_t *dna, int L, const uint8_t basic[64]); /* p7_bg.c:522 */
+
+bo_profile    *bo_profile_config(const bo_hmm *h, const bo_bg *bg, int L);           /* modelconfig.c:48 (p7_LOCAL) */
+void           bo_profile_reconfig_length(bo_profile *gm, int L);                    /* modelconfig.c:723 */
+void           bo_profile_free(bo_profile *gm);
+bo_fs_profile *bo_fs_profile_config(const bo_hmm *h, const bo_bg *bg, const uint8_t basic[64], int codon_lengths, int L_amino); /* modelconfig.c:220 */
+void           bo_fs_profile_reconfig_length(bo_fs_profile *gm, int L_amino);        /* modelconfig.c:760 */
+void           bo_fs_profile_reconfig_unihit(bo_fs_profile *gm, int L_amino);        /* modelconfig.c:868 */
+void           bo_fs_profile_reconfig_multihit(bo_fs_profile *gm, int L_amino);      /* modelconfig.c:825 */
+void           bo_fs_profile_free(bo_fs_profile *gm);
+bo_oprofile   *bo_oprofile_convert(const bo_profile *gm);                            /* p7_oprofile.c:1091 */
+void           bo_oprofile_reconfig_length(bo_oprofile *om, int L);                  /* p7_oprofile.c:1261 */
+void           bo_oprofile_reconfig_msv_length(bo_oprofile *om, int L);              /* p7_oprofile.c:1286 */
+void           bo_oprofile_free(bo_oprofile *om);
+bo_scoredata  *bo_scoredata_create(const bo_oprofile *om);                           /* p7_scoredata.c:57,314 */
+void           bo_scoredata_free(bo_scoredata *sd);
+
+/* ============ statistics (easel esl_gumbel.c / esl_exponential.c) ============ */
+double bo_gumbel_surv(double x, double mu, double lambda);
+double bo_gumbel_invsurv(double p, double mu, double lambda);
+double bo_exp_surv(double x, double mu, double lambda);
+
+/* ============ logsum (logsum.c:80-111) ============ */
+void  bo_flogsum_init(void);
+float bo_flogsum(float a, float b);
+void  bo_flogsum_set_exact(int exact);  /* 1: use exact log(1+exp()) instead of table (logsum.c:109) */
+const float *bo_flogsum_table(void);
+
+/* ============ filters (filters.c) ============ */
+int   bo_ssvfilter(const uint8_t *dsq, int L, const bo_oprofile *om, float *ret_sc);  /* ssvfilter.c:876 */
+int   bo_msvfilter(const uint8_t *dsq, int L, const bo_oprofile *om, float *ret_sc);  /* msvfilter.c:74 (incl. SSV first) */
+int   bo_msvfilter_noSSV(const uint8_t *dsq, int L, const bo_oprofile *om, float *ret_sc); /* msvfilter.c:106-207 only */
+int   bo_ssvfilter_bath(const uint8_t *dsq, int L, bo_oprofile *om, const bo_scoredata *sd, bo_bg *bg, double P, bo_windowlist *wl); /* msvfilter.c:250 */
+int   bo_vitfilter(const uint8_t *dsq, int L, const bo_oprofile *om, float *ret_sc);  /* vitfilter.c:83 */
+int   bo_vitfilter_bath(const uint8_t *dsq, int L, const bo_oprofile *om, const bo_scoredata *sd, float filtersc, double P, bo_windowlist *wl, float *ret_sc); /* vitfilter.c:286 */
+int   bo_forward_parser(const uint8_t *dsq, int L, const bo_oprofile *om, float *xmx6 /* (L+1)*6 or NULL */, float *ret_sc); /* fwdback.c:132,256 */
+int   bo_backward_parser(const uint8_t *dsq, int L, const bo_oprofile *om, const float *fwd_xmx6, float *bck_xmx6, float *ret_sc); /* fwdback.c:236,468 */
+/* generic scalar std kernels used for the exact-emulation identities (generic_viterbi.c, generic_msv.c) */
+int   bo_gviterbi(const uint8_t *dsq, int L, const bo_profile *gm, float *ret_sc);    /* generic_viterbi.c */
+int   bo_gforward(const uint8_t *dsq, int L, const bo_profile *gm, float *ret_sc);    /* generic_fwdback.c */
+bo_profile *bo_profile_same_as_mf(const bo_oprofile *om, const bo_profile *gm);       /* p7_oprofile.c:2141 */
+bo_profile *bo_profile_same_as_vf(const bo_oprofile *om, const bo_profile *gm);       /* p7_oprofile.c:2202 */
+
+void  bo_windowlist_init(bo_windowlist *wl);
+void  bo_windowlist_free(bo_windowlist *wl);
+
+/* ============ ORF finder (translate.c) ============ */
+void  bo_orfblock_init(bo_orfblock *b);
+void  bo_orfblock_reuse(bo_orfblock *b);
+void  bo_orfblock_free(bo_orfblock *b);
+/* translate one strand of dsq[1..n] (already reverse-complemented by the caller for the bottom strand) */
+int   bo_translate_orfs(const uint8_t *dsq, int n, const uint8_t basic[64], int minlen, bo_orfblock *out);
+
+/* ============ frameshift generic kernels (fs_*.c) ============ */
+/* GMX-like matrices: dp rows of (M+1)*nscells floats, xmx (L+1)*5 floats */
+typedef struct { int M, L, nrows, nscells; float *dp; float *xmx; } bo_gmx;
+bo_gmx *bo_gmx_create(int M, int nrows, int L, int nscells);
+void    bo_gmx_free(bo_gmx *gx);
+#define BO_DP(gx,i,k,s) ((gx)->dp[((size_t)(i) * ((gx)->M+1) + (k)) * (gx)->nscells + (s)])
+#define BO_X(gx,i,s)    ((gx)->xmx[(size_t)(i) * BO_NXCELLS + (s)])
+
+/* c5_compat=1 reproduces generic_fwdback_frameshift.c:324 `(i-5)%5` aliasing; 0 uses (i-4) like fwdback_fs.c:1464 */
+int bo_gforward_fs(const uint8_t *dsq, int L, const bo_fs_profile *gm5, bo_gmx *gx, int c5_compat, float *ret_sc);      /* generic_fwdback_frameshift.c:64 */
+int bo_gbackward_fs(const uint8_t *dsq, int L, const bo_fs_profile *gm5, bo_gmx *gx, float *ret_sc);                    /* :1035 */
+int bo_gforward_parser_fs3(const uint8_t *dsq, int L, const bo_fs_profile *gm3, bo_gmx *gx, float *ret_sc);            /* :451 */
+int bo_gbackward_parser_fs3(const uint8_t *dsq, int L, const bo_fs_profile *gm3, bo_gmx *gx, float *ret_sc);           /* :1422 */
+int bo_gforward_parser_fs5(const uint8_t *dsq, int L, const bo_fs_profile *gm5, bo_gmx *gx, int c5_compat, float *ret_sc); /* :659 */
+int bo_gdecoding_fs(const bo_fs_profile *gm5, const bo_gmx *fwd, bo_gmx *bck, bo_gmx *pp);                             /* generic_decoding_frameshift.c:36 */
+int bo_goptacc_fs(const bo_fs_profile *gm5, const bo_gmx *pp, bo_gmx *oa, float *ret_e);                               /* generic_optacc_frameshift.c:53 */
+int bo_gnull2_fs(const bo_fs_profile *gm5, const bo_gmx *pp, float *null2 /* Kp */);                                    /* generic_null2_frameshift.c:46 */
+
+/* ============ pipeline (pipeline.c): p7_Pipeline_BATH restatement, filter cascade ============ */
+typedef struct {
+  double F1, F2, F3, F4;
+  int    do_biasfilter, fs_pipe, minlen;
+  /* counters (hmmer.h:1115-1128) */
+  int64_t nres, n_orfs, n_past_msv, n_past_bias, n_past_vit, n_past_fwd;
+  int64_t pos_past_msv, pos_past_bias, pos_past_vit, pos_past_fwd;
+  int64_t cells_msv, cells_vit, cells_fwd;
+} bo_pipeline;
+
+typedef struct {                 /* per-ORF cascade record (what the GPU path must reproduce) */
+  int32_t strand, frame, start, end, n;
+  int32_t stage;                 /* 0: failed MSV, 1: failed bias, 2: failed Vit, 3: failed Fwd(F3/F4), 4: passed */
+  int32_t msv_status, vit_status;
+  float   usc, nullsc, filtersc, vfsc, fwdsc;
+  double  P;
+} bo_orfresult;
+
+void bo_pipeline_init(bo_pipeline *pli, int fs_pipe);
+/* run translate + cascade on both strands of one DNA window dsq[1..n]; results appended (realloc'd) */
+int  bo_pipeline_window(bo_pipeline *pli, bo_oprofile *om, const bo_scoredata *sd, bo_bg *bg,
+                        const uint8_t basic[64], const uint8_t *dna, int n,
+                        bo_orfresult **res, int *nres, int *res_alloc);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,288 @@
+"""ctypes binding of oracle/liboracle.so -- TEST INFRASTRUCTURE ONLY.
+
+The oracle is the CPU restatement of the reference's hot path (oracle/bath_oracle.h).  Only tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+GOLDEN = os.path.join(HERE, "golden")
+
+NEVPARAM = 8
+K = 20
+KP = 29
+NTRANS = 8
+
+
+def build():
+    so = os.path.join(ORACLE_DIR, "liboracle.so")
+    srcs = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR) if f.endswith((".c", ".h"))]
+    if (not os.path.exists(so)) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-s", "-C", ORACLE_DIR], stdout=subprocess.DEVNULL)
+    return so
+
+
+class Hmm(C.Structure):
+    _fields_ = [("M", C.c_int), ("max_length", C.c_int), ("ct", C.c_int), ("fsprob", C.c_float),
+                ("t", C.POINTER(C.c_float)), ("mat", C.POINTER(C.c_float)), ("ins", C.POINTER(C.c_float)),
+                ("compo", C.c_float * K), ("evparam", C.c_float * NEVPARAM),
+                ("name", C.c_char * 128), ("acc", C.c_char * 64), ("consensus", C.c_char_p)]
+
+
+class Profile(C.Structure):
+    _fields_ = [("M", C.c_int), ("L", C.c_int), ("max_length", C.c_int), ("nj", C.c_float),
+                ("tsc", C.POINTER(C.c_float)), ("rsc", C.POINTER(C.c_float)),
+                ("xsc", (C.c_float * 2) * 4), ("evparam", C.c_float * NEVPARAM), ("compo", C.c_float * K)]
+
+
+class FsProfile(C.Structure):
+    _fields_ = [("M", C.c_int), ("L", C.c_int), ("max_length", C.c_int), ("codon_lengths", C.c_int),
+                ("maxcodons", C.c_int), ("nj", C.c_float), ("fsprob", C.c_float),
+                ("tsc", C.POINTER(C.c_float)), ("rsc", C.POINTER(C.c_float)),
+                ("codons", C.POINTER(C.c_uint8)), ("indel_pos", C.POINTER(C.c_uint8)),
+                ("xsc", (C.c_float * 2) * 4), ("evparam", C.c_float * NEVPARAM), ("compo", C.c_float * K)]
+
+
+class OProfile(C.Structure):
+    _fields_ = [("M", C.c_int), ("L", C.c_int), ("max_length", C.c_int), ("nj", C.c_float),
+                ("rb", C.POINTER(C.c_uint8)),
+                ("tbm_b", C.c_uint8), ("tec_b", C.c_uint8), ("tjb_b", C.c_uint8), ("base_b", C.c_uint8),
+                ("bias_b", C.c_uint8), ("scale_b", C.c_float),
+                ("rw", C.POINTER(C.c_int16)), ("tw", C.POINTER(C.c_int16)),
+                ("xw", (C.c_int16 * 2) * 4), ("scale_w", C.c_float), ("base_w", C.c_int16), ("ddbound_w", C.c_int16),
+                ("rf", C.POINTER(C.c_float)), ("tf", C.POINTER(C.c_float)), ("xf", (C.c_float * 2) * 4),
+                ("evparam", C.c_float * NEVPARAM), ("compo", C.c_float * K)]
+
+
+class Bg(C.Structure):
+    _fields_ = [("f", C.c_float * K), ("p1", C.c_float), ("t", (C.c_float * 3) * 2),
+                ("e", (C.c_float * K) * 2), ("eo", (C.c_float * 2) * KP), ("pi", C.c_float * 3)]
+
+
+class ScoreData(C.Structure):
+    _fields_ = [("M", C.c_int), ("ssv_scores", C.POINTER(C.c_uint8)),
+                ("prefix_lengths", C.POINTER(C.c_float)), ("suffix_lengths", C.POINTER(C.c_float))]
+
+
+class Window(C.Structure):
+    _fields_ = [("id", C.c_int32), ("n", C.c_int32), ("k", C.c_int32), ("length", C.c_int32), ("score", C.c_float)]
+
+
+class WindowList(C.Structure):
+    _fields_ = [("w", C.POINTER(Window)), ("count", C.c_int), ("size", C.c_int)]
+
+
+class Orf(C.Structure):
+    _fields_ = [("start", C.c_int32), ("end", C.c_int32), ("n", C.c_int32), ("frame", C.c_int32), ("off", C.c_int64)]
+
+
+class OrfBlock(C.Structure):
+    _fields_ = [("orf", C.POINTER(Orf)), ("count", C.c_int), ("size", C.c_int),
+                ("aa", C.POINTER(C.c_uint8)), ("aa_n", C.c_int64), ("aa_size", C.c_int64)]
+
+
+class Gmx(C.Structure):
+    _fields_ = [("M", C.c_int), ("L", C.c_int), ("nrows", C.c_int), ("nscells", C.c_int),
+                ("dp", C.POINTER(C.c_float)), ("xmx", C.POINTER(C.c_float))]
+
+
+class Pipeline(C.Structure):
+    _fields_ = [("F1", C.c_double), ("F2", C.c_double), ("F3", C.c_double), ("F4", C.c_double),
+                ("do_biasfilter", C.c_int), ("fs_pipe", C.c_int), ("minlen", C.c_int),
+                ("nres", C.c_int64), ("n_orfs", C.c_int64), ("n_past_msv", C.c_int64), ("n_past_bias", C.c_int64),
+                ("n_past_vit", C.c_int64), ("n_past_fwd", C.c_int64),
+                ("pos_past_msv", C.c_int64), ("pos_past_bias", C.c_int64), ("pos_past_vit", C.c_int64),
+                ("pos_past_fwd", C.c_int64),
+                ("cells_msv", C.c_int64), ("cells_vit", C.c_int64), ("cells_fwd", C.c_int64)]
+
+
+class OrfResult(C.Structure):
+    _fields_ = [("strand", C.c_int32), ("frame", C.c_int32), ("start", C.c_int32), ("end", C.c_int32), ("n", C.c_int32),
+                ("stage", C.c_int32), ("msv_status", C.c_int32), ("vit_status", C.c_int32),
+                ("usc", C.c_float), ("nullsc", C.c_float), ("filtersc", C.c_float), ("vfsc", C.c_float),
+                ("fwdsc", C.c_float), ("P", C.c_double)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    L = C.CDLL(build())
+    u8p, f32p = C.POINTER(C.c_uint8), C.POINTER(C.c_float)
+    L.bo_hmmfile_read.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.POINTER(Hmm))]
+    L.bo_hmmfile_count.argtypes = [C.c_char_p]
+    L.bo_hmm_free.argtypes = [C.POINTER(Hmm)]
+    L.bo_bg_create.argtypes = [C.POINTER(Bg)]
+    L.bo_bg_setlength.argtypes = [C.POINTER(Bg), C.c_int]
+    L.bo_bg_setfilter.argtypes = [C.POINTER(Bg), C.c_int, f32p]
+    L.bo_bg_nullone.argtypes = [C.POINTER(Bg), C.c_int]; L.bo_bg_nullone.restype = C.c_float
+    L.bo_bg_fs_nullone.argtypes = [C.POINTER(Bg), C.c_int]; L.bo_bg_fs_nullone.restype = C.c_float
+    L.bo_bg_filterscore.argtypes = [C.POINTER(Bg), u8p, C.c_int]; L.bo_bg_filterscore.restype = C.c_float
+    L.bo_bg_fs_filterscore.argtypes = [C.POINTER(Bg), u8p, C.c_int, u8p]; L.bo_bg_fs_filterscore.restype = C.c_float
+    L.bo_profile_config.argtypes = [C.POINTER(Hmm), C.POINTER(Bg), C.c_int]; L.bo_profile_config.restype = C.POINTER(Profile)
+    L.bo_profile_reconfig_length.argtypes = [C.POINTER(Profile), C.c_int]
+    L.bo_profile_free.argtypes = [C.POINTER(Profile)]
+    L.bo_fs_profile_config.argtypes = [C.POINTER(Hmm), C.POINTER(Bg), u8p, C.c_int, C.c_int]
+    L.bo_fs_profile_config.restype = C.POINTER(FsProfile)
+    L.bo_fs_profile_reconfig_length.argtypes = [C.POINTER(FsProfile), C.c_int]
+    L.bo_fs_profile_reconfig_unihit.argtypes = [C.POINTER(FsProfile), C.c_int]
+    L.bo_fs_profile_reconfig_multihit.argtypes = [C.POINTER(FsProfile), C.c_int]
+    L.bo_fs_profile_free.argtypes = [C.POINTER(FsProfile)]
+    L.bo_oprofile_convert.argtypes = [C.POINTER(Profile)]; L.bo_oprofile_convert.restype = C.POINTER(OProfile)
+    L.bo_oprofile_reconfig_length.argtypes = [C.POINTER(OProfile), C.c_int]
+    L.bo_oprofile_reconfig_msv_length.argtypes = [C.POINTER(OProfile), C.c_int]
+    L.bo_oprofile_free.argtypes = [C.POINTER(OProfile)]
+    L.bo_scoredata_create.argtypes = [C.POINTER(OProfile)]; L.bo_scoredata_create.restype = C.POINTER(ScoreData)
+    L.bo_scoredata_free.argtypes = [C.POINTER(ScoreData)]
+    for fn in (L.bo_gumbel_surv, L.bo_gumbel_invsurv, L.bo_exp_surv):
+        fn.argtypes = [C.c_double] * 3; fn.restype = C.c_double
+    L.bo_flogsum.argtypes = [C.c_float, C.c_float]; L.bo_flogsum.restype = C.c_float
+    L.bo_flogsum_set_exact.argtypes = [C.c_int]
+    L.bo_flogsum_table.restype = f32p
+    for fn in (L.bo_ssvfilter, L.bo_msvfilter, L.bo_msvfilter_noSSV, L.bo_vitfilter):
+        fn.argtypes = [u8p, C.c_int, C.POINTER(OProfile), f32p]
+    L.bo_ssvfilter_bath.argtypes = [u8p, C.c_int, C.POINTER(OProfile), C.POINTER(ScoreData), C.POINTER(Bg), C.c_double, C.POINTER(WindowList)]
+    L.bo_vitfilter_bath.argtypes = [u8p, C.c_int, C.POINTER(OProfile), C.POINTER(ScoreData), C.c_float, C.c_double, C.POINTER(WindowList), f32p]
+    L.bo_forward_parser.argtypes = [u8p, C.c_int, C.POINTER(OProfile), f32p, f32p]
+    L.bo_backward_parser.argtypes = [u8p, C.c_int, C.POINTER(OProfile), f32p, f32p, f32p]
+    L.bo_gviterbi.argtypes = [u8p, C.c_int, C.POINTER(Profile), f32p]
+    L.bo_gforward.argtypes = [u8p, C.c_int, C.POINTER(Profile), f32p]
+    L.bo_profile_same_as_mf.argtypes = [C.POINTER(OProfile), C.POINTER(Profile)]; L.bo_profile_same_as_mf.restype = C.POINTER(Profile)
+    L.bo_profile_same_as_vf.argtypes = [C.POINTER(OProfile), C.POINTER(Profile)]; L.bo_profile_same_as_vf.restype = C.POINTER(Profile)
+    L.bo_windowlist_init.argtypes = [C.POINTER(WindowList)]
+    L.bo_windowlist_free.argtypes = [C.POINTER(WindowList)]
+    L.bo_orfblock_init.argtypes = [C.POINTER(OrfBlock)]
+    L.bo_orfblock_reuse.argtypes = [C.POINTER(OrfBlock)]
+    L.bo_orfblock_free.argtypes = [C.POINTER(OrfBlock)]
+    L.bo_translate_orfs.argtypes = [u8p, C.c_int, u8p, C.c_int, C.POINTER(OrfBlock)]
+    L.bo_gencode_basic.argtypes = [C.c_int, u8p]
+    L.bo_revcomp.argtypes = [u8p, C.c_int, u8p]
+    L.bo_pipeline_init.argtypes = [C.POINTER(Pipeline), C.c_int]
+    L.bo_pipeline_window.argtypes = [C.POINTER(Pipeline), C.POINTER(OProfile), C.POINTER(ScoreData), C.POINTER(Bg),
+                                     u8p, u8p, C.c_int, C.POINTER(C.POINTER(OrfResult)), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    if hasattr(L, "bo_gmx_create"):
+        L.bo_gmx_create.argtypes = [C.c_int] * 4; L.bo_gmx_create.restype = C.POINTER(Gmx)
+        L.bo_gmx_free.argtypes = [C.POINTER(Gmx)]
+        L.bo_gforward_fs.argtypes = [u8p, C.c_int, C.POINTER(FsProfile), C.POINTER(Gmx), C.c_int, f32p]
+        L.bo_gbackward_fs.argtypes = [u8p, C.c_int, C.POINTER(FsProfile), C.POINTER(Gmx), f32p]
+        L.bo_gforward_parser_fs3.argtypes = [u8p, C.c_int, C.POINTER(FsProfile), C.POINTER(Gmx), f32p]
+        L.bo_gbackward_parser_fs3.argtypes = [u8p, C.c_int, C.POINTER(FsProfile), C.POINTER(Gmx), f32p]
+        L.bo_gforward_parser_fs5.argtypes = [u8p, C.c_int, C.POINTER(FsProfile), C.POINTER(Gmx), C.c_int, f32p]
+        L.bo_gdecoding_fs.argtypes = [C.POINTER(FsProfile), C.POINTER(Gmx), C.POINTER(Gmx), C.POINTER(Gmx)]
+        L.bo_goptacc_fs.argtypes = [C.POINTER(FsProfile), C.POINTER(Gmx), C.POINTER(Gmx), f32p]
+        L.bo_gnull2_fs.argtypes = [C.POINTER(FsProfile), C.POINTER(Gmx), f32p]
+    _lib = L
+    return L
+
+
+def u8(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint8))
+
+
+def f32(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def dsq_from(codes):
+    """1-based digital sequence with sentinels, as a numpy uint8 array of length n+2."""
+    a = np.empty(len(codes) + 2, dtype=np.uint8)
+    a[0] = a[-1] = 255
+    a[1:-1] = codes
+    return a
+
+
+DNA_SYMS = "ACGT-RYMKSWHBVDN*~"
+AMINO_SYMS = "ACDEFGHIKLMNPQRSTVWY-BJZOUX*~"
+
+
+def digitize_dna(s):
+    lut = np.full(256, 255, dtype=np.uint8)
+    for i, ch in enumerate(DNA_SYMS):
+        lut[ord(ch)] = i
+        lut[ord(ch.lower())] = i
+    lut[ord("U")] = lut[ord("u")] = 3
+    lut[ord("X")] = lut[ord("x")] = 15
+    codes = lut[np.frombuffer(s.encode(), dtype=np.uint8)]
+    assert (codes != 255).all(), "bad DNA symbol"
+    return codes
+
+
+def digitize_amino(s):
+    lut = np.full(256, 255, dtype=np.uint8)
+    for i, ch in enumerate(AMINO_SYMS):
+        lut[ord(ch)] = i
+        lut[ord(ch.lower())] = i
+    codes = lut[np.frombuffer(s.encode(), dtype=np.uint8)]
+    assert (codes != 255).all(), "bad amino symbol"
+    return codes
+
+
+def read_fasta(path):
+    out, name, buf = [], None, []
+    with open(path) as fh:
+        for line in fh:
+            line = line.strip()
+            if not line:
+                continue
+            if line.startswith(">"):
+                if name is not None:
+                    out.append((name, "".join(buf)))
+                name, buf = line[1:].split()[0], []
+            else:
+                buf.append(line)
+    if name is not None:
+        out.append((name, "".join(buf)))
+    return out
+
+
+class Model:
+    """Everything the oracle derives from one .bhmm record."""
+
+    def __init__(self, path, index=0, L=100):
+        L_ = lib()
+        hp = C.POINTER(Hmm)()
+        st = L_.bo_hmmfile_read(path.encode(), index, C.byref(hp))
+        assert st == 0, "cannot read %s[%d]: %d" % (path, index, st)
+        self.hmm = hp
+        self.M = hp.contents.M
+        self.bg = Bg()
+        L_.bo_bg_create(C.byref(self.bg))
+        self.gm = L_.bo_profile_config(hp, C.byref(self.bg), L)
+        self.om = L_.bo_oprofile_convert(self.gm)
+        self.sd = L_.bo_scoredata_create(self.om)
+        self.basic = np.zeros(64, dtype=np.uint8)
+        assert L_.bo_gencode_basic(hp.contents.ct, u8(self.basic)) == 0
+        L_.bo_bg_setfilter(C.byref(self.bg), self.M, self.om.contents.compo)
+        self._fs = {}
+
+    def fs(self, codon_lengths, L_amino=100):
+        key = codon_lengths
+        if key not in self._fs:
+            self._fs[key] = lib().bo_fs_profile_config(self.hmm, C.byref(self.bg), u8(self.basic), codon_lengths, L_amino)
+        return self._fs[key]
+
+    def run_pipeline(self, seqs, fs_pipe=False):
+        """seqs: list of digitized DNA code arrays. Returns (Pipeline counters, list of OrfResult copies)."""
+        L_ = lib()
+        pli = Pipeline()
+        L_.bo_pipeline_init(C.byref(pli), 1 if fs_pipe else 0)
+        res = C.POINTER(OrfResult)()
+        nres, alloc = C.c_int(0), C.c_int(0)
+        per_seq = []
+        for codes in seqs:
+            d = dsq_from(codes)
+            before = nres.value
+            L_.bo_pipeline_window(C.byref(pli), self.om, self.sd, C.byref(self.bg), u8(self.basic), u8(d), len(codes),
+                                  C.byref(res), C.byref(nres), C.byref(alloc))
+            per_seq.append((before, nres.value))
+        out = [res[i] for i in range(nres.value)]
+        return pli, out, per_seq
