@@ -1,0 +1,494 @@
+"""bath_amd -- MI355X (gfx950) backend for BATH's bathsearch DP hot path.
+
+Thin Python mirror of the C ABI in include/bath_hip.h (the product is libbathhip.so: hand-written HIP
+kernels behind `extern "C"` entry points).  Names follow the reference's objects:
+
+    HMM          P7_HMM            (p7_hmmfile.c:1342)
+    Profile      P7_PROFILE        (modelconfig.c:48  p7_ProfileConfig)
+    FSProfile    P7_FS_PROFILE     (modelconfig.c:220 p7_ProfileConfig_fs)
+    OProfile     P7_OPROFILE       (impl_sse/p7_oprofile.c:1091 p7_oprofile_Convert), device resident
+    FSOProfile   P7_FS_OPROFILE    (impl_sse/p7_fs_oprofile.c:221), device resident
+    SeqBlock     ESL_SQ_BLOCK      digital sequences, device resident
+    Pipeline     P7_PIPELINE       (p7_pipeline.c:94, :1584), the filter cascade
+
+There is no CPU fallback: importing works anywhere (so the CPU test tier can check the library
+loads and exports every symbol), but creating a Context without a usable GPU raises.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+LIB_PATH = os.path.join(_HERE, "libbathhip.so")
+
+OK, ERANGE, ENORESULT = 0, 16, 19
+KP, K, NEVPARAM = 29, 20, 8
+LOGSUM_TABLE, LOGSUM_EXACT = 0, 1
+
+DNA_SYMS = "ACGT-RYMKSWHBVDN*~"
+AMINO_SYMS = "ACDEFGHIKLMNPQRSTVWY-BJZOUX*~"
+
+
+class BathError(RuntimeError):
+    pass
+
+
+def build(force=False):
+    """Compile libbathhip.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    srcdir = os.path.join(_HERE, "csrc")
+    srcs = [os.path.join(srcdir, f) for f in os.listdir(srcdir) if f.endswith((".hip", ".cpp", ".hpp"))]
+    srcs.append(os.path.join(_ROOT, "include", "bath_hip.h"))
+    stale = force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if stale:
+        subprocess.check_call(["make", "-s", "-j4", "-C", srcdir])
+    return LIB_PATH
+
+
+class _Hmm(C.Structure):
+    _fields_ = [("M", C.c_int32), ("max_length", C.c_int32), ("ct", C.c_int32), ("fsprob", C.c_float),
+                ("t", C.POINTER(C.c_float)), ("mat", C.POINTER(C.c_float)), ("ins", C.POINTER(C.c_float)),
+                ("compo", C.c_float * K), ("evparam", C.c_float * NEVPARAM), ("name", C.c_char * 128)]
+
+
+class _Profile(C.Structure):
+    _fields_ = [("M", C.c_int32), ("L", C.c_int32), ("max_length", C.c_int32), ("nj", C.c_float),
+                ("tsc", C.POINTER(C.c_float)), ("rsc", C.POINTER(C.c_float)), ("xsc", (C.c_float * 2) * 4),
+                ("evparam", C.c_float * NEVPARAM), ("compo", C.c_float * K)]
+
+
+class _FsProfile(C.Structure):
+    _fields_ = [("M", C.c_int32), ("L", C.c_int32), ("max_length", C.c_int32), ("codon_lengths", C.c_int32),
+                ("maxcodons", C.c_int32), ("nj", C.c_float), ("fsprob", C.c_float),
+                ("tsc", C.POINTER(C.c_float)), ("rsc", C.POINTER(C.c_float)),
+                ("codons", C.POINTER(C.c_uint8)), ("indel_pos", C.POINTER(C.c_uint8)),
+                ("xsc", (C.c_float * 2) * 4), ("evparam", C.c_float * NEVPARAM), ("compo", C.c_float * K)]
+
+
+class OProfileScalars(C.Structure):
+    _fields_ = [("tbm_b", C.c_uint8), ("tec_b", C.c_uint8), ("tjb_b", C.c_uint8), ("base_b", C.c_uint8), ("bias_b", C.c_uint8),
+                ("scale_b", C.c_float), ("xw", (C.c_int16 * 2) * 4), ("scale_w", C.c_float),
+                ("base_w", C.c_int16), ("ddbound_w", C.c_int16), ("xf", (C.c_float * 2) * 4)]
+
+
+class PipelineParams(C.Structure):
+    _fields_ = [("F1", C.c_double), ("F2", C.c_double), ("F3", C.c_double), ("F4", C.c_double),
+                ("do_biasfilter", C.c_int32), ("fs_pipe", C.c_int32), ("min_orf_len", C.c_int32), ("ncbi_table", C.c_int32)]
+
+
+class OrfResult(C.Structure):
+    _fields_ = [("window", C.c_int64), ("strand", C.c_int32), ("frame", C.c_int32), ("start", C.c_int32), ("end", C.c_int32),
+                ("n", C.c_int32), ("stage", C.c_int32), ("msv_status", C.c_int32), ("vit_status", C.c_int32),
+                ("usc", C.c_float), ("nullsc", C.c_float), ("filtersc", C.c_float), ("vfsc", C.c_float), ("fwdsc", C.c_float),
+                ("P", C.c_double)]
+
+
+ORF_RESULT_DTYPE = np.dtype([("window", "<i8"), ("strand", "<i4"), ("frame", "<i4"), ("start", "<i4"), ("end", "<i4"),
+                             ("n", "<i4"), ("stage", "<i4"), ("msv_status", "<i4"), ("vit_status", "<i4"),
+                             ("usc", "<f4"), ("nullsc", "<f4"), ("filtersc", "<f4"), ("vfsc", "<f4"), ("fwdsc", "<f4"),
+                             ("P", "<f8")], align=True)
+
+
+class PipelineStats(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ("nres", "n_orfs", "n_past_msv", "n_past_bias", "n_past_vit", "n_past_fwd",
+                                          "pos_past_msv", "pos_past_bias", "pos_past_vit", "pos_past_fwd",
+                                          "cells_msv", "cells_vit", "cells_fwd")]
+
+
+class Fs5Result(C.Structure):
+    _fields_ = [("fwdsc", C.c_float), ("bcksc", C.c_float), ("oasc", C.c_float), ("null2", C.c_float * KP)]
+
+
+# name -> (restype, argtypes); every symbol include/bath_hip.h declares
+_vp, _u8p, _f32p, _i32p, _i64p = C.c_void_p, C.POINTER(C.c_uint8), C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_int64)
+ABI = {
+    "bath_hmmfile_count": (C.c_int, [C.c_char_p]),
+    "bath_hmmfile_read": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.POINTER(_Hmm))]),
+    "bath_hmm_destroy": (None, [C.POINTER(_Hmm)]),
+    "bath_gencode_basic": (C.c_int, [C.c_int, _u8p]),
+    "bath_profile_config": (C.c_int, [C.POINTER(_Hmm), C.c_int, C.POINTER(C.POINTER(_Profile))]),
+    "bath_profile_destroy": (None, [C.POINTER(_Profile)]),
+    "bath_fs_profile_config": (C.c_int, [C.POINTER(_Hmm), _u8p, C.c_int, C.c_int, C.POINTER(C.POINTER(_FsProfile))]),
+    "bath_fs_profile_destroy": (None, [C.POINTER(_FsProfile)]),
+    "bath_hip_init": (C.c_int, [C.c_int, C.POINTER(_vp)]),
+    "bath_hip_finalize": (None, [_vp]),
+    "bath_hip_last_error": (C.c_char_p, [_vp]),
+    "bath_hip_synchronize": (C.c_int, [_vp]),
+    "bath_hip_stream": (_vp, [_vp]),
+    "bath_hip_oprofile_convert": (C.c_int, [_vp, C.POINTER(_Profile), C.POINTER(_vp)]),
+    "bath_hip_oprofile_destroy": (None, [_vp]),
+    "bath_hip_oprofile_M": (C.c_int, [_vp]),
+    "bath_hip_oprofile_scalars": (C.c_int, [_vp, C.c_int, C.POINTER(OProfileScalars)]),
+    "bath_hip_oprofile_get_ssv_scores": (C.c_int, [_vp, _u8p]),
+    "bath_hip_oprofile_get_vit": (C.c_int, [_vp, C.POINTER(C.c_int16), C.POINTER(C.c_int16)]),
+    "bath_hip_oprofile_get_fwd": (C.c_int, [_vp, _f32p, _f32p]),
+    "bath_hip_seqs_create": (C.c_int, [_vp, _u8p, _i64p, C.c_int64, C.POINTER(_vp)]),
+    "bath_hip_seqs_destroy": (None, [_vp]),
+    "bath_hip_seqs_count": (C.c_int64, [_vp]),
+    "bath_hip_ssvfilter": (C.c_int, [_vp, _vp, _vp, _f32p, _i32p]),
+    "bath_hip_msvfilter": (C.c_int, [_vp, _vp, _vp, _f32p, _i32p]),
+    "bath_hip_vitfilter": (C.c_int, [_vp, _vp, _vp, _f32p, _i32p]),
+    "bath_hip_forward_parser": (C.c_int, [_vp, _vp, _vp, _f32p, _i32p]),
+    "bath_hip_bias_filter": (C.c_int, [_vp, _vp, _vp, _f32p, _f32p]),
+    "bath_pipeline_params_default": (None, [C.POINTER(PipelineParams), C.c_int]),
+    "bath_hip_pipeline_filters": (C.c_int, [_vp, _vp, _vp, C.POINTER(PipelineParams), C.POINTER(PipelineStats),
+                                            C.POINTER(C.POINTER(OrfResult)), _i64p]),
+    "bath_hip_pipeline_timings": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_char_p), _f32p, _i64p]),
+    "bath_hip_fsprofile_convert": (C.c_int, [_vp, C.POINTER(_FsProfile), C.POINTER(_vp)]),
+    "bath_hip_fsprofile_destroy": (None, [_vp]),
+    "bath_hip_fs3_forward_parser": (C.c_int, [_vp, _vp, _vp, C.c_int, _f32p, _f32p, _i64p]),
+    "bath_hip_fs3_backward_parser": (C.c_int, [_vp, _vp, _vp, C.c_int, _f32p, _f32p, _i64p]),
+    "bath_hip_fs5_envelopes": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.POINTER(Fs5Result), _f32p, _i64p, _f32p, _i64p]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libbathhip.so (raises BathError with the build hint if it is missing)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise BathError("libbathhip.so not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                            "(or `make -C bath_amd/csrc`). There is no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in ABI.items():
+            fn = getattr(L, name)          # AttributeError => the library does not export a declared symbol
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def _u8(a):
+    return a.ctypes.data_as(_u8p)
+
+
+def _f32(a):
+    return None if a is None else a.ctypes.data_as(_f32p)
+
+
+def _i64(a):
+    return None if a is None else a.ctypes.data_as(_i64p)
+
+
+def digitize(seq, syms):
+    lut = np.full(256, 255, dtype=np.uint8)
+    for i, ch in enumerate(syms):
+        lut[ord(ch)] = i
+        lut[ord(ch.lower())] = i
+    if syms is DNA_SYMS:
+        lut[ord("U")] = lut[ord("u")] = 3
+        lut[ord("X")] = lut[ord("x")] = 15
+    codes = lut[np.frombuffer(seq.encode(), dtype=np.uint8)]
+    if (codes == 255).any():
+        raise BathError("symbol outside the alphabet")
+    return codes
+
+
+class HMM:
+    """A profile HMM read from a BATH3/f file."""
+
+    def __init__(self, path, index=0):
+        p = C.POINTER(_Hmm)()
+        st = lib().bath_hmmfile_read(os.fsencode(path), index, C.byref(p))
+        if st != OK:
+            raise BathError("cannot read model %d of %s (status %d)" % (index, path, st))
+        self._p = p
+        self.M = p.contents.M
+        self.ct = p.contents.ct
+        self.max_length = p.contents.max_length
+        self.name = p.contents.name.decode()
+        self.evparam = np.array(p.contents.evparam[:], dtype=np.float32)
+
+    @staticmethod
+    def count(path):
+        return lib().bath_hmmfile_count(os.fsencode(path))
+
+    def __del__(self):
+        if getattr(self, "_p", None):
+            lib().bath_hmm_destroy(self._p)
+            self._p = None
+
+
+def gencode_basic(ncbi_table):
+    b = np.zeros(64, dtype=np.uint8)
+    if lib().bath_gencode_basic(ncbi_table, _u8(b)) != OK:
+        raise BathError("unknown NCBI translation table %d" % ncbi_table)
+    return b
+
+
+class Profile:
+    """p7_ProfileConfig(hmm, bg, gm, L, p7_LOCAL)."""
+
+    def __init__(self, hmm, L=100):
+        p = C.POINTER(_Profile)()
+        st = lib().bath_profile_config(hmm._p, L, C.byref(p))
+        if st != OK:
+            raise BathError("profile config failed (%d)" % st)
+        self._p, self.M, self.hmm = p, hmm.M, hmm
+
+    def arrays(self):
+        g = self._p.contents
+        tsc = np.ctypeslib.as_array(g.tsc, shape=(self.M, 8)).copy()
+        rsc = np.ctypeslib.as_array(g.rsc, shape=(KP, self.M + 1, 2)).copy()
+        xsc = np.array([[g.xsc[i][j] for j in range(2)] for i in range(4)], dtype=np.float32)
+        return tsc, rsc, xsc
+
+    def __del__(self):
+        if getattr(self, "_p", None):
+            lib().bath_profile_destroy(self._p)
+            self._p = None
+
+
+class FSProfile:
+    """p7_ProfileConfig_fs(hmm, bg, gcode, gm_fs, L, p7_LOCAL) for 3 or 5 codon lengths."""
+
+    def __init__(self, hmm, codon_lengths, L_amino=100, ncbi_table=None):
+        self.basic = gencode_basic(hmm.ct if ncbi_table is None else ncbi_table)
+        p = C.POINTER(_FsProfile)()
+        st = lib().bath_fs_profile_config(hmm._p, _u8(self.basic), codon_lengths, L_amino, C.byref(p))
+        if st != OK:
+            raise BathError("fs profile config failed (%d)" % st)
+        self._p, self.M, self.hmm, self.codon_lengths = p, hmm.M, hmm, codon_lengths
+        self.maxcodons = p.contents.maxcodons
+
+    def arrays(self):
+        g = self._p.contents
+        nrows = self.maxcodons + KP
+        tsc = np.ctypeslib.as_array(g.tsc, shape=(self.M, 8)).copy()
+        rsc = np.ctypeslib.as_array(g.rsc, shape=(nrows, self.M + 1)).copy()
+        codons = np.ctypeslib.as_array(g.codons, shape=(self.M + 1, self.maxcodons)).copy()
+        indel = np.ctypeslib.as_array(g.indel_pos, shape=(self.M + 1, self.maxcodons)).copy()
+        return tsc, rsc, codons, indel
+
+    def __del__(self):
+        if getattr(self, "_p", None):
+            lib().bath_fs_profile_destroy(self._p)
+            self._p = None
+
+
+class Context:
+    """One GPU + one HIP stream (the reference's per-thread WORKER_INFO, bathsearch.c:34)."""
+
+    def __init__(self, device=0):
+        h = _vp()
+        st = lib().bath_hip_init(device, C.byref(h))
+        if st != OK:
+            raise BathError("bath_hip_init(device=%d) failed with status %d: no usable gfx950 GPU; "
+                            "this backend has no CPU fallback" % (device, st))
+        self._h = h
+
+    def _check(self, st, what):
+        if st != OK:
+            raise BathError("%s failed (%d): %s" % (what, st, lib().bath_hip_last_error(self._h).decode()))
+
+    def synchronize(self):
+        self._check(lib().bath_hip_synchronize(self._h), "synchronize")
+
+    @property
+    def stream(self):
+        return lib().bath_hip_stream(self._h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().bath_hip_finalize(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+
+class OProfile:
+    """p7_oprofile_Convert(gm, om): the device-resident limited-precision profile."""
+
+    def __init__(self, ctx, gm):
+        h = _vp()
+        ctx._check(lib().bath_hip_oprofile_convert(ctx._h, gm._p, C.byref(h)), "oprofile_convert")
+        self.ctx, self._h, self.M, self.gm = ctx, h, gm.M, gm
+
+    def scalars(self, L):
+        s = OProfileScalars()
+        self.ctx._check(lib().bath_hip_oprofile_scalars(self._h, L, C.byref(s)), "oprofile_scalars")
+        return s
+
+    def ssv_scores(self):
+        a = np.zeros((self.M + 1, KP), dtype=np.uint8)
+        lib().bath_hip_oprofile_get_ssv_scores(self._h, _u8(a))
+        return a
+
+    def vit_arrays(self):
+        rw = np.zeros((KP, self.M + 1), dtype=np.int16)
+        tw = np.zeros((self.M + 1, 8), dtype=np.int16)
+        lib().bath_hip_oprofile_get_vit(self._h, rw.ctypes.data_as(C.POINTER(C.c_int16)), tw.ctypes.data_as(C.POINTER(C.c_int16)))
+        return rw, tw
+
+    def fwd_arrays(self):
+        rf = np.zeros((KP, self.M + 1), dtype=np.float32)
+        tf = np.zeros((self.M + 1, 8), dtype=np.float32)
+        lib().bath_hip_oprofile_get_fwd(self._h, _f32(rf), _f32(tf))
+        return rf, tf
+
+    def __del__(self):
+        if getattr(self, "_h", None) and getattr(self.ctx, "_h", None):
+            lib().bath_hip_oprofile_destroy(self._h)
+        self._h = None
+
+
+class FSOProfile:
+    """p7_fs_oprofile_Convert(gm_fs, om_fs)."""
+
+    def __init__(self, ctx, gm_fs):
+        h = _vp()
+        ctx._check(lib().bath_hip_fsprofile_convert(ctx._h, gm_fs._p, C.byref(h)), "fsprofile_convert")
+        self.ctx, self._h, self.M, self.gm = ctx, h, gm_fs.M, gm_fs
+
+    def __del__(self):
+        if getattr(self, "_h", None) and getattr(self.ctx, "_h", None):
+            lib().bath_hip_fsprofile_destroy(self._h)
+        self._h = None
+
+
+class SeqBlock:
+    """A block of digital sequences resident in HBM.  <seqs>: list of uint8 code arrays, or (flat, offsets)."""
+
+    def __init__(self, ctx, seqs, offsets=None):
+        if offsets is None:
+            lens = np.array([len(s) for s in seqs], dtype=np.int64)
+            offsets = np.zeros(len(seqs) + 1, dtype=np.int64)
+            np.cumsum(lens, out=offsets[1:])
+            flat = np.concatenate([np.asarray(s, dtype=np.uint8) for s in seqs]) if len(seqs) else np.zeros(0, np.uint8)
+        else:
+            flat = np.ascontiguousarray(seqs, dtype=np.uint8)
+            offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        if flat.size == 0:
+            flat = np.zeros(1, np.uint8)
+        self.n = len(offsets) - 1
+        self.lengths = np.diff(offsets)
+        h = _vp()
+        ctx._check(lib().bath_hip_seqs_create(ctx._h, _u8(flat), _i64(offsets), self.n, C.byref(h)), "seqs_create")
+        self.ctx, self._h = ctx, h
+
+    def __del__(self):
+        if getattr(self, "_h", None) and getattr(self.ctx, "_h", None):
+            lib().bath_hip_seqs_destroy(self._h)
+        self._h = None
+
+
+def _score_call(fn, what, ctx, om, sq):
+    sc = np.zeros(sq.n, dtype=np.float32)
+    st = np.zeros(sq.n, dtype=np.int32)
+    ctx._check(fn(ctx._h, om._h, sq._h, _f32(sc), st.ctypes.data_as(_i32p)), what)
+    return sc, st
+
+
+def SSVFilter(ctx, om, sq):
+    """p7_SSVFilter over a block: (scores[n] nats, status[n])."""
+    return _score_call(lib().bath_hip_ssvfilter, "ssvfilter", ctx, om, sq)
+
+
+def MSVFilter(ctx, om, sq):
+    """p7_MSVFilter over a block."""
+    return _score_call(lib().bath_hip_msvfilter, "msvfilter", ctx, om, sq)
+
+
+def ViterbiFilter(ctx, om, sq):
+    """p7_ViterbiFilter over a block."""
+    return _score_call(lib().bath_hip_vitfilter, "vitfilter", ctx, om, sq)
+
+
+def ForwardParser(ctx, om, sq):
+    """p7_ForwardParser over a block."""
+    return _score_call(lib().bath_hip_forward_parser, "forward_parser", ctx, om, sq)
+
+
+def BiasFilter(ctx, om, sq):
+    """(p7_bg_NullOne, p7_bg_FilterScore) over a block."""
+    nullsc = np.zeros(sq.n, dtype=np.float32)
+    filtersc = np.zeros(sq.n, dtype=np.float32)
+    ctx._check(lib().bath_hip_bias_filter(ctx._h, om._h, sq._h, _f32(nullsc), _f32(filtersc)), "bias_filter")
+    return nullsc, filtersc
+
+
+class Pipeline:
+    """The filter cascade of p7_Pipeline_BATH over blocks of DNA windows."""
+
+    def __init__(self, ctx, om, fs_pipe=False, ncbi_table=1, **overrides):
+        self.ctx, self.om = ctx, om
+        self.params = PipelineParams()
+        lib().bath_pipeline_params_default(C.byref(self.params), 1 if fs_pipe else 0)
+        self.params.ncbi_table = ncbi_table
+        for k, v in overrides.items():
+            setattr(self.params, k, v)
+
+    def run(self, dna, want_results=True):
+        stats = PipelineStats()
+        res = C.POINTER(OrfResult)()
+        n = C.c_int64(0)
+        self.ctx._check(lib().bath_hip_pipeline_filters(self.ctx._h, self.om._h, dna._h, C.byref(self.params), C.byref(stats),
+                                                        C.byref(res) if want_results else None, C.byref(n)), "pipeline_filters")
+        out = None
+        if want_results:
+            if n.value:
+                buf = (OrfResult * n.value).from_address(C.addressof(res.contents))
+                out = np.frombuffer(buf, dtype=ORF_RESULT_DTYPE).copy()
+            else:
+                out = np.zeros(0, dtype=ORF_RESULT_DTYPE)
+        return stats, out
+
+    def timings(self):
+        names = (C.c_char_p * 32)()
+        ms = np.zeros(32, dtype=np.float32)
+        launches = np.zeros(32, dtype=np.int64)
+        k = lib().bath_hip_pipeline_timings(self.ctx._h, 32, names, _f32(ms), _i64(launches))
+        return [(names[i].decode(), float(ms[i]), int(launches[i])) for i in range(k)]
+
+
+def FS3ForwardParser(ctx, om3, dna, logsum=LOGSUM_TABLE, want_xmx=False):
+    """p7_ForwardParser_Frameshift_3Codons over a block of DNA windows."""
+    return _fs3(lib().bath_hip_fs3_forward_parser, "fs3_forward_parser", ctx, om3, dna, logsum, want_xmx)
+
+
+def FS3BackwardParser(ctx, om3, dna, logsum=LOGSUM_TABLE, want_xmx=False):
+    """p7_BackwardParser_Frameshift_3Codons over a block of DNA windows."""
+    return _fs3(lib().bath_hip_fs3_backward_parser, "fs3_backward_parser", ctx, om3, dna, logsum, want_xmx)
+
+
+def _fs3(fn, what, ctx, om3, dna, logsum, want_xmx):
+    sc = np.zeros(dna.n, dtype=np.float32)
+    xmx, offs = None, None
+    if want_xmx:
+        offs = np.zeros(dna.n + 1, dtype=np.int64)
+        np.cumsum((dna.lengths + 1) * 5, out=offs[1:])
+        xmx = np.zeros(int(offs[-1]), dtype=np.float32)
+    ctx._check(fn(ctx._h, om3._h, dna._h, logsum, _f32(sc), _f32(xmx), _i64(offs)), what)
+    if want_xmx:
+        return sc, [xmx[offs[i]:offs[i + 1]].reshape(-1, 5) for i in range(dna.n)]
+    return sc
+
+
+def FS5Envelopes(ctx, om5, dna, logsum=LOGSUM_TABLE, c5_compat=False, want_pp=False, want_oa=False):
+    """Forward/Backward/Decoding/OptimalAccuracy/Null2 (frameshift, 5 codon lengths) per envelope."""
+    M = om5.M
+    res = (Fs5Result * max(dna.n, 1))()
+    pp = ppo = oa = oao = None
+    if want_pp:
+        ppo = np.zeros(dna.n + 1, dtype=np.int64)
+        np.cumsum((dna.lengths + 1) * (M + 1) * 8, out=ppo[1:])
+        pp = np.zeros(int(ppo[-1]), dtype=np.float32)
+    if want_oa:
+        oao = np.zeros(dna.n + 1, dtype=np.int64)
+        np.cumsum((dna.lengths + 1) * (M + 1) * 3, out=oao[1:])
+        oa = np.zeros(int(oao[-1]), dtype=np.float32)
+    ctx._check(lib().bath_hip_fs5_envelopes(ctx._h, om5._h, dna._h, logsum, 1 if c5_compat else 0, res,
+                                            _f32(pp), _i64(ppo), _f32(oa), _i64(oao)), "fs5_envelopes")
+    out = {"fwdsc": np.array([res[i].fwdsc for i in range(dna.n)], dtype=np.float32),
+           "bcksc": np.array([res[i].bcksc for i in range(dna.n)], dtype=np.float32),
+           "oasc": np.array([res[i].oasc for i in range(dna.n)], dtype=np.float32),
+           "null2": np.array([list(res[i].null2) for i in range(dna.n)], dtype=np.float32).reshape(dna.n, KP)}
+    if want_pp:
+        out["pp"] = [pp[ppo[i]:ppo[i + 1]].reshape(-1, M + 1, 8) for i in range(dna.n)]
+    if want_oa:
+        out["oa"] = [oa[oao[i]:oao[i + 1]].reshape(-1, M + 1, 3) for i in range(dna.n)]
+    return out

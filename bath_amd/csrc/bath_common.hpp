@@ -1,0 +1,138 @@
+// bath_common.hpp -- internal types shared by the HIP translation units of libbathhip.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "bath_hip.h"
+
+namespace bath {
+
+constexpr int kKp = BATH_KP_AMINO;       // 29 amino symbols
+constexpr int kRowReset = 29;            // extra "row" of the SSV cost table: every cost +127 (resets every diagonal)
+constexpr int kSsvRows = 30;
+constexpr int kStop = 27;                // '*'
+constexpr int kXaa = 26;                 // 'X'
+
+#define BATH_HIP_TRY(ctx, call)                                                            \
+  do {                                                                                     \
+    hipError_t e_ = (call);                                                                \
+    if (e_ != hipSuccess) {                                                                \
+      (ctx)->set_error(std::string(#call) + ": " + hipGetErrorString(e_));                 \
+      return BATH_EFAIL;                                                                   \
+    }                                                                                      \
+  } while (0)
+
+// A growable device buffer.
+struct DevBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  hipError_t reserve(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr; cap = 0;
+    size_t want = bytes + bytes / 4 + 256;
+    hipError_t e = hipMalloc(&p, want);
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+  template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+struct StageTiming { const char *name; float ms; int64_t launches; };
+
+}  // namespace bath
+
+struct bath_hip_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipDeviceProp_t prop{};
+  std::string err;
+  void set_error(const std::string &m) { err = m; }
+  // scratch owned by the context (reused across calls)
+  bath::DevBuf scratch[24];
+  std::vector<bath_orf_result> results;
+  std::vector<bath::StageTiming> timings;
+  std::vector<hipEvent_t> ev_pool;
+};
+
+// Device view of a sequence block.
+struct SeqView {
+  const uint8_t *data;     // residues, each sequence 16-byte aligned
+  const int64_t *off;      // [n]
+  const int32_t *len;      // [n]
+  int64_t n;
+};
+
+struct bath_hip_seqs {
+  bath_hip_ctx *ctx = nullptr;
+  int64_t n = 0;
+  int64_t total = 0;       // total residues
+  int32_t maxlen = 0;
+  uint8_t *d_data = nullptr;
+  int64_t *d_off = nullptr;
+  int32_t *d_len = nullptr;
+  std::vector<int64_t> h_off;   // device offsets (aligned)
+  std::vector<int32_t> h_len;
+  SeqView view() const { return SeqView{d_data, d_off, d_len, n}; }
+};
+
+// Per-length scalars of the limited-precision score systems (p7_oprofile_ReconfigLength, p7_oprofile.c:1261):
+// computed on the host with the reference's exact libm calls, looked up by the kernels.
+struct LenTables {
+  int32_t maxL = -1;
+  uint8_t *d_tjb = nullptr;     // [maxL+1] tjb_b(L)
+  int16_t *d_xwmove = nullptr;  // [maxL+1] xw[N|C|J][MOVE](L)
+  float   *d_pmove = nullptr;   // [maxL+1] xf[..][MOVE](L); LOOP = 1 - pmove
+  float   *d_nullsc = nullptr;  // [maxL+1] p7_bg_NullOne for length L
+  float   *d_lt1 = nullptr;     // [maxL+1] (float)L*logf(p1)      } the two length terms p7_bg_FilterScore adds, in order
+  float   *d_lt2 = nullptr;     // [maxL+1] logf(1-p1)             } (p7_bg.c:501)
+  float   *d_p1 = nullptr;      // [maxL+1] bg->p1 = L/(L+1)
+  std::vector<uint8_t> h_tjb;
+  std::vector<int16_t> h_xwmove;
+  std::vector<float> h_pmove, h_nullsc;
+};
+
+struct bath_hip_oprofile {
+  bath_hip_ctx *ctx = nullptr;
+  int M = 0, max_length = 0, L0 = 0;
+  float nj = 1.f;
+  float evparam[BATH_NEVPARAM];
+  float compo[BATH_K_AMINO];
+  // host copies, unstriped
+  std::vector<uint8_t> rb;      // [Kp][M+1]
+  std::vector<int16_t> rw;      // [Kp][M+1]
+  std::vector<int16_t> tw;      // [M+1][8]
+  std::vector<float> rf, tf;    // [Kp][M+1], [M+1][8]
+  uint8_t tbm_b = 0, tec_b = 0, base_b = 0, bias_b = 0;
+  float scale_b = 0;
+  int16_t xw_E[2] = {0, 0};
+  float scale_w = 0;
+  int16_t base_w = 0, ddbound_w = 0;
+  float xf_E[2] = {0, 0};
+  // device tables
+  int NR = 0;                   // packed int16 register count of the SSV kernel (2*NR >= M)
+  int ssv_row_bytes = 0;
+  int16_t *d_ssv = nullptr;     // [kSsvRows][ssv_row_bytes/2] signed SSV costs (sf_conversion), +127 padding
+  uint8_t *d_rb = nullptr;      // [Kp][rb_stride]
+  int rb_stride = 0;
+  int16_t *d_rw = nullptr;      // [Kp][M+1]
+  int16_t *d_tw = nullptr;      // [M+1][8]
+  float *d_rf = nullptr, *d_tf = nullptr;
+  float *d_bias_eo = nullptr;   // [Kp][2] emission odds of the 2-state bias filter HMM for om->compo
+  mutable LenTables lt;
+  int ensure_len_tables(int maxL) const;
+};
+
+// implemented in bath_profile.hip
+namespace bath {
+int build_len_tables(const bath_hip_oprofile *om, int maxL);
+void bias_filter_eo(const float *compo, float eo[kKp][2]);
+double gumbel_surv(double x, double mu, double lambda);
+double gumbel_invsurv(double p, double mu, double lambda);
+double exp_surv(double x, double mu, double lambda);
+}  // namespace bath

@@ -1,0 +1,637 @@
+// bath_filters.hip -- HMMER3 filter-cascade kernels for gfx950 and their batched C entry points.
+//
+//   ssv_lane_kernel     <- p7_SSVFilter / get_xE / calc_band_N    src/impl_sse/ssvfilter.c:668-925
+//   msv_wave_kernel     <- p7_MSVFilter (J-state path)            src/impl_sse/msvfilter.c:106-207
+//   vit_wave_kernel     <- p7_ViterbiFilter[_BATH]                src/impl_sse/vitfilter.c:83-465
+//   fwd_wave_kernel     <- p7_ForwardParser / forward_engine      src/impl_sse/fwdback.c:256-463
+//   bias_lane_kernel    <- p7_bg_FilterScore / esl_hmm_Forward    src/p7_bg.c:491-505
+//
+// Work decomposition (MI355X-first, not the reference's 16-lane stripes):
+//  * SSV has no dependency along a DP row (only along diagonals), so ONE LANE owns one target and
+//    keeps the whole DP row in packed-int16 VGPRs (2 model nodes per register); 64 targets per
+//    wavefront advance in lock step, emission costs are gathered from an LDS table by residue.
+//    No cross-lane traffic at all.  4 VALU ops per 2 cells.
+//  * MSV(J)/Viterbi/Forward have a serial dependency along the row (xE->xB, D->D), and only the
+//    ~2% of targets that survive SSV reach them: ONE WAVEFRONT owns one target, lanes own
+//    contiguous blocks of model nodes, the row recurrence is a wavefront scan (shuffle), and the
+//    along-sequence recurrence stays in registers.
+#include <cmath>
+#include <cstring>
+#include <algorithm>
+#include <numeric>
+
+#include "bath_common.hpp"
+#include "bath_kernels.hpp"
+#include "bath_launch.hpp"
+
+using namespace bath;
+
+namespace bath {
+
+// ============================================================================================
+// SSV, lane per target.
+// ============================================================================================
+
+// Amino-acid targets: lane t scores sequence order[t] (or t), writes the raw maximum v in the
+// kernel's signed domain (begin score = -128), i.e. get_xE()'s byte minus 256.
+template <int NR>
+__global__ __launch_bounds__(256) void ssv_lane_kernel(SeqView sq, const int32_t *__restrict__ order,
+                                                       const int16_t *__restrict__ cost_tab, int row_bytes,
+                                                       int16_t *__restrict__ out_v) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  {
+    const int n16 = kSsvRows * row_bytes / 4;
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(cost_tab);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(lds);
+    for (int i = threadIdx.x; i < n16; i += blockDim.x) dst[i] = src[i];
+  }
+  __syncthreads();
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = t < sq.n;
+  const int64_t sid = live ? (order ? (int64_t)order[t] : t) : 0;
+  const int L = live ? sq.len[sid] : 0;
+  const uint8_t *s = sq.data + sq.off[sid];
+  const int Lw = wave_max_i32(L);
+
+  s16x2 reg[NR];
+  const s16x2 fl = {-128, -128};
+#pragma unroll
+  for (int r = 0; r < NR; r++) reg[r] = fl;
+  s16x2 xE = fl;
+
+  uint32_t wnext = (0 < L) ? *reinterpret_cast<const uint32_t *>(s) : 0x1d1d1d1du;
+  for (int i0 = 0; i0 < Lw; i0 += 4) {
+    const uint32_t w = wnext;
+    wnext = (i0 + 4 < L) ? *reinterpret_cast<const uint32_t *>(s + i0 + 4) : 0x1d1d1d1du;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      int x = (w >> (8 * j)) & 0xff;
+      x = (i0 + j < L) ? min(x, kKp - 1) : kRowReset;
+      ssv_row<NR>(reg, xE, lds + x * row_bytes);
+    }
+  }
+  if (live) out_v[sid] = (int16_t)max((int)xE.x, (int)xE.y);
+}
+
+__global__ void ssv_classify_kernel(int64_t n, const int32_t *__restrict__ len, const int16_t *__restrict__ v,
+                                    const uint8_t *__restrict__ tjb_tab, MsvConsts c, float *__restrict__ sc,
+                                    int32_t *__restrict__ status) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  float s = 0.f;
+  const int st = ssv_classify(v[t], tjb_tab[len[t]], c, &s);
+  sc[t] = s;
+  status[t] = st;
+}
+
+// ============================================================================================
+// Full MSV with the J state, wave per target (only for targets SSV could not decide).
+// Lane l owns nodes l*C+1 .. l*C+C.
+// ============================================================================================
+template <int C>
+__global__ __launch_bounds__(256) void msv_wave_kernel(SeqView sq, int M, const uint8_t *__restrict__ rb, int rb_stride,
+                                                       const uint8_t *__restrict__ tjb_tab, MsvConsts c,
+                                                       const int32_t *__restrict__ todo, int64_t ntodo, const int *__restrict__ ntodo_dev,
+                                                       float *__restrict__ sc, int32_t *__restrict__ status) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  if (ntodo_dev) ntodo = *ntodo_dev;
+  for (int64_t job = wid; job < ntodo; job += nw) {
+    const int64_t sid = todo ? (int64_t)todo[job] : job;
+    const int L = sq.len[sid];
+    const uint8_t *s = sq.data + sq.off[sid];
+    const int tjb = tjb_tab[L];
+    const int tjbm = (uint8_t)((int8_t)tjb + (int8_t)c.tbm);
+    int dp[C];
+#pragma unroll
+    for (int k = 0; k < C; k++) dp[k] = 0;
+    int xJ = 0;
+    int xB = satu8(c.base - tjbm);
+    bool overflow = false;
+    for (int i = 0; i < L; i++) {
+      const int x = min((int)s[i], kKp - 1);
+      const uint8_t *row = rb + (size_t)x * rb_stride;
+      int prev = __shfl_up(dp[C - 1], 1, 64);
+      if (lane == 0) prev = 0;
+      int xE = 0;
+#pragma unroll
+      for (int k = 0; k < C; k++) {
+        const int node = lane * C + k + 1;
+        const int cost = (node <= M) ? (int)row[node] : 255;
+        int sv = max(prev, xB);
+        sv = satu8(sv + c.bias);
+        sv = satu8(sv - cost);
+        prev = dp[k];
+        dp[k] = sv;
+        xE = max(xE, sv);
+      }
+      xE = wave_max_i32(xE);
+      if (satu8(xE + c.bias) == 255) { overflow = true; break; }
+      xE = satu8(xE - c.tec);
+      xJ = max(xJ, xE);
+      xB = satu8(max(c.base, xJ) - tjbm);
+    }
+    if (lane == 0) {
+      if (overflow) { sc[sid] = INFINITY; status[sid] = BATH_ERANGE; }
+      else {
+        float r = ((float)(xJ - tjb) - (float)c.base);
+        r /= c.scale_b;
+        r = (float)((double)r - 3.0);
+        sc[sid] = r; status[sid] = BATH_OK;
+      }
+    }
+  }
+}
+
+// ============================================================================================
+// Viterbi filter, wave per target.  int16 semantics of the reference kept exactly: every add
+// saturates to [-32768, 32767] (adds_epi16), special states wrap like int16_t assignments.
+// The D->D chain is evaluated exactly every row with a wavefront scan over (max,+) maps; the
+// reference's "lazy F" shortcut only skips work that provably cannot change any M cell.
+// ============================================================================================
+struct VitConsts {
+  int base_w, xwE_loop, xwE_move;
+  float scale_w;
+  // window finding (p7_ViterbiFilter_BATH), all optional
+  double invP_vit, invP_msv;     // esl_gumbel_invsurv(F2, VMU,VLAMBDA) / (F2, MMU,MLAMBDA), as float->double
+  float scale_b;
+  int base_b, tec_b, bias_b;
+  int Q8;
+};
+
+template <int C>
+__global__ __launch_bounds__(256) void vit_wave_kernel(SeqView sq, int M, const int16_t *__restrict__ g_rw,
+                                                       const int16_t *__restrict__ g_tw,
+                                                       const int16_t *__restrict__ xwmove_tab, const uint8_t *__restrict__ tjb_tab,
+                                                       VitConsts c, const int32_t *__restrict__ todo, int64_t ntodo, const int *__restrict__ ntodo_dev,
+                                                       float *__restrict__ sc, int32_t *__restrict__ status,
+                                                       // BATH window outputs (null => plain p7_ViterbiFilter)
+                                                       const float *__restrict__ filtersc, const uint8_t *__restrict__ ssv_scores,
+                                                       WindowRec *__restrict__ wins, int *__restrict__ win_count, int win_cap,
+                                                       int32_t *__restrict__ kminmax) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  int16_t *s_tw = reinterpret_cast<int16_t *>(lds);                  // [(M+1)*8]
+  int16_t *s_rw = s_tw + (size_t)(M + 1) * 8;                        // [Kp][M+1]
+  for (int i = threadIdx.x; i < (M + 1) * 8; i += blockDim.x) s_tw[i] = g_tw[i];
+  for (int i = threadIdx.x; i < kKp * (M + 1); i += blockDim.x) s_rw[i] = g_rw[i];
+  __syncthreads();
+  enum { MM, IM, DM, BM, MD, DD, MI, II };
+  const int lane = threadIdx.x & 63;
+  const int64_t wid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  const bool do_win = (wins != nullptr);
+  if (ntodo_dev) ntodo = *ntodo_dev;
+
+  for (int64_t job = wid; job < ntodo; job += nw) {
+    const int64_t sid = todo ? (int64_t)todo[job] : job;
+    const int L = sq.len[sid];
+    const uint8_t *s = sq.data + sq.off[sid];
+    const int xw_move = xwmove_tab[L];
+    int sc_thresh = 0, sc_ext_thresh = 0, skip_until = 0, kmin = 1 << 30, kmax = 0;
+    if (do_win) {
+      const double fsc = (double)filtersc[sid];
+      sc_thresh = (int)(int16_t)(int)ceil(((fsc + 0.69314718055994529 * c.invP_vit + 3.0) * (double)c.scale_w) -
+                                          (double)(float)c.xwE_move - (double)(float)xw_move + (double)(float)c.base_w);
+      sc_ext_thresh = (int)ceil(((fsc + 0.69314718055994529 * c.invP_msv + 3.0) * (double)c.scale_b) + c.base_b + c.tec_b + (int)tjb_tab[L]);
+    }
+    int Mp[C], Ip[C], Dp[C];
+#pragma unroll
+    for (int k = 0; k < C; k++) Mp[k] = Ip[k] = Dp[k] = -32768;
+    int xN = c.base_w;
+    int xB = (int16_t)(xN + xw_move);
+    int xJ = -32768, xC = -32768, xE = -32768;
+    bool overflow = false;
+
+    for (int i = 1; i <= L; i++) {
+      const int x = min((int)s[i - 1], kKp - 1);
+      const int16_t *rw = s_rw + (size_t)x * (M + 1);
+      int mIn = __shfl_up(Mp[C - 1], 1, 64), iIn = __shfl_up(Ip[C - 1], 1, 64), dIn = __shfl_up(Dp[C - 1], 1, 64);
+      if (lane == 0) mIn = iIn = dIn = -32768;
+      int Mc[C], Ic[C], dcv[C], tdd[C];
+      int xEl = -32768;
+#pragma unroll
+      for (int k = 0; k < C; k++) {
+        const int node = lane * C + k + 1;
+        if (node <= M) {
+          const int4 tq = *reinterpret_cast<const int4 *>(s_tw + (size_t)node * 8);
+          const int tMM = (int16_t)(tq.x & 0xffff), tIM = (int16_t)(tq.x >> 16);
+          const int tDM = (int16_t)(tq.y & 0xffff), tBM = (int16_t)(tq.y >> 16);
+          const int tMD = (int16_t)(tq.z & 0xffff), tDD = (int16_t)(tq.z >> 16);
+          const int tMI = (int16_t)(tq.w & 0xffff), tII = (int16_t)(tq.w >> 16);
+          const int m1 = (k == 0) ? mIn : Mp[k - 1];
+          const int i1 = (k == 0) ? iIn : Ip[k - 1];
+          const int d1 = (k == 0) ? dIn : Dp[k - 1];
+          int sv = sat16(xB + tBM);
+          sv = max(sv, sat16(m1 + tMM));
+          sv = max(sv, sat16(i1 + tIM));
+          sv = max(sv, sat16(d1 + tDM));
+          sv = sat16(sv + (int)rw[node]);
+          Mc[k] = sv;
+          xEl = max(xEl, sv);
+          dcv[k] = sat16(sv + tMD);
+          tdd[k] = tDD;
+          Ic[k] = max(sat16(Mp[k] + tMI), sat16(Ip[k] + tII));
+        } else {
+          Mc[k] = -32768; Ic[k] = -32768; dcv[k] = -32768; tdd[k] = -32768;
+        }
+      }
+      xE = wave_max_i32(xEl);
+      if (xE >= 32767) { overflow = true; break; }
+      xN = (int16_t)(xN + 0);
+      xC = (int16_t)max(xC + 0, xE + c.xwE_move);
+      xJ = (int16_t)max(xJ + 0, xE + c.xwE_loop);
+      xB = (int16_t)max(xJ + xw_move, xN + xw_move);
+
+      if (do_win && i > skip_until && xE >= sc_thresh) {           // vitfilter.c:386-424
+        int rank = 1 << 30;
+#pragma unroll
+        for (int k = 0; k < C; k++) {
+          const int node = lane * C + k + 1;
+          if (node <= M && Mc[k] == xE) rank = min(rank, ((node - 1) % c.Q8) * 8 + (node - 1) / c.Q8);
+        }
+        rank = wave_min_i32(rank);
+        const int k_start = (rank / 8) + c.Q8 * (rank % 8) + 1;
+        int max_k_end = k_start, max_i_end = i, sc_ext = sc_ext_thresh, max_sc_ext = sc_ext, since = 0;
+        int kk = k_start + 1, nn = i + 1;
+        while (kk <= M && nn <= L) {
+          sc_ext += c.bias_b - (int)ssv_scores[(size_t)kk * kKp + min((int)s[nn - 1], kKp - 1)];
+          if (sc_ext >= max_sc_ext) { max_sc_ext = sc_ext; max_k_end = kk; max_i_end = nn; since = 0; }
+          else if (++since == 5) break;
+          kk++; nn++;
+        }
+        if (lane == 0) {
+          int slot = atomicAdd(win_count, 1);
+          if (slot < win_cap) wins[slot] = WindowRec{(int32_t)sid, i, max_k_end, max_k_end - k_start + 1, 0.0f};
+        }
+        kmax = max(kmax, max_k_end);
+        kmin = min(kmin, k_start);
+        skip_until = max_i_end;
+      }
+
+      // exact D row: D(node+1) = max(dcv(node), D(node)+tDD(node)); chain across lanes by scan
+      int A = -(1 << 28), B = 0;
+#pragma unroll
+      for (int k = 0; k < C; k++) { A = max(dcv[k], A + tdd[k]); B += tdd[k]; A = max(A, -(1 << 28)); }
+      // inclusive scan of f_l(x) = max(A_l, x + B_l)
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int Ap = __shfl_up(A, d, 64), Bp = __shfl_up(B, d, 64);
+        if (lane >= d) { A = max(A, max(Ap, -(1 << 28)) + B); B = max(B + Bp, -(1 << 28)); }
+      }
+      int din = __shfl_up(A, 1, 64);
+      if (lane == 0) din = -32768;
+      din = max(din, -32768);
+      int Dc[C];
+      Dc[0] = din;
+#pragma unroll
+      for (int k = 1; k < C; k++) Dc[k] = max(dcv[k - 1], sat16(Dc[k - 1] + tdd[k - 1]));
+#pragma unroll
+      for (int k = 0; k < C; k++) { Mp[k] = Mc[k]; Ip[k] = Ic[k]; Dp[k] = Dc[k]; }
+    }
+    if (lane == 0) {
+      if (overflow) { sc[sid] = INFINITY; status[sid] = BATH_ERANGE; }
+      else if (xC > -32768) {
+        float r = (float)xC + (float)xw_move - (float)c.base_w;
+        r /= c.scale_w;
+        r = (float)((double)r - 3.0);
+        sc[sid] = r; status[sid] = BATH_OK;
+      } else { sc[sid] = -INFINITY; status[sid] = BATH_OK; }
+      if (do_win && kminmax) { kminmax[2 * sid] = kmin; kminmax[2 * sid + 1] = kmax; }
+    }
+  }
+}
+
+// ============================================================================================
+// Forward parser, wave per target (odds-ratio space, sparse rescaling as fwdback.c:418-434).
+// ============================================================================================
+struct FwdConsts { float xfE_loop, xfE_move; };
+
+template <int C>
+__global__ __launch_bounds__(256) void fwd_wave_kernel(SeqView sq, int M, const float *__restrict__ g_rf, const float *__restrict__ g_tf,
+                                                       const float *__restrict__ pmove_tab, FwdConsts c,
+                                                       const int32_t *__restrict__ todo, int64_t ntodo, const int *__restrict__ ntodo_dev,
+                                                       float *__restrict__ sc, int32_t *__restrict__ status) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  float *s_tf = reinterpret_cast<float *>(lds);          // [(M+1)*8]
+  float *s_rf = s_tf + (size_t)(M + 1) * 8;              // [Kp][M+1]
+  if (ntodo_dev) ntodo = *ntodo_dev;
+  for (int i = threadIdx.x; i < (M + 1) * 8; i += blockDim.x) s_tf[i] = g_tf[i];
+  for (int i = threadIdx.x; i < kKp * (M + 1); i += blockDim.x) s_rf[i] = g_rf[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int64_t wid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+
+  for (int64_t job = wid; job < ntodo; job += nw) {
+    const int64_t sid = todo ? (int64_t)todo[job] : job;
+    const int L = sq.len[sid];
+    const uint8_t *s = sq.data + sq.off[sid];
+    const float pmove = pmove_tab[L], ploop = 1.0f - pmove;
+    float Mp[C], Ip[C], Dp[C];
+#pragma unroll
+    for (int k = 0; k < C; k++) Mp[k] = Ip[k] = Dp[k] = 0.f;
+    float xN = 1.f, xE = 0.f, xJ = 0.f, xC = 0.f, xB = pmove;
+    float totscale = 0.f;
+
+    for (int i = 1; i <= L; i++) {
+      const int x = min((int)s[i - 1], kKp - 1);
+      const float *rf = s_rf + (size_t)x * (M + 1);
+      float mIn = __shfl_up(Mp[C - 1], 1, 64), iIn = __shfl_up(Ip[C - 1], 1, 64), dIn = __shfl_up(Dp[C - 1], 1, 64);
+      if (lane == 0) mIn = iIn = dIn = 0.f;
+      float Mc[C], Ic[C], md[C], tdd[C];
+      float sumE = 0.f;
+#pragma unroll
+      for (int k = 0; k < C; k++) {
+        const int node = lane * C + k + 1;
+        if (node <= M) {
+          const float4 ta = *reinterpret_cast<const float4 *>(s_tf + (size_t)node * 8);      // MM IM DM BM
+          const float4 tb = *reinterpret_cast<const float4 *>(s_tf + (size_t)node * 8 + 4);  // MD DD MI II
+          const float m1 = (k == 0) ? mIn : Mp[k - 1];
+          const float i1 = (k == 0) ? iIn : Ip[k - 1];
+          const float d1 = (k == 0) ? dIn : Dp[k - 1];
+          float sv = xB * ta.w;
+          sv = sv + m1 * ta.x;
+          sv = sv + i1 * ta.y;
+          sv = sv + d1 * ta.z;
+          sv = sv * rf[node];
+          Mc[k] = sv;
+          sumE += sv;
+          md[k] = sv * tb.x;
+          tdd[k] = tb.y;
+          Ic[k] = Mp[k] * tb.z + Ip[k] * tb.w;
+        } else { Mc[k] = 0.f; Ic[k] = 0.f; md[k] = 0.f; tdd[k] = 0.f; }
+      }
+      // D(node+1) = md(node) + D(node)*tDD(node): affine maps composed by wavefront scan
+      float A = 0.f, B = 1.f;
+#pragma unroll
+      for (int k = 0; k < C; k++) { A = md[k] + A * tdd[k]; B *= tdd[k]; }
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const float Ap = __shfl_up(A, d, 64), Bp = __shfl_up(B, d, 64);
+        if (lane >= d) { A = A + Ap * B; B = B * Bp; }
+      }
+      float din = __shfl_up(A, 1, 64);
+      if (lane == 0) din = 0.f;
+      float Dc[C];
+      Dc[0] = din;
+#pragma unroll
+      for (int k = 1; k < C; k++) Dc[k] = md[k - 1] + Dc[k - 1] * tdd[k - 1];
+#pragma unroll
+      for (int k = 0; k < C; k++) sumE += Dc[k];
+      xE = wave_sum_f32(sumE);
+      xN = xN * ploop;
+      xC = (xC * ploop) + (xE * c.xfE_move);
+      xJ = (xJ * ploop) + (xE * c.xfE_loop);
+      xB = (xJ * pmove) + (xN * pmove);
+      if (xE > 1.0e4f) {
+        xN = xN / xE; xC = xC / xE; xJ = xJ / xE; xB = xB / xE;
+        const float inv = (float)(1.0 / (double)xE);
+#pragma unroll
+        for (int k = 0; k < C; k++) { Mc[k] *= inv; Dc[k] *= inv; Ic[k] *= inv; }
+        totscale += (float)log((double)xE);
+        xE = 1.0f;
+      }
+#pragma unroll
+      for (int k = 0; k < C; k++) { Mp[k] = Mc[k]; Ip[k] = Ic[k]; Dp[k] = Dc[k]; }
+    }
+    if (lane == 0) {
+      if (isnan(xC) || (L > 0 && xC == 0.0f) || isinf(xC)) { sc[sid] = -INFINITY; status[sid] = BATH_ERANGE; }
+      else { sc[sid] = (float)((double)totscale + log((double)(xC * pmove))); status[sid] = BATH_OK; }
+    }
+  }
+}
+
+// ============================================================================================
+// Bias filter: Forward of the 2-state HMM (p7_bg_FilterScore), lane per target.
+// eo is [Kp][2] emission odds; per-target eo (local composition) if eo_stride != 0.
+// ============================================================================================
+__global__ __launch_bounds__(256) void bias_lane_kernel(SeqView sq, int M, const float *__restrict__ eo, int eo_stride,
+                                                        const float *__restrict__ p1_tab, const float *__restrict__ lt1_tab, const float *__restrict__ lt2_tab,
+                                                        const float *__restrict__ nullsc_tab,
+                                                        const int32_t *__restrict__ todo, int64_t ntodo,
+                                                        float *__restrict__ nullsc, float *__restrict__ filtersc) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= ntodo) return;
+  const int64_t sid = todo ? (int64_t)todo[t] : t;
+  const int L = sq.len[sid];
+  const uint8_t *s = sq.data + sq.off[sid];
+  const float *e = eo + (size_t)(eo_stride ? t * eo_stride : 0);
+  const float logsc = bias_forward(s, L, M, e, p1_tab[L]);
+  if (nullsc) nullsc[sid] = nullsc_tab[L];
+  filtersc[sid] = (logsc + lt1_tab[L]) + lt2_tab[L];
+}
+
+}  // namespace bath
+
+// ============================================================================================
+// Host side: batched entry points.
+// ============================================================================================
+namespace bath {
+
+MsvConsts msv_consts(const bath_hip_oprofile *om) { return MsvConsts{om->tbm_b, om->tec_b, om->base_b, om->bias_b, om->scale_b}; }
+
+VitConsts vit_consts(const bath_hip_oprofile *om) {
+  VitConsts c{};
+  c.base_w = om->base_w; c.xwE_loop = om->xw_E[0]; c.xwE_move = om->xw_E[1]; c.scale_w = om->scale_w;
+  c.scale_b = om->scale_b; c.base_b = om->base_b; c.tec_b = om->tec_b; c.bias_b = om->bias_b;
+  c.Q8 = std::max(2, ((om->M - 1) / 8) + 1);
+  return c;
+}
+
+// sequences sorted by length so the 64 lanes of a wavefront finish together
+static int length_order(bath_hip_ctx *ctx, const bath_hip_seqs *sq, DevBuf &buf) {
+  std::vector<int32_t> order((size_t)sq->n);
+  std::iota(order.begin(), order.end(), 0);
+  std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return sq->h_len[a] > sq->h_len[b]; });
+  BATH_HIP_TRY(ctx, buf.reserve(order.size() * sizeof(int32_t) + 16));
+  BATH_HIP_TRY(ctx, hipMemcpyAsync(buf.p, order.data(), order.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+  return BATH_OK;
+}
+
+int launch_ssv_lane(bath_hip_ctx *ctx, const bath_hip_oprofile *om, SeqView v, const int32_t *d_order, int16_t *d_v) {
+  if (v.n == 0) return BATH_OK;
+  const int blocks = (int)((v.n + 255) / 256);
+  const size_t shmem = (size_t)kSsvRows * om->ssv_row_bytes;
+  const int rb = om->ssv_row_bytes;
+#define BATH_SSV_CASE(N)                                                                                         \
+  case N:                                                                                                        \
+    hipLaunchKernelGGL(ssv_lane_kernel<N>, dim3(blocks), dim3(256), shmem, ctx->stream, v, d_order, om->d_ssv, rb, d_v); \
+    break;
+  switch (om->NR) {
+    BATH_SSV_CASE(16) BATH_SSV_CASE(32) BATH_SSV_CASE(48) BATH_SSV_CASE(64) BATH_SSV_CASE(80) BATH_SSV_CASE(96)
+    BATH_SSV_CASE(112) BATH_SSV_CASE(128) BATH_SSV_CASE(144) BATH_SSV_CASE(160) BATH_SSV_CASE(176) BATH_SSV_CASE(192) BATH_SSV_CASE(208)
+    default:
+      ctx->set_error("SSV kernel: model length " + std::to_string(om->M) + " exceeds the single-tile limit (416 nodes)");
+      return BATH_EINVAL;
+  }
+#undef BATH_SSV_CASE
+  BATH_HIP_TRY(ctx, hipGetLastError());
+  return BATH_OK;
+}
+
+static int columns_per_lane(int M) {
+  int c = (M + 63) / 64;
+  for (int opt : {1, 2, 3, 4, 6, 8, 12, 16, 24, 32}) if (c <= opt) return opt;
+  return -1;
+}
+
+#define BATH_C_SWITCH(C, BODY)                                   \
+  switch (C) {                                                   \
+    case 1: { constexpr int CC = 1; BODY } break;                \
+    case 2: { constexpr int CC = 2; BODY } break;                \
+    case 3: { constexpr int CC = 3; BODY } break;                \
+    case 4: { constexpr int CC = 4; BODY } break;                \
+    case 6: { constexpr int CC = 6; BODY } break;                \
+    case 8: { constexpr int CC = 8; BODY } break;                \
+    case 12: { constexpr int CC = 12; BODY } break;              \
+    case 16: { constexpr int CC = 16; BODY } break;              \
+    case 24: { constexpr int CC = 24; BODY } break;              \
+    case 32: { constexpr int CC = 32; BODY } break;              \
+    default: ctx->set_error("model too long (> 2048 nodes)"); return BATH_EINVAL; \
+  }
+
+static int wave_grid(bath_hip_ctx *ctx, int64_t njobs) {
+  int64_t blocks = (njobs + 3) / 4;
+  int64_t cap = (int64_t)ctx->prop.multiProcessorCount * 8;
+  return (int)std::max<int64_t>(1, std::min(blocks, cap));
+}
+
+int launch_msv_wave(bath_hip_ctx *ctx, const bath_hip_oprofile *om, SeqView v, const int32_t *d_todo, int64_t ntodo, float *d_sc, int32_t *d_status, const int *ntodo_dev) {
+  if (ntodo == 0) return BATH_OK;
+  const int C = columns_per_lane(om->M);
+  const int grid = wave_grid(ctx, ntodo);
+  BATH_C_SWITCH(C, hipLaunchKernelGGL(msv_wave_kernel<CC>, dim3(grid), dim3(256), 0, ctx->stream, v, om->M, om->d_rb, om->rb_stride,
+                                      om->lt.d_tjb, msv_consts(om), d_todo, ntodo, ntodo_dev, d_sc, d_status);)
+  BATH_HIP_TRY(ctx, hipGetLastError());
+  return BATH_OK;
+}
+
+int launch_vit_wave(bath_hip_ctx *ctx, const bath_hip_oprofile *om, SeqView v, const int32_t *d_todo, int64_t ntodo, float *d_sc, int32_t *d_status,
+                    const VitWindowArgs *wa, const int *ntodo_dev) {
+  if (ntodo == 0) return BATH_OK;
+  const int C = columns_per_lane(om->M);
+  const int grid = wave_grid(ctx, ntodo);
+  const size_t shmem = ((size_t)(om->M + 1) * 8 + (size_t)kKp * (om->M + 1)) * sizeof(int16_t);
+  VitConsts c = vit_consts(om);
+  const float *fsc = nullptr; const uint8_t *ssv = nullptr; WindowRec *wins = nullptr; int *wc = nullptr; int cap = 0; int32_t *kmm = nullptr;
+  if (wa) { c.invP_vit = wa->invP_vit; c.invP_msv = wa->invP_msv; fsc = wa->d_filtersc; ssv = wa->d_ssv_scores; wins = (WindowRec *)wa->d_wins; wc = wa->d_win_count; cap = wa->win_cap; kmm = wa->d_kminmax; }
+  BATH_C_SWITCH(C, {
+    if (shmem > 64 * 1024) BATH_HIP_TRY(ctx, hipFuncSetAttribute((const void *)vit_wave_kernel<CC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    hipLaunchKernelGGL(vit_wave_kernel<CC>, dim3(grid), dim3(256), shmem, ctx->stream, v, om->M, om->d_rw, om->d_tw, om->lt.d_xwmove, om->lt.d_tjb, c,
+                       d_todo, ntodo, ntodo_dev, d_sc, d_status, fsc, ssv, wins, wc, cap, kmm);
+  })
+  BATH_HIP_TRY(ctx, hipGetLastError());
+  return BATH_OK;
+}
+
+int launch_fwd_wave(bath_hip_ctx *ctx, const bath_hip_oprofile *om, SeqView v, const int32_t *d_todo, int64_t ntodo, float *d_sc, int32_t *d_status, const int *ntodo_dev) {
+  if (ntodo == 0) return BATH_OK;
+  const int C = columns_per_lane(om->M);
+  const int grid = wave_grid(ctx, ntodo);
+  const size_t shmem = ((size_t)(om->M + 1) * 8 + (size_t)kKp * (om->M + 1)) * sizeof(float);
+  FwdConsts c{om->xf_E[0], om->xf_E[1]};
+  BATH_C_SWITCH(C, {
+    if (shmem > 64 * 1024) BATH_HIP_TRY(ctx, hipFuncSetAttribute((const void *)fwd_wave_kernel<CC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    hipLaunchKernelGGL(fwd_wave_kernel<CC>, dim3(grid), dim3(256), shmem, ctx->stream, v, om->M, om->d_rf, om->d_tf, om->lt.d_pmove, c, d_todo, ntodo, ntodo_dev, d_sc, d_status);
+  })
+  BATH_HIP_TRY(ctx, hipGetLastError());
+  return BATH_OK;
+}
+
+int launch_bias_lane(bath_hip_ctx *ctx, const bath_hip_oprofile *om, SeqView v, const float *d_eo, int eo_stride, const int32_t *d_todo, int64_t ntodo,
+                     float *d_nullsc, float *d_filtersc) {
+  if (ntodo == 0) return BATH_OK;
+  const int blocks = (int)((ntodo + 255) / 256);
+  hipLaunchKernelGGL(bias_lane_kernel, dim3(blocks), dim3(256), 0, ctx->stream, v, om->M, d_eo ? d_eo : om->d_bias_eo, eo_stride, om->lt.d_p1,
+                     om->lt.d_lt1, om->lt.d_lt2, om->lt.d_nullsc, d_todo, ntodo, d_nullsc, d_filtersc);
+  BATH_HIP_TRY(ctx, hipGetLastError());
+  return BATH_OK;
+}
+
+int launch_ssv_classify(bath_hip_ctx *ctx, const bath_hip_oprofile *om, int64_t n, const int32_t *d_len, const int16_t *d_v, float *d_sc, int32_t *d_status) {
+  if (n == 0) return BATH_OK;
+  hipLaunchKernelGGL(ssv_classify_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, n, d_len, d_v, om->lt.d_tjb, msv_consts(om), d_sc, d_status);
+  BATH_HIP_TRY(ctx, hipGetLastError());
+  return BATH_OK;
+}
+
+}  // namespace bath
+
+static int check_batch(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bath_hip_seqs *sq) {
+  if (!ctx || !om || !sq) return BATH_EINVAL;
+  BATH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  return om->ensure_len_tables(sq->maxlen);
+}
+
+static int ssv_or_msv(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bath_hip_seqs *sq, float *sc, int32_t *status, bool do_msv) {
+  int st = check_batch(ctx, om, sq);
+  if (st != BATH_OK) return st;
+  const int64_t n = sq->n;
+  if (n == 0) return BATH_OK;
+  DevBuf &b_order = ctx->scratch[0], &b_v = ctx->scratch[1], &b_sc = ctx->scratch[2], &b_st = ctx->scratch[3], &b_todo = ctx->scratch[4];
+  if ((st = length_order(ctx, sq, b_order)) != BATH_OK) return st;
+  BATH_HIP_TRY(ctx, b_v.reserve((size_t)n * sizeof(int16_t)));
+  BATH_HIP_TRY(ctx, b_sc.reserve((size_t)n * sizeof(float)));
+  BATH_HIP_TRY(ctx, b_st.reserve((size_t)n * sizeof(int32_t)));
+  if ((st = launch_ssv_lane(ctx, om, sq->view(), b_order.as<int32_t>(), b_v.as<int16_t>())) != BATH_OK) return st;
+  if ((st = launch_ssv_classify(ctx, om, n, sq->d_len, b_v.as<int16_t>(), b_sc.as<float>(), b_st.as<int32_t>())) != BATH_OK) return st;
+  BATH_HIP_TRY(ctx, hipMemcpyAsync(sc, b_sc.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  BATH_HIP_TRY(ctx, hipMemcpyAsync(status, b_st.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  BATH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (!do_msv) return BATH_OK;
+  std::vector<int32_t> todo;
+  for (int64_t i = 0; i < n; i++) if (status[i] == BATH_ENORESULT) todo.push_back((int32_t)i);
+  if (todo.empty()) return BATH_OK;
+  BATH_HIP_TRY(ctx, b_todo.reserve(todo.size() * sizeof(int32_t)));
+  BATH_HIP_TRY(ctx, hipMemcpyAsync(b_todo.p, todo.data(), todo.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+  if ((st = launch_msv_wave(ctx, om, sq->view(), b_todo.as<int32_t>(), (int64_t)todo.size(), b_sc.as<float>(), b_st.as<int32_t>(), nullptr)) != BATH_OK) return st;
+  BATH_HIP_TRY(ctx, hipMemcpyAsync(sc, b_sc.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  BATH_HIP_TRY(ctx, hipMemcpyAsync(status, b_st.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  BATH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return BATH_OK;
+}
+
+extern "C" int bath_hip_ssvfilter(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bath_hip_seqs *sq, float *sc, int32_t *status) {
+  return ssv_or_msv(ctx, om, sq, sc, status, false);
+}
+extern "C" int bath_hip_msvfilter(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bath_hip_seqs *sq, float *sc, int32_t *status) {
+  return ssv_or_msv(ctx, om, sq, sc, status, true);
+}
+
+template <class F>
+static int score_batch(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bath_hip_seqs *sq, float *sc, int32_t *status, F launch) {
+  int st = check_batch(ctx, om, sq);
+  if (st != BATH_OK) return st;
+  const int64_t n = sq->n;
+  if (n == 0) return BATH_OK;
+  DevBuf &b_sc = ctx->scratch[2], &b_st = ctx->scratch[3];
+  BATH_HIP_TRY(ctx, b_sc.reserve((size_t)n * sizeof(float)));
+  BATH_HIP_TRY(ctx, b_st.reserve((size_t)n * sizeof(int32_t)));
+  if ((st = launch(b_sc.as<float>(), b_st.as<int32_t>())) != BATH_OK) return st;
+  BATH_HIP_TRY(ctx, hipMemcpyAsync(sc, b_sc.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  if (status) BATH_HIP_TRY(ctx, hipMemcpyAsync(status, b_st.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  BATH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return BATH_OK;
+}
+
+extern "C" int bath_hip_vitfilter(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bath_hip_seqs *sq, float *sc, int32_t *status) {
+  return score_batch(ctx, om, sq, sc, status, [&](float *d_sc, int32_t *d_st) { return launch_vit_wave(ctx, om, sq->view(), nullptr, sq->n, d_sc, d_st, nullptr, nullptr); });
+}
+extern "C" int bath_hip_forward_parser(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bath_hip_seqs *sq, float *sc, int32_t *status) {
+  return score_batch(ctx, om, sq, sc, status, [&](float *d_sc, int32_t *d_st) { return launch_fwd_wave(ctx, om, sq->view(), nullptr, sq->n, d_sc, d_st, nullptr); });
+}
+extern "C" int bath_hip_bias_filter(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bath_hip_seqs *sq, float *nullsc, float *filtersc) {
+  int st = check_batch(ctx, om, sq);
+  if (st != BATH_OK) return st;
+  const int64_t n = sq->n;
+  if (n == 0) return BATH_OK;
+  DevBuf &b_a = ctx->scratch[2], &b_b = ctx->scratch[5];
+  BATH_HIP_TRY(ctx, b_a.reserve((size_t)n * sizeof(float)));
+  BATH_HIP_TRY(ctx, b_b.reserve((size_t)n * sizeof(float)));
+  if ((st = launch_bias_lane(ctx, om, sq->view(), nullptr, 0, nullptr, n, b_a.as<float>(), b_b.as<float>())) != BATH_OK) return st;
+  if (nullsc) BATH_HIP_TRY(ctx, hipMemcpyAsync(nullsc, b_a.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  BATH_HIP_TRY(ctx, hipMemcpyAsync(filtersc, b_b.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  BATH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return BATH_OK;
+}

@@ -1,0 +1,109 @@
+// bath_kernels.hpp -- device helpers shared by the kernels (gfx950, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "bath_hip.h"
+
+namespace bath {
+
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ int wave_max_i32(int v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v = max(v, __shfl_xor(v, d, 64));
+  return v;
+}
+__device__ __forceinline__ int wave_min_i32(int v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v = min(v, __shfl_xor(v, d, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_sum_f32(float v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+  return v;
+}
+__device__ __forceinline__ int sat16(int v) { return min(max(v, -32768), 32767); }
+__device__ __forceinline__ int satu8(int v) { return min(max(v, 0), 255); }
+
+
+// ---- SSV: one DP row of the lane-per-target kernels ----------------------------------------------
+// One DP row for this lane: residue row <rowbase> (LDS byte address of the residue's cost row).
+template <int NR>
+__device__ __forceinline__ void ssv_row(s16x2 (&reg)[NR], s16x2 &xE, const char *rowbase) {
+  const s16x2 fl = {-128, -128};
+#pragma unroll
+  for (int r = NR - 2; r >= 0; r -= 2) {
+    const int2 c = *reinterpret_cast<const int2 *>(rowbase + 4 * r);     // costs of nodes 2r+1..2r+4
+    const unsigned hi = __builtin_bit_cast(unsigned, reg[r + 1]);
+    const unsigned lo = __builtin_bit_cast(unsigned, reg[r]);
+    // nodes (2r+3, 2r+4) take the previous row's (2r+2, 2r+3)
+    s16x2 v = __builtin_bit_cast(s16x2, __builtin_amdgcn_alignbit(hi, lo, 16));
+    v = __builtin_elementwise_sub_sat(v, __builtin_bit_cast(s16x2, c.y));
+    v = __builtin_elementwise_max(v, fl);
+    xE = __builtin_elementwise_max(xE, v);
+    reg[r + 1] = v;
+    // nodes (2r+1, 2r+2) take (2r, 2r+1); node 0 is the constant begin score -128
+    const unsigned lo2 = (r > 0) ? __builtin_bit_cast(unsigned, reg[r - 1]) : 0xff80ff80u;
+    v = __builtin_bit_cast(s16x2, __builtin_amdgcn_alignbit(lo, lo2, 16));
+    v = __builtin_elementwise_sub_sat(v, __builtin_bit_cast(s16x2, c.x));
+    v = __builtin_elementwise_max(v, fl);
+    xE = __builtin_elementwise_max(xE, v);
+    reg[r] = v;
+  }
+}
+
+// p7_SSVFilter's decision logic (ssvfilter.c:876-925) applied to the raw maximum.
+struct MsvConsts {
+  int tbm, tec, base, bias;
+  float scale_b;
+};
+
+__device__ __forceinline__ int ssv_classify(int v, int tjb, const MsvConsts &c, float *sc) {
+  if (tjb + c.tbm + c.tec + c.bias >= 127) return BATH_ENORESULT;
+  unsigned xE = (v >= -1 - c.bias) ? 255u : (unsigned)(v + 256);
+  if ((int)xE >= 255 - c.bias) {
+    *sc = INFINITY;
+    return (c.base - tjb - c.tbm < 128) ? BATH_ENORESULT : BATH_ERANGE;
+  }
+  xE = (xE + (unsigned)(c.base - tjb - c.tbm) - 128u) & 0xffffu;
+  if ((int)xE >= 255 - c.bias) { *sc = INFINITY; return BATH_ERANGE; }
+  unsigned xJ = (xE - (unsigned)c.tec) & 0xffffu;
+  if ((int)xJ > c.base) return BATH_ENORESULT;
+  float r = ((float)((int)xJ - tjb) - (float)c.base);
+  r /= c.scale_b;
+  r = (float)((double)r - 3.0);
+  *sc = r;
+  return BATH_OK;
+}
+
+struct WindowRec { int32_t cand, n, k, length; float score; };   // P7_HMM_WINDOW fields used on the path (hmmer.h:998)
+
+// esl_hmm_Forward on the 2-state bias-filter HMM (p7_bg_FilterScore, p7_bg.c:491): per-row max scaling,
+// float accumulation in the reference's order; t[0][*] follow p7_bg_SetLength (p7_bg.c:193).
+__device__ __forceinline__ float bias_forward(const uint8_t *s, int L, int M, const float *e /* [Kp][2] */, float p1) {
+  const float L1 = (float)M / 8.0f;
+  const float t00 = p1, t01 = 1.0f - p1, t10 = 1.0f / (L1 + 1.0f), t11 = L1 / (L1 + 1.0f);
+  float logsc = 0.0f;
+  if (L <= 0) return logsc;
+  int x = min((int)s[0], 28);
+  float d0 = e[2 * x] * 0.999f, d1 = e[2 * x + 1] * 0.001f;
+  float mx = fmaxf(fmaxf(d0, 0.0f), d1);
+  d0 /= mx; d1 /= mx;
+  logsc += (float)log((double)mx);
+  for (int i = 1; i < L; i++) {
+    x = min((int)s[i], 28);
+    float n0 = 0.0f + d0 * t00; n0 = n0 + d1 * t10; n0 *= e[2 * x];
+    float n1 = 0.0f + d0 * t01; n1 = n1 + d1 * t11; n1 *= e[2 * x + 1];
+    mx = fmaxf(fmaxf(n0, 0.0f), n1);
+    d0 = n0 / mx; d1 = n1 / mx;
+    logsc += (float)log((double)mx);
+  }
+  float end = 0.0f + d0 * 1.0f; end = end + d1 * 1.0f;
+  logsc += (float)log((double)end);
+  return logsc;
+}
+
+}  // namespace bath

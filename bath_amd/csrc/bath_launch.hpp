@@ -1,0 +1,29 @@
+// bath_launch.hpp -- host-side launchers shared between bath_filters.hip and bath_pipeline.hip.
+#pragma once
+#include "bath_common.hpp"
+
+namespace bath {
+
+struct VitWindowArgs {            // p7_ViterbiFilter_BATH's extra inputs/outputs (vitfilter.c:286)
+  double invP_vit, invP_msv;
+  const float *d_filtersc;        // [n] indexed by sequence id
+  const uint8_t *d_ssv_scores;    // [(M+1)*Kp]
+  void *d_wins;                   // WindowRec[win_cap]
+  int *d_win_count;
+  int win_cap;
+  int32_t *d_kminmax;             // [2n] min start node / max end node over the target's windows
+};
+
+int launch_ssv_lane(bath_hip_ctx *ctx, const bath_hip_oprofile *om, SeqView v, const int32_t *d_order, int16_t *d_v);
+int launch_ssv_classify(bath_hip_ctx *ctx, const bath_hip_oprofile *om, int64_t n, const int32_t *d_len, const int16_t *d_v, float *d_sc, int32_t *d_status);
+int launch_msv_wave(bath_hip_ctx *ctx, const bath_hip_oprofile *om, SeqView v, const int32_t *d_todo, int64_t ntodo, float *d_sc, int32_t *d_status, const int *ntodo_dev);
+int launch_vit_wave(bath_hip_ctx *ctx, const bath_hip_oprofile *om, SeqView v, const int32_t *d_todo, int64_t ntodo, float *d_sc, int32_t *d_status,
+                    const VitWindowArgs *wa, const int *ntodo_dev);
+int launch_fwd_wave(bath_hip_ctx *ctx, const bath_hip_oprofile *om, SeqView v, const int32_t *d_todo, int64_t ntodo, float *d_sc, int32_t *d_status, const int *ntodo_dev);
+int launch_bias_lane(bath_hip_ctx *ctx, const bath_hip_oprofile *om, SeqView v, const float *d_eo, int eo_stride, const int32_t *d_todo, int64_t ntodo,
+                     float *d_nullsc, float *d_filtersc);
+
+struct MsvConsts;
+MsvConsts msv_consts(const bath_hip_oprofile *om);
+
+}  // namespace bath

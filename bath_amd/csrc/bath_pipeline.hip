@@ -1,0 +1,744 @@
+// bath_pipeline.hip -- the filter cascade of p7_Pipeline_BATH() as a batched GPU pipeline.
+//
+// Reference control flow (src/p7_pipeline.c:1632-1791), per ORF of a DNA window and strand:
+//   MSV (F1) -> bias filter (F1) -> ViterbiFilter_BATH (F2) or SSVFilter_BATH windows
+//   -> local-composition re-filter -> ForwardParser (F3, or F4 when fs_pipe)
+// with the ORFs produced by easel's six-frame translation (src/bathsearch.c:384-392).
+//
+// GPU formulation:
+//   1. ssv_dna_kernel: one LANE per (window, strand, frame) stream.  The lane translates codons on
+//      the fly and feeds the SSV recurrence (bath_filters.hip); a stop codon is a cost row of +127
+//      which resets every diagonal, so consecutive ORFs of a frame never interact.  At each ORF end
+//      the lane compares its running maximum with a per-length threshold table computed on the host
+//      with the reference's double-precision P-value maths (so the F1 decision is bit-identical)
+//      and appends the ~2% survivors to a candidate list.  The ~98% of ORFs that stop at MSV never
+//      touch HBM beyond the 1 byte/nt read of the DNA.
+//   2. survivors are materialised as amino-acid sequences and flow through decision kernels
+//      (lane per candidate) and DP kernels (wave per candidate) with device-side work lists:
+//      no host round trip until the final copy-out.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "bath_common.hpp"
+#include "bath_kernels.hpp"
+#include "bath_launch.hpp"
+#include "host_model.hpp"
+
+using namespace bath;
+
+namespace bath {
+
+static const double kLog2 = 0.69314718055994529;
+
+// ---------------------------------------------------------------------------------------------
+// translation tables
+// ---------------------------------------------------------------------------------------------
+struct DnaTables {
+  const uint8_t *aa;      // [18*18*18] amino code of every (possibly degenerate) codon, esl_gencode_GetTranslation
+  const uint8_t *comp;    // [18] complement
+};
+
+static bool dna_degen_has(int x, int y) {
+  static const char *members[18] = {"A", "C", "G", "T", "", "AG", "CT", "AC", "GT", "CG", "AT", "ACT", "CGT", "ACG", "AGT", "ACGT", "", ""};
+  static const char nt[] = "ACGT";
+  return std::strchr(members[x], nt[y]) != nullptr;
+}
+
+// codon -> amino acid for all 18^3 digital codons: canonical codons through basic[]; degenerate codons
+// give the amino acid all expansions agree on, else X (easel esl_gencode_GetTranslation semantics).
+static void build_codon_table(const uint8_t basic[64], std::vector<uint8_t> &tab) {
+  tab.assign(18 * 18 * 18, (uint8_t)kXaa);
+  for (int a = 0; a < 18; a++) for (int b = 0; b < 18; b++) for (int c = 0; c < 18; c++) {
+    int aa = -1; bool mixed = false;
+    for (int x = 0; x < 4 && !mixed; x++) { if (!dna_degen_has(a, x)) continue;
+      for (int y = 0; y < 4 && !mixed; y++) { if (!dna_degen_has(b, y)) continue;
+        for (int z = 0; z < 4; z++) { if (!dna_degen_has(c, z)) continue;
+          int v = basic[16 * x + 4 * y + z];
+          if (aa == -1) aa = v; else if (aa != v) { mixed = true; break; }
+        } } }
+    tab[(a * 18 + b) * 18 + c] = (uint8_t)((mixed || aa == -1) ? kXaa : aa);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// candidate storage (structure of arrays, indexed by candidate id)
+// ---------------------------------------------------------------------------------------------
+struct Cand {
+  int64_t *window;  int32_t *sf;      // strand*3+frame
+  int32_t *startj;  int32_t *len;     // first codon index within the stream, length in aa
+  int16_t *v;                         // raw SSV maximum
+  int64_t *off;                       // offset of the amino-acid sequence in the pool
+  int32_t *msv_status, *vit_status, *fwd_status, *stage, *flags;
+  float *usc, *nullsc, *filtersc, *vfsc, *fwdsc;
+  double *P;
+  int32_t *kminmax;                   // [2*cap]
+};
+
+enum { FLAG_VIT_RUN = 1, FLAG_HAS_WIN = 2 };
+
+struct Counters {                     // device-side counters, one struct per pipeline call
+  int cand_count, todo_msv, todo_vit, todo_ssvb, todo_vit2, todo_fwd, win_count, overflow;
+  unsigned long long aa_bump;
+  unsigned long long n_orfs, orf_res;                       // ORFs >= minlen, their total aa
+  unsigned long long n_past_msv, n_past_bias, n_past_vit, n_past_fwd;
+  unsigned long long pos_past_msv, pos_past_bias, pos_past_vit, pos_past_fwd;
+  unsigned long long res_vit, res_fwd;                      // residues entering Viterbi / Forward
+};
+
+struct Params {
+  double F1, F2, F3, F4;
+  int do_bias, fs_pipe, minlen;
+  float evparam[BATH_NEVPARAM];
+};
+
+// ---------------------------------------------------------------------------------------------
+// 1. SSV over six-frame translated DNA, lane per stream
+// ---------------------------------------------------------------------------------------------
+template <int NR>
+__global__ __launch_bounds__(256) void ssv_dna_kernel(SeqView dna, DnaTables tabs, const int16_t *__restrict__ cost_tab, int row_bytes,
+                                                      const int16_t *__restrict__ emit_thresh, int thresh_max, int minlen,
+                                                      Cand cand, int cand_cap, unsigned long long aa_cap, Counters *__restrict__ ctr) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  uint8_t *s_aa = reinterpret_cast<uint8_t *>(lds + kSsvRows * row_bytes);       // [5832]
+  uint8_t *s_comp = s_aa + 5832;                                                  // [18] (+pad)
+  {
+    const int n32 = kSsvRows * row_bytes / 4;
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(cost_tab);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(lds);
+    for (int i = threadIdx.x; i < n32; i += blockDim.x) dst[i] = src[i];
+    for (int i = threadIdx.x; i < 5832; i += blockDim.x) s_aa[i] = tabs.aa[i];
+    if (threadIdx.x < 18) s_comp[threadIdx.x] = tabs.comp[threadIdx.x];
+  }
+  __syncthreads();
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t w = t / 6;
+  const int sf = (int)(t - w * 6);
+  const int strand = sf / 3, frame = sf - strand * 3;
+  const bool live = w < dna.n;
+  const int n = live ? dna.len[w] : 0;
+  const uint8_t *d = dna.data + (live ? dna.off[w] : 0);
+  const int ncod = (n >= 15 && n - frame >= 3) ? (n - frame) / 3 : 0;      // windows < 15 nt are skipped, bathsearch.c:1066
+  const int Lw = wave_max_i32(ncod);
+
+  s16x2 reg[NR];
+  const s16x2 fl = {-128, -128};
+#pragma unroll
+  for (int r = 0; r < NR; r++) reg[r] = fl;
+  s16x2 xE = fl;
+  int orf_len = 0, start_j = 0;
+  unsigned my_orfs = 0, my_res = 0;
+
+  for (int j = 0; j <= Lw; j++) {
+    int x = kRowReset;
+    bool close = false;
+    if (j < ncod) {
+      int a, b, c;
+      if (strand == 0) {
+        const int p = frame + 3 * j;
+        a = d[p]; b = d[p + 1]; c = d[p + 2];
+      } else {
+        const int q = n - 1 - (frame + 3 * j);
+        a = s_comp[min((int)d[q], 17)]; b = s_comp[min((int)d[q - 1], 17)]; c = s_comp[min((int)d[q - 2], 17)];
+      }
+      a = min(a, 17); b = min(b, 17); c = min(c, 17);
+      const int aa = s_aa[(a * 18 + b) * 18 + c];
+      if (aa == kStop) close = true;
+      else { if (orf_len == 0) start_j = j; orf_len++; x = aa; }
+    } else if (j == ncod) close = true;
+    if (close) {
+      if (orf_len >= minlen) {
+        my_orfs++; my_res += (unsigned)orf_len;
+        const int v = max((int)xE.x, (int)xE.y);
+        if (v >= (int)emit_thresh[min(orf_len, thresh_max)]) {
+          const int slot = atomicAdd(&ctr->cand_count, 1);
+          const unsigned long long need = ((unsigned long long)orf_len + 3ull) & ~3ull;
+          const unsigned long long off = atomicAdd(&ctr->aa_bump, need);
+          if (slot < cand_cap && off + need <= aa_cap) {
+            cand.window[slot] = w; cand.sf[slot] = sf; cand.startj[slot] = start_j; cand.len[slot] = orf_len;
+            cand.v[slot] = (int16_t)min(v, 32767); cand.off[slot] = (int64_t)off;
+          } else atomicOr(&ctr->overflow, 1);
+        }
+      }
+      xE = fl; orf_len = 0;
+    }
+    ssv_row<NR>(reg, xE, lds + x * row_bytes);
+  }
+  // block-level reduction of the ORF counters
+  __shared__ unsigned red[2];
+  if (threadIdx.x == 0) red[0] = red[1] = 0;
+  __syncthreads();
+  if (my_orfs) { atomicAdd(&red[0], my_orfs); atomicAdd(&red[1], my_res); }
+  __syncthreads();
+  if (threadIdx.x == 0 && red[0]) { atomicAdd(&ctr->n_orfs, (unsigned long long)red[0]); atomicAdd(&ctr->orf_res, (unsigned long long)red[1]); }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 2. write the candidates' amino-acid sequences, wave per candidate
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void materialize_kernel(SeqView dna, DnaTables tabs, Cand cand, int cand_cap, const Counters *__restrict__ ctr,
+                                                          uint8_t *__restrict__ pool) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  const int ncand = min(ctr->cand_count, cand_cap);
+  for (int64_t c = wid; c < ncand; c += nw) {
+    const int64_t w = cand.window[c];
+    const int sf = cand.sf[c], strand = sf / 3, frame = sf - strand * 3;
+    const int n = dna.len[w];
+    const uint8_t *d = dna.data + dna.off[w];
+    const int j0 = cand.startj[c], L = cand.len[c];
+    uint8_t *out = pool + cand.off[c];
+    for (int i = lane; i < L; i += 64) {
+      const int j = j0 + i;
+      int a, b, cc;
+      if (strand == 0) { const int p = frame + 3 * j; a = d[p]; b = d[p + 1]; cc = d[p + 2]; }
+      else { const int q = n - 1 - (frame + 3 * j); a = tabs.comp[min((int)d[q], 17)]; b = tabs.comp[min((int)d[q - 1], 17)]; cc = tabs.comp[min((int)d[q - 2], 17)]; }
+      a = min(a, 17); b = min(b, 17); cc = min(cc, 17);
+      out[i] = tabs.aa[(a * 18 + b) * 18 + cc];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// decision kernels (lane per candidate)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double d_gumbel_surv(double x, double mu, double lambda) {
+  const double ey = -exp(-lambda * (x - mu));
+  if (fabs(ey) < 5e-9) return -ey;
+  return 1.0 - exp(ey);
+}
+__device__ __forceinline__ double d_exp_surv(double x, double mu, double lambda) { return (x < mu) ? 1.0 : exp(-lambda * (x - mu)); }
+
+// classify the SSV maxima (ssvfilter.c:876-925); undecided targets go to the full-MSV list
+__global__ void classify_kernel(Cand cand, int cand_cap, Counters *__restrict__ ctr, const uint8_t *__restrict__ tjb_tab, MsvConsts mc,
+                                int32_t *__restrict__ todo_msv) {
+  const int ncand = min(ctr->cand_count, cand_cap);
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < ncand; c += gridDim.x * blockDim.x) {
+    float sc = 0.f;
+    const int st = ssv_classify(cand.v[c], tjb_tab[cand.len[c]], mc, &sc);
+    cand.usc[c] = sc; cand.msv_status[c] = st; cand.stage[c] = 0; cand.flags[c] = 0;
+    cand.vfsc[c] = -INFINITY; cand.fwdsc[c] = -INFINITY; cand.vit_status[c] = 0; cand.filtersc[c] = 0.f; cand.P[c] = 1.0;
+    cand.kminmax[2 * c] = 1 << 30; cand.kminmax[2 * c + 1] = 0;
+    if (st == BATH_ENORESULT) todo_msv[atomicAdd(&ctr->todo_msv, 1)] = c;
+  }
+}
+
+// MSV P-value (F1), bias filter (F1), then route to Viterbi (P > F2) or SSV windows (P <= F2): p7_pipeline.c:1649-1677
+__global__ void f1_bias_kernel(Cand cand, int cand_cap, Counters *__restrict__ ctr, Params p, const uint8_t *__restrict__ pool, int M,
+                               const float *__restrict__ eo, const float *__restrict__ nullsc_tab, const float *__restrict__ p1_tab,
+                               const float *__restrict__ lt1_tab, const float *__restrict__ lt2_tab,
+                               int32_t *__restrict__ todo_vit, int32_t *__restrict__ todo_ssvb) {
+  const int ncand = min(ctr->cand_count, cand_cap);
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < ncand; c += gridDim.x * blockDim.x) {
+    const int L = cand.len[c];
+    const float usc = cand.usc[c];
+    const float nullsc = nullsc_tab[L];
+    cand.nullsc[c] = nullsc;
+    float seqsc = (float)((double)(usc - nullsc) / kLog2);
+    double P = d_gumbel_surv(seqsc, p.evparam[0], p.evparam[1]);
+    cand.P[c] = P;
+    if (P > p.F1) continue;
+    atomicAdd(&ctr->n_past_msv, 1ull); atomicAdd(&ctr->pos_past_msv, (unsigned long long)L * 3ull);
+    cand.stage[c] = 1;
+    float filtersc = nullsc;
+    if (p.do_bias) {
+      filtersc = bias_forward(pool + cand.off[c], L, M, eo, p1_tab[L]);
+      filtersc = (filtersc + lt1_tab[L]) + lt2_tab[L];
+      seqsc = (float)((double)(usc - filtersc) / kLog2);
+      P = d_gumbel_surv(seqsc, p.evparam[0], p.evparam[1]);
+      cand.P[c] = P; cand.filtersc[c] = filtersc;
+      if (P > p.F1) continue;
+    }
+    cand.filtersc[c] = filtersc;
+    atomicAdd(&ctr->n_past_bias, 1ull); atomicAdd(&ctr->pos_past_bias, (unsigned long long)L * 3ull);
+    cand.stage[c] = 2;
+    if (P > p.F2) { cand.flags[c] |= FLAG_VIT_RUN; todo_vit[atomicAdd(&ctr->todo_vit, 1)] = c; atomicAdd(&ctr->res_vit, (unsigned long long)L); }
+    else todo_ssvb[atomicAdd(&ctr->todo_ssvb, 1)] = c;
+  }
+}
+
+// p7_SSVFilter_BATH (msvfilter.c:250-427): diagonal windows for strong MSV hits, lane per candidate.
+// dp scratch: one row of MP+1 bytes per thread.
+__global__ void ssv_bath_kernel(Cand cand, const Counters *__restrict__ ctr, const int32_t *__restrict__ todo, const uint8_t *__restrict__ pool,
+                                int M, const uint8_t *__restrict__ rb, int rb_stride, const uint8_t *__restrict__ ssv_scores,
+                                const uint8_t *__restrict__ tjb_tab, const float *__restrict__ nullsc_tab, MsvConsts mc, double invP_f1,
+                                uint8_t *__restrict__ scratch, int MP, WindowRec *__restrict__ wins, int win_cap, Counters *__restrict__ ctrw) {
+  const int ntodo = ctr->todo_ssvb;
+  const int Q = max(2, ((M - 1) / 16) + 1);
+  uint8_t *dp = scratch + (size_t)(blockIdx.x * blockDim.x + threadIdx.x) * (MP + 1);
+  for (int job = blockIdx.x * blockDim.x + threadIdx.x; job < ntodo; job += gridDim.x * blockDim.x) {
+    const int c = todo[job];
+    const int L = cand.len[c];
+    const uint8_t *s = pool + cand.off[c];
+    const int tjb = tjb_tab[L];
+    const float nullsc = nullsc_tab[L];
+    const int sc_thresh = (uint8_t)(int)ceil((((double)nullsc + ((double)(float)invP_f1 * kLog2) + 3.0) * (double)mc.scale_b) + mc.base + mc.tec + tjb);
+    const int tjbm = (uint8_t)((int8_t)tjb + (int8_t)mc.tbm);
+    const int xB = satu8(mc.base - tjbm);
+    int kmin = 1 << 30, kmax = 0;
+    for (int k = 0; k <= MP; k++) dp[k] = 0;
+    for (int i = 1; i <= L; i++) {
+      const int x = min((int)s[i - 1], kKp - 1);
+      const uint8_t *row = rb + (size_t)x * rb_stride;
+      int xE = 0;
+      for (int k = MP; k >= 1; k--) {
+        const int cost = (k <= M) ? (int)row[k] : 255;
+        int sv = max((int)dp[k - 1], xB);
+        sv = satu8(sv + mc.bias);
+        sv = satu8(sv - cost);
+        xE = max(xE, sv);
+        dp[k] = (uint8_t)sv;
+      }
+      if (xE >= sc_thresh) {
+        int end = -1, rem_sc = -1;
+        for (int q = 0; q < Q; q++)
+          for (int z = 0; z < 16; z++) {
+            const int k = q + Q * z + 1;
+            const int b = dp[k];
+            if (b >= sc_thresh && b > rem_sc && k <= M) { end = k; rem_sc = b; }
+          }
+        for (int k = 0; k <= MP; k++) dp[k] = 0;
+        int start = end, target_end = i, target_start = i;
+        int sc = rem_sc;
+        while (rem_sc > mc.base - tjb - mc.tbm && start >= 1 && target_start >= 1) {
+          rem_sc -= mc.bias - (int)ssv_scores[(size_t)start * kKp + min((int)s[target_start - 1], kKp - 1)];
+          --start; --target_start;
+        }
+        start++; target_start++;
+        int k = end + 1, n = target_end + 1, max_end = target_end, max_sc = sc, since = 0;
+        while (k < M && n <= L) {
+          sc += mc.bias - (int)ssv_scores[(size_t)k * kKp + min((int)s[n - 1], kKp - 1)];
+          if (sc >= max_sc) { max_sc = sc; max_end = n; since = 0; }
+          else { since++; if (since == 5) break; }
+          k++; n++;
+        }
+        end += (max_end - target_end);
+        target_end = max_end;
+        float ret = ((float)(max_sc - tjb) - (float)mc.base);
+        ret /= mc.scale_b;
+        ret = (float)((double)ret - 3.0);
+        const int slot = atomicAdd(&ctrw->win_count, 1);
+        if (slot < win_cap) wins[slot] = WindowRec{c, target_start, end, end - start + 1, ret};
+        kmin = min(kmin, start); kmax = max(kmax, end);
+        i = target_end;
+      }
+    }
+    cand.kminmax[2 * c] = kmin; cand.kminmax[2 * c + 1] = kmax;
+  }
+}
+
+// p7_pli_ComputeLocalCompo (p7_pipeline.c:427-458) + p7_bg_SetFilter + esl_hmm_Configure for one candidate
+__device__ void local_compo_eo(const uint8_t *ssv_scores, int M, int base_b, float scale_b, const float *bgf, int k_start, int k_end, float *eo /* [Kp][2] */) {
+  float compo[20];
+  const int k_len = k_end - k_start + 1;
+  if (k_len < 20) { k_start -= (20 - k_len) / 2; k_end += (20 - k_len) / 2; }
+  k_start = max(1, k_start); k_end = min(M, k_end);
+  for (int x = 0; x < 20; x++) compo[x] = 0.0f;
+  for (int k = k_start; k <= k_end; k++)
+    for (int x = 0; x < 20; x++) {
+      const float lo = ((float)base_b - (float)ssv_scores[(size_t)k * kKp + x]) / scale_b;
+      compo[x] += bgf[x] * expf(lo);
+    }
+  float sum = 0.f, cc = 0.f;
+  for (int x = 0; x < 20; x++) { const float y = compo[x] - cc; const float t = sum + y; cc = (t - sum) - y; sum = t; }
+  if (sum != 0.0f) for (int x = 0; x < 20; x++) compo[x] /= sum;
+  else for (int x = 0; x < 20; x++) compo[x] = 1.0f / 20.0f;
+  for (int x = 0; x < 20; x++) { eo[2 * x] = bgf[x] / bgf[x]; eo[2 * x + 1] = compo[x] / bgf[x]; }
+  eo[2 * 20] = eo[2 * 20 + 1] = 1.0f; eo[2 * 27] = eo[2 * 27 + 1] = 1.0f; eo[2 * 28] = eo[2 * 28 + 1] = 1.0f;
+  // degenerate residues 21..26: B=DN J=IL Z=EQ O=K U=C X=all
+  const int mem[6][2] = {{2, 11}, {7, 9}, {3, 13}, {8, 8}, {1, 1}, {-1, -1}};
+  for (int dx = 0; dx < 6; dx++) {
+    float n0 = 0.f, n1 = 0.f, den = 0.f;
+    if (dx == 5) { for (int y = 0; y < 20; y++) { n0 += bgf[y]; n1 += compo[y]; den += bgf[y]; } }
+    else {
+      const int a = min(mem[dx][0], mem[dx][1]), b = max(mem[dx][0], mem[dx][1]);
+      n0 += bgf[a]; n1 += compo[a]; den += bgf[a];
+      if (b != a) { n0 += bgf[b]; n1 += compo[b]; den += bgf[b]; }
+    }
+    eo[2 * (21 + dx)] = den > 0.f ? n0 / den : 0.f;
+    eo[2 * (21 + dx) + 1] = den > 0.f ? n1 / den : 0.f;
+  }
+}
+
+// after Viterbi / SSV windows: F2 test, local-composition re-filter (p7_pipeline.c:1672-1718)
+__global__ void post_vit_kernel(Cand cand, int cand_cap, Counters *__restrict__ ctr, Params p, const uint8_t *__restrict__ pool, int M,
+                                const uint8_t *__restrict__ ssv_scores, int base_b, float scale_b, const float *__restrict__ bgf,
+                                const float *__restrict__ p1_tab, const float *__restrict__ lt1_tab, const float *__restrict__ lt2_tab,
+                                int32_t *__restrict__ todo_vit2, int32_t *__restrict__ todo_fwd) {
+  const int ncand = min(ctr->cand_count, cand_cap);
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < ncand; c += gridDim.x * blockDim.x) {
+    if (cand.stage[c] != 2) continue;
+    const int L = cand.len[c];
+    const float usc = cand.usc[c];
+    float filtersc = cand.filtersc[c];
+    float vfsc = cand.vfsc[c];
+    double P = cand.P[c];
+    if (cand.flags[c] & FLAG_VIT_RUN) {
+      const float seqsc = (float)((double)(vfsc - filtersc) / kLog2);
+      P = d_gumbel_surv(seqsc, p.evparam[2], p.evparam[3]);
+      cand.P[c] = P;
+      if (P > p.F2) { cand.kminmax[2 * c] = 1 << 30; cand.kminmax[2 * c + 1] = 0; continue; }
+    } else vfsc = -INFINITY;
+    atomicAdd(&ctr->n_past_vit, 1ull); atomicAdd(&ctr->pos_past_vit, (unsigned long long)L * 3ull);
+    const int kmin = cand.kminmax[2 * c], kmax = cand.kminmax[2 * c + 1];
+    if (p.do_bias && kmin <= kmax) {
+      cand.flags[c] |= FLAG_HAS_WIN;
+      float eo[kKp * 2];
+      local_compo_eo(ssv_scores, M, base_b, scale_b, bgf, kmin, kmax, eo);
+      float lf = bias_forward(pool + cand.off[c], L, M, eo, p1_tab[L]);
+      lf = (lf + lt1_tab[L]) + lt2_tab[L];
+      if (lf > filtersc) {
+        filtersc = lf;
+        cand.filtersc[c] = filtersc;
+        if (vfsc == -INFINITY) {
+          const float seqsc = (float)((double)(usc - filtersc) / kLog2);
+          P = d_gumbel_surv(seqsc, p.evparam[0], p.evparam[1]);
+          cand.P[c] = P;
+          if (P > p.F2) { cand.stage[c] = 5; todo_vit2[atomicAdd(&ctr->todo_vit2, 1)] = c; atomicAdd(&ctr->res_vit, (unsigned long long)L); continue; }
+        } else {
+          const float seqsc = (float)((double)(vfsc - filtersc) / kLog2);
+          P = d_gumbel_surv(seqsc, p.evparam[2], p.evparam[3]);
+          cand.P[c] = P;
+          if (P > p.F2) continue;                          // rejected; stays at stage 2 (the reference has already counted it past Vit)
+        }
+      }
+    }
+    cand.stage[c] = 3;
+    todo_fwd[atomicAdd(&ctr->todo_fwd, 1)] = c; atomicAdd(&ctr->res_fwd, (unsigned long long)L);
+  }
+}
+
+// plain p7_ViterbiFilter re-run for candidates whose local filter score demanded it (p7_pipeline.c:1703-1708)
+__global__ void post_vit2_kernel(Cand cand, Counters *__restrict__ ctr, Params p, const int32_t *__restrict__ todo_vit2, int32_t *__restrict__ todo_fwd) {
+  const int ntodo = ctr->todo_vit2;
+  for (int job = blockIdx.x * blockDim.x + threadIdx.x; job < ntodo; job += gridDim.x * blockDim.x) {
+    const int c = todo_vit2[job];
+    const float seqsc = (float)((double)(cand.vfsc[c] - cand.filtersc[c]) / kLog2);
+    const double P = d_gumbel_surv(seqsc, p.evparam[2], p.evparam[3]);
+    cand.P[c] = P;
+    if (P > p.F2) { cand.stage[c] = 2; continue; }
+    cand.stage[c] = 3;
+    todo_fwd[atomicAdd(&ctr->todo_fwd, 1)] = c; atomicAdd(&ctr->res_fwd, (unsigned long long)cand.len[c]);
+  }
+}
+
+// Forward P-value: F3, or F4 in the frameshift pipeline (p7_pipeline.c:1735-1738, 1779-1785)
+__global__ void final_kernel(Cand cand, Counters *__restrict__ ctr, Params p, const int32_t *__restrict__ todo_fwd) {
+  const int ntodo = ctr->todo_fwd;
+  for (int job = blockIdx.x * blockDim.x + threadIdx.x; job < ntodo; job += gridDim.x * blockDim.x) {
+    const int c = todo_fwd[job];
+    const float seqsc = (float)((double)(cand.fwdsc[c] - cand.filtersc[c]) / kLog2);
+    const double P = d_exp_surv(seqsc, p.evparam[4], p.evparam[5]);
+    cand.P[c] = P;
+    if (P > (p.fs_pipe ? p.F4 : p.F3)) continue;
+    cand.stage[c] = 4;
+    atomicAdd(&ctr->n_past_fwd, 1ull);
+    if (!p.fs_pipe) atomicAdd(&ctr->pos_past_fwd, (unsigned long long)cand.len[c] * 3ull);
+  }
+}
+
+// wave-per-candidate kernels take their work list length from device memory
+__global__ void copy_count_kernel(const int *src, int64_t *dst) { *dst = *src; }
+
+}  // namespace bath
+
+
+// =================================================================================================
+// host orchestration
+// =================================================================================================
+namespace bath {
+
+// host twin of ssv_classify (ssvfilter.c:876-925), used only to build the emission threshold table
+static int ssv_classify_host(int v, int tjb, const MsvConsts &c, float *sc) {
+  if (tjb + c.tbm + c.tec + c.bias >= 127) return BATH_ENORESULT;
+  unsigned xE = (v >= -1 - c.bias) ? 255u : (unsigned)(v + 256);
+  if ((int)xE >= 255 - c.bias) { *sc = INFINITY; return (c.base - tjb - c.tbm < 128) ? BATH_ENORESULT : BATH_ERANGE; }
+  xE = (xE + (unsigned)(c.base - tjb - c.tbm) - 128u) & 0xffffu;
+  if ((int)xE >= 255 - c.bias) { *sc = INFINITY; return BATH_ERANGE; }
+  unsigned xJ = (xE - (unsigned)c.tec) & 0xffffu;
+  if ((int)xJ > c.base) return BATH_ENORESULT;
+  float r = ((float)((int)xJ - tjb) - (float)c.base);
+  r /= c.scale_b;
+  r = (float)((double)r - 3.0);
+  *sc = r;
+  return BATH_OK;
+}
+
+// E[len] = smallest raw SSV maximum for which an ORF of <len> residues must be kept: either p7_SSVFilter
+// would not return eslOK (overflow / J state possible -> needs the full MSV) or its score passes F1
+// (p7_pipeline.c:1650-1652, same float/double operation order).
+static void build_emit_table(const bath_hip_oprofile *om, double F1, int maxlen, std::vector<int16_t> &tab) {
+  const MsvConsts mc = msv_consts(om);
+  tab.assign((size_t)maxlen + 1, (int16_t)32767);
+  for (int len = 0; len <= maxlen; len++) {
+    const int tjb = om->lt.h_tjb[len];
+    const float nullsc = om->lt.h_nullsc[len];
+    for (int v = -128; v <= 127; v++) {
+      float usc = 0.f;
+      const int st = ssv_classify_host(v, tjb, mc, &usc);
+      bool keep = (st != BATH_OK);
+      if (!keep) {
+        const float seqsc = (float)((double)(usc - nullsc) / kLog2);
+        keep = !(gumbel_surv(seqsc, om->evparam[0], om->evparam[1]) > F1);
+      }
+      if (keep) { tab[len] = (int16_t)v; break; }
+    }
+  }
+}
+
+static int wave_grid_blocks(bath_hip_ctx *ctx) { return ctx->prop.multiProcessorCount * 8; }
+
+struct PipelineWork {
+  // device allocations live in ctx->scratch[8..]; this struct only carves them up
+  Cand cand;
+  int cand_cap = 0;
+  unsigned long long aa_cap = 0;
+  uint8_t *pool = nullptr;
+  int32_t *todo_msv = nullptr, *todo_vit = nullptr, *todo_ssvb = nullptr, *todo_vit2 = nullptr, *todo_fwd = nullptr;
+  WindowRec *wins = nullptr;
+  int win_cap = 0;
+  Counters *ctr = nullptr;
+};
+
+template <class T>
+static T *carve(char *&p, size_t n) {
+  T *r = reinterpret_cast<T *>(p);
+  p += (n * sizeof(T) + 255) / 256 * 256;
+  return r;
+}
+
+static size_t layout(PipelineWork &w, char *base, int cap, unsigned long long aa_cap) {
+  char *p = base;
+  const size_t n = (size_t)cap;
+  w.cand_cap = cap; w.aa_cap = aa_cap; w.win_cap = 2 * cap;
+  w.ctr = carve<Counters>(p, 1);
+  w.cand.window = carve<int64_t>(p, n); w.cand.off = carve<int64_t>(p, n); w.cand.P = carve<double>(p, n);
+  w.cand.sf = carve<int32_t>(p, n); w.cand.startj = carve<int32_t>(p, n); w.cand.len = carve<int32_t>(p, n);
+  w.cand.msv_status = carve<int32_t>(p, n); w.cand.vit_status = carve<int32_t>(p, n); w.cand.fwd_status = carve<int32_t>(p, n); w.cand.stage = carve<int32_t>(p, n);
+  w.cand.flags = carve<int32_t>(p, n); w.cand.kminmax = carve<int32_t>(p, 2 * n);
+  w.cand.usc = carve<float>(p, n); w.cand.nullsc = carve<float>(p, n); w.cand.filtersc = carve<float>(p, n);
+  w.cand.vfsc = carve<float>(p, n); w.cand.fwdsc = carve<float>(p, n);
+  w.cand.v = carve<int16_t>(p, n);
+  w.todo_msv = carve<int32_t>(p, n); w.todo_vit = carve<int32_t>(p, n); w.todo_ssvb = carve<int32_t>(p, n);
+  w.todo_vit2 = carve<int32_t>(p, n); w.todo_fwd = carve<int32_t>(p, n);
+  w.wins = carve<WindowRec>(p, (size_t)w.win_cap);
+  w.pool = carve<uint8_t>(p, (size_t)aa_cap + 64);
+  return (size_t)(p - base);
+}
+
+}  // namespace bath
+
+extern "C" void bath_pipeline_params_default(bath_pipeline_params *p, int fs_pipe) {   // p7_pipeline.c:219-222, bathsearch.c:104
+  p->F1 = 0.02; p->F2 = 1e-3; p->F3 = 1e-5; p->F4 = 5e-4;
+  p->do_biasfilter = 1; p->fs_pipe = fs_pipe; p->min_orf_len = 20; p->ncbi_table = 1;
+}
+
+extern "C" int bath_hip_pipeline_timings(const bath_hip_ctx *ctx, int max, const char **names, float *ms, int64_t *launches) {
+  int n = std::min<int>(max, (int)ctx->timings.size());
+  for (int i = 0; i < n; i++) { names[i] = ctx->timings[i].name; ms[i] = ctx->timings[i].ms; launches[i] = ctx->timings[i].launches; }
+  return n;
+}
+
+extern "C" int bath_hip_pipeline_filters(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bath_hip_seqs *dna,
+                                         const bath_pipeline_params *prm, bath_pipeline_stats *stats,
+                                         const bath_orf_result **results, int64_t *n_results) {
+  if (!ctx || !om || !dna || !prm) return BATH_EINVAL;
+  BATH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (n_results) *n_results = 0;
+  if (results) *results = nullptr;
+  if (stats) std::memset(stats, 0, sizeof *stats);
+  const int64_t nwin = dna->n;
+  if (nwin == 0) return BATH_OK;
+  const int M = om->M;
+  const int max_orf = dna->maxlen / 3 + 1;
+  int st = om->ensure_len_tables(max_orf);
+  if (st != BATH_OK) return st;
+
+  // ---- per-call tables
+  uint8_t basic[64];
+  if (bath_gencode_basic(prm->ncbi_table, basic) != BATH_OK) { ctx->set_error("unknown NCBI translation table"); return BATH_EINVAL; }
+  std::vector<uint8_t> codon_tab;
+  build_codon_table(basic, codon_tab);
+  static const uint8_t comp[18] = {3, 2, 1, 0, 4, 6, 5, 8, 7, 9, 10, 14, 13, 12, 11, 15, 16, 17};
+  std::vector<int16_t> emit;
+  build_emit_table(om, prm->F1, max_orf, emit);
+  std::vector<uint8_t> ssv_scores((size_t)(M + 1) * kKp, 0);
+  bath_hip_oprofile_get_ssv_scores(om, ssv_scores.data());
+
+  DevBuf &b_tabs = ctx->scratch[8], &b_work = ctx->scratch[9], &b_scr = ctx->scratch[10];
+  const size_t tabs_bytes = 8192 + emit.size() * 2 + 256 + ssv_scores.size() + 256 + 20 * 4 + 256;
+  BATH_HIP_TRY(ctx, b_tabs.reserve(tabs_bytes));
+  char *tp = b_tabs.as<char>();
+  uint8_t *d_codon = reinterpret_cast<uint8_t *>(tp); tp += 6144;
+  uint8_t *d_comp = reinterpret_cast<uint8_t *>(tp); tp += 256;
+  int16_t *d_emit = reinterpret_cast<int16_t *>(tp); tp += (emit.size() * 2 + 255) / 256 * 256;
+  uint8_t *d_ssvsc = reinterpret_cast<uint8_t *>(tp); tp += (ssv_scores.size() + 255) / 256 * 256;
+  float *d_bgf = reinterpret_cast<float *>(tp);
+  BATH_HIP_TRY(ctx, hipMemcpyAsync(d_codon, codon_tab.data(), codon_tab.size(), hipMemcpyHostToDevice, ctx->stream));
+  BATH_HIP_TRY(ctx, hipMemcpyAsync(d_comp, comp, 18, hipMemcpyHostToDevice, ctx->stream));
+  BATH_HIP_TRY(ctx, hipMemcpyAsync(d_emit, emit.data(), emit.size() * 2, hipMemcpyHostToDevice, ctx->stream));
+  BATH_HIP_TRY(ctx, hipMemcpyAsync(d_ssvsc, ssv_scores.data(), ssv_scores.size(), hipMemcpyHostToDevice, ctx->stream));
+  BATH_HIP_TRY(ctx, hipMemcpyAsync(d_bgf, kAminoBg, 20 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  BATH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // the host vectors above go out of scope with this call only, but be explicit
+  DnaTables tabs{d_codon, d_comp};
+
+  Params P{};
+  P.F1 = prm->F1; P.F2 = prm->F2; P.F3 = prm->F3; P.F4 = prm->F4;
+  P.do_bias = prm->do_biasfilter; P.fs_pipe = prm->fs_pipe; P.minlen = prm->min_orf_len;
+  std::memcpy(P.evparam, om->evparam, sizeof P.evparam);
+  const MsvConsts mc = msv_consts(om);
+  const double invP_f1 = gumbel_invsurv(prm->F1, om->evparam[0], om->evparam[1]);   // p7_SSVFilter_BATH's threshold, msvfilter.c:302
+  VitWindowArgs wa{};
+  wa.invP_vit = (double)(float)gumbel_invsurv(prm->F2, om->evparam[2], om->evparam[3]);   // vitfilter.c:314 (float invP)
+  wa.invP_msv = (double)(float)gumbel_invsurv(prm->F2, om->evparam[0], om->evparam[1]);   // vitfilter.c:319
+
+  // ---- capacity guess: all ORFs that could exist, scaled by the expected MSV pass rate (+ slack); retried on overflow
+  int64_t nres = 0, max_orfs = 0;
+  for (int64_t i = 0; i < nwin; i++) {
+    const int n = dna->h_len[i];
+    if (n < 15) continue;
+    nres += 2 * (int64_t)n;
+    max_orfs += 6 * (int64_t)((n / 3 + 1) / (prm->min_orf_len + 1) + 1);
+  }
+  int64_t cap = std::max<int64_t>(4096, (int64_t)((double)max_orfs * std::min(1.0, prm->F1 * 4.0 + 0.01)));
+  cap = std::min<int64_t>(cap, std::max<int64_t>(max_orfs, 4096));
+  unsigned long long aa_cap = std::max<unsigned long long>(1u << 20, (unsigned long long)cap * 96ull);
+
+  const int NRk = om->NR;
+  const size_t ssv_shmem = (size_t)kSsvRows * om->ssv_row_bytes + 5832 + 64;
+  const int64_t nstreams = nwin * 6;
+  const int MP = std::max(2, ((M - 1) / 16) + 1) * 16;
+  const int dec_blocks = ctx->prop.multiProcessorCount * 4;
+
+  std::vector<hipEvent_t> &ev = ctx->ev_pool;
+  while (ev.size() < 10) { hipEvent_t e; BATH_HIP_TRY(ctx, hipEventCreate(&e)); ev.push_back(e); }
+
+  PipelineWork W;
+  Counters hc{};
+  for (int attempt = 0;; attempt++) {
+    size_t need = layout(W, nullptr, (int)cap, aa_cap);
+    BATH_HIP_TRY(ctx, b_work.reserve(need + 4096));
+    layout(W, b_work.as<char>(), (int)cap, aa_cap);
+    const size_t scr_bytes = (size_t)64 * 64 * (MP + 1);
+    BATH_HIP_TRY(ctx, b_scr.reserve(scr_bytes));
+    BATH_HIP_TRY(ctx, hipMemsetAsync(W.ctr, 0, sizeof(Counters), ctx->stream));
+    SeqView cv{W.pool, W.cand.off, W.cand.len, cap};
+
+    int e = 0;
+    BATH_HIP_TRY(ctx, hipEventRecord(ev[e++], ctx->stream));
+    // 1. translate + SSV + F1 threshold
+    {
+      const int blocks = (int)((nstreams + 255) / 256);
+#define BATH_DNA_CASE(N)                                                                                                         \
+  case N:                                                                                                                        \
+    hipLaunchKernelGGL(ssv_dna_kernel<N>, dim3(blocks), dim3(256), ssv_shmem, ctx->stream, dna->view(), tabs, om->d_ssv,          \
+                       om->ssv_row_bytes, d_emit, max_orf, prm->min_orf_len, W.cand, W.cand_cap, W.aa_cap, W.ctr);               \
+    break;
+      switch (NRk) {
+        BATH_DNA_CASE(16) BATH_DNA_CASE(32) BATH_DNA_CASE(48) BATH_DNA_CASE(64) BATH_DNA_CASE(80) BATH_DNA_CASE(96)
+        BATH_DNA_CASE(112) BATH_DNA_CASE(128) BATH_DNA_CASE(144) BATH_DNA_CASE(160) BATH_DNA_CASE(176) BATH_DNA_CASE(192) BATH_DNA_CASE(208)
+        default: ctx->set_error("SSV kernel: model length exceeds the single-tile limit (416 nodes)"); return BATH_EINVAL;
+      }
+#undef BATH_DNA_CASE
+      BATH_HIP_TRY(ctx, hipGetLastError());
+    }
+    BATH_HIP_TRY(ctx, hipEventRecord(ev[e++], ctx->stream));
+    // 2. survivors -> amino-acid pool; SSV status; full MSV for the undecided
+    hipLaunchKernelGGL(materialize_kernel, dim3(wave_grid_blocks(ctx)), dim3(256), 0, ctx->stream, dna->view(), tabs, W.cand, W.cand_cap, W.ctr, W.pool);
+    hipLaunchKernelGGL(classify_kernel, dim3(dec_blocks), dim3(256), 0, ctx->stream, W.cand, W.cand_cap, W.ctr, om->lt.d_tjb, mc, W.todo_msv);
+    BATH_HIP_TRY(ctx, hipGetLastError());
+    if ((st = launch_msv_wave(ctx, om, cv, W.todo_msv, cap, W.cand.usc, W.cand.msv_status, &W.ctr->todo_msv)) != BATH_OK) return st;
+    BATH_HIP_TRY(ctx, hipEventRecord(ev[e++], ctx->stream));
+    // 3. F1 on the MSV score, bias filter
+    hipLaunchKernelGGL(f1_bias_kernel, dim3(dec_blocks), dim3(256), 0, ctx->stream, W.cand, W.cand_cap, W.ctr, P, W.pool, M, om->d_bias_eo,
+                       om->lt.d_nullsc, om->lt.d_p1, om->lt.d_lt1, om->lt.d_lt2, W.todo_vit, W.todo_ssvb);
+    BATH_HIP_TRY(ctx, hipGetLastError());
+    BATH_HIP_TRY(ctx, hipEventRecord(ev[e++], ctx->stream));
+    // 4. Viterbi filter with windows (P > F2) / SSV windows (P <= F2)
+    wa.d_filtersc = W.cand.filtersc; wa.d_ssv_scores = d_ssvsc; wa.d_wins = W.wins; wa.d_win_count = &W.ctr->win_count; wa.win_cap = W.win_cap;
+    wa.d_kminmax = W.cand.kminmax;
+    if ((st = launch_vit_wave(ctx, om, cv, W.todo_vit, cap, W.cand.vfsc, W.cand.vit_status, &wa, &W.ctr->todo_vit)) != BATH_OK) return st;
+    hipLaunchKernelGGL(ssv_bath_kernel, dim3(64), dim3(64), 0, ctx->stream, W.cand, W.ctr, W.todo_ssvb, W.pool, M, om->d_rb, om->rb_stride, d_ssvsc,
+                       om->lt.d_tjb, om->lt.d_nullsc, mc, invP_f1, b_scr.as<uint8_t>(), MP, W.wins, W.win_cap, W.ctr);
+    BATH_HIP_TRY(ctx, hipGetLastError());
+    BATH_HIP_TRY(ctx, hipEventRecord(ev[e++], ctx->stream));
+    // 5. F2, local composition re-filter, optional plain Viterbi re-run
+    hipLaunchKernelGGL(post_vit_kernel, dim3(dec_blocks), dim3(256), 0, ctx->stream, W.cand, W.cand_cap, W.ctr, P, W.pool, M, d_ssvsc, (int)om->base_b,
+                       om->scale_b, d_bgf, om->lt.d_p1, om->lt.d_lt1, om->lt.d_lt2, W.todo_vit2, W.todo_fwd);
+    BATH_HIP_TRY(ctx, hipGetLastError());
+    if ((st = launch_vit_wave(ctx, om, cv, W.todo_vit2, cap, W.cand.vfsc, W.cand.vit_status, nullptr, &W.ctr->todo_vit2)) != BATH_OK) return st;
+    hipLaunchKernelGGL(post_vit2_kernel, dim3(64), dim3(256), 0, ctx->stream, W.cand, W.ctr, P, W.todo_vit2, W.todo_fwd);
+    BATH_HIP_TRY(ctx, hipGetLastError());
+    BATH_HIP_TRY(ctx, hipEventRecord(ev[e++], ctx->stream));
+    // 6. Forward parser, F3/F4
+    if ((st = launch_fwd_wave(ctx, om, cv, W.todo_fwd, cap, W.cand.fwdsc, W.cand.fwd_status, &W.ctr->todo_fwd)) != BATH_OK) return st;
+    hipLaunchKernelGGL(final_kernel, dim3(dec_blocks), dim3(256), 0, ctx->stream, W.cand, W.ctr, P, W.todo_fwd);
+    BATH_HIP_TRY(ctx, hipGetLastError());
+    BATH_HIP_TRY(ctx, hipEventRecord(ev[e++], ctx->stream));
+
+    BATH_HIP_TRY(ctx, hipMemcpyAsync(&hc, W.ctr, sizeof(Counters), hipMemcpyDeviceToHost, ctx->stream));
+    BATH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (hc.overflow || hc.cand_count > cap || hc.aa_bump > aa_cap) {
+      if (attempt >= 4) { ctx->set_error("candidate buffers overflowed repeatedly"); return BATH_EMEM; }
+      cap = std::max<int64_t>(cap * 2, (int64_t)hc.cand_count + 1024);
+      aa_cap = std::max<unsigned long long>(aa_cap * 2, hc.aa_bump + (1u << 20));
+      continue;
+    }
+    static const char *names[] = {"ssv_translate_f1", "materialize_classify_msv", "f1_bias", "viterbi_windows", "post_vit", "forward_final"};
+    static const int64_t launches[] = {1, 3, 1, 2, 3, 2};
+    ctx->timings.clear();
+    for (int i = 0; i + 1 < e; i++) {
+      float ms = 0.f;
+      BATH_HIP_TRY(ctx, hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+      ctx->timings.push_back(StageTiming{names[i], ms, launches[i]});
+    }
+    break;
+  }
+
+  if (stats) {
+    stats->nres = nres; stats->n_orfs = (int64_t)hc.n_orfs;
+    stats->n_past_msv = (int64_t)hc.n_past_msv; stats->n_past_bias = (int64_t)hc.n_past_bias;
+    stats->n_past_vit = (int64_t)hc.n_past_vit; stats->n_past_fwd = (int64_t)hc.n_past_fwd;
+    stats->pos_past_msv = (int64_t)hc.pos_past_msv; stats->pos_past_bias = (int64_t)hc.pos_past_bias;
+    stats->pos_past_vit = (int64_t)hc.pos_past_vit; stats->pos_past_fwd = (int64_t)hc.pos_past_fwd;
+    stats->cells_msv = (int64_t)hc.orf_res * M; stats->cells_vit = (int64_t)hc.res_vit * M; stats->cells_fwd = (int64_t)hc.res_fwd * M;
+  }
+
+  if (results) {
+    const int nc = hc.cand_count;
+    std::vector<int64_t> h_window(nc); std::vector<int32_t> h_sf(nc), h_startj(nc), h_len(nc), h_ms(nc), h_vs(nc), h_stage(nc);
+    std::vector<float> h_usc(nc), h_null(nc), h_fsc(nc), h_vf(nc), h_fw(nc); std::vector<double> h_P(nc);
+    auto pull = [&](void *dst, const void *src, size_t bytes) { return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream); };
+    if (nc > 0) {
+      BATH_HIP_TRY(ctx, pull(h_window.data(), W.cand.window, nc * 8)); BATH_HIP_TRY(ctx, pull(h_sf.data(), W.cand.sf, nc * 4));
+      BATH_HIP_TRY(ctx, pull(h_startj.data(), W.cand.startj, nc * 4)); BATH_HIP_TRY(ctx, pull(h_len.data(), W.cand.len, nc * 4));
+      BATH_HIP_TRY(ctx, pull(h_ms.data(), W.cand.msv_status, nc * 4)); BATH_HIP_TRY(ctx, pull(h_vs.data(), W.cand.vit_status, nc * 4));
+      BATH_HIP_TRY(ctx, pull(h_stage.data(), W.cand.stage, nc * 4)); BATH_HIP_TRY(ctx, pull(h_usc.data(), W.cand.usc, nc * 4));
+      BATH_HIP_TRY(ctx, pull(h_null.data(), W.cand.nullsc, nc * 4)); BATH_HIP_TRY(ctx, pull(h_fsc.data(), W.cand.filtersc, nc * 4));
+      BATH_HIP_TRY(ctx, pull(h_vf.data(), W.cand.vfsc, nc * 4)); BATH_HIP_TRY(ctx, pull(h_fw.data(), W.cand.fwdsc, nc * 4));
+      BATH_HIP_TRY(ctx, pull(h_P.data(), W.cand.P, nc * 8));
+      BATH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    ctx->results.clear();
+    for (int c = 0; c < nc; c++) {
+      if (h_stage[c] < 1) continue;
+      bath_orf_result r{};
+      r.window = h_window[c]; r.strand = h_sf[c] / 3; r.frame = h_sf[c] % 3;
+      r.start = r.frame + 3 * h_startj[c] + 1; r.end = r.start + 3 * h_len[c] - 1; r.n = h_len[c];
+      r.stage = (h_stage[c] == 5) ? 2 : h_stage[c];
+      r.msv_status = h_ms[c]; r.vit_status = h_vs[c];
+      r.usc = h_usc[c]; r.nullsc = h_null[c]; r.filtersc = h_fsc[c]; r.vfsc = h_vf[c]; r.fwdsc = h_fw[c]; r.P = h_P[c];
+      ctx->results.push_back(r);
+    }
+    std::sort(ctx->results.begin(), ctx->results.end(), [](const bath_orf_result &a, const bath_orf_result &b) {
+      if (a.window != b.window) return a.window < b.window;
+      if (a.strand != b.strand) return a.strand < b.strand;
+      if (a.frame != b.frame) return a.frame < b.frame;
+      return a.start < b.start;
+    });
+    *results = ctx->results.data();
+    if (n_results) *n_results = (int64_t)ctx->results.size();
+  } else if (n_results) *n_results = (int64_t)hc.n_past_msv;
+  return BATH_OK;
+}

@@ -1,0 +1,329 @@
+// bath_profile.hip -- device context, optimized-profile construction and sequence blocks.
+//
+//   bath_hip_oprofile_convert  <- p7_oprofile_Convert()      src/impl_sse/p7_oprofile.c:1091
+//                                 (mf_conversion :773, vf_conversion :826, fb_conversion :929, sf_conversion :721)
+//   length tables              <- p7_oprofile_ReconfigLength src/impl_sse/p7_oprofile.c:1261-1326,
+//                                 p7_bg_SetLength/NullOne    src/p7_bg.c:189,356
+// The striped SIMD layout of the reference is an implementation detail of impl_sse; here every
+// table is indexed by model node and laid out for the kernels in bath_filters.hip.
+#include <cmath>
+#include <cstring>
+
+#include "bath_common.hpp"
+#include "host_model.hpp"
+
+using namespace bath;
+
+namespace bath {
+
+static const double kLog2 = 0.69314718055994529;
+
+// Tail probabilities (easel esl_gumbel.c / esl_exponential.c closed forms; call sites p7_pipeline.c:1651,1737).
+double gumbel_surv(double x, double mu, double lambda) {
+  double ey = -std::exp(-lambda * (x - mu));
+  if (std::fabs(ey) < 5e-9) return -ey;
+  return 1.0 - std::exp(ey);
+}
+double gumbel_invsurv(double p, double mu, double lambda) {
+  double lp = (p < 5e-9) ? (std::pow(p, p) - 1) / p : std::log(-1. * std::log(1 - p));
+  return mu - lp / lambda;
+}
+double exp_surv(double x, double mu, double lambda) { return (x < mu) ? 1.0 : std::exp(-lambda * (x - mu)); }
+
+// Limited-precision converters (p7_oprofile.c:667-705).
+static inline uint8_t cost_u8(float scale, float sc) {
+  float c = -1.0f * roundf(scale * sc);
+  return (c > 255.) ? 255 : (uint8_t)(int)c;
+}
+static inline uint8_t cost_u8_biased(float scale, uint8_t bias, float sc) {
+  float c = -1.0f * roundf(scale * sc);
+  return (c > 255 - bias) ? 255 : (uint8_t)((int)c + bias);
+}
+static inline int16_t score_i16(float scale, float sc) {
+  float v = roundf(scale * sc);
+  if (v >= 32767.0) return 32767;
+  if (v <= -32768.0) return -32768;
+  return (int16_t)v;
+}
+
+// Emission odds of the two-state bias-filter HMM (p7_bg_SetFilter p7_bg.c:449 + esl_hmm_Configure).
+void bias_filter_eo(const float *compo, float eo[kKp][2]) {
+  for (int x = 0; x < 20; x++) { eo[x][0] = kAminoBg[x] / kAminoBg[x]; eo[x][1] = compo[x] / kAminoBg[x]; }
+  for (int x : {20, 27, 28}) eo[x][0] = eo[x][1] = 1.0f;
+  for (int x = 21; x <= 26; x++)
+    for (int s = 0; s < 2; s++) {
+      float num = 0.f, den = 0.f;
+      for (int y = 0; y < 20; y++)
+        if (amino_degen_has(x, y)) { num += (s == 0 ? kAminoBg[y] : compo[y]); den += kAminoBg[y]; }
+      eo[x][s] = den > 0.f ? num / den : 0.f;
+    }
+}
+
+template <class T>
+static hipError_t upload(T **dst, const T *src, size_t n, hipStream_t st) {
+  hipError_t e = hipMalloc((void **)dst, n * sizeof(T) + 64);
+  if (e != hipSuccess) return e;
+  return hipMemcpyAsync(*dst, src, n * sizeof(T), hipMemcpyHostToDevice, st);
+}
+
+int build_len_tables(const bath_hip_oprofile *om, int maxL) {
+  LenTables &lt = om->lt;
+  if (maxL <= lt.maxL) return BATH_OK;
+  bath_hip_ctx *ctx = om->ctx;
+  int n = std::max(maxL, 4096) + 1;
+  for (void *p : {(void *)lt.d_tjb, (void *)lt.d_xwmove, (void *)lt.d_pmove, (void *)lt.d_nullsc, (void *)lt.d_lt1, (void *)lt.d_lt2, (void *)lt.d_p1})
+    if (p) (void)hipFree(p);
+  lt.h_tjb.resize(n); lt.h_xwmove.resize(n); lt.h_pmove.resize(n); lt.h_nullsc.resize(n);
+  std::vector<float> lt1(n), lt2(n), p1v(n);
+  for (int L = 0; L < n; L++) {
+    lt.h_tjb[L] = cost_u8(om->scale_b, logf(3.0f / (float)(L + 3)));                 // p7_oprofile.c:1288
+    float pmove = (2.0f + om->nj) / ((float)L + 2.0f + om->nj);                      // p7_oprofile.c:1311
+    lt.h_pmove[L] = pmove;
+    lt.h_xwmove[L] = score_i16(om->scale_w, logf(pmove));                            // p7_oprofile.c:1319
+    float p1 = (float)L / (float)(L + 1);                                            // p7_bg.c:191
+    p1v[L] = p1;
+    lt.h_nullsc[L] = (float)((float)L * std::log((double)p1) + std::log(1. - p1));           // p7_bg.c:358
+    lt1[L] = (float)L * logf(p1);                                                    // p7_bg.c:501
+    lt2[L] = logf((float)(1. - p1));
+  }
+  BATH_HIP_TRY(ctx, upload(&lt.d_tjb, lt.h_tjb.data(), n, ctx->stream));
+  BATH_HIP_TRY(ctx, upload(&lt.d_xwmove, lt.h_xwmove.data(), n, ctx->stream));
+  BATH_HIP_TRY(ctx, upload(&lt.d_pmove, lt.h_pmove.data(), n, ctx->stream));
+  BATH_HIP_TRY(ctx, upload(&lt.d_nullsc, lt.h_nullsc.data(), n, ctx->stream));
+  BATH_HIP_TRY(ctx, upload(&lt.d_lt1, lt1.data(), n, ctx->stream));
+  BATH_HIP_TRY(ctx, upload(&lt.d_lt2, lt2.data(), n, ctx->stream));
+  BATH_HIP_TRY(ctx, upload(&lt.d_p1, p1v.data(), n, ctx->stream));
+  BATH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  lt.maxL = n - 1;
+  return BATH_OK;
+}
+
+}  // namespace bath
+
+int bath_hip_oprofile::ensure_len_tables(int maxL) const { return bath::build_len_tables(this, maxL); }
+
+// ------------------------------------------------------------------------------------------ context
+
+extern "C" int bath_hip_init(int device, bath_hip_ctx **out) {
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return BATH_ENODEVICE;
+  if (device < 0 || device >= ndev) return BATH_EINVAL;
+  bath_hip_ctx *ctx = new bath_hip_ctx();
+  ctx->device = device;
+  if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&ctx->prop, device) != hipSuccess ||
+      hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete ctx;
+    return BATH_ENODEVICE;
+  }
+  *out = ctx;
+  return BATH_OK;
+}
+
+extern "C" void bath_hip_finalize(bath_hip_ctx *ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  for (auto &b : ctx->scratch) b.release();
+  for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
+  (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+extern "C" const char *bath_hip_last_error(const bath_hip_ctx *ctx) { return ctx ? ctx->err.c_str() : "no context"; }
+
+extern "C" int bath_hip_synchronize(bath_hip_ctx *ctx) {
+  BATH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return BATH_OK;
+}
+
+extern "C" void *bath_hip_stream(bath_hip_ctx *ctx) { return (void *)ctx->stream; }
+
+// ------------------------------------------------------------------------------------------ oprofile
+
+extern "C" void bath_hip_oprofile_destroy(bath_hip_oprofile *om) {
+  if (!om) return;
+  for (void *p : {(void *)om->d_ssv, (void *)om->d_rb, (void *)om->d_rw, (void *)om->d_tw, (void *)om->d_rf, (void *)om->d_tf,
+                  (void *)om->d_bias_eo, (void *)om->lt.d_tjb, (void *)om->lt.d_xwmove, (void *)om->lt.d_pmove,
+                  (void *)om->lt.d_nullsc, (void *)om->lt.d_lt1, (void *)om->lt.d_lt2, (void *)om->lt.d_p1})
+    if (p) (void)hipFree(p);
+  delete om;
+}
+
+extern "C" int bath_hip_oprofile_M(const bath_hip_oprofile *om) { return om->M; }
+
+extern "C" int bath_hip_oprofile_convert(bath_hip_ctx *ctx, const bath_profile *gm, bath_hip_oprofile **ret) {
+  *ret = nullptr;
+  const int M = gm->M;
+  if (M < 1) { ctx->set_error("profile has no nodes"); return BATH_EINVAL; }
+  const size_t W = (size_t)M + 1;
+  auto msc = [&](int k, int x) { return gm->rsc[(size_t)x * W * 2 + 2 * k]; };
+  auto tsc = [&](int k, int s) { return gm->tsc[(size_t)k * 8 + s]; };   // valid for 0 <= k < M
+  enum { MM, IM, DM, BM, MD, DD, MI, II };
+
+  bath_hip_oprofile *om = new bath_hip_oprofile();
+  om->ctx = ctx; om->M = M; om->max_length = gm->max_length; om->nj = gm->nj; om->L0 = gm->L;
+  std::memcpy(om->evparam, gm->evparam, sizeof om->evparam);
+  std::memcpy(om->compo, gm->compo, sizeof om->compo);
+
+  // ---- MSV bytes (mf_conversion): third-bit units, base 190, bias = -max score
+  float maxsc = 0.0f;
+  for (int x = 0; x < 20; x++)
+    for (size_t i = 0; i < W * 2; i++) maxsc = std::max(maxsc, gm->rsc[(size_t)x * W * 2 + i]);
+  om->scale_b = (float)(3.0 / kLog2);
+  om->base_b = 190;
+  om->bias_b = cost_u8(om->scale_b, (float)(-1.0 * maxsc));
+  om->rb.assign((size_t)kKp * W, 255);
+  for (int x = 0; x < kKp; x++)
+    for (int k = 1; k <= M; k++) om->rb[x * W + k] = cost_u8_biased(om->scale_b, om->bias_b, msc(k, x));
+  om->tbm_b = cost_u8(om->scale_b, logf(2.0f / ((float)M * (float)(M + 1))));
+  om->tec_b = cost_u8(om->scale_b, logf(0.5f));
+
+  // ---- Viterbi words (vf_conversion): 1/500 bit units; into-node transitions come from gm node k-1,
+  //      out-of-node ones from gm node k (absent, i.e. -32768, at k == M); no transition above 0, II <= -1.
+  om->scale_w = (float)(500.0 / kLog2);
+  om->base_w = 12000;
+  om->rw.assign((size_t)kKp * W, -32768);
+  for (int x = 0; x < kKp; x++)
+    for (int k = 1; k <= M; k++) om->rw[x * W + k] = score_i16(om->scale_w, msc(k, x));
+  om->tw.assign(W * 8, -32768);
+  for (int k = 1; k <= M; k++) {
+    int16_t *t = &om->tw[(size_t)k * 8];
+    for (int s : {BM, MM, IM, DM}) t[s] = std::min<int16_t>(score_i16(om->scale_w, tsc(k - 1, s)), 0);
+    for (int s : {MD, MI}) t[s] = (k < M) ? std::min<int16_t>(score_i16(om->scale_w, tsc(k, s)), 0) : (int16_t)-32768;
+    t[II] = (k < M) ? std::min<int16_t>(score_i16(om->scale_w, tsc(k, II)), -1) : (int16_t)-32768;
+    t[DD] = (k < M) ? score_i16(om->scale_w, tsc(k, DD)) : (int16_t)-32768;
+  }
+  om->xw_E[0] = score_i16(om->scale_w, gm->xsc[0][0]);
+  om->xw_E[1] = score_i16(om->scale_w, gm->xsc[0][1]);
+  int ddb = -32768;
+  for (int k = 2; k < M - 1; k++)
+    ddb = std::max(ddb, (int)score_i16(om->scale_w, tsc(k, DD)) + (int)score_i16(om->scale_w, tsc(k + 1, DM)) -
+                            (int)score_i16(om->scale_w, tsc(k + 1, BM)));
+  om->ddbound_w = (int16_t)ddb;
+
+  // ---- Forward odds ratios (fb_conversion)
+  om->rf.assign((size_t)kKp * W, 0.f);
+  for (int x = 0; x < kKp; x++)
+    for (int k = 1; k <= M; k++) om->rf[x * W + k] = expf(msc(k, x));
+  om->tf.assign(W * 8, 0.f);
+  for (int k = 1; k <= M; k++) {
+    float *t = &om->tf[(size_t)k * 8];
+    for (int s : {BM, MM, IM, DM}) t[s] = expf(tsc(k - 1, s));
+    for (int s : {MD, MI, II, DD}) t[s] = (k < M) ? expf(tsc(k, s)) : 0.f;
+  }
+  om->xf_E[0] = expf(gm->xsc[0][0]);
+  om->xf_E[1] = expf(gm->xsc[0][1]);
+
+  // ---- device layouts
+  // SSV: signed costs sb = min(rb - bias, 127) (sf_conversion) as int16, one row per residue plus a
+  // "reset" row; columns 1..M real, padded with +127 up to 2*NR.  Row pitch chosen with (pitch/8) odd so
+  // that lanes holding different residues hit different LDS bank groups on 8-byte reads.
+  int NR = ((M + 1) / 2 + 15) / 16 * 16;
+  om->NR = NR;
+  om->ssv_row_bytes = 4 * NR + 8;
+  {
+    size_t rowsz = (size_t)om->ssv_row_bytes / 2;
+    std::vector<int16_t> tab((size_t)kSsvRows * rowsz, 127);
+    for (int x = 0; x < kKp; x++)
+      for (int k = 1; k <= M; k++) tab[x * rowsz + (k - 1)] = (int16_t)std::min((int)om->rb[x * W + k] - (int)om->bias_b, 127);
+    BATH_HIP_TRY(ctx, upload(&om->d_ssv, tab.data(), tab.size(), ctx->stream));
+  }
+  om->rb_stride = (int)W;
+  BATH_HIP_TRY(ctx, upload(&om->d_rb, om->rb.data(), om->rb.size(), ctx->stream));
+  BATH_HIP_TRY(ctx, upload(&om->d_rw, om->rw.data(), om->rw.size(), ctx->stream));
+  BATH_HIP_TRY(ctx, upload(&om->d_tw, om->tw.data(), om->tw.size(), ctx->stream));
+  BATH_HIP_TRY(ctx, upload(&om->d_rf, om->rf.data(), om->rf.size(), ctx->stream));
+  BATH_HIP_TRY(ctx, upload(&om->d_tf, om->tf.data(), om->tf.size(), ctx->stream));
+  {
+    float eo[kKp][2];
+    bias_filter_eo(om->compo, eo);
+    BATH_HIP_TRY(ctx, upload(&om->d_bias_eo, &eo[0][0], (size_t)kKp * 2, ctx->stream));
+  }
+  BATH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  int st = om->ensure_len_tables(4096);
+  if (st != BATH_OK) { bath_hip_oprofile_destroy(om); return st; }
+  *ret = om;
+  return BATH_OK;
+}
+
+extern "C" int bath_hip_oprofile_scalars(const bath_hip_oprofile *om, int L, bath_oprofile_scalars *o) {
+  int st = om->ensure_len_tables(L);
+  if (st != BATH_OK) return st;
+  o->tbm_b = om->tbm_b; o->tec_b = om->tec_b; o->tjb_b = om->lt.h_tjb[L]; o->base_b = om->base_b; o->bias_b = om->bias_b;
+  o->scale_b = om->scale_b;
+  o->xw[0][0] = om->xw_E[0]; o->xw[0][1] = om->xw_E[1];
+  for (int s = 1; s < 4; s++) { o->xw[s][0] = 0; o->xw[s][1] = om->lt.h_xwmove[L]; }
+  o->scale_w = om->scale_w; o->base_w = om->base_w; o->ddbound_w = om->ddbound_w;
+  o->xf[0][0] = om->xf_E[0]; o->xf[0][1] = om->xf_E[1];
+  for (int s = 1; s < 4; s++) { o->xf[s][1] = om->lt.h_pmove[L]; o->xf[s][0] = 1.0f - om->lt.h_pmove[L]; }
+  return BATH_OK;
+}
+
+extern "C" int bath_hip_oprofile_get_ssv_scores(const bath_hip_oprofile *om, uint8_t *arr) {
+  const size_t W = (size_t)om->M + 1;
+  std::memset(arr, 0, W * kKp);
+  for (int k = 1; k <= om->M; k++)
+    for (int x = 0; x < kKp; x++) arr[(size_t)k * kKp + x] = om->rb[x * W + k];
+  return BATH_OK;
+}
+extern "C" int bath_hip_oprofile_get_vit(const bath_hip_oprofile *om, int16_t *rw, int16_t *tw) {
+  std::memcpy(rw, om->rw.data(), om->rw.size() * sizeof(int16_t));
+  std::memcpy(tw, om->tw.data(), om->tw.size() * sizeof(int16_t));
+  return BATH_OK;
+}
+extern "C" int bath_hip_oprofile_get_fwd(const bath_hip_oprofile *om, float *rf, float *tf) {
+  std::memcpy(rf, om->rf.data(), om->rf.size() * sizeof(float));
+  std::memcpy(tf, om->tf.data(), om->tf.size() * sizeof(float));
+  return BATH_OK;
+}
+
+// ------------------------------------------------------------------------------------------ sequence blocks
+
+extern "C" void bath_hip_seqs_destroy(bath_hip_seqs *sq) {
+  if (!sq) return;
+  for (void *p : {(void *)sq->d_data, (void *)sq->d_off, (void *)sq->d_len})
+    if (p) (void)hipFree(p);
+  delete sq;
+}
+
+extern "C" int64_t bath_hip_seqs_count(const bath_hip_seqs *sq) { return sq->n; }
+
+extern "C" int bath_hip_seqs_create(bath_hip_ctx *ctx, const uint8_t *dsq, const int64_t *offsets, int64_t n, bath_hip_seqs **ret) {
+  *ret = nullptr;
+  if (n < 0) return BATH_EINVAL;
+  bath_hip_seqs *sq = new bath_hip_seqs();
+  sq->ctx = ctx; sq->n = n;
+  sq->h_off.resize(n); sq->h_len.resize(n);
+  // each sequence starts on a 16-byte boundary and is followed by >= 16 readable bytes
+  int64_t pos = 0;
+  bool contiguous_ok = true;
+  for (int64_t i = 0; i < n; i++) {
+    int64_t L = offsets[i + 1] - offsets[i];
+    if (L < 0 || L > INT32_MAX) { delete sq; ctx->set_error("bad sequence offsets"); return BATH_EINVAL; }
+    sq->h_off[i] = pos; sq->h_len[i] = (int32_t)L;
+    if (pos != offsets[i] - offsets[0]) contiguous_ok = false;
+    sq->maxlen = std::max(sq->maxlen, (int32_t)L);
+    sq->total += L;
+    pos += (L + 15) / 16 * 16;
+  }
+  size_t bytes = (size_t)pos + 64;
+  BATH_HIP_TRY(ctx, hipMalloc((void **)&sq->d_data, bytes));
+  BATH_HIP_TRY(ctx, hipMalloc((void **)&sq->d_off, (size_t)std::max<int64_t>(n, 1) * sizeof(int64_t)));
+  BATH_HIP_TRY(ctx, hipMalloc((void **)&sq->d_len, (size_t)std::max<int64_t>(n, 1) * sizeof(int32_t)));
+  BATH_HIP_TRY(ctx, hipMemsetAsync(sq->d_data, 0x1d, bytes, ctx->stream));
+  if (n > 0) {
+    if (contiguous_ok) {
+      BATH_HIP_TRY(ctx, hipMemcpyAsync(sq->d_data, dsq + offsets[0], (size_t)(offsets[n] - offsets[0]), hipMemcpyHostToDevice, ctx->stream));
+    } else {
+      std::vector<uint8_t> staged((size_t)pos, 0x1d);
+      for (int64_t i = 0; i < n; i++) std::memcpy(staged.data() + sq->h_off[i], dsq + offsets[i], (size_t)sq->h_len[i]);
+      BATH_HIP_TRY(ctx, hipMemcpy(sq->d_data, staged.data(), staged.size(), hipMemcpyHostToDevice));
+    }
+    BATH_HIP_TRY(ctx, hipMemcpyAsync(sq->d_off, sq->h_off.data(), (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+    BATH_HIP_TRY(ctx, hipMemcpyAsync(sq->d_len, sq->h_len.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+  }
+  BATH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  *ret = sq;
+  return BATH_OK;
+}

@@ -1,0 +1,217 @@
+/* bath_hip.h -- C ABI of the MI355X (gfx950) backend for BATH's bathsearch DP hot path.
+ *
+ * This is the drop-in boundary: the reference selects its DP backend at build time through the
+ * impl_* directory contract (src/hmmer.h:1044-1052, src/Makefile.in:39) and every kernel there has
+ * the shape  int f(const ESL_DSQ *dsq, int L, const PROFILE *om, MATRIX *ox, float *opt_sc)
+ * (src/impl_sse/impl_sse.h:408-553).  A GPU cannot be fed one target per call, so each entry
+ * point below is the BATCHED form of the reference function named in its comment: same inputs
+ * (digital sequences, 1..L, easel codes), same outputs (nat scores, easel status codes
+ * eslOK=0 / eslERANGE=16 / eslENORESULT=19), one array element per target.  INTEGRATION.md shows the
+ * impl_hip/ shims that bind these to the reference's single-target prototypes.
+ *
+ * Plain C types only.  All pointers are HOST pointers unless the name ends in _dev.
+ * Every function returns 0 (BATH_OK) or an easel-compatible error code; bath_hip_last_error()
+ * returns a message.  There is no CPU fallback: if no gfx950 device is usable, bath_hip_init fails.
+ */
+#ifndef BATH_HIP_H
+#define BATH_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BATH_OK          0
+#define BATH_EFAIL       1
+#define BATH_EMEM        5
+#define BATH_EFORMAT     7
+#define BATH_EINVAL     11
+#define BATH_ERANGE     16   /* eslERANGE: filter score overflow (score = +inf) / Forward range error */
+#define BATH_ENORESULT  19   /* eslENORESULT: SSV cannot decide, full MSV needed                      */
+#define BATH_ENODEVICE  40
+
+#define BATH_KP_AMINO   29   /* easel amino alphabet "ACDEFGHIKLMNPQRSTVWY-BJZOUX*~" */
+#define BATH_K_AMINO    20
+#define BATH_KP_DNA     18   /* easel DNA alphabet   "ACGT-RYMKSWHBVDN*~"            */
+#define BATH_NEVPARAM    8   /* MMU MLAMBDA VMU VLAMBDA FTAU FLAMBDA FTAUFS3 FTAUFS5 (hmmer.h:67) */
+
+typedef struct bath_hip_ctx      bath_hip_ctx;      /* one GPU + one HIP stream (a reference "worker", bathsearch.c:34-52) */
+typedef struct bath_hip_oprofile bath_hip_oprofile; /* device-resident P7_OPROFILE  (impl_sse.h:75)   */
+typedef struct bath_hip_fsprofile bath_hip_fsprofile; /* device-resident P7_FS_OPROFILE (impl_sse.h:200) */
+typedef struct bath_hip_seqs     bath_hip_seqs;     /* device-resident block of digital sequences (ESL_SQ_BLOCK) */
+
+/* ------------------------------------------------------------------------------------------
+ * Host-side model objects (generic layer the impl boundary consumes).
+ * ------------------------------------------------------------------------------------------ */
+
+/* P7_HMM as read from a BATH3/f file (p7_hmmfile.c:1342 read_asc30hmm). */
+typedef struct {
+  int32_t M, max_length, ct;
+  float   fsprob;
+  float  *t;        /* [(M+1)*7]  MM MI MD IM II DM DD   */
+  float  *mat;      /* [(M+1)*20]                         */
+  float  *ins;      /* [(M+1)*20]                         */
+  float   compo[BATH_K_AMINO];
+  float   evparam[BATH_NEVPARAM];
+  char    name[128];
+} bath_hmm;
+
+/* P7_PROFILE (hmmer.h:338): what p7_oprofile_Convert() reads. */
+typedef struct {
+  int32_t M, L, max_length;
+  float   nj;
+  float  *tsc;      /* [M*8]  order MM IM DM BM MD DD MI II (hmmer.h:221), BM stored off by one */
+  float  *rsc;      /* [Kp][(M+1)*2]  match at [x][2k], insert at [x][2k+1]                     */
+  float   xsc[4][2];/* [E N J C][LOOP MOVE]                                                     */
+  float   evparam[BATH_NEVPARAM];
+  float   compo[BATH_K_AMINO];
+} bath_profile;
+
+/* P7_FS_PROFILE (hmmer.h:371): what p7_fs_oprofile_Convert() reads. */
+typedef struct {
+  int32_t M, L, max_length, codon_lengths, maxcodons;
+  float   nj, fsprob;
+  float  *tsc;      /* [M*8]                                   */
+  float  *rsc;      /* [(maxcodons+Kp)][M+1]  rsc[codon][k]    */
+  uint8_t *codons;  /* [(M+1)][maxcodons] argmax amino acid    */
+  uint8_t *indel_pos;
+  float   xsc[4][2];
+  float   evparam[BATH_NEVPARAM];
+  float   compo[BATH_K_AMINO];
+} bath_fs_profile;
+
+int  bath_hmmfile_count(const char *path);
+int  bath_hmmfile_read(const char *path, int index, bath_hmm **ret);            /* p7_hmmfile.c:1342 */
+void bath_hmm_destroy(bath_hmm *hmm);
+int  bath_gencode_basic(int ncbi_table, uint8_t basic[64]);                     /* gcode->basic[16a+4b+c] */
+int  bath_profile_config(const bath_hmm *hmm, int L, bath_profile **ret);       /* p7_ProfileConfig, modelconfig.c:48 (p7_LOCAL, Swiss-Prot bg) */
+void bath_profile_destroy(bath_profile *gm);
+int  bath_fs_profile_config(const bath_hmm *hmm, const uint8_t basic[64], int codon_lengths, int L_amino,
+                            bath_fs_profile **ret);                             /* p7_ProfileConfig_fs, modelconfig.c:220 */
+void bath_fs_profile_destroy(bath_fs_profile *gm);
+
+/* ------------------------------------------------------------------------------------------
+ * Device context.
+ * ------------------------------------------------------------------------------------------ */
+int         bath_hip_init(int device, bath_hip_ctx **ctx);          /* impl_Init(), impl_sse.h:559 */
+void        bath_hip_finalize(bath_hip_ctx *ctx);
+const char *bath_hip_last_error(const bath_hip_ctx *ctx);
+int         bath_hip_synchronize(bath_hip_ctx *ctx);
+void       *bath_hip_stream(bath_hip_ctx *ctx);                      /* hipStream_t, for event timing */
+
+/* ------------------------------------------------------------------------------------------
+ * Optimized profile (P7_OPROFILE surface).
+ * ------------------------------------------------------------------------------------------ */
+int  bath_hip_oprofile_convert(bath_hip_ctx *ctx, const bath_profile *gm, bath_hip_oprofile **ret); /* p7_oprofile_Convert, p7_oprofile.c:1091 */
+void bath_hip_oprofile_destroy(bath_hip_oprofile *om);
+int  bath_hip_oprofile_M(const bath_hip_oprofile *om);
+
+/* Scalars of the limited-precision score systems (impl_sse.h:79-96), for L as configured by
+ * p7_oprofile_ReconfigLength(om, L) (p7_oprofile.c:1261). */
+typedef struct {
+  uint8_t tbm_b, tec_b, tjb_b, base_b, bias_b;
+  float   scale_b;
+  int16_t xw[4][2];
+  float   scale_w;
+  int16_t base_w, ddbound_w;
+  float   xf[4][2];
+} bath_oprofile_scalars;
+int  bath_hip_oprofile_scalars(const bath_hip_oprofile *om, int L, bath_oprofile_scalars *out);
+/* p7_oprofile_GetSSVEmissionScoreArray (p7_oprofile.c:1507): arr[(M+1)*Kp], arr[k*Kp+x] */
+int  bath_hip_oprofile_get_ssv_scores(const bath_hip_oprofile *om, uint8_t *arr);
+/* unstriped views for parity tests: rw[Kp*(M+1)], tw[(M+1)*8] (MM IM DM BM MD DD MI II), rf, tf likewise */
+int  bath_hip_oprofile_get_vit(const bath_hip_oprofile *om, int16_t *rw, int16_t *tw);
+int  bath_hip_oprofile_get_fwd(const bath_hip_oprofile *om, float *rf, float *tf);
+
+/* ------------------------------------------------------------------------------------------
+ * Sequence blocks.  dsq holds n sequences back to back, sequence i = dsq[offsets[i] .. offsets[i+1]),
+ * residues only (no sentinels), easel digital codes.
+ * ------------------------------------------------------------------------------------------ */
+int     bath_hip_seqs_create(bath_hip_ctx *ctx, const uint8_t *dsq, const int64_t *offsets, int64_t n, bath_hip_seqs **ret);
+void    bath_hip_seqs_destroy(bath_hip_seqs *sq);
+int64_t bath_hip_seqs_count(const bath_hip_seqs *sq);
+
+/* ------------------------------------------------------------------------------------------
+ * Filter kernels, batched.  Each target i is scored exactly as the reference would after
+ * p7_oprofile_ReconfigLength(om, L_i) (p7_pipeline.c:1644).  sc[n] nats, status[n] easel codes.
+ * ------------------------------------------------------------------------------------------ */
+int bath_hip_ssvfilter(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bath_hip_seqs *sq, float *sc, int32_t *status);      /* p7_SSVFilter, ssvfilter.c:876 */
+int bath_hip_msvfilter(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bath_hip_seqs *sq, float *sc, int32_t *status);      /* p7_MSVFilter, msvfilter.c:74  */
+int bath_hip_vitfilter(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bath_hip_seqs *sq, float *sc, int32_t *status);      /* p7_ViterbiFilter, vitfilter.c:83 */
+int bath_hip_forward_parser(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bath_hip_seqs *sq, float *sc, int32_t *status); /* p7_ForwardParser, fwdback.c:132 */
+/* p7_bg_NullOne + p7_bg_FilterScore (p7_bg.c:356,491) with p7_bg_SetFilter(bg, M, om->compo): nullsc[n], filtersc[n] */
+int bath_hip_bias_filter(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bath_hip_seqs *sq, float *nullsc, float *filtersc);
+
+/* ------------------------------------------------------------------------------------------
+ * The filter cascade of p7_Pipeline_BATH (p7_pipeline.c:1632-1791) over a block of DNA windows:
+ * six-frame translation (esl_gencode_Process*, bathsearch.c:384-392), MSV, bias, Viterbi, Forward.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  double  F1, F2, F3, F4;         /* p7_pipeline.c:219-222 */
+  int32_t do_biasfilter, fs_pipe, min_orf_len, ncbi_table;
+} bath_pipeline_params;
+
+typedef struct {                   /* one per ORF that passed the MSV filter (P <= F1) */
+  int64_t window;                  /* index of the DNA window in the block                               */
+  int32_t strand, frame;           /* 0 top / 1 bottom; 0..2                                             */
+  int32_t start, end;              /* 1-based nt coords on that strand (start<end), as esl_gencode gives */
+  int32_t n;                       /* ORF length in aa                                                   */
+  int32_t stage;                   /* 1 failed bias, 2 failed Vit, 3 failed Fwd, 4 passed (F3, or F4 if fs_pipe) */
+  int32_t msv_status, vit_status;
+  float   usc, nullsc, filtersc, vfsc, fwdsc;
+  double  P;                       /* P-value at the stage where the ORF stopped                         */
+} bath_orf_result;
+
+typedef struct {                   /* pipeline counters, hmmer.h:1115-1128 */
+  int64_t nres, n_orfs;
+  int64_t n_past_msv, n_past_bias, n_past_vit, n_past_fwd;
+  int64_t pos_past_msv, pos_past_bias, pos_past_vit, pos_past_fwd;
+  int64_t cells_msv, cells_vit, cells_fwd;     /* sum of L*M per stage (Mc/s numerator, msvfilter.c:563) */
+} bath_pipeline_stats;
+
+void bath_pipeline_params_default(bath_pipeline_params *p, int fs_pipe);
+/* Runs the cascade on every window of <dna>, both strands.  On return *results points to an array of
+ * *n_results records owned by ctx (valid until the next call); pass NULL to skip the copy-out. */
+int  bath_hip_pipeline_filters(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bath_hip_seqs *dna,
+                               const bath_pipeline_params *params, bath_pipeline_stats *stats,
+                               const bath_orf_result **results, int64_t *n_results);
+/* Device time of the stages of the last bath_hip_pipeline_filters call, ms (HIP events on ctx's stream).
+ * names[i] are static strings. */
+int  bath_hip_pipeline_timings(const bath_hip_ctx *ctx, int max, const char **names, float *ms, int64_t *launches);
+
+/* ------------------------------------------------------------------------------------------
+ * Frameshift kernels (P7_FS_OPROFILE surface), batched over DNA windows.
+ * ------------------------------------------------------------------------------------------ */
+#define BATH_LOGSUM_TABLE 0   /* emulate p7_FLogsum's 0.001-nat truncating table (logsum.c:105) */
+#define BATH_LOGSUM_EXACT 1   /* exact log(1+exp(x))                                            */
+
+int  bath_hip_fsprofile_convert(bath_hip_ctx *ctx, const bath_fs_profile *gm_fs, bath_hip_fsprofile **ret); /* p7_fs_oprofile_Convert, p7_fs_oprofile.c:221 */
+void bath_hip_fsprofile_destroy(bath_hip_fsprofile *om);
+
+/* p7_ForwardParser_Frameshift_3Codons (fwdback_fs.c:97) / p7_GForwardParser_Frameshift_3Codons
+ * (generic_fwdback_frameshift.c:451): per window i, after p7_fs_oprofile_ReconfigLength(om, L_i/3).
+ * xmx (optional) receives the special-state rows: for window i, (L_i+1)*5 floats {E,N,J,B,C} at xmx_offsets[i]. */
+int bath_hip_fs3_forward_parser(bath_hip_ctx *ctx, const bath_hip_fsprofile *om3, const bath_hip_seqs *dna, int logsum_mode,
+                                float *sc, float *xmx, const int64_t *xmx_offsets);
+int bath_hip_fs3_backward_parser(bath_hip_ctx *ctx, const bath_hip_fsprofile *om3, const bath_hip_seqs *dna, int logsum_mode,
+                                 float *sc, float *xmx, const int64_t *xmx_offsets);  /* fwdback_fs.c:565 / generic :1422 */
+
+/* Envelope rescoring (p7_domaindef.c:993-1082): p7_Forward_Frameshift + p7_Backward_Frameshift +
+ * p7_Decoding_Frameshift + p7_OptimalAccuracy_Frameshift fill + p7_Null2_fs_ByExpectation, one
+ * envelope per sequence of <dna>, unihit profile reconfigured to L_i/3.
+ * c5_compat: 1 = generic_fwdback_frameshift.c:324 ring aliasing for 5-nt codons, 0 = fwdback_fs.c:1464. */
+typedef struct {
+  float fwdsc, bcksc, oasc;
+  float null2[BATH_KP_AMINO];
+} bath_fs5_result;
+int bath_hip_fs5_envelopes(bath_hip_ctx *ctx, const bath_hip_fsprofile *om5, const bath_hip_seqs *dna, int logsum_mode, int c5_compat,
+                           bath_fs5_result *res,
+                           float *pp /* optional: posterior matrices, (L_i+1)*(M+1)*8 floats at pp_offsets[i] */, const int64_t *pp_offsets,
+                           float *oa /* optional: OA matrices (L_i+1)*(M+1)*3 */, const int64_t *oa_offsets);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BATH_HIP_H */

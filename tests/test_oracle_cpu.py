@@ -1,0 +1,149 @@
+"""CPU tier: the oracle against the reference's own recorded results and unit-test identities.
+
+There are no per-kernel known-answer vectors in the reference tree; what exists is
+  (i)  the pipeline counters of recorded bathsearch runs (tutorial/*.out, copied to tests/golden), which pin
+       translation + MSV + bias + Viterbi + Forward decisions end to end, and
+  (ii) the exact-emulation identities of the reference's unit tests (msvfilter.c:621-658, vitfilter.c:645-685).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import common
+import oracle_lib as ol
+
+GOLDEN_RUNS = [
+    ("PTH2.bhmm", 0, "target-PTH2.fa", (6000, 1503, 1503, 1401, 1287)),
+    ("AMP_N.bhmm", 0, "target-AMP_N.fa", (822, 537, 537, 393, 237)),
+    ("MET-ct4.bhmm", 0, "target-MET.fa", (71226, 2487, 2298, 666, 549)),
+    ("MET-ct4.bhmm", 1, "target-MET.fa", (71226, 9168, 2775, 1062, 618)),
+]
+
+
+def _printed_counters(outfile, which):
+    """Parse the which-th 'Internal pipeline statistics summary' block of a recorded bathsearch output."""
+    txt = open(ol.GOLDEN + "/" + outfile).read().split("Internal pipeline statistics summary:")[1 + which]
+    vals = {}
+    for line in txt.splitlines():
+        for key, tag in (("nres", "Target sequence(s):"), ("msv", "Residues passing SSV filter:"), ("bias", "Residues passing bias filter:"),
+                         ("vit", "Residues passing Vit filter:"), ("fwd", "Residues passing Fwd filter:")):
+            if line.startswith(tag):
+                rest = line[len(tag):].split()
+                vals[key] = int(rest[1].strip("(")) if key == "nres" else int(rest[0])
+    return (vals["nres"], vals["msv"], vals["bias"], vals["vit"], vals["fwd"])
+
+
+@pytest.mark.parametrize("hmmfile,idx,fasta,expect", GOLDEN_RUNS, ids=[g[0] + str(g[1]) for g in GOLDEN_RUNS])
+def test_pipeline_counters_match_recorded_runs(hmmfile, idx, fasta, expect):
+    outfile = hmmfile.replace(".bhmm", ".out")
+    assert _printed_counters(outfile, idx) == expect            # the table above is what the reference printed
+    m = ol.Model(ol.GOLDEN + "/" + hmmfile, idx)
+    seqs = [ol.digitize_dna(s) for _, s in ol.read_fasta(ol.GOLDEN + "/" + fasta)]
+    pli, _, _ = m.run_pipeline(seqs)
+    assert (pli.nres, pli.pos_past_msv, pli.pos_past_bias, pli.pos_past_vit, pli.pos_past_fwd) == expect
+
+
+@pytest.fixture(scope="module")
+def caudal():
+    return ol.Model(ol.GOLDEN + "/Caudal_act.bhmm")
+
+
+def test_msv_equals_generic_viterbi_on_same_as_mf(caudal):
+    """utest_msv_filter, msvfilter.c:621-658: GViterbi(SameAsMF)/scale_b - 3 == MSVFilter (tol 0.001)."""
+    L_ = ol.lib()
+    rng = np.random.default_rng(42)
+    out = C.c_float()
+    n_checked = 0
+    for s in common.random_aa(rng, 60, 20, 200, with_degenerate=False):
+        L = len(s)
+        L_.bo_profile_reconfig_length(caudal.gm, L)
+        L_.bo_oprofile_reconfig_length(caudal.om, L)
+        gm2 = L_.bo_profile_same_as_mf(caudal.om, caudal.gm)
+        d = ol.dsq_from(s)
+        st = L_.bo_msvfilter(ol.u8(d), L, caudal.om, C.byref(out)); sc1 = out.value
+        L_.bo_gviterbi(ol.u8(d), L, gm2, C.byref(out)); sc2 = out.value / caudal.om.contents.scale_b - 3.0
+        L_.bo_profile_free(gm2)
+        if st == 0:
+            assert abs(sc1 - sc2) < 0.001
+            n_checked += 1
+    assert n_checked > 40
+
+
+def test_vitfilter_equals_generic_viterbi_on_same_as_vf(caudal):
+    """utest_viterbi_filter, vitfilter.c:645-685."""
+    L_ = ol.lib()
+    rng = np.random.default_rng(43)
+    out = C.c_float()
+    seqs = common.random_aa(rng, 40, 20, 200, with_degenerate=False) + common.emit_from_model(rng, caudal, 20)
+    for s in seqs:
+        L = len(s)
+        L_.bo_profile_reconfig_length(caudal.gm, L)
+        L_.bo_oprofile_reconfig_length(caudal.om, L)
+        gm2 = L_.bo_profile_same_as_vf(caudal.om, caudal.gm)
+        d = ol.dsq_from(s)
+        st = L_.bo_vitfilter(ol.u8(d), L, caudal.om, C.byref(out)); sc1 = out.value
+        L_.bo_gviterbi(ol.u8(d), L, gm2, C.byref(out)); sc2 = out.value / caudal.om.contents.scale_w - 3.0
+        L_.bo_profile_free(gm2)
+        if st == 0:
+            assert abs(sc1 - sc2) < 0.001
+
+
+def test_viterbi_bath_score_equals_plain(caudal):
+    """utest in vitfilter.c:688-760: the window-emitting variant returns the same score; windows lie inside the target/model."""
+    L_ = ol.lib()
+    rng = np.random.default_rng(44)
+    out1, out2 = C.c_float(), C.c_float()
+    for s in common.emit_from_model(rng, caudal, 30):
+        L = len(s)
+        L_.bo_oprofile_reconfig_length(caudal.om, L)
+        L_.bo_bg_setlength(C.byref(caudal.bg), L)
+        d = ol.dsq_from(s)
+        wl = ol.WindowList(); L_.bo_windowlist_init(C.byref(wl))
+        fsc = L_.bo_bg_filterscore(C.byref(caudal.bg), ol.u8(d), L)
+        st1 = L_.bo_vitfilter(ol.u8(d), L, caudal.om, C.byref(out1))
+        st2 = L_.bo_vitfilter_bath(ol.u8(d), L, caudal.om, caudal.sd, fsc, 1e-3, C.byref(wl), C.byref(out2))
+        assert st1 == st2 and (out1.value == out2.value or (np.isinf(out1.value) and np.isinf(out2.value)))
+        for i in range(wl.count):
+            w = wl.w[i]
+            assert 1 <= w.n <= L and 1 <= w.k <= caudal.M and 1 <= w.length <= w.k
+        L_.bo_windowlist_free(C.byref(wl))
+
+
+def test_forward_backward_agree(caudal):
+    """Fwd == Bwd (fwdback.c unit tests): parser scores agree to fp32 accuracy; Forward >= Viterbi."""
+    L_ = ol.lib()
+    rng = np.random.default_rng(45)
+    f, b, v = C.c_float(), C.c_float(), C.c_float()
+    for s in common.random_aa(rng, 10, 30, 300, False) + common.emit_from_model(rng, caudal, 10):
+        L = len(s)
+        L_.bo_oprofile_reconfig_length(caudal.om, L)
+        d = ol.dsq_from(s)
+        fx = np.zeros((L + 1) * 6, np.float32); bx = np.zeros((L + 1) * 6, np.float32)
+        assert L_.bo_forward_parser(ol.u8(d), L, caudal.om, ol.f32(fx), C.byref(f)) == 0
+        assert L_.bo_backward_parser(ol.u8(d), L, caudal.om, ol.f32(fx), ol.f32(bx), C.byref(b)) == 0
+        assert abs(f.value - b.value) < 1e-3 + 1e-5 * abs(f.value)
+        if L_.bo_vitfilter(ol.u8(d), L, caudal.om, C.byref(v)) == 0:
+            assert f.value >= v.value - 3.1      # VF carries the -3 nat NN/CC/JJ approximation
+
+
+def test_logsum_table():
+    """p7_FLogsum: table entry i = float(log(1+exp(-i/1000))) (logsum.c:89), truncating index (logsum.c:110)."""
+    L_ = ol.lib()
+    tab = np.ctypeslib.as_array(L_.bo_flogsum_table(), shape=(16000,))
+    assert tab[0] == np.float32(np.log(2.0)) and tab[15999] > 0
+    assert L_.bo_flogsum(1.0, -np.inf) == 1.0
+    assert L_.bo_flogsum(0.0, -15.7) == 0.0
+    assert L_.bo_flogsum(2.0, 1.9995) == np.float32(2.0) + tab[0]
+
+
+def test_orf_finder_basic():
+    L_ = ol.lib()
+    basic = np.zeros(64, np.uint8); L_.bo_gencode_basic(1, ol.u8(basic))
+    # 25 x GCT (Ala) then TAA then 19 x GCT: one ORF of 25 aa in frame 0; the 19-aa run is below -l 20
+    dna = ol.digitize_dna("GCT" * 25 + "TAA" + "GCT" * 19)
+    blk = ol.OrfBlock(); L_.bo_orfblock_init(C.byref(blk))
+    L_.bo_translate_orfs(ol.u8(ol.dsq_from(dna)), len(dna), ol.u8(basic), 20, C.byref(blk))
+    f0 = [blk.orf[i] for i in range(blk.count) if blk.orf[i].frame == 0]
+    assert len(f0) == 1 and (f0[0].start, f0[0].end, f0[0].n) == (1, 75, 25)
+    L_.bo_orfblock_free(C.byref(blk))

@@ -1,0 +1,111 @@
+"""GPU parity of the filter cascade (bath_hip_pipeline_filters) against the oracle's restatement of
+p7_Pipeline_BATH (oracle/pipeline.c), ORF by ORF, plus the reference's own recorded counters
+(tutorial/*.out, tests/golden) reproduced end to end on the GPU."""
+import numpy as np
+import pytest
+
+import bath_amd as ba
+import common
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+
+
+def make_windows(rng, model, n_random=150, n_planted=60, L=1000):
+    basic = model.basic
+    wins = common.random_dna(rng, n_random, L)
+    planted = common.emit_from_model(rng, model, n_planted // 2, flank=10) + common.emit_from_model(rng, model, n_planted // 2, flank=10, sharpen=2.0)
+    for i, aa in enumerate(planted):
+        nt = common.revtranslate(rng, aa, basic)
+        pre = rng.integers(0, 4, size=int(rng.integers(0, 200))).astype(np.uint8)
+        post = rng.integers(0, 4, size=int(rng.integers(0, 200))).astype(np.uint8)
+        w = np.concatenate([pre, nt, post])
+        if i % 2:
+            w = (3 - w[::-1]).astype(np.uint8)          # put it on the bottom strand
+        wins.append(w)
+    wins += common.random_dna(rng, 10, 300, degenerate_frac=0.02)
+    wins += [rng.integers(0, 4, size=n).astype(np.uint8) for n in (0, 1, 14, 15, 16, 59, 60, 61, 62, 63, 3001)]
+    return wins
+
+
+def run_both(ctx, path, idx, wins, fs_pipe):
+    model = ol.Model(path, idx)
+    hmm = ba.HMM(path, idx)
+    om = ba.OProfile(ctx, ba.Profile(hmm))
+    pipe = ba.Pipeline(ctx, om, fs_pipe=fs_pipe, ncbi_table=hmm.ct)
+    stats, res = pipe.run(ba.SeqBlock(ctx, wins))
+    pli, ores, per_seq = model.run_pipeline(wins, fs_pipe=fs_pipe)
+    return stats, res, pli, ores, per_seq, pipe
+
+
+def compare(stats, res, pli, ores, per_seq):
+    for name in ("nres", "n_orfs", "n_past_msv", "n_past_bias", "n_past_vit", "n_past_fwd",
+                 "pos_past_msv", "pos_past_bias", "pos_past_vit", "pos_past_fwd", "cells_msv", "cells_vit", "cells_fwd"):
+        assert getattr(stats, name) == getattr(pli, name), name
+    want = {}
+    for w, (a, b) in enumerate(per_seq):
+        for r in ores[a:b]:
+            if r.stage >= 1:
+                want[(w, r.strand, r.frame, r.start)] = r
+    assert len(res) == len(want)
+    for g in res:
+        o = want[(int(g["window"]), int(g["strand"]), int(g["frame"]), int(g["start"]))]
+        assert (g["end"], g["n"], g["stage"], g["msv_status"]) == (o.end, o.n, o.stage, o.msv_status)
+        assert np.float32(g["usc"]).view(np.uint32) == np.float32(o.usc).view(np.uint32)            # integer filter: bit exact
+        assert np.float32(g["nullsc"]).view(np.uint32) == np.float32(o.nullsc).view(np.uint32)
+        if o.stage >= 2 or (o.stage == 1):
+            assert abs(g["filtersc"] - o.filtersc) <= 1e-4 + 1e-5 * abs(o.filtersc)
+        if np.isfinite(o.vfsc) or np.isinf(g["vfsc"]):
+            assert np.float32(g["vfsc"]).view(np.uint32) == np.float32(o.vfsc).view(np.uint32)      # integer filter: bit exact
+            assert g["vit_status"] == o.vit_status
+        if o.stage >= 3 and np.isfinite(o.fwdsc):
+            assert abs(g["fwdsc"] - o.fwdsc) <= 2e-4 + 1e-4 * abs(o.fwdsc)
+
+
+@pytest.mark.parametrize("name,fs", [("Caudal_act.bhmm", False), ("Caudal_act.bhmm", True), ("PTH2.bhmm", False), ("2OG-FeII_Oxy_3.bhmm", True)])
+def test_cascade_matches_oracle(gpu_ctx, name, fs):
+    rng = np.random.default_rng(7)
+    path = ol.GOLDEN + "/" + name
+    wins = make_windows(rng, ol.Model(path, 0))
+    stats, res, pli, ores, per_seq, _ = run_both(gpu_ctx, path, 0, wins, fs)
+    compare(stats, res, pli, ores, per_seq)
+    assert stats.n_past_fwd > 0 and stats.n_past_msv > stats.n_past_fwd      # the set exercises every stage
+
+
+GOLDEN_RUNS = [  # (model file, index, target fasta, counters printed by the reference: p7_pli_Statistics)
+    ("PTH2.bhmm", 0, "target-PTH2.fa", (6000, 1503, 1503, 1401, 1287)),
+    ("AMP_N.bhmm", 0, "target-AMP_N.fa", (822, 537, 537, 393, 237)),
+    ("MET-ct4.bhmm", 0, "target-MET.fa", (71226, 2487, 2298, 666, 549)),
+    ("MET-ct4.bhmm", 1, "target-MET.fa", (71226, 9168, 2775, 1062, 618)),
+]
+
+
+@pytest.mark.parametrize("hmmfile,idx,fasta,expect", GOLDEN_RUNS, ids=[g[0] + str(g[1]) for g in GOLDEN_RUNS])
+def test_reference_recorded_counters(gpu_ctx, hmmfile, idx, fasta, expect):
+    """tutorial/*.out 'Internal pipeline statistics summary' reproduced by the GPU pipeline."""
+    hmm = ba.HMM(ol.GOLDEN + "/" + hmmfile, idx)
+    om = ba.OProfile(gpu_ctx, ba.Profile(hmm))
+    seqs = [ba.digitize(s, ba.DNA_SYMS) for _, s in ol.read_fasta(ol.GOLDEN + "/" + fasta)]
+    stats, _ = ba.Pipeline(gpu_ctx, om, fs_pipe=False, ncbi_table=hmm.ct).run(ba.SeqBlock(gpu_ctx, seqs))
+    assert (stats.nres, stats.pos_past_msv, stats.pos_past_bias, stats.pos_past_vit, stats.pos_past_fwd) == expect
+
+
+def test_nobias_and_thresholds(gpu_ctx):
+    rng = np.random.default_rng(11)
+    path = ol.GOLDEN + "/Caudal_act.bhmm"
+    model = ol.Model(path, 0)
+    wins = make_windows(rng, model, 60, 30)
+    hmm = ba.HMM(path)
+    om = ba.OProfile(gpu_ctx, ba.Profile(hmm))
+    pipe = ba.Pipeline(gpu_ctx, om, fs_pipe=False, do_biasfilter=0, F1=0.1, F2=0.01)
+    stats, res = pipe.run(ba.SeqBlock(gpu_ctx, wins))
+    import ctypes as C
+    L = ol.lib()
+    pli = ol.Pipeline(); L.bo_pipeline_init(C.byref(pli), 0)
+    pli.do_biasfilter = 0; pli.F1 = 0.1; pli.F2 = 0.01
+    resp = C.POINTER(ol.OrfResult)(); n = C.c_int(0); a = C.c_int(0)
+    for w in wins:
+        d = ol.dsq_from(w)
+        L.bo_pipeline_window(C.byref(pli), model.om, model.sd, C.byref(model.bg), ol.u8(model.basic), ol.u8(d), len(w), C.byref(resp), C.byref(n), C.byref(a))
+    for name in ("n_orfs", "n_past_msv", "n_past_bias", "n_past_vit", "n_past_fwd", "pos_past_fwd"):
+        assert getattr(stats, name) == getattr(pli, name), name
