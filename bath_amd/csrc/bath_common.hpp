@@ -115,7 +115,7 @@ struct bath_hip_oprofile {
   int16_t base_w = 0, ddbound_w = 0;
   float xf_E[2] = {0, 0};
   // device tables
-  int NR = 0;                   // packed int16 register count of the SSV kernel (2*NR >= M)
+  int NR = 0, G = 1;            // SSV kernel tile: NR packed int16 registers per lane, G lanes per target (2*NR*G >= M)
   int ssv_row_bytes = 0;
   int16_t *d_ssv = nullptr;     // [kSsvRows][ssv_row_bytes/2] signed SSV costs (sf_conversion), +127 padding
   uint8_t *d_rb = nullptr;      // [Kp][rb_stride]

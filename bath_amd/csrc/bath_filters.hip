@@ -32,26 +32,29 @@ namespace bath {
 // SSV, lane per target.
 // ============================================================================================
 
-// Amino-acid targets: lane t scores sequence order[t] (or t), writes the raw maximum v in the
+// Amino-acid targets: G adjacent lanes score sequence order[t] (or t); writes the raw maximum v in the
 // kernel's signed domain (begin score = -128), i.e. get_xE()'s byte minus 256.
-template <int NR>
+template <int NR, int G>
 __global__ __launch_bounds__(256) void ssv_lane_kernel(SeqView sq, const int32_t *__restrict__ order,
                                                        const int16_t *__restrict__ cost_tab, int row_bytes,
                                                        int16_t *__restrict__ out_v) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   {
-    const int n16 = kSsvRows * row_bytes / 4;
+    const int n32 = kSsvRows * row_bytes / 4;
     const uint32_t *src = reinterpret_cast<const uint32_t *>(cost_tab);
     uint32_t *dst = reinterpret_cast<uint32_t *>(lds);
-    for (int i = threadIdx.x; i < n16; i += blockDim.x) dst[i] = src[i];
+    for (int i = threadIdx.x; i < n32; i += blockDim.x) dst[i] = src[i];
   }
   __syncthreads();
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t gt = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t t = gt / G;
+  const int grank = (int)(gt - t * G);
   const bool live = t < sq.n;
   const int64_t sid = live ? (order ? (int64_t)order[t] : t) : 0;
   const int L = live ? sq.len[sid] : 0;
   const uint8_t *s = sq.data + sq.off[sid];
   const int Lw = wave_max_i32(L);
+  const char *tile = lds + grank * (4 * NR);
 
   s16x2 reg[NR];
   const s16x2 fl = {-128, -128};
@@ -67,10 +70,12 @@ __global__ __launch_bounds__(256) void ssv_lane_kernel(SeqView sq, const int32_t
     for (int j = 0; j < 4; j++) {
       int x = (w >> (8 * j)) & 0xff;
       x = (i0 + j < L) ? min(x, kKp - 1) : kRowReset;
-      ssv_row<NR>(reg, xE, lds + x * row_bytes);
+      const unsigned carry = ssv_carry<NR, G>(reg, grank);
+      ssv_row<NR>(reg, xE, tile + x * row_bytes, carry);
     }
   }
-  if (live) out_v[sid] = (int16_t)max((int)xE.x, (int)xE.y);
+  const int v = ssv_group_max<G>(xE);
+  if (live && grank == 0) out_v[sid] = (int16_t)min(v, 32767);
 }
 
 __global__ void ssv_classify_kernel(int64_t n, const int32_t *__restrict__ len, const int16_t *__restrict__ v,
@@ -451,21 +456,20 @@ static int length_order(bath_hip_ctx *ctx, const bath_hip_seqs *sq, DevBuf &buf)
 
 int launch_ssv_lane(bath_hip_ctx *ctx, const bath_hip_oprofile *om, SeqView v, const int32_t *d_order, int16_t *d_v) {
   if (v.n == 0) return BATH_OK;
-  const int blocks = (int)((v.n + 255) / 256);
+  const int G = om->G;
+  const int blocks = (int)((v.n * G + 255) / 256);
   const size_t shmem = (size_t)kSsvRows * om->ssv_row_bytes;
   const int rb = om->ssv_row_bytes;
-#define BATH_SSV_CASE(N)                                                                                         \
-  case N:                                                                                                        \
-    hipLaunchKernelGGL(ssv_lane_kernel<N>, dim3(blocks), dim3(256), shmem, ctx->stream, v, d_order, om->d_ssv, rb, d_v); \
-    break;
-  switch (om->NR) {
-    BATH_SSV_CASE(16) BATH_SSV_CASE(32) BATH_SSV_CASE(48) BATH_SSV_CASE(64) BATH_SSV_CASE(80) BATH_SSV_CASE(96)
-    BATH_SSV_CASE(112) BATH_SSV_CASE(128) BATH_SSV_CASE(144) BATH_SSV_CASE(160) BATH_SSV_CASE(176) BATH_SSV_CASE(192) BATH_SSV_CASE(208)
-    default:
-      ctx->set_error("SSV kernel: model length " + std::to_string(om->M) + " exceeds the single-tile limit (416 nodes)");
-      return BATH_EINVAL;
+  bool launched = false;
+#define BATH_SSV_CASE(N, GG)                                                                                             \
+  if (!launched && om->NR == N && G == GG) {                                                                             \
+    if (shmem > 64 * 1024) (void)hipFuncSetAttribute((const void *)ssv_lane_kernel<N, GG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
+    hipLaunchKernelGGL((ssv_lane_kernel<N, GG>), dim3(blocks), dim3(256), shmem, ctx->stream, v, d_order, om->d_ssv, rb, d_v); \
+    launched = true;                                                                                                     \
   }
+  BATH_SSV_SHAPES(BATH_SSV_CASE)
 #undef BATH_SSV_CASE
+  if (!launched) { ctx->set_error("SSV kernel: no tile shape for model length " + std::to_string(om->M)); return BATH_EINVAL; }
   BATH_HIP_TRY(ctx, hipGetLastError());
   return BATH_OK;
 }

@@ -30,9 +30,12 @@ __device__ __forceinline__ int satu8(int v) { return min(max(v, 0), 255); }
 
 
 // ---- SSV: one DP row of the lane-per-target kernels ----------------------------------------------
-// One DP row for this lane: residue row <rowbase> (LDS byte address of the residue's cost row).
+// One DP row for this lane: residue row <rowbase> (LDS byte address of the residue's cost row, already
+// offset to this lane's column tile).  <carry> holds, in its high half, the previous row's value of the
+// node just left of the tile: the constant begin score -128 for the first tile, otherwise the last node
+// of the neighbouring lane's tile (models longer than one lane's registers are split over G lanes).
 template <int NR>
-__device__ __forceinline__ void ssv_row(s16x2 (&reg)[NR], s16x2 &xE, const char *rowbase) {
+__device__ __forceinline__ void ssv_row(s16x2 (&reg)[NR], s16x2 &xE, const char *rowbase, unsigned carry) {
   const s16x2 fl = {-128, -128};
 #pragma unroll
   for (int r = NR - 2; r >= 0; r -= 2) {
@@ -46,13 +49,28 @@ __device__ __forceinline__ void ssv_row(s16x2 (&reg)[NR], s16x2 &xE, const char 
     xE = __builtin_elementwise_max(xE, v);
     reg[r + 1] = v;
     // nodes (2r+1, 2r+2) take (2r, 2r+1); node 0 is the constant begin score -128
-    const unsigned lo2 = (r > 0) ? __builtin_bit_cast(unsigned, reg[r - 1]) : 0xff80ff80u;
+    const unsigned lo2 = (r > 0) ? __builtin_bit_cast(unsigned, reg[r - 1]) : carry;
     v = __builtin_bit_cast(s16x2, __builtin_amdgcn_alignbit(lo, lo2, 16));
     v = __builtin_elementwise_sub_sat(v, __builtin_bit_cast(s16x2, c.x));
     v = __builtin_elementwise_max(v, fl);
     xE = __builtin_elementwise_max(xE, v);
     reg[r] = v;
   }
+}
+
+// Per-row helpers for models split over G lanes (G = 1, 2, 4 or 8 adjacent lanes per target).
+template <int NR, int G>
+__device__ __forceinline__ unsigned ssv_carry(const s16x2 (&reg)[NR], int grank) {
+  if (G == 1) return 0xff80ff80u;
+  const unsigned up = (unsigned)__shfl_up((int)__builtin_bit_cast(unsigned, reg[NR - 1]), 1, 64);
+  return (grank == 0) ? 0xff80ff80u : up;
+}
+template <int G>
+__device__ __forceinline__ int ssv_group_max(s16x2 xE) {
+  int v = max((int)xE.x, (int)xE.y);
+#pragma unroll
+  for (int d = 1; d < G; d <<= 1) v = max(v, __shfl_xor(v, d, 64));
+  return v;
 }
 
 // p7_SSVFilter's decision logic (ssvfilter.c:876-925) applied to the raw maximum.

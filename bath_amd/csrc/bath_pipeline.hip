@@ -95,7 +95,7 @@ struct Params {
 // ---------------------------------------------------------------------------------------------
 // 1. SSV over six-frame translated DNA, lane per stream
 // ---------------------------------------------------------------------------------------------
-template <int NR>
+template <int NR, int G>
 __global__ __launch_bounds__(256) void ssv_dna_kernel(SeqView dna, DnaTables tabs, const int16_t *__restrict__ cost_tab, int row_bytes,
                                                       const int16_t *__restrict__ emit_thresh, int thresh_max, int minlen,
                                                       Cand cand, int cand_cap, unsigned long long aa_cap, Counters *__restrict__ ctr) {
@@ -111,7 +111,10 @@ __global__ __launch_bounds__(256) void ssv_dna_kernel(SeqView dna, DnaTables tab
     if (threadIdx.x < 18) s_comp[threadIdx.x] = tabs.comp[threadIdx.x];
   }
   __syncthreads();
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t gt = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t t = gt / G;
+  const int grank = (int)(gt - t * G);
+  const char *tile = lds + grank * (4 * NR);
   const int64_t w = t / 6;
   const int sf = (int)(t - w * 6);
   const int strand = sf / 3, frame = sf - strand * 3;
@@ -146,11 +149,12 @@ __global__ __launch_bounds__(256) void ssv_dna_kernel(SeqView dna, DnaTables tab
       if (aa == kStop) close = true;
       else { if (orf_len == 0) start_j = j; orf_len++; x = aa; }
     } else if (j == ncod) close = true;
+    const int gmax = ssv_group_max<G>(xE);
     if (close) {
       if (orf_len >= minlen) {
-        my_orfs++; my_res += (unsigned)orf_len;
-        const int v = max((int)xE.x, (int)xE.y);
-        if (v >= (int)emit_thresh[min(orf_len, thresh_max)]) {
+        if (grank == 0) { my_orfs++; my_res += (unsigned)orf_len; }
+        if (grank == 0 && gmax >= (int)emit_thresh[min(orf_len, thresh_max)]) {
+          const int v = gmax;
           const int slot = atomicAdd(&ctr->cand_count, 1);
           const unsigned long long need = ((unsigned long long)orf_len + 3ull) & ~3ull;
           const unsigned long long off = atomicAdd(&ctr->aa_bump, need);
@@ -162,7 +166,8 @@ __global__ __launch_bounds__(256) void ssv_dna_kernel(SeqView dna, DnaTables tab
       }
       xE = fl; orf_len = 0;
     }
-    ssv_row<NR>(reg, xE, lds + x * row_bytes);
+    const unsigned carry = ssv_carry<NR, G>(reg, grank);
+    ssv_row<NR>(reg, xE, tile + x * row_bytes, carry);
   }
   // block-level reduction of the ORF counters
   __shared__ unsigned red[2];
@@ -608,6 +613,7 @@ extern "C" int bath_hip_pipeline_filters(bath_hip_ctx *ctx, const bath_hip_oprof
   const int NRk = om->NR;
   const size_t ssv_shmem = (size_t)kSsvRows * om->ssv_row_bytes + 5832 + 64;
   const int64_t nstreams = nwin * 6;
+  if (ssv_shmem > 160 * 1024) { ctx->set_error("model too long for the LDS-resident SSV cost table"); return BATH_EINVAL; }
   const int MP = std::max(2, ((M - 1) / 16) + 1) * 16;
   const int dec_blocks = ctx->prop.multiProcessorCount * 4;
 
@@ -629,18 +635,18 @@ extern "C" int bath_hip_pipeline_filters(bath_hip_ctx *ctx, const bath_hip_oprof
     BATH_HIP_TRY(ctx, hipEventRecord(ev[e++], ctx->stream));
     // 1. translate + SSV + F1 threshold
     {
-      const int blocks = (int)((nstreams + 255) / 256);
-#define BATH_DNA_CASE(N)                                                                                                         \
-  case N:                                                                                                                        \
-    hipLaunchKernelGGL(ssv_dna_kernel<N>, dim3(blocks), dim3(256), ssv_shmem, ctx->stream, dna->view(), tabs, om->d_ssv,          \
+      const int blocks = (int)((nstreams * om->G + 255) / 256);
+      bool launched = false;
+#define BATH_DNA_CASE(N, GG)                                                                                                     \
+  if (!launched && NRk == N && om->G == GG) {                                                                                    \
+    if (ssv_shmem > 64 * 1024) (void)hipFuncSetAttribute((const void *)ssv_dna_kernel<N, GG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ssv_shmem); \
+    hipLaunchKernelGGL((ssv_dna_kernel<N, GG>), dim3(blocks), dim3(256), ssv_shmem, ctx->stream, dna->view(), tabs, om->d_ssv,    \
                        om->ssv_row_bytes, d_emit, max_orf, prm->min_orf_len, W.cand, W.cand_cap, W.aa_cap, W.ctr);               \
-    break;
-      switch (NRk) {
-        BATH_DNA_CASE(16) BATH_DNA_CASE(32) BATH_DNA_CASE(48) BATH_DNA_CASE(64) BATH_DNA_CASE(80) BATH_DNA_CASE(96)
-        BATH_DNA_CASE(112) BATH_DNA_CASE(128) BATH_DNA_CASE(144) BATH_DNA_CASE(160) BATH_DNA_CASE(176) BATH_DNA_CASE(192) BATH_DNA_CASE(208)
-        default: ctx->set_error("SSV kernel: model length exceeds the single-tile limit (416 nodes)"); return BATH_EINVAL;
-      }
+    launched = true;                                                                                                             \
+  }
+      BATH_SSV_SHAPES(BATH_DNA_CASE)
 #undef BATH_DNA_CASE
+      if (!launched) { ctx->set_error("SSV kernel: no tile shape for this model length"); return BATH_EINVAL; }
       BATH_HIP_TRY(ctx, hipGetLastError());
     }
     BATH_HIP_TRY(ctx, hipEventRecord(ev[e++], ctx->stream));

@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""bench.py -- the north-star measurement: the bathsearch filter cascade on MI355X.
+
+Workload (BASELINE.json configs[1]): testsuite/Caudal_act.bhmm (M=145) against 10^6 synthetic 1 kb DNA
+windows (iid ACGT, seed 42, 1% carrying a planted domain), both strands, six-frame translation ->
+MSV/SSV -> bias -> Viterbi -> Forward, standard codon table, no --fs.  One "step" is one pass of the whole
+cascade over the block, with the DNA already resident in HBM.
+
+  value   = DNA residues searched per second, counted as the reference counts pli->nres
+            (both strands: bathsearch.c:1073,1086), whole job over all ranks.
+  roofline = the dominant kernel (ssv_dna_kernel): algorithmic HBM bytes per launch / its device time,
+            timed with HIP events on the library's own stream (bath_hip_pipeline_timings).
+  cpu_baseline = the scalar C oracle (oracle/pipeline.c, a port of the same algorithms) on a bounded
+            sample of the same windows, one process per host core.  A reported baseline, not the target.
+
+N>1: launched by torch.distributed.run, one rank per GPU; the model is broadcast from rank 0 over RCCL,
+every rank scores its own 10^6 windows (weak scaling), counters and hits are gathered on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+MODEL = os.path.join(ROOT, "tests", "golden", "Caudal_act.bhmm")
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak, MI355X_MICROARCH.md
+
+
+def cpu_baseline_worker(args):
+    """Scalar oracle cascade over a slice of windows (runs in a forked worker)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ctypes as C
+    import oracle_lib as ol
+    flat, length, lo, hi = args
+    m = ol.Model(MODEL, 0)
+    L = ol.lib()
+    pli = ol.Pipeline()
+    L.bo_pipeline_init(C.byref(pli), 0)
+    res = C.POINTER(ol.OrfResult)()
+    n, a = C.c_int(0), C.c_int(0)
+    t0 = time.perf_counter()
+    for w in range(lo, hi):
+        d = ol.dsq_from(flat[w * length:(w + 1) * length])
+        n.value = 0
+        L.bo_pipeline_window(C.byref(pli), m.om, m.sd, C.byref(m.bg), ol.u8(m.basic), ol.u8(d), length,
+                             C.byref(res), C.byref(n), C.byref(a))
+    dt = time.perf_counter() - t0
+    return dt, pli.nres, pli.cells_msv + pli.cells_vit + pli.cells_fwd, pli.pos_past_msv, pli.pos_past_fwd
+
+
+def cpu_baseline(flat, length, n_windows, budget_s=12.0):
+    import multiprocessing as mp
+    cores = os.cpu_count() or 1
+    # calibrate on a few windows, then size the sample for ~budget_s of wall time on all cores
+    dt, *_ = cpu_baseline_worker((flat, length, 0, 8))
+    per_win = max(dt / 8, 1e-5)
+    per_core = int(max(16, min(n_windows // cores, budget_s / per_win)))
+    jobs = [(flat, length, c * per_core, (c + 1) * per_core) for c in range(cores)]
+    t0 = time.perf_counter()
+    with mp.get_context("fork").Pool(cores) as pool:
+        outs = pool.map(cpu_baseline_worker, jobs)
+    wall = time.perf_counter() - t0
+    nres = sum(o[1] for o in outs)
+    cells = sum(o[2] for o in outs)
+    return {"value": nres / wall, "unit": "residues/s", "cores": cores, "kind": "port",
+            "sample": "%d windows x %d nt (both strands) through oracle/pipeline.c, one process per core, %.1f s wall" % (per_core * cores, length, wall),
+            "gcells_per_s": cells / wall / 1e9}, outs
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--windows", type=int, default=1_000_000, help="DNA windows per GPU (BASELINE config: 10^6)")
+    ap.add_argument("--length", type=int, default=1000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    import torch.distributed as dist
+    import bath_amd as ba
+    from bath_amd import dist as bdist, synth
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the backend has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    # query model: read on rank 0, broadcast (RCCL over xGMI), parsed by every rank
+    blob = open(MODEL, "rb").read() if rank == 0 else b""
+    blob = bdist.broadcast_bytes(blob, 0, dev)
+    tmp = "/tmp/bath_bench_model_%d.bhmm" % os.getpid()
+    with open(tmp, "wb") as fh:
+        fh.write(blob)
+    hmm = ba.HMM(tmp)
+    os.unlink(tmp)
+
+    ctx = ba.Context(local_rank)
+    om = ba.OProfile(ctx, ba.Profile(hmm))
+    flat, offsets, planted = synth.dna_windows(args.windows, args.length, seed=42 + rank, hmm=hmm)
+    dna = ba.SeqBlock(ctx, flat, offsets)
+    pipe = ba.Pipeline(ctx, om, fs_pipe=False, ncbi_table=hmm.ct)
+
+    def sync():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    stats = None
+    for _ in range(args.warmup):
+        stats, _ = pipe.run(dna, want_results=False)
+    sync()
+    t0 = time.perf_counter()
+    stage_ms = {}
+    for _ in range(args.steps):
+        stats, _ = pipe.run(dna, want_results=False)
+        for name, ms, _n in pipe.timings():
+            stage_ms.setdefault(name, []).append(ms)
+    sync()
+    elapsed = bdist.max_over_ranks(time.perf_counter() - t0, dev)
+
+    # one more pass with the copy-out, to gather the hits on rank 0 (outside the timed region)
+    stats, res = pipe.run(dna, want_results=True)
+    lo = rank * args.windows
+    merged = bdist.reduce_stats(stats, dev)
+    hits = bdist.gather_results(res, lo, 0, dev)
+
+    if rank == 0:
+        tot = merged
+        nres_step = tot["nres"]
+        cells_step = tot["cells_msv"] + tot["cells_vit"] + tot["cells_fwd"]
+        ms_step = elapsed / args.steps * 1e3
+        value = nres_step / (elapsed / args.steps)
+        # dominant kernel: ssv_dna_kernel, one launch per step
+        k_ms = float(np.mean(stage_ms["ssv_translate_f1"]))
+        algo_bytes = stats.nres / 2 + 32.0 * stats.n_past_msv          # 1 B/nt read once + ~32 B per surviving ORF record
+        achieved = algo_bytes / (k_ms * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_ssv_dna_pmc.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "DP Gcells/s + residues/s through bathsearch pipeline at 1/2/4/8 MI355X",
+            "value": value, "unit": "residues/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8/i16 (MSV, Viterbi) + f32 (Forward)", "data": "synthetic",
+            "config": {"workload": "Caudal_act.bhmm (M=%d) vs %d x %d nt iid DNA windows per GPU (1%% planted), both strands, "
+                                   "6-frame translation + MSV/bias/Viterbi/Forward filter cascade, codon table %d, no --fs"
+                                   % (hmm.M, args.windows, args.length, hmm.ct),
+                       "windows_per_gpu": args.windows, "window_nt": args.length, "M": hmm.M},
+            "gcells_per_s": cells_step / (elapsed / args.steps) / 1e9,
+            "cells_per_step": cells_step, "residues_per_step": nres_step,
+            "stage_ms": {k: float(np.mean(v)) for k, v in stage_ms.items()},
+            "survivors": {k: tot[k] for k in ("n_orfs", "n_past_msv", "n_past_bias", "n_past_vit", "n_past_fwd")},
+            "hits_gathered": int(len(hits)) if hits is not None else 0,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "kernel": "ssv_dna_kernel", "kernel_ms": k_ms,
+                         "note": "integer DP held in VGPRs: compulsory HBM traffic is 1 B/nt, the kernel is VALU-issue bound (see DESIGN.md); "
+                                 "cell rate of this kernel = %.2f Tcells/s" % (stats.cells_msv / (k_ms * 1e-3) / 1e12)},
+        }
+        if not args.no_cpu_baseline:
+            base, _ = cpu_baseline(flat, args.length, args.windows)
+            out["cpu_baseline"] = base
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,75 @@
+"""CPU tier: the N>1 path (one process per GPU, model broadcast, sharded targets, counters reduced and hits
+gathered on rank 0) exercised with two gloo processes.  No GPU compute: each rank fabricates the records
+a shard would produce, so the collectives, shard arithmetic and record packing are what is under test."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    import bath_amd as ba
+    from bath_amd import dist as bd
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    blob = open(os.path.join(ROOT, "tests", "golden", "PTH2.bhmm"), "rb").read() if rank == 0 else b""
+    blob = bd.broadcast_bytes(blob, 0)
+    n_total = 11
+    lo, hi = bd.shard_range(n_total, rank, world)
+    stats = ba.PipelineStats()
+    stats.nres = 2000 * (hi - lo)
+    stats.n_past_msv = hi - lo
+    res = np.zeros(hi - lo, dtype=ba.ORF_RESULT_DTYPE)
+    res["window"] = np.arange(hi - lo)
+    res["usc"] = 10.0 * rank + np.arange(hi - lo)
+    merged = bd.reduce_stats(stats)
+    hits = bd.gather_results(res, lo, 0)
+    t = bd.max_over_ranks(1.0 + rank)
+    q.put((rank, len(blob), (lo, hi), merged["nres"], merged["n_past_msv"], None if hits is None else hits["window"].tolist(), t))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gather_and_reduce():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    size = os.path.getsize(os.path.join(ROOT, "tests", "golden", "PTH2.bhmm"))
+    assert [o[1] for o in outs] == [size, size]                     # the model reached every rank
+    assert [o[2] for o in outs] == [(0, 6), (6, 11)]                # contiguous shards cover all targets once
+    assert all(o[3] == 2000 * 11 and o[4] == 11 for o in outs)      # p7_pipeline_Merge
+    assert outs[0][5] == list(range(11)) and outs[1][5] is None     # p7_tophits_Merge on rank 0, global window ids
+    assert all(o[6] == 2.0 for o in outs)                           # max-over-ranks timing
+
+
+def test_shard_range_partitions():
+    from bath_amd.dist import shard_range
+    for n in (0, 1, 7, 8, 1000003):
+        for world in (1, 2, 4, 8):
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1

@@ -13,13 +13,18 @@ import oracle_lib as ol
 
 pytestmark = pytest.mark.gpu
 
-MODELS = [("Caudal_act.bhmm", 0), ("PTH2.bhmm", 0), ("2OG-FeII_Oxy_3.bhmm", 0), ("MET-ct4.bhmm", 0)]
+MODELS = [("Caudal_act.bhmm", 0), ("PTH2.bhmm", 0), ("2OG-FeII_Oxy_3.bhmm", 0), ("MET-ct4.bhmm", 0), ("MET-ct4.bhmm", 1),
+          ("synthetic:1024", 0), ("synthetic:700", 0), ("synthetic:7", 0)]   # M=458: 2 lanes/target; M=1024: 4 lanes/target
 
 
-@pytest.fixture(scope="module", params=MODELS, ids=[m[0] for m in MODELS])
-def setup(request, gpu_ctx):
+@pytest.fixture(scope="module", params=MODELS, ids=[m[0] + "#" + str(m[1]) for m in MODELS])
+def setup(request, gpu_ctx, tmp_path_factory):
     name, idx = request.param
-    path = ol.GOLDEN + "/" + name
+    if name.startswith("synthetic:"):
+        M = int(name.split(":")[1])
+        path = common.write_synthetic_bhmm(str(tmp_path_factory.mktemp("hmm") / ("s%d.bhmm" % M)), M, seed=M)
+    else:
+        path = ol.GOLDEN + "/" + name
     model = ol.Model(path, idx)
     hmm = ba.HMM(path, idx)
     gm = ba.Profile(hmm)
@@ -56,7 +61,8 @@ def test_msv_bit_exact(setup):
     assert _same_scores(sc, osc)
     # the set has to reach the J-state re-run and the overflow branch, or this test proves little
     _, sst = common.oracle_scores(model, seqs, "bo_ssvfilter")
-    assert (sst == 19).sum() > 0 and (ost == 16).sum() > 0
+    if model.M >= 50:
+        assert (sst == 19).sum() > 0 and (ost == 16).sum() > 0
 
 
 def test_viterbi_bit_exact(setup):

@@ -109,3 +109,14 @@ def test_nobias_and_thresholds(gpu_ctx):
         L.bo_pipeline_window(C.byref(pli), model.om, model.sd, C.byref(model.bg), ol.u8(model.basic), ol.u8(d), len(w), C.byref(resp), C.byref(n), C.byref(a))
     for name in ("n_orfs", "n_past_msv", "n_past_bias", "n_past_vit", "n_past_fwd", "pos_past_fwd"):
         assert getattr(stats, name) == getattr(pli, name), name
+
+
+def test_cascade_long_synthetic_model(gpu_ctx, tmp_path):
+    """BASELINE config 5 shape: a 1024-node model does not fit one lane's registers; the SSV kernel splits
+    the model over 4 adjacent lanes.  Same ORF-by-ORF parity bar."""
+    rng = np.random.default_rng(5)
+    path = common.write_synthetic_bhmm(str(tmp_path / "s1024.bhmm"), 1024, seed=1024)
+    wins = make_windows(rng, ol.Model(path, 0), 40, 24, L=3500)
+    stats, res, pli, ores, per_seq, _ = run_both(gpu_ctx, path, 0, wins, True)
+    compare(stats, res, pli, ores, per_seq)
+    assert stats.n_past_fwd > 0
