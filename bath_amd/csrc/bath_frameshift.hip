@@ -1,7 +1,998 @@
-// placeholder until the frameshift kernels land (replaced later in this round)
+// bath_frameshift.hip -- frameshift-aware Forward/Backward, posterior decoding, optimal accuracy and
+// null2 for gfx950, batched over DNA windows / envelopes.
+//
+//   fs3_fwd_kernel   <- p7_ForwardParser_Frameshift_3Codons  impl_sse/fwdback_fs.c:97
+//                       (scalar twin p7_GForwardParser_Frameshift_3Codons generic_fwdback_frameshift.c:451)
+//   fs_bwd_kernel<3> <- p7_BackwardParser_Frameshift_3Codons impl_sse/fwdback_fs.c:565  / generic :1422
+//   fs5_fwd_kernel   <- p7_Forward_Frameshift                impl_sse/fwdback_fs.c:2054 / generic :64
+//   fs_bwd_kernel<5> <- p7_Backward_Frameshift               impl_sse/fwdback_fs.c:2634 / generic :1035
+//   fs5_decode_kernel<- p7_Decoding_Frameshift               generic_decoding_frameshift.c:36
+//   fs5_oa_kernel    <- p7_OptimalAccuracy_Frameshift (fill) generic_optacc_frameshift.c:53
+//   fs5_null2_kernel <- p7_Null2_fs_ByExpectation            generic_null2_frameshift.c:46
+//
+// One wavefront owns one DNA window; lanes own contiguous blocks of model nodes; the nucleotide
+// recurrence (rows i-1..i-5) lives in registers as ring buffers; the D->D chain along the model and
+// the E-state sum are wavefront scans/reductions.  Arithmetic is the log-space arithmetic of the
+// generic reference with p7_FLogsum's 16000-entry table (logsum.c:105) held in LDS, so every
+// individual log-sum is bit-identical to the reference's; only the ASSOCIATION of the sums along the
+// model differs (scan instead of a serial loop), which with a 0.001-nat table moves scores by
+// O(1e-3) nats (the reference's own SIMD-vs-generic tolerance is 1.0 nat, fwdback_fs.c:3189).
+#include <cmath>
+#include <cstring>
+#include <vector>
+
 #include "bath_common.hpp"
-extern "C" int bath_hip_fsprofile_convert(bath_hip_ctx *ctx, const bath_fs_profile *, bath_hip_fsprofile **) { ctx->set_error("fs not built yet"); return BATH_EINVAL; }
-extern "C" void bath_hip_fsprofile_destroy(bath_hip_fsprofile *) {}
-extern "C" int bath_hip_fs3_forward_parser(bath_hip_ctx *ctx, const bath_hip_fsprofile *, const bath_hip_seqs *, int, float *, float *, const int64_t *) { ctx->set_error("fs not built yet"); return BATH_EINVAL; }
-extern "C" int bath_hip_fs3_backward_parser(bath_hip_ctx *ctx, const bath_hip_fsprofile *, const bath_hip_seqs *, int, float *, float *, const int64_t *) { ctx->set_error("fs not built yet"); return BATH_EINVAL; }
-extern "C" int bath_hip_fs5_envelopes(bath_hip_ctx *ctx, const bath_hip_fsprofile *, const bath_hip_seqs *, int, int, bath_fs5_result *, float *, const int64_t *, float *, const int64_t *) { ctx->set_error("fs not built yet"); return BATH_EINVAL; }
+#include "bath_kernels.hpp"
+
+using namespace bath;
+
+struct bath_hip_fsprofile {
+  bath_hip_ctx *ctx = nullptr;
+  int M = 0, codon_lengths = 0, maxcodons = 0, max_length = 0;
+  int pitch = 0;                 // floats per emission row (M+1 rounded up to 4)
+  float fsprob = 0.f;
+  float evparam[BATH_NEVPARAM];
+  float *d_rsc = nullptr;        // [(maxcodons+Kp)][pitch]
+  float *d_tf = nullptr;         // [(M+2)][8] forward-ordered transitions per node
+  float *d_tb = nullptr;         // [(M+2)][8] backward-ordered transitions per node
+  float *d_logsum = nullptr;     // [16000]
+  // length model: xsc[N|C|J][LOOP|MOVE] for L_amino, multihit (nj=1) and unihit (nj=0); host libm log()
+  mutable int maxL = -1;
+  mutable float *d_loop[2] = {nullptr, nullptr}, *d_move[2] = {nullptr, nullptr};
+  int ensure_len(int maxL_amino) const;
+};
+
+namespace bath {
+
+constexpr int kLogsumTbl = 16000;
+
+struct FsDev {
+  int M, pitch, maxcodons;
+  const float *rsc, *tf, *tb, *logsum;
+};
+
+// p7_FLogsum (logsum.c:105-111): truncating table lookup, or the exact form (logsum.c:109)
+template <bool EXACT>
+__device__ __forceinline__ float flogsum(float a, float b, const float *tbl) {
+  const float mx = fmaxf(a, b), mn = fminf(a, b);
+  if (mn == -INFINITY || (mx - mn) >= 15.7f) return mx;
+  if (EXACT) return mx + log1pf(expf(mn - mx));
+  return mx + tbl[(int)((mx - mn) * 1000.f)];
+}
+
+template <bool EXACT>
+__device__ __forceinline__ float wave_logsum(float v, const float *tbl) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v = flogsum<EXACT>(v, __shfl_xor(v, d, 64), tbl);
+  return v;
+}
+
+__device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
+
+// D(i,k) = LS(M(i,k-1)+tMD(k-1), D(i,k-1)+tDD(k-1)) for this lane's nodes, chained across lanes.
+// md[c] = M(i,node_c)+tMD(node_c) and dd[c] = tDD(node_c) describe the step OUT of node c.
+// Returns D at the lane's nodes in Dout[]; the step into the lane's first node comes from the previous lane.
+template <int C, bool EXACT>
+__device__ __forceinline__ void d_chain_fwd(const float (&md)[C], const float (&dd)[C], float (&Dout)[C], int lane, const float *tbl) {
+  // lane function f(x) = LS(A, x + B): value handed to the next lane's first node
+  float A = -INFINITY, B = 0.f;
+#pragma unroll
+  for (int c = 0; c < C; c++) { A = flogsum<EXACT>(md[c], A + dd[c], tbl); B += dd[c]; }
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const float Ap = __shfl_up(A, d, 64), Bp = __shfl_up(B, d, 64);
+    if (lane >= d) { A = flogsum<EXACT>(A, Ap + B, tbl); B += Bp; }
+  }
+  float din = __shfl_up(A, 1, 64);
+  if (lane == 0) din = -INFINITY;
+  Dout[0] = din;
+#pragma unroll
+  for (int c = 1; c < C; c++) Dout[c] = flogsum<EXACT>(md[c - 1], Dout[c - 1] + dd[c - 1], tbl);
+}
+
+// ---------------------------------------------------------------------------------------------
+// 3-codon Forward parser.  Row convention of the reference's parser: IVX(i,k) collects the paths
+// leaving row i-2 (generic_fwdback_frameshift.c:562-569), so codon lengths 2,3,4 read IVX(i), IVX(i-1), IVX(i-2).
+// tf[node] = {tMM(k-1), tIM(k-1), tDM(k-1), tBM(k-1), tMD(k), tDD(k), tMI(k), tII(k)}
+// ---------------------------------------------------------------------------------------------
+template <int C, bool EXACT>
+__global__ __launch_bounds__(256) void fs3_fwd_kernel(SeqView dna, FsDev p, const float *__restrict__ loop_tab, const float *__restrict__ move_tab,
+                                                      float tEL, float tEM, float *__restrict__ sc, float *__restrict__ xmx, const int64_t *__restrict__ xmx_off) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  float *s_tbl = reinterpret_cast<float *>(lds);
+  float *s_tf = s_tbl + kLogsumTbl;
+  for (int i = threadIdx.x; i < kLogsumTbl; i += blockDim.x) s_tbl[i] = p.logsum[i];
+  for (int i = threadIdx.x; i < (p.M + 2) * 8; i += blockDim.x) s_tf[i] = p.tf[i];
+  __syncthreads();
+  const int M = p.M;
+  const int lane = threadIdx.x & 63;
+  const int64_t wid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+#define LS(a, b) flogsum<EXACT>((a), (b), s_tbl)
+  for (int64_t job = wid; job < dna.n; job += nw) {
+    const int L = dna.len[job];
+    const uint8_t *d = dna.data + dna.off[job];
+    float *xo = xmx ? xmx + xmx_off[job] : nullptr;
+    if (L < 3) { if (lane == 0) sc[job] = -INFINITY; continue; }
+    const float tNL = loop_tab[L / 3], tNM = move_tab[L / 3], tJL = tNL, tJM = tNM, tCL = tNL, tCM = tNM;
+    // rows i-1, i-2, i-3 of M/I/D (index 0 = most recent) and IVX(i-1), IVX(i-2)
+    float Mr[3][C], Ir[3][C], Dr[3][C], iv1[C], iv2[C];
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int c = 0; c < C; c++) Mr[r][c] = Ir[r][c] = Dr[r][c] = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < C; c++) iv1[c] = iv2[c] = -INFINITY;
+    // specials of rows i-1, i-2, i-3
+    float xN[3] = {0.f, 0.f, 0.f}, xJ[3] = {-INFINITY, -INFINITY, -INFINITY}, xC[3] = {-INFINITY, -INFINITY, -INFINITY}, xB[3] = {tNM, tNM, tNM};
+    if (xo && lane == 0) for (int i = 0; i < 2; i++) { xo[i * 5 + 0] = -INFINITY; xo[i * 5 + 1] = 0.f; xo[i * 5 + 2] = -INFINITY; xo[i * 5 + 3] = tNM; xo[i * 5 + 4] = -INFINITY; }
+    int u = 338, v = 338, w = 338, x = (d[0] < 4) ? d[0] : 338;       // p7P_MAXCODONS3 marks a degenerate nucleotide
+    float cL = -INFINITY, cL1 = -INFINITY, cL2 = -INFINITY;           // C(L), C(L-1), C(L-2) for the final score
+
+    for (int i = 2; i <= L; i++) {
+      u = v; v = w; w = x; x = (d[i - 1] < 4) ? d[i - 1] : 338;
+      const float *r2 = p.rsc + (size_t)imin(x * 84 + w * 21, 337) * p.pitch;
+      const float *r3 = p.rsc + (size_t)imin(x * 84 + w * 21 + v * 5 + 1, 336) * p.pitch;
+      const float *r4 = p.rsc + (size_t)imin(x * 84 + w * 21 + v * 5 + u + 2, 337) * p.pitch;
+      // values of row i-2 at node-1 for the lane's first node
+      float mIn = __shfl_up(Mr[1][C - 1], 1, 64), iIn = __shfl_up(Ir[1][C - 1], 1, 64), dIn = __shfl_up(Dr[1][C - 1], 1, 64);
+      if (lane == 0) mIn = iIn = dIn = -INFINITY;
+      float Mc[C], Ic[C], ivc[C], md[C], dd[C];
+      float eloc = -INFINITY;
+#pragma unroll
+      for (int c = 0; c < C; c++) {
+        const int node = lane * C + c + 1;
+        if (node <= M) {
+          const float4 ta = *reinterpret_cast<const float4 *>(s_tf + node * 8);
+          const float4 tb = *reinterpret_cast<const float4 *>(s_tf + node * 8 + 4);
+          const float m1 = (c == 0) ? mIn : Mr[1][c - 1], i1 = (c == 0) ? iIn : Ir[1][c - 1], d1 = (c == 0) ? dIn : Dr[1][c - 1];
+          float iv;
+          if (i == 2) iv = xB[1] + ta.w;                                           // row 2: IVX3(2,k) = B(0) + tBM (:503)
+          else iv = LS(m1 + ta.x, LS(i1 + ta.y, LS(d1 + ta.z, xB[1] + ta.w)));     // from row i-2, B(i-2)
+          ivc[c] = iv;
+          float mv = iv + r2[node];
+          if (i > 2) { mv = LS(mv, iv1[c] + r3[node]); mv = LS(mv, iv2[c] + r4[node]); }
+          Mc[c] = mv;
+          Ic[c] = (i > 2 && node < M) ? LS(Mr[2][c] + tb.z, Ir[2][c] + tb.w) : -INFINITY;
+          md[c] = mv + tb.x; dd[c] = tb.y;
+        } else { Mc[c] = -INFINITY; Ic[c] = -INFINITY; ivc[c] = -INFINITY; md[c] = -INFINITY; dd[c] = -INFINITY; }
+      }
+      float Dc[C];
+      d_chain_fwd<C, EXACT>(md, dd, Dc, lane, s_tbl);
+#pragma unroll
+      for (int c = 0; c < C; c++) {
+        const int node = lane * C + c + 1;
+        if (node <= M) eloc = LS(Mc[c], LS(Dc[c], eloc));
+        else Dc[c] = -INFINITY;
+      }
+      const float xE = wave_logsum<EXACT>(eloc, s_tbl);
+      float nN, nJ, nC, nB;
+      if (i == 2) { nN = 0.f; nJ = xE + tEL; nC = xE + tEM; }
+      else { nN = xN[2] + tNL; nJ = LS(xJ[2] + tJL, xE + tEL); nC = LS(xC[2] + tCL, xE + tEM); }
+      nB = LS(nN + tNM, nJ + tJM);
+      if (xo && lane == 0) { xo[i * 5 + 0] = xE; xo[i * 5 + 1] = nN; xo[i * 5 + 2] = nJ; xo[i * 5 + 3] = nB; xo[i * 5 + 4] = nC; }
+      xN[2] = xN[1]; xN[1] = xN[0]; xN[0] = nN;
+      xJ[2] = xJ[1]; xJ[1] = xJ[0]; xJ[0] = nJ;
+      xC[2] = xC[1]; xC[1] = xC[0]; xC[0] = nC;
+      xB[2] = xB[1]; xB[1] = xB[0]; xB[0] = nB;
+      cL2 = cL1; cL1 = cL; cL = nC;
+#pragma unroll
+      for (int c = 0; c < C; c++) {
+        Mr[2][c] = Mr[1][c]; Mr[1][c] = Mr[0][c]; Mr[0][c] = Mc[c];
+        Ir[2][c] = Ir[1][c]; Ir[1][c] = Ir[0][c]; Ir[0][c] = Ic[c];
+        Dr[2][c] = Dr[1][c]; Dr[1][c] = Dr[0][c]; Dr[0][c] = Dc[c];
+        iv2[c] = iv1[c]; iv1[c] = ivc[c];
+      }
+    }
+    if (lane == 0) sc[job] = LS(cL, LS(cL1 + tCL, cL2 + tCL)) + tCM;
+  }
+#undef LS
+}
+
+// ---------------------------------------------------------------------------------------------
+// 5-codon Forward, full matrix: fwd[(i*(M+1)+k)*8 + {D,I,C0..C5}], xmx[i*5 + {E,N,J,B,C}].
+// IVX(i,k) collects the paths leaving row i-1; codon length c reads IVX(i-c+1).
+// c5_compat selects the ring slot the generic reference reads for 5-nt codons.
+// ---------------------------------------------------------------------------------------------
+template <int C, bool EXACT>
+__global__ __launch_bounds__(256) void fs5_fwd_kernel(SeqView dna, FsDev p, const float *__restrict__ loop_tab, const float *__restrict__ move_tab,
+                                                      float tEL, float tEM, int c5_compat, float *__restrict__ sc,
+                                                      float *__restrict__ fwd, const int64_t *__restrict__ fwd_off, float *__restrict__ xmx, const int64_t *__restrict__ xmx_off) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  float *s_tbl = reinterpret_cast<float *>(lds);
+  float *s_tf = s_tbl + kLogsumTbl;
+  for (int i = threadIdx.x; i < kLogsumTbl; i += blockDim.x) s_tbl[i] = p.logsum[i];
+  for (int i = threadIdx.x; i < (p.M + 2) * 8; i += blockDim.x) s_tf[i] = p.tf[i];
+  __syncthreads();
+  const int M = p.M;
+  const int lane = threadIdx.x & 63;
+  const int64_t wid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+#define LS(a, b) flogsum<EXACT>((a), (b), s_tbl)
+  for (int64_t job = wid; job < dna.n; job += nw) {
+    const int L = dna.len[job];
+    const uint8_t *d = dna.data + dna.off[job];
+    float *fo = fwd + fwd_off[job];
+    float *xo = xmx + xmx_off[job];
+    if (L < 5) { if (lane == 0) sc[job] = -INFINITY; continue; }
+    const float tNL = loop_tab[L / 3], tNM = move_tab[L / 3], tJL = tNL, tJM = tNM, tCL = tNL, tCM = tNM;
+    float Mr[3][C], Ir[3][C], Dr1[C], iv[4][C];       // M,I of rows i-1..i-3 (C0 totals); D of row i-1; IVX(i-1..i-4)
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+      Mr[0][c] = Mr[1][c] = Mr[2][c] = Ir[0][c] = Ir[1][c] = Ir[2][c] = Dr1[c] = -INFINITY;
+      iv[0][c] = iv[1][c] = iv[2][c] = iv[3][c] = -INFINITY;
+    }
+    // row 0
+    for (int k = lane; k <= M; k += 64)
+#pragma unroll
+      for (int s = 0; s < 8; s++) fo[(size_t)k * 8 + s] = -INFINITY;
+    if (lane == 0) { xo[0] = -INFINITY; xo[1] = 0.f; xo[2] = -INFINITY; xo[3] = tNM; xo[4] = -INFINITY; }
+    float xN[3] = {0.f, 0.f, 0.f}, xJ[3] = {-INFINITY, -INFINITY, -INFINITY}, xC[3] = {-INFINITY, -INFINITY, -INFINITY};
+    float xBprev = tNM;
+    int t = 1367, u = 1367, v = 1367, w = 1367, x = 1367;
+    float cL = -INFINITY, cL1 = -INFINITY, cL2 = -INFINITY;
+
+    for (int i = 1; i <= L; i++) {
+      t = u; u = v; v = w; w = x; x = (d[i - 1] < 4) ? d[i - 1] : 1367;
+      const float *r1 = p.rsc + (size_t)imin(x * 341, 1366) * p.pitch;
+      const float *r2 = p.rsc + (size_t)imin(x * 341 + w * 85 + 1, 1365) * p.pitch;
+      const float *r3 = p.rsc + (size_t)imin(x * 341 + w * 85 + v * 21 + 2, 1364) * p.pitch;
+      const float *r4 = p.rsc + (size_t)imin(x * 341 + w * 85 + v * 21 + u * 5 + 3, 1365) * p.pitch;
+      const float *r5 = p.rsc + (size_t)imin(x * 341 + w * 85 + v * 21 + u * 5 + t + 4, 1366) * p.pitch;
+      float mIn = __shfl_up(Mr[0][C - 1], 1, 64), iIn = __shfl_up(Ir[0][C - 1], 1, 64), dIn = __shfl_up(Dr1[C - 1], 1, 64);
+      if (lane == 0) mIn = iIn = dIn = -INFINITY;
+      float Mc[C], Ic[C], ivc[C], md[C], dd[C];
+      float *row = fo + (size_t)i * (M + 1) * 8;
+      if (lane == 0) {
+#pragma unroll
+        for (int s = 0; s < 8; s++) row[s] = -INFINITY;
+      }
+#pragma unroll
+      for (int c = 0; c < C; c++) {
+        const int node = lane * C + c + 1;
+        if (node <= M) {
+          const float4 ta = *reinterpret_cast<const float4 *>(s_tf + node * 8);
+          const float4 tb = *reinterpret_cast<const float4 *>(s_tf + node * 8 + 4);
+          const float m1 = (c == 0) ? mIn : Mr[0][c - 1], i1 = (c == 0) ? iIn : Ir[0][c - 1], d1 = (c == 0) ? dIn : Dr1[c - 1];
+          float ivn;
+          if (i <= 2) ivn = xBprev + ta.w;                                          // rows 1,2: only B(i-1) enters (:109,:150)
+          else ivn = LS(m1 + ta.x, LS(i1 + ta.y, LS(d1 + ta.z, xBprev + ta.w)));
+          ivc[c] = ivn;
+          const float c1 = ivn + r1[node];
+          const float c2 = (i >= 2) ? iv[0][c] + r2[node] : -INFINITY;
+          const float c3 = (i >= 3) ? iv[1][c] + r3[node] : -INFINITY;
+          const float c4 = (i >= 4) ? iv[2][c] + r4[node] : -INFINITY;
+          const float c5 = (i >= 5) ? (c5_compat ? ivn : iv[3][c]) + r5[node] : -INFINITY;
+          float c0;
+          if (i == 1) c0 = c1;
+          else if (i == 2) c0 = LS(c1, c2);
+          else if (i < 5) c0 = LS(c1, LS(c2, LS(c3, c4)));
+          else c0 = LS(LS(c1, LS(c2, c3)), LS(c4, c5));
+          Mc[c] = c0;
+          Ic[c] = (i >= 3 && node < M) ? LS(Mr[2][c] + tb.z, Ir[2][c] + tb.w) : -INFINITY;
+          md[c] = c0 + tb.x; dd[c] = tb.y;
+          float *cell = row + (size_t)node * 8;
+          cell[1] = Ic[c]; cell[2] = c0; cell[3] = c1; cell[4] = c2; cell[5] = c3; cell[6] = c4; cell[7] = c5;
+        } else { Mc[c] = -INFINITY; Ic[c] = -INFINITY; ivc[c] = -INFINITY; md[c] = -INFINITY; dd[c] = -INFINITY; }
+      }
+      float Dc[C];
+      d_chain_fwd<C, EXACT>(md, dd, Dc, lane, s_tbl);
+      float eloc = -INFINITY;
+#pragma unroll
+      for (int c = 0; c < C; c++) {
+        const int node = lane * C + c + 1;
+        if (node <= M) { row[(size_t)node * 8] = Dc[c]; eloc = LS(Mc[c], LS(Dc[c], eloc)); }
+        else Dc[c] = -INFINITY;
+      }
+      const float xE = wave_logsum<EXACT>(eloc, s_tbl);
+      float nN, nJ, nC, nB;
+      if (i <= 2) { nN = 0.f; nJ = xE + tEL; nC = xE + tEM; nB = tNM; }           // :126-132, :166-167
+      else {
+        nN = xN[2] + tNL; nJ = LS(xJ[2] + tJL, xE + tEL); nC = LS(xC[2] + tCL, xE + tEM);
+        nB = LS(nN + tNM, nJ + tJM);
+      }
+      if (lane == 0) { xo[i * 5 + 0] = xE; xo[i * 5 + 1] = nN; xo[i * 5 + 2] = nJ; xo[i * 5 + 3] = nB; xo[i * 5 + 4] = nC; }
+      xN[2] = xN[1]; xN[1] = xN[0]; xN[0] = nN;
+      xJ[2] = xJ[1]; xJ[1] = xJ[0]; xJ[0] = nJ;
+      xC[2] = xC[1]; xC[1] = xC[0]; xC[0] = nC;
+      xBprev = nB;
+      cL2 = cL1; cL1 = cL; cL = nC;
+#pragma unroll
+      for (int c = 0; c < C; c++) {
+        Mr[2][c] = Mr[1][c]; Mr[1][c] = Mr[0][c]; Mr[0][c] = Mc[c];
+        Ir[2][c] = Ir[1][c]; Ir[1][c] = Ir[0][c]; Ir[0][c] = Ic[c];
+        Dr1[c] = Dc[c];
+        iv[3][c] = iv[2][c]; iv[2][c] = iv[1][c]; iv[1][c] = iv[0][c]; iv[0][c] = ivc[c];
+      }
+    }
+    if (lane == 0) sc[job] = LS(cL, LS(cL1 + tCL, cL2 + tCL)) + tCM;
+  }
+#undef LS
+}
+
+// ---------------------------------------------------------------------------------------------
+// Backward, both codon systems (NCOD = 3: parser, no matrix stored; NCOD = 5: full, 3 cells per node).
+// tb[node] = {tMD(k), tMI(k), tMM(k), tDD(k), tDM(k), tII(k), tIM(k), tBM(k-1)}
+// Row types follow the reference: rows without an emitted codon, "tail" rows with no i+3 row,
+// accumulate-left-to-right rows (L-3, L-4) and the main recursion (generic_fwdback_frameshift.c:1054-1323, 1442-1677).
+// ---------------------------------------------------------------------------------------------
+template <int C, int NCOD, bool EXACT>
+__global__ __launch_bounds__(256) void fs_bwd_kernel(SeqView dna, FsDev p, const float *__restrict__ loop_tab, const float *__restrict__ move_tab,
+                                                     float tEL, float tEM, float *__restrict__ sc,
+                                                     float *__restrict__ bck, const int64_t *__restrict__ bck_off, float *__restrict__ xmx, const int64_t *__restrict__ xmx_off) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  float *s_tbl = reinterpret_cast<float *>(lds);
+  float *s_tb = s_tbl + kLogsumTbl;
+  for (int i = threadIdx.x; i < kLogsumTbl; i += blockDim.x) s_tbl[i] = p.logsum[i];
+  for (int i = threadIdx.x; i < (p.M + 2) * 8; i += blockDim.x) s_tb[i] = p.tb[i];
+  __syncthreads();
+  constexpr bool FIVE = (NCOD == 5);
+  constexpr int DEG = FIVE ? 1367 : 338;
+  constexpr int NR = 5;                             // rows i+1..i+5 of M kept in registers
+  const int M = p.M;
+  const int lane = threadIdx.x & 63;
+  const int64_t wid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+#define LS(a, b) flogsum<EXACT>((a), (b), s_tbl)
+  for (int64_t job = wid; job < dna.n; job += nw) {
+    const int L = dna.len[job];
+    const uint8_t *d = dna.data + dna.off[job];
+    float *bo = bck ? bck + bck_off[job] : nullptr;
+    float *xo = xmx ? xmx + xmx_off[job] : nullptr;
+    if (L < 5) { if (lane == 0) sc[job] = -INFINITY; continue; }
+    const float tNL = loop_tab[L / 3], tNM = move_tab[L / 3], tJL = tNL, tJM = tNM, tCL = tNL, tCM = tNM;
+    float Mr[NR][C], Ir3[3][C];                     // M(i+1..i+5); I(i+1..i+3)
+#pragma unroll
+    for (int r = 0; r < NR; r++)
+#pragma unroll
+      for (int c = 0; c < C; c++) Mr[r][c] = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int c = 0; c < C; c++) Ir3[r][c] = -INFINITY;
+    float xN3[3] = {-INFINITY, -INFINITY, -INFINITY}, xJ3[3] = {-INFINITY, -INFINITY, -INFINITY}, xC3[3] = {-INFINITY, -INFINITY, -INFINITY};
+    float n0 = -INFINITY, n1 = -INFINITY, n2 = -INFINITY;           // N(0), N(1), N(2)
+    const int first_emit = FIVE ? L - 1 : L - 2;
+    int t = DEG, u = DEG, v = DEG, w = DEG, x = DEG;
+    if (!FIVE) w = (d[L - 1] < 4) ? d[L - 1] : DEG;
+
+    for (int i = L; i >= 0; i--) {
+      float Mc[C], Ic[C], Dc[C];
+      float xE, xNn, xJn, xCn, xBn = -INFINITY;
+      if (i > first_emit) {
+        // rows before any codon can be emitted (:1054-1073, :1442-1465)
+        xCn = (i == L) ? tCM : tCL + tCM;
+        xJn = xNn = -INFINITY;
+        xE = xCn + tEM;
+        // D(i,k) = LS(E, D(i,k+1)+tDD(k)), M(i,k) = LS(E, D(i,k+1)+tMD(k)): reverse chain
+        float A = -INFINITY, B = 0.f;              // lane function applied to D(i, last node of lane + 1)
+#pragma unroll
+        for (int c = C - 1; c >= 0; c--) {
+          const int node = lane * C + c + 1;
+          const float tdd = (node < M) ? s_tb[node * 8 + 3] : -INFINITY;
+          if (node <= M) { A = (node == M) ? xE : LS(xE, A + tdd); B = (node == M) ? -INFINITY : B + tdd; }
+        }
+#pragma unroll
+        for (int dlt = 1; dlt < 64; dlt <<= 1) {
+          const float An = __shfl_down(A, dlt, 64), Bn = __shfl_down(B, dlt, 64);
+          if (lane + dlt < 64) { A = LS(A, An + B); B += Bn; }
+        }
+        float dnext = __shfl_down(A, 1, 64);
+        if (lane == 63) dnext = -INFINITY;
+#pragma unroll
+        for (int c = C - 1; c >= 0; c--) {
+          const int node = lane * C + c + 1;
+          if (node > M) { Mc[c] = Ic[c] = Dc[c] = -INFINITY; continue; }
+          const float dn = (c == C - 1) ? dnext : Dc[c + 1];
+          if (node == M) { Mc[c] = Dc[c] = xE; }
+          else { Mc[c] = LS(xE, dn + s_tb[node * 8 + 0]); Dc[c] = LS(xE, dn + s_tb[node * 8 + 3]); }
+          Ic[c] = -INFINITY;
+        }
+      } else {
+        if (FIVE || i < first_emit) { t = u; u = v; v = w; w = x; }
+        x = (d[i] < 4) ? d[i] : DEG;                // x_{i+1}
+        const int avail = L - i;
+        const bool mainrow = (i <= L - 5);
+        const bool tail = (avail < 3);
+        const float *r1 = nullptr, *r2 = nullptr, *r3 = nullptr, *r4 = nullptr, *r5 = nullptr;
+        if (FIVE) {
+          r1 = p.rsc + (size_t)imin(x * 341, 1366) * p.pitch;                                          // C1(x): x is the only (and last) base
+          // reversed argument order: the codon's LAST base is the oldest one in the window (:1260-1270)
+          if (avail >= 2) r2 = p.rsc + (size_t)imin(w * 341 + x * 85 + 1, 1365) * p.pitch;
+          if (avail >= 3) r3 = p.rsc + (size_t)imin(v * 341 + w * 85 + x * 21 + 2, 1364) * p.pitch;
+          if (avail >= 4) r4 = p.rsc + (size_t)imin(u * 341 + v * 85 + w * 21 + x * 5 + 3, 1365) * p.pitch;
+          if (avail >= 5) r5 = p.rsc + (size_t)imin(t * 341 + u * 85 + v * 21 + w * 5 + x + 4, 1366) * p.pitch;
+        } else {
+          if (avail >= 2) r2 = p.rsc + (size_t)imin(w * 84 + x * 21, 337) * p.pitch;
+          if (avail >= 3) r3 = p.rsc + (size_t)imin(v * 84 + w * 21 + x * 5 + 1, 336) * p.pitch;
+          if (avail >= 4) r4 = p.rsc + (size_t)imin(u * 84 + v * 21 + w * 5 + x + 2, 337) * p.pitch;
+        }
+        // ivx[k] = logsum_c M(i+c,k)+e_c(k);  B(i) = logsum_k ivx[k]+tBM(k-1)
+        float ivx[C];
+        float bloc = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+          const int node = lane * C + c + 1;
+          if (node > M) { ivx[c] = -INFINITY; continue; }
+          float a;
+          if (FIVE) {
+            if (mainrow) a = LS(Mr[0][c] + r1[node], LS(Mr[1][c] + r2[node], LS(Mr[2][c] + r3[node], LS(Mr[3][c] + r4[node], Mr[4][c] + r5[node]))));
+            else {
+              a = Mr[0][c] + r1[node];
+              if (avail >= 2) a = LS(a, Mr[1][c] + r2[node]);
+              if (avail >= 3) a = LS(a, Mr[2][c] + r3[node]);
+              if (avail >= 4) a = LS(a, Mr[3][c] + r4[node]);
+            }
+          } else {
+            if (mainrow) a = LS(Mr[1][c] + r2[node], LS(Mr[2][c] + r3[node], Mr[3][c] + r4[node]));
+            else {
+              a = Mr[1][c] + r2[node];
+              if (avail >= 3) a = LS(a, Mr[2][c] + r3[node]);
+              if (avail >= 4) a = LS(a, Mr[3][c] + r4[node]);
+            }
+          }
+          ivx[c] = a;
+          bloc = LS(bloc, a + s_tb[node * 8 + 7]);
+        }
+        xBn = wave_logsum<EXACT>(bloc, s_tbl);
+        if (i == 0) {
+          n0 = LS(xN3[2] + tNL, xBn + tNM);
+          if (xo && lane == 0) { xo[0] = -INFINITY; xo[1] = n0; xo[2] = -INFINITY; xo[3] = xBn; xo[4] = -INFINITY; }
+          if (bo) for (int k = lane; k <= M; k += 64) { bo[(size_t)k * 3] = bo[(size_t)k * 3 + 1] = bo[(size_t)k * 3 + 2] = -INFINITY; }
+          break;
+        }
+        if (tail) { xJn = xBn + tJM; xNn = xBn + tNM; xCn = tCL + tCM; }
+        else { xJn = LS(xJ3[2] + tJL, xBn + tJM); xCn = xC3[2] + tCL; xNn = LS(xN3[2] + tNL, xBn + tNM); }
+        xE = LS(xJn + tEL, xCn + tEM);
+        // ivx at node+1 for every node of the lane
+        float ivNext = __shfl_down(ivx[0], 1, 64);
+        if (lane == 63) ivNext = -INFINITY;
+        // D chain (descending): D(k) = LS(LS(E, D(k+1)+tDD(k)), ivx(k+1)+tDM(k)); a(k) := LS(E, ivx(k+1)+tDM(k)) up to association
+        float A = -INFINITY, B = 0.f;
+        float base[C];
+#pragma unroll
+        for (int c = C - 1; c >= 0; c--) {
+          const int node = lane * C + c + 1;
+          if (node > M) { base[c] = -INFINITY; continue; }
+          const float ivn = (c == C - 1) ? ivNext : ivx[c + 1];
+          const float tdd = s_tb[node * 8 + 3], tdm = s_tb[node * 8 + 4];
+          if (node == M) { base[c] = xE; A = xE; B = -INFINITY; }
+          else {
+            base[c] = ivn + tdm;
+            A = (!FIVE && !mainrow && !tail) ? LS(A + tdd, LS(xE, base[c])) : LS(LS(xE, A + tdd), base[c]);
+            B += tdd;
+          }
+        }
+#pragma unroll
+        for (int dlt = 1; dlt < 64; dlt <<= 1) {
+          const float An = __shfl_down(A, dlt, 64), Bn = __shfl_down(B, dlt, 64);
+          if (lane + dlt < 64) { A = LS(A, An + B); B += Bn; }
+        }
+        float dnext = __shfl_down(A, 1, 64);
+        if (lane == 63) dnext = -INFINITY;
+#pragma unroll
+        for (int c = C - 1; c >= 0; c--) {
+          const int node = lane * C + c + 1;
+          if (node > M) { Mc[c] = Ic[c] = Dc[c] = -INFINITY; continue; }
+          if (node == M) { Mc[c] = Dc[c] = xE; Ic[c] = -INFINITY; continue; }
+          const float dn = (c == C - 1) ? dnext : Dc[c + 1];
+          const float ivn = (c == C - 1) ? ivNext : ivx[c + 1];
+          const float tmd = s_tb[node * 8 + 0], tmi = s_tb[node * 8 + 1], tmm = s_tb[node * 8 + 2], tdd = s_tb[node * 8 + 3];
+          const float tii = s_tb[node * 8 + 5], tim = s_tb[node * 8 + 6];
+          if (tail) {
+            Mc[c] = LS(dn + tmd, LS(ivn + tmm, xE));
+            Dc[c] = LS(LS(xE, dn + tdd), base[c]);
+            Ic[c] = ivn + tim;
+          } else if (!FIVE && !mainrow) {
+            Mc[c] = LS(dn + tmd, LS(Ir3[2][c] + tmi, LS(ivn + tmm, xE)));
+            Dc[c] = LS(dn + tdd, LS(xE, base[c]));
+            Ic[c] = LS(Ir3[2][c] + tii, ivn + tim);
+          } else {
+            Mc[c] = LS(LS(dn + tmd, LS(Ir3[2][c] + tmi, ivn + tmm)), xE);
+            Dc[c] = LS(LS(xE, dn + tdd), base[c]);
+            Ic[c] = LS(Ir3[2][c] + tii, ivn + tim);
+          }
+        }
+      }
+      // store row i
+      if (bo) {
+        float *row = bo + (size_t)i * (M + 1) * 3;
+        if (lane == 0) row[0] = row[1] = row[2] = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+          const int node = lane * C + c + 1;
+          if (node <= M) { row[(size_t)node * 3 + 0] = Dc[c]; row[(size_t)node * 3 + 1] = Ic[c]; row[(size_t)node * 3 + 2] = Mc[c]; }
+        }
+      }
+      if (xo && lane == 0) { xo[i * 5 + 0] = xE; xo[i * 5 + 1] = xNn; xo[i * 5 + 2] = xJn; xo[i * 5 + 3] = xBn; xo[i * 5 + 4] = xCn; }
+      if (i == 2) n2 = xNn;
+      if (i == 1) n1 = xNn;
+      xN3[2] = xN3[1]; xN3[1] = xN3[0]; xN3[0] = xNn;
+      xJ3[2] = xJ3[1]; xJ3[1] = xJ3[0]; xJ3[0] = xJn;
+      xC3[2] = xC3[1]; xC3[1] = xC3[0]; xC3[0] = xCn;
+#pragma unroll
+      for (int c = 0; c < C; c++) {
+#pragma unroll
+        for (int r = NR - 1; r > 0; r--) Mr[r][c] = Mr[r - 1][c];
+        Mr[0][c] = Mc[c];
+        Ir3[2][c] = Ir3[1][c]; Ir3[1][c] = Ir3[0][c]; Ir3[0][c] = Ic[c];
+      }
+    }
+    if (lane == 0) sc[job] = LS(n0, LS(n1, n2));
+  }
+#undef LS
+}
+
+// ---------------------------------------------------------------------------------------------
+// Posterior decoding in place on the Forward matrix (generic_decoding_frameshift.c:36-156), plus the
+// column sums null2 needs (generic_null2_frameshift.c:62-68) accumulated in the same pass.
+// One wave per envelope, rows in order.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fs5_decode_kernel(SeqView dna, int M, const float *__restrict__ loop_tab, const float *__restrict__ bcksc,
+                                                         float *__restrict__ fwd, const int64_t *__restrict__ fwd_off, float *__restrict__ fx, const int64_t *__restrict__ fx_off,
+                                                         const float *__restrict__ bck, const int64_t *__restrict__ bck_off, const float *__restrict__ bx,
+                                                         float *__restrict__ colsum /* [n][(M+1)*8 + 8] */) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t job = wid; job < dna.n; job += nw) {
+    const int L = dna.len[job];
+    if (L < 5) continue;
+    float *f = fwd + fwd_off[job];
+    float *x = fx + fx_off[job];
+    const float *b = bck + bck_off[job];
+    const float *y = bx + fx_off[job];
+    float *cs = colsum + (size_t)job * ((size_t)(M + 1) * 8 + 8);
+    const float overall = bcksc[job];
+    const float tL = loop_tab[L / 3];
+    float N0 = x[1], J0 = x[2], C0 = x[4], N1 = 0, N2 = 0, N3 = 0, J1 = 0, J2 = 0, J3 = 0, C1 = 0, C2 = 0, C3 = 0;
+    for (int k = lane; k < (M + 1) * 8; k += 64) f[k] = 0.f;
+    if (lane < 5) x[lane] = 0.f;
+    for (int i = 1; i <= L; i++) {
+      N3 = N2; N2 = N1; N1 = N0; J3 = J2; J2 = J1; J1 = J0; C3 = C2; C2 = C1; C1 = C0;
+      float *fr = f + (size_t)i * (M + 1) * 8;
+      const float *br = b + (size_t)i * (M + 1) * 3;
+      float dloc = 0.f;
+      if (lane == 0) for (int s = 0; s < 8; s++) fr[s] = 0.f;
+      for (int k = 1 + lane; k <= M; k += 64) {
+        const float bm = br[(size_t)k * 3 + 2], bi = br[(size_t)k * 3 + 1];
+        float *cell = fr + (size_t)k * 8;
+#pragma unroll
+        for (int c = 2; c < 8; c++) cell[c] = expf(cell[c] + bm - overall);
+        dloc += cell[2];
+        if (k < M) { cell[1] = expf(cell[1] + bi - overall); dloc += cell[1]; } else cell[1] = 0.f;
+        cell[0] = 0.f;
+      }
+      N0 = x[i * 5 + 1]; J0 = x[i * 5 + 2]; C0 = x[i * 5 + 4];
+      float pn, pc, pj;
+      if (i > 2) {
+        pn = expf(N3 + y[i * 5 + 1] + tL - overall);
+        pc = expf(C3 + y[i * 5 + 4] + tL - overall);
+        pj = expf(J3 + y[i * 5 + 2] + tL - overall);
+      } else { pn = expf(y[i * 5 + 1] - overall); pc = 0.f; pj = 0.f; }
+      float denom = wave_sum_f32(dloc) + ((i > 2) ? (pn + pj + pc) : pn);
+      denom = (float)(1.0 / (double)denom);
+      for (int k = 1 + lane; k <= M; k += 64) {
+        float *cell = fr + (size_t)k * 8;
+#pragma unroll
+        for (int c = 2; c < 8; c++) { cell[c] *= denom; cs[(size_t)k * 8 + c] += cell[c]; }
+        if (k < M) { cell[1] *= denom; cs[(size_t)k * 8 + 1] += cell[1]; }
+      }
+      pn *= denom; pc *= denom; pj *= denom;
+      if (lane == 0) {
+        x[i * 5 + 0] = 0.f; x[i * 5 + 3] = 0.f; x[i * 5 + 1] = pn; x[i * 5 + 4] = pc; x[i * 5 + 2] = pj;
+        float *xs = cs + (size_t)(M + 1) * 8;
+        xs[1] += pn; xs[2] += pj; xs[4] += pc;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Optimal-accuracy fill (generic_optacc_frameshift.c:53-324): max-sum over posteriors.  TSCDELTA is 1 for a
+// possible transition and FLT_MIN for an impossible one.  oa[(i*(M+1)+k)*3 + {D,I,M}], xmx in ox.
+// The D row is a running maximum along the model: an exact wavefront scan (max is associative).
+// ---------------------------------------------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(256) void fs5_oa_kernel(SeqView dna, int M, const float *__restrict__ tf /* forward-ordered log transitions */,
+                                                     const float *__restrict__ pp, const int64_t *__restrict__ pp_off, const float *__restrict__ px, const int64_t *__restrict__ px_off,
+                                                     float *__restrict__ oa, const int64_t *__restrict__ oa_off, float *__restrict__ oasc, float ej, float ec) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  float *s_dl = reinterpret_cast<float *>(lds);                 // [(M+2)][8] deltas, same order as tf
+  for (int i = threadIdx.x; i < (M + 2) * 8; i += blockDim.x) s_dl[i] = (tf[i] == -INFINITY) ? 1.17549435e-38f : 1.0f;
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int64_t wid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t job = wid; job < dna.n; job += nw) {
+    const int L = dna.len[job];
+    if (L < 5) { if (lane == 0) oasc[job] = -INFINITY; continue; }
+    const float *P = pp + pp_off[job];
+    const float *X = px + px_off[job];
+    float *O = oa + oa_off[job];
+    // rows i-1..i-5 of M, I, D and B; rows i-1..i-3 of N, J, C
+    float Mr[5][C], Ir[5][C], Dr[5][C];
+#pragma unroll
+    for (int r = 0; r < 5; r++)
+#pragma unroll
+      for (int c = 0; c < C; c++) Mr[r][c] = Ir[r][c] = Dr[r][c] = -INFINITY;
+    float Bh[5] = {0.f, -INFINITY, -INFINITY, -INFINITY, -INFINITY};      // B(i-1) ... ; B(0) = 0
+    float Nh[3] = {0.f, 0.f, 0.f}, Jh[3] = {-INFINITY, -INFINITY, -INFINITY}, Ch[3] = {-INFINITY, -INFINITY, -INFINITY};
+    float cL = -INFINITY, cL1 = -INFINITY, cL2 = -INFINITY;
+    for (int k = lane; k <= M; k += 64) { O[(size_t)k * 3] = O[(size_t)k * 3 + 1] = O[(size_t)k * 3 + 2] = -INFINITY; }
+    for (int i = 1; i <= L; i++) {
+      const float *pr = P + (size_t)i * (M + 1) * 8;
+      float *orow = O + (size_t)i * (M + 1) * 3;
+      if (lane == 0) orow[0] = orow[1] = orow[2] = -INFINITY;
+      float mIn[5], iIn[5], dIn[5];
+#pragma unroll
+      for (int r = 0; r < 5; r++) {
+        mIn[r] = __shfl_up(Mr[r][C - 1], 1, 64); iIn[r] = __shfl_up(Ir[r][C - 1], 1, 64); dIn[r] = __shfl_up(Dr[r][C - 1], 1, 64);
+        if (lane == 0) mIn[r] = iIn[r] = dIn[r] = -INFINITY;
+      }
+      float Mc[C], Ic[C], am[C], bm[C];
+      float eloc = -INFINITY;
+#pragma unroll
+      for (int c = 0; c < C; c++) {
+        const int node = lane * C + c + 1;
+        if (node > M) { Mc[c] = Ic[c] = -INFINITY; am[c] = -INFINITY; bm[c] = 1.0f; continue; }
+        const float dMM = s_dl[node * 8 + 0], dIM = s_dl[node * 8 + 1], dDM = s_dl[node * 8 + 2], dBM = s_dl[node * 8 + 3];
+        const float dMD = s_dl[node * 8 + 4], dDD = s_dl[node * 8 + 5], dMI = s_dl[node * 8 + 6], dII = s_dl[node * 8 + 7];
+        const float *cell = pr + (size_t)node * 8;
+        float best;
+        if (i == 1) best = dBM * cell[3];
+        else {
+          float mx[6];
+          const int cmax = (i >= 5) ? 5 : (i == 2 ? 2 : (i == 4 ? 4 : 3));
+#pragma unroll
+          for (int cl = 1; cl <= 5; cl++) {
+            if (cl > cmax) { mx[cl] = -INFINITY; continue; }
+            const float pv = cell[2 + cl];
+            if ((i == 2 && cl == 2) || (i == 4 && cl == 4)) mx[cl] = dBM * (0.0f + pv);     // only B(0)=0 can precede
+            else {
+              const int r = cl - 1;
+              const float m1 = (c == 0) ? mIn[r] : Mr[r][c - 1], i1 = (c == 0) ? iIn[r] : Ir[r][c - 1], d1 = (c == 0) ? dIn[r] : Dr[r][c - 1];
+              mx[cl] = fmaxf(dMM * (m1 + pv), fmaxf(dIM * (i1 + pv), fmaxf(dDM * (d1 + pv), dBM * (Bh[r] + pv))));
+            }
+          }
+          if (i == 2) best = fmaxf(mx[1], mx[2]);
+          else if (i < 5) best = fmaxf(fmaxf(mx[1], mx[2]), fmaxf(mx[3], mx[4]));
+          else best = fmaxf(fmaxf(mx[1], mx[2]), fmaxf(fmaxf(mx[3], mx[4]), mx[5]));
+        }
+        Mc[c] = best;
+        Ic[c] = (i >= 3 && node < M) ? fmaxf(dMI * (Mr[2][c] + cell[1]), dII * (Ir[2][c] + cell[1])) : -INFINITY;
+        am[c] = dMD * best;                       // contribution to D(node+1) from M(node)
+        bm[c] = dDD;                              // multiplier on D(node) into D(node+1)
+        // NB tf[node] holds the transitions OUT of node for MD,DD (k) and INTO node for MM.. (k-1); the reference's
+        // D(i,k) uses TSCDELTA(MD,k-1), (DD,k-1): i.e. the out-of-(k-1) deltas, which is what am/bm of node k-1 are.
+      }
+      // D(node+1) = max(am(node), bm(node) * D(node)): scan of x -> max(A, B*x)
+      float A = -INFINITY, Bm = 1.0f;
+#pragma unroll
+      for (int c = 0; c < C; c++) { A = fmaxf(am[c], bm[c] * A); Bm *= bm[c]; }
+#pragma unroll
+      for (int dlt = 1; dlt < 64; dlt <<= 1) {
+        const float Ap = __shfl_up(A, dlt, 64), Bp = __shfl_up(Bm, dlt, 64);
+        if (lane >= dlt) { A = fmaxf(A, Bm * Ap); Bm *= Bp; }
+      }
+      float din = __shfl_up(A, 1, 64);
+      if (lane == 0) din = -INFINITY;
+      float Dc[C];
+      Dc[0] = din;
+#pragma unroll
+      for (int c = 1; c < C; c++) Dc[c] = fmaxf(am[c - 1], bm[c - 1] * Dc[c - 1]);
+#pragma unroll
+      for (int c = 0; c < C; c++) {
+        const int node = lane * C + c + 1;
+        if (node > M) { Dc[c] = -INFINITY; continue; }
+        orow[(size_t)node * 3 + 0] = Dc[c]; orow[(size_t)node * 3 + 1] = Ic[c]; orow[(size_t)node * 3 + 2] = Mc[c];
+        eloc = fmaxf(eloc, (node < M) ? Mc[c] : fmaxf(Mc[c], Dc[c]));
+      }
+      float xE = eloc;
+#pragma unroll
+      for (int dlt = 32; dlt >= 1; dlt >>= 1) xE = fmaxf(xE, __shfl_xor(xE, dlt, 64));
+      float nN, nJ, nC;
+      if (i <= 2) { nJ = ej * xE; nC = ec * xE; nN = X[i * 5 + 1]; }
+      else { nJ = fmaxf(Jh[2] + X[i * 5 + 2], ej * xE); nC = fmaxf(Ch[2] + X[i * 5 + 4], ec * xE); nN = Nh[2] + X[i * 5 + 1]; }
+      const float nB = fmaxf(nN, nJ);
+      Nh[2] = Nh[1]; Nh[1] = Nh[0]; Nh[0] = nN;
+      Jh[2] = Jh[1]; Jh[1] = Jh[0]; Jh[0] = nJ;
+      Ch[2] = Ch[1]; Ch[1] = Ch[0]; Ch[0] = nC;
+      Bh[4] = Bh[3]; Bh[3] = Bh[2]; Bh[2] = Bh[1]; Bh[1] = Bh[0]; Bh[0] = nB;
+      cL2 = cL1; cL1 = cL; cL = nC;
+#pragma unroll
+      for (int c = 0; c < C; c++) {
+#pragma unroll
+        for (int r = 4; r > 0; r--) { Mr[r][c] = Mr[r - 1][c]; Ir[r][c] = Ir[r - 1][c]; Dr[r][c] = Dr[r - 1][c]; }
+        Mr[0][c] = Mc[c]; Ir[0][c] = Ic[c]; Dr[0][c] = Dc[c];
+      }
+    }
+    if (lane == 0) oasc[job] = cL + cL1 + cL2;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// null2 (generic_null2_frameshift.c:70-125) from the column sums: 20 lanes, each runs the reference's serial
+// log-sum over the model for one residue, so the association is the reference's.
+// ---------------------------------------------------------------------------------------------
+__global__ void fs5_null2_kernel(int64_t n, const int32_t *__restrict__ len, int M, int pitch, const float *__restrict__ amino /* rsc + maxcodons*pitch */,
+                                 const float *__restrict__ logsum, const float *__restrict__ colsum, float *__restrict__ null2 /* [n][Kp] */) {
+  const int64_t job = blockIdx.x;
+  const int x = threadIdx.x;
+  if (job >= n) return;
+  const int Ld = len[job];
+  float *out = null2 + (size_t)job * kKp;
+  if (Ld < 5) { if (x < kKp) out[x] = 1.0f; return; }
+  const float *cs = colsum + (size_t)job * ((size_t)(M + 1) * 8 + 8);
+  const float *xs = cs + (size_t)(M + 1) * 8;
+  const float lld = (float)-log((double)(float)Ld);
+  __shared__ float res[20];
+  if (x < 20) {
+    float xf = (float)log((double)xs[1]) + lld;
+    xf = flogsum<false>(xf, (float)log((double)xs[4]) + lld, logsum);
+    xf = flogsum<false>(xf, (float)log((double)xs[2]) + lld, logsum);
+    float v = -INFINITY;
+    for (int k = 1; k < M; k++) {
+      v = flogsum<false>(v, ((float)log((double)cs[(size_t)k * 8 + 2]) + lld) + amino[(size_t)x * pitch + k], logsum);
+      v = flogsum<false>(v, (float)log((double)cs[(size_t)k * 8 + 1]) + lld, logsum);
+    }
+    v = flogsum<false>(v, ((float)log((double)cs[(size_t)M * 8 + 2]) + lld) + amino[(size_t)x * pitch + M], logsum);
+    v = flogsum<false>(v, xf, logsum);
+    res[x] = expf(v);
+    out[x] = res[x];
+  }
+  __syncthreads();
+  if (x == 0) {
+    // esl_abc_FAvgScVec: degenerate residues = plain mean over members; gap, '*', '~' = 1
+    const int mem[5][2] = {{2, 11}, {7, 9}, {3, 13}, {8, 8}, {1, 1}};
+    for (int dx = 0; dx < 5; dx++) {
+      const int a = mem[dx][0], b = mem[dx][1];
+      out[21 + dx] = (a == b) ? res[a] / 1.0f : ((a < b ? res[a] + res[b] : res[b] + res[a]) / 2.0f);
+    }
+    float s = 0.f;
+    for (int y = 0; y < 20; y++) s += res[y];
+    out[26] = s / 20.0f;
+    out[20] = 1.0f; out[27] = 1.0f; out[28] = 1.0f;
+  }
+}
+
+}  // namespace bath
+
+// =================================================================================================
+// host side
+// =================================================================================================
+
+int bath_hip_fsprofile::ensure_len(int maxL_amino) const {
+  if (maxL_amino <= maxL) return BATH_OK;
+  const int n = std::max(maxL_amino, 4096) + 1;
+  for (int h = 0; h < 2; h++) {
+    const float nj = (h == 0) ? 1.0f : 0.0f;                       // 0: multihit (parsers), 1: unihit (envelopes)
+    std::vector<float> lo(n), mv(n);
+    for (int L = 0; L < n; L++) {
+      const float pmove = (2.0f + nj) / ((float)L + 2.0f + nj);    // p7_fs_ReconfigLength, modelconfig.c:767-770
+      const float ploop = 1.0f - pmove;
+      lo[L] = (float)std::log((double)ploop); mv[L] = (float)std::log((double)pmove);
+    }
+    if (d_loop[h]) (void)hipFree(d_loop[h]);
+    if (d_move[h]) (void)hipFree(d_move[h]);
+    BATH_HIP_TRY(ctx, hipMalloc((void **)&d_loop[h], n * sizeof(float)));
+    BATH_HIP_TRY(ctx, hipMalloc((void **)&d_move[h], n * sizeof(float)));
+    BATH_HIP_TRY(ctx, hipMemcpy(d_loop[h], lo.data(), n * sizeof(float), hipMemcpyHostToDevice));
+    BATH_HIP_TRY(ctx, hipMemcpy(d_move[h], mv.data(), n * sizeof(float), hipMemcpyHostToDevice));
+  }
+  maxL = n - 1;
+  return BATH_OK;
+}
+
+extern "C" void bath_hip_fsprofile_destroy(bath_hip_fsprofile *om) {
+  if (!om) return;
+  for (void *p : {(void *)om->d_rsc, (void *)om->d_tf, (void *)om->d_tb, (void *)om->d_logsum, (void *)om->d_loop[0], (void *)om->d_loop[1],
+                  (void *)om->d_move[0], (void *)om->d_move[1]})
+    if (p) (void)hipFree(p);
+  delete om;
+}
+
+extern "C" int bath_hip_fsprofile_convert(bath_hip_ctx *ctx, const bath_fs_profile *gm, bath_hip_fsprofile **ret) {
+  *ret = nullptr;
+  BATH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const int M = gm->M;
+  bath_hip_fsprofile *om = new bath_hip_fsprofile();
+  om->ctx = ctx; om->M = M; om->codon_lengths = gm->codon_lengths; om->maxcodons = gm->maxcodons; om->max_length = gm->max_length;
+  om->fsprob = gm->fsprob;
+  std::memcpy(om->evparam, gm->evparam, sizeof om->evparam);
+  om->pitch = (M + 1 + 3) / 4 * 4;
+  const int nrows = gm->maxcodons + kKp;
+  std::vector<float> rsc((size_t)nrows * om->pitch, -INFINITY);
+  for (int r = 0; r < nrows; r++) std::memcpy(&rsc[(size_t)r * om->pitch], gm->rsc + (size_t)r * (M + 1), sizeof(float) * (M + 1));
+  enum { MM, IM, DM, BM, MD, DD, MI, II };
+  auto tsc = [&](int k, int s) -> float { return (k >= 0 && k < M) ? gm->tsc[(size_t)k * 8 + s] : -INFINITY; };
+  std::vector<float> tf((size_t)(M + 2) * 8, -INFINITY), tb((size_t)(M + 2) * 8, -INFINITY);
+  for (int k = 1; k <= M; k++) {
+    float *f = &tf[(size_t)k * 8];
+    f[0] = tsc(k - 1, MM); f[1] = tsc(k - 1, IM); f[2] = tsc(k - 1, DM); f[3] = tsc(k - 1, BM);
+    f[4] = tsc(k, MD); f[5] = tsc(k, DD); f[6] = tsc(k, MI); f[7] = tsc(k, II);
+    float *b = &tb[(size_t)k * 8];
+    b[0] = tsc(k, MD); b[1] = tsc(k, MI); b[2] = tsc(k, MM); b[3] = tsc(k, DD); b[4] = tsc(k, DM); b[5] = tsc(k, II); b[6] = tsc(k, IM);
+    b[7] = tsc(k - 1, BM);
+  }
+  std::vector<float> tbl(kLogsumTbl);
+  for (int i = 0; i < kLogsumTbl; i++) tbl[i] = (float)std::log(1. + std::exp((double)-i / 1000.f));     // p7_FLogsumInit, logsum.c:89
+  auto up = [&](float **dst, const std::vector<float> &src) -> hipError_t {
+    hipError_t e = hipMalloc((void **)dst, src.size() * sizeof(float) + 64);
+    if (e != hipSuccess) return e;
+    return hipMemcpy(*dst, src.data(), src.size() * sizeof(float), hipMemcpyHostToDevice);
+  };
+  BATH_HIP_TRY(ctx, up(&om->d_rsc, rsc));
+  BATH_HIP_TRY(ctx, up(&om->d_tf, tf));
+  BATH_HIP_TRY(ctx, up(&om->d_tb, tb));
+  BATH_HIP_TRY(ctx, up(&om->d_logsum, tbl));
+  int st = om->ensure_len(4096);
+  if (st != BATH_OK) { bath_hip_fsprofile_destroy(om); return st; }
+  *ret = om;
+  return BATH_OK;
+}
+
+namespace bath {
+
+static int fs_columns(int M) {
+  const int c = (M + 63) / 64;
+  for (int opt : {1, 2, 3, 4, 6, 8, 12, 16}) if (c <= opt) return opt;
+  return -1;
+}
+
+#define BATH_FS_SWITCH(Cv, BODY)                          \
+  switch (Cv) {                                           \
+    case 1: { constexpr int CC = 1; BODY } break;         \
+    case 2: { constexpr int CC = 2; BODY } break;         \
+    case 3: { constexpr int CC = 3; BODY } break;         \
+    case 4: { constexpr int CC = 4; BODY } break;         \
+    case 6: { constexpr int CC = 6; BODY } break;         \
+    case 8: { constexpr int CC = 8; BODY } break;         \
+    case 12: { constexpr int CC = 12; BODY } break;       \
+    case 16: { constexpr int CC = 16; BODY } break;       \
+    default: ctx->set_error("frameshift kernels support models up to 1024 nodes"); return BATH_EINVAL; \
+  }
+
+static FsDev fsdev(const bath_hip_fsprofile *om) { return FsDev{om->M, om->pitch, om->maxcodons, om->d_rsc, om->d_tf, om->d_tb, om->d_logsum}; }
+
+static int fs_grid(bath_hip_ctx *ctx, int64_t n) {
+  return (int)std::max<int64_t>(1, std::min<int64_t>((n + 3) / 4, (int64_t)ctx->prop.multiProcessorCount * 2));
+}
+
+template <class K>
+static int fs_set_shmem(bath_hip_ctx *ctx, K kernel, size_t shmem) {
+  if (shmem > 64 * 1024) BATH_HIP_TRY(ctx, hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+  return BATH_OK;
+}
+
+// xmx rows live in a device buffer laid out like the host array the caller passes (offsets in floats)
+static int upload_offsets(bath_hip_ctx *ctx, DevBuf &buf, const int64_t *off, int64_t n) {
+  BATH_HIP_TRY(ctx, buf.reserve((size_t)(n + 1) * sizeof(int64_t)));
+  BATH_HIP_TRY(ctx, hipMemcpyAsync(buf.p, off, (size_t)(n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+  return BATH_OK;
+}
+
+}  // namespace bath
+
+static int fs3_parser(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, const bath_hip_seqs *dna, int logsum_mode, float *sc, float *xmx,
+                      const int64_t *xmx_off, bool backward) {
+  if (!ctx || !om || !dna || om->codon_lengths != 3) { if (ctx) ctx->set_error("fs3 parser needs a 3-codon profile"); return BATH_EINVAL; }
+  BATH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const int64_t n = dna->n;
+  if (n == 0) return BATH_OK;
+  int st = om->ensure_len(dna->maxlen / 3 + 1);
+  if (st != BATH_OK) return st;
+  DevBuf &b_sc = ctx->scratch[12], &b_x = ctx->scratch[13], &b_off = ctx->scratch[14];
+  BATH_HIP_TRY(ctx, b_sc.reserve((size_t)n * sizeof(float)));
+  float *d_x = nullptr;
+  if (xmx) {
+    BATH_HIP_TRY(ctx, b_x.reserve((size_t)xmx_off[n] * sizeof(float) + 64));
+    if ((st = upload_offsets(ctx, b_off, xmx_off, n)) != BATH_OK) return st;
+    d_x = b_x.as<float>();
+  }
+  const int Cv = fs_columns(om->M);
+  const size_t shmem = (size_t)(kLogsumTbl + (om->M + 2) * 8) * sizeof(float);
+  const float tE = (float)-0.69314718055994529;
+  const int grid = fs_grid(ctx, n);
+  const bool exact = (logsum_mode == BATH_LOGSUM_EXACT);
+  BATH_FS_SWITCH(Cv, {
+    if (!backward) {
+      if (exact) { if ((st = fs_set_shmem(ctx, fs3_fwd_kernel<CC, true>, shmem)) != BATH_OK) return st;
+        hipLaunchKernelGGL((fs3_fwd_kernel<CC, true>), dim3(grid), dim3(256), shmem, ctx->stream, dna->view(), fsdev(om), om->d_loop[0], om->d_move[0], tE, tE, b_sc.as<float>(), d_x, b_off.as<int64_t>());
+      } else { if ((st = fs_set_shmem(ctx, fs3_fwd_kernel<CC, false>, shmem)) != BATH_OK) return st;
+        hipLaunchKernelGGL((fs3_fwd_kernel<CC, false>), dim3(grid), dim3(256), shmem, ctx->stream, dna->view(), fsdev(om), om->d_loop[0], om->d_move[0], tE, tE, b_sc.as<float>(), d_x, b_off.as<int64_t>());
+      }
+    } else {
+      if (exact) { if ((st = fs_set_shmem(ctx, fs_bwd_kernel<CC, 3, true>, shmem)) != BATH_OK) return st;
+        hipLaunchKernelGGL((fs_bwd_kernel<CC, 3, true>), dim3(grid), dim3(256), shmem, ctx->stream, dna->view(), fsdev(om), om->d_loop[0], om->d_move[0], tE, tE, b_sc.as<float>(), (float *)nullptr, (const int64_t *)nullptr, d_x, b_off.as<int64_t>());
+      } else { if ((st = fs_set_shmem(ctx, fs_bwd_kernel<CC, 3, false>, shmem)) != BATH_OK) return st;
+        hipLaunchKernelGGL((fs_bwd_kernel<CC, 3, false>), dim3(grid), dim3(256), shmem, ctx->stream, dna->view(), fsdev(om), om->d_loop[0], om->d_move[0], tE, tE, b_sc.as<float>(), (float *)nullptr, (const int64_t *)nullptr, d_x, b_off.as<int64_t>());
+      }
+    }
+  })
+  BATH_HIP_TRY(ctx, hipGetLastError());
+  BATH_HIP_TRY(ctx, hipMemcpyAsync(sc, b_sc.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  if (xmx) BATH_HIP_TRY(ctx, hipMemcpyAsync(xmx, d_x, (size_t)xmx_off[n] * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  BATH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return BATH_OK;
+}
+
+extern "C" int bath_hip_fs3_forward_parser(bath_hip_ctx *ctx, const bath_hip_fsprofile *om3, const bath_hip_seqs *dna, int logsum_mode,
+                                           float *sc, float *xmx, const int64_t *xmx_offsets) {
+  return fs3_parser(ctx, om3, dna, logsum_mode, sc, xmx, xmx_offsets, false);
+}
+extern "C" int bath_hip_fs3_backward_parser(bath_hip_ctx *ctx, const bath_hip_fsprofile *om3, const bath_hip_seqs *dna, int logsum_mode,
+                                            float *sc, float *xmx, const int64_t *xmx_offsets) {
+  return fs3_parser(ctx, om3, dna, logsum_mode, sc, xmx, xmx_offsets, true);
+}
+
+extern "C" int bath_hip_fs5_envelopes(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, const bath_hip_seqs *dna, int logsum_mode, int c5_compat,
+                                      bath_fs5_result *res, float *pp, const int64_t *pp_off_h, float *oa, const int64_t *oa_off_h) {
+  if (!ctx || !om || !dna || om->codon_lengths != 5) { if (ctx) ctx->set_error("fs5 envelopes need a 5-codon profile"); return BATH_EINVAL; }
+  BATH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const int64_t n = dna->n;
+  if (n == 0) return BATH_OK;
+  const int M = om->M;
+  int st = om->ensure_len(dna->maxlen / 3 + 1);
+  if (st != BATH_OK) return st;
+  // matrix layouts: fwd (L+1)*(M+1)*8, bck/oa (L+1)*(M+1)*3, xmx (L+1)*5
+  std::vector<int64_t> foff(n + 1, 0), boff(n + 1, 0), xoff(n + 1, 0);
+  for (int64_t i = 0; i < n; i++) {
+    const int64_t rows = (int64_t)dna->h_len[i] + 1;
+    foff[i + 1] = foff[i] + rows * (M + 1) * 8; boff[i + 1] = boff[i] + rows * (M + 1) * 3; xoff[i + 1] = xoff[i] + rows * 5;
+  }
+  DevBuf &b_f = ctx->scratch[15], &b_b = ctx->scratch[16], &b_o = ctx->scratch[17], &b_fx = ctx->scratch[18], &b_bx = ctx->scratch[19];
+  DevBuf &b_off = ctx->scratch[20], &b_sc = ctx->scratch[21], &b_cs = ctx->scratch[22], &b_n2 = ctx->scratch[23];
+  BATH_HIP_TRY(ctx, b_f.reserve((size_t)foff[n] * 4 + 64)); BATH_HIP_TRY(ctx, b_b.reserve((size_t)boff[n] * 4 + 64)); BATH_HIP_TRY(ctx, b_o.reserve((size_t)boff[n] * 4 + 64));
+  BATH_HIP_TRY(ctx, b_fx.reserve((size_t)xoff[n] * 4 + 64)); BATH_HIP_TRY(ctx, b_bx.reserve((size_t)xoff[n] * 4 + 64));
+  BATH_HIP_TRY(ctx, b_off.reserve((size_t)(n + 1) * 3 * sizeof(int64_t)));
+  BATH_HIP_TRY(ctx, b_sc.reserve((size_t)n * 3 * sizeof(float)));
+  const size_t cs_stride = (size_t)(M + 1) * 8 + 8;
+  BATH_HIP_TRY(ctx, b_cs.reserve((size_t)n * cs_stride * sizeof(float)));
+  BATH_HIP_TRY(ctx, b_n2.reserve((size_t)n * kKp * sizeof(float)));
+  int64_t *d_foff = b_off.as<int64_t>(), *d_boff = d_foff + (n + 1), *d_xoff = d_boff + (n + 1);
+  BATH_HIP_TRY(ctx, hipMemcpyAsync(d_foff, foff.data(), (n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+  BATH_HIP_TRY(ctx, hipMemcpyAsync(d_boff, boff.data(), (n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+  BATH_HIP_TRY(ctx, hipMemcpyAsync(d_xoff, xoff.data(), (n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+  float *d_fsc = b_sc.as<float>(), *d_bsc = d_fsc + n, *d_osc = d_bsc + n;
+  const int Cv = fs_columns(M);
+  const size_t shmem = (size_t)(kLogsumTbl + (M + 2) * 8) * sizeof(float);
+  const size_t oa_shmem = (size_t)(M + 2) * 8 * sizeof(float);
+  const int grid = fs_grid(ctx, n);
+  const bool exact = (logsum_mode == BATH_LOGSUM_EXACT);
+  const float tEL = -INFINITY, tEM = 0.0f;                                      // unihit: p7_fs_ReconfigUnihit, modelconfig.c:868
+  BATH_FS_SWITCH(Cv, {
+    if (exact) {
+      if ((st = fs_set_shmem(ctx, fs5_fwd_kernel<CC, true>, shmem)) != BATH_OK) return st;
+      if ((st = fs_set_shmem(ctx, fs_bwd_kernel<CC, 5, true>, shmem)) != BATH_OK) return st;
+      hipLaunchKernelGGL((fs5_fwd_kernel<CC, true>), dim3(grid), dim3(256), shmem, ctx->stream, dna->view(), fsdev(om), om->d_loop[1], om->d_move[1], tEL, tEM, c5_compat, d_fsc, b_f.as<float>(), d_foff, b_fx.as<float>(), d_xoff);
+      hipLaunchKernelGGL((fs_bwd_kernel<CC, 5, true>), dim3(grid), dim3(256), shmem, ctx->stream, dna->view(), fsdev(om), om->d_loop[1], om->d_move[1], tEL, tEM, d_bsc, b_b.as<float>(), d_boff, b_bx.as<float>(), d_xoff);
+    } else {
+      if ((st = fs_set_shmem(ctx, fs5_fwd_kernel<CC, false>, shmem)) != BATH_OK) return st;
+      if ((st = fs_set_shmem(ctx, fs_bwd_kernel<CC, 5, false>, shmem)) != BATH_OK) return st;
+      hipLaunchKernelGGL((fs5_fwd_kernel<CC, false>), dim3(grid), dim3(256), shmem, ctx->stream, dna->view(), fsdev(om), om->d_loop[1], om->d_move[1], tEL, tEM, c5_compat, d_fsc, b_f.as<float>(), d_foff, b_fx.as<float>(), d_xoff);
+      hipLaunchKernelGGL((fs_bwd_kernel<CC, 5, false>), dim3(grid), dim3(256), shmem, ctx->stream, dna->view(), fsdev(om), om->d_loop[1], om->d_move[1], tEL, tEM, d_bsc, b_b.as<float>(), d_boff, b_bx.as<float>(), d_xoff);
+    }
+    BATH_HIP_TRY(ctx, hipMemsetAsync(b_cs.p, 0, (size_t)n * cs_stride * sizeof(float), ctx->stream));
+    hipLaunchKernelGGL(fs5_decode_kernel, dim3(grid), dim3(256), 0, ctx->stream, dna->view(), M, om->d_loop[1], d_bsc, b_f.as<float>(), d_foff, b_fx.as<float>(), d_xoff,
+                       b_b.as<float>(), d_boff, b_bx.as<float>(), b_cs.as<float>());
+    if ((st = fs_set_shmem(ctx, fs5_oa_kernel<CC>, oa_shmem)) != BATH_OK) return st;
+    hipLaunchKernelGGL((fs5_oa_kernel<CC>), dim3(grid), dim3(256), oa_shmem, ctx->stream, dna->view(), M, om->d_tf, b_f.as<float>(), d_foff, b_fx.as<float>(), d_xoff, b_o.as<float>(), d_boff, d_osc,
+                       1.17549435e-38f /* E->J impossible in unihit mode: TSCDELTA = FLT_MIN */, 1.0f);
+  })
+  hipLaunchKernelGGL(fs5_null2_kernel, dim3((unsigned)n), dim3(32), 0, ctx->stream, n, dna->d_len, M, om->pitch, om->d_rsc + (size_t)om->maxcodons * om->pitch, om->d_logsum,
+                     b_cs.as<float>(), b_n2.as<float>());
+  BATH_HIP_TRY(ctx, hipGetLastError());
+  std::vector<float> h_sc((size_t)n * 3), h_n2((size_t)n * kKp);
+  BATH_HIP_TRY(ctx, hipMemcpyAsync(h_sc.data(), d_fsc, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  BATH_HIP_TRY(ctx, hipMemcpyAsync(h_n2.data(), b_n2.p, (size_t)n * kKp * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  if (pp) BATH_HIP_TRY(ctx, hipMemcpyAsync(pp, b_f.p, (size_t)foff[n] * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  if (oa) BATH_HIP_TRY(ctx, hipMemcpyAsync(oa, b_o.p, (size_t)boff[n] * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  BATH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  for (int64_t i = 0; i < n; i++) {
+    res[i].fwdsc = h_sc[i]; res[i].bcksc = h_sc[n + i]; res[i].oasc = h_sc[2 * n + i];
+    std::memcpy(res[i].null2, &h_n2[(size_t)i * kKp], sizeof(float) * kKp);
+  }
+  (void)pp_off_h; (void)oa_off_h;
+  return BATH_OK;
+}

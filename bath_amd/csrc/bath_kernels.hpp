@@ -30,29 +30,44 @@ __device__ __forceinline__ int satu8(int v) { return min(max(v, 0), 255); }
 
 
 // ---- SSV: one DP row of the lane-per-target kernels ----------------------------------------------
+// Number system: the reference keeps each diagonal in signed bytes starting at -128 with saturating
+// subtraction (ssvfilter.c:130-141).  Here cells are int16 and the begin score is the int16 minimum,
+// so v_pk_sub_i16 with clamp IS "max(prev - cost, begin)": no separate floor operation.  A cell's value
+// relative to the begin score (v + 32768) equals the reference byte's distance from its begin score
+// as long as that distance is below 255 - bias - 128, beyond which the reference reports overflow anyway.
+constexpr int kSsvBegin = -32768;
+constexpr unsigned kSsvBeginPair = 0x80008000u;
+
 // One DP row for this lane: residue row <rowbase> (LDS byte address of the residue's cost row, already
 // offset to this lane's column tile).  <carry> holds, in its high half, the previous row's value of the
-// node just left of the tile: the constant begin score -128 for the first tile, otherwise the last node
-// of the neighbouring lane's tile (models longer than one lane's registers are split over G lanes).
+// node just left of the tile: the begin score for the first tile, otherwise the last node of the
+// neighbouring lane's tile (models longer than one lane's registers are split over G lanes).
+// 3 VALU ops per 2 cells: v_alignbit_b32, v_pk_sub_i16 clamp, v_pk_max_i16.
 template <int NR>
 __device__ __forceinline__ void ssv_row(s16x2 (&reg)[NR], s16x2 &xE, const char *rowbase, unsigned carry) {
-  const s16x2 fl = {-128, -128};
+  static_assert(NR % 4 == 0, "registers are consumed four at a time (one 16-byte LDS read)");
 #pragma unroll
-  for (int r = NR - 2; r >= 0; r -= 2) {
-    const int2 c = *reinterpret_cast<const int2 *>(rowbase + 4 * r);     // costs of nodes 2r+1..2r+4
-    const unsigned hi = __builtin_bit_cast(unsigned, reg[r + 1]);
-    const unsigned lo = __builtin_bit_cast(unsigned, reg[r]);
-    // nodes (2r+3, 2r+4) take the previous row's (2r+2, 2r+3)
-    s16x2 v = __builtin_bit_cast(s16x2, __builtin_amdgcn_alignbit(hi, lo, 16));
+  for (int r = NR - 4; r >= 0; r -= 4) {
+    // costs of nodes 2r+1 .. 2r+8: one ds_read_b128 (rows are 16-byte aligned, pitch/16 odd)
+    const int4 c = *reinterpret_cast<const int4 *>(rowbase + 4 * r);
+    const unsigned r3 = __builtin_bit_cast(unsigned, reg[r + 3]), r2 = __builtin_bit_cast(unsigned, reg[r + 2]);
+    const unsigned r1 = __builtin_bit_cast(unsigned, reg[r + 1]), r0 = __builtin_bit_cast(unsigned, reg[r]);
+    const unsigned rm = (r > 0) ? __builtin_bit_cast(unsigned, reg[r - 1]) : carry;
+    // node pair j takes the previous row's pair shifted by one node: (hi of the left register, lo of its own)
+    s16x2 v = __builtin_bit_cast(s16x2, __builtin_amdgcn_alignbit(r3, r2, 16));
+    v = __builtin_elementwise_sub_sat(v, __builtin_bit_cast(s16x2, c.w));
+    xE = __builtin_elementwise_max(xE, v);
+    reg[r + 3] = v;
+    v = __builtin_bit_cast(s16x2, __builtin_amdgcn_alignbit(r2, r1, 16));
+    v = __builtin_elementwise_sub_sat(v, __builtin_bit_cast(s16x2, c.z));
+    xE = __builtin_elementwise_max(xE, v);
+    reg[r + 2] = v;
+    v = __builtin_bit_cast(s16x2, __builtin_amdgcn_alignbit(r1, r0, 16));
     v = __builtin_elementwise_sub_sat(v, __builtin_bit_cast(s16x2, c.y));
-    v = __builtin_elementwise_max(v, fl);
     xE = __builtin_elementwise_max(xE, v);
     reg[r + 1] = v;
-    // nodes (2r+1, 2r+2) take (2r, 2r+1); node 0 is the constant begin score -128
-    const unsigned lo2 = (r > 0) ? __builtin_bit_cast(unsigned, reg[r - 1]) : carry;
-    v = __builtin_bit_cast(s16x2, __builtin_amdgcn_alignbit(lo, lo2, 16));
+    v = __builtin_bit_cast(s16x2, __builtin_amdgcn_alignbit(r0, rm, 16));
     v = __builtin_elementwise_sub_sat(v, __builtin_bit_cast(s16x2, c.x));
-    v = __builtin_elementwise_max(v, fl);
     xE = __builtin_elementwise_max(xE, v);
     reg[r] = v;
   }
@@ -61,13 +76,14 @@ __device__ __forceinline__ void ssv_row(s16x2 (&reg)[NR], s16x2 &xE, const char 
 // Per-row helpers for models split over G lanes (G = 1, 2, 4 or 8 adjacent lanes per target).
 template <int NR, int G>
 __device__ __forceinline__ unsigned ssv_carry(const s16x2 (&reg)[NR], int grank) {
-  if (G == 1) return 0xff80ff80u;
+  if (G == 1) return kSsvBeginPair;
   const unsigned up = (unsigned)__shfl_up((int)__builtin_bit_cast(unsigned, reg[NR - 1]), 1, 64);
-  return (grank == 0) ? 0xff80ff80u : up;
+  return (grank == 0) ? kSsvBeginPair : up;
 }
+// Maximum over the target's lanes, converted to the reference's signed-byte domain (begin score = -128).
 template <int G>
 __device__ __forceinline__ int ssv_group_max(s16x2 xE) {
-  int v = max((int)xE.x, (int)xE.y);
+  int v = max((int)xE.x, (int)xE.y) - kSsvBegin - 128;
 #pragma unroll
   for (int d = 1; d < G; d <<= 1) v = max(v, __shfl_xor(v, d, 64));
   return v;

@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void ssv_dna_kernel(SeqView dna, DnaTables tab
   const int Lw = wave_max_i32(ncod);
 
   s16x2 reg[NR];
-  const s16x2 fl = {-128, -128};
+  const s16x2 fl = {(short)kSsvBegin, (short)kSsvBegin};
 #pragma unroll
   for (int r = 0; r < NR; r++) reg[r] = fl;
   s16x2 xE = fl;
@@ -163,6 +163,13 @@ __global__ __launch_bounds__(256) void ssv_dna_kernel(SeqView dna, DnaTables tab
             cand.v[slot] = (int16_t)min(v, 32767); cand.off[slot] = (int64_t)off;
           } else atomicOr(&ctr->overflow, 1);
         }
+      }
+      // The stop codon's cost row (+32767 everywhere) returns every diagonal to the begin score unless a cell
+      // of this lane climbed past the int16 midpoint (a hit strong enough to be an overflow anyway): rare, so
+      // the explicit clear below is almost never executed.
+      if (max((int)xE.x, (int)xE.y) >= 0) {
+#pragma unroll
+        for (int r = 0; r < NR; r++) reg[r] = fl;
       }
       xE = fl; orf_len = 0;
     }
@@ -263,16 +270,23 @@ __global__ void f1_bias_kernel(Cand cand, int cand_cap, Counters *__restrict__ c
   }
 }
 
-// p7_SSVFilter_BATH (msvfilter.c:250-427): diagonal windows for strong MSV hits, lane per candidate.
-// dp scratch: one row of MP+1 bytes per thread.
-__global__ void ssv_bath_kernel(Cand cand, const Counters *__restrict__ ctr, const int32_t *__restrict__ todo, const uint8_t *__restrict__ pool,
-                                int M, const uint8_t *__restrict__ rb, int rb_stride, const uint8_t *__restrict__ ssv_scores,
-                                const uint8_t *__restrict__ tjb_tab, const float *__restrict__ nullsc_tab, MsvConsts mc, double invP_f1,
-                                uint8_t *__restrict__ scratch, int MP, WindowRec *__restrict__ wins, int win_cap, Counters *__restrict__ ctrw) {
+// p7_SSVFilter_BATH (msvfilter.c:250-427): diagonal windows for strong MSV hits, wave per candidate.
+// Lane l owns nodes l*C+1 .. l*C+C (byte arithmetic of the reference kept exactly).  When the row maximum
+// reaches the threshold, the reference scans its striped vectors q=0..Q-1, lanes 0..15 and keeps the strictly
+// greatest byte (msvfilter.c:358-366): i.e. the first maximal cell in that order, found here by a wave min
+// over the striped rank.
+template <int C>
+__global__ __launch_bounds__(256) void ssv_bath_kernel(Cand cand, const Counters *__restrict__ ctr, const int32_t *__restrict__ todo,
+                                                       const uint8_t *__restrict__ pool, int M, const uint8_t *__restrict__ rb, int rb_stride,
+                                                       const uint8_t *__restrict__ ssv_scores, const uint8_t *__restrict__ tjb_tab,
+                                                       const float *__restrict__ nullsc_tab, MsvConsts mc, double invP_f1,
+                                                       WindowRec *__restrict__ wins, int win_cap, Counters *__restrict__ ctrw) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
   const int ntodo = ctr->todo_ssvb;
   const int Q = max(2, ((M - 1) / 16) + 1);
-  uint8_t *dp = scratch + (size_t)(blockIdx.x * blockDim.x + threadIdx.x) * (MP + 1);
-  for (int job = blockIdx.x * blockDim.x + threadIdx.x; job < ntodo; job += gridDim.x * blockDim.x) {
+  for (int64_t job = wid; job < ntodo; job += nw) {
     const int c = todo[job];
     const int L = cand.len[c];
     const uint8_t *s = pool + cand.off[c];
@@ -282,28 +296,39 @@ __global__ void ssv_bath_kernel(Cand cand, const Counters *__restrict__ ctr, con
     const int tjbm = (uint8_t)((int8_t)tjb + (int8_t)mc.tbm);
     const int xB = satu8(mc.base - tjbm);
     int kmin = 1 << 30, kmax = 0;
-    for (int k = 0; k <= MP; k++) dp[k] = 0;
+    int dp[C];
+#pragma unroll
+    for (int k = 0; k < C; k++) dp[k] = 0;
     for (int i = 1; i <= L; i++) {
       const int x = min((int)s[i - 1], kKp - 1);
       const uint8_t *row = rb + (size_t)x * rb_stride;
+      int prev = __shfl_up(dp[C - 1], 1, 64);
+      if (lane == 0) prev = 0;
       int xE = 0;
-      for (int k = MP; k >= 1; k--) {
-        const int cost = (k <= M) ? (int)row[k] : 255;
-        int sv = max((int)dp[k - 1], xB);
+#pragma unroll
+      for (int k = 0; k < C; k++) {
+        const int node = lane * C + k + 1;
+        const int cost = (node <= M) ? (int)row[node] : 255;
+        int sv = max(prev, xB);
         sv = satu8(sv + mc.bias);
         sv = satu8(sv - cost);
+        prev = dp[k];
+        dp[k] = sv;
         xE = max(xE, sv);
-        dp[k] = (uint8_t)sv;
       }
+      xE = wave_max_i32(xE);
       if (xE >= sc_thresh) {
-        int end = -1, rem_sc = -1;
-        for (int q = 0; q < Q; q++)
-          for (int z = 0; z < 16; z++) {
-            const int k = q + Q * z + 1;
-            const int b = dp[k];
-            if (b >= sc_thresh && b > rem_sc && k <= M) { end = k; rem_sc = b; }
-          }
-        for (int k = 0; k <= MP; k++) dp[k] = 0;
+        int rank = 1 << 30;
+#pragma unroll
+        for (int k = 0; k < C; k++) {
+          const int node = lane * C + k + 1;
+          if (node <= M && dp[k] == xE) rank = min(rank, ((node - 1) % Q) * 16 + (node - 1) / Q);
+        }
+        rank = wave_min_i32(rank);
+        int end = (rank / 16) + Q * (rank % 16) + 1;
+        int rem_sc = xE;
+#pragma unroll
+        for (int k = 0; k < C; k++) dp[k] = 0;
         int start = end, target_end = i, target_start = i;
         int sc = rem_sc;
         while (rem_sc > mc.base - tjb - mc.tbm && start >= 1 && target_start >= 1) {
@@ -323,13 +348,15 @@ __global__ void ssv_bath_kernel(Cand cand, const Counters *__restrict__ ctr, con
         float ret = ((float)(max_sc - tjb) - (float)mc.base);
         ret /= mc.scale_b;
         ret = (float)((double)ret - 3.0);
-        const int slot = atomicAdd(&ctrw->win_count, 1);
-        if (slot < win_cap) wins[slot] = WindowRec{c, target_start, end, end - start + 1, ret};
+        if (lane == 0) {
+          const int slot = atomicAdd(&ctrw->win_count, 1);
+          if (slot < win_cap) wins[slot] = WindowRec{c, target_start, end, end - start + 1, ret};
+        }
         kmin = min(kmin, start); kmax = max(kmax, end);
         i = target_end;
       }
     }
-    cand.kminmax[2 * c] = kmin; cand.kminmax[2 * c + 1] = kmax;
+    if (lane == 0) { cand.kminmax[2 * c] = kmin; cand.kminmax[2 * c + 1] = kmax; }
   }
 }
 
@@ -571,7 +598,7 @@ extern "C" int bath_hip_pipeline_filters(bath_hip_ctx *ctx, const bath_hip_oprof
   std::vector<uint8_t> ssv_scores((size_t)(M + 1) * kKp, 0);
   bath_hip_oprofile_get_ssv_scores(om, ssv_scores.data());
 
-  DevBuf &b_tabs = ctx->scratch[8], &b_work = ctx->scratch[9], &b_scr = ctx->scratch[10];
+  DevBuf &b_tabs = ctx->scratch[8], &b_work = ctx->scratch[9];
   const size_t tabs_bytes = 8192 + emit.size() * 2 + 256 + ssv_scores.size() + 256 + 20 * 4 + 256;
   BATH_HIP_TRY(ctx, b_tabs.reserve(tabs_bytes));
   char *tp = b_tabs.as<char>();
@@ -614,7 +641,6 @@ extern "C" int bath_hip_pipeline_filters(bath_hip_ctx *ctx, const bath_hip_oprof
   const size_t ssv_shmem = (size_t)kSsvRows * om->ssv_row_bytes + 5832 + 64;
   const int64_t nstreams = nwin * 6;
   if (ssv_shmem > 160 * 1024) { ctx->set_error("model too long for the LDS-resident SSV cost table"); return BATH_EINVAL; }
-  const int MP = std::max(2, ((M - 1) / 16) + 1) * 16;
   const int dec_blocks = ctx->prop.multiProcessorCount * 4;
 
   std::vector<hipEvent_t> &ev = ctx->ev_pool;
@@ -626,8 +652,6 @@ extern "C" int bath_hip_pipeline_filters(bath_hip_ctx *ctx, const bath_hip_oprof
     size_t need = layout(W, nullptr, (int)cap, aa_cap);
     BATH_HIP_TRY(ctx, b_work.reserve(need + 4096));
     layout(W, b_work.as<char>(), (int)cap, aa_cap);
-    const size_t scr_bytes = (size_t)64 * 64 * (MP + 1);
-    BATH_HIP_TRY(ctx, b_scr.reserve(scr_bytes));
     BATH_HIP_TRY(ctx, hipMemsetAsync(W.ctr, 0, sizeof(Counters), ctx->stream));
     SeqView cv{W.pool, W.cand.off, W.cand.len, cap};
 
@@ -665,8 +689,23 @@ extern "C" int bath_hip_pipeline_filters(bath_hip_ctx *ctx, const bath_hip_oprof
     wa.d_filtersc = W.cand.filtersc; wa.d_ssv_scores = d_ssvsc; wa.d_wins = W.wins; wa.d_win_count = &W.ctr->win_count; wa.win_cap = W.win_cap;
     wa.d_kminmax = W.cand.kminmax;
     if ((st = launch_vit_wave(ctx, om, cv, W.todo_vit, cap, W.cand.vfsc, W.cand.vit_status, &wa, &W.ctr->todo_vit)) != BATH_OK) return st;
-    hipLaunchKernelGGL(ssv_bath_kernel, dim3(64), dim3(64), 0, ctx->stream, W.cand, W.ctr, W.todo_ssvb, W.pool, M, om->d_rb, om->rb_stride, d_ssvsc,
-                       om->lt.d_tjb, om->lt.d_nullsc, mc, invP_f1, b_scr.as<uint8_t>(), MP, W.wins, W.win_cap, W.ctr);
+    BATH_HIP_TRY(ctx, hipEventRecord(ev[e++], ctx->stream));
+    {
+      const int Cc = (M + 63) / 64;
+      int Cs = -1;
+      for (int opt : {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 52}) if (Cc <= opt) { Cs = opt; break; }
+#define BATH_SSVB_CASE(N)                                                                                                          \
+  case N:                                                                                                                          \
+    hipLaunchKernelGGL(ssv_bath_kernel<N>, dim3(wave_grid_blocks(ctx) / 4), dim3(256), 0, ctx->stream, W.cand, W.ctr, W.todo_ssvb, W.pool, M, \
+                       om->d_rb, om->rb_stride, d_ssvsc, om->lt.d_tjb, om->lt.d_nullsc, mc, invP_f1, W.wins, W.win_cap, W.ctr);    \
+    break;
+      switch (Cs) {
+        BATH_SSVB_CASE(1) BATH_SSVB_CASE(2) BATH_SSVB_CASE(3) BATH_SSVB_CASE(4) BATH_SSVB_CASE(6) BATH_SSVB_CASE(8)
+        BATH_SSVB_CASE(12) BATH_SSVB_CASE(16) BATH_SSVB_CASE(24) BATH_SSVB_CASE(32) BATH_SSVB_CASE(52)
+        default: ctx->set_error("model too long for the SSV window kernel"); return BATH_EINVAL;
+      }
+#undef BATH_SSVB_CASE
+    }
     BATH_HIP_TRY(ctx, hipGetLastError());
     BATH_HIP_TRY(ctx, hipEventRecord(ev[e++], ctx->stream));
     // 5. F2, local composition re-filter, optional plain Viterbi re-run
@@ -691,8 +730,8 @@ extern "C" int bath_hip_pipeline_filters(bath_hip_ctx *ctx, const bath_hip_oprof
       aa_cap = std::max<unsigned long long>(aa_cap * 2, hc.aa_bump + (1u << 20));
       continue;
     }
-    static const char *names[] = {"ssv_translate_f1", "materialize_classify_msv", "f1_bias", "viterbi_windows", "post_vit", "forward_final"};
-    static const int64_t launches[] = {1, 3, 1, 2, 3, 2};
+    static const char *names[] = {"ssv_translate_f1", "materialize_classify_msv", "f1_bias", "viterbi_windows", "ssv_windows", "post_vit", "forward_final"};
+    static const int64_t launches[] = {1, 3, 1, 1, 1, 3, 2};
     ctx->timings.clear();
     for (int i = 0; i + 1 < e; i++) {
       float ms = 0.f;

@@ -30,12 +30,17 @@ def sample_domain(rng, mat, cum=None):
 
 
 def reverse_translate(rng, aa, basic):
-    codons_of = [np.flatnonzero(basic == a) for a in range(20)]
-    out = np.empty(3 * len(aa), dtype=np.uint8)
-    for i, a in enumerate(aa):
-        c = int(rng.choice(codons_of[int(a)]))
-        out[3 * i], out[3 * i + 1], out[3 * i + 2] = c >> 4, (c >> 2) & 3, c & 3
-    return out
+    """Uniformly chosen synonymous codon per residue (vectorised)."""
+    table = np.zeros((20, 6), dtype=np.int64)
+    count = np.zeros(20, dtype=np.int64)
+    for a in range(20):
+        c = np.flatnonzero(basic == a)
+        table[a, : len(c)] = c
+        count[a] = len(c)
+    aa = np.asarray(aa, dtype=np.int64)
+    pick = (rng.random(len(aa)) * count[aa]).astype(np.int64)
+    c = table[aa, pick]
+    return np.stack([c >> 4, (c >> 2) & 3, c & 3], axis=1).reshape(-1).astype(np.uint8)
 
 
 def dna_windows(n_windows, length, seed, hmm=None, planted_frac=0.01, ncbi_table=1):

@@ -176,8 +176,7 @@ def lib():
         L.bo_gbackward_fs.argtypes = [u8p, C.c_int, C.POINTER(FsProfile), C.POINTER(Gmx), f32p]
         L.bo_gforward_parser_fs3.argtypes = [u8p, C.c_int, C.POINTER(FsProfile), C.POINTER(Gmx), f32p]
         L.bo_gbackward_parser_fs3.argtypes = [u8p, C.c_int, C.POINTER(FsProfile), C.POINTER(Gmx), f32p]
-        L.bo_gforward_parser_fs5.argtypes = [u8p, C.c_int, C.POINTER(FsProfile), C.POINTER(Gmx), C.c_int, f32p]
-        L.bo_gdecoding_fs.argtypes = [C.POINTER(FsProfile), C.POINTER(Gmx), C.POINTER(Gmx), C.POINTER(Gmx)]
+        L.bo_gdecoding_fs.argtypes = [C.POINTER(FsProfile), C.POINTER(Gmx), C.POINTER(Gmx)]
         L.bo_goptacc_fs.argtypes = [C.POINTER(FsProfile), C.POINTER(Gmx), C.POINTER(Gmx), f32p]
         L.bo_gnull2_fs.argtypes = [C.POINTER(FsProfile), C.POINTER(Gmx), f32p]
     _lib = L
