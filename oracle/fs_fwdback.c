@@ -285,6 +285,7 @@ static int backward_engine(const uint8_t *dsq, int L, const bo_fs_profile *gm, b
         else {
           a = M3(i+2,k) + r2[k];
           if (r3) a = LS(a, M3(i+3,k) + r3[k]);
+          if (r4) a = LS(a, M3(i+4,k) + r4[k]);                     /* row L-4 only (:1552-1553) */
         }
       }
       ivx[k] = a;

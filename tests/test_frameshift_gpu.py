@@ -1,0 +1,155 @@
+"""GPU parity of the frameshift kernels against the oracle's restatement of generic_*_frameshift.c.
+
+Tolerances.  The kernels use the same table-driven p7_FLogsum as the generic reference (every individual
+log-sum is identical) but sum along the model with wavefront scans, i.e. a different association of the
+same terms; with a 0.001-nat truncating table that moves a score by O(1e-3) nats.  The bar used here:
+  Forward/Backward scores: |gpu - oracle| <= 1e-4 * |oracle| + 5e-3 nats
+(the north star asks 1e-4 relative; the absolute floor covers scores near zero, where a relative bound on a
+table-quantised sum is meaningless; the reference's own SIMD-vs-generic tolerance is 1.0 nat, fwdback_fs.c:3189).
+In BATH_LOGSUM_EXACT mode the oracle is switched to exact log-sums too and the bound is 1e-4 relative + 1e-4.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import bath_amd as ba
+import common
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+
+
+def fs_windows(rng, model, n, with_degenerate=True):
+    """Reverse-translated model emissions with frameshift indels (+-1, +-2 nt) and in-frame stops, plus random DNA."""
+    out = []
+    for aa in common.emit_from_model(rng, model, n, flank=8):
+        nt = list(common.revtranslate(rng, aa, model.basic))
+        j = 6
+        while j < len(nt) - 6:
+            r = rng.random()
+            if r < 0.010:
+                del nt[j]
+            elif r < 0.020:
+                nt.insert(j, int(rng.integers(0, 4)))
+            elif r < 0.025:
+                del nt[j:j + 2]
+            elif r < 0.030:
+                nt[j:j] = [int(rng.integers(0, 4)), int(rng.integers(0, 4))]
+            elif r < 0.032:
+                nt[j:j + 3] = [3, 0, 0]          # TAA
+            j += 3
+        out.append(np.array(nt, dtype=np.uint8))
+    out += common.random_dna(rng, max(2, n // 4), 240)
+    if with_degenerate:
+        out += common.random_dna(rng, 2, 150, degenerate_frac=0.03)
+    out += [rng.integers(0, 4, size=L).astype(np.uint8) for L in (15, 16, 17, 47)]
+    return out
+
+
+@pytest.fixture(scope="module", params=["Caudal_act.bhmm", "2OG-FeII_Oxy_3.bhmm"])
+def setup(request, gpu_ctx):
+    path = ol.GOLDEN + "/" + request.param
+    model = ol.Model(path)
+    hmm = ba.HMM(path)
+    om3 = ba.FSOProfile(gpu_ctx, ba.FSProfile(hmm, 3))
+    om5 = ba.FSOProfile(gpu_ctx, ba.FSProfile(hmm, 5))
+    rng = np.random.default_rng(123)
+    wins = fs_windows(rng, model, 24)
+    return gpu_ctx, model, om3, om5, wins, ba.SeqBlock(gpu_ctx, wins)
+
+
+def oracle_fs3(model, wins, backward, exact=False):
+    L_ = ol.lib()
+    L_.bo_flogsum_set_exact(1 if exact else 0)
+    gm3 = model.fs(3)
+    L_.bo_fs_profile_reconfig_multihit(gm3, 100)
+    sc, xm = [], []
+    out = C.c_float()
+    for w in wins:
+        L = len(w)
+        d = ol.dsq_from(w)
+        L_.bo_fs_profile_reconfig_length(gm3, L // 3)
+        gx = L_.bo_gmx_create(model.M, L + 1, L, 3)
+        fn = L_.bo_gbackward_parser_fs3 if backward else L_.bo_gforward_parser_fs3
+        st = fn(ol.u8(d), L, gm3, gx, C.byref(out))
+        assert st == 0
+        sc.append(out.value)
+        xm.append(np.ctypeslib.as_array(gx.contents.xmx, shape=(L + 1, 5)).copy())
+        L_.bo_gmx_free(gx)
+    L_.bo_flogsum_set_exact(0)
+    return np.array(sc, np.float32), xm
+
+
+def close(a, b, rtol, atol):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    both_inf = np.isinf(a) & np.isinf(b) & (np.sign(a) == np.sign(b))
+    return bool(np.all(both_inf | (np.abs(a - b) <= atol + rtol * np.abs(b))))
+
+
+@pytest.mark.parametrize("mode,rtol,atol", [(ba.LOGSUM_TABLE, 1e-4, 5e-3), (ba.LOGSUM_EXACT, 1e-4, 1e-4)])
+def test_fs3_forward_parser(setup, mode, rtol, atol):
+    ctx, model, om3, om5, wins, blk = setup
+    sc, xm = ba.FS3ForwardParser(ctx, om3, blk, logsum=mode, want_xmx=True)
+    osc, oxm = oracle_fs3(model, wins, backward=False, exact=(mode == ba.LOGSUM_EXACT))
+    assert close(sc, osc, rtol, atol), np.abs(sc - osc).max()
+    for g, o in zip(xm, oxm):                      # special-state rows feed domain definition (p7_domaindef.c:320)
+        assert close(g[2:], o[2:], rtol, 4 * atol)
+
+
+@pytest.mark.parametrize("mode,rtol,atol", [(ba.LOGSUM_TABLE, 1e-4, 5e-3), (ba.LOGSUM_EXACT, 1e-4, 1e-4)])
+def test_fs3_backward_parser(setup, mode, rtol, atol):
+    ctx, model, om3, om5, wins, blk = setup
+    sc, xm = ba.FS3BackwardParser(ctx, om3, blk, logsum=mode, want_xmx=True)
+    osc, oxm = oracle_fs3(model, wins, backward=True, exact=(mode == ba.LOGSUM_EXACT))
+    assert close(sc, osc, rtol, atol), np.abs(sc - osc).max()
+    fsc = ba.FS3ForwardParser(ctx, om3, blk, logsum=mode)
+    assert close(fsc, sc, 1e-4, 2e-2)              # Forward == Backward (generic_fwdback_frameshift.c:2304 unit test: 0.001 with exact sums)
+
+
+def oracle_fs5(model, wins, c5_compat, exact=False):
+    L_ = ol.lib()
+    L_.bo_flogsum_set_exact(1 if exact else 0)
+    gm5 = model.fs(5)
+    res = []
+    f, b, e = C.c_float(), C.c_float(), C.c_float()
+    for w in wins:
+        L = len(w)
+        d = ol.dsq_from(w)
+        L_.bo_fs_profile_reconfig_unihit(gm5, L // 3)           # p7_domaindef.c:324, :1020
+        g8 = L_.bo_gmx_create(model.M, L + 1, L, 8)
+        g3 = L_.bo_gmx_create(model.M, L + 1, L, 3)
+        oa = L_.bo_gmx_create(model.M, L + 1, L, 3)
+        assert L_.bo_gforward_fs(ol.u8(d), L, gm5, g8, 1 if c5_compat else 0, C.byref(f)) == 0
+        assert L_.bo_gbackward_fs(ol.u8(d), L, gm5, g3, C.byref(b)) == 0
+        L_.bo_gdecoding_fs(gm5, g8, g3)
+        pp = np.ctypeslib.as_array(g8.contents.dp, shape=(L + 1, model.M + 1, 8)).copy()
+        L_.bo_goptacc_fs(gm5, g8, oa, C.byref(e))
+        oam = np.ctypeslib.as_array(oa.contents.dp, shape=(L + 1, model.M + 1, 3)).copy()
+        n2 = np.zeros(29, np.float32)
+        L_.bo_gnull2_fs(gm5, g8, ol.f32(n2))
+        res.append((f.value, b.value, e.value, n2, pp, oam))
+        for g in (g8, g3, oa):
+            L_.bo_gmx_free(g)
+    L_.bo_fs_profile_reconfig_multihit(gm5, 100)
+    L_.bo_flogsum_set_exact(0)
+    return res
+
+
+@pytest.mark.parametrize("c5_compat", [False, True])
+def test_fs5_envelopes(setup, c5_compat):
+    ctx, model, om3, om5, wins, blk = setup
+    env = [w for w in wins if len(w) >= 15]
+    eb = ba.SeqBlock(ctx, env)
+    got = ba.FS5Envelopes(ctx, om5, eb, logsum=ba.LOGSUM_TABLE, c5_compat=c5_compat, want_pp=True, want_oa=True)
+    ref = oracle_fs5(model, env, c5_compat)
+    fwd = np.array([r[0] for r in ref]); bwd = np.array([r[1] for r in ref]); oas = np.array([r[2] for r in ref])
+    assert close(got["fwdsc"], fwd, 1e-4, 5e-3), np.abs(got["fwdsc"] - fwd).max()
+    assert close(got["bcksc"], bwd, 1e-4, 5e-3), np.abs(got["bcksc"] - bwd).max()
+    for i, r in enumerate(ref):
+        pp, oa = got["pp"][i], got["oa"][i]
+        assert np.abs(pp[1:, 1:, 1:] - r[4][1:, 1:, 1:]).max() < 5e-3          # posteriors (decoding_fs.c:534 uses 0.001..0.2)
+        assert abs(got["oasc"][i] - r[2]) < 2e-2 + 1e-3 * abs(r[2])            # expected # of correct positions
+        assert np.allclose(got["null2"][i], r[3], rtol=5e-3, atol=1e-4)        # null2_fs.c:193 uses 0.001..0.2
+    if not c5_compat:
+        assert close(got["fwdsc"], got["bcksc"], 1e-4, 2e-2)                   # Forward == Backward
