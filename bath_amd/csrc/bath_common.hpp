@@ -124,6 +124,9 @@ struct bath_hip_oprofile {
   int16_t *d_tw = nullptr;      // [M+1][8]
   float *d_rf = nullptr, *d_tf = nullptr;
   float *d_bias_eo = nullptr;   // [Kp][2] emission odds of the 2-state bias filter HMM for om->compo
+  // lane-per-target Viterbi kernel tables (bath_viterbi.hip); vit_NR == 0 when the model is too long for it
+  int vit_NR = 0, vit_rw_pitch = 0;
+  int16_t *d_vit_rw = nullptr; uint32_t *d_vit_tw2 = nullptr; int32_t *d_vit_tdd = nullptr; int16_t *d_vit_rank = nullptr;
   mutable LenTables lt;
   int ensure_len_tables(int maxL) const;
 };

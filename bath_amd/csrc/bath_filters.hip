@@ -620,6 +620,14 @@ static int score_batch(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bat
 }
 
 extern "C" int bath_hip_vitfilter(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bath_hip_seqs *sq, float *sc, int32_t *status) {
+  if (vit_lane_supported(om) && sq && sq->n > 0) {       // lane-per-target kernel: targets sorted by length
+    int st0 = check_batch(ctx, om, sq);
+    if (st0 != BATH_OK) return st0;
+    DevBuf &b_order = ctx->scratch[0];
+    if ((st0 = length_order(ctx, sq, b_order)) != BATH_OK) return st0;
+    return score_batch(ctx, om, sq, sc, status, [&](float *d_sc, int32_t *d_st) {
+      return launch_vit_lane(ctx, om, sq->view(), b_order.as<int32_t>(), sq->n, nullptr, d_sc, d_st, nullptr); });
+  }
   return score_batch(ctx, om, sq, sc, status, [&](float *d_sc, int32_t *d_st) { return launch_vit_wave(ctx, om, sq->view(), nullptr, sq->n, d_sc, d_st, nullptr, nullptr); });
 }
 extern "C" int bath_hip_forward_parser(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bath_hip_seqs *sq, float *sc, int32_t *status) {

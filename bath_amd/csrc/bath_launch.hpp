@@ -30,6 +30,10 @@ int launch_fwd_wave(bath_hip_ctx *ctx, const bath_hip_oprofile *om, SeqView v, c
 int launch_bias_lane(bath_hip_ctx *ctx, const bath_hip_oprofile *om, SeqView v, const float *d_eo, int eo_stride, const int32_t *d_todo, int64_t ntodo,
                      float *d_nullsc, float *d_filtersc);
 
+int vit_lane_supported(const bath_hip_oprofile *om);
+int launch_len_sort(bath_hip_ctx *ctx, const int32_t *d_todo, const int *d_ntodo, const int32_t *d_len, int *d_bins, int32_t *d_sorted);
+int launch_vit_lane(bath_hip_ctx *ctx, const bath_hip_oprofile *om, SeqView v, const int32_t *d_todo, int64_t ntodo, const int *ntodo_dev,
+                    float *d_sc, int32_t *d_status, const VitWindowArgs *wa);
 struct MsvConsts;
 MsvConsts msv_consts(const bath_hip_oprofile *om);
 

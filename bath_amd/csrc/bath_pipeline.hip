@@ -527,7 +527,8 @@ struct PipelineWork {
   int cand_cap = 0;
   unsigned long long aa_cap = 0;
   uint8_t *pool = nullptr;
-  int32_t *todo_msv = nullptr, *todo_vit = nullptr, *todo_ssvb = nullptr, *todo_vit2 = nullptr, *todo_fwd = nullptr;
+  int32_t *todo_msv = nullptr, *todo_vit = nullptr, *todo_ssvb = nullptr, *todo_vit2 = nullptr, *todo_fwd = nullptr, *todo_sorted = nullptr;
+  int *len_bins = nullptr;
   WindowRec *wins = nullptr;
   int win_cap = 0;
   Counters *ctr = nullptr;
@@ -553,7 +554,8 @@ static size_t layout(PipelineWork &w, char *base, int cap, unsigned long long aa
   w.cand.vfsc = carve<float>(p, n); w.cand.fwdsc = carve<float>(p, n);
   w.cand.v = carve<int16_t>(p, n);
   w.todo_msv = carve<int32_t>(p, n); w.todo_vit = carve<int32_t>(p, n); w.todo_ssvb = carve<int32_t>(p, n);
-  w.todo_vit2 = carve<int32_t>(p, n); w.todo_fwd = carve<int32_t>(p, n);
+  w.todo_vit2 = carve<int32_t>(p, n); w.todo_fwd = carve<int32_t>(p, n); w.todo_sorted = carve<int32_t>(p, n);
+  w.len_bins = carve<int>(p, 2048);
   w.wins = carve<WindowRec>(p, (size_t)w.win_cap);
   w.pool = carve<uint8_t>(p, (size_t)aa_cap + 64);
   return (size_t)(p - base);
@@ -688,7 +690,10 @@ extern "C" int bath_hip_pipeline_filters(bath_hip_ctx *ctx, const bath_hip_oprof
     // 4. Viterbi filter with windows (P > F2) / SSV windows (P <= F2)
     wa.d_filtersc = W.cand.filtersc; wa.d_ssv_scores = d_ssvsc; wa.d_wins = W.wins; wa.d_win_count = &W.ctr->win_count; wa.win_cap = W.win_cap;
     wa.d_kminmax = W.cand.kminmax;
-    if ((st = launch_vit_wave(ctx, om, cv, W.todo_vit, cap, W.cand.vfsc, W.cand.vit_status, &wa, &W.ctr->todo_vit)) != BATH_OK) return st;
+    if (vit_lane_supported(om)) {       // lane per ORF, ORFs bucketed by length (bath_viterbi.hip)
+      if ((st = launch_len_sort(ctx, W.todo_vit, &W.ctr->todo_vit, W.cand.len, W.len_bins, W.todo_sorted)) != BATH_OK) return st;
+      if ((st = launch_vit_lane(ctx, om, cv, W.todo_sorted, cap, &W.ctr->todo_vit, W.cand.vfsc, W.cand.vit_status, &wa)) != BATH_OK) return st;
+    } else if ((st = launch_vit_wave(ctx, om, cv, W.todo_vit, cap, W.cand.vfsc, W.cand.vit_status, &wa, &W.ctr->todo_vit)) != BATH_OK) return st;
     BATH_HIP_TRY(ctx, hipEventRecord(ev[e++], ctx->stream));
     {
       const int Cc = (M + 63) / 64;
