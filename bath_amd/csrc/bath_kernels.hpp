@@ -39,35 +39,32 @@ constexpr int kSsvBegin = -32768;
 constexpr unsigned kSsvBeginPair = 0x80008000u;
 
 // One DP row for this lane: residue row <rowbase> (LDS byte address of the residue's cost row, already
-// offset to this lane's column tile).  <carry> holds, in its high half, the previous row's value of the
-// node just left of the tile: the begin score for the first tile, otherwise the last node of the
-// neighbouring lane's tile (models longer than one lane's registers are split over G lanes).
-// 3 VALU ops per 2 cells: v_alignbit_b32, v_pk_sub_i16 clamp, v_pk_max_i16.
+// offset to this lane's column tile).  Register r of a tile holds the tile's nodes r+1 (low half) and
+// NR+r+1 (high half), so "the previous row's value of the node to the left" is simply the previous
+// register: the diagonal shift is folded into the subtract's destination (registers are updated in
+// place, descending).  Only register 0 needs assembling: its low half takes the node left of the tile
+// (high half of <carry>: the begin score for the first tile, otherwise the last node of the neighbouring
+// lane's tile when a model is split over G lanes), its high half the old low half of register NR-1.
+// 2 VALU ops per 2 cells: v_pk_sub_i16 clamp, v_pk_max_i16.
 template <int NR>
 __device__ __forceinline__ void ssv_row(s16x2 (&reg)[NR], s16x2 &xE, const char *rowbase, unsigned carry) {
   static_assert(NR % 4 == 0, "registers are consumed four at a time (one 16-byte LDS read)");
+  const s16x2 wrap = __builtin_bit_cast(s16x2, __builtin_amdgcn_alignbit(__builtin_bit_cast(unsigned, reg[NR - 1]), carry, 16));
 #pragma unroll
   for (int r = NR - 4; r >= 0; r -= 4) {
-    // costs of nodes 2r+1 .. 2r+8: one ds_read_b128 (rows are 16-byte aligned, pitch/16 odd)
+    // costs of registers r .. r+3: one ds_read_b128 (rows are 16-byte aligned, pitch/16 odd).  Measured on MI355X:
+    // ds_read_b64 gathers (32 slots, conflict free) are slower here than ds_read_b128 with its 2-way conflicts.
     const int4 c = *reinterpret_cast<const int4 *>(rowbase + 4 * r);
-    const unsigned r3 = __builtin_bit_cast(unsigned, reg[r + 3]), r2 = __builtin_bit_cast(unsigned, reg[r + 2]);
-    const unsigned r1 = __builtin_bit_cast(unsigned, reg[r + 1]), r0 = __builtin_bit_cast(unsigned, reg[r]);
-    const unsigned rm = (r > 0) ? __builtin_bit_cast(unsigned, reg[r - 1]) : carry;
-    // node pair j takes the previous row's pair shifted by one node: (hi of the left register, lo of its own)
-    s16x2 v = __builtin_bit_cast(s16x2, __builtin_amdgcn_alignbit(r3, r2, 16));
-    v = __builtin_elementwise_sub_sat(v, __builtin_bit_cast(s16x2, c.w));
+    s16x2 v = __builtin_elementwise_sub_sat(reg[r + 2], __builtin_bit_cast(s16x2, c.w));
     xE = __builtin_elementwise_max(xE, v);
     reg[r + 3] = v;
-    v = __builtin_bit_cast(s16x2, __builtin_amdgcn_alignbit(r2, r1, 16));
-    v = __builtin_elementwise_sub_sat(v, __builtin_bit_cast(s16x2, c.z));
+    v = __builtin_elementwise_sub_sat(reg[r + 1], __builtin_bit_cast(s16x2, c.z));
     xE = __builtin_elementwise_max(xE, v);
     reg[r + 2] = v;
-    v = __builtin_bit_cast(s16x2, __builtin_amdgcn_alignbit(r1, r0, 16));
-    v = __builtin_elementwise_sub_sat(v, __builtin_bit_cast(s16x2, c.y));
+    v = __builtin_elementwise_sub_sat(reg[r], __builtin_bit_cast(s16x2, c.y));
     xE = __builtin_elementwise_max(xE, v);
     reg[r + 1] = v;
-    v = __builtin_bit_cast(s16x2, __builtin_amdgcn_alignbit(r0, rm, 16));
-    v = __builtin_elementwise_sub_sat(v, __builtin_bit_cast(s16x2, c.x));
+    v = __builtin_elementwise_sub_sat((r > 0) ? reg[r - 1] : wrap, __builtin_bit_cast(s16x2, c.x));
     xE = __builtin_elementwise_max(xE, v);
     reg[r] = v;
   }

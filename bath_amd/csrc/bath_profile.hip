@@ -217,20 +217,25 @@ extern "C" int bath_hip_oprofile_convert(bath_hip_ctx *ctx, const bath_profile *
 
   // ---- device layouts
   // SSV: signed costs sb = min(rb - bias, 127) (sf_conversion) as int16, one row per residue plus a
-  // "reset" row; columns 1..M real, padded with +127 up to 2*NR*G.  Row pitch is 16-byte aligned with
-  // (pitch/16) odd so that lanes holding different residues spread over the LDS banks on ds_read_b128.
+  // "reset" row; columns 1..M real, padded with +127 up to 2*NR*G.  Row pitch is an odd multiple of 16 bytes so
+  // that lanes holding different residues spread over the 16 sixteen-byte LDS slots on ds_read_b128.
   int G = 1;
   while (G < 8 && M > 416 * G) G *= 2;                        // up to 208 registers (416 nodes) per lane
   if (M > 416 * G) { ctx->set_error("model longer than 3328 nodes"); delete om; return BATH_EINVAL; }
-  int NR = (((M + G - 1) / G + 1) / 2 + 15) / 16 * 16;
-  if (G > 1) NR = std::max(NR, 112);
+  int NR = ((M + G - 1) / G + 1) / 2;
+  NR = (G == 1 && NR <= 112) ? (NR + 3) / 4 * 4 : (NR + 15) / 16 * 16;   // the shapes of BATH_SSV_SHAPES
+  NR = std::max(NR, G > 1 ? 112 : 16);
   om->NR = NR; om->G = G;
-  om->ssv_row_bytes = 4 * NR * G + 16;                        // 16-byte aligned rows, (pitch/16) odd
+  om->ssv_row_bytes = 16 * ((NR * G / 4 + 1) | 1);            // 16-byte aligned rows, (pitch/16) odd
   {
     size_t rowsz = (size_t)om->ssv_row_bytes / 2;
     std::vector<int16_t> tab((size_t)kSsvRows * rowsz, 32767);   // padding nodes and the reset row: cost +32767
+    // node k -> lane tile g = (k-1)/(2NR); inside the tile, register r = (k-1)%NR, half (k-1)/NR%2 (see ssv_row)
     for (int x = 0; x < kKp; x++)
-      for (int k = 1; k <= M; k++) tab[x * rowsz + (k - 1)] = (int16_t)std::min((int)om->rb[x * W + k] - (int)om->bias_b, 127);
+      for (int k = 1; k <= M; k++) {
+        const int g = (k - 1) / (2 * NR), q = (k - 1) - g * 2 * NR;
+        tab[x * rowsz + (size_t)g * 2 * NR + 2 * (q % NR) + q / NR] = (int16_t)std::min((int)om->rb[x * W + k] - (int)om->bias_b, 127);
+      }
     BATH_HIP_TRY(ctx, upload(&om->d_ssv, tab.data(), tab.size(), ctx->stream));
   }
   // lane-per-target Viterbi tables (bath_viterbi.hip)
