@@ -16,6 +16,7 @@ constexpr int kRowReset = 29;            // extra "row" of the SSV cost table: e
 constexpr int kSsvRows = 30;
 constexpr int kStop = 27;                // '*'
 constexpr int kXaa = 26;                 // 'X'
+constexpr int kOrfBins = 2048;           // ORF length histogram of the work-list sort (longer ORFs share the last bin)
 
 #define BATH_HIP_TRY(ctx, call)                                                            \
   do {                                                                                     \
@@ -54,7 +55,7 @@ struct bath_hip_ctx {
   std::string err;
   void set_error(const std::string &m) { err = m; }
   // scratch owned by the context (reused across calls)
-  bath::DevBuf scratch[24];
+  bath::DevBuf scratch[32];
   std::vector<bath_orf_result> results;
   std::vector<bath::StageTiming> timings;
   std::vector<hipEvent_t> ev_pool;
@@ -72,6 +73,8 @@ struct bath_hip_seqs {
   bath_hip_ctx *ctx = nullptr;
   int64_t n = 0;
   int64_t total = 0;       // total residues
+  int64_t total_aligned = 0;   // bytes of d_data in use (every sequence padded to 16)
+  mutable int64_t cache_minlen = -1, cache_nres = 0, cache_max_orfs = 0;   // pipeline sizing, per min_orf_len
   int32_t maxlen = 0;
   uint8_t *d_data = nullptr;
   int64_t *d_off = nullptr;

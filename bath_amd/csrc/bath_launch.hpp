@@ -39,4 +39,18 @@ int launch_vit_lane(bath_hip_ctx *ctx, const bath_hip_oprofile *om, SeqView v, c
 struct MsvConsts;
 MsvConsts msv_consts(const bath_hip_oprofile *om);
 
+// ---- six-frame translation + ORF work list (bath_orfs.hip)
+struct OrfRec {                   // one ORF of the length-sorted work list
+  int64_t aa_off;                 // offset of its first residue in the amino-acid stream pool
+  int32_t w;                      // window
+  int32_t len_sf;                 // length | (strand*3+frame) << 28
+};
+__host__ __device__ inline int orf_stream_pitch(int n) { return (n / 3 + 16) & ~15; }   // bytes reserved per frame of an n-nt window
+size_t orf_aa_bytes(const bath_hip_seqs *dna);
+size_t orf_slot_count(const bath_hip_seqs *dna, int minlen);
+void build_codon64(const uint8_t basic[64], uint8_t fwd[64], uint8_t rev[64]);
+int launch_orf_scan(bath_hip_ctx *ctx, const bath_hip_seqs *dna, const uint8_t *d_aa_full, const uint8_t *d_aa64_fwd, const uint8_t *d_aa64_rev,
+                    const uint8_t *d_comp, int minlen, uint8_t *d_aa, void *d_slots, int32_t *d_cnt, int *d_hist, int *d_cursor, int *d_ntotal,
+                    unsigned long long *d_n_orfs, unsigned long long *d_orf_res, OrfRec *d_sorted);
+
 }  // namespace bath

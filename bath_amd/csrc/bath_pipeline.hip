@@ -6,16 +6,14 @@
 // with the ORFs produced by easel's six-frame translation (src/bathsearch.c:384-392).
 //
 // GPU formulation:
-//   1. ssv_dna_kernel: one LANE per (window, strand, frame) stream.  The lane translates codons on
-//      the fly and feeds the SSV recurrence (bath_filters.hip); a stop codon is a cost row of +127
-//      which resets every diagonal, so consecutive ORFs of a frame never interact.  At each ORF end
-//      the lane compares its running maximum with a per-length threshold table computed on the host
-//      with the reference's double-precision P-value maths (so the F1 decision is bit-identical)
-//      and appends the ~2% survivors to a candidate list.  The ~98% of ORFs that stop at MSV never
-//      touch HBM beyond the 1 byte/nt read of the DNA.
-//   2. survivors are materialised as amino-acid sequences and flow through decision kernels
-//      (lane per candidate) and DP kernels (wave per candidate) with device-side work lists:
-//      no host round trip until the final copy-out.
+//   1. bath_orfs.hip: six-frame translation, ORF finding and a length-sorted ORF work list (lane per stream).
+//   2. ssv_orf_kernel: one LANE per ORF (G lanes for long models) runs the SSV recurrence with the whole DP row in
+//      packed int16 registers; lanes of a wave hold ORFs of equal length.  The lane compares its maximum with a
+//      per-length threshold table computed on the host with the reference's double-precision P-value maths (so the
+//      F1 decision is bit-identical) and appends the ~2% survivors to a candidate list.
+//   3. survivors flow through decision kernels (lane per candidate) and DP kernels (lane or wave per candidate)
+//      with device-side work lists: no host round trip until the final copy-out.  Their residues are read in place
+//      from the amino-acid streams written by step 1.
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -79,7 +77,6 @@ enum { FLAG_VIT_RUN = 1, FLAG_HAS_WIN = 2 };
 
 struct Counters {                     // device-side counters, one struct per pipeline call
   int cand_count, todo_msv, todo_vit, todo_ssvb, todo_vit2, todo_fwd, win_count, overflow;
-  unsigned long long aa_bump;
   unsigned long long n_orfs, orf_res;                       // ORFs >= minlen, their total aa
   unsigned long long n_past_msv, n_past_bias, n_past_vit, n_past_fwd;
   unsigned long long pos_past_msv, pos_past_bias, pos_past_vit, pos_past_fwd;
@@ -93,121 +90,63 @@ struct Params {
 };
 
 // ---------------------------------------------------------------------------------------------
-// 1. SSV over six-frame translated DNA, lane per stream
+// 1. SSV over the length-sorted ORF list, lane per ORF (persistent waves striding over the list)
 // ---------------------------------------------------------------------------------------------
 template <int NR, int G>
-__global__ __launch_bounds__(256) void ssv_dna_kernel(SeqView dna, DnaTables tabs, const int16_t *__restrict__ cost_tab, int row_bytes,
-                                                      const int16_t *__restrict__ emit_thresh, int thresh_max, int minlen,
-                                                      Cand cand, int cand_cap, unsigned long long aa_cap, Counters *__restrict__ ctr) {
+__global__ __launch_bounds__(256) void ssv_orf_kernel(const uint8_t *__restrict__ aa, const OrfRec *__restrict__ orfs, const int *__restrict__ n_orfs_dev,
+                                                      SeqView dna, const int16_t *__restrict__ cost_tab, int row_bytes,
+                                                      const int16_t *__restrict__ emit_thresh, int thresh_max,
+                                                      Cand cand, int cand_cap, Counters *__restrict__ ctr) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  uint8_t *s_aa = reinterpret_cast<uint8_t *>(lds + kSsvRows * row_bytes);       // [5832]
-  uint8_t *s_comp = s_aa + 5832;                                                  // [18] (+pad)
   {
     const int n32 = kSsvRows * row_bytes / 4;
     const uint32_t *src = reinterpret_cast<const uint32_t *>(cost_tab);
     uint32_t *dst = reinterpret_cast<uint32_t *>(lds);
     for (int i = threadIdx.x; i < n32; i += blockDim.x) dst[i] = src[i];
-    for (int i = threadIdx.x; i < 5832; i += blockDim.x) s_aa[i] = tabs.aa[i];
-    if (threadIdx.x < 18) s_comp[threadIdx.x] = tabs.comp[threadIdx.x];
   }
   __syncthreads();
-  const int64_t gt = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t t = gt / G;
-  const int grank = (int)(gt - t * G);
-  const char *tile = lds + grank * (4 * NR);
-  const int64_t w = t / 6;
-  const int sf = (int)(t - w * 6);
-  const int strand = sf / 3, frame = sf - strand * 3;
-  const bool live = w < dna.n;
-  const int n = live ? dna.len[w] : 0;
-  const uint8_t *d = dna.data + (live ? dna.off[w] : 0);
-  const int ncod = (n >= 15 && n - frame >= 3) ? (n - frame) / 3 : 0;      // windows < 15 nt are skipped, bathsearch.c:1066
-  const int Lw = wave_max_i32(ncod);
-
-  s16x2 reg[NR];
-  const s16x2 fl = {(short)kSsvBegin, (short)kSsvBegin};
-#pragma unroll
-  for (int r = 0; r < NR; r++) reg[r] = fl;
-  s16x2 xE = fl;
-  int orf_len = 0, start_j = 0;
-  unsigned my_orfs = 0, my_res = 0;
-
-  for (int j = 0; j <= Lw; j++) {
-    int x = kRowReset;
-    bool close = false;
-    if (j < ncod) {
-      int a, b, c;
-      if (strand == 0) {
-        const int p = frame + 3 * j;
-        a = d[p]; b = d[p + 1]; c = d[p + 2];
-      } else {
-        const int q = n - 1 - (frame + 3 * j);
-        a = s_comp[min((int)d[q], 17)]; b = s_comp[min((int)d[q - 1], 17)]; c = s_comp[min((int)d[q - 2], 17)];
-      }
-      a = min(a, 17); b = min(b, 17); c = min(c, 17);
-      const int aa = s_aa[(a * 18 + b) * 18 + c];
-      if (aa == kStop) close = true;
-      else { if (orf_len == 0) start_j = j; orf_len++; x = aa; }
-    } else if (j == ncod) close = true;
-    const int gmax = ssv_group_max<G>(xE);
-    if (close) {
-      if (orf_len >= minlen) {
-        if (grank == 0) { my_orfs++; my_res += (unsigned)orf_len; }
-        if (grank == 0 && gmax >= (int)emit_thresh[min(orf_len, thresh_max)]) {
-          const int v = gmax;
-          const int slot = atomicAdd(&ctr->cand_count, 1);
-          const unsigned long long need = ((unsigned long long)orf_len + 3ull) & ~3ull;
-          const unsigned long long off = atomicAdd(&ctr->aa_bump, need);
-          if (slot < cand_cap && off + need <= aa_cap) {
-            cand.window[slot] = w; cand.sf[slot] = sf; cand.startj[slot] = start_j; cand.len[slot] = orf_len;
-            cand.v[slot] = (int16_t)min(v, 32767); cand.off[slot] = (int64_t)off;
-          } else atomicOr(&ctr->overflow, 1);
-        }
-      }
-      // The stop codon's cost row (+32767 everywhere) returns every diagonal to the begin score unless a cell
-      // of this lane climbed past the int16 midpoint (a hit strong enough to be an overflow anyway): rare, so
-      // the explicit clear below is almost never executed.
-      if (max((int)xE.x, (int)xE.y) >= 0) {
-#pragma unroll
-        for (int r = 0; r < NR; r++) reg[r] = fl;
-      }
-      xE = fl; orf_len = 0;
-    }
-    const unsigned carry = ssv_carry<NR, G>(reg, grank);
-    ssv_row<NR>(reg, xE, tile + x * row_bytes, carry);
-  }
-  // block-level reduction of the ORF counters
-  __shared__ unsigned red[2];
-  if (threadIdx.x == 0) red[0] = red[1] = 0;
-  __syncthreads();
-  if (my_orfs) { atomicAdd(&red[0], my_orfs); atomicAdd(&red[1], my_res); }
-  __syncthreads();
-  if (threadIdx.x == 0 && red[0]) { atomicAdd(&ctr->n_orfs, (unsigned long long)red[0]); atomicAdd(&ctr->orf_res, (unsigned long long)red[1]); }
-}
-
-// ---------------------------------------------------------------------------------------------
-// 2. write the candidates' amino-acid sequences, wave per candidate
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void materialize_kernel(SeqView dna, DnaTables tabs, Cand cand, int cand_cap, const Counters *__restrict__ ctr,
-                                                          uint8_t *__restrict__ pool) {
+  constexpr int TPW = 64 / G;                                   // ORFs per wave
+  const int64_t n_orfs = *n_orfs_dev;
   const int lane = threadIdx.x & 63;
-  const int64_t wid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  const int ncand = min(ctr->cand_count, cand_cap);
-  for (int64_t c = wid; c < ncand; c += nw) {
-    const int64_t w = cand.window[c];
-    const int sf = cand.sf[c], strand = sf / 3, frame = sf - strand * 3;
-    const int n = dna.len[w];
-    const uint8_t *d = dna.data + dna.off[w];
-    const int j0 = cand.startj[c], L = cand.len[c];
-    uint8_t *out = pool + cand.off[c];
-    for (int i = lane; i < L; i += 64) {
-      const int j = j0 + i;
-      int a, b, cc;
-      if (strand == 0) { const int p = frame + 3 * j; a = d[p]; b = d[p + 1]; cc = d[p + 2]; }
-      else { const int q = n - 1 - (frame + 3 * j); a = tabs.comp[min((int)d[q], 17)]; b = tabs.comp[min((int)d[q - 1], 17)]; cc = tabs.comp[min((int)d[q - 2], 17)]; }
-      a = min(a, 17); b = min(b, 17); cc = min(cc, 17);
-      out[i] = tabs.aa[(a * 18 + b) * 18 + cc];
+  const int grank = lane % G;
+  const char *tile = lds + grank * (4 * NR);
+  const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  const s16x2 fl = {(short)kSsvBegin, (short)kSsvBegin};
+  for (int64_t tb = wave0 * TPW; tb < n_orfs; tb += nwaves * TPW) {
+    const int64_t t = tb + lane / G;
+    const bool live = t < n_orfs;
+    OrfRec rec{0, 0, 0};
+    if (live) rec = orfs[t];
+    const int L = rec.len_sf & 0x0fffffff;
+    const uint8_t *s = aa + rec.aa_off;
+    const int Lw = wave_max_i32(L);
+    s16x2 reg[NR];
+#pragma unroll
+    for (int r = 0; r < NR; r++) reg[r] = fl;
+    s16x2 xE = fl;
+    uint32_t wnext = (0 < L) ? *reinterpret_cast<const uint32_t *>(s) : 0x1d1d1d1du;
+    for (int i0 = 0; i0 < Lw; i0 += 4) {
+      const uint32_t w4 = wnext;
+      wnext = (i0 + 4 < L) ? *reinterpret_cast<const uint32_t *>(s + i0 + 4) : 0x1d1d1d1du;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        int x = (w4 >> (8 * j)) & 0xff;
+        x = (i0 + j < L) ? min(x, kKp - 1) : kRowReset;
+        const unsigned carry = ssv_carry<NR, G>(reg, grank);
+        ssv_row<NR>(reg, xE, tile + x * row_bytes, carry);
+      }
+    }
+    const int v = ssv_group_max<G>(xE);
+    if (live && grank == 0 && v >= (int)emit_thresh[min(L, thresh_max)]) {
+      const int slot = atomicAdd(&ctr->cand_count, 1);
+      if (slot < cand_cap) {
+        const int sf = (int)((unsigned)rec.len_sf >> 28);
+        const int64_t w = rec.w;
+        const int64_t stream = 2 * dna.off[w] + 96 * w + (int64_t)sf * orf_stream_pitch(dna.len[w]);
+        cand.window[slot] = w; cand.sf[slot] = sf; cand.startj[slot] = (int32_t)(rec.aa_off - stream); cand.len[slot] = L;
+        cand.v[slot] = (int16_t)min(v, 32767); cand.off[slot] = rec.aa_off;
+      } else atomicOr(&ctr->overflow, 1);
     }
   }
 }
@@ -525,8 +464,7 @@ struct PipelineWork {
   // device allocations live in ctx->scratch[8..]; this struct only carves them up
   Cand cand;
   int cand_cap = 0;
-  unsigned long long aa_cap = 0;
-  uint8_t *pool = nullptr;
+  uint8_t *pool = nullptr;             // the amino-acid streams of bath_orfs.hip (ctx->scratch[24])
   int32_t *todo_msv = nullptr, *todo_vit = nullptr, *todo_ssvb = nullptr, *todo_vit2 = nullptr, *todo_fwd = nullptr, *todo_sorted = nullptr;
   int *len_bins = nullptr;
   WindowRec *wins = nullptr;
@@ -541,10 +479,10 @@ static T *carve(char *&p, size_t n) {
   return r;
 }
 
-static size_t layout(PipelineWork &w, char *base, int cap, unsigned long long aa_cap) {
+static size_t layout(PipelineWork &w, char *base, int cap) {
   char *p = base;
   const size_t n = (size_t)cap;
-  w.cand_cap = cap; w.aa_cap = aa_cap; w.win_cap = 2 * cap;
+  w.cand_cap = cap; w.win_cap = 2 * cap;
   w.ctr = carve<Counters>(p, 1);
   w.cand.window = carve<int64_t>(p, n); w.cand.off = carve<int64_t>(p, n); w.cand.P = carve<double>(p, n);
   w.cand.sf = carve<int32_t>(p, n); w.cand.startj = carve<int32_t>(p, n); w.cand.len = carve<int32_t>(p, n);
@@ -557,7 +495,6 @@ static size_t layout(PipelineWork &w, char *base, int cap, unsigned long long aa
   w.todo_vit2 = carve<int32_t>(p, n); w.todo_fwd = carve<int32_t>(p, n); w.todo_sorted = carve<int32_t>(p, n);
   w.len_bins = carve<int>(p, 2048);
   w.wins = carve<WindowRec>(p, (size_t)w.win_cap);
-  w.pool = carve<uint8_t>(p, (size_t)aa_cap + 64);
   return (size_t)(p - base);
 }
 
@@ -600,22 +537,27 @@ extern "C" int bath_hip_pipeline_filters(bath_hip_ctx *ctx, const bath_hip_oprof
   std::vector<uint8_t> ssv_scores((size_t)(M + 1) * kKp, 0);
   bath_hip_oprofile_get_ssv_scores(om, ssv_scores.data());
 
+  uint8_t codon64_fwd[64], codon64_rev[64];
+  build_codon64(basic, codon64_fwd, codon64_rev);
   DevBuf &b_tabs = ctx->scratch[8], &b_work = ctx->scratch[9];
   const size_t tabs_bytes = 8192 + emit.size() * 2 + 256 + ssv_scores.size() + 256 + 20 * 4 + 256;
   BATH_HIP_TRY(ctx, b_tabs.reserve(tabs_bytes));
   char *tp = b_tabs.as<char>();
   uint8_t *d_codon = reinterpret_cast<uint8_t *>(tp); tp += 6144;
-  uint8_t *d_comp = reinterpret_cast<uint8_t *>(tp); tp += 256;
+  uint8_t *d_comp = reinterpret_cast<uint8_t *>(tp); tp += 64;
+  uint8_t *d_c64f = reinterpret_cast<uint8_t *>(tp); tp += 64;
+  uint8_t *d_c64r = reinterpret_cast<uint8_t *>(tp); tp += 128;
   int16_t *d_emit = reinterpret_cast<int16_t *>(tp); tp += (emit.size() * 2 + 255) / 256 * 256;
   uint8_t *d_ssvsc = reinterpret_cast<uint8_t *>(tp); tp += (ssv_scores.size() + 255) / 256 * 256;
   float *d_bgf = reinterpret_cast<float *>(tp);
   BATH_HIP_TRY(ctx, hipMemcpyAsync(d_codon, codon_tab.data(), codon_tab.size(), hipMemcpyHostToDevice, ctx->stream));
   BATH_HIP_TRY(ctx, hipMemcpyAsync(d_comp, comp, 18, hipMemcpyHostToDevice, ctx->stream));
+  BATH_HIP_TRY(ctx, hipMemcpyAsync(d_c64f, codon64_fwd, 64, hipMemcpyHostToDevice, ctx->stream));
+  BATH_HIP_TRY(ctx, hipMemcpyAsync(d_c64r, codon64_rev, 64, hipMemcpyHostToDevice, ctx->stream));
   BATH_HIP_TRY(ctx, hipMemcpyAsync(d_emit, emit.data(), emit.size() * 2, hipMemcpyHostToDevice, ctx->stream));
   BATH_HIP_TRY(ctx, hipMemcpyAsync(d_ssvsc, ssv_scores.data(), ssv_scores.size(), hipMemcpyHostToDevice, ctx->stream));
   BATH_HIP_TRY(ctx, hipMemcpyAsync(d_bgf, kAminoBg, 20 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
   BATH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // the host vectors above go out of scope with this call only, but be explicit
-  DnaTables tabs{d_codon, d_comp};
 
   Params P{};
   P.F1 = prm->F1; P.F2 = prm->F2; P.F3 = prm->F3; P.F4 = prm->F4;
@@ -628,56 +570,74 @@ extern "C" int bath_hip_pipeline_filters(bath_hip_ctx *ctx, const bath_hip_oprof
   wa.invP_msv = (double)(float)gumbel_invsurv(prm->F2, om->evparam[0], om->evparam[1]);   // vitfilter.c:319
 
   // ---- capacity guess: all ORFs that could exist, scaled by the expected MSV pass rate (+ slack); retried on overflow
-  int64_t nres = 0, max_orfs = 0;
-  for (int64_t i = 0; i < nwin; i++) {
-    const int n = dna->h_len[i];
-    if (n < 15) continue;
-    nres += 2 * (int64_t)n;
-    max_orfs += 6 * (int64_t)((n / 3 + 1) / (prm->min_orf_len + 1) + 1);
+  if (dna->cache_minlen != prm->min_orf_len) {
+    int64_t nres_c = 0, max_orfs_c = 0;
+    for (int64_t i = 0; i < nwin; i++) {
+      const int n = dna->h_len[i];
+      if (n < 15) continue;
+      nres_c += 2 * (int64_t)n;
+      max_orfs_c += 6 * (int64_t)((n / 3 + 1) / (prm->min_orf_len + 1) + 1);
+    }
+    dna->cache_minlen = prm->min_orf_len; dna->cache_nres = nres_c; dna->cache_max_orfs = max_orfs_c;
   }
+  const int64_t nres = dna->cache_nres, max_orfs = dna->cache_max_orfs;
+  if (max_orfs >= (int64_t)INT32_MAX) { ctx->set_error("DNA block too large for one pipeline call (ORF list indices are 32-bit): split it"); return BATH_EINVAL; }
   int64_t cap = std::max<int64_t>(4096, (int64_t)((double)max_orfs * std::min(1.0, prm->F1 * 4.0 + 0.01)));
   cap = std::min<int64_t>(cap, std::max<int64_t>(max_orfs, 4096));
-  unsigned long long aa_cap = std::max<unsigned long long>(1u << 20, (unsigned long long)cap * 96ull);
+
+  // ---- translation / ORF work-list buffers (bath_orfs.hip)
+  DevBuf &b_aa = ctx->scratch[24], &b_slots = ctx->scratch[25], &b_orfs = ctx->scratch[26], &b_misc = ctx->scratch[27];
+  BATH_HIP_TRY(ctx, b_aa.reserve(orf_aa_bytes(dna)));
+  BATH_HIP_TRY(ctx, b_slots.reserve(orf_slot_count(dna, prm->min_orf_len) * sizeof(uint2)));
+  BATH_HIP_TRY(ctx, b_orfs.reserve((size_t)(max_orfs + 64) * sizeof(OrfRec)));
+  BATH_HIP_TRY(ctx, b_misc.reserve((size_t)nwin * 6 * sizeof(int32_t) + (2 * kOrfBins + 64) * sizeof(int)));
+  int32_t *d_orf_cnt = b_misc.as<int32_t>();
+  int *d_orf_hist = reinterpret_cast<int *>(d_orf_cnt + nwin * 6);
+  int *d_orf_cursor = d_orf_hist + kOrfBins;
+  int *d_orf_total = d_orf_cursor + kOrfBins;
 
   const int NRk = om->NR;
-  const size_t ssv_shmem = (size_t)kSsvRows * om->ssv_row_bytes + 5832 + 64;
-  const int64_t nstreams = nwin * 6;
+  const size_t ssv_shmem = (size_t)kSsvRows * om->ssv_row_bytes;
   if (ssv_shmem > 160 * 1024) { ctx->set_error("model too long for the LDS-resident SSV cost table"); return BATH_EINVAL; }
   const int dec_blocks = ctx->prop.multiProcessorCount * 4;
 
   std::vector<hipEvent_t> &ev = ctx->ev_pool;
-  while (ev.size() < 10) { hipEvent_t e; BATH_HIP_TRY(ctx, hipEventCreate(&e)); ev.push_back(e); }
+  while (ev.size() < 12) { hipEvent_t e; BATH_HIP_TRY(ctx, hipEventCreate(&e)); ev.push_back(e); }
 
   PipelineWork W;
   Counters hc{};
   for (int attempt = 0;; attempt++) {
-    size_t need = layout(W, nullptr, (int)cap, aa_cap);
+    size_t need = layout(W, nullptr, (int)cap);
     BATH_HIP_TRY(ctx, b_work.reserve(need + 4096));
-    layout(W, b_work.as<char>(), (int)cap, aa_cap);
+    layout(W, b_work.as<char>(), (int)cap);
+    W.pool = b_aa.as<uint8_t>();
     BATH_HIP_TRY(ctx, hipMemsetAsync(W.ctr, 0, sizeof(Counters), ctx->stream));
     SeqView cv{W.pool, W.cand.off, W.cand.len, cap};
 
     int e = 0;
     BATH_HIP_TRY(ctx, hipEventRecord(ev[e++], ctx->stream));
-    // 1. translate + SSV + F1 threshold
+    // 1. six-frame translation, ORFs, length-sorted work list
+    if ((st = launch_orf_scan(ctx, dna, d_codon, d_c64f, d_c64r, d_comp, prm->min_orf_len, W.pool, b_slots.p, d_orf_cnt, d_orf_hist, d_orf_cursor,
+                              d_orf_total, &W.ctr->n_orfs, &W.ctr->orf_res, b_orfs.as<OrfRec>())) != BATH_OK) return st;
+    BATH_HIP_TRY(ctx, hipEventRecord(ev[e++], ctx->stream));
+    // 2. SSV + F1 threshold, lane per ORF
     {
-      const int blocks = (int)((nstreams * om->G + 255) / 256);
+      const int blocks = ctx->prop.multiProcessorCount * 4;
       bool launched = false;
-#define BATH_DNA_CASE(N, GG)                                                                                                     \
+#define BATH_ORF_CASE(N, GG)                                                                                                     \
   if (!launched && NRk == N && om->G == GG) {                                                                                    \
-    if (ssv_shmem > 64 * 1024) (void)hipFuncSetAttribute((const void *)ssv_dna_kernel<N, GG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ssv_shmem); \
-    hipLaunchKernelGGL((ssv_dna_kernel<N, GG>), dim3(blocks), dim3(256), ssv_shmem, ctx->stream, dna->view(), tabs, om->d_ssv,    \
-                       om->ssv_row_bytes, d_emit, max_orf, prm->min_orf_len, W.cand, W.cand_cap, W.aa_cap, W.ctr);               \
+    if (ssv_shmem > 64 * 1024) (void)hipFuncSetAttribute((const void *)ssv_orf_kernel<N, GG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ssv_shmem); \
+    hipLaunchKernelGGL((ssv_orf_kernel<N, GG>), dim3(blocks), dim3(256), ssv_shmem, ctx->stream, W.pool, b_orfs.as<OrfRec>(), d_orf_total,        \
+                       dna->view(), om->d_ssv, om->ssv_row_bytes, d_emit, max_orf, W.cand, W.cand_cap, W.ctr);                   \
     launched = true;                                                                                                             \
   }
-      BATH_SSV_SHAPES(BATH_DNA_CASE)
-#undef BATH_DNA_CASE
+      BATH_SSV_SHAPES(BATH_ORF_CASE)
+#undef BATH_ORF_CASE
       if (!launched) { ctx->set_error("SSV kernel: no tile shape for this model length"); return BATH_EINVAL; }
       BATH_HIP_TRY(ctx, hipGetLastError());
     }
     BATH_HIP_TRY(ctx, hipEventRecord(ev[e++], ctx->stream));
-    // 2. survivors -> amino-acid pool; SSV status; full MSV for the undecided
-    hipLaunchKernelGGL(materialize_kernel, dim3(wave_grid_blocks(ctx)), dim3(256), 0, ctx->stream, dna->view(), tabs, W.cand, W.cand_cap, W.ctr, W.pool);
+    // 3. SSV status; full MSV for the undecided
     hipLaunchKernelGGL(classify_kernel, dim3(dec_blocks), dim3(256), 0, ctx->stream, W.cand, W.cand_cap, W.ctr, om->lt.d_tjb, mc, W.todo_msv);
     BATH_HIP_TRY(ctx, hipGetLastError());
     if ((st = launch_msv_wave(ctx, om, cv, W.todo_msv, cap, W.cand.usc, W.cand.msv_status, &W.ctr->todo_msv)) != BATH_OK) return st;
@@ -729,14 +689,13 @@ extern "C" int bath_hip_pipeline_filters(bath_hip_ctx *ctx, const bath_hip_oprof
 
     BATH_HIP_TRY(ctx, hipMemcpyAsync(&hc, W.ctr, sizeof(Counters), hipMemcpyDeviceToHost, ctx->stream));
     BATH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if (hc.overflow || hc.cand_count > cap || hc.aa_bump > aa_cap) {
+    if (hc.overflow || hc.cand_count > cap) {
       if (attempt >= 4) { ctx->set_error("candidate buffers overflowed repeatedly"); return BATH_EMEM; }
       cap = std::max<int64_t>(cap * 2, (int64_t)hc.cand_count + 1024);
-      aa_cap = std::max<unsigned long long>(aa_cap * 2, hc.aa_bump + (1u << 20));
       continue;
     }
-    static const char *names[] = {"ssv_translate_f1", "materialize_classify_msv", "f1_bias", "viterbi_windows", "ssv_windows", "post_vit", "forward_final"};
-    static const int64_t launches[] = {1, 3, 1, 1, 1, 3, 2};
+    static const char *names[] = {"translate_orfs", "ssv_f1", "classify_msv", "f1_bias", "viterbi_windows", "ssv_windows", "post_vit", "forward_final"};
+    static const int64_t launches[] = {3, 1, 2, 1, 4, 1, 3, 2};
     ctx->timings.clear();
     for (int i = 0; i + 1 < e; i++) {
       float ms = 0.f;

@@ -340,6 +340,7 @@ extern "C" int bath_hip_seqs_create(bath_hip_ctx *ctx, const uint8_t *dsq, const
     sq->total += L;
     pos += (L + 15) / 16 * 16;
   }
+  sq->total_aligned = pos;
   size_t bytes = (size_t)pos + 64;
   BATH_HIP_TRY(ctx, hipMalloc((void **)&sq->d_data, bytes));
   BATH_HIP_TRY(ctx, hipMalloc((void **)&sq->d_off, (size_t)std::max<int64_t>(n, 1) * sizeof(int64_t)));

@@ -205,10 +205,23 @@ __global__ __launch_bounds__(256, 1) void vit_lane_kernel(SeqView sq, VitLaneTab
 }
 
 // ---- counting sort of a work list by target length, so that the 64 lanes of a wave finish together ----
+// Global atomics on a few hot addresses serialise (~3 ns each on MI355X), so both passes count in LDS first and
+// touch each global bin once per block.
 constexpr int kLenBins = 2048;
-__global__ void len_hist_kernel(const int32_t *__restrict__ todo, const int *__restrict__ ntodo_dev, const int32_t *__restrict__ len, int *__restrict__ hist) {
-  const int n = *ntodo_dev;
-  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) atomicAdd(&hist[min(len[todo[j]], kLenBins - 1)], 1);
+__device__ __forceinline__ void len_block_range(int n, int &lo, int &hi) {
+  const int per = (n + (int)gridDim.x - 1) / (int)gridDim.x;
+  lo = min(n, (int)blockIdx.x * per); hi = min(n, lo + per);
+}
+__global__ __launch_bounds__(256) void len_hist_kernel(const int32_t *__restrict__ todo, const int *__restrict__ ntodo_dev, const int32_t *__restrict__ len,
+                                                       int *__restrict__ hist) {
+  __shared__ int s_cnt[kLenBins];
+  for (int i = threadIdx.x; i < kLenBins; i += blockDim.x) s_cnt[i] = 0;
+  __syncthreads();
+  int lo, hi;
+  len_block_range(*ntodo_dev, lo, hi);
+  for (int j = lo + threadIdx.x; j < hi; j += blockDim.x) atomicAdd(&s_cnt[min(len[todo[j]], kLenBins - 1)], 1);
+  __syncthreads();
+  for (int i = threadIdx.x; i < kLenBins; i += blockDim.x) if (s_cnt[i]) atomicAdd(&hist[i], s_cnt[i]);
 }
 __global__ void len_scan_kernel(int *__restrict__ hist /* in: counts, out: start offsets; longest first */) {
   __shared__ int tmp[kLenBins];
@@ -221,12 +234,20 @@ __global__ void len_scan_kernel(int *__restrict__ hist /* in: counts, out: start
   __syncthreads();
   for (int i = threadIdx.x; i < kLenBins; i += blockDim.x) hist[i] = tmp[i];
 }
-__global__ void len_scatter_kernel(const int32_t *__restrict__ todo, const int *__restrict__ ntodo_dev, const int32_t *__restrict__ len, int *__restrict__ cursor,
-                                   int32_t *__restrict__ sorted) {
-  const int n = *ntodo_dev;
-  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+__global__ __launch_bounds__(256) void len_scatter_kernel(const int32_t *__restrict__ todo, const int *__restrict__ ntodo_dev, const int32_t *__restrict__ len,
+                                                          int *__restrict__ cursor, int32_t *__restrict__ sorted) {
+  __shared__ int s_cnt[kLenBins];
+  for (int i = threadIdx.x; i < kLenBins; i += blockDim.x) s_cnt[i] = 0;
+  __syncthreads();
+  int lo, hi;
+  len_block_range(*ntodo_dev, lo, hi);
+  for (int j = lo + threadIdx.x; j < hi; j += blockDim.x) atomicAdd(&s_cnt[min(len[todo[j]], kLenBins - 1)], 1);
+  __syncthreads();
+  for (int i = threadIdx.x; i < kLenBins; i += blockDim.x) { const int c = s_cnt[i]; if (c) s_cnt[i] = atomicAdd(&cursor[i], c); }
+  __syncthreads();
+  for (int j = lo + threadIdx.x; j < hi; j += blockDim.x) {
     const int cnd = todo[j];
-    sorted[atomicAdd(&cursor[min(len[cnd], kLenBins - 1)], 1)] = cnd;
+    sorted[atomicAdd(&s_cnt[min(len[cnd], kLenBins - 1)], 1)] = cnd;
   }
 }
 

@@ -8,8 +8,9 @@ cascade over the block, with the DNA already resident in HBM.
 
   value   = DNA residues searched per second, counted as the reference counts pli->nres
             (both strands: bathsearch.c:1073,1086), whole job over all ranks.
-  roofline = the dominant kernel (ssv_dna_kernel): algorithmic HBM bytes per launch / its device time,
-            timed with HIP events on the library's own stream (bath_hip_pipeline_timings).
+  roofline = the dominant kernel (ssv_orf_kernel, SSV over the length-sorted ORF list): algorithmic HBM bytes
+            per launch / its device time, timed with HIP events on the library's own stream
+            (bath_hip_pipeline_timings).
   cpu_baseline = the scalar C oracle (oracle/pipeline.c, a port of the same algorithms) on a bounded
             sample of the same windows, one process per host core.  A reported baseline, not the target.
 
@@ -163,12 +164,14 @@ def main():
         cells_step = tot["cells_msv"] + tot["cells_vit"] + tot["cells_fwd"]
         ms_step = elapsed / args.steps * 1e3
         value = nres_step / (elapsed / args.steps)
-        # dominant kernel: ssv_dna_kernel, one launch per step
-        k_ms = float(np.mean(stage_ms["ssv_translate_f1"]))
-        algo_bytes = stats.nres / 2 + 32.0 * stats.n_past_msv          # 1 B/nt read once + ~32 B per surviving ORF record
+        # dominant kernel: ssv_orf_kernel, one launch per step
+        k_ms = float(np.mean(stage_ms["ssv_f1"]))
+        orf_res = stats.cells_msv / hmm.M
+        # 1 B per ORF residue + 16 B per ORF work-list record read once, ~34 B written per surviving ORF
+        algo_bytes = orf_res + 16.0 * stats.n_orfs + 34.0 * stats.n_past_msv
         achieved = algo_bytes / (k_ms * 1e-3) / 1e9
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_ssv_dna_pmc.json")
+        pmc = os.path.join(ROOT, "profiles", "r01_ssv_orf_pmc.json")
         if os.path.exists(pmc):
             try:
                 traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
@@ -189,8 +192,8 @@ def main():
             "survivors": {k: tot[k] for k in ("n_orfs", "n_past_msv", "n_past_bias", "n_past_vit", "n_past_fwd")},
             "hits_gathered": int(len(hits)) if hits is not None else 0,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "ssv_dna_kernel", "kernel_ms": k_ms,
-                         "note": "integer DP held in VGPRs: compulsory HBM traffic is 1 B/nt, the kernel is VALU-issue bound (see DESIGN.md); "
+                         "traffic": traffic, "kernel": "ssv_orf_kernel", "kernel_ms": k_ms,
+                         "note": "integer DP held in VGPRs: compulsory HBM traffic is 1 B per ORF residue, the kernel is VALU-issue bound (see DESIGN.md); "
                                  "cell rate of this kernel = %.2f Tcells/s" % (stats.cells_msv / (k_ms * 1e-3) / 1e12)},
         }
         if not args.no_cpu_baseline:
