@@ -75,6 +75,8 @@ struct bath_hip_seqs {
   int64_t total = 0;       // total residues
   int64_t total_aligned = 0;   // bytes of d_data in use (every sequence padded to 16)
   mutable int64_t cache_minlen = -1, cache_nres = 0, cache_max_orfs = 0;   // pipeline sizing, per min_orf_len
+  mutable int64_t ntiles = -1;             // translation tiles (bath_orfs.hip), built on first use
+  mutable int32_t *d_tile_win = nullptr, *d_tile_first = nullptr;
   int32_t maxlen = 0;
   uint8_t *d_data = nullptr;
   int64_t *d_off = nullptr;

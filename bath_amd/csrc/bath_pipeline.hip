@@ -586,15 +586,17 @@ extern "C" int bath_hip_pipeline_filters(bath_hip_ctx *ctx, const bath_hip_oprof
   cap = std::min<int64_t>(cap, std::max<int64_t>(max_orfs, 4096));
 
   // ---- translation / ORF work-list buffers (bath_orfs.hip)
+  if ((st = orf_tiles_ensure(ctx, dna)) != BATH_OK) return st;
+  const size_t nent = (size_t)dna->ntiles * 6;
   DevBuf &b_aa = ctx->scratch[24], &b_slots = ctx->scratch[25], &b_orfs = ctx->scratch[26], &b_misc = ctx->scratch[27];
   BATH_HIP_TRY(ctx, b_aa.reserve(orf_aa_bytes(dna)));
-  BATH_HIP_TRY(ctx, b_slots.reserve(orf_slot_count(dna, prm->min_orf_len) * sizeof(uint2)));
+  BATH_HIP_TRY(ctx, b_slots.reserve((nent * (size_t)orf_slot_cap(prm->min_orf_len) + 64) * 8));
   BATH_HIP_TRY(ctx, b_orfs.reserve((size_t)(max_orfs + 64) * sizeof(OrfRec)));
-  BATH_HIP_TRY(ctx, b_misc.reserve((size_t)nwin * 6 * sizeof(int32_t) + (2 * kOrfBins + 64) * sizeof(int)));
-  int32_t *d_orf_cnt = b_misc.as<int32_t>();
-  int *d_orf_hist = reinterpret_cast<int *>(d_orf_cnt + nwin * 6);
-  int *d_orf_cursor = d_orf_hist + kOrfBins;
-  int *d_orf_total = d_orf_cursor + kOrfBins;
+  BATH_HIP_TRY(ctx, b_misc.reserve((3 * nent + 2 * kOrfBins + 64) * sizeof(int32_t)));
+  OrfBuffers ob{};
+  ob.aa = b_aa.as<uint8_t>(); ob.slots = b_slots.p; ob.sorted = b_orfs.as<OrfRec>();
+  ob.cnt = b_misc.as<int32_t>(); ob.prefix = ob.cnt + nent; ob.suffix = ob.prefix + nent;
+  ob.hist = reinterpret_cast<int *>(ob.suffix + nent); ob.cursor = ob.hist + kOrfBins; ob.ntotal = ob.cursor + kOrfBins;
 
   const int NRk = om->NR;
   const size_t ssv_shmem = (size_t)kSsvRows * om->ssv_row_bytes;
@@ -617,8 +619,7 @@ extern "C" int bath_hip_pipeline_filters(bath_hip_ctx *ctx, const bath_hip_oprof
     int e = 0;
     BATH_HIP_TRY(ctx, hipEventRecord(ev[e++], ctx->stream));
     // 1. six-frame translation, ORFs, length-sorted work list
-    if ((st = launch_orf_scan(ctx, dna, d_codon, d_c64f, d_c64r, d_comp, prm->min_orf_len, W.pool, b_slots.p, d_orf_cnt, d_orf_hist, d_orf_cursor,
-                              d_orf_total, &W.ctr->n_orfs, &W.ctr->orf_res, b_orfs.as<OrfRec>())) != BATH_OK) return st;
+    if ((st = launch_orf_scan(ctx, dna, d_codon, d_c64f, d_c64r, d_comp, prm->min_orf_len, ob, &W.ctr->n_orfs, &W.ctr->orf_res)) != BATH_OK) return st;
     BATH_HIP_TRY(ctx, hipEventRecord(ev[e++], ctx->stream));
     // 2. SSV + F1 threshold, lane per ORF
     {
@@ -627,7 +628,7 @@ extern "C" int bath_hip_pipeline_filters(bath_hip_ctx *ctx, const bath_hip_oprof
 #define BATH_ORF_CASE(N, GG)                                                                                                     \
   if (!launched && NRk == N && om->G == GG) {                                                                                    \
     if (ssv_shmem > 64 * 1024) (void)hipFuncSetAttribute((const void *)ssv_orf_kernel<N, GG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ssv_shmem); \
-    hipLaunchKernelGGL((ssv_orf_kernel<N, GG>), dim3(blocks), dim3(256), ssv_shmem, ctx->stream, W.pool, b_orfs.as<OrfRec>(), d_orf_total,        \
+    hipLaunchKernelGGL((ssv_orf_kernel<N, GG>), dim3(blocks), dim3(256), ssv_shmem, ctx->stream, W.pool, ob.sorted, ob.ntotal,                  \
                        dna->view(), om->d_ssv, om->ssv_row_bytes, d_emit, max_orf, W.cand, W.cand_cap, W.ctr);                   \
     launched = true;                                                                                                             \
   }
@@ -695,7 +696,7 @@ extern "C" int bath_hip_pipeline_filters(bath_hip_ctx *ctx, const bath_hip_oprof
       continue;
     }
     static const char *names[] = {"translate_orfs", "ssv_f1", "classify_msv", "f1_bias", "viterbi_windows", "ssv_windows", "post_vit", "forward_final"};
-    static const int64_t launches[] = {3, 1, 2, 1, 4, 1, 3, 2};
+    static const int64_t launches[] = {4, 1, 2, 1, 4, 1, 3, 2};
     ctx->timings.clear();
     for (int i = 0; i + 1 < e; i++) {
       float ms = 0.f;

@@ -315,7 +315,7 @@ extern "C" int bath_hip_oprofile_get_fwd(const bath_hip_oprofile *om, float *rf,
 
 extern "C" void bath_hip_seqs_destroy(bath_hip_seqs *sq) {
   if (!sq) return;
-  for (void *p : {(void *)sq->d_data, (void *)sq->d_off, (void *)sq->d_len})
+  for (void *p : {(void *)sq->d_data, (void *)sq->d_off, (void *)sq->d_len, (void *)sq->d_tile_win, (void *)sq->d_tile_first})
     if (p) (void)hipFree(p);
   delete sq;
 }
