@@ -97,6 +97,12 @@ class PipelineStats(C.Structure):
                                           "cells_msv", "cells_vit", "cells_fwd")]
 
 
+class Orf(C.Structure):
+    """bath_orf (include/bath_hip.h): one ORF of the six-frame translation."""
+    _fields_ = [("window", C.c_int64), ("strand", C.c_int32), ("frame", C.c_int32), ("start", C.c_int32), ("end", C.c_int32),
+                ("n", C.c_int32), ("aa_off", C.c_int64)]
+
+
 class Fs5Result(C.Structure):
     _fields_ = [("fwdsc", C.c_float), ("bcksc", C.c_float), ("oasc", C.c_float), ("null2", C.c_float * KP)]
 
@@ -132,6 +138,7 @@ ABI = {
     "bath_hip_vitfilter": (C.c_int, [_vp, _vp, _vp, _f32p, _i32p]),
     "bath_hip_forward_parser": (C.c_int, [_vp, _vp, _vp, _f32p, _i32p]),
     "bath_hip_bias_filter": (C.c_int, [_vp, _vp, _vp, _f32p, _f32p]),
+    "bath_hip_translate_orfs": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.POINTER(C.POINTER(Orf)), _i64p, C.POINTER(_u8p)]),
     "bath_pipeline_params_default": (None, [C.POINTER(PipelineParams), C.c_int]),
     "bath_hip_pipeline_filters": (C.c_int, [_vp, _vp, _vp, C.POINTER(PipelineParams), C.POINTER(PipelineStats),
                                             C.POINTER(C.POINTER(OrfResult)), _i64p]),
@@ -374,6 +381,25 @@ class SeqBlock:
         if getattr(self, "_h", None) and getattr(self.ctx, "_h", None):
             lib().bath_hip_seqs_destroy(self._h)
         self._h = None
+
+
+def translate_orfs(ctx, dna, ncbi_table=1, min_orf_len=20):
+    """Six-frame translation of a DNA SeqBlock (esl_gencode_Process*, bathsearch.c:384-392).
+
+    Returns a list of (window, strand, frame, start, end, residues[np.uint8]) sorted by window, strand, frame, start."""
+    orfs = C.POINTER(Orf)()
+    n = C.c_int64(0)
+    aa = _u8p()
+    ctx._check(lib().bath_hip_translate_orfs(ctx._h, dna._h, ncbi_table, min_orf_len, C.byref(orfs), C.byref(n), C.byref(aa)), "translate_orfs")
+    out = []
+    if n.value == 0:
+        return out
+    last = orfs[n.value - 1]
+    pool = np.ctypeslib.as_array(aa, shape=(last.aa_off + last.n,))      # residues are stored in list order
+    for i in range(n.value):
+        o = orfs[i]
+        out.append((o.window, o.strand, o.frame, o.start, o.end, pool[o.aa_off:o.aa_off + o.n].copy()))
+    return out
 
 
 def _score_call(fn, what, ctx, om, sq):

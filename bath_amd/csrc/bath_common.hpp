@@ -57,6 +57,8 @@ struct bath_hip_ctx {
   // scratch owned by the context (reused across calls)
   bath::DevBuf scratch[32];
   std::vector<bath_orf_result> results;
+  std::vector<bath_orf> orfs;             // bath_hip_translate_orfs output
+  std::vector<uint8_t> orf_aa;
   std::vector<bath::StageTiming> timings;
   std::vector<hipEvent_t> ev_pool;
 };

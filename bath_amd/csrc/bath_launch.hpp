@@ -49,7 +49,8 @@ __host__ __device__ inline int orf_stream_pitch(int n) { return (n / 3 + 16) & ~
 size_t orf_aa_bytes(const bath_hip_seqs *dna);
 int orf_slot_cap(int minlen);                                   // ORF records reserved per (tile, frame)
 int orf_tiles_ensure(bath_hip_ctx *ctx, const bath_hip_seqs *dna);   // fills dna->ntiles, d_tile_win, d_tile_first
-void build_codon64(const uint8_t basic[64], uint8_t fwd[64], uint8_t rev[64]);
+struct OrfTablesDev { const uint8_t *full, *fwd, *rev, *comp; };   // 18^3 general table, canonical 64-entry tables per strand, complement
+int orf_tables_upload(bath_hip_ctx *ctx, int ncbi_table, OrfTablesDev *t);
 struct OrfBuffers {               // device buffers of one translation pass
   uint8_t *aa;                    // orf_aa_bytes()
   void *slots;                    // ntiles*6*orf_slot_cap() records of 8 bytes
@@ -57,7 +58,7 @@ struct OrfBuffers {               // device buffers of one translation pass
   int *hist, *cursor, *ntotal;    // kOrfBins, kOrfBins, 1
   OrfRec *sorted;                 // the work list, longest ORFs first; *ntotal entries
 };
-int launch_orf_scan(bath_hip_ctx *ctx, const bath_hip_seqs *dna, const uint8_t *d_aa_full, const uint8_t *d_aa64_fwd, const uint8_t *d_aa64_rev,
-                    const uint8_t *d_comp, int minlen, const OrfBuffers &b, unsigned long long *d_n_orfs, unsigned long long *d_orf_res);
+int launch_orf_scan(bath_hip_ctx *ctx, const bath_hip_seqs *dna, const OrfTablesDev &tt, int minlen, const OrfBuffers &b,
+                    unsigned long long *d_n_orfs, unsigned long long *d_orf_res);
 
 }  // namespace bath

@@ -22,6 +22,9 @@
 //   orf_sort_kernel   compacts the per-(tile, frame) slots into the dense work list ordered by length (block-local
 //                     counting sort: one global atomic per block and non-empty length bin).
 // Amino stream of (w, sf):  aa + 2*off[w] + 96*w + sf*pitch(n),  pitch(n) = (n/3 + 16) & ~15   (closed form: no prefix sums)
+#include <algorithm>
+#include <cstring>
+
 #include "bath_common.hpp"
 #include "bath_kernels.hpp"
 #include "bath_launch.hpp"
@@ -311,19 +314,57 @@ int orf_tiles_ensure(bath_hip_ctx *ctx, const bath_hip_seqs *dna) {
   return BATH_OK;
 }
 
-void build_codon64(const uint8_t basic[64], uint8_t fwd[64], uint8_t rev[64]) {
+// ---- translation tables ------------------------------------------------------------------------------------------
+static bool dna_degen_has(int x, int y) {
+  static const char *members[18] = {"A", "C", "G", "T", "", "AG", "CT", "AC", "GT", "CG", "AT", "ACT", "CGT", "ACG", "AGT", "ACGT", "", ""};
+  static const char nt[] = "ACGT";
+  return std::strchr(members[x], nt[y]) != nullptr;
+}
+
+// codon -> amino acid for all 18^3 digital codons: canonical codons through basic[]; degenerate codons
+// give the amino acid all expansions agree on, else X (easel esl_gencode_GetTranslation semantics).
+static void build_codon_table(const uint8_t basic[64], std::vector<uint8_t> &tab) {
+  tab.assign(18 * 18 * 18, (uint8_t)kXaa);
+  for (int a = 0; a < 18; a++) for (int b = 0; b < 18; b++) for (int c = 0; c < 18; c++) {
+    int aa = -1; bool mixed = false;
+    for (int x = 0; x < 4 && !mixed; x++) { if (!dna_degen_has(a, x)) continue;
+      for (int y = 0; y < 4 && !mixed; y++) { if (!dna_degen_has(b, y)) continue;
+        for (int z = 0; z < 4; z++) { if (!dna_degen_has(c, z)) continue;
+          int v = basic[16 * x + 4 * y + z];
+          if (aa == -1) aa = v; else if (aa != v) { mixed = true; break; }
+        } } }
+    tab[(a * 18 + b) * 18 + c] = (uint8_t)((mixed || aa == -1) ? kXaa : aa);
+  }
+}
+
+int orf_tables_upload(bath_hip_ctx *ctx, int ncbi_table, OrfTablesDev *t) {
+  uint8_t basic[64];
+  if (bath_gencode_basic(ncbi_table, basic) != BATH_OK) { ctx->set_error("unknown NCBI translation table"); return BATH_EINVAL; }
+  std::vector<uint8_t> host(6144 + 256, 0);
+  std::vector<uint8_t> full;
+  build_codon_table(basic, full);
+  std::memcpy(host.data(), full.data(), full.size());
+  uint8_t *fwd = host.data() + 6144, *rev = fwd + 64, *comp = rev + 64;
   for (int a = 0; a < 4; a++) for (int b = 0; b < 4; b++) for (int c = 0; c < 4; c++) {
     fwd[a * 16 + b * 4 + c] = basic[16 * a + 4 * b + c];
     // memory-order bytes (x0,x1,x2) = (a,b,c): the reverse-strand codon is comp(x2), comp(x1), comp(x0)
     rev[a * 16 + b * 4 + c] = basic[16 * (3 - c) + 4 * (3 - b) + (3 - a)];
   }
+  static const uint8_t kComp[18] = {3, 2, 1, 0, 4, 6, 5, 8, 7, 9, 10, 14, 13, 12, 11, 15, 16, 17};   // ACGT-RYMKSWHBVDN*~
+  std::memcpy(comp, kComp, 18);
+  DevBuf &b = ctx->scratch[28];
+  BATH_HIP_TRY(ctx, b.reserve(host.size()));
+  BATH_HIP_TRY(ctx, hipMemcpyAsync(b.p, host.data(), host.size(), hipMemcpyHostToDevice, ctx->stream));
+  BATH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  t->full = b.as<uint8_t>(); t->fwd = t->full + 6144; t->rev = t->fwd + 64; t->comp = t->rev + 64;
+  return BATH_OK;
 }
 
-int launch_orf_scan(bath_hip_ctx *ctx, const bath_hip_seqs *dna, const uint8_t *d_aa_full, const uint8_t *d_aa64_fwd, const uint8_t *d_aa64_rev,
-                    const uint8_t *d_comp, int minlen, const OrfBuffers &b, unsigned long long *d_n_orfs, unsigned long long *d_orf_res) {
+int launch_orf_scan(bath_hip_ctx *ctx, const bath_hip_seqs *dna, const OrfTablesDev &tt, int minlen, const OrfBuffers &b,
+                    unsigned long long *d_n_orfs, unsigned long long *d_orf_res) {
   const int64_t ntiles = dna->ntiles;
   BATH_HIP_TRY(ctx, hipMemsetAsync(b.hist, 0, kOrfBins * sizeof(int), ctx->stream));
-  OrfScanTables tabs{d_aa_full, d_aa64_fwd, d_aa64_rev, d_comp};
+  OrfScanTables tabs{tt.full, tt.fwd, tt.rev, tt.comp};
   OrfTiles tiles{dna->d_tile_win, dna->d_tile_first, ntiles};
   OrfScanOut out{b.aa, reinterpret_cast<uint2 *>(b.slots), b.cnt, b.prefix, b.suffix, b.hist, d_n_orfs, d_orf_res, orf_slot_cap(minlen)};
   const int cus = ctx->prop.multiProcessorCount;
@@ -340,3 +381,67 @@ int launch_orf_scan(bath_hip_ctx *ctx, const bath_hip_seqs *dna, const uint8_t *
 }
 
 }  // namespace bath
+
+using namespace bath;
+
+// esl_gencode_Process* as driven by bathsearch.c:384-392, for a whole block: the ORF list and residues, on the host.
+extern "C" int bath_hip_translate_orfs(bath_hip_ctx *ctx, const bath_hip_seqs *dna, int ncbi_table, int min_orf_len,
+                                       const bath_orf **orfs, int64_t *n_orfs, const uint8_t **aa) {
+  if (!ctx || !dna || !orfs || !n_orfs || min_orf_len < 0) return BATH_EINVAL;
+  BATH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  *orfs = nullptr; *n_orfs = 0;
+  if (aa) *aa = nullptr;
+  ctx->orfs.clear(); ctx->orf_aa.clear();
+  if (dna->n == 0) return BATH_OK;
+  int st;
+  OrfTablesDev tt{};
+  if ((st = orf_tables_upload(ctx, ncbi_table, &tt)) != BATH_OK) return st;
+  if ((st = orf_tiles_ensure(ctx, dna)) != BATH_OK) return st;
+  int64_t max_orfs = 0;
+  for (int64_t i = 0; i < dna->n; i++) if (dna->h_len[i] >= 15) max_orfs += 6 * (int64_t)((dna->h_len[i] / 3 + 1) / (min_orf_len + 1) + 1);
+  const size_t nent = (size_t)dna->ntiles * 6;
+  DevBuf &b_aa = ctx->scratch[24], &b_slots = ctx->scratch[25], &b_orfs = ctx->scratch[26], &b_misc = ctx->scratch[27];
+  BATH_HIP_TRY(ctx, b_aa.reserve(orf_aa_bytes(dna)));
+  BATH_HIP_TRY(ctx, b_slots.reserve((nent * (size_t)orf_slot_cap(min_orf_len) + 64) * 8));
+  BATH_HIP_TRY(ctx, b_orfs.reserve((size_t)(max_orfs + 64) * sizeof(OrfRec)));
+  BATH_HIP_TRY(ctx, b_misc.reserve((3 * nent + 2 * kOrfBins + 64) * sizeof(int32_t) + 64));
+  OrfBuffers ob{};
+  ob.aa = b_aa.as<uint8_t>(); ob.slots = b_slots.p; ob.sorted = b_orfs.as<OrfRec>();
+  ob.cnt = b_misc.as<int32_t>(); ob.prefix = ob.cnt + nent; ob.suffix = ob.prefix + nent;
+  ob.hist = reinterpret_cast<int *>(ob.suffix + nent); ob.cursor = ob.hist + kOrfBins; ob.ntotal = ob.cursor + kOrfBins;
+  unsigned long long *d_ctr = reinterpret_cast<unsigned long long *>(ob.ntotal + 2);   // two counters nobody reads here
+  BATH_HIP_TRY(ctx, hipMemsetAsync(d_ctr, 0, 16, ctx->stream));
+  if ((st = launch_orf_scan(ctx, dna, tt, min_orf_len, ob, d_ctr, d_ctr + 1)) != BATH_OK) return st;
+  int total = 0;
+  BATH_HIP_TRY(ctx, hipMemcpyAsync(&total, ob.ntotal, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  BATH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  std::vector<OrfRec> recs((size_t)total);
+  std::vector<uint8_t> pool(orf_aa_bytes(dna));
+  if (total > 0) BATH_HIP_TRY(ctx, hipMemcpy(recs.data(), ob.sorted, recs.size() * sizeof(OrfRec), hipMemcpyDeviceToHost));
+  BATH_HIP_TRY(ctx, hipMemcpy(pool.data(), ob.aa, pool.size(), hipMemcpyDeviceToHost));
+  ctx->orfs.resize((size_t)total);
+  for (int i = 0; i < total; i++) {
+    const OrfRec &r = recs[(size_t)i];
+    const int64_t w = r.w;
+    const int sf = (int)((unsigned)r.len_sf >> 28), len = r.len_sf & 0x0fffffff;
+    const int64_t stream = 2 * dna->h_off[w] + 96 * w + (int64_t)sf * orf_stream_pitch(dna->h_len[w]);
+    bath_orf &o = ctx->orfs[(size_t)i];
+    o.window = w; o.strand = sf / 3; o.frame = sf % 3; o.n = len;
+    o.start = o.frame + 3 * (int32_t)(r.aa_off - stream) + 1; o.end = o.start + 3 * len - 1;
+    o.aa_off = r.aa_off;                                     // device pool offset for now; rewritten below
+  }
+  std::sort(ctx->orfs.begin(), ctx->orfs.end(), [](const bath_orf &a, const bath_orf &b) {
+    if (a.window != b.window) return a.window < b.window;
+    if (a.strand != b.strand) return a.strand < b.strand;
+    if (a.frame != b.frame) return a.frame < b.frame;
+    return a.start < b.start;
+  });
+  for (bath_orf &o : ctx->orfs) {
+    const int64_t src = o.aa_off;
+    o.aa_off = (int64_t)ctx->orf_aa.size();
+    ctx->orf_aa.insert(ctx->orf_aa.end(), pool.begin() + src, pool.begin() + src + o.n);
+  }
+  *orfs = ctx->orfs.data(); *n_orfs = total;
+  if (aa) *aa = ctx->orf_aa.data();
+  return BATH_OK;
+}

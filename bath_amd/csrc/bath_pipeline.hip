@@ -30,36 +30,6 @@ namespace bath {
 static const double kLog2 = 0.69314718055994529;
 
 // ---------------------------------------------------------------------------------------------
-// translation tables
-// ---------------------------------------------------------------------------------------------
-struct DnaTables {
-  const uint8_t *aa;      // [18*18*18] amino code of every (possibly degenerate) codon, esl_gencode_GetTranslation
-  const uint8_t *comp;    // [18] complement
-};
-
-static bool dna_degen_has(int x, int y) {
-  static const char *members[18] = {"A", "C", "G", "T", "", "AG", "CT", "AC", "GT", "CG", "AT", "ACT", "CGT", "ACG", "AGT", "ACGT", "", ""};
-  static const char nt[] = "ACGT";
-  return std::strchr(members[x], nt[y]) != nullptr;
-}
-
-// codon -> amino acid for all 18^3 digital codons: canonical codons through basic[]; degenerate codons
-// give the amino acid all expansions agree on, else X (easel esl_gencode_GetTranslation semantics).
-static void build_codon_table(const uint8_t basic[64], std::vector<uint8_t> &tab) {
-  tab.assign(18 * 18 * 18, (uint8_t)kXaa);
-  for (int a = 0; a < 18; a++) for (int b = 0; b < 18; b++) for (int c = 0; c < 18; c++) {
-    int aa = -1; bool mixed = false;
-    for (int x = 0; x < 4 && !mixed; x++) { if (!dna_degen_has(a, x)) continue;
-      for (int y = 0; y < 4 && !mixed; y++) { if (!dna_degen_has(b, y)) continue;
-        for (int z = 0; z < 4; z++) { if (!dna_degen_has(c, z)) continue;
-          int v = basic[16 * x + 4 * y + z];
-          if (aa == -1) aa = v; else if (aa != v) { mixed = true; break; }
-        } } }
-    tab[(a * 18 + b) * 18 + c] = (uint8_t)((mixed || aa == -1) ? kXaa : aa);
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
 // candidate storage (structure of arrays, indexed by candidate id)
 // ---------------------------------------------------------------------------------------------
 struct Cand {
@@ -527,33 +497,20 @@ extern "C" int bath_hip_pipeline_filters(bath_hip_ctx *ctx, const bath_hip_oprof
   if (st != BATH_OK) return st;
 
   // ---- per-call tables
-  uint8_t basic[64];
-  if (bath_gencode_basic(prm->ncbi_table, basic) != BATH_OK) { ctx->set_error("unknown NCBI translation table"); return BATH_EINVAL; }
-  std::vector<uint8_t> codon_tab;
-  build_codon_table(basic, codon_tab);
-  static const uint8_t comp[18] = {3, 2, 1, 0, 4, 6, 5, 8, 7, 9, 10, 14, 13, 12, 11, 15, 16, 17};
+  OrfTablesDev tt{};
+  if ((st = orf_tables_upload(ctx, prm->ncbi_table, &tt)) != BATH_OK) return st;
   std::vector<int16_t> emit;
   build_emit_table(om, prm->F1, max_orf, emit);
   std::vector<uint8_t> ssv_scores((size_t)(M + 1) * kKp, 0);
   bath_hip_oprofile_get_ssv_scores(om, ssv_scores.data());
 
-  uint8_t codon64_fwd[64], codon64_rev[64];
-  build_codon64(basic, codon64_fwd, codon64_rev);
   DevBuf &b_tabs = ctx->scratch[8], &b_work = ctx->scratch[9];
   const size_t tabs_bytes = 8192 + emit.size() * 2 + 256 + ssv_scores.size() + 256 + 20 * 4 + 256;
   BATH_HIP_TRY(ctx, b_tabs.reserve(tabs_bytes));
   char *tp = b_tabs.as<char>();
-  uint8_t *d_codon = reinterpret_cast<uint8_t *>(tp); tp += 6144;
-  uint8_t *d_comp = reinterpret_cast<uint8_t *>(tp); tp += 64;
-  uint8_t *d_c64f = reinterpret_cast<uint8_t *>(tp); tp += 64;
-  uint8_t *d_c64r = reinterpret_cast<uint8_t *>(tp); tp += 128;
   int16_t *d_emit = reinterpret_cast<int16_t *>(tp); tp += (emit.size() * 2 + 255) / 256 * 256;
   uint8_t *d_ssvsc = reinterpret_cast<uint8_t *>(tp); tp += (ssv_scores.size() + 255) / 256 * 256;
   float *d_bgf = reinterpret_cast<float *>(tp);
-  BATH_HIP_TRY(ctx, hipMemcpyAsync(d_codon, codon_tab.data(), codon_tab.size(), hipMemcpyHostToDevice, ctx->stream));
-  BATH_HIP_TRY(ctx, hipMemcpyAsync(d_comp, comp, 18, hipMemcpyHostToDevice, ctx->stream));
-  BATH_HIP_TRY(ctx, hipMemcpyAsync(d_c64f, codon64_fwd, 64, hipMemcpyHostToDevice, ctx->stream));
-  BATH_HIP_TRY(ctx, hipMemcpyAsync(d_c64r, codon64_rev, 64, hipMemcpyHostToDevice, ctx->stream));
   BATH_HIP_TRY(ctx, hipMemcpyAsync(d_emit, emit.data(), emit.size() * 2, hipMemcpyHostToDevice, ctx->stream));
   BATH_HIP_TRY(ctx, hipMemcpyAsync(d_ssvsc, ssv_scores.data(), ssv_scores.size(), hipMemcpyHostToDevice, ctx->stream));
   BATH_HIP_TRY(ctx, hipMemcpyAsync(d_bgf, kAminoBg, 20 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
@@ -619,7 +576,7 @@ extern "C" int bath_hip_pipeline_filters(bath_hip_ctx *ctx, const bath_hip_oprof
     int e = 0;
     BATH_HIP_TRY(ctx, hipEventRecord(ev[e++], ctx->stream));
     // 1. six-frame translation, ORFs, length-sorted work list
-    if ((st = launch_orf_scan(ctx, dna, d_codon, d_c64f, d_c64r, d_comp, prm->min_orf_len, ob, &W.ctr->n_orfs, &W.ctr->orf_res)) != BATH_OK) return st;
+    if ((st = launch_orf_scan(ctx, dna, tt, prm->min_orf_len, ob, &W.ctr->n_orfs, &W.ctr->orf_res)) != BATH_OK) return st;
     BATH_HIP_TRY(ctx, hipEventRecord(ev[e++], ctx->stream));
     // 2. SSV + F1 threshold, lane per ORF
     {

@@ -171,6 +171,20 @@ typedef struct {                   /* pipeline counters, hmmer.h:1115-1128 */
   int64_t cells_msv, cells_vit, cells_fwd;     /* sum of L*M per stage (Mc/s numerator, msvfilter.c:563) */
 } bath_pipeline_stats;
 
+/* Six-frame translation of a block of DNA windows: esl_gencode_ProcessStart/Piece/End as driven by
+ * bathsearch.c:384-392 (both strands, no initiator requirement; windows < 15 nt skipped, bathsearch.c:1066).
+ * Every maximal run of non-stop codons of >= min_orf_len residues is one ORF. */
+typedef struct {
+  int64_t window;                  /* index in the block                                                   */
+  int32_t strand, frame;           /* 0 = as given, 1 = reverse complement; frame 0..2                      */
+  int32_t start, end;              /* 1-based nt coordinates on that strand (orfsq->start/end convention)   */
+  int32_t n;                       /* residues                                                              */
+  int64_t aa_off;                  /* residues of this ORF are aa[aa_off .. aa_off+n)                       */
+} bath_orf;
+/* On return *orfs (sorted by window, strand, frame, start) and *aa are owned by ctx, valid until the next call. */
+int  bath_hip_translate_orfs(bath_hip_ctx *ctx, const bath_hip_seqs *dna, int ncbi_table, int min_orf_len,
+                             const bath_orf **orfs, int64_t *n_orfs, const uint8_t **aa);
+
 void bath_pipeline_params_default(bath_pipeline_params *p, int fs_pipe);
 /* Runs the cascade on every window of <dna>, both strands.  On return *results points to an array of
  * *n_results records owned by ctx (valid until the next call); pass NULL to skip the copy-out. */
