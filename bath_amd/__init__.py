@@ -103,6 +103,15 @@ class Orf(C.Structure):
                 ("n", C.c_int32), ("aa_off", C.c_int64)]
 
 
+class FsWindow(C.Structure):
+    """bath_fs_window (include/bath_hip.h): one DNA window of the frameshift stage."""
+    _fields_ = [("window", C.c_int64), ("strand", C.c_int32), ("n", C.c_int32), ("length", C.c_int32),
+                ("orf_cnt", C.c_int32), ("k_min", C.c_int32), ("k_max", C.c_int32),
+                ("tot_orfsc", C.c_float), ("nullsc", C.c_float), ("filtersc", C.c_float), ("fwdsc", C.c_float),
+                ("P_tot", C.c_double), ("P_min", C.c_double), ("P_fs", C.c_double), ("P_null", C.c_double),
+                ("branch", C.c_int32)]
+
+
 class Fs5Result(C.Structure):
     _fields_ = [("fwdsc", C.c_float), ("bcksc", C.c_float), ("oasc", C.c_float), ("null2", C.c_float * KP)]
 
@@ -142,6 +151,8 @@ ABI = {
     "bath_pipeline_params_default": (None, [C.POINTER(PipelineParams), C.c_int]),
     "bath_hip_pipeline_filters": (C.c_int, [_vp, _vp, _vp, C.POINTER(PipelineParams), C.POINTER(PipelineStats),
                                             C.POINTER(C.POINTER(OrfResult)), _i64p]),
+    "bath_hip_pipeline_frameshift": (C.c_int, [_vp, _vp, _vp, _vp, C.POINTER(PipelineParams), C.POINTER(PipelineStats),
+                                              C.POINTER(C.POINTER(OrfResult)), _i64p, C.POINTER(C.POINTER(FsWindow)), _i64p]),
     "bath_hip_pipeline_timings": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_char_p), _f32p, _i64p]),
     "bath_hip_fsprofile_convert": (C.c_int, [_vp, C.POINTER(_FsProfile), C.POINTER(_vp)]),
     "bath_hip_fsprofile_destroy": (None, [_vp]),
@@ -462,6 +473,27 @@ class Pipeline:
             else:
                 out = np.zeros(0, dtype=ORF_RESULT_DTYPE)
         return stats, out
+
+    def run_frameshift(self, om_fs3, dna):
+        """bathsearch --fs up to the branch decision: (stats, ORF records, list of FsWindow copies)."""
+        stats = PipelineStats()
+        res = C.POINTER(OrfResult)()
+        n = C.c_int64(0)
+        fw = C.POINTER(FsWindow)()
+        nfw = C.c_int64(0)
+        self.ctx._check(lib().bath_hip_pipeline_frameshift(self.ctx._h, self.om._h, om_fs3._h, dna._h, C.byref(self.params), C.byref(stats),
+                                                           C.byref(res), C.byref(n), C.byref(fw), C.byref(nfw)), "pipeline_frameshift")
+        if n.value:
+            buf = (OrfResult * n.value).from_address(C.addressof(res.contents))
+            out = np.frombuffer(buf, dtype=ORF_RESULT_DTYPE).copy()
+        else:
+            out = np.zeros(0, dtype=ORF_RESULT_DTYPE)
+        wins = []
+        for i in range(nfw.value):
+            w = FsWindow()
+            C.memmove(C.byref(w), C.byref(fw[i]), C.sizeof(FsWindow))
+            wins.append(w)
+        return stats, out, wins
 
     def timings(self):
         names = (C.c_char_p * 32)()

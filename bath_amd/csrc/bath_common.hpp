@@ -58,6 +58,7 @@ struct bath_hip_ctx {
   bath::DevBuf scratch[32];
   std::vector<bath_orf_result> results;
   std::vector<bath_orf> orfs;             // bath_hip_translate_orfs output
+  std::vector<bath_fs_window> fs_windows; // bath_hip_pipeline_frameshift output
   std::vector<uint8_t> orf_aa;
   std::vector<bath::StageTiming> timings;
   std::vector<hipEvent_t> ev_pool;
@@ -121,6 +122,7 @@ struct bath_hip_oprofile {
   float scale_w = 0;
   int16_t base_w = 0, ddbound_w = 0;
   float xf_E[2] = {0, 0};
+  std::vector<float> prefix_lengths, suffix_lengths;   // [M+1] P7_SCOREDATA window padding fractions (p7_scoredata.c:357-380)
   // device tables
   int NR = 0, G = 1;            // SSV kernel tile: NR packed int16 registers per lane, G lanes per target (2*NR*G >= M)
   int ssv_row_bytes = 0;

@@ -917,6 +917,15 @@ static int fs3_parser(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, const bat
   return BATH_OK;
 }
 
+namespace bath {
+// used by the pipeline's frameshift stage (bath_pipeline.hip)
+int fs3_forward_scores(bath_hip_ctx *ctx, const bath_hip_fsprofile *om3, const bath_hip_seqs *dna, float *sc) {
+  return fs3_parser(ctx, om3, dna, BATH_LOGSUM_TABLE, sc, nullptr, nullptr, false);
+}
+const float *fsprofile_evparam(const bath_hip_fsprofile *om) { return om->evparam; }
+int fsprofile_codon_lengths(const bath_hip_fsprofile *om) { return om->codon_lengths; }
+}  // namespace bath
+
 extern "C" int bath_hip_fs3_forward_parser(bath_hip_ctx *ctx, const bath_hip_fsprofile *om3, const bath_hip_seqs *dna, int logsum_mode,
                                            float *sc, float *xmx, const int64_t *xmx_offsets) {
   return fs3_parser(ctx, om3, dna, logsum_mode, sc, xmx, xmx_offsets, false);

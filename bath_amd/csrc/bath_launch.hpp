@@ -39,6 +39,11 @@ int launch_vit_lane(bath_hip_ctx *ctx, const bath_hip_oprofile *om, SeqView v, c
 struct MsvConsts;
 MsvConsts msv_consts(const bath_hip_oprofile *om);
 
+// ---- frameshift helpers for the pipeline (bath_frameshift.hip)
+int fs3_forward_scores(bath_hip_ctx *ctx, const bath_hip_fsprofile *om3, const bath_hip_seqs *dna, float *sc);   // table log-sum, host array out
+const float *fsprofile_evparam(const bath_hip_fsprofile *om);
+int fsprofile_codon_lengths(const bath_hip_fsprofile *om);
+
 // ---- six-frame translation + ORF work list (bath_orfs.hip)
 struct OrfRec {                   // one ORF of the length-sorted work list
   int64_t aa_off;                 // offset of its first residue in the amino-acid stream pool

@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <map>
 
 #include "bath_common.hpp"
 #include "bath_kernels.hpp"
@@ -481,9 +482,19 @@ extern "C" int bath_hip_pipeline_timings(const bath_hip_ctx *ctx, int max, const
   return n;
 }
 
-extern "C" int bath_hip_pipeline_filters(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bath_hip_seqs *dna,
-                                         const bath_pipeline_params *prm, bath_pipeline_stats *stats,
-                                         const bath_orf_result **results, int64_t *n_results) {
+namespace bath {
+struct FilterState {               // what the frameshift stage reads after the cascade (device memory stays in ctx->scratch)
+  PipelineWork W;
+  Counters hc;
+  const uint8_t *d_ssvsc = nullptr;
+  const float *d_bgf = nullptr;
+  OrfTablesDev tt{};
+};
+}  // namespace bath
+
+static int run_filters(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bath_hip_seqs *dna,
+                       const bath_pipeline_params *prm, bath_pipeline_stats *stats,
+                       const bath_orf_result **results, int64_t *n_results, FilterState *state) {
   if (!ctx || !om || !dna || !prm) return BATH_EINVAL;
   BATH_HIP_TRY(ctx, hipSetDevice(ctx->device));
   if (n_results) *n_results = 0;
@@ -707,5 +718,317 @@ extern "C" int bath_hip_pipeline_filters(bath_hip_ctx *ctx, const bath_hip_oprof
     *results = ctx->results.data();
     if (n_results) *n_results = (int64_t)ctx->results.size();
   } else if (n_results) *n_results = (int64_t)hc.n_past_msv;
+  if (state) { state->W = W; state->hc = hc; state->d_ssvsc = d_ssvsc; state->d_bgf = d_bgf; state->tt = tt; }
+  return BATH_OK;
+}
+
+extern "C" int bath_hip_pipeline_filters(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bath_hip_seqs *dna,
+                                         const bath_pipeline_params *prm, bath_pipeline_stats *stats,
+                                         const bath_orf_result **results, int64_t *n_results) {
+  return run_filters(ctx, om, dna, prm, stats, results, n_results, nullptr);
+}
+
+// =================================================================================================
+// Frameshift stage: p7_pli_BuildDNAWindows + p7_pli_Frameshift up to the branch decision
+// (p7_pipeline.c:462-572, 1339-1470).  The ORFs that passed F4 are few (10^-4 of all ORFs): window building is
+// the reference's own serial logic on the host; the DNA windows' bias filter and 3-codon frameshift Forward run
+// on the GPU, batched over all windows of the block.
+// =================================================================================================
+namespace bath {
+
+struct FsWinDev {                  // one DNA window, device view
+  int64_t src_off;                 // offset of its sequence in the DNA block
+  int64_t dst_off;                 // offset of the window's copy in the pool
+  int32_t seq_n, start, len, strand, kmin, kmax;
+};
+
+// copy each window out of its sequence, reverse-complemented for the bottom strand
+__global__ void fs_window_gather_kernel(const uint8_t *__restrict__ dna, const FsWinDev *__restrict__ wins, int nw, const uint8_t *__restrict__ comp,
+                                        uint8_t *__restrict__ pool) {
+  for (int w = blockIdx.x; w < nw; w += gridDim.x) {
+    const FsWinDev d = wins[w];
+    const uint8_t *src = dna + d.src_off;
+    uint8_t *dst = pool + d.dst_off;
+    for (int i = threadIdx.x; i < d.len; i += blockDim.x) {
+      const int r = d.start - 1 + i;                     // 0-based position on the strand being read
+      dst[i] = d.strand ? comp[min((int)src[d.seq_n - 1 - r], 17)] : src[r];
+    }
+  }
+}
+
+// p7_bg_fs_FilterScore (p7_bg.c:522-561) without its length term: esl_hmm_Forward of the 2-state filter HMM over the
+// canonical residues of each of the three frames.  Lane per (window, pass): pass 0 uses the model's composition,
+// pass 1 the local composition of nodes kmin..kmax (p7_pli_ComputeLocalCompo).  out[(w*2+pass)*3 + frame].
+__global__ void fs_bias_kernel(const uint8_t *__restrict__ pool, const FsWinDev *__restrict__ wins, int nw, const uint8_t *__restrict__ aa_full, int M,
+                               const float *__restrict__ eo_global, const uint8_t *__restrict__ ssv_scores, int base_b, float scale_b,
+                               const float *__restrict__ bgf, float *__restrict__ out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 2 * nw) return;
+  const int w = t >> 1, pass = t & 1;
+  const FsWinDev d = wins[w];
+  float eo_local[2 * kKp];
+  const float *e = eo_global;
+  if (pass == 1) {
+    if (d.kmin > d.kmax) { out[t * 3] = out[t * 3 + 1] = out[t * 3 + 2] = -INFINITY; return; }
+    local_compo_eo(ssv_scores, M, base_b, scale_b, bgf, d.kmin, d.kmax, eo_local);
+    e = eo_local;
+  }
+  const uint8_t *s = pool + d.dst_off;
+  const int L = d.len, L3 = L / 3;
+  const float p1 = (float)L3 / (float)(L3 + 1);                             // p7_bg_SetLength(bg, length/3), p7_bg.c:193
+  const float L1 = (float)M / 8.0f;
+  const float t00 = p1, t01 = 1.0f - p1, t10 = 1.0f / (L1 + 1.0f), t11 = L1 / (L1 + 1.0f);
+  for (int f = 0; f < 3; f++) {
+    float logsc = 0.0f, d0 = 0.f, d1 = 0.f;
+    int cnt = 0;
+    for (int i = f; i + 2 < L; i += 3) {
+      const int a = min((int)s[i], 17), b = min((int)s[i + 1], 17), c = min((int)s[i + 2], 17);
+      const int x = aa_full[(a * 18 + b) * 18 + c];
+      if (x >= 20) continue;                                                // esl_abc_XIsCanonical
+      float n0, n1;
+      if (cnt == 0) { n0 = e[2 * x] * 0.999f; n1 = e[2 * x + 1] * 0.001f; }
+      else {
+        n0 = 0.0f + d0 * t00; n0 = n0 + d1 * t10; n0 *= e[2 * x];
+        n1 = 0.0f + d0 * t01; n1 = n1 + d1 * t11; n1 *= e[2 * x + 1];
+      }
+      const float mx = fmaxf(fmaxf(n0, 0.0f), n1);
+      d0 = n0 / mx; d1 = n1 / mx;
+      logsc += (float)log((double)mx);
+      cnt++;
+    }
+    if (cnt == 0) logsc = -INFINITY;                                         // esl_hmm_Forward, L = 0: log(pi[M]) = log 0
+    else { float end = 0.0f + d0 * 1.0f; end = end + d1 * 1.0f; logsc += (float)log((double)end); }
+    out[t * 3 + f] = logsc;
+  }
+}
+
+static float flogsum_host(float a, float b) {               // p7_FLogsum, logsum.c:105-111 (table of logsum.c:89)
+  static std::vector<float> tbl;
+  if (tbl.empty()) { tbl.resize(16000); for (int i = 0; i < 16000; i++) tbl[i] = (float)std::log(1. + std::exp((double)-i / 1000.f)); }
+  const float mx = std::max(a, b), mn = std::min(a, b);
+  return (mn == -INFINITY || (mx - mn) >= 15.7f) ? mx : mx + tbl[(int)((mx - mn) * 1000.f)];
+}
+
+struct FsOrf {                      // an ORF that passed F4, host side
+  int cand;
+  int32_t start, end, n;            // nt coordinates on the strand being read, residues
+  double P;
+  float fwd_null;                   // fwdsc - nullsc (pli_tmp->fwdsc, p7_pipeline.c:1782)
+  std::vector<WindowRec> wins;      // hit windows in emission order
+};
+struct DnaWin { int64_t n; int32_t k, length; };
+
+}  // namespace bath
+
+extern "C" int bath_hip_pipeline_frameshift(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bath_hip_fsprofile *om_fs3, const bath_hip_seqs *dna,
+                                            const bath_pipeline_params *prm_in, bath_pipeline_stats *stats,
+                                            const bath_orf_result **results, int64_t *n_results,
+                                            const bath_fs_window **fs_windows, int64_t *n_fs_windows) {
+  if (!ctx || !om || !om_fs3 || !dna || !prm_in || !fs_windows || !n_fs_windows) return BATH_EINVAL;
+  if (fsprofile_codon_lengths(om_fs3) != 3) { ctx->set_error("the frameshift stage needs the 3-codon frameshift profile"); return BATH_EINVAL; }
+  *fs_windows = nullptr; *n_fs_windows = 0;
+  ctx->fs_windows.clear();
+  bath_pipeline_params prm = *prm_in;
+  prm.fs_pipe = 1;
+  bath_pipeline_stats st_local{};
+  FilterState S;
+  int st = run_filters(ctx, om, dna, &prm, &st_local, results, n_results, &S);
+  if (st != BATH_OK) return st;
+  const int nc = S.hc.cand_count;
+  const int M = om->M;
+  const double kLn2 = 0.69314718055994529;
+
+  // ---- the ORFs that passed F4, with their hit windows
+  std::vector<int32_t> h_stage(nc), h_sf(nc), h_startj(nc), h_len(nc);
+  std::vector<int64_t> h_window(nc);
+  std::vector<float> h_fw(nc), h_null(nc);
+  std::vector<double> h_P(nc);
+  const int nwins = std::min(S.hc.win_count, S.W.win_cap);
+  std::vector<WindowRec> h_wins((size_t)std::max(nwins, 0));
+  if (nc > 0) {
+    auto pull = [&](void *dst, const void *src, size_t bytes) { return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream); };
+    BATH_HIP_TRY(ctx, pull(h_stage.data(), S.W.cand.stage, (size_t)nc * 4)); BATH_HIP_TRY(ctx, pull(h_sf.data(), S.W.cand.sf, (size_t)nc * 4));
+    BATH_HIP_TRY(ctx, pull(h_startj.data(), S.W.cand.startj, (size_t)nc * 4)); BATH_HIP_TRY(ctx, pull(h_len.data(), S.W.cand.len, (size_t)nc * 4));
+    BATH_HIP_TRY(ctx, pull(h_window.data(), S.W.cand.window, (size_t)nc * 8)); BATH_HIP_TRY(ctx, pull(h_fw.data(), S.W.cand.fwdsc, (size_t)nc * 4));
+    BATH_HIP_TRY(ctx, pull(h_null.data(), S.W.cand.nullsc, (size_t)nc * 4)); BATH_HIP_TRY(ctx, pull(h_P.data(), S.W.cand.P, (size_t)nc * 8));
+    if (nwins > 0) BATH_HIP_TRY(ctx, pull(h_wins.data(), S.W.wins, (size_t)nwins * sizeof(WindowRec)));
+    BATH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  struct Key { int64_t w; int strand; bool operator<(const Key &o) const { return w != o.w ? w < o.w : strand < o.strand; } };
+  std::map<Key, std::vector<FsOrf>> groups;
+  std::vector<int> slot_of(nc, -1);
+  std::vector<std::pair<Key, int>> where;
+  for (int c = 0; c < nc; c++) {
+    if (h_stage[c] != 4) continue;
+    const int strand = h_sf[c] / 3, frame = h_sf[c] % 3;
+    FsOrf o;
+    o.cand = c; o.n = h_len[c]; o.start = frame + 3 * h_startj[c] + 1; o.end = o.start + 3 * o.n - 1; o.P = h_P[c]; o.fwd_null = h_fw[c] - h_null[c];
+    groups[Key{h_window[c], strand}].push_back(o);
+  }
+  for (auto &g : groups) {
+    // the order in which esl_gencode emits a strand's ORFs: when the closing stop codon is read; ORFs still open at the
+    // end of the sequence follow, frame by frame
+    const int n_seq = dna->h_len[g.first.w];
+    std::stable_sort(g.second.begin(), g.second.end(), [n_seq](const FsOrf &a, const FsOrf &b) {
+      const bool ea = a.end + 3 > n_seq, eb = b.end + 3 > n_seq;
+      if (ea != eb) return !ea;
+      if (!ea) return a.end < b.end;
+      return (a.start - 1) % 3 < (b.start - 1) % 3;
+    });
+    for (size_t i = 0; i < g.second.size(); i++) slot_of[g.second[i].cand] = (int)i;
+  }
+  {
+    std::map<int, std::pair<Key, int>> by_cand;
+    for (auto &g : groups) for (size_t i = 0; i < g.second.size(); i++) by_cand[g.second[i].cand] = {g.first, (int)i};
+    for (const WindowRec &wr : h_wins) {
+      auto it = by_cand.find(wr.cand);
+      if (it != by_cand.end()) groups[it->second.first][(size_t)it->second.second].wins.push_back(wr);
+    }
+    for (auto &g : groups) for (FsOrf &o : g.second)
+      std::stable_sort(o.wins.begin(), o.wins.end(), [](const WindowRec &a, const WindowRec &b) { return a.n < b.n; });
+  }
+
+  // ---- p7_pli_BuildDNAWindows + the per-window ORF summary of p7_pli_Frameshift
+  std::vector<bath_fs_window> out;
+  std::vector<FsWinDev> dev;
+  std::vector<int64_t> std_branch_pos;            // pos_past_fwd the standard branch would add for each window
+  int64_t pool_bytes = 0;
+  for (auto &g : groups) {
+    const int64_t w = g.first.w;
+    const int strand = g.first.strand;
+    const int n_seq = dna->h_len[w];
+    std::vector<FsOrf> &orfs = g.second;
+    std::vector<DnaWin> wl;
+    for (const FsOrf &o : orfs) {
+      int best = -1;
+      float best_score = -INFINITY;
+      for (size_t i = 0; i < o.wins.size(); i++) {                          // :486-495
+        const WindowRec &x = o.wins[i];
+        if (x.score > best_score || (x.score == best_score && x.length > (best >= 0 ? o.wins[(size_t)best].length : 0))) { best_score = x.score; best = (int)i; }
+      }
+      int32_t cn, ck, cl;
+      if (best >= 0) { cn = o.wins[(size_t)best].n; ck = o.wins[(size_t)best].k; cl = o.wins[(size_t)best].length; }
+      else if (o.n >= M) { cn = (o.n - M) / 2 + 1; ck = M; cl = M; }        // :500-510: no window, centre of the model
+      else { cn = 1; ck = M - ((M - o.n) / 2); cl = o.n; }
+      int64_t ws = (int64_t)((double)(uint32_t)cn - (om->max_length * (0.1 + om->prefix_lengths[(size_t)(ck - cl + 1)])) + 1);      // :513
+      int64_t we = (int64_t)((double)((uint32_t)cn + (uint32_t)cl) + (om->max_length * (0.1 + om->suffix_lengths[(size_t)ck])) - 2);   // :514
+      ws = std::min<int64_t>(0, ws);                                        // :516-517 (sic)
+      we = std::max<int64_t>(o.n, we);
+      ws = std::max<int64_t>(1, (int64_t)o.start + ws * 3);                 // :520-527, o.start already on the strand being read
+      we = std::min<int64_t>(n_seq, (int64_t)o.start + we * 3);
+      wl.push_back(DnaWin{ws, ck, (int32_t)(we - ws + 1)});
+    }
+    std::stable_sort(wl.begin(), wl.end(), [](const DnaWin &a, const DnaWin &b) { return a.n < b.n; });      // p7_hmmwindow_SortByStart
+    size_t keep = 0;
+    for (size_t i = 1; i < wl.size(); i++) {                                // :541-566, pct_overlap = 0
+      DnaWin &prev = wl[keep];
+      const DnaWin &cur = wl[i];
+      const int64_t pe = prev.n + prev.length - 1, ce = cur.n + cur.length - 1;
+      const int32_t ov = (int32_t)(std::min(pe, ce) - std::max(prev.n, cur.n) + 1);
+      const int64_t ms = std::min(prev.n, cur.n), me = std::max(pe, ce);
+      const int32_t ml = (int32_t)(me - ms + 1);
+      if (((float)ov / std::min(prev.length, cur.length) > 0.f) && ml < (2 * (om->max_length * 3))) { prev.n = ms; prev.length = ml; }
+      else wl[++keep] = wl[i];
+    }
+    wl.resize(wl.empty() ? 0 : keep + 1);
+
+    const int64_t dstart = strand ? n_seq : 1;                             // dnasq->start of a whole sequence
+    for (const DnaWin &dw : wl) {
+      bath_fs_window r{};
+      r.window = w; r.strand = strand; r.n = (int32_t)dw.n; r.length = dw.length;
+      const int64_t wstart = strand ? dstart - (dw.n + dw.length) : dstart + dw.n - 1;       // :1373-1374
+      const int64_t wend = strand ? dstart - dw.n + 1 : wstart + dw.length - 1;
+      int orf_cnt = 0, k_min = M, k_max = 0;
+      float tot = -INFINITY;
+      double P_min = INFINITY;
+      int64_t std_pos = 0;
+      for (const FsOrf &o : orfs) {
+        int64_t os, oe;
+        if (strand) { const int64_t rs = (int64_t)n_seq - o.start + 1, re = (int64_t)n_seq - o.end + 1; os = dstart - (n_seq - re + 1) + 1; oe = dstart - (n_seq - rs + 1) + 1; }
+        else { os = dstart + o.start - 1; oe = dstart + o.end - 1; }
+        if (!(os >= wstart && oe <= wend)) continue;                        // :1405
+        P_min = std::min(P_min, o.P);
+        tot = flogsum_host(tot, o.fwd_null);
+        orf_cnt++;
+        for (const WindowRec &x : o.wins) { k_min = std::min(k_min, x.k - x.length + 1); k_max = std::max(k_max, x.k); }
+        if (!(o.P > prm.F3)) std_pos += (int64_t)o.n * 3;                   // :1483-1487
+      }
+      r.orf_cnt = orf_cnt; r.k_min = k_min; r.k_max = k_max; r.tot_orfsc = tot; r.P_min = P_min;
+      r.P_tot = exp_surv((double)tot / kLn2, om->evparam[BATH_FTAU], om->evparam[BATH_FLAMBDA]);
+      out.push_back(r);
+      std_branch_pos.push_back(std_pos);
+      FsWinDev d{};
+      d.src_off = dna->h_off[w]; d.dst_off = pool_bytes; d.seq_n = n_seq; d.start = (int32_t)dw.n; d.len = dw.length; d.strand = strand;
+      d.kmin = k_min; d.kmax = k_max;
+      dev.push_back(d);
+      pool_bytes += ((int64_t)dw.length + 15) / 16 * 16 + 16;
+    }
+  }
+  const int nw = (int)out.size();
+  int64_t pos_fwd = 0;
+  if (nw > 0) {
+    // ---- windows -> device, bias filter and 3-codon frameshift Forward for all of them
+    DevBuf &b_pool = ctx->scratch[29], &b_desc = ctx->scratch[30], &b_out = ctx->scratch[31];
+    BATH_HIP_TRY(ctx, b_pool.reserve((size_t)pool_bytes + 256));
+    const size_t desc_bytes = ((size_t)nw * sizeof(FsWinDev) + 255) / 256 * 256;
+    BATH_HIP_TRY(ctx, b_desc.reserve(desc_bytes + (size_t)nw * 12 + 64));        // descriptors, then the view's off[] and len[]
+    BATH_HIP_TRY(ctx, b_out.reserve((size_t)nw * 6 * sizeof(float) + 64));
+    BATH_HIP_TRY(ctx, hipMemsetAsync(b_pool.p, 0x1d, (size_t)pool_bytes + 256, ctx->stream));
+    FsWinDev *d_desc = b_desc.as<FsWinDev>();
+    BATH_HIP_TRY(ctx, hipMemcpyAsync(d_desc, dev.data(), (size_t)nw * sizeof(FsWinDev), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(fs_window_gather_kernel, dim3((unsigned)std::min(nw, 65535)), dim3(256), 0, ctx->stream, dna->d_data, d_desc, nw, S.tt.comp, b_pool.as<uint8_t>());
+    hipLaunchKernelGGL(fs_bias_kernel, dim3((unsigned)((2 * nw + 63) / 64)), dim3(64), 0, ctx->stream, b_pool.as<uint8_t>(), d_desc, nw, S.tt.full, M, om->d_bias_eo,
+                       S.d_ssvsc, (int)om->base_b, om->scale_b, S.d_bgf, b_out.as<float>());
+    BATH_HIP_TRY(ctx, hipGetLastError());
+    std::vector<float> h_bias((size_t)nw * 6);
+    BATH_HIP_TRY(ctx, hipMemcpyAsync(h_bias.data(), b_out.p, h_bias.size() * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    // a sequence-block view of the window pool for the Forward parser
+    bath_hip_seqs view;
+    view.ctx = ctx; view.n = nw; view.d_data = b_pool.as<uint8_t>();
+    view.h_off.resize((size_t)nw); view.h_len.resize((size_t)nw);
+    for (int i = 0; i < nw; i++) { view.h_off[(size_t)i] = dev[(size_t)i].dst_off; view.h_len[(size_t)i] = dev[(size_t)i].len; view.maxlen = std::max(view.maxlen, dev[(size_t)i].len); view.total += dev[(size_t)i].len; }
+    view.total_aligned = pool_bytes;
+    int64_t *d_voff = reinterpret_cast<int64_t *>(reinterpret_cast<char *>(d_desc) + desc_bytes);
+    int32_t *d_vlen = reinterpret_cast<int32_t *>(d_voff + nw);
+    BATH_HIP_TRY(ctx, hipMemcpyAsync(d_voff, view.h_off.data(), (size_t)nw * 8, hipMemcpyHostToDevice, ctx->stream));
+    BATH_HIP_TRY(ctx, hipMemcpyAsync(d_vlen, view.h_len.data(), (size_t)nw * 4, hipMemcpyHostToDevice, ctx->stream));
+    view.d_off = d_voff; view.d_len = d_vlen;
+    std::vector<float> h_fsc((size_t)nw);
+    st = fs3_forward_scores(ctx, om_fs3, &view, h_fsc.data());
+    view.d_data = nullptr; view.d_off = nullptr; view.d_len = nullptr;     // borrowed pointers: nothing for a destructor to free
+    if (st != BATH_OK) return st;
+    BATH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+
+    // ---- scores -> P-values -> which branch each window takes (:1425-1464)
+    const float *ev3 = fsprofile_evparam(om_fs3);
+    for (int i = 0; i < nw; i++) {
+      bath_fs_window &r = out[(size_t)i];
+      const int L = r.length, L3 = L / 3;
+      const float p1 = (float)L3 / (float)(L3 + 1);
+      const float per_frame = (float)((float)L3 * std::log((double)p1) + std::log(1. - p1));           // p7_bg_fs_NullOne, p7_bg.c:380
+      r.nullsc = (float)(per_frame + std::log(3.0));
+      if (prm.do_biasfilter) {
+        float fsc[2];
+        for (int pass = 0; pass < 2; pass++) {
+          const float *b = &h_bias[((size_t)i * 2 + pass) * 3];
+          float sum = -INFINITY;
+          for (int f = 0; f < 3; f++) sum = flogsum_host(sum, b[f]);
+          fsc[pass] = (float)((double)sum + ((double)((float)L3 * logf(p1) + logf((float)(1. - p1))) + std::log(3.0)));   // p7_bg.c:561
+        }
+        r.filtersc = fsc[0];
+        if (r.k_min <= r.k_max && fsc[1] > r.filtersc) r.filtersc = fsc[1];                             // :1432-1440
+      } else r.filtersc = r.nullsc;
+      r.fwdsc = h_fsc[(size_t)i];
+      const float seqscore = (float)((r.fwdsc - r.filtersc) / kLn2);
+      r.P_fs = exp_surv(seqscore, ev3[BATH_FTAUFS3], ev3[BATH_FLAMBDA]);
+      r.P_null = exp_surv((r.fwdsc - r.nullsc) / kLn2, ev3[BATH_FTAUFS3], ev3[BATH_FLAMBDA]);
+      if (r.P_fs <= prm.F3 && (r.P_null < r.P_tot || (r.P_null == r.P_tot && r.orf_cnt > 1) || r.P_min > prm.F3)) { r.branch = 1; pos_fwd += L; }
+      else { r.branch = 2; pos_fwd += std_branch_pos[(size_t)i]; }
+    }
+  }
+  st_local.pos_past_fwd = pos_fwd;                                         // in the fs pipeline only this stage counts it (:1468, :1490)
+  if (stats) *stats = st_local;
+  ctx->fs_windows = out;
+  *fs_windows = ctx->fs_windows.data(); *n_fs_windows = nw;
   return BATH_OK;
 }

@@ -215,6 +215,25 @@ extern "C" int bath_hip_oprofile_convert(bath_hip_ctx *ctx, const bath_profile *
   om->xf_E[0] = expf(gm->xsc[0][0]);
   om->xf_E[1] = expf(gm->xsc[0][1]);
 
+  // ---- P7_SCOREDATA prefix/suffix fractions (p7_hmm_ScoreDataComputeRest, p7_scoredata.c:357-380): how much of MAXL a DNA
+  // window reserves before / after a seed diagonal that starts / ends at node k.  Inputs are the Forward transition
+  // odds MI, II exactly as p7_oprofile_GetFwdTransitionArray returns them.
+  {
+    std::vector<float> &pre = om->prefix_lengths, &suf = om->suffix_lengths;
+    pre.assign(W, 0.f); suf.assign(W, 0.f);
+    float total = 0;
+    for (int k = 1; k < M; k++) {
+      const float t_mi = om->tf[(size_t)k * 8 + MI], t_ii = om->tf[(size_t)k * 8 + II];
+      pre[k] = (t_mi == 0) ? 1.f : (float)(1 + (int)(std::log(1e-7 / t_mi) / std::log((double)t_ii)));   // p7_DEFAULT_WINDOW_BETA
+      total += pre[k];
+    }
+    pre[0] = pre[M] = 0;
+    for (int k = 1; k < M; k++) pre[k] /= total;
+    suf[M] = pre[M - 1];
+    for (int k = M - 1; k >= 1; k--) suf[k] = suf[k + 1] + pre[k - 1];
+    for (int k = 2; k < M; k++) pre[k] += pre[k - 1];
+  }
+
   // ---- device layouts
   // SSV: signed costs sb = min(rb - bias, 127) (sf_conversion) as int16, one row per residue plus a
   // "reset" row; columns 1..M real, padded with +127 up to 2*NR*G.  Row pitch is an odd multiple of 16 bytes so
@@ -346,13 +365,14 @@ extern "C" int bath_hip_seqs_create(bath_hip_ctx *ctx, const uint8_t *dsq, const
   BATH_HIP_TRY(ctx, hipMalloc((void **)&sq->d_off, (size_t)std::max<int64_t>(n, 1) * sizeof(int64_t)));
   BATH_HIP_TRY(ctx, hipMalloc((void **)&sq->d_len, (size_t)std::max<int64_t>(n, 1) * sizeof(int32_t)));
   BATH_HIP_TRY(ctx, hipMemsetAsync(sq->d_data, 0x1d, bytes, ctx->stream));
+  std::vector<uint8_t> staged;      // must outlive the asynchronous copy: everything here is ordered on ctx->stream
   if (n > 0) {
     if (contiguous_ok) {
       BATH_HIP_TRY(ctx, hipMemcpyAsync(sq->d_data, dsq + offsets[0], (size_t)(offsets[n] - offsets[0]), hipMemcpyHostToDevice, ctx->stream));
     } else {
-      std::vector<uint8_t> staged((size_t)pos, 0x1d);
+      staged.assign((size_t)pos, 0x1d);
       for (int64_t i = 0; i < n; i++) std::memcpy(staged.data() + sq->h_off[i], dsq + offsets[i], (size_t)sq->h_len[i]);
-      BATH_HIP_TRY(ctx, hipMemcpy(sq->d_data, staged.data(), staged.size(), hipMemcpyHostToDevice));
+      BATH_HIP_TRY(ctx, hipMemcpyAsync(sq->d_data, staged.data(), staged.size(), hipMemcpyHostToDevice, ctx->stream));
     }
     BATH_HIP_TRY(ctx, hipMemcpyAsync(sq->d_off, sq->h_off.data(), (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
     BATH_HIP_TRY(ctx, hipMemcpyAsync(sq->d_len, sq->h_len.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));

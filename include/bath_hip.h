@@ -36,6 +36,9 @@ extern "C" {
 #define BATH_K_AMINO    20
 #define BATH_KP_DNA     18   /* easel DNA alphabet   "ACGT-RYMKSWHBVDN*~"            */
 #define BATH_NEVPARAM    8   /* MMU MLAMBDA VMU VLAMBDA FTAU FLAMBDA FTAUFS3 FTAUFS5 (hmmer.h:67) */
+#define BATH_FTAU        4
+#define BATH_FLAMBDA     5
+#define BATH_FTAUFS3     6
 
 typedef struct bath_hip_ctx      bath_hip_ctx;      /* one GPU + one HIP stream (a reference "worker", bathsearch.c:34-52) */
 typedef struct bath_hip_oprofile bath_hip_oprofile; /* device-resident P7_OPROFILE  (impl_sse.h:75)   */
@@ -194,6 +197,29 @@ int  bath_hip_pipeline_filters(bath_hip_ctx *ctx, const bath_hip_oprofile *om, c
 /* Device time of the stages of the last bath_hip_pipeline_filters call, ms (HIP events on ctx's stream).
  * names[i] are static strings. */
 int  bath_hip_pipeline_timings(const bath_hip_ctx *ctx, int max, const char **names, float *ms, int64_t *launches);
+
+/* The frameshift pipeline (bathsearch --fs) up to the decision which branch a DNA window takes:
+ * the cascade with F4 at the Forward stage (p7_pipeline.c:1774-1789), then p7_pli_BuildDNAWindows (:462-572) and the
+ * per-window part of p7_pli_Frameshift (:1368-1464): summed ORF score, window null / bias scores
+ * (p7_bg_fs_NullOne, p7_bg_fs_FilterScore), p7_ForwardParser_Frameshift_3Codons, and the P-value comparison.
+ * Domain definition after the decision is not part of this library yet. */
+typedef struct {
+  int64_t window;                  /* sequence index in the block                                            */
+  int32_t strand;                  /* 0 = as given, 1 = reverse complement                                    */
+  int32_t n, length;               /* window start (1-based on that strand) and length, nt (P7_HMM_WINDOW n, length) */
+  int32_t orf_cnt, k_min, k_max;   /* ORFs with P <= F4 inside the window; model range of their hit windows   */
+  float   tot_orfsc;               /* log-sum of the ORFs' (Forward - null) scores, nats (:1408)             */
+  float   nullsc, filtersc, fwdsc; /* of the DNA window: null, bias-filter and frameshift Forward scores      */
+  double  P_tot, P_min, P_fs, P_null;
+  int32_t branch;                  /* 1: frameshift branch (:1464); 2: standard branch (:1479)               */
+} bath_fs_window;
+/* <om_fs3> is the 3-codon frameshift profile.  stats->pos_past_fwd counts as the reference does in this mode
+ * (:1468, :1490).  *fs_windows is owned by ctx, valid until the next call; results/n_results as in
+ * bath_hip_pipeline_filters (may be NULL). */
+int  bath_hip_pipeline_frameshift(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bath_hip_fsprofile *om_fs3,
+                                  const bath_hip_seqs *dna, const bath_pipeline_params *params, bath_pipeline_stats *stats,
+                                  const bath_orf_result **results, int64_t *n_results,
+                                  const bath_fs_window **fs_windows, int64_t *n_fs_windows);
 
 /* ------------------------------------------------------------------------------------------
  * Frameshift kernels (P7_FS_OPROFILE surface), batched over DNA windows.

@@ -275,7 +275,24 @@ typedef struct {                 /* per-ORF cascade record (what the GPU path mu
   double  P;
 } bo_orfresult;
 
+typedef struct {                 /* per DNA-window record of p7_pli_Frameshift (p7_pipeline.c:1368-1470) */
+  int32_t strand, n, length, k;  /* window start (1-based on the strand being read), length in nt, k of the seed window */
+  int32_t orf_cnt, k_min, k_max;
+  float   tot_orfsc, nullsc, filtersc, fwdsc;
+  double  P_tot, P_min, P_fs, P_null;
+  int32_t branch;                /* 1: frameshift branch (:1464), 2: standard branch (:1479) */
+} bo_fswindow;
+
 void bo_pipeline_init(bo_pipeline *pli, int fs_pipe);
+void  bo_local_compo(const bo_scoredata *sd, const bo_oprofile *om, const bo_bg *bg, int k_min, int k_max, float *compo); /* p7_pipeline.c:427 */
+/* frameshift stage for one strand (fs_pipeline.c); dsq[1..n] is the strand being read */
+int  bo_pli_frameshift(bo_pipeline *pli, bo_oprofile *om, bo_fs_profile *gm3, const bo_scoredata *sd, bo_bg *bg, const uint8_t basic[64],
+                       const bo_orfblock *blk, const double *P_orf, const float *fwdsc, const bo_windowlist *hw,
+                       const uint8_t *dsq, int n, int complementarity, bo_fswindow **fw, int *nfw, int *fw_alloc);
+/* bo_pipeline_window with the frameshift stage (pli->fs_pipe must be set; gm3 = 3-codon frameshift profile) */
+int  bo_pipeline_window_fs(bo_pipeline *pli, bo_oprofile *om, bo_fs_profile *gm3, const bo_scoredata *sd, bo_bg *bg,
+                           const uint8_t basic[64], const uint8_t *dna, int n,
+                           bo_orfresult **res, int *nres, int *res_alloc, bo_fswindow **fw, int *nfw, int *fw_alloc);
 /* run translate + cascade on both strands of one DNA window dsq[1..n]; results appended (realloc'd) */
 int  bo_pipeline_window(bo_pipeline *pli, bo_oprofile *om, const bo_scoredata *sd, bo_bg *bg,
                         const uint8_t basic[64], const uint8_t *dna, int n,

@@ -23,7 +23,7 @@ void bo_pipeline_init(bo_pipeline *pli, int fs_pipe)      /* p7_pipeline.c:219-2
 }
 
 /* p7_pli_ComputeLocalCompo, p7_pipeline.c:427-458 */
-static void local_compo(const bo_scoredata *sd, const bo_oprofile *om, const bo_bg *bg, int k_start, int k_end, float *compo)
+void bo_local_compo(const bo_scoredata *sd, const bo_oprofile *om, const bo_bg *bg, int k_start, int k_end, float *compo)
 {
   int Kp = BO_KP_AMINO;
   int k_len = k_end - k_start + 1;
@@ -43,11 +43,21 @@ static void local_compo(const bo_scoredata *sd, const bo_oprofile *om, const bo_
   else             for (int x = 0; x < BO_K_AMINO; x++) compo[x] = 1.0f / BO_K_AMINO;
 }
 
+typedef struct {                 /* what the frameshift stage needs beyond the cascade (NULL gm3: no such stage) */
+  bo_fs_profile *gm3;
+  const uint8_t *basic, *dsq;    /* dsq[1..n]: the strand being read */
+  int n;
+  bo_fswindow **fw; int *nfw, *fw_alloc;
+} fs_stage;
+
 static void strand_cascade(bo_pipeline *pli, bo_oprofile *om, const bo_scoredata *sd, bo_bg *bg,
-                           const bo_orfblock *blk, int strand, bo_orfresult **res, int *nres, int *res_alloc)
+                           const bo_orfblock *blk, int strand, bo_orfresult **res, int *nres, int *res_alloc, const fs_stage *fs)
 {
   bo_windowlist hw;
   bo_windowlist_init(&hw);
+  double *P_orf = malloc(sizeof(double) * (size_t)(blk->count + 1));      /* p7_pipeline.c:1615-1623 */
+  float *fwd_null = malloc(sizeof(float) * (size_t)(blk->count + 1));
+  for (int i = 0; i < blk->count; i++) { P_orf[i] = 1.0; fwd_null[i] = -INFINITY; }
   for (int i = 0; i < blk->count; i++) {
     const bo_orf *o = &blk->orf[i];
     const uint8_t *dsq = blk->aa + o->off;
@@ -111,7 +121,7 @@ static void strand_cascade(bo_pipeline *pli, bo_oprofile *om, const bo_scoredata
         if (hw.w[w].k - hw.w[w].length + 1 < k_min) k_min = hw.w[w].k - hw.w[w].length + 1;
       }
       float lc[BO_K_AMINO];
-      local_compo(sd, om, bg, k_min, k_max, lc);
+      bo_local_compo(sd, om, bg, k_min, k_max, lc);
       bo_bg_setfilter(bg, om->M, lc);
       bo_bg_setlength(bg, n);
       float local_filtersc = bo_bg_filterscore(bg, dsq, n);
@@ -146,34 +156,47 @@ static void strand_cascade(bo_pipeline *pli, bo_oprofile *om, const bo_scoredata
     seqsc = (float)((fwdsc - filtersc) / LOG2C);
     P = bo_exp_surv(seqsc, om->evparam[BO_FTAU], om->evparam[BO_FLAMBDA]);
     r->fwdsc = fwdsc; r->P = P;
+    if (pli->fs_pipe) { P_orf[i] = P; fwd_null[i] = fwdsc - nullsc; }   /* :1781-1782 */
     if (P > (pli->fs_pipe ? pli->F4 : pli->F3)) continue;
     r->stage = 4;
     pli->n_past_fwd++;
     if (!pli->fs_pipe) pli->pos_past_fwd += (int64_t) n * 3;  /* :1761; the fs branch counts later (:1468,1490) */
   }
+  if (pli->fs_pipe && fs && fs->gm3)                            /* :1793 */
+    bo_pli_frameshift(pli, om, fs->gm3, sd, bg, fs->basic, blk, P_orf, fwd_null, &hw, fs->dsq, fs->n, strand, fs->fw, fs->nfw, fs->fw_alloc);
+  free(P_orf); free(fwd_null);
   bo_windowlist_free(&hw);
 }
 
-int bo_pipeline_window(bo_pipeline *pli, bo_oprofile *om, const bo_scoredata *sd, bo_bg *bg,
-                       const uint8_t basic[64], const uint8_t *dna, int n,
-                       bo_orfresult **res, int *nres, int *res_alloc)
+int bo_pipeline_window_fs(bo_pipeline *pli, bo_oprofile *om, bo_fs_profile *gm3, const bo_scoredata *sd, bo_bg *bg,
+                          const uint8_t basic[64], const uint8_t *dna, int n,
+                          bo_orfresult **res, int *nres, int *res_alloc, bo_fswindow **fw, int *nfw, int *fw_alloc)
 {
   if (n < 15) return BO_OK;                                   /* bathsearch.c:1066, p7_pipeline.c:1605 */
   bo_orfblock blk;
   bo_orfblock_init(&blk);
   bo_bg_setfilter(bg, om->M, om->compo);                      /* p7_pli_NewModel, p7_pipeline.c:635 */
+  fs_stage fs = { gm3, basic, dna, n, fw, nfw, fw_alloc };
 
   pli->nres += n;                                             /* top strand, bathsearch.c:1073 */
   bo_translate_orfs(dna, n, basic, pli->minlen, &blk);
-  strand_cascade(pli, om, sd, bg, &blk, 0, res, nres, res_alloc);
+  strand_cascade(pli, om, sd, bg, &blk, 0, res, nres, res_alloc, &fs);
   bo_orfblock_reuse(&blk);
 
   uint8_t *rc = malloc((size_t) n + 2);                       /* bottom strand, bathsearch.c:1084-1091 */
   bo_revcomp(dna, n, rc);
   pli->nres += n;
   bo_translate_orfs(rc, n, basic, pli->minlen, &blk);
-  strand_cascade(pli, om, sd, bg, &blk, 1, res, nres, res_alloc);
+  fs.dsq = rc;
+  strand_cascade(pli, om, sd, bg, &blk, 1, res, nres, res_alloc, &fs);
   free(rc);
   bo_orfblock_free(&blk);
   return BO_OK;
+}
+
+int bo_pipeline_window(bo_pipeline *pli, bo_oprofile *om, const bo_scoredata *sd, bo_bg *bg,
+                       const uint8_t basic[64], const uint8_t *dna, int n,
+                       bo_orfresult **res, int *nres, int *res_alloc)
+{
+  return bo_pipeline_window_fs(pli, om, NULL, sd, bg, basic, dna, n, res, nres, res_alloc, NULL, NULL, NULL);
 }

@@ -132,7 +132,8 @@ float bo_bg_fs_filterscore(const bo_bg *bg, const uint8_t *dna, int L, const uin
     sum = bo_flogsum(sum, nullsc);
   }
   free(orf);
-  return sum + (float)((float) (L / 3) * logf(bg->p1) + logf((float)(1. - bg->p1)) + log(3.0));
+  /* p7_bg.c:561: float + (float*float + float + double) evaluated in double, stored to float */
+  return (float)((double) sum + ((double)((float) (L / 3) * logf(bg->p1) + logf((float)(1. - bg->p1))) + log(3.0)));
 }
 
 /* ------------------------------------------------------------------ generic profile */

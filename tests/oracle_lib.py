@@ -109,6 +109,15 @@ class OrfResult(C.Structure):
                 ("fwdsc", C.c_float), ("P", C.c_double)]
 
 
+class FsWindow(C.Structure):
+    """bo_fswindow: one DNA window of p7_pli_Frameshift (oracle/fs_pipeline.c)."""
+    _fields_ = [("strand", C.c_int32), ("n", C.c_int32), ("length", C.c_int32), ("k", C.c_int32),
+                ("orf_cnt", C.c_int32), ("k_min", C.c_int32), ("k_max", C.c_int32),
+                ("tot_orfsc", C.c_float), ("nullsc", C.c_float), ("filtersc", C.c_float), ("fwdsc", C.c_float),
+                ("P_tot", C.c_double), ("P_min", C.c_double), ("P_fs", C.c_double), ("P_null", C.c_double),
+                ("branch", C.c_int32)]
+
+
 _lib = None
 
 
@@ -167,6 +176,9 @@ def lib():
     L.bo_gencode_basic.argtypes = [C.c_int, u8p]
     L.bo_revcomp.argtypes = [u8p, C.c_int, u8p]
     L.bo_pipeline_init.argtypes = [C.POINTER(Pipeline), C.c_int]
+    L.bo_pipeline_window_fs.argtypes = [C.POINTER(Pipeline), C.POINTER(OProfile), C.POINTER(FsProfile), C.POINTER(ScoreData), C.POINTER(Bg),
+                                        u8p, u8p, C.c_int, C.POINTER(C.POINTER(OrfResult)), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                        C.POINTER(C.POINTER(FsWindow)), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.bo_pipeline_window.argtypes = [C.POINTER(Pipeline), C.POINTER(OProfile), C.POINTER(ScoreData), C.POINTER(Bg),
                                      u8p, u8p, C.c_int, C.POINTER(C.POINTER(OrfResult)), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     if hasattr(L, "bo_gmx_create"):
@@ -285,3 +297,24 @@ class Model:
             per_seq.append((before, nres.value))
         out = [res[i] for i in range(nres.value)]
         return pli, out, per_seq
+
+    def run_pipeline_fs(self, seqs):
+        """The cascade with fs_pipe set plus the frameshift stage (oracle/fs_pipeline.c) on every window.
+
+        Returns (Pipeline counters, ORF records, per-sequence ORF ranges, FsWindow records, per-sequence window ranges)."""
+        L_ = lib()
+        pli = Pipeline()
+        L_.bo_pipeline_init(C.byref(pli), 1)
+        gm3 = self.fs(3)
+        res = C.POINTER(OrfResult)()
+        nres, alloc = C.c_int(0), C.c_int(0)
+        fw = C.POINTER(FsWindow)()
+        nfw, fwalloc = C.c_int(0), C.c_int(0)
+        per_seq, per_seq_w = [], []
+        for codes in seqs:
+            d = dsq_from(codes)
+            b0, w0 = nres.value, nfw.value
+            L_.bo_pipeline_window_fs(C.byref(pli), self.om, gm3, self.sd, C.byref(self.bg), u8(self.basic), u8(d), len(codes),
+                                     C.byref(res), C.byref(nres), C.byref(alloc), C.byref(fw), C.byref(nfw), C.byref(fwalloc))
+            per_seq.append((b0, nres.value)); per_seq_w.append((w0, nfw.value))
+        return pli, [res[i] for i in range(nres.value)], per_seq, [fw[i] for i in range(nfw.value)], per_seq_w

@@ -1,0 +1,115 @@
+"""The frameshift stage of the pipeline on the GPU (bath_hip_pipeline_frameshift) against the oracle's restatement of
+p7_pli_BuildDNAWindows + p7_pli_Frameshift (oracle/fs_pipeline.c), DNA window by DNA window, and against the one number
+the reference recorded for this stage (tutorial/AMP_N-fs.out).
+
+Integer outputs (window coordinates, ORF counts, model ranges) must be identical.  Null and bias scores are fp32
+re-statements of the same arithmetic (1e-4).  The frameshift Forward score carries the tolerance of
+tests/test_frameshift_gpu.py (table log-sum accumulated in a different association: 1e-4 relative + 5e-3 nats), and the
+P-values derived from it inherit that as a relative factor exp(lambda * delta / ln 2)."""
+import numpy as np
+import pytest
+
+import bath_amd as ba
+import common
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+
+
+def frameshifted_windows(rng, model, n=40, L_flank=250):
+    """Planted genes, most of them with 1-3 single-nucleotide insertions or deletions, on either strand."""
+    wins = []
+    genes = common.emit_from_model(rng, model, n // 2, flank=5) + common.emit_from_model(rng, model, n - n // 2, flank=5, sharpen=2.0)
+    for i, aa in enumerate(genes):
+        nt = list(common.revtranslate(rng, aa, model.basic))
+        for _ in range(int(rng.integers(0, 4))):
+            p = int(rng.integers(10, max(11, len(nt) - 10)))
+            if rng.random() < 0.5:
+                del nt[p]
+            else:
+                nt.insert(p, int(rng.integers(0, 4)))
+        pre = rng.integers(0, 4, size=int(rng.integers(0, L_flank)))
+        post = rng.integers(0, 4, size=int(rng.integers(0, L_flank)))
+        w = np.concatenate([pre, np.array(nt, dtype=np.int64), post]).astype(np.uint8)
+        if i % 2:
+            w = (3 - w[::-1]).astype(np.uint8)
+        wins.append(w)
+    # two genes in one long window (two DNA windows, or one merged), and background
+    a = np.concatenate([wins[0], rng.integers(0, 4, size=4000).astype(np.uint8), wins[2]])
+    b = np.concatenate([wins[1], rng.integers(0, 4, size=60).astype(np.uint8), wins[3]])
+    return wins + [a, b] + common.random_dna(rng, 20, 1000)
+
+
+def run_both(ctx, path, idx, wins):
+    model = ol.Model(path, idx)
+    hmm = ba.HMM(path, idx)
+    om = ba.OProfile(ctx, ba.Profile(hmm))
+    om3 = ba.FSOProfile(ctx, ba.FSProfile(hmm, 3, ncbi_table=hmm.ct))
+    pipe = ba.Pipeline(ctx, om, fs_pipe=True, ncbi_table=hmm.ct)
+    stats, res, fw = pipe.run_frameshift(om3, ba.SeqBlock(ctx, wins))
+    pli, ores, per_seq, ofw, per_seq_w = model.run_pipeline_fs(wins)
+    return model, stats, res, fw, pli, ores, per_seq, ofw, per_seq_w
+
+
+def compare(model, stats, fw, pli, ofw, per_seq_w, F3=1e-5):
+    want = []
+    for w, (a, b) in enumerate(per_seq_w):
+        want += [(w, o) for o in ofw[a:b]]
+    want.sort(key=lambda t: (t[0], t[1].strand, t[1].n))
+    got = sorted(fw, key=lambda g: (g.window, g.strand, g.n))
+    assert len(got) == len(want)
+    lam = model.om.contents.evparam[5]
+    unsure = 0
+    pos = 0
+    for g, (w, o) in zip(got, want):
+        assert (g.window, g.strand, g.n, g.length, g.orf_cnt, g.k_min, g.k_max) == (w, o.strand, o.n, o.length, o.orf_cnt, o.k_min, o.k_max)
+        assert abs(g.tot_orfsc - o.tot_orfsc) <= 2e-3 + 1e-4 * abs(o.tot_orfsc)       # sum of Forward scores, each 1e-4 relative
+        assert abs(g.nullsc - o.nullsc) <= 1e-5 * max(1.0, abs(o.nullsc))
+        assert abs(g.filtersc - o.filtersc) <= 1e-4 * max(1.0, abs(o.filtersc))
+        tol = 5e-3 + 1e-4 * abs(o.fwdsc)
+        assert abs(g.fwdsc - o.fwdsc) <= tol
+        fac = np.exp(lam * (tol + 1e-3) / np.log(2.0)) * 1.001
+        for a, b in ((g.P_fs, o.P_fs), (g.P_null, o.P_null), (g.P_tot, o.P_tot)):
+            assert b / fac <= a <= b * fac or (a < 1e-300 and b < 1e-300)
+        # the branch must agree unless the oracle's own decision is within the score tolerance of flipping
+        clear = (o.P_fs > F3 * fac or o.P_fs < F3 / fac) and (o.P_null > o.P_tot * fac * fac or o.P_null < o.P_tot / (fac * fac))
+        if clear:
+            assert g.branch == o.branch
+        else:
+            unsure += 1
+    assert unsure <= max(2, len(got) // 10)
+    if unsure == 0:
+        assert stats.pos_past_fwd == pli.pos_past_fwd
+    for name in ("nres", "n_orfs", "n_past_msv", "n_past_bias", "n_past_vit", "n_past_fwd", "pos_past_msv", "pos_past_bias", "pos_past_vit"):
+        assert getattr(stats, name) == getattr(pli, name), name
+    return len(got)
+
+
+def test_recorded_fs_run_on_gpu(gpu_ctx):
+    """tutorial/AMP_N-fs.out: 'Residues passing Fwd filter: 411' comes out of the frameshift stage."""
+    path = ol.GOLDEN + "/AMP_N.bhmm"
+    seqs = [ba.digitize(s, ba.DNA_SYMS) for _, s in ol.read_fasta(ol.GOLDEN + "/target-AMP_N.fa")]
+    model, stats, res, fw, pli, ores, per_seq, ofw, per_seq_w = run_both(gpu_ctx, path, 0, seqs)
+    assert (stats.nres, stats.pos_past_msv, stats.pos_past_bias, stats.pos_past_vit, stats.pos_past_fwd) == (822, 537, 537, 393, 411)
+    assert len(fw) == 1 and (fw[0].n, fw[0].length, fw[0].orf_cnt, fw[0].branch) == (1, 411, 3, 1)
+    compare(model, stats, fw, pli, ofw, per_seq_w)
+
+
+@pytest.mark.parametrize("fasta", ["2OG-FeII_Oxy_3-nt-fs.fa", "2OG-FeII_Oxy_3-nt.fa"])
+def test_reference_fs_example(gpu_ctx, fasta):
+    """BASELINE configs[0]: testsuite/2OG-FeII_Oxy_3.bhmm against its frameshifted / unshifted DNA targets."""
+    path = ol.GOLDEN + "/2OG-FeII_Oxy_3.bhmm"
+    seqs = [ba.digitize(s, ba.DNA_SYMS) for _, s in ol.read_fasta(ol.GOLDEN + "/" + fasta)]
+    model, stats, res, fw, pli, ores, per_seq, ofw, per_seq_w = run_both(gpu_ctx, path, 0, seqs)
+    assert compare(model, stats, fw, pli, ofw, per_seq_w) == 10
+
+
+@pytest.mark.parametrize("name", ["Caudal_act.bhmm", "PTH2.bhmm", "2OG-FeII_Oxy_3.bhmm"])
+def test_planted_frameshifted_genes(gpu_ctx, name):
+    rng = np.random.default_rng(31)
+    path = ol.GOLDEN + "/" + name
+    wins = frameshifted_windows(rng, ol.Model(path, 0))
+    model, stats, res, fw, pli, ores, per_seq, ofw, per_seq_w = run_both(gpu_ctx, path, 0, wins)
+    n = compare(model, stats, fw, pli, ofw, per_seq_w)
+    assert n >= 20 and any(w.branch == 1 for w in fw) and any(w.branch == 2 for w in fw)
+    assert any(w.strand == 1 for w in fw) and any(w.orf_cnt > 1 for w in fw)

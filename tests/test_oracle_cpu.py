@@ -147,3 +147,31 @@ def test_orf_finder_basic():
     f0 = [blk.orf[i] for i in range(blk.count) if blk.orf[i].frame == 0]
     assert len(f0) == 1 and (f0[0].start, f0[0].end, f0[0].n) == (1, 75, 25)
     L_.bo_orfblock_free(C.byref(blk))
+
+
+def test_frameshift_stage_matches_recorded_fs_run():
+    """tutorial/AMP_N-fs.out (bathsearch --fs): the only number the reference prints about the frameshift stage is
+    'Residues passing Fwd filter', which in this mode is counted inside p7_pli_Frameshift (p7_pipeline.c:1468,1490):
+    the length of every DNA window that takes the frameshift branch plus 3n for ORFs aligned by the standard branch.
+    411 = the single window (the whole 411-nt target) taking the frameshift branch."""
+    assert _printed_counters("AMP_N-fs.out", 0) == (822, 537, 537, 393, 411)
+    m = ol.Model(ol.GOLDEN + "/AMP_N.bhmm", 0)
+    seqs = [ol.digitize_dna(s) for _, s in ol.read_fasta(ol.GOLDEN + "/target-AMP_N.fa")]
+    pli, _, _, fw, _ = m.run_pipeline_fs(seqs)
+    assert (pli.nres, pli.pos_past_msv, pli.pos_past_bias, pli.pos_past_vit, pli.pos_past_fwd) == (822, 537, 537, 393, 411)
+    assert len(fw) == 1 and (fw[0].strand, fw[0].n, fw[0].length, fw[0].orf_cnt, fw[0].branch) == (0, 1, 411, 3, 1)
+
+
+def test_frameshift_stage_separates_shifted_from_unshifted_targets():
+    """testsuite 2OG-FeII_Oxy_3: the same ten genes with and without frameshifts.  Unshifted genes are one ORF and stay
+    on the standard branch; genes whose frameshifts split them into several ORFs go to the frameshift branch."""
+    m = ol.Model(ol.GOLDEN + "/2OG-FeII_Oxy_3.bhmm", 0)
+    plain = [ol.digitize_dna(s) for _, s in ol.read_fasta(ol.GOLDEN + "/2OG-FeII_Oxy_3-nt.fa")]
+    shifted = [ol.digitize_dna(s) for _, s in ol.read_fasta(ol.GOLDEN + "/2OG-FeII_Oxy_3-nt-fs.fa")]
+    _, _, _, fw_plain, _ = m.run_pipeline_fs(plain)
+    _, _, _, fw_shift, _ = m.run_pipeline_fs(shifted)
+    assert len(fw_plain) == 10 and all(w.orf_cnt == 1 and w.branch == 2 for w in fw_plain)
+    assert len(fw_shift) == 10
+    assert all(w.branch == 1 for w in fw_shift if w.orf_cnt > 1) and sum(w.orf_cnt > 1 for w in fw_shift) >= 3
+    for w in fw_plain + fw_shift:                       # every window covers its whole (short) target
+        assert w.n == 1 and w.P_fs < 1e-20
