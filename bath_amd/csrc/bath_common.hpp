@@ -62,6 +62,8 @@ struct bath_hip_ctx {
   std::vector<uint8_t> orf_aa;
   std::vector<bath::StageTiming> timings;
   std::vector<hipEvent_t> ev_pool;
+  // worker lanes: contexts with their own stream and scratch, used by the pipeline to run parts of a block concurrently
+  std::vector<bath_hip_ctx *> lanes;
 };
 
 // Device view of a sequence block.
@@ -80,6 +82,11 @@ struct bath_hip_seqs {
   mutable int64_t cache_minlen = -1, cache_nres = 0, cache_max_orfs = 0;   // pipeline sizing, per min_orf_len
   mutable int64_t ntiles = -1;             // translation tiles (bath_orfs.hip), built on first use
   mutable int32_t *d_tile_win = nullptr, *d_tile_first = nullptr;
+  // parts of this block (consecutive windows, about equal in residues) for the pipeline's concurrent lanes: views into
+  // d_data / d_len with their own rebased offsets; built on first use
+  bool is_part = false;
+  int64_t first_window = 0;
+  mutable std::vector<bath_hip_seqs *> parts;
   int32_t maxlen = 0;
   uint8_t *d_data = nullptr;
   int64_t *d_off = nullptr;

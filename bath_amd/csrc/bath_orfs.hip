@@ -368,7 +368,10 @@ int launch_orf_scan(bath_hip_ctx *ctx, const bath_hip_seqs *dna, const OrfTables
   OrfTiles tiles{dna->d_tile_win, dna->d_tile_first, ntiles};
   OrfScanOut out{b.aa, reinterpret_cast<uint2 *>(b.slots), b.cnt, b.prefix, b.suffix, b.hist, d_n_orfs, d_orf_res, orf_slot_cap(minlen)};
   const int cus = ctx->prop.multiProcessorCount;
-  const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((ntiles + 7) / 8, (int64_t)cus * 8));
+  // persistent blocks: exactly as many as are resident at once, so that every block gets the same share of the tiles
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, orf_tile_kernel, 256, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+  const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((ntiles + 7) / 8, (int64_t)cus * per_cu));
   hipLaunchKernelGGL(orf_tile_kernel, dim3(blocks), dim3(256), 0, ctx->stream, dna->view(), tiles, tabs, out, minlen);
   const int sblocks = (int)std::max<int64_t>(1, std::min<int64_t>((dna->n * 6 + 255) / 256, (int64_t)cus * 8));
   hipLaunchKernelGGL(orf_stitch_kernel, dim3(sblocks), dim3(256), 0, ctx->stream, dna->view(), tiles, out, minlen);

@@ -17,7 +17,9 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <cstdlib>
 #include <map>
+#include <thread>
 
 #include "bath_common.hpp"
 #include "bath_kernels.hpp"
@@ -722,10 +724,111 @@ static int run_filters(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bat
   return BATH_OK;
 }
 
+// ---- concurrent lanes --------------------------------------------------------------------------------------------
+// The cascade's tail (decision kernels, wave-per-candidate DP over a few 10^5 survivors) is latency bound and leaves
+// most of the chip idle, while SSV saturates the VALUs.  A large block is therefore cut into K parts of consecutive
+// windows that run the whole cascade concurrently, each on its own HIP stream with its own scratch memory (a "lane"
+// context) driven by its own host thread: one part's tail overlaps another part's translation and SSV.
+static int pipeline_lane_count(const bath_hip_seqs *dna) {
+  const char *e = std::getenv("BATH_HIP_LANES");                  // override for tests and tuning
+  const int forced = e ? std::atoi(e) : 0;
+  if (forced > 0) return (int)std::min<int64_t>(forced, std::max<int64_t>(dna->n, 1));
+  if (dna->is_part || dna->n < 8) return 1;
+  // measured on MI355X, 10^6 x 1 kb: 1 lane 18.2 ms, 2 lanes 16.5 ms, 3 lanes 15.4 ms, 4 lanes 19.7 ms per pass
+  return (int)std::min<int64_t>(3, std::max<int64_t>(1, dna->total >> 28));     // one lane per 256 MB of DNA, at most 3
+}
+
+static int ensure_parts(bath_hip_ctx *ctx, const bath_hip_seqs *dna, int K) {
+  if ((int)dna->parts.size() == K) return BATH_OK;
+  for (bath_hip_seqs *p : dna->parts) bath_hip_seqs_destroy(p);
+  dna->parts.clear();
+  int64_t w0 = 0;
+  for (int k = 0; k < K; k++) {
+    // cut where the running residue count passes (k+1)/K of the total
+    int64_t w1 = w0;
+    if (k == K - 1) w1 = dna->n;
+    else {
+      const int64_t target = dna->total_aligned / K * (k + 1);
+      w1 = std::lower_bound(dna->h_off.begin() + w0, dna->h_off.end(), target) - dna->h_off.begin();
+      w1 = std::max(w1, std::min(w0 + 1, dna->n));
+    }
+    bath_hip_seqs *p = new bath_hip_seqs();
+    p->ctx = ctx; p->is_part = true; p->first_window = w0; p->n = w1 - w0;
+    const int64_t base = w0 < dna->n ? dna->h_off[(size_t)w0] : dna->total_aligned;
+    p->h_off.resize((size_t)p->n); p->h_len.assign(dna->h_len.begin() + w0, dna->h_len.begin() + w1);
+    for (int64_t i = 0; i < p->n; i++) {
+      p->h_off[(size_t)i] = dna->h_off[(size_t)(w0 + i)] - base;
+      p->maxlen = std::max(p->maxlen, p->h_len[(size_t)i]);
+      p->total += p->h_len[(size_t)i];
+    }
+    p->total_aligned = (w1 < dna->n ? dna->h_off[(size_t)w1] : dna->total_aligned) - base;
+    p->d_data = dna->d_data + base;
+    p->d_len = dna->d_len + w0;
+    dna->parts.push_back(p);
+    if (hipMalloc((void **)&p->d_off, (size_t)std::max<int64_t>(p->n, 1) * sizeof(int64_t)) != hipSuccess) { ctx->set_error("hipMalloc (block parts)"); return BATH_EMEM; }
+    if (p->n > 0 && hipMemcpy(p->d_off, p->h_off.data(), (size_t)p->n * sizeof(int64_t), hipMemcpyHostToDevice) != hipSuccess) { ctx->set_error("hipMemcpy (block parts)"); return BATH_EFAIL; }
+    w0 = w1;
+  }
+  return BATH_OK;
+}
+
 extern "C" int bath_hip_pipeline_filters(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bath_hip_seqs *dna,
                                          const bath_pipeline_params *prm, bath_pipeline_stats *stats,
                                          const bath_orf_result **results, int64_t *n_results) {
-  return run_filters(ctx, om, dna, prm, stats, results, n_results, nullptr);
+  if (!ctx || !om || !dna || !prm) return BATH_EINVAL;
+  const int K = pipeline_lane_count(dna);
+  if (K <= 1) return run_filters(ctx, om, dna, prm, stats, results, n_results, nullptr);
+
+  BATH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int st = om->ensure_len_tables(dna->maxlen / 3 + 1);            // the only mutable state of the profile: fill it before the threads start
+  if (st != BATH_OK) return st;
+  while ((int)ctx->lanes.size() < K) {
+    bath_hip_ctx *lane = nullptr;
+    if ((st = bath_hip_init(ctx->device, &lane)) != BATH_OK) { ctx->set_error("cannot create a pipeline lane"); return st; }
+    ctx->lanes.push_back(lane);
+  }
+  if ((st = ensure_parts(ctx, dna, K)) != BATH_OK) return st;
+  std::vector<bath_pipeline_stats> pst((size_t)K);
+  std::vector<const bath_orf_result *> pres((size_t)K, nullptr);
+  std::vector<int64_t> pn((size_t)K, 0);
+  std::vector<int> rc((size_t)K, BATH_OK);
+  std::vector<std::thread> th;
+  for (int k = 0; k < K; k++)
+    th.emplace_back([&, k] { rc[(size_t)k] = run_filters(ctx->lanes[(size_t)k], om, dna->parts[(size_t)k], prm, &pst[(size_t)k], results ? &pres[(size_t)k] : nullptr, &pn[(size_t)k], nullptr); });
+  for (std::thread &t : th) t.join();
+  for (int k = 0; k < K; k++)
+    if (rc[(size_t)k] != BATH_OK) { ctx->set_error(ctx->lanes[(size_t)k]->err); return rc[(size_t)k]; }
+
+  bath_pipeline_stats tot{};
+  int64_t ntot = 0;
+  for (int k = 0; k < K; k++) {
+    const bath_pipeline_stats &a = pst[(size_t)k];
+    tot.nres += a.nres; tot.n_orfs += a.n_orfs; tot.n_past_msv += a.n_past_msv; tot.n_past_bias += a.n_past_bias; tot.n_past_vit += a.n_past_vit;
+    tot.n_past_fwd += a.n_past_fwd; tot.pos_past_msv += a.pos_past_msv; tot.pos_past_bias += a.pos_past_bias; tot.pos_past_vit += a.pos_past_vit;
+    tot.pos_past_fwd += a.pos_past_fwd; tot.cells_msv += a.cells_msv; tot.cells_vit += a.cells_vit; tot.cells_fwd += a.cells_fwd;
+    ntot += pn[(size_t)k];
+  }
+  if (stats) *stats = tot;
+  if (results) {                                                   // parts are consecutive windows and each part's list is sorted
+    ctx->results.clear();
+    ctx->results.reserve((size_t)ntot);
+    for (int k = 0; k < K; k++) {
+      const int64_t w0 = dna->parts[(size_t)k]->first_window;
+      for (int64_t i = 0; i < pn[(size_t)k]; i++) { bath_orf_result r = pres[(size_t)k][i]; r.window += w0; ctx->results.push_back(r); }
+    }
+    *results = ctx->results.data();
+  }
+  if (n_results) *n_results = ntot;
+  // stage timings: device time summed over the lanes (they overlap in wall-clock time)
+  ctx->timings.clear();
+  for (int k = 0; k < K; k++) {
+    const std::vector<StageTiming> &t = ctx->lanes[(size_t)k]->timings;
+    for (size_t i = 0; i < t.size(); i++) {
+      if (k == 0) ctx->timings.push_back(t[i]);
+      else if (i < ctx->timings.size()) { ctx->timings[i].ms += t[i].ms; ctx->timings[i].launches += t[i].launches; }
+    }
+  }
+  return BATH_OK;
 }
 
 // =================================================================================================

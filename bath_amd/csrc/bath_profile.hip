@@ -124,6 +124,8 @@ extern "C" void bath_hip_finalize(bath_hip_ctx *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
+  for (bath_hip_ctx *lane : ctx->lanes) bath_hip_finalize(lane);
+  ctx->lanes.clear();
   for (auto &b : ctx->scratch) b.release();
   for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
   (void)hipStreamDestroy(ctx->stream);
@@ -334,6 +336,9 @@ extern "C" int bath_hip_oprofile_get_fwd(const bath_hip_oprofile *om, float *rf,
 
 extern "C" void bath_hip_seqs_destroy(bath_hip_seqs *sq) {
   if (!sq) return;
+  for (bath_hip_seqs *part : sq->parts) bath_hip_seqs_destroy(part);
+  sq->parts.clear();
+  if (sq->is_part) { sq->d_data = nullptr; sq->d_len = nullptr; }      // borrowed from the parent block
   for (void *p : {(void *)sq->d_data, (void *)sq->d_off, (void *)sq->d_len, (void *)sq->d_tile_win, (void *)sq->d_tile_first})
     if (p) (void)hipFree(p);
   delete sq;

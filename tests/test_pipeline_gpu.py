@@ -120,3 +120,26 @@ def test_cascade_long_synthetic_model(gpu_ctx, tmp_path):
     stats, res, pli, ores, per_seq, _ = run_both(gpu_ctx, path, 0, wins, True)
     compare(stats, res, pli, ores, per_seq)
     assert stats.n_past_fwd > 0
+
+
+@pytest.mark.parametrize("lanes", [2, 3])
+def test_concurrent_lanes_give_identical_results(gpu_ctx, lanes, monkeypatch):
+    """A block cut into parts that run the cascade concurrently on separate streams (bath_hip_pipeline_filters does this
+    for large blocks) must return exactly what one pass over the whole block returns."""
+    rng = np.random.default_rng(17)
+    path = ol.GOLDEN + "/Caudal_act.bhmm"
+    wins = make_windows(rng, ol.Model(path, 0), n_random=300, n_planted=80)
+    hmm = ba.HMM(path, 0)
+    om = ba.OProfile(gpu_ctx, ba.Profile(hmm))
+    dna = ba.SeqBlock(gpu_ctx, wins)
+    pipe = ba.Pipeline(gpu_ctx, om, ncbi_table=hmm.ct)
+    monkeypatch.setenv("BATH_HIP_LANES", "1")
+    s1, r1 = pipe.run(dna)
+    monkeypatch.setenv("BATH_HIP_LANES", str(lanes))
+    s2, r2 = pipe.run(dna)
+    for name, _ in ba.PipelineStats._fields_:
+        assert getattr(s1, name) == getattr(s2, name), name
+    assert len(r1) == len(r2)
+    for f in r1.dtype.names:                              # field by field: the records carry padding bytes
+        assert np.array_equal(r1[f], r2[f], equal_nan=True), f
+    assert s1.n_past_fwd > 0
