@@ -81,7 +81,8 @@ struct bath_hip_seqs {
   int64_t total_aligned = 0;   // bytes of d_data in use (every sequence padded to 16)
   mutable int64_t cache_minlen = -1, cache_nres = 0, cache_max_orfs = 0;   // pipeline sizing, per min_orf_len
   mutable int64_t ntiles = -1;             // translation tiles (bath_orfs.hip), built on first use
-  mutable int32_t *d_tile_win = nullptr, *d_tile_first = nullptr;
+  mutable void *d_tile_desc = nullptr;     // int4 per tile: {window offset / 16, window length, window, tile index in the window}
+  mutable int32_t *d_tile_first = nullptr;
   // parts of this block (consecutive windows, about equal in residues) for the pipeline's concurrent lanes: views into
   // d_data / d_len with their own rebased offsets; built on first use
   bool is_part = false;

@@ -52,17 +52,19 @@ struct OrfRec {                   // one ORF of the length-sorted work list
 };
 __host__ __device__ inline int orf_stream_pitch(int n) { return (n / 3 + 16) & ~15; }   // bytes reserved per frame of an n-nt window
 size_t orf_aa_bytes(const bath_hip_seqs *dna);
-int orf_slot_cap(int minlen);                                   // ORF records reserved per (tile, frame)
-int orf_tiles_ensure(bath_hip_ctx *ctx, const bath_hip_seqs *dna);   // fills dna->ntiles, d_tile_win, d_tile_first
+int orf_slot_cap(int minlen);                                   // ORF records reserved per tile (all six frames)
+int orf_tiles_ensure(bath_hip_ctx *ctx, const bath_hip_seqs *dna);   // fills dna->ntiles, d_tile_desc, d_tile_first
 struct OrfTablesDev { const uint8_t *full, *fwd, *rev, *comp; };   // 18^3 general table, canonical 64-entry tables per strand, complement
 int orf_tables_upload(bath_hip_ctx *ctx, int ncbi_table, OrfTablesDev *t);
 struct OrfBuffers {               // device buffers of one translation pass
   uint8_t *aa;                    // orf_aa_bytes()
-  void *slots;                    // ntiles*6*orf_slot_cap() records of 8 bytes
-  int32_t *cnt, *prefix, *suffix; // ntiles*6 each
+  void *slots;                    // ntiles*orf_slot_cap() records of 8 bytes
+  void *cross;                    // ntiles*6 records of 8 bytes: ORFs crossing tile edges
+  int32_t *cnt, *prefix, *suffix; // ntiles*6 each (cnt uses ntiles)
   int *hist, *cursor, *ntotal;    // kOrfBins, kOrfBins, 1
   OrfRec *sorted;                 // the work list, longest ORFs first; *ntotal entries
 };
+void orf_buffers_carve(OrfBuffers *ob, void *aa, void *slots, void *sorted, void *misc /* (5*nent + 2*kOrfBins + 64) ints */, size_t nent);
 int launch_orf_scan(bath_hip_ctx *ctx, const bath_hip_seqs *dna, const OrfTablesDev &tt, int minlen, const OrfBuffers &b,
                     unsigned long long *d_n_orfs, unsigned long long *d_orf_res);
 

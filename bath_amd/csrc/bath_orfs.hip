@@ -14,13 +14,13 @@
 //                     so reverse frames are scanned in memory order too).  Canonical ACGT codons are decoded by one
 //                     24-bit multiply + bit-field extract + a 64-entry LDS table per strand, degenerate codes by the
 //                     general 18^3 table.  Per stream, the length of the stop-free run entering each lane's four codons
-//                     comes from a 5-step shuffle scan; runs closed by two stops inside the tile are recorded as ORFs
+//                     comes from four wave ballots (the last stop before the lane); runs closed by two stops inside the tile are recorded as ORFs
 //                     at once, the run touching the tile's left edge ("prefix") and the one open at its right edge
 //                     ("suffix") are left in the tile summary.  Positions past the end of a stream count as stops.
 //   orf_stitch_kernel one lane per (window, frame) walks the tile summaries and records the ORFs that cross tiles.
 //   orf_scan_bins     turns the ORF length histogram into start offsets, longest ORFs first.
-//   orf_sort_kernel   compacts the per-(tile, frame) slots into the dense work list ordered by length (block-local
-//                     counting sort: one global atomic per block and non-empty length bin).
+//   orf_sort_kernel   compacts the per-tile records into the dense work list ordered by length (block-local counting
+//                     sort: one global atomic per block and non-empty length bin).
 // Amino stream of (w, sf):  aa + 2*off[w] + 96*w + sf*pitch(n),  pitch(n) = (n/3 + 16) & ~15   (closed form: no prefix sums)
 #include <algorithm>
 #include <cstring>
@@ -43,15 +43,16 @@ struct OrfScanTables {
 };
 
 struct OrfTiles {
-  const int32_t *tile_win;    // [ntiles] window of each tile
+  const int4 *desc;           // [ntiles] {offset of the window in the DNA block / 16, window length, window, tile index within the window}
   const int32_t *tile_first;  // [nwin] first tile of each window
   int64_t ntiles;
 };
 
 struct OrfScanOut {
   uint8_t *aa;              // amino-acid streams
-  uint2 *slots;             // [ntiles*6][cap] {first codon index within the stream, length}
-  int32_t *cnt;             // [ntiles*6] ORFs recorded per tile and frame
+  uint2 *slots;             // [ntiles][cap] {first codon index within its stream, length | (strand*3+frame) << 28}
+  int32_t *cnt;             // [ntiles] ORFs recorded per tile
+  uint2 *cross;             // [ntiles*6] the ORF that ends at the first stop of (tile, frame) and began in an earlier tile; length 0: none
   int32_t *prefix, *suffix; // [ntiles*6] tile summaries: stop-free run at the left / right edge (kTileCodons: no stop in the tile)
   int *hist;                // [kOrfBins] ORF length histogram (lengths above the last bin are clamped into it)
   unsigned long long *n_orfs, *orf_res;
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(256) void orf_tile_kernel(SeqView dna, OrfTiles til
   __shared__ __attribute__((aligned(16))) uint8_t s_full[5832 + 8];
   __shared__ uint8_t s_fwd[64], s_rev[64], s_comp[32];
   __shared__ unsigned s_red[2];
-  __shared__ int s_cnt[8][6];                                  // per half wave: ORFs recorded in the current tile, per frame
+  __shared__ int s_cnt[8];                                     // per half wave: ORFs recorded in the current tile
   for (int i = threadIdx.x; i < kOrfBins; i += blockDim.x) s_hist[i] = 0;
   for (int i = threadIdx.x; i < 5832; i += blockDim.x) s_full[i] = tabs.aa_full[i];
   if (threadIdx.x < 64) { s_fwd[threadIdx.x] = tabs.aa64_fwd[threadIdx.x]; s_rev[threadIdx.x] = tabs.aa64_rev[threadIdx.x]; }
@@ -76,29 +77,47 @@ __global__ __launch_bounds__(256) void orf_tile_kernel(SeqView dna, OrfTiles til
   __syncthreads();
   const int hw = threadIdx.x / kTileLanes;                     // half wave within the block
   const int i = threadIdx.x % kTileLanes;                      // lane within the tile
+  const bool hi_half = (threadIdx.x & 32) != 0;
+  const unsigned lt_mask = (1u << i) - 1u;
   const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   unsigned my_orfs = 0, my_res = 0;
-  for (int64_t tb = wave0 * 2; tb < tiles.ntiles; tb += nwaves * 2) {
-    const int64_t tile = tb + ((threadIdx.x & 63) / kTileLanes);
-    const bool live = tile < tiles.ntiles;
-    const int w = live ? tiles.tile_win[tile] : 0;
-    const int T = live ? (int)(tile - tiles.tile_first[w]) : 0;
-    const int n = live ? dna.len[w] : 0;                       // n >= 15 for every window that has tiles
-    const int64_t off = dna.off[w];
-    const int p0 = kTileNt * T + 12 * i;
-    if (i < 6) s_cnt[hw][i] = 0;
-    // ---- the lane's 16 bytes; bytes past the window end read as 0 (they only feed positions that count as stops)
-    uint32_t D[4] = {0u, 0u, 0u, 0u};
-    if (live && p0 < n) {
-      const uint8_t *d = dna.data + off + p0;
+  // Software pipeline over this wave's tiles: descriptors are fetched two tiles ahead and the lane's 16 bytes of DNA one
+  // tile ahead, so the dependent loads (descriptor -> sequence data) of a tile are in flight while the previous one computes.
+  const int half = (threadIdx.x & 63) / kTileLanes;
+  const int4 none = {0, 0, 0, 0};
+  auto fetch_desc = [&](int64_t tb) { const int64_t t = tb + half; return t < tiles.ntiles ? tiles.desc[t] : none; };
+  auto fetch_data = [&](const int4 &dsc, uint32_t (&D)[4]) {
+    const int p0 = kTileNt * dsc.w + 12 * i;
+    D[0] = D[1] = D[2] = D[3] = 0u;
+    if (p0 < dsc.y) {
+      const uint8_t *d = dna.data + ((int64_t)(uint32_t)dsc.x << 4) + p0;
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const int rem = n - (p0 + 4 * k);
-        uint32_t v = *reinterpret_cast<const uint32_t *>(d + 4 * k);
-        if (rem < 4) v = (rem <= 0) ? 0u : (v & ((1u << (8 * rem)) - 1u));
-        D[k] = v;
-      }
+      for (int k = 0; k < 4; k++) D[k] = *reinterpret_cast<const uint32_t *>(d + 4 * k);
+    }
+  };
+  const int64_t tstep = nwaves * 2;
+  int4 d_next = fetch_desc(wave0 * 2), d_next2 = fetch_desc(wave0 * 2 + tstep);
+  uint32_t D_next[4];
+  fetch_data(d_next, D_next);
+  for (int64_t tb = wave0 * 2; tb < tiles.ntiles; tb += tstep) {
+    const int64_t tile = tb + half;
+    const int4 dsc = d_next;
+    uint32_t D[4] = {D_next[0], D_next[1], D_next[2], D_next[3]};
+    d_next = d_next2;
+    d_next2 = fetch_desc(tb + 2 * tstep);
+    fetch_data(d_next, D_next);
+    const int n = dsc.y;                                       // n >= 15 for every window that has tiles; 0: no tile for this half wave
+    const bool live = n > 0;
+    const int w = dsc.z, T = dsc.w;
+    const int64_t off = (int64_t)(uint32_t)dsc.x << 4;
+    const int p0 = kTileNt * T + 12 * i;
+    if (i == 0) s_cnt[hw] = 0;
+    // ---- bytes past the window end read as 0 (they only feed positions that count as stops)
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int rem = n - (p0 + 4 * k);
+      if (rem < 4) D[k] = (rem <= 0) ? 0u : (D[k] & ((1u << (8 * rem)) - 1u));
     }
     const bool canonical = ((D[0] | D[1] | D[2] | (D[3] & 0xffffu)) & 0xfcfcfcfcu) == 0u;
     int af[12], ar[12];
@@ -145,17 +164,17 @@ __global__ __launch_bounds__(256) void orf_tile_kernel(SeqView dna, OrfTiles til
 #pragma unroll
         for (int c = 0; c < 4; c++) if (ph + 3 * c < nvalid) stream[rev ? C - u0 - c : u0 + c] = (uint8_t)aa4[c];
       }
-      // ---- stop-free run ending at the end of each lane's chunk (inclusive scan over the tile's lanes)
-      int s = (int)__clz(m << 28);                                        // trailing non-stop codons of the chunk: 4 when m == 0
-      s = min(s, 4);
+      // ---- length of the stop-free run entering this lane's four codons: scan position of the last stop before them in
+      // the tile, from four wave ballots (one per codon of the chunk; a wave holds two tiles, one per 32-lane half)
+      int last = -4;
 #pragma unroll
-      for (int d = 1; d < kTileLanes; d <<= 1) {
-        const int o = half_shfl_up(s, d);
-        if (i >= d && s == 4 * min(i + 1, d)) s += o;
+      for (int c = 0; c < 4; c++) {
+        const unsigned long long B = __ballot((m >> c) & 1u);
+        const unsigned below = (hi_half ? (unsigned)(B >> 32) : (unsigned)B) & lt_mask;
+        last = max(last, 4 * (31 - (int)__clz(below)) + c);                // no stop in lanes below: 4*(-1)+c < 0
       }
-      int run_in = half_shfl_up(s, 1);
-      if (i == 0) run_in = 0;
-      bool open = (run_in == 4 * i);                                      // no stop in the tile before this lane
+      bool open = last < 0;                                               // no stop in the tile before this lane
+      const int run_in = open ? 4 * i : 4 * i - 1 - last;
       int len = run_in;
       const int64_t e = tile * 6 + sf;
 #pragma unroll
@@ -164,20 +183,20 @@ __global__ __launch_bounds__(256) void orf_tile_kernel(SeqView dna, OrfTiles til
           if (open) { if (live) out.prefix[e] = len; open = false; }
           else if (live && len >= minlen) {
             const int u_stop = u0 + c;
-            const int k = atomicAdd(&s_cnt[hw][sf], 1);
-            out.slots[e * out.cap + k] = make_uint2((unsigned)(rev ? C - u_stop + 1 : u_stop - len), (unsigned)len);
+            const int k = atomicAdd(&s_cnt[hw], 1);
+            out.slots[tile * out.cap + k] = make_uint2((unsigned)(rev ? C - u_stop + 1 : u_stop - len), (unsigned)len | ((unsigned)sf << 28));
             atomicAdd(&s_hist[orf_bin(len)], 1);
             my_orfs++; my_res += (unsigned)len;
           }
           len = 0;
         } else len++;
       }
-      if (live && i == kTileLanes - 1) {
-        out.suffix[e] = s;
-        if (s == kTileCodons) out.prefix[e] = kTileCodons;
+      if (live && i == kTileLanes - 1) {                                  // len is now the run open at the tile's right edge
+        out.suffix[e] = len;
+        if (open) out.prefix[e] = kTileCodons;                            // no stop anywhere in the tile
       }
     }
-    if (live && i < 6) out.cnt[tile * 6 + i] = s_cnt[hw][i];
+    if (live && i == 0) out.cnt[tile] = s_cnt[hw];
   }
   if (my_orfs) { atomicAdd(&s_red[0], my_orfs); atomicAdd(&s_red[1], my_res); }
   __syncthreads();
@@ -211,16 +230,16 @@ __global__ __launch_bounds__(256) void orf_stitch_kernel(SeqView dna, OrfTiles t
       const int p = out.prefix[e];
       if (p < kTileCodons) {
         const int len = carry + p;
-        if (len >= minlen) {
+        uint2 none = make_uint2(0u, 0u);
+        if (len < minlen) out.cross[e] = none;
+        else {
           const int u_stop = kTileCodons * T + p;
-          const int k = out.cnt[e];
-          out.slots[e * out.cap + k] = make_uint2((unsigned)(rev ? C - u_stop + 1 : u_stop - len), (unsigned)len);
-          out.cnt[e] = k + 1;
+          out.cross[e] = make_uint2((unsigned)(rev ? C - u_stop + 1 : u_stop - len), (unsigned)len | ((unsigned)sf << 28));
           atomicAdd(&s_hist[orf_bin(len)], 1);
           my_orfs++; my_res += (unsigned)len;
         }
         carry = out.suffix[e];
-      } else carry += kTileCodons;
+      } else { carry += kTileCodons; out.cross[e] = make_uint2(0u, 0u); }
     }
   }
   if (my_orfs) { atomicAdd(&s_red[0], my_orfs); atomicAdd(&s_red[1], my_res); }
@@ -243,22 +262,22 @@ __global__ void orf_scan_bins(const int *__restrict__ hist, int *__restrict__ cu
   for (int i = threadIdx.x; i < kOrfBins; i += blockDim.x) cursor[i] = tmp[i];
 }
 
-constexpr int kSortEntriesPerThread = 16;
+constexpr int kSortTilesPerThread = 8;
 
 __global__ __launch_bounds__(256) void orf_sort_kernel(SeqView dna, OrfTiles tiles, const uint2 *__restrict__ slots, int cap, const int32_t *__restrict__ cnt,
-                                                       int *__restrict__ cursor, OrfRec *__restrict__ sorted) {
+                                                       const uint2 *__restrict__ cross, int *__restrict__ cursor, OrfRec *__restrict__ sorted) {
   __shared__ int s_cnt[kOrfBins];
   for (int i = threadIdx.x; i < kOrfBins; i += blockDim.x) s_cnt[i] = 0;
   __syncthreads();
-  const int64_t nent = tiles.ntiles * 6;
-  const int64_t base = (int64_t)blockIdx.x * (256 * kSortEntriesPerThread);
+  const int64_t base = (int64_t)blockIdx.x * (256 * kSortTilesPerThread);
   // pass 1: this block's ORFs per length bin
-  for (int i = 0; i < kSortEntriesPerThread; i++) {
-    const int64_t e = base + (int64_t)i * 256 + threadIdx.x;
-    if (e >= nent) break;
-    const int c = cnt[e];
-    const uint2 *sl = slots + e * cap;
-    for (int k = 0; k < c; k++) atomicAdd(&s_cnt[orf_bin((int)sl[k].y)], 1);
+  for (int i = 0; i < kSortTilesPerThread; i++) {
+    const int64_t t = base + (int64_t)i * 256 + threadIdx.x;
+    if (t >= tiles.ntiles) break;
+    const int c = cnt[t];
+    const uint2 *sl = slots + t * cap;
+    for (int k = 0; k < c; k++) atomicAdd(&s_cnt[orf_bin((int)(sl[k].y & 0x0fffffffu))], 1);
+    for (int f = 0; f < 6; f++) { const unsigned y = cross[t * 6 + f].y & 0x0fffffffu; if (y) atomicAdd(&s_cnt[orf_bin((int)y)], 1); }
   }
   __syncthreads();
   // reserve this block's range in every non-empty bin
@@ -268,21 +287,21 @@ __global__ __launch_bounds__(256) void orf_sort_kernel(SeqView dna, OrfTiles til
   }
   __syncthreads();
   // pass 2: scatter
-  for (int i = 0; i < kSortEntriesPerThread; i++) {
-    const int64_t e = base + (int64_t)i * 256 + threadIdx.x;
-    if (e >= nent) break;
-    const int c = cnt[e];
-    if (c == 0) continue;
-    const int64_t tile = e / 6;
-    const int sf = (int)(e - tile * 6);
-    const int w = tiles.tile_win[tile];
-    const int64_t stream = 2 * dna.off[w] + 96 * (int64_t)w + (int64_t)sf * orf_stream_pitch(dna.len[w]);
-    const uint2 *sl = slots + e * cap;
-    for (int k = 0; k < c; k++) {
-      const uint2 r = sl[k];
-      const int pos = atomicAdd(&s_cnt[orf_bin((int)r.y)], 1);
+  for (int i = 0; i < kSortTilesPerThread; i++) {
+    const int64_t t = base + (int64_t)i * 256 + threadIdx.x;
+    if (t >= tiles.ntiles) break;
+    const int c = cnt[t];
+    const int4 dsc = tiles.desc[t];
+    const int w = dsc.z;
+    const int64_t wbase = 2 * ((int64_t)(uint32_t)dsc.x << 4) + 96 * (int64_t)w;
+    const int pitch = orf_stream_pitch(dsc.y);
+    const uint2 *sl = slots + t * cap;
+    for (int k = 0; k < c + 6; k++) {
+      const uint2 r = k < c ? sl[k] : cross[t * 6 + (k - c)];
+      if ((r.y & 0x0fffffffu) == 0u) continue;
+      const int pos = atomicAdd(&s_cnt[orf_bin((int)(r.y & 0x0fffffffu))], 1);
       OrfRec rec;
-      rec.aa_off = stream + (int64_t)r.x; rec.w = w; rec.len_sf = (int32_t)(r.y | ((unsigned)sf << 28));
+      rec.aa_off = wbase + (int64_t)(r.y >> 28) * pitch + (int64_t)r.x; rec.w = w; rec.len_sf = (int32_t)r.y;
       sorted[pos] = rec;
     }
   }
@@ -290,25 +309,33 @@ __global__ __launch_bounds__(256) void orf_sort_kernel(SeqView dna, OrfTiles til
 
 // ------------------------------------------------------------------------------------------------------------------
 size_t orf_aa_bytes(const bath_hip_seqs *dna) { return (size_t)(2 * dna->total_aligned + 96 * dna->n + 256); }
-int orf_slot_cap(int minlen) { return kTileCodons / (std::max(minlen, 0) + 1) + 2; }
+void orf_buffers_carve(OrfBuffers *ob, void *aa, void *slots, void *sorted, void *misc, size_t nent) {
+  ob->aa = static_cast<uint8_t *>(aa); ob->slots = slots; ob->sorted = static_cast<OrfRec *>(sorted);
+  ob->cross = misc;                                           // nent records of 8 bytes first (keeps them 8-byte aligned)
+  ob->cnt = static_cast<int32_t *>(misc) + 2 * nent; ob->prefix = ob->cnt + nent; ob->suffix = ob->prefix + nent;
+  ob->hist = reinterpret_cast<int *>(ob->suffix + nent); ob->cursor = ob->hist + kOrfBins; ob->ntotal = ob->cursor + kOrfBins;
+}
+
+int orf_slot_cap(int minlen) { return 6 * (kTileCodons / (std::max(minlen, 0) + 1) + 2); }   // six frames share a tile's record region
 
 // tile -> window map of a DNA block, built once per block and kept with it
 int orf_tiles_ensure(bath_hip_ctx *ctx, const bath_hip_seqs *dna) {
   if (dna->ntiles >= 0) return BATH_OK;
-  std::vector<int32_t> first((size_t)std::max<int64_t>(dna->n, 1)), win;
+  std::vector<int32_t> first((size_t)std::max<int64_t>(dna->n, 1));
+  std::vector<int4> desc;
   int64_t nt = 0;
   for (int64_t w = 0; w < dna->n; w++) {
-    first[w] = (int32_t)nt;
-    const int n = dna->h_len[w];
+    first[(size_t)w] = (int32_t)nt;
+    const int n = dna->h_len[(size_t)w];
     const int k = n >= 15 ? (n / 3) / kTileCodons + 1 : 0;
     nt += k;
-    if (nt >= (int64_t)INT32_MAX / 8) { ctx->set_error("DNA block too large for one pipeline call: split it"); return BATH_EINVAL; }
-    win.insert(win.end(), (size_t)k, (int32_t)w);
+    if (nt >= (int64_t)INT32_MAX / 8 || (dna->h_off[(size_t)w] >> 4) > (int64_t)UINT32_MAX) { ctx->set_error("DNA block too large for one pipeline call: split it"); return BATH_EINVAL; }
+    for (int T = 0; T < k; T++) desc.push_back(int4{(int)(uint32_t)(dna->h_off[(size_t)w] >> 4), n, (int)w, T});
   }
-  if (win.empty()) win.push_back(0);
-  BATH_HIP_TRY(ctx, hipMalloc((void **)&dna->d_tile_win, win.size() * sizeof(int32_t)));
+  if (desc.empty()) desc.push_back(int4{0, 0, 0, 0});
+  BATH_HIP_TRY(ctx, hipMalloc((void **)&dna->d_tile_desc, desc.size() * sizeof(int4)));
   BATH_HIP_TRY(ctx, hipMalloc((void **)&dna->d_tile_first, first.size() * sizeof(int32_t)));
-  BATH_HIP_TRY(ctx, hipMemcpy(dna->d_tile_win, win.data(), win.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  BATH_HIP_TRY(ctx, hipMemcpy(dna->d_tile_desc, desc.data(), desc.size() * sizeof(int4), hipMemcpyHostToDevice));
   BATH_HIP_TRY(ctx, hipMemcpy(dna->d_tile_first, first.data(), first.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   dna->ntiles = nt;
   return BATH_OK;
@@ -365,8 +392,8 @@ int launch_orf_scan(bath_hip_ctx *ctx, const bath_hip_seqs *dna, const OrfTables
   const int64_t ntiles = dna->ntiles;
   BATH_HIP_TRY(ctx, hipMemsetAsync(b.hist, 0, kOrfBins * sizeof(int), ctx->stream));
   OrfScanTables tabs{tt.full, tt.fwd, tt.rev, tt.comp};
-  OrfTiles tiles{dna->d_tile_win, dna->d_tile_first, ntiles};
-  OrfScanOut out{b.aa, reinterpret_cast<uint2 *>(b.slots), b.cnt, b.prefix, b.suffix, b.hist, d_n_orfs, d_orf_res, orf_slot_cap(minlen)};
+  OrfTiles tiles{reinterpret_cast<const int4 *>(dna->d_tile_desc), dna->d_tile_first, ntiles};
+  OrfScanOut out{b.aa, reinterpret_cast<uint2 *>(b.slots), b.cnt, reinterpret_cast<uint2 *>(b.cross), b.prefix, b.suffix, b.hist, d_n_orfs, d_orf_res, orf_slot_cap(minlen)};
   const int cus = ctx->prop.multiProcessorCount;
   // persistent blocks: exactly as many as are resident at once, so that every block gets the same share of the tiles
   int per_cu = 0;
@@ -376,9 +403,9 @@ int launch_orf_scan(bath_hip_ctx *ctx, const bath_hip_seqs *dna, const OrfTables
   const int sblocks = (int)std::max<int64_t>(1, std::min<int64_t>((dna->n * 6 + 255) / 256, (int64_t)cus * 8));
   hipLaunchKernelGGL(orf_stitch_kernel, dim3(sblocks), dim3(256), 0, ctx->stream, dna->view(), tiles, out, minlen);
   hipLaunchKernelGGL(orf_scan_bins, dim3(1), dim3(256), 0, ctx->stream, b.hist, b.cursor, b.ntotal);
-  const int per_block = 256 * kSortEntriesPerThread;
-  hipLaunchKernelGGL(orf_sort_kernel, dim3((unsigned)std::max<int64_t>(1, (ntiles * 6 + per_block - 1) / per_block)), dim3(256), 0, ctx->stream, dna->view(), tiles,
-                     reinterpret_cast<const uint2 *>(b.slots), out.cap, b.cnt, b.cursor, b.sorted);
+  const int per_block = 256 * kSortTilesPerThread;
+  hipLaunchKernelGGL(orf_sort_kernel, dim3((unsigned)std::max<int64_t>(1, (ntiles + per_block - 1) / per_block)), dim3(256), 0, ctx->stream, dna->view(), tiles,
+                     reinterpret_cast<const uint2 *>(b.slots), out.cap, b.cnt, reinterpret_cast<const uint2 *>(b.cross), b.cursor, b.sorted);
   BATH_HIP_TRY(ctx, hipGetLastError());
   return BATH_OK;
 }
@@ -405,13 +432,11 @@ extern "C" int bath_hip_translate_orfs(bath_hip_ctx *ctx, const bath_hip_seqs *d
   const size_t nent = (size_t)dna->ntiles * 6;
   DevBuf &b_aa = ctx->scratch[24], &b_slots = ctx->scratch[25], &b_orfs = ctx->scratch[26], &b_misc = ctx->scratch[27];
   BATH_HIP_TRY(ctx, b_aa.reserve(orf_aa_bytes(dna)));
-  BATH_HIP_TRY(ctx, b_slots.reserve((nent * (size_t)orf_slot_cap(min_orf_len) + 64) * 8));
+  BATH_HIP_TRY(ctx, b_slots.reserve(((size_t)dna->ntiles * (size_t)orf_slot_cap(min_orf_len) + 64) * 8));
   BATH_HIP_TRY(ctx, b_orfs.reserve((size_t)(max_orfs + 64) * sizeof(OrfRec)));
-  BATH_HIP_TRY(ctx, b_misc.reserve((3 * nent + 2 * kOrfBins + 64) * sizeof(int32_t) + 64));
+  BATH_HIP_TRY(ctx, b_misc.reserve((5 * nent + 2 * kOrfBins + 64) * sizeof(int32_t) + 64));
   OrfBuffers ob{};
-  ob.aa = b_aa.as<uint8_t>(); ob.slots = b_slots.p; ob.sorted = b_orfs.as<OrfRec>();
-  ob.cnt = b_misc.as<int32_t>(); ob.prefix = ob.cnt + nent; ob.suffix = ob.prefix + nent;
-  ob.hist = reinterpret_cast<int *>(ob.suffix + nent); ob.cursor = ob.hist + kOrfBins; ob.ntotal = ob.cursor + kOrfBins;
+  orf_buffers_carve(&ob, b_aa.p, b_slots.p, b_orfs.p, b_misc.p, nent);
   unsigned long long *d_ctr = reinterpret_cast<unsigned long long *>(ob.ntotal + 2);   // two counters nobody reads here
   BATH_HIP_TRY(ctx, hipMemsetAsync(d_ctr, 0, 16, ctx->stream));
   if ((st = launch_orf_scan(ctx, dna, tt, min_orf_len, ob, d_ctr, d_ctr + 1)) != BATH_OK) return st;

@@ -560,13 +560,11 @@ static int run_filters(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bat
   const size_t nent = (size_t)dna->ntiles * 6;
   DevBuf &b_aa = ctx->scratch[24], &b_slots = ctx->scratch[25], &b_orfs = ctx->scratch[26], &b_misc = ctx->scratch[27];
   BATH_HIP_TRY(ctx, b_aa.reserve(orf_aa_bytes(dna)));
-  BATH_HIP_TRY(ctx, b_slots.reserve((nent * (size_t)orf_slot_cap(prm->min_orf_len) + 64) * 8));
+  BATH_HIP_TRY(ctx, b_slots.reserve(((size_t)dna->ntiles * (size_t)orf_slot_cap(prm->min_orf_len) + 64) * 8));
   BATH_HIP_TRY(ctx, b_orfs.reserve((size_t)(max_orfs + 64) * sizeof(OrfRec)));
-  BATH_HIP_TRY(ctx, b_misc.reserve((3 * nent + 2 * kOrfBins + 64) * sizeof(int32_t)));
+  BATH_HIP_TRY(ctx, b_misc.reserve((5 * nent + 2 * kOrfBins + 64) * sizeof(int32_t)));
   OrfBuffers ob{};
-  ob.aa = b_aa.as<uint8_t>(); ob.slots = b_slots.p; ob.sorted = b_orfs.as<OrfRec>();
-  ob.cnt = b_misc.as<int32_t>(); ob.prefix = ob.cnt + nent; ob.suffix = ob.prefix + nent;
-  ob.hist = reinterpret_cast<int *>(ob.suffix + nent); ob.cursor = ob.hist + kOrfBins; ob.ntotal = ob.cursor + kOrfBins;
+  orf_buffers_carve(&ob, b_aa.p, b_slots.p, b_orfs.p, b_misc.p, nent);
 
   const int NRk = om->NR;
   const size_t ssv_shmem = (size_t)kSsvRows * om->ssv_row_bytes;

@@ -339,7 +339,7 @@ extern "C" void bath_hip_seqs_destroy(bath_hip_seqs *sq) {
   for (bath_hip_seqs *part : sq->parts) bath_hip_seqs_destroy(part);
   sq->parts.clear();
   if (sq->is_part) { sq->d_data = nullptr; sq->d_len = nullptr; }      // borrowed from the parent block
-  for (void *p : {(void *)sq->d_data, (void *)sq->d_off, (void *)sq->d_len, (void *)sq->d_tile_win, (void *)sq->d_tile_first})
+  for (void *p : {(void *)sq->d_data, (void *)sq->d_off, (void *)sq->d_len, (void *)sq->d_tile_desc, (void *)sq->d_tile_first})
     if (p) (void)hipFree(p);
   delete sq;
 }
