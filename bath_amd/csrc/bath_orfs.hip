@@ -175,25 +175,39 @@ __global__ __launch_bounds__(256) void orf_tile_kernel(SeqView dna, OrfTiles til
       }
       bool open = last < 0;                                               // no stop in the tile before this lane
       const int run_in = open ? 4 * i : 4 * i - 1 - last;
-      int len = run_in;
       const int64_t e = tile * 6 + sf;
+      auto record = [&](int u_stop, int len) {
+        const int k = atomicAdd(&s_cnt[hw], 1);
+        out.slots[tile * out.cap + k] = make_uint2((unsigned)(rev ? C - u_stop + 1 : u_stop - len), (unsigned)len | ((unsigned)sf << 28));
+        atomicAdd(&s_hist[orf_bin(len)], 1);
+        my_orfs++; my_res += (unsigned)len;
+      };
+      if (minlen > 2) {
+        // a run that starts after a stop inside these four codons is at most 2 long: only the chunk's first stop can close an ORF
+        if (m != 0u) {
+          const int first = __ffs((int)m) - 1;
+          const int len = run_in + first;
+          if (open) { if (live) out.prefix[e] = len; }
+          else if (live && len >= minlen) record(u0 + first, len);
+        }
+        if (live && i == kTileLanes - 1) {
+          out.suffix[e] = m ? (int)__clz(m) - 28 : run_in + 4;             // the run open at the tile's right edge
+          if (open && m == 0u) out.prefix[e] = kTileCodons;                // no stop anywhere in the tile
+        }
+      } else {
+        int len = run_in;
 #pragma unroll
-      for (int c = 0; c < 4; c++) {
-        if ((m >> c) & 1u) {
-          if (open) { if (live) out.prefix[e] = len; open = false; }
-          else if (live && len >= minlen) {
-            const int u_stop = u0 + c;
-            const int k = atomicAdd(&s_cnt[hw], 1);
-            out.slots[tile * out.cap + k] = make_uint2((unsigned)(rev ? C - u_stop + 1 : u_stop - len), (unsigned)len | ((unsigned)sf << 28));
-            atomicAdd(&s_hist[orf_bin(len)], 1);
-            my_orfs++; my_res += (unsigned)len;
-          }
-          len = 0;
-        } else len++;
-      }
-      if (live && i == kTileLanes - 1) {                                  // len is now the run open at the tile's right edge
-        out.suffix[e] = len;
-        if (open) out.prefix[e] = kTileCodons;                            // no stop anywhere in the tile
+        for (int c = 0; c < 4; c++) {
+          if ((m >> c) & 1u) {
+            if (open) { if (live) out.prefix[e] = len; open = false; }
+            else if (live && len >= minlen) record(u0 + c, len);
+            len = 0;
+          } else len++;
+        }
+        if (live && i == kTileLanes - 1) {
+          out.suffix[e] = len;
+          if (open) out.prefix[e] = kTileCodons;
+        }
       }
     }
     if (live && i == 0) out.cnt[tile] = s_cnt[hw];
