@@ -147,6 +147,7 @@ ABI = {
     "bath_hip_vitfilter": (C.c_int, [_vp, _vp, _vp, _f32p, _i32p]),
     "bath_hip_forward_parser": (C.c_int, [_vp, _vp, _vp, _f32p, _i32p]),
     "bath_hip_bias_filter": (C.c_int, [_vp, _vp, _vp, _f32p, _f32p]),
+    "bath_hip_fwdback_parser": (C.c_int, [_vp, _vp, _vp, _i64p, _f32p, _f32p, _i32p, _i32p, _f32p, _f32p]),
     "bath_hip_translate_orfs": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.POINTER(C.POINTER(Orf)), _i64p, C.POINTER(_u8p)]),
     "bath_pipeline_params_default": (None, [C.POINTER(PipelineParams), C.c_int]),
     "bath_hip_pipeline_filters": (C.c_int, [_vp, _vp, _vp, C.POINTER(PipelineParams), C.POINTER(PipelineStats),
@@ -438,6 +439,21 @@ def ViterbiFilter(ctx, om, sq):
 def ForwardParser(ctx, om, sq):
     """p7_ForwardParser over a block."""
     return _score_call(lib().bath_hip_forward_parser, "forward_parser", ctx, om, sq)
+
+
+def FwdBackParser(ctx, om, sq):
+    """p7_ForwardParser + p7_BackwardParser over a block: (fwd_sc[n], bck_sc[n], fwd_status[n], bck_status[n],
+    [fwd xmx (L+1,6)], [bck xmx (L+1,6)]) with xmx columns {E,N,J,B,C,SCALE}."""
+    n = sq.n
+    offs = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum((sq.lengths + 1) * 6, out=offs[1:])
+    fsc, bsc = np.zeros(n, np.float32), np.zeros(n, np.float32)
+    fst, bst = np.zeros(n, np.int32), np.zeros(n, np.int32)
+    fx, bx = np.zeros(max(int(offs[-1]), 1), np.float32), np.zeros(max(int(offs[-1]), 1), np.float32)
+    ctx._check(lib().bath_hip_fwdback_parser(ctx._h, om._h, sq._h, _i64(offs), _f32(fsc), _f32(bsc), fst.ctypes.data_as(_i32p),
+                                             bst.ctypes.data_as(_i32p), _f32(fx), _f32(bx)), "fwdback_parser")
+    cut = lambda a: [a[offs[i]:offs[i + 1]].reshape(-1, 6) for i in range(n)]
+    return fsc, bsc, fst, bst, cut(fx), cut(bx)
 
 
 def BiasFilter(ctx, om, sq):

@@ -316,7 +316,8 @@ template <int C>
 __global__ __launch_bounds__(256) void fwd_wave_kernel(SeqView sq, int M, const float *__restrict__ g_rf, const float *__restrict__ g_tf,
                                                        const float *__restrict__ pmove_tab, FwdConsts c,
                                                        const int32_t *__restrict__ todo, int64_t ntodo, const int *__restrict__ ntodo_dev,
-                                                       float *__restrict__ sc, int32_t *__restrict__ status) {
+                                                       float *__restrict__ sc, int32_t *__restrict__ status,
+                                                       float *__restrict__ xmx, const int64_t *__restrict__ xmx_off) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   float *s_tf = reinterpret_cast<float *>(lds);          // [(M+1)*8]
   float *s_rf = s_tf + (size_t)(M + 1) * 8;              // [Kp][M+1]
@@ -338,6 +339,8 @@ __global__ __launch_bounds__(256) void fwd_wave_kernel(SeqView sq, int M, const 
     for (int k = 0; k < C; k++) Mp[k] = Ip[k] = Dp[k] = 0.f;
     float xN = 1.f, xE = 0.f, xJ = 0.f, xC = 0.f, xB = pmove;
     float totscale = 0.f;
+    float *xrow = xmx ? xmx + xmx_off[sid] : nullptr;      // (L+1) x {E,N,J,B,C,SCALE}, P7_OMX xmx (impl_sse.h:253-262)
+    if (xrow && lane == 0) { xrow[0] = xE; xrow[1] = xN; xrow[2] = xJ; xrow[3] = xB; xrow[4] = xC; xrow[5] = 1.0f; }
 
     for (int i = 1; i <= L; i++) {
       const int x = min((int)s[i - 1], kKp - 1);
@@ -389,20 +392,162 @@ __global__ __launch_bounds__(256) void fwd_wave_kernel(SeqView sq, int M, const 
       xC = (xC * ploop) + (xE * c.xfE_move);
       xJ = (xJ * ploop) + (xE * c.xfE_loop);
       xB = (xJ * pmove) + (xN * pmove);
+      float scale = 1.0f;
       if (xE > 1.0e4f) {
         xN = xN / xE; xC = xC / xE; xJ = xJ / xE; xB = xB / xE;
         const float inv = (float)(1.0 / (double)xE);
 #pragma unroll
         for (int k = 0; k < C; k++) { Mc[k] *= inv; Dc[k] *= inv; Ic[k] *= inv; }
         totscale += (float)log((double)xE);
+        scale = xE;
         xE = 1.0f;
       }
+      if (xrow && lane == 0) { float *r = xrow + (size_t)i * 6; r[0] = xE; r[1] = xN; r[2] = xJ; r[3] = xB; r[4] = xC; r[5] = scale; }
 #pragma unroll
       for (int k = 0; k < C; k++) { Mp[k] = Mc[k]; Ip[k] = Ic[k]; Dp[k] = Dc[k]; }
     }
     if (lane == 0) {
       if (isnan(xC) || (L > 0 && xC == 0.0f) || isinf(xC)) { sc[sid] = -INFINITY; status[sid] = BATH_ERANGE; }
       else { sc[sid] = (float)((double)totscale + log((double)(xC * pmove))); status[sid] = BATH_OK; }
+    }
+  }
+}
+
+// ============================================================================================
+// Backward parser, wave per target: p7_BackwardParser / backward_engine (src/impl_sse/fwdback.c:468-740), odds-ratio
+// fp32, rescaled row by row with the Forward pass's scale factors (fwd xmx SCALE) unless xB outgrows 1e16 (:668-675).
+// Lane l owns nodes l*C+1 .. l*C+C; D(i,k) = ... + D(i,k+1)*tDD(k) is a right-to-left scan over affine maps.
+// ============================================================================================
+template <int C>
+__global__ __launch_bounds__(256) void bwd_wave_kernel(SeqView sq, int M, const float *__restrict__ g_rf, const float *__restrict__ g_tf,
+                                                       const float *__restrict__ pmove_tab, FwdConsts c, int64_t ntodo,
+                                                       const float *__restrict__ fwd_xmx, const int64_t *__restrict__ xmx_off,
+                                                       float *__restrict__ sc, int32_t *__restrict__ status, float *__restrict__ bck_xmx) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  float *s_tf = reinterpret_cast<float *>(lds);          // [(M+2)*8], node M+1 all zero
+  float *s_rf = s_tf + (size_t)(M + 2) * 8;              // [Kp][M+2], column M+1 zero
+  for (int i = threadIdx.x; i < (M + 2) * 8; i += blockDim.x) s_tf[i] = (i < (M + 1) * 8) ? g_tf[i] : 0.f;
+  for (int i = threadIdx.x; i < kKp * (M + 2); i += blockDim.x) { const int x = i / (M + 2), k = i - x * (M + 2); s_rf[i] = (k <= M) ? g_rf[(size_t)x * (M + 1) + k] : 0.f; }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int64_t wid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t sid = wid; sid < ntodo; sid += nw) {
+    const int L = sq.len[sid];
+    const uint8_t *s = sq.data + sq.off[sid];
+    const float pmove = pmove_tab[L], ploop = 1.0f - pmove;
+    const float *fx = fwd_xmx + xmx_off[sid];
+    float *bx = bck_xmx ? bck_xmx + xmx_off[sid] : nullptr;
+    float xJ = 0.f, xB = 0.f, xN = 0.f, xC = pmove, xE = xC * c.xfE_move;
+    float Mn[C], In[C], Dn[C];
+    // ---- row L: M = D = xE plus the D->D->..->E and M->D->..->E paths (:499-532)
+    {
+      float A = 0.f, B = 1.f;                              // D(k) = xE + D(k+1)*tDD(k)
+#pragma unroll
+      for (int k = C - 1; k >= 0; k--) { const int node = lane * C + k + 1; const float tdd = (node <= M) ? s_tf[(size_t)node * 8 + 5] : 0.f; A = ((node <= M) ? xE : 0.f) + A * tdd; B *= tdd; }
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const float An = __shfl_down(A, d, 64), Bn = __shfl_down(B, d, 64);
+        if (lane + d < 64) { A = A + An * B; B = B * Bn; }
+      }
+      float dnext = __shfl_down(A, 1, 64);                 // D of the first node of the lane to the right
+      if (lane == 63) dnext = 0.f;
+#pragma unroll
+      for (int k = C - 1; k >= 0; k--) {
+        const int node = lane * C + k + 1;
+        if (node <= M) {
+          const float tdd = s_tf[(size_t)node * 8 + 5], tmd = s_tf[(size_t)node * 8 + 4];
+          Dn[k] = xE + dnext * tdd;
+          Mn[k] = xE + dnext * tmd;
+          dnext = Dn[k];
+        } else { Dn[k] = 0.f; Mn[k] = 0.f; dnext = 0.f; }
+        In[k] = 0.f;
+      }
+    }
+    float totscale;
+    {
+      const float scl = (L >= 1) ? fx[(size_t)L * 6 + 5] : 1.0f;
+      if (scl > 1.0f) {
+        xE /= scl; xN /= scl; xC /= scl; xJ /= scl; xB /= scl;
+        const float inv = (float)(1.0 / (double)scl);
+#pragma unroll
+        for (int k = 0; k < C; k++) { Mn[k] *= inv; Dn[k] *= inv; In[k] *= inv; }
+      }
+      totscale = (float)log((double)scl);
+      if (bx && lane == 0) { float *r = bx + (size_t)L * 6; r[0] = xE; r[1] = xN; r[2] = xJ; r[3] = xB; r[4] = xC; r[5] = scl; }
+    }
+    bool own_scales = false;
+    for (int i = L - 1; i >= 0; i--) {
+      const int x = min((int)s[i], kKp - 1);               // residue i+1
+      const float *rf = s_rf + (size_t)x * (M + 2);
+      // B(i) = sum_k M(i+1,k) * e(k, x_{i+1}) * tBM(k)
+      float me[C];                                         // M(i+1,k) * e(k, x_{i+1})
+      float b = 0.f;
+#pragma unroll
+      for (int k = 0; k < C; k++) { const int node = lane * C + k + 1; me[k] = Mn[k] * rf[min(node, M + 1)]; b += me[k] * s_tf[(size_t)min(node, M + 1) * 8 + 3]; }
+      xB = wave_sum_f32(b);
+      if (i == 0) { xN = (xB * pmove) + (xN * ploop); break; }                                       // :695-740: only N and B are reachable
+      xC = xC * ploop;
+      xJ = (xB * pmove) + (xJ * ploop);
+      xN = (xB * pmove) + (xN * ploop);
+      xE = (xC * c.xfE_move) + (xJ * c.xfE_loop);
+      // the node to the right of each lane's block
+      float meR = __shfl_down(me[0], 1, 64);
+      if (lane == 63) meR = 0.f;
+      float mnext[C];                                      // M(i+1,k+1) * e(k+1)
+#pragma unroll
+      for (int k = 0; k < C; k++) mnext[k] = (k + 1 < C) ? me[k + 1] : meR;
+      // D(k) = mnext(k)*tDM(k+1) + xE + D(k+1)*tDD(k): right-to-left affine scan
+      float A = 0.f, B = 1.f, dconst[C], tddv[C];
+#pragma unroll
+      for (int k = C - 1; k >= 0; k--) {
+        const int node = lane * C + k + 1;
+        const bool in = node <= M;
+        const float tdm = (node < M) ? s_tf[(size_t)(node + 1) * 8 + 2] : 0.f;
+        tddv[k] = in ? s_tf[(size_t)node * 8 + 5] : 0.f;
+        dconst[k] = in ? (mnext[k] * tdm) : 0.f;
+        // reference order (:608-612 restated): Dc = mnext*tdm + Dc[k+1]*tdd + xE
+        A = in ? ((dconst[k] + A * tddv[k]) + xE) : 0.f; B = in ? B * tddv[k] : 0.f;
+      }
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const float An = __shfl_down(A, d, 64), Bn = __shfl_down(B, d, 64);
+        if (lane + d < 64) { A = A + An * B; B = B * Bn; }
+      }
+      float dnext = __shfl_down(A, 1, 64);
+      if (lane == 63) dnext = 0.f;
+      float Mc[C], Ic[C], Dc[C];
+#pragma unroll
+      for (int k = C - 1; k >= 0; k--) {
+        const int node = lane * C + k + 1;
+        if (node <= M) {
+          const float *t = s_tf + (size_t)node * 8;               // MD, DD, MI, II leave node k
+          const float *t1 = s_tf + (size_t)(node + 1) * 8;        // MM, IM, DM enter node k+1 (zero at M+1)
+          const float tmm = (node < M) ? t1[0] : 0.f, tim = (node < M) ? t1[1] : 0.f;
+          Ic[k] = In[k] * t[7] + mnext[k] * tim;
+          Dc[k] = (dconst[k] + dnext * tddv[k]) + xE;
+          Mc[k] = ((In[k] * t[6] + mnext[k] * tmm) + xE) + dnext * t[4];
+          dnext = Dc[k];
+        } else { Mc[k] = Ic[k] = Dc[k] = 0.f; dnext = 0.f; }
+      }
+      const float fs = fx[(size_t)i * 6 + 5];
+      if (xB > 1.0e16f) own_scales = true;
+      const float scl = own_scales ? ((xB > 1.0e4f) ? xB : 1.0f) : fs;
+      if (scl > 1.0f) {
+        xE /= scl; xN /= scl; xJ /= scl; xB /= scl; xC /= scl;
+        const float inv = (float)(1.0 / (double)scl);
+#pragma unroll
+        for (int k = 0; k < C; k++) { Mc[k] *= inv; Dc[k] *= inv; Ic[k] *= inv; }
+        totscale += (float)log((double)scl);
+      }
+      if (bx && lane == 0) { float *r = bx + (size_t)i * 6; r[0] = xE; r[1] = xN; r[2] = xJ; r[3] = xB; r[4] = xC; r[5] = scl; }
+#pragma unroll
+      for (int k = 0; k < C; k++) { Mn[k] = Mc[k]; In[k] = Ic[k]; Dn[k] = Dc[k]; }
+    }
+    if (lane == 0) {
+      if (bx) { bx[0] = 0.f; bx[1] = xN; bx[2] = 0.f; bx[3] = xB; bx[4] = 0.f; bx[5] = 1.0f; }
+      if (isnan(xN) || (L > 0 && xN == 0.0f) || isinf(xN)) { sc[sid] = -INFINITY; status[sid] = BATH_ERANGE; }
+      else { sc[sid] = (float)((double)totscale + log((double)xN)); status[sid] = BATH_OK; }
     }
   }
 }
@@ -529,7 +674,8 @@ int launch_vit_wave(bath_hip_ctx *ctx, const bath_hip_oprofile *om, SeqView v, c
   return BATH_OK;
 }
 
-int launch_fwd_wave(bath_hip_ctx *ctx, const bath_hip_oprofile *om, SeqView v, const int32_t *d_todo, int64_t ntodo, float *d_sc, int32_t *d_status, const int *ntodo_dev) {
+int launch_fwd_wave(bath_hip_ctx *ctx, const bath_hip_oprofile *om, SeqView v, const int32_t *d_todo, int64_t ntodo, float *d_sc, int32_t *d_status, const int *ntodo_dev,
+                    float *d_xmx, const int64_t *d_xmx_off) {
   if (ntodo == 0) return BATH_OK;
   const int C = columns_per_lane(om->M);
   const int grid = wave_grid(ctx, ntodo);
@@ -537,7 +683,22 @@ int launch_fwd_wave(bath_hip_ctx *ctx, const bath_hip_oprofile *om, SeqView v, c
   FwdConsts c{om->xf_E[0], om->xf_E[1]};
   BATH_C_SWITCH(C, {
     if (shmem > 64 * 1024) BATH_HIP_TRY(ctx, hipFuncSetAttribute((const void *)fwd_wave_kernel<CC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    hipLaunchKernelGGL(fwd_wave_kernel<CC>, dim3(grid), dim3(256), shmem, ctx->stream, v, om->M, om->d_rf, om->d_tf, om->lt.d_pmove, c, d_todo, ntodo, ntodo_dev, d_sc, d_status);
+    hipLaunchKernelGGL(fwd_wave_kernel<CC>, dim3(grid), dim3(256), shmem, ctx->stream, v, om->M, om->d_rf, om->d_tf, om->lt.d_pmove, c, d_todo, ntodo, ntodo_dev, d_sc, d_status, d_xmx, d_xmx_off);
+  })
+  BATH_HIP_TRY(ctx, hipGetLastError());
+  return BATH_OK;
+}
+
+int launch_bwd_wave(bath_hip_ctx *ctx, const bath_hip_oprofile *om, SeqView v, int64_t n, const float *d_fwd_xmx, const int64_t *d_xmx_off,
+                    float *d_sc, int32_t *d_status, float *d_bck_xmx) {
+  if (n == 0) return BATH_OK;
+  const int C = columns_per_lane(om->M);
+  const int grid = wave_grid(ctx, n);
+  const size_t shmem = ((size_t)(om->M + 2) * 8 + (size_t)kKp * (om->M + 2)) * sizeof(float);
+  FwdConsts c{om->xf_E[0], om->xf_E[1]};
+  BATH_C_SWITCH(C, {
+    if (shmem > 64 * 1024) BATH_HIP_TRY(ctx, hipFuncSetAttribute((const void *)bwd_wave_kernel<CC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    hipLaunchKernelGGL(bwd_wave_kernel<CC>, dim3(grid), dim3(256), shmem, ctx->stream, v, om->M, om->d_rf, om->d_tf, om->lt.d_pmove, c, n, d_fwd_xmx, d_xmx_off, d_sc, d_status, d_bck_xmx);
   })
   BATH_HIP_TRY(ctx, hipGetLastError());
   return BATH_OK;
@@ -631,7 +792,38 @@ extern "C" int bath_hip_vitfilter(bath_hip_ctx *ctx, const bath_hip_oprofile *om
   return score_batch(ctx, om, sq, sc, status, [&](float *d_sc, int32_t *d_st) { return launch_vit_wave(ctx, om, sq->view(), nullptr, sq->n, d_sc, d_st, nullptr, nullptr); });
 }
 extern "C" int bath_hip_forward_parser(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bath_hip_seqs *sq, float *sc, int32_t *status) {
-  return score_batch(ctx, om, sq, sc, status, [&](float *d_sc, int32_t *d_st) { return launch_fwd_wave(ctx, om, sq->view(), nullptr, sq->n, d_sc, d_st, nullptr); });
+  return score_batch(ctx, om, sq, sc, status, [&](float *d_sc, int32_t *d_st) { return launch_fwd_wave(ctx, om, sq->view(), nullptr, sq->n, d_sc, d_st, nullptr, nullptr, nullptr); });
+}
+
+// p7_ForwardParser + p7_BackwardParser with their special-state rows (what p7_domaindef reads): xmx layout (L_i+1) x
+// {E,N,J,B,C,SCALE} at xmx_offsets[i] floats, for both passes.
+extern "C" int bath_hip_fwdback_parser(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bath_hip_seqs *sq, const int64_t *xmx_offsets,
+                                       float *fwd_sc, float *bck_sc, int32_t *fwd_status, int32_t *bck_status, float *fwd_xmx, float *bck_xmx) {
+  int st = check_batch(ctx, om, sq);
+  if (st != BATH_OK) return st;
+  if (!xmx_offsets || !fwd_sc || !bck_sc) return BATH_EINVAL;
+  const int64_t n = sq->n;
+  if (n == 0) return BATH_OK;
+  const size_t nx = (size_t)xmx_offsets[n];
+  DevBuf &b_sc = ctx->scratch[2], &b_st = ctx->scratch[3], &b_off = ctx->scratch[4], &b_fx = ctx->scratch[6], &b_bx = ctx->scratch[7];
+  BATH_HIP_TRY(ctx, b_sc.reserve((size_t)n * 2 * sizeof(float)));
+  BATH_HIP_TRY(ctx, b_st.reserve((size_t)n * 2 * sizeof(int32_t)));
+  BATH_HIP_TRY(ctx, b_off.reserve((size_t)(n + 1) * sizeof(int64_t)));
+  BATH_HIP_TRY(ctx, b_fx.reserve(nx * sizeof(float) + 64));
+  BATH_HIP_TRY(ctx, b_bx.reserve(nx * sizeof(float) + 64));
+  BATH_HIP_TRY(ctx, hipMemcpyAsync(b_off.p, xmx_offsets, (size_t)(n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+  float *d_fsc = b_sc.as<float>(), *d_bsc = d_fsc + n;
+  int32_t *d_fst = b_st.as<int32_t>(), *d_bst = d_fst + n;
+  if ((st = launch_fwd_wave(ctx, om, sq->view(), nullptr, n, d_fsc, d_fst, nullptr, b_fx.as<float>(), b_off.as<int64_t>())) != BATH_OK) return st;
+  if ((st = launch_bwd_wave(ctx, om, sq->view(), n, b_fx.as<float>(), b_off.as<int64_t>(), d_bsc, d_bst, b_bx.as<float>())) != BATH_OK) return st;
+  BATH_HIP_TRY(ctx, hipMemcpyAsync(fwd_sc, d_fsc, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  BATH_HIP_TRY(ctx, hipMemcpyAsync(bck_sc, d_bsc, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  if (fwd_status) BATH_HIP_TRY(ctx, hipMemcpyAsync(fwd_status, d_fst, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  if (bck_status) BATH_HIP_TRY(ctx, hipMemcpyAsync(bck_status, d_bst, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  if (fwd_xmx) BATH_HIP_TRY(ctx, hipMemcpyAsync(fwd_xmx, b_fx.p, nx * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  if (bck_xmx) BATH_HIP_TRY(ctx, hipMemcpyAsync(bck_xmx, b_bx.p, nx * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  BATH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return BATH_OK;
 }
 extern "C" int bath_hip_bias_filter(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bath_hip_seqs *sq, float *nullsc, float *filtersc) {
   int st = check_batch(ctx, om, sq);

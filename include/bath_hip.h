@@ -146,6 +146,12 @@ int bath_hip_vitfilter(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bat
 int bath_hip_forward_parser(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bath_hip_seqs *sq, float *sc, int32_t *status); /* p7_ForwardParser, fwdback.c:132 */
 /* p7_bg_NullOne + p7_bg_FilterScore (p7_bg.c:356,491) with p7_bg_SetFilter(bg, M, om->compo): nullsc[n], filtersc[n] */
 int bath_hip_bias_filter(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bath_hip_seqs *sq, float *nullsc, float *filtersc);
+/* p7_ForwardParser followed by p7_BackwardParser (fwdback.c:132,236) with the special-state rows p7_domaindef reads:
+ * for target i, (L_i+1) rows of {E,N,J,B,C,SCALE} (P7_OMX xmx, impl_sse.h:253-262) at xmx_offsets[i] floats in fwd_xmx and
+ * bck_xmx (either may be NULL).  Backward is scaled by Forward's per-row factors (fwdback.c:660-675).  Scores in nats;
+ * status eslOK / eslERANGE per target (may be NULL). */
+int bath_hip_fwdback_parser(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bath_hip_seqs *sq, const int64_t *xmx_offsets,
+                            float *fwd_sc, float *bck_sc, int32_t *fwd_status, int32_t *bck_status, float *fwd_xmx, float *bck_xmx);
 
 /* ------------------------------------------------------------------------------------------
  * The filter cascade of p7_Pipeline_BATH (p7_pipeline.c:1632-1791) over a block of DNA windows:

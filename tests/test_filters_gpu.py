@@ -81,6 +81,42 @@ def test_forward_parser(setup):
     assert np.allclose(sc, osc, rtol=1e-4, atol=2e-4)
 
 
+def test_backward_parser(setup):
+    """p7_BackwardParser on the GPU against the oracle (oracle/filters.c, fwdback.c:468-740): score, and every
+    special-state row {E,N,J,B,C} of both passes with the same per-row SCALE.  Backward is rescaled by Forward's row
+    factors, which are exactly 1 except on the sparse rows where xE passed 1e4, so the SCALE columns must be identical
+    unless a row's xE sits within rounding of that threshold.  Forward == Backward per target (the reference's own
+    utest, fwdback.c:1015-1085, demands 0.001)."""
+    ctx, model, om, seqs, sq = setup
+    fsc, bsc, fst, bst, fx, bx = ba.FwdBackParser(ctx, om, sq)
+    L_ = ol.lib()
+    import ctypes as C
+    out = C.c_float(0)
+    checked = 0
+    for i, s_ in enumerate(seqs):
+        n = len(s_)
+        d = ol.dsq_from(s_)
+        L_.bo_oprofile_reconfig_length(model.om, n)
+        ofx = np.zeros((n + 1) * 6, np.float32); obx = np.zeros((n + 1) * 6, np.float32)
+        st_f = L_.bo_forward_parser(ol.u8(d), n, model.om, ofx.ctypes.data_as(C.POINTER(C.c_float)), C.byref(out)); of = out.value
+        st_b = L_.bo_backward_parser(ol.u8(d), n, model.om, ofx.ctypes.data_as(C.POINTER(C.c_float)), obx.ctypes.data_as(C.POINTER(C.c_float)), C.byref(out)); ob = out.value
+        assert (fst[i], bst[i]) == (st_f, st_b)
+        if st_f != 0 or st_b != 0:
+            continue
+        assert abs(fsc[i] - of) <= 2e-4 + 1e-4 * abs(of)
+        assert abs(bsc[i] - ob) <= 2e-4 + 1e-4 * abs(ob)
+        assert abs(fsc[i] - bsc[i]) <= 1e-3 + 1e-4 * abs(of)
+        ofx, obx = ofx.reshape(-1, 6), obx.reshape(-1, 6)
+        if i % 7 == 0 or n > 1000:                        # row-level comparison on a sample (and on every long target)
+            same_scale = np.array_equal(fx[i][:, 5], ofx[:, 5])
+            if same_scale:
+                assert np.allclose(fx[i][:, :5], ofx[:, :5], rtol=2e-4, atol=1e-30)
+                assert np.array_equal(bx[i][:, 5], obx[:, 5])
+                assert np.allclose(bx[i][:, :5], obx[:, :5], rtol=5e-4, atol=1e-30)
+                checked += 1
+    assert checked > 50
+
+
 def test_bias_filter(setup):
     ctx, model, om, seqs, sq = setup
     nullsc, fsc = ba.BiasFilter(ctx, om, sq)
