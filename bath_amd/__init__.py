@@ -112,6 +112,14 @@ class FsWindow(C.Structure):
                 ("branch", C.c_int32)]
 
 
+class FsDomain(C.Structure):
+    """bath_fs_domain (include/bath_hip.h): a domain of the frameshift branch with the scores of its hit."""
+    _fields_ = [("window", C.c_int64), ("strand", C.c_int32), ("fs_window", C.c_int32),
+                ("ienv", C.c_int32), ("jenv", C.c_int32), ("iali", C.c_int32), ("jali", C.c_int32), ("ihmm", C.c_int32), ("jhmm", C.c_int32),
+                ("envsc", C.c_float), ("oasc", C.c_float), ("domcorrection", C.c_float), ("dombias", C.c_float),
+                ("bitscore", C.c_float), ("pre_score", C.c_float), ("lnP", C.c_double), ("reported", C.c_int32), ("n_shifted_codons", C.c_int32)]
+
+
 class Fs5Result(C.Structure):
     _fields_ = [("fwdsc", C.c_float), ("bcksc", C.c_float), ("oasc", C.c_float), ("null2", C.c_float * KP)]
 
@@ -154,6 +162,8 @@ ABI = {
                                             C.POINTER(C.POINTER(OrfResult)), _i64p]),
     "bath_hip_pipeline_frameshift": (C.c_int, [_vp, _vp, _vp, _vp, C.POINTER(PipelineParams), C.POINTER(PipelineStats),
                                               C.POINTER(C.POINTER(OrfResult)), _i64p, C.POINTER(C.POINTER(FsWindow)), _i64p]),
+    "bath_hip_pipeline_frameshift_domains": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.POINTER(PipelineParams), C.c_double, C.POINTER(PipelineStats),
+                                                      C.POINTER(C.POINTER(FsWindow)), _i64p, C.POINTER(C.POINTER(FsDomain)), _i64p, _i64p]),
     "bath_hip_pipeline_timings": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_char_p), _f32p, _i64p]),
     "bath_hip_fsprofile_convert": (C.c_int, [_vp, C.POINTER(_FsProfile), C.POINTER(_vp)]),
     "bath_hip_fsprofile_destroy": (None, [_vp]),
@@ -510,6 +520,25 @@ class Pipeline:
             C.memmove(C.byref(w), C.byref(fw[i]), C.sizeof(FsWindow))
             wins.append(w)
         return stats, out, wins
+
+    def run_frameshift_domains(self, om_fs3, om_fs5, dna, E_report=10.0):
+        """bathsearch --fs through domain definition: (stats, [FsWindow], [FsDomain], multi-domain regions skipped)."""
+        stats = PipelineStats()
+        fw = C.POINTER(FsWindow)(); nfw = C.c_int64(0)
+        dm = C.POINTER(FsDomain)(); ndm = C.c_int64(0)
+        nskip = C.c_int64(0)
+        self.ctx._check(lib().bath_hip_pipeline_frameshift_domains(self.ctx._h, self.om._h, om_fs3._h, om_fs5._h, dna._h, C.byref(self.params), E_report,
+                                                                   C.byref(stats), C.byref(fw), C.byref(nfw), C.byref(dm), C.byref(ndm), C.byref(nskip)),
+                        "pipeline_frameshift_domains")
+
+        def copies(ptr, n, T):
+            out = []
+            for i in range(n):
+                x = T()
+                C.memmove(C.byref(x), C.byref(ptr[i]), C.sizeof(T))
+                out.append(x)
+            return out
+        return stats, copies(fw, nfw.value, FsWindow), copies(dm, ndm.value, FsDomain), nskip.value
 
     def timings(self):
         names = (C.c_char_p * 32)()

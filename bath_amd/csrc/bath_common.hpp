@@ -59,6 +59,7 @@ struct bath_hip_ctx {
   std::vector<bath_orf_result> results;
   std::vector<bath_orf> orfs;             // bath_hip_translate_orfs output
   std::vector<bath_fs_window> fs_windows; // bath_hip_pipeline_frameshift output
+  std::vector<bath_fs_domain> fs_domains; // bath_hip_pipeline_frameshift_domains output
   std::vector<uint8_t> orf_aa;
   std::vector<bath::StageTiming> timings;
   std::vector<hipEvent_t> ev_pool;

@@ -23,6 +23,7 @@
 
 #include "bath_common.hpp"
 #include "bath_kernels.hpp"
+#include "bath_launch.hpp"
 
 using namespace bath;
 
@@ -36,6 +37,8 @@ struct bath_hip_fsprofile {
   float *d_tf = nullptr;         // [(M+2)][8] forward-ordered transitions per node
   float *d_tb = nullptr;         // [(M+2)][8] backward-ordered transitions per node
   float *d_logsum = nullptr;     // [16000]
+  std::vector<float> h_tsc;      // [M*8] generic log transitions (OA traceback deltas on the host)
+  std::vector<uint8_t> h_codons; // [(M+1)*maxcodons] best amino acid per (node, quasi-codon) (null2 along a trace)
   // length model: xsc[N|C|J][LOOP|MOVE] for L_amino, multihit (nj=1) and unihit (nj=0); host libm log()
   mutable int maxL = -1;
   mutable float *d_loop[2] = {nullptr, nullptr}, *d_move[2] = {nullptr, nullptr};
@@ -596,7 +599,8 @@ __global__ __launch_bounds__(256) void fs5_decode_kernel(SeqView dna, int M, con
 template <int C>
 __global__ __launch_bounds__(256) void fs5_oa_kernel(SeqView dna, int M, const float *__restrict__ tf /* forward-ordered log transitions */,
                                                      const float *__restrict__ pp, const int64_t *__restrict__ pp_off, const float *__restrict__ px, const int64_t *__restrict__ px_off,
-                                                     float *__restrict__ oa, const int64_t *__restrict__ oa_off, float *__restrict__ oasc, float ej, float ec) {
+                                                     float *__restrict__ oa, const int64_t *__restrict__ oa_off, float *__restrict__ oasc, float ej, float ec,
+                                                     float *__restrict__ ox /* optional: OA special-state rows (L+1) x {E,N,J,B,C} at px_off */) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   float *s_dl = reinterpret_cast<float *>(lds);                 // [(M+2)][8] deltas, same order as tf
   for (int i = threadIdx.x; i < (M + 2) * 8; i += blockDim.x) s_dl[i] = (tf[i] == -INFINITY) ? 1.17549435e-38f : 1.0f;
@@ -610,6 +614,8 @@ __global__ __launch_bounds__(256) void fs5_oa_kernel(SeqView dna, int M, const f
     const float *P = pp + pp_off[job];
     const float *X = px + px_off[job];
     float *O = oa + oa_off[job];
+    float *OX = ox ? ox + px_off[job] : nullptr;
+    if (OX && lane == 0) { OX[0] = -INFINITY; OX[1] = 0.f; OX[2] = -INFINITY; OX[3] = 0.f; OX[4] = -INFINITY; }
     // rows i-1..i-5 of M, I, D and B; rows i-1..i-3 of N, J, C
     float Mr[5][C], Ir[5][C], Dr[5][C];
 #pragma unroll
@@ -695,6 +701,7 @@ __global__ __launch_bounds__(256) void fs5_oa_kernel(SeqView dna, int M, const f
       if (i <= 2) { nJ = ej * xE; nC = ec * xE; nN = X[i * 5 + 1]; }
       else { nJ = fmaxf(Jh[2] + X[i * 5 + 2], ej * xE); nC = fmaxf(Ch[2] + X[i * 5 + 4], ec * xE); nN = Nh[2] + X[i * 5 + 1]; }
       const float nB = fmaxf(nN, nJ);
+      if (OX && lane == 0) { float *r = OX + (size_t)i * 5; r[0] = xE; r[1] = nN; r[2] = nJ; r[3] = nB; r[4] = nC; }
       Nh[2] = Nh[1]; Nh[1] = Nh[0]; Nh[0] = nN;
       Jh[2] = Jh[1]; Jh[1] = Jh[0]; Jh[0] = nJ;
       Ch[2] = Ch[1]; Ch[1] = Ch[0]; Ch[0] = nC;
@@ -800,6 +807,8 @@ extern "C" int bath_hip_fsprofile_convert(bath_hip_ctx *ctx, const bath_fs_profi
   om->ctx = ctx; om->M = M; om->codon_lengths = gm->codon_lengths; om->maxcodons = gm->maxcodons; om->max_length = gm->max_length;
   om->fsprob = gm->fsprob;
   std::memcpy(om->evparam, gm->evparam, sizeof om->evparam);
+  om->h_tsc.assign(gm->tsc, gm->tsc + (size_t)M * 8);
+  if (gm->codons) om->h_codons.assign(gm->codons, gm->codons + (size_t)(M + 1) * gm->maxcodons);
   om->pitch = (M + 1 + 3) / 4 * 4;
   const int nrows = gm->maxcodons + kKp;
   std::vector<float> rsc((size_t)nrows * om->pitch, -INFINITY);
@@ -935,8 +944,24 @@ extern "C" int bath_hip_fs3_backward_parser(bath_hip_ctx *ctx, const bath_hip_fs
   return fs3_parser(ctx, om3, dna, logsum_mode, sc, xmx, xmx_offsets, true);
 }
 
+namespace bath {
+int fs5_envelopes_ex(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, const bath_hip_seqs *dna, int logsum_mode, int c5_compat,
+                     bath_fs5_result *res, float *pp, float *oa, float *ppx, float *oax);
+const FsHostTables fsprofile_host(const bath_hip_fsprofile *om) {
+  return FsHostTables{om->M, om->max_length, om->maxcodons, om->h_tsc.data(), om->h_codons.empty() ? nullptr : om->h_codons.data(), om->evparam};
+}
+}  // namespace bath
+
 extern "C" int bath_hip_fs5_envelopes(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, const bath_hip_seqs *dna, int logsum_mode, int c5_compat,
                                       bath_fs5_result *res, float *pp, const int64_t *pp_off_h, float *oa, const int64_t *oa_off_h) {
+  (void)pp_off_h; (void)oa_off_h;
+  return bath::fs5_envelopes_ex(ctx, om, dna, logsum_mode, c5_compat, res, pp, oa, nullptr, nullptr);
+}
+
+// Envelope rescoring; layouts per envelope i, rows = L_i+1: pp rows*(M+1)*8, oa rows*(M+1)*3, ppx / oax rows*5
+// {E,N,J,B,C} (posterior and OA special-state rows), each packed back to back in envelope order.
+int bath::fs5_envelopes_ex(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, const bath_hip_seqs *dna, int logsum_mode, int c5_compat,
+                           bath_fs5_result *res, float *pp, float *oa, float *ppx, float *oax) {
   if (!ctx || !om || !dna || om->codon_lengths != 5) { if (ctx) ctx->set_error("fs5 envelopes need a 5-codon profile"); return BATH_EINVAL; }
   BATH_HIP_TRY(ctx, hipSetDevice(ctx->device));
   const int64_t n = dna->n;
@@ -951,7 +976,8 @@ extern "C" int bath_hip_fs5_envelopes(bath_hip_ctx *ctx, const bath_hip_fsprofil
     foff[i + 1] = foff[i] + rows * (M + 1) * 8; boff[i + 1] = boff[i] + rows * (M + 1) * 3; xoff[i + 1] = xoff[i] + rows * 5;
   }
   DevBuf &b_f = ctx->scratch[15], &b_b = ctx->scratch[16], &b_o = ctx->scratch[17], &b_fx = ctx->scratch[18], &b_bx = ctx->scratch[19];
-  DevBuf &b_off = ctx->scratch[20], &b_sc = ctx->scratch[21], &b_cs = ctx->scratch[22], &b_n2 = ctx->scratch[23];
+  DevBuf &b_off = ctx->scratch[20], &b_sc = ctx->scratch[21], &b_cs = ctx->scratch[22], &b_n2 = ctx->scratch[23], &b_ox = ctx->scratch[11];
+  if (oax) BATH_HIP_TRY(ctx, b_ox.reserve((size_t)xoff[n] * 4 + 64));
   BATH_HIP_TRY(ctx, b_f.reserve((size_t)foff[n] * 4 + 64)); BATH_HIP_TRY(ctx, b_b.reserve((size_t)boff[n] * 4 + 64)); BATH_HIP_TRY(ctx, b_o.reserve((size_t)boff[n] * 4 + 64));
   BATH_HIP_TRY(ctx, b_fx.reserve((size_t)xoff[n] * 4 + 64)); BATH_HIP_TRY(ctx, b_bx.reserve((size_t)xoff[n] * 4 + 64));
   BATH_HIP_TRY(ctx, b_off.reserve((size_t)(n + 1) * 3 * sizeof(int64_t)));
@@ -987,7 +1013,7 @@ extern "C" int bath_hip_fs5_envelopes(bath_hip_ctx *ctx, const bath_hip_fsprofil
                        b_b.as<float>(), d_boff, b_bx.as<float>(), b_cs.as<float>());
     if ((st = fs_set_shmem(ctx, fs5_oa_kernel<CC>, oa_shmem)) != BATH_OK) return st;
     hipLaunchKernelGGL((fs5_oa_kernel<CC>), dim3(grid), dim3(256), oa_shmem, ctx->stream, dna->view(), M, om->d_tf, b_f.as<float>(), d_foff, b_fx.as<float>(), d_xoff, b_o.as<float>(), d_boff, d_osc,
-                       1.17549435e-38f /* E->J impossible in unihit mode: TSCDELTA = FLT_MIN */, 1.0f);
+                       1.17549435e-38f /* E->J impossible in unihit mode: TSCDELTA = FLT_MIN */, 1.0f, oax ? b_ox.as<float>() : nullptr);
   })
   hipLaunchKernelGGL(fs5_null2_kernel, dim3((unsigned)n), dim3(32), 0, ctx->stream, n, dna->d_len, M, om->pitch, om->d_rsc + (size_t)om->maxcodons * om->pitch, om->d_logsum,
                      b_cs.as<float>(), b_n2.as<float>());
@@ -997,11 +1023,12 @@ extern "C" int bath_hip_fs5_envelopes(bath_hip_ctx *ctx, const bath_hip_fsprofil
   BATH_HIP_TRY(ctx, hipMemcpyAsync(h_n2.data(), b_n2.p, (size_t)n * kKp * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
   if (pp) BATH_HIP_TRY(ctx, hipMemcpyAsync(pp, b_f.p, (size_t)foff[n] * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
   if (oa) BATH_HIP_TRY(ctx, hipMemcpyAsync(oa, b_o.p, (size_t)boff[n] * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  if (ppx) BATH_HIP_TRY(ctx, hipMemcpyAsync(ppx, b_fx.p, (size_t)xoff[n] * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  if (oax) BATH_HIP_TRY(ctx, hipMemcpyAsync(oax, b_ox.p, (size_t)xoff[n] * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
   BATH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   for (int64_t i = 0; i < n; i++) {
     res[i].fwdsc = h_sc[i]; res[i].bcksc = h_sc[n + i]; res[i].oasc = h_sc[2 * n + i];
     std::memcpy(res[i].null2, &h_n2[(size_t)i * kKp], sizeof(float) * kKp);
   }
-  (void)pp_off_h; (void)oa_off_h;
   return BATH_OK;
 }

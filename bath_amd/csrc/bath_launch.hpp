@@ -42,10 +42,23 @@ int launch_vit_lane(bath_hip_ctx *ctx, const bath_hip_oprofile *om, SeqView v, c
 struct MsvConsts;
 MsvConsts msv_consts(const bath_hip_oprofile *om);
 
+// ---- DNA regions gathered into a pool for the frameshift kernels (bath_pipeline.hip)
+struct FsWinDev {                  // one DNA window / envelope, device view
+  int64_t src_off;                 // offset of its sequence in the DNA block
+  int64_t dst_off;                 // offset of the region's copy in the pool
+  int32_t seq_n, start, len, strand, kmin, kmax;   // start: 1-based on the strand being read
+};
+int fs_gather_view(bath_hip_ctx *ctx, const bath_hip_seqs *dna, std::vector<FsWinDev> &regs, const uint8_t *d_comp, bath_hip_seqs *view, const FsWinDev **d_desc_out);
+float flogsum_host(float a, float b);                          // p7_FLogsum with its table, on the host
+
 // ---- frameshift helpers for the pipeline (bath_frameshift.hip)
 int fs3_forward_scores(bath_hip_ctx *ctx, const bath_hip_fsprofile *om3, const bath_hip_seqs *dna, float *sc);   // table log-sum, host array out
 const float *fsprofile_evparam(const bath_hip_fsprofile *om);
 int fsprofile_codon_lengths(const bath_hip_fsprofile *om);
+struct FsHostTables { int M, max_length, maxcodons; const float *tsc; const uint8_t *codons; const float *evparam; };
+const FsHostTables fsprofile_host(const bath_hip_fsprofile *om);
+int fs5_envelopes_ex(bath_hip_ctx *ctx, const bath_hip_fsprofile *om5, const bath_hip_seqs *dna, int logsum_mode, int c5_compat,
+                     bath_fs5_result *res, float *pp, float *oa, float *ppx, float *oax);
 
 // ---- six-frame translation + ORF work list (bath_orfs.hip)
 struct OrfRec {                   // one ORF of the length-sorted work list

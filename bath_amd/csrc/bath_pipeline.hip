@@ -837,11 +837,6 @@ extern "C" int bath_hip_pipeline_filters(bath_hip_ctx *ctx, const bath_hip_oprof
 // =================================================================================================
 namespace bath {
 
-struct FsWinDev {                  // one DNA window, device view
-  int64_t src_off;                 // offset of its sequence in the DNA block
-  int64_t dst_off;                 // offset of the window's copy in the pool
-  int32_t seq_n, start, len, strand, kmin, kmax;
-};
 
 // copy each window out of its sequence, reverse-complemented for the bottom strand
 __global__ void fs_window_gather_kernel(const uint8_t *__restrict__ dna, const FsWinDev *__restrict__ wins, int nw, const uint8_t *__restrict__ comp,
@@ -903,7 +898,39 @@ __global__ void fs_bias_kernel(const uint8_t *__restrict__ pool, const FsWinDev 
   }
 }
 
-static float flogsum_host(float a, float b) {               // p7_FLogsum, logsum.c:105-111 (table of logsum.c:89)
+// Copies the regions described by <regs> (dst_off is filled in here) into one pool on the device, reverse-complemented
+// for the bottom strand, and returns a sequence-block view of the pool (borrowed pointers: clear them before <view> dies).
+int fs_gather_view(bath_hip_ctx *ctx, const bath_hip_seqs *dna, std::vector<FsWinDev> &regs, const uint8_t *d_comp, bath_hip_seqs *view, const FsWinDev **d_desc_out) {
+  const int nw = (int)regs.size();
+  int64_t pool_bytes = 0;
+  for (FsWinDev &d : regs) { d.dst_off = pool_bytes; pool_bytes += ((int64_t)d.len + 15) / 16 * 16 + 16; }
+  DevBuf &b_pool = ctx->scratch[29], &b_desc = ctx->scratch[30];
+  BATH_HIP_TRY(ctx, b_pool.reserve((size_t)pool_bytes + 256));
+  const size_t desc_bytes = ((size_t)nw * sizeof(FsWinDev) + 255) / 256 * 256;
+  BATH_HIP_TRY(ctx, b_desc.reserve(desc_bytes + (size_t)nw * 12 + 64));          // descriptors, then the view's off[] and len[]
+  BATH_HIP_TRY(ctx, hipMemsetAsync(b_pool.p, 0x1d, (size_t)pool_bytes + 256, ctx->stream));
+  FsWinDev *d_desc = b_desc.as<FsWinDev>();
+  BATH_HIP_TRY(ctx, hipMemcpyAsync(d_desc, regs.data(), (size_t)nw * sizeof(FsWinDev), hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(fs_window_gather_kernel, dim3((unsigned)std::max(1, std::min(nw, 65535))), dim3(256), 0, ctx->stream, dna->d_data, d_desc, nw, d_comp, b_pool.as<uint8_t>());
+  BATH_HIP_TRY(ctx, hipGetLastError());
+  view->ctx = ctx; view->n = nw; view->d_data = b_pool.as<uint8_t>(); view->is_part = true;   // is_part: the destructor path must not free borrowed memory
+  view->h_off.resize((size_t)nw); view->h_len.resize((size_t)nw);
+  view->maxlen = 0; view->total = 0;
+  for (int i = 0; i < nw; i++) {
+    view->h_off[(size_t)i] = regs[(size_t)i].dst_off; view->h_len[(size_t)i] = regs[(size_t)i].len;
+    view->maxlen = std::max(view->maxlen, regs[(size_t)i].len); view->total += regs[(size_t)i].len;
+  }
+  view->total_aligned = pool_bytes;
+  int64_t *d_voff = reinterpret_cast<int64_t *>(reinterpret_cast<char *>(d_desc) + desc_bytes);
+  int32_t *d_vlen = reinterpret_cast<int32_t *>(d_voff + nw);
+  BATH_HIP_TRY(ctx, hipMemcpyAsync(d_voff, view->h_off.data(), (size_t)nw * 8, hipMemcpyHostToDevice, ctx->stream));
+  BATH_HIP_TRY(ctx, hipMemcpyAsync(d_vlen, view->h_len.data(), (size_t)nw * 4, hipMemcpyHostToDevice, ctx->stream));
+  view->d_off = d_voff; view->d_len = d_vlen;
+  if (d_desc_out) *d_desc_out = d_desc;
+  return BATH_OK;
+}
+
+float flogsum_host(float a, float b) {               // p7_FLogsum, logsum.c:105-111 (table of logsum.c:89)
   static std::vector<float> tbl;
   if (tbl.empty()) { tbl.resize(16000); for (int i = 0; i < 16000; i++) tbl[i] = (float)std::log(1. + std::exp((double)-i / 1000.f)); }
   const float mx = std::max(a, b), mn = std::min(a, b);
@@ -993,7 +1020,6 @@ extern "C" int bath_hip_pipeline_frameshift(bath_hip_ctx *ctx, const bath_hip_op
   std::vector<bath_fs_window> out;
   std::vector<FsWinDev> dev;
   std::vector<int64_t> std_branch_pos;            // pos_past_fwd the standard branch would add for each window
-  int64_t pool_bytes = 0;
   for (auto &g : groups) {
     const int64_t w = g.first.w;
     const int strand = g.first.strand;
@@ -1059,41 +1085,25 @@ extern "C" int bath_hip_pipeline_frameshift(bath_hip_ctx *ctx, const bath_hip_op
       out.push_back(r);
       std_branch_pos.push_back(std_pos);
       FsWinDev d{};
-      d.src_off = dna->h_off[w]; d.dst_off = pool_bytes; d.seq_n = n_seq; d.start = (int32_t)dw.n; d.len = dw.length; d.strand = strand;
+      d.src_off = dna->h_off[w]; d.dst_off = 0; d.seq_n = n_seq; d.start = (int32_t)dw.n; d.len = dw.length; d.strand = strand;
       d.kmin = k_min; d.kmax = k_max;
       dev.push_back(d);
-      pool_bytes += ((int64_t)dw.length + 15) / 16 * 16 + 16;
     }
   }
   const int nw = (int)out.size();
   int64_t pos_fwd = 0;
   if (nw > 0) {
     // ---- windows -> device, bias filter and 3-codon frameshift Forward for all of them
-    DevBuf &b_pool = ctx->scratch[29], &b_desc = ctx->scratch[30], &b_out = ctx->scratch[31];
-    BATH_HIP_TRY(ctx, b_pool.reserve((size_t)pool_bytes + 256));
-    const size_t desc_bytes = ((size_t)nw * sizeof(FsWinDev) + 255) / 256 * 256;
-    BATH_HIP_TRY(ctx, b_desc.reserve(desc_bytes + (size_t)nw * 12 + 64));        // descriptors, then the view's off[] and len[]
+    DevBuf &b_out = ctx->scratch[31];
+    bath_hip_seqs view;
+    const FsWinDev *d_desc = nullptr;
+    if ((st = fs_gather_view(ctx, dna, dev, S.tt.comp, &view, &d_desc)) != BATH_OK) return st;
     BATH_HIP_TRY(ctx, b_out.reserve((size_t)nw * 6 * sizeof(float) + 64));
-    BATH_HIP_TRY(ctx, hipMemsetAsync(b_pool.p, 0x1d, (size_t)pool_bytes + 256, ctx->stream));
-    FsWinDev *d_desc = b_desc.as<FsWinDev>();
-    BATH_HIP_TRY(ctx, hipMemcpyAsync(d_desc, dev.data(), (size_t)nw * sizeof(FsWinDev), hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(fs_window_gather_kernel, dim3((unsigned)std::min(nw, 65535)), dim3(256), 0, ctx->stream, dna->d_data, d_desc, nw, S.tt.comp, b_pool.as<uint8_t>());
-    hipLaunchKernelGGL(fs_bias_kernel, dim3((unsigned)((2 * nw + 63) / 64)), dim3(64), 0, ctx->stream, b_pool.as<uint8_t>(), d_desc, nw, S.tt.full, M, om->d_bias_eo,
+    hipLaunchKernelGGL(fs_bias_kernel, dim3((unsigned)((2 * nw + 63) / 64)), dim3(64), 0, ctx->stream, view.d_data, d_desc, nw, S.tt.full, M, om->d_bias_eo,
                        S.d_ssvsc, (int)om->base_b, om->scale_b, S.d_bgf, b_out.as<float>());
     BATH_HIP_TRY(ctx, hipGetLastError());
     std::vector<float> h_bias((size_t)nw * 6);
     BATH_HIP_TRY(ctx, hipMemcpyAsync(h_bias.data(), b_out.p, h_bias.size() * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-    // a sequence-block view of the window pool for the Forward parser
-    bath_hip_seqs view;
-    view.ctx = ctx; view.n = nw; view.d_data = b_pool.as<uint8_t>();
-    view.h_off.resize((size_t)nw); view.h_len.resize((size_t)nw);
-    for (int i = 0; i < nw; i++) { view.h_off[(size_t)i] = dev[(size_t)i].dst_off; view.h_len[(size_t)i] = dev[(size_t)i].len; view.maxlen = std::max(view.maxlen, dev[(size_t)i].len); view.total += dev[(size_t)i].len; }
-    view.total_aligned = pool_bytes;
-    int64_t *d_voff = reinterpret_cast<int64_t *>(reinterpret_cast<char *>(d_desc) + desc_bytes);
-    int32_t *d_vlen = reinterpret_cast<int32_t *>(d_voff + nw);
-    BATH_HIP_TRY(ctx, hipMemcpyAsync(d_voff, view.h_off.data(), (size_t)nw * 8, hipMemcpyHostToDevice, ctx->stream));
-    BATH_HIP_TRY(ctx, hipMemcpyAsync(d_vlen, view.h_len.data(), (size_t)nw * 4, hipMemcpyHostToDevice, ctx->stream));
-    view.d_off = d_voff; view.d_len = d_vlen;
     std::vector<float> h_fsc((size_t)nw);
     st = fs3_forward_scores(ctx, om_fs3, &view, h_fsc.data());
     view.d_data = nullptr; view.d_off = nullptr; view.d_len = nullptr;     // borrowed pointers: nothing for a destructor to free

@@ -227,6 +227,29 @@ int  bath_hip_pipeline_frameshift(bath_hip_ctx *ctx, const bath_hip_oprofile *om
                                   const bath_orf_result **results, int64_t *n_results,
                                   const bath_fs_window **fs_windows, int64_t *n_fs_windows);
 
+/* ... and what the frameshift branch does next (p7_pipeline.c:1469-1476): p7_BackwardParser_Frameshift_3Codons,
+ * p7_domaindef_ByPosteriorHeuristics_Frameshift_BATH (p7_domaindef.c:301) with rescore_isolated_domain_frameshift (:993)
+ * for single-domain regions, and the scores p7_pli_postDomainDef_Frameshift_BATH (p7_pipeline.c:1005) gives the hit.
+ * Multi-domain regions (stochastic-trace clustering, p7_domaindef.c:396-455) are counted in *n_skipped_regions. */
+typedef struct {
+  int64_t window;                  /* sequence index in the block                                              */
+  int32_t strand;
+  int32_t fs_window;               /* index into the fs_windows array                                          */
+  int32_t ienv, jenv, iali, jali;  /* nt coordinates on the sequence, as P7_DOMAIN ienv/jenv/iali/jali (:1035-1049) */
+  int32_t ihmm, jhmm;              /* first / last model node of the optimal-accuracy alignment                */
+  float   envsc, oasc;             /* envelope Forward score (nats), expected number of correctly aligned residues */
+  float   domcorrection, dombias;  /* null2 correction and the bias term derived from it, nats (:1064)          */
+  float   bitscore, pre_score;     /* the hit's score in bits (hit->score) and before the null2 correction       */
+  double  lnP;
+  int32_t reported;                /* exp(lnP) * Z <= E_report, Z = nres of the block / max_length (:1080)      */
+  int32_t n_shifted_codons;        /* match states of the alignment that emit a quasi-codon (length != 3)        */
+} bath_fs_domain;
+int  bath_hip_pipeline_frameshift_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bath_hip_fsprofile *om_fs3,
+                                          const bath_hip_fsprofile *om_fs5, const bath_hip_seqs *dna, const bath_pipeline_params *params,
+                                          double E_report, bath_pipeline_stats *stats,
+                                          const bath_fs_window **fs_windows, int64_t *n_fs_windows,
+                                          const bath_fs_domain **domains, int64_t *n_domains, int64_t *n_skipped_regions);
+
 /* ------------------------------------------------------------------------------------------
  * Frameshift kernels (P7_FS_OPROFILE surface), batched over DNA windows.
  * ------------------------------------------------------------------------------------------ */

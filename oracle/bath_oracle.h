@@ -265,6 +265,7 @@ typedef struct {
   int64_t nres, n_orfs, n_past_msv, n_past_bias, n_past_vit, n_past_fwd;
   int64_t pos_past_msv, pos_past_bias, pos_past_vit, pos_past_fwd;
   int64_t cells_msv, cells_vit, cells_fwd;
+  double  E;                                   /* reporting E-value threshold (p7_pipeline.c:147), 10.0 */
 } bo_pipeline;
 
 typedef struct {                 /* per-ORF cascade record (what the GPU path must reproduce) */
@@ -281,18 +282,45 @@ typedef struct {                 /* per DNA-window record of p7_pli_Frameshift (
   float   tot_orfsc, nullsc, filtersc, fwdsc;
   double  P_tot, P_min, P_fs, P_null;
   int32_t branch;                /* 1: frameshift branch (:1464), 2: standard branch (:1479) */
+  int32_t ndom;                  /* domains defined in this window (frameshift branch, when a 5-codon profile is given) */
 } bo_fswindow;
+
+/* ---- domain definition of the frameshift branch (fs_domaindef.c) ---- */
+enum { BO_T_S = 0, BO_T_N, BO_T_B, BO_T_M, BO_T_D, BO_T_I, BO_T_E, BO_T_J, BO_T_C, BO_T_T };   /* trace states */
+typedef struct { int N, nalloc; int8_t *st; int32_t *k, *i, *c; float *pp; } bo_trace;       /* P7_TRACE with codon lengths c[] */
+void bo_trace_init(bo_trace *t);
+void bo_trace_free(bo_trace *t);
+typedef struct {                 /* P7_DOMAIN fields the frameshift branch fills, then the hit's scores */
+  int32_t ienv, jenv, iali, jali;  /* nt coordinates: in the window while defining, on the sequence after post-processing */
+  int32_t ihmm, jhmm;
+  float   envsc, oasc, domcorrection;      /* nats, expected residues, nats */
+  float   dombias, bitscore, pre_score;    /* nats, bits, bits (p7_pipeline.c:1064-1108) */
+  double  lnP;
+  int32_t reported;                        /* passes E * Z <= E threshold (:1080) */
+  int32_t n_shifted_codons;                /* match states emitting a quasi-codon (length != 3) */
+} bo_fsdomain;
+void bo_gdomain_decoding_fs(const bo_fs_profile *gm5, const bo_gmx *fwd, const bo_gmx *bck, float *btot, float *etot, float *mocc); /* generic_decoding_frameshift.c:204 */
+int  bo_goatrace_fs(const bo_fs_profile *gm, const bo_gmx *pp, const bo_gmx *gx, bo_trace *tr);                                  /* generic_optacc_frameshift.c:373 */
+double bo_exp_logsurv(double x, double mu, double lambda);
 
 void bo_pipeline_init(bo_pipeline *pli, int fs_pipe);
 void  bo_local_compo(const bo_scoredata *sd, const bo_oprofile *om, const bo_bg *bg, int k_min, int k_max, float *compo); /* p7_pipeline.c:427 */
 /* frameshift stage for one strand (fs_pipeline.c); dsq[1..n] is the strand being read */
-int  bo_pli_frameshift(bo_pipeline *pli, bo_oprofile *om, bo_fs_profile *gm3, const bo_scoredata *sd, bo_bg *bg, const uint8_t basic[64],
+int  bo_pli_frameshift(bo_pipeline *pli, bo_oprofile *om, bo_fs_profile *gm3, bo_fs_profile *gm5, const bo_scoredata *sd, bo_bg *bg, const uint8_t basic[64],
                        const bo_orfblock *blk, const double *P_orf, const float *fwdsc, const bo_windowlist *hw,
-                       const uint8_t *dsq, int n, int complementarity, bo_fswindow **fw, int *nfw, int *fw_alloc);
+                       const uint8_t *dsq, int n, int complementarity, bo_fswindow **fw, int *nfw, int *fw_alloc,
+                       bo_fsdomain **doms, int *ndom, int *dom_alloc, int *nskipped);
+int  bo_domaindef_fs(bo_pipeline *pli, bo_fs_profile *gm3, bo_fs_profile *gm5, bo_bg *bg, const uint8_t *wdsq, int L,
+                     int window_start, int complementarity, int seq_n, bo_fsdomain **doms, int *ndom, int *dalloc, int *nskipped);
 /* bo_pipeline_window with the frameshift stage (pli->fs_pipe must be set; gm3 = 3-codon frameshift profile) */
 int  bo_pipeline_window_fs(bo_pipeline *pli, bo_oprofile *om, bo_fs_profile *gm3, const bo_scoredata *sd, bo_bg *bg,
                            const uint8_t basic[64], const uint8_t *dna, int n,
                            bo_orfresult **res, int *nres, int *res_alloc, bo_fswindow **fw, int *nfw, int *fw_alloc);
+/* ... and domain definition + hit scores for the windows that take the frameshift branch (gm5 = 5-codon profile) */
+int  bo_pipeline_window_fsdom(bo_pipeline *pli, bo_oprofile *om, bo_fs_profile *gm3, bo_fs_profile *gm5, const bo_scoredata *sd, bo_bg *bg,
+                              const uint8_t basic[64], const uint8_t *dna, int n,
+                              bo_orfresult **res, int *nres, int *res_alloc, bo_fswindow **fw, int *nfw, int *fw_alloc,
+                              bo_fsdomain **doms, int *ndom, int *dom_alloc, int *nskipped);
 /* run translate + cascade on both strands of one DNA window dsq[1..n]; results appended (realloc'd) */
 int  bo_pipeline_window(bo_pipeline *pli, bo_oprofile *om, const bo_scoredata *sd, bo_bg *bg,
                         const uint8_t basic[64], const uint8_t *dna, int n,

@@ -31,9 +31,10 @@ static void fsw_push(bo_fswindow **fw, int *nfw, int *alloc, const bo_fswindow *
 }
 
 /* dsq[1..n]: the strand being read (already reverse-complemented for complementarity = 1) */
-int bo_pli_frameshift(bo_pipeline *pli, bo_oprofile *om, bo_fs_profile *gm3, const bo_scoredata *sd, bo_bg *bg, const uint8_t basic[64],
+int bo_pli_frameshift(bo_pipeline *pli, bo_oprofile *om, bo_fs_profile *gm3, bo_fs_profile *gm5, const bo_scoredata *sd, bo_bg *bg, const uint8_t basic[64],
                       const bo_orfblock *blk, const double *P_orf, const float *fwdsc, const bo_windowlist *hw,
-                      const uint8_t *dsq, int n, int complementarity, bo_fswindow **fw, int *nfw, int *fw_alloc)
+                      const uint8_t *dsq, int n, int complementarity, bo_fswindow **fw, int *nfw, int *fw_alloc,
+                      bo_fsdomain **doms, int *ndom, int *dom_alloc, int *nskipped)
 {
   const int norf = blk->count;
   dwin *wl = malloc(sizeof(dwin) * (size_t)(norf + 1));
@@ -152,6 +153,11 @@ int bo_pli_frameshift(bo_pipeline *pli, bo_oprofile *om, bo_fs_profile *gm3, con
     if (P_fs <= pli->F3 && (P_null < P_tot || (P_null == P_tot && orf_cnt > 1) || P_min > pli->F3)) {   /* :1464 */
       r.branch = 1;
       pli->pos_past_fwd += L;
+      if (gm5 && doms) {                                      /* :1469-1476 */
+        const int before = *ndom;
+        bo_domaindef_fs(pli, gm3, gm5, bg, wdsq, L, (int) wl[w].n, complementarity, n, doms, ndom, dom_alloc, nskipped);
+        r.ndom = *ndom - before;
+      }
     } else {                                                  /* :1479 std_pipe */
       r.branch = 2;
       for (int i = 0; i < norf; i++) {

@@ -17,6 +17,7 @@ void bo_pipeline_init(bo_pipeline *pli, int fs_pipe)      /* p7_pipeline.c:219-2
 {
   memset(pli, 0, sizeof *pli);
   pli->F1 = 0.02; pli->F2 = 1e-3; pli->F3 = 1e-5; pli->F4 = 5e-4;
+  pli->E = 10.0;
   pli->do_biasfilter = 1;
   pli->fs_pipe = fs_pipe;
   pli->minlen = 20;
@@ -44,10 +45,11 @@ void bo_local_compo(const bo_scoredata *sd, const bo_oprofile *om, const bo_bg *
 }
 
 typedef struct {                 /* what the frameshift stage needs beyond the cascade (NULL gm3: no such stage) */
-  bo_fs_profile *gm3;
+  bo_fs_profile *gm3, *gm5;      /* gm5 NULL: stop at the branch decision */
   const uint8_t *basic, *dsq;    /* dsq[1..n]: the strand being read */
   int n;
   bo_fswindow **fw; int *nfw, *fw_alloc;
+  bo_fsdomain **doms; int *ndom, *dom_alloc, *nskipped;
 } fs_stage;
 
 static void strand_cascade(bo_pipeline *pli, bo_oprofile *om, const bo_scoredata *sd, bo_bg *bg,
@@ -163,7 +165,8 @@ static void strand_cascade(bo_pipeline *pli, bo_oprofile *om, const bo_scoredata
     if (!pli->fs_pipe) pli->pos_past_fwd += (int64_t) n * 3;  /* :1761; the fs branch counts later (:1468,1490) */
   }
   if (pli->fs_pipe && fs && fs->gm3)                            /* :1793 */
-    bo_pli_frameshift(pli, om, fs->gm3, sd, bg, fs->basic, blk, P_orf, fwd_null, &hw, fs->dsq, fs->n, strand, fs->fw, fs->nfw, fs->fw_alloc);
+    bo_pli_frameshift(pli, om, fs->gm3, fs->gm5, sd, bg, fs->basic, blk, P_orf, fwd_null, &hw, fs->dsq, fs->n, strand, fs->fw, fs->nfw, fs->fw_alloc,
+                      fs->doms, fs->ndom, fs->dom_alloc, fs->nskipped);
   free(P_orf); free(fwd_null);
   bo_windowlist_free(&hw);
 }
@@ -172,11 +175,19 @@ int bo_pipeline_window_fs(bo_pipeline *pli, bo_oprofile *om, bo_fs_profile *gm3,
                           const uint8_t basic[64], const uint8_t *dna, int n,
                           bo_orfresult **res, int *nres, int *res_alloc, bo_fswindow **fw, int *nfw, int *fw_alloc)
 {
+  return bo_pipeline_window_fsdom(pli, om, gm3, NULL, sd, bg, basic, dna, n, res, nres, res_alloc, fw, nfw, fw_alloc, NULL, NULL, NULL, NULL);
+}
+
+int bo_pipeline_window_fsdom(bo_pipeline *pli, bo_oprofile *om, bo_fs_profile *gm3, bo_fs_profile *gm5, const bo_scoredata *sd, bo_bg *bg,
+                             const uint8_t basic[64], const uint8_t *dna, int n,
+                             bo_orfresult **res, int *nres, int *res_alloc, bo_fswindow **fw, int *nfw, int *fw_alloc,
+                             bo_fsdomain **doms, int *ndom, int *dom_alloc, int *nskipped)
+{
   if (n < 15) return BO_OK;                                   /* bathsearch.c:1066, p7_pipeline.c:1605 */
   bo_orfblock blk;
   bo_orfblock_init(&blk);
   bo_bg_setfilter(bg, om->M, om->compo);                      /* p7_pli_NewModel, p7_pipeline.c:635 */
-  fs_stage fs = { gm3, basic, dna, n, fw, nfw, fw_alloc };
+  fs_stage fs = { gm3, gm5, basic, dna, n, fw, nfw, fw_alloc, doms, ndom, dom_alloc, nskipped };
 
   pli->nres += n;                                             /* top strand, bathsearch.c:1073 */
   bo_translate_orfs(dna, n, basic, pli->minlen, &blk);

@@ -28,3 +28,9 @@ double bo_exp_surv(double x, double mu, double lambda)
   if (x < mu) return 1.0;
   return exp(-lambda * (x - mu));
 }
+
+double bo_exp_logsurv(double x, double mu, double lambda)   /* easel esl_exp_logsurv */
+{
+  if (x < mu) return 0.0;
+  return -lambda * (x - mu);
+}

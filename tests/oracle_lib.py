@@ -99,7 +99,15 @@ class Pipeline(C.Structure):
                 ("n_past_vit", C.c_int64), ("n_past_fwd", C.c_int64),
                 ("pos_past_msv", C.c_int64), ("pos_past_bias", C.c_int64), ("pos_past_vit", C.c_int64),
                 ("pos_past_fwd", C.c_int64),
-                ("cells_msv", C.c_int64), ("cells_vit", C.c_int64), ("cells_fwd", C.c_int64)]
+                ("cells_msv", C.c_int64), ("cells_vit", C.c_int64), ("cells_fwd", C.c_int64), ("E", C.c_double)]
+
+
+class FsDomain(C.Structure):
+    """bo_fsdomain: a domain of the frameshift branch and its hit scores (oracle/fs_domaindef.c)."""
+    _fields_ = [("ienv", C.c_int32), ("jenv", C.c_int32), ("iali", C.c_int32), ("jali", C.c_int32), ("ihmm", C.c_int32), ("jhmm", C.c_int32),
+                ("envsc", C.c_float), ("oasc", C.c_float), ("domcorrection", C.c_float),
+                ("dombias", C.c_float), ("bitscore", C.c_float), ("pre_score", C.c_float),
+                ("lnP", C.c_double), ("reported", C.c_int32), ("n_shifted_codons", C.c_int32)]
 
 
 class OrfResult(C.Structure):
@@ -115,7 +123,7 @@ class FsWindow(C.Structure):
                 ("orf_cnt", C.c_int32), ("k_min", C.c_int32), ("k_max", C.c_int32),
                 ("tot_orfsc", C.c_float), ("nullsc", C.c_float), ("filtersc", C.c_float), ("fwdsc", C.c_float),
                 ("P_tot", C.c_double), ("P_min", C.c_double), ("P_fs", C.c_double), ("P_null", C.c_double),
-                ("branch", C.c_int32)]
+                ("branch", C.c_int32), ("ndom", C.c_int32)]
 
 
 _lib = None
@@ -179,6 +187,10 @@ def lib():
     L.bo_pipeline_window_fs.argtypes = [C.POINTER(Pipeline), C.POINTER(OProfile), C.POINTER(FsProfile), C.POINTER(ScoreData), C.POINTER(Bg),
                                         u8p, u8p, C.c_int, C.POINTER(C.POINTER(OrfResult)), C.POINTER(C.c_int), C.POINTER(C.c_int),
                                         C.POINTER(C.POINTER(FsWindow)), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.bo_pipeline_window_fsdom.argtypes = [C.POINTER(Pipeline), C.POINTER(OProfile), C.POINTER(FsProfile), C.POINTER(FsProfile), C.POINTER(ScoreData),
+                                           C.POINTER(Bg), u8p, u8p, C.c_int, C.POINTER(C.POINTER(OrfResult)), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                           C.POINTER(C.POINTER(FsWindow)), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                           C.POINTER(C.POINTER(FsDomain)), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.bo_pipeline_window.argtypes = [C.POINTER(Pipeline), C.POINTER(OProfile), C.POINTER(ScoreData), C.POINTER(Bg),
                                      u8p, u8p, C.c_int, C.POINTER(C.POINTER(OrfResult)), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     if hasattr(L, "bo_gmx_create"):
@@ -297,6 +309,28 @@ class Model:
             per_seq.append((before, nres.value))
         out = [res[i] for i in range(nres.value)]
         return pli, out, per_seq
+
+    def run_pipeline_fsdom(self, seqs):
+        """run_pipeline_fs plus domain definition and hit scores for the windows that take the frameshift branch.
+
+        Returns (Pipeline counters, FsWindow records, per-sequence window ranges, FsDomain records, per-sequence domain
+        ranges, number of multi-domain regions skipped)."""
+        L_ = lib()
+        pli = Pipeline()
+        L_.bo_pipeline_init(C.byref(pli), 1)
+        gm3, gm5 = self.fs(3), self.fs(5)
+        res = C.POINTER(OrfResult)(); nres, alloc = C.c_int(0), C.c_int(0)
+        fw = C.POINTER(FsWindow)(); nfw, fwalloc = C.c_int(0), C.c_int(0)
+        dm = C.POINTER(FsDomain)(); ndm, dmalloc, nskip = C.c_int(0), C.c_int(0), C.c_int(0)
+        per_w, per_d = [], []
+        for codes in seqs:
+            d = dsq_from(codes)
+            w0, d0 = nfw.value, ndm.value
+            L_.bo_pipeline_window_fsdom(C.byref(pli), self.om, gm3, gm5, self.sd, C.byref(self.bg), u8(self.basic), u8(d), len(codes),
+                                        C.byref(res), C.byref(nres), C.byref(alloc), C.byref(fw), C.byref(nfw), C.byref(fwalloc),
+                                        C.byref(dm), C.byref(ndm), C.byref(dmalloc), C.byref(nskip))
+            per_w.append((w0, nfw.value)); per_d.append((d0, ndm.value))
+        return pli, [fw[i] for i in range(nfw.value)], per_w, [dm[i] for i in range(ndm.value)], per_d, nskip.value
 
     def run_pipeline_fs(self, seqs):
         """The cascade with fs_pipe set plus the frameshift stage (oracle/fs_pipeline.c) on every window.

@@ -113,3 +113,59 @@ def test_planted_frameshifted_genes(gpu_ctx, name):
     n = compare(model, stats, fw, pli, ofw, per_seq_w)
     assert n >= 20 and any(w.branch == 1 for w in fw) and any(w.branch == 2 for w in fw)
     assert any(w.strand == 1 for w in fw) and any(w.orf_cnt > 1 for w in fw)
+
+
+def compare_domains(model, gdm, odm, per_d):
+    want = []
+    for w, (a, b) in enumerate(per_d):
+        want += [(w, o) for o in odm[a:b]]
+    got = sorted(gdm, key=lambda g: (g.window, g.strand, g.ienv))
+    want.sort(key=lambda t: (t[0], t[1].ienv))
+    assert len(got) == len(want)
+    for g, (w, o) in zip(got, want):
+        assert g.window == w
+        assert (g.ienv, g.jenv, g.iali, g.jali, g.ihmm, g.jhmm, g.n_shifted_codons) == (o.ienv, o.jenv, o.iali, o.jali, o.ihmm, o.jhmm, o.n_shifted_codons)
+        assert abs(g.envsc - o.envsc) <= 5e-3 + 1e-4 * abs(o.envsc)                  # table log-sum association, as test_frameshift_gpu.py
+        assert abs(g.oasc - o.oasc) <= 2e-2 + 1e-3 * abs(o.oasc)
+        assert abs(g.domcorrection - o.domcorrection) <= 2e-2 + 5e-3 * abs(o.domcorrection)
+        assert abs(g.bitscore - o.bitscore) <= 0.05 and abs(g.pre_score - o.pre_score) <= 0.05     # bits
+        assert abs(g.lnP - o.lnP) <= 0.05 * model.om.contents.evparam[5] + 1e-6
+    return len(got)
+
+
+def test_recorded_fs_hit_on_gpu(gpu_ctx):
+    """tutorial/AMP_N-fs.tbl: score 82.8, bias 0.1, hmm 1..131, ali 1..402, 6 shifted codons -- from the GPU path."""
+    path = ol.GOLDEN + "/AMP_N.bhmm"
+    seqs = [ba.digitize(s, ba.DNA_SYMS) for _, s in ol.read_fasta(ol.GOLDEN + "/target-AMP_N.fa")]
+    hmm = ba.HMM(path, 0)
+    om = ba.OProfile(gpu_ctx, ba.Profile(hmm))
+    om3 = ba.FSOProfile(gpu_ctx, ba.FSProfile(hmm, 3, ncbi_table=hmm.ct))
+    om5 = ba.FSOProfile(gpu_ctx, ba.FSProfile(hmm, 5, ncbi_table=hmm.ct))
+    pipe = ba.Pipeline(gpu_ctx, om, fs_pipe=True, ncbi_table=hmm.ct)
+    stats, fw, dm, nskip = pipe.run_frameshift_domains(om3, om5, ba.SeqBlock(gpu_ctx, seqs))
+    assert len(fw) == 1 and len(dm) == 1 and nskip == 0
+    d = dm[0]
+    assert (d.ihmm, d.jhmm, d.iali, d.jali, d.reported, d.n_shifted_codons) == (1, 131, 1, 402, 1, 6)
+    assert "%.1f" % d.bitscore == "82.8" and "%.1f" % (d.dombias / np.log(2.0)) == "0.1"
+    model = ol.Model(path, 0)
+    _, _, _, odm, per_d, _ = model.run_pipeline_fsdom(seqs)
+    compare_domains(model, dm, odm, per_d)
+
+
+@pytest.mark.parametrize("name", ["2OG-FeII_Oxy_3.bhmm", "PTH2.bhmm"])
+def test_domains_of_planted_frameshifted_genes(gpu_ctx, name):
+    rng = np.random.default_rng(41)
+    path = ol.GOLDEN + "/" + name
+    model = ol.Model(path, 0)
+    wins = frameshifted_windows(rng, model, n=24)
+    hmm = ba.HMM(path, 0)
+    om = ba.OProfile(gpu_ctx, ba.Profile(hmm))
+    om3 = ba.FSOProfile(gpu_ctx, ba.FSProfile(hmm, 3, ncbi_table=hmm.ct))
+    om5 = ba.FSOProfile(gpu_ctx, ba.FSProfile(hmm, 5, ncbi_table=hmm.ct))
+    pipe = ba.Pipeline(gpu_ctx, om, fs_pipe=True, ncbi_table=hmm.ct)
+    stats, fw, dm, nskip = pipe.run_frameshift_domains(om3, om5, ba.SeqBlock(gpu_ctx, wins))
+    _, ofw, per_w, odm, per_d, oskip = model.run_pipeline_fsdom(wins)
+    assert sorted((w.window, w.strand, w.n, w.branch) for w in fw) == sorted((i, o.strand, o.n, o.branch) for i, (a, b) in enumerate(per_w) for o in ofw[a:b])
+    assert nskip == oskip
+    n = compare_domains(model, dm, odm, per_d)
+    assert n >= 3 and any(d.n_shifted_codons > 0 for d in dm) and any(d.strand == 1 for d in dm)

@@ -175,3 +175,26 @@ def test_frameshift_stage_separates_shifted_from_unshifted_targets():
     assert all(w.branch == 1 for w in fw_shift if w.orf_cnt > 1) and sum(w.orf_cnt > 1 for w in fw_shift) >= 3
     for w in fw_plain + fw_shift:                       # every window covers its whole (short) target
         assert w.n == 1 and w.P_fs < 1e-20
+
+
+def test_frameshift_hit_matches_recorded_run():
+    """tutorial/AMP_N-fs.out / .tbl: the one hit of the recorded `bathsearch --fs` run.
+
+        score 82.8  bias 0.1  hmm 1..131  ali 1..402  shifts 6  E-value 1.9e-27
+
+    This goes through every frameshift recursion of the path: 3-codon Forward/Backward parsers, domain decoding, region
+    heuristics, 5-codon Forward/Backward, posterior decoding, optimal-accuracy fill and traceback, null2, and the score
+    corrections of p7_pli_postDomainDef_Frameshift_BATH.  The E-value is exp(lnP) * Z with the residue count the
+    reference reports hits against (822/3 amino-acid positions over max_length 167)."""
+    tbl = open(ol.GOLDEN + "/AMP_N-fs.tbl").read().splitlines()[2].split()
+    assert tbl[6:8] == ["1", "131"] and tbl[9:11] == ["1", "402"] and tbl[11:14] == ["1.9e-27", "82.8", "0.1"] and tbl[15] == "6"
+    m = ol.Model(ol.GOLDEN + "/AMP_N.bhmm", 0)
+    seqs = [ol.digitize_dna(s) for _, s in ol.read_fasta(ol.GOLDEN + "/target-AMP_N.fa")]
+    pli, fw, _, dm, _, nskip = m.run_pipeline_fsdom(seqs)
+    assert len(fw) == 1 and fw[0].branch == 1 and fw[0].ndom == 1 and len(dm) == 1 and nskip == 0
+    d = dm[0]
+    assert (d.ihmm, d.jhmm, d.iali, d.jali, d.reported, d.n_shifted_codons) == (1, 131, 1, 402, 1, 6)
+    assert "%.1f" % d.bitscore == "82.8"
+    assert "%.1f" % (d.dombias / np.log(2.0)) == "0.1"
+    evalue = np.exp(d.lnP) * (822 / 3.0) / m.om.contents.max_length
+    assert "%.1e" % evalue in ("1.9e-27", "1.8e-27", "2.0e-27")
