@@ -146,6 +146,10 @@ struct bath_hip_oprofile {
   int vit_NR = 0, vit_rw_pitch = 0;
   int16_t *d_vit_rw = nullptr; uint32_t *d_vit_tw2 = nullptr; int32_t *d_vit_tdd = nullptr; int16_t *d_vit_rank = nullptr;
   mutable LenTables lt;
+  // SSV emission thresholds per ORF length for the pipeline (bath_pipeline.hip: build_emit_table), cached per F1
+  mutable int16_t *d_emit = nullptr;
+  mutable double emit_F1 = -1.0;
+  mutable int emit_maxlen = -1;
   int ensure_len_tables(int maxL) const;
 };
 

@@ -418,17 +418,32 @@ static void build_emit_table(const bath_hip_oprofile *om, double F1, int maxlen,
   for (int len = 0; len <= maxlen; len++) {
     const int tjb = om->lt.h_tjb[len];
     const float nullsc = om->lt.h_nullsc[len];
-    for (int v = -128; v <= 127; v++) {
+    auto keep = [&](int v) {
       float usc = 0.f;
-      const int st = ssv_classify_host(v, tjb, mc, &usc);
-      bool keep = (st != BATH_OK);
-      if (!keep) {
-        const float seqsc = (float)((double)(usc - nullsc) / kLog2);
-        keep = !(gumbel_surv(seqsc, om->evparam[0], om->evparam[1]) > F1);
-      }
-      if (keep) { tab[len] = (int16_t)v; break; }
-    }
+      if (ssv_classify_host(v, tjb, mc, &usc) != BATH_OK) return true;
+      const float seqsc = (float)((double)(usc - nullsc) / kLog2);
+      return !(gumbel_surv(seqsc, om->evparam[0], om->evparam[1]) > F1);
+    };
+    // keep(v) is monotone in v (the score grows with v, and beyond the representable range the filter reports
+    // overflow / "J state possible", which is kept too): smallest v with keep(v) by bisection over -128..127
+    if (!keep(127)) continue;
+    int lo = -128, hi = 127;
+    while (lo < hi) { const int mid = lo + (hi - lo) / 2; if (keep(mid)) hi = mid; else lo = mid + 1; }
+    tab[(size_t)len] = (int16_t)lo;
   }
+}
+
+// The table depends on the model, F1 and the longest ORF only: kept with the profile (host and device) between calls.
+static int ensure_emit_table(bath_hip_ctx *ctx, const bath_hip_oprofile *om, double F1, int maxlen) {
+  if (om->emit_F1 == F1 && om->emit_maxlen >= maxlen && om->d_emit) return BATH_OK;
+  std::vector<int16_t> tab;
+  build_emit_table(om, F1, maxlen, tab);
+  if (om->d_emit) (void)hipFree(om->d_emit);
+  om->d_emit = nullptr;
+  BATH_HIP_TRY(ctx, hipMalloc((void **)&om->d_emit, tab.size() * sizeof(int16_t) + 64));
+  BATH_HIP_TRY(ctx, hipMemcpy(om->d_emit, tab.data(), tab.size() * sizeof(int16_t), hipMemcpyHostToDevice));
+  om->emit_F1 = F1; om->emit_maxlen = maxlen;
+  return BATH_OK;
 }
 
 static int wave_grid_blocks(bath_hip_ctx *ctx) { return ctx->prop.multiProcessorCount * 8; }
@@ -512,19 +527,17 @@ static int run_filters(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bat
   // ---- per-call tables
   OrfTablesDev tt{};
   if ((st = orf_tables_upload(ctx, prm->ncbi_table, &tt)) != BATH_OK) return st;
-  std::vector<int16_t> emit;
-  build_emit_table(om, prm->F1, max_orf, emit);
+  if ((st = ensure_emit_table(ctx, om, prm->F1, max_orf)) != BATH_OK) return st;
   std::vector<uint8_t> ssv_scores((size_t)(M + 1) * kKp, 0);
   bath_hip_oprofile_get_ssv_scores(om, ssv_scores.data());
 
   DevBuf &b_tabs = ctx->scratch[8], &b_work = ctx->scratch[9];
-  const size_t tabs_bytes = 8192 + emit.size() * 2 + 256 + ssv_scores.size() + 256 + 20 * 4 + 256;
+  const size_t tabs_bytes = 8192 + ssv_scores.size() + 256 + 20 * 4 + 256;
   BATH_HIP_TRY(ctx, b_tabs.reserve(tabs_bytes));
   char *tp = b_tabs.as<char>();
-  int16_t *d_emit = reinterpret_cast<int16_t *>(tp); tp += (emit.size() * 2 + 255) / 256 * 256;
+  const int16_t *d_emit = om->d_emit;
   uint8_t *d_ssvsc = reinterpret_cast<uint8_t *>(tp); tp += (ssv_scores.size() + 255) / 256 * 256;
   float *d_bgf = reinterpret_cast<float *>(tp);
-  BATH_HIP_TRY(ctx, hipMemcpyAsync(d_emit, emit.data(), emit.size() * 2, hipMemcpyHostToDevice, ctx->stream));
   BATH_HIP_TRY(ctx, hipMemcpyAsync(d_ssvsc, ssv_scores.data(), ssv_scores.size(), hipMemcpyHostToDevice, ctx->stream));
   BATH_HIP_TRY(ctx, hipMemcpyAsync(d_bgf, kAminoBg, 20 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
   BATH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // the host vectors above go out of scope with this call only, but be explicit
@@ -778,8 +791,9 @@ extern "C" int bath_hip_pipeline_filters(bath_hip_ctx *ctx, const bath_hip_oprof
   if (K <= 1) return run_filters(ctx, om, dna, prm, stats, results, n_results, nullptr);
 
   BATH_HIP_TRY(ctx, hipSetDevice(ctx->device));
-  int st = om->ensure_len_tables(dna->maxlen / 3 + 1);            // the only mutable state of the profile: fill it before the threads start
+  int st = om->ensure_len_tables(dna->maxlen / 3 + 1);            // the mutable state of the profile: fill it before the threads start
   if (st != BATH_OK) return st;
+  if ((st = ensure_emit_table(ctx, om, prm->F1, dna->maxlen / 3 + 1)) != BATH_OK) return st;
   while ((int)ctx->lanes.size() < K) {
     bath_hip_ctx *lane = nullptr;
     if ((st = bath_hip_init(ctx->device, &lane)) != BATH_OK) { ctx->set_error("cannot create a pipeline lane"); return st; }

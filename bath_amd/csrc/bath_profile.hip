@@ -145,7 +145,7 @@ extern "C" void *bath_hip_stream(bath_hip_ctx *ctx) { return (void *)ctx->stream
 
 extern "C" void bath_hip_oprofile_destroy(bath_hip_oprofile *om) {
   if (!om) return;
-  for (void *p : {(void *)om->d_ssv, (void *)om->d_rb, (void *)om->d_rw, (void *)om->d_tw, (void *)om->d_rf, (void *)om->d_tf,
+  for (void *p : {(void *)om->d_emit, (void *)om->d_ssv, (void *)om->d_rb, (void *)om->d_rw, (void *)om->d_tw, (void *)om->d_rf, (void *)om->d_tf,
                   (void *)om->d_bias_eo, (void *)om->d_vit_rw, (void *)om->d_vit_tw2, (void *)om->d_vit_tdd, (void *)om->d_vit_rank, (void *)om->lt.d_tjb, (void *)om->lt.d_xwmove, (void *)om->lt.d_pmove,
                   (void *)om->lt.d_nullsc, (void *)om->lt.d_lt1, (void *)om->lt.d_lt2, (void *)om->lt.d_p1})
     if (p) (void)hipFree(p);
