@@ -39,6 +39,7 @@ struct bath_hip_fsprofile {
   float *d_logsum = nullptr;     // [16000]
   std::vector<float> h_tsc;      // [M*8] generic log transitions (OA traceback deltas on the host)
   std::vector<uint8_t> h_codons; // [(M+1)*maxcodons] best amino acid per (node, quasi-codon) (null2 along a trace)
+  uint8_t *d_codons = nullptr;   // the same on the device (5-codon profiles)
   // length model: xsc[N|C|J][LOOP|MOVE] for L_amino, multihit (nj=1) and unihit (nj=0); host libm log()
   mutable int maxL = -1;
   mutable float *d_loop[2] = {nullptr, nullptr}, *d_move[2] = {nullptr, nullptr};
@@ -722,6 +723,142 @@ __global__ __launch_bounds__(256) void fs5_oa_kernel(SeqView dna, int M, const f
 // null2 (generic_null2_frameshift.c:70-125) from the column sums: 20 lanes, each runs the reference's serial
 // log-sum over the model for one residue, so the association is the reference's.
 // ---------------------------------------------------------------------------------------------
+// p7_OATrace_Frameshift (generic form: generic_optacc_frameshift.c:373-588) and the null2 score of the aligned residues
+// (rescore_isolated_domain_frameshift, p7_domaindef.c:1086-1147), one LANE per envelope: the walk is serial (at most L+M
+// steps of a few dependent loads), envelopes are independent, and doing it here means the posterior and OA matrices
+// (>1 MB per envelope) never leave the device.  The trace is written backwards into <tbuf> and read forwards again.
+__global__ void fs5_trace_kernel(SeqView dna, int M, int maxcodons, const float *__restrict__ tf, const uint8_t *__restrict__ codons,
+                                 const float *__restrict__ pp, const int64_t *__restrict__ pp_off, const float *__restrict__ px, const int64_t *__restrict__ x_off,
+                                 const float *__restrict__ oa, const int64_t *__restrict__ oa_off, const float *__restrict__ ox,
+                                 const float *__restrict__ null2 /* [n][Kp] */, uint2 *__restrict__ tbuf, const int64_t *__restrict__ t_off, FsTraceOut *__restrict__ out) {
+  const int64_t job = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (job >= dna.n) return;
+  enum { sS = 0, sN, sB, sM, sD, sI, sE, sJ, sC, sT };
+  enum { XE = 0, XN, XJ, XB, XC };
+  const float kTiny = 1.17549435e-38f;                          // FLT_MIN: TSCDELTA of an impossible transition
+  const int L = dna.len[job];
+  const uint8_t *dsq = dna.data + dna.off[job] - 1;             // dsq[1..L]
+  const float *P = pp + pp_off[job], *PX = px + x_off[job], *O = oa + oa_off[job], *OX = ox + x_off[job];
+  uint2 *T = tbuf + t_off[job];
+  const int cap = (int)(t_off[job + 1] - t_off[job]);
+  FsTraceOut r{0, 0, 0, 0, 0, 0, 0.f};
+  auto dl = [&](int node, int s) { return (node >= 1 && node <= M && tf[(size_t)node * 8 + s] != -INFINITY) ? 1.0f : kTiny; };
+  auto OM = [&](int i, int k) { return O[((size_t)i * (M + 1) + k) * 3 + 2]; };
+  auto OI = [&](int i, int k) { return O[((size_t)i * (M + 1) + k) * 3 + 1]; };
+  auto OD = [&](int i, int k) { return O[((size_t)i * (M + 1) + k) * 3 + 0]; };
+  int n = 0;
+  auto push = [&](int st, int k, int i, int c) { if (n < cap) T[n] = make_uint2((unsigned)st | ((unsigned)c << 8) | ((unsigned)k << 16), (unsigned)i); n++; };
+  int i = L, k = 0, c = 0, prev = sC;
+  bool bad = (L < 5);
+  push(sT, k, i, c); push(sC, k, i, c);
+  while (!bad && prev != sS) {
+    int cur = -1;
+    switch (prev) {
+    case sM: {          // transitions into node k: MM, IM, DM, BM are tf[k][0..3]
+      const float p0 = dl(k, 0) * OM(i, k - 1), p1 = dl(k, 1) * OI(i, k - 1), p2 = dl(k, 2) * OD(i, k - 1), p3 = dl(k, 3) * OX[(size_t)i * 5 + XB];
+      cur = sM; float b = p0;
+      if (p1 > b) { b = p1; cur = sI; }
+      if (p2 > b) { b = p2; cur = sD; }
+      if (p3 > b) { b = p3; cur = sB; }
+      k--; break; }
+    case sD: {          // transitions leaving node k-1: MD, DD are tf[k-1][4..5]
+      const float p0 = dl(k - 1, 4) * OM(i, k - 1), p1 = dl(k - 1, 5) * OD(i, k - 1);
+      cur = p0 >= p1 ? sM : sD; k--; break; }
+    case sI: {          // MI, II of node k: tf[k][6..7]
+      const float p0 = dl(k, 6) * OM(i - 3, k), p1 = dl(k, 7) * OI(i - 3, k);
+      cur = p0 >= p1 ? sM : sI; i -= 3; break; }
+    case sN: cur = (i == 0) ? sS : sN; break;
+    case sC: {
+      if (i < 4) { cur = sE; break; }
+      const float p0 = OX[(size_t)(i - 3) * 5 + XC] + PX[(size_t)i * 5 + XC];
+      const float p1 = (i < L) ? OX[(size_t)(i - 2) * 5 + XC] + PX[(size_t)(i + 1) * 5 + XC] : kTiny;
+      const float p2 = (i < L - 1) ? OX[(size_t)(i - 1) * 5 + XC] + PX[(size_t)(i + 2) * 5 + XC] : kTiny;
+      const float p3 = OX[(size_t)i * 5 + XE];
+      cur = sC; float b = p0;
+      if (p1 > b) b = p1;
+      if (p2 > b) b = p2;
+      if (p3 > b) { b = p3; cur = sE; }
+      break; }
+    case sJ: {
+      if (i <= 5) { cur = sE; break; }
+      const float p0 = OX[(size_t)i * 5 + XJ] + PX[(size_t)i * 5 + XJ], p1 = kTiny * OX[(size_t)i * 5 + XE];      // unihit: E->J impossible
+      cur = (p1 > p0) ? sE : sJ; break; }
+    case sE: {
+      float mx = -INFINITY; int smax = -1, kmax = -1;
+      for (int q = 1; q <= M; q++) {
+        const float m = OM(i, q), d = OD(i, q);
+        if (m > mx) { mx = m; smax = sM; kmax = q; }
+        if (d > mx) { mx = d; smax = sD; kmax = q; }
+      }
+      k = kmax; cur = smax; break; }
+    case sB: cur = (OX[(size_t)i * 5 + XN] > OX[(size_t)i * 5 + XJ]) ? sN : sJ; break;
+    default: bad = true; break;
+    }
+    if (bad || cur < 0 || k < 0 || i < 0) { bad = true; break; }
+    if (cur == sM) {
+      const float *cell = P + ((size_t)i * (M + 1) + k) * 8;
+      c = 1; float b = cell[3];
+#pragma unroll
+      for (int q = 1; q < 5; q++) if (cell[3 + q] > b) { b = cell[3 + q]; c = q + 1; }
+    } else c = 0;
+    push(cur, k, i, c);
+    if ((cur == sN || cur == sC || cur == sJ) && cur == prev) i--;
+    prev = cur;
+    i -= c;
+    if (n > cap) bad = true;
+  }
+  if (!bad) {
+    // forward order = T[n-1] .. T[0]
+    const float *n2 = null2 + (size_t)job * kKp;
+    auto st_of = [&](int z) { return (int)(T[n - 1 - z].x & 0xffu); };
+    auto c_of = [&](int z) { return (int)((T[n - 1 - z].x >> 8) & 0xffu); };
+    auto k_of = [&](int z) { return (int)(T[n - 1 - z].x >> 16); };
+    auto i_of = [&](int z) { return (int)T[n - 1 - z].y; };
+    int z1 = 0, z2 = n - 1;
+    while (z1 < n && st_of(z1) != sM) z1++;
+    while (z2 >= 0 && st_of(z2) != sM) z2--;
+    if (z1 < n && z2 >= 0) {
+      r.ok = 1;
+      r.ihmm = k_of(z1); r.jhmm = k_of(z2);
+      r.iali = i_of(z1) - (c_of(z1) - 1); r.jali = i_of(z2);
+      float corr = 0.f;
+      int t = -1, u = -1, v = -1, w = -1, x = -1, pos = 1, z = 0;
+      while (pos <= L && z < n) {
+        x = dsq[pos] < 4 ? (int)dsq[pos] : 1367;
+        const int s = st_of(z);
+        if (s == sN || s == sC || s == sJ) { if (i_of(z) == pos && pos > 2) pos++; z++; }
+        else if (s == sM) {
+          if (i_of(z) == pos) {
+            int ci, capi;
+            switch (c_of(z)) {
+            case 1: ci = x * 341; capi = 1366; break;
+            case 2: ci = x * 341 + w * 85 + 1; capi = 1365; break;
+            case 3: ci = x * 341 + w * 85 + v * 21 + 2; capi = 1364; break;
+            case 4: ci = x * 341 + w * 85 + v * 21 + u * 5 + 3; capi = 1365; break;
+            default: ci = x * 341 + w * 85 + v * 21 + u * 5 + t + 4; capi = 1366; break;
+            }
+            if (c_of(z) != 3) r.nshift++;
+            const float sc = logf(n2[codons[(size_t)k_of(z) * maxcodons + min(ci, capi)]]);
+            if (sc != -INFINITY) corr += sc;
+            z++;
+          }
+          pos++;
+        } else if (s == sI) {
+          if (i_of(z) == pos) {
+            const float sc = logf(n2[codons[(size_t)k_of(z) * maxcodons + min(x * 341 + w * 85 + v * 21 + 2, 1364)]]);
+            if (sc != -INFINITY) corr += sc;
+            z++;
+          }
+          pos++;
+        } else z++;
+        t = u; u = v; v = w; w = x;
+      }
+      r.domcorrection = corr;
+    }
+  }
+  out[job] = r;
+}
+
 __global__ void fs5_null2_kernel(int64_t n, const int32_t *__restrict__ len, int M, int pitch, const float *__restrict__ amino /* rsc + maxcodons*pitch */,
                                  const float *__restrict__ logsum, const float *__restrict__ colsum, float *__restrict__ null2 /* [n][Kp] */) {
   const int64_t job = blockIdx.x;
@@ -793,7 +930,7 @@ int bath_hip_fsprofile::ensure_len(int maxL_amino) const {
 
 extern "C" void bath_hip_fsprofile_destroy(bath_hip_fsprofile *om) {
   if (!om) return;
-  for (void *p : {(void *)om->d_rsc, (void *)om->d_tf, (void *)om->d_tb, (void *)om->d_logsum, (void *)om->d_loop[0], (void *)om->d_loop[1],
+  for (void *p : {(void *)om->d_codons, (void *)om->d_rsc, (void *)om->d_tf, (void *)om->d_tb, (void *)om->d_logsum, (void *)om->d_loop[0], (void *)om->d_loop[1],
                   (void *)om->d_move[0], (void *)om->d_move[1]})
     if (p) (void)hipFree(p);
   delete om;
@@ -808,7 +945,11 @@ extern "C" int bath_hip_fsprofile_convert(bath_hip_ctx *ctx, const bath_fs_profi
   om->fsprob = gm->fsprob;
   std::memcpy(om->evparam, gm->evparam, sizeof om->evparam);
   om->h_tsc.assign(gm->tsc, gm->tsc + (size_t)M * 8);
-  if (gm->codons) om->h_codons.assign(gm->codons, gm->codons + (size_t)(M + 1) * gm->maxcodons);
+  if (gm->codons) {
+    om->h_codons.assign(gm->codons, gm->codons + (size_t)(M + 1) * gm->maxcodons);
+    BATH_HIP_TRY(ctx, hipMalloc((void **)&om->d_codons, om->h_codons.size() + 64));
+    BATH_HIP_TRY(ctx, hipMemcpy(om->d_codons, om->h_codons.data(), om->h_codons.size(), hipMemcpyHostToDevice));
+  }
   om->pitch = (M + 1 + 3) / 4 * 4;
   const int nrows = gm->maxcodons + kKp;
   std::vector<float> rsc((size_t)nrows * om->pitch, -INFINITY);
@@ -945,8 +1086,6 @@ extern "C" int bath_hip_fs3_backward_parser(bath_hip_ctx *ctx, const bath_hip_fs
 }
 
 namespace bath {
-int fs5_envelopes_ex(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, const bath_hip_seqs *dna, int logsum_mode, int c5_compat,
-                     bath_fs5_result *res, float *pp, float *oa, float *ppx, float *oax);
 const FsHostTables fsprofile_host(const bath_hip_fsprofile *om) {
   return FsHostTables{om->M, om->max_length, om->maxcodons, om->h_tsc.data(), om->h_codons.empty() ? nullptr : om->h_codons.data(), om->evparam};
 }
@@ -955,13 +1094,13 @@ const FsHostTables fsprofile_host(const bath_hip_fsprofile *om) {
 extern "C" int bath_hip_fs5_envelopes(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, const bath_hip_seqs *dna, int logsum_mode, int c5_compat,
                                       bath_fs5_result *res, float *pp, const int64_t *pp_off_h, float *oa, const int64_t *oa_off_h) {
   (void)pp_off_h; (void)oa_off_h;
-  return bath::fs5_envelopes_ex(ctx, om, dna, logsum_mode, c5_compat, res, pp, oa, nullptr, nullptr);
+  return bath::fs5_envelopes_ex(ctx, om, dna, logsum_mode, c5_compat, res, pp, oa, nullptr, nullptr, nullptr);
 }
 
 // Envelope rescoring; layouts per envelope i, rows = L_i+1: pp rows*(M+1)*8, oa rows*(M+1)*3, ppx / oax rows*5
 // {E,N,J,B,C} (posterior and OA special-state rows), each packed back to back in envelope order.
 int bath::fs5_envelopes_ex(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, const bath_hip_seqs *dna, int logsum_mode, int c5_compat,
-                           bath_fs5_result *res, float *pp, float *oa, float *ppx, float *oax) {
+                           bath_fs5_result *res, float *pp, float *oa, float *ppx, float *oax, FsTraceOut *trace) {
   if (!ctx || !om || !dna || om->codon_lengths != 5) { if (ctx) ctx->set_error("fs5 envelopes need a 5-codon profile"); return BATH_EINVAL; }
   BATH_HIP_TRY(ctx, hipSetDevice(ctx->device));
   const int64_t n = dna->n;
@@ -977,7 +1116,7 @@ int bath::fs5_envelopes_ex(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, cons
   }
   DevBuf &b_f = ctx->scratch[15], &b_b = ctx->scratch[16], &b_o = ctx->scratch[17], &b_fx = ctx->scratch[18], &b_bx = ctx->scratch[19];
   DevBuf &b_off = ctx->scratch[20], &b_sc = ctx->scratch[21], &b_cs = ctx->scratch[22], &b_n2 = ctx->scratch[23], &b_ox = ctx->scratch[11];
-  if (oax) BATH_HIP_TRY(ctx, b_ox.reserve((size_t)xoff[n] * 4 + 64));
+  if (oax || trace) BATH_HIP_TRY(ctx, b_ox.reserve((size_t)xoff[n] * 4 + 64));
   BATH_HIP_TRY(ctx, b_f.reserve((size_t)foff[n] * 4 + 64)); BATH_HIP_TRY(ctx, b_b.reserve((size_t)boff[n] * 4 + 64)); BATH_HIP_TRY(ctx, b_o.reserve((size_t)boff[n] * 4 + 64));
   BATH_HIP_TRY(ctx, b_fx.reserve((size_t)xoff[n] * 4 + 64)); BATH_HIP_TRY(ctx, b_bx.reserve((size_t)xoff[n] * 4 + 64));
   BATH_HIP_TRY(ctx, b_off.reserve((size_t)(n + 1) * 3 * sizeof(int64_t)));
@@ -1013,11 +1152,27 @@ int bath::fs5_envelopes_ex(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, cons
                        b_b.as<float>(), d_boff, b_bx.as<float>(), b_cs.as<float>());
     if ((st = fs_set_shmem(ctx, fs5_oa_kernel<CC>, oa_shmem)) != BATH_OK) return st;
     hipLaunchKernelGGL((fs5_oa_kernel<CC>), dim3(grid), dim3(256), oa_shmem, ctx->stream, dna->view(), M, om->d_tf, b_f.as<float>(), d_foff, b_fx.as<float>(), d_xoff, b_o.as<float>(), d_boff, d_osc,
-                       1.17549435e-38f /* E->J impossible in unihit mode: TSCDELTA = FLT_MIN */, 1.0f, oax ? b_ox.as<float>() : nullptr);
+                       1.17549435e-38f /* E->J impossible in unihit mode: TSCDELTA = FLT_MIN */, 1.0f, (oax || trace) ? b_ox.as<float>() : nullptr);
   })
   hipLaunchKernelGGL(fs5_null2_kernel, dim3((unsigned)n), dim3(32), 0, ctx->stream, n, dna->d_len, M, om->pitch, om->d_rsc + (size_t)om->maxcodons * om->pitch, om->d_logsum,
                      b_cs.as<float>(), b_n2.as<float>());
   BATH_HIP_TRY(ctx, hipGetLastError());
+  if (trace) {                                                  // optimal-accuracy traceback + null2 along the trace, on the device
+    if (!om->d_codons) { ctx->set_error("traceback needs the profile's codon table"); return BATH_EINVAL; }
+    std::vector<int64_t> toff((size_t)n + 1, 0);
+    for (int64_t i = 0; i < n; i++) toff[(size_t)i + 1] = toff[(size_t)i] + dna->h_len[(size_t)i] + M + 16;
+    DevBuf &b_tb = ctx->scratch[10], &b_to = ctx->scratch[13];
+    BATH_HIP_TRY(ctx, b_tb.reserve((size_t)toff[(size_t)n] * sizeof(uint2) + (size_t)(n + 1) * sizeof(int64_t) + 256));
+    BATH_HIP_TRY(ctx, b_to.reserve((size_t)n * sizeof(FsTraceOut) + 64));
+    int64_t *d_toff = reinterpret_cast<int64_t *>(b_tb.as<char>() + ((size_t)toff[(size_t)n] * sizeof(uint2) + 255) / 256 * 256);
+    BATH_HIP_TRY(ctx, hipMemcpyAsync(d_toff, toff.data(), (size_t)(n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(fs5_trace_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, dna->view(), M, om->maxcodons, om->d_tf, om->d_codons,
+                       b_f.as<float>(), d_foff, b_fx.as<float>(), d_xoff, b_o.as<float>(), d_boff, b_ox.as<float>(), b_n2.as<float>(), b_tb.as<uint2>(), d_toff,
+                       b_to.as<FsTraceOut>());
+    BATH_HIP_TRY(ctx, hipGetLastError());
+    BATH_HIP_TRY(ctx, hipMemcpyAsync(trace, b_to.p, (size_t)n * sizeof(FsTraceOut), hipMemcpyDeviceToHost, ctx->stream));
+    BATH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));       // toff is a local
+  }
   std::vector<float> h_sc((size_t)n * 3), h_n2((size_t)n * kKp);
   BATH_HIP_TRY(ctx, hipMemcpyAsync(h_sc.data(), d_fsc, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
   BATH_HIP_TRY(ctx, hipMemcpyAsync(h_n2.data(), b_n2.p, (size_t)n * kKp * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));

@@ -57,8 +57,9 @@ const float *fsprofile_evparam(const bath_hip_fsprofile *om);
 int fsprofile_codon_lengths(const bath_hip_fsprofile *om);
 struct FsHostTables { int M, max_length, maxcodons; const float *tsc; const uint8_t *codons; const float *evparam; };
 const FsHostTables fsprofile_host(const bath_hip_fsprofile *om);
+struct FsTraceOut { int32_t ihmm, jhmm, iali, jali, nshift, ok; float domcorrection; };   // what the pipeline keeps of an envelope's OA trace
 int fs5_envelopes_ex(bath_hip_ctx *ctx, const bath_hip_fsprofile *om5, const bath_hip_seqs *dna, int logsum_mode, int c5_compat,
-                     bath_fs5_result *res, float *pp, float *oa, float *ppx, float *oax);
+                     bath_fs5_result *res, float *pp, float *oa, float *ppx, float *oax, FsTraceOut *trace);
 
 // ---- six-frame translation + ORF work list (bath_orfs.hip)
 struct OrfRec {                   // one ORF of the length-sorted work list
