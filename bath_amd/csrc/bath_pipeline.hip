@@ -745,8 +745,9 @@ static int pipeline_lane_count(const bath_hip_seqs *dna) {
   const int forced = e ? std::atoi(e) : 0;
   if (forced > 0) return (int)std::min<int64_t>(forced, std::max<int64_t>(dna->n, 1));
   if (dna->is_part || dna->n < 8) return 1;
-  // measured on MI355X, 10^6 x 1 kb: 1 lane 18.2 ms, 2 lanes 16.5 ms, 3 lanes 15.4 ms, 4 lanes 19.7 ms per pass
-  return (int)std::min<int64_t>(3, std::max<int64_t>(1, dna->total >> 28));     // one lane per 256 MB of DNA, at most 3
+  // measured on MI355X, 10^6 x 1 kb: 1 lane 17.2 ms, 2 lanes 15.5 ms per pass; 3 lanes 15.4-19.3 ms depending on how the
+  // persistent grids of the three parts happen to interleave, 4 lanes 19.7 ms: two lanes is the robust choice
+  return (dna->total >= ((int64_t)1 << 28)) ? 2 : 1;           // blocks under 256 MB: one launch sequence is short enough
 }
 
 static int ensure_parts(bath_hip_ctx *ctx, const bath_hip_seqs *dna, int K) {
