@@ -51,6 +51,8 @@ struct StageTiming { const char *name; float ms; int64_t launches; };
 struct bath_hip_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t side_stream = nullptr;    // created on first use: kernels that may overlap the main stream's (pipeline)
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   hipDeviceProp_t prop{};
   std::string err;
   void set_error(const std::string &m) { err = m; }

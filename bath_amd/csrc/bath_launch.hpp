@@ -38,7 +38,8 @@ int launch_bias_lane(bath_hip_ctx *ctx, const bath_hip_oprofile *om, SeqView v, 
 int vit_lane_supported(const bath_hip_oprofile *om);
 int launch_len_sort(bath_hip_ctx *ctx, const int32_t *d_todo, const int *d_ntodo, const int32_t *d_len, int *d_bins, int32_t *d_sorted);
 int launch_vit_lane(bath_hip_ctx *ctx, const bath_hip_oprofile *om, SeqView v, const int32_t *d_todo, int64_t ntodo, const int *ntodo_dev,
-                    float *d_sc, int32_t *d_status, const VitWindowArgs *wa);
+                    float *d_sc, int32_t *d_status, const VitWindowArgs *wa, const int *skip_dev = nullptr);
+const int *len_sort_count_longer(const int *d_bins, int T);     // device pointer: after launch_len_sort, the number of targets longer than T
 struct MsvConsts;
 MsvConsts msv_consts(const bath_hip_oprofile *om);
 

@@ -31,6 +31,7 @@ using namespace bath;
 namespace bath {
 
 static const double kLog2 = 0.69314718055994529;
+constexpr int kVitLongOrf = 128;         // ORFs longer than this take the wave-per-ORF Viterbi kernel (see the pipeline)
 
 // ---------------------------------------------------------------------------------------------
 // candidate storage (structure of arrays, indexed by candidate id)
@@ -634,7 +635,28 @@ static int run_filters(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bat
     wa.d_kminmax = W.cand.kminmax;
     if (vit_lane_supported(om)) {       // lane per ORF, ORFs bucketed by length (bath_viterbi.hip)
       if ((st = launch_len_sort(ctx, W.todo_vit, &W.ctr->todo_vit, W.cand.len, W.len_bins, W.todo_sorted)) != BATH_OK) return st;
-      if ((st = launch_vit_lane(ctx, om, cv, W.todo_sorted, cap, &W.ctr->todo_vit, W.cand.vfsc, W.cand.vit_status, &wa)) != BATH_OK) return st;
+      // The lane kernel runs one wave per SIMD and a wave takes as long as its longest ORF (3.6 us per residue): the few
+      // long ORFs at the head of the sorted list would set the duration of the whole stage.  They go to the
+      // wave-per-ORF kernel on a side stream instead, concurrently with the lane kernel on the rest.
+      if (!ctx->side_stream) {
+        BATH_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
+        BATH_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+        BATH_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+      }
+      static const int long_orf = [] { const char *e = std::getenv("BATH_HIP_VIT_LONG"); return e ? std::atoi(e) : kVitLongOrf; }();
+      const int *d_nlong = len_sort_count_longer(W.len_bins, long_orf);
+      BATH_HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+      BATH_HIP_TRY(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->ev_fork, 0));
+      {
+        hipStream_t main_stream = ctx->stream;
+        ctx->stream = ctx->side_stream;
+        st = launch_vit_wave(ctx, om, cv, W.todo_sorted, cap, W.cand.vfsc, W.cand.vit_status, &wa, d_nlong);
+        ctx->stream = main_stream;
+        if (st != BATH_OK) return st;
+      }
+      BATH_HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->side_stream));
+      if ((st = launch_vit_lane(ctx, om, cv, W.todo_sorted, cap, &W.ctr->todo_vit, W.cand.vfsc, W.cand.vit_status, &wa, d_nlong)) != BATH_OK) return st;
+      BATH_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
     } else if ((st = launch_vit_wave(ctx, om, cv, W.todo_vit, cap, W.cand.vfsc, W.cand.vit_status, &wa, &W.ctr->todo_vit)) != BATH_OK) return st;
     BATH_HIP_TRY(ctx, hipEventRecord(ev[e++], ctx->stream));
     {

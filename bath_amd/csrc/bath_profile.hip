@@ -128,6 +128,9 @@ extern "C" void bath_hip_finalize(bath_hip_ctx *ctx) {
   ctx->lanes.clear();
   for (auto &b : ctx->scratch) b.release();
   for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
+  if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+  if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+  if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }

@@ -47,7 +47,7 @@ typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
 template <int NR>
 __global__ __launch_bounds__(256, 1) void vit_lane_kernel(SeqView sq, VitLaneTables tb, const uint32_t *__restrict__ tw2g, VitLaneConsts c, const int16_t *__restrict__ xwmove_tab,
                                                           const uint8_t *__restrict__ tjb_tab, const int32_t *__restrict__ todo, int64_t ntodo,
-                                                          const int *__restrict__ ntodo_dev, float *__restrict__ sc, int32_t *__restrict__ status,
+                                                          const int *__restrict__ ntodo_dev, const int *__restrict__ skip_dev, float *__restrict__ sc, int32_t *__restrict__ status,
                                                           const float *__restrict__ filtersc, const uint8_t *__restrict__ ssv_scores,
                                                           WindowRec *__restrict__ wins, int *__restrict__ win_count, int win_cap, int32_t *__restrict__ kminmax) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -61,8 +61,8 @@ __global__ __launch_bounds__(256, 1) void vit_lane_kernel(SeqView sq, VitLaneTab
   }
   __syncthreads();
   if (ntodo_dev) ntodo = *ntodo_dev;
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if ((t & ~63ll) >= ntodo) return;                              // whole wave idle
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x + (skip_dev ? *skip_dev : 0);   // the first *skip_dev entries are someone else's
+  if (t - (threadIdx.x & 63) >= ntodo) return;                   // whole wave idle
   const bool live = t < ntodo;
   const int64_t sid = live ? (todo ? (int64_t)todo[t] : t) : (todo ? (int64_t)todo[0] : 0);
   const int L = live ? sq.len[sid] : 0;
@@ -254,6 +254,8 @@ __global__ __launch_bounds__(256) void len_scatter_kernel(const int32_t *__restr
 int vit_lane_supported(const bath_hip_oprofile *om) { return om->vit_NR > 0; }
 
 // todo (device list, count on device) -> sorted by length into <d_sorted>; <d_bins> is kLenBins ints of scratch
+const int *len_sort_count_longer(const int *d_bins, int T) { return d_bins + std::min(T + 1, kLenBins - 1); }   // after the sort: #targets longer than T
+
 int launch_len_sort(bath_hip_ctx *ctx, const int32_t *d_todo, const int *d_ntodo, const int32_t *d_len, int *d_bins, int32_t *d_sorted) {
   BATH_HIP_TRY(ctx, hipMemsetAsync(d_bins, 0, kLenBins * sizeof(int), ctx->stream));
   hipLaunchKernelGGL(len_hist_kernel, dim3(256), dim3(256), 0, ctx->stream, d_todo, d_ntodo, d_len, d_bins);
@@ -264,7 +266,7 @@ int launch_len_sort(bath_hip_ctx *ctx, const int32_t *d_todo, const int *d_ntodo
 }
 
 int launch_vit_lane(bath_hip_ctx *ctx, const bath_hip_oprofile *om, SeqView v, const int32_t *d_todo, int64_t ntodo, const int *ntodo_dev,
-                    float *d_sc, int32_t *d_status, const VitWindowArgs *wa) {
+                    float *d_sc, int32_t *d_status, const VitWindowArgs *wa, const int *skip_dev) {
   if (ntodo == 0) return BATH_OK;
   VitLaneTables tb{om->d_vit_rw, om->vit_rw_pitch, om->d_vit_tw2, om->d_vit_tdd, om->d_vit_rank};
   VitLaneConsts c{};
@@ -279,7 +281,7 @@ int launch_vit_lane(bath_hip_ctx *ctx, const bath_hip_oprofile *om, SeqView v, c
 #define BATH_VITL_CASE(N)                                                                                                              \
   if (!launched && NRv == N) {                                                                                                         \
     hipLaunchKernelGGL(vit_lane_kernel<N>, dim3(blocks), dim3(256), shmem, ctx->stream, v, tb, tb.tw2, c, om->lt.d_xwmove, om->lt.d_tjb, d_todo, ntodo, \
-                       ntodo_dev, d_sc, d_status, fsc, ssv, wins, wc, cap, kmm);                                                       \
+                       ntodo_dev, skip_dev, d_sc, d_status, fsc, ssv, wins, wc, cap, kmm);                                                       \
     launched = true;                                                                                                                   \
   }
   BATH_VITL_CASE(16) BATH_VITL_CASE(32) BATH_VITL_CASE(48) BATH_VITL_CASE(64) BATH_VITL_CASE(80) BATH_VITL_CASE(96) BATH_VITL_CASE(112)
