@@ -12,8 +12,9 @@
 // Division of labour.  Everything that touches a DP matrix runs on the GPU, batched over all windows / envelopes of the
 // block: the 3-codon parsers (fs3_fwd_kernel, fs_bwd_kernel<.,3,.>), the five envelope kernels of bath_frameshift.hip and
 // the optimal-accuracy traceback with the null2 score of the aligned residues (fs5_trace_kernel, a lane per envelope), so
-// the posterior and OA matrices (>1 MB per envelope) never leave the device.  What remains is O(L) per window on the
-// parsers' special-state rows (posterior sums, region heuristics) and the score arithmetic of the hit: done here.
+// the posterior and OA matrices (>1 MB per envelope) never leave the device; the posterior sums over the parsers'
+// special-state rows and the region heuristics run there too (fs_regions_kernel, a lane per window).  What remains for
+// the host is bookkeeping and the score arithmetic of the hit.
 // Not built: stochastic-trace clustering of multi-domain regions (:396-455; counted in *n_skipped_regions), the
 // "aliscore < 0" garbage rule of p7_pli_computeAliScores_BATH (:1070-1080), alignment display.
 // The reference carries om_fs5's length configuration from one window to the next; here the domain decoding always uses
@@ -31,86 +32,10 @@ using namespace bath;
 
 namespace {
 
-enum { XE = 0, XN, XJ, XB, XC };                       // special-state columns of the generic matrices (p7G_E ... p7G_C)
 
 const double kLn2 = 0.69314718055994529;
 
 double exp_logsurv(double x, double mu, double lambda) { return x < mu ? 0.0 : -lambda * (x - mu); }
-
-// btot / etot / mocc of a window from the parsers' rows (log space), generic_decoding_frameshift.c:204-290
-void domain_decoding(const float *fx, const float *bx, int L, float loopN, float loopC, float loopJ, std::vector<float> &btot, std::vector<float> &etot,
-                     std::vector<float> &mocc) {
-  btot.assign((size_t)L + 1, 0.f); etot.assign((size_t)L + 1, 0.f); mocc.assign((size_t)L + 1, 0.f);
-  auto F = [&](int i, int s) { return fx[(size_t)i * 5 + s]; };
-  auto B = [&](int i, int s) { return bx[(size_t)i * 5 + s]; };
-  const float Z = flogsum_host(B(0, XN), flogsum_host(B(1, XN), B(2, XN)));
-  for (int i = 3; i <= L; i++) {
-    btot[(size_t)i] = btot[(size_t)i - 3] + expf(F(i - 3, XB) + B(i - 3, XB) - Z);
-    etot[(size_t)i] = etot[(size_t)i - 3] + expf(F(i, XE) + B(i, XE) - Z);
-  }
-  // i is emitted by N, C or J in any of the three codon phases that cover it
-  auto emitted = [&](int s, float loop, int a, int b) { return expf(F(a, s) + B(b, s) + loop - Z); };
-  for (int i = 3; i < L - 1; i++) {
-    float p = 0.0f;
-    for (int s : {XN, XC, XJ}) {
-      const float loop = s == XN ? loopN : (s == XC ? loopC : loopJ);
-      p += emitted(s, loop, i - 3, i); p += emitted(s, loop, i - 2, i + 1); p += emitted(s, loop, i - 1, i + 2);
-    }
-    mocc[(size_t)i] = (float)(1. - p);
-  }
-  if (L >= 4) {
-    float p = 0.0f;
-    for (int s : {XN, XC, XJ}) { const float loop = s == XN ? loopN : (s == XC ? loopC : loopJ); p += emitted(s, loop, L - 4, L - 1); p += emitted(s, loop, L - 3, L); }
-    mocc[(size_t)L - 1] = (float)(1. - p);
-    p = 0.0f;
-    for (int s : {XN, XC, XJ}) { const float loop = s == XN ? loopN : (s == XC ? loopC : loopJ); p += emitted(s, loop, L - 3, L); }
-    mocc[(size_t)L] = (float)(1. - p);
-  }
-}
-
-// more than one domain expected somewhere inside i..j? (p7_domaindef.c:684-714)
-bool multidomain(const std::vector<float> &btot, const std::vector<float> &etot, int i, int j, float rt3) {
-  float best = -1.0f;
-  for (int ph = 0; ph < 3; ph++) {
-    const int f = (j - i + 1 - ph) % 3;
-    for (int z = i + 2 + ph; z <= j - f; z += 3)
-      best = std::max(best, std::min(etot[(size_t)z] - etot[(size_t)(i - 1 + ph)], btot[(size_t)(j - f)] - btot[(size_t)z - 3]));
-  }
-  return best >= rt3;
-}
-
-// regions of a window: p7_domaindef.c:328-392 (the start / end of a frameshift-aware domain must show in all three frames)
-void find_regions(const std::vector<float> &btot, const std::vector<float> &etot, const std::vector<float> &mocc, int L, std::vector<std::pair<int, int>> &single,
-                  int *n_multi) {
-  const float rt1 = 0.25f, rt2 = 0.10f, rt3 = 0.20f;      // p7_domaindef.c:80-82
-  bool triggered = false;
-  int d = 0;
-  for (int j = 1; j < L; j++) {
-    if (!triggered) { if (mocc[(size_t)j] >= rt1) triggered = true; d = j; continue; }
-    bool found = false;
-    while (d > 1 && !found) {
-      int run = 0;
-      d--;
-      while (run < 3 && d > 3 && mocc[(size_t)d] - (btot[(size_t)d] - btot[(size_t)d - 3]) < rt2) { d--; run++; }
-      if (run == 3) found = true;
-    }
-    const int i = std::max(1, d - 3);
-    d = j + 1;
-    found = false;
-    while (d < L && !found) {
-      int run = 0;
-      d++;
-      while (run < 3 && d < L && mocc[(size_t)d] - (etot[(size_t)d] - etot[(size_t)d - 3]) < rt2) { d++; run++; }
-      if (run == 3) found = true;
-    }
-    j = std::min(L, d + 3);
-    if (j - i + 1 >= 12) {
-      if (multidomain(btot, etot, i, j, rt3)) (*n_multi)++;
-      else single.emplace_back(i, j);
-    }
-    triggered = false;
-  }
-}
 
 }  // namespace
 
@@ -148,32 +73,27 @@ extern "C" int bath_hip_pipeline_frameshift_domains(bath_hip_ctx *ctx, const bat
   OrfTablesDev tt{};
   if ((st = orf_tables_upload(ctx, prm->ncbi_table, &tt)) != BATH_OK) return st;
   const int nsel = (int)sel.size();
-  std::vector<int64_t> xoff((size_t)nsel + 1, 0);
-  for (int i = 0; i < nsel; i++) xoff[(size_t)i + 1] = xoff[(size_t)i] + ((int64_t)regs[(size_t)i].len + 1) * 5;
-  std::vector<float> fx((size_t)xoff[(size_t)nsel]), bx((size_t)xoff[(size_t)nsel]), fsc((size_t)nsel), bsc((size_t)nsel);
+  const int RS = 1 + 3 * fs_max_regions();
+  std::vector<int32_t> regions((size_t)nsel * RS, 0);
+  const float pmove = (2.0f + 1.0f) / (100.0f + 2.0f + 1.0f);                 // p7_fs_ReconfigLength(L = 100, nj = 1), modelconfig.c:767-770
+  const float loop = (float)std::log((double)(1.0f - pmove));
   {
     bath_hip_seqs view;
     if ((st = fs_gather_view(ctx, dna, regs, tt.comp, &view, nullptr)) != BATH_OK) return st;
-    st = bath_hip_fs3_forward_parser(ctx, om_fs3, &view, BATH_LOGSUM_TABLE, fsc.data(), fx.data(), xoff.data());
-    if (st == BATH_OK) st = bath_hip_fs3_backward_parser(ctx, om_fs3, &view, BATH_LOGSUM_TABLE, bsc.data(), bx.data(), xoff.data());
+    st = fs3_regions(ctx, om_fs3, &view, loop, regions.data());               // parsers, domain decoding, region heuristics: all on the device
     view.d_data = nullptr; view.d_off = nullptr; view.d_len = nullptr;
     if (st != BATH_OK) return st;
   }
-
-  // ---- posterior sums over the special states -> regions -> envelopes
-  const float pmove = (2.0f + 1.0f) / (100.0f + 2.0f + 1.0f);                 // p7_fs_ReconfigLength(L = 100, nj = 1), modelconfig.c:767-770
-  const float loop = (float)std::log((double)(1.0f - pmove));
   struct Env { int sel, i, j; };
   std::vector<Env> envs;
   int n_multi = 0;
   for (int q = 0; q < nsel; q++) {
-    if (!(bsc[(size_t)q] > -INFINITY)) continue;                              // Backward underflow: the reference skips the window (:1471)
-    const int L = regs[(size_t)q].len;
-    std::vector<float> btot, etot, mocc;
-    domain_decoding(&fx[(size_t)xoff[(size_t)q]], &bx[(size_t)xoff[(size_t)q]], L, loop, loop, loop, btot, etot, mocc);
-    std::vector<std::pair<int, int>> single;
-    find_regions(btot, etot, mocc, L, single, &n_multi);
-    for (auto &r : single) if (r.second - r.first + 1 >= 15) envs.push_back(Env{q, r.first, r.second});      // rescore_isolated_domain: Ld < 15 -> nothing
+    const int32_t *r = &regions[(size_t)q * RS];
+    for (int k = 0; k < r[0]; k++) {                                          // r[0] == -1: Backward underflow, the reference skips the window (:1471)
+      const int i = r[1 + 3 * k], j = r[2 + 3 * k];
+      if (r[3 + 3 * k]) n_multi++;
+      else if (j - i + 1 >= 15) envs.push_back(Env{q, i, j});                 // rescore_isolated_domain: Ld < 15 -> nothing
+    }
   }
   if (n_skipped_regions) *n_skipped_regions = n_multi;
   if (envs.empty()) return BATH_OK;

@@ -1067,6 +1067,123 @@ static int fs3_parser(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, const bat
   return BATH_OK;
 }
 
+// p7_DomainDecoding_Frameshift (generic form, generic_decoding_frameshift.c:204-290) and the region heuristics of
+// p7_domaindef_ByPosteriorHeuristics_Frameshift_BATH (p7_domaindef.c:328-392, is_multidomain_region_frameshift :684-714)
+// on the parsers' special-state rows, one lane per window: O(L) work on rows that are already in HBM, so that only the
+// regions (a few integers per window) travel to the host.
+constexpr int kMaxRegions = 24;
+__global__ void fs_regions_kernel(int64_t n, const int32_t *__restrict__ len, const float *__restrict__ fx, const float *__restrict__ bx,
+                                  const int64_t *__restrict__ x_off, const float *__restrict__ tbl, float loop, float *__restrict__ work /* 3 floats per xmx row */,
+                                  int32_t *__restrict__ regions /* [n][1 + 3*kMaxRegions]: count, then {i, j, multidomain} */) {
+  const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= n) return;
+  enum { XE = 0, XN, XJ, XB, XC };
+  const int L = len[w];
+  const float *F = fx + x_off[w], *B = bx + x_off[w];
+  float *btot = work + (x_off[w] / 5) * 3, *etot = btot + (L + 1), *mocc = etot + (L + 1);
+  int32_t *out = regions + w * (1 + 3 * kMaxRegions);
+  int nreg = 0;
+  out[0] = 0;
+  if (L < 6) return;
+  const float Z = flogsum<false>(B[0 * 5 + XN], flogsum<false>(B[1 * 5 + XN], B[2 * 5 + XN], tbl), tbl);
+  if (!(Z > -INFINITY)) { out[0] = -1; return; }                              // Backward underflow: the window is skipped (p7_pipeline.c:1471)
+  for (int i = 0; i < 3; i++) btot[i] = etot[i] = mocc[i] = 0.f;
+  for (int i = 3; i <= L; i++) {
+    btot[i] = btot[i - 3] + expf(F[(size_t)(i - 3) * 5 + XB] + B[(size_t)(i - 3) * 5 + XB] - Z);
+    etot[i] = etot[i - 3] + expf(F[(size_t)i * 5 + XE] + B[(size_t)i * 5 + XE] - Z);
+  }
+  auto em = [&](int s, int a, int b) { return expf(F[(size_t)a * 5 + s] + B[(size_t)b * 5 + s] + loop - Z); };
+  for (int i = 3; i < L - 1; i++) {
+    float p = 0.0f;
+    p += em(XN, i - 3, i); p += em(XN, i - 2, i + 1); p += em(XN, i - 1, i + 2);
+    p += em(XC, i - 3, i); p += em(XC, i - 2, i + 1); p += em(XC, i - 1, i + 2);
+    p += em(XJ, i - 3, i); p += em(XJ, i - 2, i + 1); p += em(XJ, i - 1, i + 2);
+    mocc[i] = (float)(1. - p);
+  }
+  {
+    float p = 0.0f;
+    p += em(XN, L - 4, L - 1); p += em(XN, L - 3, L); p += em(XC, L - 4, L - 1); p += em(XC, L - 3, L); p += em(XJ, L - 4, L - 1); p += em(XJ, L - 3, L);
+    mocc[L - 1] = (float)(1. - p);
+    p = 0.0f;
+    p += em(XN, L - 3, L); p += em(XC, L - 3, L); p += em(XJ, L - 3, L);
+    mocc[L] = (float)(1. - p);
+  }
+  const float rt1 = 0.25f, rt2 = 0.10f, rt3 = 0.20f;                         // p7_domaindef.c:80-82
+  bool triggered = false;
+  int d = 0;
+  for (int j = 1; j < L; j++) {
+    if (!triggered) { if (mocc[j] >= rt1) triggered = true; d = j; continue; }
+    bool found = false;
+    while (d > 1 && !found) {                                                // the start must show in all three frames
+      int run = 0;
+      d--;
+      while (run < 3 && d > 3 && mocc[d] - (btot[d] - btot[d - 3]) < rt2) { d--; run++; }
+      if (run == 3) found = true;
+    }
+    const int i = max(1, d - 3);
+    d = j + 1;
+    found = false;
+    while (d < L && !found) {
+      int run = 0;
+      d++;
+      while (run < 3 && d < L && mocc[d] - (etot[d] - etot[d - 3]) < rt2) { d++; run++; }
+      if (run == 3) found = true;
+    }
+    j = min(L, d + 3);
+    if (j - i + 1 >= 12) {
+      float best = -1.0f;                                                    // is_multidomain_region_frameshift
+      for (int ph = 0; ph < 3; ph++) {
+        const int f = (j - i + 1 - ph) % 3;
+        for (int z = i + 2 + ph; z <= j - f; z += 3) best = fmaxf(best, fminf(etot[z] - etot[i - 1 + ph], btot[j - f] - btot[z - 3]));
+      }
+      if (nreg < kMaxRegions) { out[1 + 3 * nreg] = i; out[2 + 3 * nreg] = j; out[3 + 3 * nreg] = best >= rt3 ? 1 : 0; }
+      nreg++;
+    }
+    triggered = false;
+  }
+  out[0] = min(nreg, kMaxRegions);
+}
+
+namespace bath {
+// Both 3-codon parsers and the regions of every window of <dna>; regions_out[i] = {count (or -1: Backward underflow),
+// then count x {i, j, multidomain}}, 1 + 3*fs_max_regions() ints per window.
+int fs_max_regions() { return kMaxRegions; }
+int fs3_regions(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, const bath_hip_seqs *dna, float loop, int32_t *regions_out) {
+  if (!ctx || !om || !dna || om->codon_lengths != 3) { if (ctx) ctx->set_error("fs3 parser needs a 3-codon profile"); return BATH_EINVAL; }
+  BATH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const int64_t n = dna->n;
+  if (n == 0) return BATH_OK;
+  int st = om->ensure_len(dna->maxlen / 3 + 1);
+  if (st != BATH_OK) return st;
+  std::vector<int64_t> xoff((size_t)n + 1, 0);
+  for (int64_t i = 0; i < n; i++) xoff[(size_t)i + 1] = xoff[(size_t)i] + ((int64_t)dna->h_len[(size_t)i] + 1) * 5;
+  DevBuf &b_sc = ctx->scratch[12], &b_fx = ctx->scratch[13], &b_off = ctx->scratch[14], &b_bx = ctx->scratch[11], &b_work = ctx->scratch[10], &b_reg = ctx->scratch[15];
+  BATH_HIP_TRY(ctx, b_sc.reserve((size_t)n * sizeof(float)));
+  BATH_HIP_TRY(ctx, b_fx.reserve((size_t)xoff[(size_t)n] * sizeof(float) + 64));
+  BATH_HIP_TRY(ctx, b_bx.reserve((size_t)xoff[(size_t)n] * sizeof(float) + 64));
+  BATH_HIP_TRY(ctx, b_work.reserve((size_t)xoff[(size_t)n] / 5 * 3 * sizeof(float) + 64));
+  const size_t reg_ints = (size_t)n * (1 + 3 * kMaxRegions);
+  BATH_HIP_TRY(ctx, b_reg.reserve(reg_ints * sizeof(int32_t) + 64));
+  if ((st = upload_offsets(ctx, b_off, xoff.data(), n)) != BATH_OK) return st;
+  const int Cv = fs_columns(om->M);
+  const size_t shmem = (size_t)(kLogsumTbl + (om->M + 2) * 8) * sizeof(float);
+  const float tE = (float)-0.69314718055994529;
+  const int grid = fs_grid(ctx, n);
+  BATH_FS_SWITCH(Cv, {
+    if ((st = fs_set_shmem(ctx, fs3_fwd_kernel<CC, false>, shmem)) != BATH_OK) return st;
+    hipLaunchKernelGGL((fs3_fwd_kernel<CC, false>), dim3(grid), dim3(256), shmem, ctx->stream, dna->view(), fsdev(om), om->d_loop[0], om->d_move[0], tE, tE, b_sc.as<float>(), b_fx.as<float>(), b_off.as<int64_t>());
+    if ((st = fs_set_shmem(ctx, fs_bwd_kernel<CC, 3, false>, shmem)) != BATH_OK) return st;
+    hipLaunchKernelGGL((fs_bwd_kernel<CC, 3, false>), dim3(grid), dim3(256), shmem, ctx->stream, dna->view(), fsdev(om), om->d_loop[0], om->d_move[0], tE, tE, b_sc.as<float>(), (float *)nullptr, (const int64_t *)nullptr, b_bx.as<float>(), b_off.as<int64_t>());
+  })
+  hipLaunchKernelGGL(fs_regions_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, n, dna->d_len, b_fx.as<float>(), b_bx.as<float>(), b_off.as<int64_t>(), om->d_logsum, loop,
+                     b_work.as<float>(), b_reg.as<int32_t>());
+  BATH_HIP_TRY(ctx, hipGetLastError());
+  BATH_HIP_TRY(ctx, hipMemcpyAsync(regions_out, b_reg.p, reg_ints * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  BATH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return BATH_OK;
+}
+}  // namespace bath
+
 namespace bath {
 // used by the pipeline's frameshift stage (bath_pipeline.hip)
 int fs3_forward_scores(bath_hip_ctx *ctx, const bath_hip_fsprofile *om3, const bath_hip_seqs *dna, float *sc) {
