@@ -303,6 +303,15 @@ void bo_gdomain_decoding_fs(const bo_fs_profile *gm5, const bo_gmx *fwd, const b
 int  bo_goatrace_fs(const bo_fs_profile *gm, const bo_gmx *pp, const bo_gmx *gx, bo_trace *tr);                                  /* generic_optacc_frameshift.c:373 */
 double bo_exp_logsurv(double x, double mu, double lambda);
 
+/* ---- domain definition of the standard branch (domaindef.c) ---- */
+int  bo_forward_full(const uint8_t *dsq, int L, const bo_oprofile *om, float *dpf, float *xmx, float *ret_sc);                                   /* fwdback.c:94 */
+int  bo_backward_full(const uint8_t *dsq, int L, const bo_oprofile *om, const float *fwd_xmx, float *dpb, float *bck_xmx, float *ret_sc, int *own_scales); /* :196 */
+void bo_oprofile_reconfig_unihit(bo_oprofile *om, int L);       /* p7_oprofile.c:1418 */
+void bo_oprofile_reconfig_multihit(bo_oprofile *om, int L);     /* p7_oprofile.c:1395 */
+int  bo_domain_decoding(const bo_oprofile *om, const float *fx, const float *bx, int L, int own_scales, float *btot, float *etot, float *mocc); /* decoding.c:155 */
+int  bo_domaindef_std(bo_pipeline *pli, bo_oprofile *om, bo_bg *bg, const uint8_t *dsq, int n, int orf_start, int win_start,
+                      int complementarity, int seq_n, bo_fsdomain **doms, int *ndom, int *dalloc, int *nskipped);
+
 void bo_pipeline_init(bo_pipeline *pli, int fs_pipe);
 void  bo_local_compo(const bo_scoredata *sd, const bo_oprofile *om, const bo_bg *bg, int k_min, int k_max, float *compo); /* p7_pipeline.c:427 */
 /* frameshift stage for one strand (fs_pipeline.c); dsq[1..n] is the strand being read */
@@ -312,6 +321,9 @@ int  bo_pli_frameshift(bo_pipeline *pli, bo_oprofile *om, bo_fs_profile *gm3, bo
                        bo_fsdomain **doms, int *ndom, int *dom_alloc, int *nskipped);
 int  bo_domaindef_fs(bo_pipeline *pli, bo_fs_profile *gm3, bo_fs_profile *gm5, bo_bg *bg, const uint8_t *wdsq, int L,
                      int window_start, int complementarity, int seq_n, bo_fsdomain **doms, int *ndom, int *dalloc, int *nskipped);
+int  bo_pipeline_window_hits(bo_pipeline *pli, bo_oprofile *om, const bo_scoredata *sd, bo_bg *bg,
+                             const uint8_t basic[64], const uint8_t *dna, int n,
+                             bo_orfresult **res, int *nres, int *res_alloc, bo_fsdomain **doms, int *ndom, int *dom_alloc, int *nskipped);
 /* bo_pipeline_window with the frameshift stage (pli->fs_pipe must be set; gm3 = 3-codon frameshift profile) */
 int  bo_pipeline_window_fs(bo_pipeline *pli, bo_oprofile *om, bo_fs_profile *gm3, const bo_scoredata *sd, bo_bg *bg,
                            const uint8_t basic[64], const uint8_t *dna, int n,

@@ -292,7 +292,7 @@ int bo_vitfilter_bath(const uint8_t *dsq, int L, const bo_oprofile *om, const bo
  * reference's (mul,add,add,add,mul); the D row is the exact serial recurrence that the striped DD
  * passes converge to; row sums (xE) are accumulated in node order, so fp32 rounding differs from the
  * striped order at the 1e-7 level.  xmx6 (optional) receives (L+1) x {E,N,J,B,C,SCALE}. */
-int bo_forward_parser(const uint8_t *dsq, int L, const bo_oprofile *om, float *xmx, float *ret_sc)
+static int forward_engine(const uint8_t *dsq, int L, const bo_oprofile *om, float *dpf, float *xmx, float *ret_sc)
 {
   int M = om->M;
   size_t W = (size_t) M + 1;
@@ -304,6 +304,7 @@ int bo_forward_parser(const uint8_t *dsq, int L, const bo_oprofile *om, float *x
   double totscale = 0.0;   /* ox->totscale is a float in the reference (impl_sse.h); accumulated with log() */
   float  totscale_f = 0.0f;
   if (xmx) { xmx[0] = xE; xmx[1] = xN; xmx[2] = xJ; xmx[3] = xB; xmx[4] = xC; xmx[5] = 1.0f; }
+  if (dpf) memset(dpf, 0, sizeof(float) * W * 3);        /* row 0 */
   (void) totscale;
 
   for (int i = 1; i <= L; i++) {
@@ -340,6 +341,7 @@ int bo_forward_parser(const uint8_t *dsq, int L, const bo_oprofile *om, float *x
       xE = 1.0f;
     }
     if (xmx) { float *x = xmx + (size_t) i * 6; x[0] = xE; x[1] = xN; x[2] = xJ; x[3] = xB; x[4] = xC; x[5] = scale; }
+    if (dpf) { float *r = dpf + (size_t) i * W * 3; r[0] = r[1] = r[2] = 0.f; for (int k = 1; k <= M; k++) { r[k*3+0] = Mc[k]; r[k*3+1] = Dc[k]; r[k*3+2] = Ic[k]; } }
     float *tmp;
     tmp = Mp; Mp = Mc; Mc = tmp;
     tmp = Ip; Ip = Ic; Ic = tmp;
@@ -351,9 +353,13 @@ int bo_forward_parser(const uint8_t *dsq, int L, const bo_oprofile *om, float *x
   return BO_OK;
 }
 
+int bo_forward_parser(const uint8_t *dsq, int L, const bo_oprofile *om, float *xmx, float *ret_sc) { return forward_engine(dsq, L, om, NULL, xmx, ret_sc); }
+/* p7_Forward (fwdback.c:94): full matrix dpf[(L+1)][(M+1)][3] = {M, D, I}, scaled like the parser; xmx as the parser's */
+int bo_forward_full(const uint8_t *dsq, int L, const bo_oprofile *om, float *dpf, float *xmx, float *ret_sc) { return forward_engine(dsq, L, om, dpf, xmx, ret_sc); }
+
 /* backward_engine(do_full=FALSE), fwdback.c:468-760, unstriped; uses the Forward scale factors.
  * bck_xmx6 receives (L+1) x {E,N,J,B,C,SCALE}; score = totscale + log(xN(0)). */
-int bo_backward_parser(const uint8_t *dsq, int L, const bo_oprofile *om, const float *fwd, float *bck, float *ret_sc)
+static int backward_engine(const uint8_t *dsq, int L, const bo_oprofile *om, const float *fwd, float *dpb, float *bck, float *ret_sc, int *ret_own_scales)
 {
   int M = om->M;
   size_t W = (size_t) M + 2;
@@ -383,6 +389,7 @@ int bo_backward_parser(const uint8_t *dsq, int L, const bo_oprofile *om, const f
   }
   totscale = (float) log(sc);
   if (bck) { float *x = bck + (size_t) L * 6; x[0] = xE; x[1] = xN; x[2] = xJ; x[3] = xB; x[4] = xC; x[5] = sc; }
+  if (dpb) { float *r = dpb + (size_t) L * (M + 1) * 3; r[0] = r[1] = r[2] = 0.f; for (int k = 1; k <= M; k++) { r[k*3+0] = Mn[k]; r[k*3+1] = Dn[k]; r[k*3+2] = In[k]; } }
 
   for (int i = L - 1; i >= 1; i--) {
     const float *rf = om->rf + dsq[i+1] * (size_t)(M + 1);
@@ -414,6 +421,7 @@ int bo_backward_parser(const uint8_t *dsq, int L, const bo_oprofile *om, const f
       totscale += (float) log(s);
     }
     if (bck) { float *x = bck + (size_t) i * 6; x[0] = xE; x[1] = xN; x[2] = xJ; x[3] = xB; x[4] = xC; x[5] = s; }
+    if (dpb) { float *r = dpb + (size_t) i * (M + 1) * 3; r[0] = r[1] = r[2] = 0.f; for (int k = 1; k <= M; k++) { r[k*3+0] = Mc[k]; r[k*3+1] = Dc[k]; r[k*3+2] = Ic[k]; } }
     float *tmp;
     tmp = Mn; Mn = Mc; Mc = tmp;
     tmp = In; In = Ic; Ic = tmp;
@@ -427,12 +435,18 @@ int bo_backward_parser(const uint8_t *dsq, int L, const bo_oprofile *om, const f
     xB = b;
     xN = (xB * om->xf[BO_XN][BO_MOVE]) + (xN * om->xf[BO_XN][BO_LOOP]);
     if (bck) { bck[0] = 0.f; bck[1] = xN; bck[2] = 0.f; bck[3] = xB; bck[4] = 0.f; bck[5] = 1.0f; }
+    if (dpb) memset(dpb, 0, sizeof(float) * (size_t)(M + 1) * 3);
   }
+  if (ret_own_scales) *ret_own_scales = own_scales;
   free(alloc);
   if (isnan(xN) || (L > 0 && xN == 0.0) || isinf(xN)) { if (ret_sc) *ret_sc = -INFINITY; return BO_ERANGE; }
   if (ret_sc) *ret_sc = (float)(totscale + log(xN));
   return BO_OK;
 }
+
+int bo_backward_parser(const uint8_t *dsq, int L, const bo_oprofile *om, const float *fwd, float *bck, float *ret_sc) { return backward_engine(dsq, L, om, fwd, NULL, bck, ret_sc, NULL); }
+/* p7_Backward (fwdback.c:196): full matrix, same layout as bo_forward_full */
+int bo_backward_full(const uint8_t *dsq, int L, const bo_oprofile *om, const float *fwd_xmx, float *dpb, float *bck_xmx, float *ret_sc, int *own_scales) { return backward_engine(dsq, L, om, fwd_xmx, dpb, bck_xmx, ret_sc, own_scales); }
 
 /* ------------------------------------------------------------------ generic scalar Viterbi / Forward */
 

@@ -163,6 +163,8 @@ static void strand_cascade(bo_pipeline *pli, bo_oprofile *om, const bo_scoredata
     r->stage = 4;
     pli->n_past_fwd++;
     if (!pli->fs_pipe) pli->pos_past_fwd += (int64_t) n * 3;  /* :1761; the fs branch counts later (:1468,1490) */
+    if (!pli->fs_pipe && fs && fs->doms && !fs->gm3)          /* :1763-1771: Backward parser, domain definition, hit scores */
+      bo_domaindef_std(pli, om, bg, dsq, n, o->start, o->start, strand, fs->n, fs->doms, fs->ndom, fs->dom_alloc, fs->nskipped);
   }
   if (pli->fs_pipe && fs && fs->gm3)                            /* :1793 */
     bo_pli_frameshift(pli, om, fs->gm3, fs->gm5, sd, bg, fs->basic, blk, P_orf, fwd_null, &hw, fs->dsq, fs->n, strand, fs->fw, fs->nfw, fs->fw_alloc,
@@ -203,6 +205,14 @@ int bo_pipeline_window_fsdom(bo_pipeline *pli, bo_oprofile *om, bo_fs_profile *g
   free(rc);
   bo_orfblock_free(&blk);
   return BO_OK;
+}
+
+/* the plain pipeline with domain definition and hit scores for the ORFs that pass the Forward filter */
+int bo_pipeline_window_hits(bo_pipeline *pli, bo_oprofile *om, const bo_scoredata *sd, bo_bg *bg,
+                            const uint8_t basic[64], const uint8_t *dna, int n,
+                            bo_orfresult **res, int *nres, int *res_alloc, bo_fsdomain **doms, int *ndom, int *dom_alloc, int *nskipped)
+{
+  return bo_pipeline_window_fsdom(pli, om, NULL, NULL, sd, bg, basic, dna, n, res, nres, res_alloc, NULL, NULL, NULL, doms, ndom, dom_alloc, nskipped);
 }
 
 int bo_pipeline_window(bo_pipeline *pli, bo_oprofile *om, const bo_scoredata *sd, bo_bg *bg,

@@ -191,6 +191,9 @@ def lib():
                                            C.POINTER(Bg), u8p, u8p, C.c_int, C.POINTER(C.POINTER(OrfResult)), C.POINTER(C.c_int), C.POINTER(C.c_int),
                                            C.POINTER(C.POINTER(FsWindow)), C.POINTER(C.c_int), C.POINTER(C.c_int),
                                            C.POINTER(C.POINTER(FsDomain)), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.bo_pipeline_window_hits.argtypes = [C.POINTER(Pipeline), C.POINTER(OProfile), C.POINTER(ScoreData), C.POINTER(Bg), u8p, u8p, C.c_int,
+                                          C.POINTER(C.POINTER(OrfResult)), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                          C.POINTER(C.POINTER(FsDomain)), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.bo_pipeline_window.argtypes = [C.POINTER(Pipeline), C.POINTER(OProfile), C.POINTER(ScoreData), C.POINTER(Bg),
                                      u8p, u8p, C.c_int, C.POINTER(C.POINTER(OrfResult)), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     if hasattr(L, "bo_gmx_create"):
@@ -309,6 +312,22 @@ class Model:
             per_seq.append((before, nres.value))
         out = [res[i] for i in range(nres.value)]
         return pli, out, per_seq
+
+    def run_pipeline_hits(self, seqs):
+        """The plain pipeline through domain definition: (Pipeline counters, FsDomain records, per-sequence ranges, skipped)."""
+        L_ = lib()
+        pli = Pipeline()
+        L_.bo_pipeline_init(C.byref(pli), 0)
+        res = C.POINTER(OrfResult)(); nres, alloc = C.c_int(0), C.c_int(0)
+        dm = C.POINTER(FsDomain)(); ndm, dmalloc, nskip = C.c_int(0), C.c_int(0), C.c_int(0)
+        per_d = []
+        for codes in seqs:
+            d = dsq_from(codes)
+            d0 = ndm.value
+            L_.bo_pipeline_window_hits(C.byref(pli), self.om, self.sd, C.byref(self.bg), u8(self.basic), u8(d), len(codes),
+                                       C.byref(res), C.byref(nres), C.byref(alloc), C.byref(dm), C.byref(ndm), C.byref(dmalloc), C.byref(nskip))
+            per_d.append((d0, ndm.value))
+        return pli, [dm[i] for i in range(ndm.value)], per_d, nskip.value
 
     def run_pipeline_fsdom(self, seqs):
         """run_pipeline_fs plus domain definition and hit scores for the windows that take the frameshift branch.

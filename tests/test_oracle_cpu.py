@@ -198,3 +198,32 @@ def test_frameshift_hit_matches_recorded_run():
     assert "%.1f" % (d.dombias / np.log(2.0)) == "0.1"
     evalue = np.exp(d.lnP) * (822 / 3.0) / m.om.contents.max_length
     assert "%.1e" % evalue in ("1.9e-27", "1.8e-27", "2.0e-27")
+
+
+RECORDED_STD_HITS = {   # tutorial/PTH2.tbl and tutorial/AMP_N.out: (hmm from, hmm to, ali from, ali to, score, bias)
+    "PTH2.bhmm": ("target-PTH2.fa", [(2, 116, 672, 325, "110.6", "0.3"), (35, 116, 1486, 1731, "86.4", "0.0"),
+                                     (71, 113, 2468, 2343, "36.2", "0.0"), (2, 30, 1273, 1359, "36.0", "0.3")]),
+    "AMP_N.bhmm": ("target-AMP_N.fa", [(None, None, 7, 234, "47.8", "0.0")]),
+}
+
+
+@pytest.mark.parametrize("hmmfile", sorted(RECORDED_STD_HITS))
+def test_standard_branch_hits_match_recorded_runs(hmmfile):
+    """The hits of the recorded plain `bathsearch` runs: every hit of tutorial/PTH2.tbl (both strands) and the hit of
+    tutorial/AMP_N.out, to the printed digits.  Path: cascade -> Forward/Backward parsers -> domain decoding -> region
+    heuristics -> full Forward/Backward of the envelope -> posterior decoding -> optimal accuracy fill and traceback ->
+    null2 -> p7_pli_postDomainDef_BATH's score arithmetic and coordinate mapping."""
+    fasta, want = RECORDED_STD_HITS[hmmfile]
+    if hmmfile == "PTH2.bhmm":                       # the fixture really holds these rows
+        rows = [l.split() for l in open(ol.GOLDEN + "/PTH2.tbl") if l and l[0] != "#"]
+        assert [(int(r[6]), int(r[7]), int(r[9]), int(r[10]), r[12], r[13]) for r in rows] == want
+    m = ol.Model(ol.GOLDEN + "/" + hmmfile, 0)
+    seqs = [ol.digitize_dna(s) for _, s in ol.read_fasta(ol.GOLDEN + "/" + fasta)]
+    pli, dm, _, nskip = m.run_pipeline_hits(seqs)
+    got = sorted(dm, key=lambda d: -d.bitscore)
+    assert nskip == 0 and len(got) == len(want) and all(d.reported for d in got)
+    for d, (h1, h2, a1, a2, score, bias) in zip(got, want):
+        assert (d.iali, d.jali) == (a1, a2)
+        if h1 is not None:
+            assert (d.ihmm, d.jhmm) == (h1, h2)
+        assert "%.1f" % d.bitscore == score and "%.1f" % (d.dombias / np.log(2.0)) == bias
