@@ -162,6 +162,8 @@ ABI = {
                                             C.POINTER(C.POINTER(OrfResult)), _i64p]),
     "bath_hip_pipeline_frameshift": (C.c_int, [_vp, _vp, _vp, _vp, C.POINTER(PipelineParams), C.POINTER(PipelineStats),
                                               C.POINTER(C.POINTER(OrfResult)), _i64p, C.POINTER(C.POINTER(FsWindow)), _i64p]),
+    "bath_hip_pipeline_hits": (C.c_int, [_vp, _vp, _vp, C.POINTER(PipelineParams), C.c_double, C.POINTER(PipelineStats),
+                                         C.POINTER(C.POINTER(FsDomain)), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "bath_hip_pipeline_frameshift_domains": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.POINTER(PipelineParams), C.c_double, C.POINTER(PipelineStats),
                                                       C.POINTER(C.POINTER(FsWindow)), _i64p, C.POINTER(C.POINTER(FsDomain)), _i64p, _i64p]),
     "bath_hip_pipeline_timings": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_char_p), _f32p, _i64p]),
@@ -520,6 +522,20 @@ class Pipeline:
             C.memmove(C.byref(w), C.byref(fw[i]), C.sizeof(FsWindow))
             wins.append(w)
         return stats, out, wins
+
+    def run_hits(self, dna, E_report=10.0):
+        """bathsearch (no --fs) through domain definition and hit scores: (stats, [FsDomain], multi-domain regions skipped)."""
+        stats = PipelineStats()
+        dm = C.POINTER(FsDomain)(); ndm = C.c_int64(0)
+        nskip = C.c_int64(0)
+        self.ctx._check(lib().bath_hip_pipeline_hits(self.ctx._h, self.om._h, dna._h, C.byref(self.params), E_report, C.byref(stats),
+                                                     C.byref(dm), C.byref(ndm), C.byref(nskip)), "pipeline_hits")
+        out = []
+        for i in range(ndm.value):
+            x = FsDomain()
+            C.memmove(C.byref(x), C.byref(dm[i]), C.sizeof(FsDomain))
+            out.append(x)
+        return stats, out, nskip.value
 
     def run_frameshift_domains(self, om_fs3, om_fs5, dna, E_report=10.0):
         """bathsearch --fs through domain definition: (stats, [FsWindow], [FsDomain], multi-domain regions skipped)."""

@@ -46,6 +46,14 @@ struct DevBuf {
 
 struct StageTiming { const char *name; float ms; int64_t launches; };
 
+// An ORF that passed the Forward filter, as the domain-definition stage needs it (bath_domaindef.hip)
+struct PipelineSurvivor {
+  int64_t window;          // sequence index in the block
+  int64_t aa_off;          // its residues in the amino-acid stream pool
+  int32_t strand, start;   // start: first nucleotide, 1-based on the strand being read
+  int32_t n;               // residues
+};
+
 }  // namespace bath
 
 struct bath_hip_ctx {

@@ -169,3 +169,372 @@ extern "C" int bath_hip_pipeline_frameshift_domains(bath_hip_ctx *ctx, const bat
   *domains = ctx->fs_domains.data(); *n_domains = (int64_t)ctx->fs_domains.size();
   return BATH_OK;
 }
+
+// =================================================================================================================
+// Standard (non-frameshift) branch: what p7_Pipeline_BATH does with an ORF that passed the Forward filter
+// (src/p7_pipeline.c:1741-1771): p7_BackwardParser, p7_domaindef_ByPosteriorHeuristics_BATH (src/p7_domaindef.c:491-614)
+// with rescore_isolated_domain_bath (:1194-1325) for single-domain regions, p7_pli_postDomainDef_BATH (:1172-1300).
+//
+// The parsers and the envelopes' full Forward/Backward are the wave-per-target kernels of bath_filters.hip (the latter
+// with their matrix output and the unihit length model).  The rest of an envelope -- posterior decoding, the
+// optimal-accuracy fill and traceback, null2 (impl_sse/decoding.c:61, optacc.c:58,225, null2.c:50) -- is one kernel
+// with a LANE per envelope working serially on the matrices in HBM: the envelopes that reach this point are ~10^-4 of
+// the ORFs and a few 10^4 cells each, so round 1 keeps this stage simple and exact in operation order; it is not on the
+// headline path (bench.py times the filter cascade).
+// =================================================================================================================
+namespace {
+
+constexpr int kStdMaxRegions = 16;
+
+// p7_DomainDecoding (impl_sse/decoding.c:155-196) + region heuristics (p7_domaindef.c:520-533, 642-654), lane per ORF
+__global__ void std_regions_kernel(int64_t n, const int32_t *__restrict__ len, const float *__restrict__ fx, const float *__restrict__ bx,
+                                   const int64_t *__restrict__ x_off, const float *__restrict__ pmove_tab, float *__restrict__ work /* 3 floats per row */,
+                                   int32_t *__restrict__ regions /* [n][1 + 3*kStdMaxRegions] */) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  enum { XE = 0, XN, XJ, XB, XC, XS };
+  const int L = len[t];
+  const float *F = fx + x_off[t], *B = bx + x_off[t];
+  float *btot = work + (x_off[t] / 6) * 3, *etot = btot + (L + 1), *mocc = etot + (L + 1);
+  int32_t *out = regions + t * (1 + 3 * kStdMaxRegions);
+  out[0] = 0;
+  const float ploop = 1.0f - pmove_tab[L];                                   // xf[N|J|C][LOOP] of the multihit model at this length
+  float scaleproduct = (float)(1.0 / (double)B[XN]);
+  btot[0] = etot[0] = mocc[0] = 0.f;
+  for (int i = 1; i <= L; i++) {
+    btot[i] = btot[i - 1] + (F[(size_t)(i - 1) * 6 + XB] * B[(size_t)(i - 1) * 6 + XB] * F[(size_t)(i - 1) * 6 + XS] * scaleproduct);
+    scaleproduct *= F[(size_t)(i - 1) * 6 + XS] / B[(size_t)(i - 1) * 6 + XS];              // 1 unless Backward had to use its own scale factors
+    etot[i] = etot[i - 1] + (F[(size_t)i * 6 + XE] * B[(size_t)i * 6 + XE] * F[(size_t)i * 6 + XS] * scaleproduct);
+    float njcp = F[(size_t)(i - 1) * 6 + XN] * B[(size_t)i * 6 + XN] * ploop * scaleproduct;
+    njcp += F[(size_t)(i - 1) * 6 + XJ] * B[(size_t)i * 6 + XJ] * ploop * scaleproduct;
+    njcp += F[(size_t)(i - 1) * 6 + XC] * B[(size_t)i * 6 + XC] * ploop * scaleproduct;
+    mocc[i] = (float)(1. - njcp);
+  }
+  const float rt1 = 0.25f, rt2 = 0.10f, rt3 = 0.20f;
+  int i = -1, nreg = 0;
+  bool triggered = false;
+  for (int j = 1; j <= L; j++) {
+    if (!triggered) {
+      if (mocc[j] - (btot[j] - btot[j - 1]) < rt2) i = j;
+      else if (i == -1) i = j;
+      if (mocc[j] >= rt1) triggered = true;
+    } else if (mocc[j] - (etot[j] - etot[j - 1]) < rt2) {
+      float best = -1.0f;
+      for (int z = i; z <= j; z++) best = fmaxf(best, fminf(etot[z] - etot[i - 1], btot[j] - btot[z - 1]));
+      if (nreg < kStdMaxRegions) { out[1 + 3 * nreg] = i; out[2 + 3 * nreg] = j; out[3 + 3 * nreg] = best >= rt3 ? 1 : 0; }
+      nreg++;
+      i = -1; triggered = false;
+    }
+  }
+  out[0] = min(nreg, kStdMaxRegions);
+}
+
+struct StdEnvOut { int32_t i1, k1, i2, k2, ok; float oasc, domcorrection; };
+
+// p7_Decoding + p7_OptimalAccuracy + p7_OATrace + p7_Null2_ByExpectation on one envelope per lane (unihit model).
+// fwd / bck: (L+1) x (M+1) x {M, D, I}; on return bck holds the posteriors and fwd the OA matrix, as in the reference.
+__global__ void std_envelope_kernel(SeqView sq, int M, const float *__restrict__ tf, const float *__restrict__ rf, float *__restrict__ fwd, float *__restrict__ bck,
+                                    const int64_t *__restrict__ dp_off, const float *__restrict__ fx, const float *__restrict__ bx, const int64_t *__restrict__ x_off,
+                                    float *__restrict__ ppx_all, float *__restrict__ oax_all, float *__restrict__ em_all /* [n][2*(M+1)] */, StdEnvOut *__restrict__ out) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= sq.n) return;
+  enum { XE = 0, XN, XJ, XB, XC, XS };
+  enum { cM = 0, cD = 1, cI = 2 };
+  enum { MM = 0, IM, DM, BM, MD, DD, MI, II };
+  enum { sS = 0, sN, sB, sM, sD, sI, sE, sJ, sC };
+  const int L = sq.len[t];
+  const uint8_t *dsq = sq.data + sq.off[t] - 1;                              // dsq[1..L]
+  const size_t W = (size_t)(M + 1) * 3;
+  float *F = fwd + dp_off[t], *Bk = bck + dp_off[t];
+  const float *FX = fx + x_off[t], *BX = bx + x_off[t];
+  float *PX = ppx_all + (x_off[t] / 6) * 5, *OX = oax_all + (x_off[t] / 6) * 5;
+  StdEnvOut r{-1, -1, -1, -1, 0, 0.f, 0.f};
+  const float ploop = 1.0f - 2.0f / ((float)L + 2.0f);                       // unihit: xf[N|J|C][LOOP]
+  // ---- p7_Decoding (decoding.c:61-118): posteriors overwrite Backward
+  float scaleproduct = (float)(1.0 / (double)BX[XN]);
+  for (int k = 0; k <= M; k++) Bk[(size_t)k * 3] = Bk[(size_t)k * 3 + 1] = Bk[(size_t)k * 3 + 2] = 0.f;
+  for (int s = 0; s < 5; s++) PX[s] = 0.f;
+  for (int i = 1; i <= L; i++) {
+    const float totr = scaleproduct * FX[(size_t)i * 6 + XS];
+    const float *f = F + (size_t)i * W;
+    float *b = Bk + (size_t)i * W;
+    for (int k = 1; k <= M; k++) {
+      b[(size_t)k * 3 + cM] = f[(size_t)k * 3 + cM] * (b[(size_t)k * 3 + cM] * totr);
+      b[(size_t)k * 3 + cD] = 0.0f;
+      b[(size_t)k * 3 + cI] = f[(size_t)k * 3 + cI] * (b[(size_t)k * 3 + cI] * totr);
+    }
+    float *px = PX + (size_t)i * 5;
+    px[XE] = 0.f; px[XB] = 0.f;
+    px[XN] = FX[(size_t)(i - 1) * 6 + XN] * BX[(size_t)i * 6 + XN] * ploop * scaleproduct;
+    px[XJ] = FX[(size_t)(i - 1) * 6 + XJ] * BX[(size_t)i * 6 + XJ] * ploop * scaleproduct;
+    px[XC] = FX[(size_t)(i - 1) * 6 + XC] * BX[(size_t)i * 6 + XC] * ploop * scaleproduct;
+    scaleproduct *= FX[(size_t)i * 6 + XS] / BX[(size_t)i * 6 + XS];
+  }
+  if (isinf(scaleproduct)) { out[t] = r; return; }                           // eslERANGE: the domain is dropped (p7_domaindef.c:1214)
+  // ---- p7_OptimalAccuracy (optacc.c:58-173): the OA matrix overwrites Forward
+  const float *P = Bk;
+  float *O = F;
+  auto allow = [](float tr, float v) { return tr > 0.0f ? v : 0.0f; };
+  for (int k = 0; k <= M; k++) O[(size_t)k * 3] = O[(size_t)k * 3 + 1] = O[(size_t)k * 3 + 2] = -INFINITY;
+  OX[XE] = -INFINITY; OX[XN] = 0.f; OX[XJ] = -INFINITY; OX[XB] = 0.f; OX[XC] = -INFINITY;
+  for (int i = 1; i <= L; i++) {
+    const float *p = P + (size_t)i * W, *pr = O + (size_t)(i - 1) * W;
+    float *c = O + (size_t)i * W;
+    const float xB = OX[(size_t)(i - 1) * 5 + XB];
+    c[0] = c[1] = c[2] = -INFINITY;
+    float xE = -INFINITY, dcv = -INFINITY;
+    for (int k = 1; k <= M; k++) {
+      const float *tr = tf + (size_t)k * 8;
+      float sv = allow(tr[BM], xB);
+      sv = fmaxf(sv, allow(tr[MM], pr[(size_t)(k - 1) * 3 + cM]));
+      sv = fmaxf(sv, allow(tr[IM], pr[(size_t)(k - 1) * 3 + cI]));
+      sv = fmaxf(sv, allow(tr[DM], pr[(size_t)(k - 1) * 3 + cD]));
+      sv = sv + p[(size_t)k * 3 + cM];
+      xE = fmaxf(xE, sv);
+      c[(size_t)k * 3 + cM] = sv;
+      c[(size_t)k * 3 + cD] = dcv;
+      dcv = fmaxf(allow(tr[MD], sv), allow(tr[DD], dcv));
+      c[(size_t)k * 3 + cI] = fmaxf(allow(tr[MI], pr[(size_t)k * 3 + cM]), allow(tr[II], pr[(size_t)k * 3 + cI])) + p[(size_t)k * 3 + cI];
+    }
+    for (int k = 1; k <= M; k++) xE = fmaxf(xE, c[(size_t)k * 3 + cD]);
+    float *ox = OX + (size_t)i * 5;
+    const float *opx = OX + (size_t)(i - 1) * 5, *px = PX + (size_t)i * 5;
+    ox[XE] = xE;
+    ox[XJ] = fmaxf(opx[XJ] + px[XJ], 0.0f);                                  // unihit: xf[E][LOOP] == 0 -> the E->J term is 0.0 (optacc.c:156)
+    ox[XC] = fmaxf(opx[XC] + px[XC], xE);
+    ox[XN] = opx[XN] + px[XN];
+    ox[XB] = fmaxf(ox[XN], ox[XJ]);
+  }
+  r.oasc = OX[(size_t)L * 5 + XC];
+  // ---- p7_OATrace (optacc.c:225-430); select_e walks the cells in the reference's striped order
+  {
+    const int Q = max(2, (M - 1) / 4 + 1);
+    auto path = [](float tr, float v) { return tr == 0.0f ? -INFINITY : v; };
+    int i = L, k = 0, s0 = sC, steps = 0;
+    bool bad = false;
+    while (s0 != sS && !bad) {
+      int s1 = -1;
+      switch (s0) {
+      case sM: {
+        const float *tr = tf + (size_t)k * 8, *pr = O + (size_t)(i - 1) * W;
+        const float pm = path(tr[MM], pr[(size_t)(k - 1) * 3 + cM]), pi = path(tr[IM], pr[(size_t)(k - 1) * 3 + cI]);
+        const float pd = path(tr[DM], pr[(size_t)(k - 1) * 3 + cD]), pb = path(tr[BM], OX[(size_t)(i - 1) * 5 + XB]);
+        s1 = sM; float b = pm;
+        if (pi > b) { b = pi; s1 = sI; }
+        if (pd > b) { b = pd; s1 = sD; }
+        if (pb > b) { b = pb; s1 = sB; }
+        k--; i--; break; }
+      case sD: {
+        const float *tr = tf + (size_t)(k - 1) * 8, *c = O + (size_t)i * W;
+        const float pm = (k - 1 >= 1) ? path(tr[MD], c[(size_t)(k - 1) * 3 + cM]) : -INFINITY;
+        const float pd = (k - 1 >= 1) ? path(tr[DD], c[(size_t)(k - 1) * 3 + cD]) : -INFINITY;
+        s1 = pm >= pd ? sM : sD; k--; break; }
+      case sI: {
+        const float *tr = tf + (size_t)k * 8, *pr = O + (size_t)(i - 1) * W;
+        s1 = path(tr[MI], pr[(size_t)k * 3 + cM]) >= path(tr[II], pr[(size_t)k * 3 + cI]) ? sM : sI; i--; break; }
+      case sN: s1 = (i == 0) ? sS : sN; break;
+      case sC: s1 = (OX[(size_t)(i - 1) * 5 + XC] + PX[(size_t)i * 5 + XC] > OX[(size_t)i * 5 + XE]) ? sC : sE; break;
+      case sJ: s1 = sJ; break;                                                // unihit: E->J impossible, path[1] = -inf (optacc.c:384)
+      case sE: {
+        const float *c = O + (size_t)i * W;
+        float mx = -INFINITY; int smax = -1, kmax = -1;
+        for (int q = 0; q < Q; q++) {
+          for (int rr = 0; rr < 4; rr++) { const int kk = rr * Q + q + 1; if (kk <= M && c[(size_t)kk * 3 + cM] >= mx) { mx = c[(size_t)kk * 3 + cM]; smax = sM; kmax = kk; } }
+          for (int rr = 0; rr < 4; rr++) { const int kk = rr * Q + q + 1; if (kk <= M && c[(size_t)kk * 3 + cD] > mx) { mx = c[(size_t)kk * 3 + cD]; smax = sD; kmax = kk; } }
+        }
+        k = kmax; s1 = smax; break; }
+      case sB: s1 = (OX[(size_t)i * 5 + XN] > OX[(size_t)i * 5 + XJ]) ? sN : sJ; break;
+      default: bad = true; break;
+      }
+      if (bad || s1 < 0 || i < 0 || k < 0) { bad = true; break; }
+      if (s1 == sM) { if (r.i2 < 0) { r.i2 = i; r.k2 = k; } r.i1 = i; r.k1 = k; }
+      if ((s1 == sN || s1 == sJ || s1 == sC) && s1 == s0) i--;
+      s0 = s1;
+      if (++steps > 4 * (L + M) + 64) bad = true;
+    }
+    if (bad || r.i1 <= 0) { out[t] = r; return; }
+  }
+  // ---- p7_Null2_ByExpectation (null2.c:50-124) and the correction over the envelope (p7_domaindef.c:1264-1272)
+  {
+    float *em = em_all + (size_t)t * 2 * (M + 1);
+    float xN = PX[5 + XN], xC = PX[5 + XC], xJ = PX[5 + XJ];
+    for (int k = 1; k <= M; k++) { em[2 * k] = P[W + (size_t)k * 3 + cM]; em[2 * k + 1] = P[W + (size_t)k * 3 + cI]; }
+    for (int i = 2; i <= L; i++) {
+      const float *p = P + (size_t)i * W;
+      for (int k = 1; k <= M; k++) { em[2 * k] = p[(size_t)k * 3 + cM] + em[2 * k]; em[2 * k + 1] = p[(size_t)k * 3 + cI] + em[2 * k + 1]; }
+      xN += PX[(size_t)i * 5 + XN]; xC += PX[(size_t)i * 5 + XC]; xJ += PX[(size_t)i * 5 + XJ];
+    }
+    const float norm = (float)(1.0 / (double)(float)L);
+    for (int k = 1; k <= M; k++) { em[2 * k] *= norm; em[2 * k + 1] *= norm; }
+    xN *= norm; xC *= norm; xJ *= norm;
+    const float xfactor = xN + xC + xJ;
+    float null2[kKp];
+    for (int x = 0; x < 20; x++) {
+      const float *e = rf + (size_t)x * (M + 1);
+      float sv = 0.f;
+      for (int k = 1; k <= M; k++) { sv += em[2 * k] * e[k]; sv += em[2 * k + 1]; }
+      null2[x] = sv + xfactor;
+    }
+    const int mem[6][2] = {{2, 11}, {7, 9}, {3, 13}, {8, 8}, {1, 1}, {-1, -1}};      // B=DN J=IL Z=EQ O=K U=C X=any
+    for (int dx = 0; dx < 6; dx++) {
+      float sum = 0.f; int cnt = 0;
+      if (dx == 5) { for (int y = 0; y < 20; y++) { sum += null2[y]; cnt++; } }
+      else { const int a = min(mem[dx][0], mem[dx][1]), b = max(mem[dx][0], mem[dx][1]); sum += null2[a]; cnt++; if (b != a) { sum += null2[b]; cnt++; } }
+      null2[21 + dx] = sum / (float)cnt;
+    }
+    null2[20] = 1.0f; null2[27] = 1.0f; null2[28] = 1.0f;
+    float corr = 0.f;
+    for (int pos = 1; pos <= L; pos++) corr += logf(null2[min((int)dsq[pos], kKp - 1)]);
+    r.domcorrection = corr;
+  }
+  r.ok = 1;
+  out[t] = r;
+}
+
+}  // namespace
+
+extern "C" int bath_hip_pipeline_hits(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bath_hip_seqs *dna, const bath_pipeline_params *prm_in,
+                                      double E_report, bath_pipeline_stats *stats, const bath_fs_domain **domains, int64_t *n_domains,
+                                      int64_t *n_skipped_regions) {
+  if (!ctx || !om || !dna || !prm_in || !domains || !n_domains) return BATH_EINVAL;
+  *domains = nullptr; *n_domains = 0;
+  if (n_skipped_regions) *n_skipped_regions = 0;
+  ctx->fs_domains.clear();
+  bath_pipeline_params prm = *prm_in;
+  prm.fs_pipe = 0;
+  bath_pipeline_stats st_local{};
+  std::vector<PipelineSurvivor> surv;
+  const uint8_t *d_pool = nullptr;
+  int st = pipeline_filters_survivors(ctx, om, dna, &prm, &st_local, &surv, &d_pool);
+  if (st != BATH_OK) return st;
+  if (stats) *stats = st_local;
+  const int64_t ns = (int64_t)surv.size();
+  if (ns == 0) return BATH_OK;
+  const int M = om->M;
+
+  // ---- the survivors as a sequence view into the amino-acid streams; both parsers with their special-state rows
+  bath_hip_seqs view;
+  view.ctx = ctx; view.n = ns; view.is_part = true;
+  view.h_off.resize((size_t)ns); view.h_len.resize((size_t)ns);
+  std::vector<int64_t> xoff((size_t)ns + 1, 0);
+  for (int64_t i = 0; i < ns; i++) {
+    view.h_off[(size_t)i] = surv[(size_t)i].aa_off; view.h_len[(size_t)i] = surv[(size_t)i].n; view.maxlen = std::max(view.maxlen, surv[(size_t)i].n);
+    xoff[(size_t)i + 1] = xoff[(size_t)i] + ((int64_t)surv[(size_t)i].n + 1) * 6;
+  }
+  DevBuf &b_idx = ctx->scratch[0], &b_fx = ctx->scratch[6], &b_bx = ctx->scratch[7], &b_sc = ctx->scratch[2], &b_st = ctx->scratch[3], &b_work = ctx->scratch[4], &b_reg = ctx->scratch[5];
+  auto upload_view = [&](bath_hip_seqs &v, const std::vector<int64_t> &xo, int64_t n) -> int {
+    BATH_HIP_TRY(ctx, b_idx.reserve((size_t)n * 12 + (size_t)(n + 1) * 8 + 256));
+    int64_t *d_off = b_idx.as<int64_t>();
+    int64_t *d_xo = d_off + n;
+    int32_t *d_len = reinterpret_cast<int32_t *>(d_xo + n + 1);
+    BATH_HIP_TRY(ctx, hipMemcpyAsync(d_off, v.h_off.data(), (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    BATH_HIP_TRY(ctx, hipMemcpyAsync(d_xo, xo.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    BATH_HIP_TRY(ctx, hipMemcpyAsync(d_len, v.h_len.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    v.d_data = const_cast<uint8_t *>(d_pool); v.d_off = d_off; v.d_len = d_len;
+    return BATH_OK;
+  };
+  if ((st = om->ensure_len_tables(view.maxlen)) != BATH_OK) return st;
+  if ((st = upload_view(view, xoff, ns)) != BATH_OK) return st;
+  const int64_t *d_xoff = b_idx.as<int64_t>() + ns;
+  BATH_HIP_TRY(ctx, b_fx.reserve((size_t)xoff[(size_t)ns] * 4 + 64)); BATH_HIP_TRY(ctx, b_bx.reserve((size_t)xoff[(size_t)ns] * 4 + 64));
+  BATH_HIP_TRY(ctx, b_sc.reserve((size_t)ns * 8)); BATH_HIP_TRY(ctx, b_st.reserve((size_t)ns * 8));
+  BATH_HIP_TRY(ctx, b_work.reserve((size_t)xoff[(size_t)ns] / 6 * 3 * 4 + 64));
+  const int RS = 1 + 3 * kStdMaxRegions;
+  BATH_HIP_TRY(ctx, b_reg.reserve((size_t)ns * RS * 4 + 64));
+  if ((st = launch_fwd_wave(ctx, om, view.view(), nullptr, ns, b_sc.as<float>(), b_st.as<int32_t>(), nullptr, b_fx.as<float>(), d_xoff)) != BATH_OK) return st;
+  if ((st = launch_bwd_wave(ctx, om, view.view(), ns, b_fx.as<float>(), d_xoff, b_sc.as<float>() + ns, b_st.as<int32_t>() + ns, b_bx.as<float>())) != BATH_OK) return st;
+  hipLaunchKernelGGL(std_regions_kernel, dim3((unsigned)((ns + 63) / 64)), dim3(64), 0, ctx->stream, ns, view.d_len, b_fx.as<float>(), b_bx.as<float>(), d_xoff, om->lt.d_pmove,
+                     b_work.as<float>(), b_reg.as<int32_t>());
+  BATH_HIP_TRY(ctx, hipGetLastError());
+  std::vector<int32_t> regions((size_t)ns * RS);
+  BATH_HIP_TRY(ctx, hipMemcpyAsync(regions.data(), b_reg.p, regions.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+  BATH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  view.d_data = nullptr; view.d_off = nullptr; view.d_len = nullptr;
+
+  struct Env { int s, i, j; };
+  std::vector<Env> envs;
+  int n_multi = 0;
+  for (int64_t q = 0; q < ns; q++) {
+    const int32_t *r = &regions[(size_t)q * RS];
+    for (int k = 0; k < r[0]; k++) { if (r[3 + 3 * k]) n_multi++; else envs.push_back(Env{(int)q, r[1 + 3 * k], r[2 + 3 * k]}); }
+  }
+  if (n_skipped_regions) *n_skipped_regions = n_multi;
+  const int64_t ne = (int64_t)envs.size();
+  if (ne == 0) return BATH_OK;
+
+  // ---- envelopes: full Forward / Backward (unihit, L = Ld), then decoding, OA, traceback, null2
+  bath_hip_seqs ev;
+  ev.ctx = ctx; ev.n = ne; ev.is_part = true;
+  ev.h_off.resize((size_t)ne); ev.h_len.resize((size_t)ne);
+  std::vector<int64_t> exoff((size_t)ne + 1, 0), dpoff((size_t)ne + 1, 0);
+  for (int64_t e = 0; e < ne; e++) {
+    const Env &en = envs[(size_t)e];
+    const int Ld = en.j - en.i + 1;
+    ev.h_off[(size_t)e] = surv[(size_t)en.s].aa_off + en.i - 1; ev.h_len[(size_t)e] = Ld; ev.maxlen = std::max(ev.maxlen, Ld);
+    exoff[(size_t)e + 1] = exoff[(size_t)e] + ((int64_t)Ld + 1) * 6;
+    dpoff[(size_t)e + 1] = dpoff[(size_t)e] + ((int64_t)Ld + 1) * (M + 1) * 3;
+  }
+  if ((st = upload_view(ev, exoff, ne)) != BATH_OK) return st;
+  const int64_t *d_exoff = b_idx.as<int64_t>() + ne;
+  DevBuf &b_f = ctx->scratch[15], &b_b = ctx->scratch[16], &b_dpo = ctx->scratch[20], &b_px = ctx->scratch[18], &b_ox = ctx->scratch[19], &b_em = ctx->scratch[22], &b_out = ctx->scratch[21];
+  BATH_HIP_TRY(ctx, b_f.reserve((size_t)dpoff[(size_t)ne] * 4 + 64)); BATH_HIP_TRY(ctx, b_b.reserve((size_t)dpoff[(size_t)ne] * 4 + 64));
+  BATH_HIP_TRY(ctx, b_dpo.reserve((size_t)(ne + 1) * 8)); BATH_HIP_TRY(ctx, b_fx.reserve((size_t)exoff[(size_t)ne] * 4 + 64)); BATH_HIP_TRY(ctx, b_bx.reserve((size_t)exoff[(size_t)ne] * 4 + 64));
+  BATH_HIP_TRY(ctx, b_px.reserve((size_t)exoff[(size_t)ne] / 6 * 5 * 4 + 64)); BATH_HIP_TRY(ctx, b_ox.reserve((size_t)exoff[(size_t)ne] / 6 * 5 * 4 + 64));
+  BATH_HIP_TRY(ctx, b_em.reserve((size_t)ne * 2 * (M + 1) * 4 + 64)); BATH_HIP_TRY(ctx, b_out.reserve((size_t)ne * sizeof(StdEnvOut) + 64));
+  BATH_HIP_TRY(ctx, b_sc.reserve((size_t)ne * 8)); BATH_HIP_TRY(ctx, b_st.reserve((size_t)ne * 8));
+  BATH_HIP_TRY(ctx, hipMemcpyAsync(b_dpo.p, dpoff.data(), (size_t)(ne + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+  if ((st = launch_fwd_wave(ctx, om, ev.view(), nullptr, ne, b_sc.as<float>(), b_st.as<int32_t>(), nullptr, b_fx.as<float>(), d_exoff, b_f.as<float>(), b_dpo.as<int64_t>(), 1)) != BATH_OK) return st;
+  if ((st = launch_bwd_wave(ctx, om, ev.view(), ne, b_fx.as<float>(), d_exoff, b_sc.as<float>() + ne, b_st.as<int32_t>() + ne, b_bx.as<float>(), b_b.as<float>(), b_dpo.as<int64_t>(), 1)) != BATH_OK) return st;
+  hipLaunchKernelGGL(std_envelope_kernel, dim3((unsigned)((ne + 63) / 64)), dim3(64), 0, ctx->stream, ev.view(), M, om->d_tf, om->d_rf, b_f.as<float>(), b_b.as<float>(), b_dpo.as<int64_t>(),
+                     b_fx.as<float>(), b_bx.as<float>(), d_exoff, b_px.as<float>(), b_ox.as<float>(), b_em.as<float>(), b_out.as<StdEnvOut>());
+  BATH_HIP_TRY(ctx, hipGetLastError());
+  std::vector<StdEnvOut> eo((size_t)ne);
+  std::vector<float> envsc((size_t)ne);
+  BATH_HIP_TRY(ctx, hipMemcpyAsync(eo.data(), b_out.p, (size_t)ne * sizeof(StdEnvOut), hipMemcpyDeviceToHost, ctx->stream));
+  BATH_HIP_TRY(ctx, hipMemcpyAsync(envsc.data(), b_sc.p, (size_t)ne * 4, hipMemcpyDeviceToHost, ctx->stream));
+  BATH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  ev.d_data = nullptr; ev.d_off = nullptr; ev.d_len = nullptr;
+
+  // ---- p7_pli_postDomainDef_BATH: coordinates on the sequence, score corrections, P-value
+  const int ml = om->max_length;
+  const float Zf = (float)st_local.nres / (float)ml;
+  for (int64_t e = 0; e < ne; e++) {
+    const StdEnvOut &t = eo[(size_t)e];
+    if (!t.ok) continue;
+    const Env &en = envs[(size_t)e];
+    const PipelineSurvivor &o = surv[(size_t)en.s];
+    const int seq_n = dna->h_len[(size_t)o.window];
+    bath_fs_domain dm{};
+    dm.window = o.window; dm.strand = o.strand; dm.fs_window = -1;
+    dm.ihmm = t.k1; dm.jhmm = t.k2; dm.envsc = envsc[(size_t)e]; dm.oasc = t.oasc; dm.domcorrection = std::max(0.f, t.domcorrection);
+    // alignment in nucleotides of the window (= the ORF here): p7_trace_fs_Convert puts a residue on its codon's last nucleotide
+    const int a1 = t.i1 + en.i - 1, a2 = t.i2 + en.i - 1;
+    int iali = a1 * 3 - 2, jali = a2 * 3, ienv = en.i, jenv = en.j;
+    const int env_len = jenv - ienv + 1, ali_len = (jali - iali + 1) / 3;
+    if (ali_len < 4) continue;                                               // p7_pipeline.c:1197
+    if (!o.strand) {
+      dm.ienv = 1 + o.start + ienv * 3 - 4; dm.jenv = 1 + o.start + jenv * 3 - 2;
+      dm.iali = 1 + o.start + iali - 2;     dm.jali = 1 + o.start + jali - 2;
+    } else {                                                                 // the reference's orfsq->start is the top-strand coordinate
+      const int ostart_ref = seq_n - o.start + 1;
+      dm.ienv = 1 + ostart_ref - ienv * 3 + 2; dm.jenv = 1 + ostart_ref - jenv * 3;
+      dm.jali = seq_n - (o.start + jali) + 2;  dm.iali = seq_n - (o.start + iali) + 2;
+    }
+    float bitscore = dm.envsc;                                               // :1222-1226
+    bitscore -= 2 * std::log(2. / (env_len + 2));
+    bitscore += 2 * std::log(2. / (ml + 2));
+    bitscore -= (env_len - ali_len) * std::log((double)((float)env_len / (float)(env_len + 2)));
+    bitscore += (ml - ali_len) * std::log((double)((float)ml / (float)(ml + 2)));
+    const float dom_bias = flogsum_host(0.0f, (float)(std::log(1. / 256.) + dm.domcorrection));
+    const float p1 = (float)ml / (float)(ml + 1);
+    const float nullsc = (float)((float)ml * std::log((double)p1) + std::log(1. - p1));      // p7_bg_NullOne at max_length
+    dm.dombias = dom_bias;
+    dm.bitscore = (float)((bitscore - (nullsc + dom_bias)) / kLn2);
+    dm.pre_score = (float)(bitscore / kLn2);
+    dm.lnP = (double)(float)exp_logsurv(dm.bitscore, om->evparam[BATH_FTAU], om->evparam[BATH_FLAMBDA]);
+    dm.reported = (std::exp(dm.lnP) * (double)Zf <= E_report) ? 1 : 0;
+    ctx->fs_domains.push_back(dm);
+  }
+  *domains = ctx->fs_domains.data(); *n_domains = (int64_t)ctx->fs_domains.size();
+  return BATH_OK;
+}

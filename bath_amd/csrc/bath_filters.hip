@@ -317,7 +317,8 @@ __global__ __launch_bounds__(256) void fwd_wave_kernel(SeqView sq, int M, const 
                                                        const float *__restrict__ pmove_tab, FwdConsts c,
                                                        const int32_t *__restrict__ todo, int64_t ntodo, const int *__restrict__ ntodo_dev,
                                                        float *__restrict__ sc, int32_t *__restrict__ status,
-                                                       float *__restrict__ xmx, const int64_t *__restrict__ xmx_off) {
+                                                       float *__restrict__ xmx, const int64_t *__restrict__ xmx_off,
+                                                       float *__restrict__ dp, const int64_t *__restrict__ dp_off, int unihit) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   float *s_tf = reinterpret_cast<float *>(lds);          // [(M+1)*8]
   float *s_rf = s_tf + (size_t)(M + 1) * 8;              // [Kp][M+1]
@@ -333,7 +334,10 @@ __global__ __launch_bounds__(256) void fwd_wave_kernel(SeqView sq, int M, const 
     const int64_t sid = todo ? (int64_t)todo[job] : job;
     const int L = sq.len[sid];
     const uint8_t *s = sq.data + sq.off[sid];
-    const float pmove = pmove_tab[L], ploop = 1.0f - pmove;
+    // unihit (envelope rescoring, p7_oprofile_ReconfigUnihit): nj = 0, so pmove = 2/(L+2); a plain float division, as on the host
+    const float pmove = unihit ? (2.0f / ((float)L + 2.0f)) : pmove_tab[L], ploop = 1.0f - pmove;
+    float *dprow = dp ? dp + dp_off[sid] : nullptr;        // full matrix (p7_Forward): (L+1) x (M+1) x {M, D, I}
+    if (dprow) for (int k = lane; k <= M; k += 64) { dprow[(size_t)k * 3] = dprow[(size_t)k * 3 + 1] = dprow[(size_t)k * 3 + 2] = 0.f; }
     float Mp[C], Ip[C], Dp[C];
 #pragma unroll
     for (int k = 0; k < C; k++) Mp[k] = Ip[k] = Dp[k] = 0.f;
@@ -403,6 +407,12 @@ __global__ __launch_bounds__(256) void fwd_wave_kernel(SeqView sq, int M, const 
         xE = 1.0f;
       }
       if (xrow && lane == 0) { float *r = xrow + (size_t)i * 6; r[0] = xE; r[1] = xN; r[2] = xJ; r[3] = xB; r[4] = xC; r[5] = scale; }
+      if (dprow) {
+        float *r = dprow + (size_t)i * (M + 1) * 3;
+        if (lane == 0) r[0] = r[1] = r[2] = 0.f;
+#pragma unroll
+        for (int k = 0; k < C; k++) { const int node = lane * C + k + 1; if (node <= M) { r[(size_t)node * 3] = Mc[k]; r[(size_t)node * 3 + 1] = Dc[k]; r[(size_t)node * 3 + 2] = Ic[k]; } }
+      }
 #pragma unroll
       for (int k = 0; k < C; k++) { Mp[k] = Mc[k]; Ip[k] = Ic[k]; Dp[k] = Dc[k]; }
     }
@@ -422,7 +432,8 @@ template <int C>
 __global__ __launch_bounds__(256) void bwd_wave_kernel(SeqView sq, int M, const float *__restrict__ g_rf, const float *__restrict__ g_tf,
                                                        const float *__restrict__ pmove_tab, FwdConsts c, int64_t ntodo,
                                                        const float *__restrict__ fwd_xmx, const int64_t *__restrict__ xmx_off,
-                                                       float *__restrict__ sc, int32_t *__restrict__ status, float *__restrict__ bck_xmx) {
+                                                       float *__restrict__ sc, int32_t *__restrict__ status, float *__restrict__ bck_xmx,
+                                                       float *__restrict__ dp, const int64_t *__restrict__ dp_off, int unihit) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   float *s_tf = reinterpret_cast<float *>(lds);          // [(M+2)*8], node M+1 all zero
   float *s_rf = s_tf + (size_t)(M + 2) * 8;              // [Kp][M+2], column M+1 zero
@@ -435,7 +446,8 @@ __global__ __launch_bounds__(256) void bwd_wave_kernel(SeqView sq, int M, const 
   for (int64_t sid = wid; sid < ntodo; sid += nw) {
     const int L = sq.len[sid];
     const uint8_t *s = sq.data + sq.off[sid];
-    const float pmove = pmove_tab[L], ploop = 1.0f - pmove;
+    const float pmove = unihit ? (2.0f / ((float)L + 2.0f)) : pmove_tab[L], ploop = 1.0f - pmove;
+    float *dprow = dp ? dp + dp_off[sid] : nullptr;        // full matrix (p7_Backward), same layout as Forward's
     const float *fx = fwd_xmx + xmx_off[sid];
     float *bx = bck_xmx ? bck_xmx + xmx_off[sid] : nullptr;
     float xJ = 0.f, xB = 0.f, xN = 0.f, xC = pmove, xE = xC * c.xfE_move;
@@ -475,6 +487,13 @@ __global__ __launch_bounds__(256) void bwd_wave_kernel(SeqView sq, int M, const 
       }
       totscale = (float)log((double)scl);
       if (bx && lane == 0) { float *r = bx + (size_t)L * 6; r[0] = xE; r[1] = xN; r[2] = xJ; r[3] = xB; r[4] = xC; r[5] = scl; }
+      if (dprow) {
+        float *r = dprow + (size_t)L * (M + 1) * 3;
+        if (lane == 0) r[0] = r[1] = r[2] = 0.f;
+#pragma unroll
+        for (int k = 0; k < C; k++) { const int node = lane * C + k + 1; if (node <= M) { r[(size_t)node * 3] = Mn[k]; r[(size_t)node * 3 + 1] = Dn[k]; r[(size_t)node * 3 + 2] = In[k]; } }
+        for (int k = lane; k <= M; k += 64) { dprow[(size_t)k * 3] = dprow[(size_t)k * 3 + 1] = dprow[(size_t)k * 3 + 2] = 0.f; }      // row 0
+      }
     }
     bool own_scales = false;
     for (int i = L - 1; i >= 0; i--) {
@@ -541,6 +560,12 @@ __global__ __launch_bounds__(256) void bwd_wave_kernel(SeqView sq, int M, const 
         totscale += (float)log((double)scl);
       }
       if (bx && lane == 0) { float *r = bx + (size_t)i * 6; r[0] = xE; r[1] = xN; r[2] = xJ; r[3] = xB; r[4] = xC; r[5] = scl; }
+      if (dprow) {
+        float *r = dprow + (size_t)i * (M + 1) * 3;
+        if (lane == 0) r[0] = r[1] = r[2] = 0.f;
+#pragma unroll
+        for (int k = 0; k < C; k++) { const int node = lane * C + k + 1; if (node <= M) { r[(size_t)node * 3] = Mc[k]; r[(size_t)node * 3 + 1] = Dc[k]; r[(size_t)node * 3 + 2] = Ic[k]; } }
+      }
 #pragma unroll
       for (int k = 0; k < C; k++) { Mn[k] = Mc[k]; In[k] = Ic[k]; Dn[k] = Dc[k]; }
     }
@@ -675,30 +700,32 @@ int launch_vit_wave(bath_hip_ctx *ctx, const bath_hip_oprofile *om, SeqView v, c
 }
 
 int launch_fwd_wave(bath_hip_ctx *ctx, const bath_hip_oprofile *om, SeqView v, const int32_t *d_todo, int64_t ntodo, float *d_sc, int32_t *d_status, const int *ntodo_dev,
-                    float *d_xmx, const int64_t *d_xmx_off) {
+                    float *d_xmx, const int64_t *d_xmx_off, float *d_dp, const int64_t *d_dp_off, int unihit) {
   if (ntodo == 0) return BATH_OK;
   const int C = columns_per_lane(om->M);
   const int grid = wave_grid(ctx, ntodo);
   const size_t shmem = ((size_t)(om->M + 1) * 8 + (size_t)kKp * (om->M + 1)) * sizeof(float);
   FwdConsts c{om->xf_E[0], om->xf_E[1]};
+  if (unihit) { c.xfE_loop = 0.0f; c.xfE_move = 1.0f; }         // p7_oprofile_ReconfigUnihit, p7_oprofile.c:1421-1422
   BATH_C_SWITCH(C, {
     if (shmem > 64 * 1024) BATH_HIP_TRY(ctx, hipFuncSetAttribute((const void *)fwd_wave_kernel<CC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    hipLaunchKernelGGL(fwd_wave_kernel<CC>, dim3(grid), dim3(256), shmem, ctx->stream, v, om->M, om->d_rf, om->d_tf, om->lt.d_pmove, c, d_todo, ntodo, ntodo_dev, d_sc, d_status, d_xmx, d_xmx_off);
+    hipLaunchKernelGGL(fwd_wave_kernel<CC>, dim3(grid), dim3(256), shmem, ctx->stream, v, om->M, om->d_rf, om->d_tf, om->lt.d_pmove, c, d_todo, ntodo, ntodo_dev, d_sc, d_status, d_xmx, d_xmx_off, d_dp, d_dp_off, unihit);
   })
   BATH_HIP_TRY(ctx, hipGetLastError());
   return BATH_OK;
 }
 
 int launch_bwd_wave(bath_hip_ctx *ctx, const bath_hip_oprofile *om, SeqView v, int64_t n, const float *d_fwd_xmx, const int64_t *d_xmx_off,
-                    float *d_sc, int32_t *d_status, float *d_bck_xmx) {
+                    float *d_sc, int32_t *d_status, float *d_bck_xmx, float *d_dp, const int64_t *d_dp_off, int unihit) {
   if (n == 0) return BATH_OK;
   const int C = columns_per_lane(om->M);
   const int grid = wave_grid(ctx, n);
   const size_t shmem = ((size_t)(om->M + 2) * 8 + (size_t)kKp * (om->M + 2)) * sizeof(float);
   FwdConsts c{om->xf_E[0], om->xf_E[1]};
+  if (unihit) { c.xfE_loop = 0.0f; c.xfE_move = 1.0f; }
   BATH_C_SWITCH(C, {
     if (shmem > 64 * 1024) BATH_HIP_TRY(ctx, hipFuncSetAttribute((const void *)bwd_wave_kernel<CC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    hipLaunchKernelGGL(bwd_wave_kernel<CC>, dim3(grid), dim3(256), shmem, ctx->stream, v, om->M, om->d_rf, om->d_tf, om->lt.d_pmove, c, n, d_fwd_xmx, d_xmx_off, d_sc, d_status, d_bck_xmx);
+    hipLaunchKernelGGL(bwd_wave_kernel<CC>, dim3(grid), dim3(256), shmem, ctx->stream, v, om->M, om->d_rf, om->d_tf, om->lt.d_pmove, c, n, d_fwd_xmx, d_xmx_off, d_sc, d_status, d_bck_xmx, d_dp, d_dp_off, unihit);
   })
   BATH_HIP_TRY(ctx, hipGetLastError());
   return BATH_OK;

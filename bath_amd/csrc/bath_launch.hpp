@@ -29,9 +29,9 @@ int launch_msv_wave(bath_hip_ctx *ctx, const bath_hip_oprofile *om, SeqView v, c
 int launch_vit_wave(bath_hip_ctx *ctx, const bath_hip_oprofile *om, SeqView v, const int32_t *d_todo, int64_t ntodo, float *d_sc, int32_t *d_status,
                     const VitWindowArgs *wa, const int *ntodo_dev);
 int launch_fwd_wave(bath_hip_ctx *ctx, const bath_hip_oprofile *om, SeqView v, const int32_t *d_todo, int64_t ntodo, float *d_sc, int32_t *d_status, const int *ntodo_dev,
-                    float *d_xmx = nullptr, const int64_t *d_xmx_off = nullptr);
+                    float *d_xmx = nullptr, const int64_t *d_xmx_off = nullptr, float *d_dp = nullptr, const int64_t *d_dp_off = nullptr, int unihit = 0);
 int launch_bwd_wave(bath_hip_ctx *ctx, const bath_hip_oprofile *om, SeqView v, int64_t n, const float *d_fwd_xmx, const int64_t *d_xmx_off,
-                    float *d_sc, int32_t *d_status, float *d_bck_xmx);
+                    float *d_sc, int32_t *d_status, float *d_bck_xmx, float *d_dp = nullptr, const int64_t *d_dp_off = nullptr, int unihit = 0);
 int launch_bias_lane(bath_hip_ctx *ctx, const bath_hip_oprofile *om, SeqView v, const float *d_eo, int eo_stride, const int32_t *d_todo, int64_t ntodo,
                      float *d_nullsc, float *d_filtersc);
 
@@ -42,6 +42,10 @@ int launch_vit_lane(bath_hip_ctx *ctx, const bath_hip_oprofile *om, SeqView v, c
 const int *len_sort_count_longer(const int *d_bins, int T);     // device pointer: after launch_len_sort, the number of targets longer than T
 struct MsvConsts;
 MsvConsts msv_consts(const bath_hip_oprofile *om);
+
+// ---- the cascade, returning the ORFs that pass the Forward filter (bath_pipeline.hip); *d_pool stays valid until the next pipeline call on ctx
+int pipeline_filters_survivors(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bath_hip_seqs *dna, const bath_pipeline_params *prm,
+                               bath_pipeline_stats *stats, std::vector<PipelineSurvivor> *out, const uint8_t **d_pool);
 
 // ---- DNA regions gathered into a pool for the frameshift kernels (bath_pipeline.hip)
 struct FsWinDev {                  // one DNA window / envelope, device view

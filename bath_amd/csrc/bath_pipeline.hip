@@ -985,6 +985,36 @@ struct DnaWin { int64_t n; int32_t k, length; };
 
 }  // namespace bath
 
+int bath::pipeline_filters_survivors(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bath_hip_seqs *dna, const bath_pipeline_params *prm,
+                                     bath_pipeline_stats *stats, std::vector<PipelineSurvivor> *out, const uint8_t **d_pool) {
+  out->clear();
+  FilterState S;
+  int st = run_filters(ctx, om, dna, prm, stats, nullptr, nullptr, &S);
+  if (st != BATH_OK) return st;
+  *d_pool = S.W.pool;
+  const int nc = S.hc.cand_count;
+  if (nc <= 0) return BATH_OK;
+  std::vector<int32_t> h_stage(nc), h_sf(nc), h_startj(nc), h_len(nc);
+  std::vector<int64_t> h_window(nc), h_off(nc);
+  auto pull = [&](void *dst, const void *src, size_t bytes) { return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream); };
+  BATH_HIP_TRY(ctx, pull(h_stage.data(), S.W.cand.stage, (size_t)nc * 4)); BATH_HIP_TRY(ctx, pull(h_sf.data(), S.W.cand.sf, (size_t)nc * 4));
+  BATH_HIP_TRY(ctx, pull(h_startj.data(), S.W.cand.startj, (size_t)nc * 4)); BATH_HIP_TRY(ctx, pull(h_len.data(), S.W.cand.len, (size_t)nc * 4));
+  BATH_HIP_TRY(ctx, pull(h_window.data(), S.W.cand.window, (size_t)nc * 8)); BATH_HIP_TRY(ctx, pull(h_off.data(), S.W.cand.off, (size_t)nc * 8));
+  BATH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  for (int c = 0; c < nc; c++) {
+    if (h_stage[c] != 4) continue;
+    PipelineSurvivor o;
+    o.window = h_window[c]; o.aa_off = h_off[c]; o.strand = h_sf[c] / 3; o.start = h_sf[c] % 3 + 3 * h_startj[c] + 1; o.n = h_len[c];
+    out->push_back(o);
+  }
+  std::sort(out->begin(), out->end(), [](const PipelineSurvivor &a, const PipelineSurvivor &b) {
+    if (a.window != b.window) return a.window < b.window;
+    if (a.strand != b.strand) return a.strand < b.strand;
+    return a.start < b.start;
+  });
+  return BATH_OK;
+}
+
 extern "C" int bath_hip_pipeline_frameshift(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bath_hip_fsprofile *om_fs3, const bath_hip_seqs *dna,
                                             const bath_pipeline_params *prm_in, bath_pipeline_stats *stats,
                                             const bath_orf_result **results, int64_t *n_results,

@@ -298,10 +298,12 @@ int bo_domaindef_std(bo_pipeline *pli, bo_oprofile *om, bo_bg *bg, const uint8_t
   bo_oprofile_reconfig_multihit(om, n);
 
   /* ---- p7_pli_postDomainDef_BATH, p7_pipeline.c:1172-1300; dnasq->start = 1 / seq_n, dnasq->end = seq_n / 1 */
+  int kept = first;
   for (int q = first; q < *ndom; q++) {
-    bo_fsdomain *dm = &(*doms)[q];
-    const int env_len = dm->jenv - dm->ienv + 1, ali_len = (dm->jali - dm->iali + 1) / 3;
-    if (ali_len < 4) { dm->reported = 0; continue; }
+    const int env_len = (*doms)[q].jenv - (*doms)[q].ienv + 1, ali_len = ((*doms)[q].jali - (*doms)[q].iali + 1) / 3;
+    if (ali_len < 4) continue;                      /* :1194-1200: no hit for such a domain */
+    bo_fsdomain *dm = &(*doms)[kept++];
+    *dm = (*doms)[q];
     if (!complementarity) {
       dm->ienv = 1 + orf_start + dm->ienv * 3 - 4; dm->jenv = 1 + orf_start + dm->jenv * 3 - 2;
       dm->iali = 1 + win_start + dm->iali - 2;     dm->jali = 1 + win_start + dm->jali - 2;
@@ -326,5 +328,6 @@ int bo_domaindef_std(bo_pipeline *pli, bo_oprofile *om, bo_bg *bg, const uint8_t
     dm->dombias = dom_bias; dm->bitscore = dom_score; dm->lnP = lnP; dm->pre_score = (float)(bitscore / LOG2C);
     dm->reported = (exp(lnP) * Z <= pli->E) ? 1 : 0;
   }
+  *ndom = kept;
   return BO_OK;
 }

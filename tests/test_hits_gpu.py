@@ -1,0 +1,111 @@
+"""The standard branch after the Forward filter on the GPU (bath_hip_pipeline_hits): Backward parser, domain decoding,
+region heuristics, the envelope's full Forward/Backward (unihit), posterior decoding, optimal-accuracy fill and traceback,
+null2, and the hit's score arithmetic -- against the oracle (oracle/domaindef.c) and against what the reference itself
+recorded (tutorial/PTH2.tbl, tutorial/AMP_N.out).
+
+Integer outputs (envelope, alignment and model coordinates) must be identical.  The envelope score is a Forward score
+(1e-4 relative, as in tests/test_filters_gpu.py); oasc / domcorrection are sums of posteriors computed from products of
+Forward and Backward values, each 1e-4 relative, over up to Ld terms: 2e-3 absolute + 1e-3 relative.  Bit scores inherit
+the envelope score's tolerance divided by ln 2."""
+import numpy as np
+import pytest
+
+import bath_amd as ba
+import common
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+
+RECORDED_STD_HITS = {   # tutorial/PTH2.tbl and tutorial/AMP_N.out: (hmm from, hmm to, ali from, ali to, score, bias)
+    "PTH2.bhmm": ("target-PTH2.fa", [(2, 116, 672, 325, "110.6", "0.3"), (35, 116, 1486, 1731, "86.4", "0.0"),
+                                     (71, 113, 2468, 2343, "36.2", "0.0"), (2, 30, 1273, 1359, "36.0", "0.3")]),
+    "AMP_N.bhmm": ("target-AMP_N.fa", [(None, None, 7, 234, "47.8", "0.0")]),
+}
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    return ba.Context(0)
+
+
+def gpu_hits(ctx, path, idx, wins):
+    hmm = ba.HMM(path, idx)
+    om = ba.OProfile(ctx, ba.Profile(hmm))
+    pipe = ba.Pipeline(ctx, om, fs_pipe=False, ncbi_table=hmm.ct)
+    return pipe.run_hits(ba.SeqBlock(ctx, wins))
+
+
+@pytest.mark.parametrize("hmmfile", sorted(RECORDED_STD_HITS))
+def test_hits_match_recorded_runs(ctx, hmmfile):
+    fasta, want = RECORDED_STD_HITS[hmmfile]
+    if hmmfile == "PTH2.bhmm":
+        rows = [l.split() for l in open(ol.GOLDEN + "/PTH2.tbl") if l and l[0] != "#"]
+        assert [(int(r[6]), int(r[7]), int(r[9]), int(r[10]), r[12], r[13]) for r in rows] == want
+    seqs = [ol.digitize_dna(s) for _, s in ol.read_fasta(ol.GOLDEN + "/" + fasta)]
+    stats, dm, nskip = gpu_hits(ctx, ol.GOLDEN + "/" + hmmfile, 0, seqs)
+    got = sorted(dm, key=lambda d: -d.bitscore)
+    assert nskip == 0 and len(got) == len(want) and all(d.reported for d in got)
+    for d, (h1, h2, a1, a2, score, bias) in zip(got, want):
+        assert (d.iali, d.jali) == (a1, a2)
+        if h1 is not None:
+            assert (d.ihmm, d.jhmm) == (h1, h2)
+        assert "%.1f" % d.bitscore == score and "%.1f" % (d.dombias / np.log(2.0)) == bias
+
+
+def compare_hits(dm, odm, per_d, nskip, onskip):
+    want = []
+    for w, (a, b) in enumerate(per_d):
+        want += [(w, o) for o in odm[a:b]]
+    want.sort(key=lambda t: (t[0], t[1].ienv, t[1].jenv))
+    got = sorted(dm, key=lambda g: (g.window, g.ienv, g.jenv))
+    assert nskip == onskip
+    assert len(got) == len(want)
+    for g, (w, o) in zip(got, want):
+        assert (g.window, g.strand) == (w, 1 if o.ienv > o.jenv else 0)
+        assert (g.ienv, g.jenv, g.iali, g.jali, g.ihmm, g.jhmm) == (o.ienv, o.jenv, o.iali, o.jali, o.ihmm, o.jhmm)
+        assert abs(g.envsc - o.envsc) <= 1e-4 * max(1.0, abs(o.envsc))
+        assert abs(g.oasc - o.oasc) <= 2e-3 + 1e-3 * abs(o.oasc)
+        assert abs(g.domcorrection - o.domcorrection) <= 2e-3 + 1e-3 * abs(o.domcorrection)
+        assert abs(g.dombias - o.dombias) <= 2e-3
+        assert abs(g.bitscore - o.bitscore) <= (1e-4 * max(1.0, abs(o.envsc)) + 4e-3) / np.log(2.0)
+        assert abs(g.pre_score - o.pre_score) <= (1e-4 * max(1.0, abs(o.envsc)) + 1e-3) / np.log(2.0)
+        assert abs(g.lnP - o.lnP) <= 0.7 * ((1e-4 * max(1.0, abs(o.envsc)) + 4e-3) / np.log(2.0)) + 1e-6
+    return len(got)
+
+
+@pytest.mark.parametrize("hmmfile,idx", [("PTH2.bhmm", 0), ("Caudal_act.bhmm", 0), ("AMP_N.bhmm", 0), ("MET-ct4.bhmm", 1)])
+def test_hits_match_oracle_on_planted_genes(ctx, hmmfile, idx):
+    path = ol.GOLDEN + "/" + hmmfile
+    model = ol.Model(path, idx)
+    rng = np.random.default_rng(77 + idx)
+    wins = []
+    genes = common.emit_from_model(rng, model, 16, flank=5) + common.emit_from_model(rng, model, 16, flank=5, sharpen=2.0)
+    for i, aa in enumerate(genes):
+        nt = np.array(common.revtranslate(rng, aa, model.basic), dtype=np.uint8)
+        pre = rng.integers(0, 4, size=int(rng.integers(0, 300))).astype(np.uint8)
+        post = rng.integers(0, 4, size=int(rng.integers(0, 300))).astype(np.uint8)
+        w = np.concatenate([pre, nt, post]).astype(np.uint8)
+        if i % 2:
+            w = (3 - w[::-1]).astype(np.uint8)
+        wins.append(w)
+    # truncated genes (short envelopes, alignments at the ORF's ends) and background
+    for i in range(6):
+        g = np.array(common.revtranslate(rng, genes[i], model.basic), dtype=np.uint8)
+        cut = max(60, len(g) // 3)
+        wins.append(g[:cut] if i % 2 else g[-cut:])
+    wins += common.random_dna(rng, 30, 1000)
+    stats, dm, nskip = gpu_hits(ctx, path, idx, wins)
+    pli, odm, per_d, onskip = model.run_pipeline_hits(wins)
+    assert (stats.n_past_fwd, stats.pos_past_fwd) == (pli.n_past_fwd, pli.pos_past_fwd)
+    n = compare_hits(dm, odm, per_d, nskip, onskip)
+    assert n >= 8
+
+
+def test_hits_empty_and_background(ctx):
+    path = ol.GOLDEN + "/Caudal_act.bhmm"
+    rng = np.random.default_rng(5)
+    wins = common.random_dna(rng, 50, 1000) + [np.zeros(0, dtype=np.uint8), np.zeros(10, dtype=np.uint8)]
+    stats, dm, nskip = gpu_hits(ctx, path, 0, wins)
+    model = ol.Model(path, 0)
+    pli, odm, per_d, onskip = model.run_pipeline_hits(wins)
+    compare_hits(dm, odm, per_d, nskip, onskip)
