@@ -52,6 +52,8 @@ struct PipelineSurvivor {
   int64_t aa_off;          // its residues in the amino-acid stream pool
   int32_t strand, start;   // start: first nucleotide, 1-based on the strand being read
   int32_t n;               // residues
+  int32_t win_start = 0;   // windowsq->start on that strand: the ORF's own start, or the DNA window's in the --fs pipeline
+  int32_t fs_window = -1;  // index of that DNA window in the frameshift stage's output
 };
 
 }  // namespace bath
@@ -70,6 +72,8 @@ struct bath_hip_ctx {
   std::vector<bath_orf> orfs;             // bath_hip_translate_orfs output
   std::vector<bath_fs_window> fs_windows; // bath_hip_pipeline_frameshift output
   std::vector<bath_fs_domain> fs_domains; // bath_hip_pipeline_frameshift_domains output
+  std::vector<bath::PipelineSurvivor> fs_std_orfs;   // ORFs of the windows that take the standard branch (p7_pipeline.c:1479-1510)
+  const uint8_t *fs_std_pool = nullptr;              // their residues: the amino-acid streams of the last cascade
   std::vector<uint8_t> orf_aa;
   std::vector<bath::StageTiming> timings;
   std::vector<hipEvent_t> ev_pool;

@@ -39,11 +39,14 @@ double exp_logsurv(double x, double mu, double lambda) { return x < mu ? 0.0 : -
 
 }  // namespace
 
-extern "C" int bath_hip_pipeline_frameshift_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bath_hip_fsprofile *om_fs3,
-                                                    const bath_hip_fsprofile *om_fs5, const bath_hip_seqs *dna, const bath_pipeline_params *prm,
-                                                    double E_report, bath_pipeline_stats *stats,
-                                                    const bath_fs_window **fs_windows, int64_t *n_fs_windows,
-                                                    const bath_fs_domain **domains, int64_t *n_domains, int64_t *n_skipped_regions) {
+static int std_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bath_hip_seqs *dna, const std::vector<PipelineSurvivor> &surv,
+                       const uint8_t *d_pool, int64_t nres, double E_report, int64_t *n_skipped_regions);
+
+static int fs_branch_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bath_hip_fsprofile *om_fs3,
+                             const bath_hip_fsprofile *om_fs5, const bath_hip_seqs *dna, const bath_pipeline_params *prm,
+                             double E_report, bath_pipeline_stats *stats,
+                             const bath_fs_window **fs_windows, int64_t *n_fs_windows,
+                             const bath_fs_domain **domains, int64_t *n_domains, int64_t *n_skipped_regions) {
   if (!ctx || !om || !om_fs3 || !om_fs5 || !dna || !prm || !domains || !n_domains) return BATH_EINVAL;
   if (fsprofile_codon_lengths(om_fs5) != 5) { ctx->set_error("domain definition needs the 5-codon frameshift profile"); return BATH_EINVAL; }
   *domains = nullptr; *n_domains = 0;
@@ -166,6 +169,25 @@ extern "C" int bath_hip_pipeline_frameshift_domains(bath_hip_ctx *ctx, const bat
     } else { dm.ienv = ienv; dm.jenv = jenv; dm.iali = iali; dm.jali = jali; dm.reported = 0; }
     ctx->fs_domains.push_back(dm);
   }
+  *domains = ctx->fs_domains.data(); *n_domains = (int64_t)ctx->fs_domains.size();
+  return BATH_OK;
+}
+
+// p7_pli_Frameshift's two branches (p7_pipeline.c:1464-1510): windows that take the frameshift branch get the codon-model
+// domain definition above; in the others every ORF with P <= F3 goes through the standard domain definition below, its
+// alignment placed on the DNA window's coordinates.
+extern "C" int bath_hip_pipeline_frameshift_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bath_hip_fsprofile *om_fs3,
+                                                    const bath_hip_fsprofile *om_fs5, const bath_hip_seqs *dna, const bath_pipeline_params *prm,
+                                                    double E_report, bath_pipeline_stats *stats,
+                                                    const bath_fs_window **fs_windows, int64_t *n_fs_windows,
+                                                    const bath_fs_domain **domains, int64_t *n_domains, int64_t *n_skipped_regions) {
+  bath_pipeline_stats st_local{};
+  int st = fs_branch_domains(ctx, om, om_fs3, om_fs5, dna, prm, E_report, &st_local, fs_windows, n_fs_windows, domains, n_domains, n_skipped_regions);
+  if (st != BATH_OK) return st;
+  if (stats) *stats = st_local;
+  int64_t nskip = n_skipped_regions ? *n_skipped_regions : 0;
+  if ((st = std_domains(ctx, om, dna, ctx->fs_std_orfs, ctx->fs_std_pool, st_local.nres, E_report, &nskip)) != BATH_OK) return st;
+  if (n_skipped_regions) *n_skipped_regions = nskip;
   *domains = ctx->fs_domains.data(); *n_domains = (int64_t)ctx->fs_domains.size();
   return BATH_OK;
 }
@@ -393,21 +415,10 @@ __global__ void std_envelope_kernel(SeqView sq, int M, const float *__restrict__
 
 }  // namespace
 
-extern "C" int bath_hip_pipeline_hits(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bath_hip_seqs *dna, const bath_pipeline_params *prm_in,
-                                      double E_report, bath_pipeline_stats *stats, const bath_fs_domain **domains, int64_t *n_domains,
-                                      int64_t *n_skipped_regions) {
-  if (!ctx || !om || !dna || !prm_in || !domains || !n_domains) return BATH_EINVAL;
-  *domains = nullptr; *n_domains = 0;
-  if (n_skipped_regions) *n_skipped_regions = 0;
-  ctx->fs_domains.clear();
-  bath_pipeline_params prm = *prm_in;
-  prm.fs_pipe = 0;
-  bath_pipeline_stats st_local{};
-  std::vector<PipelineSurvivor> surv;
-  const uint8_t *d_pool = nullptr;
-  int st = pipeline_filters_survivors(ctx, om, dna, &prm, &st_local, &surv, &d_pool);
-  if (st != BATH_OK) return st;
-  if (stats) *stats = st_local;
+// Domain definition and hit scores for ORFs that passed the Forward filter; appends to ctx->fs_domains.
+static int std_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bath_hip_seqs *dna, const std::vector<PipelineSurvivor> &surv,
+                       const uint8_t *d_pool, int64_t nres, double E_report, int64_t *n_skipped_regions) {
+  int st;
   const int64_t ns = (int64_t)surv.size();
   if (ns == 0) return BATH_OK;
   const int M = om->M;
@@ -458,7 +469,7 @@ extern "C" int bath_hip_pipeline_hits(bath_hip_ctx *ctx, const bath_hip_oprofile
     const int32_t *r = &regions[(size_t)q * RS];
     for (int k = 0; k < r[0]; k++) { if (r[3 + 3 * k]) n_multi++; else envs.push_back(Env{(int)q, r[1 + 3 * k], r[2 + 3 * k]}); }
   }
-  if (n_skipped_regions) *n_skipped_regions = n_multi;
+  if (n_skipped_regions) *n_skipped_regions += n_multi;
   const int64_t ne = (int64_t)envs.size();
   if (ne == 0) return BATH_OK;
 
@@ -497,7 +508,7 @@ extern "C" int bath_hip_pipeline_hits(bath_hip_ctx *ctx, const bath_hip_oprofile
 
   // ---- p7_pli_postDomainDef_BATH: coordinates on the sequence, score corrections, P-value
   const int ml = om->max_length;
-  const float Zf = (float)st_local.nres / (float)ml;
+  const float Zf = (float)nres / (float)ml;
   for (int64_t e = 0; e < ne; e++) {
     const StdEnvOut &t = eo[(size_t)e];
     if (!t.ok) continue;
@@ -505,20 +516,21 @@ extern "C" int bath_hip_pipeline_hits(bath_hip_ctx *ctx, const bath_hip_oprofile
     const PipelineSurvivor &o = surv[(size_t)en.s];
     const int seq_n = dna->h_len[(size_t)o.window];
     bath_fs_domain dm{};
-    dm.window = o.window; dm.strand = o.strand; dm.fs_window = -1;
+    dm.window = o.window; dm.strand = o.strand; dm.fs_window = o.fs_window;
     dm.ihmm = t.k1; dm.jhmm = t.k2; dm.envsc = envsc[(size_t)e]; dm.oasc = t.oasc; dm.domcorrection = std::max(0.f, t.domcorrection);
-    // alignment in nucleotides of the window (= the ORF here): p7_trace_fs_Convert puts a residue on its codon's last nucleotide
-    const int a1 = t.i1 + en.i - 1, a2 = t.i2 + en.i - 1;
-    int iali = a1 * 3 - 2, jali = a2 * 3, ienv = en.i, jenv = en.j;
+    // alignment in nucleotides of the window (the ORF itself in the plain pipeline): p7_trace_fs_Convert puts a residue on its
+    // codon's last nucleotide, offset by where the ORF starts in the window
+    const int a1 = t.i1 + en.i - 1, a2 = t.i2 + en.i - 1, shift = o.start - o.win_start;
+    int iali = shift + a1 * 3 - 2, jali = shift + a2 * 3, ienv = en.i, jenv = en.j;
     const int env_len = jenv - ienv + 1, ali_len = (jali - iali + 1) / 3;
     if (ali_len < 4) continue;                                               // p7_pipeline.c:1197
     if (!o.strand) {
       dm.ienv = 1 + o.start + ienv * 3 - 4; dm.jenv = 1 + o.start + jenv * 3 - 2;
-      dm.iali = 1 + o.start + iali - 2;     dm.jali = 1 + o.start + jali - 2;
+      dm.iali = 1 + o.win_start + iali - 2; dm.jali = 1 + o.win_start + jali - 2;
     } else {                                                                 // the reference's orfsq->start is the top-strand coordinate
       const int ostart_ref = seq_n - o.start + 1;
       dm.ienv = 1 + ostart_ref - ienv * 3 + 2; dm.jenv = 1 + ostart_ref - jenv * 3;
-      dm.jali = seq_n - (o.start + jali) + 2;  dm.iali = seq_n - (o.start + iali) + 2;
+      dm.jali = seq_n - (o.win_start + jali) + 2; dm.iali = seq_n - (o.win_start + iali) + 2;
     }
     float bitscore = dm.envsc;                                               // :1222-1226
     bitscore -= 2 * std::log(2. / (env_len + 2));
@@ -535,6 +547,27 @@ extern "C" int bath_hip_pipeline_hits(bath_hip_ctx *ctx, const bath_hip_oprofile
     dm.reported = (std::exp(dm.lnP) * (double)Zf <= E_report) ? 1 : 0;
     ctx->fs_domains.push_back(dm);
   }
+  return BATH_OK;
+}
+
+extern "C" int bath_hip_pipeline_hits(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bath_hip_seqs *dna, const bath_pipeline_params *prm_in,
+                                      double E_report, bath_pipeline_stats *stats, const bath_fs_domain **domains, int64_t *n_domains,
+                                      int64_t *n_skipped_regions) {
+  if (!ctx || !om || !dna || !prm_in || !domains || !n_domains) return BATH_EINVAL;
+  *domains = nullptr; *n_domains = 0;
+  int64_t nskip = 0;
+  ctx->fs_domains.clear();
+  bath_pipeline_params prm = *prm_in;
+  prm.fs_pipe = 0;
+  bath_pipeline_stats st_local{};
+  std::vector<PipelineSurvivor> surv;
+  const uint8_t *d_pool = nullptr;
+  int st = pipeline_filters_survivors(ctx, om, dna, &prm, &st_local, &surv, &d_pool);
+  if (st != BATH_OK) return st;
+  if (stats) *stats = st_local;
+  for (PipelineSurvivor &o : surv) o.win_start = o.start;                  // windowsq is the ORF's own stretch of DNA (p7_pipeline.c:1755)
+  if ((st = std_domains(ctx, om, dna, surv, d_pool, st_local.nres, E_report, &nskip)) != BATH_OK) return st;
+  if (n_skipped_regions) *n_skipped_regions = nskip;
   *domains = ctx->fs_domains.data(); *n_domains = (int64_t)ctx->fs_domains.size();
   return BATH_OK;
 }

@@ -1035,7 +1035,7 @@ extern "C" int bath_hip_pipeline_frameshift(bath_hip_ctx *ctx, const bath_hip_op
 
   // ---- the ORFs that passed F4, with their hit windows
   std::vector<int32_t> h_stage(nc), h_sf(nc), h_startj(nc), h_len(nc);
-  std::vector<int64_t> h_window(nc);
+  std::vector<int64_t> h_window(nc), h_aaoff(nc);
   std::vector<float> h_fw(nc), h_null(nc);
   std::vector<double> h_P(nc);
   const int nwins = std::min(S.hc.win_count, S.W.win_cap);
@@ -1046,6 +1046,7 @@ extern "C" int bath_hip_pipeline_frameshift(bath_hip_ctx *ctx, const bath_hip_op
     BATH_HIP_TRY(ctx, pull(h_startj.data(), S.W.cand.startj, (size_t)nc * 4)); BATH_HIP_TRY(ctx, pull(h_len.data(), S.W.cand.len, (size_t)nc * 4));
     BATH_HIP_TRY(ctx, pull(h_window.data(), S.W.cand.window, (size_t)nc * 8)); BATH_HIP_TRY(ctx, pull(h_fw.data(), S.W.cand.fwdsc, (size_t)nc * 4));
     BATH_HIP_TRY(ctx, pull(h_null.data(), S.W.cand.nullsc, (size_t)nc * 4)); BATH_HIP_TRY(ctx, pull(h_P.data(), S.W.cand.P, (size_t)nc * 8));
+    BATH_HIP_TRY(ctx, pull(h_aaoff.data(), S.W.cand.off, (size_t)nc * 8));
     if (nwins > 0) BATH_HIP_TRY(ctx, pull(h_wins.data(), S.W.wins, (size_t)nwins * sizeof(WindowRec)));
     BATH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   }
@@ -1086,7 +1087,7 @@ extern "C" int bath_hip_pipeline_frameshift(bath_hip_ctx *ctx, const bath_hip_op
   // ---- p7_pli_BuildDNAWindows + the per-window ORF summary of p7_pli_Frameshift
   std::vector<bath_fs_window> out;
   std::vector<FsWinDev> dev;
-  std::vector<int64_t> std_branch_pos;            // pos_past_fwd the standard branch would add for each window
+  std::vector<std::vector<PipelineSurvivor>> std_branch_orfs;   // per window: the ORFs the standard branch would take (:1479-1487)
   for (auto &g : groups) {
     const int64_t w = g.first.w;
     const int strand = g.first.strand;
@@ -1135,7 +1136,7 @@ extern "C" int bath_hip_pipeline_frameshift(bath_hip_ctx *ctx, const bath_hip_op
       int orf_cnt = 0, k_min = M, k_max = 0;
       float tot = -INFINITY;
       double P_min = INFINITY;
-      int64_t std_pos = 0;
+      std::vector<PipelineSurvivor> std_orfs;
       for (const FsOrf &o : orfs) {
         int64_t os, oe;
         if (strand) { const int64_t rs = (int64_t)n_seq - o.start + 1, re = (int64_t)n_seq - o.end + 1; os = dstart - (n_seq - re + 1) + 1; oe = dstart - (n_seq - rs + 1) + 1; }
@@ -1145,12 +1146,16 @@ extern "C" int bath_hip_pipeline_frameshift(bath_hip_ctx *ctx, const bath_hip_op
         tot = flogsum_host(tot, o.fwd_null);
         orf_cnt++;
         for (const WindowRec &x : o.wins) { k_min = std::min(k_min, x.k - x.length + 1); k_max = std::max(k_max, x.k); }
-        if (!(o.P > prm.F3)) std_pos += (int64_t)o.n * 3;                   // :1483-1487
+        if (!(o.P > prm.F3)) {                                              // :1483-1487
+          PipelineSurvivor ps;
+          ps.window = w; ps.aa_off = h_aaoff[(size_t)o.cand]; ps.strand = strand; ps.start = o.start; ps.n = o.n; ps.win_start = (int32_t)dw.n; ps.fs_window = o.cand;
+          std_orfs.push_back(ps);                                           // fs_window carries the candidate id until the branch is known
+        }
       }
       r.orf_cnt = orf_cnt; r.k_min = k_min; r.k_max = k_max; r.tot_orfsc = tot; r.P_min = P_min;
       r.P_tot = exp_surv((double)tot / kLn2, om->evparam[BATH_FTAU], om->evparam[BATH_FLAMBDA]);
       out.push_back(r);
-      std_branch_pos.push_back(std_pos);
+      std_branch_orfs.push_back(std::move(std_orfs));
       FsWinDev d{};
       d.src_off = dna->h_off[w]; d.dst_off = 0; d.seq_n = n_seq; d.start = (int32_t)dw.n; d.len = dw.length; d.strand = strand;
       d.kmin = k_min; d.kmax = k_max;
@@ -1159,6 +1164,9 @@ extern "C" int bath_hip_pipeline_frameshift(bath_hip_ctx *ctx, const bath_hip_op
   }
   const int nw = (int)out.size();
   int64_t pos_fwd = 0;
+  ctx->fs_std_orfs.clear();
+  ctx->fs_std_pool = S.W.pool;
+  std::vector<char> aligned((size_t)std::max(nc, 1), 0);                   // oxf_holder[i] == NULL: an overlapping window already took the ORF (:1485)
   if (nw > 0) {
     // ---- windows -> device, bias filter and 3-codon frameshift Forward for all of them
     DevBuf &b_out = ctx->scratch[31];
@@ -1201,7 +1209,16 @@ extern "C" int bath_hip_pipeline_frameshift(bath_hip_ctx *ctx, const bath_hip_op
       r.P_fs = exp_surv(seqscore, ev3[BATH_FTAUFS3], ev3[BATH_FLAMBDA]);
       r.P_null = exp_surv((r.fwdsc - r.nullsc) / kLn2, ev3[BATH_FTAUFS3], ev3[BATH_FLAMBDA]);
       if (r.P_fs <= prm.F3 && (r.P_null < r.P_tot || (r.P_null == r.P_tot && r.orf_cnt > 1) || r.P_min > prm.F3)) { r.branch = 1; pos_fwd += L; }
-      else { r.branch = 2; pos_fwd += std_branch_pos[(size_t)i]; }
+      else {
+        r.branch = 2;
+        for (PipelineSurvivor ps : std_branch_orfs[(size_t)i]) {
+          if (aligned[(size_t)ps.fs_window]) continue;
+          aligned[(size_t)ps.fs_window] = 1;
+          pos_fwd += (int64_t)ps.n * 3;
+          ps.fs_window = i;
+          ctx->fs_std_orfs.push_back(ps);
+        }
+      }
     }
   }
   st_local.pos_past_fwd = pos_fwd;                                         // in the fs pipeline only this stage counts it (:1468, :1490)

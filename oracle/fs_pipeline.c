@@ -68,6 +68,7 @@ int bo_pli_frameshift(bo_pipeline *pli, bo_oprofile *om, bo_fs_profile *gm3, bo_
     wl[nw].n = ws; wl[nw].k = ck; wl[nw].length = (int32_t)(we - ws + 1); nw++;
   }
   if (nw == 0) { free(wl); return BO_OK; }
+  char *aligned = calloc((size_t) norf + 1, 1);               /* oxf_holder[i] freed: the ORF went through the standard branch */
   qsort(wl, (size_t) nw, sizeof(dwin), dwin_cmp);
   int cnt = 0;
   for (int i = 1; i < nw; i++) {                              /* :541-566 */
@@ -167,11 +168,15 @@ int bo_pli_frameshift(bo_pipeline *pli, bo_oprofile *om, bo_fs_profile *gm3, bo_
         if (complementarity) { int64_t rs = (int64_t) n - o->start + 1, re = (int64_t) n - o->end + 1; os = dstart - (n - re + 1) + 1; oe = dstart - (n - rs + 1) + 1; }
         else { os = dstart + o->start - 1; oe = dstart + o->end - 1; }
         if (!(os >= wstart && oe <= wend)) continue;          /* orfsq->idx == w */
+        if (aligned[i]) continue;                             /* oxf_holder[i] == NULL: an overlapping window already took it */
+        aligned[i] = 1;
         pli->pos_past_fwd += (int64_t) o->n * 3;
+        if (doms)                                             /* :1489-1505: Backward parser, domain definition, hit scores */
+          bo_domaindef_std(pli, om, bg, blk->aa + o->off, o->n, o->start, (int) wl[w].n, complementarity, n, doms, ndom, dom_alloc, nskipped);
       }
     }
     fsw_push(fw, nfw, fw_alloc, &r);
   }
-  free(wl);
+  free(wl); free(aligned);
   return BO_OK;
 }

@@ -119,8 +119,8 @@ def compare_domains(model, gdm, odm, per_d):
     want = []
     for w, (a, b) in enumerate(per_d):
         want += [(w, o) for o in odm[a:b]]
-    got = sorted(gdm, key=lambda g: (g.window, g.strand, g.ienv))
-    want.sort(key=lambda t: (t[0], t[1].ienv))
+    got = sorted(gdm, key=lambda g: (g.window, g.ienv, g.jenv))
+    want.sort(key=lambda t: (t[0], t[1].ienv, t[1].jenv))
     assert len(got) == len(want)
     for g, (w, o) in zip(got, want):
         assert g.window == w
@@ -169,3 +169,5 @@ def test_domains_of_planted_frameshifted_genes(gpu_ctx, name):
     assert nskip == oskip
     n = compare_domains(model, dm, odm, per_d)
     assert n >= 3 and any(d.n_shifted_codons > 0 for d in dm) and any(d.strand == 1 for d in dm)
+    # both branches of p7_pli_Frameshift produce hits: codon-model domains and standard domains on window coordinates
+    assert any(fw[d.fs_window].branch == 1 for d in dm) and any(fw[d.fs_window].branch == 2 for d in dm)
