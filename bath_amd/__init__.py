@@ -50,7 +50,8 @@ def build(force=False):
 class _Hmm(C.Structure):
     _fields_ = [("M", C.c_int32), ("max_length", C.c_int32), ("ct", C.c_int32), ("fsprob", C.c_float),
                 ("t", C.POINTER(C.c_float)), ("mat", C.POINTER(C.c_float)), ("ins", C.POINTER(C.c_float)),
-                ("compo", C.c_float * K), ("evparam", C.c_float * NEVPARAM), ("name", C.c_char * 128)]
+                ("compo", C.c_float * K), ("evparam", C.c_float * NEVPARAM), ("name", C.c_char * 128),
+                ("acc", C.c_char * 64), ("consensus", C.c_char_p)]
 
 
 class _Profile(C.Structure):
@@ -117,7 +118,9 @@ class FsDomain(C.Structure):
     _fields_ = [("window", C.c_int64), ("strand", C.c_int32), ("fs_window", C.c_int32),
                 ("ienv", C.c_int32), ("jenv", C.c_int32), ("iali", C.c_int32), ("jali", C.c_int32), ("ihmm", C.c_int32), ("jhmm", C.c_int32),
                 ("envsc", C.c_float), ("oasc", C.c_float), ("domcorrection", C.c_float), ("dombias", C.c_float),
-                ("bitscore", C.c_float), ("pre_score", C.c_float), ("lnP", C.c_double), ("reported", C.c_int32), ("n_shifted_codons", C.c_int32)]
+                ("bitscore", C.c_float), ("pre_score", C.c_float), ("lnP", C.c_double), ("reported", C.c_int32), ("n_shifted_codons", C.c_int32),
+                ("n_stops", C.c_int32), ("pid", C.c_float), ("ali_columns", C.c_int32), ("cigar_off", C.c_int64)]
+    cigar = ""       # filled by Pipeline.run_hits / run_frameshift_domains
 
 
 class Fs5Result(C.Structure):
@@ -162,6 +165,17 @@ ABI = {
                                             C.POINTER(C.POINTER(OrfResult)), _i64p]),
     "bath_hip_pipeline_frameshift": (C.c_int, [_vp, _vp, _vp, _vp, C.POINTER(PipelineParams), C.POINTER(PipelineStats),
                                               C.POINTER(C.POINTER(OrfResult)), _i64p, C.POINTER(C.POINTER(FsWindow)), _i64p]),
+    "bath_hip_oprofile_set_consensus": (C.c_int, [_vp, C.c_char_p]),
+    "bath_hip_domain_cigars": (C.c_void_p, [_vp]),
+    "bath_tophits_create": (_vp, []),
+    "bath_tophits_destroy": (None, [_vp]),
+    "bath_tophits_add": (C.c_int, [_vp, C.POINTER(FsDomain), C.c_int64, C.c_void_p, C.c_int64, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p),
+                                   C.POINTER(C.c_char_p), C.POINTER(C.c_int64)]),
+    "bath_tophits_finalize": (C.c_int, [_vp, C.c_int64, C.c_int, C.c_double]),
+    "bath_tophits_count": (C.c_int64, [_vp]),
+    "bath_tophits_reported": (C.c_int64, [_vp]),
+    "bath_tophits_get": (C.c_int, [_vp, C.c_int64, C.POINTER(FsDomain), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
+    "bath_tophits_tabular_targets": (C.c_int64, [_vp, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int64]),
     "bath_hip_pipeline_hits": (C.c_int, [_vp, _vp, _vp, C.POINTER(PipelineParams), C.c_double, C.POINTER(PipelineStats),
                                          C.POINTER(C.POINTER(FsDomain)), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "bath_hip_pipeline_frameshift_domains": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.POINTER(PipelineParams), C.c_double, C.POINTER(PipelineStats),
@@ -231,6 +245,8 @@ class HMM:
         self.ct = p.contents.ct
         self.max_length = p.contents.max_length
         self.name = p.contents.name.decode()
+        self.acc = p.contents.acc.decode()
+        self.consensus = p.contents.consensus.decode() if p.contents.consensus else ""
         self.evparam = np.array(p.contents.evparam[:], dtype=np.float32)
 
     @staticmethod
@@ -338,6 +354,9 @@ class OProfile:
         h = _vp()
         ctx._check(lib().bath_hip_oprofile_convert(ctx._h, gm._p, C.byref(h)), "oprofile_convert")
         self.ctx, self._h, self.M, self.gm = ctx, h, gm.M, gm
+        hmm = getattr(gm, "hmm", None)
+        if hmm is not None and hmm.consensus:                 # om->consensus, copied by p7_oprofile_Convert
+            ctx._check(lib().bath_hip_oprofile_set_consensus(h, hmm.consensus.encode()), "oprofile_set_consensus")
 
     def scalars(self, L):
         s = OProfileScalars()
@@ -530,12 +549,18 @@ class Pipeline:
         nskip = C.c_int64(0)
         self.ctx._check(lib().bath_hip_pipeline_hits(self.ctx._h, self.om._h, dna._h, C.byref(self.params), E_report, C.byref(stats),
                                                      C.byref(dm), C.byref(ndm), C.byref(nskip)), "pipeline_hits")
+        return stats, self._domains(dm, ndm.value), nskip.value
+
+    def _domains(self, dm, n):
+        """Copies of the ctx-owned domain records, each with its --cigar string attached."""
+        base = lib().bath_hip_domain_cigars(self.ctx._h)
         out = []
-        for i in range(ndm.value):
+        for i in range(n):
             x = FsDomain()
             C.memmove(C.byref(x), C.byref(dm[i]), C.sizeof(FsDomain))
+            x.cigar = C.string_at(base + x.cigar_off).decode() if base else ""
             out.append(x)
-        return stats, out, nskip.value
+        return out
 
     def run_frameshift_domains(self, om_fs3, om_fs5, dna, E_report=10.0):
         """bathsearch --fs through domain definition: (stats, [FsWindow], [FsDomain], multi-domain regions skipped)."""
@@ -554,7 +579,7 @@ class Pipeline:
                 C.memmove(C.byref(x), C.byref(ptr[i]), C.sizeof(T))
                 out.append(x)
             return out
-        return stats, copies(fw, nfw.value, FsWindow), copies(dm, ndm.value, FsDomain), nskip.value
+        return stats, copies(fw, nfw.value, FsWindow), self._domains(dm, ndm.value), nskip.value
 
     def timings(self):
         names = (C.c_char_p * 32)()
@@ -562,6 +587,60 @@ class Pipeline:
         launches = np.zeros(32, dtype=np.int64)
         k = lib().bath_hip_pipeline_timings(self.ctx._h, 32, names, _f32(ms), _i64(launches))
         return [(names[i].decode(), float(ms[i]), int(launches[i])) for i in range(k)]
+
+
+class TopHits:
+    """P7_TOPHITS for this path: collect the hits of pipeline calls, finish the search (E-values, duplicates, sorting,
+    thresholds; bathsearch.c:868-921) and print --tblout (p7_tophits_TabularTargets)."""
+
+    def __init__(self):
+        self._h = lib().bath_tophits_create()
+
+    def add(self, domains, names, lengths, seqidx0=0, accs=None, descs=None):
+        n = len(domains)
+        arr = (FsDomain * max(n, 1))()
+        pool = bytearray()
+        for i, d in enumerate(domains):
+            C.memmove(C.byref(arr[i]), C.byref(d), C.sizeof(FsDomain))
+            arr[i].cigar_off = len(pool)
+            pool += d.cigar.encode() + b"\0"
+        cig = C.create_string_buffer(bytes(pool) + b"\0")
+
+        def strs(v):
+            if v is None:
+                return None
+            a = (C.c_char_p * len(v))()
+            for i, x in enumerate(v):
+                a[i] = x.encode() if x else None
+            return a
+        lens = (C.c_int64 * len(lengths))(*[int(x) for x in lengths])
+        st = lib().bath_tophits_add(self._h, arr, n, C.cast(cig, C.c_void_p), seqidx0, strs(names), strs(accs), strs(descs), lens)
+        if st != OK:
+            raise BathError("tophits_add failed (%d)" % st)
+
+    def finalize(self, nres, max_length, E=10.0):
+        if lib().bath_tophits_finalize(self._h, nres, max_length, E) != OK:
+            raise BathError("tophits_finalize failed")
+
+    def hits(self):
+        out = []
+        for r in range(lib().bath_tophits_count(self._h)):
+            d, idx, fl = FsDomain(), C.c_int64(0), C.c_int32(0)
+            lib().bath_tophits_get(self._h, r, C.byref(d), C.byref(idx), C.byref(fl))
+            out.append((d, idx.value, fl.value))
+        return out
+
+    def tblout(self, qname, qacc, M, fs_pipe=False, show_cigar=False, show_header=True):
+        args = (self._h, qname.encode(), (qacc or "").encode(), M, int(fs_pipe), int(show_cigar), int(show_header))
+        n = lib().bath_tophits_tabular_targets(*args, None, 0)
+        buf = C.create_string_buffer(n + 1)
+        lib().bath_tophits_tabular_targets(*args, buf, n)
+        return buf.raw[:n].decode()
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().bath_tophits_destroy(self._h)
+            self._h = None
 
 
 def FS3ForwardParser(ctx, om3, dna, logsum=LOGSUM_TABLE, want_xmx=False):

@@ -72,6 +72,7 @@ struct bath_hip_ctx {
   std::vector<bath_orf> orfs;             // bath_hip_translate_orfs output
   std::vector<bath_fs_window> fs_windows; // bath_hip_pipeline_frameshift output
   std::vector<bath_fs_domain> fs_domains; // bath_hip_pipeline_frameshift_domains output
+  std::string cigars;                     // NUL-terminated CIGAR strings of fs_domains (bath_fs_domain.cigar_off)
   std::vector<bath::PipelineSurvivor> fs_std_orfs;   // ORFs of the windows that take the standard branch (p7_pipeline.c:1479-1510)
   const uint8_t *fs_std_pool = nullptr;              // their residues: the amino-acid streams of the last cascade
   std::vector<uint8_t> orf_aa;
@@ -145,6 +146,9 @@ struct bath_hip_oprofile {
   float scale_w = 0;
   int16_t base_w = 0, ddbound_w = 0;
   float xf_E[2] = {0, 0};
+  std::string consensus;              // [M+2], ' ' where unset (bath_hip_oprofile_set_consensus)
+  std::vector<uint8_t> cons_digital;  // [M+1] residue code of consensus[k], 255 = none
+  uint8_t *d_cons = nullptr;
   std::vector<float> prefix_lengths, suffix_lengths;   // [M+1] P7_SCOREDATA window padding fractions (p7_scoredata.c:357-380)
   // device tables
   int NR = 0, G = 1;            // SSV kernel tile: NR packed int16 registers per lane, G lanes per target (2*NR*G >= M)

@@ -23,6 +23,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstring>
+#include <string>
 #include <vector>
 
 #include "bath_common.hpp"
@@ -36,6 +37,39 @@ namespace {
 const double kLn2 = 0.69314718055994529;
 
 double exp_logsurv(double x, double mu, double lambda) { return x < mu ? 0.0 : -lambda * (x - mu); }
+
+// The --cigar string of an alignment (p7_alidisplay_fs_Create, p7_alidisplay.c:777-815, 841-869; the non-frameshift display
+// :1140-1200 is the special case "every codon has 3 nucleotides").  One code per alignment column:
+// state (3 = M, 4 = D, 5 = I) | codon length << 4 | indel label << 8 (hmmer.h:259-276).
+std::string cigar_from_columns(const uint16_t *S, int n) {
+  enum { sM = 3, sD = 4, sI = 5 };
+  enum { L___X = 0, L_X__, L_XX_, L_X_X, L__XX, L_XXX, L_XXx, L_XxX, L_xXX, L_xxx, L_XXxX, L_XxXX, L_xXXX, L_XXxxX, L_XxxXX, L_xxXXX };
+  std::string out;
+  int cnt = 0;
+  auto emit = [&](int v, char ch) { out += std::to_string(v); out += ch; };
+  for (int z = 0; z < n; z++) {
+    const int s = S[z] & 0xf, c = (S[z] >> 4) & 0xf, indel = S[z] >> 8;
+    const int next = (z + 1 < n) ? (S[z + 1] & 0xf) : -1;
+    if (s == sM) {
+      if (next != sM || c != 3) {
+        if (c == 3) cnt += 3;
+        else if (indel == L_XX_ || indel == L_XXxX || indel == L_XXxxX) cnt += 2;
+        else if (indel == L_X_X || indel == L_X__ || indel == L_XxXX || indel == L_XxxXX) cnt += 1;
+        emit(cnt, 'M');
+        cnt = 0;
+        if (c == 1) emit(2, 'B'); else if (c == 2) emit(1, 'B'); else if (c == 4) emit(1, 'F'); else if (c == 5) emit(2, 'F');
+        if (indel == L___X || indel == L_X_X || indel == L_XXxX || indel == L_XXxxX) cnt = 1;
+        if (indel == L__XX || indel == L_XxXX || indel == L_XxxXX) cnt = 2;
+        if (indel == L_xXXX || indel == L_xxXXX) cnt = 3;
+        if (next != sM && cnt > 0) { emit(cnt, 'M'); cnt = 0; }
+      } else cnt += 3;
+    } else if (s == sI || s == sD) {
+      cnt += 3;
+      if (next != s) { emit(cnt, s == sI ? 'I' : 'D'); cnt = 0; }
+    }
+  }
+  return out;
+}
 
 }  // namespace
 
@@ -52,6 +86,7 @@ static int fs_branch_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, con
   *domains = nullptr; *n_domains = 0;
   if (n_skipped_regions) *n_skipped_regions = 0;
   ctx->fs_domains.clear();
+  ctx->cigars.clear();
   bath_pipeline_stats st_local{};
   const bath_fs_window *fw = nullptr;
   int64_t nfw = 0;
@@ -112,10 +147,12 @@ static int fs_branch_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, con
   }
   std::vector<bath_fs5_result> res((size_t)nenv);
   std::vector<FsTraceOut> traces((size_t)nenv);
+  std::vector<uint16_t> steps;
+  std::vector<int64_t> step_off;
   {
     bath_hip_seqs view;
     if ((st = fs_gather_view(ctx, dna, eregs, tt.comp, &view, nullptr)) != BATH_OK) return st;
-    st = fs5_envelopes_ex(ctx, om_fs5, &view, BATH_LOGSUM_TABLE, 0, res.data(), nullptr, nullptr, nullptr, nullptr, traces.data());
+    st = fs5_envelopes_ex(ctx, om_fs5, &view, BATH_LOGSUM_TABLE, 0, res.data(), nullptr, nullptr, nullptr, nullptr, traces.data(), om->d_cons, &steps, &step_off);
     view.d_data = nullptr; view.d_off = nullptr; view.d_len = nullptr;
     if (st != BATH_OK) return st;
   }
@@ -167,6 +204,11 @@ static int fs_branch_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, con
       dm.lnP = exp_logsurv(dm.bitscore, h5.evparam[7], h5.evparam[BATH_FLAMBDA]);
       dm.reported = (std::exp(dm.lnP) * (double)Zf <= E_report) ? 1 : 0;
     } else { dm.ienv = ienv; dm.jenv = jenv; dm.iali = iali; dm.jali = jali; dm.reported = 0; }
+    dm.n_stops = tq.nstops; dm.ali_columns = tq.ncol;
+    dm.pid = tq.ncol > 0 ? ((float)tq.exact / tq.ncol) * 100 : 0.f;
+    dm.cigar_off = (int64_t)ctx->cigars.size();
+    ctx->cigars += cigar_from_columns(steps.data() + step_off[(size_t)e], tq.ncol);
+    ctx->cigars.push_back('\0');
     ctx->fs_domains.push_back(dm);
   }
   *domains = ctx->fs_domains.data(); *n_domains = (int64_t)ctx->fs_domains.size();
@@ -251,13 +293,14 @@ __global__ void std_regions_kernel(int64_t n, const int32_t *__restrict__ len, c
   out[0] = min(nreg, kStdMaxRegions);
 }
 
-struct StdEnvOut { int32_t i1, k1, i2, k2, ok; float oasc, domcorrection; };
+struct StdEnvOut { int32_t i1, k1, i2, k2, ok; float oasc, domcorrection; int32_t ncol, exact; };
 
 // p7_Decoding + p7_OptimalAccuracy + p7_OATrace + p7_Null2_ByExpectation on one envelope per lane (unihit model).
 // fwd / bck: (L+1) x (M+1) x {M, D, I}; on return bck holds the posteriors and fwd the OA matrix, as in the reference.
 __global__ void std_envelope_kernel(SeqView sq, int M, const float *__restrict__ tf, const float *__restrict__ rf, float *__restrict__ fwd, float *__restrict__ bck,
                                     const int64_t *__restrict__ dp_off, const float *__restrict__ fx, const float *__restrict__ bx, const int64_t *__restrict__ x_off,
-                                    float *__restrict__ ppx_all, float *__restrict__ oax_all, float *__restrict__ em_all /* [n][2*(M+1)] */, StdEnvOut *__restrict__ out) {
+                                    float *__restrict__ ppx_all, float *__restrict__ oax_all, float *__restrict__ em_all /* [n][2*(M+1)] */, StdEnvOut *__restrict__ out,
+                                    const uint8_t *__restrict__ cons /* [M+1] or null */, uint8_t *__restrict__ tbuf, const int64_t *__restrict__ t_off) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= sq.n) return;
   enum { XE = 0, XN, XJ, XB, XC, XS };
@@ -270,7 +313,7 @@ __global__ void std_envelope_kernel(SeqView sq, int M, const float *__restrict__
   float *F = fwd + dp_off[t], *Bk = bck + dp_off[t];
   const float *FX = fx + x_off[t], *BX = bx + x_off[t];
   float *PX = ppx_all + (x_off[t] / 6) * 5, *OX = oax_all + (x_off[t] / 6) * 5;
-  StdEnvOut r{-1, -1, -1, -1, 0, 0.f, 0.f};
+  StdEnvOut r{-1, -1, -1, -1, 0, 0.f, 0.f, 0, 0};
   const float ploop = 1.0f - 2.0f / ((float)L + 2.0f);                       // unihit: xf[N|J|C][LOOP]
   // ---- p7_Decoding (decoding.c:61-118): posteriors overwrite Backward
   float scaleproduct = (float)(1.0 / (double)BX[XN]);
@@ -334,6 +377,10 @@ __global__ void std_envelope_kernel(SeqView sq, int M, const float *__restrict__
     auto path = [](float tr, float v) { return tr == 0.0f ? -INFINITY : v; };
     int i = L, k = 0, s0 = sC, steps = 0;
     bool bad = false;
+    // the alignment columns from the last match state back to the first, for the display (p7_alidisplay_nonfs_Create)
+    uint8_t *T = tbuf + t_off[t];
+    const int cap = (int)(t_off[t + 1] - t_off[t]);
+    int ncol = 0, exact = 0;
     while (s0 != sS && !bad) {
       int s1 = -1;
       switch (s0) {
@@ -370,6 +417,11 @@ __global__ void std_envelope_kernel(SeqView sq, int M, const float *__restrict__
       }
       if (bad || s1 < 0 || i < 0 || k < 0) { bad = true; break; }
       if (s1 == sM) { if (r.i2 < 0) { r.i2 = i; r.k2 = k; } r.i1 = i; r.k1 = k; }
+      if ((s1 == sM || s1 == sD || s1 == sI) && r.i2 >= 0) {
+        if (ncol < cap) T[ncol] = (uint8_t)s1;
+        ncol++;
+        if (s1 == sM) { r.ncol = ncol; if (cons && min((int)dsq[i], kKp - 1) == cons[k]) exact++; r.exact = exact; }
+      }
       if ((s1 == sN || s1 == sJ || s1 == sC) && s1 == s0) i--;
       s0 = s1;
       if (++steps > 4 * (L + M) + 64) bad = true;
@@ -492,15 +544,23 @@ static int std_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bat
   BATH_HIP_TRY(ctx, b_dpo.reserve((size_t)(ne + 1) * 8)); BATH_HIP_TRY(ctx, b_fx.reserve((size_t)exoff[(size_t)ne] * 4 + 64)); BATH_HIP_TRY(ctx, b_bx.reserve((size_t)exoff[(size_t)ne] * 4 + 64));
   BATH_HIP_TRY(ctx, b_px.reserve((size_t)exoff[(size_t)ne] / 6 * 5 * 4 + 64)); BATH_HIP_TRY(ctx, b_ox.reserve((size_t)exoff[(size_t)ne] / 6 * 5 * 4 + 64));
   BATH_HIP_TRY(ctx, b_em.reserve((size_t)ne * 2 * (M + 1) * 4 + 64)); BATH_HIP_TRY(ctx, b_out.reserve((size_t)ne * sizeof(StdEnvOut) + 64));
+  std::vector<int64_t> toff((size_t)ne + 1, 0);
+  for (int64_t e = 0; e < ne; e++) toff[(size_t)e + 1] = toff[(size_t)e] + ev.h_len[(size_t)e] + M + 2;
+  DevBuf &b_tb = ctx->scratch[10], &b_toff = ctx->scratch[13];
+  BATH_HIP_TRY(ctx, b_tb.reserve((size_t)toff[(size_t)ne] + 64)); BATH_HIP_TRY(ctx, b_toff.reserve((size_t)(ne + 1) * 8));
+  BATH_HIP_TRY(ctx, hipMemcpyAsync(b_toff.p, toff.data(), (size_t)(ne + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
   BATH_HIP_TRY(ctx, b_sc.reserve((size_t)ne * 8)); BATH_HIP_TRY(ctx, b_st.reserve((size_t)ne * 8));
   BATH_HIP_TRY(ctx, hipMemcpyAsync(b_dpo.p, dpoff.data(), (size_t)(ne + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
   if ((st = launch_fwd_wave(ctx, om, ev.view(), nullptr, ne, b_sc.as<float>(), b_st.as<int32_t>(), nullptr, b_fx.as<float>(), d_exoff, b_f.as<float>(), b_dpo.as<int64_t>(), 1)) != BATH_OK) return st;
   if ((st = launch_bwd_wave(ctx, om, ev.view(), ne, b_fx.as<float>(), d_exoff, b_sc.as<float>() + ne, b_st.as<int32_t>() + ne, b_bx.as<float>(), b_b.as<float>(), b_dpo.as<int64_t>(), 1)) != BATH_OK) return st;
   hipLaunchKernelGGL(std_envelope_kernel, dim3((unsigned)((ne + 63) / 64)), dim3(64), 0, ctx->stream, ev.view(), M, om->d_tf, om->d_rf, b_f.as<float>(), b_b.as<float>(), b_dpo.as<int64_t>(),
-                     b_fx.as<float>(), b_bx.as<float>(), d_exoff, b_px.as<float>(), b_ox.as<float>(), b_em.as<float>(), b_out.as<StdEnvOut>());
+                     b_fx.as<float>(), b_bx.as<float>(), d_exoff, b_px.as<float>(), b_ox.as<float>(), b_em.as<float>(), b_out.as<StdEnvOut>(),
+                     om->d_cons, b_tb.as<uint8_t>(), b_toff.as<int64_t>());
   BATH_HIP_TRY(ctx, hipGetLastError());
   std::vector<StdEnvOut> eo((size_t)ne);
   std::vector<float> envsc((size_t)ne);
+  std::vector<uint8_t> tcols((size_t)toff[(size_t)ne]);
+  BATH_HIP_TRY(ctx, hipMemcpyAsync(tcols.data(), b_tb.p, tcols.size(), hipMemcpyDeviceToHost, ctx->stream));
   BATH_HIP_TRY(ctx, hipMemcpyAsync(eo.data(), b_out.p, (size_t)ne * sizeof(StdEnvOut), hipMemcpyDeviceToHost, ctx->stream));
   BATH_HIP_TRY(ctx, hipMemcpyAsync(envsc.data(), b_sc.p, (size_t)ne * 4, hipMemcpyDeviceToHost, ctx->stream));
   BATH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -545,6 +605,16 @@ static int std_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bat
     dm.pre_score = (float)(bitscore / kLn2);
     dm.lnP = (double)(float)exp_logsurv(dm.bitscore, om->evparam[BATH_FTAU], om->evparam[BATH_FLAMBDA]);
     dm.reported = (std::exp(dm.lnP) * (double)Zf <= E_report) ? 1 : 0;
+    {                                                                        // columns were written last to first; every codon has 3 nucleotides
+      const int nc = std::min<int>(t.ncol, (int)(toff[(size_t)e + 1] - toff[(size_t)e]));
+      std::vector<uint16_t> cols((size_t)nc);
+      for (int z = 0; z < nc; z++) cols[(size_t)z] = (uint16_t)(tcols[(size_t)toff[(size_t)e] + (size_t)(nc - 1 - z)] | (3u << 4) | (5u << 8));
+      dm.ali_columns = nc; dm.n_stops = 0;
+      dm.pid = nc > 0 ? ((float)t.exact / nc) * 100 : 0.f;
+      dm.cigar_off = (int64_t)ctx->cigars.size();
+      ctx->cigars += cigar_from_columns(cols.data(), nc);
+      ctx->cigars.push_back('\0');
+    }
     ctx->fs_domains.push_back(dm);
   }
   return BATH_OK;
@@ -557,6 +627,7 @@ extern "C" int bath_hip_pipeline_hits(bath_hip_ctx *ctx, const bath_hip_oprofile
   *domains = nullptr; *n_domains = 0;
   int64_t nskip = 0;
   ctx->fs_domains.clear();
+  ctx->cigars.clear();
   bath_pipeline_params prm = *prm_in;
   prm.fs_pipe = 0;
   bath_pipeline_stats st_local{};
@@ -571,3 +642,5 @@ extern "C" int bath_hip_pipeline_hits(bath_hip_ctx *ctx, const bath_hip_oprofile
   *domains = ctx->fs_domains.data(); *n_domains = (int64_t)ctx->fs_domains.size();
   return BATH_OK;
 }
+
+extern "C" const char *bath_hip_domain_cigars(const bath_hip_ctx *ctx) { return ctx ? ctx->cigars.c_str() : nullptr; }

@@ -40,6 +40,7 @@ struct bath_hip_fsprofile {
   std::vector<float> h_tsc;      // [M*8] generic log transitions (OA traceback deltas on the host)
   std::vector<uint8_t> h_codons; // [(M+1)*maxcodons] best amino acid per (node, quasi-codon) (null2 along a trace)
   uint8_t *d_codons = nullptr;   // the same on the device (5-codon profiles)
+  uint8_t *d_indel = nullptr;    // [(M+1)*maxcodons] indel-type label of that choice (hmmer.h:259-276), for the alignment display
   // length model: xsc[N|C|J][LOOP|MOVE] for L_amino, multihit (nj=1) and unihit (nj=0); host libm log()
   mutable int maxL = -1;
   mutable float *d_loop[2] = {nullptr, nullptr}, *d_move[2] = {nullptr, nullptr};
@@ -730,7 +731,8 @@ __global__ __launch_bounds__(256) void fs5_oa_kernel(SeqView dna, int M, const f
 __global__ void fs5_trace_kernel(SeqView dna, int M, int maxcodons, const float *__restrict__ tf, const uint8_t *__restrict__ codons,
                                  const float *__restrict__ pp, const int64_t *__restrict__ pp_off, const float *__restrict__ px, const int64_t *__restrict__ x_off,
                                  const float *__restrict__ oa, const int64_t *__restrict__ oa_off, const float *__restrict__ ox,
-                                 const float *__restrict__ null2 /* [n][Kp] */, uint2 *__restrict__ tbuf, const int64_t *__restrict__ t_off, FsTraceOut *__restrict__ out) {
+                                 const float *__restrict__ null2 /* [n][Kp] */, uint2 *__restrict__ tbuf, const int64_t *__restrict__ t_off, FsTraceOut *__restrict__ out,
+                                 const uint8_t *__restrict__ indel_tab, const uint8_t *__restrict__ cons, uint16_t *__restrict__ steps) {
   const int64_t job = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (job >= dna.n) return;
   enum { sS = 0, sN, sB, sM, sD, sI, sE, sJ, sC, sT };
@@ -741,7 +743,7 @@ __global__ void fs5_trace_kernel(SeqView dna, int M, int maxcodons, const float 
   const float *P = pp + pp_off[job], *PX = px + x_off[job], *O = oa + oa_off[job], *OX = ox + x_off[job];
   uint2 *T = tbuf + t_off[job];
   const int cap = (int)(t_off[job + 1] - t_off[job]);
-  FsTraceOut r{0, 0, 0, 0, 0, 0, 0.f};
+  FsTraceOut r{0, 0, 0, 0, 0, 0, 0.f, 0, 0, 0};
   auto dl = [&](int node, int s) { return (node >= 1 && node <= M && tf[(size_t)node * 8 + s] != -INFINITY) ? 1.0f : kTiny; };
   auto OM = [&](int i, int k) { return O[((size_t)i * (M + 1) + k) * 3 + 2]; };
   auto OI = [&](int i, int k) { return O[((size_t)i * (M + 1) + k) * 3 + 1]; };
@@ -854,6 +856,33 @@ __global__ void fs5_trace_kernel(SeqView dna, int M, int maxcodons, const float 
         t = u; u = v; v = w; w = x;
       }
       r.domcorrection = corr;
+      // what the alignment display keeps of the trace (p7_alidisplay_fs_Create, p7_alidisplay.c:700-925): per column the
+      // state, codon length and indel type (for --cigar), identities with the consensus, stop codons
+      uint16_t *S = steps ? steps + t_off[job] : nullptr;
+      r.ncol = z2 - z1 + 1;
+      for (int zz = z1; zz <= z2; zz++) {
+        const int s = st_of(zz), cc = (s == sM) ? c_of(zz) : (s == sI ? 3 : 0), kk = k_of(zz), ii = i_of(zz);
+        unsigned code = (unsigned)s;
+        if (cc > 0 && ii - cc + 1 >= 1 && ii <= L) {
+          int nn[5] = {0, 0, 0, 0, 0};
+          bool degen = false;
+          for (int q = 0; q < cc; q++) { nn[q] = dsq[ii - cc + 1 + q]; degen |= nn[q] >= 4; }
+          int ci;
+          switch (cc) {                                       // p7P_CODON{1..5}_FS5, hmmer.h:292-316; the last nucleotide is the most significant
+          case 1: ci = degen ? 1366 : nn[0] * 341; break;
+          case 2: ci = degen ? 1365 : nn[1] * 341 + nn[0] * 85 + 1; break;
+          case 3: ci = degen ? 1364 : nn[2] * 341 + nn[1] * 85 + nn[0] * 21 + 2; break;
+          case 4: ci = degen ? 1365 : nn[3] * 341 + nn[2] * 85 + nn[1] * 21 + nn[0] * 5 + 3; break;
+          default: ci = degen ? 1366 : nn[4] * 341 + nn[3] * 85 + nn[2] * 21 + nn[1] * 5 + nn[0] + 4; break;
+          }
+          const int indel = indel_tab ? indel_tab[(size_t)kk * maxcodons + ci] : 5;
+          const bool stop = (cc == 3) && (indel == 6 || indel == 7 || indel == 8);      // p7P_XXx, p7P_XxX, p7P_xXX
+          if (stop) r.nstops++;
+          if (s == sM && cons && codons[(size_t)kk * maxcodons + ci] == cons[kk]) r.exact++;
+          code |= (unsigned)cc << 4 | (unsigned)indel << 8;
+        }
+        if (S) S[zz - z1] = (uint16_t)code;
+      }
     }
   }
   out[job] = r;
@@ -930,7 +959,7 @@ int bath_hip_fsprofile::ensure_len(int maxL_amino) const {
 
 extern "C" void bath_hip_fsprofile_destroy(bath_hip_fsprofile *om) {
   if (!om) return;
-  for (void *p : {(void *)om->d_codons, (void *)om->d_rsc, (void *)om->d_tf, (void *)om->d_tb, (void *)om->d_logsum, (void *)om->d_loop[0], (void *)om->d_loop[1],
+  for (void *p : {(void *)om->d_codons, (void *)om->d_indel, (void *)om->d_rsc, (void *)om->d_tf, (void *)om->d_tb, (void *)om->d_logsum, (void *)om->d_loop[0], (void *)om->d_loop[1],
                   (void *)om->d_move[0], (void *)om->d_move[1]})
     if (p) (void)hipFree(p);
   delete om;
@@ -949,6 +978,10 @@ extern "C" int bath_hip_fsprofile_convert(bath_hip_ctx *ctx, const bath_fs_profi
     om->h_codons.assign(gm->codons, gm->codons + (size_t)(M + 1) * gm->maxcodons);
     BATH_HIP_TRY(ctx, hipMalloc((void **)&om->d_codons, om->h_codons.size() + 64));
     BATH_HIP_TRY(ctx, hipMemcpy(om->d_codons, om->h_codons.data(), om->h_codons.size(), hipMemcpyHostToDevice));
+    if (gm->indel_pos) {
+      BATH_HIP_TRY(ctx, hipMalloc((void **)&om->d_indel, om->h_codons.size() + 64));
+      BATH_HIP_TRY(ctx, hipMemcpy(om->d_indel, gm->indel_pos, om->h_codons.size(), hipMemcpyHostToDevice));
+    }
   }
   om->pitch = (M + 1 + 3) / 4 * 4;
   const int nrows = gm->maxcodons + kKp;
@@ -1217,7 +1250,8 @@ extern "C" int bath_hip_fs5_envelopes(bath_hip_ctx *ctx, const bath_hip_fsprofil
 // Envelope rescoring; layouts per envelope i, rows = L_i+1: pp rows*(M+1)*8, oa rows*(M+1)*3, ppx / oax rows*5
 // {E,N,J,B,C} (posterior and OA special-state rows), each packed back to back in envelope order.
 int bath::fs5_envelopes_ex(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, const bath_hip_seqs *dna, int logsum_mode, int c5_compat,
-                           bath_fs5_result *res, float *pp, float *oa, float *ppx, float *oax, FsTraceOut *trace) {
+                           bath_fs5_result *res, float *pp, float *oa, float *ppx, float *oax, FsTraceOut *trace,
+                           const uint8_t *cons, std::vector<uint16_t> *steps, std::vector<int64_t> *step_off) {
   if (!ctx || !om || !dna || om->codon_lengths != 5) { if (ctx) ctx->set_error("fs5 envelopes need a 5-codon profile"); return BATH_EINVAL; }
   BATH_HIP_TRY(ctx, hipSetDevice(ctx->device));
   const int64_t n = dna->n;
@@ -1278,16 +1312,22 @@ int bath::fs5_envelopes_ex(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, cons
     if (!om->d_codons) { ctx->set_error("traceback needs the profile's codon table"); return BATH_EINVAL; }
     std::vector<int64_t> toff((size_t)n + 1, 0);
     for (int64_t i = 0; i < n; i++) toff[(size_t)i + 1] = toff[(size_t)i] + dna->h_len[(size_t)i] + M + 16;
-    DevBuf &b_tb = ctx->scratch[10], &b_to = ctx->scratch[13];
+    DevBuf &b_tb = ctx->scratch[10], &b_to = ctx->scratch[13], &b_steps = ctx->scratch[14];
     BATH_HIP_TRY(ctx, b_tb.reserve((size_t)toff[(size_t)n] * sizeof(uint2) + (size_t)(n + 1) * sizeof(int64_t) + 256));
+    if (steps) BATH_HIP_TRY(ctx, b_steps.reserve((size_t)toff[(size_t)n] * sizeof(uint16_t) + 64));
     BATH_HIP_TRY(ctx, b_to.reserve((size_t)n * sizeof(FsTraceOut) + 64));
     int64_t *d_toff = reinterpret_cast<int64_t *>(b_tb.as<char>() + ((size_t)toff[(size_t)n] * sizeof(uint2) + 255) / 256 * 256);
     BATH_HIP_TRY(ctx, hipMemcpyAsync(d_toff, toff.data(), (size_t)(n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(fs5_trace_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, dna->view(), M, om->maxcodons, om->d_tf, om->d_codons,
                        b_f.as<float>(), d_foff, b_fx.as<float>(), d_xoff, b_o.as<float>(), d_boff, b_ox.as<float>(), b_n2.as<float>(), b_tb.as<uint2>(), d_toff,
-                       b_to.as<FsTraceOut>());
+                       b_to.as<FsTraceOut>(), om->d_indel, cons, steps ? b_steps.as<uint16_t>() : nullptr);
     BATH_HIP_TRY(ctx, hipGetLastError());
     BATH_HIP_TRY(ctx, hipMemcpyAsync(trace, b_to.p, (size_t)n * sizeof(FsTraceOut), hipMemcpyDeviceToHost, ctx->stream));
+    if (steps) {                                                // columns z1..z2 of envelope e: (*steps)[step_off[e] .. +trace[e].ncol)
+      steps->resize((size_t)toff[(size_t)n]);
+      BATH_HIP_TRY(ctx, hipMemcpyAsync(steps->data(), b_steps.p, steps->size() * sizeof(uint16_t), hipMemcpyDeviceToHost, ctx->stream));
+      *step_off = toff;
+    }
     BATH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));       // toff is a local
   }
   std::vector<float> h_sc((size_t)n * 3), h_n2((size_t)n * kKp);

@@ -64,9 +64,15 @@ int fs3_regions(bath_hip_ctx *ctx, const bath_hip_fsprofile *om3, const bath_hip
 int fsprofile_codon_lengths(const bath_hip_fsprofile *om);
 struct FsHostTables { int M, max_length, maxcodons; const float *tsc; const uint8_t *codons; const float *evparam; };
 const FsHostTables fsprofile_host(const bath_hip_fsprofile *om);
-struct FsTraceOut { int32_t ihmm, jhmm, iali, jali, nshift, ok; float domcorrection; };   // what the pipeline keeps of an envelope's OA trace
+struct FsTraceOut {               // what the pipeline keeps of an envelope's OA trace
+  int32_t ihmm, jhmm, iali, jali, nshift, ok; float domcorrection;
+  int32_t ncol, exact, nstops;    // alignment display: columns (first to last match state), identities with the consensus, stop codons
+};
+// <cons>: device array [M+1] of consensus residue codes or nullptr; <steps>/<step_off>: per alignment column
+// state | codon length << 4 | indel label << 8 (columns of envelope e start at (*step_off)[e])
 int fs5_envelopes_ex(bath_hip_ctx *ctx, const bath_hip_fsprofile *om5, const bath_hip_seqs *dna, int logsum_mode, int c5_compat,
-                     bath_fs5_result *res, float *pp, float *oa, float *ppx, float *oax, FsTraceOut *trace);
+                     bath_fs5_result *res, float *pp, float *oa, float *ppx, float *oax, FsTraceOut *trace,
+                     const uint8_t *cons = nullptr, std::vector<uint16_t> *steps = nullptr, std::vector<int64_t> *step_off = nullptr);
 
 // ---- six-frame translation + ORF work list (bath_orfs.hip)
 struct OrfRec {                   // one ORF of the length-sorted work list

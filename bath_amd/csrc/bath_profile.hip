@@ -6,6 +6,7 @@
 //                                 p7_bg_SetLength/NullOne    src/p7_bg.c:189,356
 // The striped SIMD layout of the reference is an implementation detail of impl_sse; here every
 // table is indexed by model node and laid out for the kernels in bath_filters.hip.
+#include <cctype>
 #include <cmath>
 #include <cstring>
 
@@ -150,9 +151,27 @@ extern "C" void bath_hip_oprofile_destroy(bath_hip_oprofile *om) {
   if (!om) return;
   for (void *p : {(void *)om->d_emit, (void *)om->d_ssv, (void *)om->d_rb, (void *)om->d_rw, (void *)om->d_tw, (void *)om->d_rf, (void *)om->d_tf,
                   (void *)om->d_bias_eo, (void *)om->d_vit_rw, (void *)om->d_vit_tw2, (void *)om->d_vit_tdd, (void *)om->d_vit_rank, (void *)om->lt.d_tjb, (void *)om->lt.d_xwmove, (void *)om->lt.d_pmove,
-                  (void *)om->lt.d_nullsc, (void *)om->lt.d_lt1, (void *)om->lt.d_lt2, (void *)om->lt.d_p1})
+                  (void *)om->lt.d_nullsc, (void *)om->lt.d_lt1, (void *)om->lt.d_lt2, (void *)om->lt.d_p1, (void *)om->d_cons})
     if (p) (void)hipFree(p);
   delete om;
+}
+
+// P7_OPROFILE.consensus (impl_sse.h:128; copied by p7_oprofile_Convert): the alignment display compares aligned residues with
+// it for the hit table's percent identity.  Stored digitized as esl_abc_DigitizeSymbol would (case-insensitive).
+extern "C" int bath_hip_oprofile_set_consensus(bath_hip_oprofile *om, const char *consensus) {
+  if (!om || !consensus) return BATH_EINVAL;
+  bath_hip_ctx *ctx = om->ctx;
+  static const char syms[] = "ACDEFGHIKLMNPQRSTVWY-BJZOUX*~";
+  om->consensus.assign((size_t)om->M + 2, ' ');
+  om->cons_digital.assign((size_t)om->M + 1, 255);
+  for (int k = 1; k <= om->M && consensus[k]; k++) {
+    om->consensus[(size_t)k] = consensus[k];
+    const char *q = std::strchr(syms, std::toupper((unsigned char)consensus[k]));
+    if (q) om->cons_digital[(size_t)k] = (uint8_t)(q - syms);
+  }
+  if (!om->d_cons) BATH_HIP_TRY(ctx, hipMalloc(&om->d_cons, (size_t)om->M + 1));
+  BATH_HIP_TRY(ctx, hipMemcpy(om->d_cons, om->cons_digital.data(), (size_t)om->M + 1, hipMemcpyHostToDevice));
+  return BATH_OK;
 }
 
 extern "C" int bath_hip_oprofile_M(const bath_hip_oprofile *om) { return om->M; }

@@ -9,6 +9,7 @@
 // Written from scratch in C++; numerics (float/double promotion order) follow the cited lines so the
 // resulting score tables are bit-identical to the reference's.
 #include <algorithm>
+#include <cctype>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -77,7 +78,7 @@ extern "C" int bath_hmmfile_count(const char *path) {
 
 extern "C" void bath_hmm_destroy(bath_hmm *h) {
   if (!h) return;
-  delete[] h->t; delete[] h->mat; delete[] h->ins; delete h;
+  delete[] h->t; delete[] h->mat; delete[] h->ins; delete[] h->consensus; delete h;
 }
 
 extern "C" int bath_hmmfile_read(const char *path, int index, bath_hmm **ret) {
@@ -98,11 +99,13 @@ extern "C" int bath_hmmfile_read(const char *path, int index, bath_hmm **ret) {
   for (float &e : h->evparam) e = -99999.0f;
   auto fail = [&](int code) { bath_hmm_destroy(h); return code; };
 
-  bool body = false;
+  bool body = false, has_cons = false;
   while (std::getline(in, line)) {
     std::istringstream ss(line);
     std::string tag; ss >> tag;
     if (tag == "NAME") { std::string v; ss >> v; std::snprintf(h->name, sizeof h->name, "%s", v.c_str()); }
+    else if (tag == "ACC") { std::string v; ss >> v; std::snprintf(h->acc, sizeof h->acc, "%s", v.c_str()); }
+    else if (tag == "CONS") { std::string v; ss >> v; has_cons = (v == "yes"); }
     else if (tag == "LENG") ss >> h->M;
     else if (tag == "MAXL") ss >> h->max_length;
     else if (tag == "ALPH") { std::string v; ss >> v; if (v != "amino") return fail(BATH_EFORMAT); }
@@ -126,6 +129,8 @@ extern "C" int bath_hmmfile_read(const char *path, int index, bath_hmm **ret) {
   h->t   = new float[(size_t)(M + 1) * 7]();
   h->mat = new float[(size_t)(M + 1) * 20]();
   h->ins = new float[(size_t)(M + 1) * 20]();
+  h->consensus = new char[(size_t)M + 2]();
+  h->consensus[0] = ' ';
 
   auto read_tokens = [&](std::vector<std::string> &toks) -> bool {
     if (!std::getline(in, line)) return false;
@@ -149,6 +154,13 @@ extern "C" int bath_hmmfile_read(const char *path, int index, bath_hmm **ret) {
   for (int k = 1; k <= M; k++) {
     if (!read_tokens(tk) || tk.size() < 21 || atoi(tk[0].c_str()) != k) return fail(BATH_EFORMAT);
     for (int x = 0; x < 20; x++) h->mat[(size_t)k * 20 + x] = prob_from_token(tk[1 + x]);
+    if (has_cons && tk.size() >= 23) h->consensus[k] = tk[22][0];             // columns after the emissions: MAP CONS RF MM CS (p7_hmmfile.c:1624-1640)
+    else {                                                                    // p7_hmm_SetConsensus for an amino model
+      int best = 0;
+      for (int x = 1; x < 20; x++) if (h->mat[(size_t)k * 20 + x] > h->mat[(size_t)k * 20 + best]) best = x;
+      const char c = kAminoSyms[best];
+      h->consensus[k] = h->mat[(size_t)k * 20 + best] >= 0.5f ? c : (char)std::tolower(c);
+    }
     if (!read_tokens(tk) || tk.size() < 20) return fail(BATH_EFORMAT);
     for (int x = 0; x < 20; x++) h->ins[(size_t)k * 20 + x] = prob_from_token(tk[x]);
     if (!read_tokens(tk) || tk.size() < 7) return fail(BATH_EFORMAT);

@@ -59,6 +59,10 @@ typedef struct {
   float   compo[BATH_K_AMINO];
   float   evparam[BATH_NEVPARAM];
   char    name[128];
+  char    acc[64];  /* ACC line, "" when absent                                              */
+  char   *consensus;/* [M+2] consensus residue per node, consensus[0] = ' ' (P7_HMM.consensus): the file's CONS column,
+                     * or p7_hmm_SetConsensus's rule when the file has none (p7_hmm.c: most probable residue,
+                     * upper case if its probability is >= 0.5)                                */
 } bath_hmm;
 
 /* P7_PROFILE (hmmer.h:338): what p7_oprofile_Convert() reads. */
@@ -109,6 +113,8 @@ void       *bath_hip_stream(bath_hip_ctx *ctx);                      /* hipStrea
  * ------------------------------------------------------------------------------------------ */
 int  bath_hip_oprofile_convert(bath_hip_ctx *ctx, const bath_profile *gm, bath_hip_oprofile **ret); /* p7_oprofile_Convert, p7_oprofile.c:1091 */
 void bath_hip_oprofile_destroy(bath_hip_oprofile *om);
+/* P7_OPROFILE.consensus (impl_sse.h:128), consensus[1..M] as in bath_hmm: needed only for the hits' percent identity. */
+int  bath_hip_oprofile_set_consensus(bath_hip_oprofile *om, const char *consensus);
 int  bath_hip_oprofile_M(const bath_hip_oprofile *om);
 
 /* Scalars of the limited-precision score systems (impl_sse.h:79-96), for L as configured by
@@ -243,7 +249,13 @@ typedef struct {
   double  lnP;
   int32_t reported;                /* exp(lnP) * Z <= E_report, Z = nres of the block / max_length (:1080)      */
   int32_t n_shifted_codons;        /* match states of the alignment that emit a quasi-codon (length != 3)        */
+  /* what --tblout prints of the alignment display (p7_alidisplay.c:538-935, 937-1245) */
+  int32_t n_stops;                 /* aligned codons that are stop codons (ad->stops)                            */
+  float   pid;                     /* percent of alignment columns whose residue is the consensus residue (ad->pid); 0 without a consensus */
+  int32_t ali_columns;             /* ad->N: trace states from the first to the last match state                  */
+  int64_t cigar_off;               /* the --cigar string starts at bath_hip_domain_cigars(ctx) + cigar_off        */
 } bath_fs_domain;
+const char *bath_hip_domain_cigars(const bath_hip_ctx *ctx);   /* NUL-terminated strings, valid until the next pipeline call */
 int  bath_hip_pipeline_frameshift_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bath_hip_fsprofile *om_fs3,
                                           const bath_hip_fsprofile *om_fs5, const bath_hip_seqs *dna, const bath_pipeline_params *params,
                                           double E_report, bath_pipeline_stats *stats,
@@ -257,6 +269,32 @@ int  bath_hip_pipeline_frameshift_domains(bath_hip_ctx *ctx, const bath_hip_opro
 int  bath_hip_pipeline_hits(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bath_hip_seqs *dna,
                             const bath_pipeline_params *params, double E_report, bath_pipeline_stats *stats,
                             const bath_fs_domain **domains, int64_t *n_domains, int64_t *n_skipped_regions);
+
+/* ------------------------------------------------------------------------------------------
+ * Hit list of a search and its tabular output (P7_TOPHITS; host code).
+ * What bathsearch does after its workers finish (bathsearch.c:868-921): p7_tophits_ComputeEvalues_BATH
+ * (p7_tophits.c:789), SortBySeqidxAndAlipos (:379), RemoveDuplicates (:816), SortBySortkey (:345), Threshold (:914),
+ * and p7_tophits_TabularTargets (:1603) for --tblout.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct bath_tophits bath_tophits;
+bath_tophits *bath_tophits_create(void);
+void bath_tophits_destroy(bath_tophits *th);
+/* One hit per domain with reported != 0 (the pipeline's own E-value test, p7_pipeline.c:1080,1246).  <cigars> is
+ * bath_hip_domain_cigars(ctx) or NULL; the block's sequence w has global index seqidx0 + w, name seq_names[w], length
+ * seq_lens[w]; seq_accs / seq_descs may be NULL. */
+int  bath_tophits_add(bath_tophits *th, const bath_fs_domain *dom, int64_t n, const char *cigars, int64_t seqidx0,
+                      const char *const *seq_names, const char *const *seq_accs, const char *const *seq_descs, const int64_t *seq_lens);
+/* <nres>: residues searched, both strands (sum of the pipelines' nres); E: reporting threshold (-E, default 10). */
+int  bath_tophits_finalize(bath_tophits *th, int64_t nres, int max_length, double E);
+int64_t bath_tophits_count(const bath_tophits *th);       /* hits held, reported or not */
+int64_t bath_tophits_reported(const bath_tophits *th);
+#define BATH_HIT_REPORTED  1
+#define BATH_HIT_DUPLICATE 4
+/* The rank-th hit in the current sort order (by E-value after finalize); dom->lnP is the E-value's log after finalize. */
+int  bath_tophits_get(const bath_tophits *th, int64_t rank, bath_fs_domain *dom, int64_t *seqidx, int32_t *flags);
+/* Returns the table's size in bytes and copies at most <cap> of them to <buf>. */
+int64_t bath_tophits_tabular_targets(const bath_tophits *th, const char *qname, const char *qacc, int M, int fs_pipe,
+                                     int show_cigar, int show_header, char *buf, int64_t cap);
 
 /* ------------------------------------------------------------------------------------------
  * Frameshift kernels (P7_FS_OPROFILE surface), batched over DNA windows.
