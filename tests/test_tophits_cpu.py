@@ -93,3 +93,31 @@ def test_empty_list_prints_header_only():
     text = th.tblout("query", "ACC1", 50, fs_pipe=True, show_cigar=False)
     lines = text.split("\n")
     assert len(lines) == 3 and lines[2] == "" and lines[0].startswith("# hit ID") and "shifts" in lines[0] and lines[0].endswith("description of target")
+
+
+import recorded
+
+
+@pytest.mark.parametrize("outfile,hmmfile,fasta,fs", recorded.RUNS, ids=[r[0] for r in recorded.RUNS])
+def test_oracle_reproduces_recorded_annotation_lines(outfile, hmmfile, fasta, fs):
+    """All 12 per-hit lines of tutorial/*.out from the ORACLE's domains (stop counts excepted: an alignment-display output
+    the oracle does not restate).  Pins oracle/domaindef.c and oracle/fs_domaindef.c on two more models and codon table 4."""
+    want = recorded.annotation_lines(outfile)
+    recs = ol.read_fasta(ol.GOLDEN + "/" + fasta)
+    seqs = [ol.digitize_dna(s) for _, s in recs]
+    for q, lines in enumerate(want):
+        m = ol.Model(ol.GOLDEN + "/" + hmmfile, q)
+        hmm = ba.HMM(ol.GOLDEN + "/" + hmmfile, q)
+        if fs:
+            pli, _, _, odm, per_d, _ = m.run_pipeline_fsdom(seqs)
+        else:
+            pli, odm, per_d, _ = m.run_pipeline_hits(seqs)
+        doms = [from_oracle(o, w) for w, (a, b) in enumerate(per_d) for o in odm[a:b]]
+        th = ba.TopHits()
+        th.add(doms, [n.split()[0] for n, _ in recs], [len(s) for s in seqs])
+        th.finalize(pli.nres, hmm.max_length)
+        got = [recorded.fields_of(d, len(seqs[idx]), fs, with_env=len(lines[0]) == 11) for d, idx, fl in th.hits() if fl & 1]
+        if fs:
+            for g, w in zip(got, lines):
+                g[8] = w[8]                                            # stops
+        assert got == lines
