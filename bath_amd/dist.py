@@ -11,7 +11,9 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from . import ORF_RESULT_DTYPE, PipelineStats
+import ctypes as C
+
+from . import ORF_RESULT_DTYPE, FsDomain, PipelineStats
 
 STAT_FIELDS = [n for n, _ in PipelineStats._fields_]
 
@@ -65,6 +67,49 @@ def gather_results(res, window_offset, dst=0, device="cpu"):
         return None
     parts = [np.frombuffer(bufs[r][: int(counts[r].item())].cpu().numpy().tobytes(), dtype=ORF_RESULT_DTYPE) for r in range(world)]
     return np.concatenate(parts)
+
+
+def gather_bytes(data, dst=0, device="cpu"):
+    """Variable-length gather of one bytes object per rank; the list on rank <dst>, None elsewhere."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [data]
+    world, rank = dist.get_world_size(), dist.get_rank()
+    counts = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(counts, torch.tensor([len(data)], dtype=torch.int64, device=device))
+    mx = max(1, int(max(int(c.item()) for c in counts)))
+    pad = torch.zeros(mx, dtype=torch.uint8, device=device)
+    if len(data):
+        pad[: len(data)] = torch.frombuffer(bytearray(data), dtype=torch.uint8).to(device)
+    bufs = [torch.empty(mx, dtype=torch.uint8, device=device) for _ in range(world)]
+    dist.all_gather(bufs, pad)
+    if rank != dst:
+        return None
+    return [bytes(bufs[r][: int(counts[r].item())].cpu().numpy().tobytes()) for r in range(world)]
+
+
+def gather_domains(domains, window_offset, dst=0, device="cpu"):
+    """p7_tophits_Merge for the hits proper: every rank's bath_fs_domain records with their CIGAR strings arrive on rank
+    <dst> (a list of FsDomain with .cigar set and window indices made global); None on the other ranks."""
+    sz = C.sizeof(FsDomain)
+    blob = bytearray()
+    for d in domains:
+        x = FsDomain()
+        C.memmove(C.byref(x), C.byref(d), sz)
+        x.window += window_offset
+        cig = d.cigar.encode()
+        blob += bytes(x) + len(cig).to_bytes(4, "little") + cig
+    parts = gather_bytes(bytes(blob), dst, device)
+    if parts is None:
+        return None
+    out = []
+    for part in parts:
+        p = 0
+        while p < len(part):
+            x = FsDomain.from_buffer_copy(part[p : p + sz]); p += sz
+            n = int.from_bytes(part[p : p + 4], "little"); p += 4
+            x.cigar = part[p : p + n].decode(); p += n
+            out.append(x)
+    return out
 
 
 def max_over_ranks(x, device="cpu"):

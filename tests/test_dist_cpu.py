@@ -40,8 +40,22 @@ def _worker(rank, world, port, q):
     res["usc"] = 10.0 * rank + np.arange(hi - lo)
     merged = bd.reduce_stats(stats)
     hits = bd.gather_results(res, lo, 0)
+    doms = []
+    for w in range(hi - lo):                                    # one hit per local sequence, CIGAR of rank-dependent length
+        d = ba.FsDomain()
+        d.window, d.iali, d.jali, d.ihmm, d.jhmm, d.bitscore, d.lnP, d.reported = w, 10 + w, 300 + w, 1, 100, 50.0 + lo + w, -30.0 - (lo + w), 1
+        d.cigar = "%dM" % (3 * (lo + w + 1)) * (rank + 1)
+        doms.append(d)
+    gd = bd.gather_domains(doms, lo, 0)
+    table = None
+    if gd is not None:                                          # rank 0 finishes the search: hit list + table
+        th = ba.TopHits()
+        th.add(gd, ["s%d" % i for i in range(n_total)], [5000] * n_total)
+        th.finalize(merged["nres"], 100)
+        table = [l.split() for l in th.tblout("q", "", 100, show_cigar=True, show_header=False).split("\n") if l]
     t = bd.max_over_ranks(1.0 + rank)
-    q.put((rank, len(blob), (lo, hi), merged["nres"], merged["n_past_msv"], None if hits is None else hits["window"].tolist(), t))
+    q.put((rank, len(blob), (lo, hi), merged["nres"], merged["n_past_msv"], None if hits is None else hits["window"].tolist(), t,
+           None if gd is None else [(d.window, d.cigar) for d in gd], table))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -63,6 +77,12 @@ def test_two_rank_gather_and_reduce():
     assert all(o[3] == 2000 * 11 and o[4] == 11 for o in outs)      # p7_pipeline_Merge
     assert outs[0][5] == list(range(11)) and outs[1][5] is None     # p7_tophits_Merge on rank 0, global window ids
     assert all(o[6] == 2.0 for o in outs)                           # max-over-ranks timing
+    # the hits themselves: records and CIGAR strings of both ranks on rank 0, global sequence indices, then one table
+    assert outs[1][7] is None and [w for w, _ in outs[0][7]] == list(range(11))
+    assert all(c == "%dM" % (3 * (w + 1)) * (1 if w < 6 else 2) for w, c in outs[0][7])
+    table = outs[0][8]
+    assert [r[1] for r in table] == ["s%d" % i for i in range(10, -1, -1)]          # best E-value (last sequence) first
+    assert table[0][-1] == "33M33M" and table[-1][-1] == "3M"
 
 
 def test_shard_range_partitions():
