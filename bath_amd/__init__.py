@@ -153,6 +153,7 @@ ABI = {
     "bath_hip_seqs_create": (C.c_int, [_vp, _u8p, _i64p, C.c_int64, C.POINTER(_vp)]),
     "bath_hip_seqs_destroy": (None, [_vp]),
     "bath_hip_seqs_count": (C.c_int64, [_vp]),
+    "bath_hip_seqs_set_context": (C.c_int, [_vp, C.POINTER(C.c_int32)]),
     "bath_hip_ssvfilter": (C.c_int, [_vp, _vp, _vp, _f32p, _i32p]),
     "bath_hip_msvfilter": (C.c_int, [_vp, _vp, _vp, _f32p, _i32p]),
     "bath_hip_vitfilter": (C.c_int, [_vp, _vp, _vp, _f32p, _i32p]),
@@ -419,6 +420,15 @@ class SeqBlock:
         h = _vp()
         ctx._check(lib().bath_hip_seqs_create(ctx._h, _u8(flat), _i64(offsets), self.n, C.byref(h)), "seqs_create")
         self.ctx, self._h = ctx, h
+
+    def set_context(self, context):
+        """ESL_SQ.C per window: leading nucleotides shared with the previous window of the same target (or None)."""
+        if context is None:
+            self.ctx._check(lib().bath_hip_seqs_set_context(self._h, None), "seqs_set_context")
+            return
+        c = np.ascontiguousarray(context, dtype=np.int32)
+        assert c.shape == (self.n,)
+        self.ctx._check(lib().bath_hip_seqs_set_context(self._h, c.ctypes.data_as(C.POINTER(C.c_int32))), "seqs_set_context")
 
     def __del__(self):
         if getattr(self, "_h", None) and getattr(self.ctx, "_h", None):

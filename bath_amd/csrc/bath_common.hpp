@@ -88,6 +88,7 @@ struct SeqView {
   const int64_t *off;      // [n]
   const int32_t *len;      // [n]
   int64_t n;
+  const int32_t *context;  // [n] or null: leading nucleotides already searched with the previous window (ESL_SQ.C)
 };
 
 struct bath_hip_seqs {
@@ -108,9 +109,11 @@ struct bath_hip_seqs {
   uint8_t *d_data = nullptr;
   int64_t *d_off = nullptr;
   int32_t *d_len = nullptr;
+  int32_t *d_context = nullptr; // [n] ESL_SQ.C of every window (bath_hip_seqs_set_context); null: all zero
   std::vector<int64_t> h_off;   // device offsets (aligned)
   std::vector<int32_t> h_len;
-  SeqView view() const { return SeqView{d_data, d_off, d_len, n}; }
+  std::vector<int32_t> h_context;
+  SeqView view() const { return SeqView{d_data, d_off, d_len, n, d_context}; }
 };
 
 // Per-length scalars of the limited-precision score systems (p7_oprofile_ReconfigLength, p7_oprofile.c:1261):

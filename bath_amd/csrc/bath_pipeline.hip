@@ -113,12 +113,19 @@ __global__ __launch_bounds__(256) void ssv_orf_kernel(const uint8_t *__restrict_
     }
     const int v = ssv_group_max<G>(xE);
     if (live && grank == 0 && v >= (int)emit_thresh[min(L, thresh_max)]) {
-      const int slot = atomicAdd(&ctr->cand_count, 1);
-      if (slot < cand_cap) {
-        const int sf = (int)((unsigned)rec.len_sf >> 28);
-        const int64_t w = rec.w;
-        const int64_t stream = 2 * dna.off[w] + 96 * w + (int64_t)sf * orf_stream_pitch(dna.len[w]);
-        cand.window[slot] = w; cand.sf[slot] = sf; cand.startj[slot] = (int32_t)(rec.aa_off - stream); cand.len[slot] = L;
+      const int sf = (int)((unsigned)rec.len_sf >> 28);
+      const int64_t w = rec.w;
+      const int64_t stream = 2 * dna.off[w] + 96 * w + (int64_t)sf * orf_stream_pitch(dna.len[w]);
+      const int startj = (int32_t)(rec.aa_off - stream);
+      bool seen = false;                // an ORF that lies inside the previous window's share of this one (p7_pipeline.c:1635-1637)
+      if (dna.context) {
+        const int C = dna.context[w], start_s = sf % 3 + 3 * startj + 1;
+        seen = sf < 3 ? (start_s + 3 * L - 1 < C) : (dna.len[w] - start_s + 1 < C);
+      }
+      const int slot = seen ? cand_cap + 1 : atomicAdd(&ctr->cand_count, 1);
+      if (seen) {
+      } else if (slot < cand_cap) {
+        cand.window[slot] = w; cand.sf[slot] = sf; cand.startj[slot] = startj; cand.len[slot] = L;
         cand.v[slot] = (int16_t)min(v, 32767); cand.off[slot] = rec.aa_off;
       } else atomicOr(&ctr->overflow, 1);
     }
@@ -559,7 +566,7 @@ static int run_filters(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bat
     for (int64_t i = 0; i < nwin; i++) {
       const int n = dna->h_len[i];
       if (n < 15) continue;
-      nres_c += 2 * (int64_t)n;
+      nres_c += 2 * (int64_t)(n - (dna->h_context.empty() ? 0 : dna->h_context[(size_t)i]));    // dnaSeq->W per strand
       max_orfs_c += 6 * (int64_t)((n / 3 + 1) / (prm->min_orf_len + 1) + 1);
     }
     dna->cache_minlen = prm->min_orf_len; dna->cache_nres = nres_c; dna->cache_max_orfs = max_orfs_c;
@@ -798,6 +805,7 @@ static int ensure_parts(bath_hip_ctx *ctx, const bath_hip_seqs *dna, int K) {
     p->total_aligned = (w1 < dna->n ? dna->h_off[(size_t)w1] : dna->total_aligned) - base;
     p->d_data = dna->d_data + base;
     p->d_len = dna->d_len + w0;
+    if (dna->d_context) { p->d_context = dna->d_context + w0; p->h_context.assign(dna->h_context.begin() + w0, dna->h_context.begin() + w1); }
     dna->parts.push_back(p);
     if (hipMalloc((void **)&p->d_off, (size_t)std::max<int64_t>(p->n, 1) * sizeof(int64_t)) != hipSuccess) { ctx->set_error("hipMalloc (block parts)"); return BATH_EMEM; }
     if (p->n > 0 && hipMemcpy(p->d_off, p->h_off.data(), (size_t)p->n * sizeof(int64_t), hipMemcpyHostToDevice) != hipSuccess) { ctx->set_error("hipMemcpy (block parts)"); return BATH_EFAIL; }

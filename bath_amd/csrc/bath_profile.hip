@@ -360,13 +360,30 @@ extern "C" void bath_hip_seqs_destroy(bath_hip_seqs *sq) {
   if (!sq) return;
   for (bath_hip_seqs *part : sq->parts) bath_hip_seqs_destroy(part);
   sq->parts.clear();
-  if (sq->is_part) { sq->d_data = nullptr; sq->d_len = nullptr; }      // borrowed from the parent block
-  for (void *p : {(void *)sq->d_data, (void *)sq->d_off, (void *)sq->d_len, (void *)sq->d_tile_desc, (void *)sq->d_tile_first})
+  if (sq->is_part) { sq->d_data = nullptr; sq->d_len = nullptr; sq->d_context = nullptr; }      // borrowed from the parent block
+  for (void *p : {(void *)sq->d_data, (void *)sq->d_off, (void *)sq->d_len, (void *)sq->d_context, (void *)sq->d_tile_desc, (void *)sq->d_tile_first})
     if (p) (void)hipFree(p);
   delete sq;
 }
 
 extern "C" int64_t bath_hip_seqs_count(const bath_hip_seqs *sq) { return sq->n; }
+
+// ESL_SQ.C of the windows of a long target read with esl_sqio_ReadWindow(dbfp, 3 * max_length, block_length, .)
+// (bathsearch.c:1099): the pipeline skips ORFs that lie inside the context (p7_pipeline.c:1635-1637) and counts only the
+// new residues (pli->nres += dnaSeq->W, bathsearch.c:1258,1268).
+extern "C" int bath_hip_seqs_set_context(bath_hip_seqs *sq, const int32_t *context) {
+  if (!sq || sq->is_part) return BATH_EINVAL;
+  bath_hip_ctx *ctx = sq->ctx;
+  for (bath_hip_seqs *part : sq->parts) bath_hip_seqs_destroy(part);    // parts carry a pointer into d_context: rebuild on next use
+  sq->parts.clear();
+  sq->cache_minlen = -1;
+  if (!context) { if (sq->d_context) (void)hipFree(sq->d_context); sq->d_context = nullptr; sq->h_context.clear(); return BATH_OK; }
+  for (int64_t i = 0; i < sq->n; i++) if (context[i] < 0 || context[i] > sq->h_len[(size_t)i]) { ctx->set_error("context longer than its window"); return BATH_EINVAL; }
+  sq->h_context.assign(context, context + sq->n);
+  if (!sq->d_context) BATH_HIP_TRY(ctx, hipMalloc((void **)&sq->d_context, (size_t)std::max<int64_t>(sq->n, 1) * sizeof(int32_t)));
+  if (sq->n > 0) BATH_HIP_TRY(ctx, hipMemcpy(sq->d_context, sq->h_context.data(), (size_t)sq->n * sizeof(int32_t), hipMemcpyHostToDevice));
+  return BATH_OK;
+}
 
 extern "C" int bath_hip_seqs_create(bath_hip_ctx *ctx, const uint8_t *dsq, const int64_t *offsets, int64_t n, bath_hip_seqs **ret) {
   *ret = nullptr;

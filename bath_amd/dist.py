@@ -25,6 +25,31 @@ def shard_range(n_items, rank, world):
     return lo, lo + per + (1 if rank < rem else 0)
 
 
+BLOCK_LENGTH = 262144        # BATH_MAX_RESIDUE_COUNT, the default --block_length (bathsearch.c:839)
+
+
+def split_targets(lengths, max_length, block_length=BLOCK_LENGTH):
+    """The windows esl_sqio_ReadWindow hands to the workers (bathsearch.c:1060, 1099): a target longer than <block_length>
+    is read in windows of at most block_length new nucleotides, each after the first preceded by a context of
+    C = 3 * max_length nucleotides of the previous window, so that no ORF is lost at a boundary.
+
+    Returns a list of (seqidx, start0, n, C): window = target[start0 : start0 + n], its first C nucleotides are context.
+    A hit found at window coordinate p lies at target coordinate start0 + p on either strand."""
+    C_ = 3 * int(max_length)
+    out = []
+    for idx, L in enumerate(lengths):
+        L = int(L)
+        pos = 0
+        while True:
+            c = 0 if pos == 0 else C_
+            n_new = min(block_length, L - pos)
+            out.append((idx, pos - c, n_new + c, c))
+            pos += n_new
+            if pos >= L:
+                break
+    return out
+
+
 def broadcast_bytes(data, src=0, device="cpu"):
     """Broadcast a bytes object (the query model file) from <src> to every rank."""
     if not dist.is_initialized() or dist.get_world_size() == 1:

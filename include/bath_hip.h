@@ -141,6 +141,10 @@ int  bath_hip_oprofile_get_fwd(const bath_hip_oprofile *om, float *rf, float *tf
 int     bath_hip_seqs_create(bath_hip_ctx *ctx, const uint8_t *dsq, const int64_t *offsets, int64_t n, bath_hip_seqs **ret);
 void    bath_hip_seqs_destroy(bath_hip_seqs *sq);
 int64_t bath_hip_seqs_count(const bath_hip_seqs *sq);
+/* Windows of a long target (esl_sqio_ReadWindow with context, bathsearch.c:1099): context[i] = ESL_SQ.C of window i, the
+ * leading nucleotides that also ended the previous window.  ORFs inside the context are skipped (p7_pipeline.c:1635-1637)
+ * and only the new residues are counted in stats->nres (bathsearch.c:1258).  NULL clears it. */
+int  bath_hip_seqs_set_context(bath_hip_seqs *sq, const int32_t *context);
 
 /* ------------------------------------------------------------------------------------------
  * Filter kernels, batched.  Each target i is scored exactly as the reference would after

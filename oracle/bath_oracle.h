@@ -266,6 +266,8 @@ typedef struct {
   int64_t pos_past_msv, pos_past_bias, pos_past_vit, pos_past_fwd;
   int64_t cells_msv, cells_vit, cells_fwd;
   double  E;                                   /* reporting E-value threshold (p7_pipeline.c:147), 10.0 */
+  int32_t context;                             /* ESL_SQ.C of the window being searched: leading nucleotides the previous window
+                                                * already covered (bathsearch.c:1099; p7_pipeline.c:1635-1637); 0 for whole sequences */
 } bo_pipeline;
 
 typedef struct {                 /* per-ORF cascade record (what the GPU path must reproduce) */

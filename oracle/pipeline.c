@@ -71,6 +71,9 @@ static void strand_cascade(bo_pipeline *pli, bo_oprofile *om, const bo_scoredata
     r->vfsc = -INFINITY; r->fwdsc = -INFINITY; r->P = 1.0; r->stage = 0;
     pli->n_orfs++;
     if (n <= 0) continue;
+    /* p7_pipeline.c:1635-1637: the ORF showed up completely within the previous window (orfsq->start of the bottom strand is a
+     * top-strand coordinate, window length - o->start + 1) */
+    if (pli->context > 0 && fs && ((strand == 0 && o->end < pli->context) || (strand == 1 && fs->n - o->start + 1 < pli->context))) { r->stage = -1; continue; }
 
     float usc, vfsc = -INFINITY, fwdsc, filtersc, seqsc;
     double P;
@@ -191,14 +194,14 @@ int bo_pipeline_window_fsdom(bo_pipeline *pli, bo_oprofile *om, bo_fs_profile *g
   bo_bg_setfilter(bg, om->M, om->compo);                      /* p7_pli_NewModel, p7_pipeline.c:635 */
   fs_stage fs = { gm3, gm5, basic, dna, n, fw, nfw, fw_alloc, doms, ndom, dom_alloc, nskipped };
 
-  pli->nres += n;                                             /* top strand, bathsearch.c:1073 */
+  pli->nres += n - pli->context;                              /* top strand: dnaSeq->W, bathsearch.c:1258 */
   bo_translate_orfs(dna, n, basic, pli->minlen, &blk);
   strand_cascade(pli, om, sd, bg, &blk, 0, res, nres, res_alloc, &fs);
   bo_orfblock_reuse(&blk);
 
   uint8_t *rc = malloc((size_t) n + 2);                       /* bottom strand, bathsearch.c:1084-1091 */
   bo_revcomp(dna, n, rc);
-  pli->nres += n;
+  pli->nres += n - pli->context;
   bo_translate_orfs(rc, n, basic, pli->minlen, &blk);
   fs.dsq = rc;
   strand_cascade(pli, om, sd, bg, &blk, 1, res, nres, res_alloc, &fs);

@@ -99,7 +99,7 @@ class Pipeline(C.Structure):
                 ("n_past_vit", C.c_int64), ("n_past_fwd", C.c_int64),
                 ("pos_past_msv", C.c_int64), ("pos_past_bias", C.c_int64), ("pos_past_vit", C.c_int64),
                 ("pos_past_fwd", C.c_int64),
-                ("cells_msv", C.c_int64), ("cells_vit", C.c_int64), ("cells_fwd", C.c_int64), ("E", C.c_double)]
+                ("cells_msv", C.c_int64), ("cells_vit", C.c_int64), ("cells_fwd", C.c_int64), ("E", C.c_double), ("context", C.c_int32)]
 
 
 class FsDomain(C.Structure):
@@ -313,16 +313,18 @@ class Model:
         out = [res[i] for i in range(nres.value)]
         return pli, out, per_seq
 
-    def run_pipeline_hits(self, seqs):
-        """The plain pipeline through domain definition: (Pipeline counters, FsDomain records, per-sequence ranges, skipped)."""
+    def run_pipeline_hits(self, seqs, contexts=None):
+        """The plain pipeline through domain definition: (Pipeline counters, FsDomain records, per-sequence ranges, skipped).
+        contexts[i]: ESL_SQ.C of window i (leading nucleotides shared with the previous window of the same target)."""
         L_ = lib()
         pli = Pipeline()
         L_.bo_pipeline_init(C.byref(pli), 0)
         res = C.POINTER(OrfResult)(); nres, alloc = C.c_int(0), C.c_int(0)
         dm = C.POINTER(FsDomain)(); ndm, dmalloc, nskip = C.c_int(0), C.c_int(0), C.c_int(0)
         per_d = []
-        for codes in seqs:
+        for i, codes in enumerate(seqs):
             d = dsq_from(codes)
+            pli.context = 0 if contexts is None else int(contexts[i])
             d0 = ndm.value
             L_.bo_pipeline_window_hits(C.byref(pli), self.om, self.sd, C.byref(self.bg), u8(self.basic), u8(d), len(codes),
                                        C.byref(res), C.byref(nres), C.byref(alloc), C.byref(dm), C.byref(ndm), C.byref(dmalloc), C.byref(nskip))
