@@ -514,14 +514,63 @@ static int std_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bat
   BATH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   view.d_data = nullptr; view.d_off = nullptr; view.d_len = nullptr;
 
-  struct Env { int s, i, j; };
-  std::vector<Env> envs;
-  int n_multi = 0;
+  struct Env { int s, i, j; bool clustered; float n2corr; };
+  std::vector<Env> envs, mregs;
   for (int64_t q = 0; q < ns; q++) {
     const int32_t *r = &regions[(size_t)q * RS];
-    for (int k = 0; k < r[0]; k++) { if (r[3 + 3 * k]) n_multi++; else envs.push_back(Env{(int)q, r[1 + 3 * k], r[2 + 3 * k]}); }
+    for (int k = 0; k < r[0]; k++) (r[3 + 3 * k] ? mregs : envs).push_back(Env{(int)q, r[1 + 3 * k], r[2 + 3 * k], false, 0.f});
   }
-  if (n_skipped_regions) *n_skipped_regions += n_multi;
+  if (n_skipped_regions) *n_skipped_regions += (int64_t)mregs.size();      // regions resolved by clustering (ddef->nclustered)
+
+  // ---- multi-domain regions (p7_domaindef.c:539-583): p7_Forward of the region with the ORF's multihit configuration on the
+  // GPU, then the stochastic-trace ensemble and its clustering on the host (bath_ensemble.hip); every cluster is an envelope
+  if (!mregs.empty()) {
+    const int64_t nm = (int64_t)mregs.size();
+    bath_hip_seqs mv;
+    mv.ctx = ctx; mv.n = nm; mv.is_part = true;
+    mv.h_off.resize((size_t)nm); mv.h_len.resize((size_t)nm);
+    std::vector<int64_t> mxoff((size_t)nm + 1, 0), mdpoff((size_t)nm + 1, 0);
+    std::vector<int32_t> cfg((size_t)nm);
+    for (int64_t e = 0; e < nm; e++) {
+      const Env &en = mregs[(size_t)e];
+      const int Lr = en.j - en.i + 1;
+      mv.h_off[(size_t)e] = surv[(size_t)en.s].aa_off + en.i - 1; mv.h_len[(size_t)e] = Lr; mv.maxlen = std::max(mv.maxlen, Lr);
+      cfg[(size_t)e] = surv[(size_t)en.s].n;
+      mxoff[(size_t)e + 1] = mxoff[(size_t)e] + ((int64_t)Lr + 1) * 6;
+      mdpoff[(size_t)e + 1] = mdpoff[(size_t)e] + ((int64_t)Lr + 1) * (M + 1) * 3;
+    }
+    if ((st = upload_view(mv, mxoff, nm)) != BATH_OK) return st;
+    DevBuf &b_mf = ctx->scratch[15], &b_mdpo = ctx->scratch[20], &b_cfg = ctx->scratch[5];
+    BATH_HIP_TRY(ctx, b_mf.reserve((size_t)mdpoff[(size_t)nm] * 4 + 64)); BATH_HIP_TRY(ctx, b_mdpo.reserve((size_t)(nm + 1) * 8)); BATH_HIP_TRY(ctx, b_cfg.reserve((size_t)nm * 4 + 64));
+    BATH_HIP_TRY(ctx, b_fx.reserve((size_t)mxoff[(size_t)nm] * 4 + 64)); BATH_HIP_TRY(ctx, b_sc.reserve((size_t)nm * 8)); BATH_HIP_TRY(ctx, b_st.reserve((size_t)nm * 8));
+    BATH_HIP_TRY(ctx, hipMemcpyAsync(b_mdpo.p, mdpoff.data(), (size_t)(nm + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    BATH_HIP_TRY(ctx, hipMemcpyAsync(b_cfg.p, cfg.data(), (size_t)nm * 4, hipMemcpyHostToDevice, ctx->stream));
+    if ((st = launch_fwd_wave(ctx, om, mv.view(), nullptr, nm, b_sc.as<float>(), b_st.as<int32_t>(), nullptr, b_fx.as<float>(), b_idx.as<int64_t>() + nm,
+                              b_mf.as<float>(), b_mdpo.as<int64_t>(), 0, b_cfg.as<int32_t>())) != BATH_OK) return st;
+    std::vector<float> h_dp((size_t)mdpoff[(size_t)nm]), h_x((size_t)mxoff[(size_t)nm]);
+    std::vector<uint8_t> h_res;
+    std::vector<int64_t> roff((size_t)nm + 1, 0);
+    for (int64_t e = 0; e < nm; e++) roff[(size_t)e + 1] = roff[(size_t)e] + mv.h_len[(size_t)e];
+    h_res.resize((size_t)roff[(size_t)nm] + 1);
+    BATH_HIP_TRY(ctx, hipMemcpyAsync(h_dp.data(), b_mf.p, h_dp.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+    BATH_HIP_TRY(ctx, hipMemcpyAsync(h_x.data(), b_fx.p, h_x.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+    for (int64_t e = 0; e < nm; e++)
+      BATH_HIP_TRY(ctx, hipMemcpyAsync(h_res.data() + roff[(size_t)e], d_pool + mv.h_off[(size_t)e], (size_t)mv.h_len[(size_t)e], hipMemcpyDeviceToHost, ctx->stream));
+    BATH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    mv.d_data = nullptr; mv.d_off = nullptr; mv.d_len = nullptr;
+    std::vector<float> n2sc;
+    std::vector<std::pair<int, int>> cl;
+    for (int64_t e = 0; e < nm; e++) {
+      const Env &en = mregs[(size_t)e];
+      const int Lr = en.j - en.i + 1;
+      if (region_trace_ensemble(om, cfg[(size_t)e], h_res.data() + roff[(size_t)e], Lr, h_dp.data() + mdpoff[(size_t)e], h_x.data() + mxoff[(size_t)e], &n2sc, &cl) != BATH_OK) continue;
+      for (const auto &c : cl) {
+        float corr = 0.f;
+        for (int pos = c.first; pos <= c.second; pos++) corr += n2sc[(size_t)pos];       // null2_is_done: p7_domaindef.c:1270-1272
+        envs.push_back(Env{en.s, en.i + c.first - 1, en.i + c.second - 1, true, corr});
+      }
+    }
+  }
   const int64_t ne = (int64_t)envs.size();
   if (ne == 0) return BATH_OK;
 
@@ -577,7 +626,8 @@ static int std_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bat
     const int seq_n = dna->h_len[(size_t)o.window];
     bath_fs_domain dm{};
     dm.window = o.window; dm.strand = o.strand; dm.fs_window = o.fs_window;
-    dm.ihmm = t.k1; dm.jhmm = t.k2; dm.envsc = envsc[(size_t)e]; dm.oasc = t.oasc; dm.domcorrection = std::max(0.f, t.domcorrection);
+    dm.ihmm = t.k1; dm.jhmm = t.k2; dm.envsc = envsc[(size_t)e]; dm.oasc = t.oasc;
+    dm.domcorrection = std::max(0.f, en.clustered ? en.n2corr : t.domcorrection);
     // alignment in nucleotides of the window (the ORF itself in the plain pipeline): p7_trace_fs_Convert puts a residue on its
     // codon's last nucleotide, offset by where the ORF starts in the window
     const int a1 = t.i1 + en.i - 1, a2 = t.i2 + en.i - 1, shift = o.start - o.win_start;

@@ -1,0 +1,225 @@
+// bath_ensemble.hip -- multi-domain regions: envelopes from a clustered ensemble of stochastic tracebacks (host code).
+//
+// Reference: region_trace_ensemble (src/p7_domaindef.c:766-850) with p7_StochasticTrace (src/impl_sse/stotrace.c:71-300),
+// p7_trace_Index (src/p7_trace.c:2592), p7_Null2_ByTrace (src/impl_sse/null2.c:131-215), p7_spensemble_Add / _Cluster and
+// link_spsamples (src/p7_spensemble.c:189-217, 300-440), parameters of p7_domaindef_Create_BATH (src/p7_domaindef.c:83-97).
+//
+// Where it runs.  The region's Forward matrix is computed on the GPU by fwd_wave_kernel (multihit, full matrix) and copied
+// to the host; the 200 tracebacks are a strictly serial consumer of one random-number stream (every choice draws the next
+// number), about 200 x (Lr + M) dependent steps per region, and regions of this kind are a few per thousand ORFs that pass
+// the Forward filter -- so the walk, the null2 bookkeeping and the clustering stay on the host.
+//
+// easel is not part of the reference tree (un-pinned submodule), so its pieces are restated from their published
+// algorithms: the "fast" generator of esl_randomness_CreateFast (x <- 69069 x + 1 on a Jenkins-mixed seed; u = x / 2^32;
+// re-seeded with 42 before every region, p7_pipeline.c:135-143), esl_rnd_FChoose, esl_vec_FNorm, and
+// esl_cluster_SingleLinkage (connected components of the link relation).  Parity of the sampled ensemble with a real
+// bathsearch run is therefore unpinned; tests compare this code with the oracle's independent restatement.
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <vector>
+
+#include "bath_common.hpp"
+#include "bath_launch.hpp"
+
+namespace {
+
+enum { XE = 0, XN, XJ, XB, XC, XS };
+enum { cM = 0, cD = 1, cI = 2 };
+enum { MM = 0, IM, DM, BM, MD, DD, MI, II };
+enum { sS = 0, sN, sB, sM, sD, sI, sE, sJ, sC, sT };
+
+struct FastRng {
+  uint32_t x;
+  explicit FastRng(uint32_t seed) {
+    uint32_t a = seed, b = 87654321u, c = 12345678u;
+    a -= b; a -= c; a ^= (c >> 13);  b -= c; b -= a; b ^= (a << 8);   c -= a; c -= b; c ^= (b >> 13);
+    a -= b; a -= c; a ^= (c >> 12);  b -= c; b -= a; b ^= (a << 16);  c -= a; c -= b; c ^= (b >> 5);
+    a -= b; a -= c; a ^= (c >> 3);   b -= c; b -= a; b ^= (a << 10);  c -= a; c -= b; c ^= (b >> 15);
+    x = c ? c : 42u;
+  }
+  double next() { x = x * 69069u + 1u; return (double)x / 4294967296.0; }
+};
+
+template <int N>
+int choose(FastRng &rng, float (&p)[N]) {
+  float sum = 0.f, comp = 0.f;                            // esl_vec_FNorm
+  for (int q = 0; q < N; q++) { const float y = p[q] - comp, t = sum + y; comp = (t - sum) - y; sum = t; }
+  for (int q = 0; q < N; q++) p[q] = (sum != 0.0f) ? p[q] / sum : 1.0f / (float)N;
+  for (;;) {                                              // esl_rnd_FChoose
+    const float roll = (float)rng.next();
+    float acc = 0.f;
+    for (int q = 0; q < N; q++) { acc += p[q]; if (roll < acc) return q; }
+  }
+}
+
+struct Step { int8_t st; int32_t k, i; };
+struct Seg { int idx, i, j, k, m; float prob; };
+
+}  // namespace
+
+// One region of an ORF.  fwd: (Lr+1) x (M+1) x {M,D,I}, fx: (Lr+1) x {E,N,J,B,C,SCALE} of p7_Forward on the region with the
+// model in the multihit configuration for length <cfg_L>; res[0..Lr): the region's residues.
+// Out: n2sc[0..Lr) per-residue null2 log odds; env: envelopes (1-based, region-relative), ordered by start.
+int bath::region_trace_ensemble(const bath_hip_oprofile *om, int cfg_L, const uint8_t *res, int Lr, const float *fwd, const float *fx,
+                                std::vector<float> *n2sc_out, std::vector<std::pair<int, int>> *env) {
+  const int M = om->M, Q = std::max(2, (M - 1) / 4 + 1);
+  const size_t W = (size_t)(M + 1) * 3;
+  const float *tf = om->tf.data();
+  if (om->ensure_len_tables(cfg_L) != BATH_OK) return BATH_EFAIL;
+  const float pmove = om->lt.h_pmove[(size_t)cfg_L], ploop = 1.0f - pmove;
+  const float tEL = om->xf_E[0], tEM = om->xf_E[1];
+  const int nsamples = 200, max_diagdiff = 4;
+  const float min_overlap = 0.8f, min_posterior = 0.25f, min_endpointp = 0.02f;
+  std::vector<float> &n2sc = *n2sc_out;
+  n2sc.assign((size_t)Lr + 1, 0.f);                       // 1-based positions of the region
+  env->clear();
+
+  FastRng rng(42);
+  std::vector<Step> tr;
+  std::vector<Seg> sp;
+  std::vector<float> cnt((size_t)M + 1);
+  const int step_cap = 4 * (Lr + M) + 64;
+  for (int t = 0; t < nsamples; t++) {
+    tr.clear();
+    int i = Lr, k = 0, s0 = sC;
+    tr.push_back(Step{(int8_t)sT, 0, i}); tr.push_back(Step{(int8_t)sC, 0, i});
+    while (s0 != sS) {
+      int s1 = -1;
+      switch (s0) {
+      case sM: {
+        const float *tk = tf + (size_t)k * 8, *pr = fwd + (size_t)(i - 1) * W;
+        float p[4] = {fx[(size_t)(i - 1) * 6 + XB] * tk[BM], pr[(size_t)(k - 1) * 3 + cM] * tk[MM], pr[(size_t)(k - 1) * 3 + cI] * tk[IM], pr[(size_t)(k - 1) * 3 + cD] * tk[DM]};
+        static const int state[4] = {sB, sM, sI, sD};
+        s1 = state[choose(rng, p)]; k--; i--; break; }
+      case sD: {
+        const float *c = fwd + (size_t)i * W;
+        float p[2] = {k - 1 >= 1 ? c[(size_t)(k - 1) * 3 + cM] * tf[(size_t)(k - 1) * 8 + MD] : 0.f, k - 1 >= 1 ? c[(size_t)(k - 1) * 3 + cD] * tf[(size_t)(k - 1) * 8 + DD] : 0.f};
+        s1 = choose(rng, p) == 0 ? sM : sD; k--; break; }
+      case sI: {
+        const float *pr = fwd + (size_t)(i - 1) * W;
+        float p[2] = {pr[(size_t)k * 3 + cM] * tf[(size_t)k * 8 + MI], pr[(size_t)k * 3 + cI] * tf[(size_t)k * 8 + II]};
+        s1 = choose(rng, p) == 0 ? sM : sI; i--; break; }
+      case sN: s1 = (i == 0) ? sS : sN; break;
+      case sC: {
+        float p[2] = {fx[(size_t)(i - 1) * 6 + XC] * ploop, fx[(size_t)i * 6 + XE] * tEM * fx[(size_t)i * 6 + XS]};
+        s1 = choose(rng, p) == 0 ? sC : sE; break; }
+      case sJ: {
+        float p[2] = {fx[(size_t)(i - 1) * 6 + XJ] * ploop, fx[(size_t)i * 6 + XE] * tEL * fx[(size_t)i * 6 + XS]};
+        s1 = choose(rng, p) == 0 ? sJ : sE; break; }
+      case sE: {                                          // select_e: cumulative sum in double over the cells in striped order
+        const float *c = fwd + (size_t)i * W;
+        const double roll = rng.next();
+        const float norm = (float)(1.0 / fx[(size_t)i * 6 + XE]);
+        double sum = 0.0;
+        for (int pass = 0; pass < 4 && s1 < 0; pass++)
+          for (int q = 0; q < Q && s1 < 0; q++) {
+            for (int r = 0; r < 4 && s1 < 0; r++) { const int kk = r * Q + q + 1; sum += kk <= M ? c[(size_t)kk * 3 + cM] * norm : 0.0f; if (roll < sum) { k = kk; s1 = sM; } }
+            for (int r = 0; r < 4 && s1 < 0; r++) { const int kk = r * Q + q + 1; sum += kk <= M ? c[(size_t)kk * 3 + cD] * norm : 0.0f; if (roll < sum) { k = kk; s1 = sD; } }
+          }
+        break; }
+      case sB: {
+        float p[2] = {fx[(size_t)i * 6 + XN] * pmove, fx[(size_t)i * 6 + XJ] * pmove};
+        s1 = choose(rng, p) == 0 ? sN : sJ; break; }
+      default: break;
+      }
+      if (s1 < 0 || i < 0 || k < 0 || (int)tr.size() > step_cap) return BATH_EFAIL;
+      tr.push_back(Step{(int8_t)s1, k, i});
+      if ((s1 == sN || s1 == sJ || s1 == sC) && s1 == s0) i--;
+      s0 = s1;
+    }
+    std::reverse(tr.begin(), tr.end());
+
+    // domains of this trace (p7_trace_Index), their null2 by trace, and the per-residue bookkeeping of :790-803
+    int pos = 1;
+    for (size_t z = 0; z < tr.size();) {
+      if (tr[z].st != sB) { z++; continue; }
+      const size_t zb = z;
+      int sqfrom = 0, sqto = 0, hmmfrom = 0, hmmto = 0, Ld = 0;
+      std::fill(cnt.begin(), cnt.end(), 0.f);
+      for (z = zb + 1; z < tr.size() && tr[z].st != sE; z++) {
+        if (tr[z].st == sM) { if (!sqfrom) sqfrom = tr[z].i; if (!hmmfrom) hmmfrom = tr[z].k; sqto = tr[z].i; hmmto = tr[z].k; }
+        if (tr[z].st == sM || tr[z].st == sI) { Ld++; cnt[(size_t)tr[z].k] += 1.0f; }      // inserts land in the match slot (null2.c:160-166)
+      }
+      sp.push_back(Seg{t, sqfrom, sqto, hmmfrom, hmmto, 0.f});
+      const float norm = (float)(1.0 / (float)Ld);
+      for (int q = 1; q <= M; q++) cnt[(size_t)q] *= norm;
+      float null2[kKp];
+      for (int x = 0; x < 20; x++) {
+        const float *e = om->rf.data() + (size_t)x * (M + 1);
+        float sv = 0.f;
+        for (int q = 1; q <= M; q++) sv += cnt[(size_t)q] * e[q];
+        null2[x] = sv;
+      }
+      static const int mem[6][2] = {{2, 11}, {7, 9}, {3, 13}, {8, 8}, {1, 1}, {-1, -1}};     // B=DN J=IL Z=EQ O=K U=C X=any
+      for (int dx = 0; dx < 6; dx++) {
+        float s = 0.f; int c = 0;
+        if (dx == 5) { for (int y = 0; y < 20; y++) { s += null2[y]; c++; } }
+        else { s += null2[mem[dx][0]]; c++; if (mem[dx][1] != mem[dx][0]) { s += null2[mem[dx][1]]; c++; } }
+        null2[21 + dx] = s / (float)c;
+      }
+      null2[20] = 1.0f; null2[27] = 1.0f; null2[28] = 1.0f;
+      for (; pos <= sqfrom; pos++) n2sc[(size_t)pos] += 1.0f;
+      for (; pos <= sqto; pos++) n2sc[(size_t)pos] += null2[std::min<int>(res[pos - 1], kKp - 1)];
+      z++;
+    }
+    for (; pos <= Lr; pos++) n2sc[(size_t)pos] += 1.0f;
+  }
+  for (int pos = 1; pos <= Lr; pos++) n2sc[(size_t)pos] = logf(n2sc[(size_t)pos] / (float)nsamples);
+
+  // ---- p7_spensemble_Cluster
+  auto linked = [&](const Seg &a, const Seg &b) {
+    int nov = std::min(a.j, b.j) - std::max(a.i, b.i) + 1, n = std::min(a.j - a.i + 1, b.j - b.i + 1);
+    if ((float)nov / (float)n < min_overlap) return false;
+    nov = std::min(a.m, b.m) - std::max(a.k, b.k); n = std::min(a.m - a.k + 1, b.m - b.k + 1);
+    if ((float)nov / (float)n < min_overlap) return false;
+    if (std::abs((a.i - a.k) - (b.i - b.k)) <= max_diagdiff) return true;
+    return std::abs((a.j - a.m) - (b.j - b.m)) <= max_diagdiff;
+  };
+  const int nsp = (int)sp.size();
+  std::vector<int> assign((size_t)nsp, -1), stack;
+  int nc = 0;
+  for (int h = 0; h < nsp; h++) {
+    if (assign[(size_t)h] >= 0) continue;
+    assign[(size_t)h] = nc; stack.assign(1, h);
+    while (!stack.empty()) {
+      const int a = stack.back(); stack.pop_back();
+      for (int b = 0; b < nsp; b++) if (assign[(size_t)b] < 0 && linked(sp[(size_t)a], sp[(size_t)b])) { assign[(size_t)b] = nc; stack.push_back(b); }
+    }
+    nc++;
+  }
+  std::vector<Seg> sig;
+  std::vector<int> epc;
+  for (int c = 0; c < nc; c++) {
+    int ninc = 0, last = -1;
+    for (int h = 0; h < nsp; h++) if (assign[(size_t)h] == c) { if (sp[(size_t)h].idx != last) ninc++; last = sp[(size_t)h].idx; }
+    if ((float)ninc / (float)nsamples < min_posterior) continue;
+    const int thr = (int)ceilf((float)ninc * min_endpointp);
+    // widest end point that at least thr segments of the cluster share, independently for i, k (leftmost) and j, m (rightmost)
+    auto consensus = [&](int Seg::*f, bool leftmost) {
+      int lo = 0, hi = 0; bool first = true;
+      for (int h = 0; h < nsp; h++) if (assign[(size_t)h] == c) { const int v = sp[(size_t)h].*f; if (first) { lo = hi = v; first = false; } else { lo = std::min(lo, v); hi = std::max(hi, v); } }
+      epc.assign((size_t)(hi - lo + 1), 0);
+      for (int h = 0; h < nsp; h++) if (assign[(size_t)h] == c) epc[(size_t)(sp[(size_t)h].*f - lo)]++;
+      if (leftmost) { for (int v = lo; v <= hi; v++) if (epc[(size_t)(v - lo)] >= thr) return v; }
+      else          { for (int v = hi; v >= lo; v--) if (epc[(size_t)(v - lo)] >= thr) return v; }
+      return lo + (int)(std::max_element(epc.begin(), epc.end()) - epc.begin());
+    };
+    const int bi = consensus(&Seg::i, true), bk = consensus(&Seg::k, true), bj = consensus(&Seg::j, false), bm = consensus(&Seg::m, false);
+    if (bi > bj || bk > bm) continue;
+    sig.push_back(Seg{c, bi, bj, bk, bm, (float)ninc / (float)nsamples});
+  }
+  std::stable_sort(sig.begin(), sig.end(), [](const Seg &a, const Seg &b) { return a.i < b.i; });
+  // ---- clusters dominated by a more probable one that overlaps them (p7_domaindef.c:815-843)
+  std::vector<char> dominated(sig.size(), 0);
+  for (size_t d = 0; d < sig.size(); d++)
+    for (size_t d2 = d + 1; d2 < sig.size(); d2++) {
+      const int nov = std::min(sig[d].j, sig[d2].j) - std::max(sig[d].i, sig[d2].i) + 1;
+      if (nov == 0) break;
+      const int n = std::min(sig[d].j - sig[d].i + 1, sig[d2].j - sig[d2].i + 1);
+      if ((float)nov / (float)n >= 0.8) { if (sig[d].prob > sig[d2].prob) dominated[d2] = 1; else dominated[d] = 1; }
+    }
+  for (size_t d = 0; d < sig.size(); d++) if (!dominated[d]) env->push_back({sig[d].i, sig[d].j});
+  return BATH_OK;
+}

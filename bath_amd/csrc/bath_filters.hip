@@ -318,7 +318,8 @@ __global__ __launch_bounds__(256) void fwd_wave_kernel(SeqView sq, int M, const 
                                                        const int32_t *__restrict__ todo, int64_t ntodo, const int *__restrict__ ntodo_dev,
                                                        float *__restrict__ sc, int32_t *__restrict__ status,
                                                        float *__restrict__ xmx, const int64_t *__restrict__ xmx_off,
-                                                       float *__restrict__ dp, const int64_t *__restrict__ dp_off, int unihit) {
+                                                       float *__restrict__ dp, const int64_t *__restrict__ dp_off, int unihit,
+                                                       const int32_t *__restrict__ cfg_len) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   float *s_tf = reinterpret_cast<float *>(lds);          // [(M+1)*8]
   float *s_rf = s_tf + (size_t)(M + 1) * 8;              // [Kp][M+1]
@@ -335,7 +336,8 @@ __global__ __launch_bounds__(256) void fwd_wave_kernel(SeqView sq, int M, const 
     const int L = sq.len[sid];
     const uint8_t *s = sq.data + sq.off[sid];
     // unihit (envelope rescoring, p7_oprofile_ReconfigUnihit): nj = 0, so pmove = 2/(L+2); a plain float division, as on the host
-    const float pmove = unihit ? (2.0f / ((float)L + 2.0f)) : pmove_tab[L], ploop = 1.0f - pmove;
+    // cfg_len: the length the model was configured for when that is not this target's (a region of an ORF, p7_domaindef.c:553)
+    const float pmove = unihit ? (2.0f / ((float)L + 2.0f)) : pmove_tab[cfg_len ? cfg_len[sid] : L], ploop = 1.0f - pmove;
     float *dprow = dp ? dp + dp_off[sid] : nullptr;        // full matrix (p7_Forward): (L+1) x (M+1) x {M, D, I}
     if (dprow) for (int k = lane; k <= M; k += 64) { dprow[(size_t)k * 3] = dprow[(size_t)k * 3 + 1] = dprow[(size_t)k * 3 + 2] = 0.f; }
     float Mp[C], Ip[C], Dp[C];
@@ -700,7 +702,7 @@ int launch_vit_wave(bath_hip_ctx *ctx, const bath_hip_oprofile *om, SeqView v, c
 }
 
 int launch_fwd_wave(bath_hip_ctx *ctx, const bath_hip_oprofile *om, SeqView v, const int32_t *d_todo, int64_t ntodo, float *d_sc, int32_t *d_status, const int *ntodo_dev,
-                    float *d_xmx, const int64_t *d_xmx_off, float *d_dp, const int64_t *d_dp_off, int unihit) {
+                    float *d_xmx, const int64_t *d_xmx_off, float *d_dp, const int64_t *d_dp_off, int unihit, const int32_t *d_cfg_len) {
   if (ntodo == 0) return BATH_OK;
   const int C = columns_per_lane(om->M);
   const int grid = wave_grid(ctx, ntodo);
@@ -709,7 +711,7 @@ int launch_fwd_wave(bath_hip_ctx *ctx, const bath_hip_oprofile *om, SeqView v, c
   if (unihit) { c.xfE_loop = 0.0f; c.xfE_move = 1.0f; }         // p7_oprofile_ReconfigUnihit, p7_oprofile.c:1421-1422
   BATH_C_SWITCH(C, {
     if (shmem > 64 * 1024) BATH_HIP_TRY(ctx, hipFuncSetAttribute((const void *)fwd_wave_kernel<CC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    hipLaunchKernelGGL(fwd_wave_kernel<CC>, dim3(grid), dim3(256), shmem, ctx->stream, v, om->M, om->d_rf, om->d_tf, om->lt.d_pmove, c, d_todo, ntodo, ntodo_dev, d_sc, d_status, d_xmx, d_xmx_off, d_dp, d_dp_off, unihit);
+    hipLaunchKernelGGL(fwd_wave_kernel<CC>, dim3(grid), dim3(256), shmem, ctx->stream, v, om->M, om->d_rf, om->d_tf, om->lt.d_pmove, c, d_todo, ntodo, ntodo_dev, d_sc, d_status, d_xmx, d_xmx_off, d_dp, d_dp_off, unihit, d_cfg_len);
   })
   BATH_HIP_TRY(ctx, hipGetLastError());
   return BATH_OK;

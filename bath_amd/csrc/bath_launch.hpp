@@ -1,5 +1,7 @@
 // bath_launch.hpp -- host-side launchers shared between bath_filters.hip and bath_pipeline.hip.
 #pragma once
+#include <utility>
+
 #include "bath_common.hpp"
 
 // <NR, G> tile shapes of the SSV kernels: NR packed registers per lane, G lanes per target
@@ -29,7 +31,8 @@ int launch_msv_wave(bath_hip_ctx *ctx, const bath_hip_oprofile *om, SeqView v, c
 int launch_vit_wave(bath_hip_ctx *ctx, const bath_hip_oprofile *om, SeqView v, const int32_t *d_todo, int64_t ntodo, float *d_sc, int32_t *d_status,
                     const VitWindowArgs *wa, const int *ntodo_dev);
 int launch_fwd_wave(bath_hip_ctx *ctx, const bath_hip_oprofile *om, SeqView v, const int32_t *d_todo, int64_t ntodo, float *d_sc, int32_t *d_status, const int *ntodo_dev,
-                    float *d_xmx = nullptr, const int64_t *d_xmx_off = nullptr, float *d_dp = nullptr, const int64_t *d_dp_off = nullptr, int unihit = 0);
+                    float *d_xmx = nullptr, const int64_t *d_xmx_off = nullptr, float *d_dp = nullptr, const int64_t *d_dp_off = nullptr, int unihit = 0,
+                    const int32_t *d_cfg_len = nullptr);
 int launch_bwd_wave(bath_hip_ctx *ctx, const bath_hip_oprofile *om, SeqView v, int64_t n, const float *d_fwd_xmx, const int64_t *d_xmx_off,
                     float *d_sc, int32_t *d_status, float *d_bck_xmx, float *d_dp = nullptr, const int64_t *d_dp_off = nullptr, int unihit = 0);
 int launch_bias_lane(bath_hip_ctx *ctx, const bath_hip_oprofile *om, SeqView v, const float *d_eo, int eo_stride, const int32_t *d_todo, int64_t ntodo,
@@ -73,6 +76,10 @@ struct FsTraceOut {               // what the pipeline keeps of an envelope's OA
 int fs5_envelopes_ex(bath_hip_ctx *ctx, const bath_hip_fsprofile *om5, const bath_hip_seqs *dna, int logsum_mode, int c5_compat,
                      bath_fs5_result *res, float *pp, float *oa, float *ppx, float *oax, FsTraceOut *trace,
                      const uint8_t *cons = nullptr, std::vector<uint16_t> *steps = nullptr, std::vector<int64_t> *step_off = nullptr);
+
+// ---- multi-domain regions (bath_ensemble.hip, host): envelopes and per-residue null2 scores from 200 stochastic tracebacks
+int region_trace_ensemble(const bath_hip_oprofile *om, int cfg_L, const uint8_t *res, int Lr, const float *fwd, const float *fx,
+                          std::vector<float> *n2sc, std::vector<std::pair<int, int>> *env);
 
 // ---- six-frame translation + ORF work list (bath_orfs.hip)
 struct OrfRec {                   // one ORF of the length-sorted work list

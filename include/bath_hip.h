@@ -269,7 +269,8 @@ int  bath_hip_pipeline_frameshift_domains(bath_hip_ctx *ctx, const bath_hip_opro
 /* The standard pipeline (bathsearch without --fs) after the Forward filter (p7_pipeline.c:1741-1771): p7_BackwardParser,
  * p7_domaindef_ByPosteriorHeuristics_BATH (p7_domaindef.c:491) with rescore_isolated_domain_bath (:1194) for single-domain
  * regions, p7_pli_postDomainDef_BATH (p7_pipeline.c:1172).  One bath_fs_domain per hit (fs_window = -1,
- * n_shifted_codons = 0), sorted by window, strand, ORF start; multi-domain regions are counted in *n_skipped_regions. */
+ * n_shifted_codons = 0).  Multi-domain regions are resolved by stochastic-trace clustering (p7_domaindef.c:539-583);
+ * *n_skipped_regions counts them (ddef->nclustered). */
 int  bath_hip_pipeline_hits(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bath_hip_seqs *dna,
                             const bath_pipeline_params *params, double E_report, bath_pipeline_stats *stats,
                             const bath_fs_domain **domains, int64_t *n_domains, int64_t *n_skipped_regions);

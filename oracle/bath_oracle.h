@@ -305,6 +305,14 @@ void bo_gdomain_decoding_fs(const bo_fs_profile *gm5, const bo_gmx *fwd, const b
 int  bo_goatrace_fs(const bo_fs_profile *gm, const bo_gmx *pp, const bo_gmx *gx, bo_trace *tr);                                  /* generic_optacc_frameshift.c:373 */
 double bo_exp_logsurv(double x, double mu, double lambda);
 
+/* ---- multi-domain regions: stochastic-trace ensemble and clustering (stotrace.c; parity unpinned, see its header) ---- */
+typedef struct { uint32_t x; } bo_rng;                 /* easel's "fast" generator (esl_randomness_CreateFast) */
+void   bo_rng_init(bo_rng *r, uint32_t seed);
+double bo_rng_next(bo_rng *r);
+int    bo_stochastic_trace(bo_rng *rng, int L, const bo_oprofile *om, const float *fwd, const float *fx, int8_t *st, int32_t *tk, int32_t *ti, int cap);
+int    bo_region_trace_ensemble(const bo_oprofile *om, const uint8_t *dsq, int ireg, int jreg, const float *fwd, const float *fx,
+                                float *n2sc, int *env, int max_env);
+
 /* ---- domain definition of the standard branch (domaindef.c) ---- */
 int  bo_forward_full(const uint8_t *dsq, int L, const bo_oprofile *om, float *dpf, float *xmx, float *ret_sc);                                   /* fwdback.c:94 */
 int  bo_backward_full(const uint8_t *dsq, int L, const bo_oprofile *om, const float *fwd_xmx, float *dpb, float *bck_xmx, float *ret_sc, int *own_scales); /* :196 */

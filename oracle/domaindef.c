@@ -228,6 +228,46 @@ static void dom_push(bo_fsdomain **d, int *n, int *alloc, const bo_fsdomain *r)
   (*d)[(*n)++] = *r;
 }
 
+/* rescore_isolated_domain_bath, p7_domaindef.c:1194-1325: envelope i..j of dsq[1..n]; n2sc != NULL: null2_is_done (the region
+ * went through stochastic-trace clustering and its per-residue null2 scores are already there) */
+static void rescore_envelope(bo_oprofile *om, const uint8_t *dsq, int i, int j, int orf_start, int win_start, const float *n2sc,
+                             bo_fsdomain **doms, int *ndom, int *dalloc)
+{
+  const int M = om->M;
+  const int Ld = j - i + 1;
+  const size_t W = (size_t)(M + 1) * 3;
+  bo_oprofile_reconfig_length(om, Ld);
+  float *fwd = calloc((size_t)(Ld + 1) * W, sizeof(float)), *bck = calloc((size_t)(Ld + 1) * W, sizeof(float));
+  float *efx = calloc((size_t)(Ld + 1) * 6, sizeof(float)), *ebx = calloc((size_t)(Ld + 1) * 6, sizeof(float));
+  float *ppx = calloc((size_t)(Ld + 1) * 5, sizeof(float)), *oax = calloc((size_t)(Ld + 1) * 5, sizeof(float));
+  float envsc, bcksc;
+  int eown = 0;
+  bo_forward_full(dsq + i - 1, Ld, om, fwd, efx, &envsc);
+  bo_backward_full(dsq + i - 1, Ld, om, efx, bck, ebx, &bcksc, &eown);
+  if (decoding(om, Ld, fwd, efx, bck, ebx, eown, ppx) != BO_ERANGE) {
+    const float oasc = optimal_accuracy(om, Ld, bck, ppx, fwd, oax);          /* fwd now holds the OA matrix */
+    int i1, k1, i2, k2;
+    if (oa_trace(om, Ld, bck, ppx, fwd, oax, &i1, &k1, &i2, &k2) == BO_OK && i1 > 0) {
+      float domcorrection = 0.f;
+      if (!n2sc) {
+        float null2[BO_KP_AMINO];
+        null2_by_expectation(om, Ld, bck, ppx, null2);
+        for (int pos = i; pos <= j; pos++) domcorrection += logf(null2[dsq[pos]]);
+      } else for (int pos = i; pos <= j; pos++) domcorrection += n2sc[pos];
+      bo_fsdomain d;
+      memset(&d, 0, sizeof d);
+      /* trace coordinates -> ORF -> window nucleotides (p7_trace_fs_Convert: the codon's last nucleotide) */
+      const int start = orf_start - win_start;
+      const int a1 = i1 + i - 1, a2 = i2 + i - 1;
+      d.iali = start + a1 * 3 - 2; d.jali = start + a2 * 3;
+      d.ienv = i; d.jenv = j; d.ihmm = k1; d.jhmm = k2;
+      d.envsc = envsc; d.oasc = oasc; d.domcorrection = domcorrection > 0.f ? domcorrection : 0.f;
+      dom_push(doms, ndom, dalloc, &d);
+    }
+  }
+  free(fwd); free(bck); free(efx); free(ebx); free(ppx); free(oax);
+}
+
 /* p7_domaindef_ByPosteriorHeuristics_BATH + p7_pli_postDomainDef_BATH for one ORF that passed the Forward filter.
  * dsq[1..n]: the ORF; orf_start: first nucleotide of the ORF on the strand being read; win_start: windowsq->start on
  * that strand (= orf_start in the plain pipeline, the DNA window's start in the frameshift pipeline's standard branch);
@@ -258,39 +298,20 @@ int bo_domaindef_std(bo_pipeline *pli, bo_oprofile *om, bo_bg *bg, const uint8_t
     } else if (mocc[j] - (etot[j] - etot[j-1]) < rt2) {
       float mx = -1.0f;                                           /* is_multidomain_region */
       for (int z = i; z <= j; z++) { const float a = etot[z] - etot[i-1], b = btot[j] - btot[z-1]; const float e = a < b ? a : b; if (e > mx) mx = e; }
-      if (mx >= rt3) (*nskipped)++;
-      else {                                                      /* rescore_isolated_domain_bath */
-        const int Ld = j - i + 1;
+      if (mx >= rt3) {                                            /* p7_domaindef.c:539-583: stochastic-trace clustering */
+        const int Lr = j - i + 1;
         const size_t W = (size_t)(M + 1) * 3;
-        bo_oprofile_reconfig_length(om, Ld);
-        float *fwd = calloc((size_t)(Ld + 1) * W, sizeof(float)), *bck = calloc((size_t)(Ld + 1) * W, sizeof(float));
-        float *efx = calloc((size_t)(Ld + 1) * 6, sizeof(float)), *ebx = calloc((size_t)(Ld + 1) * 6, sizeof(float));
-        float *ppx = calloc((size_t)(Ld + 1) * 5, sizeof(float)), *oax = calloc((size_t)(Ld + 1) * 5, sizeof(float));
-        float envsc, bcksc;
-        int eown = 0;
-        bo_forward_full(dsq + i - 1, Ld, om, fwd, efx, &envsc);
-        bo_backward_full(dsq + i - 1, Ld, om, efx, bck, ebx, &bcksc, &eown);
-        if (decoding(om, Ld, fwd, efx, bck, ebx, eown, ppx) != BO_ERANGE) {
-          const float oasc = optimal_accuracy(om, Ld, bck, ppx, fwd, oax);          /* fwd now holds the OA matrix */
-          int i1, k1, i2, k2;
-          if (oa_trace(om, Ld, bck, ppx, fwd, oax, &i1, &k1, &i2, &k2) == BO_OK && i1 > 0) {
-            float null2[BO_KP_AMINO];
-            null2_by_expectation(om, Ld, bck, ppx, null2);
-            float domcorrection = 0.f;
-            for (int pos = i; pos <= j; pos++) domcorrection += logf(null2[dsq[pos]]);
-            bo_fsdomain d;
-            memset(&d, 0, sizeof d);
-            /* trace coordinates -> ORF -> window nucleotides (p7_trace_fs_Convert: the codon's last nucleotide) */
-            const int start = orf_start - win_start;
-            const int a1 = i1 + i - 1, a2 = i2 + i - 1;
-            d.iali = start + a1 * 3 - 2; d.jali = start + a2 * 3;
-            d.ienv = i; d.jenv = j; d.ihmm = k1; d.jhmm = k2;
-            d.envsc = envsc; d.oasc = oasc; d.domcorrection = domcorrection > 0.f ? domcorrection : 0.f;
-            dom_push(doms, ndom, dalloc, &d);
-          }
-        }
-        free(fwd); free(bck); free(efx); free(ebx); free(ppx); free(oax);
-      }
+        float *rfwd = calloc((size_t)(Lr + 1) * W, sizeof(float)), *rfx = calloc((size_t)(Lr + 1) * 6, sizeof(float));
+        float *n2sc = calloc((size_t) n + 2, sizeof(float)), rsc;
+        int env[2 * 32];
+        bo_oprofile_reconfig_multihit(om, n);                     /* saveL: the ORF's length */
+        bo_forward_full(dsq + i - 1, Lr, om, rfwd, rfx, &rsc);
+        const int nc = bo_region_trace_ensemble(om, dsq, i, j, rfwd, rfx, n2sc, env, 32);
+        bo_oprofile_reconfig_unihit(om, n);
+        (*nskipped)++;                                            /* counts clustered regions (ddef->nclustered) */
+        for (int d = 0; d < nc; d++) rescore_envelope(om, dsq, env[2 * d], env[2 * d + 1], orf_start, win_start, n2sc, doms, ndom, dalloc);
+        free(rfwd); free(rfx); free(n2sc);
+      } else rescore_envelope(om, dsq, i, j, orf_start, win_start, NULL, doms, ndom, dalloc);
       i = -1; triggered = 0;
     }
   }

@@ -3,7 +3,8 @@ region heuristics, the envelope's full Forward/Backward (unihit), posterior deco
 null2, and the hit's score arithmetic -- against the oracle (oracle/domaindef.c) and against what the reference itself
 recorded (tutorial/PTH2.tbl, tutorial/AMP_N.out).
 
-Integer outputs (envelope, alignment and model coordinates) must be identical.  The envelope score is a Forward score
+Integer outputs (envelope, alignment and model coordinates) must be identical -- also for multi-domain regions, where both
+sides sample 200 stochastic tracebacks from the same random-number stream (oracle/stotrace.c has the caveats).  The envelope score is a Forward score
 (1e-4 relative, as in tests/test_filters_gpu.py); oasc / domcorrection are sums of posteriors computed from products of
 Forward and Backward values, each 1e-4 relative, over up to Ld terms: 2e-3 absolute + 1e-3 relative.  Bit scores inherit
 the envelope score's tolerance divided by ln 2."""
@@ -93,12 +94,24 @@ def test_hits_match_oracle_on_planted_genes(ctx, hmmfile, idx):
         g = np.array(common.revtranslate(rng, genes[i], model.basic), dtype=np.uint8)
         cut = max(60, len(g) // 3)
         wins.append(g[:cut] if i % 2 else g[-cut:])
+    # two and three genes in one reading frame without a stop between them: multi-domain regions, resolved by clustering an
+    # ensemble of stochastic tracebacks (p7_domaindef.c:539-583); nskip counts the regions that went that way
+    for i in range(0, 12, 2):
+        tandem = list(genes[i]) + list(genes[i + 1]) + (list(genes[i + 2]) if i % 4 == 0 else [])
+        nt = np.array(common.revtranslate(rng, tandem, model.basic), dtype=np.uint8)
+        w = np.concatenate([rng.integers(0, 4, size=33).astype(np.uint8), nt, rng.integers(0, 4, size=60).astype(np.uint8)])
+        wins.append((3 - w[::-1]).astype(np.uint8) if i % 4 else w)
     wins += common.random_dna(rng, 30, 1000)
     stats, dm, nskip = gpu_hits(ctx, path, idx, wins)
     pli, odm, per_d, onskip = model.run_pipeline_hits(wins)
     assert (stats.n_past_fwd, stats.pos_past_fwd) == (pli.n_past_fwd, pli.pos_past_fwd)
     n = compare_hits(dm, odm, per_d, nskip, onskip)
-    assert n >= 8
+    assert n >= 8 and nskip >= 2
+    # a clustered region gives several hits on one ORF: some window must carry more than one hit on a strand
+    per = {}
+    for d in dm:
+        per[(d.window, d.strand)] = per.get((d.window, d.strand), 0) + 1
+    assert max(per.values()) >= 2
 
 
 def test_hits_empty_and_background(ctx):
