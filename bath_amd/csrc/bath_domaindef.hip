@@ -15,8 +15,8 @@
 // the posterior and OA matrices (>1 MB per envelope) never leave the device; the posterior sums over the parsers'
 // special-state rows and the region heuristics run there too (fs_regions_kernel, a lane per window).  What remains for
 // the host is bookkeeping and the score arithmetic of the hit.
-// Not built: stochastic-trace clustering of multi-domain regions (:396-455; counted in *n_skipped_regions), the
-// "aliscore < 0" garbage rule of p7_pli_computeAliScores_BATH (:1070-1080), alignment display.
+// Multi-domain regions (:396-455) are resolved by stochastic-trace clustering (bath_ensemble.hip); *n_skipped_regions counts them.
+// Not built: the "aliscore < 0" garbage rule of p7_pli_computeAliScores_BATH (:1070-1080), the printed alignment blocks.
 // The reference carries om_fs5's length configuration from one window to the next; here the domain decoding always uses
 // the configuration bathsearch starts with (L = 100 residues, multihit; bathsearch.c:797).
 #include <algorithm>
@@ -123,17 +123,48 @@ static int fs_branch_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, con
     if (st != BATH_OK) return st;
   }
   struct Env { int sel, i, j; };
-  std::vector<Env> envs;
-  int n_multi = 0;
+  std::vector<Env> envs, mregs;
   for (int q = 0; q < nsel; q++) {
     const int32_t *r = &regions[(size_t)q * RS];
     for (int k = 0; k < r[0]; k++) {                                          // r[0] == -1: Backward underflow, the reference skips the window (:1471)
       const int i = r[1 + 3 * k], j = r[2 + 3 * k];
-      if (r[3 + 3 * k]) n_multi++;
+      if (r[3 + 3 * k]) mregs.push_back(Env{q, i, j});
       else if (j - i + 1 >= 15) envs.push_back(Env{q, i, j});                 // rescore_isolated_domain: Ld < 15 -> nothing
     }
   }
-  if (n_skipped_regions) *n_skipped_regions = n_multi;
+  if (n_skipped_regions) *n_skipped_regions = (int64_t)mregs.size();          // regions resolved by clustering (ddef->nclustered)
+
+  // ---- multi-domain regions (p7_domaindef.c:396-455): Forward of the region in the multihit configuration (GPU), ensemble of
+  // stochastic tracebacks and clustering (host, bath_ensemble.hip); every cluster is an envelope
+  if (!mregs.empty()) {
+    std::vector<FsWinDev> rregs(mregs.size());
+    for (size_t e = 0; e < mregs.size(); e++) {
+      FsWinDev d = regs[(size_t)mregs[e].sel];
+      d.start = regs[(size_t)mregs[e].sel].start + mregs[e].i - 1; d.len = mregs[e].j - mregs[e].i + 1;
+      rregs[e] = d;
+    }
+    std::vector<float> h_f, h_x, h_sc;
+    std::vector<int64_t> foff, xoff;
+    {
+      bath_hip_seqs view;
+      if ((st = fs_gather_view(ctx, dna, rregs, tt.comp, &view, nullptr)) != BATH_OK) return st;
+      st = fs5_region_forward(ctx, om_fs5, &view, 100, &h_f, &foff, &h_x, &xoff, &h_sc);      // saveL: the configuration bathsearch starts with
+      view.d_data = nullptr; view.d_off = nullptr; view.d_len = nullptr;
+      if (st != BATH_OK) return st;
+    }
+    const float pm = (2.0f + 1.0f) / (100.0f + 2.0f + 1.0f);                 // p7_fs_ReconfigLength(L = 100), multihit (nj = 1)
+    const float xNL = (float)std::log((double)(1.0f - pm)), xNM = (float)std::log((double)pm), xE = (float)-kLn2;
+    std::vector<std::pair<int, int>> cl;
+    for (size_t e = 0; e < mregs.size(); e++) {
+      if (!(h_sc[e] > -INFINITY)) continue;                                   // Forward underflow: no valid traces for this region (:413)
+      const int Lr = rregs[e].len;
+      if (fs_region_trace_ensemble(h5.M, h5.tsc, xNL, xNM, xE, mregs[e].i, Lr, h_f.data() + foff[e], h_x.data() + xoff[e], &cl) != BATH_OK) continue;
+      for (const auto &c : cl) {
+        const int i2 = std::max(1, c.first), j2 = c.second;                   // :449
+        if (j2 - i2 + 1 >= 15) envs.push_back(Env{mregs[e].sel, i2, j2});
+      }
+    }
+  }
   if (envs.empty()) return BATH_OK;
 
   // ---- envelopes: Forward, Backward, decoding, optimal accuracy, null2 on the GPU (unihit, length Ld/3)

@@ -57,6 +57,70 @@ int choose(FastRng &rng, float (&p)[N]) {
 struct Step { int8_t st; int32_t k, i; };
 struct Seg { int idx, i, j, k, m; float prob; };
 
+// p7_spensemble_Cluster / p7_spensemble_fs_Cluster (single linkage, significant clusters, consensus end points) and the removal
+// of dominated clusters (p7_domaindef.c:815-843, 923-953)
+void cluster_segments(const std::vector<Seg> &sp, int nsamples, bool fs, std::vector<std::pair<int, int>> *env) {
+  const int max_diagdiff = 4;
+  const float min_overlap = 0.8f, min_posterior = 0.25f, min_endpointp = 0.02f;
+  // ---- p7_spensemble_Cluster
+  auto linked = [&](const Seg &a, const Seg &b) {
+    int nov = std::min(a.j, b.j) - std::max(a.i, b.i) + 1, n = std::min(a.j - a.i + 1, b.j - b.i + 1);
+    if ((float)nov / (float)n < min_overlap) return false;
+    nov = std::min(a.m, b.m) - std::max(a.k, b.k); n = std::min(a.m - a.k + 1, b.m - b.k + 1);
+    if ((float)nov / (float)n < min_overlap) return false;
+    if (fs) {                                             // nucleotide coordinates: diagonals in codons (link_spsamples_fs)
+      if (std::abs((a.i / 3 - a.k) - (b.i / 3 - b.k)) <= max_diagdiff) return true;
+      return std::abs((a.j / 3 - a.m) - (b.j / 3 - b.m)) <= max_diagdiff;
+    }
+    if (std::abs((a.i - a.k) - (b.i - b.k)) <= max_diagdiff) return true;
+    return std::abs((a.j - a.m) - (b.j - b.m)) <= max_diagdiff;
+  };
+  const int nsp = (int)sp.size();
+  std::vector<int> assign((size_t)nsp, -1), stack;
+  int nc = 0;
+  for (int h = 0; h < nsp; h++) {
+    if (assign[(size_t)h] >= 0) continue;
+    assign[(size_t)h] = nc; stack.assign(1, h);
+    while (!stack.empty()) {
+      const int a = stack.back(); stack.pop_back();
+      for (int b = 0; b < nsp; b++) if (assign[(size_t)b] < 0 && linked(sp[(size_t)a], sp[(size_t)b])) { assign[(size_t)b] = nc; stack.push_back(b); }
+    }
+    nc++;
+  }
+  std::vector<Seg> sig;
+  std::vector<int> epc;
+  for (int c = 0; c < nc; c++) {
+    int ninc = 0, last = -1;
+    for (int h = 0; h < nsp; h++) if (assign[(size_t)h] == c) { if (sp[(size_t)h].idx != last) ninc++; last = sp[(size_t)h].idx; }
+    if ((float)ninc / (float)nsamples < min_posterior) continue;
+    const int thr = (int)ceilf((float)ninc * min_endpointp);
+    // widest end point that at least thr segments of the cluster share, independently for i, k (leftmost) and j, m (rightmost)
+    auto consensus = [&](int Seg::*f, bool leftmost) {
+      int lo = 0, hi = 0; bool first = true;
+      for (int h = 0; h < nsp; h++) if (assign[(size_t)h] == c) { const int v = sp[(size_t)h].*f; if (first) { lo = hi = v; first = false; } else { lo = std::min(lo, v); hi = std::max(hi, v); } }
+      epc.assign((size_t)(hi - lo + 1), 0);
+      for (int h = 0; h < nsp; h++) if (assign[(size_t)h] == c) epc[(size_t)(sp[(size_t)h].*f - lo)]++;
+      if (leftmost) { for (int v = lo; v <= hi; v++) if (epc[(size_t)(v - lo)] >= thr) return v; }
+      else          { for (int v = hi; v >= lo; v--) if (epc[(size_t)(v - lo)] >= thr) return v; }
+      return lo + (int)(std::max_element(epc.begin(), epc.end()) - epc.begin());
+    };
+    const int bi = consensus(&Seg::i, true), bk = consensus(&Seg::k, true), bj = consensus(&Seg::j, false), bm = consensus(&Seg::m, false);
+    if (bi > bj || bk > bm) continue;
+    sig.push_back(Seg{c, bi, bj, bk, bm, (float)ninc / (float)nsamples});
+  }
+  std::stable_sort(sig.begin(), sig.end(), [](const Seg &a, const Seg &b) { return a.i < b.i; });
+  // ---- clusters dominated by a more probable one that overlaps them (p7_domaindef.c:815-843)
+  std::vector<char> dominated(sig.size(), 0);
+  for (size_t d = 0; d < sig.size(); d++)
+    for (size_t d2 = d + 1; d2 < sig.size(); d2++) {
+      const int nov = std::min(sig[d].j, sig[d2].j) - std::max(sig[d].i, sig[d2].i) + 1;
+      if (nov == 0) break;
+      const int n = std::min(sig[d].j - sig[d].i + 1, sig[d2].j - sig[d2].i + 1);
+      if ((float)nov / (float)n >= 0.8) { if (sig[d].prob > sig[d2].prob) dominated[d2] = 1; else dominated[d] = 1; }
+    }
+  for (size_t d = 0; d < sig.size(); d++) if (!dominated[d]) env->push_back({sig[d].i, sig[d].j});
+}
+
 }  // namespace
 
 // One region of an ORF.  fwd: (Lr+1) x (M+1) x {M,D,I}, fx: (Lr+1) x {E,N,J,B,C,SCALE} of p7_Forward on the region with the
@@ -70,8 +134,7 @@ int bath::region_trace_ensemble(const bath_hip_oprofile *om, int cfg_L, const ui
   if (om->ensure_len_tables(cfg_L) != BATH_OK) return BATH_EFAIL;
   const float pmove = om->lt.h_pmove[(size_t)cfg_L], ploop = 1.0f - pmove;
   const float tEL = om->xf_E[0], tEM = om->xf_E[1];
-  const int nsamples = 200, max_diagdiff = 4;
-  const float min_overlap = 0.8f, min_posterior = 0.25f, min_endpointp = 0.02f;
+  const int nsamples = 200;
   std::vector<float> &n2sc = *n2sc_out;
   n2sc.assign((size_t)Lr + 1, 0.f);                       // 1-based positions of the region
   env->clear();
@@ -168,58 +231,115 @@ int bath::region_trace_ensemble(const bath_hip_oprofile *om, int cfg_L, const ui
   }
   for (int pos = 1; pos <= Lr; pos++) n2sc[(size_t)pos] = logf(n2sc[(size_t)pos] / (float)nsamples);
 
-  // ---- p7_spensemble_Cluster
-  auto linked = [&](const Seg &a, const Seg &b) {
-    int nov = std::min(a.j, b.j) - std::max(a.i, b.i) + 1, n = std::min(a.j - a.i + 1, b.j - b.i + 1);
-    if ((float)nov / (float)n < min_overlap) return false;
-    nov = std::min(a.m, b.m) - std::max(a.k, b.k); n = std::min(a.m - a.k + 1, b.m - b.k + 1);
-    if ((float)nov / (float)n < min_overlap) return false;
-    if (std::abs((a.i - a.k) - (b.i - b.k)) <= max_diagdiff) return true;
-    return std::abs((a.j - a.m) - (b.j - b.m)) <= max_diagdiff;
+  cluster_segments(sp, nsamples, false, env);
+  return BATH_OK;
+}
+
+// ---- frameshift branch: region_trace_ensemble_frameshift (p7_domaindef.c:891-958) with the generic log-space stochastic
+// traceback (generic_stotrace_frameshift.c:40-215) on the region's Forward matrix from fs5_fwd_kernel (multihit).
+// fwd: (Lr+1) x (M+1) x {D, I, M_C0, M_C1..M_C5}; fx: (Lr+1) x {E,N,J,B,C}; tsc: generic [M][8]; xNL/xNM: log loop / move of
+// N, C, J; xE: log 1/2.  The region starts at nucleotide <ireg> of its window: segments are clustered in window coordinates
+// (the link rule divides them by 3).  env: envelopes in window nucleotides, ordered by start (empty: no valid traces).
+int bath::fs_region_trace_ensemble(int M, const float *tsc, float xNL, float xNM, float xE, int ireg, int Lr, const float *fwd, const float *fx,
+                                   std::vector<std::pair<int, int>> *env) {
+  enum { gD = 0, gI = 1, gM = 2 };
+  enum { gE = 0, gN, gJ, gB, gC };
+  env->clear();
+  const size_t W = (size_t)(M + 1) * 8;
+  auto DP = [&](int i, int k, int s) { return fwd[(size_t)i * W + (size_t)k * 8 + s]; };
+  auto X = [&](int i, int s) { return fx[(size_t)i * 5 + s]; };
+  auto TS = [&](int s, int k) { return tsc[(size_t)k * 8 + s]; };
+  std::vector<float> sc((size_t)2 * M + 8);
+  auto lognorm_choose = [&](FastRng &rng, int n) {       // esl_vec_FLogNorm, then esl_rnd_FChoose
+    float *v = sc.data();
+    float mx = v[0];
+    for (int q = 1; q < n; q++) mx = std::max(mx, v[q]);
+    float denom;
+    if (mx == INFINITY) denom = INFINITY;
+    else if (mx == -INFINITY) denom = -INFINITY;
+    else { float sum = 0.f; for (int q = 0; q < n; q++) if (v[q] > mx - 50.f) sum += expf(v[q] - mx); denom = logf(sum) + mx; }
+    for (int q = 0; q < n; q++) v[q] = expf(v[q] - denom);
+    float sum = 0.f, comp = 0.f;
+    for (int q = 0; q < n; q++) { const float y = v[q] - comp, t = sum + y; comp = (t - sum) - y; sum = t; }
+    for (int q = 0; q < n; q++) v[q] = (sum != 0.0f) ? v[q] / sum : 1.0f / (float)n;
+    for (;;) {
+      const float roll = (float)rng.next();
+      float acc = 0.f;
+      for (int q = 0; q < n; q++) { acc += v[q]; if (roll < acc) return q; }
+    }
   };
-  const int nsp = (int)sp.size();
-  std::vector<int> assign((size_t)nsp, -1), stack;
-  int nc = 0;
-  for (int h = 0; h < nsp; h++) {
-    if (assign[(size_t)h] >= 0) continue;
-    assign[(size_t)h] = nc; stack.assign(1, h);
-    while (!stack.empty()) {
-      const int a = stack.back(); stack.pop_back();
-      for (int b = 0; b < nsp; b++) if (assign[(size_t)b] < 0 && linked(sp[(size_t)a], sp[(size_t)b])) { assign[(size_t)b] = nc; stack.push_back(b); }
+  const int nsamples = 200, step_cap = 4 * (Lr + M) + 64;
+  FastRng rng(42);
+  std::vector<Seg> sp;
+  struct FsStep { int8_t st, c; int32_t k, i; };
+  std::vector<FsStep> tr;
+  for (int t = 0; t < nsamples; t++) {
+    tr.clear();
+    int i = Lr, k = 0, c = 0, sprv = sC;
+    tr.push_back(FsStep{(int8_t)sT, 0, 0, i}); tr.push_back(FsStep{(int8_t)sC, 0, 0, i});
+    while (sprv != sS) {
+      int scur = -1;
+      switch (sprv) {
+      case sC:
+        if (X(i, gC) == -INFINITY) return BATH_OK;
+        if (i < 4) { scur = sE; break; }
+        sc[0] = X(i - 3, gC) + xNL; sc[1] = X(i - 2, gC) + xNL; sc[2] = X(i - 1, gC) + xNL; sc[3] = X(i, gE) + xE;
+        scur = lognorm_choose(rng, 4) < 3 ? sC : sE; break;
+      case sE:
+        if (X(i, gE) == -INFINITY) return BATH_OK;
+        sc[0] = sc[(size_t)M + 1] = -INFINITY;
+        for (int q = 1; q <= M; q++) sc[(size_t)q] = DP(i, q, gM);
+        for (int q = 2; q <= M; q++) sc[(size_t)q + M] = DP(i, q, gD);
+        k = lognorm_choose(rng, 2 * M + 1);
+        if (k <= M) scur = sM; else { k -= M; scur = sD; }
+        break;
+      case sM: {
+        sc[0] = X(i, gB) + TS(BM, k - 1); sc[1] = DP(i, k - 1, gM) + TS(MM, k - 1); sc[2] = DP(i, k - 1, gI) + TS(IM, k - 1); sc[3] = DP(i, k - 1, gD) + TS(DM, k - 1);
+        static const int state[4] = {sB, sM, sI, sD};
+        scur = state[lognorm_choose(rng, 4)]; k--; break; }
+      case sD:
+        if (DP(i, k, gD) == -INFINITY) return BATH_OK;
+        sc[0] = DP(i, k - 1, gM) + TS(MD, k - 1); sc[1] = DP(i, k - 1, gD) + TS(DD, k - 1);
+        scur = lognorm_choose(rng, 2) == 0 ? sM : sD; k--; break;
+      case sI:
+        if (DP(i, k, gI) == -INFINITY || i < 3) return BATH_OK;
+        sc[0] = DP(i - 3, k, gM) + TS(MI, k); sc[1] = DP(i - 3, k, gI) + TS(II, k);
+        scur = lognorm_choose(rng, 2) == 0 ? sM : sI; i -= 3; break;
+      case sN:
+        if (X(i, gN) == -INFINITY) return BATH_OK;
+        scur = (i == 0) ? sS : sN; break;
+      case sB:
+        if (X(i, gB) == -INFINITY) return BATH_OK;
+        sc[0] = X(i, gN) + xNM; sc[1] = X(i, gJ) + xNM;
+        scur = lognorm_choose(rng, 2) == 0 ? sN : sJ; break;
+      case sJ:
+        if (X(i, gJ) == -INFINITY) return BATH_OK;
+        if (i < 4) { scur = sE; break; }
+        sc[0] = X(i - 3, gJ) + xNL; sc[1] = X(i - 2, gJ) + xNL; sc[2] = X(i - 1, gJ) + xNL; sc[3] = X(i, gE) + xE;
+        scur = lognorm_choose(rng, 4) < 3 ? sJ : sE; break;
+      default: return BATH_OK;
+      }
+      if (scur == sM) {                                   // codon length from the C1..C5 cells
+        for (int q = 0; q < 5; q++) sc[(size_t)q] = DP(i, k, gM + 1 + q);
+        c = lognorm_choose(rng, 5) + 1;
+        if (i - c < 0) scur = sB;
+      } else c = 0;
+      if (scur < 0 || k < 0 || i < 0 || (int)tr.size() > step_cap) return BATH_OK;
+      tr.push_back(FsStep{(int8_t)scur, (int8_t)c, k, i});
+      if ((scur == sN || scur == sC || scur == sJ) && scur == sprv) i--;
+      sprv = scur;
+      i -= c;
+      if (i < 0) return BATH_OK;
     }
-    nc++;
-  }
-  std::vector<Seg> sig;
-  std::vector<int> epc;
-  for (int c = 0; c < nc; c++) {
-    int ninc = 0, last = -1;
-    for (int h = 0; h < nsp; h++) if (assign[(size_t)h] == c) { if (sp[(size_t)h].idx != last) ninc++; last = sp[(size_t)h].idx; }
-    if ((float)ninc / (float)nsamples < min_posterior) continue;
-    const int thr = (int)ceilf((float)ninc * min_endpointp);
-    // widest end point that at least thr segments of the cluster share, independently for i, k (leftmost) and j, m (rightmost)
-    auto consensus = [&](int Seg::*f, bool leftmost) {
-      int lo = 0, hi = 0; bool first = true;
-      for (int h = 0; h < nsp; h++) if (assign[(size_t)h] == c) { const int v = sp[(size_t)h].*f; if (first) { lo = hi = v; first = false; } else { lo = std::min(lo, v); hi = std::max(hi, v); } }
-      epc.assign((size_t)(hi - lo + 1), 0);
-      for (int h = 0; h < nsp; h++) if (assign[(size_t)h] == c) epc[(size_t)(sp[(size_t)h].*f - lo)]++;
-      if (leftmost) { for (int v = lo; v <= hi; v++) if (epc[(size_t)(v - lo)] >= thr) return v; }
-      else          { for (int v = hi; v >= lo; v--) if (epc[(size_t)(v - lo)] >= thr) return v; }
-      return lo + (int)(std::max_element(epc.begin(), epc.end()) - epc.begin());
-    };
-    const int bi = consensus(&Seg::i, true), bk = consensus(&Seg::k, true), bj = consensus(&Seg::j, false), bm = consensus(&Seg::m, false);
-    if (bi > bj || bk > bm) continue;
-    sig.push_back(Seg{c, bi, bj, bk, bm, (float)ninc / (float)nsamples});
-  }
-  std::stable_sort(sig.begin(), sig.end(), [](const Seg &a, const Seg &b) { return a.i < b.i; });
-  // ---- clusters dominated by a more probable one that overlaps them (p7_domaindef.c:815-843)
-  std::vector<char> dominated(sig.size(), 0);
-  for (size_t d = 0; d < sig.size(); d++)
-    for (size_t d2 = d + 1; d2 < sig.size(); d2++) {
-      const int nov = std::min(sig[d].j, sig[d2].j) - std::max(sig[d].i, sig[d2].i) + 1;
-      if (nov == 0) break;
-      const int n = std::min(sig[d].j - sig[d].i + 1, sig[d2].j - sig[d2].i + 1);
-      if ((float)nov / (float)n >= 0.8) { if (sig[d].prob > sig[d2].prob) dominated[d2] = 1; else dominated[d] = 1; }
+    std::reverse(tr.begin(), tr.end());
+    for (size_t z = 0; z < tr.size(); z++) {              // p7_trace_fs_Index
+      if (tr[z].st != sB) continue;
+      int sqfrom = 0, sqto = 0, hmmfrom = 0, hmmto = 0;
+      for (z = z + 1; z < tr.size() && tr[z].st != sE; z++)
+        if (tr[z].st == sM) { if (!sqfrom) sqfrom = tr[z].i - tr[z].c + 1; if (!hmmfrom) hmmfrom = tr[z].k; sqto = tr[z].i; hmmto = tr[z].k; }
+      sp.push_back(Seg{t, sqfrom + ireg - 1, sqto + ireg - 1, hmmfrom, hmmto, 0.f});
     }
-  for (size_t d = 0; d < sig.size(); d++) if (!dominated[d]) env->push_back({sig[d].i, sig[d].j});
+  }
+  cluster_segments(sp, nsamples, true, env);
   return BATH_OK;
 }

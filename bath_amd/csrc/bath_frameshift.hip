@@ -202,7 +202,8 @@ __global__ __launch_bounds__(256) void fs3_fwd_kernel(SeqView dna, FsDev p, cons
 template <int C, bool EXACT>
 __global__ __launch_bounds__(256) void fs5_fwd_kernel(SeqView dna, FsDev p, const float *__restrict__ loop_tab, const float *__restrict__ move_tab,
                                                       float tEL, float tEM, int c5_compat, float *__restrict__ sc,
-                                                      float *__restrict__ fwd, const int64_t *__restrict__ fwd_off, float *__restrict__ xmx, const int64_t *__restrict__ xmx_off) {
+                                                      float *__restrict__ fwd, const int64_t *__restrict__ fwd_off, float *__restrict__ xmx, const int64_t *__restrict__ xmx_off,
+                                                      int cfg_len /* >= 0: the amino length the model is configured for, instead of L/3 */) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   float *s_tbl = reinterpret_cast<float *>(lds);
   float *s_tf = s_tbl + kLogsumTbl;
@@ -220,7 +221,8 @@ __global__ __launch_bounds__(256) void fs5_fwd_kernel(SeqView dna, FsDev p, cons
     float *fo = fwd + fwd_off[job];
     float *xo = xmx + xmx_off[job];
     if (L < 5) { if (lane == 0) sc[job] = -INFINITY; continue; }
-    const float tNL = loop_tab[L / 3], tNM = move_tab[L / 3], tJL = tNL, tJM = tNM, tCL = tNL, tCM = tNM;
+    const int Lc = cfg_len >= 0 ? cfg_len : L / 3;
+    const float tNL = loop_tab[Lc], tNM = move_tab[Lc], tJL = tNL, tJM = tNM, tCL = tNL, tCM = tNM;
     float Mr[3][C], Ir[3][C], Dr1[C], iv[4][C];       // M,I of rows i-1..i-3 (C0 totals); D of row i-1; IVX(i-1..i-4)
 #pragma unroll
     for (int c = 0; c < C; c++) {
@@ -1290,12 +1292,12 @@ int bath::fs5_envelopes_ex(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, cons
     if (exact) {
       if ((st = fs_set_shmem(ctx, fs5_fwd_kernel<CC, true>, shmem)) != BATH_OK) return st;
       if ((st = fs_set_shmem(ctx, fs_bwd_kernel<CC, 5, true>, shmem)) != BATH_OK) return st;
-      hipLaunchKernelGGL((fs5_fwd_kernel<CC, true>), dim3(grid), dim3(256), shmem, ctx->stream, dna->view(), fsdev(om), om->d_loop[1], om->d_move[1], tEL, tEM, c5_compat, d_fsc, b_f.as<float>(), d_foff, b_fx.as<float>(), d_xoff);
+      hipLaunchKernelGGL((fs5_fwd_kernel<CC, true>), dim3(grid), dim3(256), shmem, ctx->stream, dna->view(), fsdev(om), om->d_loop[1], om->d_move[1], tEL, tEM, c5_compat, d_fsc, b_f.as<float>(), d_foff, b_fx.as<float>(), d_xoff, -1);
       hipLaunchKernelGGL((fs_bwd_kernel<CC, 5, true>), dim3(grid), dim3(256), shmem, ctx->stream, dna->view(), fsdev(om), om->d_loop[1], om->d_move[1], tEL, tEM, d_bsc, b_b.as<float>(), d_boff, b_bx.as<float>(), d_xoff);
     } else {
       if ((st = fs_set_shmem(ctx, fs5_fwd_kernel<CC, false>, shmem)) != BATH_OK) return st;
       if ((st = fs_set_shmem(ctx, fs_bwd_kernel<CC, 5, false>, shmem)) != BATH_OK) return st;
-      hipLaunchKernelGGL((fs5_fwd_kernel<CC, false>), dim3(grid), dim3(256), shmem, ctx->stream, dna->view(), fsdev(om), om->d_loop[1], om->d_move[1], tEL, tEM, c5_compat, d_fsc, b_f.as<float>(), d_foff, b_fx.as<float>(), d_xoff);
+      hipLaunchKernelGGL((fs5_fwd_kernel<CC, false>), dim3(grid), dim3(256), shmem, ctx->stream, dna->view(), fsdev(om), om->d_loop[1], om->d_move[1], tEL, tEM, c5_compat, d_fsc, b_f.as<float>(), d_foff, b_fx.as<float>(), d_xoff, -1);
       hipLaunchKernelGGL((fs_bwd_kernel<CC, 5, false>), dim3(grid), dim3(256), shmem, ctx->stream, dna->view(), fsdev(om), om->d_loop[1], om->d_move[1], tEL, tEM, d_bsc, b_b.as<float>(), d_boff, b_bx.as<float>(), d_xoff);
     }
     BATH_HIP_TRY(ctx, hipMemsetAsync(b_cs.p, 0, (size_t)n * cs_stride * sizeof(float), ctx->stream));
@@ -1342,5 +1344,44 @@ int bath::fs5_envelopes_ex(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, cons
     res[i].fwdsc = h_sc[i]; res[i].bcksc = h_sc[n + i]; res[i].oasc = h_sc[2 * n + i];
     std::memcpy(res[i].null2, &h_n2[(size_t)i * kKp], sizeof(float) * kKp);
   }
+  return BATH_OK;
+}
+
+// p7_Forward_Frameshift of regions in the MULTIHIT configuration of a fixed amino length (p7_domaindef.c:411-414: the model's
+// saved length), matrices and special-state rows copied to the host for the stochastic-trace ensemble (bath_ensemble.hip).
+// fwd: (L+1) x (M+1) x {D, I, M_C0, M_C1..M_C5}; xmx: (L+1) x {E,N,J,B,C}.  sc[e] = -inf: no path (the region is dropped).
+int bath::fs5_region_forward(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, const bath_hip_seqs *dna, int cfg_len_amino,
+                             std::vector<float> *fwd, std::vector<int64_t> *fwd_off, std::vector<float> *xmx, std::vector<int64_t> *xmx_off, std::vector<float> *sc) {
+  const int64_t n = dna->n;
+  const int M = om->M;
+  int st = om->ensure_len(std::max(dna->maxlen / 3 + 1, cfg_len_amino));
+  if (st != BATH_OK) return st;
+  std::vector<int64_t> &foff = *fwd_off, &xoff = *xmx_off;
+  foff.assign((size_t)n + 1, 0); xoff.assign((size_t)n + 1, 0);
+  for (int64_t i = 0; i < n; i++) {
+    const int64_t rows = (int64_t)dna->h_len[(size_t)i] + 1;
+    foff[(size_t)i + 1] = foff[(size_t)i] + rows * (M + 1) * 8; xoff[(size_t)i + 1] = xoff[(size_t)i] + rows * 5;
+  }
+  DevBuf &b_f = ctx->scratch[15], &b_fx = ctx->scratch[18], &b_off = ctx->scratch[20], &b_sc = ctx->scratch[21];
+  BATH_HIP_TRY(ctx, b_f.reserve((size_t)foff[(size_t)n] * 4 + 64)); BATH_HIP_TRY(ctx, b_fx.reserve((size_t)xoff[(size_t)n] * 4 + 64));
+  BATH_HIP_TRY(ctx, b_off.reserve((size_t)(n + 1) * 3 * sizeof(int64_t))); BATH_HIP_TRY(ctx, b_sc.reserve((size_t)n * 3 * sizeof(float)));
+  int64_t *d_foff = b_off.as<int64_t>(), *d_xoff = d_foff + (n + 1);
+  BATH_HIP_TRY(ctx, hipMemcpyAsync(d_foff, foff.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+  BATH_HIP_TRY(ctx, hipMemcpyAsync(d_xoff, xoff.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+  const int Cv = fs_columns(M);
+  const size_t shmem = (size_t)(kLogsumTbl + (M + 2) * 8) * sizeof(float);
+  const int grid = fs_grid(ctx, n);
+  const float tE = (float)-0.69314718055994529;                               // multihit: E->C and E->J both log 1/2 (modelconfig.c:825-831)
+  BATH_FS_SWITCH(Cv, {
+    if ((st = fs_set_shmem(ctx, fs5_fwd_kernel<CC, false>, shmem)) != BATH_OK) return st;
+    hipLaunchKernelGGL((fs5_fwd_kernel<CC, false>), dim3(grid), dim3(256), shmem, ctx->stream, dna->view(), fsdev(om), om->d_loop[0], om->d_move[0], tE, tE, 0, b_sc.as<float>(),
+                       b_f.as<float>(), d_foff, b_fx.as<float>(), d_xoff, cfg_len_amino);
+  })
+  BATH_HIP_TRY(ctx, hipGetLastError());
+  fwd->resize((size_t)foff[(size_t)n]); xmx->resize((size_t)xoff[(size_t)n]); sc->resize((size_t)n);
+  BATH_HIP_TRY(ctx, hipMemcpyAsync(fwd->data(), b_f.p, fwd->size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+  BATH_HIP_TRY(ctx, hipMemcpyAsync(xmx->data(), b_fx.p, xmx->size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+  BATH_HIP_TRY(ctx, hipMemcpyAsync(sc->data(), b_sc.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  BATH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return BATH_OK;
 }

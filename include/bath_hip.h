@@ -240,7 +240,8 @@ int  bath_hip_pipeline_frameshift(bath_hip_ctx *ctx, const bath_hip_oprofile *om
 /* ... and what the frameshift branch does next (p7_pipeline.c:1469-1476): p7_BackwardParser_Frameshift_3Codons,
  * p7_domaindef_ByPosteriorHeuristics_Frameshift_BATH (p7_domaindef.c:301) with rescore_isolated_domain_frameshift (:993)
  * for single-domain regions, and the scores p7_pli_postDomainDef_Frameshift_BATH (p7_pipeline.c:1005) gives the hit.
- * Multi-domain regions (stochastic-trace clustering, p7_domaindef.c:396-455) are counted in *n_skipped_regions. */
+ * Multi-domain regions are resolved by stochastic-trace clustering (p7_domaindef.c:396-455); *n_skipped_regions counts them
+ * (ddef->nclustered; the name predates that stage). */
 typedef struct {
   int64_t window;                  /* sequence index in the block                                              */
   int32_t strand;

@@ -333,8 +333,18 @@ int bo_domaindef_fs(bo_pipeline *pli, bo_fs_profile *gm3, bo_fs_profile *gm5, bo
       }
       j = (d + 3 < L) ? d + 3 : L;
       if (j - i + 1 >= 12) {
-        if (is_multidomain(btot, etot, i, j, rt3)) (*nskipped)++;
-        else rescore_domain(pli, gm5, bg, wdsq, i, j, doms, ndom, dalloc, &tr);
+        if (is_multidomain(btot, etot, i, j, rt3)) {              /* p7_domaindef.c:396-455 */
+          const int Lr = j - i + 1;
+          int env[2 * 32], nc = 0;
+          float rsc;
+          (*nskipped)++;                                          /* ddef->nclustered */
+          bo_fs_profile_reconfig_multihit(gm5, 100);              /* saveL */
+          bo_gmx *rf = bo_gmx_create(M, Lr + 1, Lr, BO_NSCELLS_FS);
+          if (bo_gforward_fs(wdsq + i - 1, Lr, gm5, rf, 0, &rsc) != BO_ERANGE && rsc > -INFINITY) nc = bo_region_trace_ensemble_fs(gm5, i, j, rf, env, 32);
+          bo_gmx_free(rf);
+          bo_fs_profile_reconfig_unihit(gm5, 100 / 3);
+          for (int q = 0; q < nc; q++) rescore_domain(pli, gm5, bg, wdsq, env[2 * q] > 1 ? env[2 * q] : 1, env[2 * q + 1], doms, ndom, dalloc, &tr);
+        } else rescore_domain(pli, gm5, bg, wdsq, i, j, doms, ndom, dalloc, &tr);
       }
       i = -1; triggered = 0; start = 0; end = 0;
     }

@@ -138,7 +138,7 @@ int bo_stochastic_trace(bo_rng *rng, int L, const bo_oprofile *om, const float *
 
 typedef struct { int idx, i, j, k, m; float prob; } spcoord;
 
-static int linked(const spcoord *h1, const spcoord *h2, float min_overlap, int max_diagdiff)      /* link_spsamples, of_smaller = TRUE */
+static int linked(const spcoord *h1, const spcoord *h2, float min_overlap, int max_diagdiff, int fs)      /* link_spsamples[_fs], of_smaller = TRUE */
 {
   int nov = (h1->j < h2->j ? h1->j : h2->j) - (h1->i > h2->i ? h1->i : h2->i) + 1;
   int l1 = h1->j - h1->i + 1, l2 = h2->j - h2->i + 1, n = l1 < l2 ? l1 : l2;
@@ -146,6 +146,11 @@ static int linked(const spcoord *h1, const spcoord *h2, float min_overlap, int m
   nov = (h1->m < h2->m ? h1->m : h2->m) - (h1->k > h2->k ? h1->k : h2->k);
   l1 = h1->m - h1->k + 1; l2 = h2->m - h2->k + 1; n = l1 < l2 ? l1 : l2;
   if ((float) nov / (float) n < min_overlap) return 0;
+  if (fs) {                                               /* nucleotide coordinates: diagonals in codons (p7_spensemble.c:249-250) */
+    if (abs(((h1->i / 3) - h1->k) - ((h2->i / 3) - h2->k)) <= max_diagdiff) return 1;
+    if (abs(((h1->j / 3) - h1->m) - ((h2->j / 3) - h2->m)) <= max_diagdiff) return 1;
+    return 0;
+  }
   if (abs((h1->i - h1->k) - (h2->i - h2->k)) <= max_diagdiff) return 1;
   if (abs((h1->j - h1->m) - (h2->j - h2->m)) <= max_diagdiff) return 1;
   return 0;
@@ -154,14 +159,85 @@ static int linked(const spcoord *h1, const spcoord *h2, float min_overlap, int m
 static int argmax_i(const int *v, int n) { int b = 0; for (int x = 1; x < n; x++) if (v[x] > v[b]) b = x; return b; }
 static int sp_cmp(const void *a, const void *b) { const spcoord *x = a, *y = b; return x->i < y->i ? -1 : (x->i > y->i ? 1 : 0); }
 
+/* p7_spensemble_Cluster / p7_spensemble_fs_Cluster (p7_spensemble.c:300-440, 500-640) and the removal of dominated clusters
+ * (p7_domaindef.c:815-843, 923-953).  Takes ownership of sp.  span: an upper bound on any coordinate range. */
+static int cluster_segments(spcoord *sp, int nsp, int nsamples, int span, int fs, int *env, int max_env)
+{
+  const int max_diagdiff = 4;
+  const float min_overlap = 0.8f, min_posterior = 0.25f, min_endpointp = 0.02f;
+  /* ---- p7_spensemble_Cluster: single linkage = connected components */
+  int *assign = malloc(sizeof(int) * (size_t)(nsp + 1)), *stack = malloc(sizeof(int) * (size_t)(nsp + 1));
+  int nc = 0;
+  for (int h = 0; h < nsp; h++) assign[h] = -1;
+  for (int h = 0; h < nsp; h++) {
+    if (assign[h] >= 0) continue;
+    int top = 0;
+    stack[top++] = h; assign[h] = nc;
+    while (top) {
+      const int a = stack[--top];
+      for (int b = 0; b < nsp; b++) if (assign[b] < 0 && linked(&sp[a], &sp[b], min_overlap, max_diagdiff, fs)) { assign[b] = nc; stack[top++] = b; }
+    }
+    nc++;
+  }
+  spcoord *sig = malloc(sizeof(spcoord) * (size_t)(nc + 1));
+  int nsig = 0;
+  int *epc = malloc(sizeof(int) * (size_t) span);
+  for (int c = 0; c < nc; c++) {
+    int ninc = 0, last = -1;
+    for (int h = 0; h < nsp; h++) if (assign[h] == c) { if (sp[h].idx != last) ninc++; last = sp[h].idx; }
+    if ((float) ninc / (float) nsamples < min_posterior) continue;
+    int imin = 0, imax = 0, jmin = 0, jmax = 0, kmin = 0, kmax = 0, mmin = 0, mmax = 0;
+    for (int h = 0; h < nsp; h++) if (assign[h] == c) {
+      if (imin == 0) { imin = imax = sp[h].i; jmin = jmax = sp[h].j; kmin = kmax = sp[h].k; mmin = mmax = sp[h].m; }
+      else {
+        imin = MINI(imin, sp[h].i); imax = MAXI(imax, sp[h].i);
+        jmin = MINI(jmin, sp[h].j); jmax = MAXI(jmax, sp[h].j);
+        kmin = MINI(kmin, sp[h].k); kmax = MAXI(kmax, sp[h].k);
+        mmin = MINI(mmin, sp[h].m); mmax = MAXI(mmax, sp[h].m);
+      }
+    }
+    const int thr = (int) ceilf((float) ninc * min_endpointp);
+    int best_i, best_j, best_k, best_m;
+#define COUNT(field, lo, hi) do { for (int x = 0; x <= (hi) - (lo); x++) epc[x] = 0; for (int h = 0; h < nsp; h++) if (assign[h] == c) epc[sp[h].field - (lo)]++; } while (0)
+    COUNT(i, imin, imax); for (best_i = imin; best_i <= imax; best_i++) if (epc[best_i - imin] >= thr) break;
+    if (best_i > imax) best_i = imin + argmax_i(epc, imax - imin + 1);
+    COUNT(k, kmin, kmax); for (best_k = kmin; best_k <= kmax; best_k++) if (epc[best_k - kmin] >= thr) break;
+    if (best_k > kmax) best_k = kmin + argmax_i(epc, kmax - kmin + 1);
+    COUNT(j, jmin, jmax); for (best_j = jmax; best_j >= jmin; best_j--) if (epc[best_j - jmin] >= thr) break;
+    if (best_j < jmin) best_j = jmin + argmax_i(epc, jmax - jmin + 1);
+    COUNT(m, mmin, mmax); for (best_m = mmax; best_m >= mmin; best_m--) if (epc[best_m - mmin] >= thr) break;
+    if (best_m < mmin) best_m = mmin + argmax_i(epc, mmax - mmin + 1);
+#undef COUNT
+    if (best_i > best_j || best_k > best_m) continue;
+    sig[nsig].i = best_i; sig[nsig].j = best_j; sig[nsig].k = best_k; sig[nsig].m = best_m; sig[nsig].idx = c;
+    sig[nsig].prob = (float) ninc / (float) nsamples; nsig++;
+  }
+  qsort(sig, (size_t) nsig, sizeof(spcoord), sp_cmp);
+  free(epc); free(assign); free(stack); free(sp);
+
+  /* ---- dominated clusters (p7_domaindef.c:815-843) */
+  char *dominated = calloc((size_t) nsig + 1, 1);
+  for (int d = 0; d < nsig; d++)
+    for (int d2 = d + 1; d2 < nsig; d2++) {
+      const int nov = (sig[d].j < sig[d2].j ? sig[d].j : sig[d2].j) - (sig[d].i > sig[d2].i ? sig[d].i : sig[d2].i) + 1;
+      if (nov == 0) break;
+      const int l1 = sig[d].j - sig[d].i + 1, l2 = sig[d2].j - sig[d2].i + 1, n = l1 < l2 ? l1 : l2;
+      if ((float) nov / (float) n >= 0.8) { if (sig[d].prob > sig[d2].prob) dominated[d2] = 1; else dominated[d] = 1; }
+    }
+  int out = 0;
+  for (int d = 0; d < nsig; d++) if (!dominated[d] && out < max_env) { env[2 * out] = sig[d].i; env[2 * out + 1] = sig[d].j; out++; }
+  free(dominated); free(sig);
+  return out;
+}
+
+
 /* region_trace_ensemble, p7_domaindef.c:766-850.  dsq[1..n]: the ORF; region ireg..jreg; fwd/fx: p7_Forward of the region in
  * the multihit configuration of length saveL.  n2sc[ireg..jreg] receives the null2 log odds; env[2*c], env[2*c+1] the
  * envelopes of the surviving clusters (sequence coordinates of the ORF), ordered by start. */
 int bo_region_trace_ensemble(const bo_oprofile *om, const uint8_t *dsq, int ireg, int jreg, const float *fwd, const float *fx,
                              float *n2sc, int *env, int max_env)
 {
-  const int nsamples = 200, max_diagdiff = 4, M = om->M;
-  const float min_overlap = 0.8f, min_posterior = 0.25f, min_endpointp = 0.02f;
+  const int nsamples = 200, M = om->M;
   const int Lr = jreg - ireg + 1;
   const int cap = 2 * Lr + M + 16;
   int8_t *st = malloc((size_t) cap);
@@ -212,67 +288,138 @@ int bo_region_trace_ensemble(const bo_oprofile *om, const uint8_t *dsq, int ireg
   for (int pos = ireg; pos <= jreg; pos++) n2sc[pos] = logf(n2sc[pos] / (float) nsamples);
   free(st); free(tk); free(ti); free(cnt);
 
-  /* ---- p7_spensemble_Cluster: single linkage = connected components */
-  int *assign = malloc(sizeof(int) * (size_t)(nsp + 1)), *stack = malloc(sizeof(int) * (size_t)(nsp + 1));
-  int nc = 0;
-  for (int h = 0; h < nsp; h++) assign[h] = -1;
-  for (int h = 0; h < nsp; h++) {
-    if (assign[h] >= 0) continue;
-    int top = 0;
-    stack[top++] = h; assign[h] = nc;
-    while (top) {
-      const int a = stack[--top];
-      for (int b = 0; b < nsp; b++) if (assign[b] < 0 && linked(&sp[a], &sp[b], min_overlap, max_diagdiff)) { assign[b] = nc; stack[top++] = b; }
-    }
-    nc++;
-  }
-  spcoord *sig = malloc(sizeof(spcoord) * (size_t)(nc + 1));
-  int nsig = 0;
-  int *epc = malloc(sizeof(int) * (size_t)(Lr + M + 4));
-  for (int c = 0; c < nc; c++) {
-    int ninc = 0, last = -1;
-    for (int h = 0; h < nsp; h++) if (assign[h] == c) { if (sp[h].idx != last) ninc++; last = sp[h].idx; }
-    if ((float) ninc / (float) nsamples < min_posterior) continue;
-    int imin = 0, imax = 0, jmin = 0, jmax = 0, kmin = 0, kmax = 0, mmin = 0, mmax = 0;
-    for (int h = 0; h < nsp; h++) if (assign[h] == c) {
-      if (imin == 0) { imin = imax = sp[h].i; jmin = jmax = sp[h].j; kmin = kmax = sp[h].k; mmin = mmax = sp[h].m; }
-      else {
-        imin = MINI(imin, sp[h].i); imax = MAXI(imax, sp[h].i);
-        jmin = MINI(jmin, sp[h].j); jmax = MAXI(jmax, sp[h].j);
-        kmin = MINI(kmin, sp[h].k); kmax = MAXI(kmax, sp[h].k);
-        mmin = MINI(mmin, sp[h].m); mmax = MAXI(mmax, sp[h].m);
-      }
-    }
-    const int thr = (int) ceilf((float) ninc * min_endpointp);
-    int best_i, best_j, best_k, best_m;
-#define COUNT(field, lo, hi) do { for (int x = 0; x <= (hi) - (lo); x++) epc[x] = 0; for (int h = 0; h < nsp; h++) if (assign[h] == c) epc[sp[h].field - (lo)]++; } while (0)
-    COUNT(i, imin, imax); for (best_i = imin; best_i <= imax; best_i++) if (epc[best_i - imin] >= thr) break;
-    if (best_i > imax) best_i = imin + argmax_i(epc, imax - imin + 1);
-    COUNT(k, kmin, kmax); for (best_k = kmin; best_k <= kmax; best_k++) if (epc[best_k - kmin] >= thr) break;
-    if (best_k > kmax) best_k = kmin + argmax_i(epc, kmax - kmin + 1);
-    COUNT(j, jmin, jmax); for (best_j = jmax; best_j >= jmin; best_j--) if (epc[best_j - jmin] >= thr) break;
-    if (best_j < jmin) best_j = jmin + argmax_i(epc, jmax - jmin + 1);
-    COUNT(m, mmin, mmax); for (best_m = mmax; best_m >= mmin; best_m--) if (epc[best_m - mmin] >= thr) break;
-    if (best_m < mmin) best_m = mmin + argmax_i(epc, mmax - mmin + 1);
-#undef COUNT
-    if (best_i > best_j || best_k > best_m) continue;
-    sig[nsig].i = best_i; sig[nsig].j = best_j; sig[nsig].k = best_k; sig[nsig].m = best_m; sig[nsig].idx = c;
-    sig[nsig].prob = (float) ninc / (float) nsamples; nsig++;
-  }
-  qsort(sig, (size_t) nsig, sizeof(spcoord), sp_cmp);
-  free(epc); free(assign); free(stack); free(sp);
+  return cluster_segments(sp, nsp, nsamples, Lr + M + 4, 0, env, max_env);
+}
 
-  /* ---- dominated clusters (p7_domaindef.c:815-843) */
-  char *dominated = calloc((size_t) nsig + 1, 1);
-  for (int d = 0; d < nsig; d++)
-    for (int d2 = d + 1; d2 < nsig; d2++) {
-      const int nov = (sig[d].j < sig[d2].j ? sig[d].j : sig[d2].j) - (sig[d].i > sig[d2].i ? sig[d].i : sig[d2].i) + 1;
-      if (nov == 0) break;
-      const int l1 = sig[d].j - sig[d].i + 1, l2 = sig[d2].j - sig[d2].i + 1, n = l1 < l2 ? l1 : l2;
-      if ((float) nov / (float) n >= 0.8) { if (sig[d].prob > sig[d2].prob) dominated[d2] = 1; else dominated[d] = 1; }
+/* ================================================================================================================
+ * Frameshift branch: p7_GStochasticTrace_Frameshift (src/generic_stotrace_frameshift.c:40-215) on the generic log-space
+ * Forward matrix, region_trace_ensemble_frameshift (src/p7_domaindef.c:891-958), p7_trace_fs_Index (src/p7_trace.c:2645),
+ * p7_spensemble_fs_Cluster.  (bathsearch itself samples from the SSE matrix, impl_sse/stotrace_fs.c, whose E-state choice
+ * walks the cells in striped order; this oracle follows the generic code like the rest of its frameshift functions.)
+ * ================================================================================================================ */
+static void flognorm(float *v, int n)                     /* esl_vec_FLogNorm: FLogSum, subtract, exp, FNorm */
+{
+  float mx = v[0];
+  for (int x = 1; x < n; x++) if (v[x] > mx) mx = v[x];
+  float denom;
+  if (mx == INFINITY) denom = INFINITY;
+  else if (mx == -INFINITY) denom = -INFINITY;
+  else { float sum = 0.f; for (int x = 0; x < n; x++) if (v[x] > mx - 50.f) sum += expf(v[x] - mx); denom = logf(sum) + mx; }
+  for (int x = 0; x < n; x++) v[x] = expf(v[x] - denom);
+  fnorm(v, n);
+}
+
+/* one sampled path; st/k/i/c first state first.  Returns the number of states or -1. */
+static int stochastic_trace_fs(bo_rng *rng, int L, const bo_fs_profile *gm, const bo_gmx *gx, float *sc /* 2M+2 */, int8_t *st, int32_t *tk, int32_t *ti, int8_t *tc, int cap)
+{
+  const int M = gm->M;
+  const float *tsc = gm->tsc;
+#define TS(s, k) (tsc[(size_t)(k) * BO_NTRANS + (s)])
+#define PUSHF(s) do { if (n >= cap) return -1; st[n] = (int8_t)(s); tk[n] = k; ti[n] = i; tc[n] = (int8_t) c; n++; } while (0)
+  int n = 0, i = L, k = 0, c = 0, sprv = BO_T_C;
+  PUSHF(BO_T_T); PUSHF(BO_T_C);
+  while (sprv != BO_T_S) {
+    int scur = -1;
+    switch (sprv) {
+    case BO_T_C:
+      if (BO_X(gx, i, BO_GC) == -INFINITY) return -1;
+      if (i < 4) { scur = BO_T_E; break; }
+      sc[0] = BO_X(gx, i - 3, BO_GC) + gm->xsc[BO_XC][BO_LOOP]; sc[1] = BO_X(gx, i - 2, BO_GC) + gm->xsc[BO_XC][BO_LOOP];
+      sc[2] = BO_X(gx, i - 1, BO_GC) + gm->xsc[BO_XC][BO_LOOP]; sc[3] = BO_X(gx, i, BO_GE) + gm->xsc[BO_XE][BO_MOVE];
+      flognorm(sc, 4);
+      scur = fchoose(rng, sc, 4) < 3 ? BO_T_C : BO_T_E; break;
+    case BO_T_E:
+      if (BO_X(gx, i, BO_GE) == -INFINITY) return -1;
+      sc[0] = sc[M + 1] = -INFINITY;
+      for (k = 1; k <= M; k++) sc[k] = BO_DP(gx, i, k, BO_GM);
+      for (k = 2; k <= M; k++) sc[k + M] = BO_DP(gx, i, k, BO_GD);
+      flognorm(sc, 2 * M + 1);
+      k = fchoose(rng, sc, 2 * M + 1);
+      if (k <= M) scur = BO_T_M; else { k -= M; scur = BO_T_D; }
+      break;
+    case BO_T_M:
+      sc[0] = BO_X(gx, i, BO_GB) + TS(BO_BM, k - 1); sc[1] = BO_DP(gx, i, k - 1, BO_GM) + TS(BO_MM, k - 1);
+      sc[2] = BO_DP(gx, i, k - 1, BO_GI) + TS(BO_IM, k - 1); sc[3] = BO_DP(gx, i, k - 1, BO_GD) + TS(BO_DM, k - 1);
+      flognorm(sc, 4);
+      { static const int state[4] = { BO_T_B, BO_T_M, BO_T_I, BO_T_D }; scur = state[fchoose(rng, sc, 4)]; }
+      k--; break;
+    case BO_T_D:
+      if (BO_DP(gx, i, k, BO_GD) == -INFINITY) return -1;
+      sc[0] = BO_DP(gx, i, k - 1, BO_GM) + TS(BO_MD, k - 1); sc[1] = BO_DP(gx, i, k - 1, BO_GD) + TS(BO_DD, k - 1);
+      flognorm(sc, 2);
+      scur = fchoose(rng, sc, 2) == 0 ? BO_T_M : BO_T_D; k--; break;
+    case BO_T_I:
+      if (BO_DP(gx, i, k, BO_GI) == -INFINITY || i < 3) return -1;
+      sc[0] = BO_DP(gx, i - 3, k, BO_GM) + TS(BO_MI, k); sc[1] = BO_DP(gx, i - 3, k, BO_GI) + TS(BO_II, k);
+      flognorm(sc, 2);
+      scur = fchoose(rng, sc, 2) == 0 ? BO_T_M : BO_T_I; i -= 3; break;
+    case BO_T_N:
+      if (BO_X(gx, i, BO_GN) == -INFINITY) return -1;
+      scur = (i == 0) ? BO_T_S : BO_T_N; break;
+    case BO_T_B:
+      if (BO_X(gx, i, BO_GB) == -INFINITY) return -1;
+      sc[0] = BO_X(gx, i, BO_GN) + gm->xsc[BO_XN][BO_MOVE]; sc[1] = BO_X(gx, i, BO_GJ) + gm->xsc[BO_XJ][BO_MOVE];
+      flognorm(sc, 2);
+      scur = fchoose(rng, sc, 2) == 0 ? BO_T_N : BO_T_J; break;
+    case BO_T_J:
+      if (BO_X(gx, i, BO_GJ) == -INFINITY) return -1;
+      if (i < 4) { scur = BO_T_E; break; }
+      sc[0] = BO_X(gx, i - 3, BO_GJ) + gm->xsc[BO_XJ][BO_LOOP]; sc[1] = BO_X(gx, i - 2, BO_GJ) + gm->xsc[BO_XJ][BO_LOOP];
+      sc[2] = BO_X(gx, i - 1, BO_GJ) + gm->xsc[BO_XJ][BO_LOOP]; sc[3] = BO_X(gx, i, BO_GE) + gm->xsc[BO_XE][BO_LOOP];
+      flognorm(sc, 4);
+      scur = fchoose(rng, sc, 4) < 3 ? BO_T_J : BO_T_E; break;
+    default: return -1;
     }
-  int out = 0;
-  for (int d = 0; d < nsig; d++) if (!dominated[d] && out < max_env) { env[2 * out] = sig[d].i; env[2 * out + 1] = sig[d].j; out++; }
-  free(dominated); free(sig);
-  return out;
+    if (scur == BO_T_M) {                                   /* codon length from the C1..C5 cells */
+      for (int q = 0; q < 5; q++) sc[q] = BO_DP(gx, i, k, BO_GM + 1 + q);
+      flognorm(sc, 5);
+      c = fchoose(rng, sc, 5) + 1;
+      if (i - c < 0) scur = BO_T_B;
+    } else c = 0;
+    if (scur < 0 || k < 0 || i < 0) return -1;
+    PUSHF(scur);
+    if ((scur == BO_T_N || scur == BO_T_C || scur == BO_T_J) && scur == sprv) i--;
+    sprv = scur;
+    i -= c;
+    if (i < 0) return -1;
+  }
+#undef PUSHF
+#undef TS
+  for (int a = 0, b = n - 1; a < b; a++, b--) {
+    int8_t s = st[a]; st[a] = st[b]; st[b] = s;
+    s = tc[a]; tc[a] = tc[b]; tc[b] = s;
+    int32_t x = tk[a]; tk[a] = tk[b]; tk[b] = x;
+    x = ti[a]; ti[a] = ti[b]; ti[b] = x;
+  }
+  return n;
+}
+
+/* region_trace_ensemble_frameshift: fwd = p7_GForward_Frameshift of the region (multihit).  env: envelopes in window
+ * coordinates (nucleotides), ordered by start.  Returns their number (0 when a traceback is impossible). */
+int bo_region_trace_ensemble_fs(const bo_fs_profile *gm5, int ireg, int jreg, const bo_gmx *fwd, int *env, int max_env)
+{
+  const int nsamples = 200, M = gm5->M, Lr = jreg - ireg + 1;
+  const int cap = 2 * Lr + M + 16;
+  int8_t *st = malloc((size_t) cap), *tc = malloc((size_t) cap);
+  int32_t *tk = malloc(sizeof(int32_t) * (size_t) cap), *ti = malloc(sizeof(int32_t) * (size_t) cap);
+  float *sc = malloc(sizeof(float) * (size_t)(2 * M + 8));
+  spcoord *sp = NULL;
+  int nsp = 0, sp_alloc = 0, ok = 1;
+  bo_rng rng;
+  bo_rng_init(&rng, 42);
+  for (int t = 0; t < nsamples && ok; t++) {
+    const int N = stochastic_trace_fs(&rng, Lr, gm5, fwd, sc, st, tk, ti, tc, cap);
+    if (N < 0) { ok = 0; break; }
+    for (int z = 0; z < N; z++) {
+      if (st[z] != BO_T_B) continue;
+      int sqfrom = 0, sqto = 0, hmmfrom = 0, hmmto = 0;
+      for (z = z + 1; z < N && st[z] != BO_T_E; z++)
+        if (st[z] == BO_T_M) { if (!sqfrom) sqfrom = ti[z] - tc[z] + 1; if (!hmmfrom) hmmfrom = tk[z]; sqto = ti[z]; hmmto = tk[z]; }
+      if (nsp == sp_alloc) { sp_alloc = sp_alloc ? sp_alloc * 2 : 256; sp = realloc(sp, sizeof(spcoord) * (size_t) sp_alloc); }
+      sp[nsp].idx = t; sp[nsp].i = sqfrom + ireg - 1; sp[nsp].j = sqto + ireg - 1; sp[nsp].k = hmmfrom; sp[nsp].m = hmmto; sp[nsp].prob = 0.f; nsp++;
+    }
+  }
+  free(st); free(tc); free(tk); free(ti); free(sc);
+  if (!ok) { free(sp); return 0; }
+  return cluster_segments(sp, nsp, nsamples, jreg + M + 8, 1, env, max_env);
 }

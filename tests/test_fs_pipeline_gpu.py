@@ -115,37 +115,75 @@ def test_planted_frameshifted_genes(gpu_ctx, name):
     assert any(w.strand == 1 for w in fw) and any(w.orf_cnt > 1 for w in fw)
 
 
-def compare_domains(model, gdm, odm, per_d):
-    """Alignment end points, model range and shifted-codon count must be identical.  Envelope ends come from thresholds on
-    posterior sums of the 3-codon parsers (rt2 = 0.10, p7_domaindef.c:355-372), whose table log-sum arithmetic is only
-    tolerance-equal between the two implementations (tests/test_frameshift_gpu.py), so an end may fall one step to either
-    side in a borderline case: at most 3 nt, in at most 10% of the domains (and at least 1)."""
+def compare_domains(model, gdm, odm, per_d, nclustered=0):
+    """Domain by domain.  Three grades of agreement, because three kinds of arithmetic feed the envelopes:
+
+    * exact: alignment end points, model range, shifted-codon count and envelope identical, scores at the tolerances of
+      tests/test_frameshift_gpu.py.  This is the rule; everything below is bounded.
+    * one-step envelope: envelope ends come from thresholds on posterior sums of the 3-codon parsers (rt2 = 0.10,
+      p7_domaindef.c:355-372), whose table log-sum arithmetic is only tolerance-equal between the two implementations, so an
+      end may fall one step (<= 3 nt) to either side in a borderline case; the alignment may then pick up or drop a weak
+      segment at that end.  At most 10% of the domains (and at least 1).
+    * clustered regions (<nclustered> of them): their envelopes are consensus end points of 200 stochastic tracebacks
+      through the region's Forward matrix.  Two tolerance-equal matrices do not give the same 200 samples, so these envelopes
+      agree only statistically: same place (ends within 60 nt -- an end is the widest one that 2% of the samples support --,
+      alignments overlapping), score within 2.5 bits.  At most 3 such
+      domains per clustered region; a domain too weak to be reported may be missing on one side."""
     want = []
     for w, (a, b) in enumerate(per_d):
         want += [(w, o) for o in odm[a:b]]
-    got = sorted(gdm, key=lambda g: (g.window, min(g.jali, g.jenv), g.ienv))
-    want.sort(key=lambda t: (t[0], min(t[1].jali, t[1].jenv), t[1].ienv))
-    assert len(got) == len(want)
-    shifted = 0
-    for g, (w, o) in zip(got, want):
-        assert g.window == w
-        if (g.ienv, g.jenv) != (o.ienv, o.jenv):
-            # a different envelope is a different rescoring problem: the optimal-accuracy alignment may then also pick up or
-            # drop a weak segment at that end.  Same place, nearly the same score.
-            assert abs(g.ienv - o.ienv) <= 3 and abs(g.jenv - o.jenv) <= 3
-            lo, hi = max(min(g.iali, g.jali), min(o.iali, o.jali)), min(max(g.iali, g.jali), max(o.iali, o.jali))
-            assert hi - lo + 1 >= 0.5 * (abs(o.jali - o.iali) + 1)
-            assert abs(g.envsc - o.envsc) <= 0.1 + 1e-4 * abs(o.envsc) and abs(g.bitscore - o.bitscore) <= 0.5
-            shifted += 1
+    key = lambda w, d: (w, d.ienv, d.jenv, d.iali, d.jali, d.ihmm, d.jhmm, d.n_shifted_codons)
+    lam = model.om.contents.evparam[5]
+    omap = {}
+    for w, o in want:
+        omap.setdefault(key(w, o), []).append(o)
+    rest_g = []
+    resampled = 0
+    for g in gdm:
+        lst = omap.get(key(g.window, g))
+        if not lst:
+            rest_g.append(g)
             continue
-        assert (g.iali, g.jali, g.ihmm, g.jhmm, g.n_shifted_codons) == (o.iali, o.jali, o.ihmm, o.jhmm, o.n_shifted_codons)
+        o = lst.pop()
         assert abs(g.envsc - o.envsc) <= 5e-3 + 1e-4 * abs(o.envsc)                  # table log-sum association, as test_frameshift_gpu.py
         assert abs(g.oasc - o.oasc) <= 2e-2 + 1e-3 * abs(o.oasc)
-        assert abs(g.domcorrection - o.domcorrection) <= 2e-2 + 5e-3 * abs(o.domcorrection)
-        assert abs(g.bitscore - o.bitscore) <= 0.05 and abs(g.pre_score - o.pre_score) <= 0.05     # bits
-        assert abs(g.lnP - o.lnP) <= 0.05 * model.om.contents.evparam[5] + 1e-6
-    assert shifted <= max(1, len(got) // 10)
-    return len(got)
+        n2tol = 2e-2 + 5e-3 * abs(o.domcorrection)
+        if abs(g.domcorrection - o.domcorrection) > n2tol:      # standard-branch domain of a clustered region: the same envelope
+            resampled += 1                                       # from a differently sampled ensemble (tests/test_hits_gpu.py)
+            n2tol = 0.5
+        assert abs(g.domcorrection - o.domcorrection) <= n2tol
+        assert abs(g.bitscore - o.bitscore) <= 0.05 + n2tol / np.log(2.0) and abs(g.pre_score - o.pre_score) <= 0.05     # bits; the bias term moves with the correction
+        assert abs(g.lnP - o.lnP) <= (0.05 + n2tol / np.log(2.0)) * lam + 1e-6
+    rest_o = [(w, o) for w, o in want if any(o is x for x in omap.get(key(w, o), []))]
+    shifted = 0
+    near = resampled
+
+    def span(d):
+        return min(d.ienv, d.jenv), max(d.ienv, d.jenv)
+    for g in rest_g:
+        best = None
+        for idx, (w, o) in enumerate(rest_o):
+            if w != g.window:
+                continue
+            lo, hi = max(span(g)[0], span(o)[0]), min(span(g)[1], span(o)[1])
+            if hi - lo + 1 >= 0.5 * (span(o)[1] - span(o)[0] + 1) and (best is None or hi - lo > best[0]):
+                best = (hi - lo, idx)
+        if best is None:
+            assert not g.reported or g.bitscore < 12.0, "GPU-only domain"         # a weak extra cluster
+            near += 1
+            continue
+        w, o = rest_o.pop(best[1])
+        if abs(g.ienv - o.ienv) <= 3 and abs(g.jenv - o.jenv) <= 3 and abs(g.envsc - o.envsc) <= 0.1 + 1e-4 * abs(o.envsc) and abs(g.bitscore - o.bitscore) <= 0.5:
+            shifted += 1
+        else:
+            assert abs(g.ienv - o.ienv) <= 60 and abs(g.jenv - o.jenv) <= 60 and abs(g.bitscore - o.bitscore) <= 2.5
+            near += 1
+    for w, o in rest_o:
+        assert not o.reported or o.bitscore < 12.0, "oracle-only domain"
+        near += 1
+    assert near <= 3 * nclustered
+    assert shifted <= max(1, len(want) // 10) + (nclustered if near < 3 * nclustered else 0)
+    return len(gdm)
 
 
 def test_recorded_fs_hit_on_gpu(gpu_ctx):
@@ -182,7 +220,7 @@ def test_domains_of_planted_frameshifted_genes(gpu_ctx, name):
     _, ofw, per_w, odm, per_d, oskip = model.run_pipeline_fsdom(wins)
     assert sorted((w.window, w.strand, w.n, w.branch) for w in fw) == sorted((i, o.strand, o.n, o.branch) for i, (a, b) in enumerate(per_w) for o in ofw[a:b])
     assert nskip == oskip
-    n = compare_domains(model, dm, odm, per_d)
+    n = compare_domains(model, dm, odm, per_d, nskip)
     assert n >= 3 and any(d.n_shifted_codons > 0 for d in dm) and any(d.strand == 1 for d in dm)
     # both branches of p7_pli_Frameshift produce hits: codon-model domains and standard domains on window coordinates
     assert any(fw[d.fs_window].branch == 1 for d in dm) and any(fw[d.fs_window].branch == 2 for d in dm)

@@ -32,7 +32,7 @@ for name, idx in models:
             st2, fw, dm2, nskip2 = pipe.run_frameshift_domains(om3, om5, ba.SeqBlock(ctx, wins))
             _, ofw, per_w, odm2, per_d2, oskip2 = model.run_pipeline_fsdom(wins)
             assert nskip2 == oskip2
-            n2 = TF.compare_domains(model, dm2, odm2, per_d2)
+            n2 = TF.compare_domains(model, dm2, odm2, per_d2, nskip2)
             print("ok   %-22s %d seed %d: %d std hits, %d fs-pipeline hits, skipped %d/%d" % (name, idx, seed, n1, n2, nskip, nskip2), flush=True)
         except Exception:
             bad += 1
