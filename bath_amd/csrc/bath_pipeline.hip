@@ -510,7 +510,7 @@ extern "C" int bath_hip_pipeline_timings(const bath_hip_ctx *ctx, int max, const
 namespace bath {
 struct FilterState {               // what the frameshift stage reads after the cascade (device memory stays in ctx->scratch)
   PipelineWork W;
-  Counters hc;
+  Counters hc{};                     // zero when the block is empty and the cascade returns before running
   const uint8_t *d_ssvsc = nullptr;
   const float *d_bgf = nullptr;
   OrfTablesDev tt{};

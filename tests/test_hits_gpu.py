@@ -145,3 +145,15 @@ def test_hits_empty_and_background(ctx):
     model = ol.Model(path, 0)
     pli, odm, per_d, onskip = model.run_pipeline_hits(wins)
     compare_hits(dm, odm, per_d, nskip, onskip)
+
+
+def test_hits_of_an_empty_block(ctx):
+    path = ol.GOLDEN + "/Caudal_act.bhmm"
+    stats, dm, nskip = gpu_hits(ctx, path, 0, [])
+    assert (stats.nres, stats.n_orfs, len(dm), nskip) == (0, 0, 0, 0)
+    hmm = ba.HMM(path, 0)
+    om = ba.OProfile(ctx, ba.Profile(hmm))
+    om3 = ba.FSOProfile(ctx, ba.FSProfile(hmm, 3, ncbi_table=hmm.ct))
+    om5 = ba.FSOProfile(ctx, ba.FSProfile(hmm, 5, ncbi_table=hmm.ct))
+    st, fw, dm, nskip = ba.Pipeline(ctx, om, fs_pipe=True, ncbi_table=hmm.ct).run_frameshift_domains(om3, om5, ba.SeqBlock(ctx, []))
+    assert (st.nres, len(fw), len(dm), nskip) == (0, 0, 0, 0)

@@ -9,6 +9,9 @@ export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/round
 rm -rf $OUT; mkdir -p $OUT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline > $OUT/bench_under_prof.log 2>&1
+export BATH_HIP_LANES=1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats1 -o bench1 -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline > $OUT/bench_under_prof_1lane.log 2>&1
+unset BATH_HIP_LANES
 P="python3 bench.py --steps 2 --warmup 0 --no-cpu-baseline --windows 200000"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $P > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $P > $OUT/pmc_write.log 2>&1
@@ -17,4 +20,5 @@ rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONF
 rocprofv3 --pmc GRBM_GUI_ACTIVE GRBM_COUNT --output-format csv -d $OUT/pmc_grbm -- $P > $OUT/pmc_grbm.log 2>&1
 python3 tools/pmc_summary.py $OUT/pmc_by_kernel.json $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq1 $OUT/pmc_sq2 $OUT/pmc_grbm
 cp $OUT/stats/*kernel_stats.csv $OUT/kernel_stats.csv 2>/dev/null || find $OUT/stats -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
+find $OUT/stats1 -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats_1lane.csv \;
 tail -1 $OUT/bench_under_prof.log | cut -c1-400
