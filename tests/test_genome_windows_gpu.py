@@ -88,3 +88,32 @@ def test_split_target_equals_whole_target(hmmfile):
         assert any(fl & 4 for _, _, fl in th_split.hits())
     if not (split - whole):
         assert text_split == text_whole
+
+
+@pytest.mark.parametrize("lanes", [2, 3])
+def test_contexts_survive_the_split_into_concurrent_parts(monkeypatch, lanes):
+    """bath_hip_pipeline_filters runs big blocks as concurrent parts; each part must see its own windows' contexts."""
+    ctx = ba.Context(0)
+    path = ol.GOLDEN + "/PTH2.bhmm"
+    model = ol.Model(path, 0)
+    hmm = ba.HMM(path, 0)
+    rng = np.random.default_rng(7)
+    genome = planted_genome(rng, model, L=300000)
+    wins = bd.split_targets([len(genome)], hmm.max_length, 20000)
+    seqs = [genome[s:s + n] for _, s, n, _ in wins]
+    ctxs = [c for _, _, _, c in wins]
+    om = ba.OProfile(ctx, ba.Profile(hmm))
+    pipe = ba.Pipeline(ctx, om, fs_pipe=False, ncbi_table=hmm.ct)
+    out = []
+    for k in (1, lanes):
+        monkeypatch.setenv("BATH_HIP_LANES", str(k))
+        block = ba.SeqBlock(ctx, seqs)
+        block.set_context(ctxs)
+        stats, res = pipe.run(block)
+        out.append(((stats.nres, stats.n_past_msv, stats.pos_past_msv, stats.pos_past_bias, stats.pos_past_vit, stats.pos_past_fwd), np.sort(res, order=["window", "strand", "frame", "start"])))
+    assert out[0][0] == out[1][0] and len(out[0][1]) == len(out[1][1])
+    for f in out[0][1].dtype.names:                       # field by field: the records carry padding bytes
+        assert np.array_equal(out[0][1][f], out[1][1][f], equal_nan=True), f
+    pli, _, _, _ = model.run_pipeline_hits(seqs, contexts=ctxs)
+    assert out[0][0] == (pli.nres, pli.n_past_msv, pli.pos_past_msv, pli.pos_past_bias, pli.pos_past_vit, pli.pos_past_fwd)
+    assert pli.nres == 2 * len(genome)
