@@ -22,11 +22,14 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "bath_common.hpp"
+#include "bath_kernels.hpp"
 #include "bath_launch.hpp"
 
 using namespace bath;
@@ -37,6 +40,16 @@ namespace {
 const double kLn2 = 0.69314718055994529;
 
 double exp_logsurv(double x, double mu, double lambda) { return x < mu ? 0.0 : -lambda * (x - mu); }
+
+// run work(first, step) on up to 16 host threads (regions of one block are independent)
+template <class F>
+void run_striped(int64_t n, F &&work) {
+  const int T = (int)std::min<int64_t>(std::min<int64_t>(n, 16), std::max(1u, std::thread::hardware_concurrency()));
+  if (T <= 1) { work(0, 1); return; }
+  std::vector<std::thread> th;
+  for (int k = 0; k < T; k++) th.emplace_back([&work, k, T] { work(k, T); });
+  for (std::thread &t : th) t.join();
+}
 
 // The --cigar string of an alignment (p7_alidisplay_fs_Create, p7_alidisplay.c:777-815, 841-869; the non-frameshift display
 // :1140-1200 is the special case "every codon has 3 nucleotides").  One code per alignment column:
@@ -154,16 +167,21 @@ static int fs_branch_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, con
     }
     const float pm = (2.0f + 1.0f) / (100.0f + 2.0f + 1.0f);                 // p7_fs_ReconfigLength(L = 100), multihit (nj = 1)
     const float xNL = (float)std::log((double)(1.0f - pm)), xNM = (float)std::log((double)pm), xE = (float)-kLn2;
-    std::vector<std::pair<int, int>> cl;
-    for (size_t e = 0; e < mregs.size(); e++) {
-      if (!(h_sc[e] > -INFINITY)) continue;                                   // Forward underflow: no valid traces for this region (:413)
-      const int Lr = rregs[e].len;
-      if (fs_region_trace_ensemble(h5.M, h5.tsc, xNL, xNM, xE, mregs[e].i, Lr, h_f.data() + foff[e], h_x.data() + xoff[e], &cl) != BATH_OK) continue;
-      for (const auto &c : cl) {
-        const int i2 = std::max(1, c.first), j2 = c.second;                   // :449
-        if (j2 - i2 + 1 >= 15) envs.push_back(Env{mregs[e].sel, i2, j2});
+    std::vector<std::vector<Env>> found(mregs.size());
+    auto work = [&](int64_t first, int64_t step) {
+      std::vector<std::pair<int, int>> cl;
+      for (size_t e = (size_t)first; e < mregs.size(); e += (size_t)step) {
+        if (!(h_sc[e] > -INFINITY)) continue;                                 // Forward underflow: no valid traces for this region (:413)
+        const int Lr = rregs[e].len;
+        if (fs_region_trace_ensemble(h5.M, h5.tsc, xNL, xNM, xE, mregs[e].i, Lr, h_f.data() + foff[e], h_x.data() + xoff[e], &cl) != BATH_OK) continue;
+        for (const auto &c : cl) {
+          const int i2 = std::max(1, c.first), j2 = c.second;                 // :449
+          if (j2 - i2 + 1 >= 15) found[e].push_back(Env{mregs[e].sel, i2, j2});
+        }
       }
-    }
+    };
+    run_striped((int64_t)mregs.size(), work);
+    for (size_t e = 0; e < mregs.size(); e++) envs.insert(envs.end(), found[e].begin(), found[e].end());
   }
   if (envs.empty()) return BATH_OK;
 
@@ -331,7 +349,8 @@ struct StdEnvOut { int32_t i1, k1, i2, k2, ok; float oasc, domcorrection; int32_
 __global__ void std_envelope_kernel(SeqView sq, int M, const float *__restrict__ tf, const float *__restrict__ rf, float *__restrict__ fwd, float *__restrict__ bck,
                                     const int64_t *__restrict__ dp_off, const float *__restrict__ fx, const float *__restrict__ bx, const int64_t *__restrict__ x_off,
                                     float *__restrict__ ppx_all, float *__restrict__ oax_all, float *__restrict__ em_all /* [n][2*(M+1)] */, StdEnvOut *__restrict__ out,
-                                    const uint8_t *__restrict__ cons /* [M+1] or null */, uint8_t *__restrict__ tbuf, const int64_t *__restrict__ t_off) {
+                                    const uint8_t *__restrict__ cons /* [M+1] or null */, uint8_t *__restrict__ tbuf, const int64_t *__restrict__ t_off,
+                                    int filled /* std_envelope_fill_kernel already did decoding, OA fill and null2: traceback only */) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= sq.n) return;
   enum { XE = 0, XN, XJ, XB, XC, XS };
@@ -346,6 +365,14 @@ __global__ void std_envelope_kernel(SeqView sq, int M, const float *__restrict__
   float *PX = ppx_all + (x_off[t] / 6) * 5, *OX = oax_all + (x_off[t] / 6) * 5;
   StdEnvOut r{-1, -1, -1, -1, 0, 0.f, 0.f, 0, 0};
   const float ploop = 1.0f - 2.0f / ((float)L + 2.0f);                       // unihit: xf[N|J|C][LOOP]
+  const float *P = Bk;
+  float *O = F;
+  if (filled) {
+    const StdEnvOut pre = out[t];
+    if (!pre.ok) { out[t] = r; return; }
+    r.oasc = pre.oasc; r.domcorrection = pre.domcorrection;
+  }
+  if (!filled) {
   // ---- p7_Decoding (decoding.c:61-118): posteriors overwrite Backward
   float scaleproduct = (float)(1.0 / (double)BX[XN]);
   for (int k = 0; k <= M; k++) Bk[(size_t)k * 3] = Bk[(size_t)k * 3 + 1] = Bk[(size_t)k * 3 + 2] = 0.f;
@@ -368,8 +395,6 @@ __global__ void std_envelope_kernel(SeqView sq, int M, const float *__restrict__
   }
   if (isinf(scaleproduct)) { out[t] = r; return; }                           // eslERANGE: the domain is dropped (p7_domaindef.c:1214)
   // ---- p7_OptimalAccuracy (optacc.c:58-173): the OA matrix overwrites Forward
-  const float *P = Bk;
-  float *O = F;
   auto allow = [](float tr, float v) { return tr > 0.0f ? v : 0.0f; };
   for (int k = 0; k <= M; k++) O[(size_t)k * 3] = O[(size_t)k * 3 + 1] = O[(size_t)k * 3 + 2] = -INFINITY;
   OX[XE] = -INFINITY; OX[XN] = 0.f; OX[XJ] = -INFINITY; OX[XB] = 0.f; OX[XC] = -INFINITY;
@@ -402,6 +427,7 @@ __global__ void std_envelope_kernel(SeqView sq, int M, const float *__restrict__
     ox[XB] = fmaxf(ox[XN], ox[XJ]);
   }
   r.oasc = OX[(size_t)L * 5 + XC];
+  }
   // ---- p7_OATrace (optacc.c:225-430); select_e walks the cells in the reference's striped order
   {
     const int Q = max(2, (M - 1) / 4 + 1);
@@ -460,7 +486,7 @@ __global__ void std_envelope_kernel(SeqView sq, int M, const float *__restrict__
     if (bad || r.i1 <= 0) { out[t] = r; return; }
   }
   // ---- p7_Null2_ByExpectation (null2.c:50-124) and the correction over the envelope (p7_domaindef.c:1264-1272)
-  {
+  if (!filled) {
     float *em = em_all + (size_t)t * 2 * (M + 1);
     float xN = PX[5 + XN], xC = PX[5 + XC], xJ = PX[5 + XJ];
     for (int k = 1; k <= M; k++) { em[2 * k] = P[W + (size_t)k * 3 + cM]; em[2 * k + 1] = P[W + (size_t)k * 3 + cI]; }
@@ -494,6 +520,169 @@ __global__ void std_envelope_kernel(SeqView sq, int M, const float *__restrict__
   }
   r.ok = 1;
   out[t] = r;
+}
+
+// The same decoding, optimal-accuracy fill and null2 with a WAVE per envelope: lanes own C consecutive nodes each, rows are
+// walked in order with the previous row in registers (neighbours by shuffle), the row's D chain D(k+1) = max(MD_k ? M_k : 0,
+// DD_k ? D_k : 0) is a wavefront scan over functions x -> pass ? max(c, x) : c (closed under composition), xE a wave max.
+// max / select only, so the OA matrix is bit-identical to the serial fill and the traceback (std_envelope_kernel with
+// filled = 1, a lane per envelope) takes the same path.  Posteriors live in registers only: their column sums for null2 are
+// accumulated on the fly in the serial kernel's order; only null2's sum over the nodes is associated differently (wave sum).
+// The lane-per-envelope fill took 35 ms for 1500 envelopes (every cell a dependent trip to HBM); this one is well under 1 ms.
+template <int C>
+__global__ __launch_bounds__(256) void std_envelope_fill_kernel(SeqView sq, int M, const float *__restrict__ tf, const float *__restrict__ rf, float *__restrict__ fwd,
+                                                                const float *__restrict__ bck, const int64_t *__restrict__ dp_off, const float *__restrict__ fx,
+                                                                const float *__restrict__ bx, const int64_t *__restrict__ x_off, float *__restrict__ ppx_all,
+                                                                float *__restrict__ oax_all, StdEnvOut *__restrict__ out) {
+  enum { XE = 0, XN, XJ, XB, XC, XS };
+  enum { cM = 0, cD = 1, cI = 2 };
+  enum { MM = 0, IM, DM, BM, MD, DD, MI, II };
+  const int lane = threadIdx.x & 63;
+  const int64_t wid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  auto allow = [](float tr, float v) { return tr > 0.0f ? v : 0.0f; };
+  for (int64_t t = wid; t < sq.n; t += nw) {
+    const int L = sq.len[t];
+    const uint8_t *dsq = sq.data + sq.off[t] - 1;
+    const size_t W = (size_t)(M + 1) * 3;
+    float *F = fwd + dp_off[t];
+    const float *Bk = bck + dp_off[t];
+    const float *FX = fx + x_off[t], *BX = bx + x_off[t];
+    float *PX = ppx_all + (x_off[t] / 6) * 5, *OX = oax_all + (x_off[t] / 6) * 5;
+    const float ploop = 1.0f - 2.0f / ((float)L + 2.0f);
+    float tr[C][8];
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+      const int node = lane * C + c + 1;
+#pragma unroll
+      for (int q = 0; q < 8; q++) tr[c][q] = node <= M ? tf[(size_t)node * 8 + q] : 0.f;
+    }
+    float pvM[C], pvI[C], pvD[C], emM[C], emI[C];
+#pragma unroll
+    for (int c = 0; c < C; c++) { pvM[c] = pvI[c] = pvD[c] = -INFINITY; emM[c] = emI[c] = 0.f; }
+    float oxN = 0.f, oxJ = -INFINITY, oxC = -INFINITY, oxB = 0.f, sN = 0.f, sC = 0.f, sJ = 0.f;
+    float scaleproduct = (float)(1.0 / (double)BX[XN]);
+    for (int k = lane; k <= M; k += 64) F[(size_t)k * 3] = F[(size_t)k * 3 + 1] = F[(size_t)k * 3 + 2] = -INFINITY;      // OA row 0
+    if (lane == 0) {
+      for (int q = 0; q < 5; q++) PX[q] = 0.f;
+      OX[XE] = -INFINITY; OX[XN] = 0.f; OX[XJ] = -INFINITY; OX[XB] = 0.f; OX[XC] = -INFINITY;
+    }
+    for (int i = 1; i <= L; i++) {
+      const float totr = scaleproduct * FX[(size_t)i * 6 + XS];
+      float *frow = F + (size_t)i * W;
+      const float *brow = Bk + (size_t)i * W;
+      // posteriors of this row (p7_Decoding), special states included
+      float pM[C], pI[C];
+#pragma unroll
+      for (int c = 0; c < C; c++) {
+        const int node = lane * C + c + 1;
+        if (node <= M) {
+          pM[c] = frow[(size_t)node * 3 + cM] * (brow[(size_t)node * 3 + cM] * totr);
+          pI[c] = frow[(size_t)node * 3 + cI] * (brow[(size_t)node * 3 + cI] * totr);
+        } else pM[c] = pI[c] = 0.f;
+        if (i == 1) { emM[c] = pM[c]; emI[c] = pI[c]; } else { emM[c] = pM[c] + emM[c]; emI[c] = pI[c] + emI[c]; }
+      }
+      const float pxN = FX[(size_t)(i - 1) * 6 + XN] * BX[(size_t)i * 6 + XN] * ploop * scaleproduct;
+      const float pxJ = FX[(size_t)(i - 1) * 6 + XJ] * BX[(size_t)i * 6 + XJ] * ploop * scaleproduct;
+      const float pxC = FX[(size_t)(i - 1) * 6 + XC] * BX[(size_t)i * 6 + XC] * ploop * scaleproduct;
+      if (i == 1) { sN = pxN; sC = pxC; sJ = pxJ; } else { sN += pxN; sC += pxC; sJ += pxJ; }
+      scaleproduct *= FX[(size_t)i * 6 + XS] / BX[(size_t)i * 6 + XS];
+      // optimal-accuracy row (p7_OptimalAccuracy)
+      float mIn = __shfl_up(pvM[C - 1], 1, 64), iIn = __shfl_up(pvI[C - 1], 1, 64), dIn = __shfl_up(pvD[C - 1], 1, 64);
+      if (lane == 0) mIn = iIn = dIn = -INFINITY;
+      float cuM[C], cuI[C], cuD[C];
+      float fc = -INFINITY; bool fpass = true;                              // the lane's composite D-chain function
+      float xE = -INFINITY;
+#pragma unroll
+      for (int c = 0; c < C; c++) {
+        const int node = lane * C + c + 1;
+        if (node <= M) {
+          const float m1 = c == 0 ? mIn : pvM[c - 1], i1 = c == 0 ? iIn : pvI[c - 1], d1 = c == 0 ? dIn : pvD[c - 1];
+          float sv = allow(tr[c][BM], oxB);
+          sv = fmaxf(sv, allow(tr[c][MM], m1));
+          sv = fmaxf(sv, allow(tr[c][IM], i1));
+          sv = fmaxf(sv, allow(tr[c][DM], d1));
+          sv = sv + pM[c];
+          cuM[c] = sv;
+          xE = fmaxf(xE, sv);
+          cuI[c] = fmaxf(allow(tr[c][MI], pvM[c]), allow(tr[c][II], pvI[c])) + pI[c];
+          const float cst = allow(tr[c][MD], sv);                           // f_node(x) = max(cst, DD ? x : 0)
+          const bool pass = tr[c][DD] > 0.0f;
+          const float g = pass ? cst : fmaxf(cst, 0.0f);
+          if (pass) fc = fmaxf(g, fc); else { fc = g; fpass = false; }      // f_node o (what the lane has so far)
+        } else { cuM[c] = cuI[c] = -INFINITY; }
+      }
+      // inclusive scan of the lanes' functions, then the value entering each lane: D(first node of the lane)
+      float sc_c = fc; bool sc_p = fpass;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const float oc = __shfl_up(sc_c, d, 64);
+        const int op = __shfl_up((int)sc_p, d, 64);
+        if (lane >= d && sc_p) { sc_c = fmaxf(sc_c, oc); sc_p = op != 0; }
+      }
+      float din = __shfl_up(sc_c, 1, 64);                                   // prefix over lanes 0..lane-1 applied to D(1) = -inf
+      if (lane == 0) din = -INFINITY;
+#pragma unroll
+      for (int c = 0; c < C; c++) {
+        const int node = lane * C + c + 1;
+        if (node <= M) {
+          cuD[c] = din;
+          xE = fmaxf(xE, din);
+          din = fmaxf(allow(tr[c][MD], cuM[c]), allow(tr[c][DD], din));
+          frow[(size_t)node * 3 + cM] = cuM[c]; frow[(size_t)node * 3 + cD] = cuD[c]; frow[(size_t)node * 3 + cI] = cuI[c];
+        } else cuD[c] = -INFINITY;
+        pvM[c] = cuM[c]; pvI[c] = cuI[c]; pvD[c] = cuD[c];
+      }
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) xE = fmaxf(xE, __shfl_xor(xE, d, 64));
+      oxJ = fmaxf(oxJ + pxJ, 0.0f);
+      oxC = fmaxf(oxC + pxC, xE);
+      oxN = oxN + pxN;
+      oxB = fmaxf(oxN, oxJ);
+      if (lane == 0) {
+        frow[0] = frow[1] = frow[2] = -INFINITY;
+        float *px = PX + (size_t)i * 5, *ox = OX + (size_t)i * 5;
+        px[XE] = 0.f; px[XN] = pxN; px[XJ] = pxJ; px[XB] = 0.f; px[XC] = pxC;
+        ox[XE] = xE; ox[XN] = oxN; ox[XJ] = oxJ; ox[XB] = oxB; ox[XC] = oxC;
+      }
+    }
+    StdEnvOut r{-1, -1, -1, -1, 0, 0.f, 0.f, 0, 0};
+    if (!isinf(scaleproduct)) {                                             // else eslERANGE: the domain is dropped
+      // p7_Null2_ByExpectation and the correction over the envelope
+      const float norm = (float)(1.0 / (double)(float)L);
+#pragma unroll
+      for (int c = 0; c < C; c++) { emM[c] *= norm; emI[c] *= norm; }
+      const float xfactor = sN * norm + sC * norm + sJ * norm;
+      float null2[kKp];
+      for (int x = 0; x < 20; x++) {
+        const float *e = rf + (size_t)x * (M + 1);
+        float sv = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; c++) { const int node = lane * C + c + 1; if (node <= M) { sv += emM[c] * e[node]; sv += emI[c]; } }
+        null2[x] = wave_sum_f32(sv) + xfactor;
+      }
+      const int mem[6][2] = {{2, 11}, {7, 9}, {3, 13}, {8, 8}, {1, 1}, {-1, -1}};      // B=DN J=IL Z=EQ O=K U=C X=any
+      for (int dx = 0; dx < 6; dx++) {
+        float sum = 0.f; int cnt = 0;
+        if (dx == 5) { for (int y = 0; y < 20; y++) { sum += null2[y]; cnt++; } }
+        else { const int a = min(mem[dx][0], mem[dx][1]), b = max(mem[dx][0], mem[dx][1]); sum += null2[a]; cnt++; if (b != a) { sum += null2[b]; cnt++; } }
+        null2[21 + dx] = sum / (float)cnt;
+      }
+      null2[20] = 1.0f; null2[27] = 1.0f; null2[28] = 1.0f;
+      float corr = 0.f;
+      for (int pos = 1 + lane; pos <= L; pos += 64) {
+        const int x = min((int)dsq[pos], kKp - 1);
+        float v = null2[0];
+#pragma unroll
+        for (int q = 1; q < kKp; q++) v = (x == q) ? null2[q] : v;          // registers cannot be indexed: select
+        corr += logf(v);
+      }
+      r.domcorrection = wave_sum_f32(corr);
+      r.oasc = oxC;
+      r.ok = 1;
+    }
+    if (lane == 0) out[t] = r;
+  }
 }
 
 }  // namespace
@@ -589,18 +778,26 @@ static int std_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bat
       BATH_HIP_TRY(ctx, hipMemcpyAsync(h_res.data() + roff[(size_t)e], d_pool + mv.h_off[(size_t)e], (size_t)mv.h_len[(size_t)e], hipMemcpyDeviceToHost, ctx->stream));
     BATH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     mv.d_data = nullptr; mv.d_off = nullptr; mv.d_len = nullptr;
-    std::vector<float> n2sc;
-    std::vector<std::pair<int, int>> cl;
-    for (int64_t e = 0; e < nm; e++) {
-      const Env &en = mregs[(size_t)e];
-      const int Lr = en.j - en.i + 1;
-      if (region_trace_ensemble(om, cfg[(size_t)e], h_res.data() + roff[(size_t)e], Lr, h_dp.data() + mdpoff[(size_t)e], h_x.data() + mxoff[(size_t)e], &n2sc, &cl) != BATH_OK) continue;
-      for (const auto &c : cl) {
-        float corr = 0.f;
-        for (int pos = c.first; pos <= c.second; pos++) corr += n2sc[(size_t)pos];       // null2_is_done: p7_domaindef.c:1270-1272
-        envs.push_back(Env{en.s, en.i + c.first - 1, en.i + c.second - 1, true, corr});
+    // the regions are independent (each ensemble starts from the seed): host threads take them round-robin, results are
+    // appended in region order
+    if (om->ensure_len_tables(*std::max_element(cfg.begin(), cfg.end())) != BATH_OK) return BATH_EFAIL;
+    std::vector<std::vector<Env>> found((size_t)nm);
+    auto work = [&](int64_t first, int64_t step) {
+      std::vector<float> n2sc;
+      std::vector<std::pair<int, int>> cl;
+      for (int64_t e = first; e < nm; e += step) {
+        const Env &en = mregs[(size_t)e];
+        const int Lr = en.j - en.i + 1;
+        if (region_trace_ensemble(om, cfg[(size_t)e], h_res.data() + roff[(size_t)e], Lr, h_dp.data() + mdpoff[(size_t)e], h_x.data() + mxoff[(size_t)e], &n2sc, &cl) != BATH_OK) continue;
+        for (const auto &c : cl) {
+          float corr = 0.f;
+          for (int pos = c.first; pos <= c.second; pos++) corr += n2sc[(size_t)pos];     // null2_is_done: p7_domaindef.c:1270-1272
+          found[(size_t)e].push_back(Env{en.s, en.i + c.first - 1, en.i + c.second - 1, true, corr});
+        }
       }
-    }
+    };
+    run_striped(nm, work);
+    for (int64_t e = 0; e < nm; e++) envs.insert(envs.end(), found[(size_t)e].begin(), found[(size_t)e].end());
   }
   const int64_t ne = (int64_t)envs.size();
   if (ne == 0) return BATH_OK;
@@ -633,9 +830,25 @@ static int std_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bat
   BATH_HIP_TRY(ctx, hipMemcpyAsync(b_dpo.p, dpoff.data(), (size_t)(ne + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
   if ((st = launch_fwd_wave(ctx, om, ev.view(), nullptr, ne, b_sc.as<float>(), b_st.as<int32_t>(), nullptr, b_fx.as<float>(), d_exoff, b_f.as<float>(), b_dpo.as<int64_t>(), 1)) != BATH_OK) return st;
   if ((st = launch_bwd_wave(ctx, om, ev.view(), ne, b_fx.as<float>(), d_exoff, b_sc.as<float>() + ne, b_st.as<int32_t>() + ne, b_bx.as<float>(), b_b.as<float>(), b_dpo.as<int64_t>(), 1)) != BATH_OK) return st;
+  // decoding + OA fill + null2: a wave per envelope; then the traceback, a lane per envelope.  BATH_HIP_STD_SERIAL=1 (tests) or a
+  // model longer than 1024 nodes: everything in the lane-per-envelope kernel.
+  int filled = 0;
+  {
+    const char *e = std::getenv("BATH_HIP_STD_SERIAL");
+    const int c = (M + 63) / 64;
+    const unsigned grid = (unsigned)std::min<int64_t>((ne + 3) / 4, (int64_t)ctx->prop.multiProcessorCount * 8);
+#define BATH_FILL(CC) hipLaunchKernelGGL(std_envelope_fill_kernel<CC>, dim3(grid), dim3(256), 0, ctx->stream, ev.view(), M, om->d_tf, om->d_rf, b_f.as<float>(), b_b.as<float>(), \
+                                         b_dpo.as<int64_t>(), b_fx.as<float>(), b_bx.as<float>(), d_exoff, b_px.as<float>(), b_ox.as<float>(), b_out.as<StdEnvOut>()); filled = 1
+    if (!(e && e[0] == '1')) {
+      if (c <= 1) { BATH_FILL(1); } else if (c <= 2) { BATH_FILL(2); } else if (c <= 3) { BATH_FILL(3); } else if (c <= 4) { BATH_FILL(4); }
+      else if (c <= 6) { BATH_FILL(6); } else if (c <= 8) { BATH_FILL(8); } else if (c <= 12) { BATH_FILL(12); } else if (c <= 16) { BATH_FILL(16); }
+    }
+#undef BATH_FILL
+    BATH_HIP_TRY(ctx, hipGetLastError());
+  }
   hipLaunchKernelGGL(std_envelope_kernel, dim3((unsigned)((ne + 63) / 64)), dim3(64), 0, ctx->stream, ev.view(), M, om->d_tf, om->d_rf, b_f.as<float>(), b_b.as<float>(), b_dpo.as<int64_t>(),
                      b_fx.as<float>(), b_bx.as<float>(), d_exoff, b_px.as<float>(), b_ox.as<float>(), b_em.as<float>(), b_out.as<StdEnvOut>(),
-                     om->d_cons, b_tb.as<uint8_t>(), b_toff.as<int64_t>());
+                     om->d_cons, b_tb.as<uint8_t>(), b_toff.as<int64_t>(), filled);
   BATH_HIP_TRY(ctx, hipGetLastError());
   std::vector<StdEnvOut> eo((size_t)ne);
   std::vector<float> envsc((size_t)ne);

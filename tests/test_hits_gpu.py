@@ -157,3 +157,27 @@ def test_hits_of_an_empty_block(ctx):
     om5 = ba.FSOProfile(ctx, ba.FSProfile(hmm, 5, ncbi_table=hmm.ct))
     st, fw, dm, nskip = ba.Pipeline(ctx, om, fs_pipe=True, ncbi_table=hmm.ct).run_frameshift_domains(om3, om5, ba.SeqBlock(ctx, []))
     assert (st.nres, len(fw), len(dm), nskip) == (0, 0, 0, 0)
+
+
+def test_wave_and_lane_envelope_kernels_agree(ctx, monkeypatch):
+    """Decoding, optimal-accuracy fill and null2 of an envelope run with a wave per envelope (rows in registers, the D chain
+    a wavefront scan); the lane-per-envelope kernel does the same serially (BATH_HIP_STD_SERIAL=1).  Coordinates, oasc and
+    the envelope score must be identical (max / select arithmetic); the null2 correction differs only by the association of
+    one sum."""
+    path = ol.GOLDEN + "/MET-ct4.bhmm"                   # M = 409: 7 nodes per lane -> the 8-node instantiation
+    model = ol.Model(path, 0)
+    rng = np.random.default_rng(99)
+    wins = []
+    for i, aa in enumerate(common.emit_from_model(rng, model, 24, flank=4, sharpen=2.0)):
+        nt = np.array(common.revtranslate(rng, aa, model.basic), dtype=np.uint8)
+        w = np.concatenate([rng.integers(0, 4, size=60).astype(np.uint8), nt, rng.integers(0, 4, size=45).astype(np.uint8)])
+        wins.append((3 - w[::-1]).astype(np.uint8) if i % 2 else w)
+    out = []
+    for serial in ("0", "1"):
+        monkeypatch.setenv("BATH_HIP_STD_SERIAL", serial)
+        _, dm, nskip = gpu_hits(ctx, path, 0, wins)
+        out.append((nskip, sorted((d.window, d.ienv, d.jenv, d.iali, d.jali, d.ihmm, d.jhmm, d.envsc, d.oasc, d.ali_columns, d.pid, d.cigar, d.domcorrection) for d in dm)))
+    assert out[0][0] == out[1][0] and len(out[0][1]) == len(out[1][1]) >= 15
+    for a, b in zip(out[0][1], out[1][1]):
+        assert a[:12] == b[:12]
+        assert abs(a[12] - b[12]) <= 1e-4 * max(1.0, abs(b[12]))
