@@ -853,11 +853,13 @@ extern "C" int bath_hip_pipeline_filters(bath_hip_ctx *ctx, const bath_hip_oprof
   }
   if (stats) *stats = tot;
   if (results) {                                                   // parts are consecutive windows and each part's list is sorted
-    ctx->results.clear();
-    ctx->results.reserve((size_t)ntot);
+    ctx->results.resize((size_t)ntot);
+    int64_t at = 0;
     for (int k = 0; k < K; k++) {
-      const int64_t w0 = dna->parts[(size_t)k]->first_window;
-      for (int64_t i = 0; i < pn[(size_t)k]; i++) { bath_orf_result r = pres[(size_t)k][i]; r.window += w0; ctx->results.push_back(r); }
+      const int64_t w0 = dna->parts[(size_t)k]->first_window, nk = pn[(size_t)k];
+      if (nk > 0) std::memcpy(ctx->results.data() + at, pres[(size_t)k], (size_t)nk * sizeof(bath_orf_result));
+      for (int64_t i = 0; i < nk; i++) ctx->results[(size_t)(at + i)].window += w0;
+      at += nk;
     }
     *results = ctx->results.data();
   }
