@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void ssv_lane_kernel(SeqView sq, const int32_t
   const char *tile = lds + grank * (4 * NR);
 
   s16x2 reg[NR];
-  const s16x2 fl = {(short)kSsvBegin, (short)kSsvBegin};
+  const s16x2 fl = {0, 0};                                      // the begin score
 #pragma unroll
   for (int r = 0; r < NR; r++) reg[r] = fl;
   s16x2 xE = fl;

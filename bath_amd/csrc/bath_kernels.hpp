@@ -30,43 +30,53 @@ __device__ __forceinline__ int satu8(int v) { return min(max(v, 0), 255); }
 
 
 // ---- SSV: one DP row of the lane-per-target kernels ----------------------------------------------
-// Number system: the reference keeps each diagonal in signed bytes starting at -128 with saturating
-// subtraction (ssvfilter.c:130-141).  Here cells are int16 and the begin score is the int16 minimum,
-// so v_pk_sub_i16 with clamp IS "max(prev - cost, begin)": no separate floor operation.  A cell's value
-// relative to the begin score (v + 32768) equals the reference byte's distance from its begin score
-// as long as that distance is below 255 - bias - 128, beyond which the reference reports overflow anyway.
-constexpr int kSsvBegin = -32768;
-constexpr unsigned kSsvBeginPair = 0x80008000u;
+// Number system: the reference keeps each diagonal in bytes above a begin score with saturating subtraction
+// (ssvfilter.c:130-141).  Here a cell is a binary16 number d * 2^-11, d = the score's distance above the begin score
+// (d = 0: the begin score).  Every d in 0..2048 and every cost in -2047..2047 is exact in binary16 at that scale, sums
+// below 1.0 are exact, and v_pk_add_f16 with the clamp modifier clamps to [0, 1]: the lower clamp IS the reference's
+// "max(prev - cost, begin)", the upper one sits at d = 2048, far above where the reference reports overflow (d >= 127 - bias).
+// Why floating point for integer scores: gfx950 has a three-operand packed maximum (v_pk_maximum3_f16) and no integer
+// counterpart, so the running maximum costs one VALU op per FOUR cells instead of one per two:
+// 1.5 VALU ops per 2 cells (v_pk_add_f16 clamp per pair + half a v_pk_maximum3_f16).
+constexpr unsigned kSsvBeginPair = 0x00000000u;          // two cells at the begin score
 
-// One DP row for this lane: residue row <rowbase> (LDS byte address of the residue's cost row, already
+__device__ __forceinline__ s16x2 ssv_add(s16x2 a, int inc) {
+  s16x2 r;
+  asm("v_pk_add_f16 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(inc));
+  return r;
+}
+__device__ __forceinline__ s16x2 ssv_max3(s16x2 a, s16x2 b, s16x2 c) {
+  s16x2 r;
+  asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
+// One DP row for this lane: residue row <rowbase> (LDS byte address of the residue's increment row, already
 // offset to this lane's column tile).  Register r of a tile holds the tile's nodes r+1 (low half) and
 // NR+r+1 (high half), so "the previous row's value of the node to the left" is simply the previous
-// register: the diagonal shift is folded into the subtract's destination (registers are updated in
+// register: the diagonal shift is folded into the add's destination (registers are updated in
 // place, descending).  Only register 0 needs assembling: its low half takes the node left of the tile
 // (high half of <carry>: the begin score for the first tile, otherwise the last node of the neighbouring
 // lane's tile when a model is split over G lanes), its high half the old low half of register NR-1.
-// 2 VALU ops per 2 cells: v_pk_sub_i16 clamp, v_pk_max_i16.
 template <int NR>
 __device__ __forceinline__ void ssv_row(s16x2 (&reg)[NR], s16x2 &xE, const char *rowbase, unsigned carry) {
   static_assert(NR % 4 == 0, "registers are consumed four at a time (one 16-byte LDS read)");
   const s16x2 wrap = __builtin_bit_cast(s16x2, __builtin_amdgcn_alignbit(__builtin_bit_cast(unsigned, reg[NR - 1]), carry, 16));
 #pragma unroll
   for (int r = NR - 4; r >= 0; r -= 4) {
-    // costs of registers r .. r+3: one ds_read_b128 (rows are 16-byte aligned, pitch/16 odd).  Measured on MI355X:
+    // increments of registers r .. r+3: one ds_read_b128 (rows are 16-byte aligned, pitch/16 odd).  Measured on MI355X:
     // ds_read_b64 gathers (32 slots, conflict free) are slower here than ds_read_b128 with its 2-way conflicts.
     const int4 c = *reinterpret_cast<const int4 *>(rowbase + 4 * r);
-    s16x2 v = __builtin_elementwise_sub_sat(reg[r + 2], __builtin_bit_cast(s16x2, c.w));
-    xE = __builtin_elementwise_max(xE, v);
-    reg[r + 3] = v;
-    v = __builtin_elementwise_sub_sat(reg[r + 1], __builtin_bit_cast(s16x2, c.z));
-    xE = __builtin_elementwise_max(xE, v);
-    reg[r + 2] = v;
-    v = __builtin_elementwise_sub_sat(reg[r], __builtin_bit_cast(s16x2, c.y));
-    xE = __builtin_elementwise_max(xE, v);
-    reg[r + 1] = v;
-    v = __builtin_elementwise_sub_sat((r > 0) ? reg[r - 1] : wrap, __builtin_bit_cast(s16x2, c.x));
-    xE = __builtin_elementwise_max(xE, v);
-    reg[r] = v;
+    const s16x2 v3 = ssv_add(reg[r + 2], c.w);
+    const s16x2 v2 = ssv_add(reg[r + 1], c.z);
+    reg[r + 3] = v3;
+    reg[r + 2] = v2;
+    xE = ssv_max3(xE, v3, v2);
+    const s16x2 v1 = ssv_add(reg[r], c.y);
+    const s16x2 v0 = ssv_add((r > 0) ? reg[r - 1] : wrap, c.x);
+    reg[r + 1] = v1;
+    reg[r] = v0;
+    xE = ssv_max3(xE, v1, v0);
   }
 }
 
@@ -80,7 +90,9 @@ __device__ __forceinline__ unsigned ssv_carry(const s16x2 (&reg)[NR], int grank)
 // Maximum over the target's lanes, converted to the reference's signed-byte domain (begin score = -128).
 template <int G>
 __device__ __forceinline__ int ssv_group_max(s16x2 xE) {
-  int v = max((int)xE.x, (int)xE.y) - kSsvBegin - 128;
+  typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+  const h16x2 h = __builtin_bit_cast(h16x2, xE);
+  int v = (int)(fmaxf((float)h.x, (float)h.y) * 2048.0f) - 128;            // distance above the begin score, then begin = -128
 #pragma unroll
   for (int d = 1; d < G; d <<= 1) v = max(v, __shfl_xor(v, d, 64));
   return v;

@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void ssv_orf_kernel(const uint8_t *__restrict_
   const char *tile = lds + grank * (4 * NR);
   const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  const s16x2 fl = {(short)kSsvBegin, (short)kSsvBegin};
+  const s16x2 fl = {0, 0};                                      // the begin score
   for (int64_t tb = wave0 * TPW; tb < n_orfs; tb += nwaves * TPW) {
     const int64_t t = tb + lane / G;
     const bool live = t < n_orfs;

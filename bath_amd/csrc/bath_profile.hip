@@ -259,8 +259,8 @@ extern "C" int bath_hip_oprofile_convert(bath_hip_ctx *ctx, const bath_profile *
   }
 
   // ---- device layouts
-  // SSV: signed costs sb = min(rb - bias, 127) (sf_conversion) as int16, one row per residue plus a
-  // "reset" row; columns 1..M real, padded with +127 up to 2*NR*G.  Row pitch is an odd multiple of 16 bytes so
+  // SSV: signed costs sb = min(rb - bias, 127) (sf_conversion), stored as binary16 increments -sb * 2^-11, one row per
+  // residue plus a "reset" row; columns 1..M real, padded with -1.0 (a full reset) up to 2*NR*G.  Row pitch is an odd multiple of 16 bytes so
   // that lanes holding different residues spread over the 16 sixteen-byte LDS slots on ds_read_b128.
   int G = 1;
   while (G < 8 && M > 416 * G) G *= 2;                        // up to 208 registers (416 nodes) per lane
@@ -272,12 +272,15 @@ extern "C" int bath_hip_oprofile_convert(bath_hip_ctx *ctx, const bath_profile *
   om->ssv_row_bytes = 16 * ((NR * G / 4 + 1) | 1);            // 16-byte aligned rows, (pitch/16) odd
   {
     size_t rowsz = (size_t)om->ssv_row_bytes / 2;
-    std::vector<int16_t> tab((size_t)kSsvRows * rowsz, 32767);   // padding nodes and the reset row: cost +32767
+    // cells are binary16 numbers in units of 2^-11 (see ssv_row): the table holds the increments -cost * 2^-11, exact
+    auto half_bits = [](float v) { const _Float16 h = (_Float16)v; int16_t b; std::memcpy(&b, &h, 2); return b; };
+    std::vector<int16_t> tab((size_t)kSsvRows * rowsz, half_bits(-1.0f));   // padding nodes and the reset row: back to the begin score
     // node k -> lane tile g = (k-1)/(2NR); inside the tile, register r = (k-1)%NR, half (k-1)/NR%2 (see ssv_row)
     for (int x = 0; x < kKp; x++)
       for (int k = 1; k <= M; k++) {
         const int g = (k - 1) / (2 * NR), q = (k - 1) - g * 2 * NR;
-        tab[x * rowsz + (size_t)g * 2 * NR + 2 * (q % NR) + q / NR] = (int16_t)std::min((int)om->rb[x * W + k] - (int)om->bias_b, 127);
+        const int cost = std::min((int)om->rb[x * W + k] - (int)om->bias_b, 127);
+        tab[x * rowsz + (size_t)g * 2 * NR + 2 * (q % NR) + q / NR] = half_bits(-(float)cost / 2048.0f);
       }
     BATH_HIP_TRY(ctx, upload(&om->d_ssv, tab.data(), tab.size(), ctx->stream));
   }

@@ -200,10 +200,11 @@ def main():
                          "note": "integer DP held in VGPRs: compulsory HBM traffic is 1 B per ORF residue, the kernel is VALU-issue bound (see DESIGN.md); "
                                  "cell rate of this kernel = %.2f Tcells/s per launch while %d parts of the block overlap on separate streams"
                                  % (stats.cells_msv / lanes / (k_ms * 1e-3) / 1e12, lanes), "launches_per_step": lanes,
-                         # the bound that does apply, for the reader: one packed-int16 VALU op per cell, 1024 SIMDs x 64 lanes x 2 cells
-                         # per op every 4 cycles at 2.4 GHz = 39.3 Tcells/s for the chip; concurrent parts share it
-                         "valu": {"tcells_per_s_per_launch": stats.cells_msv / lanes / (k_ms * 1e-3) / 1e12, "peak_tcells_per_s": 39.3,
-                                  "frac_per_launch": stats.cells_msv / lanes / (k_ms * 1e-3) / 1e12 / 39.3, "concurrent_launches": lanes}},
+                         # the bound that does apply, for the reader: 1.5 packed VALU ops per 2 cells (v_pk_add_f16 clamp + half a
+                         # v_pk_maximum3_f16), 1024 SIMDs x 64 lanes, one op per 4 cycles at 2.4 GHz = 52.4 Tcells/s for the chip
+                         # (DESIGN.md 4.1); concurrent parts share it
+                         "valu": {"tcells_per_s_per_launch": stats.cells_msv / lanes / (k_ms * 1e-3) / 1e12, "peak_tcells_per_s": 52.4,
+                                  "frac_per_launch": stats.cells_msv / lanes / (k_ms * 1e-3) / 1e12 / 52.4, "concurrent_launches": lanes}},
         }
         if not args.no_cpu_baseline:
             base, _ = cpu_baseline(flat, args.length, args.windows)
