@@ -15,7 +15,8 @@ flat, offsets, planted = synth.dna_windows(1000000, 1000, seed=42, hmm=hmm)
 block = ba.SeqBlock(ctx, flat, offsets)
 pipe = ba.Pipeline(ctx, om, fs_pipe=False, ncbi_table=hmm.ct)
 for lanes in (sys.argv[2],):
-    os.environ["BATH_HIP_LANES"] = lanes
+    os.environ["BATH_HIP_LANES"] = lanes.rstrip("c")
+    os.environ["BATH_HIP_LANE_CHAIN"] = "1" if lanes.endswith("c") else "0"
     ts = []
     for i in range(13):
         t0 = time.perf_counter(); pipe.run(block, want_results=False); ts.append((time.perf_counter() - t0) * 1e3)
@@ -24,8 +25,9 @@ for lanes in (sys.argv[2],):
     print("%%s lanes %%s: mean %%.2f min %%.2f max %%.2f  (ssv kernel %%.2f ms)" %% (os.path.basename(sys.argv[1]), lanes, np.mean(ts), min(ts), max(ts), ssv[0] if ssv else -1), flush=True)
 os._exit(0)
 ''' % (ROOT, ROOT)
-libs = sys.argv[1:3]
-for r in range(int(sys.argv[3]) if len(sys.argv) > 3 else 3):
+libs = [a for a in sys.argv[1:] if a.endswith(".so")]
+rounds = [int(a) for a in sys.argv[1:] if a.isdigit()]
+for r in range(rounds[0] if rounds else 3):
     for lanes in ("2", "1"):
         for lib in libs:
             subprocess.run([sys.executable, "-c", CHILD, os.path.abspath(lib), lanes], check=False)
