@@ -197,7 +197,7 @@ def main():
             "hits_gathered": int(len(hits)) if hits is not None else 0,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": "ssv_orf_kernel", "kernel_ms": k_ms,
-                         "note": "integer DP held in VGPRs: compulsory HBM traffic is 1 B per ORF residue, the kernel is VALU-issue bound (see DESIGN.md); "
+                         "note": "DP rows held in VGPRs (integer scores as binary16): compulsory HBM traffic is 1 B per ORF residue, the kernel is bound by VALU issue and the LDS gather (see DESIGN.md 4.1); "
                                  "cell rate of this kernel = %.2f Tcells/s per launch while %d parts of the block overlap on separate streams"
                                  % (stats.cells_msv / lanes / (k_ms * 1e-3) / 1e12, lanes), "launches_per_step": lanes,
                          # the bound that does apply, for the reader: 1.5 packed VALU ops per 2 cells (v_pk_add_f16 clamp + half a
