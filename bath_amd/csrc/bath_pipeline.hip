@@ -828,6 +828,19 @@ extern "C" int bath_hip_pipeline_filters(bath_hip_ctx *ctx, const bath_hip_oprof
   while ((int)ctx->lanes.size() < K) {
     bath_hip_ctx *lane = nullptr;
     if ((st = bath_hip_init(ctx->device, &lane)) != BATH_OK) { ctx->set_error("cannot create a pipeline lane"); return st; }
+    // Descending stream priorities: when two parts have work ready, the earlier part's workgroups are dispatched first.  Left to
+    // the hardware queues the interleaving of the parts is a race and about every third process lands on a schedule that is
+    // 20% slower (13.4 vs 16 ms per step on the bench block); with priorities it is 13.2-13.9 ms every time (tools/ab_probe.py).
+    // BATH_HIP_LANE_PRIO=0 turns it off.
+    const char *pe = std::getenv("BATH_HIP_LANE_PRIO");
+    if (!(pe && pe[0] == '0')) {
+      int lo = 0, hi = 0;
+      if (hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi) {
+        (void)hipStreamDestroy(lane->stream);
+        const int prio = ctx->lanes.empty() ? hi : lo;           // hi is numerically the smallest value = highest priority
+        if (hipStreamCreateWithPriority(&lane->stream, hipStreamNonBlocking, prio) != hipSuccess) { ctx->set_error("hipStreamCreateWithPriority"); return BATH_EFAIL; }
+      }
+    }
     ctx->lanes.push_back(lane);
   }
   if ((st = ensure_parts(ctx, dna, K)) != BATH_OK) return st;

@@ -16,7 +16,7 @@ block = ba.SeqBlock(ctx, flat, offsets)
 pipe = ba.Pipeline(ctx, om, fs_pipe=False, ncbi_table=hmm.ct)
 for lanes in (sys.argv[2],):
     os.environ["BATH_HIP_LANES"] = lanes.rstrip("c")
-    os.environ["BATH_HIP_LANE_CHAIN"] = "1" if lanes.endswith("c") else "0"
+    os.environ["BATH_HIP_LANE_PRIO"] = "0" if lanes.endswith("c") else "1"      # "2c": two parts without stream priorities
     ts = []
     for i in range(13):
         t0 = time.perf_counter(); pipe.run(block, want_results=False); ts.append((time.perf_counter() - t0) * 1e3)
