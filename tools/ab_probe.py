@@ -28,6 +28,6 @@ os._exit(0)
 libs = [a for a in sys.argv[1:] if a.endswith(".so")]
 rounds = [int(a) for a in sys.argv[1:] if a.isdigit()]
 for r in range(rounds[0] if rounds else 3):
-    for lanes in ("2", "1"):
+    for lanes in (os.environ.get("AB_LANES", "2,1").split(",")):
         for lib in libs:
             subprocess.run([sys.executable, "-c", CHILD, os.path.abspath(lib), lanes], check=False)
