@@ -44,6 +44,23 @@ struct DevBuf {
   template <class T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 
+// A growable pinned host buffer (D2H copies of matrices the host walks: page-locked memory copies at PCIe speed).
+struct HostBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  hipError_t reserve(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) (void)hipHostFree(p);
+    p = nullptr; cap = 0;
+    size_t want = bytes + bytes / 4 + 256;
+    hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+  template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
 struct StageTiming { const char *name; float ms; int64_t launches; };
 
 // An ORF that passed the Forward filter, as the domain-definition stage needs it (bath_domaindef.hip)
@@ -68,6 +85,7 @@ struct bath_hip_ctx {
   void set_error(const std::string &m) { err = m; }
   // scratch owned by the context (reused across calls)
   bath::DevBuf scratch[32];
+  bath::HostBuf pinned[2];
   std::vector<bath_orf_result> results;
   std::vector<bath_orf> orfs;             // bath_hip_translate_orfs output
   std::vector<bath_fs_window> fs_windows; // bath_hip_pipeline_frameshift output

@@ -21,6 +21,7 @@
 // the configuration bathsearch starts with (L = 100 residues, multihit; bathsearch.c:797).
 #include <algorithm>
 #include <cfloat>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -89,6 +90,17 @@ std::string cigar_from_columns(const uint16_t *S, int n) {
 static int std_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bath_hip_seqs *dna, const std::vector<PipelineSurvivor> &surv,
                        const uint8_t *d_pool, int64_t nres, double E_report, int64_t *n_skipped_regions);
 
+struct StageClock {                         // BATH_HIP_TIMING=1: wall time of the host-visible stages, to stderr
+  bool on; std::chrono::steady_clock::time_point t;
+  StageClock() { const char *e = std::getenv("BATH_HIP_TIMING"); on = e && e[0] == '1'; t = std::chrono::steady_clock::now(); }
+  void lap(const char *what) {
+    if (!on) return;
+    const auto n = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[bath timing] %-34s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count());
+    t = n;
+  }
+};
+
 static int fs_branch_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bath_hip_fsprofile *om_fs3,
                              const bath_hip_fsprofile *om_fs5, const bath_hip_seqs *dna, const bath_pipeline_params *prm,
                              double E_report, bath_pipeline_stats *stats,
@@ -103,8 +115,10 @@ static int fs_branch_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, con
   bath_pipeline_stats st_local{};
   const bath_fs_window *fw = nullptr;
   int64_t nfw = 0;
+  StageClock clk;
   int st = bath_hip_pipeline_frameshift(ctx, om, om_fs3, dna, prm, &st_local, nullptr, nullptr, &fw, &nfw);
   if (st != BATH_OK) return st;
+  clk.lap("fs: cascade + windows + decision");
   if (stats) *stats = st_local;
   if (fs_windows) *fs_windows = fw;
   if (n_fs_windows) *n_fs_windows = nfw;
@@ -135,6 +149,7 @@ static int fs_branch_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, con
     view.d_data = nullptr; view.d_off = nullptr; view.d_len = nullptr;
     if (st != BATH_OK) return st;
   }
+  clk.lap("fs: parsers + regions");
   struct Env { int sel, i, j; };
   std::vector<Env> envs, mregs;
   for (int q = 0; q < nsel; q++) {
@@ -156,7 +171,8 @@ static int fs_branch_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, con
       d.start = regs[(size_t)mregs[e].sel].start + mregs[e].i - 1; d.len = mregs[e].j - mregs[e].i + 1;
       rregs[e] = d;
     }
-    std::vector<float> h_f, h_x, h_sc;
+    const float *h_f = nullptr, *h_x = nullptr;                              // pinned buffers of the context
+    std::vector<float> h_sc;
     std::vector<int64_t> foff, xoff;
     {
       bath_hip_seqs view;
@@ -165,6 +181,7 @@ static int fs_branch_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, con
       view.d_data = nullptr; view.d_off = nullptr; view.d_len = nullptr;
       if (st != BATH_OK) return st;
     }
+    clk.lap("fs: region Forward + copy to host");
     const float pm = (2.0f + 1.0f) / (100.0f + 2.0f + 1.0f);                 // p7_fs_ReconfigLength(L = 100), multihit (nj = 1)
     const float xNL = (float)std::log((double)(1.0f - pm)), xNM = (float)std::log((double)pm), xE = (float)-kLn2;
     std::vector<std::vector<Env>> found(mregs.size());
@@ -173,7 +190,7 @@ static int fs_branch_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, con
       for (size_t e = (size_t)first; e < mregs.size(); e += (size_t)step) {
         if (!(h_sc[e] > -INFINITY)) continue;                                 // Forward underflow: no valid traces for this region (:413)
         const int Lr = rregs[e].len;
-        if (fs_region_trace_ensemble(h5.M, h5.tsc, xNL, xNM, xE, mregs[e].i, Lr, h_f.data() + foff[e], h_x.data() + xoff[e], &cl) != BATH_OK) continue;
+        if (fs_region_trace_ensemble(h5.M, h5.tsc, xNL, xNM, xE, mregs[e].i, Lr, h_f + foff[e], h_x + xoff[e], &cl) != BATH_OK) continue;
         for (const auto &c : cl) {
           const int i2 = std::max(1, c.first), j2 = c.second;                 // :449
           if (j2 - i2 + 1 >= 15) found[e].push_back(Env{mregs[e].sel, i2, j2});
@@ -182,6 +199,7 @@ static int fs_branch_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, con
     };
     run_striped((int64_t)mregs.size(), work);
     for (size_t e = 0; e < mregs.size(); e++) envs.insert(envs.end(), found[e].begin(), found[e].end());
+    clk.lap("fs: ensembles (host threads)");
   }
   if (envs.empty()) return BATH_OK;
 
@@ -205,6 +223,7 @@ static int fs_branch_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, con
     view.d_data = nullptr; view.d_off = nullptr; view.d_len = nullptr;
     if (st != BATH_OK) return st;
   }
+  clk.lap("fs: envelope kernels + traces");
 
   // ---- traceback, null2 along the trace, the hit's scores
   const int ml = h5.max_length;
@@ -277,7 +296,9 @@ extern "C" int bath_hip_pipeline_frameshift_domains(bath_hip_ctx *ctx, const bat
   if (st != BATH_OK) return st;
   if (stats) *stats = st_local;
   int64_t nskip = n_skipped_regions ? *n_skipped_regions : 0;
+  StageClock clk;
   if ((st = std_domains(ctx, om, dna, ctx->fs_std_orfs, ctx->fs_std_pool, st_local.nres, E_report, &nskip)) != BATH_OK) return st;
+  clk.lap("fs: standard-branch domains");
   if (n_skipped_regions) *n_skipped_regions = nskip;
   *domains = ctx->fs_domains.data(); *n_domains = (int64_t)ctx->fs_domains.size();
   return BATH_OK;
@@ -767,13 +788,14 @@ static int std_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bat
     BATH_HIP_TRY(ctx, hipMemcpyAsync(b_cfg.p, cfg.data(), (size_t)nm * 4, hipMemcpyHostToDevice, ctx->stream));
     if ((st = launch_fwd_wave(ctx, om, mv.view(), nullptr, nm, b_sc.as<float>(), b_st.as<int32_t>(), nullptr, b_fx.as<float>(), b_idx.as<int64_t>() + nm,
                               b_mf.as<float>(), b_mdpo.as<int64_t>(), 0, b_cfg.as<int32_t>())) != BATH_OK) return st;
-    std::vector<float> h_dp((size_t)mdpoff[(size_t)nm]), h_x((size_t)mxoff[(size_t)nm]);
+    BATH_HIP_TRY(ctx, ctx->pinned[0].reserve((size_t)mdpoff[(size_t)nm] * 4 + 64)); BATH_HIP_TRY(ctx, ctx->pinned[1].reserve((size_t)mxoff[(size_t)nm] * 4 + 64));
+    float *h_dp = ctx->pinned[0].as<float>(), *h_x = ctx->pinned[1].as<float>();      // page-locked
     std::vector<uint8_t> h_res;
     std::vector<int64_t> roff((size_t)nm + 1, 0);
     for (int64_t e = 0; e < nm; e++) roff[(size_t)e + 1] = roff[(size_t)e] + mv.h_len[(size_t)e];
     h_res.resize((size_t)roff[(size_t)nm] + 1);
-    BATH_HIP_TRY(ctx, hipMemcpyAsync(h_dp.data(), b_mf.p, h_dp.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
-    BATH_HIP_TRY(ctx, hipMemcpyAsync(h_x.data(), b_fx.p, h_x.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+    BATH_HIP_TRY(ctx, hipMemcpyAsync(h_dp, b_mf.p, (size_t)mdpoff[(size_t)nm] * 4, hipMemcpyDeviceToHost, ctx->stream));
+    BATH_HIP_TRY(ctx, hipMemcpyAsync(h_x, b_fx.p, (size_t)mxoff[(size_t)nm] * 4, hipMemcpyDeviceToHost, ctx->stream));
     for (int64_t e = 0; e < nm; e++)
       BATH_HIP_TRY(ctx, hipMemcpyAsync(h_res.data() + roff[(size_t)e], d_pool + mv.h_off[(size_t)e], (size_t)mv.h_len[(size_t)e], hipMemcpyDeviceToHost, ctx->stream));
     BATH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -788,7 +810,7 @@ static int std_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bat
       for (int64_t e = first; e < nm; e += step) {
         const Env &en = mregs[(size_t)e];
         const int Lr = en.j - en.i + 1;
-        if (region_trace_ensemble(om, cfg[(size_t)e], h_res.data() + roff[(size_t)e], Lr, h_dp.data() + mdpoff[(size_t)e], h_x.data() + mxoff[(size_t)e], &n2sc, &cl) != BATH_OK) continue;
+        if (region_trace_ensemble(om, cfg[(size_t)e], h_res.data() + roff[(size_t)e], Lr, h_dp + mdpoff[(size_t)e], h_x + mxoff[(size_t)e], &n2sc, &cl) != BATH_OK) continue;
         for (const auto &c : cl) {
           float corr = 0.f;
           for (int pos = c.first; pos <= c.second; pos++) corr += n2sc[(size_t)pos];     // null2_is_done: p7_domaindef.c:1270-1272

@@ -134,11 +134,28 @@ __global__ __launch_bounds__(256) void fs3_fwd_kernel(SeqView dna, FsDev p, cons
     int u = 338, v = 338, w = 338, x = (d[0] < 4) ? d[0] : 338;       // p7P_MAXCODONS3 marks a degenerate nucleotide
     float cL = -INFINITY, cL1 = -INFINITY, cL2 = -INFINITY;           // C(L), C(L-1), C(L-2) for the final score
 
+    // The emission scores of a row depend on the nucleotides only, not on the DP state: they are fetched one row ahead, so
+    // that their trip to L2 (the table has 0.2-1.5 MB) overlaps the previous row's log-sum chains instead of heading the
+    // row's dependency chain.
+    float e2n[C], e3n[C], e4n[C];
+    auto fetch = [&](int xx, int ww, int vv, int uu) {
+      const float *q2 = p.rsc + (size_t)imin(xx * 84 + ww * 21, 337) * p.pitch;
+      const float *q3 = p.rsc + (size_t)imin(xx * 84 + ww * 21 + vv * 5 + 1, 336) * p.pitch;
+      const float *q4 = p.rsc + (size_t)imin(xx * 84 + ww * 21 + vv * 5 + uu + 2, 337) * p.pitch;
+#pragma unroll
+      for (int c = 0; c < C; c++) {
+        const int node = lane * C + c + 1;
+        if (node <= M) { e2n[c] = q2[node]; e3n[c] = q3[node]; e4n[c] = q4[node]; } else { e2n[c] = e3n[c] = e4n[c] = -INFINITY; }
+      }
+    };
+    int xn = (d[1] < 4) ? d[1] : 338;                                  // nucleotide of row 2
+    fetch(xn, x, w, v);
     for (int i = 2; i <= L; i++) {
-      u = v; v = w; w = x; x = (d[i - 1] < 4) ? d[i - 1] : 338;
-      const float *r2 = p.rsc + (size_t)imin(x * 84 + w * 21, 337) * p.pitch;
-      const float *r3 = p.rsc + (size_t)imin(x * 84 + w * 21 + v * 5 + 1, 336) * p.pitch;
-      const float *r4 = p.rsc + (size_t)imin(x * 84 + w * 21 + v * 5 + u + 2, 337) * p.pitch;
+      u = v; v = w; w = x; x = xn;
+      float e2[C], e3[C], e4[C];
+#pragma unroll
+      for (int c = 0; c < C; c++) { e2[c] = e2n[c]; e3[c] = e3n[c]; e4[c] = e4n[c]; }
+      if (i < L) { xn = (d[i] < 4) ? d[i] : 338; fetch(xn, x, w, v); }
       // values of row i-2 at node-1 for the lane's first node
       float mIn = __shfl_up(Mr[1][C - 1], 1, 64), iIn = __shfl_up(Ir[1][C - 1], 1, 64), dIn = __shfl_up(Dr[1][C - 1], 1, 64);
       if (lane == 0) mIn = iIn = dIn = -INFINITY;
@@ -155,8 +172,8 @@ __global__ __launch_bounds__(256) void fs3_fwd_kernel(SeqView dna, FsDev p, cons
           if (i == 2) iv = xB[1] + ta.w;                                           // row 2: IVX3(2,k) = B(0) + tBM (:503)
           else iv = LS(m1 + ta.x, LS(i1 + ta.y, LS(d1 + ta.z, xB[1] + ta.w)));     // from row i-2, B(i-2)
           ivc[c] = iv;
-          float mv = iv + r2[node];
-          if (i > 2) { mv = LS(mv, iv1[c] + r3[node]); mv = LS(mv, iv2[c] + r4[node]); }
+          float mv = iv + e2[c];
+          if (i > 2) { mv = LS(mv, iv1[c] + e3[c]); mv = LS(mv, iv2[c] + e4[c]); }
           Mc[c] = mv;
           Ic[c] = (i > 2 && node < M) ? LS(Mr[2][c] + tb.z, Ir[2][c] + tb.w) : -INFINITY;
           md[c] = mv + tb.x; dd[c] = tb.y;
@@ -1183,6 +1200,24 @@ namespace bath {
 // Both 3-codon parsers and the regions of every window of <dna>; regions_out[i] = {count (or -1: Backward underflow),
 // then count x {i, j, multidomain}}, 1 + 3*fs_max_regions() ints per window.
 int fs_max_regions() { return kMaxRegions; }
+// Forward and Backward of a batch are independent and, with few windows, each is bound by the latency of its longest window's
+// row chain: run Backward on the context's side stream while Forward runs on the main one.
+static int fs_fork(bath_hip_ctx *ctx) {
+  if (!ctx->side_stream) {
+    BATH_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
+    BATH_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+    BATH_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+  }
+  BATH_HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+  BATH_HIP_TRY(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->ev_fork, 0));
+  return BATH_OK;
+}
+static int fs_join(bath_hip_ctx *ctx) {
+  BATH_HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->side_stream));
+  BATH_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+  return BATH_OK;
+}
+
 int fs3_regions(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, const bath_hip_seqs *dna, float loop, int32_t *regions_out) {
   if (!ctx || !om || !dna || om->codon_lengths != 3) { if (ctx) ctx->set_error("fs3 parser needs a 3-codon profile"); return BATH_EINVAL; }
   BATH_HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1204,12 +1239,15 @@ int fs3_regions(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, const bath_hip_
   const size_t shmem = (size_t)(kLogsumTbl + (om->M + 2) * 8) * sizeof(float);
   const float tE = (float)-0.69314718055994529;
   const int grid = fs_grid(ctx, n);
+  BATH_HIP_TRY(ctx, b_sc.reserve((size_t)n * 2 * sizeof(float)));
+  if ((st = fs_fork(ctx)) != BATH_OK) return st;
   BATH_FS_SWITCH(Cv, {
     if ((st = fs_set_shmem(ctx, fs3_fwd_kernel<CC, false>, shmem)) != BATH_OK) return st;
     hipLaunchKernelGGL((fs3_fwd_kernel<CC, false>), dim3(grid), dim3(256), shmem, ctx->stream, dna->view(), fsdev(om), om->d_loop[0], om->d_move[0], tE, tE, b_sc.as<float>(), b_fx.as<float>(), b_off.as<int64_t>());
     if ((st = fs_set_shmem(ctx, fs_bwd_kernel<CC, 3, false>, shmem)) != BATH_OK) return st;
-    hipLaunchKernelGGL((fs_bwd_kernel<CC, 3, false>), dim3(grid), dim3(256), shmem, ctx->stream, dna->view(), fsdev(om), om->d_loop[0], om->d_move[0], tE, tE, b_sc.as<float>(), (float *)nullptr, (const int64_t *)nullptr, b_bx.as<float>(), b_off.as<int64_t>());
+    hipLaunchKernelGGL((fs_bwd_kernel<CC, 3, false>), dim3(grid), dim3(256), shmem, ctx->side_stream, dna->view(), fsdev(om), om->d_loop[0], om->d_move[0], tE, tE, b_sc.as<float>() + n, (float *)nullptr, (const int64_t *)nullptr, b_bx.as<float>(), b_off.as<int64_t>());
   })
+  if ((st = fs_join(ctx)) != BATH_OK) return st;
   hipLaunchKernelGGL(fs_regions_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, n, dna->d_len, b_fx.as<float>(), b_bx.as<float>(), b_off.as<int64_t>(), om->d_logsum, loop,
                      b_work.as<float>(), b_reg.as<int32_t>());
   BATH_HIP_TRY(ctx, hipGetLastError());
@@ -1288,18 +1326,20 @@ int bath::fs5_envelopes_ex(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, cons
   const int grid = fs_grid(ctx, n);
   const bool exact = (logsum_mode == BATH_LOGSUM_EXACT);
   const float tEL = -INFINITY, tEM = 0.0f;                                      // unihit: p7_fs_ReconfigUnihit, modelconfig.c:868
+  if ((st = fs_fork(ctx)) != BATH_OK) return st;                                // Backward on the side stream, concurrently with Forward
   BATH_FS_SWITCH(Cv, {
     if (exact) {
       if ((st = fs_set_shmem(ctx, fs5_fwd_kernel<CC, true>, shmem)) != BATH_OK) return st;
       if ((st = fs_set_shmem(ctx, fs_bwd_kernel<CC, 5, true>, shmem)) != BATH_OK) return st;
       hipLaunchKernelGGL((fs5_fwd_kernel<CC, true>), dim3(grid), dim3(256), shmem, ctx->stream, dna->view(), fsdev(om), om->d_loop[1], om->d_move[1], tEL, tEM, c5_compat, d_fsc, b_f.as<float>(), d_foff, b_fx.as<float>(), d_xoff, -1);
-      hipLaunchKernelGGL((fs_bwd_kernel<CC, 5, true>), dim3(grid), dim3(256), shmem, ctx->stream, dna->view(), fsdev(om), om->d_loop[1], om->d_move[1], tEL, tEM, d_bsc, b_b.as<float>(), d_boff, b_bx.as<float>(), d_xoff);
+      hipLaunchKernelGGL((fs_bwd_kernel<CC, 5, true>), dim3(grid), dim3(256), shmem, ctx->side_stream, dna->view(), fsdev(om), om->d_loop[1], om->d_move[1], tEL, tEM, d_bsc, b_b.as<float>(), d_boff, b_bx.as<float>(), d_xoff);
     } else {
       if ((st = fs_set_shmem(ctx, fs5_fwd_kernel<CC, false>, shmem)) != BATH_OK) return st;
       if ((st = fs_set_shmem(ctx, fs_bwd_kernel<CC, 5, false>, shmem)) != BATH_OK) return st;
       hipLaunchKernelGGL((fs5_fwd_kernel<CC, false>), dim3(grid), dim3(256), shmem, ctx->stream, dna->view(), fsdev(om), om->d_loop[1], om->d_move[1], tEL, tEM, c5_compat, d_fsc, b_f.as<float>(), d_foff, b_fx.as<float>(), d_xoff, -1);
-      hipLaunchKernelGGL((fs_bwd_kernel<CC, 5, false>), dim3(grid), dim3(256), shmem, ctx->stream, dna->view(), fsdev(om), om->d_loop[1], om->d_move[1], tEL, tEM, d_bsc, b_b.as<float>(), d_boff, b_bx.as<float>(), d_xoff);
+      hipLaunchKernelGGL((fs_bwd_kernel<CC, 5, false>), dim3(grid), dim3(256), shmem, ctx->side_stream, dna->view(), fsdev(om), om->d_loop[1], om->d_move[1], tEL, tEM, d_bsc, b_b.as<float>(), d_boff, b_bx.as<float>(), d_xoff);
     }
+    if ((st = fs_join(ctx)) != BATH_OK) return st;
     BATH_HIP_TRY(ctx, hipMemsetAsync(b_cs.p, 0, (size_t)n * cs_stride * sizeof(float), ctx->stream));
     hipLaunchKernelGGL(fs5_decode_kernel, dim3(grid), dim3(256), 0, ctx->stream, dna->view(), M, om->d_loop[1], d_bsc, b_f.as<float>(), d_foff, b_fx.as<float>(), d_xoff,
                        b_b.as<float>(), d_boff, b_bx.as<float>(), b_cs.as<float>());
@@ -1351,7 +1391,7 @@ int bath::fs5_envelopes_ex(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, cons
 // saved length), matrices and special-state rows copied to the host for the stochastic-trace ensemble (bath_ensemble.hip).
 // fwd: (L+1) x (M+1) x {D, I, M_C0, M_C1..M_C5}; xmx: (L+1) x {E,N,J,B,C}.  sc[e] = -inf: no path (the region is dropped).
 int bath::fs5_region_forward(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, const bath_hip_seqs *dna, int cfg_len_amino,
-                             std::vector<float> *fwd, std::vector<int64_t> *fwd_off, std::vector<float> *xmx, std::vector<int64_t> *xmx_off, std::vector<float> *sc) {
+                             const float **fwd, std::vector<int64_t> *fwd_off, const float **xmx, std::vector<int64_t> *xmx_off, std::vector<float> *sc) {
   const int64_t n = dna->n;
   const int M = om->M;
   int st = om->ensure_len(std::max(dna->maxlen / 3 + 1, cfg_len_amino));
@@ -1378,9 +1418,11 @@ int bath::fs5_region_forward(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, co
                        b_f.as<float>(), d_foff, b_fx.as<float>(), d_xoff, cfg_len_amino);
   })
   BATH_HIP_TRY(ctx, hipGetLastError());
-  fwd->resize((size_t)foff[(size_t)n]); xmx->resize((size_t)xoff[(size_t)n]); sc->resize((size_t)n);
-  BATH_HIP_TRY(ctx, hipMemcpyAsync(fwd->data(), b_f.p, fwd->size() * 4, hipMemcpyDeviceToHost, ctx->stream));
-  BATH_HIP_TRY(ctx, hipMemcpyAsync(xmx->data(), b_fx.p, xmx->size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+  sc->resize((size_t)n);
+  BATH_HIP_TRY(ctx, ctx->pinned[0].reserve((size_t)foff[(size_t)n] * 4 + 64)); BATH_HIP_TRY(ctx, ctx->pinned[1].reserve((size_t)xoff[(size_t)n] * 4 + 64));
+  *fwd = ctx->pinned[0].as<float>(); *xmx = ctx->pinned[1].as<float>();      // page-locked: the matrices are a few MB per region
+  BATH_HIP_TRY(ctx, hipMemcpyAsync(ctx->pinned[0].p, b_f.p, (size_t)foff[(size_t)n] * 4, hipMemcpyDeviceToHost, ctx->stream));
+  BATH_HIP_TRY(ctx, hipMemcpyAsync(ctx->pinned[1].p, b_fx.p, (size_t)xoff[(size_t)n] * 4, hipMemcpyDeviceToHost, ctx->stream));
   BATH_HIP_TRY(ctx, hipMemcpyAsync(sc->data(), b_sc.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
   BATH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return BATH_OK;

@@ -128,6 +128,7 @@ extern "C" void bath_hip_finalize(bath_hip_ctx *ctx) {
   for (bath_hip_ctx *lane : ctx->lanes) bath_hip_finalize(lane);
   ctx->lanes.clear();
   for (auto &b : ctx->scratch) b.release();
+  for (auto &b : ctx->pinned) b.release();
   for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
