@@ -206,7 +206,7 @@ def main():
                          "valu": {"tcells_per_s_per_launch": stats.cells_msv / lanes / (k_ms * 1e-3) / 1e12, "peak_tcells_per_s": 52.4,
                                   "frac_per_launch": stats.cells_msv / lanes / (k_ms * 1e-3) / 1e12 / 52.4, "concurrent_launches": lanes}},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:           # the CPU baseline is measured on rank 0 of the 1-GPU run only
             base, _ = cpu_baseline(flat, args.length, args.windows)
             out["cpu_baseline"] = base
         print(json.dumps(out))
