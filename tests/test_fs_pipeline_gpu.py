@@ -224,3 +224,22 @@ def test_domains_of_planted_frameshifted_genes(gpu_ctx, name):
     assert n >= 3 and any(d.n_shifted_codons > 0 for d in dm) and any(d.strand == 1 for d in dm)
     # both branches of p7_pli_Frameshift produce hits: codon-model domains and standard domains on window coordinates
     assert any(fw[d.fs_window].branch == 1 for d in dm) and any(fw[d.fs_window].branch == 2 for d in dm)
+
+
+def test_frameshift_path_with_a_long_model(gpu_ctx, tmp_path):
+    """A 700-node synthetic model (11 nodes per lane in the frameshift kernels -> the 12-node instantiation, 5.7 MB of
+    5-codon emissions): the whole --fs path to hits against the oracle."""
+    path = common.write_synthetic_bhmm(str(tmp_path / "s700.bhmm"), 700, seed=700)
+    model = ol.Model(path, 0)
+    rng = np.random.default_rng(12)
+    wins = frameshifted_windows(rng, model, n=8, L_flank=60)[:10] + common.random_dna(rng, 4, 1200)
+    hmm = ba.HMM(path, 0)
+    om = ba.OProfile(gpu_ctx, ba.Profile(hmm))
+    om3 = ba.FSOProfile(gpu_ctx, ba.FSProfile(hmm, 3, ncbi_table=hmm.ct))
+    om5 = ba.FSOProfile(gpu_ctx, ba.FSProfile(hmm, 5, ncbi_table=hmm.ct))
+    pipe = ba.Pipeline(gpu_ctx, om, fs_pipe=True, ncbi_table=hmm.ct)
+    stats, fw, dm, nskip = pipe.run_frameshift_domains(om3, om5, ba.SeqBlock(gpu_ctx, wins))
+    _, ofw, per_w, odm, per_d, oskip = model.run_pipeline_fsdom(wins)
+    assert sorted((w.window, w.strand, w.n, w.length) for w in fw) == sorted((i, o.strand, o.n, o.length) for i, (a, b) in enumerate(per_w) for o in ofw[a:b])
+    assert nskip == oskip
+    assert compare_domains(model, dm, odm, per_d, nskip) >= 3

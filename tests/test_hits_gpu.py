@@ -181,3 +181,20 @@ def test_wave_and_lane_envelope_kernels_agree(ctx, monkeypatch):
     for a, b in zip(out[0][1], out[1][1]):
         assert a[:12] == b[:12]
         assert abs(a[12] - b[12]) <= 1e-4 * max(1.0, abs(b[12]))
+
+
+def test_hits_with_a_1024_node_model(ctx, tmp_path):
+    """BASELINE config 5 shape: 16 nodes per lane in the wave-per-envelope kernels, 4 lanes per ORF in SSV."""
+    path = common.write_synthetic_bhmm(str(tmp_path / "s1024.bhmm"), 1024, seed=1024)
+    model = ol.Model(path, 0)
+    rng = np.random.default_rng(4)
+    wins = []
+    for i, aa in enumerate(common.emit_from_model(rng, model, 6, flank=3, sharpen=2.0)):
+        nt = np.array(common.revtranslate(rng, aa, model.basic), dtype=np.uint8)
+        w = np.concatenate([rng.integers(0, 4, size=45).astype(np.uint8), nt, rng.integers(0, 4, size=30).astype(np.uint8)])
+        wins.append((3 - w[::-1]).astype(np.uint8) if i % 2 else w)
+    wins += common.random_dna(rng, 6, 1500)
+    stats, dm, nskip = gpu_hits(ctx, path, 0, wins)
+    pli, odm, per_d, onskip = model.run_pipeline_hits(wins)
+    assert (stats.n_past_fwd, stats.pos_past_fwd) == (pli.n_past_fwd, pli.pos_past_fwd)
+    assert compare_hits(dm, odm, per_d, nskip, onskip) >= 4
