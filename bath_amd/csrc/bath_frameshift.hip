@@ -50,6 +50,9 @@ struct bath_hip_fsprofile {
 namespace bath {
 
 constexpr int kLogsumTbl = 16000;
+// threads per block of the DP kernels that hold p7_FLogsum's 64 KB table in LDS: 8 waves share one copy, so two blocks = 16 waves
+// fit a CU (4 per SIMD); with 4 waves per block the table limited a CU to 8 waves, and these kernels live on latency hiding
+constexpr int kFsBlock = 512;
 
 struct FsDev {
   int M, pitch, maxcodons;
@@ -101,7 +104,7 @@ __device__ __forceinline__ void d_chain_fwd(const float (&md)[C], const float (&
 // tf[node] = {tMM(k-1), tIM(k-1), tDM(k-1), tBM(k-1), tMD(k), tDD(k), tMI(k), tII(k)}
 // ---------------------------------------------------------------------------------------------
 template <int C, bool EXACT>
-__global__ __launch_bounds__(256) void fs3_fwd_kernel(SeqView dna, FsDev p, const float *__restrict__ loop_tab, const float *__restrict__ move_tab,
+__global__ __launch_bounds__(kFsBlock) void fs3_fwd_kernel(SeqView dna, FsDev p, const float *__restrict__ loop_tab, const float *__restrict__ move_tab,
                                                       float tEL, float tEM, float *__restrict__ sc, float *__restrict__ xmx, const int64_t *__restrict__ xmx_off) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   float *s_tbl = reinterpret_cast<float *>(lds);
@@ -131,7 +134,7 @@ __global__ __launch_bounds__(256) void fs3_fwd_kernel(SeqView dna, FsDev p, cons
     // specials of rows i-1, i-2, i-3
     float xN[3] = {0.f, 0.f, 0.f}, xJ[3] = {-INFINITY, -INFINITY, -INFINITY}, xC[3] = {-INFINITY, -INFINITY, -INFINITY}, xB[3] = {tNM, tNM, tNM};
     if (xo && lane == 0) for (int i = 0; i < 2; i++) { xo[i * 5 + 0] = -INFINITY; xo[i * 5 + 1] = 0.f; xo[i * 5 + 2] = -INFINITY; xo[i * 5 + 3] = tNM; xo[i * 5 + 4] = -INFINITY; }
-    int u = 338, v = 338, w = 338, x = (d[0] < 4) ? d[0] : 338;       // p7P_MAXCODONS3 marks a degenerate nucleotide
+    int v = 338, w = 338, x = (d[0] < 4) ? d[0] : 338;                // p7P_MAXCODONS3 marks a degenerate nucleotide
     float cL = -INFINITY, cL1 = -INFINITY, cL2 = -INFINITY;           // C(L), C(L-1), C(L-2) for the final score
 
     // The emission scores of a row depend on the nucleotides only, not on the DP state: they are fetched one row ahead, so
@@ -151,7 +154,7 @@ __global__ __launch_bounds__(256) void fs3_fwd_kernel(SeqView dna, FsDev p, cons
     int xn = (d[1] < 4) ? d[1] : 338;                                  // nucleotide of row 2
     fetch(xn, x, w, v);
     for (int i = 2; i <= L; i++) {
-      u = v; v = w; w = x; x = xn;
+      v = w; w = x; x = xn;
       float e2[C], e3[C], e4[C];
 #pragma unroll
       for (int c = 0; c < C; c++) { e2[c] = e2n[c]; e3[c] = e3n[c]; e4[c] = e4n[c]; }
@@ -217,7 +220,7 @@ __global__ __launch_bounds__(256) void fs3_fwd_kernel(SeqView dna, FsDev p, cons
 // c5_compat selects the ring slot the generic reference reads for 5-nt codons.
 // ---------------------------------------------------------------------------------------------
 template <int C, bool EXACT>
-__global__ __launch_bounds__(256) void fs5_fwd_kernel(SeqView dna, FsDev p, const float *__restrict__ loop_tab, const float *__restrict__ move_tab,
+__global__ __launch_bounds__(kFsBlock) void fs5_fwd_kernel(SeqView dna, FsDev p, const float *__restrict__ loop_tab, const float *__restrict__ move_tab,
                                                       float tEL, float tEM, int c5_compat, float *__restrict__ sc,
                                                       float *__restrict__ fwd, const int64_t *__restrict__ fwd_off, float *__restrict__ xmx, const int64_t *__restrict__ xmx_off,
                                                       int cfg_len /* >= 0: the amino length the model is configured for, instead of L/3 */) {
@@ -341,7 +344,7 @@ __global__ __launch_bounds__(256) void fs5_fwd_kernel(SeqView dna, FsDev p, cons
 // accumulate-left-to-right rows (L-3, L-4) and the main recursion (generic_fwdback_frameshift.c:1054-1323, 1442-1677).
 // ---------------------------------------------------------------------------------------------
 template <int C, int NCOD, bool EXACT>
-__global__ __launch_bounds__(256) void fs_bwd_kernel(SeqView dna, FsDev p, const float *__restrict__ loop_tab, const float *__restrict__ move_tab,
+__global__ __launch_bounds__(kFsBlock) void fs_bwd_kernel(SeqView dna, FsDev p, const float *__restrict__ loop_tab, const float *__restrict__ move_tab,
                                                      float tEL, float tEM, float *__restrict__ sc,
                                                      float *__restrict__ bck, const int64_t *__restrict__ bck_off, float *__restrict__ xmx, const int64_t *__restrict__ xmx_off) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -1060,6 +1063,10 @@ static FsDev fsdev(const bath_hip_fsprofile *om) { return FsDev{om->M, om->pitch
 static int fs_grid(bath_hip_ctx *ctx, int64_t n) {
   return (int)std::max<int64_t>(1, std::min<int64_t>((n + 3) / 4, (int64_t)ctx->prop.multiProcessorCount * 2));
 }
+static int fs_grid_dp(bath_hip_ctx *ctx, int64_t n) {           // blocks of kFsBlock threads, two per CU
+  const int wpb = kFsBlock / 64;
+  return (int)std::max<int64_t>(1, std::min<int64_t>((n + wpb - 1) / wpb, (int64_t)ctx->prop.multiProcessorCount * 2));
+}
 
 template <class K>
 static int fs_set_shmem(bath_hip_ctx *ctx, K kernel, size_t shmem) {
@@ -1095,20 +1102,21 @@ static int fs3_parser(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, const bat
   const int Cv = fs_columns(om->M);
   const size_t shmem = (size_t)(kLogsumTbl + (om->M + 2) * 8) * sizeof(float);
   const float tE = (float)-0.69314718055994529;
-  const int grid = fs_grid(ctx, n);
+  [[maybe_unused]] const int grid = fs_grid(ctx, n);
+  const int grid_dp = fs_grid_dp(ctx, n);
   const bool exact = (logsum_mode == BATH_LOGSUM_EXACT);
   BATH_FS_SWITCH(Cv, {
     if (!backward) {
       if (exact) { if ((st = fs_set_shmem(ctx, fs3_fwd_kernel<CC, true>, shmem)) != BATH_OK) return st;
-        hipLaunchKernelGGL((fs3_fwd_kernel<CC, true>), dim3(grid), dim3(256), shmem, ctx->stream, dna->view(), fsdev(om), om->d_loop[0], om->d_move[0], tE, tE, b_sc.as<float>(), d_x, b_off.as<int64_t>());
+        hipLaunchKernelGGL((fs3_fwd_kernel<CC, true>), dim3(grid_dp), dim3(kFsBlock), shmem, ctx->stream, dna->view(), fsdev(om), om->d_loop[0], om->d_move[0], tE, tE, b_sc.as<float>(), d_x, b_off.as<int64_t>());
       } else { if ((st = fs_set_shmem(ctx, fs3_fwd_kernel<CC, false>, shmem)) != BATH_OK) return st;
-        hipLaunchKernelGGL((fs3_fwd_kernel<CC, false>), dim3(grid), dim3(256), shmem, ctx->stream, dna->view(), fsdev(om), om->d_loop[0], om->d_move[0], tE, tE, b_sc.as<float>(), d_x, b_off.as<int64_t>());
+        hipLaunchKernelGGL((fs3_fwd_kernel<CC, false>), dim3(grid_dp), dim3(kFsBlock), shmem, ctx->stream, dna->view(), fsdev(om), om->d_loop[0], om->d_move[0], tE, tE, b_sc.as<float>(), d_x, b_off.as<int64_t>());
       }
     } else {
       if (exact) { if ((st = fs_set_shmem(ctx, fs_bwd_kernel<CC, 3, true>, shmem)) != BATH_OK) return st;
-        hipLaunchKernelGGL((fs_bwd_kernel<CC, 3, true>), dim3(grid), dim3(256), shmem, ctx->stream, dna->view(), fsdev(om), om->d_loop[0], om->d_move[0], tE, tE, b_sc.as<float>(), (float *)nullptr, (const int64_t *)nullptr, d_x, b_off.as<int64_t>());
+        hipLaunchKernelGGL((fs_bwd_kernel<CC, 3, true>), dim3(grid_dp), dim3(kFsBlock), shmem, ctx->stream, dna->view(), fsdev(om), om->d_loop[0], om->d_move[0], tE, tE, b_sc.as<float>(), (float *)nullptr, (const int64_t *)nullptr, d_x, b_off.as<int64_t>());
       } else { if ((st = fs_set_shmem(ctx, fs_bwd_kernel<CC, 3, false>, shmem)) != BATH_OK) return st;
-        hipLaunchKernelGGL((fs_bwd_kernel<CC, 3, false>), dim3(grid), dim3(256), shmem, ctx->stream, dna->view(), fsdev(om), om->d_loop[0], om->d_move[0], tE, tE, b_sc.as<float>(), (float *)nullptr, (const int64_t *)nullptr, d_x, b_off.as<int64_t>());
+        hipLaunchKernelGGL((fs_bwd_kernel<CC, 3, false>), dim3(grid_dp), dim3(kFsBlock), shmem, ctx->stream, dna->view(), fsdev(om), om->d_loop[0], om->d_move[0], tE, tE, b_sc.as<float>(), (float *)nullptr, (const int64_t *)nullptr, d_x, b_off.as<int64_t>());
       }
     }
   })
@@ -1238,14 +1246,15 @@ int fs3_regions(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, const bath_hip_
   const int Cv = fs_columns(om->M);
   const size_t shmem = (size_t)(kLogsumTbl + (om->M + 2) * 8) * sizeof(float);
   const float tE = (float)-0.69314718055994529;
-  const int grid = fs_grid(ctx, n);
+  [[maybe_unused]] const int grid = fs_grid(ctx, n);
+  const int grid_dp = fs_grid_dp(ctx, n);
   BATH_HIP_TRY(ctx, b_sc.reserve((size_t)n * 2 * sizeof(float)));
   if ((st = fs_fork(ctx)) != BATH_OK) return st;
   BATH_FS_SWITCH(Cv, {
     if ((st = fs_set_shmem(ctx, fs3_fwd_kernel<CC, false>, shmem)) != BATH_OK) return st;
-    hipLaunchKernelGGL((fs3_fwd_kernel<CC, false>), dim3(grid), dim3(256), shmem, ctx->stream, dna->view(), fsdev(om), om->d_loop[0], om->d_move[0], tE, tE, b_sc.as<float>(), b_fx.as<float>(), b_off.as<int64_t>());
+    hipLaunchKernelGGL((fs3_fwd_kernel<CC, false>), dim3(grid_dp), dim3(kFsBlock), shmem, ctx->stream, dna->view(), fsdev(om), om->d_loop[0], om->d_move[0], tE, tE, b_sc.as<float>(), b_fx.as<float>(), b_off.as<int64_t>());
     if ((st = fs_set_shmem(ctx, fs_bwd_kernel<CC, 3, false>, shmem)) != BATH_OK) return st;
-    hipLaunchKernelGGL((fs_bwd_kernel<CC, 3, false>), dim3(grid), dim3(256), shmem, ctx->side_stream, dna->view(), fsdev(om), om->d_loop[0], om->d_move[0], tE, tE, b_sc.as<float>() + n, (float *)nullptr, (const int64_t *)nullptr, b_bx.as<float>(), b_off.as<int64_t>());
+    hipLaunchKernelGGL((fs_bwd_kernel<CC, 3, false>), dim3(grid_dp), dim3(kFsBlock), shmem, ctx->side_stream, dna->view(), fsdev(om), om->d_loop[0], om->d_move[0], tE, tE, b_sc.as<float>() + n, (float *)nullptr, (const int64_t *)nullptr, b_bx.as<float>(), b_off.as<int64_t>());
   })
   if ((st = fs_join(ctx)) != BATH_OK) return st;
   hipLaunchKernelGGL(fs_regions_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, n, dna->d_len, b_fx.as<float>(), b_bx.as<float>(), b_off.as<int64_t>(), om->d_logsum, loop,
@@ -1323,7 +1332,8 @@ int bath::fs5_envelopes_ex(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, cons
   const int Cv = fs_columns(M);
   const size_t shmem = (size_t)(kLogsumTbl + (M + 2) * 8) * sizeof(float);
   const size_t oa_shmem = (size_t)(M + 2) * 8 * sizeof(float);
-  const int grid = fs_grid(ctx, n);
+  [[maybe_unused]] const int grid = fs_grid(ctx, n);
+  const int grid_dp = fs_grid_dp(ctx, n);
   const bool exact = (logsum_mode == BATH_LOGSUM_EXACT);
   const float tEL = -INFINITY, tEM = 0.0f;                                      // unihit: p7_fs_ReconfigUnihit, modelconfig.c:868
   if ((st = fs_fork(ctx)) != BATH_OK) return st;                                // Backward on the side stream, concurrently with Forward
@@ -1331,13 +1341,13 @@ int bath::fs5_envelopes_ex(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, cons
     if (exact) {
       if ((st = fs_set_shmem(ctx, fs5_fwd_kernel<CC, true>, shmem)) != BATH_OK) return st;
       if ((st = fs_set_shmem(ctx, fs_bwd_kernel<CC, 5, true>, shmem)) != BATH_OK) return st;
-      hipLaunchKernelGGL((fs5_fwd_kernel<CC, true>), dim3(grid), dim3(256), shmem, ctx->stream, dna->view(), fsdev(om), om->d_loop[1], om->d_move[1], tEL, tEM, c5_compat, d_fsc, b_f.as<float>(), d_foff, b_fx.as<float>(), d_xoff, -1);
-      hipLaunchKernelGGL((fs_bwd_kernel<CC, 5, true>), dim3(grid), dim3(256), shmem, ctx->side_stream, dna->view(), fsdev(om), om->d_loop[1], om->d_move[1], tEL, tEM, d_bsc, b_b.as<float>(), d_boff, b_bx.as<float>(), d_xoff);
+      hipLaunchKernelGGL((fs5_fwd_kernel<CC, true>), dim3(grid_dp), dim3(kFsBlock), shmem, ctx->stream, dna->view(), fsdev(om), om->d_loop[1], om->d_move[1], tEL, tEM, c5_compat, d_fsc, b_f.as<float>(), d_foff, b_fx.as<float>(), d_xoff, -1);
+      hipLaunchKernelGGL((fs_bwd_kernel<CC, 5, true>), dim3(grid_dp), dim3(kFsBlock), shmem, ctx->side_stream, dna->view(), fsdev(om), om->d_loop[1], om->d_move[1], tEL, tEM, d_bsc, b_b.as<float>(), d_boff, b_bx.as<float>(), d_xoff);
     } else {
       if ((st = fs_set_shmem(ctx, fs5_fwd_kernel<CC, false>, shmem)) != BATH_OK) return st;
       if ((st = fs_set_shmem(ctx, fs_bwd_kernel<CC, 5, false>, shmem)) != BATH_OK) return st;
-      hipLaunchKernelGGL((fs5_fwd_kernel<CC, false>), dim3(grid), dim3(256), shmem, ctx->stream, dna->view(), fsdev(om), om->d_loop[1], om->d_move[1], tEL, tEM, c5_compat, d_fsc, b_f.as<float>(), d_foff, b_fx.as<float>(), d_xoff, -1);
-      hipLaunchKernelGGL((fs_bwd_kernel<CC, 5, false>), dim3(grid), dim3(256), shmem, ctx->side_stream, dna->view(), fsdev(om), om->d_loop[1], om->d_move[1], tEL, tEM, d_bsc, b_b.as<float>(), d_boff, b_bx.as<float>(), d_xoff);
+      hipLaunchKernelGGL((fs5_fwd_kernel<CC, false>), dim3(grid_dp), dim3(kFsBlock), shmem, ctx->stream, dna->view(), fsdev(om), om->d_loop[1], om->d_move[1], tEL, tEM, c5_compat, d_fsc, b_f.as<float>(), d_foff, b_fx.as<float>(), d_xoff, -1);
+      hipLaunchKernelGGL((fs_bwd_kernel<CC, 5, false>), dim3(grid_dp), dim3(kFsBlock), shmem, ctx->side_stream, dna->view(), fsdev(om), om->d_loop[1], om->d_move[1], tEL, tEM, d_bsc, b_b.as<float>(), d_boff, b_bx.as<float>(), d_xoff);
     }
     if ((st = fs_join(ctx)) != BATH_OK) return st;
     BATH_HIP_TRY(ctx, hipMemsetAsync(b_cs.p, 0, (size_t)n * cs_stride * sizeof(float), ctx->stream));
@@ -1410,11 +1420,12 @@ int bath::fs5_region_forward(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, co
   BATH_HIP_TRY(ctx, hipMemcpyAsync(d_xoff, xoff.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
   const int Cv = fs_columns(M);
   const size_t shmem = (size_t)(kLogsumTbl + (M + 2) * 8) * sizeof(float);
-  const int grid = fs_grid(ctx, n);
+  [[maybe_unused]] const int grid = fs_grid(ctx, n);
+  const int grid_dp = fs_grid_dp(ctx, n);
   const float tE = (float)-0.69314718055994529;                               // multihit: E->C and E->J both log 1/2 (modelconfig.c:825-831)
   BATH_FS_SWITCH(Cv, {
     if ((st = fs_set_shmem(ctx, fs5_fwd_kernel<CC, false>, shmem)) != BATH_OK) return st;
-    hipLaunchKernelGGL((fs5_fwd_kernel<CC, false>), dim3(grid), dim3(256), shmem, ctx->stream, dna->view(), fsdev(om), om->d_loop[0], om->d_move[0], tE, tE, 0, b_sc.as<float>(),
+    hipLaunchKernelGGL((fs5_fwd_kernel<CC, false>), dim3(grid_dp), dim3(kFsBlock), shmem, ctx->stream, dna->view(), fsdev(om), om->d_loop[0], om->d_move[0], tE, tE, 0, b_sc.as<float>(),
                        b_f.as<float>(), d_foff, b_fx.as<float>(), d_xoff, cfg_len_amino);
   })
   BATH_HIP_TRY(ctx, hipGetLastError());
