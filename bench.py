@@ -185,7 +185,7 @@ def main():
             "metric": "DP Gcells/s + residues/s through bathsearch pipeline at 1/2/4/8 MI355X",
             "value": value, "unit": "residues/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u8/i16 (MSV, Viterbi) + f32 (Forward)", "data": "synthetic",
+            "dtype": "integer scores: u8 as exact binary16 (SSV), u8 (MSV), i16 (Viterbi); f32 (Forward, bias)", "data": "synthetic",
             "config": {"workload": "Caudal_act.bhmm (M=%d) vs %d x %d nt iid DNA windows per GPU (1%% planted), both strands, "
                                    "6-frame translation + MSV/bias/Viterbi/Forward filter cascade, codon table %d, no --fs"
                                    % (hmm.M, args.windows, args.length, hmm.ct),
