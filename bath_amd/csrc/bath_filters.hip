@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void ssv_lane_kernel(SeqView sq, const int32_t
   const s16x2 fl = {0, 0};                                      // the begin score
 #pragma unroll
   for (int r = 0; r < NR; r++) reg[r] = fl;
-  s16x2 xE = fl;
+  s16x2 xE = fl, xE2 = fl;
 
   uint32_t wnext = (0 < L) ? *reinterpret_cast<const uint32_t *>(s) : 0x1d1d1d1du;
   for (int i0 = 0; i0 < Lw; i0 += 4) {
@@ -71,9 +71,10 @@ __global__ __launch_bounds__(256) void ssv_lane_kernel(SeqView sq, const int32_t
       int x = (w >> (8 * j)) & 0xff;
       x = (i0 + j < L) ? min(x, kKp - 1) : kRowReset;
       const unsigned carry = ssv_carry<NR, G>(reg, grank);
-      ssv_row<NR>(reg, xE, tile + x * row_bytes, carry);
+      ssv_row<NR>(reg, xE, xE2, tile + x * row_bytes, carry);
     }
   }
+  xE = ssv_max3(xE, xE2, xE2);
   const int v = ssv_group_max<G>(xE);
   if (live && grank == 0) out_v[sid] = (int16_t)min(v, 32767);
 }

@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void ssv_orf_kernel(const uint8_t *__restrict_
     s16x2 reg[NR];
 #pragma unroll
     for (int r = 0; r < NR; r++) reg[r] = fl;
-    s16x2 xE = fl;
+    s16x2 xE = fl, xE2 = fl;
     // residues 8 at a time, the next 8 in flight: an ORF's 64-byte sectors are touched by half as many loads as with a dword
     // per 4 rows, and each touch is a chance to find the sector evicted from L2 again (HBM traffic of the launch -32%, kernel
     // -4%; the loop also stops at the wave's longest ORF instead of the next multiple of 4 rows).  16 at a time costs 150 VGPRs:
@@ -113,9 +113,10 @@ __global__ __launch_bounds__(256) void ssv_orf_kernel(const uint8_t *__restrict_
         int x = (int)(q >> (8 * j)) & 0xff;
         x = (i0 + j < L) ? min(x, kKp - 1) : kRowReset;
         const unsigned carry = ssv_carry<NR, G>(reg, grank);
-        ssv_row<NR>(reg, xE, tile + x * row_bytes, carry);
+        ssv_row<NR>(reg, xE, xE2, tile + x * row_bytes, carry);
       }
     }
+    xE = ssv_max3(xE, xE2, xE2);
     const int v = ssv_group_max<G>(xE);
     if (live && grank == 0 && v >= (int)emit_thresh[min(L, thresh_max)]) {
       const int sf = (int)((unsigned)rec.len_sf >> 28);
