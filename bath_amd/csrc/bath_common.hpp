@@ -172,7 +172,7 @@ struct bath_hip_oprofile {
   uint8_t *d_cons = nullptr;
   std::vector<float> prefix_lengths, suffix_lengths;   // [M+1] P7_SCOREDATA window padding fractions (p7_scoredata.c:357-380)
   // device tables
-  int NR = 0, G = 1;            // SSV kernel tile: NR packed int16 registers per lane, G lanes per target (2*NR*G >= M)
+  int NR = 0, G = 1;            // SSV kernel tile: NR registers (two cells each) per lane, G lanes per target (2*NR*G >= M)
   int ssv_row_bytes = 0;
   int16_t *d_ssv = nullptr;     // [kSsvRows][ssv_row_bytes/2] signed SSV costs (sf_conversion), +127 padding
   uint8_t *d_rb = nullptr;      // [Kp][rb_stride]

@@ -8,7 +8,7 @@
 //
 // Work decomposition (MI355X-first, not the reference's 16-lane stripes):
 //  * SSV has no dependency along a DP row (only along diagonals), so ONE LANE owns one target and
-//    keeps the whole DP row in packed-int16 VGPRs (2 model nodes per register); 64 targets per
+//    keeps the whole DP row in VGPRs, two cells (binary16, see bath_kernels.hpp) per register; 64 targets per
 //    wavefront advance in lock step, emission costs are gathered from an LDS table by residue.
 //    No cross-lane traffic at all.  4 VALU ops per 2 cells.
 //  * MSV(J)/Viterbi/Forward have a serial dependency along the row (xE->xB, D->D), and only the

@@ -8,7 +8,7 @@
 // GPU formulation:
 //   1. bath_orfs.hip: six-frame translation, ORF finding and a length-sorted ORF work list (lane per stream).
 //   2. ssv_orf_kernel: one LANE per ORF (G lanes for long models) runs the SSV recurrence with the whole DP row in
-//      packed int16 registers; lanes of a wave hold ORFs of equal length.  The lane compares its maximum with a
+//      registers, two binary16 cells each; lanes of a wave hold ORFs of equal length.  The lane compares its maximum with a
 //      per-length threshold table computed on the host with the reference's double-precision P-value maths (so the
 //      F1 decision is bit-identical) and appends the ~2% survivors to a candidate list.
 //   3. survivors flow through decision kernels (lane per candidate) and DP kernels (lane or wave per candidate)
