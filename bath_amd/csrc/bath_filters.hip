@@ -10,7 +10,7 @@
 //  * SSV has no dependency along a DP row (only along diagonals), so ONE LANE owns one target and
 //    keeps the whole DP row in VGPRs, two cells (binary16, see bath_kernels.hpp) per register; 64 targets per
 //    wavefront advance in lock step, emission costs are gathered from an LDS table by residue.
-//    No cross-lane traffic at all.  4 VALU ops per 2 cells.
+//    No cross-lane traffic at all.  1.5 VALU ops per 2 cells.
 //  * MSV(J)/Viterbi/Forward have a serial dependency along the row (xE->xB, D->D), and only the
 //    ~2% of targets that survive SSV reach them: ONE WAVEFRONT owns one target, lanes own
 //    contiguous blocks of model nodes, the row recurrence is a wavefront scan (shuffle), and the
