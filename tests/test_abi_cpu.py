@@ -72,3 +72,33 @@ def test_no_gpu_is_a_loud_error():
         pytest.skip("GPU present")
     with pytest.raises(ba.BathError, match="no CPU fallback"):
         ba.Context(0)
+
+
+def test_header_is_plain_c_and_links(tmp_path):
+    """include/bath_hip.h is the boundary a C host (BATH itself) compiles against: it must be valid C99 with no C++ or torch
+    types, and a C program using it must link against libbathhip.so (host-side entry points only: no GPU here)."""
+    import os
+    import shutil
+    import subprocess
+    ROOT = ba._ROOT
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "host.c"
+    src.write_text(
+        '#include <stdio.h>\n#include "bath_hip.h"\n'
+        "int main(int argc, char **argv) {\n"
+        "  bath_hmm *hmm = NULL; bath_profile *gm = NULL; bath_pipeline_params prm;\n"
+        "  if (argc < 2 || bath_hmmfile_read(argv[1], 0, &hmm) != BATH_OK) return 2;\n"
+        "  if (bath_profile_config(hmm, 100, &gm) != BATH_OK) return 3;\n"
+        "  bath_pipeline_params_default(&prm, 1);\n"
+        "  bath_tophits *th = bath_tophits_create();\n"
+        "  if (bath_tophits_finalize(th, 1000, hmm->max_length, 10.0) != BATH_OK) return 4;\n"
+        '  printf("%s %d %s %d %g %ld\\n", hmm->name, hmm->M, hmm->acc, gm->M, prm.F4, (long) bath_tophits_count(th));\n'
+        "  bath_tophits_destroy(th); bath_profile_destroy(gm); bath_hmm_destroy(hmm);\n"
+        "  return 0;\n}\n")
+    exe = tmp_path / "host"
+    libdir = os.path.dirname(ba.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                           "-L", libdir, "-lbathhip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.check_output([str(exe), os.path.join(ROOT, "tests", "golden", "PTH2.bhmm")], text=True).split()
+    assert out == ["PTH2", "116", "PF01981.11", "116", "0.0005", "0"]
