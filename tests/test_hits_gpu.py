@@ -198,3 +198,22 @@ def test_hits_with_a_1024_node_model(ctx, tmp_path):
     pli, odm, per_d, onskip = model.run_pipeline_hits(wins)
     assert (stats.n_past_fwd, stats.pos_past_fwd) == (pli.n_past_fwd, pli.pos_past_fwd)
     assert compare_hits(dm, odm, per_d, nskip, onskip) >= 4
+
+
+def test_hits_with_degenerate_nucleotides(ctx):
+    """IUPAC codes in the DNA (codes 5..15) translate to X: the hit stages see X residues in ORFs, envelopes and alignments
+    (null2 of a degenerate residue is the mean over its members; X never equals the consensus)."""
+    path = ol.GOLDEN + "/PTH2.bhmm"
+    model = ol.Model(path, 0)
+    rng = np.random.default_rng(2024)
+    wins = []
+    for i, aa in enumerate(common.emit_from_model(rng, model, 24, flank=4, sharpen=3.0)):
+        nt = np.array(common.revtranslate(rng, aa, model.basic), dtype=np.uint8)
+        w = np.concatenate([rng.integers(0, 4, size=40).astype(np.uint8), nt, rng.integers(0, 4, size=40).astype(np.uint8)])
+        m = rng.random(len(w)) < 0.01
+        w[m] = rng.choice([5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15], size=int(m.sum()))
+        wins.append((3 - w[::-1]).astype(np.uint8) if i % 2 and not m.any() else w)
+    stats, dm, nskip = gpu_hits(ctx, path, 0, wins)
+    pli, odm, per_d, onskip = model.run_pipeline_hits(wins)
+    assert (stats.n_orfs, stats.n_past_fwd, stats.pos_past_fwd) == (pli.n_orfs, pli.n_past_fwd, pli.pos_past_fwd)
+    assert compare_hits(dm, odm, per_d, nskip, onskip) >= 8
