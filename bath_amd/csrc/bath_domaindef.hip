@@ -215,13 +215,35 @@ static int fs_branch_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, con
   std::vector<bath_fs5_result> res((size_t)nenv);
   std::vector<FsTraceOut> traces((size_t)nenv);
   std::vector<uint16_t> steps;
-  std::vector<int64_t> step_off;
+  std::vector<int64_t> step_off((size_t)nenv + 1, 0);
   {
-    bath_hip_seqs view;
-    if ((st = fs_gather_view(ctx, dna, eregs, tt.comp, &view, nullptr)) != BATH_OK) return st;
-    st = fs5_envelopes_ex(ctx, om_fs5, &view, BATH_LOGSUM_TABLE, 0, res.data(), nullptr, nullptr, nullptr, nullptr, traces.data(), om->d_cons, &steps, &step_off);
-    view.d_data = nullptr; view.d_off = nullptr; view.d_len = nullptr;
-    if (st != BATH_OK) return st;
+    // The envelope kernels keep three matrices per envelope in HBM (Forward 32 B, Backward 12 B, optimal accuracy 12 B per
+    // cell): the envelopes go through in batches of at most 24 GB of matrices (BATH_HIP_ENV_MB overrides, for tests), so a block
+    // of any size fits next to the DNA and the amino-acid streams.
+    size_t budget = (size_t)24 << 30;
+    if (const char *e = std::getenv("BATH_HIP_ENV_MB")) budget = (size_t)std::max(1, std::atoi(e)) << 20;
+    for (int e0 = 0; e0 < nenv;) {
+      int e1 = e0;
+      size_t bytes = 0;
+      while (e1 < nenv) {
+        const size_t b = ((size_t)eregs[(size_t)e1].len + 1) * (size_t)(h5.M + 1) * 56;
+        if (e1 > e0 && bytes + b > budget) break;
+        bytes += b; e1++;
+      }
+      std::vector<FsWinDev> chunk(eregs.begin() + e0, eregs.begin() + e1);
+      std::vector<uint16_t> csteps;
+      std::vector<int64_t> coff;
+      bath_hip_seqs view;
+      if ((st = fs_gather_view(ctx, dna, chunk, tt.comp, &view, nullptr)) != BATH_OK) return st;
+      st = fs5_envelopes_ex(ctx, om_fs5, &view, BATH_LOGSUM_TABLE, 0, res.data() + e0, nullptr, nullptr, nullptr, nullptr, traces.data() + e0, om->d_cons, &csteps, &coff);
+      view.d_data = nullptr; view.d_off = nullptr; view.d_len = nullptr;
+      if (st != BATH_OK) return st;
+      const int64_t base = (int64_t)steps.size();
+      for (int k = 0; k < e1 - e0; k++) step_off[(size_t)(e0 + k)] = base + coff[(size_t)k];
+      steps.insert(steps.end(), csteps.begin(), csteps.end());
+      e0 = e1;
+    }
+    step_off[(size_t)nenv] = (int64_t)steps.size();
   }
   clk.lap("fs: envelope kernels + traces");
 

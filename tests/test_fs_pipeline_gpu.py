@@ -243,3 +243,24 @@ def test_frameshift_path_with_a_long_model(gpu_ctx, tmp_path):
     assert sorted((w.window, w.strand, w.n, w.length) for w in fw) == sorted((i, o.strand, o.n, o.length) for i, (a, b) in enumerate(per_w) for o in ofw[a:b])
     assert nskip == oskip
     assert compare_domains(model, dm, odm, per_d, nskip) >= 3
+
+
+def test_envelope_batches_give_the_same_hits(gpu_ctx, monkeypatch):
+    """The envelope kernels work through the envelopes in batches bounded by the memory of their matrices; a tiny bound
+    (many batches) must give exactly what one batch gives."""
+    rng = np.random.default_rng(77)
+    path = ol.GOLDEN + "/PTH2.bhmm"
+    model = ol.Model(path, 0)
+    wins = frameshifted_windows(rng, model, n=30)
+    hmm = ba.HMM(path, 0)
+    om = ba.OProfile(gpu_ctx, ba.Profile(hmm))
+    om3 = ba.FSOProfile(gpu_ctx, ba.FSProfile(hmm, 3, ncbi_table=hmm.ct))
+    om5 = ba.FSOProfile(gpu_ctx, ba.FSProfile(hmm, 5, ncbi_table=hmm.ct))
+    pipe = ba.Pipeline(gpu_ctx, om, fs_pipe=True, ncbi_table=hmm.ct)
+    out = []
+    for mb in ("100000", "1"):                       # one batch; about one envelope per batch
+        monkeypatch.setenv("BATH_HIP_ENV_MB", mb)
+        _, fw, dm, nskip = pipe.run_frameshift_domains(om3, om5, ba.SeqBlock(gpu_ctx, wins))
+        out.append((nskip, [(d.window, d.fs_window, d.ienv, d.jenv, d.iali, d.jali, d.ihmm, d.jhmm, d.envsc, d.oasc, d.domcorrection, d.bitscore, d.lnP,
+                             d.n_shifted_codons, d.n_stops, d.pid, d.cigar) for d in dm]))
+    assert out[0] == out[1] and len(out[0][1]) >= 10
