@@ -176,6 +176,8 @@ ABI = {
     "bath_tophits_count": (C.c_int64, [_vp]),
     "bath_tophits_reported": (C.c_int64, [_vp]),
     "bath_tophits_get": (C.c_int, [_vp, C.c_int64, C.POINTER(FsDomain), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
+    "bath_tophits_targets": (C.c_int64, [_vp, C.c_int, C.c_int, C.c_char_p, C.c_int64]),
+    "bath_tophits_set_inclusion": (None, [_vp, C.c_double]),
     "bath_tophits_tabular_targets": (C.c_int64, [_vp, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int64]),
     "bath_hip_pipeline_hits": (C.c_int, [_vp, _vp, _vp, C.POINTER(PipelineParams), C.c_double, C.POINTER(PipelineStats),
                                          C.POINTER(C.POINTER(FsDomain)), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
@@ -645,6 +647,13 @@ class TopHits:
         n = lib().bath_tophits_tabular_targets(*args, None, 0)
         buf = C.create_string_buffer(n + 1)
         lib().bath_tophits_tabular_targets(*args, buf, n)
+        return buf.raw[:n].decode()
+
+    def targets(self, fs_pipe=False, textw=120):
+        """The 'Scores for complete hits' block of bathsearch's main output (p7_tophits_Targets)."""
+        n = lib().bath_tophits_targets(self._h, int(fs_pipe), textw, None, 0)
+        buf = C.create_string_buffer(n + 1)
+        lib().bath_tophits_targets(self._h, int(fs_pipe), textw, buf, n)
         return buf.raw[:n].decode()
 
     def __del__(self):

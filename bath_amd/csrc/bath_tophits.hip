@@ -42,12 +42,14 @@ struct bath_tophits {
   std::vector<Hit> unsrt;
   std::vector<int> order;              // th->hit[]: indices into unsrt
   int64_t nreported = 0, nincluded = 0;
+  double incE = 0.01;                  // pli->incE, p7_pipeline.c:166
 };
 
 extern "C" bath_tophits *bath_tophits_create(void) { return new bath_tophits(); }
 extern "C" void bath_tophits_destroy(bath_tophits *th) { delete th; }
 extern "C" int64_t bath_tophits_count(const bath_tophits *th) { return th ? (int64_t)th->unsrt.size() : 0; }
 extern "C" int64_t bath_tophits_reported(const bath_tophits *th) { return th ? th->nreported : 0; }
+extern "C" void bath_tophits_set_inclusion(bath_tophits *th, double incE) { if (th) th->incE = incE; }
 
 extern "C" int bath_tophits_add(bath_tophits *th, const bath_fs_domain *dom, int64_t n, const char *cigars, int64_t seqidx0,
                                 const char *const *seq_names, const char *const *seq_accs, const char *const *seq_descs, const int64_t *seq_lens) {
@@ -132,7 +134,10 @@ extern "C" int bath_tophits_finalize(bath_tophits *th, int64_t nres, int max_len
   th->nreported = th->nincluded = 0;
   for (Hit &h : H) {
     h.flags &= ~(IS_REPORTED | IS_INCLUDED);
-    if (!(h.flags & IS_DUPLICATE) && std::exp(h.lnP) <= E) { h.flags |= IS_REPORTED; th->nreported++; }
+    if (!(h.flags & IS_DUPLICATE) && std::exp(h.lnP) <= E) {
+      h.flags |= IS_REPORTED; th->nreported++;
+      if (std::exp(h.lnP) <= th->incE) { h.flags |= IS_INCLUDED; th->nincluded++; }      // p7_pli_TargetIncludable
+    }
   }
   return BATH_OK;
 }
@@ -211,6 +216,49 @@ extern "C" int64_t bath_tophits_tabular_targets(const bath_tophits *th, const ch
     if (show_cigar) appendf(out, " %s\n", h.cigar.c_str());
     else appendf(out, " %s\n", h.desc.empty() ? "-" : h.desc.c_str());
   }
+  if (buf && cap > 0) std::memcpy(buf, out.data(), (size_t)std::min<int64_t>(cap, (int64_t)out.size()));
+  return (int64_t)out.size();
+}
+
+// p7_tophits_Targets, p7_tophits.c:1073-1228 (search mode, no --acc, not spliced): the "Scores for complete hits" block of
+// bathsearch's main output.  textw: the --textw line width (120 by default; <= 0: unlimited).  Returns the size in bytes.
+extern "C" int64_t bath_tophits_targets(const bath_tophits *th, int fs_pipe, int textw, char *buf, int64_t cap) {
+  if (!th) return -1;
+  const std::vector<Hit> &H = th->unsrt;
+  size_t maxname = 0;
+  int maxpos = 0;
+  for (const Hit &h : H) {
+    maxname = std::max(maxname, h.name.size());
+    if (h.d.iali > 0) {
+      char b[32];
+      maxpos = std::max(maxpos, snprintf(b, sizeof b, "%" PRId64, (int64_t)h.d.iali));
+      maxpos = std::max(maxpos, snprintf(b, sizeof b, "%" PRId64, (int64_t)h.d.jali));
+    }
+  }
+  const int namew = (int)std::max<size_t>(8, maxname), posw = std::max(6, maxpos);
+  const int descw = textw > 0 ? std::max(32, textw - namew - 2 * posw - 32) : 0;
+  std::string out;
+  appendf(out, "Scores for complete hits:\n");
+  if (fs_pipe) {
+    appendf(out, "  %9s %6s %5s  %-*s %*s %*s  %6s  %5s  %s\n", "E-value", " score", " bias", namew, "Sequence", posw, "start", posw, "end", "shifts", "stops", "Description");
+    appendf(out, "  %9s %6s %5s  %-*s %*s %*s  %6s  %5s  %s\n", "-------", "------", "-----", namew, "--------", posw, "-----", posw, "-----", "------", "-----", "-----------");
+  } else {
+    appendf(out, "  %9s %6s %5s  %-*s %*s %*s  %s\n", "E-value", " score", " bias", namew, "Sequence", posw, "start", posw, "end", "Description");
+    appendf(out, "  %9s %6s %5s  %-*s %*s %*s  %s\n", "-------", "------", "-----", namew, "--------", posw, "-----", posw, "-----", "-----------");
+  }
+  const double kLog2R = 1.44269504088896341;
+  bool printed_incthresh = false;
+  for (size_t r = 0; r < H.size(); r++) {
+    const Hit &h = H[(size_t)(th->order.empty() ? (int)r : th->order[r])];
+    if (!(h.flags & IS_REPORTED)) continue;
+    if (!(h.flags & IS_INCLUDED) && !printed_incthresh) { appendf(out, "  ------ inclusion threshold ------\n"); printed_incthresh = true; }
+    appendf(out, "%c %9.2g %6.1f %5.1f  %-*s %*" PRId64 " %*" PRId64 "  ", ' ', std::exp(h.lnP), h.score, kLog2R * h.d.dombias, namew, h.name.c_str(), posw, (int64_t)h.d.iali, posw,
+            (int64_t)h.d.jali);
+    if (fs_pipe) appendf(out, "%6d  %5d", h.d.n_shifted_codons, h.d.n_stops);
+    if (textw > 0) appendf(out, "  %-.*s\n", descw, h.desc.c_str());
+    else appendf(out, "  %s\n", h.desc.c_str());
+  }
+  if (th->nreported == 0) appendf(out, "\n   [No hits detected that satisfy reporting thresholds]\n");
   if (buf && cap > 0) std::memcpy(buf, out.data(), (size_t)std::min<int64_t>(cap, (int64_t)out.size()));
   return (int64_t)out.size();
 }

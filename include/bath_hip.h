@@ -299,6 +299,10 @@ int64_t bath_tophits_reported(const bath_tophits *th);
 /* The rank-th hit in the current sort order (by E-value after finalize); dom->lnP is the E-value's log after finalize. */
 int  bath_tophits_get(const bath_tophits *th, int64_t rank, bath_fs_domain *dom, int64_t *seqidx, int32_t *flags);
 /* Returns the table's size in bytes and copies at most <cap> of them to <buf>. */
+/* p7_tophits_Targets (:1073): the "Scores for complete hits" block of the main output; textw = --textw (120; <= 0 unlimited). */
+int64_t bath_tophits_targets(const bath_tophits *th, int fs_pipe, int textw, char *buf, int64_t cap);
+void bath_tophits_set_inclusion(bath_tophits *th, double incE);   /* --incE, default 0.01; before finalize */
+#define BATH_HIT_INCLUDED  2
 int64_t bath_tophits_tabular_targets(const bath_tophits *th, const char *qname, const char *qacc, int M, int fs_pipe,
                                      int show_cigar, int show_header, char *buf, int64_t cap);
 

@@ -33,3 +33,19 @@ def fields_of(d, sq_len, fs, with_env):
     elif with_env:
         out += [str(d.ienv), str(d.jenv)]
     return out + [str(sq_len), "%.2f" % acc]
+
+
+def targets_blocks(outfile):
+    """The 'Scores for complete hits' block of every query in a recorded bathsearch output, up to its last hit line."""
+    blocks = []
+    lines = open(ol.GOLDEN + "/" + outfile).read().split("\n")
+    i = 0
+    while i < len(lines):
+        if lines[i].startswith("Scores for complete hits"):
+            j = i + 3
+            while j < len(lines) and lines[j].strip():
+                j += 1
+            blocks.append("\n".join(lines[i:j]) + "\n")
+            i = j
+        i += 1
+    return blocks

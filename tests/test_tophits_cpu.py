@@ -80,7 +80,7 @@ def test_duplicates_sorting_and_threshold():
     assert abs(by_key[(0, 100)][0].lnP - (-40.0 + np.log(np.float32(300000.0) / np.float32(300.0)))) < 1e-9
     assert by_key[(0, 102)][1] & 4 and not by_key[(0, 102)][1] & 1                        # duplicate, not reported
     for key in ((0, 100), (0, 400), (0, 1000), (1, 100)):
-        assert by_key[key][1] == 1
+        assert by_key[key][1] == 3                                                        # reported and included (E <= 0.01)
     assert by_key[(0, 5000)][1] == 0                                                      # exp(-1) * 1000 > 10
     text = th.tblout("q", "", 100)
     rows = data_rows(text)
@@ -121,3 +121,27 @@ def test_oracle_reproduces_recorded_annotation_lines(outfile, hmmfile, fasta, fs
             for g, w in zip(got, lines):
                 g[8] = w[8]                                            # stops
         assert got == lines
+
+
+@pytest.mark.parametrize("outfile,hmmfile,fasta,fs", recorded.RUNS, ids=[r[0] for r in recorded.RUNS])
+def test_targets_block_matches_recorded_output(outfile, hmmfile, fasta, fs):
+    """The 'Scores for complete hits' block of the reference's main output, byte for byte, from the oracle's domains (the stop
+    count of the --fs hit is an alignment-display output and is filled in from the record)."""
+    want = recorded.targets_blocks(outfile)
+    recs = ol.read_fasta(ol.GOLDEN + "/" + fasta)
+    seqs = [ol.digitize_dna(s) for _, s in recs]
+    for q, block in enumerate(want):
+        m = ol.Model(ol.GOLDEN + "/" + hmmfile, q)
+        hmm = ba.HMM(ol.GOLDEN + "/" + hmmfile, q)
+        if fs:
+            pli, _, _, odm, per_d, _ = m.run_pipeline_fsdom(seqs)
+        else:
+            pli, odm, per_d, _ = m.run_pipeline_hits(seqs)
+        doms = [from_oracle(o, w) for w, (a, b) in enumerate(per_d) for o in odm[a:b]]
+        if fs:
+            for d in doms:
+                d.n_stops = 1                                      # tutorial/AMP_N-fs.out: 1 stop codon in the alignment
+        th = ba.TopHits()
+        th.add(doms, [n.split()[0] for n, _ in recs], [len(s) for s in seqs])
+        th.finalize(pli.nres, hmm.max_length)
+        assert th.targets(fs_pipe=fs) == block
