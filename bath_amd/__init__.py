@@ -177,6 +177,7 @@ ABI = {
     "bath_tophits_reported": (C.c_int64, [_vp]),
     "bath_tophits_get": (C.c_int, [_vp, C.c_int64, C.POINTER(FsDomain), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     "bath_tophits_targets": (C.c_int64, [_vp, C.c_int, C.c_int, C.c_char_p, C.c_int64]),
+    "bath_tophits_domain_annotation": (C.c_int64, [_vp, C.c_int64, C.c_int, C.c_int, C.c_char_p, C.c_int64]),
     "bath_tophits_set_inclusion": (None, [_vp, C.c_double]),
     "bath_tophits_tabular_targets": (C.c_int64, [_vp, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int64]),
     "bath_hip_pipeline_hits": (C.c_int, [_vp, _vp, _vp, C.POINTER(PipelineParams), C.c_double, C.POINTER(PipelineStats),
@@ -648,6 +649,17 @@ class TopHits:
         buf = C.create_string_buffer(n + 1)
         lib().bath_tophits_tabular_targets(*args, buf, n)
         return buf.raw[:n].decode()
+
+    def annotations(self, M, fs_pipe=False):
+        """Per reported hit, in rank order: the head of its 'Annotation for each hit' entry (p7_tophits_Domains)."""
+        out = []
+        for r in range(lib().bath_tophits_count(self._h)):
+            n = lib().bath_tophits_domain_annotation(self._h, r, M, int(fs_pipe), None, 0)
+            if n > 0:
+                buf = C.create_string_buffer(n + 1)
+                lib().bath_tophits_domain_annotation(self._h, r, M, int(fs_pipe), buf, n)
+                out.append(buf.raw[:n].decode())
+        return out
 
     def targets(self, fs_pipe=False, textw=120):
         """The 'Scores for complete hits' block of bathsearch's main output (p7_tophits_Targets)."""

@@ -262,3 +262,35 @@ extern "C" int64_t bath_tophits_targets(const bath_tophits *th, int fs_pipe, int
   if (buf && cap > 0) std::memcpy(buf, out.data(), (size_t)std::min<int64_t>(cap, (int64_t)out.size()));
   return (int64_t)out.size();
 }
+
+// The head of a hit's entry in "Annotation for each hit" (p7_tophits_Domains, p7_tophits.c:1256-1378; search mode, not spliced):
+// the ">> name  description" line, the two header lines and the hit's line.  The alignment block that follows in the reference's
+// output (p7_alidisplay_Print_BATH) is not produced.  <rank>: position in the current sort order; returns 0 for a hit that is
+// not reported, else the size in bytes.
+extern "C" int64_t bath_tophits_domain_annotation(const bath_tophits *th, int64_t rank, int M, int fs_pipe, char *buf, int64_t cap) {
+  if (!th || rank < 0 || rank >= (int64_t)th->unsrt.size()) return -1;
+  const Hit &h = th->unsrt[(size_t)(th->order.empty() ? rank : th->order[(size_t)rank])];
+  if (!(h.flags & IS_REPORTED)) return 0;
+  std::string out;
+  appendf(out, ">> %s  %s\n", h.name.c_str(), h.desc.c_str());
+  if (fs_pipe) {
+    appendf(out, "   %6s %5s %9s %10s %9s    %9s %9s    %6s  %5s %9s   %4s\n", "score", "bias", "   Evalue", "hmm-from", " hmm-to", " ali-from", "   ali-to", "shifts", "stops", "   sq-len", "acc");
+    appendf(out, "   %6s %5s %9s %10s %9s    %9s %9s    %6s  %5s %9s   %4s\n", "------", "-----", "---------", "--------", "-------", "---------", "---------", "------", "-----", "---------", "----");
+  } else {
+    appendf(out, "   %6s %5s %9s %10s %9s    %9s %9s    %9s   %4s\n", "score", "bias", "   Evalue", "hmm-from", " hmm-to", " ali-from", "   ali-to", "   sq-len", "acc");
+    appendf(out, "   %6s %5s %9s %10s %9s    %9s %9s    %9s   %4s\n", "------", "-----", "---------", "--------", "-------", "---------", "---------", "---------", "----");
+  }
+  const double kLog2R = 1.44269504088896341;
+  const double acc = h.d.oasc / (1.0 + std::fabs((float)(h.d.jenv - h.d.ienv) / 3));
+  const char inc = (h.flags & IS_INCLUDED) ? '!' : '?';
+  const char h1 = h.d.ihmm == 1 ? '[' : '.', h2 = h.d.jhmm == M ? ']' : '.';
+  const char s1 = h.d.iali == 1 ? '[' : '.', s2 = (int64_t)h.d.jali == h.target_len ? ']' : '.';
+  if (fs_pipe)
+    appendf(out, " %c %6.1f %5.1f %9.2g %10d %9d %c%c %9" PRId64 " %9" PRId64 " %c%c %6d  %5d %9" PRId64 "   %4.2f\n", inc, h.d.bitscore, h.d.dombias * kLog2R, std::exp(h.d.lnP), h.d.ihmm,
+            h.d.jhmm, h1, h2, (int64_t)h.d.iali, (int64_t)h.d.jali, s1, s2, h.d.n_shifted_codons, h.d.n_stops, h.target_len, acc);
+  else
+    appendf(out, " %c %6.1f %5.1f %9.2g %10d %9d %c%c %9" PRId64 " %9" PRId64 " %c%c %9" PRId64 "   %4.2f\n", inc, h.d.bitscore, h.d.dombias * kLog2R, std::exp(h.d.lnP), h.d.ihmm, h.d.jhmm, h1, h2,
+            (int64_t)h.d.iali, (int64_t)h.d.jali, s1, s2, h.target_len, acc);
+  if (buf && cap > 0) std::memcpy(buf, out.data(), (size_t)std::min<int64_t>(cap, (int64_t)out.size()));
+  return (int64_t)out.size();
+}

@@ -301,6 +301,9 @@ int  bath_tophits_get(const bath_tophits *th, int64_t rank, bath_fs_domain *dom,
 /* Returns the table's size in bytes and copies at most <cap> of them to <buf>. */
 /* p7_tophits_Targets (:1073): the "Scores for complete hits" block of the main output; textw = --textw (120; <= 0 unlimited). */
 int64_t bath_tophits_targets(const bath_tophits *th, int fs_pipe, int textw, char *buf, int64_t cap);
+/* Head of the rank-th hit's entry under "Annotation for each hit" (p7_tophits_Domains, :1256-1378): ">> name", the two header
+ * lines and the hit's line; 0 for a hit that is not reported.  The alignment block itself is not produced. */
+int64_t bath_tophits_domain_annotation(const bath_tophits *th, int64_t rank, int M, int fs_pipe, char *buf, int64_t cap);
 void bath_tophits_set_inclusion(bath_tophits *th, double incE);   /* --incE, default 0.01; before finalize */
 #define BATH_HIT_INCLUDED  2
 int64_t bath_tophits_tabular_targets(const bath_tophits *th, const char *qname, const char *qacc, int M, int fs_pipe,

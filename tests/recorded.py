@@ -49,3 +49,9 @@ def targets_blocks(outfile):
             i = j
         i += 1
     return blocks
+
+
+def annotation_heads(outfile):
+    """For every hit of a recorded output: '>> name  desc', the two header lines and the hit's line."""
+    lines = open(ol.GOLDEN + "/" + outfile).read().split("\n")
+    return ["\n".join(lines[i:i + 4]) + "\n" for i in range(len(lines)) if lines[i].startswith(">> ")]

@@ -65,3 +65,26 @@ def test_targets_block_matches_recorded_output(outfile, hmmfile, fasta, fs):
     th.add(dm, [n.split()[0] for n, _ in recs], [len(s) for s in seqs])
     th.finalize(stats.nres, hmm.max_length)
     assert th.targets(fs_pipe=fs) == recorded.targets_blocks(outfile)[0]
+
+
+@pytest.mark.parametrize("outfile,hmmfile,fasta,fs", [("PTH2.out", "PTH2.bhmm", "target-PTH2.fa", False), ("AMP_N-fs.out", "AMP_N.bhmm", "target-AMP_N.fa", True)])
+def test_annotation_heads_match_recorded_output(outfile, hmmfile, fasta, fs):
+    """'>> name', header lines and hit line of every entry under 'Annotation for each hit', byte for byte, from the GPU path."""
+    import recorded
+    ctx = ba.Context(0)
+    hmm = ba.HMM(ol.GOLDEN + "/" + hmmfile, 0)
+    recs = ol.read_fasta(ol.GOLDEN + "/" + fasta)
+    seqs = [ba.digitize(s, ba.DNA_SYMS) for _, s in recs]
+    om = ba.OProfile(ctx, ba.Profile(hmm))
+    pipe = ba.Pipeline(ctx, om, fs_pipe=fs, ncbi_table=hmm.ct)
+    block = ba.SeqBlock(ctx, seqs)
+    if fs:
+        om3 = ba.FSOProfile(ctx, ba.FSProfile(hmm, 3, ncbi_table=hmm.ct))
+        om5 = ba.FSOProfile(ctx, ba.FSProfile(hmm, 5, ncbi_table=hmm.ct))
+        stats, _, dm, _ = pipe.run_frameshift_domains(om3, om5, block)
+    else:
+        stats, dm, _ = pipe.run_hits(block)
+    th = ba.TopHits()
+    th.add(dm, [n.split()[0] for n, _ in recs], [len(s) for s in seqs])
+    th.finalize(stats.nres, hmm.max_length)
+    assert th.annotations(hmm.M, fs_pipe=fs) == recorded.annotation_heads(outfile)

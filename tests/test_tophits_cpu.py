@@ -145,3 +145,24 @@ def test_targets_block_matches_recorded_output(outfile, hmmfile, fasta, fs):
         th.add(doms, [n.split()[0] for n, _ in recs], [len(s) for s in seqs])
         th.finalize(pli.nres, hmm.max_length)
         assert th.targets(fs_pipe=fs) == block
+
+
+@pytest.mark.parametrize("outfile,hmmfile,fasta,fs", [("PTH2.out", "PTH2.bhmm", "target-PTH2.fa", False), ("AMP_N-fs.out", "AMP_N.bhmm", "target-AMP_N.fa", True)])
+def test_annotation_heads_match_recorded_output(outfile, hmmfile, fasta, fs):
+    """'>> seq1', header lines and the hit line of each entry under 'Annotation for each hit', byte for byte, for the two
+    recorded outputs written by the reference version in /root/reference (the other two predate a column change)."""
+    m = ol.Model(ol.GOLDEN + "/" + hmmfile, 0)
+    hmm = ba.HMM(ol.GOLDEN + "/" + hmmfile, 0)
+    recs = ol.read_fasta(ol.GOLDEN + "/" + fasta)
+    seqs = [ol.digitize_dna(s) for _, s in recs]
+    if fs:
+        pli, _, _, odm, per_d, _ = m.run_pipeline_fsdom(seqs)
+    else:
+        pli, odm, per_d, _ = m.run_pipeline_hits(seqs)
+    doms = [from_oracle(o, w) for w, (a, b) in enumerate(per_d) for o in odm[a:b]]
+    for d in doms:
+        d.n_stops = 1 if fs else 0
+    th = ba.TopHits()
+    th.add(doms, [n.split()[0] for n, _ in recs], [len(s) for s in seqs])
+    th.finalize(pli.nres, hmm.max_length)
+    assert th.annotations(hmm.M, fs_pipe=fs) == recorded.annotation_heads(outfile)
