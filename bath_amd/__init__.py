@@ -178,6 +178,7 @@ ABI = {
     "bath_tophits_get": (C.c_int, [_vp, C.c_int64, C.POINTER(FsDomain), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     "bath_tophits_targets": (C.c_int64, [_vp, C.c_int, C.c_int, C.c_char_p, C.c_int64]),
     "bath_tophits_domain_annotation": (C.c_int64, [_vp, C.c_int64, C.c_int, C.c_int, C.c_char_p, C.c_int64]),
+    "bath_tophits_pipeline_statistics": (C.c_int64, [_vp, C.POINTER(PipelineStats), C.POINTER(PipelineParams), C.c_int64, C.c_int64, C.c_int64, C.c_char_p, C.c_int64]),
     "bath_tophits_set_inclusion": (None, [_vp, C.c_double]),
     "bath_tophits_tabular_targets": (C.c_int64, [_vp, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int64]),
     "bath_hip_pipeline_hits": (C.c_int, [_vp, _vp, _vp, C.POINTER(PipelineParams), C.c_double, C.POINTER(PipelineStats),
@@ -660,6 +661,14 @@ class TopHits:
                 lib().bath_tophits_domain_annotation(self._h, r, M, int(fs_pipe), buf, n)
                 out.append(buf.raw[:n].decode())
         return out
+
+    def statistics(self, stats, params, nmodels, nnodes, nseqs):
+        """The 'Internal pipeline statistics summary' block of the main output, without its timing lines (p7_pli_Statistics)."""
+        args = (self._h, C.byref(stats), C.byref(params), nmodels, nnodes, nseqs)
+        n = lib().bath_tophits_pipeline_statistics(*args, None, 0)
+        buf = C.create_string_buffer(n + 1)
+        lib().bath_tophits_pipeline_statistics(*args, buf, n)
+        return buf.raw[:n].decode()
 
     def targets(self, fs_pipe=False, textw=120):
         """The 'Scores for complete hits' block of bathsearch's main output (p7_tophits_Targets)."""

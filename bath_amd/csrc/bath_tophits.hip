@@ -294,3 +294,26 @@ extern "C" int64_t bath_tophits_domain_annotation(const bath_tophits *th, int64_
   if (buf && cap > 0) std::memcpy(buf, out.data(), (size_t)std::min<int64_t>(cap, (int64_t)out.size()));
   return (int64_t)out.size();
 }
+
+// p7_pli_Statistics (p7_pipeline.c:1836-1873) for a finished search: the "Internal pipeline statistics summary" block of the main
+// output without its two timing lines.  n_output / pos_output are taken over the reported hits as bathsearch.c:950-957 does.
+extern "C" int64_t bath_tophits_pipeline_statistics(const bath_tophits *th, const bath_pipeline_stats *st, const bath_pipeline_params *prm, int64_t nmodels,
+                                                    int64_t nnodes, int64_t nseqs, char *buf, int64_t cap) {
+  if (!th || !st || !prm) return -1;
+  int64_t n_output = 0, pos_output = 0;
+  for (const Hit &h : th->unsrt)
+    if ((h.flags & IS_REPORTED) && !(h.flags & IS_DUPLICATE)) { n_output++; pos_output += 1 + (h.d.jali > h.d.iali ? h.d.jali - h.d.iali : h.d.iali - h.d.jali); }
+  const double denom = (double)(st->nres * nmodels);
+  std::string out;
+  appendf(out, "Internal pipeline statistics summary:\n");
+  appendf(out, "-------------------------------------\n");
+  appendf(out, "Query model(s):              %15" PRId64 "  (%" PRId64 " nodes)\n", nmodels, nnodes);
+  appendf(out, "Target %-12s          %15" PRId64 "  (%" PRId64 " residues searched)\n", "sequence(s):", nseqs, (int64_t)st->nres);
+  appendf(out, "Residues passing SSV filter: %15" PRId64 "  (%.3g); expected (%.3g)\n", (int64_t)st->pos_past_msv, (double)st->pos_past_msv / denom, prm->F1);
+  appendf(out, "Residues passing bias filter:%15" PRId64 "  (%.3g); expected (%.3g)\n", (int64_t)st->pos_past_bias, (double)st->pos_past_bias / denom, prm->F1);
+  appendf(out, "Residues passing Vit filter: %15" PRId64 "  (%.3g); expected (%.3g)\n", (int64_t)st->pos_past_vit, (double)st->pos_past_vit / denom, prm->F2);
+  appendf(out, "Residues passing Fwd filter: %15" PRId64 "  (%.3g); expected (%.3g)\n", (int64_t)st->pos_past_fwd, (double)st->pos_past_fwd / denom, prm->F3);
+  appendf(out, "Total number of hits:        %15d  (%.3g)\n", (int)n_output, (double)pos_output / denom);
+  if (buf && cap > 0) std::memcpy(buf, out.data(), (size_t)std::min<int64_t>(cap, (int64_t)out.size()));
+  return (int64_t)out.size();
+}

@@ -304,6 +304,9 @@ int64_t bath_tophits_targets(const bath_tophits *th, int fs_pipe, int textw, cha
 /* Head of the rank-th hit's entry under "Annotation for each hit" (p7_tophits_Domains, :1256-1378): ">> name", the two header
  * lines and the hit's line; 0 for a hit that is not reported.  The alignment block itself is not produced. */
 int64_t bath_tophits_domain_annotation(const bath_tophits *th, int64_t rank, int M, int fs_pipe, char *buf, int64_t cap);
+/* p7_pli_Statistics (p7_pipeline.c:1836): the "Internal pipeline statistics summary" block without its two timing lines. */
+int64_t bath_tophits_pipeline_statistics(const bath_tophits *th, const bath_pipeline_stats *stats, const bath_pipeline_params *params,
+                                         int64_t nmodels, int64_t nnodes, int64_t nseqs, char *buf, int64_t cap);
 void bath_tophits_set_inclusion(bath_tophits *th, double incE);   /* --incE, default 0.01; before finalize */
 #define BATH_HIT_INCLUDED  2
 int64_t bath_tophits_tabular_targets(const bath_tophits *th, const char *qname, const char *qacc, int M, int fs_pipe,

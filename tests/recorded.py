@@ -55,3 +55,9 @@ def annotation_heads(outfile):
     """For every hit of a recorded output: '>> name  desc', the two header lines and the hit's line."""
     lines = open(ol.GOLDEN + "/" + outfile).read().split("\n")
     return ["\n".join(lines[i:i + 4]) + "\n" for i in range(len(lines)) if lines[i].startswith(">> ")]
+
+
+def statistics_blocks(outfile):
+    """'Internal pipeline statistics summary' of every query, without the two timing lines."""
+    lines = open(ol.GOLDEN + "/" + outfile).read().split("\n")
+    return ["\n".join(lines[i:i + 9]) + "\n" for i in range(len(lines)) if lines[i].startswith("Internal pipeline statistics summary")]

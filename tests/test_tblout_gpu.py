@@ -88,3 +88,5 @@ def test_annotation_heads_match_recorded_output(outfile, hmmfile, fasta, fs):
     th.add(dm, [n.split()[0] for n, _ in recs], [len(s) for s in seqs])
     th.finalize(stats.nres, hmm.max_length)
     assert th.annotations(hmm.M, fs_pipe=fs) == recorded.annotation_heads(outfile)
+    # ... and the 'Internal pipeline statistics summary' block from the GPU path's counters
+    assert th.statistics(stats, pipe.params, 1, hmm.M, len(seqs)) == recorded.statistics_blocks(outfile)[0]

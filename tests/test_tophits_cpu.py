@@ -166,3 +166,28 @@ def test_annotation_heads_match_recorded_output(outfile, hmmfile, fasta, fs):
     th.add(doms, [n.split()[0] for n, _ in recs], [len(s) for s in seqs])
     th.finalize(pli.nres, hmm.max_length)
     assert th.annotations(hmm.M, fs_pipe=fs) == recorded.annotation_heads(outfile)
+
+
+@pytest.mark.parametrize("outfile,hmmfile,fasta,fs", recorded.RUNS, ids=[r[0] for r in recorded.RUNS])
+def test_statistics_block_matches_recorded_output(outfile, hmmfile, fasta, fs):
+    """The 'Internal pipeline statistics summary' block (counters, fractions, hit count and covered fraction), byte for byte."""
+    want = recorded.statistics_blocks(outfile)
+    recs = ol.read_fasta(ol.GOLDEN + "/" + fasta)
+    seqs = [ol.digitize_dna(s) for _, s in recs]
+    for q, block in enumerate(want):
+        m = ol.Model(ol.GOLDEN + "/" + hmmfile, q)
+        hmm = ba.HMM(ol.GOLDEN + "/" + hmmfile, q)
+        if fs:
+            pli, _, _, odm, per_d, _ = m.run_pipeline_fsdom(seqs)
+        else:
+            pli, odm, per_d, _ = m.run_pipeline_hits(seqs)
+        doms = [from_oracle(o, w) for w, (a, b) in enumerate(per_d) for o in odm[a:b]]
+        th = ba.TopHits()
+        th.add(doms, [n.split()[0] for n, _ in recs], [len(s) for s in seqs])
+        th.finalize(pli.nres, hmm.max_length)
+        st = ba.PipelineStats()
+        for f in ("nres", "pos_past_msv", "pos_past_bias", "pos_past_vit", "pos_past_fwd"):
+            setattr(st, f, getattr(pli, f))
+        prm = ba.PipelineParams()
+        ba.lib().bath_pipeline_params_default(C.byref(prm), 1 if fs else 0)
+        assert th.statistics(st, prm, 1, hmm.M, len(seqs)) == block
