@@ -265,6 +265,7 @@ static int fs_branch_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, con
     }
     const FsTraceOut &tq = traces[(size_t)e];
     if (!tq.ok) continue;
+    if (tq.aliscore < 0.0f) continue;                                          // p7_domaindef.c:1072: "repetitive garbage", no domain
     bath_fs_domain dm{};
     dm.window = win.window; dm.strand = win.strand; dm.fs_window = sel[(size_t)en.sel];
     // window coordinates first (:1148-1163), then the sequence's (p7_pipeline.c:1035-1049); envelope i..j in the window
@@ -385,7 +386,7 @@ __global__ void std_regions_kernel(int64_t n, const int32_t *__restrict__ len, c
   out[0] = min(nreg, kStdMaxRegions);
 }
 
-struct StdEnvOut { int32_t i1, k1, i2, k2, ok; float oasc, domcorrection; int32_t ncol, exact; };
+struct StdEnvOut { int32_t i1, k1, i2, k2, ok; float oasc, domcorrection; int32_t ncol, exact; float aliscore; };
 
 // p7_Decoding + p7_OptimalAccuracy + p7_OATrace + p7_Null2_ByExpectation on one envelope per lane (unihit model).
 // fwd / bck: (L+1) x (M+1) x {M, D, I}; on return bck holds the posteriors and fwd the OA matrix, as in the reference.
@@ -393,7 +394,9 @@ __global__ void std_envelope_kernel(SeqView sq, int M, const float *__restrict__
                                     const int64_t *__restrict__ dp_off, const float *__restrict__ fx, const float *__restrict__ bx, const int64_t *__restrict__ x_off,
                                     float *__restrict__ ppx_all, float *__restrict__ oax_all, float *__restrict__ em_all /* [n][2*(M+1)] */, StdEnvOut *__restrict__ out,
                                     const uint8_t *__restrict__ cons /* [M+1] or null */, uint8_t *__restrict__ tbuf, const int64_t *__restrict__ t_off,
-                                    int filled /* std_envelope_fill_kernel already did decoding, OA fill and null2: traceback only */) {
+                                    int filled /* std_envelope_fill_kernel already did decoding, OA fill and null2: traceback only */,
+                                    const float *__restrict__ msc /* [Kp][M+1] log-odds */, const float *__restrict__ tsc /* [M][8] log */,
+                                    const uint8_t *__restrict__ nt /* the DNA block */, const int64_t *__restrict__ nt_base, const int64_t *__restrict__ nt_dir) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= sq.n) return;
   enum { XE = 0, XN, XJ, XB, XC, XS };
@@ -406,7 +409,7 @@ __global__ void std_envelope_kernel(SeqView sq, int M, const float *__restrict__
   float *F = fwd + dp_off[t], *Bk = bck + dp_off[t];
   const float *FX = fx + x_off[t], *BX = bx + x_off[t];
   float *PX = ppx_all + (x_off[t] / 6) * 5, *OX = oax_all + (x_off[t] / 6) * 5;
-  StdEnvOut r{-1, -1, -1, -1, 0, 0.f, 0.f, 0, 0};
+  StdEnvOut r{-1, -1, -1, -1, 0, 0.f, 0.f, 0, 0, 0.f};
   const float ploop = 1.0f - 2.0f / ((float)L + 2.0f);                       // unihit: xf[N|J|C][LOOP]
   const float *P = Bk;
   float *O = F;
@@ -527,6 +530,34 @@ __global__ void std_envelope_kernel(SeqView sq, int M, const float *__restrict__
       if (++steps > 4 * (L + M) + 64) bad = true;
     }
     if (bad || r.i1 <= 0) { out[t] = r; return; }
+    // ---- p7_pli_computeAliScores_BATH (p7_pipeline.c:781-979) on the columns, first to last match state: the emission score of
+    // each codon's amino acid (X for a codon with a degenerate nucleotide, p7P_DEGEN5_C) plus the transition that entered the
+    // state; the last match state gets no MM transition (the reference's inner loops stop at z1 < z2).  Negative total: the
+    // caller drops the domain (p7_domaindef.c:1286).
+    if (msc && r.ncol <= cap) {
+      const size_t W1 = (size_t)M + 1;
+      const int64_t base = nt_base[t], dir = nt_dir[t];
+      float total = 0.f;
+      int prev = sB, kk = r.k1 - 1, ii = r.i1 - 1;
+      for (int idx = r.ncol - 1; idx >= 0; idx--) {
+        const int s = T[idx];
+        float sc;
+        if (s == sM) {
+          kk++; ii++;
+          int amino = min((int)dsq[ii], kKp - 1);
+          const int64_t c0 = base + dir * (int64_t)(3 * (ii - 1));
+          if (nt[c0] >= 4 || nt[c0 + dir] >= 4 || nt[c0 + 2 * dir] >= 4) amino = 26;
+          sc = msc[(size_t)amino * W1 + kk];
+          if (prev == sI) sc += tsc[(size_t)(kk - 1) * 8 + IM];
+          else if (prev == sD) sc += tsc[(size_t)(kk - 1) * 8 + DM];
+          else if (prev == sM && idx > 0) sc += tsc[(size_t)(kk - 1) * 8 + MM];
+        } else if (s == sI) { ii++; sc = tsc[(size_t)kk * 8 + (prev == sI ? II : MI)]; }
+        else { kk++; sc = tsc[(size_t)(kk - 1) * 8 + (prev == sD ? DD : MD)]; }
+        total += sc;
+        prev = s;
+      }
+      r.aliscore = total;
+    }
   }
   // ---- p7_Null2_ByExpectation (null2.c:50-124) and the correction over the envelope (p7_domaindef.c:1264-1272)
   if (!filled) {
@@ -865,11 +896,21 @@ static int std_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bat
   BATH_HIP_TRY(ctx, b_dpo.reserve((size_t)(ne + 1) * 8)); BATH_HIP_TRY(ctx, b_fx.reserve((size_t)exoff[(size_t)ne] * 4 + 64)); BATH_HIP_TRY(ctx, b_bx.reserve((size_t)exoff[(size_t)ne] * 4 + 64));
   BATH_HIP_TRY(ctx, b_px.reserve((size_t)exoff[(size_t)ne] / 6 * 5 * 4 + 64)); BATH_HIP_TRY(ctx, b_ox.reserve((size_t)exoff[(size_t)ne] / 6 * 5 * 4 + 64));
   BATH_HIP_TRY(ctx, b_em.reserve((size_t)ne * 2 * (M + 1) * 4 + 64)); BATH_HIP_TRY(ctx, b_out.reserve((size_t)ne * sizeof(StdEnvOut) + 64));
-  std::vector<int64_t> toff((size_t)ne + 1, 0);
-  for (int64_t e = 0; e < ne; e++) toff[(size_t)e + 1] = toff[(size_t)e] + ev.h_len[(size_t)e] + M + 2;
+  // toff: the envelopes' slices of the column buffer; then, per envelope, where the codon of its first residue starts in the DNA
+  // block and which way the strand runs (for the degenerate-codon test of the alignment score)
+  std::vector<int64_t> toff((size_t)ne + 1 + 2 * (size_t)ne, 0);
+  for (int64_t e = 0; e < ne; e++) {
+    toff[(size_t)e + 1] = toff[(size_t)e] + ev.h_len[(size_t)e] + M + 2;
+    const Env &en = envs[(size_t)e];
+    const PipelineSurvivor &o = surv[(size_t)en.s];
+    const int64_t p = (int64_t)o.start + 3 * (int64_t)(en.i - 1);           // strand position (1-based) of that codon's first nucleotide
+    const int64_t woff = dna->h_off[(size_t)o.window], wn = dna->h_len[(size_t)o.window];
+    toff[(size_t)ne + 1 + (size_t)e] = o.strand ? woff + wn - p : woff + p - 1;
+    toff[(size_t)ne + 1 + (size_t)ne + (size_t)e] = o.strand ? -1 : 1;
+  }
   DevBuf &b_tb = ctx->scratch[10], &b_toff = ctx->scratch[13];
-  BATH_HIP_TRY(ctx, b_tb.reserve((size_t)toff[(size_t)ne] + 64)); BATH_HIP_TRY(ctx, b_toff.reserve((size_t)(ne + 1) * 8));
-  BATH_HIP_TRY(ctx, hipMemcpyAsync(b_toff.p, toff.data(), (size_t)(ne + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+  BATH_HIP_TRY(ctx, b_tb.reserve((size_t)toff[(size_t)ne] + 64)); BATH_HIP_TRY(ctx, b_toff.reserve(toff.size() * 8));
+  BATH_HIP_TRY(ctx, hipMemcpyAsync(b_toff.p, toff.data(), toff.size() * 8, hipMemcpyHostToDevice, ctx->stream));
   BATH_HIP_TRY(ctx, b_sc.reserve((size_t)ne * 8)); BATH_HIP_TRY(ctx, b_st.reserve((size_t)ne * 8));
   BATH_HIP_TRY(ctx, hipMemcpyAsync(b_dpo.p, dpoff.data(), (size_t)(ne + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
   if ((st = launch_fwd_wave(ctx, om, ev.view(), nullptr, ne, b_sc.as<float>(), b_st.as<int32_t>(), nullptr, b_fx.as<float>(), d_exoff, b_f.as<float>(), b_dpo.as<int64_t>(), 1)) != BATH_OK) return st;
@@ -892,7 +933,8 @@ static int std_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bat
   }
   hipLaunchKernelGGL(std_envelope_kernel, dim3((unsigned)((ne + 63) / 64)), dim3(64), 0, ctx->stream, ev.view(), M, om->d_tf, om->d_rf, b_f.as<float>(), b_b.as<float>(), b_dpo.as<int64_t>(),
                      b_fx.as<float>(), b_bx.as<float>(), d_exoff, b_px.as<float>(), b_ox.as<float>(), b_em.as<float>(), b_out.as<StdEnvOut>(),
-                     om->d_cons, b_tb.as<uint8_t>(), b_toff.as<int64_t>(), filled);
+                     om->d_cons, b_tb.as<uint8_t>(), b_toff.as<int64_t>(), filled,
+                     om->d_msc, om->d_tsc, dna->d_data, b_toff.as<int64_t>() + ne + 1, b_toff.as<int64_t>() + 2 * ne + 1);
   BATH_HIP_TRY(ctx, hipGetLastError());
   std::vector<StdEnvOut> eo((size_t)ne);
   std::vector<float> envsc((size_t)ne);
@@ -909,6 +951,7 @@ static int std_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bat
   for (int64_t e = 0; e < ne; e++) {
     const StdEnvOut &t = eo[(size_t)e];
     if (!t.ok) continue;
+    if (t.aliscore < 0.0f) continue;                                         // p7_domaindef.c:1286: "repetitive garbage", no domain
     const Env &en = envs[(size_t)e];
     const PipelineSurvivor &o = surv[(size_t)en.s];
     const int seq_n = dna->h_len[(size_t)o.window];

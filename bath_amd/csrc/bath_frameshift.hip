@@ -754,7 +754,8 @@ __global__ void fs5_trace_kernel(SeqView dna, int M, int maxcodons, const float 
                                  const float *__restrict__ pp, const int64_t *__restrict__ pp_off, const float *__restrict__ px, const int64_t *__restrict__ x_off,
                                  const float *__restrict__ oa, const int64_t *__restrict__ oa_off, const float *__restrict__ ox,
                                  const float *__restrict__ null2 /* [n][Kp] */, uint2 *__restrict__ tbuf, const int64_t *__restrict__ t_off, FsTraceOut *__restrict__ out,
-                                 const uint8_t *__restrict__ indel_tab, const uint8_t *__restrict__ cons, uint16_t *__restrict__ steps) {
+                                 const uint8_t *__restrict__ indel_tab, const uint8_t *__restrict__ cons, uint16_t *__restrict__ steps,
+                                 const float *__restrict__ amino /* rsc + maxcodons*pitch: the amino rows */, int pitch) {
   const int64_t job = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (job >= dna.n) return;
   enum { sS = 0, sN, sB, sM, sD, sI, sE, sJ, sC, sT };
@@ -765,7 +766,7 @@ __global__ void fs5_trace_kernel(SeqView dna, int M, int maxcodons, const float 
   const float *P = pp + pp_off[job], *PX = px + x_off[job], *O = oa + oa_off[job], *OX = ox + x_off[job];
   uint2 *T = tbuf + t_off[job];
   const int cap = (int)(t_off[job + 1] - t_off[job]);
-  FsTraceOut r{0, 0, 0, 0, 0, 0, 0.f, 0, 0, 0};
+  FsTraceOut r{0, 0, 0, 0, 0, 0, 0.f, 0, 0, 0, 0.f};
   auto dl = [&](int node, int s) { return (node >= 1 && node <= M && tf[(size_t)node * 8 + s] != -INFINITY) ? 1.0f : kTiny; };
   auto OM = [&](int i, int k) { return O[((size_t)i * (M + 1) + k) * 3 + 2]; };
   auto OI = [&](int i, int k) { return O[((size_t)i * (M + 1) + k) * 3 + 1]; };
@@ -882,9 +883,16 @@ __global__ void fs5_trace_kernel(SeqView dna, int M, int maxcodons, const float 
       // state, codon length and indel type (for --cigar), identities with the consensus, stop codons
       uint16_t *S = steps ? steps + t_off[job] : nullptr;
       r.ncol = z2 - z1 + 1;
+      // ... and p7_pli_computeAliScores_BATH (p7_pipeline.c:781-979): per column the amino row score of the quasi-codon's best
+      // amino acid plus the transition that entered the state (the last match state gets no MM: inner loops stop at z1 < z2)
+      float ali = 0.f;
+      int prevs = sB;
       for (int zz = z1; zz <= z2; zz++) {
         const int s = st_of(zz), cc = (s == sM) ? c_of(zz) : (s == sI ? 3 : 0), kk = k_of(zz), ii = i_of(zz);
         unsigned code = (unsigned)s;
+        float colsc = 0.f;
+        if (s == sI) colsc = tf[(size_t)kk * 8 + (prevs == sI ? 7 : 6)];
+        else if (s == sD) colsc = tf[(size_t)(kk - 1) * 8 + (prevs == sD ? 5 : 4)];
         if (cc > 0 && ii - cc + 1 >= 1 && ii <= L) {
           int nn[5] = {0, 0, 0, 0, 0};
           bool degen = false;
@@ -902,9 +910,18 @@ __global__ void fs5_trace_kernel(SeqView dna, int M, int maxcodons, const float 
           if (stop) r.nstops++;
           if (s == sM && cons && codons[(size_t)kk * maxcodons + ci] == cons[kk]) r.exact++;
           code |= (unsigned)cc << 4 | (unsigned)indel << 8;
+          if (s == sM && amino) {
+            colsc = amino[(size_t)codons[(size_t)kk * maxcodons + ci] * pitch + kk];
+            if (prevs == sI) colsc += tf[(size_t)kk * 8 + 1];
+            else if (prevs == sD) colsc += tf[(size_t)kk * 8 + 2];
+            else if (prevs == sM && zz < z2) colsc += tf[(size_t)kk * 8 + 0];
+          }
         }
+        ali += colsc;
+        prevs = s;
         if (S) S[zz - z1] = (uint16_t)code;
       }
+      r.aliscore = ali;
     }
   }
   out[job] = r;
@@ -1372,7 +1389,8 @@ int bath::fs5_envelopes_ex(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, cons
     BATH_HIP_TRY(ctx, hipMemcpyAsync(d_toff, toff.data(), (size_t)(n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(fs5_trace_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, dna->view(), M, om->maxcodons, om->d_tf, om->d_codons,
                        b_f.as<float>(), d_foff, b_fx.as<float>(), d_xoff, b_o.as<float>(), d_boff, b_ox.as<float>(), b_n2.as<float>(), b_tb.as<uint2>(), d_toff,
-                       b_to.as<FsTraceOut>(), om->d_indel, cons, steps ? b_steps.as<uint16_t>() : nullptr);
+                       b_to.as<FsTraceOut>(), om->d_indel, cons, steps ? b_steps.as<uint16_t>() : nullptr,
+                       om->d_rsc + (size_t)om->maxcodons * om->pitch, om->pitch);
     BATH_HIP_TRY(ctx, hipGetLastError());
     BATH_HIP_TRY(ctx, hipMemcpyAsync(trace, b_to.p, (size_t)n * sizeof(FsTraceOut), hipMemcpyDeviceToHost, ctx->stream));
     if (steps) {                                                // columns z1..z2 of envelope e: (*steps)[step_off[e] .. +trace[e].ncol)

@@ -70,6 +70,7 @@ const FsHostTables fsprofile_host(const bath_hip_fsprofile *om);
 struct FsTraceOut {               // what the pipeline keeps of an envelope's OA trace
   int32_t ihmm, jhmm, iali, jali, nshift, ok; float domcorrection;
   int32_t ncol, exact, nstops;    // alignment display: columns (first to last match state), identities with the consensus, stop codons
+  float aliscore;                 // p7_pli_computeAliScores_BATH: sum of the per-column scores; negative = the domain is dropped
 };
 // <cons>: device array [M+1] of consensus residue codes or nullptr; <steps>/<step_off>: per alignment column
 // state | codon length << 4 | indel label << 8 (columns of envelope e start at (*step_off)[e])

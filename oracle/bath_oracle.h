@@ -125,6 +125,10 @@ typedef struct {
   float    xf[4][2];
   float    evparam[BO_NEVPARAM];
   float    compo[BO_K_AMINO];
+  /* log-odds match scores [Kp][M+1] and log transitions [M+1][8] of the generic profile: what p7_pli_computeAliScores_BATH
+   * reads from gm_fs5 (its amino rows and tsc are the same numbers, modelconfig.c:313-318 vs :106-113) */
+  float   *msc;
+  float   *tsc;
 } bo_oprofile;
 
 /* ---------- background (p7_bg.c) ---------- */
@@ -321,7 +325,7 @@ void bo_oprofile_reconfig_unihit(bo_oprofile *om, int L);       /* p7_oprofile.c
 void bo_oprofile_reconfig_multihit(bo_oprofile *om, int L);     /* p7_oprofile.c:1395 */
 int  bo_domain_decoding(const bo_oprofile *om, const float *fx, const float *bx, int L, int own_scales, float *btot, float *etot, float *mocc); /* decoding.c:155 */
 int  bo_domaindef_std(bo_pipeline *pli, bo_oprofile *om, bo_bg *bg, const uint8_t *dsq, int n, int orf_start, int win_start,
-                      int complementarity, int seq_n, bo_fsdomain **doms, int *ndom, int *dalloc, int *nskipped);
+                      int complementarity, int seq_n, bo_fsdomain **doms, int *ndom, int *dalloc, int *nskipped, const uint8_t *strand_dsq);
 
 void bo_pipeline_init(bo_pipeline *pli, int fs_pipe);
 void  bo_local_compo(const bo_scoredata *sd, const bo_oprofile *om, const bo_bg *bg, int k_min, int k_max, float *compo); /* p7_pipeline.c:427 */

@@ -126,7 +126,7 @@ static float optimal_accuracy(const bo_oprofile *om, int L, const float *pp, con
 
 /* p7_OATrace, optacc.c:225-430: returns the first / last match state of the alignment (all the pipeline uses) */
 static int oa_trace(const bo_oprofile *om, int L, const float *pp, const float *ppx, const float *oa, const float *ox,
-                    int *i1, int *k1, int *i2, int *k2)
+                    int *i1, int *k1, int *i2, int *k2, int *path_st, int *path_k, int *path_i, int *path_n)
 {
   const int M = om->M;
   const size_t W = (size_t)(M + 1) * 3;
@@ -180,6 +180,9 @@ static int oa_trace(const bo_oprofile *om, int L, const float *pp, const float *
     }
     if (s1 == -1 || i < 0 || k < 0) return BO_EINVAL;
     if (s1 == BO_T_M) { if (*i2 < 0) { *i2 = i; *k2 = k; } *i1 = i; *k1 = k; }   /* walking backwards: last M first */
+    if ((s1 == BO_T_M || s1 == BO_T_D || s1 == BO_T_I) && *i2 >= 0) {            /* the alignment's states, last to first */
+      path_st[*path_n] = s1; path_k[*path_n] = k; path_i[*path_n] = i; (*path_n)++;
+    }
     if ((s1 == BO_T_N || s1 == BO_T_J || s1 == BO_T_C) && s1 == s0) i--;
     s0 = s1;
     if (++n > 4 * (L + M) + 64) return BO_EINVAL;
@@ -230,8 +233,44 @@ static void dom_push(bo_fsdomain **d, int *n, int *alloc, const bo_fsdomain *r)
 
 /* rescore_isolated_domain_bath, p7_domaindef.c:1194-1325: envelope i..j of dsq[1..n]; n2sc != NULL: null2_is_done (the region
  * went through stochastic-trace clustering and its per-residue null2 scores are already there) */
+/* p7_pli_computeAliScores_BATH, p7_pipeline.c:781-979, for an amino trace (every match state has a 3-nt codon): sum over the
+ * aligned columns, first to last match state, of the emission score of the codon's amino acid (X when the codon holds a
+ * degenerate nucleotide: p7P_DEGEN5_C) plus the transition that entered the state.  Quirk kept: the last match state gets
+ * no MM transition (the inner loops stop at z1 < z2, :899).  path_*: the columns, last to first; deg[a]: codon of ORF
+ * residue a (1-based) holds a degenerate nucleotide. */
+int bo_aliscore_drops = 0;
+float bo_aliscore_min = 1e30f;             /* test hook: smallest aliscore seen */                /* test hook: envelopes dropped by the aliscore < 0 rule (both branches) */
+
+static float std_aliscore(const bo_oprofile *om, const uint8_t *dsq, int off, const int *st, const int *pk, const int *pi, int n,
+                          const uint8_t *strand_dsq, int orf_start)
+{
+  const size_t W = (size_t) om->M + 1;
+  float total = 0.0f;
+  int prev = BO_T_B;
+  for (int z = n - 1; z >= 0; z--) {
+    const int k = pk[z];
+    float sc;
+    if (st[z] == BO_T_M) {
+      const int a = pi[z] + off;                                  /* ORF residue */
+      int amino = dsq[a];
+      if (strand_dsq) {
+        const int p = orf_start + 3 * (a - 1);
+        if (strand_dsq[p] >= 4 || strand_dsq[p + 1] >= 4 || strand_dsq[p + 2] >= 4) amino = 26;   /* codons[k][p7P_DEGEN5_C] = X */
+      }
+      sc = om->msc[(size_t) amino * W + k];
+      if      (prev == BO_T_I) sc += om->tsc[(k - 1) * BO_NTRANS + BO_IM];
+      else if (prev == BO_T_D) sc += om->tsc[(k - 1) * BO_NTRANS + BO_DM];
+      else if (prev == BO_T_M && z > 0) sc += om->tsc[(k - 1) * BO_NTRANS + BO_MM];
+    } else if (st[z] == BO_T_I) sc = om->tsc[k * BO_NTRANS + (prev == BO_T_I ? BO_II : BO_MI)];
+    else                        sc = om->tsc[(k - 1) * BO_NTRANS + (prev == BO_T_D ? BO_DD : BO_MD)];
+    total += sc;
+    prev = st[z];
+  }
+  return total;
+}
+
 static void rescore_envelope(bo_oprofile *om, const uint8_t *dsq, int i, int j, int orf_start, int win_start, const float *n2sc,
-                             bo_fsdomain **doms, int *ndom, int *dalloc)
+                             bo_fsdomain **doms, int *ndom, int *dalloc, const uint8_t *strand_dsq)
 {
   const int M = om->M;
   const int Ld = j - i + 1;
@@ -246,8 +285,13 @@ static void rescore_envelope(bo_oprofile *om, const uint8_t *dsq, int i, int j, 
   bo_backward_full(dsq + i - 1, Ld, om, efx, bck, ebx, &bcksc, &eown);
   if (decoding(om, Ld, fwd, efx, bck, ebx, eown, ppx) != BO_ERANGE) {
     const float oasc = optimal_accuracy(om, Ld, bck, ppx, fwd, oax);          /* fwd now holds the OA matrix */
-    int i1, k1, i2, k2;
-    if (oa_trace(om, Ld, bck, ppx, fwd, oax, &i1, &k1, &i2, &k2) == BO_OK && i1 > 0) {
+    int i1, k1, i2, k2, pn = 0;
+    int *pst = malloc(sizeof(int) * 3 * (size_t)(Ld + M + 8)), *pk = pst + (Ld + M + 8), *pi = pk + (Ld + M + 8);
+    int ok = oa_trace(om, Ld, bck, ppx, fwd, oax, &i1, &k1, &i2, &k2, pst, pk, pi, &pn) == BO_OK && i1 > 0;
+    const float alisc = ok ? std_aliscore(om, dsq, i - 1, pst, pk, pi, pn, strand_dsq, orf_start) : 0.0f;
+    if (ok && alisc < bo_aliscore_min) bo_aliscore_min = alisc;
+    if (ok && alisc < 0.0f) { ok = 0; bo_aliscore_drops++; }   /* p7_domaindef.c:1286: "repetitive garbage" */
+    if (ok) {
       float domcorrection = 0.f;
       if (!n2sc) {
         float null2[BO_KP_AMINO];
@@ -264,6 +308,7 @@ static void rescore_envelope(bo_oprofile *om, const uint8_t *dsq, int i, int j, 
       d.envsc = envsc; d.oasc = oasc; d.domcorrection = domcorrection > 0.f ? domcorrection : 0.f;
       dom_push(doms, ndom, dalloc, &d);
     }
+    free(pst);
   }
   free(fwd); free(bck); free(efx); free(ebx); free(ppx); free(oax);
 }
@@ -273,7 +318,7 @@ static void rescore_envelope(bo_oprofile *om, const uint8_t *dsq, int i, int j, 
  * that strand (= orf_start in the plain pipeline, the DNA window's start in the frameshift pipeline's standard branch);
  * seq_n: length of the DNA sequence.  Appends bo_fsdomain records (nt coordinates on the sequence). */
 int bo_domaindef_std(bo_pipeline *pli, bo_oprofile *om, bo_bg *bg, const uint8_t *dsq, int n, int orf_start, int win_start,
-                     int complementarity, int seq_n, bo_fsdomain **doms, int *ndom, int *dalloc, int *nskipped)
+                     int complementarity, int seq_n, bo_fsdomain **doms, int *ndom, int *dalloc, int *nskipped, const uint8_t *strand_dsq)
 {
   const float rt1 = 0.25f, rt2 = 0.10f, rt3 = 0.20f;
   const int M = om->M, first = *ndom;
@@ -309,9 +354,9 @@ int bo_domaindef_std(bo_pipeline *pli, bo_oprofile *om, bo_bg *bg, const uint8_t
         const int nc = bo_region_trace_ensemble(om, dsq, i, j, rfwd, rfx, n2sc, env, 32);
         bo_oprofile_reconfig_unihit(om, n);
         (*nskipped)++;                                            /* counts clustered regions (ddef->nclustered) */
-        for (int d = 0; d < nc; d++) rescore_envelope(om, dsq, env[2 * d], env[2 * d + 1], orf_start, win_start, n2sc, doms, ndom, dalloc);
+        for (int d = 0; d < nc; d++) rescore_envelope(om, dsq, env[2 * d], env[2 * d + 1], orf_start, win_start, n2sc, doms, ndom, dalloc, strand_dsq);
         free(rfwd); free(rfx); free(n2sc);
-      } else rescore_envelope(om, dsq, i, j, orf_start, win_start, NULL, doms, ndom, dalloc);
+      } else rescore_envelope(om, dsq, i, j, orf_start, win_start, NULL, doms, ndom, dalloc, strand_dsq);
       i = -1; triggered = 0;
     }
   }

@@ -193,6 +193,45 @@ static void dom_push(bo_fsdomain **d, int *n, int *alloc, const bo_fsdomain *r)
   (*d)[(*n)++] = *r;
 }
 
+/* p7_pli_computeAliScores_BATH, p7_pipeline.c:781-979, on a frameshift trace (tr->i already window-absolute): per aligned
+ * column from the first to the last match state, the amino row score of the (quasi-)codon's best amino acid plus the
+ * transition that entered the state; the last match state gets no MM transition (inner loops stop at z1 < z2, :899). */
+extern int bo_aliscore_drops;
+extern float bo_aliscore_min;
+
+static float fs_aliscore(const bo_fs_profile *gm, const uint8_t *wdsq, const bo_trace *tr)
+{
+  const size_t W = (size_t) gm->M + 1;
+  int z1, z2;
+  for (z1 = 0; z1 < tr->N; z1++) if (tr->st[z1] == BO_T_M) break;
+  for (z2 = tr->N - 1; z2 >= 0; z2--) if (tr->st[z2] == BO_T_M) break;
+  float total = 0.0f;
+  for (int z = z1; z <= z2; z++) {
+    const int k = tr->k[z], prev = tr->st[z - 1];
+    float sc;
+    if (tr->st[z] == BO_T_M) {
+      const int i = tr->i[z], c = tr->c[z];
+      int degen = 0, ci = 0;
+      for (int q = 0; q < c; q++) if (wdsq[i - q] >= 4) degen = 1;
+      /* p7P_CODON{1..5}_FS5, hmmer.h:306-310: the last nucleotide is the most significant digit */
+      if      (c == 1) ci = degen ? BO_DEGEN5_QC2 : wdsq[i] * 341;
+      else if (c == 2) ci = degen ? BO_DEGEN5_QC1 : wdsq[i] * 341 + wdsq[i-1] * 85 + 1;
+      else if (c == 3) ci = degen ? BO_DEGEN5_C   : wdsq[i] * 341 + wdsq[i-1] * 85 + wdsq[i-2] * 21 + 2;
+      else if (c == 4) ci = degen ? BO_DEGEN5_QC1 : wdsq[i] * 341 + wdsq[i-1] * 85 + wdsq[i-2] * 21 + wdsq[i-3] * 5 + 3;
+      else             ci = degen ? BO_DEGEN5_QC2 : wdsq[i] * 341 + wdsq[i-1] * 85 + wdsq[i-2] * 21 + wdsq[i-3] * 5 + wdsq[i-4] + 4;
+      const int amino = gm->codons[(size_t) k * gm->maxcodons + ci];
+      sc = gm->rsc[(size_t)(gm->maxcodons + amino) * W + k];
+      if      (prev == BO_T_I) sc += gm->tsc[(k - 1) * BO_NTRANS + BO_IM];
+      else if (prev == BO_T_D) sc += gm->tsc[(k - 1) * BO_NTRANS + BO_DM];
+      else if (prev == BO_T_M && z < z2) sc += gm->tsc[(k - 1) * BO_NTRANS + BO_MM];
+    } else if (tr->st[z] == BO_T_I) sc = gm->tsc[k * BO_NTRANS + (prev == BO_T_I ? BO_II : BO_MI)];
+    else if (tr->st[z] == BO_T_D)   sc = gm->tsc[(k - 1) * BO_NTRANS + (prev == BO_T_D ? BO_DD : BO_MD)];
+    else continue;
+    total += sc;
+  }
+  return total;
+}
+
 /* rescore_isolated_domain_frameshift (p7_domaindef.c:993-1175) on wdsq[i..j] (1-based in the window) */
 static int rescore_domain(const bo_pipeline *pli, bo_fs_profile *gm5, bo_bg *bg, const uint8_t *wdsq, int i, int j,
                           bo_fsdomain **doms, int *ndom, int *dalloc, bo_trace *tr)
@@ -217,6 +256,9 @@ static int rescore_domain(const bo_pipeline *pli, bo_fs_profile *gm5, bo_bg *bg,
   bo_goptacc_fs(gm5, fwd, bck, &oasc);                          /* fwd now holds posteriors, bck the OA matrix */
   if ((status = bo_goatrace_fs(gm5, fwd, bck, tr)) != BO_OK) goto DONE;
   for (int z = 0; z < tr->N; z++) if (tr->i[z] >= 0) tr->i[z] += i - 1;
+  { const float alisc = fs_aliscore(gm5, wdsq, tr);
+    if (alisc < bo_aliscore_min) bo_aliscore_min = alisc;
+    if (alisc < 0.0f) { bo_aliscore_drops++; status = BO_FAIL; goto DONE; } }        /* p7_domaindef.c:1072: "repetitive garbage" */
   {
     float null2[BO_KP_AMINO];
     bo_gnull2_fs(gm5, fwd, null2);

@@ -172,7 +172,7 @@ int bo_pli_frameshift(bo_pipeline *pli, bo_oprofile *om, bo_fs_profile *gm3, bo_
         aligned[i] = 1;
         pli->pos_past_fwd += (int64_t) o->n * 3;
         if (doms)                                             /* :1489-1505: Backward parser, domain definition, hit scores */
-          bo_domaindef_std(pli, om, bg, blk->aa + o->off, o->n, o->start, (int) wl[w].n, complementarity, n, doms, ndom, dom_alloc, nskipped);
+          bo_domaindef_std(pli, om, bg, blk->aa + o->off, o->n, o->start, (int) wl[w].n, complementarity, n, doms, ndom, dom_alloc, nskipped, dsq);
       }
     }
     fsw_push(fw, nfw, fw_alloc, &r);

@@ -167,7 +167,7 @@ static void strand_cascade(bo_pipeline *pli, bo_oprofile *om, const bo_scoredata
     pli->n_past_fwd++;
     if (!pli->fs_pipe) pli->pos_past_fwd += (int64_t) n * 3;  /* :1761; the fs branch counts later (:1468,1490) */
     if (!pli->fs_pipe && fs && fs->doms && !fs->gm3)          /* :1763-1771: Backward parser, domain definition, hit scores */
-      bo_domaindef_std(pli, om, bg, dsq, n, o->start, o->start, strand, fs->n, fs->doms, fs->ndom, fs->dom_alloc, fs->nskipped);
+      bo_domaindef_std(pli, om, bg, dsq, n, o->start, o->start, strand, fs->n, fs->doms, fs->ndom, fs->dom_alloc, fs->nskipped, fs->dsq);
   }
   if (pli->fs_pipe && fs && fs->gm3)                            /* :1793 */
     bo_pli_frameshift(pli, om, fs->gm3, fs->gm5, sd, bg, fs->basic, blk, P_orf, fwd_null, &hw, fs->dsq, fs->n, strand, fs->fw, fs->nfw, fs->fw_alloc,

@@ -456,6 +456,10 @@ bo_oprofile *bo_oprofile_convert(const bo_profile *gm)             /* p7_oprofil
   om->tw = malloc(sizeof(int16_t) * W * BO_NTRANS);
   om->rf = malloc(sizeof(float) * Kp * W);
   om->tf = malloc(sizeof(float) * W * BO_NTRANS);
+  om->msc = malloc(sizeof(float) * Kp * W);
+  om->tsc = malloc(sizeof(float) * W * BO_NTRANS);
+  for (int x = 0; x < Kp; x++) { om->msc[x * W] = -INFINITY; for (int k = 1; k <= M; k++) om->msc[x * W + k] = GM_MSC(gm, k, x); }
+  memcpy(om->tsc, gm->tsc, sizeof(float) * W * BO_NTRANS);
 
   /* ---- mf_conversion, p7_oprofile.c:773-813 ---- */
   float mx = 0.0f;
@@ -552,7 +556,7 @@ void bo_oprofile_reconfig_length(bo_oprofile *om, int L)           /* p7_oprofil
 
 void bo_oprofile_free(bo_oprofile *om)
 {
-  if (om) { free(om->rb); free(om->rw); free(om->tw); free(om->rf); free(om->tf); free(om); }
+  if (om) { free(om->rb); free(om->rw); free(om->tw); free(om->rf); free(om->tf); free(om->msc); free(om->tsc); free(om); }
 }
 
 /* ------------------------------------------------------------------ score data */

@@ -57,7 +57,13 @@ class OProfile(C.Structure):
                 ("rw", C.POINTER(C.c_int16)), ("tw", C.POINTER(C.c_int16)),
                 ("xw", (C.c_int16 * 2) * 4), ("scale_w", C.c_float), ("base_w", C.c_int16), ("ddbound_w", C.c_int16),
                 ("rf", C.POINTER(C.c_float)), ("tf", C.POINTER(C.c_float)), ("xf", (C.c_float * 2) * 4),
-                ("evparam", C.c_float * NEVPARAM), ("compo", C.c_float * K)]
+                ("evparam", C.c_float * NEVPARAM), ("compo", C.c_float * K),
+                ("msc", C.POINTER(C.c_float)), ("tsc", C.POINTER(C.c_float))]
+
+
+def aliscore_drops():
+    """Test hook of the oracle: envelopes dropped so far by the aliscore < 0 rule (p7_domaindef.c:1072,1286), both branches."""
+    return C.c_int.in_dll(lib(), "bo_aliscore_drops").value
 
 
 class Bg(C.Structure):

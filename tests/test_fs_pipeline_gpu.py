@@ -226,6 +226,37 @@ def test_domains_of_planted_frameshifted_genes(gpu_ctx, name):
     assert any(fw[d.fs_window].branch == 1 for d in dm) and any(fw[d.fs_window].branch == 2 for d in dm)
 
 
+def test_negative_alignment_score_drops_the_domain(gpu_ctx):
+    """p7_pli_computeAliScores_BATH + p7_domaindef.c:1072,1286 in the --fs pipeline: mutated genes (25% of the residues
+    replaced) with nucleotide insertions and deletions; the oracle's counter shows the rule fired on this input."""
+    path = ol.GOLDEN + "/Caudal_act.bhmm"
+    model = ol.Model(path, 0)
+    rng = np.random.default_rng(1)
+    wins = []
+    for aa in common.emit_from_model(rng, model, 150, flank=5):
+        aa = [a if rng.random() > 0.25 else int(rng.integers(0, 20)) for a in aa]
+        nt = list(common.revtranslate(rng, aa, model.basic))
+        for _ in range(int(rng.integers(1, 4))):
+            p = int(rng.integers(10, max(11, len(nt) - 10)))
+            if rng.random() < 0.5:
+                del nt[p]
+            else:
+                nt.insert(p, int(rng.integers(0, 4)))
+        wins.append(np.array(nt, dtype=np.uint8))
+    before = ol.aliscore_drops()
+    _, ofw, per_w, odm, per_d, oskip = model.run_pipeline_fsdom(wins)
+    assert ol.aliscore_drops() - before >= 1
+    hmm = ba.HMM(path, 0)
+    om = ba.OProfile(gpu_ctx, ba.Profile(hmm))
+    om3 = ba.FSOProfile(gpu_ctx, ba.FSProfile(hmm, 3, ncbi_table=hmm.ct))
+    om5 = ba.FSOProfile(gpu_ctx, ba.FSProfile(hmm, 5, ncbi_table=hmm.ct))
+    pipe = ba.Pipeline(gpu_ctx, om, fs_pipe=True, ncbi_table=hmm.ct)
+    stats, fw, dm, nskip = pipe.run_frameshift_domains(om3, om5, ba.SeqBlock(gpu_ctx, wins))
+    assert nskip == oskip
+    assert compare_domains(model, dm, odm, per_d, nskip) >= 8
+    assert len(dm) == sum(b - a for a, b in per_d)            # no extra domain hiding in compare_domains' allowances
+
+
 def test_frameshift_path_with_a_long_model(gpu_ctx, tmp_path):
     """A 700-node synthetic model (11 nodes per lane in the frameshift kernels -> the 12-node instantiation, 5.7 MB of
     5-codon emissions): the whole --fs path to hits against the oracle."""

@@ -137,6 +137,36 @@ def test_hits_match_oracle_on_planted_genes(ctx, hmmfile, idx):
     assert max(per.values()) >= 2
 
 
+def test_negative_alignment_score_drops_the_domain(ctx):
+    """p7_pli_computeAliScores_BATH + p7_domaindef.c:1286: an envelope whose optimal-accuracy alignment sums to a negative
+    per-position score gives no domain.  Heavily mutated genes (30% of the residues replaced) produce such envelopes now and
+    then; some windows also carry degenerate nucleotides inside aligned codons (those columns score as X).  The oracle's
+    counter shows that the rule fired; the hit lists must agree as everywhere else."""
+    path = ol.GOLDEN + "/Caudal_act.bhmm"
+    model = ol.Model(path, 0)
+    rng = np.random.default_rng(1)
+    wins = []
+    for aa in common.emit_from_model(rng, model, 300, flank=5):
+        aa = [a if rng.random() > 0.3 else int(rng.integers(0, 20)) for a in aa]
+        wins.append(np.array(common.revtranslate(rng, aa, model.basic), dtype=np.uint8))
+    rng2 = np.random.default_rng(2)
+    for aa in common.emit_from_model(rng2, model, 24, flank=5):
+        nt = np.array(common.revtranslate(rng2, aa, model.basic), dtype=np.uint8)
+        for p in rng2.integers(0, len(nt), size=4):
+            nt[int(p)] = 15                                     # N
+        rc = np.where(nt < 4, 3 - nt, nt)[::-1].astype(np.uint8)          # reverse complement; N stays N
+        wins.append(nt if len(wins) % 2 else rc)
+    before = ol.aliscore_drops()
+    pli, odm, per_d, onskip = model.run_pipeline_hits(wins)
+    assert ol.aliscore_drops() - before >= 1
+    stats, dm, nskip = gpu_hits(ctx, path, 0, wins)
+    assert compare_hits(dm, odm, per_d, nskip, onskip) >= 20
+    # compare_hits tolerates a few unmatched domains per clustered region; on this input none is needed, so a domain the rule
+    # should have dropped cannot hide there
+    key = lambda w, d: (w, d.ienv, d.jenv, d.iali, d.jali, d.ihmm, d.jhmm)
+    assert sorted(key(d.window, d) for d in dm) == sorted(key(w, o) for w, (a, b) in enumerate(per_d) for o in odm[a:b])
+
+
 def test_hits_empty_and_background(ctx):
     path = ol.GOLDEN + "/Caudal_act.bhmm"
     rng = np.random.default_rng(5)
