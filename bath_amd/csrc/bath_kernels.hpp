@@ -62,11 +62,17 @@ template <int NR>
 __device__ __forceinline__ void ssv_row(s16x2 (&reg)[NR], s16x2 &xE, s16x2 &xE2, const char *rowbase, unsigned carry) {
   static_assert(NR % 4 == 0, "registers are consumed four at a time (one 16-byte LDS read)");
   const s16x2 wrap = __builtin_bit_cast(s16x2, __builtin_amdgcn_alignbit(__builtin_bit_cast(unsigned, reg[NR - 1]), carry, 16));
+  // increments of registers r .. r+3: one ds_read_b128 (rows are 16-byte aligned, pitch/16 odd).  Measured on MI355X:
+  // ds_read_b64 gathers (32 slots, conflict free) are slower here than ds_read_b128 with its 2-way conflicts.
+  // The read of the next four registers' increments is issued before the current four are used (one read in flight per
+  // lane while the adds of the previous one run).
+  int4 cn = *reinterpret_cast<const int4 *>(rowbase + 4 * (NR - 4));
+  int4 cn2 = *reinterpret_cast<const int4 *>(rowbase + 4 * (NR >= 8 ? NR - 8 : 0));
 #pragma unroll
   for (int r = NR - 4; r >= 0; r -= 4) {
-    // increments of registers r .. r+3: one ds_read_b128 (rows are 16-byte aligned, pitch/16 odd).  Measured on MI355X:
-    // ds_read_b64 gathers (32 slots, conflict free) are slower here than ds_read_b128 with its 2-way conflicts.
-    const int4 c = *reinterpret_cast<const int4 *>(rowbase + 4 * r);
+    const int4 c = cn;
+    cn = cn2;
+    if (r >= 8) cn2 = *reinterpret_cast<const int4 *>(rowbase + 4 * (r - 8));
     const s16x2 v3 = ssv_add(reg[r + 2], c.w);
     const s16x2 v2 = ssv_add(reg[r + 1], c.z);
     reg[r + 3] = v3;
@@ -79,6 +85,58 @@ __device__ __forceinline__ void ssv_row(s16x2 (&reg)[NR], s16x2 &xE, s16x2 &xE2,
     xE2 = ssv_max3(xE2, v1, v0);                   // two running maxima: half the length of the dependent chain per row (-3.4%;
                                                    // four would need 129 VGPRs, one more than 4 waves per SIMD allow)
   }
+}
+
+// The same row with the LDS reads software-pipelined by hand: two 16-byte buffers rotate, the read of group g+2 is issued as soon
+// as group g has been consumed, so one or two reads are always in flight behind the adds (the compiler's own schedule under the
+// 128-VGPR cap of 4 waves per SIMD drains the LDS queue after every pair of reads).  The reads and their waits are inline asm:
+// "s_waitcnt lgkmcnt(1)" relies on LDS reads of a wave completing in order -- with at most one younger read outstanding, the older
+// one has landed (a scalar load slipped in between only makes the wait longer).  The wait is tied to the buffer it guards by a
+// "+v" operand, so its consumers cannot be scheduled above it.
+typedef int ssv_i4 __attribute__((ext_vector_type(4)));
+template <int N> __device__ __forceinline__ void ssv_lgkm_wait(ssv_i4 &c) {       // wait until at most N LDS reads are outstanding
+  if (N <= 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c));
+  else if (N == 1) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(c));
+  else asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(c));
+}
+template <int NR, int NB, int g, int US = 16>
+struct SsvRowPipe {
+  static constexpr int NG = NR / 4;
+  static __device__ __forceinline__ void run(s16x2 (&reg)[NR], s16x2 &xE, s16x2 &xE2, unsigned rowaddr, s16x2 wrap, ssv_i4 (&b)[NB]) {
+    constexpr int r = NR - 4 - 4 * g;
+    ssv_i4 &c = b[g % NB];
+    ssv_lgkm_wait<(NG - 1 - g < NB - 1) ? NG - 1 - g : NB - 1>(c);
+    const s16x2 v3 = ssv_add(reg[r + 2], c.w);
+    const s16x2 v2 = ssv_add(reg[r + 1], c.z);
+    reg[r + 3] = v3;
+    reg[r + 2] = v2;
+    xE = ssv_max3(xE, v3, v2);
+    const s16x2 v1 = ssv_add(reg[r], c.y);
+    const s16x2 v0 = ssv_add((r > 0) ? reg[r - 1] : wrap, c.x);
+    reg[r + 1] = v1;
+    reg[r] = v0;
+    xE2 = ssv_max3(xE2, v1, v0);
+    if (g + NB < NG) {
+      // the buffer's last use is above: the asm inputs v0, v1 make the read depend on those adds, which keeps it below them
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(c) : "v"(rowaddr), "n"(US * ((NR - 4 - 4 * (g + NB)) / 4)), "v"(v0), "v"(v1));
+    }
+    SsvRowPipe<NR, NB, g + 1, US>::run(reg, xE, xE2, rowaddr, wrap, b);
+  }
+};
+template <int NR, int NB, int US>
+struct SsvRowPipe<NR, NB, NR / 4, US> {
+  static __device__ __forceinline__ void run(s16x2 (&)[NR], s16x2 &, s16x2 &, unsigned, s16x2, ssv_i4 (&)[NB]) {}
+};
+// US: bytes between the 16-byte units of consecutive register groups in the row (16: a plain row; 256: the replicated table)
+template <int NR, int NB = 2, int US = 16>
+__device__ __forceinline__ void ssv_row_pipe(s16x2 (&reg)[NR], s16x2 &xE, s16x2 &xE2, unsigned rowaddr /* LDS byte address */, unsigned carry) {
+  static_assert(NR % 4 == 0 && NR >= 4 * NB && NB >= 2 && NB <= 3, "registers are consumed four at a time (one 16-byte LDS read)");
+  const s16x2 wrap = __builtin_bit_cast(s16x2, __builtin_amdgcn_alignbit(__builtin_bit_cast(unsigned, reg[NR - 1]), carry, 16));
+  ssv_i4 b[NB];
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(b[0]) : "v"(rowaddr), "n"(US * ((NR - 4) / 4)));
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(b[1]) : "v"(rowaddr), "n"(US * ((NR - 8) / 4)));
+  if (NB > 2) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(b[NB - 1]) : "v"(rowaddr), "n"(US * ((NR - 12) / 4)));
+  SsvRowPipe<NR, NB, 0, US>::run(reg, xE, xE2, rowaddr, wrap, b);
 }
 
 // Per-row helpers for models split over G lanes (G = 1, 2, 4 or 8 adjacent lanes per target).

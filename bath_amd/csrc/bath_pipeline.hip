@@ -67,7 +67,7 @@ struct Params {
 // 1. SSV over the length-sorted ORF list, lane per ORF (persistent waves striding over the list)
 // ---------------------------------------------------------------------------------------------
 template <int NR, int G>
-__global__ __launch_bounds__(256) void ssv_orf_kernel(const uint8_t *__restrict__ aa, const OrfRec *__restrict__ orfs, const int *__restrict__ n_orfs_dev,
+__global__ __launch_bounds__(256, (NR <= 76 ? 4 : 1)) void ssv_orf_kernel(const uint8_t *__restrict__ aa, const OrfRec *__restrict__ orfs, const int *__restrict__ n_orfs_dev,
                                                       SeqView dna, const int16_t *__restrict__ cost_tab, int row_bytes,
                                                       const int16_t *__restrict__ emit_thresh, int thresh_max,
                                                       Cand cand, int cand_cap, Counters *__restrict__ ctr) {
@@ -84,6 +84,7 @@ __global__ __launch_bounds__(256) void ssv_orf_kernel(const uint8_t *__restrict_
   const int lane = threadIdx.x & 63;
   const int grank = lane % G;
   const char *tile = lds + grank * (4 * NR);
+  const unsigned tile_addr = (unsigned)(size_t)(__attribute__((address_space(3))) const char *)tile;   // LDS byte address
   const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   const s16x2 fl = {0, 0};                                      // the begin score
@@ -100,20 +101,26 @@ __global__ __launch_bounds__(256) void ssv_orf_kernel(const uint8_t *__restrict_
     for (int r = 0; r < NR; r++) reg[r] = fl;
     s16x2 xE = fl, xE2 = fl;
     // residues 8 at a time, the next 8 in flight: an ORF's 64-byte sectors are touched by half as many loads as with a dword
-    // per 4 rows, and each touch is a chance to find the sector evicted from L2 again (HBM traffic of the launch -32%, kernel
-    // -4%; the loop also stops at the wave's longest ORF instead of the next multiple of 4 rows).  16 at a time costs 150 VGPRs:
-    // 3 waves per SIMD instead of 4, which alone costs 8%.
+    // per 4 rows (HBM traffic of the launch -32%, kernel -4%; the loop also stops at the wave's longest ORF instead of the next
+    // multiple of 4 rows).  Staging the residues through LDS instead (three global_load_lds_dwordx4 per wave and 32 rows, double
+    // buffered) was measured at -2% time and -20% traffic and not kept: most of the excess traffic is 128-byte lines shared by
+    // ORFs of different lengths, which no read pattern of this kernel can merge.
     uint64_t qnext = (0 < L) ? *reinterpret_cast<const uint64_t *>(s) : 0x1d1d1d1d1d1d1d1dull;
     for (int i0 = 0; i0 < Lw; i0 += 8) {
       const uint64_t q = qnext;
       qnext = (i0 + 8 < L) ? *reinterpret_cast<const uint64_t *>(s + i0 + 8) : 0x1d1d1d1d1d1d1d1dull;
       const int nrow = min(8, Lw - i0);                              // wave-uniform
-#pragma unroll 2                        // unrolling more rows costs VGPRs (159 at 4 rows: 3 waves per SIMD); 2 rows: 4 waves, 8% faster
-      for (int j = 0; j < nrow; j++) {
-        int x = (int)(q >> (8 * j)) & 0xff;
-        x = (i0 + j < L) ? min(x, kKp - 1) : kRowReset;
-        const unsigned carry = ssv_carry<NR, G>(reg, grank);
-        ssv_row<NR>(reg, xE, xE2, tile + x * row_bytes, carry);
+      // the row's overhead is kept to full-rate 32-bit ops: a bit-field extract on the dword holding the residue (no 64-bit
+      // shift), a 24-bit multiply for the row offset (v_mul_lo_u32 is quarter rate); bytes inside an ORF are residue codes < 29
+      for (int h = 0; h < 2; h++) {
+        const uint32_t qh = h ? (uint32_t)(q >> 32) : (uint32_t)q;
+        const int nh = min(4, nrow - 4 * h);                         // wave-uniform
+        for (int j = 0; j < nh; j++) {
+          int x = (int)__builtin_amdgcn_ubfe(qh, 8 * j, 8);
+          x = (i0 + 4 * h + j < L) ? x : kRowReset;
+          const unsigned carry = ssv_carry<NR, G>(reg, grank);
+          ssv_row_pipe<NR, 3>(reg, xE, xE2, tile_addr + __umul24((unsigned)x, (unsigned)row_bytes), carry);
+        }
       }
     }
     xE = ssv_max3(xE, xE2, xE2);

@@ -197,14 +197,16 @@ def main():
             "hits_gathered": int(len(hits)) if hits is not None else 0,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": "ssv_orf_kernel", "kernel_ms": k_ms,
-                         "note": "DP rows held in VGPRs (integer scores as binary16): compulsory HBM traffic is 1 B per ORF residue, the kernel is bound by VALU issue and the LDS gather (see DESIGN.md 4.1); "
+                         "note": "DP rows held in VGPRs (integer scores as binary16): compulsory HBM traffic is 1 B per ORF residue, the kernel is bound by the issue rate of packed 16-bit VALU ops (see DESIGN.md 4.1); "
                                  "cell rate of this kernel = %.2f Tcells/s per launch while %d parts of the block overlap on separate streams"
                                  % (stats.cells_msv / lanes / (k_ms * 1e-3) / 1e12, lanes), "launches_per_step": lanes,
-                         # the bound that does apply, for the reader: 1.5 packed VALU ops per 2 cells (v_pk_add_f16 clamp + half a
-                         # v_pk_maximum3_f16), 1024 SIMDs x 64 lanes, one op per 4 cycles at 2.4 GHz = 52.4 Tcells/s for the chip
-                         # (DESIGN.md 4.1); concurrent parts share it
-                         "valu": {"tcells_per_s_per_launch": stats.cells_msv / lanes / (k_ms * 1e-3) / 1e12, "peak_tcells_per_s": 52.4,
-                                  "frac_per_launch": stats.cells_msv / lanes / (k_ms * 1e-3) / 1e12 / 52.4, "concurrent_launches": lanes}},
+                         # the bound that does apply, for the reader: the issue rate of packed 16-bit VALU ops.  tools/valu_rate.hip
+                         # measures 5.2e11 wave-instructions/s for v_pk_add_f16 / v_pk_maximum3_f16 on this chip at 8 waves per SIMD (4.4e11 at
+                         # the 4 this kernel's registers allow; v_fma_f32: 9.3e11); a row costs 3 of them per 4 cells (2 adds + 1 maximum3),
+                         # 64 lanes each: 5.2e11 x 64 x 4/3 = 44.4 Tcells/s for the chip; concurrent parts share it
+                         "valu": {"tcells_per_s_per_launch": stats.cells_msv / lanes / (k_ms * 1e-3) / 1e12, "peak_tcells_per_s": 44.4,
+                                  "frac_per_launch": stats.cells_msv / lanes / (k_ms * 1e-3) / 1e12 / 44.4, "concurrent_launches": lanes,
+                                  "peak_source": "measured packed-op issue rate, tools/valu_rate.hip, profiles/r01_valu_rate.txt"}},
         }
         if not args.no_cpu_baseline and world == 1:           # the CPU baseline is measured on rank 0 of the 1-GPU run only
             base, _ = cpu_baseline(flat, args.length, args.windows)
