@@ -35,7 +35,7 @@ namespace bath {
 // Amino-acid targets: G adjacent lanes score sequence order[t] (or t); writes the raw maximum v in the
 // kernel's signed domain (begin score = -128), i.e. get_xE()'s byte minus 256.
 template <int NR, int G>
-__global__ __launch_bounds__(256) void ssv_lane_kernel(SeqView sq, const int32_t *__restrict__ order,
+__global__ __launch_bounds__(256, (NR <= 76 ? 4 : 1)) void ssv_lane_kernel(SeqView sq, const int32_t *__restrict__ order,
                                                        const int16_t *__restrict__ cost_tab, int row_bytes,
                                                        int16_t *__restrict__ out_v) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -55,6 +55,7 @@ __global__ __launch_bounds__(256) void ssv_lane_kernel(SeqView sq, const int32_t
   const uint8_t *s = sq.data + sq.off[sid];
   const int Lw = wave_max_i32(L);
   const char *tile = lds + grank * (4 * NR);
+  const unsigned tile_addr = (unsigned)(size_t)(__attribute__((address_space(3))) const char *)tile;   // LDS byte address
 
   s16x2 reg[NR];
   const s16x2 fl = {0, 0};                                      // the begin score
@@ -66,12 +67,12 @@ __global__ __launch_bounds__(256) void ssv_lane_kernel(SeqView sq, const int32_t
   for (int i0 = 0; i0 < Lw; i0 += 4) {
     const uint32_t w = wnext;
     wnext = (i0 + 4 < L) ? *reinterpret_cast<const uint32_t *>(s + i0 + 4) : 0x1d1d1d1du;
-#pragma unroll
+#pragma unroll 1                   // one row body: the 128-VGPR budget of 4 waves per SIMD (as in ssv_orf_kernel)
     for (int j = 0; j < 4; j++) {
       int x = (w >> (8 * j)) & 0xff;
       x = (i0 + j < L) ? min(x, kKp - 1) : kRowReset;
       const unsigned carry = ssv_carry<NR, G>(reg, grank);
-      ssv_row<NR>(reg, xE, xE2, tile + x * row_bytes, carry);
+      ssv_row_pipe<NR, 3>(reg, xE, xE2, tile_addr + (unsigned)(x * row_bytes), carry);
     }
   }
   xE = ssv_max3(xE, xE2, xE2);

@@ -58,37 +58,9 @@ __device__ __forceinline__ s16x2 ssv_max3(s16x2 a, s16x2 b, s16x2 c) {
 // place, descending).  Only register 0 needs assembling: its low half takes the node left of the tile
 // (high half of <carry>: the begin score for the first tile, otherwise the last node of the neighbouring
 // lane's tile when a model is split over G lanes), its high half the old low half of register NR-1.
-template <int NR>
-__device__ __forceinline__ void ssv_row(s16x2 (&reg)[NR], s16x2 &xE, s16x2 &xE2, const char *rowbase, unsigned carry) {
-  static_assert(NR % 4 == 0, "registers are consumed four at a time (one 16-byte LDS read)");
-  const s16x2 wrap = __builtin_bit_cast(s16x2, __builtin_amdgcn_alignbit(__builtin_bit_cast(unsigned, reg[NR - 1]), carry, 16));
-  // increments of registers r .. r+3: one ds_read_b128 (rows are 16-byte aligned, pitch/16 odd).  Measured on MI355X:
-  // ds_read_b64 gathers (32 slots, conflict free) are slower here than ds_read_b128 with its 2-way conflicts.
-  // The read of the next four registers' increments is issued before the current four are used (one read in flight per
-  // lane while the adds of the previous one run).
-  int4 cn = *reinterpret_cast<const int4 *>(rowbase + 4 * (NR - 4));
-  int4 cn2 = *reinterpret_cast<const int4 *>(rowbase + 4 * (NR >= 8 ? NR - 8 : 0));
-#pragma unroll
-  for (int r = NR - 4; r >= 0; r -= 4) {
-    const int4 c = cn;
-    cn = cn2;
-    if (r >= 8) cn2 = *reinterpret_cast<const int4 *>(rowbase + 4 * (r - 8));
-    const s16x2 v3 = ssv_add(reg[r + 2], c.w);
-    const s16x2 v2 = ssv_add(reg[r + 1], c.z);
-    reg[r + 3] = v3;
-    reg[r + 2] = v2;
-    xE = ssv_max3(xE, v3, v2);
-    const s16x2 v1 = ssv_add(reg[r], c.y);
-    const s16x2 v0 = ssv_add((r > 0) ? reg[r - 1] : wrap, c.x);
-    reg[r + 1] = v1;
-    reg[r] = v0;
-    xE2 = ssv_max3(xE2, v1, v0);                   // two running maxima: half the length of the dependent chain per row (-3.4%;
-                                                   // four would need 129 VGPRs, one more than 4 waves per SIMD allow)
-  }
-}
-
-// The same row with the LDS reads software-pipelined by hand: two 16-byte buffers rotate, the read of group g+2 is issued as soon
-// as group g has been consumed, so one or two reads are always in flight behind the adds (the compiler's own schedule under the
+// The LDS reads are software-pipelined by hand: NB 16-byte buffers rotate (increments of registers r .. r+3: one ds_read_b128;
+// rows are 16-byte aligned, pitch/16 odd), the read of group g+NB is issued as soon as group g has been consumed, so NB-1 or NB
+// reads are always in flight behind the adds (the compiler's own schedule under the
 // 128-VGPR cap of 4 waves per SIMD drains the LDS queue after every pair of reads).  The reads and their waits are inline asm:
 // "s_waitcnt lgkmcnt(1)" relies on LDS reads of a wave completing in order -- with at most one younger read outstanding, the older
 // one has landed (a scalar load slipped in between only makes the wait longer).  The wait is tied to the buffer it guards by a
