@@ -180,6 +180,7 @@ struct bath_hip_oprofile {
   int16_t *d_rw = nullptr;      // [Kp][M+1]
   int16_t *d_tw = nullptr;      // [M+1][8]
   float *d_rf = nullptr, *d_tf = nullptr;
+  float *d_rfb = nullptr, *d_tfb = nullptr;   // d_rf / d_tf padded to M+2 nodes (zeros), for the Backward kernel when the tables stay in global memory
   float *d_msc = nullptr, *d_tsc = nullptr;   // log-odds match scores [Kp][M+1] and log transitions [M][8] (p7_pli_computeAliScores_BATH)
   float *d_bias_eo = nullptr;   // [Kp][2] emission odds of the 2-state bias filter HMM for om->compo
   // lane-per-target Viterbi kernel tables (bath_viterbi.hip); vit_NR == 0 when the model is too long for it

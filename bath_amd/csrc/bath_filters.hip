@@ -314,7 +314,8 @@ __global__ __launch_bounds__(256) void vit_wave_kernel(SeqView sq, int M, const 
 // ============================================================================================
 struct FwdConsts { float xfE_loop, xfE_move; };
 
-template <int C>
+// GT: the tables of a model too long for the LDS (above ~1100 nodes) are read from global memory (L2-resident) instead
+template <int C, bool GT = false>
 __global__ __launch_bounds__(256) void fwd_wave_kernel(SeqView sq, int M, const float *__restrict__ g_rf, const float *__restrict__ g_tf,
                                                        const float *__restrict__ pmove_tab, FwdConsts c,
                                                        const int32_t *__restrict__ todo, int64_t ntodo, const int *__restrict__ ntodo_dev,
@@ -323,12 +324,15 @@ __global__ __launch_bounds__(256) void fwd_wave_kernel(SeqView sq, int M, const 
                                                        float *__restrict__ dp, const int64_t *__restrict__ dp_off, int unihit,
                                                        const int32_t *__restrict__ cfg_len) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  float *s_tf = reinterpret_cast<float *>(lds);          // [(M+1)*8]
-  float *s_rf = s_tf + (size_t)(M + 1) * 8;              // [Kp][M+1]
+  const float *s_tf = GT ? g_tf : reinterpret_cast<const float *>(lds);          // [(M+1)*8]
+  const float *s_rf = GT ? g_rf : s_tf + (size_t)(M + 1) * 8;                    // [Kp][M+1]
   if (ntodo_dev) ntodo = *ntodo_dev;
-  for (int i = threadIdx.x; i < (M + 1) * 8; i += blockDim.x) s_tf[i] = g_tf[i];
-  for (int i = threadIdx.x; i < kKp * (M + 1); i += blockDim.x) s_rf[i] = g_rf[i];
-  __syncthreads();
+  if (!GT) {
+    float *w_tf = reinterpret_cast<float *>(lds), *w_rf = w_tf + (size_t)(M + 1) * 8;
+    for (int i = threadIdx.x; i < (M + 1) * 8; i += blockDim.x) w_tf[i] = g_tf[i];
+    for (int i = threadIdx.x; i < kKp * (M + 1); i += blockDim.x) w_rf[i] = g_rf[i];
+    __syncthreads();
+  }
   const int lane = threadIdx.x & 63;
   const int64_t wid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -432,18 +436,22 @@ __global__ __launch_bounds__(256) void fwd_wave_kernel(SeqView sq, int M, const 
 // fp32, rescaled row by row with the Forward pass's scale factors (fwd xmx SCALE) unless xB outgrows 1e16 (:668-675).
 // Lane l owns nodes l*C+1 .. l*C+C; D(i,k) = ... + D(i,k+1)*tDD(k) is a right-to-left scan over affine maps.
 // ============================================================================================
-template <int C>
+// GT: g_rf / g_tf are then the padded copies ([Kp][M+2], [(M+2)*8]) the oprofile keeps for this purpose
+template <int C, bool GT = false>
 __global__ __launch_bounds__(256) void bwd_wave_kernel(SeqView sq, int M, const float *__restrict__ g_rf, const float *__restrict__ g_tf,
                                                        const float *__restrict__ pmove_tab, FwdConsts c, int64_t ntodo,
                                                        const float *__restrict__ fwd_xmx, const int64_t *__restrict__ xmx_off,
                                                        float *__restrict__ sc, int32_t *__restrict__ status, float *__restrict__ bck_xmx,
                                                        float *__restrict__ dp, const int64_t *__restrict__ dp_off, int unihit) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  float *s_tf = reinterpret_cast<float *>(lds);          // [(M+2)*8], node M+1 all zero
-  float *s_rf = s_tf + (size_t)(M + 2) * 8;              // [Kp][M+2], column M+1 zero
-  for (int i = threadIdx.x; i < (M + 2) * 8; i += blockDim.x) s_tf[i] = (i < (M + 1) * 8) ? g_tf[i] : 0.f;
-  for (int i = threadIdx.x; i < kKp * (M + 2); i += blockDim.x) { const int x = i / (M + 2), k = i - x * (M + 2); s_rf[i] = (k <= M) ? g_rf[(size_t)x * (M + 1) + k] : 0.f; }
-  __syncthreads();
+  const float *s_tf = GT ? g_tf : reinterpret_cast<const float *>(lds);          // [(M+2)*8], node M+1 all zero
+  const float *s_rf = GT ? g_rf : s_tf + (size_t)(M + 2) * 8;                    // [Kp][M+2], column M+1 zero
+  if (!GT) {
+    float *w_tf = reinterpret_cast<float *>(lds), *w_rf = w_tf + (size_t)(M + 2) * 8;
+    for (int i = threadIdx.x; i < (M + 2) * 8; i += blockDim.x) w_tf[i] = (i < (M + 1) * 8) ? g_tf[i] : 0.f;
+    for (int i = threadIdx.x; i < kKp * (M + 2); i += blockDim.x) { const int x = i / (M + 2), k = i - x * (M + 2); w_rf[i] = (k <= M) ? g_rf[(size_t)x * (M + 1) + k] : 0.f; }
+    __syncthreads();
+  }
   const int lane = threadIdx.x & 63;
   const int64_t wid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -648,6 +656,8 @@ int launch_ssv_lane(bath_hip_ctx *ctx, const bath_hip_oprofile *om, SeqView v, c
   return BATH_OK;
 }
 
+constexpr size_t kWaveTableLdsMax = 150 * 1024;      // Forward / Backward tables above this stay in global memory (160 KB of LDS per CU)
+
 static int columns_per_lane(int M) {
   int c = (M + 63) / 64;
   for (int opt : {1, 2, 3, 4, 6, 8, 12, 16, 24, 32}) if (c <= opt) return opt;
@@ -711,10 +721,16 @@ int launch_fwd_wave(bath_hip_ctx *ctx, const bath_hip_oprofile *om, SeqView v, c
   const size_t shmem = ((size_t)(om->M + 1) * 8 + (size_t)kKp * (om->M + 1)) * sizeof(float);
   FwdConsts c{om->xf_E[0], om->xf_E[1]};
   if (unihit) { c.xfE_loop = 0.0f; c.xfE_move = 1.0f; }         // p7_oprofile_ReconfigUnihit, p7_oprofile.c:1421-1422
-  BATH_C_SWITCH(C, {
-    if (shmem > 64 * 1024) BATH_HIP_TRY(ctx, hipFuncSetAttribute((const void *)fwd_wave_kernel<CC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    hipLaunchKernelGGL(fwd_wave_kernel<CC>, dim3(grid), dim3(256), shmem, ctx->stream, v, om->M, om->d_rf, om->d_tf, om->lt.d_pmove, c, d_todo, ntodo, ntodo_dev, d_sc, d_status, d_xmx, d_xmx_off, d_dp, d_dp_off, unihit, d_cfg_len);
-  })
+  if (shmem > kWaveTableLdsMax) {                               // tables stay in global memory
+    BATH_C_SWITCH(C, {
+      hipLaunchKernelGGL((fwd_wave_kernel<CC, true>), dim3(grid), dim3(256), 0, ctx->stream, v, om->M, om->d_rf, om->d_tf, om->lt.d_pmove, c, d_todo, ntodo, ntodo_dev, d_sc, d_status, d_xmx, d_xmx_off, d_dp, d_dp_off, unihit, d_cfg_len);
+    })
+  } else {
+    BATH_C_SWITCH(C, {
+      if (shmem > 64 * 1024) BATH_HIP_TRY(ctx, hipFuncSetAttribute((const void *)fwd_wave_kernel<CC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+      hipLaunchKernelGGL(fwd_wave_kernel<CC>, dim3(grid), dim3(256), shmem, ctx->stream, v, om->M, om->d_rf, om->d_tf, om->lt.d_pmove, c, d_todo, ntodo, ntodo_dev, d_sc, d_status, d_xmx, d_xmx_off, d_dp, d_dp_off, unihit, d_cfg_len);
+    })
+  }
   BATH_HIP_TRY(ctx, hipGetLastError());
   return BATH_OK;
 }
@@ -727,10 +743,16 @@ int launch_bwd_wave(bath_hip_ctx *ctx, const bath_hip_oprofile *om, SeqView v, i
   const size_t shmem = ((size_t)(om->M + 2) * 8 + (size_t)kKp * (om->M + 2)) * sizeof(float);
   FwdConsts c{om->xf_E[0], om->xf_E[1]};
   if (unihit) { c.xfE_loop = 0.0f; c.xfE_move = 1.0f; }
-  BATH_C_SWITCH(C, {
-    if (shmem > 64 * 1024) BATH_HIP_TRY(ctx, hipFuncSetAttribute((const void *)bwd_wave_kernel<CC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    hipLaunchKernelGGL(bwd_wave_kernel<CC>, dim3(grid), dim3(256), shmem, ctx->stream, v, om->M, om->d_rf, om->d_tf, om->lt.d_pmove, c, n, d_fwd_xmx, d_xmx_off, d_sc, d_status, d_bck_xmx, d_dp, d_dp_off, unihit);
-  })
+  if (shmem > kWaveTableLdsMax) {
+    BATH_C_SWITCH(C, {
+      hipLaunchKernelGGL((bwd_wave_kernel<CC, true>), dim3(grid), dim3(256), 0, ctx->stream, v, om->M, om->d_rfb, om->d_tfb, om->lt.d_pmove, c, n, d_fwd_xmx, d_xmx_off, d_sc, d_status, d_bck_xmx, d_dp, d_dp_off, unihit);
+    })
+  } else {
+    BATH_C_SWITCH(C, {
+      if (shmem > 64 * 1024) BATH_HIP_TRY(ctx, hipFuncSetAttribute((const void *)bwd_wave_kernel<CC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+      hipLaunchKernelGGL(bwd_wave_kernel<CC>, dim3(grid), dim3(256), shmem, ctx->stream, v, om->M, om->d_rf, om->d_tf, om->lt.d_pmove, c, n, d_fwd_xmx, d_xmx_off, d_sc, d_status, d_bck_xmx, d_dp, d_dp_off, unihit);
+    })
+  }
   BATH_HIP_TRY(ctx, hipGetLastError());
   return BATH_OK;
 }

@@ -152,7 +152,7 @@ extern "C" void bath_hip_oprofile_destroy(bath_hip_oprofile *om) {
   if (!om) return;
   for (void *p : {(void *)om->d_emit, (void *)om->d_ssv, (void *)om->d_rb, (void *)om->d_rw, (void *)om->d_tw, (void *)om->d_rf, (void *)om->d_tf,
                   (void *)om->d_bias_eo, (void *)om->d_vit_rw, (void *)om->d_vit_tw2, (void *)om->d_vit_tdd, (void *)om->d_vit_rank, (void *)om->lt.d_tjb, (void *)om->lt.d_xwmove, (void *)om->lt.d_pmove,
-                  (void *)om->lt.d_nullsc, (void *)om->lt.d_lt1, (void *)om->lt.d_lt2, (void *)om->lt.d_p1, (void *)om->d_cons, (void *)om->d_msc, (void *)om->d_tsc})
+                  (void *)om->lt.d_nullsc, (void *)om->lt.d_lt1, (void *)om->lt.d_lt2, (void *)om->lt.d_p1, (void *)om->d_cons, (void *)om->d_msc, (void *)om->d_tsc, (void *)om->d_rfb, (void *)om->d_tfb})
     if (p) (void)hipFree(p);
   delete om;
 }
@@ -315,6 +315,14 @@ extern "C" int bath_hip_oprofile_convert(bath_hip_ctx *ctx, const bath_profile *
   BATH_HIP_TRY(ctx, upload(&om->d_tw, om->tw.data(), om->tw.size(), ctx->stream));
   BATH_HIP_TRY(ctx, upload(&om->d_rf, om->rf.data(), om->rf.size(), ctx->stream));
   BATH_HIP_TRY(ctx, upload(&om->d_tf, om->tf.data(), om->tf.size(), ctx->stream));
+  {
+    std::vector<float> tfb((size_t)(M + 2) * 8, 0.f), rfb((size_t)kKp * (M + 2), 0.f);
+    std::memcpy(tfb.data(), om->tf.data(), sizeof(float) * (size_t)(M + 1) * 8);
+    for (int x = 0; x < kKp; x++) std::memcpy(&rfb[(size_t)x * (M + 2)], &om->rf[(size_t)x * W], sizeof(float) * W);
+    BATH_HIP_TRY(ctx, upload(&om->d_tfb, tfb.data(), tfb.size(), ctx->stream));
+    BATH_HIP_TRY(ctx, upload(&om->d_rfb, rfb.data(), rfb.size(), ctx->stream));
+    BATH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  }
   {
     // the generic profile's own log scores, for the per-position alignment score (p7_pli_computeAliScores_BATH reads them from
     // gm_fs5, whose amino rows and transitions are these numbers)

@@ -53,6 +53,42 @@ def test_ssv_bit_exact(setup):
     assert set(np.unique(ost)) >= {0}, "test set must exercise the OK branch"
 
 
+@pytest.mark.parametrize("M", [16, 33, 64, 100, 152, 153, 200, 260, 416, 417, 600, 830, 1300, 1664])
+def test_ssv_every_register_tiling(gpu_ctx, tmp_path, M):
+    """The lane-per-target SSV kernels are instantiated per register count (NR = 16 .. 208 in steps of 4 / 16) and lanes per
+    target (G = 1, 2, 4, 8), with hand-pipelined LDS reads and a VGPR bound that depends on NR: a sweep over model lengths
+    that lands on the shapes' boundaries (152 | 153: the last NR with 4 waves per SIMD; 416 | 417: one | two lanes per target).
+    Both entry points: the standalone filter (ssv_lane_kernel) and the cascade (ssv_orf_kernel, through the survivors'
+    MSV scores and the counters)."""
+    path = common.write_synthetic_bhmm(str(tmp_path / ("s%d.bhmm" % M)), M, seed=M)
+    model = ol.Model(path, 0)
+    hmm = ba.HMM(path, 0)
+    om = ba.OProfile(gpu_ctx, ba.Profile(hmm))
+    rng = np.random.default_rng(M)
+    seqs = common.random_aa(rng, 150, 20, 300) + common.emit_from_model(rng, model, 60) + common.emit_from_model(rng, model, 20, sharpen=3.0)
+    sc, st = ba.SSVFilter(gpu_ctx, om, ba.SeqBlock(gpu_ctx, seqs))
+    osc, ost = common.oracle_scores(model, seqs, "bo_ssvfilter")
+    assert np.array_equal(st, ost)
+    ok = ost == 0
+    assert ok.sum() > 0 and _same_scores(sc[ok], osc[ok])
+    wins = [np.array(common.revtranslate(rng, aa, model.basic), dtype=np.uint8) for aa in common.emit_from_model(rng, model, 12, flank=10)]
+    wins += common.random_dna(rng, 24, 900)
+    stats, res = ba.Pipeline(gpu_ctx, om, fs_pipe=False).run(ba.SeqBlock(gpu_ctx, wins))
+    pli, ores, _ = model.run_pipeline(wins)
+    for f in ("n_orfs", "n_past_msv", "pos_past_msv", "pos_past_bias", "pos_past_vit", "pos_past_fwd"):
+        assert getattr(stats, f) == getattr(pli, f), f
+    want = sorted(np.float32(r.usc).view(np.uint32) for r in ores if r.stage >= 1)
+    got = sorted(np.float32(u).view(np.uint32) for u in res["usc"])
+    assert want == got
+    if M == 1300:
+        # above ~1100 nodes the Forward / Backward tables no longer fit the LDS and are read from global memory; above 1024 the
+        # envelope kernels take the lane-per-envelope path: the hits must still be the oracle's
+        _, dm, _ = ba.Pipeline(gpu_ctx, om, fs_pipe=False).run_hits(ba.SeqBlock(gpu_ctx, wins[:12]))
+        _, odm, per_d, _ = model.run_pipeline_hits(wins[:12])
+        key = lambda w, d: (w, d.ienv, d.jenv, d.iali, d.jali, d.ihmm, d.jhmm)
+        assert len(odm) >= 6 and sorted(key(d.window, d) for d in dm) == sorted(key(w, o) for w, (a, b) in enumerate(per_d) for o in odm[a:b])
+
+
 def test_msv_bit_exact(setup):
     ctx, model, om, seqs, sq = setup
     sc, st = ba.MSVFilter(ctx, om, sq)
