@@ -1146,13 +1146,15 @@ static int fs3_parser(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, const bat
 
 // p7_DomainDecoding_Frameshift (generic form, generic_decoding_frameshift.c:204-290) and the region heuristics of
 // p7_domaindef_ByPosteriorHeuristics_Frameshift_BATH (p7_domaindef.c:328-392, is_multidomain_region_frameshift :684-714)
-// on the parsers' special-state rows, one lane per window: O(L) work on rows that are already in HBM, so that only the
-// regions (a few integers per window) travel to the host.
+// on the parsers' special-state rows, one WAVE per window: the posterior terms (11 expf per position) are elementwise and
+// computed by all 64 lanes; the two running sums and the scan for regions are serial and short, lane 0 does them with the
+// reference's own order of additions.  Only the regions (a few integers per window) travel to the host.
 constexpr int kMaxRegions = 24;
-__global__ void fs_regions_kernel(int64_t n, const int32_t *__restrict__ len, const float *__restrict__ fx, const float *__restrict__ bx,
+__global__ __launch_bounds__(64) void fs_regions_kernel(int64_t n, const int32_t *__restrict__ len, const float *__restrict__ fx, const float *__restrict__ bx,
                                   const int64_t *__restrict__ x_off, const float *__restrict__ tbl, float loop, float *__restrict__ work /* 3 floats per xmx row */,
                                   int32_t *__restrict__ regions /* [n][1 + 3*kMaxRegions]: count, then {i, j, multidomain} */) {
-  const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t w = blockIdx.x;
+  const int lane = threadIdx.x;
   if (w >= n) return;
   enum { XE = 0, XN, XJ, XB, XC };
   const int L = len[w];
@@ -1160,31 +1162,30 @@ __global__ void fs_regions_kernel(int64_t n, const int32_t *__restrict__ len, co
   float *btot = work + (x_off[w] / 5) * 3, *etot = btot + (L + 1), *mocc = etot + (L + 1);
   int32_t *out = regions + w * (1 + 3 * kMaxRegions);
   int nreg = 0;
-  out[0] = 0;
-  if (L < 6) return;
+  if (L < 6) { if (lane == 0) out[0] = 0; return; }
   const float Z = flogsum<false>(B[0 * 5 + XN], flogsum<false>(B[1 * 5 + XN], B[2 * 5 + XN], tbl), tbl);
-  if (!(Z > -INFINITY)) { out[0] = -1; return; }                              // Backward underflow: the window is skipped (p7_pipeline.c:1471)
-  for (int i = 0; i < 3; i++) btot[i] = etot[i] = mocc[i] = 0.f;
-  for (int i = 3; i <= L; i++) {
-    btot[i] = btot[i - 3] + expf(F[(size_t)(i - 3) * 5 + XB] + B[(size_t)(i - 3) * 5 + XB] - Z);
-    etot[i] = etot[i - 3] + expf(F[(size_t)i * 5 + XE] + B[(size_t)i * 5 + XE] - Z);
-  }
+  if (!(Z > -INFINITY)) { if (lane == 0) out[0] = -1; return; }               // Backward underflow: the window is skipped (p7_pipeline.c:1471)
   auto em = [&](int s, int a, int b) { return expf(F[(size_t)a * 5 + s] + B[(size_t)b * 5 + s] + loop - Z); };
-  for (int i = 3; i < L - 1; i++) {
+  for (int i = lane; i <= L; i += 64) {
+    if (i < 3) { btot[i] = etot[i] = mocc[i] = 0.f; continue; }
+    btot[i] = expf(F[(size_t)(i - 3) * 5 + XB] + B[(size_t)(i - 3) * 5 + XB] - Z);      // the terms; summed below
+    etot[i] = expf(F[(size_t)i * 5 + XE] + B[(size_t)i * 5 + XE] - Z);
     float p = 0.0f;
-    p += em(XN, i - 3, i); p += em(XN, i - 2, i + 1); p += em(XN, i - 1, i + 2);
-    p += em(XC, i - 3, i); p += em(XC, i - 2, i + 1); p += em(XC, i - 1, i + 2);
-    p += em(XJ, i - 3, i); p += em(XJ, i - 2, i + 1); p += em(XJ, i - 1, i + 2);
+    if (i < L - 1) {
+      p += em(XN, i - 3, i); p += em(XN, i - 2, i + 1); p += em(XN, i - 1, i + 2);
+      p += em(XC, i - 3, i); p += em(XC, i - 2, i + 1); p += em(XC, i - 1, i + 2);
+      p += em(XJ, i - 3, i); p += em(XJ, i - 2, i + 1); p += em(XJ, i - 1, i + 2);
+    } else if (i == L - 1) {
+      p += em(XN, L - 4, L - 1); p += em(XN, L - 3, L); p += em(XC, L - 4, L - 1); p += em(XC, L - 3, L); p += em(XJ, L - 4, L - 1); p += em(XJ, L - 3, L);
+    } else {
+      p += em(XN, L - 3, L); p += em(XC, L - 3, L); p += em(XJ, L - 3, L);
+    }
     mocc[i] = (float)(1. - p);
   }
-  {
-    float p = 0.0f;
-    p += em(XN, L - 4, L - 1); p += em(XN, L - 3, L); p += em(XC, L - 4, L - 1); p += em(XC, L - 3, L); p += em(XJ, L - 4, L - 1); p += em(XJ, L - 3, L);
-    mocc[L - 1] = (float)(1. - p);
-    p = 0.0f;
-    p += em(XN, L - 3, L); p += em(XC, L - 3, L); p += em(XJ, L - 3, L);
-    mocc[L] = (float)(1. - p);
-  }
+  __syncthreads();
+  if (lane != 0) return;
+  out[0] = 0;
+  for (int i = 3; i <= L; i++) { btot[i] = btot[i - 3] + btot[i]; etot[i] = etot[i - 3] + etot[i]; }
   const float rt1 = 0.25f, rt2 = 0.10f, rt3 = 0.20f;                         // p7_domaindef.c:80-82
   bool triggered = false;
   int d = 0;
@@ -1274,7 +1275,7 @@ int fs3_regions(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, const bath_hip_
     hipLaunchKernelGGL((fs_bwd_kernel<CC, 3, false>), dim3(grid_dp), dim3(kFsBlock), shmem, ctx->side_stream, dna->view(), fsdev(om), om->d_loop[0], om->d_move[0], tE, tE, b_sc.as<float>() + n, (float *)nullptr, (const int64_t *)nullptr, b_bx.as<float>(), b_off.as<int64_t>());
   })
   if ((st = fs_join(ctx)) != BATH_OK) return st;
-  hipLaunchKernelGGL(fs_regions_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, n, dna->d_len, b_fx.as<float>(), b_bx.as<float>(), b_off.as<int64_t>(), om->d_logsum, loop,
+  hipLaunchKernelGGL(fs_regions_kernel, dim3((unsigned)n), dim3(64), 0, ctx->stream, n, dna->d_len, b_fx.as<float>(), b_bx.as<float>(), b_off.as<int64_t>(), om->d_logsum, loop,
                      b_work.as<float>(), b_reg.as<int32_t>());
   BATH_HIP_TRY(ctx, hipGetLastError());
   BATH_HIP_TRY(ctx, hipMemcpyAsync(regions_out, b_reg.p, reg_ints * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
