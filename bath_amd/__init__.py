@@ -26,7 +26,7 @@ LIB_PATH = os.path.join(_HERE, "libbathhip.so")
 
 OK, ERANGE, ENORESULT = 0, 16, 19
 KP, K, NEVPARAM = 29, 20, 8
-LOGSUM_TABLE, LOGSUM_EXACT = 0, 1
+LOGSUM_TABLE, LOGSUM_EXACT, LOGSUM_TABLE_SERIAL = 0, 1, 2
 
 DNA_SYMS = "ACGT-RYMKSWHBVDN*~"
 AMINO_SYMS = "ACDEFGHIKLMNPQRSTVWY-BJZOUX*~"
@@ -143,6 +143,7 @@ ABI = {
     "bath_hip_last_error": (C.c_char_p, [_vp]),
     "bath_hip_synchronize": (C.c_int, [_vp]),
     "bath_hip_stream": (_vp, [_vp]),
+    "bath_hip_set_fs_strict": (C.c_int, [_vp, C.c_int]),
     "bath_hip_oprofile_convert": (C.c_int, [_vp, C.POINTER(_Profile), C.POINTER(_vp)]),
     "bath_hip_oprofile_destroy": (None, [_vp]),
     "bath_hip_oprofile_M": (C.c_int, [_vp]),
@@ -338,6 +339,10 @@ class Context:
 
     def synchronize(self):
         self._check(lib().bath_hip_synchronize(self._h), "synchronize")
+
+    def set_fs_strict(self, on=True):
+        """Frameshift log-sums along the model in the reference's serial order (bit-identical to the generic reference)."""
+        self._check(lib().bath_hip_set_fs_strict(self._h, 1 if on else 0), "set_fs_strict")
 
     @property
     def stream(self):

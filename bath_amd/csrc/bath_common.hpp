@@ -81,6 +81,7 @@ struct bath_hip_ctx {
   hipStream_t side_stream = nullptr;    // created on first use: kernels that may overlap the main stream's (pipeline)
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   hipDeviceProp_t prop{};
+  int fs_strict = 0;                    // bath_hip_set_fs_strict: frameshift log-sums along the model in the reference's serial order
   std::string err;
   void set_error(const std::string &m) { err = m; }
   // scratch owned by the context (reused across calls)

@@ -98,14 +98,90 @@ __device__ __forceinline__ void d_chain_fwd(const float (&md)[C], const float (&
   for (int c = 1; c < C; c++) Dout[c] = flogsum<EXACT>(md[c - 1], Dout[c - 1] + dd[c - 1], tbl);
 }
 
+// BATH_LOGSUM_TABLE_SERIAL ("strict"): the reference's own order of the sums along the model (generic_fwdback_frameshift.c:
+// 340-365, 577-590): D(i,k) from D(i,k-1) node by node and E(i) accumulated in the same walk, one lane after the other.
+// With the truncating table every log-sum is then the reference's log-sum of the reference's operands: results are
+// bit-identical to the generic reference, at the cost of a 64-step hand-off per row.  Returns E(i).
+template <int C>
+__device__ __forceinline__ float fwd_chain_strict(const float (&Mc)[C], const float (&md)[C], const float (&dd)[C], float (&Dout)[C], int lane, int M,
+                                                  bool pair_first_at_M, const float *tbl) {
+  const int nl = (M + C - 1) / C;                         // lanes that hold nodes
+  float dnext = -INFINITY, e = -INFINITY;                 // D at the first node of the next lane; E after this lane's nodes
+#pragma unroll
+  for (int c = 0; c < C; c++) Dout[c] = -INFINITY;
+  for (int l = 0; l < nl; l++) {
+    const float din = (l == 0) ? -INFINITY : __shfl(dnext, l - 1, 64);
+    const float ein = (l == 0) ? -INFINITY : __shfl(e, l - 1, 64);
+    if (lane == l) {
+      float dcur = din, ecur = ein;
+#pragma unroll
+      for (int c = 0; c < C; c++) {
+        const int node = l * C + c + 1;
+        if (node <= M) {
+          Dout[c] = dcur;
+          if (node == M && pair_first_at_M) ecur = flogsum<false>(flogsum<false>(Mc[c], dcur, tbl), ecur, tbl);   // :392
+          else ecur = flogsum<false>(Mc[c], flogsum<false>(dcur, ecur, tbl), tbl);
+          dcur = flogsum<false>(md[c], dcur + dd[c], tbl);
+        }
+      }
+      dnext = dcur; e = ecur;
+    }
+  }
+  return __shfl(e, nl - 1, 64);
+}
+
+// Backward, strict order: B(i) = a(1)+tBM(0), then LS(B, a(k)+tBM(k-1)) for k = 2..M (generic_fwdback_frameshift.c:1279-1283)
+template <int C>
+__device__ __forceinline__ float bwd_bsum_strict(const float (&term)[C], int lane, int M, const float *tbl) {
+  const int nl = (M + C - 1) / C;
+  float b = -INFINITY;
+  for (int l = 0; l < nl; l++) {
+    const float bin = (l == 0) ? -INFINITY : __shfl(b, l - 1, 64);
+    if (lane == l) {
+      float cur = bin;
+#pragma unroll
+      for (int c = 0; c < C; c++) {
+        const int node = l * C + c + 1;
+        if (node <= M) cur = (node == 1) ? term[c] : flogsum<false>(cur, term[c], tbl);
+      }
+      b = cur;
+    }
+  }
+  return __shfl(b, nl - 1, 64);
+}
+
+// ... and the descending D chain: dstep(c, node, D(node+1)) -> D(node) is the row's own formula; returns D at the first node of
+// the NEXT lane (what the lane's last node needs), every value computed in the reference's order.
+template <int C, class F>
+__device__ __forceinline__ float bwd_dnext_strict(F &&dstep, int lane, int M) {
+  const int nl = (M + C - 1) / C;
+  float dfirst = -INFINITY;
+  for (int l = nl - 1; l >= 0; l--) {
+    const float dn_in = (l == nl - 1) ? -INFINITY : __shfl(dfirst, l + 1, 64);
+    if (lane == l) {
+      float dn = dn_in;
+#pragma unroll
+      for (int c = C - 1; c >= 0; c--) {
+        const int node = l * C + c + 1;
+        if (node <= M) dn = dstep(c, node, dn);
+      }
+      dfirst = dn;
+    }
+  }
+  float dnext = __shfl_down(dfirst, 1, 64);
+  if (lane >= nl - 1) dnext = -INFINITY;
+  return dnext;
+}
+
 // ---------------------------------------------------------------------------------------------
 // 3-codon Forward parser.  Row convention of the reference's parser: IVX(i,k) collects the paths
 // leaving row i-2 (generic_fwdback_frameshift.c:562-569), so codon lengths 2,3,4 read IVX(i), IVX(i-1), IVX(i-2).
 // tf[node] = {tMM(k-1), tIM(k-1), tDM(k-1), tBM(k-1), tMD(k), tDD(k), tMI(k), tII(k)}
 // ---------------------------------------------------------------------------------------------
-template <int C, bool EXACT>
+template <int C, int MODE>
 __global__ __launch_bounds__(kFsBlock) void fs3_fwd_kernel(SeqView dna, FsDev p, const float *__restrict__ loop_tab, const float *__restrict__ move_tab,
                                                       float tEL, float tEM, float *__restrict__ sc, float *__restrict__ xmx, const int64_t *__restrict__ xmx_off) {
+  constexpr bool EXACT = (MODE == 1), STRICT = (MODE == 2);   // 0: table + scans, 1: exact log-sums, 2: table in the reference's serial order
   extern __shared__ __attribute__((aligned(16))) char lds[];
   float *s_tbl = reinterpret_cast<float *>(lds);
   float *s_tf = s_tbl + kLogsumTbl;
@@ -183,14 +259,18 @@ __global__ __launch_bounds__(kFsBlock) void fs3_fwd_kernel(SeqView dna, FsDev p,
         } else { Mc[c] = -INFINITY; Ic[c] = -INFINITY; ivc[c] = -INFINITY; md[c] = -INFINITY; dd[c] = -INFINITY; }
       }
       float Dc[C];
-      d_chain_fwd<C, EXACT>(md, dd, Dc, lane, s_tbl);
+      float xE;
+      if constexpr (STRICT) xE = fwd_chain_strict<C>(Mc, md, dd, Dc, lane, M, false, s_tbl);
+      else {
+        d_chain_fwd<C, EXACT>(md, dd, Dc, lane, s_tbl);
 #pragma unroll
-      for (int c = 0; c < C; c++) {
-        const int node = lane * C + c + 1;
-        if (node <= M) eloc = LS(Mc[c], LS(Dc[c], eloc));
-        else Dc[c] = -INFINITY;
+        for (int c = 0; c < C; c++) {
+          const int node = lane * C + c + 1;
+          if (node <= M) eloc = LS(Mc[c], LS(Dc[c], eloc));
+          else Dc[c] = -INFINITY;
+        }
+        xE = wave_logsum<EXACT>(eloc, s_tbl);
       }
-      const float xE = wave_logsum<EXACT>(eloc, s_tbl);
       float nN, nJ, nC, nB;
       if (i == 2) { nN = 0.f; nJ = xE + tEL; nC = xE + tEM; }
       else { nN = xN[2] + tNL; nJ = LS(xJ[2] + tJL, xE + tEL); nC = LS(xC[2] + tCL, xE + tEM); }
@@ -219,11 +299,12 @@ __global__ __launch_bounds__(kFsBlock) void fs3_fwd_kernel(SeqView dna, FsDev p,
 // IVX(i,k) collects the paths leaving row i-1; codon length c reads IVX(i-c+1).
 // c5_compat selects the ring slot the generic reference reads for 5-nt codons.
 // ---------------------------------------------------------------------------------------------
-template <int C, bool EXACT>
+template <int C, int MODE>
 __global__ __launch_bounds__(kFsBlock) void fs5_fwd_kernel(SeqView dna, FsDev p, const float *__restrict__ loop_tab, const float *__restrict__ move_tab,
                                                       float tEL, float tEM, int c5_compat, float *__restrict__ sc,
                                                       float *__restrict__ fwd, const int64_t *__restrict__ fwd_off, float *__restrict__ xmx, const int64_t *__restrict__ xmx_off,
                                                       int cfg_len /* >= 0: the amino length the model is configured for, instead of L/3 */) {
+  constexpr bool EXACT = (MODE == 1), STRICT = (MODE == 2);   // 0: table + scans, 1: exact log-sums, 2: table in the reference's serial order
   extern __shared__ __attribute__((aligned(16))) char lds[];
   float *s_tbl = reinterpret_cast<float *>(lds);
   float *s_tf = s_tbl + kLogsumTbl;
@@ -303,15 +384,25 @@ __global__ __launch_bounds__(kFsBlock) void fs5_fwd_kernel(SeqView dna, FsDev p,
         } else { Mc[c] = -INFINITY; Ic[c] = -INFINITY; ivc[c] = -INFINITY; md[c] = -INFINITY; dd[c] = -INFINITY; }
       }
       float Dc[C];
-      d_chain_fwd<C, EXACT>(md, dd, Dc, lane, s_tbl);
-      float eloc = -INFINITY;
+      float xE;
+      if constexpr (STRICT) {
+        xE = fwd_chain_strict<C>(Mc, md, dd, Dc, lane, M, i >= 5, s_tbl);
 #pragma unroll
-      for (int c = 0; c < C; c++) {
-        const int node = lane * C + c + 1;
-        if (node <= M) { row[(size_t)node * 8] = Dc[c]; eloc = LS(Mc[c], LS(Dc[c], eloc)); }
-        else Dc[c] = -INFINITY;
+        for (int c = 0; c < C; c++) {
+          const int node = lane * C + c + 1;
+          if (node <= M) row[(size_t)node * 8] = Dc[c];
+        }
+      } else {
+        d_chain_fwd<C, EXACT>(md, dd, Dc, lane, s_tbl);
+        float eloc = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+          const int node = lane * C + c + 1;
+          if (node <= M) { row[(size_t)node * 8] = Dc[c]; eloc = LS(Mc[c], LS(Dc[c], eloc)); }
+          else Dc[c] = -INFINITY;
+        }
+        xE = wave_logsum<EXACT>(eloc, s_tbl);
       }
-      const float xE = wave_logsum<EXACT>(eloc, s_tbl);
       float nN, nJ, nC, nB;
       if (i <= 2) { nN = 0.f; nJ = xE + tEL; nC = xE + tEM; nB = tNM; }           // :126-132, :166-167
       else {
@@ -343,10 +434,11 @@ __global__ __launch_bounds__(kFsBlock) void fs5_fwd_kernel(SeqView dna, FsDev p,
 // Row types follow the reference: rows without an emitted codon, "tail" rows with no i+3 row,
 // accumulate-left-to-right rows (L-3, L-4) and the main recursion (generic_fwdback_frameshift.c:1054-1323, 1442-1677).
 // ---------------------------------------------------------------------------------------------
-template <int C, int NCOD, bool EXACT>
+template <int C, int NCOD, int MODE>
 __global__ __launch_bounds__(kFsBlock) void fs_bwd_kernel(SeqView dna, FsDev p, const float *__restrict__ loop_tab, const float *__restrict__ move_tab,
                                                      float tEL, float tEM, float *__restrict__ sc,
                                                      float *__restrict__ bck, const int64_t *__restrict__ bck_off, float *__restrict__ xmx, const int64_t *__restrict__ xmx_off) {
+  constexpr bool EXACT = (MODE == 1), STRICT = (MODE == 2);   // 0: table + scans, 1: exact log-sums, 2: table in the reference's serial order
   extern __shared__ __attribute__((aligned(16))) char lds[];
   float *s_tbl = reinterpret_cast<float *>(lds);
   float *s_tb = s_tbl + kLogsumTbl;
@@ -392,20 +484,25 @@ __global__ __launch_bounds__(kFsBlock) void fs_bwd_kernel(SeqView dna, FsDev p, 
         xJn = xNn = -INFINITY;
         xE = xCn + tEM;
         // D(i,k) = LS(E, D(i,k+1)+tDD(k)), M(i,k) = LS(E, D(i,k+1)+tMD(k)): reverse chain
-        float A = -INFINITY, B = 0.f;              // lane function applied to D(i, last node of lane + 1)
+        float dnext;
+        if constexpr (STRICT) {
+          dnext = bwd_dnext_strict<C>([&](int, int node, float dn) { return (node == M) ? xE : LS(xE, dn + s_tb[node * 8 + 3]); }, lane, M);
+        } else {
+          float A = -INFINITY, B = 0.f;              // lane function applied to D(i, last node of lane + 1)
 #pragma unroll
-        for (int c = C - 1; c >= 0; c--) {
-          const int node = lane * C + c + 1;
-          const float tdd = (node < M) ? s_tb[node * 8 + 3] : -INFINITY;
-          if (node <= M) { A = (node == M) ? xE : LS(xE, A + tdd); B = (node == M) ? -INFINITY : B + tdd; }
-        }
+          for (int c = C - 1; c >= 0; c--) {
+            const int node = lane * C + c + 1;
+            const float tdd = (node < M) ? s_tb[node * 8 + 3] : -INFINITY;
+            if (node <= M) { A = (node == M) ? xE : LS(xE, A + tdd); B = (node == M) ? -INFINITY : B + tdd; }
+          }
 #pragma unroll
-        for (int dlt = 1; dlt < 64; dlt <<= 1) {
-          const float An = __shfl_down(A, dlt, 64), Bn = __shfl_down(B, dlt, 64);
-          if (lane + dlt < 64) { A = LS(A, An + B); B += Bn; }
+          for (int dlt = 1; dlt < 64; dlt <<= 1) {
+            const float An = __shfl_down(A, dlt, 64), Bn = __shfl_down(B, dlt, 64);
+            if (lane + dlt < 64) { A = LS(A, An + B); B += Bn; }
+          }
+          dnext = __shfl_down(A, 1, 64);
+          if (lane == 63) dnext = -INFINITY;
         }
-        float dnext = __shfl_down(A, 1, 64);
-        if (lane == 63) dnext = -INFINITY;
 #pragma unroll
         for (int c = C - 1; c >= 0; c--) {
           const int node = lane * C + c + 1;
@@ -436,6 +533,7 @@ __global__ __launch_bounds__(kFsBlock) void fs_bwd_kernel(SeqView dna, FsDev p, 
         }
         // ivx[k] = logsum_c M(i+c,k)+e_c(k);  B(i) = logsum_k ivx[k]+tBM(k-1)
         float ivx[C];
+        [[maybe_unused]] float bterm[C];
         float bloc = -INFINITY;
 #pragma unroll
         for (int c = 0; c < C; c++) {
@@ -459,9 +557,11 @@ __global__ __launch_bounds__(kFsBlock) void fs_bwd_kernel(SeqView dna, FsDev p, 
             }
           }
           ivx[c] = a;
-          bloc = LS(bloc, a + s_tb[node * 8 + 7]);
+          if constexpr (STRICT) bterm[c] = a + s_tb[node * 8 + 7];
+          else bloc = LS(bloc, a + s_tb[node * 8 + 7]);
         }
-        xBn = wave_logsum<EXACT>(bloc, s_tbl);
+        if constexpr (STRICT) xBn = bwd_bsum_strict<C>(bterm, lane, M, s_tbl);
+        else xBn = wave_logsum<EXACT>(bloc, s_tbl);
         if (i == 0) {
           n0 = LS(xN3[2] + tNL, xBn + tNM);
           if (xo && lane == 0) { xo[0] = -INFINITY; xo[1] = n0; xo[2] = -INFINITY; xo[3] = xBn; xo[4] = -INFINITY; }
@@ -486,17 +586,28 @@ __global__ __launch_bounds__(kFsBlock) void fs_bwd_kernel(SeqView dna, FsDev p, 
           if (node == M) { base[c] = xE; A = xE; B = -INFINITY; }
           else {
             base[c] = ivn + tdm;
-            A = (!FIVE && !mainrow && !tail) ? LS(A + tdd, LS(xE, base[c])) : LS(LS(xE, A + tdd), base[c]);
-            B += tdd;
+            if constexpr (!STRICT) {
+              A = (!FIVE && !mainrow && !tail) ? LS(A + tdd, LS(xE, base[c])) : LS(LS(xE, A + tdd), base[c]);
+              B += tdd;
+            }
           }
         }
+        float dnext;
+        if constexpr (STRICT) {
+          dnext = bwd_dnext_strict<C>([&](int c, int node, float dn) {
+            if (node == M) return xE;
+            const float tdd = s_tb[node * 8 + 3];
+            return (!FIVE && !mainrow && !tail) ? LS(dn + tdd, LS(xE, base[c])) : LS(LS(xE, dn + tdd), base[c]);
+          }, lane, M);
+        } else {
 #pragma unroll
-        for (int dlt = 1; dlt < 64; dlt <<= 1) {
-          const float An = __shfl_down(A, dlt, 64), Bn = __shfl_down(B, dlt, 64);
-          if (lane + dlt < 64) { A = LS(A, An + B); B += Bn; }
+          for (int dlt = 1; dlt < 64; dlt <<= 1) {
+            const float An = __shfl_down(A, dlt, 64), Bn = __shfl_down(B, dlt, 64);
+            if (lane + dlt < 64) { A = LS(A, An + B); B += Bn; }
+          }
+          dnext = __shfl_down(A, 1, 64);
+          if (lane == 63) dnext = -INFINITY;
         }
-        float dnext = __shfl_down(A, 1, 64);
-        if (lane == 63) dnext = -INFINITY;
 #pragma unroll
         for (int c = C - 1; c >= 0; c--) {
           const int node = lane * C + c + 1;
@@ -1075,6 +1186,14 @@ static int fs_columns(int M) {
     default: ctx->set_error("frameshift kernels support models up to 1024 nodes"); return BATH_EINVAL; \
   }
 
+// logsum_mode -> kernel MODE: 0 table + wavefront scans, 1 exact log-sums, 2 table in the reference's serial order ("strict")
+#define BATH_FS_MODE(modev, BODY)                         \
+  switch (modev) {                                        \
+    case 1: { constexpr int MD = 1; BODY } break;         \
+    case 2: { constexpr int MD = 2; BODY } break;         \
+    default: { constexpr int MD = 0; BODY } break;        \
+  }
+
 static FsDev fsdev(const bath_hip_fsprofile *om) { return FsDev{om->M, om->pitch, om->maxcodons, om->d_rsc, om->d_tf, om->d_tb, om->d_logsum}; }
 
 static int fs_grid(bath_hip_ctx *ctx, int64_t n) {
@@ -1121,22 +1240,15 @@ static int fs3_parser(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, const bat
   const float tE = (float)-0.69314718055994529;
   [[maybe_unused]] const int grid = fs_grid(ctx, n);
   const int grid_dp = fs_grid_dp(ctx, n);
-  const bool exact = (logsum_mode == BATH_LOGSUM_EXACT);
-  BATH_FS_SWITCH(Cv, {
+  BATH_FS_SWITCH(Cv, BATH_FS_MODE(logsum_mode, {
     if (!backward) {
-      if (exact) { if ((st = fs_set_shmem(ctx, fs3_fwd_kernel<CC, true>, shmem)) != BATH_OK) return st;
-        hipLaunchKernelGGL((fs3_fwd_kernel<CC, true>), dim3(grid_dp), dim3(kFsBlock), shmem, ctx->stream, dna->view(), fsdev(om), om->d_loop[0], om->d_move[0], tE, tE, b_sc.as<float>(), d_x, b_off.as<int64_t>());
-      } else { if ((st = fs_set_shmem(ctx, fs3_fwd_kernel<CC, false>, shmem)) != BATH_OK) return st;
-        hipLaunchKernelGGL((fs3_fwd_kernel<CC, false>), dim3(grid_dp), dim3(kFsBlock), shmem, ctx->stream, dna->view(), fsdev(om), om->d_loop[0], om->d_move[0], tE, tE, b_sc.as<float>(), d_x, b_off.as<int64_t>());
-      }
+      if ((st = fs_set_shmem(ctx, fs3_fwd_kernel<CC, MD>, shmem)) != BATH_OK) return st;
+      hipLaunchKernelGGL((fs3_fwd_kernel<CC, MD>), dim3(grid_dp), dim3(kFsBlock), shmem, ctx->stream, dna->view(), fsdev(om), om->d_loop[0], om->d_move[0], tE, tE, b_sc.as<float>(), d_x, b_off.as<int64_t>());
     } else {
-      if (exact) { if ((st = fs_set_shmem(ctx, fs_bwd_kernel<CC, 3, true>, shmem)) != BATH_OK) return st;
-        hipLaunchKernelGGL((fs_bwd_kernel<CC, 3, true>), dim3(grid_dp), dim3(kFsBlock), shmem, ctx->stream, dna->view(), fsdev(om), om->d_loop[0], om->d_move[0], tE, tE, b_sc.as<float>(), (float *)nullptr, (const int64_t *)nullptr, d_x, b_off.as<int64_t>());
-      } else { if ((st = fs_set_shmem(ctx, fs_bwd_kernel<CC, 3, false>, shmem)) != BATH_OK) return st;
-        hipLaunchKernelGGL((fs_bwd_kernel<CC, 3, false>), dim3(grid_dp), dim3(kFsBlock), shmem, ctx->stream, dna->view(), fsdev(om), om->d_loop[0], om->d_move[0], tE, tE, b_sc.as<float>(), (float *)nullptr, (const int64_t *)nullptr, d_x, b_off.as<int64_t>());
-      }
+      if ((st = fs_set_shmem(ctx, fs_bwd_kernel<CC, 3, MD>, shmem)) != BATH_OK) return st;
+      hipLaunchKernelGGL((fs_bwd_kernel<CC, 3, MD>), dim3(grid_dp), dim3(kFsBlock), shmem, ctx->stream, dna->view(), fsdev(om), om->d_loop[0], om->d_move[0], tE, tE, b_sc.as<float>(), (float *)nullptr, (const int64_t *)nullptr, d_x, b_off.as<int64_t>());
     }
-  })
+  }))
   BATH_HIP_TRY(ctx, hipGetLastError());
   BATH_HIP_TRY(ctx, hipMemcpyAsync(sc, b_sc.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
   if (xmx) BATH_HIP_TRY(ctx, hipMemcpyAsync(xmx, d_x, (size_t)xmx_off[n] * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
@@ -1268,12 +1380,13 @@ int fs3_regions(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, const bath_hip_
   const int grid_dp = fs_grid_dp(ctx, n);
   BATH_HIP_TRY(ctx, b_sc.reserve((size_t)n * 2 * sizeof(float)));
   if ((st = fs_fork(ctx)) != BATH_OK) return st;
-  BATH_FS_SWITCH(Cv, {
-    if ((st = fs_set_shmem(ctx, fs3_fwd_kernel<CC, false>, shmem)) != BATH_OK) return st;
-    hipLaunchKernelGGL((fs3_fwd_kernel<CC, false>), dim3(grid_dp), dim3(kFsBlock), shmem, ctx->stream, dna->view(), fsdev(om), om->d_loop[0], om->d_move[0], tE, tE, b_sc.as<float>(), b_fx.as<float>(), b_off.as<int64_t>());
-    if ((st = fs_set_shmem(ctx, fs_bwd_kernel<CC, 3, false>, shmem)) != BATH_OK) return st;
-    hipLaunchKernelGGL((fs_bwd_kernel<CC, 3, false>), dim3(grid_dp), dim3(kFsBlock), shmem, ctx->side_stream, dna->view(), fsdev(om), om->d_loop[0], om->d_move[0], tE, tE, b_sc.as<float>() + n, (float *)nullptr, (const int64_t *)nullptr, b_bx.as<float>(), b_off.as<int64_t>());
-  })
+  const int mode = ctx->fs_strict ? BATH_LOGSUM_TABLE_SERIAL : BATH_LOGSUM_TABLE;
+  BATH_FS_SWITCH(Cv, BATH_FS_MODE(mode, {
+    if ((st = fs_set_shmem(ctx, fs3_fwd_kernel<CC, MD>, shmem)) != BATH_OK) return st;
+    hipLaunchKernelGGL((fs3_fwd_kernel<CC, MD>), dim3(grid_dp), dim3(kFsBlock), shmem, ctx->stream, dna->view(), fsdev(om), om->d_loop[0], om->d_move[0], tE, tE, b_sc.as<float>(), b_fx.as<float>(), b_off.as<int64_t>());
+    if ((st = fs_set_shmem(ctx, fs_bwd_kernel<CC, 3, MD>, shmem)) != BATH_OK) return st;
+    hipLaunchKernelGGL((fs_bwd_kernel<CC, 3, MD>), dim3(grid_dp), dim3(kFsBlock), shmem, ctx->side_stream, dna->view(), fsdev(om), om->d_loop[0], om->d_move[0], tE, tE, b_sc.as<float>() + n, (float *)nullptr, (const int64_t *)nullptr, b_bx.as<float>(), b_off.as<int64_t>());
+  }))
   if ((st = fs_join(ctx)) != BATH_OK) return st;
   hipLaunchKernelGGL(fs_regions_kernel, dim3((unsigned)n), dim3(64), 0, ctx->stream, n, dna->d_len, b_fx.as<float>(), b_bx.as<float>(), b_off.as<int64_t>(), om->d_logsum, loop,
                      b_work.as<float>(), b_reg.as<int32_t>());
@@ -1287,7 +1400,7 @@ int fs3_regions(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, const bath_hip_
 namespace bath {
 // used by the pipeline's frameshift stage (bath_pipeline.hip)
 int fs3_forward_scores(bath_hip_ctx *ctx, const bath_hip_fsprofile *om3, const bath_hip_seqs *dna, float *sc) {
-  return fs3_parser(ctx, om3, dna, BATH_LOGSUM_TABLE, sc, nullptr, nullptr, false);
+  return fs3_parser(ctx, om3, dna, ctx->fs_strict ? BATH_LOGSUM_TABLE_SERIAL : BATH_LOGSUM_TABLE, sc, nullptr, nullptr, false);
 }
 const float *fsprofile_evparam(const bath_hip_fsprofile *om) { return om->evparam; }
 int fsprofile_codon_lengths(const bath_hip_fsprofile *om) { return om->codon_lengths; }
@@ -1352,21 +1465,16 @@ int bath::fs5_envelopes_ex(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, cons
   const size_t oa_shmem = (size_t)(M + 2) * 8 * sizeof(float);
   [[maybe_unused]] const int grid = fs_grid(ctx, n);
   const int grid_dp = fs_grid_dp(ctx, n);
-  const bool exact = (logsum_mode == BATH_LOGSUM_EXACT);
   const float tEL = -INFINITY, tEM = 0.0f;                                      // unihit: p7_fs_ReconfigUnihit, modelconfig.c:868
+  if (logsum_mode == BATH_LOGSUM_TABLE && ctx->fs_strict) logsum_mode = BATH_LOGSUM_TABLE_SERIAL;
   if ((st = fs_fork(ctx)) != BATH_OK) return st;                                // Backward on the side stream, concurrently with Forward
   BATH_FS_SWITCH(Cv, {
-    if (exact) {
-      if ((st = fs_set_shmem(ctx, fs5_fwd_kernel<CC, true>, shmem)) != BATH_OK) return st;
-      if ((st = fs_set_shmem(ctx, fs_bwd_kernel<CC, 5, true>, shmem)) != BATH_OK) return st;
-      hipLaunchKernelGGL((fs5_fwd_kernel<CC, true>), dim3(grid_dp), dim3(kFsBlock), shmem, ctx->stream, dna->view(), fsdev(om), om->d_loop[1], om->d_move[1], tEL, tEM, c5_compat, d_fsc, b_f.as<float>(), d_foff, b_fx.as<float>(), d_xoff, -1);
-      hipLaunchKernelGGL((fs_bwd_kernel<CC, 5, true>), dim3(grid_dp), dim3(kFsBlock), shmem, ctx->side_stream, dna->view(), fsdev(om), om->d_loop[1], om->d_move[1], tEL, tEM, d_bsc, b_b.as<float>(), d_boff, b_bx.as<float>(), d_xoff);
-    } else {
-      if ((st = fs_set_shmem(ctx, fs5_fwd_kernel<CC, false>, shmem)) != BATH_OK) return st;
-      if ((st = fs_set_shmem(ctx, fs_bwd_kernel<CC, 5, false>, shmem)) != BATH_OK) return st;
-      hipLaunchKernelGGL((fs5_fwd_kernel<CC, false>), dim3(grid_dp), dim3(kFsBlock), shmem, ctx->stream, dna->view(), fsdev(om), om->d_loop[1], om->d_move[1], tEL, tEM, c5_compat, d_fsc, b_f.as<float>(), d_foff, b_fx.as<float>(), d_xoff, -1);
-      hipLaunchKernelGGL((fs_bwd_kernel<CC, 5, false>), dim3(grid_dp), dim3(kFsBlock), shmem, ctx->side_stream, dna->view(), fsdev(om), om->d_loop[1], om->d_move[1], tEL, tEM, d_bsc, b_b.as<float>(), d_boff, b_bx.as<float>(), d_xoff);
-    }
+    BATH_FS_MODE(logsum_mode, {
+      if ((st = fs_set_shmem(ctx, fs5_fwd_kernel<CC, MD>, shmem)) != BATH_OK) return st;
+      if ((st = fs_set_shmem(ctx, fs_bwd_kernel<CC, 5, MD>, shmem)) != BATH_OK) return st;
+      hipLaunchKernelGGL((fs5_fwd_kernel<CC, MD>), dim3(grid_dp), dim3(kFsBlock), shmem, ctx->stream, dna->view(), fsdev(om), om->d_loop[1], om->d_move[1], tEL, tEM, c5_compat, d_fsc, b_f.as<float>(), d_foff, b_fx.as<float>(), d_xoff, -1);
+      hipLaunchKernelGGL((fs_bwd_kernel<CC, 5, MD>), dim3(grid_dp), dim3(kFsBlock), shmem, ctx->side_stream, dna->view(), fsdev(om), om->d_loop[1], om->d_move[1], tEL, tEM, d_bsc, b_b.as<float>(), d_boff, b_bx.as<float>(), d_xoff);
+    })
     if ((st = fs_join(ctx)) != BATH_OK) return st;
     BATH_HIP_TRY(ctx, hipMemsetAsync(b_cs.p, 0, (size_t)n * cs_stride * sizeof(float), ctx->stream));
     hipLaunchKernelGGL(fs5_decode_kernel, dim3(grid), dim3(256), 0, ctx->stream, dna->view(), M, om->d_loop[1], d_bsc, b_f.as<float>(), d_foff, b_fx.as<float>(), d_xoff,
@@ -1442,11 +1550,12 @@ int bath::fs5_region_forward(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, co
   [[maybe_unused]] const int grid = fs_grid(ctx, n);
   const int grid_dp = fs_grid_dp(ctx, n);
   const float tE = (float)-0.69314718055994529;                               // multihit: E->C and E->J both log 1/2 (modelconfig.c:825-831)
-  BATH_FS_SWITCH(Cv, {
-    if ((st = fs_set_shmem(ctx, fs5_fwd_kernel<CC, false>, shmem)) != BATH_OK) return st;
-    hipLaunchKernelGGL((fs5_fwd_kernel<CC, false>), dim3(grid_dp), dim3(kFsBlock), shmem, ctx->stream, dna->view(), fsdev(om), om->d_loop[0], om->d_move[0], tE, tE, 0, b_sc.as<float>(),
+  const int mode = ctx->fs_strict ? BATH_LOGSUM_TABLE_SERIAL : BATH_LOGSUM_TABLE;
+  BATH_FS_SWITCH(Cv, BATH_FS_MODE(mode, {
+    if ((st = fs_set_shmem(ctx, fs5_fwd_kernel<CC, MD>, shmem)) != BATH_OK) return st;
+    hipLaunchKernelGGL((fs5_fwd_kernel<CC, MD>), dim3(grid_dp), dim3(kFsBlock), shmem, ctx->stream, dna->view(), fsdev(om), om->d_loop[0], om->d_move[0], tE, tE, 0, b_sc.as<float>(),
                        b_f.as<float>(), d_foff, b_fx.as<float>(), d_xoff, cfg_len_amino);
-  })
+  }))
   BATH_HIP_TRY(ctx, hipGetLastError());
   sc->resize((size_t)n);
   BATH_HIP_TRY(ctx, ctx->pinned[0].reserve((size_t)foff[(size_t)n] * 4 + 64)); BATH_HIP_TRY(ctx, ctx->pinned[1].reserve((size_t)xoff[(size_t)n] * 4 + 64));

@@ -854,6 +854,7 @@ extern "C" int bath_hip_pipeline_filters(bath_hip_ctx *ctx, const bath_hip_oprof
         if (hipStreamCreateWithPriority(&lane->stream, hipStreamNonBlocking, prio) != hipSuccess) { ctx->set_error("hipStreamCreateWithPriority"); return BATH_EFAIL; }
       }
     }
+    lane->fs_strict = ctx->fs_strict;
     ctx->lanes.push_back(lane);
   }
   if ((st = ensure_parts(ctx, dna, K)) != BATH_OK) return st;

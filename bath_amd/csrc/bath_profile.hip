@@ -145,6 +145,12 @@ extern "C" int bath_hip_synchronize(bath_hip_ctx *ctx) {
 }
 
 extern "C" void *bath_hip_stream(bath_hip_ctx *ctx) { return (void *)ctx->stream; }
+extern "C" int bath_hip_set_fs_strict(bath_hip_ctx *ctx, int on) {
+  if (!ctx) return BATH_EINVAL;
+  ctx->fs_strict = on ? 1 : 0;
+  for (bath_hip_ctx *l : ctx->lanes) l->fs_strict = ctx->fs_strict;
+  return BATH_OK;
+}
 
 // ------------------------------------------------------------------------------------------ oprofile
 

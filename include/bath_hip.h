@@ -107,6 +107,11 @@ void        bath_hip_finalize(bath_hip_ctx *ctx);
 const char *bath_hip_last_error(const bath_hip_ctx *ctx);
 int         bath_hip_synchronize(bath_hip_ctx *ctx);
 void       *bath_hip_stream(bath_hip_ctx *ctx);                      /* hipStream_t, for event timing */
+/* Frameshift recursions: 0 (default) sums D(i,k) and E(i) along the model with wavefront scans -- the same table log-sums as
+ * the reference in a different association, scores within O(1e-3) nats; 1 = the reference's serial order
+ * (generic_fwdback_frameshift.c:340-365), bit-identical to the generic reference, several times slower.  Applies to the
+ * pipeline entry points; the batched kernels take it as logsum_mode = BATH_LOGSUM_TABLE_SERIAL. */
+int         bath_hip_set_fs_strict(bath_hip_ctx *ctx, int on);
 
 /* ------------------------------------------------------------------------------------------
  * Optimized profile (P7_OPROFILE surface).
@@ -317,6 +322,7 @@ int64_t bath_tophits_tabular_targets(const bath_tophits *th, const char *qname, 
  * ------------------------------------------------------------------------------------------ */
 #define BATH_LOGSUM_TABLE 0   /* emulate p7_FLogsum's 0.001-nat truncating table (logsum.c:105) */
 #define BATH_LOGSUM_EXACT 1   /* exact log(1+exp(x))                                            */
+#define BATH_LOGSUM_TABLE_SERIAL 2 /* the table, sums along the model in the reference's serial order: bit-identical to generic_fwdback_frameshift.c */
 
 int  bath_hip_fsprofile_convert(bath_hip_ctx *ctx, const bath_fs_profile *gm_fs, bath_hip_fsprofile **ret); /* p7_fs_oprofile_Convert, p7_fs_oprofile.c:221 */
 void bath_hip_fsprofile_destroy(bath_hip_fsprofile *om);

@@ -1,12 +1,15 @@
 """GPU parity of the frameshift kernels against the oracle's restatement of generic_*_frameshift.c.
 
-Tolerances.  The kernels use the same table-driven p7_FLogsum as the generic reference (every individual
-log-sum is identical) but sum along the model with wavefront scans, i.e. a different association of the
-same terms; with a 0.001-nat truncating table that moves a score by O(1e-3) nats.  The bar used here:
-  Forward/Backward scores: |gpu - oracle| <= 1e-4 * |oracle| + 5e-3 nats
-(the north star asks 1e-4 relative; the absolute floor covers scores near zero, where a relative bound on a
-table-quantised sum is meaningless; the reference's own SIMD-vs-generic tolerance is 1.0 nat, fwdback_fs.c:3189).
-In BATH_LOGSUM_EXACT mode the oracle is switched to exact log-sums too and the bound is 1e-4 relative + 1e-4.
+Three modes, three bars.
+  BATH_LOGSUM_TABLE_SERIAL ("strict"): the table-driven p7_FLogsum with the sums along the model in the reference's own
+      serial order.  Every log-sum then has the reference's operands: scores AND every special-state row must be
+      BIT-IDENTICAL to the oracle (relative error 0 <= the north star's 1e-4).  This is the parity gate.
+  BATH_LOGSUM_TABLE (default, fast): the same table log-sums, but D(i,k) / E(i) / B(i) summed with wavefront scans, i.e. a
+      different association of the same terms; with a 0.001-nat truncating table that moves a score by O(1e-3) nats.
+      Bound: |gpu - oracle| <= 1e-4 * |oracle| + 5e-3 nats; the ACHIEVED maximum relative and absolute errors are measured,
+      printed and written to gpurun_out/fs_parity_errors.json (a relative bound alone is meaningless for a table-quantised
+      sum near zero; the reference's own SIMD-vs-generic tolerance is 1.0 nat, fwdback_fs.c:3189).
+  BATH_LOGSUM_EXACT: the oracle is switched to exact log-sums too; bound 1e-4 relative + 1e-4.
 """
 import ctypes as C
 
@@ -81,27 +84,74 @@ def oracle_fs3(model, wins, backward, exact=False):
     return np.array(sc, np.float32), xm
 
 
+ERRORS = {}
+
+
+def record_errors(name, got, want):
+    """Achieved error of the fast mode against the oracle, kept for the report (VERDICT r1 weak #1)."""
+    import json, os
+    g, w = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    fin = np.isfinite(g) & np.isfinite(w)
+    d = np.abs(g[fin] - w[fin])
+    rel = d / np.maximum(np.abs(w[fin]), 1e-30)
+    big = np.abs(w[fin]) >= 1.0                       # scores of at least one nat: where a relative error means something
+    ERRORS[name] = {"n": int(fin.sum()), "max_abs_nats": float(d.max()) if d.size else 0.0, "max_rel": float(rel.max()) if rel.size else 0.0,
+                    "max_rel_scores_above_1_nat": float(rel[big].max()) if big.any() else 0.0}
+    print("fs parity", name, ERRORS[name])
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        path = os.path.join(out, "fs_parity_errors.json")
+        old = json.load(open(path)) if os.path.exists(path) else {}
+        old.update(ERRORS)
+        json.dump(old, open(path, "w"), indent=1, sort_keys=True)
+    except OSError:
+        pass
+    return ERRORS[name]
+
+
+def identical(a, b):
+    a, b = np.asarray(a, np.float32), np.asarray(b, np.float32)
+    return a.shape == b.shape and bool(np.all(a.view(np.uint32) == b.view(np.uint32)))
+
+
 def close(a, b, rtol, atol):
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
     both_inf = np.isinf(a) & np.isinf(b) & (np.sign(a) == np.sign(b))
     return bool(np.all(both_inf | (np.abs(a - b) <= atol + rtol * np.abs(b))))
 
 
+def test_fs3_parsers_strict_are_bit_identical(setup):
+    """The parity gate of row a6: serial-order table log-sums reproduce generic_fwdback_frameshift.c:451,1422 bit for bit --
+    both scores and every special-state row {E,N,J,B,C} that domain definition reads."""
+    ctx, model, om3, om5, wins, blk = setup
+    for backward, fn in ((False, ba.FS3ForwardParser), (True, ba.FS3BackwardParser)):
+        sc, xm = fn(ctx, om3, blk, logsum=ba.LOGSUM_TABLE_SERIAL, want_xmx=True)
+        osc, oxm = oracle_fs3(model, wins, backward=backward)
+        assert identical(sc, osc), (backward, np.abs(sc - osc).max())
+        for g, o in zip(xm, oxm):
+            assert identical(g, o), backward
+
+
 @pytest.mark.parametrize("mode,rtol,atol", [(ba.LOGSUM_TABLE, 1e-4, 5e-3), (ba.LOGSUM_EXACT, 1e-4, 1e-4)])
-def test_fs3_forward_parser(setup, mode, rtol, atol):
+def test_fs3_forward_parser(setup, mode, rtol, atol, request):
     ctx, model, om3, om5, wins, blk = setup
     sc, xm = ba.FS3ForwardParser(ctx, om3, blk, logsum=mode, want_xmx=True)
     osc, oxm = oracle_fs3(model, wins, backward=False, exact=(mode == ba.LOGSUM_EXACT))
+    if mode == ba.LOGSUM_TABLE:
+        record_errors("fs3_forward/" + request.node.callspec.id, sc, osc)
     assert close(sc, osc, rtol, atol), np.abs(sc - osc).max()
     for g, o in zip(xm, oxm):                      # special-state rows feed domain definition (p7_domaindef.c:320)
         assert close(g[2:], o[2:], rtol, 4 * atol)
 
 
 @pytest.mark.parametrize("mode,rtol,atol", [(ba.LOGSUM_TABLE, 1e-4, 5e-3), (ba.LOGSUM_EXACT, 1e-4, 1e-4)])
-def test_fs3_backward_parser(setup, mode, rtol, atol):
+def test_fs3_backward_parser(setup, mode, rtol, atol, request):
     ctx, model, om3, om5, wins, blk = setup
     sc, xm = ba.FS3BackwardParser(ctx, om3, blk, logsum=mode, want_xmx=True)
     osc, oxm = oracle_fs3(model, wins, backward=True, exact=(mode == ba.LOGSUM_EXACT))
+    if mode == ba.LOGSUM_TABLE:
+        record_errors("fs3_backward/" + request.node.callspec.id, sc, osc)
     assert close(sc, osc, rtol, atol), np.abs(sc - osc).max()
     fsc = ba.FS3ForwardParser(ctx, om3, blk, logsum=mode)
     assert close(fsc, sc, 1e-4, 2e-2)              # Forward == Backward (generic_fwdback_frameshift.c:2304 unit test: 0.001 with exact sums)
@@ -136,20 +186,40 @@ def oracle_fs5(model, wins, c5_compat, exact=False):
     return res
 
 
+def oa_matrices_agree(g, o, atol, rtol):
+    """The optimal-accuracy matrix (generic_optacc_frameshift.c:53): max-sums of posteriors; -inf cells must coincide."""
+    g, o = g[1:, 1:, :].astype(np.float64), o[1:, 1:, :].astype(np.float64)
+    gi, oi = np.isneginf(g), np.isneginf(o)
+    if not np.array_equal(gi, oi):
+        return False
+    g, o = np.where(gi, 0.0, g), np.where(oi, 0.0, o)
+    return bool(np.all(np.abs(g - o) <= atol + rtol * np.abs(o)))
+
+
 @pytest.mark.parametrize("c5_compat", [False, True])
-def test_fs5_envelopes(setup, c5_compat):
+@pytest.mark.parametrize("mode", [ba.LOGSUM_TABLE, ba.LOGSUM_TABLE_SERIAL], ids=["scan", "strict"])
+def test_fs5_envelopes(setup, c5_compat, mode, request):
     ctx, model, om3, om5, wins, blk = setup
     env = [w for w in wins if len(w) >= 15]
     eb = ba.SeqBlock(ctx, env)
-    got = ba.FS5Envelopes(ctx, om5, eb, logsum=ba.LOGSUM_TABLE, c5_compat=c5_compat, want_pp=True, want_oa=True)
+    got = ba.FS5Envelopes(ctx, om5, eb, logsum=mode, c5_compat=c5_compat, want_pp=True, want_oa=True)
     ref = oracle_fs5(model, env, c5_compat)
-    fwd = np.array([r[0] for r in ref]); bwd = np.array([r[1] for r in ref]); oas = np.array([r[2] for r in ref])
-    assert close(got["fwdsc"], fwd, 1e-4, 5e-3), np.abs(got["fwdsc"] - fwd).max()
-    assert close(got["bcksc"], bwd, 1e-4, 5e-3), np.abs(got["bcksc"] - bwd).max()
+    fwd = np.array([r[0] for r in ref], np.float32); bwd = np.array([r[1] for r in ref], np.float32)
+    strict = mode == ba.LOGSUM_TABLE_SERIAL
+    if strict:                                      # row a7: p7_Forward_Frameshift / p7_Backward_Frameshift, bit for bit
+        assert identical(got["fwdsc"], fwd) and identical(got["bcksc"], bwd)
+    else:
+        record_errors("fs5_forward/" + request.node.callspec.id, got["fwdsc"], fwd)
+        record_errors("fs5_backward/" + request.node.callspec.id, got["bcksc"], bwd)
+        assert close(got["fwdsc"], fwd, 1e-4, 5e-3), np.abs(got["fwdsc"] - fwd).max()
+        assert close(got["bcksc"], bwd, 1e-4, 5e-3), np.abs(got["bcksc"] - bwd).max()
+    # strict: Forward and Backward matrices are the oracle's, so posteriors differ only by expf's last bit and the division
+    ptol, otol = (2e-5, 5e-4) if strict else (5e-3, 2e-2)
     for i, r in enumerate(ref):
         pp, oa = got["pp"][i], got["oa"][i]
-        assert np.abs(pp[1:, 1:, 1:] - r[4][1:, 1:, 1:]).max() < 5e-3          # posteriors (decoding_fs.c:534 uses 0.001..0.2)
-        assert abs(got["oasc"][i] - r[2]) < 2e-2 + 1e-3 * abs(r[2])            # expected # of correct positions
-        assert np.allclose(got["null2"][i], r[3], rtol=5e-3, atol=1e-4)        # null2_fs.c:193 uses 0.001..0.2
+        assert np.abs(pp[1:, 1:, 1:] - r[4][1:, 1:, 1:]).max() < ptol          # posteriors (decoding_fs.c:534 uses 0.001..0.2)
+        assert abs(got["oasc"][i] - r[2]) < otol + 1e-3 * abs(r[2])            # expected # of correct positions
+        assert oa_matrices_agree(oa, r[5], otol, 1e-3)                         # the whole OA matrix, not only its corner
+        assert np.allclose(got["null2"][i], r[3], rtol=1e-4 if strict else 5e-3, atol=1e-4)        # null2_fs.c:193 uses 0.001..0.2
     if not c5_compat:
         assert close(got["fwdsc"], got["bcksc"], 1e-4, 2e-2)                   # Forward == Backward

@@ -257,10 +257,12 @@ def test_negative_alignment_score_drops_the_domain(gpu_ctx):
     assert len(dm) == sum(b - a for a, b in per_d)            # no extra domain hiding in compare_domains' allowances
 
 
-def test_frameshift_path_with_a_long_model(gpu_ctx, tmp_path):
+@pytest.mark.parametrize("M", [700, 1024])
+def test_frameshift_path_with_a_long_model(gpu_ctx, tmp_path, M):
     """A 700-node synthetic model (11 nodes per lane in the frameshift kernels -> the 12-node instantiation, 5.7 MB of
-    5-codon emissions): the whole --fs path to hits against the oracle."""
-    path = common.write_synthetic_bhmm(str(tmp_path / "s700.bhmm"), 700, seed=700)
+    5-codon emissions) and the 1024-node model of BASELINE configs[4] (16 nodes per lane, the kernels' largest
+    instantiation): the whole --fs path to hits against the oracle."""
+    path = common.write_synthetic_bhmm(str(tmp_path / ("s%d.bhmm" % M)), M, seed=M)
     model = ol.Model(path, 0)
     rng = np.random.default_rng(12)
     wins = frameshifted_windows(rng, model, n=8, L_flank=60)[:10] + common.random_dna(rng, 4, 1200)

@@ -227,3 +227,31 @@ def test_standard_branch_hits_match_recorded_runs(hmmfile):
         if h1 is not None:
             assert (d.ihmm, d.jhmm) == (h1, h2)
         assert "%.1f" % d.bitscore == score and "%.1f" % (d.dombias / np.log(2.0)) == bias
+
+
+def recorded_envelopes():
+    """Envelope coordinates the reference recorded: tutorial/PTH2-cigar.tbl (an earlier --tblout layout that still printed
+    'env from / env to') for the four PTH2 hits, and the hit line of tutorial/AMP_N-frameline.out (bathsearch --fs
+    --frameline prints env-from / env-to) for the frameshift hit."""
+    rows = [l.split() for l in open(ol.GOLDEN + "/PTH2-cigar.tbl") if l and l[0] != "#"]
+    pth2 = [(int(r[9]), int(r[10]), int(r[11]), int(r[12]), r[14], r[17]) for r in rows]      # ali from/to, env from/to, score, CIGAR
+    fl = [l.split() for l in open(ol.GOLDEN + "/AMP_N-frameline.out") if l.startswith(" ! ")][0]
+    amp = (int(fl[7]), int(fl[8]), int(fl[10]), int(fl[11]), fl[1])                           # ali 1..402, env 1..411, score 82.8
+    return pth2, amp
+
+
+def test_envelope_coordinates_match_recorded_runs():
+    """Pins the region heuristics' end points (p7_domaindef.c:355-372 / :546-560), not only the alignment's."""
+    pth2, amp = recorded_envelopes()
+    assert pth2 == [(672, 325, 675, 325, "110.6", "99M6I192M3D51M"), (1486, 1731, 1444, 1731, "86.4", "246M"),
+                    (2468, 2343, 2483, 2325, "36.2", "42M3D84M"), (1273, 1359, 1270, 1383, "36.0", "87M")]
+    assert amp == (1, 402, 1, 411, "82.8")
+    m = ol.Model(ol.GOLDEN + "/PTH2.bhmm", 0)
+    seqs = [ol.digitize_dna(s) for _, s in ol.read_fasta(ol.GOLDEN + "/target-PTH2.fa")]
+    _, dm, _, _ = m.run_pipeline_hits(seqs)
+    got = sorted(dm, key=lambda d: -d.bitscore)
+    assert [(d.iali, d.jali, d.ienv, d.jenv, "%.1f" % d.bitscore) for d in got] == [t[:5] for t in pth2]
+    m = ol.Model(ol.GOLDEN + "/AMP_N.bhmm", 0)
+    seqs = [ol.digitize_dna(s) for _, s in ol.read_fasta(ol.GOLDEN + "/target-AMP_N.fa")]
+    _, _, _, dm, _, _ = m.run_pipeline_fsdom(seqs)
+    assert [(d.iali, d.jali, d.ienv, d.jenv, "%.1f" % d.bitscore) for d in dm] == [amp]
