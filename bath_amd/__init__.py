@@ -123,6 +123,10 @@ class FsDomain(C.Structure):
     cigar = ""       # filled by Pipeline.run_hits / run_frameshift_domains
 
 
+class KernelTime(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("ms", C.c_float), ("launches", C.c_int64), ("cells", C.c_double), ("bytes", C.c_double)]
+
+
 class Fs5Result(C.Structure):
     _fields_ = [("fwdsc", C.c_float), ("bcksc", C.c_float), ("oasc", C.c_float), ("null2", C.c_float * KP)]
 
@@ -144,6 +148,7 @@ ABI = {
     "bath_hip_synchronize": (C.c_int, [_vp]),
     "bath_hip_stream": (_vp, [_vp]),
     "bath_hip_set_fs_strict": (C.c_int, [_vp, C.c_int]),
+    "bath_hip_kernel_times": (C.c_int, [_vp, C.c_int, C.POINTER(KernelTime)]),
     "bath_hip_oprofile_convert": (C.c_int, [_vp, C.POINTER(_Profile), C.POINTER(_vp)]),
     "bath_hip_oprofile_destroy": (None, [_vp]),
     "bath_hip_oprofile_M": (C.c_int, [_vp]),
@@ -599,6 +604,13 @@ class Pipeline:
                 out.append(x)
             return out
         return stats, copies(fw, nfw.value, FsWindow), self._domains(dm, ndm.value), nskip.value
+
+    def kernel_times(self):
+        """Per-kernel device times of the stages after the cascade in the last run_frameshift_domains call:
+        {name: (ms, launches, cells, bytes)}."""
+        arr = (KernelTime * 32)()
+        n = lib().bath_hip_kernel_times(self.ctx._h, 32, arr)
+        return {arr[i].name.decode(): (float(arr[i].ms), int(arr[i].launches), float(arr[i].cells), float(arr[i].bytes)) for i in range(n)}
 
     def timings(self):
         names = (C.c_char_p * 32)()

@@ -62,6 +62,8 @@ struct HostBuf {
 };
 
 struct StageTiming { const char *name; float ms; int64_t launches; };
+// one kernel launch of the frameshift / domain stages, timed with HIP events on the stream it was launched on
+struct KernelSpan { const char *name; hipEvent_t a, b; double cells, bytes; };
 
 // An ORF that passed the Forward filter, as the domain-definition stage needs it (bath_domaindef.hip)
 struct PipelineSurvivor {
@@ -97,6 +99,23 @@ struct bath_hip_ctx {
   std::vector<uint8_t> orf_aa;
   std::vector<bath::StageTiming> timings;
   std::vector<hipEvent_t> ev_pool;
+  // per-kernel device times of the stages after the cascade (bath_hip_kernel_times): spans recorded since the last reset
+  std::vector<bath::KernelSpan> spans;
+  std::vector<hipEvent_t> span_events;
+  size_t span_events_used = 0;
+  void spans_reset() { spans.clear(); span_events_used = 0; }
+  int span_begin(const char *name, hipStream_t s, double cells, double bytes) {
+    auto get = [&]() -> hipEvent_t {
+      if (span_events_used == span_events.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return nullptr; span_events.push_back(e); }
+      return span_events[span_events_used++];
+    };
+    bath::KernelSpan k{name, get(), get(), cells, bytes};
+    if (!k.a || !k.b) return -1;
+    (void)hipEventRecord(k.a, s);
+    spans.push_back(k);
+    return (int)spans.size() - 1;
+  }
+  void span_end(int idx, hipStream_t s) { if (idx >= 0) (void)hipEventRecord(spans[(size_t)idx].b, s); }
   // worker lanes: contexts with their own stream and scratch, used by the pipeline to run parts of a block concurrently
   std::vector<bath_hip_ctx *> lanes;
 };

@@ -112,6 +112,7 @@ static int fs_branch_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, con
   if (n_skipped_regions) *n_skipped_regions = 0;
   ctx->fs_domains.clear();
   ctx->cigars.clear();
+  ctx->spans_reset();
   bath_pipeline_stats st_local{};
   const bath_fs_window *fw = nullptr;
   int64_t nfw = 0;

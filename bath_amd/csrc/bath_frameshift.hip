@@ -1381,15 +1381,23 @@ int fs3_regions(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, const bath_hip_
   BATH_HIP_TRY(ctx, b_sc.reserve((size_t)n * 2 * sizeof(float)));
   if ((st = fs_fork(ctx)) != BATH_OK) return st;
   const int mode = ctx->fs_strict ? BATH_LOGSUM_TABLE_SERIAL : BATH_LOGSUM_TABLE;
+  const double cells3 = (double)(xoff[(size_t)n] / 5) * om->M;                // rows x nodes; algorithmic HBM bytes: 1 B/nt in + 20 B/row out
+  const double bytes3 = (double)(xoff[(size_t)n] / 5) * 21.0;
   BATH_FS_SWITCH(Cv, BATH_FS_MODE(mode, {
     if ((st = fs_set_shmem(ctx, fs3_fwd_kernel<CC, MD>, shmem)) != BATH_OK) return st;
+    const int s1 = ctx->span_begin("fs3_fwd_kernel", ctx->stream, cells3, bytes3);
     hipLaunchKernelGGL((fs3_fwd_kernel<CC, MD>), dim3(grid_dp), dim3(kFsBlock), shmem, ctx->stream, dna->view(), fsdev(om), om->d_loop[0], om->d_move[0], tE, tE, b_sc.as<float>(), b_fx.as<float>(), b_off.as<int64_t>());
+    ctx->span_end(s1, ctx->stream);
     if ((st = fs_set_shmem(ctx, fs_bwd_kernel<CC, 3, MD>, shmem)) != BATH_OK) return st;
+    const int s2 = ctx->span_begin("fs_bwd_kernel<3>", ctx->side_stream, cells3, bytes3);
     hipLaunchKernelGGL((fs_bwd_kernel<CC, 3, MD>), dim3(grid_dp), dim3(kFsBlock), shmem, ctx->side_stream, dna->view(), fsdev(om), om->d_loop[0], om->d_move[0], tE, tE, b_sc.as<float>() + n, (float *)nullptr, (const int64_t *)nullptr, b_bx.as<float>(), b_off.as<int64_t>());
+    ctx->span_end(s2, ctx->side_stream);
   }))
   if ((st = fs_join(ctx)) != BATH_OK) return st;
+  const int s3 = ctx->span_begin("fs_regions_kernel", ctx->stream, (double)(xoff[(size_t)n] / 5), (double)(xoff[(size_t)n] / 5) * 52.0);
   hipLaunchKernelGGL(fs_regions_kernel, dim3((unsigned)n), dim3(64), 0, ctx->stream, n, dna->d_len, b_fx.as<float>(), b_bx.as<float>(), b_off.as<int64_t>(), om->d_logsum, loop,
                      b_work.as<float>(), b_reg.as<int32_t>());
+  ctx->span_end(s3, ctx->stream);
   BATH_HIP_TRY(ctx, hipGetLastError());
   BATH_HIP_TRY(ctx, hipMemcpyAsync(regions_out, b_reg.p, reg_ints * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
   BATH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1467,24 +1475,35 @@ int bath::fs5_envelopes_ex(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, cons
   const int grid_dp = fs_grid_dp(ctx, n);
   const float tEL = -INFINITY, tEM = 0.0f;                                      // unihit: p7_fs_ReconfigUnihit, modelconfig.c:868
   if (logsum_mode == BATH_LOGSUM_TABLE && ctx->fs_strict) logsum_mode = BATH_LOGSUM_TABLE_SERIAL;
+  const double cells5 = (double)(foff[(size_t)n] / 8);                          // (L+1) x (M+1) cells of all envelopes
   if ((st = fs_fork(ctx)) != BATH_OK) return st;                                // Backward on the side stream, concurrently with Forward
   BATH_FS_SWITCH(Cv, {
     BATH_FS_MODE(logsum_mode, {
       if ((st = fs_set_shmem(ctx, fs5_fwd_kernel<CC, MD>, shmem)) != BATH_OK) return st;
       if ((st = fs_set_shmem(ctx, fs_bwd_kernel<CC, 5, MD>, shmem)) != BATH_OK) return st;
+      const int s1 = ctx->span_begin("fs5_fwd_kernel", ctx->stream, cells5, cells5 * 32.0);
       hipLaunchKernelGGL((fs5_fwd_kernel<CC, MD>), dim3(grid_dp), dim3(kFsBlock), shmem, ctx->stream, dna->view(), fsdev(om), om->d_loop[1], om->d_move[1], tEL, tEM, c5_compat, d_fsc, b_f.as<float>(), d_foff, b_fx.as<float>(), d_xoff, -1);
+      ctx->span_end(s1, ctx->stream);
+      const int s2 = ctx->span_begin("fs_bwd_kernel<5>", ctx->side_stream, cells5, cells5 * 12.0);
       hipLaunchKernelGGL((fs_bwd_kernel<CC, 5, MD>), dim3(grid_dp), dim3(kFsBlock), shmem, ctx->side_stream, dna->view(), fsdev(om), om->d_loop[1], om->d_move[1], tEL, tEM, d_bsc, b_b.as<float>(), d_boff, b_bx.as<float>(), d_xoff);
+      ctx->span_end(s2, ctx->side_stream);
     })
     if ((st = fs_join(ctx)) != BATH_OK) return st;
     BATH_HIP_TRY(ctx, hipMemsetAsync(b_cs.p, 0, (size_t)n * cs_stride * sizeof(float), ctx->stream));
+    const int s3 = ctx->span_begin("fs5_decode_kernel", ctx->stream, cells5, cells5 * 76.0);     // reads Forward 32 + Backward 12, rewrites 32 B/cell
     hipLaunchKernelGGL(fs5_decode_kernel, dim3(grid), dim3(256), 0, ctx->stream, dna->view(), M, om->d_loop[1], d_bsc, b_f.as<float>(), d_foff, b_fx.as<float>(), d_xoff,
                        b_b.as<float>(), d_boff, b_bx.as<float>(), b_cs.as<float>());
+    ctx->span_end(s3, ctx->stream);
     if ((st = fs_set_shmem(ctx, fs5_oa_kernel<CC>, oa_shmem)) != BATH_OK) return st;
+    const int s4 = ctx->span_begin("fs5_oa_kernel", ctx->stream, cells5, cells5 * 44.0);         // reads posteriors 32, writes OA 12 B/cell
     hipLaunchKernelGGL((fs5_oa_kernel<CC>), dim3(grid), dim3(256), oa_shmem, ctx->stream, dna->view(), M, om->d_tf, b_f.as<float>(), d_foff, b_fx.as<float>(), d_xoff, b_o.as<float>(), d_boff, d_osc,
                        1.17549435e-38f /* E->J impossible in unihit mode: TSCDELTA = FLT_MIN */, 1.0f, (oax || trace) ? b_ox.as<float>() : nullptr);
+    ctx->span_end(s4, ctx->stream);
   })
+  const int s5 = ctx->span_begin("fs5_null2_kernel", ctx->stream, (double)n * M, (double)n * M * 32.0);
   hipLaunchKernelGGL(fs5_null2_kernel, dim3((unsigned)n), dim3(32), 0, ctx->stream, n, dna->d_len, M, om->pitch, om->d_rsc + (size_t)om->maxcodons * om->pitch, om->d_logsum,
                      b_cs.as<float>(), b_n2.as<float>());
+  ctx->span_end(s5, ctx->stream);
   BATH_HIP_TRY(ctx, hipGetLastError());
   if (trace) {                                                  // optimal-accuracy traceback + null2 along the trace, on the device
     if (!om->d_codons) { ctx->set_error("traceback needs the profile's codon table"); return BATH_EINVAL; }
@@ -1496,10 +1515,12 @@ int bath::fs5_envelopes_ex(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, cons
     BATH_HIP_TRY(ctx, b_to.reserve((size_t)n * sizeof(FsTraceOut) + 64));
     int64_t *d_toff = reinterpret_cast<int64_t *>(b_tb.as<char>() + ((size_t)toff[(size_t)n] * sizeof(uint2) + 255) / 256 * 256);
     BATH_HIP_TRY(ctx, hipMemcpyAsync(d_toff, toff.data(), (size_t)(n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+    const int s6 = ctx->span_begin("fs5_trace_kernel", ctx->stream, (double)toff[(size_t)n], 0.0);
     hipLaunchKernelGGL(fs5_trace_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, dna->view(), M, om->maxcodons, om->d_tf, om->d_codons,
                        b_f.as<float>(), d_foff, b_fx.as<float>(), d_xoff, b_o.as<float>(), d_boff, b_ox.as<float>(), b_n2.as<float>(), b_tb.as<uint2>(), d_toff,
                        b_to.as<FsTraceOut>(), om->d_indel, cons, steps ? b_steps.as<uint16_t>() : nullptr,
                        om->d_rsc + (size_t)om->maxcodons * om->pitch, om->pitch);
+    ctx->span_end(s6, ctx->stream);
     BATH_HIP_TRY(ctx, hipGetLastError());
     BATH_HIP_TRY(ctx, hipMemcpyAsync(trace, b_to.p, (size_t)n * sizeof(FsTraceOut), hipMemcpyDeviceToHost, ctx->stream));
     if (steps) {                                                // columns z1..z2 of envelope e: (*steps)[step_off[e] .. +trace[e].ncol)
@@ -1553,8 +1574,10 @@ int bath::fs5_region_forward(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, co
   const int mode = ctx->fs_strict ? BATH_LOGSUM_TABLE_SERIAL : BATH_LOGSUM_TABLE;
   BATH_FS_SWITCH(Cv, BATH_FS_MODE(mode, {
     if ((st = fs_set_shmem(ctx, fs5_fwd_kernel<CC, MD>, shmem)) != BATH_OK) return st;
+    const int s1 = ctx->span_begin("fs5_fwd_kernel(regions)", ctx->stream, (double)(foff[(size_t)n] / 8), (double)(foff[(size_t)n] / 8) * 32.0);
     hipLaunchKernelGGL((fs5_fwd_kernel<CC, MD>), dim3(grid_dp), dim3(kFsBlock), shmem, ctx->stream, dna->view(), fsdev(om), om->d_loop[0], om->d_move[0], tE, tE, 0, b_sc.as<float>(),
                        b_f.as<float>(), d_foff, b_fx.as<float>(), d_xoff, cfg_len_amino);
+    ctx->span_end(s1, ctx->stream);
   }))
   BATH_HIP_TRY(ctx, hipGetLastError());
   sc->resize((size_t)n);

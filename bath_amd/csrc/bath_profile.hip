@@ -130,6 +130,7 @@ extern "C" void bath_hip_finalize(bath_hip_ctx *ctx) {
   for (auto &b : ctx->scratch) b.release();
   for (auto &b : ctx->pinned) b.release();
   for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
+  for (auto e : ctx->span_events) (void)hipEventDestroy(e);
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
   if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
@@ -145,6 +146,19 @@ extern "C" int bath_hip_synchronize(bath_hip_ctx *ctx) {
 }
 
 extern "C" void *bath_hip_stream(bath_hip_ctx *ctx) { return (void *)ctx->stream; }
+extern "C" int bath_hip_kernel_times(bath_hip_ctx *ctx, int max, bath_kernel_time *out) {
+  if (!ctx || !out) return 0;
+  int n = 0;
+  for (const bath::KernelSpan &k : ctx->spans) {
+    float ms = 0.f;
+    if (hipEventSynchronize(k.b) != hipSuccess || hipEventElapsedTime(&ms, k.a, k.b) != hipSuccess) continue;
+    int i = 0;
+    while (i < n && out[i].name != k.name) i++;
+    if (i == n) { if (n == max) continue; out[n++] = bath_kernel_time{k.name, 0.f, 0, 0.0, 0.0}; }
+    out[i].ms += ms; out[i].launches++; out[i].cells += k.cells; out[i].bytes += k.bytes;
+  }
+  return n;
+}
 extern "C" int bath_hip_set_fs_strict(bath_hip_ctx *ctx, int on) {
   if (!ctx) return BATH_EINVAL;
   ctx->fs_strict = on ? 1 : 0;

@@ -72,44 +72,43 @@ def reduce_stats(stats, device="cpu"):
     return dict(zip(STAT_FIELDS, [int(v) for v in vals.cpu()]))
 
 
+def gather_bytes(data, dst=0, device="cpu"):
+    """Variable-length gather of one bytes object per rank ON RANK <dst> ONLY (p7_tophits_Merge's direction: workers -> master):
+    every rank sends its length, then its payload, point to point; nothing is replicated to the other ranks.
+    Returns the list of payloads on rank <dst>, None elsewhere."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [data]
+    world, rank = dist.get_world_size(), dist.get_rank()
+    n = torch.tensor([len(data)], dtype=torch.int64, device=device)
+    if rank == dst:
+        counts = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
+        dist.gather(n, counts, dst=dst)
+        out = []
+        for r in range(world):
+            if r == dst:
+                out.append(data)
+                continue
+            k = int(counts[r].item())
+            buf = torch.empty(max(k, 1), dtype=torch.uint8, device=device)
+            if k:
+                dist.recv(buf[:k], src=r)
+            out.append(bytes(buf[:k].cpu().numpy().tobytes()))
+        return out
+    dist.gather(n, None, dst=dst)
+    if len(data):
+        dist.send(torch.frombuffer(bytearray(data), dtype=torch.uint8).to(device), dst=dst)
+    return None
+
+
 def gather_results(res, window_offset, dst=0, device="cpu"):
     """p7_tophits_Merge: variable-length gather of the per-rank ORF records on rank <dst>; window indices
     are made global by adding each rank's shard offset."""
     res = res.copy()
     res["window"] += window_offset
-    if not dist.is_initialized() or dist.get_world_size() == 1:
-        return res
-    world, rank = dist.get_world_size(), dist.get_rank()
-    raw = torch.from_numpy(res.view(np.uint8).reshape(-1).copy()).to(device)
-    counts = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
-    dist.all_gather(counts, torch.tensor([raw.numel()], dtype=torch.int64, device=device))
-    mx = int(max(int(c.item()) for c in counts))
-    pad = torch.zeros(mx, dtype=torch.uint8, device=device)
-    pad[: raw.numel()] = raw
-    bufs = [torch.empty(mx, dtype=torch.uint8, device=device) for _ in range(world)]
-    dist.all_gather(bufs, pad)
-    if rank != dst:
+    parts = gather_bytes(res.view(np.uint8).reshape(-1).tobytes(), dst, device)
+    if parts is None:
         return None
-    parts = [np.frombuffer(bufs[r][: int(counts[r].item())].cpu().numpy().tobytes(), dtype=ORF_RESULT_DTYPE) for r in range(world)]
-    return np.concatenate(parts)
-
-
-def gather_bytes(data, dst=0, device="cpu"):
-    """Variable-length gather of one bytes object per rank; the list on rank <dst>, None elsewhere."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
-        return [data]
-    world, rank = dist.get_world_size(), dist.get_rank()
-    counts = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
-    dist.all_gather(counts, torch.tensor([len(data)], dtype=torch.int64, device=device))
-    mx = max(1, int(max(int(c.item()) for c in counts)))
-    pad = torch.zeros(mx, dtype=torch.uint8, device=device)
-    if len(data):
-        pad[: len(data)] = torch.frombuffer(bytearray(data), dtype=torch.uint8).to(device)
-    bufs = [torch.empty(mx, dtype=torch.uint8, device=device) for _ in range(world)]
-    dist.all_gather(bufs, pad)
-    if rank != dst:
-        return None
-    return [bytes(bufs[r][: int(counts[r].item())].cpu().numpy().tobytes()) for r in range(world)]
+    return np.concatenate([np.frombuffer(p, dtype=ORF_RESULT_DTYPE) for p in parts])
 
 
 def gather_domains(domains, window_offset, dst=0, device="cpu"):

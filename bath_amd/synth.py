@@ -43,8 +43,29 @@ def reverse_translate(rng, aa, basic):
     return np.stack([c >> 4, (c >> 2) & 3, c & 3], axis=1).reshape(-1).astype(np.uint8)
 
 
-def dna_windows(n_windows, length, seed, hmm=None, planted_frac=0.01, ncbi_table=1):
-    """Returns (flat uint8 codes [n_windows*length], int64 offsets[n_windows+1], planted window indices)."""
+def frameshift_mutations(rng, nt):
+    """per codon P(-1 nt) = P(+1 nt) = 0.01, P(-2) = P(+2) = 0.005, an in-frame stop (TAA) at 0.002."""
+    out = []
+    for j in range(0, len(nt) - 2, 3):
+        c = list(nt[j:j + 3])
+        r = rng.random()
+        if r < 0.010:
+            del c[int(rng.integers(0, 3))]
+        elif r < 0.020:
+            c.insert(int(rng.integers(0, 4)), int(rng.integers(0, 4)))
+        elif r < 0.025:
+            c = c[:1]
+        elif r < 0.030:
+            c = c + [int(rng.integers(0, 4)), int(rng.integers(0, 4))]
+        elif r < 0.032:
+            c = [3, 0, 0]
+        out.extend(c)
+    return np.asarray(out, dtype=np.uint8)
+
+
+def dna_windows(n_windows, length, seed, hmm=None, planted_frac=0.01, ncbi_table=1, frameshift=False):
+    """Returns (flat uint8 codes [n_windows*length], int64 offsets[n_windows+1], planted window indices).
+    frameshift: the planted domains carry indels and in-frame stops (BASELINE configs[2])."""
     rng = np.random.default_rng(seed)
     flat = rng.integers(0, 4, size=(n_windows, length), dtype=np.uint8)
     planted = np.zeros(0, dtype=np.int64)
@@ -55,6 +76,8 @@ def dna_windows(n_windows, length, seed, hmm=None, planted_frac=0.01, ncbi_table
         planted = np.sort(rng.choice(n_windows, size=n_pl, replace=False))
         for w in planted:
             nt = reverse_translate(rng, sample_domain(rng, mat), basic)[: length - 2]
+            if frameshift:
+                nt = frameshift_mutations(rng, nt)[: length - 2]
             pos = int(rng.integers(0, length - len(nt) + 1))
             if rng.random() < 0.5:
                 nt = (3 - nt[::-1]).astype(np.uint8)

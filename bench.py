@@ -6,20 +6,30 @@ windows (iid ACGT, seed 42, 1% carrying a planted domain), both strands, six-fra
 MSV/SSV -> bias -> Viterbi -> Forward, standard codon table, no --fs.  One "step" is one pass of the whole
 cascade over the block, with the DNA already resident in HBM.
 
-  value   = DNA residues searched per second, counted as the reference counts pli->nres
-            (both strands: bathsearch.c:1073,1086), whole job over all ranks.
+  value    = DNA residues searched per second, counted as the reference counts pli->nres
+             (both strands: bathsearch.c:1073,1086), whole job over all ranks.
   roofline = the dominant kernel (ssv_orf_kernel, SSV over the length-sorted ORF list): algorithmic HBM bytes
-            per launch / its device time, timed with HIP events on the library's own stream
-            (bath_hip_pipeline_timings).
-  cpu_baseline = the scalar C oracle (oracle/pipeline.c, a port of the same algorithms) on a bounded
-            sample of the same windows, one process per host core.  A reported baseline, not the target.
+             per launch / its device time, timed with HIP events on the library's own stream
+             (bath_hip_pipeline_timings).  The kernel is bound by packed 16-bit VALU issue, not HBM:
+             roofline.valu gives its cell rate from an un-overlapped (one part) pass against the measured issue ceiling.
+  cpu_baseline = oracle/sse: an SSE2 128-bit striped restatement of the reference's impl_sse filters (same algorithms
+             and layouts; the reference itself needs the un-vendored easel and cannot be built), bit-exact with the
+             scalar oracle, driving the oracle's cascade: 1 thread and one process per host core.  It runs over the
+             SAME windows as the GPU, so the run is also a full-block parity check (parity_full_block).
+  fs       = BASELINE.json configs[2]: the same profile with --fs on a block whose planted domains carry indels and
+             stops: whole path to hits; per-kernel device times and HBM fractions of the frameshift
+             kernels (bath_hip_kernel_times).
 
-N>1: launched by torch.distributed.run, one rank per GPU; the model is broadcast from rank 0 over RCCL,
-every rank scores its own 10^6 windows (weak scaling), counters and hits are gathered on rank 0.
+N>1: `python bench.py --gpus N` starts N ranks itself (a fresh torch.distributed.run child, never a re-exec); under the
+driver's own torch.distributed.run launch RANK is already set and this process is one rank.  The model is broadcast from
+rank 0 over RCCL, every rank scores its own windows (weak: 10^6 per GPU; --scaling strong: 10^6 in total, sharded), counters
+are reduced and the ORF records gathered on rank 0 (point to point, nothing replicated).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,35 +39,39 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 MODEL = os.path.join(ROOT, "tests", "golden", "Caudal_act.bhmm")
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak, MI355X_MICROARCH.md
-
+COUNTERS = ("nres", "n_orfs", "n_past_msv", "n_past_bias", "n_past_vit", "n_past_fwd", "pos_past_msv", "pos_past_bias", "pos_past_vit", "pos_past_fwd")
 
 _CPU_FLAT = None      # the DNA block, inherited by the forked baseline workers (never pickled)
 
 
+# ------------------------------------------------------------------------------------------------ CPU baseline (oracle/sse)
+
 def cpu_baseline_worker(args):
-    """Scalar oracle cascade over a slice of windows (runs in a forked worker)."""
+    """The oracle's cascade on the SSE2 striped kernels over windows [lo, hi) (runs in a forked worker, no GPU state)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import ctypes as C
     import oracle_lib as ol
-    length, lo, hi = args
+    length, lo, hi, sse = args
     flat = _CPU_FLAT
     m = ol.Model(MODEL, 0)
     L = ol.lib()
+    L.bo_pipeline_use_sse(1 if sse else 0)
     pli = ol.Pipeline()
     L.bo_pipeline_init(C.byref(pli), 0)
     res = C.POINTER(ol.OrfResult)()
     n, a = C.c_int(0), C.c_int(0)
+    d = np.full(length + 2, 255, dtype=np.uint8)
+    dp = ol.u8(d)
     t0 = time.perf_counter()
     for w in range(lo, hi):
-        d = ol.dsq_from(flat[w * length:(w + 1) * length])
+        d[1:length + 1] = flat[w * length:(w + 1) * length]
         n.value = 0
-        L.bo_pipeline_window(C.byref(pli), m.om, m.sd, C.byref(m.bg), ol.u8(m.basic), ol.u8(d), length,
-                             C.byref(res), C.byref(n), C.byref(a))
+        L.bo_pipeline_window(C.byref(pli), m.om, m.sd, C.byref(m.bg), ol.u8(m.basic), dp, length, C.byref(res), C.byref(n), C.byref(a))
     dt = time.perf_counter() - t0
-    return dt, pli.nres, pli.cells_msv + pli.cells_vit + pli.cells_fwd, pli.pos_past_msv, pli.pos_past_fwd
+    return dt, {f: int(getattr(pli, f)) for f in COUNTERS}, int(pli.cells_msv + pli.cells_vit + pli.cells_fwd)
 
 
-def usable_cores(cap=32):
+def usable_cores(cap=64):
     """Cores this job may really use: affinity mask, cgroup quota, capped (a reported baseline, not a stress test)."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     try:
@@ -69,53 +83,129 @@ def usable_cores(cap=32):
     return max(1, min(n, cap))
 
 
-def cpu_baseline(flat, length, n_windows, budget_s=12.0):
+def cpu_baseline(flat, length, n_windows, budget_s=30.0):
+    """Runs BEFORE any GPU initialisation (forked workers must not inherit HIP state).  Returns the cpu_baseline object and
+    the counters of the windows it covered (all of them when the cores allow it within the budget)."""
     import multiprocessing as mp
     global _CPU_FLAT
     _CPU_FLAT = flat
     cores = usable_cores()
-    # calibrate on one core (the worker times only its scoring loop), then size the sample for ~budget_s
-    dt, *_ = cpu_baseline_worker((length, 0, 24))
-    per_win = max(dt / 24, 1e-5)
-    per_core = int(max(8, min(n_windows // cores, budget_s / per_win)))
-    jobs = [(length, c * per_core, (c + 1) * per_core) for c in range(cores)]
+    # one thread first: a prefix of the block, ~2 s
+    n1 = min(n_windows, 4000)
+    dt1, _, _ = cpu_baseline_worker((length, 0, n1, True))
+    n1 = int(min(n_windows, max(n1, 2.0 / max(dt1 / n1, 1e-7))))
+    dt1, c1, cells1 = cpu_baseline_worker((length, 0, n1, True))
+    dts, cs, _ = cpu_baseline_worker((length, 0, min(n1, 2000), False))          # the scalar port, for the record
+    per_win = dt1 / n1
+    covered = int(min(n_windows, max(cores * 64, budget_s * cores / per_win * 0.8)))
+    bounds = [covered * c // cores for c in range(cores + 1)]
+    jobs = [(length, bounds[c], bounds[c + 1], True) for c in range(cores)]
     t0 = time.perf_counter()
     with mp.get_context("fork").Pool(cores) as pool:
         outs = pool.map(cpu_baseline_worker, jobs)
     wall = time.perf_counter() - t0
     busy = max(o[0] for o in outs)                     # slowest worker's scoring loop (excludes process start-up and model parsing)
-    nres = sum(o[1] for o in outs)
+    tot = {f: sum(o[1][f] for o in outs) for f in COUNTERS}
     cells = sum(o[2] for o in outs)
-    return {"value": nres / busy, "unit": "residues/s", "cores": cores, "kind": "port",
-            "sample": "%d windows x %d nt (both strands) through the scalar C oracle (oracle/pipeline.c), %d processes, "
-                      "%.1f s scoring (%.1f s wall incl. start-up)" % (per_core * cores, length, cores, busy, wall),
-            "gcells_per_s": cells / busy / 1e9}, outs
+    base = {"value": tot["nres"] / busy, "unit": "residues/s", "cores": cores, "kind": "port",
+            "label": "impl_sse-equivalent restatement, SSE2 128-bit (oracle/sse: striped SSV/MSV/Viterbi/Forward written from scratch, "
+                     "bit-exact with the scalar oracle; the reference's own impl_sse needs the un-vendored easel and cannot be built here)",
+            "sample": "%d of %d windows x %d nt (both strands), %d processes, %.1f s scoring (%.1f s wall incl. start-up)"
+                      % (covered, n_windows, length, cores, busy, wall),
+            "gcells_per_s": cells / busy / 1e9,
+            "one_thread": {"value": c1["nres"] / dt1, "gcells_per_s": cells1 / dt1 / 1e9, "sample": "%d windows, %.1f s" % (n1, dt1)},
+            "scalar_port_one_thread": {"value": cs["nres"] / dts, "sample": "%d windows through the scalar C oracle, %.1f s" % (min(n1, 2000), dts)}}
+    return base, tot, covered
 
+
+# ------------------------------------------------------------------------------------------------ launcher
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(n, argv):
+    """`bench.py --gpus N` outside torch.distributed.run: start N ranks in a fresh child and relay rank 0's JSON line."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + argv
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    sys.stdout.write(proc.stdout)
+    sys.stdout.flush()
+    return proc.returncode
+
+
+# ------------------------------------------------------------------------------------------------ main
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--windows", type=int, default=1_000_000, help="DNA windows per GPU (BASELINE config: 10^6)")
+    ap.add_argument("--windows", type=int, default=1_000_000, help="DNA windows per GPU (weak) or in total (strong); BASELINE config: 10^6")
     ap.add_argument("--length", type=int, default=1000)
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fs", action="store_true", help="skip the configs[2] (--fs) leg")
+    ap.add_argument("--fs-windows", type=int, default=1_000_000)
+    ap.add_argument("--plumbing-only", action="store_true",
+                    help="CPU test hook: launcher, broadcast, reduce and gather over gloo with fabricated counters; no kernels, value 0")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+
+    import bath_amd as ba
+    from bath_amd import synth
+
+    # this rank's windows: weak = its own block of --windows; strong = its contiguous shard of one block of --windows
+    from bath_amd.dist import shard_range
+    if args.scaling == "strong":
+        lo, hi = shard_range(args.windows, rank, world)
+    else:
+        lo, hi = rank * args.windows, (rank + 1) * args.windows
+    n_mine = hi - lo
+
+    # ---- before any GPU initialisation: the model, the synthetic block, the CPU baseline (forks workers)
+    hmm0 = ba.HMM(MODEL)
+    flat = offsets = None
+    base = cpu_counters = None
+    cpu_covered = 0
+    if not args.plumbing_only:
+        if args.scaling == "strong":                      # one block for the whole job: every rank generates it and keeps its shard
+            full, _, _ = synth.dna_windows(args.windows, args.length, seed=42, hmm=hmm0)
+            flat = full[lo * args.length:hi * args.length].copy()
+            del full
+        else:
+            flat, _, _ = synth.dna_windows(n_mine, args.length, seed=42 + rank, hmm=hmm0)
+        offsets = np.arange(n_mine + 1, dtype=np.int64) * args.length
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            base, cpu_counters, cpu_covered = cpu_baseline(flat, args.length, n_mine)
+
     import torch
     import torch.distributed as dist
-    import bath_amd as ba
-    from bath_amd import dist as bdist, synth
+    from bath_amd import dist as bdist
 
-    if not torch.cuda.is_available():
+    on_gpu = torch.cuda.is_available() and not args.plumbing_only
+    if not on_gpu and not args.plumbing_only:
         raise SystemExit("bench.py needs an MI355X: the backend has no CPU path")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if on_gpu:
+        torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank) if on_gpu else torch.device("cpu")
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if on_gpu:
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     # query model: read on rank 0, broadcast (RCCL over xGMI), parsed by every rank
     blob = open(MODEL, "rb").read() if rank == 0 else b""
@@ -126,46 +216,75 @@ def main():
     hmm = ba.HMM(tmp)
     os.unlink(tmp)
 
-    ctx = ba.Context(local_rank)
-    om = ba.OProfile(ctx, ba.Profile(hmm))
-    flat, offsets, planted = synth.dna_windows(args.windows, args.length, seed=42 + rank, hmm=hmm)
-    dna = ba.SeqBlock(ctx, flat, offsets)
-    pipe = ba.Pipeline(ctx, om, fs_pipe=False, ncbi_table=hmm.ct)
-
     def sync():
-        ctx.synchronize()
-        torch.cuda.synchronize()
+        if on_gpu:
+            ctx.synchronize()
+            torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-            torch.cuda.synchronize()
+            if on_gpu:
+                torch.cuda.synchronize()
 
-    stats = None
-    for _ in range(args.warmup):
-        stats, _ = pipe.run(dna, want_results=False)
-    sync()
-    t0 = time.perf_counter()
-    stage_ms = {}
-    stage_launches = {}
-    for _ in range(args.steps):
-        stats, _ = pipe.run(dna, want_results=False)
-        for name, ms, nl in pipe.timings():
-            stage_ms.setdefault(name, []).append(ms)
-            stage_launches[name] = nl
-    sync()
-    elapsed = bdist.max_over_ranks(time.perf_counter() - t0, dev)
-
-    # one more pass with the copy-out, to gather the hits on rank 0 (outside the timed region)
-    stats, res = pipe.run(dna, want_results=True)
-    lo = rank * args.windows
+    stage_ms, stage_launches = {}, {}
+    if on_gpu:
+        ctx = ba.Context(local_rank)
+        om = ba.OProfile(ctx, ba.Profile(hmm))
+        dna = ba.SeqBlock(ctx, flat, offsets)
+        pipe = ba.Pipeline(ctx, om, fs_pipe=False, ncbi_table=hmm.ct)
+        stats = None
+        for _ in range(args.warmup):
+            stats, _ = pipe.run(dna, want_results=False)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            stats, _ = pipe.run(dna, want_results=False)
+            for name, ms, nl in pipe.timings():
+                stage_ms.setdefault(name, []).append(ms)
+                stage_launches[name] = nl
+        sync()
+        elapsed = bdist.max_over_ranks(time.perf_counter() - t0, dev)
+        # one more pass with the copy-out, to gather the records on rank 0 (outside the timed region; timed on its own below)
+        t1 = time.perf_counter()
+        stats, res = pipe.run(dna, want_results=True)
+        ms_with_results = (time.perf_counter() - t1) * 1e3
+    else:                                                  # --plumbing-only: fabricated counters, the collectives are what runs
+        elapsed = bdist.max_over_ranks(1e-3, dev)
+        stats = ba.PipelineStats()
+        stats.nres, stats.n_orfs, stats.n_past_msv = 2 * n_mine * args.length, 38 * n_mine, n_mine
+        res = np.zeros(min(n_mine, 64), dtype=ba.ORF_RESULT_DTYPE)
+        res["window"] = np.arange(len(res))
+        ms_with_results = 0.0
     merged = bdist.reduce_stats(stats, dev)
     hits = bdist.gather_results(res, lo, 0, dev)
 
+    out = None
     if rank == 0:
         tot = merged
         nres_step = tot["nres"]
         cells_step = tot["cells_msv"] + tot["cells_vit"] + tot["cells_fwd"]
         ms_step = elapsed / args.steps * 1e3
-        value = nres_step / (elapsed / args.steps)
+        value = nres_step / (elapsed / args.steps) if on_gpu else 0.0
+        out = {
+            "metric": "DP Gcells/s + residues/s through bathsearch pipeline at 1/2/4/8 MI355X",
+            "value": value, "unit": "residues/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+            "dtype": "integer scores: u8 as exact binary16 (SSV), u8 (MSV), i16 (Viterbi); f32 (Forward, bias)", "data": "synthetic",
+            "config": {"workload": "Caudal_act.bhmm (M=%d) vs %d x %d nt iid DNA windows %s (1%% planted), both strands, "
+                                   "6-frame translation + MSV/bias/Viterbi/Forward filter cascade, codon table %d, no --fs"
+                                   % (hmm.M, args.windows, args.length, "per GPU" if args.scaling == "weak" else "in total, sharded over the GPUs", hmm.ct),
+                       "windows_per_gpu": n_mine, "window_nt": args.length, "M": hmm.M},
+            "gcells_per_s": cells_step / (elapsed / args.steps) / 1e9 if on_gpu else 0.0,
+            "cells_per_step": cells_step, "residues_per_step": nres_step,
+            "survivors": {k: tot[k] for k in ("n_orfs", "n_past_msv", "n_past_bias", "n_past_vit", "n_past_fwd")},
+            "hits_gathered": int(len(hits)) if hits is not None else 0,
+            "timed_region": "DNA resident in HBM (1 byte per nucleotide); counters only -- the surviving ORFs' records stay on the device; "
+                            "a pass that also copies them to the host takes ms_per_step_with_records",
+            "ms_per_step_with_records": ms_with_results,
+        }
+        if args.plumbing_only:
+            out["plumbing_only"] = True
+    if rank == 0 and on_gpu:
+        out["stage_ms"] = {k: float(np.mean(v)) for k, v in stage_ms.items()}
         # dominant kernel: ssv_orf_kernel.  A large block runs as <lanes> concurrent parts (bath_hip_pipeline_filters), so a
         # step launches the kernel <lanes> times, each on its part of the ORF list and overlapping the other parts' work.
         lanes = max(1, int(stage_launches.get("ssv_f1", 1)))
@@ -174,47 +293,116 @@ def main():
         # 1 B per ORF residue + 16 B per ORF work-list record read once, ~34 B written per surviving ORF; per launch
         algo_bytes = (orf_res + 16.0 * stats.n_orfs + 34.0 * stats.n_past_msv) / lanes
         achieved = algo_bytes / (k_ms * 1e-3) / 1e9
+        # the same kernel alone on the chip: one part, nothing overlapping it (outside the timed region)
+        os.environ["BATH_HIP_LANES"] = "1"
+        pipe.run(dna, want_results=False)
+        one = []
+        for _ in range(3):
+            pipe.run(dna, want_results=False)
+            one.append({n: ms for n, ms, _ in pipe.timings()})
+        del os.environ["BATH_HIP_LANES"]
+        k1_ms = float(np.mean([o["ssv_f1"] for o in one]))
+        tc1 = stats.cells_msv / (k1_ms * 1e-3) / 1e12
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_ssv_orf_pmc.json")
+        pmc = os.path.join(ROOT, "profiles", "r02_ssv_orf_pmc.json")
         if os.path.exists(pmc):
             try:
                 traffic = json.load(open(pmc)).get("hbm_bytes_per_launch_full_block") / lanes
             except Exception:
                 traffic = None
-        out = {
-            "metric": "DP Gcells/s + residues/s through bathsearch pipeline at 1/2/4/8 MI355X",
-            "value": value, "unit": "residues/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "integer scores: u8 as exact binary16 (SSV), u8 (MSV), i16 (Viterbi); f32 (Forward, bias)", "data": "synthetic",
-            "config": {"workload": "Caudal_act.bhmm (M=%d) vs %d x %d nt iid DNA windows per GPU (1%% planted), both strands, "
-                                   "6-frame translation + MSV/bias/Viterbi/Forward filter cascade, codon table %d, no --fs"
-                                   % (hmm.M, args.windows, args.length, hmm.ct),
-                       "windows_per_gpu": args.windows, "window_nt": args.length, "M": hmm.M},
-            "gcells_per_s": cells_step / (elapsed / args.steps) / 1e9,
-            "cells_per_step": cells_step, "residues_per_step": nres_step,
-            "stage_ms": {k: float(np.mean(v)) for k, v in stage_ms.items()},
-            "survivors": {k: tot[k] for k in ("n_orfs", "n_past_msv", "n_past_bias", "n_past_vit", "n_past_fwd")},
-            "hits_gathered": int(len(hits)) if hits is not None else 0,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "ssv_orf_kernel", "kernel_ms": k_ms,
-                         "note": "DP rows held in VGPRs (integer scores as binary16): compulsory HBM traffic is 1 B per ORF residue, the kernel is bound by the issue rate of packed 16-bit VALU ops (see DESIGN.md 4.1); "
-                                 "cell rate of this kernel = %.2f Tcells/s per launch while %d parts of the block overlap on separate streams"
-                                 % (stats.cells_msv / lanes / (k_ms * 1e-3) / 1e12, lanes), "launches_per_step": lanes,
-                         # the bound that does apply, for the reader: the issue rate of packed 16-bit VALU ops.  tools/valu_rate.hip
-                         # measures 5.2e11 wave-instructions/s for v_pk_add_f16 / v_pk_maximum3_f16 on this chip at 8 waves per SIMD (4.4e11 at
-                         # the 4 this kernel's registers allow; v_fma_f32: 9.3e11); a row costs 3 of them per 4 cells (2 adds + 1 maximum3),
-                         # 64 lanes each: 5.2e11 x 64 x 4/3 = 44.4 Tcells/s for the chip; concurrent parts share it
-                         "valu": {"tcells_per_s_per_launch": stats.cells_msv / lanes / (k_ms * 1e-3) / 1e12, "peak_tcells_per_s": 44.4,
-                                  "frac_per_launch": stats.cells_msv / lanes / (k_ms * 1e-3) / 1e12 / 44.4, "concurrent_launches": lanes,
-                                  "peak_source": "measured packed-op issue rate, tools/valu_rate.hip, profiles/r01_valu_rate.txt"}},
+        out["roofline"] = {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic, "traffic_source": "rocprofv3 --pmc passes of this command, profiles/r02_ssv_orf_pmc.json (static: counters cannot be read from inside the run)",
+            "kernel": "ssv_orf_kernel", "kernel_ms": k_ms, "launches_per_step": lanes,
+            "note": "DP rows held in VGPRs (integer scores as binary16): compulsory HBM traffic is 1 B per ORF residue, so the HBM fraction is small by "
+                    "construction; the kernel is bound by the issue rate of packed 16-bit VALU ops (DESIGN.md 4.1), see valu",
+            # the bound that does apply: tools/valu_rate.hip measures 5.2e11 wave-instructions/s for v_pk_add_f16 / v_pk_maximum3_f16 at 8 waves per
+            # SIMD (4.4e11 at the 4 this kernel's registers allow); a row costs 3 of them per 4 cells, 64 lanes each: 44.4 (37.9) Tcells/s
+            "valu": {"kernel_ms_one_part": k1_ms, "tcells_per_s": tc1, "peak_tcells_per_s": 44.4, "frac": tc1 / 44.4,
+                     "peak_at_this_occupancy_tcells_per_s": 37.9, "frac_at_this_occupancy": tc1 / 37.9,
+                     "how": "whole block as ONE part (BATH_HIP_LANES=1), nothing overlapping the kernel; HIP events on its stream",
+                     "peak_source": "measured packed-op issue rate, tools/valu_rate.hip, profiles/r01_valu_rate.txt"},
+            "one_part_stage_ms": {k: float(np.mean([o[k] for o in one])) for k in one[0]},
         }
-        if not args.no_cpu_baseline and world == 1:           # the CPU baseline is measured on rank 0 of the 1-GPU run only
-            base, _ = cpu_baseline(flat, args.length, args.windows)
+        out["one_part_kernel_sum_ms"] = float(sum(out["roofline"]["one_part_stage_ms"].values()))
+        if base is not None:
             out["cpu_baseline"] = base
+            # the CPU leg scored windows [0, cpu_covered) of this very block: compare every counter with the GPU's over the same windows
+            if cpu_covered == n_mine:
+                g = {f: int(getattr(stats, f)) for f in COUNTERS}
+            else:
+                sub = ba.SeqBlock(ctx, flat[:cpu_covered * args.length], offsets[:cpu_covered + 1])
+                gs, _ = pipe.run(sub, want_results=False)
+                g = {f: int(getattr(gs, f)) for f in COUNTERS}
+            diff = {f: (g[f], cpu_counters[f]) for f in COUNTERS if g[f] != cpu_counters[f]}
+            out["parity_full_block"] = (not diff) and cpu_covered == n_mine
+            out["parity_check"] = {"windows": cpu_covered, "of": n_mine, "counters": list(COUNTERS), "all_equal": not diff,
+                                   "mismatches": {k: {"gpu": v[0], "cpu": v[1]} for k, v in diff.items()}}
+        if not args.no_fs and world == 1:
+            out["fs"] = fs_leg(ba, synth, ctx, hmm, om, args)
+    if rank == 0:
         print(json.dumps(out))
+        sys.stdout.flush()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def fs_leg(ba, synth, ctx, hmm, om, args):
+    """BASELINE configs[2]: --fs on a block whose planted domains are frameshifted."""
+    flat, offsets, planted = synth.dna_windows(args.fs_windows, args.length, seed=4242, hmm=hmm, frameshift=True)
+    dna = ba.SeqBlock(ctx, flat, offsets)
+    om3 = ba.FSOProfile(ctx, ba.FSProfile(hmm, 3, ncbi_table=hmm.ct))
+    om5 = ba.FSOProfile(ctx, ba.FSProfile(hmm, 5, ncbi_table=hmm.ct))
+    pipe = ba.Pipeline(ctx, om, fs_pipe=True, ncbi_table=hmm.ct)
+    pipe.run_frameshift_domains(om3, om5, dna)
+    steps = 3
+    kt = {}
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        stats, fw, dm, nskip = pipe.run_frameshift_domains(om3, om5, dna)
+        for name, (ms, nl, cells, nbytes) in pipe.kernel_times().items():
+            k = kt.setdefault(name, {"ms": 0.0, "launches": 0, "cells": 0.0, "bytes": 0.0})
+            k["ms"] += ms / steps; k["launches"] += nl / steps; k["cells"] += cells / steps; k["bytes"] += nbytes / steps
+    dt = (time.perf_counter() - t0) / steps
+    for k in kt.values():
+        k["gcells_per_s"] = k["cells"] / (k["ms"] * 1e-3) / 1e9 if k["ms"] > 0 else 0.0
+        k["algorithmic_GBps"] = k["bytes"] / (k["ms"] * 1e-3) / 1e9 if k["ms"] > 0 else 0.0
+        k["hbm_frac"] = k["algorithmic_GBps"] / HBM_PEAK_GBS
+    env = [n for n in ("fs5_fwd_kernel", "fs_bwd_kernel<5>", "fs5_decode_kernel", "fs5_oa_kernel") if n in kt]
+    env_ms = sum(kt[n]["ms"] for n in env)
+    env_bytes = sum(kt[n]["bytes"] for n in env)
+    env_cells = kt[env[0]]["cells"] if env else 0.0
+    # the same pass with the sums along the model in the reference's serial order (bit-identical scores): the parity mode
+    ctx.set_fs_strict(True)
+    pipe.run_frameshift_domains(om3, om5, dna)
+    t0 = time.perf_counter()
+    s_stats, s_fw, s_dm, _ = pipe.run_frameshift_domains(om3, om5, dna)
+    dts = time.perf_counter() - t0
+    ctx.set_fs_strict(False)
+
+    def key(d):
+        return (d.window, d.strand, d.ienv, d.jenv, d.iali, d.jali, d.ihmm, d.jhmm, d.n_shifted_codons)
+    same = len(set(map(key, dm)) & set(map(key, s_dm)))
+    return {
+        "workload": "Caudal_act.bhmm (M=%d) --fs vs %d x %d nt windows, 1%% planted domains with indels (P(+-1 nt) = 0.01, P(+-2) = 0.005 per codon) "
+                    "and in-frame stops (0.002), both strands: cascade (F4) -> DNA windows -> 3-codon parsers -> regions -> 5-codon "
+                    "Forward/Backward/decoding/optimal accuracy/null2 -> traceback -> hits" % (hmm.M, args.fs_windows, args.length),
+        "ms_per_pass": dt * 1e3, "residues_per_s": stats.nres / dt, "steps": steps,
+        "fs_windows": len(fw), "fs_window_nt": int(sum(w.length for w in fw)), "fs_branch": int(sum(w.branch == 1 for w in fw)),
+        "std_branch": int(sum(w.branch == 2 for w in fw)), "domains": len(dm), "reported": int(sum(d.reported for d in dm)),
+        "envelope_nt": int(sum(abs(d.jenv - d.ienv) + 1 for d in dm)), "clustered_regions": int(nskip),
+        "shifted_codons_found": int(sum(d.n_shifted_codons for d in dm)),
+        "kernels": kt,
+        "roofline": {"bound": "hbm", "kernels": env, "cells": env_cells, "bytes_per_cell": env_bytes / env_cells if env_cells else None,
+                     "ms": env_ms, "achieved": env_bytes / (env_ms * 1e-3) / 1e9 if env_ms > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": env_bytes / (env_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if env_ms > 0 else None,
+                     "note": "5-codon envelope kernels: algorithmic matrix bytes (Forward 32, Backward 12, decoding 44 read + 32 written, "
+                             "optimal accuracy 32 read + 12 written per cell) / sum of their device times"},
+        "strict": {"what": "bath_hip_set_fs_strict(1): log-sums along the model in the reference's serial order, scores bit-identical to "
+                           "generic_fwdback_frameshift.c (tests/test_frameshift_gpu.py); the default sums them with wavefront scans",
+                   "ms_per_pass": dts * 1e3, "domains": len(s_dm), "domains_identical_to_default_mode": same},
+    }
 
 
 if __name__ == "__main__":

@@ -219,6 +219,18 @@ int  bath_hip_pipeline_filters(bath_hip_ctx *ctx, const bath_hip_oprofile *om, c
  * names[i] are static strings. */
 int  bath_hip_pipeline_timings(const bath_hip_ctx *ctx, int max, const char **names, float *ms, int64_t *launches);
 
+/* Device time of every kernel of the stages AFTER the cascade (3-codon parsers, region heuristics, 5-codon envelope kernels,
+ * tracebacks) launched by the last bath_hip_pipeline_frameshift_domains call, aggregated by kernel name: HIP events on the stream
+ * each kernel ran on.  cells = DP cells (rows x nodes) the launches covered, bytes = their algorithmic HBM traffic (the matrix
+ * bytes the kernel must read and write).  Returns the number of entries written (<= max). */
+typedef struct {
+  const char *name;                /* static string */
+  float   ms;
+  int64_t launches;
+  double  cells, bytes;
+} bath_kernel_time;
+int  bath_hip_kernel_times(bath_hip_ctx *ctx, int max, bath_kernel_time *out);
+
 /* The frameshift pipeline (bathsearch --fs) up to the decision which branch a DNA window takes:
  * the cascade with F4 at the Forward stage (p7_pipeline.c:1774-1789), then p7_pli_BuildDNAWindows (:462-572) and the
  * per-window part of p7_pli_Frameshift (:1368-1464): summed ORF score, window null / bias scores

@@ -234,6 +234,13 @@ int   bo_gforward(const uint8_t *dsq, int L, const bo_profile *gm, float *ret_sc
 bo_profile *bo_profile_same_as_mf(const bo_oprofile *om, const bo_profile *gm);       /* p7_oprofile.c:2141 */
 bo_profile *bo_profile_same_as_vf(const bo_oprofile *om, const bo_profile *gm);       /* p7_oprofile.c:2202 */
 
+/* kernel hooks of the cascade (oracle/sse/sse_hooks.c): the scalar restatements above, or -- after bo_pipeline_use_sse(1) -- the
+ * SSE2 striped ones of oracle/sse (the impl_sse-equivalent CPU baseline) */
+int   bo_k_msvfilter(const uint8_t *dsq, int L, const bo_oprofile *om, float *ret_sc);
+int   bo_k_vitfilter(const uint8_t *dsq, int L, const bo_oprofile *om, float *ret_sc);
+int   bo_k_vitfilter_bath(const uint8_t *dsq, int L, const bo_oprofile *om, const bo_scoredata *sd, float filtersc, double P, bo_windowlist *wl, float *ret_sc);
+int   bo_k_forward_parser(const uint8_t *dsq, int L, const bo_oprofile *om, float *ret_sc);
+void  bo_pipeline_use_sse(int on);
 void  bo_windowlist_init(bo_windowlist *wl);
 void  bo_windowlist_free(bo_windowlist *wl);
 

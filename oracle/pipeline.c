@@ -82,7 +82,7 @@ static void strand_cascade(bo_pipeline *pli, bo_oprofile *om, const bo_scoredata
     float nullsc = bo_bg_nullone(bg, n);
     r->nullsc = nullsc;
 
-    r->msv_status = bo_msvfilter(dsq, n, om, &usc);            /* :1649-1652 */
+    r->msv_status = bo_k_msvfilter(dsq, n, om, &usc);            /* :1649-1652 */
     pli->cells_msv += (int64_t) n * om->M;
     r->usc = usc;
     seqsc = (float)((usc - nullsc) / LOG2C);
@@ -105,7 +105,7 @@ static void strand_cascade(bo_pipeline *pli, bo_oprofile *om, const bo_scoredata
 
     int old_cnt = hw.count;
     if (P > pli->F2) {                                         /* :1669-1675 */
-      r->vit_status = bo_vitfilter_bath(dsq, n, om, sd, filtersc, pli->F2, &hw, &vfsc);
+      r->vit_status = bo_k_vitfilter_bath(dsq, n, om, sd, filtersc, pli->F2, &hw, &vfsc);
       pli->cells_vit += (int64_t) n * om->M;
       seqsc = (float)((vfsc - filtersc) / LOG2C);
       P = bo_gumbel_surv(seqsc, om->evparam[BO_VMU], om->evparam[BO_VLAMBDA]);
@@ -137,7 +137,7 @@ static void strand_cascade(bo_pipeline *pli, bo_oprofile *om, const bo_scoredata
           seqsc = (float)((usc - filtersc) / LOG2C);
           P = bo_gumbel_surv(seqsc, om->evparam[BO_MMU], om->evparam[BO_MLAMBDA]);
           if (P > pli->F2) {
-            r->vit_status = bo_vitfilter(dsq, n, om, &vfsc);
+            r->vit_status = bo_k_vitfilter(dsq, n, om, &vfsc);
             pli->cells_vit += (int64_t) n * om->M;
             seqsc = (float)((vfsc - filtersc) / LOG2C);
             P = bo_gumbel_surv(seqsc, om->evparam[BO_VMU], om->evparam[BO_VLAMBDA]);
@@ -156,7 +156,7 @@ static void strand_cascade(bo_pipeline *pli, bo_oprofile *om, const bo_scoredata
       if (rejected) { hw.count = old_cnt; r->stage = 2; continue; }
     }
 
-    bo_forward_parser(dsq, n, om, NULL, &fwdsc);              /* :1735 / :1779 */
+    bo_k_forward_parser(dsq, n, om, &fwdsc);                  /* :1735 / :1779 */
     pli->cells_fwd += (int64_t) n * om->M;
     seqsc = (float)((fwdsc - filtersc) / LOG2C);
     P = bo_exp_surv(seqsc, om->evparam[BO_FTAU], om->evparam[BO_FLAMBDA]);

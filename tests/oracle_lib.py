@@ -22,7 +22,7 @@ NTRANS = 8
 
 def build():
     so = os.path.join(ORACLE_DIR, "liboracle.so")
-    srcs = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR) if f.endswith((".c", ".h"))]
+    srcs = [os.path.join(d, f) for d in (ORACLE_DIR, os.path.join(ORACLE_DIR, "sse")) for f in os.listdir(d) if f.endswith((".c", ".h"))]
     if (not os.path.exists(so)) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-s", "-C", ORACLE_DIR], stdout=subprocess.DEVNULL)
     return so
@@ -181,6 +181,13 @@ def lib():
     L.bo_gforward.argtypes = [u8p, C.c_int, C.POINTER(Profile), f32p]
     L.bo_profile_same_as_mf.argtypes = [C.POINTER(OProfile), C.POINTER(Profile)]; L.bo_profile_same_as_mf.restype = C.POINTER(Profile)
     L.bo_profile_same_as_vf.argtypes = [C.POINTER(OProfile), C.POINTER(Profile)]; L.bo_profile_same_as_vf.restype = C.POINTER(Profile)
+    # oracle/sse: the SSE2 striped restatement of impl_sse (the CPU baseline)
+    L.bs_oprofile_create.argtypes = [C.POINTER(OProfile)]; L.bs_oprofile_create.restype = C.c_void_p
+    L.bs_oprofile_free.argtypes = [C.c_void_p]
+    for fn in (L.bs_ssvfilter, L.bs_msvfilter, L.bs_vitfilter, L.bs_forward_parser):
+        fn.argtypes = [u8p, C.c_int, C.c_void_p, f32p]
+    L.bs_vitfilter_bath.argtypes = [u8p, C.c_int, C.c_void_p, C.POINTER(ScoreData), C.c_float, C.c_double, C.POINTER(WindowList), f32p]
+    L.bo_pipeline_use_sse.argtypes = [C.c_int]
     L.bo_windowlist_init.argtypes = [C.POINTER(WindowList)]
     L.bo_windowlist_free.argtypes = [C.POINTER(WindowList)]
     L.bo_orfblock_init.argtypes = [C.POINTER(OrfBlock)]

@@ -93,3 +93,23 @@ def test_shard_range_partitions():
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
+
+
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_launcher_starts_the_ranks(scaling):
+    """`python bench.py --gpus 2` outside torch.distributed.run starts two ranks itself (a fresh child process) and relays rank
+    0's JSON line; --plumbing-only runs the launcher, the model broadcast, the counter reduction and the gather to rank 0
+    over gloo with fabricated counters (the kernels need the GPU)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--plumbing-only", "--windows", "1001", "--scaling", scaling],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                           # one JSON line, from rank 0
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == scaling and out["plumbing_only"] is True
+    total = 1001 if scaling == "strong" else 2002                    # strong: one block sharded; weak: a block per rank
+    assert out["residues_per_step"] == 2 * 1000 * total              # counters reduced over both ranks
+    assert out["survivors"]["n_past_msv"] == total

@@ -1,0 +1,116 @@
+"""oracle/sse -- the SSE2 striped restatement of the reference's impl_sse filters (the CPU baseline bench.py times) -- against
+the scalar oracle: the integer filters must agree bit for bit in score AND status (saturation, overflow, the SSV's "cannot
+decide" outcome), the fp32 Forward parser to 1e-5 relative (same products, row sums accumulated in striped order).  The
+cascade run on the striped kernels must give the scalar cascade's counters and records."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import common
+
+ENORESULT, ERANGE = 19, 16
+import oracle_lib as ol
+
+MODELS = [("Caudal_act.bhmm", 0), ("PTH2.bhmm", 0), ("AMP_N.bhmm", 0), ("MET-ct4.bhmm", 1), ("tRNA-proteins.bhmm", 3), ("tRNA-proteins.bhmm", 11)]
+
+
+@pytest.fixture(scope="module", params=MODELS, ids=["%s-%d" % m for m in MODELS])
+def setup(request):
+    name, idx = request.param
+    model = ol.Model(ol.GOLDEN + "/" + name, idx)
+    rng = np.random.default_rng(5 + idx)
+    seqs = common.random_aa(rng, 60, 20, 400) + common.emit_from_model(rng, model, 40) + common.emit_from_model(rng, model, 20, sharpen=3.0)
+    seqs += [np.array([0], np.uint8), rng.choice(20, size=1, p=common.BG / common.BG.sum()).astype(np.uint8), common.random_aa(rng, 1, 2000, 2000)[0]]
+    so = ol.lib().bs_oprofile_create(model.om)
+    yield model, seqs, so
+    ol.lib().bs_oprofile_free(so)
+
+
+def both(model, so, seqs, scalar, striped):
+    L_ = ol.lib()
+    a, b = C.c_float(), C.c_float()
+    out = []
+    for s in seqs:
+        d = ol.dsq_from(s)
+        L_.bo_oprofile_reconfig_length(model.om, len(s))
+        a.value = b.value = 0.0
+        sa = scalar(ol.u8(d), len(s), model.om, C.byref(a)) if scalar is not L_.bo_forward_parser else scalar(ol.u8(d), len(s), model.om, None, C.byref(a))
+        sb = striped(ol.u8(d), len(s), so, C.byref(b))
+        out.append((sa, a.value, sb, b.value))
+    return out
+
+
+@pytest.mark.parametrize("which", ["ssv", "msv", "vit"])
+def test_integer_filters_bit_exact(setup, which):
+    model, seqs, so = setup
+    L_ = ol.lib()
+    scalar, striped = {"ssv": (L_.bo_ssvfilter, L_.bs_ssvfilter), "msv": (L_.bo_msvfilter, L_.bs_msvfilter), "vit": (L_.bo_vitfilter, L_.bs_vitfilter)}[which]
+    res = both(model, so, seqs, scalar, striped)
+    statuses = set()
+    for sa, a, sb, b in res:
+        assert sa == sb
+        statuses.add(sa)
+        if sa != ENORESULT:
+            assert np.float32(a).view(np.uint32) == np.float32(b).view(np.uint32), (a, b)
+    assert 0 in statuses
+    if which == "ssv" and model.M > 60:
+        assert statuses & {ENORESULT, ERANGE}           # the homologs reach the J-state / overflow outcomes
+
+
+def test_msv_with_j_state_bit_exact(setup):
+    """The full byte recurrence (msvfilter.c:106-207), not only the SSV shortcut: repeat-carrying sequences use the J state."""
+    model, seqs, so = setup
+    L_ = ol.lib()
+    L_.bs_msv_full.argtypes = L_.bs_msvfilter.argtypes
+    for sa, a, sb, b in both(model, so, seqs, L_.bo_msvfilter_noSSV, L_.bs_msv_full):
+        assert sa == sb and np.float32(a).view(np.uint32) == np.float32(b).view(np.uint32)
+
+
+def test_forward_parser(setup):
+    model, seqs, so = setup
+    L_ = ol.lib()
+    for sa, a, sb, b in both(model, so, seqs, L_.bo_forward_parser, L_.bs_forward_parser):
+        assert sa == sb
+        assert (np.isinf(a) and np.isinf(b)) or abs(a - b) <= 1e-5 * max(1.0, abs(a)), (a, b)
+
+
+def test_viterbi_windows(setup):
+    """p7_ViterbiFilter_BATH's hit windows (vitfilter.c:386-424) from the striped kernel."""
+    model, seqs, so = setup
+    L_ = ol.lib()
+    n_win = 0
+    for s in seqs:
+        d = ol.dsq_from(s)
+        L_.bo_oprofile_reconfig_length(model.om, len(s))
+        outs = []
+        for fn, prof in ((L_.bo_vitfilter_bath, model.om), (L_.bs_vitfilter_bath, so)):
+            wl = ol.WindowList(); L_.bo_windowlist_init(C.byref(wl))
+            sc = C.c_float()
+            st = fn(ol.u8(d), len(s), prof, model.sd, C.c_float(-5.0), C.c_double(1e-3), C.byref(wl), C.byref(sc))
+            outs.append((st, np.float32(sc.value).view(np.uint32), [(wl.w[i].n, wl.w[i].k, wl.w[i].length) for i in range(wl.count)]))
+            L_.bo_windowlist_free(C.byref(wl))
+        assert outs[0] == outs[1]
+        n_win += len(outs[0][2])
+    assert n_win > 0
+
+
+def test_cascade_on_striped_kernels_equals_scalar_cascade():
+    model = ol.Model(ol.GOLDEN + "/Caudal_act.bhmm", 0)
+    rng = np.random.default_rng(3)
+    wins = common.random_dna(rng, 150, 1000)
+    for aa in common.emit_from_model(rng, model, 40, flank=10):
+        wins.append(common.revtranslate(rng, aa, model.basic))
+    L_ = ol.lib()
+    out = []
+    for on in (0, 1):
+        L_.bo_pipeline_use_sse(on)
+        pli, res, _ = model.run_pipeline(wins)
+        out.append(([getattr(pli, f) for f in ("nres", "n_orfs", "n_past_msv", "n_past_bias", "n_past_vit", "n_past_fwd", "pos_past_msv", "pos_past_bias",
+                                               "pos_past_vit", "pos_past_fwd", "cells_msv", "cells_vit", "cells_fwd")],
+                    [(r.strand, r.frame, r.start, r.n, r.stage, r.msv_status, np.float32(r.usc).view(np.uint32), np.float32(r.vfsc).view(np.uint32)) for r in res],
+                    [r.fwdsc for r in res]))
+    L_.bo_pipeline_use_sse(0)
+    assert out[0][0] == out[1][0] and out[0][1] == out[1][1] and out[0][0][5] >= 10
+    for a, b in zip(out[0][2], out[1][2]):
+        assert (np.isinf(a) and np.isinf(b)) or abs(a - b) <= 1e-5 * max(1.0, abs(a))
