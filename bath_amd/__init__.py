@@ -127,6 +127,15 @@ class KernelTime(C.Structure):
     _fields_ = [("name", C.c_char_p), ("ms", C.c_float), ("launches", C.c_int64), ("cells", C.c_double), ("bytes", C.c_double)]
 
 
+class HmmWindow(C.Structure):
+    _fields_ = [("target", C.c_int64), ("n", C.c_int32), ("k", C.c_int32), ("length", C.c_int32), ("score", C.c_float)]
+
+
+class StdResult(C.Structure):
+    _fields_ = [("fwdsc", C.c_float), ("bcksc", C.c_float), ("oasc", C.c_float), ("fwd_status", C.c_int32), ("bck_status", C.c_int32),
+                ("ok", C.c_int32), ("null2", C.c_float * KP)]
+
+
 class Fs5Result(C.Structure):
     _fields_ = [("fwdsc", C.c_float), ("bcksc", C.c_float), ("oasc", C.c_float), ("null2", C.c_float * KP)]
 
@@ -196,6 +205,12 @@ ABI = {
     "bath_hip_fsprofile_destroy": (None, [_vp]),
     "bath_hip_fs3_forward_parser": (C.c_int, [_vp, _vp, _vp, C.c_int, _f32p, _f32p, _i64p]),
     "bath_hip_fs3_backward_parser": (C.c_int, [_vp, _vp, _vp, C.c_int, _f32p, _f32p, _i64p]),
+    "bath_hip_vitfilter_bath": (C.c_int, [_vp, _vp, _vp, _f32p, C.c_double, _f32p, _i32p, C.POINTER(C.POINTER(HmmWindow)), _i64p]),
+    "bath_hip_ssvfilter_bath": (C.c_int, [_vp, _vp, _vp, C.c_double, C.POINTER(C.POINTER(HmmWindow)), _i64p]),
+    "bath_hip_forward_full": (C.c_int, [_vp, _vp, _vp, _i32p, C.c_int, _f32p, _i32p, _f32p, _f32p]),
+    "bath_hip_std_envelopes": (C.c_int, [_vp, _vp, _vp, C.POINTER(StdResult), _f32p, _f32p, _f32p, _f32p]),
+    "bath_hip_fs5_envelopes_x": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.POINTER(Fs5Result), _f32p, _f32p, _f32p, _f32p]),
+    "bath_hip_fs5_forward_full": (C.c_int, [_vp, _vp, _vp, C.c_int, _f32p, _f32p, _f32p]),
     "bath_hip_fs5_envelopes": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.POINTER(Fs5Result), _f32p, _i64p, _f32p, _i64p]),
 }
 

@@ -97,6 +97,7 @@ struct bath_hip_ctx {
   std::vector<bath::PipelineSurvivor> fs_std_orfs;   // ORFs of the windows that take the standard branch (p7_pipeline.c:1479-1510)
   const uint8_t *fs_std_pool = nullptr;              // their residues: the amino-acid streams of the last cascade
   std::vector<uint8_t> orf_aa;
+  std::vector<bath_hmm_window> hmm_windows;   // bath_hip_vitfilter_bath / bath_hip_ssvfilter_bath output
   std::vector<bath::StageTiming> timings;
   std::vector<hipEvent_t> ev_pool;
   // per-kernel device times of the stages after the cascade (bath_hip_kernel_times): spans recorded since the last reset

@@ -397,7 +397,8 @@ __global__ void std_envelope_kernel(SeqView sq, int M, const float *__restrict__
                                     const uint8_t *__restrict__ cons /* [M+1] or null */, uint8_t *__restrict__ tbuf, const int64_t *__restrict__ t_off,
                                     int filled /* std_envelope_fill_kernel already did decoding, OA fill and null2: traceback only */,
                                     const float *__restrict__ msc /* [Kp][M+1] log-odds */, const float *__restrict__ tsc /* [M][8] log */,
-                                    const uint8_t *__restrict__ nt /* the DNA block */, const int64_t *__restrict__ nt_base, const int64_t *__restrict__ nt_dir) {
+                                    const uint8_t *__restrict__ nt /* the DNA block */, const int64_t *__restrict__ nt_base, const int64_t *__restrict__ nt_dir,
+                                    float *__restrict__ null2_out = nullptr /* optional [n][Kp]: the null2 vector itself (filled == 0 only) */) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= sq.n) return;
   enum { XE = 0, XN, XJ, XB, XC, XS };
@@ -589,6 +590,7 @@ __global__ void std_envelope_kernel(SeqView sq, int M, const float *__restrict__
       null2[21 + dx] = sum / (float)cnt;
     }
     null2[20] = 1.0f; null2[27] = 1.0f; null2[28] = 1.0f;
+    if (null2_out) for (int x = 0; x < kKp; x++) null2_out[(size_t)t * kKp + x] = null2[x];
     float corr = 0.f;
     for (int pos = 1; pos <= L; pos++) corr += logf(null2[min((int)dsq[pos], kKp - 1)]);
     r.domcorrection = corr;
@@ -1022,6 +1024,111 @@ extern "C" int bath_hip_pipeline_hits(bath_hip_ctx *ctx, const bath_hip_oprofile
   if ((st = std_domains(ctx, om, dna, surv, d_pool, st_local.nres, E_report, &nskip)) != BATH_OK) return st;
   if (n_skipped_regions) *n_skipped_regions = nskip;
   *domains = ctx->fs_domains.data(); *n_domains = (int64_t)ctx->fs_domains.size();
+  return BATH_OK;
+}
+
+// =================================================================================================================
+// Full-matrix entry points over a block of amino-acid targets: what the single-target prototypes p7_Forward / p7_Backward /
+// p7_Decoding / p7_OptimalAccuracy / p7_Null2_ByExpectation of impl_hip/ bind (the domain stage above runs the same kernels).
+// =================================================================================================================
+namespace {
+struct BlockOffsets { std::vector<int64_t> x, dp; };
+BlockOffsets block_offsets(const bath_hip_seqs *sq, int M) {
+  BlockOffsets o;
+  o.x.assign((size_t)sq->n + 1, 0); o.dp.assign((size_t)sq->n + 1, 0);
+  for (int64_t i = 0; i < sq->n; i++) {
+    o.x[(size_t)i + 1] = o.x[(size_t)i] + ((int64_t)sq->h_len[(size_t)i] + 1) * 6;
+    o.dp[(size_t)i + 1] = o.dp[(size_t)i] + ((int64_t)sq->h_len[(size_t)i] + 1) * (M + 1) * 3;
+  }
+  return o;
+}
+}  // namespace
+
+extern "C" int bath_hip_forward_full(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bath_hip_seqs *sq, const int32_t *cfg_len, int unihit,
+                                     float *sc, int32_t *status, float *dp, float *xmx) {
+  if (!ctx || !om || !sq || !sc) return BATH_EINVAL;
+  BATH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const int64_t n = sq->n;
+  if (n == 0) return BATH_OK;
+  const int M = om->M;
+  int maxcfg = sq->maxlen;
+  if (cfg_len) for (int64_t i = 0; i < n; i++) maxcfg = std::max(maxcfg, (int)cfg_len[i]);
+  int st = om->ensure_len_tables(maxcfg + 1);
+  if (st != BATH_OK) return st;
+  const BlockOffsets o = block_offsets(sq, M);
+  DevBuf &b_f = ctx->scratch[15], &b_off = ctx->scratch[20], &b_fx = ctx->scratch[18], &b_sc = ctx->scratch[21], &b_cfg = ctx->scratch[5];
+  BATH_HIP_TRY(ctx, b_f.reserve((size_t)o.dp[(size_t)n] * 4 + 64)); BATH_HIP_TRY(ctx, b_fx.reserve((size_t)o.x[(size_t)n] * 4 + 64));
+  BATH_HIP_TRY(ctx, b_off.reserve((size_t)(n + 1) * 16)); BATH_HIP_TRY(ctx, b_sc.reserve((size_t)n * 8)); BATH_HIP_TRY(ctx, b_cfg.reserve((size_t)n * 4 + 64));
+  int64_t *d_xo = b_off.as<int64_t>(), *d_dpo = d_xo + (n + 1);
+  BATH_HIP_TRY(ctx, hipMemcpyAsync(d_xo, o.x.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+  BATH_HIP_TRY(ctx, hipMemcpyAsync(d_dpo, o.dp.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+  if (cfg_len) BATH_HIP_TRY(ctx, hipMemcpyAsync(b_cfg.p, cfg_len, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+  float *d_sc = b_sc.as<float>();
+  int32_t *d_st = reinterpret_cast<int32_t *>(d_sc + n);
+  if ((st = launch_fwd_wave(ctx, om, sq->view(), nullptr, n, d_sc, d_st, nullptr, b_fx.as<float>(), d_xo, b_f.as<float>(), d_dpo, unihit ? 1 : 0,
+                            cfg_len ? b_cfg.as<int32_t>() : nullptr)) != BATH_OK) return st;
+  BATH_HIP_TRY(ctx, hipMemcpyAsync(sc, d_sc, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (status) BATH_HIP_TRY(ctx, hipMemcpyAsync(status, d_st, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (dp) BATH_HIP_TRY(ctx, hipMemcpyAsync(dp, b_f.p, (size_t)o.dp[(size_t)n] * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (xmx) BATH_HIP_TRY(ctx, hipMemcpyAsync(xmx, b_fx.p, (size_t)o.x[(size_t)n] * 4, hipMemcpyDeviceToHost, ctx->stream));
+  BATH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return BATH_OK;
+}
+
+extern "C" int bath_hip_std_envelopes(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bath_hip_seqs *sq, bath_std_result *res,
+                                      float *pp, float *oa, float *ppx, float *oax) {
+  if (!ctx || !om || !sq || !res) return BATH_EINVAL;
+  BATH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const int64_t n = sq->n;
+  if (n == 0) return BATH_OK;
+  const int M = om->M;
+  int st = om->ensure_len_tables(sq->maxlen + 1);
+  if (st != BATH_OK) return st;
+  const BlockOffsets o = block_offsets(sq, M);
+  std::vector<int64_t> toff((size_t)n + 1, 0);
+  for (int64_t e = 0; e < n; e++) toff[(size_t)e + 1] = toff[(size_t)e] + sq->h_len[(size_t)e] + M + 2;
+  DevBuf &b_f = ctx->scratch[15], &b_b = ctx->scratch[16], &b_off = ctx->scratch[20], &b_fx = ctx->scratch[6], &b_bx = ctx->scratch[7], &b_px = ctx->scratch[18],
+         &b_ox = ctx->scratch[19], &b_em = ctx->scratch[22], &b_out = ctx->scratch[21], &b_tb = ctx->scratch[10], &b_sc = ctx->scratch[2], &b_n2 = ctx->scratch[23];
+  const size_t nx = (size_t)o.x[(size_t)n], ndp = (size_t)o.dp[(size_t)n];
+  BATH_HIP_TRY(ctx, b_f.reserve(ndp * 4 + 64)); BATH_HIP_TRY(ctx, b_b.reserve(ndp * 4 + 64));
+  BATH_HIP_TRY(ctx, b_fx.reserve(nx * 4 + 64)); BATH_HIP_TRY(ctx, b_bx.reserve(nx * 4 + 64));
+  BATH_HIP_TRY(ctx, b_px.reserve(nx / 6 * 5 * 4 + 64)); BATH_HIP_TRY(ctx, b_ox.reserve(nx / 6 * 5 * 4 + 64));
+  BATH_HIP_TRY(ctx, b_em.reserve((size_t)n * 2 * (M + 1) * 4 + 64)); BATH_HIP_TRY(ctx, b_out.reserve((size_t)n * sizeof(StdEnvOut) + 64));
+  BATH_HIP_TRY(ctx, b_tb.reserve((size_t)toff[(size_t)n] + 64)); BATH_HIP_TRY(ctx, b_off.reserve((size_t)(n + 1) * 24));
+  BATH_HIP_TRY(ctx, b_sc.reserve((size_t)n * 16)); BATH_HIP_TRY(ctx, b_n2.reserve((size_t)n * kKp * 4 + 64));
+  int64_t *d_xo = b_off.as<int64_t>(), *d_dpo = d_xo + (n + 1), *d_to = d_dpo + (n + 1);
+  BATH_HIP_TRY(ctx, hipMemcpyAsync(d_xo, o.x.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+  BATH_HIP_TRY(ctx, hipMemcpyAsync(d_dpo, o.dp.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+  BATH_HIP_TRY(ctx, hipMemcpyAsync(d_to, toff.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+  float *d_sc = b_sc.as<float>();
+  int32_t *d_st = reinterpret_cast<int32_t *>(d_sc + 2 * n);
+  if ((st = launch_fwd_wave(ctx, om, sq->view(), nullptr, n, d_sc, d_st, nullptr, b_fx.as<float>(), d_xo, b_f.as<float>(), d_dpo, 1)) != BATH_OK) return st;
+  if ((st = launch_bwd_wave(ctx, om, sq->view(), n, b_fx.as<float>(), d_xo, d_sc + n, d_st + n, b_bx.as<float>(), b_b.as<float>(), d_dpo, 1)) != BATH_OK) return st;
+  // p7_Decoding, p7_OptimalAccuracy, p7_Null2_ByExpectation (and the traceback, unused here), a lane per envelope: posteriors
+  // overwrite Backward, the OA matrix overwrites Forward, as in the reference
+  hipLaunchKernelGGL(std_envelope_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, sq->view(), M, om->d_tf, om->d_rf, b_f.as<float>(), b_b.as<float>(), d_dpo,
+                     b_fx.as<float>(), b_bx.as<float>(), d_xo, b_px.as<float>(), b_ox.as<float>(), b_em.as<float>(), b_out.as<StdEnvOut>(),
+                     (const uint8_t *)nullptr, b_tb.as<uint8_t>(), d_to, 0, (const float *)nullptr, (const float *)nullptr, (const uint8_t *)nullptr,
+                     (const int64_t *)nullptr, (const int64_t *)nullptr, b_n2.as<float>());
+  BATH_HIP_TRY(ctx, hipGetLastError());
+  std::vector<StdEnvOut> eo((size_t)n);
+  std::vector<float> h_sc((size_t)n * 2), h_n2((size_t)n * kKp);
+  std::vector<int32_t> h_st((size_t)n * 2);
+  BATH_HIP_TRY(ctx, hipMemcpyAsync(eo.data(), b_out.p, (size_t)n * sizeof(StdEnvOut), hipMemcpyDeviceToHost, ctx->stream));
+  BATH_HIP_TRY(ctx, hipMemcpyAsync(h_sc.data(), d_sc, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  BATH_HIP_TRY(ctx, hipMemcpyAsync(h_st.data(), d_st, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  BATH_HIP_TRY(ctx, hipMemcpyAsync(h_n2.data(), b_n2.p, (size_t)n * kKp * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (pp) BATH_HIP_TRY(ctx, hipMemcpyAsync(pp, b_b.p, ndp * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (oa) BATH_HIP_TRY(ctx, hipMemcpyAsync(oa, b_f.p, ndp * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (ppx) BATH_HIP_TRY(ctx, hipMemcpyAsync(ppx, b_px.p, nx / 6 * 5 * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (oax) BATH_HIP_TRY(ctx, hipMemcpyAsync(oax, b_ox.p, nx / 6 * 5 * 4, hipMemcpyDeviceToHost, ctx->stream));
+  BATH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  for (int64_t e = 0; e < n; e++) {
+    bath_std_result &r = res[(size_t)e];
+    r.fwdsc = h_sc[(size_t)e]; r.bcksc = h_sc[(size_t)(n + e)]; r.fwd_status = h_st[(size_t)e]; r.bck_status = h_st[(size_t)(n + e)];
+    r.ok = eo[(size_t)e].ok; r.oasc = eo[(size_t)e].oasc;
+    std::memcpy(r.null2, &h_n2[(size_t)e * kKp], sizeof(float) * kKp);
+  }
   return BATH_OK;
 }
 

@@ -1435,6 +1435,27 @@ extern "C" int bath_hip_fs5_envelopes(bath_hip_ctx *ctx, const bath_hip_fsprofil
   return bath::fs5_envelopes_ex(ctx, om, dna, logsum_mode, c5_compat, res, pp, oa, nullptr, nullptr, nullptr);
 }
 
+extern "C" int bath_hip_fs5_envelopes_x(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, const bath_hip_seqs *dna, int logsum_mode, int c5_compat,
+                                        bath_fs5_result *res, float *pp, float *oa, float *ppx, float *oax) {
+  return bath::fs5_envelopes_ex(ctx, om, dna, logsum_mode, c5_compat, res, pp, oa, ppx, oax, nullptr);
+}
+
+extern "C" int bath_hip_fs5_forward_full(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, const bath_hip_seqs *dna, int cfg_len_amino,
+                                         float *sc, float *fwd, float *xmx) {
+  if (!ctx || !om || !dna || !sc || om->codon_lengths != 5) { if (ctx) ctx->set_error("needs a 5-codon profile"); return BATH_EINVAL; }
+  BATH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (dna->n == 0) return BATH_OK;
+  const float *h_f = nullptr, *h_x = nullptr;
+  std::vector<int64_t> foff, xoff;
+  std::vector<float> h_sc;
+  const int st = bath::fs5_region_forward(ctx, om, dna, cfg_len_amino, &h_f, &foff, &h_x, &xoff, &h_sc);
+  if (st != BATH_OK) return st;
+  std::memcpy(sc, h_sc.data(), (size_t)dna->n * sizeof(float));
+  if (fwd) std::memcpy(fwd, h_f, (size_t)foff[(size_t)dna->n] * sizeof(float));
+  if (xmx) std::memcpy(xmx, h_x, (size_t)xoff[(size_t)dna->n] * sizeof(float));
+  return BATH_OK;
+}
+
 // Envelope rescoring; layouts per envelope i, rows = L_i+1: pp rows*(M+1)*8, oa rows*(M+1)*3, ppx / oax rows*5
 // {E,N,J,B,C} (posterior and OA special-state rows), each packed back to back in envelope order.
 int bath::fs5_envelopes_ex(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, const bath_hip_seqs *dna, int logsum_mode, int c5_compat,

@@ -1264,3 +1264,106 @@ extern "C" int bath_hip_pipeline_frameshift(bath_hip_ctx *ctx, const bath_hip_op
   *fs_windows = ctx->fs_windows.data(); *n_fs_windows = nw;
   return BATH_OK;
 }
+
+// =================================================================================================
+// p7_ViterbiFilter_BATH / p7_SSVFilter_BATH over a block of amino-acid targets, with their hit windows: the batched forms
+// the single-target prototypes of impl_hip/ bind (the pipeline above runs the same kernels on its own candidate lists).
+// =================================================================================================
+namespace bath {
+static int windows_out(bath_hip_ctx *ctx, const WindowRec *d_wins, const int *d_count, int cap, const bath_hmm_window **wins, int64_t *nwins) {
+  int n = 0;
+  BATH_HIP_TRY(ctx, hipMemcpyAsync(&n, d_count, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  BATH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (n > cap) { ctx->set_error("hit-window buffer too small"); return BATH_EMEM; }
+  std::vector<WindowRec> h((size_t)n);
+  if (n) BATH_HIP_TRY(ctx, hipMemcpy(h.data(), d_wins, (size_t)n * sizeof(WindowRec), hipMemcpyDeviceToHost));
+  // the kernels append in completion order: restore the reference's order (by target, then by position in the target)
+  std::sort(h.begin(), h.end(), [](const WindowRec &a, const WindowRec &b) { return a.cand != b.cand ? a.cand < b.cand : a.n < b.n; });
+  ctx->hmm_windows.resize((size_t)n);
+  for (int i = 0; i < n; i++) ctx->hmm_windows[(size_t)i] = bath_hmm_window{h[(size_t)i].cand, h[(size_t)i].n, h[(size_t)i].k, h[(size_t)i].length, h[(size_t)i].score};
+  *wins = ctx->hmm_windows.data(); *nwins = n;
+  return BATH_OK;
+}
+}  // namespace bath
+
+extern "C" int bath_hip_vitfilter_bath(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bath_hip_seqs *sq, const float *filtersc, double P,
+                                       float *sc, int32_t *status, const bath_hmm_window **wins, int64_t *nwins) {
+  if (!ctx || !om || !sq || !filtersc || !sc || !wins || !nwins) return BATH_EINVAL;
+  BATH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  *wins = nullptr; *nwins = 0;
+  const int64_t n = sq->n;
+  if (n == 0) return BATH_OK;
+  const int M = om->M;
+  int st = om->ensure_len_tables(sq->maxlen + 1);
+  if (st != BATH_OK) return st;
+  std::vector<uint8_t> ssv_scores((size_t)(M + 1) * kKp, 0);
+  bath_hip_oprofile_get_ssv_scores(om, ssv_scores.data());
+  const int cap = (int)std::min<int64_t>((int64_t)1 << 26, sq->total / 2 + 16 * n + 1024);      // a window ends at least one residue after the last
+  DevBuf &b = ctx->scratch[9];
+  const size_t o_sc = 0, o_st = o_sc + (size_t)n * 4, o_f = o_st + (size_t)n * 4, o_km = o_f + (size_t)n * 4, o_cnt = o_km + (size_t)n * 8, o_ssv = o_cnt + 256,
+               o_w = (o_ssv + ssv_scores.size() + 255) / 256 * 256, total = o_w + (size_t)cap * sizeof(WindowRec);
+  BATH_HIP_TRY(ctx, b.reserve(total + 256));
+  char *p = b.as<char>();
+  BATH_HIP_TRY(ctx, hipMemcpyAsync(p + o_f, filtersc, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+  BATH_HIP_TRY(ctx, hipMemcpyAsync(p + o_ssv, ssv_scores.data(), ssv_scores.size(), hipMemcpyHostToDevice, ctx->stream));
+  BATH_HIP_TRY(ctx, hipMemsetAsync(p + o_cnt, 0, 256, ctx->stream));
+  VitWindowArgs wa{};
+  wa.invP_vit = (double)(float)gumbel_invsurv(P, om->evparam[2], om->evparam[3]);          // vitfilter.c:314 (float invP)
+  wa.invP_msv = (double)(float)gumbel_invsurv(P, om->evparam[0], om->evparam[1]);          // vitfilter.c:319
+  wa.d_filtersc = reinterpret_cast<const float *>(p + o_f); wa.d_ssv_scores = reinterpret_cast<const uint8_t *>(p + o_ssv);
+  wa.d_wins = p + o_w; wa.d_win_count = reinterpret_cast<int *>(p + o_cnt); wa.win_cap = cap; wa.d_kminmax = reinterpret_cast<int32_t *>(p + o_km);
+  if ((st = launch_vit_wave(ctx, om, sq->view(), nullptr, n, reinterpret_cast<float *>(p + o_sc), reinterpret_cast<int32_t *>(p + o_st), &wa, nullptr)) != BATH_OK) return st;
+  BATH_HIP_TRY(ctx, hipMemcpyAsync(sc, p + o_sc, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (status) BATH_HIP_TRY(ctx, hipMemcpyAsync(status, p + o_st, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  return windows_out(ctx, reinterpret_cast<const WindowRec *>(p + o_w), wa.d_win_count, cap, wins, nwins);
+}
+
+extern "C" int bath_hip_ssvfilter_bath(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bath_hip_seqs *sq, double P,
+                                       const bath_hmm_window **wins, int64_t *nwins) {
+  if (!ctx || !om || !sq || !wins || !nwins) return BATH_EINVAL;
+  BATH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  *wins = nullptr; *nwins = 0;
+  const int64_t n = sq->n;
+  if (n == 0) return BATH_OK;
+  if (n >= (int64_t)INT32_MAX) return BATH_EINVAL;
+  const int M = om->M;
+  int st = om->ensure_len_tables(sq->maxlen + 1);
+  if (st != BATH_OK) return st;
+  std::vector<uint8_t> ssv_scores((size_t)(M + 1) * kKp, 0);
+  bath_hip_oprofile_get_ssv_scores(om, ssv_scores.data());
+  const int cap = (int)std::min<int64_t>((int64_t)1 << 26, sq->total / 2 + 16 * n + 1024);
+  DevBuf &b = ctx->scratch[9];
+  const size_t o_todo = 0, o_km = o_todo + (size_t)n * 4, o_ctr = (o_km + (size_t)n * 8 + 255) / 256 * 256, o_ssv = o_ctr + 256 + sizeof(Counters),
+               o_w = (o_ssv + ssv_scores.size() + 255) / 256 * 256, total = o_w + (size_t)cap * sizeof(WindowRec);
+  BATH_HIP_TRY(ctx, b.reserve(total + 256));
+  char *p = b.as<char>();
+  std::vector<int32_t> todo((size_t)n);
+  for (int64_t i = 0; i < n; i++) todo[(size_t)i] = (int32_t)i;
+  Counters hc{};
+  hc.todo_ssvb = (int)n;
+  BATH_HIP_TRY(ctx, hipMemcpyAsync(p + o_todo, todo.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+  BATH_HIP_TRY(ctx, hipMemcpyAsync(p + o_ctr, &hc, sizeof hc, hipMemcpyHostToDevice, ctx->stream));
+  BATH_HIP_TRY(ctx, hipMemcpyAsync(p + o_ssv, ssv_scores.data(), ssv_scores.size(), hipMemcpyHostToDevice, ctx->stream));
+  Cand cand{};                                        // the kernel reads a target's offset and length and writes its model range
+  cand.off = sq->d_off; cand.len = sq->d_len; cand.kminmax = reinterpret_cast<int32_t *>(p + o_km);
+  Counters *d_ctr = reinterpret_cast<Counters *>(p + o_ctr);
+  const MsvConsts mc = msv_consts(om);
+  const double invP = gumbel_invsurv(P, om->evparam[0], om->evparam[1]);                   // msvfilter.c:302
+  const int Cc = (M + 63) / 64;
+  int Cs = -1;
+  for (int opt : {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 52}) if (Cc <= opt) { Cs = opt; break; }
+#define BATH_SSVB_CASE(N)                                                                                                          \
+  case N:                                                                                                                          \
+    hipLaunchKernelGGL(ssv_bath_kernel<N>, dim3(wave_grid_blocks(ctx) / 4), dim3(256), 0, ctx->stream, cand, d_ctr, reinterpret_cast<const int32_t *>(p + o_todo), \
+                       sq->d_data, M, om->d_rb, om->rb_stride, reinterpret_cast<const uint8_t *>(p + o_ssv), om->lt.d_tjb, om->lt.d_nullsc, mc, invP,       \
+                       reinterpret_cast<WindowRec *>(p + o_w), cap, d_ctr);                                                        \
+    break;
+  switch (Cs) {
+    BATH_SSVB_CASE(1) BATH_SSVB_CASE(2) BATH_SSVB_CASE(3) BATH_SSVB_CASE(4) BATH_SSVB_CASE(6) BATH_SSVB_CASE(8)
+    BATH_SSVB_CASE(12) BATH_SSVB_CASE(16) BATH_SSVB_CASE(24) BATH_SSVB_CASE(32) BATH_SSVB_CASE(52)
+    default: ctx->set_error("model too long for the SSV window kernel"); return BATH_EINVAL;
+  }
+#undef BATH_SSVB_CASE
+  BATH_HIP_TRY(ctx, hipGetLastError());
+  return windows_out(ctx, reinterpret_cast<const WindowRec *>(p + o_w), &d_ctr->win_count, cap, wins, nwins);
+}

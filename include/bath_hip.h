@@ -168,6 +168,21 @@ int bath_hip_bias_filter(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const b
 int bath_hip_fwdback_parser(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bath_hip_seqs *sq, const int64_t *xmx_offsets,
                             float *fwd_sc, float *bck_sc, int32_t *fwd_status, int32_t *bck_status, float *fwd_xmx, float *bck_xmx);
 
+/* p7_ViterbiFilter_BATH (vitfilter.c:286) and p7_SSVFilter_BATH (msvfilter.c:250) over a block: the filter plus the hit windows
+ * (P7_HMM_WINDOW, hmmer.h:998: position n in the target, last model node k, length; score only from the SSV variant) that
+ * p7_pli_BuildDNAWindows and the local-composition re-filter read.  filtersc[n]: the bias-filter score of every target;
+ * P: the P-value threshold (pli->F2 / pli->F1).  *wins is owned by ctx (valid until the next call), ordered by target, then
+ * by position.  As in the pipeline each target is scored with the profile configured for its own length. */
+typedef struct {
+  int64_t target;                  /* index of the sequence in the block */
+  int32_t n, k, length;
+  float   score;
+} bath_hmm_window;
+int bath_hip_vitfilter_bath(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bath_hip_seqs *sq, const float *filtersc, double P,
+                            float *sc, int32_t *status, const bath_hmm_window **wins, int64_t *nwins);
+int bath_hip_ssvfilter_bath(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bath_hip_seqs *sq, double P,
+                            const bath_hmm_window **wins, int64_t *nwins);
+
 /* ------------------------------------------------------------------------------------------
  * The filter cascade of p7_Pipeline_BATH (p7_pipeline.c:1632-1791) over a block of DNA windows:
  * six-frame translation (esl_gencode_Process*, bathsearch.c:384-392), MSV, bias, Viterbi, Forward.
@@ -293,6 +308,26 @@ int  bath_hip_pipeline_hits(bath_hip_ctx *ctx, const bath_hip_oprofile *om, cons
                             const bath_pipeline_params *params, double E_report, bath_pipeline_stats *stats,
                             const bath_fs_domain **domains, int64_t *n_domains, int64_t *n_skipped_regions);
 
+/* Full-matrix forms over a block of amino-acid targets (the batched twins of impl_sse's single-target functions):
+ *   bath_hip_forward_full  <- p7_Forward (fwdback.c:94): Forward matrices (L_i+1) x (M+1) x {M,D,I} (odds ratios, scaled per row
+ *       like the parser) back to back in <dp>, special-state rows (L_i+1) x {E,N,J,B,C,SCALE} in <xmx> (either may be NULL).
+ *       cfg_len[n] (or NULL: each target's own length) is the length the profile is configured for
+ *       (p7_oprofile_ReconfigLength / ReconfigMultihit, p7_domaindef.c:560 uses the ORF's saved length for a region);
+ *       unihit != 0: p7_oprofile_ReconfigUnihit.  This is what p7_StochasticTrace walks.
+ *   bath_hip_std_envelopes <- p7_Forward + p7_Backward + p7_Decoding + p7_OptimalAccuracy + p7_Null2_ByExpectation on envelopes
+ *       (rescore_isolated_domain_bath, p7_domaindef.c:1194-1262; unihit, L = L_i): scores, null2[Kp], posterior matrices <pp>
+ *       and optimal-accuracy matrices <oa> in the Forward matrix layout, posterior / OA special-state rows (L_i+1) x {E,N,J,B,C}
+ *       in <ppx> / <oax> (any of the four may be NULL). */
+typedef struct {
+  float   fwdsc, bcksc, oasc;
+  int32_t fwd_status, bck_status, ok;       /* ok == 0: numeric range error in decoding (eslERANGE), the domain is dropped */
+  float   null2[BATH_KP_AMINO];
+} bath_std_result;
+int bath_hip_forward_full(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bath_hip_seqs *sq, const int32_t *cfg_len, int unihit,
+                          float *sc, int32_t *status, float *dp, float *xmx);
+int bath_hip_std_envelopes(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bath_hip_seqs *sq, bath_std_result *res,
+                           float *pp, float *oa, float *ppx, float *oax);
+
 /* ------------------------------------------------------------------------------------------
  * Hit list of a search and its tabular output (P7_TOPHITS; host code).
  * What bathsearch does after its workers finish (bathsearch.c:868-921): p7_tophits_ComputeEvalues_BATH
@@ -359,6 +394,16 @@ int bath_hip_fs5_envelopes(bath_hip_ctx *ctx, const bath_hip_fsprofile *om5, con
                            bath_fs5_result *res,
                            float *pp /* optional: posterior matrices, (L_i+1)*(M+1)*8 floats at pp_offsets[i] */, const int64_t *pp_offsets,
                            float *oa /* optional: OA matrices (L_i+1)*(M+1)*3 */, const int64_t *oa_offsets);
+
+/* bath_hip_fs5_envelopes with the special-state rows as well: posterior rows <ppx> and optimal-accuracy rows <oax>,
+ * (L_i+1) x {E,N,J,B,C} per envelope, back to back (either may be NULL). */
+int bath_hip_fs5_envelopes_x(bath_hip_ctx *ctx, const bath_hip_fsprofile *om5, const bath_hip_seqs *dna, int logsum_mode, int c5_compat,
+                             bath_fs5_result *res, float *pp, float *oa, float *ppx, float *oax);
+/* p7_Forward_Frameshift in the MULTIHIT configuration of amino length <cfg_len_amino> (p7_domaindef.c:411-414: the model's saved
+ * length): sc[n]; Forward matrices (L_i+1) x (M+1) x {D, I, M_C0, M_C1..M_C5} in <fwd>, special-state rows (L_i+1) x {E,N,J,B,C}
+ * in <xmx>, back to back (either may be NULL).  This is what p7_StochasticTrace_Frameshift walks. */
+int bath_hip_fs5_forward_full(bath_hip_ctx *ctx, const bath_hip_fsprofile *om5, const bath_hip_seqs *dna, int cfg_len_amino,
+                              float *sc, float *fwd, float *xmx);
 
 #ifdef __cplusplus
 }
