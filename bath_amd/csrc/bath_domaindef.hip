@@ -222,6 +222,10 @@ static int fs_branch_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, con
     // cell): the envelopes go through in batches of at most 24 GB of matrices (BATH_HIP_ENV_MB overrides, for tests), so a block
     // of any size fits next to the DNA and the amino-acid streams.
     size_t budget = (size_t)24 << 30;
+    {                                                                          // ... and at most half of what is free right now
+      size_t free_b = 0, total_b = 0;
+      if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b / 2 < budget) budget = std::max<size_t>(free_b / 2, (size_t)64 << 20);
+    }
     if (const char *e = std::getenv("BATH_HIP_ENV_MB")) budget = (size_t)std::max(1, std::atoi(e)) << 20;
     for (int e0 = 0; e0 < nenv;) {
       int e1 = e0;

@@ -488,10 +488,14 @@ static T *carve(char *&p, size_t n) {
   return r;
 }
 
-static size_t layout(PipelineWork &w, char *base, int cap) {
+static size_t layout(PipelineWork &w, char *base, int cap, int win_cap) {
   char *p = base;
   const size_t n = (size_t)cap;
-  w.cand_cap = cap; w.win_cap = 2 * cap;
+  w.cand_cap = cap; w.win_cap = std::max(2 * cap, win_cap);
+  if (win_cap == 0) {                                     // tests: start with a window buffer that is too small (BATH_HIP_TEST_WINCAP)
+    static const int forced = [] { const char *e = std::getenv("BATH_HIP_TEST_WINCAP"); return e ? std::atoi(e) : 0; }();
+    if (forced > 0) w.win_cap = forced;
+  }
   w.ctr = carve<Counters>(p, 1);
   w.cand.window = carve<int64_t>(p, n); w.cand.off = carve<int64_t>(p, n); w.cand.P = carve<double>(p, n);
   w.cand.sf = carve<int32_t>(p, n); w.cand.startj = carve<int32_t>(p, n); w.cand.len = carve<int32_t>(p, n);
@@ -610,10 +614,11 @@ static int run_filters(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bat
 
   PipelineWork W;
   Counters hc{};
+  int win_need = 0;                                         // hit windows seen by a pass that ran out of room for them
   for (int attempt = 0;; attempt++) {
-    size_t need = layout(W, nullptr, (int)cap);
+    size_t need = layout(W, nullptr, (int)cap, win_need);
     BATH_HIP_TRY(ctx, b_work.reserve(need + 4096));
-    layout(W, b_work.as<char>(), (int)cap);
+    layout(W, b_work.as<char>(), (int)cap, win_need);
     W.pool = b_aa.as<uint8_t>();
     BATH_HIP_TRY(ctx, hipMemsetAsync(W.ctr, 0, sizeof(Counters), ctx->stream));
     SeqView cv{W.pool, W.cand.off, W.cand.len, cap};
@@ -713,9 +718,12 @@ static int run_filters(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bat
 
     BATH_HIP_TRY(ctx, hipMemcpyAsync(&hc, W.ctr, sizeof(Counters), hipMemcpyDeviceToHost, ctx->stream));
     BATH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if (hc.overflow || hc.cand_count > cap) {
-      if (attempt >= 4) { ctx->set_error("candidate buffers overflowed repeatedly"); return BATH_EMEM; }
-      cap = std::max<int64_t>(cap * 2, (int64_t)hc.cand_count + 1024);
+    // the reference's window list grows without limit (p7_hmmwindow.c:83); here the kernels count every window they find and
+    // drop those beyond the buffer, so a pass that found more windows than fit is repeated with room for all of them
+    if (hc.overflow || hc.cand_count > cap || hc.win_count > W.win_cap) {
+      if (attempt >= 4) { ctx->set_error("candidate / window buffers overflowed repeatedly"); return BATH_EMEM; }
+      if (hc.overflow || hc.cand_count > cap) cap = std::max<int64_t>(cap * 2, (int64_t)hc.cand_count + 1024);
+      if (hc.win_count > W.win_cap) win_need = hc.win_count + hc.win_count / 4 + 1024;
       continue;
     }
     static const char *names[] = {"translate_orfs", "ssv_f1", "classify_msv", "f1_bias", "viterbi_windows", "ssv_windows", "post_vit", "forward_final"};
@@ -753,23 +761,47 @@ static int run_filters(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bat
       BATH_HIP_TRY(ctx, pull(h_P.data(), W.cand.P, nc * 8));
       BATH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     }
-    ctx->results.clear();
-    for (int c = 0; c < nc; c++) {
-      if (h_stage[c] < 1) continue;
-      bath_orf_result r{};
-      r.window = h_window[c]; r.strand = h_sf[c] / 3; r.frame = h_sf[c] % 3;
-      r.start = r.frame + 3 * h_startj[c] + 1; r.end = r.start + 3 * h_len[c] - 1; r.n = h_len[c];
-      r.stage = (h_stage[c] == 5) ? 2 : h_stage[c];
-      r.msv_status = h_ms[c]; r.vit_status = h_vs[c];
-      r.usc = h_usc[c]; r.nullsc = h_null[c]; r.filtersc = h_fsc[c]; r.vfsc = h_vf[c]; r.fwdsc = h_fw[c]; r.P = h_P[c];
-      ctx->results.push_back(r);
+    // records ordered by (window, strand, frame, start): candidates arrive in the order the SSV kernel's lanes appended them, so
+    // they are bucketed by window (a counting sort over the block's windows) and the handful within a window ordered by
+    // (strand*3 + frame, first codon) -- linear in the number of records (a comparison sort of 64-byte records took 50 ms for
+    // the 576 k survivors of the bench block)
+    std::vector<uint32_t> first((size_t)nwin + 1, 0);
+    for (int c = 0; c < nc; c++) if (h_stage[c] >= 1) first[(size_t)h_window[c] + 1]++;
+    for (int64_t w = 0; w < nwin; w++) first[(size_t)w + 1] += first[(size_t)w];
+    const size_t nrec = first[(size_t)nwin];
+    std::vector<uint32_t> order(nrec), fill(first.begin(), first.end() - 1);
+    for (int c = 0; c < nc; c++) if (h_stage[c] >= 1) order[fill[(size_t)h_window[c]]++] = (uint32_t)c;
+    ctx->results.resize(nrec);
+    bath_orf_result *out = ctx->results.data();
+    auto build = [&](int64_t w_lo, int64_t w_hi) {
+      for (int64_t w = w_lo; w < w_hi; w++) {
+        uint32_t *b = order.data() + first[(size_t)w], *e = order.data() + first[(size_t)w + 1];
+        for (uint32_t *i = b + 1; i < e; i++) {                  // insertion sort of the window's few records
+          const uint32_t v = *i;
+          const int64_t kv = ((int64_t)h_sf[v] << 32) | (uint32_t)h_startj[v];
+          uint32_t *j = i;
+          while (j > b && ((((int64_t)h_sf[j[-1]]) << 32) | (uint32_t)h_startj[j[-1]]) > kv) { *j = j[-1]; j--; }
+          *j = v;
+        }
+        for (uint32_t *i = b; i < e; i++) {
+          const int c = (int)*i;
+          bath_orf_result r{};
+          r.window = h_window[c]; r.strand = h_sf[c] / 3; r.frame = h_sf[c] % 3;
+          r.start = r.frame + 3 * h_startj[c] + 1; r.end = r.start + 3 * h_len[c] - 1; r.n = h_len[c];
+          r.stage = (h_stage[c] == 5) ? 2 : h_stage[c];
+          r.msv_status = h_ms[c]; r.vit_status = h_vs[c];
+          r.usc = h_usc[c]; r.nullsc = h_null[c]; r.filtersc = h_fsc[c]; r.vfsc = h_vf[c]; r.fwdsc = h_fw[c]; r.P = h_P[c];
+          out[i - order.data()] = r;
+        }
+      }
+    };
+    if (nrec < 65536) build(0, nwin);
+    else {                                                        // independent windows: a few host threads
+      const int T = (int)std::min<unsigned>(8, std::max(1u, std::thread::hardware_concurrency()));
+      std::vector<std::thread> th;
+      for (int t = 0; t < T; t++) th.emplace_back(build, nwin * t / T, nwin * (t + 1) / T);
+      for (std::thread &t : th) t.join();
     }
-    std::sort(ctx->results.begin(), ctx->results.end(), [](const bath_orf_result &a, const bath_orf_result &b) {
-      if (a.window != b.window) return a.window < b.window;
-      if (a.strand != b.strand) return a.strand < b.strand;
-      if (a.frame != b.frame) return a.frame < b.frame;
-      return a.start < b.start;
-    });
     *results = ctx->results.data();
     if (n_results) *n_results = (int64_t)ctx->results.size();
   } else if (n_results) *n_results = (int64_t)hc.n_past_msv;

@@ -141,7 +141,7 @@ def test_standard_region_stochastic_traces(hs, gpu_ctx):
     cfg = np.array([saveL], np.int32)
     gpu_ctx._check(ba.lib().bath_hip_forward_full(gpu_ctx._h, om._h, blk._h, ip(cfg), 0, fp(bsc), ip(bst), None, None), "forward_full")
     assert bits(sc[0]) == bits(bsc[0])
-    assert nd.min() >= 1 and nd.max() >= 2 and (nd == 2).sum() >= 25                   # most samples see both domains
+    assert nd.min() >= 2 and np.bincount(nd).max() >= 25                               # the samples agree on the region's domains (two genes, each possibly a repeat)
     assert fi.min() >= 1 and li.max() <= L
 
 
@@ -211,6 +211,7 @@ def test_frameshift_region_stochastic_traces(hs, gpu_ctx):
     assert hs.hs_fs_region(PATH.encode(), 0, ol.u8(d), L, 42, 40, fp(sc), ip(nd), ip(fi), ip(li)) == 0
     om5 = ba.FSOProfile(gpu_ctx, ba.FSProfile(hmm, 5))
     bsc = np.zeros(1, np.float32)
-    gpu_ctx._check(ba.lib().bath_hip_fs5_forward_full(gpu_ctx._h, om5._h, ba.SeqBlock(gpu_ctx, [nt])._h, 100, fp(bsc), None, None), "fs5_forward_full")
+    blk = ba.SeqBlock(gpu_ctx, [nt])
+    gpu_ctx._check(ba.lib().bath_hip_fs5_forward_full(gpu_ctx._h, om5._h, blk._h, 100, fp(bsc), None, None), "fs5_forward_full")
     assert bits(sc[0]) == bits(bsc[0])
     assert nd.min() >= 1 and (nd >= 2).sum() >= 15 and fi.min() >= 1 and li.max() <= L

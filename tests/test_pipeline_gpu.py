@@ -143,3 +143,37 @@ def test_concurrent_lanes_give_identical_results(gpu_ctx, lanes, monkeypatch):
     for f in r1.dtype.names:                              # field by field: the records carry padding bytes
         assert np.array_equal(r1[f], r2[f], equal_nan=True), f
     assert s1.n_past_fwd > 0
+
+
+def test_window_buffer_overflow_is_retried(monkeypatch):
+    """hit windows beyond the window buffer were dropped silently.  With a deliberately tiny buffer
+    (BATH_HIP_TEST_WINCAP, read once per process: this test runs the pipeline in a child process) the cascade must notice,
+    repeat the pass with room for every window, and give exactly the results of an ordinary run."""
+    import subprocess, sys, os, json
+    code = r'''
+import sys, json, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import bath_amd as ba, common, oracle_lib as ol
+path = ol.GOLDEN + "/Caudal_act.bhmm"
+model = ol.Model(path)
+rng = np.random.default_rng(5)
+wins = [common.revtranslate(rng, aa, model.basic) for aa in common.emit_from_model(rng, model, 60, flank=10, sharpen=2.0)]
+ctx = ba.Context(0)
+hmm = ba.HMM(path)
+om = ba.OProfile(ctx, ba.Profile(hmm))
+om3 = ba.FSOProfile(ctx, ba.FSProfile(hmm, 3))
+pipe = ba.Pipeline(ctx, om, fs_pipe=True)
+stats, res, fw = pipe.run_frameshift(om3, ba.SeqBlock(ctx, wins))
+print(json.dumps({"fw": sorted((w.window, w.strand, w.n, w.length, w.orf_cnt, w.k_min, w.k_max, w.branch) for w in fw),
+                  "stats": [stats.n_past_vit, stats.pos_past_vit, stats.n_past_fwd]}))
+''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for cap in (None, "3"):
+        env = dict(os.environ)
+        env.pop("BATH_HIP_TEST_WINCAP", None)
+        if cap:
+            env["BATH_HIP_TEST_WINCAP"] = cap
+        p = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        outs.append(json.loads(p.stdout.strip().splitlines()[-1]))
+    assert outs[0] == outs[1] and len(outs[0]["fw"]) >= 30
