@@ -169,6 +169,11 @@ ABI = {
     "bath_hip_seqs_destroy": (None, [_vp]),
     "bath_hip_seqs_count": (C.c_int64, [_vp]),
     "bath_hip_seqs_set_context": (C.c_int, [_vp, C.POINTER(C.c_int32)]),
+    "bath_hip_host_alloc": (C.c_void_p, [C.c_size_t]),
+    "bath_hip_host_free": (None, [C.c_void_p]),
+    "bath_hip_seqs_create_packed": (C.c_int, [_vp, _i64p, C.c_int64, C.POINTER(_vp)]),
+    "bath_hip_seqs_upload_packed": (C.c_int, [_vp, C.c_void_p, _i64p, _i32p, _u8p, C.c_int64]),
+    "bath_hip_seqs_upload_wait": (C.c_int, [_vp]),
     "bath_hip_ssvfilter": (C.c_int, [_vp, _vp, _vp, _f32p, _i32p]),
     "bath_hip_msvfilter": (C.c_int, [_vp, _vp, _vp, _f32p, _i32p]),
     "bath_hip_vitfilter": (C.c_int, [_vp, _vp, _vp, _f32p, _i32p]),
@@ -463,6 +468,71 @@ class SeqBlock:
         if getattr(self, "_h", None) and getattr(self.ctx, "_h", None):
             lib().bath_hip_seqs_destroy(self._h)
         self._h = None
+
+
+def pack2(flat, offsets):
+    """Host side of a streamed block: (packed bytes, exception sequence indices, positions, codes) for 1-byte DNA codes."""
+    flat = np.ascontiguousarray(flat, dtype=np.uint8)
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    lens = np.diff(offsets)
+    n = len(lens)
+    bad = np.flatnonzero(flat[offsets[0]:offsets[-1]] > 3) + offsets[0]
+    seq = np.searchsorted(offsets, bad, side="right") - 1
+    pos = (bad - offsets[seq]).astype(np.int32)
+    codes = flat[bad].copy()
+    if n and (lens == lens[0]).all() and lens[0] % 4 == 0:                     # equal windows, whole bytes: one reshape
+        q = (flat[offsets[0]:offsets[-1]] & 3).reshape(-1, 4)
+        packed = (q[:, 0] | (q[:, 1] << 2) | (q[:, 2] << 4) | (q[:, 3] << 6)).astype(np.uint8)
+    else:
+        parts = []
+        for i in range(n):
+            s = flat[offsets[i]:offsets[i + 1]] & 3
+            pad = (-len(s)) % 4
+            q = np.concatenate([s, np.zeros(pad, np.uint8)]).reshape(-1, 4)
+            parts.append((q[:, 0] | (q[:, 1] << 2) | (q[:, 2] << 4) | (q[:, 3] << 6)).astype(np.uint8))
+        packed = np.concatenate(parts) if parts else np.zeros(0, np.uint8)
+    return packed, seq.astype(np.int64), pos, codes
+
+
+class PinnedBuffer:
+    """Page-locked host memory (bath_hip_host_alloc) viewed as a numpy uint8 array: uploads from it are asynchronous."""
+
+    def __init__(self, nbytes):
+        self.ptr = lib().bath_hip_host_alloc(max(int(nbytes), 1))
+        if not self.ptr:
+            raise BathError("cannot allocate %d bytes of page-locked memory" % nbytes)
+        self.array = np.ctypeslib.as_array((C.c_uint8 * max(int(nbytes), 1)).from_address(self.ptr))
+
+    def __del__(self):
+        if getattr(self, "ptr", None):
+            lib().bath_hip_host_free(self.ptr)
+            self.ptr = None
+
+
+class StreamedBlock(SeqBlock):
+    """A block that is refilled from the host in 2-bit form (bath_hip_seqs_create_packed / _upload_packed / _upload_wait)."""
+
+    def __init__(self, ctx, offsets):
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        self.n = len(offsets) - 1
+        self.lengths = np.diff(offsets)
+        h = _vp()
+        ctx._check(lib().bath_hip_seqs_create_packed(ctx._h, _i64(offsets), self.n, C.byref(h)), "seqs_create_packed")
+        self.ctx, self._h = ctx, h
+
+    def upload(self, packed, exc_seq=None, exc_pos=None, exc_code=None):
+        """Queue the transfer on the copy stream (returns at once for a PinnedBuffer / page-locked array)."""
+        arr = packed.array if isinstance(packed, PinnedBuffer) else np.ascontiguousarray(packed, dtype=np.uint8)
+        n_exc = 0 if exc_seq is None else len(exc_seq)
+        es = np.ascontiguousarray(exc_seq if n_exc else np.zeros(1), dtype=np.int64)
+        ep = np.ascontiguousarray(exc_pos if n_exc else np.zeros(1), dtype=np.int32)
+        ec = np.ascontiguousarray(exc_code if n_exc else np.zeros(1), dtype=np.uint8)
+        self._keep = (arr, es, ep, ec)
+        self.ctx._check(lib().bath_hip_seqs_upload_packed(self._h, arr.ctypes.data, _i64(es), ep.ctypes.data_as(_i32p), _u8(ec), n_exc), "seqs_upload_packed")
+
+    def wait(self):
+        """Order the cascade after the upload and expand the block on the device."""
+        self.ctx._check(lib().bath_hip_seqs_upload_wait(self._h), "seqs_upload_wait")
 
 
 def translate_orfs(ctx, dna, ncbi_table=1, min_orf_len=20):

@@ -82,12 +82,13 @@ struct bath_hip_ctx {
   hipStream_t stream = nullptr;
   hipStream_t side_stream = nullptr;    // created on first use: kernels that may overlap the main stream's (pipeline)
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipStream_t copy_stream = nullptr;    // created on first use: host -> device uploads of packed blocks (bath_hip_seqs_upload_packed)
   hipDeviceProp_t prop{};
   int fs_strict = 0;                    // bath_hip_set_fs_strict: frameshift log-sums along the model in the reference's serial order
   std::string err;
   void set_error(const std::string &m) { err = m; }
   // scratch owned by the context (reused across calls)
-  bath::DevBuf scratch[32];
+  bath::DevBuf scratch[40];
   bath::HostBuf pinned[2];
   std::vector<bath_orf_result> results;
   std::vector<bath_orf> orfs;             // bath_hip_translate_orfs output
@@ -149,6 +150,14 @@ struct bath_hip_seqs {
   int64_t *d_off = nullptr;
   int32_t *d_len = nullptr;
   int32_t *d_context = nullptr; // [n] ESL_SQ.C of every window (bath_hip_seqs_set_context); null: all zero
+  // streamed blocks (bath_hip_seqs_upload_packed): the 2-bit form as it arrives, its per-sequence byte offsets, the exceptions
+  uint8_t *d_packed = nullptr;
+  int64_t *d_poff = nullptr;
+  int64_t packed_bytes = 0;
+  void *d_exc = nullptr;        // {int64 sequence, int32 position, int32 code} records
+  int64_t exc_cap = 0, n_exc = 0;
+  hipEvent_t ev_upload = nullptr;
+  bool upload_pending = false;
   std::vector<int64_t> h_off;   // device offsets (aligned)
   std::vector<int32_t> h_len;
   std::vector<int32_t> h_context;

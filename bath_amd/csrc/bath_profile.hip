@@ -133,6 +133,7 @@ extern "C" void bath_hip_finalize(bath_hip_ctx *ctx) {
   for (auto e : ctx->span_events) (void)hipEventDestroy(e);
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+  if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
   if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -403,8 +404,10 @@ extern "C" void bath_hip_seqs_destroy(bath_hip_seqs *sq) {
   for (bath_hip_seqs *part : sq->parts) bath_hip_seqs_destroy(part);
   sq->parts.clear();
   if (sq->is_part) { sq->d_data = nullptr; sq->d_len = nullptr; sq->d_context = nullptr; }      // borrowed from the parent block
-  for (void *p : {(void *)sq->d_data, (void *)sq->d_off, (void *)sq->d_len, (void *)sq->d_context, (void *)sq->d_tile_desc, (void *)sq->d_tile_first})
+  for (void *p : {(void *)sq->d_data, (void *)sq->d_off, (void *)sq->d_len, (void *)sq->d_context, (void *)sq->d_tile_desc, (void *)sq->d_tile_first,
+                  (void *)sq->d_packed, (void *)sq->d_poff, sq->d_exc})
     if (p) (void)hipFree(p);
+  if (sq->ev_upload) (void)hipEventDestroy(sq->ev_upload);
   delete sq;
 }
 
@@ -465,5 +468,113 @@ extern "C" int bath_hip_seqs_create(bath_hip_ctx *ctx, const uint8_t *dsq, const
   }
   BATH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   *ret = sq;
+  return BATH_OK;
+}
+
+
+// =================================================================================================================
+// Streamed blocks.  A resident block costs one byte per nucleotide over PCIe (1 GB for the bench block, ~20 ms against a 12 ms
+// cascade).  A block can instead arrive in 2 bits per nucleotide (A, C, G, T; the rare other codes as an exception list), 4x
+// less to move, on a copy stream of its own, so that the upload of block k+1 overlaps the cascade of block k; a kernel expands
+// it to the byte-per-nucleotide layout every other kernel reads (1.25 B/nt of HBM traffic, ~0.3 ms for the bench block).
+// =================================================================================================================
+namespace {
+struct ExcRec { int64_t seq; int32_t pos, code; };
+
+// grid.x = sequence, grid.y = 4096-byte chunk of its packed form; a thread expands one packed byte to four nucleotide bytes
+__global__ __launch_bounds__(256) void unpack2_kernel(const uint8_t *__restrict__ packed, const int64_t *__restrict__ poff, const int64_t *__restrict__ off,
+                                                      const int32_t *__restrict__ len, uint8_t *__restrict__ data) {
+  const int64_t s = blockIdx.x;
+  const int L = len[s];
+  const int nb = (L + 3) >> 2;
+  const uint8_t *src = packed + poff[s];
+  uint8_t *dst = data + off[s];
+  const int lo = blockIdx.y * 4096, hi = min(nb, lo + 4096);
+  for (int j = lo + (int)threadIdx.x; j < hi; j += 256) {
+    const unsigned b = src[j];
+    const unsigned v = (b & 3u) | ((b >> 2) & 3u) << 8 | ((b >> 4) & 3u) << 16 | ((b >> 6) & 3u) << 24;
+    if (4 * j + 4 <= L) *reinterpret_cast<uint32_t *>(dst + 4 * j) = v;           // sequences start 16-byte aligned
+    else for (int q = 0; 4 * j + q < L; q++) dst[4 * j + q] = (uint8_t)((v >> (8 * q)) & 0xffu);
+  }
+}
+__global__ void unpack_exceptions_kernel(const ExcRec *__restrict__ exc, int64_t n, const int64_t *__restrict__ off, uint8_t *__restrict__ data) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) data[off[exc[i].seq] + exc[i].pos] = (uint8_t)exc[i].code;
+}
+}  // namespace
+
+extern "C" void *bath_hip_host_alloc(size_t bytes) {
+  void *p = nullptr;
+  return hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) == hipSuccess ? p : nullptr;
+}
+extern "C" void bath_hip_host_free(void *p) { if (p) (void)hipHostFree(p); }
+
+extern "C" int bath_hip_seqs_create_packed(bath_hip_ctx *ctx, const int64_t *offsets, int64_t n, bath_hip_seqs **ret) {
+  *ret = nullptr;
+  if (!ctx || !offsets || n < 0) return BATH_EINVAL;
+  // the block's layout from its offsets, no content yet: an all-'A' block of the same shape
+  std::vector<uint8_t> zeros((size_t)std::max<int64_t>(offsets[n] - offsets[0], 1), 0);
+  std::vector<int64_t> rel((size_t)n + 1);
+  for (int64_t i = 0; i <= n; i++) rel[(size_t)i] = offsets[i] - offsets[0];
+  bath_hip_seqs *sq = nullptr;
+  int st = bath_hip_seqs_create(ctx, zeros.data(), rel.data(), n, &sq);
+  if (st != BATH_OK) return st;
+  std::vector<int64_t> poff((size_t)n + 1, 0);
+  for (int64_t i = 0; i < n; i++) poff[(size_t)i + 1] = poff[(size_t)i] + (sq->h_len[(size_t)i] + 3) / 4;
+  sq->packed_bytes = poff[(size_t)n];
+  BATH_HIP_TRY(ctx, hipMalloc((void **)&sq->d_packed, (size_t)sq->packed_bytes + 64));
+  BATH_HIP_TRY(ctx, hipMalloc((void **)&sq->d_poff, (size_t)(n + 1) * sizeof(int64_t)));
+  BATH_HIP_TRY(ctx, hipMemcpy(sq->d_poff, poff.data(), (size_t)(n + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+  BATH_HIP_TRY(ctx, hipEventCreateWithFlags(&sq->ev_upload, hipEventDisableTiming));
+  *ret = sq;
+  return BATH_OK;
+}
+
+extern "C" int bath_hip_seqs_upload_packed(bath_hip_seqs *sq, const uint8_t *packed, const int64_t *exc_seq, const int32_t *exc_pos,
+                                           const uint8_t *exc_code, int64_t n_exc) {
+  if (!sq || !sq->d_packed || !packed || n_exc < 0) return BATH_EINVAL;
+  bath_hip_ctx *ctx = sq->ctx;
+  BATH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (!ctx->copy_stream) BATH_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+  if (n_exc > sq->exc_cap) {
+    if (sq->d_exc) (void)hipFree(sq->d_exc);
+    sq->exc_cap = n_exc + n_exc / 2 + 1024;
+    BATH_HIP_TRY(ctx, hipMalloc(&sq->d_exc, (size_t)sq->exc_cap * sizeof(ExcRec)));
+  }
+  // asynchronous when <packed> is page-locked (bath_hip_host_alloc); a pageable buffer makes the call wait for its copy
+  BATH_HIP_TRY(ctx, hipMemcpyAsync(sq->d_packed, packed, (size_t)sq->packed_bytes, hipMemcpyHostToDevice, ctx->copy_stream));
+  if (n_exc > 0) {
+    std::vector<ExcRec> h((size_t)n_exc);
+    for (int64_t i = 0; i < n_exc; i++) {
+      if (exc_seq[i] < 0 || exc_seq[i] >= sq->n || exc_pos[i] < 0 || exc_pos[i] >= sq->h_len[(size_t)exc_seq[i]]) { ctx->set_error("exception outside its sequence"); return BATH_EINVAL; }
+      h[(size_t)i] = ExcRec{exc_seq[i], exc_pos[i], (int32_t)exc_code[i]};
+    }
+    BATH_HIP_TRY(ctx, hipMemcpyAsync(sq->d_exc, h.data(), (size_t)n_exc * sizeof(ExcRec), hipMemcpyHostToDevice, ctx->copy_stream));
+    BATH_HIP_TRY(ctx, hipStreamSynchronize(ctx->copy_stream));       // <h> is a local
+  }
+  sq->n_exc = n_exc;
+  BATH_HIP_TRY(ctx, hipEventRecord(sq->ev_upload, ctx->copy_stream));
+  sq->upload_pending = true;
+  return BATH_OK;
+}
+
+extern "C" int bath_hip_seqs_upload_wait(bath_hip_seqs *sq) {
+  if (!sq || !sq->d_packed) return BATH_EINVAL;
+  if (!sq->upload_pending) return BATH_OK;
+  bath_hip_ctx *ctx = sq->ctx;
+  BATH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  BATH_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, sq->ev_upload, 0));
+  if (sq->n > 0) {
+    const unsigned gy = (unsigned)std::max(1, ((sq->maxlen + 3) / 4 + 4095) / 4096);
+    hipLaunchKernelGGL(unpack2_kernel, dim3((unsigned)sq->n, gy), dim3(256), 0, ctx->stream, sq->d_packed, sq->d_poff, sq->d_off, sq->d_len, sq->d_data);
+    if (sq->n_exc > 0)
+      hipLaunchKernelGGL(unpack_exceptions_kernel, dim3((unsigned)((sq->n_exc + 255) / 256)), dim3(256), 0, ctx->stream, (const ExcRec *)sq->d_exc, sq->n_exc, sq->d_off, sq->d_data);
+    BATH_HIP_TRY(ctx, hipGetLastError());
+  }
+  // the lanes' streams read d_data too: order them after the expansion
+  hipEvent_t ev = sq->ev_upload;
+  BATH_HIP_TRY(ctx, hipEventRecord(ev, ctx->stream));
+  for (bath_hip_ctx *l : ctx->lanes) BATH_HIP_TRY(ctx, hipStreamWaitEvent(l->stream, ev, 0));
+  sq->upload_pending = false;
   return BATH_OK;
 }

@@ -151,6 +151,21 @@ int64_t bath_hip_seqs_count(const bath_hip_seqs *sq);
  * and only the new residues are counted in stats->nres (bathsearch.c:1258).  NULL clears it. */
 int  bath_hip_seqs_set_context(bath_hip_seqs *sq, const int32_t *context);
 
+/* Streamed blocks: what a host that feeds the GPU block after block uses instead of bath_hip_seqs_create.  The block arrives
+ * in 2 bits per nucleotide (A, C, G, T = 0..3, nucleotide j of a sequence in bits 2(j%4).. of its byte j/4; every sequence starts
+ * on a byte boundary, sequences back to back), 4x less to move over PCIe than the byte-per-nucleotide form; positions holding
+ * any other code (degenerate nucleotides) come as an exception list.  bath_hip_seqs_create_packed lays the block out from its
+ * offsets (in nucleotides) once; bath_hip_seqs_upload_packed queues the transfer of new content on the context's copy stream
+ * and returns at once when <packed> is page-locked memory (bath_hip_host_alloc), so that the upload of the next block overlaps
+ * the cascade of the current one; bath_hip_seqs_upload_wait orders the context's streams after the transfer and expands the
+ * block on the device to the layout every kernel reads.  The block keeps its shape (offsets, lengths, contexts) across uploads. */
+void *bath_hip_host_alloc(size_t bytes);
+void  bath_hip_host_free(void *p);
+int   bath_hip_seqs_create_packed(bath_hip_ctx *ctx, const int64_t *offsets, int64_t n, bath_hip_seqs **ret);
+int   bath_hip_seqs_upload_packed(bath_hip_seqs *sq, const uint8_t *packed, const int64_t *exc_seq, const int32_t *exc_pos,
+                                  const uint8_t *exc_code, int64_t n_exc);
+int   bath_hip_seqs_upload_wait(bath_hip_seqs *sq);
+
 /* ------------------------------------------------------------------------------------------
  * Filter kernels, batched.  Each target i is scored exactly as the reference would after
  * p7_oprofile_ReconfigLength(om, L_i) (p7_pipeline.c:1644).  sc[n] nats, status[n] easel codes.

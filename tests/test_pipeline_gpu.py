@@ -177,3 +177,51 @@ print(json.dumps({"fw": sorted((w.window, w.strand, w.n, w.length, w.orf_cnt, w.
         assert p.returncode == 0, p.stderr[-2000:]
         outs.append(json.loads(p.stdout.strip().splitlines()[-1]))
     assert outs[0] == outs[1] and len(outs[0]["fw"]) >= 30
+
+
+def test_streamed_packed_blocks_equal_resident_blocks(gpu_ctx):
+    """A block uploaded in 2 bits per nucleotide (+ exception list for degenerate codes), expanded on the device, must give the
+    cascade exactly what the byte-per-nucleotide block gives: ragged lengths (not multiples of 4 or 16), degenerate nucleotides,
+    a refill of the same block object with other content, page-locked and pageable sources."""
+    path = ol.GOLDEN + "/Caudal_act.bhmm"
+    model = ol.Model(path)
+    hmm = ba.HMM(path)
+    om = ba.OProfile(gpu_ctx, ba.Profile(hmm))
+    pipe = ba.Pipeline(gpu_ctx, om, fs_pipe=False)
+    rng = np.random.default_rng(17)
+    lens = [1000, 997, 15, 1, 0, 1003, 64, 4099] + [int(x) for x in rng.integers(200, 1400, size=40)]
+
+    def content(seed):
+        r = np.random.default_rng(seed)
+        seqs = [r.integers(0, 4, size=L).astype(np.uint8) for L in lens]
+        for i, aa in enumerate(common.emit_from_model(r, model, 12, flank=5)):
+            nt = common.revtranslate(r, aa, model.basic)
+            j = 8 + i
+            k = min(len(nt), len(seqs[j]))
+            seqs[j][:k] = nt[:k]
+        for j in (0, 5, 9, 20):                                   # degenerate nucleotides -> exception list
+            idx = r.integers(0, len(seqs[j]), size=5)
+            seqs[j][idx] = r.choice([5, 9, 15], size=5)
+        return seqs
+    offsets = np.zeros(len(lens) + 1, np.int64)
+    np.cumsum(lens, out=offsets[1:])
+    blk = ba.StreamedBlock(gpu_ctx, offsets)
+    pin = ba.PinnedBuffer(int(sum((L + 3) // 4 for L in lens)))
+    for round_, seed in enumerate((1, 2, 3)):
+        seqs = content(seed)
+        flat = np.concatenate(seqs)
+        packed, es, ep, ec = ba.pack2(flat, offsets)
+        assert len(es) >= 10
+        if round_ < 2:
+            pin.array[:len(packed)] = packed
+            blk.upload(pin, es, ep, ec)
+        else:
+            blk.upload(packed, es, ep, ec)                        # pageable source
+        blk.wait()
+        st_s, res_s = pipe.run(blk)
+        st_r, res_r = pipe.run(ba.SeqBlock(gpu_ctx, seqs))
+        for f in ("nres", "n_orfs", "n_past_msv", "n_past_bias", "n_past_vit", "n_past_fwd", "pos_past_msv", "pos_past_bias", "pos_past_vit", "pos_past_fwd"):
+            assert getattr(st_s, f) == getattr(st_r, f), f
+        assert len(res_s) == len(res_r) and st_s.n_past_fwd >= 5
+        for f in res_s.dtype.names:
+            assert np.array_equal(res_s[f], res_r[f], equal_nan=True), f
