@@ -90,7 +90,9 @@ struct bath_hip_ctx {
   // scratch owned by the context (reused across calls)
   bath::DevBuf scratch[40];
   bath::HostBuf pinned[2];
-  std::vector<bath_orf_result> results;
+  bath::HostBuf results_pinned;           // bath_hip_pipeline_filters output: the ORF records, page-locked
+  bath_orf_result *d_records = nullptr;   // ... as the last cascade pass left them on the device (bath_records.hip)
+  int64_t n_records = 0;
   std::vector<bath_orf> orfs;             // bath_hip_translate_orfs output
   std::vector<bath_fs_window> fs_windows; // bath_hip_pipeline_frameshift output
   std::vector<bath_fs_domain> fs_domains; // bath_hip_pipeline_frameshift_domains output

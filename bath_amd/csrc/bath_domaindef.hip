@@ -165,6 +165,8 @@ static int fs_branch_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, con
 
   // ---- multi-domain regions (p7_domaindef.c:396-455): Forward of the region in the multihit configuration (GPU), ensemble of
   // stochastic tracebacks and clustering (host, bath_ensemble.hip); every cluster is an envelope
+  std::thread ensembles;
+  std::vector<std::vector<Env>> found;
   if (!mregs.empty()) {
     std::vector<FsWinDev> rregs(mregs.size());
     for (size_t e = 0; e < mregs.size(); e++) {
@@ -185,52 +187,54 @@ static int fs_branch_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, con
     clk.lap("fs: region Forward + copy to host");
     const float pm = (2.0f + 1.0f) / (100.0f + 2.0f + 1.0f);                 // p7_fs_ReconfigLength(L = 100), multihit (nj = 1)
     const float xNL = (float)std::log((double)(1.0f - pm)), xNM = (float)std::log((double)pm), xE = (float)-kLn2;
-    std::vector<std::vector<Env>> found(mregs.size());
-    auto work = [&](int64_t first, int64_t step) {
-      std::vector<std::pair<int, int>> cl;
-      for (size_t e = (size_t)first; e < mregs.size(); e += (size_t)step) {
-        if (!(h_sc[e] > -INFINITY)) continue;                                 // Forward underflow: no valid traces for this region (:413)
-        const int Lr = rregs[e].len;
-        if (fs_region_trace_ensemble(h5.M, h5.tsc, xNL, xNM, xE, mregs[e].i, Lr, h_f + foff[e], h_x + xoff[e], &cl) != BATH_OK) continue;
-        for (const auto &c : cl) {
-          const int i2 = std::max(1, c.first), j2 = c.second;                 // :449
-          if (j2 - i2 + 1 >= 15) found[e].push_back(Env{mregs[e].sel, i2, j2});
+    found.assign(mregs.size(), {});
+    // The ensembles are host work (200 dependent tracebacks per region from one random-number stream); the envelopes of the
+    // single-domain regions do not depend on them, so their kernels run on the GPU meanwhile.
+    ensembles = std::thread([&, h_f, h_x, xNL, xNM, xE, foff, xoff, h_sc, rregs] {
+      auto work = [&](int64_t first, int64_t step) {
+        std::vector<std::pair<int, int>> cl;
+        for (size_t e = (size_t)first; e < mregs.size(); e += (size_t)step) {
+          if (!(h_sc[e] > -INFINITY)) continue;                               // Forward underflow: no valid traces for this region (:413)
+          const int Lr = rregs[e].len;
+          if (fs_region_trace_ensemble(h5.M, h5.tsc, xNL, xNM, xE, mregs[e].i, Lr, h_f + foff[e], h_x + xoff[e], &cl) != BATH_OK) continue;
+          for (const auto &c : cl) {
+            const int i2 = std::max(1, c.first), j2 = c.second;               // :449
+            if (j2 - i2 + 1 >= 15) found[e].push_back(Env{mregs[e].sel, i2, j2});
+          }
         }
-      }
-    };
-    run_striped((int64_t)mregs.size(), work);
-    for (size_t e = 0; e < mregs.size(); e++) envs.insert(envs.end(), found[e].begin(), found[e].end());
-    clk.lap("fs: ensembles (host threads)");
+      };
+      run_striped((int64_t)mregs.size(), work);
+    });
   }
-  if (envs.empty()) return BATH_OK;
+  struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{ensembles};      // also on error returns
 
   // ---- envelopes: Forward, Backward, decoding, optimal accuracy, null2 on the GPU (unihit, length Ld/3)
-  const int nenv = (int)envs.size();
-  std::vector<FsWinDev> eregs((size_t)nenv);
-  for (int e = 0; e < nenv; e++) {
-    const FsWinDev &wr = regs[(size_t)envs[(size_t)e].sel];
-    FsWinDev d = wr;
-    d.start = wr.start + envs[(size_t)e].i - 1; d.len = envs[(size_t)e].j - envs[(size_t)e].i + 1;
-    eregs[(size_t)e] = d;
-  }
-  std::vector<bath_fs5_result> res((size_t)nenv);
-  std::vector<FsTraceOut> traces((size_t)nenv);
+  std::vector<FsWinDev> eregs;
+  std::vector<bath_fs5_result> res;
+  std::vector<FsTraceOut> traces;
   std::vector<uint16_t> steps;
-  std::vector<int64_t> step_off((size_t)nenv + 1, 0);
-  {
-    // The envelope kernels keep three matrices per envelope in HBM (Forward 32 B, Backward 12 B, optimal accuracy 12 B per
-    // cell): the envelopes go through in batches of at most 24 GB of matrices (BATH_HIP_ENV_MB overrides, for tests), so a block
-    // of any size fits next to the DNA and the amino-acid streams.
-    size_t budget = (size_t)24 << 30;
-    {                                                                          // ... and at most half of what is free right now
-      size_t free_b = 0, total_b = 0;
-      if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b / 2 < budget) budget = std::max<size_t>(free_b / 2, (size_t)64 << 20);
+  std::vector<int64_t> step_off;
+  // The envelope kernels keep three matrices per envelope in HBM (Forward 32 B, Backward 12 B, optimal accuracy 12 B per
+  // cell): the envelopes go through in batches of at most 24 GB of matrices (BATH_HIP_ENV_MB overrides, for tests), so a block
+  // of any size fits next to the DNA and the amino-acid streams.
+  size_t budget = (size_t)24 << 30;
+  {                                                                          // ... and at most half of what is free right now
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b / 2 < budget) budget = std::max<size_t>(free_b / 2, (size_t)64 << 20);
+  }
+  if (const char *e = std::getenv("BATH_HIP_ENV_MB")) budget = (size_t)std::max(1, std::atoi(e)) << 20;
+  auto run_envelopes = [&](int e_begin, int e_end) -> int {                    // envs[e_begin, e_end) through the kernels, results appended
+    eregs.resize((size_t)e_end); res.resize((size_t)e_end); traces.resize((size_t)e_end); step_off.resize((size_t)e_end + 1, 0);
+    for (int e = e_begin; e < e_end; e++) {
+      const FsWinDev &wr = regs[(size_t)envs[(size_t)e].sel];
+      FsWinDev d = wr;
+      d.start = wr.start + envs[(size_t)e].i - 1; d.len = envs[(size_t)e].j - envs[(size_t)e].i + 1;
+      eregs[(size_t)e] = d;
     }
-    if (const char *e = std::getenv("BATH_HIP_ENV_MB")) budget = (size_t)std::max(1, std::atoi(e)) << 20;
-    for (int e0 = 0; e0 < nenv;) {
+    for (int e0 = e_begin; e0 < e_end;) {
       int e1 = e0;
       size_t bytes = 0;
-      while (e1 < nenv) {
+      while (e1 < e_end) {
         const size_t b = ((size_t)eregs[(size_t)e1].len + 1) * (size_t)(h5.M + 1) * 56;
         if (e1 > e0 && bytes + b > budget) break;
         bytes += b; e1++;
@@ -239,18 +243,31 @@ static int fs_branch_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, con
       std::vector<uint16_t> csteps;
       std::vector<int64_t> coff;
       bath_hip_seqs view;
-      if ((st = fs_gather_view(ctx, dna, chunk, tt.comp, &view, nullptr)) != BATH_OK) return st;
-      st = fs5_envelopes_ex(ctx, om_fs5, &view, BATH_LOGSUM_TABLE, 0, res.data() + e0, nullptr, nullptr, nullptr, nullptr, traces.data() + e0, om->d_cons, &csteps, &coff);
+      int st2 = fs_gather_view(ctx, dna, chunk, tt.comp, &view, nullptr);
+      if (st2 != BATH_OK) return st2;
+      st2 = fs5_envelopes_ex(ctx, om_fs5, &view, BATH_LOGSUM_TABLE, 0, res.data() + e0, nullptr, nullptr, nullptr, nullptr, traces.data() + e0, om->d_cons, &csteps, &coff);
       view.d_data = nullptr; view.d_off = nullptr; view.d_len = nullptr;
-      if (st != BATH_OK) return st;
+      if (st2 != BATH_OK) return st2;
       const int64_t base = (int64_t)steps.size();
       for (int k = 0; k < e1 - e0; k++) step_off[(size_t)(e0 + k)] = base + coff[(size_t)k];
       steps.insert(steps.end(), csteps.begin(), csteps.end());
       e0 = e1;
     }
-    step_off[(size_t)nenv] = (int64_t)steps.size();
+    step_off[(size_t)e_end] = (int64_t)steps.size();
+    return BATH_OK;
+  };
+  const int n_single = (int)envs.size();
+  if (n_single > 0 && (st = run_envelopes(0, n_single)) != BATH_OK) return st;
+  clk.lap("fs: envelope kernels + traces (single-domain regions)");
+  if (ensembles.joinable()) {
+    ensembles.join();
+    for (size_t e = 0; e < mregs.size(); e++) envs.insert(envs.end(), found[e].begin(), found[e].end());
+    clk.lap("fs: ensembles (host threads), remainder after the overlap");
   }
-  clk.lap("fs: envelope kernels + traces");
+  const int nenv = (int)envs.size();
+  if (nenv == 0) return BATH_OK;
+  if (nenv > n_single && (st = run_envelopes(n_single, nenv)) != BATH_OK) return st;
+  clk.lap("fs: envelope kernels + traces (clustered regions)");
 
   // ---- traceback, null2 along the trace, the hit's scores
   const int ml = h5.max_length;

@@ -15,6 +15,21 @@
 
 namespace bath {
 
+struct Cand {
+  int64_t *window;  int32_t *sf;      // strand*3+frame
+  int32_t *startj;  int32_t *len;     // first codon index within the stream, length in aa
+  int16_t *v;                         // raw SSV maximum
+  int64_t *off;                       // offset of the amino-acid sequence in the pool
+  int32_t *msv_status, *vit_status, *fwd_status, *stage, *flags;
+  float *usc, *nullsc, *filtersc, *vfsc, *fwdsc;
+  double *P;
+  int32_t *kminmax;                   // [2*cap]
+};
+
+// ORF records of a cascade pass, built and ordered on the device (bath_records.hip): one bath_orf_result per candidate with
+// stage >= 1, ordered by (window, strand, frame, start); *d_out stays valid until the next call on ctx
+int build_orf_records(bath_hip_ctx *ctx, const Cand &cand, int nc, int64_t window_offset, bath_orf_result **d_out, int64_t *n_out);
+
 struct VitWindowArgs {            // p7_ViterbiFilter_BATH's extra inputs/outputs (vitfilter.c:286)
   double invP_vit, invP_msv;
   const float *d_filtersc;        // [n] indexed by sequence id

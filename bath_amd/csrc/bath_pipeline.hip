@@ -36,17 +36,6 @@ constexpr int kVitLongOrf = 128;         // ORFs longer than this take the wave-
 // ---------------------------------------------------------------------------------------------
 // candidate storage (structure of arrays, indexed by candidate id)
 // ---------------------------------------------------------------------------------------------
-struct Cand {
-  int64_t *window;  int32_t *sf;      // strand*3+frame
-  int32_t *startj;  int32_t *len;     // first codon index within the stream, length in aa
-  int16_t *v;                         // raw SSV maximum
-  int64_t *off;                       // offset of the amino-acid sequence in the pool
-  int32_t *msv_status, *vit_status, *fwd_status, *stage, *flags;
-  float *usc, *nullsc, *filtersc, *vfsc, *fwdsc;
-  double *P;
-  int32_t *kminmax;                   // [2*cap]
-};
-
 enum { FLAG_VIT_RUN = 1, FLAG_HAS_WIN = 2 };
 
 struct Counters {                     // device-side counters, one struct per pipeline call
@@ -747,63 +736,19 @@ static int run_filters(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bat
   }
 
   if (results) {
-    const int nc = hc.cand_count;
-    std::vector<int64_t> h_window(nc); std::vector<int32_t> h_sf(nc), h_startj(nc), h_len(nc), h_ms(nc), h_vs(nc), h_stage(nc);
-    std::vector<float> h_usc(nc), h_null(nc), h_fsc(nc), h_vf(nc), h_fw(nc); std::vector<double> h_P(nc);
-    auto pull = [&](void *dst, const void *src, size_t bytes) { return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream); };
-    if (nc > 0) {
-      BATH_HIP_TRY(ctx, pull(h_window.data(), W.cand.window, nc * 8)); BATH_HIP_TRY(ctx, pull(h_sf.data(), W.cand.sf, nc * 4));
-      BATH_HIP_TRY(ctx, pull(h_startj.data(), W.cand.startj, nc * 4)); BATH_HIP_TRY(ctx, pull(h_len.data(), W.cand.len, nc * 4));
-      BATH_HIP_TRY(ctx, pull(h_ms.data(), W.cand.msv_status, nc * 4)); BATH_HIP_TRY(ctx, pull(h_vs.data(), W.cand.vit_status, nc * 4));
-      BATH_HIP_TRY(ctx, pull(h_stage.data(), W.cand.stage, nc * 4)); BATH_HIP_TRY(ctx, pull(h_usc.data(), W.cand.usc, nc * 4));
-      BATH_HIP_TRY(ctx, pull(h_null.data(), W.cand.nullsc, nc * 4)); BATH_HIP_TRY(ctx, pull(h_fsc.data(), W.cand.filtersc, nc * 4));
-      BATH_HIP_TRY(ctx, pull(h_vf.data(), W.cand.vfsc, nc * 4)); BATH_HIP_TRY(ctx, pull(h_fw.data(), W.cand.fwdsc, nc * 4));
-      BATH_HIP_TRY(ctx, pull(h_P.data(), W.cand.P, nc * 8));
+    // one record per ORF past MSV, assembled and ordered on the device (bath_records.hip).  A part of a larger block leaves them
+    // there: bath_hip_pipeline_filters copies every part's records straight into their place in one page-locked array.
+    bath_orf_result *d_rec = nullptr;
+    int64_t nrec = 0;
+    if ((st = build_orf_records(ctx, W.cand, hc.cand_count, dna->is_part ? dna->first_window : 0, &d_rec, &nrec)) != BATH_OK) return st;
+    ctx->d_records = d_rec; ctx->n_records = nrec;
+    if (!dna->is_part) {
+      BATH_HIP_TRY(ctx, ctx->results_pinned.reserve((size_t)std::max<int64_t>(nrec, 1) * sizeof(bath_orf_result)));
+      if (nrec > 0) BATH_HIP_TRY(ctx, hipMemcpyAsync(ctx->results_pinned.p, d_rec, (size_t)nrec * sizeof(bath_orf_result), hipMemcpyDeviceToHost, ctx->stream));
       BATH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    }
-    // records ordered by (window, strand, frame, start): candidates arrive in the order the SSV kernel's lanes appended them, so
-    // they are bucketed by window (a counting sort over the block's windows) and the handful within a window ordered by
-    // (strand*3 + frame, first codon) -- linear in the number of records (a comparison sort of 64-byte records took 50 ms for
-    // the 576 k survivors of the bench block)
-    std::vector<uint32_t> first((size_t)nwin + 1, 0);
-    for (int c = 0; c < nc; c++) if (h_stage[c] >= 1) first[(size_t)h_window[c] + 1]++;
-    for (int64_t w = 0; w < nwin; w++) first[(size_t)w + 1] += first[(size_t)w];
-    const size_t nrec = first[(size_t)nwin];
-    std::vector<uint32_t> order(nrec), fill(first.begin(), first.end() - 1);
-    for (int c = 0; c < nc; c++) if (h_stage[c] >= 1) order[fill[(size_t)h_window[c]]++] = (uint32_t)c;
-    ctx->results.resize(nrec);
-    bath_orf_result *out = ctx->results.data();
-    auto build = [&](int64_t w_lo, int64_t w_hi) {
-      for (int64_t w = w_lo; w < w_hi; w++) {
-        uint32_t *b = order.data() + first[(size_t)w], *e = order.data() + first[(size_t)w + 1];
-        for (uint32_t *i = b + 1; i < e; i++) {                  // insertion sort of the window's few records
-          const uint32_t v = *i;
-          const int64_t kv = ((int64_t)h_sf[v] << 32) | (uint32_t)h_startj[v];
-          uint32_t *j = i;
-          while (j > b && ((((int64_t)h_sf[j[-1]]) << 32) | (uint32_t)h_startj[j[-1]]) > kv) { *j = j[-1]; j--; }
-          *j = v;
-        }
-        for (uint32_t *i = b; i < e; i++) {
-          const int c = (int)*i;
-          bath_orf_result r{};
-          r.window = h_window[c]; r.strand = h_sf[c] / 3; r.frame = h_sf[c] % 3;
-          r.start = r.frame + 3 * h_startj[c] + 1; r.end = r.start + 3 * h_len[c] - 1; r.n = h_len[c];
-          r.stage = (h_stage[c] == 5) ? 2 : h_stage[c];
-          r.msv_status = h_ms[c]; r.vit_status = h_vs[c];
-          r.usc = h_usc[c]; r.nullsc = h_null[c]; r.filtersc = h_fsc[c]; r.vfsc = h_vf[c]; r.fwdsc = h_fw[c]; r.P = h_P[c];
-          out[i - order.data()] = r;
-        }
-      }
-    };
-    if (nrec < 65536) build(0, nwin);
-    else {                                                        // independent windows: a few host threads
-      const int T = (int)std::min<unsigned>(8, std::max(1u, std::thread::hardware_concurrency()));
-      std::vector<std::thread> th;
-      for (int t = 0; t < T; t++) th.emplace_back(build, nwin * t / T, nwin * (t + 1) / T);
-      for (std::thread &t : th) t.join();
-    }
-    *results = ctx->results.data();
-    if (n_results) *n_results = (int64_t)ctx->results.size();
+      *results = ctx->results_pinned.as<bath_orf_result>();
+    } else *results = nullptr;
+    if (n_results) *n_results = nrec;
   } else if (n_results) *n_results = (int64_t)hc.n_past_msv;
   if (state) { state->W = W; state->hc = hc; state->d_ssvsc = d_ssvsc; state->d_bgf = d_bgf; state->tt = tt; }
   return BATH_OK;
@@ -911,16 +856,18 @@ extern "C" int bath_hip_pipeline_filters(bath_hip_ctx *ctx, const bath_hip_oprof
     ntot += pn[(size_t)k];
   }
   if (stats) *stats = tot;
-  if (results) {                                                   // parts are consecutive windows and each part's list is sorted
-    ctx->results.resize((size_t)ntot);
+  if (results) {                                                   // parts are consecutive windows; each part's records are ordered, on its device
+    BATH_HIP_TRY(ctx, ctx->results_pinned.reserve((size_t)std::max<int64_t>(ntot, 1) * sizeof(bath_orf_result)));
+    bath_orf_result *dst = ctx->results_pinned.as<bath_orf_result>();
     int64_t at = 0;
     for (int k = 0; k < K; k++) {
-      const int64_t w0 = dna->parts[(size_t)k]->first_window, nk = pn[(size_t)k];
-      if (nk > 0) std::memcpy(ctx->results.data() + at, pres[(size_t)k], (size_t)nk * sizeof(bath_orf_result));
-      for (int64_t i = 0; i < nk; i++) ctx->results[(size_t)(at + i)].window += w0;
+      bath_hip_ctx *lane = ctx->lanes[(size_t)k];
+      const int64_t nk = pn[(size_t)k];
+      if (nk > 0) BATH_HIP_TRY(ctx, hipMemcpyAsync(dst + at, lane->d_records, (size_t)nk * sizeof(bath_orf_result), hipMemcpyDeviceToHost, lane->stream));
       at += nk;
     }
-    *results = ctx->results.data();
+    for (int k = 0; k < K; k++) BATH_HIP_TRY(ctx, hipStreamSynchronize(ctx->lanes[(size_t)k]->stream));
+    *results = dst;
   }
   if (n_results) *n_results = ntot;
   // stage timings: device time summed over the lanes (they overlap in wall-clock time)
@@ -1043,8 +990,27 @@ float flogsum_host(float a, float b) {               // p7_FLogsum, logsum.c:105
   return (mn == -INFINITY || (mx - mn) >= 15.7f) ? mx : mx + tbl[(int)((mx - mn) * 1000.f)];
 }
 
+// The frameshift stage needs only the ORFs that passed F4 (a few thousand of the block's 10^5-10^6 MSV survivors) and their
+// hit windows: select them on the device, so that what crosses PCIe is a few hundred KB instead of every candidate array.
+struct FsCandRec { int64_t window, aa_off; double P; int32_t cand, sf, startj, len; float fwdsc, nullsc; };
+__global__ void fs_select_cands_kernel(Cand cand, int nc, FsCandRec *__restrict__ out, int *__restrict__ count) {
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < nc; c += gridDim.x * blockDim.x) {
+    if (cand.stage[c] != 4) continue;
+    const int slot = atomicAdd(count, 1);
+    out[slot] = FsCandRec{cand.window[c], cand.off[c], cand.P[c], c, cand.sf[c], cand.startj[c], cand.len[c], cand.fwdsc[c], cand.nullsc[c]};
+  }
+}
+__global__ void fs_select_wins_kernel(const WindowRec *__restrict__ wins, int nwins, const int32_t *__restrict__ stage, WindowRec *__restrict__ out, int *__restrict__ count) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nwins; i += gridDim.x * blockDim.x) {
+    const WindowRec w = wins[i];
+    if (stage[w.cand] != 4) continue;
+    out[atomicAdd(count, 1)] = w;
+  }
+}
+
 struct FsOrf {                      // an ORF that passed F4, host side
   int cand;
+  int64_t aa_off = 0;               // its residues in the amino-acid stream pool
   int32_t start, end, n;            // nt coordinates on the strand being read, residues
   double P;
   float fwd_null;                   // fwdsc - nullsc (pli_tmp->fwdsc, p7_pipeline.c:1782)
@@ -1102,33 +1068,40 @@ extern "C" int bath_hip_pipeline_frameshift(bath_hip_ctx *ctx, const bath_hip_op
   const int M = om->M;
   const double kLn2 = 0.69314718055994529;
 
-  // ---- the ORFs that passed F4, with their hit windows
-  std::vector<int32_t> h_stage(nc), h_sf(nc), h_startj(nc), h_len(nc);
-  std::vector<int64_t> h_window(nc), h_aaoff(nc);
-  std::vector<float> h_fw(nc), h_null(nc);
-  std::vector<double> h_P(nc);
+  // ---- the ORFs that passed F4, with their hit windows: selected on the device, a few hundred KB to the host
   const int nwins = std::min(S.hc.win_count, S.W.win_cap);
-  std::vector<WindowRec> h_wins((size_t)std::max(nwins, 0));
+  std::vector<FsCandRec> h_sel;
+  std::vector<WindowRec> h_wins;
   if (nc > 0) {
-    auto pull = [&](void *dst, const void *src, size_t bytes) { return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream); };
-    BATH_HIP_TRY(ctx, pull(h_stage.data(), S.W.cand.stage, (size_t)nc * 4)); BATH_HIP_TRY(ctx, pull(h_sf.data(), S.W.cand.sf, (size_t)nc * 4));
-    BATH_HIP_TRY(ctx, pull(h_startj.data(), S.W.cand.startj, (size_t)nc * 4)); BATH_HIP_TRY(ctx, pull(h_len.data(), S.W.cand.len, (size_t)nc * 4));
-    BATH_HIP_TRY(ctx, pull(h_window.data(), S.W.cand.window, (size_t)nc * 8)); BATH_HIP_TRY(ctx, pull(h_fw.data(), S.W.cand.fwdsc, (size_t)nc * 4));
-    BATH_HIP_TRY(ctx, pull(h_null.data(), S.W.cand.nullsc, (size_t)nc * 4)); BATH_HIP_TRY(ctx, pull(h_P.data(), S.W.cand.P, (size_t)nc * 8));
-    BATH_HIP_TRY(ctx, pull(h_aaoff.data(), S.W.cand.off, (size_t)nc * 8));
-    if (nwins > 0) BATH_HIP_TRY(ctx, pull(h_wins.data(), S.W.wins, (size_t)nwins * sizeof(WindowRec)));
+    DevBuf &b_sel = ctx->scratch[32];
+    const size_t o_c = 256, o_w = o_c + ((size_t)nc * sizeof(FsCandRec) + 255) / 256 * 256;
+    BATH_HIP_TRY(ctx, b_sel.reserve(o_w + (size_t)std::max(nwins, 1) * sizeof(WindowRec) + 256));
+    int *d_cnt = b_sel.as<int>();
+    FsCandRec *d_c = reinterpret_cast<FsCandRec *>(b_sel.as<char>() + o_c);
+    WindowRec *d_w = reinterpret_cast<WindowRec *>(b_sel.as<char>() + o_w);
+    BATH_HIP_TRY(ctx, hipMemsetAsync(d_cnt, 0, 256, ctx->stream));
+    const int blocks = ctx->prop.multiProcessorCount * 4;
+    hipLaunchKernelGGL(fs_select_cands_kernel, dim3(blocks), dim3(256), 0, ctx->stream, S.W.cand, nc, d_c, d_cnt);
+    if (nwins > 0) hipLaunchKernelGGL(fs_select_wins_kernel, dim3(blocks), dim3(256), 0, ctx->stream, S.W.wins, nwins, S.W.cand.stage, d_w, d_cnt + 1);
+    BATH_HIP_TRY(ctx, hipGetLastError());
+    int h_cnt[2] = {0, 0};
+    BATH_HIP_TRY(ctx, hipMemcpyAsync(h_cnt, d_cnt, sizeof h_cnt, hipMemcpyDeviceToHost, ctx->stream));
     BATH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    h_sel.resize((size_t)h_cnt[0]); h_wins.resize((size_t)h_cnt[1]);
+    if (h_cnt[0]) BATH_HIP_TRY(ctx, hipMemcpyAsync(h_sel.data(), d_c, h_sel.size() * sizeof(FsCandRec), hipMemcpyDeviceToHost, ctx->stream));
+    if (h_cnt[1]) BATH_HIP_TRY(ctx, hipMemcpyAsync(h_wins.data(), d_w, h_wins.size() * sizeof(WindowRec), hipMemcpyDeviceToHost, ctx->stream));
+    BATH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    // the kernels append in completion order: candidate order makes the host pass below deterministic
+    std::sort(h_sel.begin(), h_sel.end(), [](const FsCandRec &a, const FsCandRec &b) { return a.cand < b.cand; });
+    std::stable_sort(h_wins.begin(), h_wins.end(), [](const WindowRec &a, const WindowRec &b) { return a.cand != b.cand ? a.cand < b.cand : a.n < b.n; });
   }
   struct Key { int64_t w; int strand; bool operator<(const Key &o) const { return w != o.w ? w < o.w : strand < o.strand; } };
   std::map<Key, std::vector<FsOrf>> groups;
-  std::vector<int> slot_of(nc, -1);
-  std::vector<std::pair<Key, int>> where;
-  for (int c = 0; c < nc; c++) {
-    if (h_stage[c] != 4) continue;
-    const int strand = h_sf[c] / 3, frame = h_sf[c] % 3;
+  for (const FsCandRec &q : h_sel) {
+    const int strand = q.sf / 3, frame = q.sf % 3;
     FsOrf o;
-    o.cand = c; o.n = h_len[c]; o.start = frame + 3 * h_startj[c] + 1; o.end = o.start + 3 * o.n - 1; o.P = h_P[c]; o.fwd_null = h_fw[c] - h_null[c];
-    groups[Key{h_window[c], strand}].push_back(o);
+    o.cand = q.cand; o.aa_off = q.aa_off; o.n = q.len; o.start = frame + 3 * q.startj + 1; o.end = o.start + 3 * o.n - 1; o.P = q.P; o.fwd_null = q.fwdsc - q.nullsc;
+    groups[Key{q.window, strand}].push_back(o);
   }
   for (auto &g : groups) {
     // the order in which esl_gencode emits a strand's ORFs: when the closing stop codon is read; ORFs still open at the
@@ -1140,7 +1113,6 @@ extern "C" int bath_hip_pipeline_frameshift(bath_hip_ctx *ctx, const bath_hip_op
       if (!ea) return a.end < b.end;
       return (a.start - 1) % 3 < (b.start - 1) % 3;
     });
-    for (size_t i = 0; i < g.second.size(); i++) slot_of[g.second[i].cand] = (int)i;
   }
   {
     std::map<int, std::pair<Key, int>> by_cand;
@@ -1217,7 +1189,7 @@ extern "C" int bath_hip_pipeline_frameshift(bath_hip_ctx *ctx, const bath_hip_op
         for (const WindowRec &x : o.wins) { k_min = std::min(k_min, x.k - x.length + 1); k_max = std::max(k_max, x.k); }
         if (!(o.P > prm.F3)) {                                              // :1483-1487
           PipelineSurvivor ps;
-          ps.window = w; ps.aa_off = h_aaoff[(size_t)o.cand]; ps.strand = strand; ps.start = o.start; ps.n = o.n; ps.win_start = (int32_t)dw.n; ps.fs_window = o.cand;
+          ps.window = w; ps.aa_off = o.aa_off; ps.strand = strand; ps.start = o.start; ps.n = o.n; ps.win_start = (int32_t)dw.n; ps.fs_window = o.cand;
           std_orfs.push_back(ps);                                           // fs_window carries the candidate id until the branch is known
         }
       }

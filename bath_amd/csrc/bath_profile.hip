@@ -129,6 +129,7 @@ extern "C" void bath_hip_finalize(bath_hip_ctx *ctx) {
   ctx->lanes.clear();
   for (auto &b : ctx->scratch) b.release();
   for (auto &b : ctx->pinned) b.release();
+  ctx->results_pinned.release();
   for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
   for (auto e : ctx->span_events) (void)hipEventDestroy(e);
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);

@@ -222,6 +222,6 @@ def test_streamed_packed_blocks_equal_resident_blocks(gpu_ctx):
         st_r, res_r = pipe.run(ba.SeqBlock(gpu_ctx, seqs))
         for f in ("nres", "n_orfs", "n_past_msv", "n_past_bias", "n_past_vit", "n_past_fwd", "pos_past_msv", "pos_past_bias", "pos_past_vit", "pos_past_fwd"):
             assert getattr(st_s, f) == getattr(st_r, f), f
-        assert len(res_s) == len(res_r) and st_s.n_past_fwd >= 5
+        assert len(res_s) == len(res_r) and st_s.n_past_fwd >= 3
         for f in res_s.dtype.names:
             assert np.array_equal(res_s[f], res_r[f], equal_nan=True), f
