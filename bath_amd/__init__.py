@@ -615,7 +615,8 @@ class Pipeline:
         for k, v in overrides.items():
             setattr(self.params, k, v)
 
-    def run(self, dna, want_results=True):
+    def run(self, dna, want_results=True, copy=True):
+        """copy=False: the records are a view of the library's page-locked result array, valid until the next pipeline call."""
         stats = PipelineStats()
         res = C.POINTER(OrfResult)()
         n = C.c_int64(0)
@@ -625,7 +626,9 @@ class Pipeline:
         if want_results:
             if n.value:
                 buf = (OrfResult * n.value).from_address(C.addressof(res.contents))
-                out = np.frombuffer(buf, dtype=ORF_RESULT_DTYPE).copy()
+                out = np.frombuffer(buf, dtype=ORF_RESULT_DTYPE)
+                if copy:
+                    out = out.copy()
             else:
                 out = np.zeros(0, dtype=ORF_RESULT_DTYPE)
         return stats, out

@@ -105,7 +105,7 @@ static int fs_branch_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, con
                              const bath_hip_fsprofile *om_fs5, const bath_hip_seqs *dna, const bath_pipeline_params *prm,
                              double E_report, bath_pipeline_stats *stats,
                              const bath_fs_window **fs_windows, int64_t *n_fs_windows,
-                             const bath_fs_domain **domains, int64_t *n_domains, int64_t *n_skipped_regions) {
+                             const bath_fs_domain **domains, int64_t *n_domains, int64_t *n_skipped_regions, int64_t *std_skipped) {
   if (!ctx || !om || !om_fs3 || !om_fs5 || !dna || !prm || !domains || !n_domains) return BATH_EINVAL;
   if (fsprofile_codon_lengths(om_fs5) != 5) { ctx->set_error("domain definition needs the 5-codon frameshift profile"); return BATH_EINVAL; }
   *domains = nullptr; *n_domains = 0;
@@ -259,6 +259,14 @@ static int fs_branch_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, con
   const int n_single = (int)envs.size();
   if (n_single > 0 && (st = run_envelopes(0, n_single)) != BATH_OK) return st;
   clk.lap("fs: envelope kernels + traces (single-domain regions)");
+  if (std_skipped && ensembles.joinable()) {
+    // ... and so does the standard branch of the other windows (p7_pipeline.c:1479-1510): its kernels and host work go here,
+    // while the ensemble threads are still busy (they read only their own page-locked matrices)
+    int64_t nskip_std = 0;
+    if ((st = std_domains(ctx, om, dna, ctx->fs_std_orfs, ctx->fs_std_pool, st_local.nres, E_report, &nskip_std)) != BATH_OK) return st;
+    *std_skipped = nskip_std;
+    clk.lap("fs: standard-branch domains (during the ensembles)");
+  }
   if (ensembles.joinable()) {
     ensembles.join();
     for (size_t e = 0; e < mregs.size(); e++) envs.insert(envs.end(), found[e].begin(), found[e].end());
@@ -337,13 +345,18 @@ extern "C" int bath_hip_pipeline_frameshift_domains(bath_hip_ctx *ctx, const bat
                                                     const bath_fs_window **fs_windows, int64_t *n_fs_windows,
                                                     const bath_fs_domain **domains, int64_t *n_domains, int64_t *n_skipped_regions) {
   bath_pipeline_stats st_local{};
-  int st = fs_branch_domains(ctx, om, om_fs3, om_fs5, dna, prm, E_report, &st_local, fs_windows, n_fs_windows, domains, n_domains, n_skipped_regions);
+  int64_t std_skipped = -1;                                                   // >= 0: the standard branch already ran, overlapped with the ensembles
+  int64_t fs_skipped = 0;
+  int st = fs_branch_domains(ctx, om, om_fs3, om_fs5, dna, prm, E_report, &st_local, fs_windows, n_fs_windows, domains, n_domains, &fs_skipped, &std_skipped);
   if (st != BATH_OK) return st;
   if (stats) *stats = st_local;
-  int64_t nskip = n_skipped_regions ? *n_skipped_regions : 0;
+  int64_t nskip = fs_skipped;
   StageClock clk;
-  if ((st = std_domains(ctx, om, dna, ctx->fs_std_orfs, ctx->fs_std_pool, st_local.nres, E_report, &nskip)) != BATH_OK) return st;
-  clk.lap("fs: standard-branch domains");
+  if (std_skipped >= 0) nskip += std_skipped;
+  else {
+    if ((st = std_domains(ctx, om, dna, ctx->fs_std_orfs, ctx->fs_std_pool, st_local.nres, E_report, &nskip)) != BATH_OK) return st;
+    clk.lap("fs: standard-branch domains");
+  }
   if (n_skipped_regions) *n_skipped_regions = nskip;
   *domains = ctx->fs_domains.data(); *n_domains = (int64_t)ctx->fs_domains.size();
   return BATH_OK;

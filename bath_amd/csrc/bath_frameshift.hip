@@ -854,6 +854,224 @@ __global__ __launch_bounds__(256) void fs5_oa_kernel(SeqView dna, int M, const f
 }
 
 // ---------------------------------------------------------------------------------------------
+// Posterior decoding AND the optimal-accuracy fill in one walk over the rows (fs5_decode_kernel + fs5_oa_kernel fused).
+// Both go through the rows in ascending order and the OA row needs exactly the posteriors decoding has just produced, so the
+// posteriors are taken from registers instead of being written (32 B/cell) and read back (32 B/cell) by a second kernel: the
+// pass reads Forward (32 B) and Backward (12 B) and writes the posteriors (32 B, for the traceback) and the OA cells (12 B),
+// 88 B/cell instead of 120, and -- what matters more for these latency-bound kernels -- one chain of dependent rows instead of
+// two.  Lanes own C contiguous nodes (the OA recursion's layout); the row's normalising sum is a wave reduction; null2's
+// column sums stay in registers (C <= 4) and are written once per envelope.
+// ---------------------------------------------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(256) void fs5_decode_oa_kernel(SeqView dna, int M, const float *__restrict__ tf, const float *__restrict__ loop_tab, const float *__restrict__ bcksc,
+                                                            float *__restrict__ fwd, const int64_t *__restrict__ fwd_off, float *__restrict__ fx, const int64_t *__restrict__ x_off,
+                                                            const float *__restrict__ bck, const int64_t *__restrict__ bck_off, const float *__restrict__ bx,
+                                                            float *__restrict__ colsum /* [n][(M+1)*8 + 8], zeroed */, float *__restrict__ oa, float *__restrict__ oasc,
+                                                            float ej, float ec, float *__restrict__ ox) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  float *s_dl = reinterpret_cast<float *>(lds);                 // [(M+2)][8] TSCDELTA, same order as tf
+  for (int i = threadIdx.x; i < (M + 2) * 8; i += blockDim.x) s_dl[i] = (tf[i] == -INFINITY) ? 1.17549435e-38f : 1.0f;
+  __syncthreads();
+  constexpr bool REGSUM = (C <= 4);
+  const int lane = threadIdx.x & 63;
+  const int64_t wid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t job = wid; job < dna.n; job += nw) {
+    const int L = dna.len[job];
+    if (L < 5) { if (lane == 0) oasc[job] = -INFINITY; continue; }
+    float *F = fwd + fwd_off[job];
+    float *X = fx + x_off[job];
+    const float *Bk = bck + bck_off[job];
+    const float *Y = bx + x_off[job];
+    float *O = oa + bck_off[job];
+    float *OX = ox ? ox + x_off[job] : nullptr;
+    float *cs = colsum + (size_t)job * ((size_t)(M + 1) * 8 + 8);
+    const float overall = bcksc[job];
+    const float tL = loop_tab[L / 3];
+    // Forward special states of rows i, i-1, i-2, i-3 (read before their rows are overwritten with posteriors)
+    float N0 = X[1], J0 = X[2], C0 = X[4], N1 = 0, N2 = 0, N3 = 0, J1 = 0, J2 = 0, J3 = 0, C1 = 0, C2 = 0, C3 = 0;
+    // row 0: posteriors 0, OA cells -inf
+    for (int k = lane; k < (M + 1) * 8; k += 64) F[k] = 0.f;
+    for (int k = lane; k <= M; k += 64) { O[(size_t)k * 3] = O[(size_t)k * 3 + 1] = O[(size_t)k * 3 + 2] = -INFINITY; }
+    if (lane < 5) X[lane] = 0.f;
+    if (OX && lane == 0) { OX[0] = -INFINITY; OX[1] = 0.f; OX[2] = -INFINITY; OX[3] = 0.f; OX[4] = -INFINITY; }
+    float Mr[5][C], Ir[5][C], Dr[5][C];
+#pragma unroll
+    for (int r = 0; r < 5; r++)
+#pragma unroll
+      for (int c = 0; c < C; c++) Mr[r][c] = Ir[r][c] = Dr[r][c] = -INFINITY;
+    float Bh[5] = {0.f, -INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    float Nh[3] = {0.f, 0.f, 0.f}, Jh[3] = {-INFINITY, -INFINITY, -INFINITY}, Ch[3] = {-INFINITY, -INFINITY, -INFINITY};
+    float cL = -INFINITY, cL1 = -INFINITY, cL2 = -INFINITY;
+    float csum[REGSUM ? C : 1][7];
+    float sN = 0.f, sJ = 0.f, sC = 0.f;
+    if (REGSUM) {
+#pragma unroll
+      for (int c = 0; c < C; c++)
+#pragma unroll
+        for (int q = 0; q < 7; q++) csum[c][q] = 0.f;
+    }
+    for (int i = 1; i <= L; i++) {
+      N3 = N2; N2 = N1; N1 = N0; J3 = J2; J2 = J1; J1 = J0; C3 = C2; C2 = C1; C1 = C0;
+      float *fr = F + (size_t)i * (M + 1) * 8;
+      const float *br = Bk + (size_t)i * (M + 1) * 3;
+      float *orow = O + (size_t)i * (M + 1) * 3;
+      // ---- decoding of row i (generic_decoding_frameshift.c:62-150): exp(F + B - overall), then the row normalised to sum 1
+      float pI[C], pC[C][6];
+      float dloc = 0.f;
+#pragma unroll
+      for (int c = 0; c < C; c++) {
+        const int node = lane * C + c + 1;
+        if (node <= M) {
+          const float4 a = *reinterpret_cast<const float4 *>(fr + (size_t)node * 8);
+          const float4 b = *reinterpret_cast<const float4 *>(fr + (size_t)node * 8 + 4);
+          const float bm = br[(size_t)node * 3 + 2], bi = br[(size_t)node * 3 + 1];
+          pC[c][0] = expf(a.z + bm - overall); pC[c][1] = expf(a.w + bm - overall);
+          pC[c][2] = expf(b.x + bm - overall); pC[c][3] = expf(b.y + bm - overall); pC[c][4] = expf(b.z + bm - overall); pC[c][5] = expf(b.w + bm - overall);
+          dloc += pC[c][0];
+          if (node < M) { pI[c] = expf(a.y + bi - overall); dloc += pI[c]; } else pI[c] = 0.f;
+        } else {
+          pI[c] = 0.f;
+#pragma unroll
+          for (int q = 0; q < 6; q++) pC[c][q] = 0.f;
+        }
+      }
+      N0 = X[i * 5 + 1]; J0 = X[i * 5 + 2]; C0 = X[i * 5 + 4];
+      float pn, pc, pj;
+      if (i > 2) {
+        pn = expf(N3 + Y[i * 5 + 1] + tL - overall);
+        pc = expf(C3 + Y[i * 5 + 4] + tL - overall);
+        pj = expf(J3 + Y[i * 5 + 2] + tL - overall);
+      } else { pn = expf(Y[i * 5 + 1] - overall); pc = 0.f; pj = 0.f; }
+      float denom = wave_sum_f32(dloc) + ((i > 2) ? (pn + pj + pc) : pn);
+      denom = (float)(1.0 / (double)denom);
+      pn *= denom; pc *= denom; pj *= denom;
+      if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) fr[q] = 0.f;
+        X[i * 5 + 0] = 0.f; X[i * 5 + 3] = 0.f; X[i * 5 + 1] = pn; X[i * 5 + 4] = pc; X[i * 5 + 2] = pj;
+        orow[0] = orow[1] = orow[2] = -INFINITY;
+      }
+      sN += pn; sJ += pj; sC += pc;
+#pragma unroll
+      for (int c = 0; c < C; c++) {
+        const int node = lane * C + c + 1;
+        if (node > M) continue;
+        pI[c] *= denom;
+#pragma unroll
+        for (int q = 0; q < 6; q++) pC[c][q] *= denom;
+        *reinterpret_cast<float4 *>(fr + (size_t)node * 8) = make_float4(0.f, pI[c], pC[c][0], pC[c][1]);
+        *reinterpret_cast<float4 *>(fr + (size_t)node * 8 + 4) = make_float4(pC[c][2], pC[c][3], pC[c][4], pC[c][5]);
+        if (REGSUM) {
+          csum[c][0] += pI[c];
+#pragma unroll
+          for (int q = 0; q < 6; q++) csum[c][1 + q] += pC[c][q];
+        } else {
+          if (node < M) cs[(size_t)node * 8 + 1] += pI[c];
+#pragma unroll
+          for (int q = 0; q < 6; q++) cs[(size_t)node * 8 + 2 + q] += pC[c][q];
+        }
+      }
+      // ---- optimal-accuracy row i (generic_optacc_frameshift.c:53-324) on the posteriors in registers
+      float mIn[5], iIn[5], dIn[5];
+#pragma unroll
+      for (int r = 0; r < 5; r++) {
+        mIn[r] = __shfl_up(Mr[r][C - 1], 1, 64); iIn[r] = __shfl_up(Ir[r][C - 1], 1, 64); dIn[r] = __shfl_up(Dr[r][C - 1], 1, 64);
+        if (lane == 0) mIn[r] = iIn[r] = dIn[r] = -INFINITY;
+      }
+      float Mc[C], Ic[C], am[C], bmul[C];
+      float eloc = -INFINITY;
+#pragma unroll
+      for (int c = 0; c < C; c++) {
+        const int node = lane * C + c + 1;
+        if (node > M) { Mc[c] = Ic[c] = -INFINITY; am[c] = -INFINITY; bmul[c] = 1.0f; continue; }
+        const float dMM = s_dl[node * 8 + 0], dIM = s_dl[node * 8 + 1], dDM = s_dl[node * 8 + 2], dBM = s_dl[node * 8 + 3];
+        const float dMD = s_dl[node * 8 + 4], dDD = s_dl[node * 8 + 5], dMI = s_dl[node * 8 + 6], dII = s_dl[node * 8 + 7];
+        float best;
+        if (i == 1) best = dBM * pC[c][1];
+        else {
+          float mx[6];
+          const int cmax = (i >= 5) ? 5 : (i == 2 ? 2 : (i == 4 ? 4 : 3));
+#pragma unroll
+          for (int cl = 1; cl <= 5; cl++) {
+            if (cl > cmax) { mx[cl] = -INFINITY; continue; }
+            const float pv = pC[c][cl];
+            if ((i == 2 && cl == 2) || (i == 4 && cl == 4)) mx[cl] = dBM * (0.0f + pv);
+            else {
+              const int r = cl - 1;
+              const float m1 = (c == 0) ? mIn[r] : Mr[r][c - 1], i1 = (c == 0) ? iIn[r] : Ir[r][c - 1], d1 = (c == 0) ? dIn[r] : Dr[r][c - 1];
+              mx[cl] = fmaxf(dMM * (m1 + pv), fmaxf(dIM * (i1 + pv), fmaxf(dDM * (d1 + pv), dBM * (Bh[r] + pv))));
+            }
+          }
+          if (i == 2) best = fmaxf(mx[1], mx[2]);
+          else if (i < 5) best = fmaxf(fmaxf(mx[1], mx[2]), fmaxf(mx[3], mx[4]));
+          else best = fmaxf(fmaxf(mx[1], mx[2]), fmaxf(fmaxf(mx[3], mx[4]), mx[5]));
+        }
+        Mc[c] = best;
+        Ic[c] = (i >= 3 && node < M) ? fmaxf(dMI * (Mr[2][c] + pI[c]), dII * (Ir[2][c] + pI[c])) : -INFINITY;
+        am[c] = dMD * best;
+        bmul[c] = dDD;
+      }
+      float A = -INFINITY, Bm = 1.0f;
+#pragma unroll
+      for (int c = 0; c < C; c++) { A = fmaxf(am[c], bmul[c] * A); Bm *= bmul[c]; }
+#pragma unroll
+      for (int dlt = 1; dlt < 64; dlt <<= 1) {
+        const float Ap = __shfl_up(A, dlt, 64), Bp = __shfl_up(Bm, dlt, 64);
+        if (lane >= dlt) { A = fmaxf(A, Bm * Ap); Bm *= Bp; }
+      }
+      float din = __shfl_up(A, 1, 64);
+      if (lane == 0) din = -INFINITY;
+      float Dc[C];
+      Dc[0] = din;
+#pragma unroll
+      for (int c = 1; c < C; c++) Dc[c] = fmaxf(am[c - 1], bmul[c - 1] * Dc[c - 1]);
+#pragma unroll
+      for (int c = 0; c < C; c++) {
+        const int node = lane * C + c + 1;
+        if (node > M) { Dc[c] = -INFINITY; continue; }
+        orow[(size_t)node * 3 + 0] = Dc[c]; orow[(size_t)node * 3 + 1] = Ic[c]; orow[(size_t)node * 3 + 2] = Mc[c];
+        eloc = fmaxf(eloc, (node < M) ? Mc[c] : fmaxf(Mc[c], Dc[c]));
+      }
+      float xE = eloc;
+#pragma unroll
+      for (int dlt = 32; dlt >= 1; dlt >>= 1) xE = fmaxf(xE, __shfl_xor(xE, dlt, 64));
+      float nN, nJ, nC;
+      if (i <= 2) { nJ = ej * xE; nC = ec * xE; nN = pn; }
+      else { nJ = fmaxf(Jh[2] + pj, ej * xE); nC = fmaxf(Ch[2] + pc, ec * xE); nN = Nh[2] + pn; }
+      const float nB = fmaxf(nN, nJ);
+      if (OX && lane == 0) { float *r = OX + (size_t)i * 5; r[0] = xE; r[1] = nN; r[2] = nJ; r[3] = nB; r[4] = nC; }
+      Nh[2] = Nh[1]; Nh[1] = Nh[0]; Nh[0] = nN;
+      Jh[2] = Jh[1]; Jh[1] = Jh[0]; Jh[0] = nJ;
+      Ch[2] = Ch[1]; Ch[1] = Ch[0]; Ch[0] = nC;
+      Bh[4] = Bh[3]; Bh[3] = Bh[2]; Bh[2] = Bh[1]; Bh[1] = Bh[0]; Bh[0] = nB;
+      cL2 = cL1; cL1 = cL; cL = nC;
+#pragma unroll
+      for (int c = 0; c < C; c++) {
+#pragma unroll
+        for (int r = 4; r > 0; r--) { Mr[r][c] = Mr[r - 1][c]; Ir[r][c] = Ir[r - 1][c]; Dr[r][c] = Dr[r - 1][c]; }
+        Mr[0][c] = Mc[c]; Ir[0][c] = Ic[c]; Dr[0][c] = Dc[c];
+      }
+    }
+    if (REGSUM) {
+#pragma unroll
+      for (int c = 0; c < C; c++) {
+        const int node = lane * C + c + 1;
+        if (node > M) continue;
+        if (node < M) cs[(size_t)node * 8 + 1] = csum[c][0];
+#pragma unroll
+        for (int q = 0; q < 6; q++) cs[(size_t)node * 8 + 2 + q] = csum[c][1 + q];
+      }
+    }
+    if (lane == 0) {
+      float *xs = cs + (size_t)(M + 1) * 8;
+      xs[1] = sN; xs[2] = sJ; xs[4] = sC;
+      oasc[job] = cL + cL1 + cL2;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // null2 (generic_null2_frameshift.c:70-125) from the column sums: 20 lanes, each runs the reference's serial
 // log-sum over the model for one residue, so the association is the reference's.
 // ---------------------------------------------------------------------------------------------
@@ -1511,6 +1729,16 @@ int bath::fs5_envelopes_ex(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, cons
     })
     if ((st = fs_join(ctx)) != BATH_OK) return st;
     BATH_HIP_TRY(ctx, hipMemsetAsync(b_cs.p, 0, (size_t)n * cs_stride * sizeof(float), ctx->stream));
+    // decoding + optimal-accuracy fill, one walk over the rows (BATH_HIP_FS_UNFUSED=1: the two separate kernels, for A/B runs)
+    static const bool unfused = [] { const char *e = std::getenv("BATH_HIP_FS_UNFUSED"); return e && e[0] == '1'; }();
+    if (!unfused) {
+      if ((st = fs_set_shmem(ctx, fs5_decode_oa_kernel<CC>, oa_shmem)) != BATH_OK) return st;
+      const int s3 = ctx->span_begin("fs5_decode_oa_kernel", ctx->stream, cells5, cells5 * 88.0);   // reads Forward 32 + Backward 12, writes posteriors 32 + OA 12 B/cell
+      hipLaunchKernelGGL((fs5_decode_oa_kernel<CC>), dim3(grid), dim3(256), oa_shmem, ctx->stream, dna->view(), M, om->d_tf, om->d_loop[1], d_bsc, b_f.as<float>(), d_foff,
+                         b_fx.as<float>(), d_xoff, b_b.as<float>(), d_boff, b_bx.as<float>(), b_cs.as<float>(), b_o.as<float>(), d_osc,
+                         1.17549435e-38f /* E->J impossible in unihit mode: TSCDELTA = FLT_MIN */, 1.0f, (oax || trace) ? b_ox.as<float>() : nullptr);
+      ctx->span_end(s3, ctx->stream);
+    } else {
     const int s3 = ctx->span_begin("fs5_decode_kernel", ctx->stream, cells5, cells5 * 76.0);     // reads Forward 32 + Backward 12, rewrites 32 B/cell
     hipLaunchKernelGGL(fs5_decode_kernel, dim3(grid), dim3(256), 0, ctx->stream, dna->view(), M, om->d_loop[1], d_bsc, b_f.as<float>(), d_foff, b_fx.as<float>(), d_xoff,
                        b_b.as<float>(), d_boff, b_bx.as<float>(), b_cs.as<float>());
@@ -1520,6 +1748,7 @@ int bath::fs5_envelopes_ex(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, cons
     hipLaunchKernelGGL((fs5_oa_kernel<CC>), dim3(grid), dim3(256), oa_shmem, ctx->stream, dna->view(), M, om->d_tf, b_f.as<float>(), d_foff, b_fx.as<float>(), d_xoff, b_o.as<float>(), d_boff, d_osc,
                        1.17549435e-38f /* E->J impossible in unihit mode: TSCDELTA = FLT_MIN */, 1.0f, (oax || trace) ? b_ox.as<float>() : nullptr);
     ctx->span_end(s4, ctx->stream);
+    }
   })
   const int s5 = ctx->span_begin("fs5_null2_kernel", ctx->stream, (double)n * M, (double)n * M * 32.0);
   hipLaunchKernelGGL(fs5_null2_kernel, dim3((unsigned)n), dim3(32), 0, ctx->stream, n, dna->d_len, M, om->pitch, om->d_rsc + (size_t)om->maxcodons * om->pitch, om->d_logsum,
@@ -1602,10 +1831,10 @@ int bath::fs5_region_forward(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, co
   }))
   BATH_HIP_TRY(ctx, hipGetLastError());
   sc->resize((size_t)n);
-  BATH_HIP_TRY(ctx, ctx->pinned[0].reserve((size_t)foff[(size_t)n] * 4 + 64)); BATH_HIP_TRY(ctx, ctx->pinned[1].reserve((size_t)xoff[(size_t)n] * 4 + 64));
-  *fwd = ctx->pinned[0].as<float>(); *xmx = ctx->pinned[1].as<float>();      // page-locked: the matrices are a few MB per region
-  BATH_HIP_TRY(ctx, hipMemcpyAsync(ctx->pinned[0].p, b_f.p, (size_t)foff[(size_t)n] * 4, hipMemcpyDeviceToHost, ctx->stream));
-  BATH_HIP_TRY(ctx, hipMemcpyAsync(ctx->pinned[1].p, b_fx.p, (size_t)xoff[(size_t)n] * 4, hipMemcpyDeviceToHost, ctx->stream));
+  BATH_HIP_TRY(ctx, ctx->pinned[2].reserve((size_t)foff[(size_t)n] * 4 + 64)); BATH_HIP_TRY(ctx, ctx->pinned[3].reserve((size_t)xoff[(size_t)n] * 4 + 64));
+  *fwd = ctx->pinned[2].as<float>(); *xmx = ctx->pinned[3].as<float>();      // page-locked: the matrices are a few MB per region
+  BATH_HIP_TRY(ctx, hipMemcpyAsync(ctx->pinned[2].p, b_f.p, (size_t)foff[(size_t)n] * 4, hipMemcpyDeviceToHost, ctx->stream));
+  BATH_HIP_TRY(ctx, hipMemcpyAsync(ctx->pinned[3].p, b_fx.p, (size_t)xoff[(size_t)n] * 4, hipMemcpyDeviceToHost, ctx->stream));
   BATH_HIP_TRY(ctx, hipMemcpyAsync(sc->data(), b_sc.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
   BATH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return BATH_OK;
