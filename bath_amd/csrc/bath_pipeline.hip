@@ -775,11 +775,14 @@ static int ensure_parts(bath_hip_ctx *ctx, const bath_hip_seqs *dna, int K) {
   dna->parts.clear();
   int64_t w0 = 0;
   for (int k = 0; k < K; k++) {
-    // cut where the running residue count passes (k+1)/K of the total
+    // cut where the running residue count passes the part's share of the total.  With two parts the shares are unequal: the
+    // second part's tail (decision kernels, Viterbi, Forward on its survivors) is the only work nothing else overlaps, so the
+    // second part is the smaller one (BATH_HIP_LANE_SPLIT = share of the first part, tools/ab_probe.py)
+    static const double split2 = [] { const char *e = std::getenv("BATH_HIP_LANE_SPLIT"); const double v = e ? std::atof(e) : 0.0; return (v > 0.05 && v < 0.95) ? v : 0.5; }();
     int64_t w1 = w0;
     if (k == K - 1) w1 = dna->n;
     else {
-      const int64_t target = dna->total_aligned / K * (k + 1);
+      const int64_t target = (K == 2) ? (int64_t)((double)dna->total_aligned * split2) : dna->total_aligned / K * (k + 1);
       w1 = std::lower_bound(dna->h_off.begin() + w0, dna->h_off.end(), target) - dna->h_off.begin();
       w1 = std::max(w1, std::min(w0 + 1, dna->n));
     }
