@@ -674,8 +674,10 @@ class Pipeline:
             out.append(x)
         return out
 
-    def run_frameshift_domains(self, om_fs3, om_fs5, dna, E_report=10.0):
-        """bathsearch --fs through domain definition: (stats, [FsWindow], [FsDomain], multi-domain regions skipped)."""
+    def run_frameshift_domains(self, om_fs3, om_fs5, dna, E_report=10.0, arrays=False):
+        """bathsearch --fs through domain definition: (stats, [FsWindow], [FsDomain], multi-domain regions skipped).
+        arrays=True: the windows and domains as numpy record arrays viewing the library's own memory (valid until the next
+        pipeline call), without the per-record Python objects and CIGAR strings."""
         stats = PipelineStats()
         fw = C.POINTER(FsWindow)(); nfw = C.c_int64(0)
         dm = C.POINTER(FsDomain)(); ndm = C.c_int64(0)
@@ -683,6 +685,12 @@ class Pipeline:
         self.ctx._check(lib().bath_hip_pipeline_frameshift_domains(self.ctx._h, self.om._h, om_fs3._h, om_fs5._h, dna._h, C.byref(self.params), E_report,
                                                                    C.byref(stats), C.byref(fw), C.byref(nfw), C.byref(dm), C.byref(ndm), C.byref(nskip)),
                         "pipeline_frameshift_domains")
+        if arrays:
+            def view(ptr, n, T):
+                if n == 0:
+                    return np.zeros(0, dtype=np.dtype(T))
+                return np.frombuffer((T * n).from_address(C.addressof(ptr.contents)), dtype=np.dtype(T))
+            return stats, view(fw, nfw.value, FsWindow), view(dm, ndm.value, FsDomain), nskip.value
 
         def copies(ptr, n, T):
             out = []

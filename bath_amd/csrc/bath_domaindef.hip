@@ -117,7 +117,9 @@ static int fs_branch_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, con
   const bath_fs_window *fw = nullptr;
   int64_t nfw = 0;
   StageClock clk;
+  ctx->fs_want_regions = true;
   int st = bath_hip_pipeline_frameshift(ctx, om, om_fs3, dna, prm, &st_local, nullptr, nullptr, &fw, &nfw);
+  ctx->fs_want_regions = false;
   if (st != BATH_OK) return st;
   clk.lap("fs: cascade + windows + decision");
   if (stats) *stats = st_local;
@@ -143,14 +145,16 @@ static int fs_branch_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, con
   std::vector<int32_t> regions((size_t)nsel * RS, 0);
   const float pmove = (2.0f + 1.0f) / (100.0f + 2.0f + 1.0f);                 // p7_fs_ReconfigLength(L = 100, nj = 1), modelconfig.c:767-770
   const float loop = (float)std::log((double)(1.0f - pmove));
-  {
+  if (ctx->fs_regions_all.size() == (size_t)nfw * (size_t)RS) {                // the decision stage already ran them for every window
+    for (int q = 0; q < nsel; q++) std::memcpy(&regions[(size_t)q * RS], &ctx->fs_regions_all[(size_t)sel[(size_t)q] * RS], sizeof(int32_t) * (size_t)RS);
+  } else {
     bath_hip_seqs view;
     if ((st = fs_gather_view(ctx, dna, regs, tt.comp, &view, nullptr)) != BATH_OK) return st;
     st = fs3_regions(ctx, om_fs3, &view, loop, regions.data());               // parsers, domain decoding, region heuristics: all on the device
     view.d_data = nullptr; view.d_off = nullptr; view.d_len = nullptr;
     if (st != BATH_OK) return st;
+    clk.lap("fs: parsers + regions");
   }
-  clk.lap("fs: parsers + regions");
   struct Env { int sel, i, j; };
   std::vector<Env> envs, mregs;
   for (int q = 0; q < nsel; q++) {

@@ -1458,6 +1458,7 @@ static int fs3_parser(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, const bat
   const float tE = (float)-0.69314718055994529;
   [[maybe_unused]] const int grid = fs_grid(ctx, n);
   const int grid_dp = fs_grid_dp(ctx, n);
+  const int sp = ctx->span_begin(backward ? "fs_bwd_kernel<3>" : "fs3_fwd_kernel", ctx->stream, (double)dna->total * om->M, (double)dna->total * (xmx ? 21.0 : 1.0));
   BATH_FS_SWITCH(Cv, BATH_FS_MODE(logsum_mode, {
     if (!backward) {
       if ((st = fs_set_shmem(ctx, fs3_fwd_kernel<CC, MD>, shmem)) != BATH_OK) return st;
@@ -1467,6 +1468,7 @@ static int fs3_parser(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, const bat
       hipLaunchKernelGGL((fs_bwd_kernel<CC, 3, MD>), dim3(grid_dp), dim3(kFsBlock), shmem, ctx->stream, dna->view(), fsdev(om), om->d_loop[0], om->d_move[0], tE, tE, b_sc.as<float>(), (float *)nullptr, (const int64_t *)nullptr, d_x, b_off.as<int64_t>());
     }
   }))
+  ctx->span_end(sp, ctx->stream);
   BATH_HIP_TRY(ctx, hipGetLastError());
   BATH_HIP_TRY(ctx, hipMemcpyAsync(sc, b_sc.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
   if (xmx) BATH_HIP_TRY(ctx, hipMemcpyAsync(xmx, d_x, (size_t)xmx_off[n] * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
@@ -1574,7 +1576,7 @@ static int fs_join(bath_hip_ctx *ctx) {
   return BATH_OK;
 }
 
-int fs3_regions(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, const bath_hip_seqs *dna, float loop, int32_t *regions_out) {
+int fs3_regions(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, const bath_hip_seqs *dna, float loop, int32_t *regions_out, float *fwd_sc_out) {
   if (!ctx || !om || !dna || om->codon_lengths != 3) { if (ctx) ctx->set_error("fs3 parser needs a 3-codon profile"); return BATH_EINVAL; }
   BATH_HIP_TRY(ctx, hipSetDevice(ctx->device));
   const int64_t n = dna->n;
@@ -1618,6 +1620,7 @@ int fs3_regions(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, const bath_hip_
   ctx->span_end(s3, ctx->stream);
   BATH_HIP_TRY(ctx, hipGetLastError());
   BATH_HIP_TRY(ctx, hipMemcpyAsync(regions_out, b_reg.p, reg_ints * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  if (fwd_sc_out) BATH_HIP_TRY(ctx, hipMemcpyAsync(fwd_sc_out, b_sc.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
   BATH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return BATH_OK;
 }

@@ -402,12 +402,12 @@ def fs_leg(ba, synth, ctx, hmm, om, args):
     om3 = ba.FSOProfile(ctx, ba.FSProfile(hmm, 3, ncbi_table=hmm.ct))
     om5 = ba.FSOProfile(ctx, ba.FSProfile(hmm, 5, ncbi_table=hmm.ct))
     pipe = ba.Pipeline(ctx, om, fs_pipe=True, ncbi_table=hmm.ct)
-    pipe.run_frameshift_domains(om3, om5, dna)
+    pipe.run_frameshift_domains(om3, om5, dna, arrays=True)
     steps = 3
     kt = {}
     t0 = time.perf_counter()
     for _ in range(steps):
-        stats, fw, dm, nskip = pipe.run_frameshift_domains(om3, om5, dna)
+        stats, fw, dm, nskip = pipe.run_frameshift_domains(om3, om5, dna, arrays=True)     # record arrays: views of the library's memory
         for name, (ms, nl, cells, nbytes) in pipe.kernel_times().items():
             k = kt.setdefault(name, {"ms": 0.0, "launches": 0, "cells": 0.0, "bytes": 0.0})
             k["ms"] += ms / steps; k["launches"] += nl / steps; k["cells"] += cells / steps; k["bytes"] += nbytes / steps
@@ -420,26 +420,27 @@ def fs_leg(ba, synth, ctx, hmm, om, args):
     env_ms = sum(kt[n]["ms"] for n in env)
     env_bytes = sum(kt[n]["bytes"] for n in env)
     env_cells = kt[env[0]]["cells"] if env else 0.0
+    summary = {"fs_windows": int(len(fw)), "fs_window_nt": int(fw["length"].sum()), "fs_branch": int((fw["branch"] == 1).sum()),
+               "std_branch": int((fw["branch"] == 2).sum()), "domains": int(len(dm)), "reported": int(dm["reported"].sum()),
+               "envelope_nt": int((np.abs(dm["jenv"].astype(np.int64) - dm["ienv"]) + 1).sum()), "clustered_regions": int(nskip),
+               "shifted_codons_found": int(dm["n_shifted_codons"].sum())}
+    keys = ("window", "strand", "ienv", "jenv", "iali", "jali", "ihmm", "jhmm", "n_shifted_codons")
+    fast = {tuple(int(r[k]) for k in keys) for r in dm}
     # the same pass with the sums along the model in the reference's serial order (bit-identical scores): the parity mode
     ctx.set_fs_strict(True)
-    pipe.run_frameshift_domains(om3, om5, dna)
+    pipe.run_frameshift_domains(om3, om5, dna, arrays=True)
     t0 = time.perf_counter()
-    s_stats, s_fw, s_dm, _ = pipe.run_frameshift_domains(om3, om5, dna)
+    s_stats, s_fw, s_dm, _ = pipe.run_frameshift_domains(om3, om5, dna, arrays=True)
     dts = time.perf_counter() - t0
+    strict = {tuple(int(r[k]) for k in keys) for r in s_dm}
+    n_strict = int(len(s_dm))
     ctx.set_fs_strict(False)
-
-    def key(d):
-        return (d.window, d.strand, d.ienv, d.jenv, d.iali, d.jali, d.ihmm, d.jhmm, d.n_shifted_codons)
-    same = len(set(map(key, dm)) & set(map(key, s_dm)))
     return {
         "workload": "Caudal_act.bhmm (M=%d) --fs vs %d x %d nt windows, 1%% planted domains with indels (P(+-1 nt) = 0.01, P(+-2) = 0.005 per codon) "
                     "and in-frame stops (0.002), both strands: cascade (F4) -> DNA windows -> 3-codon parsers -> regions -> 5-codon "
                     "Forward/Backward/decoding/optimal accuracy/null2 -> traceback -> hits" % (hmm.M, args.fs_windows, args.length),
         "ms_per_pass": dt * 1e3, "residues_per_s": stats.nres / dt, "steps": steps,
-        "fs_windows": len(fw), "fs_window_nt": int(sum(w.length for w in fw)), "fs_branch": int(sum(w.branch == 1 for w in fw)),
-        "std_branch": int(sum(w.branch == 2 for w in fw)), "domains": len(dm), "reported": int(sum(d.reported for d in dm)),
-        "envelope_nt": int(sum(abs(d.jenv - d.ienv) + 1 for d in dm)), "clustered_regions": int(nskip),
-        "shifted_codons_found": int(sum(d.n_shifted_codons for d in dm)),
+        **summary,
         "kernels": kt,
         "roofline": {"bound": "hbm", "kernels": env, "cells": env_cells, "bytes_per_cell": env_bytes / env_cells if env_cells else None,
                      "ms": env_ms, "achieved": env_bytes / (env_ms * 1e-3) / 1e9 if env_ms > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -449,7 +450,7 @@ def fs_leg(ba, synth, ctx, hmm, om, args):
                              "chain per row times the rows of the longest envelope (profiles/r02_fs_pmc.json: 3-16 % VALU busy, 1-13 % LDS busy), not by HBM"},
         "strict": {"what": "bath_hip_set_fs_strict(1): log-sums along the model in the reference's serial order, scores bit-identical to "
                            "generic_fwdback_frameshift.c (tests/test_frameshift_gpu.py); the default sums them with wavefront scans",
-                   "ms_per_pass": dts * 1e3, "domains": len(s_dm), "domains_identical_to_default_mode": same},
+                   "ms_per_pass": dts * 1e3, "domains": n_strict, "domains_identical_to_default_mode": len(fast & strict)},
     }
 
 
