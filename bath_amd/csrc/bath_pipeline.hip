@@ -1225,11 +1225,13 @@ extern "C" int bath_hip_pipeline_frameshift(bath_hip_ctx *ctx, const bath_hip_op
     BATH_HIP_TRY(ctx, hipMemcpyAsync(h_bias.data(), b_out.p, h_bias.size() * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     std::vector<float> h_fsc((size_t)nw);
     ctx->fs_regions_all.clear();
-    if (ctx->fs_want_regions) {
+    if (ctx->fs_want_regions && nw <= (int64_t)ctx->prop.multiProcessorCount * 16) {
       // The domain stage follows: its Backward parser, domain decoding and region heuristics run here, for every window,
       // next to the Forward parser whose score decides the branch.  These kernels are bound by the row chain of the longest
-      // window, not by the number of windows, so the windows that will take the standard branch cost nothing extra, and the
-      // windows that take the frameshift branch have their regions before the decision is even made.
+      // window as long as every window has a wave of its own (16 waves per CU), so up to that many windows the ones that will
+      // take the standard branch cost nothing extra and the frameshift-branch windows have their regions before the decision
+      // is made.  Beyond it the kernels take a second round of windows and the Backward parser of the windows that turn out
+      // not to need it costs more than it saves (bench block, 7.6 k windows: 49.6 ms instead of 35 + 11.6 ms).
       ctx->fs_regions_all.assign((size_t)nw * (size_t)(1 + 3 * fs_max_regions()), 0);
       const float pmove = (2.0f + 1.0f) / (100.0f + 2.0f + 1.0f);              // p7_fs_ReconfigLength(L = 100, nj = 1): the saved length (p7_domaindef.c:318)
       st = fs3_regions(ctx, om_fs3, &view, (float)std::log((double)(1.0f - pmove)), ctx->fs_regions_all.data(), h_fsc.data());
