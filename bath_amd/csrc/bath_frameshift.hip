@@ -77,6 +77,17 @@ __device__ __forceinline__ float wave_logsum(float v, const float *tbl) {
 
 __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
 
+// Work distribution of the wave-per-window kernels.  Their duration is the longest chain of rows any one wave walks, so the
+// windows are handed out longest first from a shared counter (<order> lists them by decreasing length): a wave that drew a
+// long window early draws fewer later, instead of every wave taking windows wid, wid + nwaves, ... whatever their lengths.
+struct FsJobs { const int32_t *order; unsigned *counter; };
+__device__ __forceinline__ int64_t fs_next_job(const FsJobs &q, int64_t n, int lane) {
+  unsigned j = 0;
+  if (lane == 0) j = atomicAdd(q.counter, 1u);
+  j = (unsigned)__shfl((int)j, 0, 64);
+  return (int64_t)j < n ? (int64_t)q.order[j] : (int64_t)-1;
+}
+
 // D(i,k) = LS(M(i,k-1)+tMD(k-1), D(i,k-1)+tDD(k-1)) for this lane's nodes, chained across lanes.
 // md[c] = M(i,node_c)+tMD(node_c) and dd[c] = tDD(node_c) describe the step OUT of node c.
 // Returns D at the lane's nodes in Dout[]; the step into the lane's first node comes from the previous lane.
@@ -180,7 +191,7 @@ __device__ __forceinline__ float bwd_dnext_strict(F &&dstep, int lane, int M) {
 // ---------------------------------------------------------------------------------------------
 template <int C, int MODE>
 __global__ __launch_bounds__(kFsBlock) void fs3_fwd_kernel(SeqView dna, FsDev p, const float *__restrict__ loop_tab, const float *__restrict__ move_tab,
-                                                      float tEL, float tEM, float *__restrict__ sc, float *__restrict__ xmx, const int64_t *__restrict__ xmx_off) {
+                                                      float tEL, float tEM, float *__restrict__ sc, float *__restrict__ xmx, const int64_t *__restrict__ xmx_off, FsJobs jobs) {
   constexpr bool EXACT = (MODE == 1), STRICT = (MODE == 2);   // 0: table + scans, 1: exact log-sums, 2: table in the reference's serial order
   extern __shared__ __attribute__((aligned(16))) char lds[];
   float *s_tbl = reinterpret_cast<float *>(lds);
@@ -190,10 +201,8 @@ __global__ __launch_bounds__(kFsBlock) void fs3_fwd_kernel(SeqView dna, FsDev p,
   __syncthreads();
   const int M = p.M;
   const int lane = threadIdx.x & 63;
-  const int64_t wid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
 #define LS(a, b) flogsum<EXACT>((a), (b), s_tbl)
-  for (int64_t job = wid; job < dna.n; job += nw) {
+  for (int64_t job = fs_next_job(jobs, dna.n, lane); job >= 0; job = fs_next_job(jobs, dna.n, lane)) {
     const int L = dna.len[job];
     const uint8_t *d = dna.data + dna.off[job];
     float *xo = xmx ? xmx + xmx_off[job] : nullptr;
@@ -303,7 +312,7 @@ template <int C, int MODE>
 __global__ __launch_bounds__(kFsBlock) void fs5_fwd_kernel(SeqView dna, FsDev p, const float *__restrict__ loop_tab, const float *__restrict__ move_tab,
                                                       float tEL, float tEM, int c5_compat, float *__restrict__ sc,
                                                       float *__restrict__ fwd, const int64_t *__restrict__ fwd_off, float *__restrict__ xmx, const int64_t *__restrict__ xmx_off,
-                                                      int cfg_len /* >= 0: the amino length the model is configured for, instead of L/3 */) {
+                                                      int cfg_len /* >= 0: the amino length the model is configured for, instead of L/3 */, FsJobs jobs) {
   constexpr bool EXACT = (MODE == 1), STRICT = (MODE == 2);   // 0: table + scans, 1: exact log-sums, 2: table in the reference's serial order
   extern __shared__ __attribute__((aligned(16))) char lds[];
   float *s_tbl = reinterpret_cast<float *>(lds);
@@ -313,10 +322,8 @@ __global__ __launch_bounds__(kFsBlock) void fs5_fwd_kernel(SeqView dna, FsDev p,
   __syncthreads();
   const int M = p.M;
   const int lane = threadIdx.x & 63;
-  const int64_t wid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
 #define LS(a, b) flogsum<EXACT>((a), (b), s_tbl)
-  for (int64_t job = wid; job < dna.n; job += nw) {
+  for (int64_t job = fs_next_job(jobs, dna.n, lane); job >= 0; job = fs_next_job(jobs, dna.n, lane)) {
     const int L = dna.len[job];
     const uint8_t *d = dna.data + dna.off[job];
     float *fo = fwd + fwd_off[job];
@@ -437,7 +444,7 @@ __global__ __launch_bounds__(kFsBlock) void fs5_fwd_kernel(SeqView dna, FsDev p,
 template <int C, int NCOD, int MODE>
 __global__ __launch_bounds__(kFsBlock) void fs_bwd_kernel(SeqView dna, FsDev p, const float *__restrict__ loop_tab, const float *__restrict__ move_tab,
                                                      float tEL, float tEM, float *__restrict__ sc,
-                                                     float *__restrict__ bck, const int64_t *__restrict__ bck_off, float *__restrict__ xmx, const int64_t *__restrict__ xmx_off) {
+                                                     float *__restrict__ bck, const int64_t *__restrict__ bck_off, float *__restrict__ xmx, const int64_t *__restrict__ xmx_off, FsJobs jobs) {
   constexpr bool EXACT = (MODE == 1), STRICT = (MODE == 2);   // 0: table + scans, 1: exact log-sums, 2: table in the reference's serial order
   extern __shared__ __attribute__((aligned(16))) char lds[];
   float *s_tbl = reinterpret_cast<float *>(lds);
@@ -450,10 +457,8 @@ __global__ __launch_bounds__(kFsBlock) void fs_bwd_kernel(SeqView dna, FsDev p, 
   constexpr int NR = 5;                             // rows i+1..i+5 of M kept in registers
   const int M = p.M;
   const int lane = threadIdx.x & 63;
-  const int64_t wid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
 #define LS(a, b) flogsum<EXACT>((a), (b), s_tbl)
-  for (int64_t job = wid; job < dna.n; job += nw) {
+  for (int64_t job = fs_next_job(jobs, dna.n, lane); job >= 0; job = fs_next_job(jobs, dna.n, lane)) {
     const int L = dna.len[job];
     const uint8_t *d = dna.data + dna.off[job];
     float *bo = bck ? bck + bck_off[job] : nullptr;
@@ -867,16 +872,14 @@ __global__ __launch_bounds__(256) void fs5_decode_oa_kernel(SeqView dna, int M, 
                                                             float *__restrict__ fwd, const int64_t *__restrict__ fwd_off, float *__restrict__ fx, const int64_t *__restrict__ x_off,
                                                             const float *__restrict__ bck, const int64_t *__restrict__ bck_off, const float *__restrict__ bx,
                                                             float *__restrict__ colsum /* [n][(M+1)*8 + 8], zeroed */, float *__restrict__ oa, float *__restrict__ oasc,
-                                                            float ej, float ec, float *__restrict__ ox) {
+                                                            float ej, float ec, float *__restrict__ ox, FsJobs jobs) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   float *s_dl = reinterpret_cast<float *>(lds);                 // [(M+2)][8] TSCDELTA, same order as tf
   for (int i = threadIdx.x; i < (M + 2) * 8; i += blockDim.x) s_dl[i] = (tf[i] == -INFINITY) ? 1.17549435e-38f : 1.0f;
   __syncthreads();
   constexpr bool REGSUM = (C <= 4);
   const int lane = threadIdx.x & 63;
-  const int64_t wid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  for (int64_t job = wid; job < dna.n; job += nw) {
+  for (int64_t job = fs_next_job(jobs, dna.n, lane); job >= 0; job = fs_next_job(jobs, dna.n, lane)) {
     const int L = dna.len[job];
     if (L < 5) { if (lane == 0) oasc[job] = -INFINITY; continue; }
     float *F = fwd + fwd_off[job];
@@ -1435,6 +1438,22 @@ static int upload_offsets(bath_hip_ctx *ctx, DevBuf &buf, const int64_t *off, in
   return BATH_OK;
 }
 
+// the windows of <dna> by decreasing length and <k> zeroed job counters (one per kernel launch that will draw from the list),
+// queued on ctx->stream; jobs[i] is what launch i passes to its kernel
+static int fs_schedule(bath_hip_ctx *ctx, const bath_hip_seqs *dna, int k, FsJobs *jobs) {
+  const int64_t n = dna->n;
+  std::vector<int32_t> order((size_t)n);
+  for (int64_t i = 0; i < n; i++) order[(size_t)i] = (int32_t)i;
+  std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return dna->h_len[(size_t)a] > dna->h_len[(size_t)b]; });
+  DevBuf &b = ctx->scratch[36];
+  BATH_HIP_TRY(ctx, b.reserve(256 + (size_t)n * sizeof(int32_t) + 64));
+  BATH_HIP_TRY(ctx, hipMemsetAsync(b.p, 0, 256, ctx->stream));
+  BATH_HIP_TRY(ctx, hipMemcpyAsync(b.as<char>() + 256, order.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+  BATH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));            // <order> is a local
+  for (int i = 0; i < k; i++) jobs[i] = FsJobs{reinterpret_cast<const int32_t *>(b.as<char>() + 256), b.as<unsigned>() + i};
+  return BATH_OK;
+}
+
 }  // namespace bath
 
 static int fs3_parser(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, const bath_hip_seqs *dna, int logsum_mode, float *sc, float *xmx,
@@ -1458,14 +1477,16 @@ static int fs3_parser(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, const bat
   const float tE = (float)-0.69314718055994529;
   [[maybe_unused]] const int grid = fs_grid(ctx, n);
   const int grid_dp = fs_grid_dp(ctx, n);
+  FsJobs jq[1];
+  if ((st = fs_schedule(ctx, dna, 1, jq)) != BATH_OK) return st;
   const int sp = ctx->span_begin(backward ? "fs_bwd_kernel<3>" : "fs3_fwd_kernel", ctx->stream, (double)dna->total * om->M, (double)dna->total * (xmx ? 21.0 : 1.0));
   BATH_FS_SWITCH(Cv, BATH_FS_MODE(logsum_mode, {
     if (!backward) {
       if ((st = fs_set_shmem(ctx, fs3_fwd_kernel<CC, MD>, shmem)) != BATH_OK) return st;
-      hipLaunchKernelGGL((fs3_fwd_kernel<CC, MD>), dim3(grid_dp), dim3(kFsBlock), shmem, ctx->stream, dna->view(), fsdev(om), om->d_loop[0], om->d_move[0], tE, tE, b_sc.as<float>(), d_x, b_off.as<int64_t>());
+      hipLaunchKernelGGL((fs3_fwd_kernel<CC, MD>), dim3(grid_dp), dim3(kFsBlock), shmem, ctx->stream, dna->view(), fsdev(om), om->d_loop[0], om->d_move[0], tE, tE, b_sc.as<float>(), d_x, b_off.as<int64_t>(), jq[0]);
     } else {
       if ((st = fs_set_shmem(ctx, fs_bwd_kernel<CC, 3, MD>, shmem)) != BATH_OK) return st;
-      hipLaunchKernelGGL((fs_bwd_kernel<CC, 3, MD>), dim3(grid_dp), dim3(kFsBlock), shmem, ctx->stream, dna->view(), fsdev(om), om->d_loop[0], om->d_move[0], tE, tE, b_sc.as<float>(), (float *)nullptr, (const int64_t *)nullptr, d_x, b_off.as<int64_t>());
+      hipLaunchKernelGGL((fs_bwd_kernel<CC, 3, MD>), dim3(grid_dp), dim3(kFsBlock), shmem, ctx->stream, dna->view(), fsdev(om), om->d_loop[0], om->d_move[0], tE, tE, b_sc.as<float>(), (float *)nullptr, (const int64_t *)nullptr, d_x, b_off.as<int64_t>(), jq[0]);
     }
   }))
   ctx->span_end(sp, ctx->stream);
@@ -1599,6 +1620,8 @@ int fs3_regions(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, const bath_hip_
   [[maybe_unused]] const int grid = fs_grid(ctx, n);
   const int grid_dp = fs_grid_dp(ctx, n);
   BATH_HIP_TRY(ctx, b_sc.reserve((size_t)n * 2 * sizeof(float)));
+  FsJobs jq[2];
+  if ((st = fs_schedule(ctx, dna, 2, jq)) != BATH_OK) return st;
   if ((st = fs_fork(ctx)) != BATH_OK) return st;
   const int mode = ctx->fs_strict ? BATH_LOGSUM_TABLE_SERIAL : BATH_LOGSUM_TABLE;
   const double cells3 = (double)(xoff[(size_t)n] / 5) * om->M;                // rows x nodes; algorithmic HBM bytes: 1 B/nt in + 20 B/row out
@@ -1606,11 +1629,11 @@ int fs3_regions(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, const bath_hip_
   BATH_FS_SWITCH(Cv, BATH_FS_MODE(mode, {
     if ((st = fs_set_shmem(ctx, fs3_fwd_kernel<CC, MD>, shmem)) != BATH_OK) return st;
     const int s1 = ctx->span_begin("fs3_fwd_kernel", ctx->stream, cells3, bytes3);
-    hipLaunchKernelGGL((fs3_fwd_kernel<CC, MD>), dim3(grid_dp), dim3(kFsBlock), shmem, ctx->stream, dna->view(), fsdev(om), om->d_loop[0], om->d_move[0], tE, tE, b_sc.as<float>(), b_fx.as<float>(), b_off.as<int64_t>());
+    hipLaunchKernelGGL((fs3_fwd_kernel<CC, MD>), dim3(grid_dp), dim3(kFsBlock), shmem, ctx->stream, dna->view(), fsdev(om), om->d_loop[0], om->d_move[0], tE, tE, b_sc.as<float>(), b_fx.as<float>(), b_off.as<int64_t>(), jq[0]);
     ctx->span_end(s1, ctx->stream);
     if ((st = fs_set_shmem(ctx, fs_bwd_kernel<CC, 3, MD>, shmem)) != BATH_OK) return st;
     const int s2 = ctx->span_begin("fs_bwd_kernel<3>", ctx->side_stream, cells3, bytes3);
-    hipLaunchKernelGGL((fs_bwd_kernel<CC, 3, MD>), dim3(grid_dp), dim3(kFsBlock), shmem, ctx->side_stream, dna->view(), fsdev(om), om->d_loop[0], om->d_move[0], tE, tE, b_sc.as<float>() + n, (float *)nullptr, (const int64_t *)nullptr, b_bx.as<float>(), b_off.as<int64_t>());
+    hipLaunchKernelGGL((fs_bwd_kernel<CC, 3, MD>), dim3(grid_dp), dim3(kFsBlock), shmem, ctx->side_stream, dna->view(), fsdev(om), om->d_loop[0], om->d_move[0], tE, tE, b_sc.as<float>() + n, (float *)nullptr, (const int64_t *)nullptr, b_bx.as<float>(), b_off.as<int64_t>(), jq[1]);
     ctx->span_end(s2, ctx->side_stream);
   }))
   if ((st = fs_join(ctx)) != BATH_OK) return st;
@@ -1718,16 +1741,18 @@ int bath::fs5_envelopes_ex(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, cons
   const float tEL = -INFINITY, tEM = 0.0f;                                      // unihit: p7_fs_ReconfigUnihit, modelconfig.c:868
   if (logsum_mode == BATH_LOGSUM_TABLE && ctx->fs_strict) logsum_mode = BATH_LOGSUM_TABLE_SERIAL;
   const double cells5 = (double)(foff[(size_t)n] / 8);                          // (L+1) x (M+1) cells of all envelopes
+  FsJobs jq[3];
+  if ((st = fs_schedule(ctx, dna, 3, jq)) != BATH_OK) return st;
   if ((st = fs_fork(ctx)) != BATH_OK) return st;                                // Backward on the side stream, concurrently with Forward
   BATH_FS_SWITCH(Cv, {
     BATH_FS_MODE(logsum_mode, {
       if ((st = fs_set_shmem(ctx, fs5_fwd_kernel<CC, MD>, shmem)) != BATH_OK) return st;
       if ((st = fs_set_shmem(ctx, fs_bwd_kernel<CC, 5, MD>, shmem)) != BATH_OK) return st;
       const int s1 = ctx->span_begin("fs5_fwd_kernel", ctx->stream, cells5, cells5 * 32.0);
-      hipLaunchKernelGGL((fs5_fwd_kernel<CC, MD>), dim3(grid_dp), dim3(kFsBlock), shmem, ctx->stream, dna->view(), fsdev(om), om->d_loop[1], om->d_move[1], tEL, tEM, c5_compat, d_fsc, b_f.as<float>(), d_foff, b_fx.as<float>(), d_xoff, -1);
+      hipLaunchKernelGGL((fs5_fwd_kernel<CC, MD>), dim3(grid_dp), dim3(kFsBlock), shmem, ctx->stream, dna->view(), fsdev(om), om->d_loop[1], om->d_move[1], tEL, tEM, c5_compat, d_fsc, b_f.as<float>(), d_foff, b_fx.as<float>(), d_xoff, -1, jq[0]);
       ctx->span_end(s1, ctx->stream);
       const int s2 = ctx->span_begin("fs_bwd_kernel<5>", ctx->side_stream, cells5, cells5 * 12.0);
-      hipLaunchKernelGGL((fs_bwd_kernel<CC, 5, MD>), dim3(grid_dp), dim3(kFsBlock), shmem, ctx->side_stream, dna->view(), fsdev(om), om->d_loop[1], om->d_move[1], tEL, tEM, d_bsc, b_b.as<float>(), d_boff, b_bx.as<float>(), d_xoff);
+      hipLaunchKernelGGL((fs_bwd_kernel<CC, 5, MD>), dim3(grid_dp), dim3(kFsBlock), shmem, ctx->side_stream, dna->view(), fsdev(om), om->d_loop[1], om->d_move[1], tEL, tEM, d_bsc, b_b.as<float>(), d_boff, b_bx.as<float>(), d_xoff, jq[1]);
       ctx->span_end(s2, ctx->side_stream);
     })
     if ((st = fs_join(ctx)) != BATH_OK) return st;
@@ -1739,7 +1764,7 @@ int bath::fs5_envelopes_ex(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, cons
       const int s3 = ctx->span_begin("fs5_decode_oa_kernel", ctx->stream, cells5, cells5 * 88.0);   // reads Forward 32 + Backward 12, writes posteriors 32 + OA 12 B/cell
       hipLaunchKernelGGL((fs5_decode_oa_kernel<CC>), dim3(grid), dim3(256), oa_shmem, ctx->stream, dna->view(), M, om->d_tf, om->d_loop[1], d_bsc, b_f.as<float>(), d_foff,
                          b_fx.as<float>(), d_xoff, b_b.as<float>(), d_boff, b_bx.as<float>(), b_cs.as<float>(), b_o.as<float>(), d_osc,
-                         1.17549435e-38f /* E->J impossible in unihit mode: TSCDELTA = FLT_MIN */, 1.0f, (oax || trace) ? b_ox.as<float>() : nullptr);
+                         1.17549435e-38f /* E->J impossible in unihit mode: TSCDELTA = FLT_MIN */, 1.0f, (oax || trace) ? b_ox.as<float>() : nullptr, jq[2]);
       ctx->span_end(s3, ctx->stream);
     } else {
     const int s3 = ctx->span_begin("fs5_decode_kernel", ctx->stream, cells5, cells5 * 76.0);     // reads Forward 32 + Backward 12, rewrites 32 B/cell
@@ -1825,11 +1850,13 @@ int bath::fs5_region_forward(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, co
   const int grid_dp = fs_grid_dp(ctx, n);
   const float tE = (float)-0.69314718055994529;                               // multihit: E->C and E->J both log 1/2 (modelconfig.c:825-831)
   const int mode = ctx->fs_strict ? BATH_LOGSUM_TABLE_SERIAL : BATH_LOGSUM_TABLE;
+  FsJobs jq[1];
+  if ((st = fs_schedule(ctx, dna, 1, jq)) != BATH_OK) return st;
   BATH_FS_SWITCH(Cv, BATH_FS_MODE(mode, {
     if ((st = fs_set_shmem(ctx, fs5_fwd_kernel<CC, MD>, shmem)) != BATH_OK) return st;
     const int s1 = ctx->span_begin("fs5_fwd_kernel(regions)", ctx->stream, (double)(foff[(size_t)n] / 8), (double)(foff[(size_t)n] / 8) * 32.0);
     hipLaunchKernelGGL((fs5_fwd_kernel<CC, MD>), dim3(grid_dp), dim3(kFsBlock), shmem, ctx->stream, dna->view(), fsdev(om), om->d_loop[0], om->d_move[0], tE, tE, 0, b_sc.as<float>(),
-                       b_f.as<float>(), d_foff, b_fx.as<float>(), d_xoff, cfg_len_amino);
+                       b_f.as<float>(), d_foff, b_fx.as<float>(), d_xoff, cfg_len_amino, jq[0]);
     ctx->span_end(s1, ctx->stream);
   }))
   BATH_HIP_TRY(ctx, hipGetLastError());
