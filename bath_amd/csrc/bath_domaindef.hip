@@ -159,6 +159,7 @@ static int fs_branch_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, con
   std::vector<Env> envs, mregs;
   for (int q = 0; q < nsel; q++) {
     const int32_t *r = &regions[(size_t)q * RS];
+    if (r[0] > fs_max_regions()) { ctx->set_error("a DNA window has more regions than the region buffer holds"); return BATH_ERANGE; }
     for (int k = 0; k < r[0]; k++) {                                          // r[0] == -1: Backward underflow, the reference skips the window (:1471)
       const int i = r[1 + 3 * k], j = r[2 + 3 * k];
       if (r[3 + 3 * k]) mregs.push_back(Env{q, i, j});
@@ -380,7 +381,7 @@ extern "C" int bath_hip_pipeline_frameshift_domains(bath_hip_ctx *ctx, const bat
 // =================================================================================================================
 namespace {
 
-constexpr int kStdMaxRegions = 16;
+constexpr int kStdMaxRegions = 48;       // regions kept per ORF; an ORF with more reports the true count and the call fails loudly (the reference has no cap)
 
 // p7_DomainDecoding (impl_sse/decoding.c:155-196) + region heuristics (p7_domaindef.c:520-533, 642-654), lane per ORF
 __global__ void std_regions_kernel(int64_t n, const int32_t *__restrict__ len, const float *__restrict__ fx, const float *__restrict__ bx,
@@ -422,7 +423,7 @@ __global__ void std_regions_kernel(int64_t n, const int32_t *__restrict__ len, c
       i = -1; triggered = false;
     }
   }
-  out[0] = min(nreg, kStdMaxRegions);
+  out[0] = nreg;                           // may exceed kStdMaxRegions: the host checks
 }
 
 struct StdEnvOut { int32_t i1, k1, i2, k2, ok; float oasc, domcorrection; int32_t ncol, exact; float aliscore; };
@@ -853,6 +854,7 @@ static int std_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bat
   std::vector<Env> envs, mregs;
   for (int64_t q = 0; q < ns; q++) {
     const int32_t *r = &regions[(size_t)q * RS];
+    if (r[0] > kStdMaxRegions) { ctx->set_error("an ORF has more regions than the region buffer holds"); return BATH_ERANGE; }
     for (int k = 0; k < r[0]; k++) (r[3 + 3 * k] ? mregs : envs).push_back(Env{(int)q, r[1 + 3 * k], r[2 + 3 * k], false, 0.f});
   }
   if (n_skipped_regions) *n_skipped_regions += (int64_t)mregs.size();      // regions resolved by clustering (ddef->nclustered)

@@ -1502,7 +1502,7 @@ static int fs3_parser(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, const bat
 // on the parsers' special-state rows, one WAVE per window: the posterior terms (11 expf per position) are elementwise and
 // computed by all 64 lanes; the two running sums and the scan for regions are serial and short, lane 0 does them with the
 // reference's own order of additions.  Only the regions (a few integers per window) travel to the host.
-constexpr int kMaxRegions = 24;
+constexpr int kMaxRegions = 64;       // regions kept per DNA window; a window with more reports the true count and the call fails loudly (the reference has no cap)
 __global__ __launch_bounds__(64) void fs_regions_kernel(int64_t n, const int32_t *__restrict__ len, const float *__restrict__ fx, const float *__restrict__ bx,
                                   const int64_t *__restrict__ x_off, const float *__restrict__ tbl, float loop, float *__restrict__ work /* 3 floats per xmx row */,
                                   int32_t *__restrict__ regions /* [n][1 + 3*kMaxRegions]: count, then {i, j, multidomain} */) {
@@ -1572,7 +1572,7 @@ __global__ __launch_bounds__(64) void fs_regions_kernel(int64_t n, const int32_t
     }
     triggered = false;
   }
-  out[0] = min(nreg, kMaxRegions);
+  out[0] = nreg;                        // may exceed kMaxRegions: the host checks
 }
 
 namespace bath {

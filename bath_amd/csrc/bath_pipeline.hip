@@ -44,6 +44,7 @@ struct Counters {                     // device-side counters, one struct per pi
   unsigned long long n_past_msv, n_past_bias, n_past_vit, n_past_fwd;
   unsigned long long pos_past_msv, pos_past_bias, pos_past_vit, pos_past_fwd;
   unsigned long long res_vit, res_fwd;                      // residues entering Viterbi / Forward
+  unsigned long long res_seen;                              // residues of ORFs lying inside a window's context: scored by SSV but not the reference's (p7_pipeline.c:1635)
 };
 
 struct Params {
@@ -114,6 +115,17 @@ __global__ __launch_bounds__(256, (NR <= 76 ? 4 : 1)) void ssv_orf_kernel(const 
     }
     xE = ssv_max3(xE, xE2, xE2);
     const int v = ssv_group_max<G>(xE);
+    if (dna.context) {                  // windows with context only: ORFs the previous window already searched do not count as MSV work
+      unsigned long long r = 0;
+      if (live && grank == 0) {
+        const int sf = (int)((unsigned)rec.len_sf >> 28);
+        const int64_t w = rec.w;
+        const int startj = (int32_t)(rec.aa_off - (2 * dna.off[w] + 96 * w + (int64_t)sf * orf_stream_pitch(dna.len[w])));
+        const int C = dna.context[w], start_s = sf % 3 + 3 * startj + 1;
+        if (sf < 3 ? (start_s + 3 * L - 1 < C) : (dna.len[w] - start_s + 1 < C)) r = (unsigned long long)L;
+      }
+      if (__ballot(r != 0)) { for (int d = 32; d >= 1; d >>= 1) r += __shfl_xor(r, d, 64); if (lane == 0) atomicAdd(&ctr->res_seen, r); }
+    }
     if (live && grank == 0 && v >= (int)emit_thresh[min(L, thresh_max)]) {
       const int sf = (int)((unsigned)rec.len_sf >> 28);
       const int64_t w = rec.w;
@@ -732,7 +744,7 @@ static int run_filters(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bat
     stats->n_past_vit = (int64_t)hc.n_past_vit; stats->n_past_fwd = (int64_t)hc.n_past_fwd;
     stats->pos_past_msv = (int64_t)hc.pos_past_msv; stats->pos_past_bias = (int64_t)hc.pos_past_bias;
     stats->pos_past_vit = (int64_t)hc.pos_past_vit; stats->pos_past_fwd = (int64_t)hc.pos_past_fwd;
-    stats->cells_msv = (int64_t)hc.orf_res * M; stats->cells_vit = (int64_t)hc.res_vit * M; stats->cells_fwd = (int64_t)hc.res_fwd * M;
+    stats->cells_msv = (int64_t)(hc.orf_res - hc.res_seen) * M; stats->cells_vit = (int64_t)hc.res_vit * M; stats->cells_fwd = (int64_t)hc.res_fwd * M;
   }
 
   if (results) {
