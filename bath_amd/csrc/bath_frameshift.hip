@@ -60,12 +60,20 @@ struct FsDev {
 };
 
 // p7_FLogsum (logsum.c:105-111): truncating table lookup, or the exact form (logsum.c:109)
+// Straight-line code: the table is read unconditionally at a clamped index and the early-out cases are a select.  With the
+// obvious `if (...) return mx;` every log-sum became its own exec-masked basic block (165 branches in the 3-codon Forward
+// kernel) and the compiler could not overlap the independent log-sums of a lane's nodes; the values are identical.
 template <bool EXACT>
 __device__ __forceinline__ float flogsum(float a, float b, const float *tbl) {
   const float mx = fmaxf(a, b), mn = fminf(a, b);
-  if (mn == -INFINITY || (mx - mn) >= 15.7f) return mx;
-  if (EXACT) return mx + log1pf(expf(mn - mx));
-  return mx + tbl[(int)((mx - mn) * 1000.f)];
+  if (EXACT) {
+    if (mn == -INFINITY || (mx - mn) >= 15.7f) return mx;
+    return mx + log1pf(expf(mn - mx));
+  }
+  const float d = mx - mn;                                    // +inf when mn = -inf, NaN when both are
+  const float dc = fminf(d, 15.999f);                         // (v_min_f32 returns the number when one operand is NaN)
+  const float t = tbl[(int)(dc * 1000.f)];
+  return (mn == -INFINITY || d >= 15.7f) ? mx : mx + t;
 }
 
 template <bool EXACT>
@@ -100,7 +108,8 @@ __device__ __forceinline__ void d_chain_fwd(const float (&md)[C], const float (&
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
     const float Ap = __shfl_up(A, d, 64), Bp = __shfl_up(B, d, 64);
-    if (lane >= d) { A = flogsum<EXACT>(A, Ap + B, tbl); B += Bp; }
+    const float An = flogsum<EXACT>(A, Ap + B, tbl);
+    A = (lane >= d) ? An : A; B = (lane >= d) ? B + Bp : B;
   }
   float din = __shfl_up(A, 1, 64);
   if (lane == 0) din = -INFINITY;
@@ -249,23 +258,24 @@ __global__ __launch_bounds__(kFsBlock) void fs3_fwd_kernel(SeqView dna, FsDev p,
       if (lane == 0) mIn = iIn = dIn = -INFINITY;
       float Mc[C], Ic[C], ivc[C], md[C], dd[C];
       float eloc = -INFINITY;
+      // nodes beyond M read the all -inf transition row M+1 and -inf emissions: every value below comes out -inf without a
+      // branch (a per-node `if (node <= M)` splits the row into exec-masked blocks and serialises the lane's log-sums)
 #pragma unroll
       for (int c = 0; c < C; c++) {
-        const int node = lane * C + c + 1;
-        if (node <= M) {
-          const float4 ta = *reinterpret_cast<const float4 *>(s_tf + node * 8);
-          const float4 tb = *reinterpret_cast<const float4 *>(s_tf + node * 8 + 4);
-          const float m1 = (c == 0) ? mIn : Mr[1][c - 1], i1 = (c == 0) ? iIn : Ir[1][c - 1], d1 = (c == 0) ? dIn : Dr[1][c - 1];
-          float iv;
-          if (i == 2) iv = xB[1] + ta.w;                                           // row 2: IVX3(2,k) = B(0) + tBM (:503)
-          else iv = LS(m1 + ta.x, LS(i1 + ta.y, LS(d1 + ta.z, xB[1] + ta.w)));     // from row i-2, B(i-2)
-          ivc[c] = iv;
-          float mv = iv + e2[c];
-          if (i > 2) { mv = LS(mv, iv1[c] + e3[c]); mv = LS(mv, iv2[c] + e4[c]); }
-          Mc[c] = mv;
-          Ic[c] = (i > 2 && node < M) ? LS(Mr[2][c] + tb.z, Ir[2][c] + tb.w) : -INFINITY;
-          md[c] = mv + tb.x; dd[c] = tb.y;
-        } else { Mc[c] = -INFINITY; Ic[c] = -INFINITY; ivc[c] = -INFINITY; md[c] = -INFINITY; dd[c] = -INFINITY; }
+        const int node = lane * C + c + 1, nd = imin(node, M + 1);
+        const float4 ta = *reinterpret_cast<const float4 *>(s_tf + nd * 8);
+        const float4 tb = *reinterpret_cast<const float4 *>(s_tf + nd * 8 + 4);
+        const float m1 = (c == 0) ? mIn : Mr[1][c - 1], i1 = (c == 0) ? iIn : Ir[1][c - 1], d1 = (c == 0) ? dIn : Dr[1][c - 1];
+        float iv;
+        if (i == 2) iv = xB[1] + ta.w;                                           // row 2: IVX3(2,k) = B(0) + tBM (:503)
+        else iv = LS(m1 + ta.x, LS(i1 + ta.y, LS(d1 + ta.z, xB[1] + ta.w)));     // from row i-2, B(i-2)
+        ivc[c] = iv;
+        float mv = iv + e2[c];
+        if (i > 2) { mv = LS(mv, iv1[c] + e3[c]); mv = LS(mv, iv2[c] + e4[c]); }
+        Mc[c] = mv;
+        const float ins = LS(Mr[2][c] + tb.z, Ir[2][c] + tb.w);
+        Ic[c] = (i > 2 && node < M) ? ins : -INFINITY;
+        md[c] = mv + tb.x; dd[c] = tb.y;
       }
       float Dc[C];
       float xE;
@@ -275,8 +285,8 @@ __global__ __launch_bounds__(kFsBlock) void fs3_fwd_kernel(SeqView dna, FsDev p,
 #pragma unroll
         for (int c = 0; c < C; c++) {
           const int node = lane * C + c + 1;
-          if (node <= M) eloc = LS(Mc[c], LS(Dc[c], eloc));
-          else Dc[c] = -INFINITY;
+          Dc[c] = (node <= M) ? Dc[c] : -INFINITY;
+          eloc = LS(Mc[c], LS(Dc[c], eloc));                        // nodes beyond M hold -inf: the sum is unchanged
         }
         xE = wave_logsum<EXACT>(eloc, s_tbl);
       }
@@ -362,33 +372,42 @@ __global__ __launch_bounds__(kFsBlock) void fs5_fwd_kernel(SeqView dna, FsDev p,
 #pragma unroll
         for (int s = 0; s < 8; s++) row[s] = -INFINITY;
       }
+      // straight-line per node (see fs3_fwd_kernel): nodes beyond M read transition row M+1 (-inf) and emission column M
+      // (finite, but added to a -inf IVX), so their values come out -inf; only the stores are guarded
+      float cc[C][5];
+#pragma unroll
+      for (int c = 0; c < C; c++) {
+        const int node = lane * C + c + 1, nd = imin(node, M + 1), ne = imin(node, M);
+        const float4 ta = *reinterpret_cast<const float4 *>(s_tf + nd * 8);
+        const float4 tb = *reinterpret_cast<const float4 *>(s_tf + nd * 8 + 4);
+        const float m1 = (c == 0) ? mIn : Mr[0][c - 1], i1 = (c == 0) ? iIn : Ir[0][c - 1], d1 = (c == 0) ? dIn : Dr1[c - 1];
+        float ivn;
+        if (i <= 2) ivn = xBprev + ta.w;                                          // rows 1,2: only B(i-1) enters (:109,:150)
+        else ivn = LS(m1 + ta.x, LS(i1 + ta.y, LS(d1 + ta.z, xBprev + ta.w)));
+        ivc[c] = ivn;
+        const float c1 = ivn + r1[ne];
+        const float c2 = (i >= 2) ? iv[0][c] + r2[ne] : -INFINITY;
+        const float c3 = (i >= 3) ? iv[1][c] + r3[ne] : -INFINITY;
+        const float c4 = (i >= 4) ? iv[2][c] + r4[ne] : -INFINITY;
+        const float c5 = (i >= 5) ? (c5_compat ? ivn : iv[3][c]) + r5[ne] : -INFINITY;
+        float c0;
+        if (i == 1) c0 = c1;
+        else if (i == 2) c0 = LS(c1, c2);
+        else if (i < 5) c0 = LS(c1, LS(c2, LS(c3, c4)));
+        else c0 = LS(LS(c1, LS(c2, c3)), LS(c4, c5));
+        Mc[c] = c0;
+        const float ins = LS(Mr[2][c] + tb.z, Ir[2][c] + tb.w);
+        Ic[c] = (i >= 3 && node < M) ? ins : -INFINITY;
+        md[c] = c0 + tb.x; dd[c] = tb.y;
+        cc[c][0] = c1; cc[c][1] = c2; cc[c][2] = c3; cc[c][3] = c4; cc[c][4] = c5;
+      }
 #pragma unroll
       for (int c = 0; c < C; c++) {
         const int node = lane * C + c + 1;
         if (node <= M) {
-          const float4 ta = *reinterpret_cast<const float4 *>(s_tf + node * 8);
-          const float4 tb = *reinterpret_cast<const float4 *>(s_tf + node * 8 + 4);
-          const float m1 = (c == 0) ? mIn : Mr[0][c - 1], i1 = (c == 0) ? iIn : Ir[0][c - 1], d1 = (c == 0) ? dIn : Dr1[c - 1];
-          float ivn;
-          if (i <= 2) ivn = xBprev + ta.w;                                          // rows 1,2: only B(i-1) enters (:109,:150)
-          else ivn = LS(m1 + ta.x, LS(i1 + ta.y, LS(d1 + ta.z, xBprev + ta.w)));
-          ivc[c] = ivn;
-          const float c1 = ivn + r1[node];
-          const float c2 = (i >= 2) ? iv[0][c] + r2[node] : -INFINITY;
-          const float c3 = (i >= 3) ? iv[1][c] + r3[node] : -INFINITY;
-          const float c4 = (i >= 4) ? iv[2][c] + r4[node] : -INFINITY;
-          const float c5 = (i >= 5) ? (c5_compat ? ivn : iv[3][c]) + r5[node] : -INFINITY;
-          float c0;
-          if (i == 1) c0 = c1;
-          else if (i == 2) c0 = LS(c1, c2);
-          else if (i < 5) c0 = LS(c1, LS(c2, LS(c3, c4)));
-          else c0 = LS(LS(c1, LS(c2, c3)), LS(c4, c5));
-          Mc[c] = c0;
-          Ic[c] = (i >= 3 && node < M) ? LS(Mr[2][c] + tb.z, Ir[2][c] + tb.w) : -INFINITY;
-          md[c] = c0 + tb.x; dd[c] = tb.y;
           float *cell = row + (size_t)node * 8;
-          cell[1] = Ic[c]; cell[2] = c0; cell[3] = c1; cell[4] = c2; cell[5] = c3; cell[6] = c4; cell[7] = c5;
-        } else { Mc[c] = -INFINITY; Ic[c] = -INFINITY; ivc[c] = -INFINITY; md[c] = -INFINITY; dd[c] = -INFINITY; }
+          cell[1] = Ic[c]; cell[2] = Mc[c]; cell[3] = cc[c][0]; cell[4] = cc[c][1]; cell[5] = cc[c][2]; cell[6] = cc[c][3]; cell[7] = cc[c][4];
+        }
       }
       float Dc[C];
       float xE;
@@ -405,8 +424,13 @@ __global__ __launch_bounds__(kFsBlock) void fs5_fwd_kernel(SeqView dna, FsDev p,
 #pragma unroll
         for (int c = 0; c < C; c++) {
           const int node = lane * C + c + 1;
-          if (node <= M) { row[(size_t)node * 8] = Dc[c]; eloc = LS(Mc[c], LS(Dc[c], eloc)); }
-          else Dc[c] = -INFINITY;
+          Dc[c] = (node <= M) ? Dc[c] : -INFINITY;
+          eloc = LS(Mc[c], LS(Dc[c], eloc));
+        }
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+          const int node = lane * C + c + 1;
+          if (node <= M) row[(size_t)node * 8] = Dc[c];
         }
         xE = wave_logsum<EXACT>(eloc, s_tbl);
       }
@@ -494,27 +518,30 @@ __global__ __launch_bounds__(kFsBlock) void fs_bwd_kernel(SeqView dna, FsDev p, 
           dnext = bwd_dnext_strict<C>([&](int, int node, float dn) { return (node == M) ? xE : LS(xE, dn + s_tb[node * 8 + 3]); }, lane, M);
         } else {
           float A = -INFINITY, B = 0.f;              // lane function applied to D(i, last node of lane + 1)
+          // node M's and node M+1's transition rows are -inf: node M falls out of the general formula (LS(E, -inf) = E) and
+          // nodes beyond M are deselected, without a branch per node
 #pragma unroll
           for (int c = C - 1; c >= 0; c--) {
             const int node = lane * C + c + 1;
-            const float tdd = (node < M) ? s_tb[node * 8 + 3] : -INFINITY;
-            if (node <= M) { A = (node == M) ? xE : LS(xE, A + tdd); B = (node == M) ? -INFINITY : B + tdd; }
+            const float tdd = s_tb[imin(node, M + 1) * 8 + 3];
+            const float An = LS(xE, A + tdd);
+            A = (node <= M) ? An : A; B = (node <= M) ? B + tdd : B;
           }
 #pragma unroll
           for (int dlt = 1; dlt < 64; dlt <<= 1) {
             const float An = __shfl_down(A, dlt, 64), Bn = __shfl_down(B, dlt, 64);
-            if (lane + dlt < 64) { A = LS(A, An + B); B += Bn; }
+            const float Am = LS(A, An + B);
+            A = (lane + dlt < 64) ? Am : A; B = (lane + dlt < 64) ? B + Bn : B;
           }
           dnext = __shfl_down(A, 1, 64);
           if (lane == 63) dnext = -INFINITY;
         }
 #pragma unroll
         for (int c = C - 1; c >= 0; c--) {
-          const int node = lane * C + c + 1;
-          if (node > M) { Mc[c] = Ic[c] = Dc[c] = -INFINITY; continue; }
+          const int node = lane * C + c + 1, nd = imin(node, M + 1);
           const float dn = (c == C - 1) ? dnext : Dc[c + 1];
-          if (node == M) { Mc[c] = Dc[c] = xE; }
-          else { Mc[c] = LS(xE, dn + s_tb[node * 8 + 0]); Dc[c] = LS(xE, dn + s_tb[node * 8 + 3]); }
+          const float mv = LS(xE, dn + s_tb[nd * 8 + 0]), dv = LS(xE, dn + s_tb[nd * 8 + 3]);
+          Mc[c] = (node <= M) ? mv : -INFINITY; Dc[c] = (node <= M) ? dv : -INFINITY;
           Ic[c] = -INFINITY;
         }
       } else {
@@ -542,28 +569,28 @@ __global__ __launch_bounds__(kFsBlock) void fs_bwd_kernel(SeqView dna, FsDev p, 
         float bloc = -INFINITY;
 #pragma unroll
         for (int c = 0; c < C; c++) {
-          const int node = lane * C + c + 1;
-          if (node > M) { ivx[c] = -INFINITY; continue; }
+          // nodes beyond M: their M rows are -inf, so ivx comes out -inf and the B term (transition row M+1 = -inf) drops out
+          const int node = lane * C + c + 1, ne = imin(node, M), nd = imin(node, M + 1);
           float a;
           if (FIVE) {
-            if (mainrow) a = LS(Mr[0][c] + r1[node], LS(Mr[1][c] + r2[node], LS(Mr[2][c] + r3[node], LS(Mr[3][c] + r4[node], Mr[4][c] + r5[node]))));
+            if (mainrow) a = LS(Mr[0][c] + r1[ne], LS(Mr[1][c] + r2[ne], LS(Mr[2][c] + r3[ne], LS(Mr[3][c] + r4[ne], Mr[4][c] + r5[ne]))));
             else {
-              a = Mr[0][c] + r1[node];
-              if (avail >= 2) a = LS(a, Mr[1][c] + r2[node]);
-              if (avail >= 3) a = LS(a, Mr[2][c] + r3[node]);
-              if (avail >= 4) a = LS(a, Mr[3][c] + r4[node]);
+              a = Mr[0][c] + r1[ne];
+              if (avail >= 2) a = LS(a, Mr[1][c] + r2[ne]);
+              if (avail >= 3) a = LS(a, Mr[2][c] + r3[ne]);
+              if (avail >= 4) a = LS(a, Mr[3][c] + r4[ne]);
             }
           } else {
-            if (mainrow) a = LS(Mr[1][c] + r2[node], LS(Mr[2][c] + r3[node], Mr[3][c] + r4[node]));
+            if (mainrow) a = LS(Mr[1][c] + r2[ne], LS(Mr[2][c] + r3[ne], Mr[3][c] + r4[ne]));
             else {
-              a = Mr[1][c] + r2[node];
-              if (avail >= 3) a = LS(a, Mr[2][c] + r3[node]);
-              if (avail >= 4) a = LS(a, Mr[3][c] + r4[node]);
+              a = Mr[1][c] + r2[ne];
+              if (avail >= 3) a = LS(a, Mr[2][c] + r3[ne]);
+              if (avail >= 4) a = LS(a, Mr[3][c] + r4[ne]);
             }
           }
           ivx[c] = a;
-          if constexpr (STRICT) bterm[c] = a + s_tb[node * 8 + 7];
-          else bloc = LS(bloc, a + s_tb[node * 8 + 7]);
+          if constexpr (STRICT) bterm[c] = a + s_tb[nd * 8 + 7];
+          else bloc = LS(bloc, a + s_tb[nd * 8 + 7]);
         }
         if constexpr (STRICT) xBn = bwd_bsum_strict<C>(bterm, lane, M, s_tbl);
         else xBn = wave_logsum<EXACT>(bloc, s_tbl);
@@ -582,59 +609,59 @@ __global__ __launch_bounds__(kFsBlock) void fs_bwd_kernel(SeqView dna, FsDev p, 
         // D chain (descending): D(k) = LS(LS(E, D(k+1)+tDD(k)), ivx(k+1)+tDM(k)); a(k) := LS(E, ivx(k+1)+tDM(k)) up to association
         float A = -INFINITY, B = 0.f;
         float base[C];
+        // node M needs no special case: its transitions out are -inf, so base = -inf and D(M) = M(M) = E fall out of the general
+        // formulas (LS(x, -inf) = x); nodes beyond M are deselected
 #pragma unroll
         for (int c = C - 1; c >= 0; c--) {
-          const int node = lane * C + c + 1;
-          if (node > M) { base[c] = -INFINITY; continue; }
+          const int node = lane * C + c + 1, nd = imin(node, M + 1);
           const float ivn = (c == C - 1) ? ivNext : ivx[c + 1];
-          const float tdd = s_tb[node * 8 + 3], tdm = s_tb[node * 8 + 4];
-          if (node == M) { base[c] = xE; A = xE; B = -INFINITY; }
-          else {
-            base[c] = ivn + tdm;
-            if constexpr (!STRICT) {
-              A = (!FIVE && !mainrow && !tail) ? LS(A + tdd, LS(xE, base[c])) : LS(LS(xE, A + tdd), base[c]);
-              B += tdd;
-            }
+          const float tdd = s_tb[nd * 8 + 3], tdm = s_tb[nd * 8 + 4];
+          base[c] = ivn + tdm;
+          if constexpr (!STRICT) {
+            const float An = (!FIVE && !mainrow && !tail) ? LS(A + tdd, LS(xE, base[c])) : LS(LS(xE, A + tdd), base[c]);
+            A = (node <= M) ? An : A; B = (node <= M) ? B + tdd : B;
           }
         }
         float dnext;
         if constexpr (STRICT) {
           dnext = bwd_dnext_strict<C>([&](int c, int node, float dn) {
-            if (node == M) return xE;
-            const float tdd = s_tb[node * 8 + 3];
+            const float tdd = s_tb[node * 8 + 3];                // node M: tdd = -inf, base = -inf: the formula gives E
             return (!FIVE && !mainrow && !tail) ? LS(dn + tdd, LS(xE, base[c])) : LS(LS(xE, dn + tdd), base[c]);
           }, lane, M);
         } else {
 #pragma unroll
           for (int dlt = 1; dlt < 64; dlt <<= 1) {
             const float An = __shfl_down(A, dlt, 64), Bn = __shfl_down(B, dlt, 64);
-            if (lane + dlt < 64) { A = LS(A, An + B); B += Bn; }
+            const float Am = LS(A, An + B);
+            A = (lane + dlt < 64) ? Am : A; B = (lane + dlt < 64) ? B + Bn : B;
           }
           dnext = __shfl_down(A, 1, 64);
           if (lane == 63) dnext = -INFINITY;
         }
 #pragma unroll
         for (int c = C - 1; c >= 0; c--) {
-          const int node = lane * C + c + 1;
-          if (node > M) { Mc[c] = Ic[c] = Dc[c] = -INFINITY; continue; }
-          if (node == M) { Mc[c] = Dc[c] = xE; Ic[c] = -INFINITY; continue; }
+          const int node = lane * C + c + 1, nd = imin(node, M + 1);
           const float dn = (c == C - 1) ? dnext : Dc[c + 1];
           const float ivn = (c == C - 1) ? ivNext : ivx[c + 1];
-          const float tmd = s_tb[node * 8 + 0], tmi = s_tb[node * 8 + 1], tmm = s_tb[node * 8 + 2], tdd = s_tb[node * 8 + 3];
-          const float tii = s_tb[node * 8 + 5], tim = s_tb[node * 8 + 6];
+          const float4 t0 = *reinterpret_cast<const float4 *>(s_tb + nd * 8);          // tMD tMI tMM tDD
+          const float tii = s_tb[nd * 8 + 5], tim = s_tb[nd * 8 + 6];
+          const float tmd = t0.x, tmi = t0.y, tmm = t0.z, tdd = t0.w;
+          float mv, dv, iv_;
           if (tail) {
-            Mc[c] = LS(dn + tmd, LS(ivn + tmm, xE));
-            Dc[c] = LS(LS(xE, dn + tdd), base[c]);
-            Ic[c] = ivn + tim;
+            mv = LS(dn + tmd, LS(ivn + tmm, xE));
+            dv = LS(LS(xE, dn + tdd), base[c]);
+            iv_ = ivn + tim;
           } else if (!FIVE && !mainrow) {
-            Mc[c] = LS(dn + tmd, LS(Ir3[2][c] + tmi, LS(ivn + tmm, xE)));
-            Dc[c] = LS(dn + tdd, LS(xE, base[c]));
-            Ic[c] = LS(Ir3[2][c] + tii, ivn + tim);
+            mv = LS(dn + tmd, LS(Ir3[2][c] + tmi, LS(ivn + tmm, xE)));
+            dv = LS(dn + tdd, LS(xE, base[c]));
+            iv_ = LS(Ir3[2][c] + tii, ivn + tim);
           } else {
-            Mc[c] = LS(LS(dn + tmd, LS(Ir3[2][c] + tmi, ivn + tmm)), xE);
-            Dc[c] = LS(LS(xE, dn + tdd), base[c]);
-            Ic[c] = LS(Ir3[2][c] + tii, ivn + tim);
+            mv = LS(LS(dn + tmd, LS(Ir3[2][c] + tmi, ivn + tmm)), xE);
+            dv = LS(LS(xE, dn + tdd), base[c]);
+            iv_ = LS(Ir3[2][c] + tii, ivn + tim);
           }
+          // node M: -inf transitions make mv = dv = E and iv_ = -inf by themselves; nodes beyond M hold -inf
+          Mc[c] = (node <= M) ? mv : -INFINITY; Dc[c] = (node <= M) ? dv : -INFINITY; Ic[c] = (node <= M) ? iv_ : -INFINITY;
         }
       }
       // store row i
