@@ -3,7 +3,9 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -235,4 +237,15 @@ void bias_filter_eo(const float *compo, float eo[kKp][2]);
 double gumbel_surv(double x, double mu, double lambda);
 double gumbel_invsurv(double p, double mu, double lambda);
 double exp_surv(double x, double mu, double lambda);
+struct StageClock {                         // BATH_HIP_TIMING=1: wall time of the host-visible stages, to stderr
+  bool on; std::chrono::steady_clock::time_point t;
+  StageClock() { const char *e = std::getenv("BATH_HIP_TIMING"); on = e && e[0] == '1'; t = std::chrono::steady_clock::now(); }
+  void lap(const char *what) {
+    if (!on) return;
+    const auto n = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[bath timing] %-34s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count());
+    t = n;
+  }
+};
+
 }  // namespace bath

@@ -90,16 +90,6 @@ std::string cigar_from_columns(const uint16_t *S, int n) {
 static int std_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bath_hip_seqs *dna, const std::vector<PipelineSurvivor> &surv,
                        const uint8_t *d_pool, int64_t nres, double E_report, int64_t *n_skipped_regions);
 
-struct StageClock {                         // BATH_HIP_TIMING=1: wall time of the host-visible stages, to stderr
-  bool on; std::chrono::steady_clock::time_point t;
-  StageClock() { const char *e = std::getenv("BATH_HIP_TIMING"); on = e && e[0] == '1'; t = std::chrono::steady_clock::now(); }
-  void lap(const char *what) {
-    if (!on) return;
-    const auto n = std::chrono::steady_clock::now();
-    std::fprintf(stderr, "[bath timing] %-34s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count());
-    t = n;
-  }
-};
 
 static int fs_branch_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bath_hip_fsprofile *om_fs3,
                              const bath_hip_fsprofile *om_fs5, const bath_hip_seqs *dna, const bath_pipeline_params *prm,
@@ -208,7 +198,9 @@ static int fs_branch_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, con
           }
         }
       };
+      StageClock eclk;
       run_striped((int64_t)mregs.size(), work);
+      eclk.lap("fs:   (ensemble threads, start to end)");
     });
   }
   struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{ensembles};      // also on error returns
@@ -261,12 +253,21 @@ static int fs_branch_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, con
     step_off[(size_t)e_end] = (int64_t)steps.size();
     return BATH_OK;
   };
+  // Order of the work.  The ensembles are host threads; the standard branch of the other windows (p7_pipeline.c:1479-1510)
+  // needs nothing from them, so its kernels and host work run meanwhile.  Then ALL envelopes -- of the single-domain regions
+  // and of the clusters -- go through the envelope kernels as one batch: those kernels last as long as their longest
+  // envelope whatever the number of envelopes (one wave each), so two batches cost two such chains (14.3 + 9.4 ms on the
+  // bench block) and one batch costs one.  BATH_HIP_FS_TWO_BATCHES=1: the single-domain regions first, during the ensembles.
   const int n_single = (int)envs.size();
-  if (n_single > 0 && (st = run_envelopes(0, n_single)) != BATH_OK) return st;
-  clk.lap("fs: envelope kernels + traces (single-domain regions)");
+  const char *tb = std::getenv("BATH_HIP_FS_TWO_BATCHES");
+  const bool two_batches = tb && tb[0] == '1';
+  int done = 0;
+  if (ensembles.joinable() && two_batches && n_single > 0) {
+    if ((st = run_envelopes(0, n_single)) != BATH_OK) return st;
+    done = n_single;
+    clk.lap("fs: envelope kernels + traces (single-domain regions)");
+  }
   if (std_skipped && ensembles.joinable()) {
-    // ... and so does the standard branch of the other windows (p7_pipeline.c:1479-1510): its kernels and host work go here,
-    // while the ensemble threads are still busy (they read only their own page-locked matrices)
     int64_t nskip_std = 0;
     if ((st = std_domains(ctx, om, dna, ctx->fs_std_orfs, ctx->fs_std_pool, st_local.nres, E_report, &nskip_std)) != BATH_OK) return st;
     *std_skipped = nskip_std;
@@ -279,8 +280,8 @@ static int fs_branch_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, con
   }
   const int nenv = (int)envs.size();
   if (nenv == 0) return BATH_OK;
-  if (nenv > n_single && (st = run_envelopes(n_single, nenv)) != BATH_OK) return st;
-  clk.lap("fs: envelope kernels + traces (clustered regions)");
+  if (nenv > done && (st = run_envelopes(done, nenv)) != BATH_OK) return st;
+  clk.lap("fs: envelope kernels + traces");
 
   // ---- traceback, null2 along the trace, the hit's scores
   const int ml = h5.max_length;

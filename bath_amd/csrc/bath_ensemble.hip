@@ -249,9 +249,22 @@ int bath::fs_region_trace_ensemble(int M, const float *tsc, float xNL, float xNM
   auto DP = [&](int i, int k, int s) { return fwd[(size_t)i * W + (size_t)k * 8 + s]; };
   auto X = [&](int i, int s) { return fx[(size_t)i * 5 + s]; };
   auto TS = [&](int s, int k) { return tsc[(size_t)k * 8 + s]; };
-  std::vector<float> sc((size_t)2 * M + 8);
-  auto lognorm_choose = [&](FastRng &rng, int n) {       // esl_vec_FLogNorm, then esl_rnd_FChoose
-    float *v = sc.data();
+  // The probability vector of a choice is a function of (state, i, k) alone, and 200 traces sampled from one posterior
+  // keep coming back to the same cells: each vector is computed once (esl_vec_FLogNorm: ~2 expf per entry, 2M+1 entries in
+  // the E state) and kept, so that a revisit costs one random number and a few compares.  Same arithmetic, same draws.
+  struct Memo {
+    std::vector<uint8_t> cflag, rflag;      // per cell: 1 = M's 4, 2 = codon's 5, 4 = D's 2, 8 = I's 2; per row: 1 = C, 2 = J, 4 = B
+    std::vector<float> cell, row, epool;    // 16 floats per cell, 12 per row, 2M+1 per E row visited
+    std::vector<int64_t> eoff;
+  };
+  static thread_local Memo mm;
+  const size_t ncell = (size_t)(Lr + 1) * (size_t)(M + 1);
+  const bool memo_cells = ncell * 64 <= ((size_t)192 << 20);
+  if (memo_cells) { mm.cflag.assign(ncell, 0); if (mm.cell.size() < ncell * 16) mm.cell.resize(ncell * 16); }
+  mm.rflag.assign((size_t)Lr + 1, 0); mm.eoff.assign((size_t)Lr + 1, -1); mm.epool.clear();
+  if (mm.row.size() < ((size_t)Lr + 1) * 12) mm.row.resize(((size_t)Lr + 1) * 12);
+  float tmp[8];
+  auto lognorm = [&](float *v, int n) {                  // esl_vec_FLogNorm, then esl_vec_FNorm as esl_rnd_FChoose's callers do
     float mx = v[0];
     for (int q = 1; q < n; q++) mx = std::max(mx, v[q]);
     float denom;
@@ -262,11 +275,24 @@ int bath::fs_region_trace_ensemble(int M, const float *tsc, float xNL, float xNM
     float sum = 0.f, comp = 0.f;
     for (int q = 0; q < n; q++) { const float y = v[q] - comp, t = sum + y; comp = (t - sum) - y; sum = t; }
     for (int q = 0; q < n; q++) v[q] = (sum != 0.0f) ? v[q] / sum : 1.0f / (float)n;
+  };
+  auto roll = [&](FastRng &rng, const float *v, int n) {  // esl_rnd_FChoose
     for (;;) {
-      const float roll = (float)rng.next();
+      const float r = (float)rng.next();
       float acc = 0.f;
-      for (int q = 0; q < n; q++) { acc += v[q]; if (roll < acc) return q; }
+      for (int q = 0; q < n; q++) { acc += v[q]; if (r < acc) return q; }
     }
+  };
+  // slot of a cell's vector (nullptr: not memoised, use tmp) and whether it still has to be filled
+  auto cell_slot = [&](int i, int k, int bit, int at, bool *fresh) -> float * {
+    if (!memo_cells) { *fresh = true; return tmp; }
+    const size_t c = (size_t)i * (size_t)(M + 1) + (size_t)k;
+    *fresh = !(mm.cflag[c] & bit); mm.cflag[c] |= (uint8_t)bit;
+    return mm.cell.data() + c * 16 + at;
+  };
+  auto row_slot = [&](int i, int bit, int at, bool *fresh) -> float * {
+    *fresh = !(mm.rflag[(size_t)i] & bit); mm.rflag[(size_t)i] |= (uint8_t)bit;
+    return mm.row.data() + (size_t)i * 12 + at;
   };
   const int nsamples = 200, step_cap = 4 * (Lr + M) + 64;
   FastRng rng(42);
@@ -283,45 +309,63 @@ int bath::fs_region_trace_ensemble(int M, const float *tsc, float xNL, float xNM
       case sC:
         if (X(i, gC) == -INFINITY) return BATH_OK;
         if (i < 4) { scur = sE; break; }
-        sc[0] = X(i - 3, gC) + xNL; sc[1] = X(i - 2, gC) + xNL; sc[2] = X(i - 1, gC) + xNL; sc[3] = X(i, gE) + xE;
-        scur = lognorm_choose(rng, 4) < 3 ? sC : sE; break;
+        { bool fresh; float *v = row_slot(i, 1, 0, &fresh);
+          if (fresh) { v[0] = X(i - 3, gC) + xNL; v[1] = X(i - 2, gC) + xNL; v[2] = X(i - 1, gC) + xNL; v[3] = X(i, gE) + xE; lognorm(v, 4); }
+          scur = roll(rng, v, 4) < 3 ? sC : sE; }
+        break;
       case sE:
         if (X(i, gE) == -INFINITY) return BATH_OK;
-        sc[0] = sc[(size_t)M + 1] = -INFINITY;
-        for (int q = 1; q <= M; q++) sc[(size_t)q] = DP(i, q, gM);
-        for (int q = 2; q <= M; q++) sc[(size_t)q + M] = DP(i, q, gD);
-        k = lognorm_choose(rng, 2 * M + 1);
+        { if (mm.eoff[(size_t)i] < 0) {
+            mm.eoff[(size_t)i] = (int64_t)mm.epool.size();
+            mm.epool.resize(mm.epool.size() + (size_t)(2 * M + 1));
+            float *v = mm.epool.data() + mm.eoff[(size_t)i];
+            v[0] = v[(size_t)M + 1] = -INFINITY;
+            for (int q = 1; q <= M; q++) v[(size_t)q] = DP(i, q, gM);
+            for (int q = 2; q <= M; q++) v[(size_t)q + M] = DP(i, q, gD);
+            lognorm(v, 2 * M + 1);
+          }
+          k = roll(rng, mm.epool.data() + mm.eoff[(size_t)i], 2 * M + 1); }
         if (k <= M) scur = sM; else { k -= M; scur = sD; }
         break;
       case sM: {
-        sc[0] = X(i, gB) + TS(BM, k - 1); sc[1] = DP(i, k - 1, gM) + TS(MM, k - 1); sc[2] = DP(i, k - 1, gI) + TS(IM, k - 1); sc[3] = DP(i, k - 1, gD) + TS(DM, k - 1);
+        bool fresh; float *v = cell_slot(i, k, 1, 0, &fresh);
+        if (fresh) { v[0] = X(i, gB) + TS(BM, k - 1); v[1] = DP(i, k - 1, gM) + TS(MM, k - 1); v[2] = DP(i, k - 1, gI) + TS(IM, k - 1); v[3] = DP(i, k - 1, gD) + TS(DM, k - 1); lognorm(v, 4); }
         static const int state[4] = {sB, sM, sI, sD};
-        scur = state[lognorm_choose(rng, 4)]; k--; break; }
+        scur = state[roll(rng, v, 4)]; k--; break; }
       case sD:
         if (DP(i, k, gD) == -INFINITY) return BATH_OK;
-        sc[0] = DP(i, k - 1, gM) + TS(MD, k - 1); sc[1] = DP(i, k - 1, gD) + TS(DD, k - 1);
-        scur = lognorm_choose(rng, 2) == 0 ? sM : sD; k--; break;
+        { bool fresh; float *v = cell_slot(i, k, 4, 9, &fresh);
+          if (fresh) { v[0] = DP(i, k - 1, gM) + TS(MD, k - 1); v[1] = DP(i, k - 1, gD) + TS(DD, k - 1); lognorm(v, 2); }
+          scur = roll(rng, v, 2) == 0 ? sM : sD; }
+        k--; break;
       case sI:
         if (DP(i, k, gI) == -INFINITY || i < 3) return BATH_OK;
-        sc[0] = DP(i - 3, k, gM) + TS(MI, k); sc[1] = DP(i - 3, k, gI) + TS(II, k);
-        scur = lognorm_choose(rng, 2) == 0 ? sM : sI; i -= 3; break;
+        { bool fresh; float *v = cell_slot(i, k, 8, 11, &fresh);
+          if (fresh) { v[0] = DP(i - 3, k, gM) + TS(MI, k); v[1] = DP(i - 3, k, gI) + TS(II, k); lognorm(v, 2); }
+          scur = roll(rng, v, 2) == 0 ? sM : sI; }
+        i -= 3; break;
       case sN:
         if (X(i, gN) == -INFINITY) return BATH_OK;
         scur = (i == 0) ? sS : sN; break;
       case sB:
         if (X(i, gB) == -INFINITY) return BATH_OK;
-        sc[0] = X(i, gN) + xNM; sc[1] = X(i, gJ) + xNM;
-        scur = lognorm_choose(rng, 2) == 0 ? sN : sJ; break;
+        { bool fresh; float *v = row_slot(i, 4, 8, &fresh);
+          if (fresh) { v[0] = X(i, gN) + xNM; v[1] = X(i, gJ) + xNM; lognorm(v, 2); }
+          scur = roll(rng, v, 2) == 0 ? sN : sJ; }
+        break;
       case sJ:
         if (X(i, gJ) == -INFINITY) return BATH_OK;
         if (i < 4) { scur = sE; break; }
-        sc[0] = X(i - 3, gJ) + xNL; sc[1] = X(i - 2, gJ) + xNL; sc[2] = X(i - 1, gJ) + xNL; sc[3] = X(i, gE) + xE;
-        scur = lognorm_choose(rng, 4) < 3 ? sJ : sE; break;
+        { bool fresh; float *v = row_slot(i, 2, 4, &fresh);
+          if (fresh) { v[0] = X(i - 3, gJ) + xNL; v[1] = X(i - 2, gJ) + xNL; v[2] = X(i - 1, gJ) + xNL; v[3] = X(i, gE) + xE; lognorm(v, 4); }
+          scur = roll(rng, v, 4) < 3 ? sJ : sE; }
+        break;
       default: return BATH_OK;
       }
       if (scur == sM) {                                   // codon length from the C1..C5 cells
-        for (int q = 0; q < 5; q++) sc[(size_t)q] = DP(i, k, gM + 1 + q);
-        c = lognorm_choose(rng, 5) + 1;
+        bool fresh; float *v = cell_slot(i, k, 2, 4, &fresh);
+        if (fresh) { for (int q = 0; q < 5; q++) v[q] = DP(i, k, gM + 1 + q); lognorm(v, 5); }
+        c = roll(rng, v, 5) + 1;
         if (i - c < 0) scur = sB;
       } else c = 0;
       if (scur < 0 || k < 0 || i < 0 || (int)tr.size() > step_cap) return BATH_OK;

@@ -1866,7 +1866,23 @@ int bath::fs5_region_forward(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, co
     foff[(size_t)i + 1] = foff[(size_t)i] + rows * (M + 1) * 8; xoff[(size_t)i + 1] = xoff[(size_t)i] + rows * 5;
   }
   DevBuf &b_f = ctx->scratch[15], &b_fx = ctx->scratch[18], &b_off = ctx->scratch[20], &b_sc = ctx->scratch[21];
-  BATH_HIP_TRY(ctx, b_f.reserve((size_t)foff[(size_t)n] * 4 + 64)); BATH_HIP_TRY(ctx, b_fx.reserve((size_t)xoff[(size_t)n] * 4 + 64));
+  // The matrices are for the host (the ensembles' tracebacks).  The kernel is bound by its row chain, not by where its stores
+  // go, so it writes them straight into page-locked host memory: the transfer rides along with the computation (32 B/cell,
+  // ~27 GB/s on the bench block) instead of following it as a copy of its own.  BATH_HIP_FS_REGION_COPY=1: HBM first, then copy.
+  BATH_HIP_TRY(ctx, ctx->pinned[2].reserve((size_t)foff[(size_t)n] * 4 + 64)); BATH_HIP_TRY(ctx, ctx->pinned[3].reserve((size_t)xoff[(size_t)n] * 4 + 64));
+  float *d_f = nullptr, *d_fx = nullptr;
+  {
+    const char *e = std::getenv("BATH_HIP_FS_REGION_COPY");
+    void *pf = nullptr, *px = nullptr;
+    if (!(e && e[0] == '1') && hipHostGetDevicePointer(&pf, ctx->pinned[2].p, 0) == hipSuccess && hipHostGetDevicePointer(&px, ctx->pinned[3].p, 0) == hipSuccess) {
+      d_f = static_cast<float *>(pf); d_fx = static_cast<float *>(px);
+    } else (void)hipGetLastError();
+  }
+  const bool direct = d_f != nullptr;
+  if (!direct) {
+    BATH_HIP_TRY(ctx, b_f.reserve((size_t)foff[(size_t)n] * 4 + 64)); BATH_HIP_TRY(ctx, b_fx.reserve((size_t)xoff[(size_t)n] * 4 + 64));
+    d_f = b_f.as<float>(); d_fx = b_fx.as<float>();
+  }
   BATH_HIP_TRY(ctx, b_off.reserve((size_t)(n + 1) * 3 * sizeof(int64_t))); BATH_HIP_TRY(ctx, b_sc.reserve((size_t)n * 3 * sizeof(float)));
   int64_t *d_foff = b_off.as<int64_t>(), *d_xoff = d_foff + (n + 1);
   BATH_HIP_TRY(ctx, hipMemcpyAsync(d_foff, foff.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
@@ -1883,15 +1899,16 @@ int bath::fs5_region_forward(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, co
     if ((st = fs_set_shmem(ctx, fs5_fwd_kernel<CC, MD>, shmem)) != BATH_OK) return st;
     const int s1 = ctx->span_begin("fs5_fwd_kernel(regions)", ctx->stream, (double)(foff[(size_t)n] / 8), (double)(foff[(size_t)n] / 8) * 32.0);
     hipLaunchKernelGGL((fs5_fwd_kernel<CC, MD>), dim3(grid_dp), dim3(kFsBlock), shmem, ctx->stream, dna->view(), fsdev(om), om->d_loop[0], om->d_move[0], tE, tE, 0, b_sc.as<float>(),
-                       b_f.as<float>(), d_foff, b_fx.as<float>(), d_xoff, cfg_len_amino, jq[0]);
+                       d_f, d_foff, d_fx, d_xoff, cfg_len_amino, jq[0]);
     ctx->span_end(s1, ctx->stream);
   }))
   BATH_HIP_TRY(ctx, hipGetLastError());
   sc->resize((size_t)n);
-  BATH_HIP_TRY(ctx, ctx->pinned[2].reserve((size_t)foff[(size_t)n] * 4 + 64)); BATH_HIP_TRY(ctx, ctx->pinned[3].reserve((size_t)xoff[(size_t)n] * 4 + 64));
   *fwd = ctx->pinned[2].as<float>(); *xmx = ctx->pinned[3].as<float>();      // page-locked: the matrices are a few MB per region
-  BATH_HIP_TRY(ctx, hipMemcpyAsync(ctx->pinned[2].p, b_f.p, (size_t)foff[(size_t)n] * 4, hipMemcpyDeviceToHost, ctx->stream));
-  BATH_HIP_TRY(ctx, hipMemcpyAsync(ctx->pinned[3].p, b_fx.p, (size_t)xoff[(size_t)n] * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (!direct) {
+    BATH_HIP_TRY(ctx, hipMemcpyAsync(ctx->pinned[2].p, b_f.p, (size_t)foff[(size_t)n] * 4, hipMemcpyDeviceToHost, ctx->stream));
+    BATH_HIP_TRY(ctx, hipMemcpyAsync(ctx->pinned[3].p, b_fx.p, (size_t)xoff[(size_t)n] * 4, hipMemcpyDeviceToHost, ctx->stream));
+  }
   BATH_HIP_TRY(ctx, hipMemcpyAsync(sc->data(), b_sc.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
   BATH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return BATH_OK;

@@ -1077,8 +1077,10 @@ extern "C" int bath_hip_pipeline_frameshift(bath_hip_ctx *ctx, const bath_hip_op
   prm.fs_pipe = 1;
   bath_pipeline_stats st_local{};
   FilterState S;
+  StageClock clk;
   int st = run_filters(ctx, om, dna, &prm, &st_local, results, n_results, &S);
   if (st != BATH_OK) return st;
+  clk.lap("fs:   cascade (one part)");
   const int nc = S.hc.cand_count;
   const int M = om->M;
   const double kLn2 = 0.69314718055994529;
@@ -1110,6 +1112,7 @@ extern "C" int bath_hip_pipeline_frameshift(bath_hip_ctx *ctx, const bath_hip_op
     std::sort(h_sel.begin(), h_sel.end(), [](const FsCandRec &a, const FsCandRec &b) { return a.cand < b.cand; });
     std::stable_sort(h_wins.begin(), h_wins.end(), [](const WindowRec &a, const WindowRec &b) { return a.cand != b.cand ? a.cand < b.cand : a.n < b.n; });
   }
+  clk.lap("fs:   F4 survivors + windows to the host");
   struct Key { int64_t w; int strand; bool operator<(const Key &o) const { return w != o.w ? w < o.w : strand < o.strand; } };
   std::map<Key, std::vector<FsOrf>> groups;
   for (const FsCandRec &q : h_sel) {
@@ -1219,6 +1222,7 @@ extern "C" int bath_hip_pipeline_frameshift(bath_hip_ctx *ctx, const bath_hip_op
     }
   }
   const int nw = (int)out.size();
+  clk.lap("fs:   DNA windows (host)");
   int64_t pos_fwd = 0;
   ctx->fs_std_orfs.clear();
   ctx->fs_std_pool = S.W.pool;
@@ -1252,6 +1256,7 @@ extern "C" int bath_hip_pipeline_frameshift(bath_hip_ctx *ctx, const bath_hip_op
     view.d_data = nullptr; view.d_off = nullptr; view.d_len = nullptr;     // borrowed pointers: nothing for a destructor to free
     if (st != BATH_OK) return st;
     BATH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    clk.lap("fs:   gather + bias + 3-codon Forward");
 
     // ---- scores -> P-values -> which branch each window takes (:1425-1464)
     const float *ev3 = fsprofile_evparam(om_fs3);
@@ -1289,6 +1294,7 @@ extern "C" int bath_hip_pipeline_frameshift(bath_hip_ctx *ctx, const bath_hip_op
       }
     }
   }
+  clk.lap("fs:   branch decision (host)");
   st_local.pos_past_fwd = pos_fwd;                                         // in the fs pipeline only this stage counts it (:1468, :1490)
   if (stats) *stats = st_local;
   ctx->fs_windows = out;
