@@ -384,6 +384,15 @@ namespace {
 
 constexpr int kStdMaxRegions = 48;       // regions kept per ORF; an ORF with more reports the true count and the call fails loudly (the reference has no cap)
 
+// the residues of each target of a view, to out + xoff[t] / 6 (a block per target)
+__global__ void gather_residues_kernel(SeqView v, const int64_t *__restrict__ xoff, uint8_t *__restrict__ out) {
+  for (int64_t t = blockIdx.x; t < v.n; t += gridDim.x) {
+    const uint8_t *s = v.data + v.off[t];
+    uint8_t *d = out + xoff[t] / 6;
+    for (int i = threadIdx.x; i < v.len[t]; i += blockDim.x) d[i] = s[i];
+  }
+}
+
 // p7_DomainDecoding (impl_sse/decoding.c:155-196) + region heuristics (p7_domaindef.c:520-533, 642-654), lane per ORF
 __global__ void std_regions_kernel(int64_t n, const int32_t *__restrict__ len, const float *__restrict__ fx, const float *__restrict__ bx,
                                    const int64_t *__restrict__ x_off, const float *__restrict__ pmove_tab, float *__restrict__ work /* 3 floats per row */,
@@ -811,6 +820,7 @@ static int std_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bat
   const int64_t ns = (int64_t)surv.size();
   if (ns == 0) return BATH_OK;
   const int M = om->M;
+  StageClock clk;
 
   // ---- the survivors as a sequence view into the amino-acid streams; both parsers with their special-state rows
   bath_hip_seqs view;
@@ -850,6 +860,7 @@ static int std_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bat
   BATH_HIP_TRY(ctx, hipMemcpyAsync(regions.data(), b_reg.p, regions.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
   BATH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   view.d_data = nullptr; view.d_off = nullptr; view.d_len = nullptr;
+  clk.lap("std:   parsers + regions");
 
   struct Env { int s, i, j; bool clustered; float n2corr; };
   std::vector<Env> envs, mregs;
@@ -878,25 +889,32 @@ static int std_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bat
       mdpoff[(size_t)e + 1] = mdpoff[(size_t)e] + ((int64_t)Lr + 1) * (M + 1) * 3;
     }
     if ((st = upload_view(mv, mxoff, nm)) != BATH_OK) return st;
-    DevBuf &b_mf = ctx->scratch[15], &b_mdpo = ctx->scratch[20], &b_cfg = ctx->scratch[5];
-    BATH_HIP_TRY(ctx, b_mf.reserve((size_t)mdpoff[(size_t)nm] * 4 + 64)); BATH_HIP_TRY(ctx, b_mdpo.reserve((size_t)(nm + 1) * 8)); BATH_HIP_TRY(ctx, b_cfg.reserve((size_t)nm * 4 + 64));
+    DevBuf &b_mdpo = ctx->scratch[20], &b_cfg = ctx->scratch[5];
+    BATH_HIP_TRY(ctx, b_mdpo.reserve((size_t)(nm + 1) * 8)); BATH_HIP_TRY(ctx, b_cfg.reserve((size_t)nm * 4 + 64));
     BATH_HIP_TRY(ctx, b_fx.reserve((size_t)mxoff[(size_t)nm] * 4 + 64)); BATH_HIP_TRY(ctx, b_sc.reserve((size_t)nm * 8)); BATH_HIP_TRY(ctx, b_st.reserve((size_t)nm * 8));
     BATH_HIP_TRY(ctx, hipMemcpyAsync(b_mdpo.p, mdpoff.data(), (size_t)(nm + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
     BATH_HIP_TRY(ctx, hipMemcpyAsync(b_cfg.p, cfg.data(), (size_t)nm * 4, hipMemcpyHostToDevice, ctx->stream));
-    if ((st = launch_fwd_wave(ctx, om, mv.view(), nullptr, nm, b_sc.as<float>(), b_st.as<int32_t>(), nullptr, b_fx.as<float>(), b_idx.as<int64_t>() + nm,
-                              b_mf.as<float>(), b_mdpo.as<int64_t>(), 0, b_cfg.as<int32_t>())) != BATH_OK) return st;
-    BATH_HIP_TRY(ctx, ctx->pinned[0].reserve((size_t)mdpoff[(size_t)nm] * 4 + 64)); BATH_HIP_TRY(ctx, ctx->pinned[1].reserve((size_t)mxoff[(size_t)nm] * 4 + 64));
+    // The matrices, the special-state rows and the regions' residues are for the host (the ensembles' tracebacks): the kernels
+    // write them straight into page-locked host memory, the transfer rides along with the computation.  Residues of region e:
+    // h_res + roff[e], one row's worth of bytes per residue row (roff = the x-row offsets / 6).
+    const size_t x_bytes = ((size_t)mxoff[(size_t)nm] * 4 + 255) / 256 * 256;
+    BATH_HIP_TRY(ctx, ctx->pinned[0].reserve((size_t)mdpoff[(size_t)nm] * 4 + 64)); BATH_HIP_TRY(ctx, ctx->pinned[1].reserve(x_bytes + (size_t)mxoff[(size_t)nm] / 6 + 64));
     float *h_dp = ctx->pinned[0].as<float>(), *h_x = ctx->pinned[1].as<float>();      // page-locked
-    std::vector<uint8_t> h_res;
+    const uint8_t *h_res = reinterpret_cast<const uint8_t *>(ctx->pinned[1].p) + x_bytes;
     std::vector<int64_t> roff((size_t)nm + 1, 0);
-    for (int64_t e = 0; e < nm; e++) roff[(size_t)e + 1] = roff[(size_t)e] + mv.h_len[(size_t)e];
-    h_res.resize((size_t)roff[(size_t)nm] + 1);
-    BATH_HIP_TRY(ctx, hipMemcpyAsync(h_dp, b_mf.p, (size_t)mdpoff[(size_t)nm] * 4, hipMemcpyDeviceToHost, ctx->stream));
-    BATH_HIP_TRY(ctx, hipMemcpyAsync(h_x, b_fx.p, (size_t)mxoff[(size_t)nm] * 4, hipMemcpyDeviceToHost, ctx->stream));
-    for (int64_t e = 0; e < nm; e++)
-      BATH_HIP_TRY(ctx, hipMemcpyAsync(h_res.data() + roff[(size_t)e], d_pool + mv.h_off[(size_t)e], (size_t)mv.h_len[(size_t)e], hipMemcpyDeviceToHost, ctx->stream));
+    for (int64_t e = 0; e <= nm; e++) roff[(size_t)e] = mxoff[(size_t)e] / 6;
+    void *dv_dp = nullptr, *dv_x = nullptr;
+    if (hipHostGetDevicePointer(&dv_dp, ctx->pinned[0].p, 0) != hipSuccess || hipHostGetDevicePointer(&dv_x, ctx->pinned[1].p, 0) != hipSuccess) {
+      ctx->set_error("page-locked host memory is not mapped into the device's address space"); return BATH_EFAIL;
+    }
+    if ((st = launch_fwd_wave(ctx, om, mv.view(), nullptr, nm, b_sc.as<float>(), b_st.as<int32_t>(), nullptr, static_cast<float *>(dv_x), b_idx.as<int64_t>() + nm,
+                              static_cast<float *>(dv_dp), b_mdpo.as<int64_t>(), 0, b_cfg.as<int32_t>())) != BATH_OK) return st;
+    hipLaunchKernelGGL(gather_residues_kernel, dim3((unsigned)std::min<int64_t>(nm, 4096)), dim3(64), 0, ctx->stream, mv.view(), b_idx.as<int64_t>() + nm,
+                       static_cast<uint8_t *>(dv_x) + x_bytes);
+    BATH_HIP_TRY(ctx, hipGetLastError());
     BATH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     mv.d_data = nullptr; mv.d_off = nullptr; mv.d_len = nullptr;
+    clk.lap("std:   region Forward + copy to host");
     // the regions are independent (each ensemble starts from the seed): host threads take them round-robin, results are
     // appended in region order
     if (om->ensure_len_tables(*std::max_element(cfg.begin(), cfg.end())) != BATH_OK) return BATH_EFAIL;
@@ -907,7 +925,7 @@ static int std_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bat
       for (int64_t e = first; e < nm; e += step) {
         const Env &en = mregs[(size_t)e];
         const int Lr = en.j - en.i + 1;
-        if (region_trace_ensemble(om, cfg[(size_t)e], h_res.data() + roff[(size_t)e], Lr, h_dp + mdpoff[(size_t)e], h_x + mxoff[(size_t)e], &n2sc, &cl) != BATH_OK) continue;
+        if (region_trace_ensemble(om, cfg[(size_t)e], h_res + roff[(size_t)e], Lr, h_dp + mdpoff[(size_t)e], h_x + mxoff[(size_t)e], &n2sc, &cl) != BATH_OK) continue;
         for (const auto &c : cl) {
           float corr = 0.f;
           for (int pos = c.first; pos <= c.second; pos++) corr += n2sc[(size_t)pos];     // null2_is_done: p7_domaindef.c:1270-1272
@@ -917,6 +935,7 @@ static int std_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bat
     };
     run_striped(nm, work);
     for (int64_t e = 0; e < nm; e++) envs.insert(envs.end(), found[(size_t)e].begin(), found[(size_t)e].end());
+    clk.lap("std:   ensembles (host threads)");
   }
   const int64_t ne = (int64_t)envs.size();
   if (ne == 0) return BATH_OK;
@@ -988,6 +1007,7 @@ static int std_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bat
   BATH_HIP_TRY(ctx, hipMemcpyAsync(envsc.data(), b_sc.p, (size_t)ne * 4, hipMemcpyDeviceToHost, ctx->stream));
   BATH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   ev.d_data = nullptr; ev.d_off = nullptr; ev.d_len = nullptr;
+  clk.lap("std:   envelope kernels");
 
   // ---- p7_pli_postDomainDef_BATH: coordinates on the sequence, score corrections, P-value
   const int ml = om->max_length;
@@ -1042,6 +1062,7 @@ static int std_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bat
     }
     ctx->fs_domains.push_back(dm);
   }
+  clk.lap("std:   post-processing (host)");
   return BATH_OK;
 }
 
@@ -1058,8 +1079,10 @@ extern "C" int bath_hip_pipeline_hits(bath_hip_ctx *ctx, const bath_hip_oprofile
   bath_pipeline_stats st_local{};
   std::vector<PipelineSurvivor> surv;
   const uint8_t *d_pool = nullptr;
+  StageClock clk;
   int st = pipeline_filters_survivors(ctx, om, dna, &prm, &st_local, &surv, &d_pool);
   if (st != BATH_OK) return st;
+  clk.lap("std: cascade + survivors to the host");
   if (stats) *stats = st_local;
   for (PipelineSurvivor &o : surv) o.win_start = o.start;                  // windowsq is the ORF's own stretch of DNA (p7_pipeline.c:1755)
   if ((st = std_domains(ctx, om, dna, surv, d_pool, st_local.nres, E_report, &nskip)) != BATH_OK) return st;

@@ -143,6 +143,11 @@ int bath::region_trace_ensemble(const bath_hip_oprofile *om, int cfg_L, const ui
   std::vector<Step> tr;
   std::vector<Seg> sp;
   std::vector<float> cnt((size_t)M + 1);
+  // match odds ratios node-major, [k][20]: the expectation sum_k cnt[k] * rf[x][k] of all 20 residues is then one pass over the
+  // nodes of the domain with 20 independent accumulators (each residue's sum still runs over k in ascending order)
+  static thread_local std::vector<float> rft;
+  rft.resize((size_t)(M + 1) * 20);
+  for (int x = 0; x < 20; x++) { const float *e = om->rf.data() + (size_t)x * (M + 1); for (int q = 0; q <= M; q++) rft[(size_t)q * 20 + x] = e[q]; }
   const int step_cap = 4 * (Lr + M) + 64;
   for (int t = 0; t < nsamples; t++) {
     tr.clear();
@@ -207,13 +212,12 @@ int bath::region_trace_ensemble(const bath_hip_oprofile *om, int cfg_L, const ui
       }
       sp.push_back(Seg{t, sqfrom, sqto, hmmfrom, hmmto, 0.f});
       const float norm = (float)(1.0 / (float)Ld);
-      for (int q = 1; q <= M; q++) cnt[(size_t)q] *= norm;
+      for (int q = std::max(hmmfrom, 1); q <= hmmto; q++) cnt[(size_t)q] *= norm;
       float null2[kKp];
-      for (int x = 0; x < 20; x++) {
-        const float *e = om->rf.data() + (size_t)x * (M + 1);
-        float sv = 0.f;
-        for (int q = 1; q <= M; q++) sv += cnt[(size_t)q] * e[q];
-        null2[x] = sv;
+      for (int x = 0; x < 20; x++) null2[x] = 0.f;
+      for (int q = std::max(hmmfrom, 1); q <= hmmto; q++) {                 // cnt is zero outside the domain's nodes
+        const float c = cnt[(size_t)q], *e = rft.data() + (size_t)q * 20;
+        for (int x = 0; x < 20; x++) null2[x] += c * e[x];
       }
       static const int mem[6][2] = {{2, 11}, {7, 9}, {3, 13}, {8, 8}, {1, 1}, {-1, -1}};     // B=DN J=IL Z=EQ O=K U=C X=any
       for (int dx = 0; dx < 6; dx++) {

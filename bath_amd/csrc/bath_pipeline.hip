@@ -819,13 +819,20 @@ static int ensure_parts(bath_hip_ctx *ctx, const bath_hip_seqs *dna, int K) {
   return BATH_OK;
 }
 
-extern "C" int bath_hip_pipeline_filters(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bath_hip_seqs *dna,
-                                         const bath_pipeline_params *prm, bath_pipeline_stats *stats,
-                                         const bath_orf_result **results, int64_t *n_results) {
+// The cascade of a block, as K concurrent parts when the block is large.  <after>(k, lane, part, S) runs on the lane's own host
+// thread right after that part's cascade, with the lane's device state still in place (S: its candidate arrays, windows, pool).
+template <class After>
+static int run_filters_lanes(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bath_hip_seqs *dna,
+                             const bath_pipeline_params *prm, bath_pipeline_stats *stats,
+                             const bath_orf_result **results, int64_t *n_results, std::vector<FilterState> *states, After after) {
   if (!ctx || !om || !dna || !prm) return BATH_EINVAL;
   const int K = pipeline_lane_count(dna);
-  if (K <= 1) return run_filters(ctx, om, dna, prm, stats, results, n_results, nullptr);
-
+  if (K <= 1) {
+    states->assign(1, FilterState{});
+    int st = run_filters(ctx, om, dna, prm, stats, results, n_results, &(*states)[0]);
+    if (st != BATH_OK) return st;
+    return after(0, ctx, dna, (*states)[0]);
+  }
   BATH_HIP_TRY(ctx, hipSetDevice(ctx->device));
   int st = om->ensure_len_tables(dna->maxlen / 3 + 1);            // the mutable state of the profile: fill it before the threads start
   if (st != BATH_OK) return st;
@@ -846,17 +853,22 @@ extern "C" int bath_hip_pipeline_filters(bath_hip_ctx *ctx, const bath_hip_oprof
         if (hipStreamCreateWithPriority(&lane->stream, hipStreamNonBlocking, prio) != hipSuccess) { ctx->set_error("hipStreamCreateWithPriority"); return BATH_EFAIL; }
       }
     }
-    lane->fs_strict = ctx->fs_strict;
     ctx->lanes.push_back(lane);
   }
+  for (bath_hip_ctx *lane : ctx->lanes) lane->fs_strict = ctx->fs_strict;
   if ((st = ensure_parts(ctx, dna, K)) != BATH_OK) return st;
   std::vector<bath_pipeline_stats> pst((size_t)K);
   std::vector<const bath_orf_result *> pres((size_t)K, nullptr);
   std::vector<int64_t> pn((size_t)K, 0);
   std::vector<int> rc((size_t)K, BATH_OK);
+  states->assign((size_t)K, FilterState{});
   std::vector<std::thread> th;
   for (int k = 0; k < K; k++)
-    th.emplace_back([&, k] { rc[(size_t)k] = run_filters(ctx->lanes[(size_t)k], om, dna->parts[(size_t)k], prm, &pst[(size_t)k], results ? &pres[(size_t)k] : nullptr, &pn[(size_t)k], nullptr); });
+    th.emplace_back([&, k] {
+      bath_hip_ctx *lane = ctx->lanes[(size_t)k];
+      rc[(size_t)k] = run_filters(lane, om, dna->parts[(size_t)k], prm, &pst[(size_t)k], results ? &pres[(size_t)k] : nullptr, &pn[(size_t)k], &(*states)[(size_t)k]);
+      if (rc[(size_t)k] == BATH_OK) rc[(size_t)k] = after(k, lane, dna->parts[(size_t)k], (*states)[(size_t)k]);
+    });
   for (std::thread &t : th) t.join();
   for (int k = 0; k < K; k++)
     if (rc[(size_t)k] != BATH_OK) { ctx->set_error(ctx->lanes[(size_t)k]->err); return rc[(size_t)k]; }
@@ -895,6 +907,14 @@ extern "C" int bath_hip_pipeline_filters(bath_hip_ctx *ctx, const bath_hip_oprof
     }
   }
   return BATH_OK;
+}
+
+extern "C" int bath_hip_pipeline_filters(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bath_hip_seqs *dna,
+                                         const bath_pipeline_params *prm, bath_pipeline_stats *stats,
+                                         const bath_orf_result **results, int64_t *n_results) {
+  std::vector<FilterState> states;
+  return run_filters_lanes(ctx, om, dna, prm, stats, results, n_results, &states,
+                           [](int, bath_hip_ctx *, const bath_hip_seqs *, const FilterState &) { return (int)BATH_OK; });
 }
 
 // =================================================================================================
@@ -1025,36 +1045,95 @@ __global__ void fs_select_wins_kernel(const WindowRec *__restrict__ wins, int nw
 
 struct FsOrf {                      // an ORF that passed F4, host side
   int cand;
+  int64_t w = 0;                    // its sequence in the block
+  int strand = 0;
   int64_t aa_off = 0;               // its residues in the amino-acid stream pool
   int32_t start, end, n;            // nt coordinates on the strand being read, residues
   double P;
   float fwd_null;                   // fwdsc - nullsc (pli_tmp->fwdsc, p7_pipeline.c:1782)
-  std::vector<WindowRec> wins;      // hit windows in emission order
+  int32_t wb = 0, we = 0;           // its hit windows, a range of the window list (ordered by start)
 };
 struct DnaWin { int64_t n; int32_t k, length; };
+
+// The ORFs that passed F4 and (frameshift pipeline) their hit windows, from every lane of the cascade: candidate ids are made
+// unique over the lanes, windows are the block's, and aa_off addresses the residues relative to <pool> (the first lane's pool;
+// another lane's pool is another allocation in the same flat address space, its ORFs carry the distance between the two).
+struct SurvivorSet {
+  std::vector<FsCandRec> sel;        // by candidate id
+  std::vector<WindowRec> wins;       // by (candidate id, n)
+  int nc_total = 0;
+  const uint8_t *pool = nullptr;
+  FilterState S0;                    // the first lane's state: the model-dependent tables any lane holds alike
+};
+
+static int select_survivors(bath_hip_ctx *lane, const FilterState &S, bool want_wins, std::vector<FsCandRec> *sel, std::vector<WindowRec> *wins) {
+  sel->clear(); wins->clear();
+  const int nc = S.hc.cand_count;
+  if (nc <= 0) return BATH_OK;
+  const int nwins = want_wins ? std::min(S.hc.win_count, S.W.win_cap) : 0;
+  DevBuf &b_sel = lane->scratch[32];
+  const size_t o_c = 256, o_w = o_c + ((size_t)nc * sizeof(FsCandRec) + 255) / 256 * 256;
+  BATH_HIP_TRY(lane, b_sel.reserve(o_w + (size_t)std::max(nwins, 1) * sizeof(WindowRec) + 256));
+  int *d_cnt = b_sel.as<int>();
+  FsCandRec *d_c = reinterpret_cast<FsCandRec *>(b_sel.as<char>() + o_c);
+  WindowRec *d_w = reinterpret_cast<WindowRec *>(b_sel.as<char>() + o_w);
+  BATH_HIP_TRY(lane, hipMemsetAsync(d_cnt, 0, 256, lane->stream));
+  const int blocks = lane->prop.multiProcessorCount * 4;
+  hipLaunchKernelGGL(fs_select_cands_kernel, dim3(blocks), dim3(256), 0, lane->stream, S.W.cand, nc, d_c, d_cnt);
+  if (nwins > 0) hipLaunchKernelGGL(fs_select_wins_kernel, dim3(blocks), dim3(256), 0, lane->stream, S.W.wins, nwins, S.W.cand.stage, d_w, d_cnt + 1);
+  BATH_HIP_TRY(lane, hipGetLastError());
+  int h_cnt[2] = {0, 0};
+  BATH_HIP_TRY(lane, hipMemcpyAsync(h_cnt, d_cnt, sizeof h_cnt, hipMemcpyDeviceToHost, lane->stream));
+  BATH_HIP_TRY(lane, hipStreamSynchronize(lane->stream));
+  sel->resize((size_t)h_cnt[0]); wins->resize((size_t)h_cnt[1]);
+  if (h_cnt[0]) BATH_HIP_TRY(lane, hipMemcpyAsync(sel->data(), d_c, sel->size() * sizeof(FsCandRec), hipMemcpyDeviceToHost, lane->stream));
+  if (h_cnt[1]) BATH_HIP_TRY(lane, hipMemcpyAsync(wins->data(), d_w, wins->size() * sizeof(WindowRec), hipMemcpyDeviceToHost, lane->stream));
+  BATH_HIP_TRY(lane, hipStreamSynchronize(lane->stream));
+  // the kernels append in completion order: candidate order makes what follows deterministic
+  std::sort(sel->begin(), sel->end(), [](const FsCandRec &a, const FsCandRec &b) { return a.cand < b.cand; });
+  std::stable_sort(wins->begin(), wins->end(), [](const WindowRec &a, const WindowRec &b) { return a.cand != b.cand ? a.cand < b.cand : a.n < b.n; });
+  return BATH_OK;
+}
+
+static int filters_with_survivors(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bath_hip_seqs *dna, const bath_pipeline_params *prm,
+                                  bath_pipeline_stats *stats, const bath_orf_result **results, int64_t *n_results, bool want_wins, SurvivorSet *out) {
+  std::vector<FilterState> states;
+  std::vector<std::vector<FsCandRec>> lsel(8);
+  std::vector<std::vector<WindowRec>> lwin(8);
+  std::vector<int64_t> first(8, 0);
+  int st = run_filters_lanes(ctx, om, dna, prm, stats, results, n_results, &states,
+                             [&](int k, bath_hip_ctx *lane, const bath_hip_seqs *part, const FilterState &S) {
+                               if (k >= 8) return (int)BATH_EFAIL;
+                               first[(size_t)k] = part->is_part ? part->first_window : 0;
+                               return select_survivors(lane, S, want_wins, &lsel[(size_t)k], &lwin[(size_t)k]);
+                             });
+  if (st != BATH_OK) return st;
+  out->sel.clear(); out->wins.clear(); out->nc_total = 0;
+  out->S0 = states.empty() ? FilterState{} : states[0];
+  out->pool = out->S0.W.pool;
+  for (size_t k = 0; k < states.size(); k++) {
+    const int base = out->nc_total;
+    const int64_t dpool = (int64_t)(reinterpret_cast<intptr_t>(states[k].W.pool) - reinterpret_cast<intptr_t>(out->pool));
+    for (FsCandRec q : lsel[k]) { q.cand += base; q.window += first[k]; q.aa_off += dpool; out->sel.push_back(q); }
+    for (WindowRec w : lwin[k]) { w.cand += base; out->wins.push_back(w); }
+    out->nc_total += std::max(states[k].hc.cand_count, 0);
+  }
+  return BATH_OK;
+}
 
 }  // namespace bath
 
 int bath::pipeline_filters_survivors(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bath_hip_seqs *dna, const bath_pipeline_params *prm,
                                      bath_pipeline_stats *stats, std::vector<PipelineSurvivor> *out, const uint8_t **d_pool) {
   out->clear();
-  FilterState S;
-  int st = run_filters(ctx, om, dna, prm, stats, nullptr, nullptr, &S);
+  SurvivorSet sv;
+  int st = filters_with_survivors(ctx, om, dna, prm, stats, nullptr, nullptr, false, &sv);
   if (st != BATH_OK) return st;
-  *d_pool = S.W.pool;
-  const int nc = S.hc.cand_count;
-  if (nc <= 0) return BATH_OK;
-  std::vector<int32_t> h_stage(nc), h_sf(nc), h_startj(nc), h_len(nc);
-  std::vector<int64_t> h_window(nc), h_off(nc);
-  auto pull = [&](void *dst, const void *src, size_t bytes) { return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream); };
-  BATH_HIP_TRY(ctx, pull(h_stage.data(), S.W.cand.stage, (size_t)nc * 4)); BATH_HIP_TRY(ctx, pull(h_sf.data(), S.W.cand.sf, (size_t)nc * 4));
-  BATH_HIP_TRY(ctx, pull(h_startj.data(), S.W.cand.startj, (size_t)nc * 4)); BATH_HIP_TRY(ctx, pull(h_len.data(), S.W.cand.len, (size_t)nc * 4));
-  BATH_HIP_TRY(ctx, pull(h_window.data(), S.W.cand.window, (size_t)nc * 8)); BATH_HIP_TRY(ctx, pull(h_off.data(), S.W.cand.off, (size_t)nc * 8));
-  BATH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  for (int c = 0; c < nc; c++) {
-    if (h_stage[c] != 4) continue;
+  *d_pool = sv.pool;
+  out->reserve(sv.sel.size());
+  for (const FsCandRec &q : sv.sel) {
     PipelineSurvivor o;
-    o.window = h_window[c]; o.aa_off = h_off[c]; o.strand = h_sf[c] / 3; o.start = h_sf[c] % 3 + 3 * h_startj[c] + 1; o.n = h_len[c];
+    o.window = q.window; o.aa_off = q.aa_off; o.strand = q.sf / 3; o.start = q.sf % 3 + 3 * q.startj + 1; o.n = q.len;
     out->push_back(o);
   }
   std::sort(out->begin(), out->end(), [](const PipelineSurvivor &a, const PipelineSurvivor &b) {
@@ -1076,92 +1155,71 @@ extern "C" int bath_hip_pipeline_frameshift(bath_hip_ctx *ctx, const bath_hip_op
   bath_pipeline_params prm = *prm_in;
   prm.fs_pipe = 1;
   bath_pipeline_stats st_local{};
-  FilterState S;
   StageClock clk;
-  int st = run_filters(ctx, om, dna, &prm, &st_local, results, n_results, &S);
+  SurvivorSet sv;
+  int st = filters_with_survivors(ctx, om, dna, &prm, &st_local, results, n_results, true, &sv);
   if (st != BATH_OK) return st;
-  clk.lap("fs:   cascade (one part)");
-  const int nc = S.hc.cand_count;
+  clk.lap("fs:   cascade + F4 survivors and their windows to the host");
+  const FilterState &S = sv.S0;
+  const int nc = sv.nc_total;
   const int M = om->M;
   const double kLn2 = 0.69314718055994529;
 
-  // ---- the ORFs that passed F4, with their hit windows: selected on the device, a few hundred KB to the host
-  const int nwins = std::min(S.hc.win_count, S.W.win_cap);
-  std::vector<FsCandRec> h_sel;
-  std::vector<WindowRec> h_wins;
-  if (nc > 0) {
-    DevBuf &b_sel = ctx->scratch[32];
-    const size_t o_c = 256, o_w = o_c + ((size_t)nc * sizeof(FsCandRec) + 255) / 256 * 256;
-    BATH_HIP_TRY(ctx, b_sel.reserve(o_w + (size_t)std::max(nwins, 1) * sizeof(WindowRec) + 256));
-    int *d_cnt = b_sel.as<int>();
-    FsCandRec *d_c = reinterpret_cast<FsCandRec *>(b_sel.as<char>() + o_c);
-    WindowRec *d_w = reinterpret_cast<WindowRec *>(b_sel.as<char>() + o_w);
-    BATH_HIP_TRY(ctx, hipMemsetAsync(d_cnt, 0, 256, ctx->stream));
-    const int blocks = ctx->prop.multiProcessorCount * 4;
-    hipLaunchKernelGGL(fs_select_cands_kernel, dim3(blocks), dim3(256), 0, ctx->stream, S.W.cand, nc, d_c, d_cnt);
-    if (nwins > 0) hipLaunchKernelGGL(fs_select_wins_kernel, dim3(blocks), dim3(256), 0, ctx->stream, S.W.wins, nwins, S.W.cand.stage, d_w, d_cnt + 1);
-    BATH_HIP_TRY(ctx, hipGetLastError());
-    int h_cnt[2] = {0, 0};
-    BATH_HIP_TRY(ctx, hipMemcpyAsync(h_cnt, d_cnt, sizeof h_cnt, hipMemcpyDeviceToHost, ctx->stream));
-    BATH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    h_sel.resize((size_t)h_cnt[0]); h_wins.resize((size_t)h_cnt[1]);
-    if (h_cnt[0]) BATH_HIP_TRY(ctx, hipMemcpyAsync(h_sel.data(), d_c, h_sel.size() * sizeof(FsCandRec), hipMemcpyDeviceToHost, ctx->stream));
-    if (h_cnt[1]) BATH_HIP_TRY(ctx, hipMemcpyAsync(h_wins.data(), d_w, h_wins.size() * sizeof(WindowRec), hipMemcpyDeviceToHost, ctx->stream));
-    BATH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    // the kernels append in completion order: candidate order makes the host pass below deterministic
-    std::sort(h_sel.begin(), h_sel.end(), [](const FsCandRec &a, const FsCandRec &b) { return a.cand < b.cand; });
-    std::stable_sort(h_wins.begin(), h_wins.end(), [](const WindowRec &a, const WindowRec &b) { return a.cand != b.cand ? a.cand < b.cand : a.n < b.n; });
-  }
-  clk.lap("fs:   F4 survivors + windows to the host");
-  struct Key { int64_t w; int strand; bool operator<(const Key &o) const { return w != o.w ? w < o.w : strand < o.strand; } };
-  std::map<Key, std::vector<FsOrf>> groups;
-  for (const FsCandRec &q : h_sel) {
-    const int strand = q.sf / 3, frame = q.sf % 3;
-    FsOrf o;
-    o.cand = q.cand; o.aa_off = q.aa_off; o.n = q.len; o.start = frame + 3 * q.startj + 1; o.end = o.start + 3 * o.n - 1; o.P = q.P; o.fwd_null = q.fwdsc - q.nullsc;
-    groups[Key{q.window, strand}].push_back(o);
-  }
-  for (auto &g : groups) {
-    // the order in which esl_gencode emits a strand's ORFs: when the closing stop codon is read; ORFs still open at the
-    // end of the sequence follow, frame by frame
-    const int n_seq = dna->h_len[g.first.w];
-    std::stable_sort(g.second.begin(), g.second.end(), [n_seq](const FsOrf &a, const FsOrf &b) {
-      const bool ea = a.end + 3 > n_seq, eb = b.end + 3 > n_seq;
-      if (ea != eb) return !ea;
-      if (!ea) return a.end < b.end;
-      return (a.start - 1) % 3 < (b.start - 1) % 3;
-    });
-  }
+  // ---- the ORFs that passed F4, grouped by (sequence, strand) in the order esl_gencode emits a strand's ORFs: when the closing
+  // stop codon is read; ORFs still open at the end of the sequence follow, frame by frame.  Each ORF's hit windows are a range
+  // of <h_wins> (sorted by candidate, then start).
+  const std::vector<WindowRec> &h_wins = sv.wins;
+  std::vector<FsOrf> orfs_all;
+  orfs_all.reserve(sv.sel.size());
   {
-    std::map<int, std::pair<Key, int>> by_cand;
-    for (auto &g : groups) for (size_t i = 0; i < g.second.size(); i++) by_cand[g.second[i].cand] = {g.first, (int)i};
-    for (const WindowRec &wr : h_wins) {
-      auto it = by_cand.find(wr.cand);
-      if (it != by_cand.end()) groups[it->second.first][(size_t)it->second.second].wins.push_back(wr);
+    size_t wi = 0;
+    for (const FsCandRec &q : sv.sel) {                                      // ascending candidate id, like h_wins
+      const int strand = q.sf / 3, frame = q.sf % 3;
+      FsOrf o;
+      o.cand = q.cand; o.w = q.window; o.strand = strand; o.aa_off = q.aa_off; o.n = q.len; o.start = frame + 3 * q.startj + 1; o.end = o.start + 3 * o.n - 1; o.P = q.P; o.fwd_null = q.fwdsc - q.nullsc;
+      while (wi < h_wins.size() && h_wins[wi].cand < q.cand) wi++;
+      o.wb = (int32_t)wi;
+      while (wi < h_wins.size() && h_wins[wi].cand == q.cand) wi++;
+      o.we = (int32_t)wi;
+      orfs_all.push_back(o);
     }
-    for (auto &g : groups) for (FsOrf &o : g.second)
-      std::stable_sort(o.wins.begin(), o.wins.end(), [](const WindowRec &a, const WindowRec &b) { return a.n < b.n; });
   }
+  std::stable_sort(orfs_all.begin(), orfs_all.end(), [dna](const FsOrf &a, const FsOrf &b) {
+    if (a.w != b.w) return a.w < b.w;
+    if (a.strand != b.strand) return a.strand < b.strand;
+    const int n_seq = dna->h_len[(size_t)a.w];
+    const bool ea = a.end + 3 > n_seq, eb = b.end + 3 > n_seq;
+    if (ea != eb) return !ea;
+    if (!ea) return a.end < b.end;
+    return (a.start - 1) % 3 < (b.start - 1) % 3;
+  });
 
   // ---- p7_pli_BuildDNAWindows + the per-window ORF summary of p7_pli_Frameshift
   std::vector<bath_fs_window> out;
   std::vector<FsWinDev> dev;
-  std::vector<std::vector<PipelineSurvivor>> std_branch_orfs;   // per window: the ORFs the standard branch would take (:1479-1487)
-  for (auto &g : groups) {
-    const int64_t w = g.first.w;
-    const int strand = g.first.strand;
-    const int n_seq = dna->h_len[w];
-    std::vector<FsOrf> &orfs = g.second;
-    std::vector<DnaWin> wl;
-    for (const FsOrf &o : orfs) {
+  std::vector<PipelineSurvivor> std_all;                                      // the ORFs the standard branch would take (:1479-1487) ...
+  std::vector<int32_t> std_begin;                                            // ... of window i: [std_begin[i], std_begin[i+1])
+  out.reserve(orfs_all.size()); dev.reserve(orfs_all.size()); std_all.reserve(orfs_all.size()); std_begin.reserve(orfs_all.size() + 1);
+  std::vector<DnaWin> wl;
+  for (size_t g0 = 0; g0 < orfs_all.size();) {
+    size_t g1 = g0;
+    while (g1 < orfs_all.size() && orfs_all[g1].w == orfs_all[g0].w && orfs_all[g1].strand == orfs_all[g0].strand) g1++;
+    const int64_t w = orfs_all[g0].w;
+    const int strand = orfs_all[g0].strand;
+    const int n_seq = dna->h_len[(size_t)w];
+    const FsOrf *orfs = orfs_all.data() + g0, *orfs_end = orfs_all.data() + g1;
+    g0 = g1;
+    wl.clear();
+    for (const FsOrf *po = orfs; po != orfs_end; po++) {
+      const FsOrf &o = *po;
       int best = -1;
       float best_score = -INFINITY;
-      for (size_t i = 0; i < o.wins.size(); i++) {                          // :486-495
-        const WindowRec &x = o.wins[i];
-        if (x.score > best_score || (x.score == best_score && x.length > (best >= 0 ? o.wins[(size_t)best].length : 0))) { best_score = x.score; best = (int)i; }
+      for (int i = o.wb; i < o.we; i++) {                                    // :486-495
+        const WindowRec &x = h_wins[(size_t)i];
+        if (x.score > best_score || (x.score == best_score && x.length > (best >= 0 ? h_wins[(size_t)best].length : 0))) { best_score = x.score; best = i; }
       }
       int32_t cn, ck, cl;
-      if (best >= 0) { cn = o.wins[(size_t)best].n; ck = o.wins[(size_t)best].k; cl = o.wins[(size_t)best].length; }
+      if (best >= 0) { cn = h_wins[(size_t)best].n; ck = h_wins[(size_t)best].k; cl = h_wins[(size_t)best].length; }
       else if (o.n >= M) { cn = (o.n - M) / 2 + 1; ck = M; cl = M; }        // :500-510: no window, centre of the model
       else { cn = 1; ck = M - ((M - o.n) / 2); cl = o.n; }
       int64_t ws = (int64_t)((double)(uint32_t)cn - (om->max_length * (0.1 + om->prefix_lengths[(size_t)(ck - cl + 1)])) + 1);      // :513
@@ -1195,8 +1253,9 @@ extern "C" int bath_hip_pipeline_frameshift(bath_hip_ctx *ctx, const bath_hip_op
       int orf_cnt = 0, k_min = M, k_max = 0;
       float tot = -INFINITY;
       double P_min = INFINITY;
-      std::vector<PipelineSurvivor> std_orfs;
-      for (const FsOrf &o : orfs) {
+      std_begin.push_back((int32_t)std_all.size());
+      for (const FsOrf *po = orfs; po != orfs_end; po++) {
+        const FsOrf &o = *po;
         int64_t os, oe;
         if (strand) { const int64_t rs = (int64_t)n_seq - o.start + 1, re = (int64_t)n_seq - o.end + 1; os = dstart - (n_seq - re + 1) + 1; oe = dstart - (n_seq - rs + 1) + 1; }
         else { os = dstart + o.start - 1; oe = dstart + o.end - 1; }
@@ -1204,28 +1263,28 @@ extern "C" int bath_hip_pipeline_frameshift(bath_hip_ctx *ctx, const bath_hip_op
         P_min = std::min(P_min, o.P);
         tot = flogsum_host(tot, o.fwd_null);
         orf_cnt++;
-        for (const WindowRec &x : o.wins) { k_min = std::min(k_min, x.k - x.length + 1); k_max = std::max(k_max, x.k); }
+        for (int i = o.wb; i < o.we; i++) { const WindowRec &x = h_wins[(size_t)i]; k_min = std::min(k_min, x.k - x.length + 1); k_max = std::max(k_max, x.k); }
         if (!(o.P > prm.F3)) {                                              // :1483-1487
           PipelineSurvivor ps;
           ps.window = w; ps.aa_off = o.aa_off; ps.strand = strand; ps.start = o.start; ps.n = o.n; ps.win_start = (int32_t)dw.n; ps.fs_window = o.cand;
-          std_orfs.push_back(ps);                                           // fs_window carries the candidate id until the branch is known
+          std_all.push_back(ps);                                            // fs_window carries the candidate id until the branch is known
         }
       }
       r.orf_cnt = orf_cnt; r.k_min = k_min; r.k_max = k_max; r.tot_orfsc = tot; r.P_min = P_min;
       r.P_tot = exp_surv((double)tot / kLn2, om->evparam[BATH_FTAU], om->evparam[BATH_FLAMBDA]);
       out.push_back(r);
-      std_branch_orfs.push_back(std::move(std_orfs));
       FsWinDev d{};
       d.src_off = dna->h_off[w]; d.dst_off = 0; d.seq_n = n_seq; d.start = (int32_t)dw.n; d.len = dw.length; d.strand = strand;
       d.kmin = k_min; d.kmax = k_max;
       dev.push_back(d);
     }
   }
+  std_begin.push_back((int32_t)std_all.size());
   const int nw = (int)out.size();
   clk.lap("fs:   DNA windows (host)");
   int64_t pos_fwd = 0;
   ctx->fs_std_orfs.clear();
-  ctx->fs_std_pool = S.W.pool;
+  ctx->fs_std_pool = sv.pool;
   std::vector<char> aligned((size_t)std::max(nc, 1), 0);                   // oxf_holder[i] == NULL: an overlapping window already took the ORF (:1485)
   if (nw > 0) {
     // ---- windows -> device, bias filter and 3-codon frameshift Forward for all of them
@@ -1284,7 +1343,8 @@ extern "C" int bath_hip_pipeline_frameshift(bath_hip_ctx *ctx, const bath_hip_op
       if (r.P_fs <= prm.F3 && (r.P_null < r.P_tot || (r.P_null == r.P_tot && r.orf_cnt > 1) || r.P_min > prm.F3)) { r.branch = 1; pos_fwd += L; }
       else {
         r.branch = 2;
-        for (PipelineSurvivor ps : std_branch_orfs[(size_t)i]) {
+        for (int32_t z = std_begin[(size_t)i]; z < std_begin[(size_t)i + 1]; z++) {
+          PipelineSurvivor ps = std_all[(size_t)z];
           if (aligned[(size_t)ps.fs_window]) continue;
           aligned[(size_t)ps.fs_window] = 1;
           pos_fwd += (int64_t)ps.n * 3;

@@ -297,3 +297,29 @@ def test_envelope_batches_give_the_same_hits(gpu_ctx, monkeypatch):
         out.append((nskip, [(d.window, d.fs_window, d.ienv, d.jenv, d.iali, d.jali, d.ihmm, d.jhmm, d.envsc, d.oasc, d.domcorrection, d.bitscore, d.lnP,
                              d.n_shifted_codons, d.n_stops, d.pid, d.cigar) for d in dm]))
     assert out[0] == out[1] and len(out[0][1]) >= 10
+
+
+def test_cascade_lanes_give_the_same_frameshift_hits(gpu_ctx, monkeypatch):
+    """Large blocks run the cascade as two concurrent parts (lanes), each selecting its F4 survivors on its own device state;
+    candidate ids, window numbers and residue addresses are merged over the lanes.  One lane and two lanes must give exactly
+    the same DNA windows, branch decisions and hits."""
+    rng = np.random.default_rng(78)
+    path = ol.GOLDEN + "/PTH2.bhmm"
+    model = ol.Model(path, 0)
+    wins = frameshifted_windows(rng, model, n=30)
+    hmm = ba.HMM(path, 0)
+    om = ba.OProfile(gpu_ctx, ba.Profile(hmm))
+    om3 = ba.FSOProfile(gpu_ctx, ba.FSProfile(hmm, 3, ncbi_table=hmm.ct))
+    om5 = ba.FSOProfile(gpu_ctx, ba.FSProfile(hmm, 5, ncbi_table=hmm.ct))
+    pipe = ba.Pipeline(gpu_ctx, om, fs_pipe=True, ncbi_table=hmm.ct)
+    out = []
+    for lanes in ("1", "2", "3"):
+        monkeypatch.setenv("BATH_HIP_LANES", lanes)
+        st, fw, dm, nskip = pipe.run_frameshift_domains(om3, om5, ba.SeqBlock(gpu_ctx, wins))
+        out.append(([getattr(st, k) for k in ("nres", "n_orfs", "n_past_msv", "n_past_bias", "n_past_vit", "n_past_fwd", "pos_past_fwd")], nskip,
+                    [(w.window, w.strand, w.n, w.length, w.orf_cnt, w.k_min, w.k_max, w.branch, w.fwdsc, w.filtersc, w.P_fs, w.P_tot) for w in fw],
+                    [(d.window, d.fs_window, d.ienv, d.jenv, d.iali, d.jali, d.ihmm, d.jhmm, d.envsc, d.oasc, d.domcorrection, d.bitscore, d.lnP,
+                      d.n_shifted_codons, d.n_stops, d.pid, d.cigar) for d in dm]))
+    assert out[0] == out[1] == out[2]
+    assert len(out[0][2]) >= 20 and len(out[0][3]) >= 10
+    assert {w[7] for w in out[0][2]} == {1, 2}                      # both branches taken: the standard branch reads the lanes' residue pools

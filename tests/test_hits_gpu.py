@@ -247,3 +247,24 @@ def test_hits_with_degenerate_nucleotides(ctx):
     pli, odm, per_d, onskip = model.run_pipeline_hits(wins)
     assert (stats.n_orfs, stats.n_past_fwd, stats.pos_past_fwd) == (pli.n_orfs, pli.n_past_fwd, pli.pos_past_fwd)
     assert compare_hits(dm, odm, per_d, nskip, onskip) >= 8
+
+
+def test_cascade_lanes_give_the_same_hits(ctx, monkeypatch):
+    """bath_hip_pipeline_hits on a block cut into concurrent parts (lanes): survivors are selected per lane on the device and
+    merged; the hits must be those of a single pass."""
+    path = ol.GOLDEN + "/Caudal_act.bhmm"
+    model = ol.Model(path, 0)
+    rng = np.random.default_rng(101)
+    wins = []
+    for i, aa in enumerate(common.emit_from_model(rng, model, 30, flank=4, sharpen=2.0)):
+        nt = np.array(common.revtranslate(rng, aa, model.basic), dtype=np.uint8)
+        w = np.concatenate([rng.integers(0, 4, size=80).astype(np.uint8), nt, rng.integers(0, 4, size=50).astype(np.uint8)])
+        wins.append((3 - w[::-1]).astype(np.uint8) if i % 2 else w)
+    wins += common.random_dna(rng, 10, 900)
+    out = []
+    for lanes in ("1", "2", "3"):
+        monkeypatch.setenv("BATH_HIP_LANES", lanes)
+        st, dm, nskip = gpu_hits(ctx, path, 0, wins)
+        out.append((st.n_past_fwd, st.pos_past_fwd, nskip,
+                    sorted((d.window, d.strand, d.ienv, d.jenv, d.iali, d.jali, d.ihmm, d.jhmm, d.envsc, d.oasc, d.ali_columns, d.pid, d.cigar, d.domcorrection, d.bitscore) for d in dm)))
+    assert out[0] == out[1] == out[2] and len(out[0][3]) >= 20
