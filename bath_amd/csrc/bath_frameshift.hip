@@ -52,7 +52,19 @@ namespace bath {
 constexpr int kLogsumTbl = 16000;
 // threads per block of the DP kernels that hold p7_FLogsum's 64 KB table in LDS: 8 waves share one copy, so two blocks = 16 waves
 // fit a CU (4 per SIMD); with 4 waves per block the table limited a CU to 8 waves, and these kernels live on latency hiding
-constexpr int kFsBlock = 512;
+#ifndef BATH_FS_BLOCK
+#define BATH_FS_BLOCK 512
+#endif
+#ifndef BATH_FS_WAVES           /* waves per SIMD the compiler must leave room for when a lane holds <= 3 nodes (0: no constraint) */
+#define BATH_FS_WAVES 4
+#endif
+constexpr int kFsBlock = BATH_FS_BLOCK;
+// Two 512-thread blocks (one 64 KB table each) fit a CU's LDS: 4 waves per SIMD if a wave keeps to 128 VGPRs.  Left alone the
+// compiler takes 134-161 for the straight-line rows (one block per CU, 2 waves per SIMD); told to stay within 128 it spills
+// 7-39 registers.  Measured on the bench's --fs pass (tools/fs_variants.sh): the parsers and Backward gain from the
+// cap (fs3_fwd 9.5 -> 7.6 ms, fs_bwd<3> 7.1 -> 5.4, fs_bwd<5> 6.0 -> 5.4), the 5-codon Forward loses (3.7 -> 5.4: 39 spills
+// in its row chain) and is left uncapped.  Models with more than 3 nodes per lane need the registers.
+constexpr int fs_min_waves(int C) { return (C <= 3 && BATH_FS_WAVES > 0) ? BATH_FS_WAVES : 1; }
 
 struct FsDev {
   int M, pitch, maxcodons;
@@ -70,10 +82,27 @@ __device__ __forceinline__ float flogsum(float a, float b, const float *tbl) {
     if (mn == -INFINITY || (mx - mn) >= 15.7f) return mx;
     return mx + log1pf(expf(mn - mx));
   }
+  // <tbl> is the kernels' LDS copy of the table, ZERO from entry 15700 on (fs_load_logsum_table): the reference's early outs
+  // "mn == -inf or mx - mn >= 15.7 -> mx" are then the look-up itself (mx + 0), and a log-sum is max, |a - b|, min, mul, cvt,
+  // shift, ds_read, add.  (int)(d * 1000.f) >= 15700 exactly when d >= 15.7f: 15.7f * 1000.f rounds to 15700.0f and the float
+  // below 15.7f to 15699.999.  a = b = -inf: |NaN| -> v_min returns 15.999 -> -inf + 0.
+  (void)mn;
+  const float dc = fminf(fabsf(a - b), 15.999f);
+  return mx + tbl[(int)(dc * 1000.f)];
+}
+
+// the same on the unpadded table in global memory (kernels that take a few log-sums per target)
+__device__ __forceinline__ float flogsum_g(float a, float b, const float *tbl) {
+  const float mx = fmaxf(a, b), mn = fminf(a, b);
   const float d = mx - mn;                                    // +inf when mn = -inf, NaN when both are
   const float dc = fminf(d, 15.999f);                         // (v_min_f32 returns the number when one operand is NaN)
   const float t = tbl[(int)(dc * 1000.f)];
   return (mn == -INFINITY || d >= 15.7f) ? mx : mx + t;
+}
+
+// p7_FLogsum's table into LDS, its entries for differences >= 15.7 (which the reference never reads) zeroed
+__device__ __forceinline__ void fs_load_logsum_table(float *s_tbl, const float *g_tbl) {
+  for (int i = threadIdx.x; i < 16000; i += blockDim.x) s_tbl[i] = (i < 15700) ? g_tbl[i] : 0.f;
 }
 
 template <bool EXACT>
@@ -199,13 +228,13 @@ __device__ __forceinline__ float bwd_dnext_strict(F &&dstep, int lane, int M) {
 // tf[node] = {tMM(k-1), tIM(k-1), tDM(k-1), tBM(k-1), tMD(k), tDD(k), tMI(k), tII(k)}
 // ---------------------------------------------------------------------------------------------
 template <int C, int MODE>
-__global__ __launch_bounds__(kFsBlock) void fs3_fwd_kernel(SeqView dna, FsDev p, const float *__restrict__ loop_tab, const float *__restrict__ move_tab,
+__global__ __launch_bounds__(kFsBlock, fs_min_waves(C)) void fs3_fwd_kernel(SeqView dna, FsDev p, const float *__restrict__ loop_tab, const float *__restrict__ move_tab,
                                                       float tEL, float tEM, float *__restrict__ sc, float *__restrict__ xmx, const int64_t *__restrict__ xmx_off, FsJobs jobs) {
   constexpr bool EXACT = (MODE == 1), STRICT = (MODE == 2);   // 0: table + scans, 1: exact log-sums, 2: table in the reference's serial order
   extern __shared__ __attribute__((aligned(16))) char lds[];
   float *s_tbl = reinterpret_cast<float *>(lds);
   float *s_tf = s_tbl + kLogsumTbl;
-  for (int i = threadIdx.x; i < kLogsumTbl; i += blockDim.x) s_tbl[i] = p.logsum[i];
+  fs_load_logsum_table(s_tbl, p.logsum);
   for (int i = threadIdx.x; i < (p.M + 2) * 8; i += blockDim.x) s_tf[i] = p.tf[i];
   __syncthreads();
   const int M = p.M;
@@ -327,7 +356,7 @@ __global__ __launch_bounds__(kFsBlock) void fs5_fwd_kernel(SeqView dna, FsDev p,
   extern __shared__ __attribute__((aligned(16))) char lds[];
   float *s_tbl = reinterpret_cast<float *>(lds);
   float *s_tf = s_tbl + kLogsumTbl;
-  for (int i = threadIdx.x; i < kLogsumTbl; i += blockDim.x) s_tbl[i] = p.logsum[i];
+  fs_load_logsum_table(s_tbl, p.logsum);
   for (int i = threadIdx.x; i < (p.M + 2) * 8; i += blockDim.x) s_tf[i] = p.tf[i];
   __syncthreads();
   const int M = p.M;
@@ -466,14 +495,14 @@ __global__ __launch_bounds__(kFsBlock) void fs5_fwd_kernel(SeqView dna, FsDev p,
 // accumulate-left-to-right rows (L-3, L-4) and the main recursion (generic_fwdback_frameshift.c:1054-1323, 1442-1677).
 // ---------------------------------------------------------------------------------------------
 template <int C, int NCOD, int MODE>
-__global__ __launch_bounds__(kFsBlock) void fs_bwd_kernel(SeqView dna, FsDev p, const float *__restrict__ loop_tab, const float *__restrict__ move_tab,
+__global__ __launch_bounds__(kFsBlock, fs_min_waves(C)) void fs_bwd_kernel(SeqView dna, FsDev p, const float *__restrict__ loop_tab, const float *__restrict__ move_tab,
                                                      float tEL, float tEM, float *__restrict__ sc,
                                                      float *__restrict__ bck, const int64_t *__restrict__ bck_off, float *__restrict__ xmx, const int64_t *__restrict__ xmx_off, FsJobs jobs) {
   constexpr bool EXACT = (MODE == 1), STRICT = (MODE == 2);   // 0: table + scans, 1: exact log-sums, 2: table in the reference's serial order
   extern __shared__ __attribute__((aligned(16))) char lds[];
   float *s_tbl = reinterpret_cast<float *>(lds);
   float *s_tb = s_tbl + kLogsumTbl;
-  for (int i = threadIdx.x; i < kLogsumTbl; i += blockDim.x) s_tbl[i] = p.logsum[i];
+  fs_load_logsum_table(s_tbl, p.logsum);
   for (int i = threadIdx.x; i < (p.M + 2) * 8; i += blockDim.x) s_tb[i] = p.tb[i];
   __syncthreads();
   constexpr bool FIVE = (NCOD == 5);
@@ -1300,15 +1329,15 @@ __global__ void fs5_null2_kernel(int64_t n, const int32_t *__restrict__ len, int
   __shared__ float res[20];
   if (x < 20) {
     float xf = (float)log((double)xs[1]) + lld;
-    xf = flogsum<false>(xf, (float)log((double)xs[4]) + lld, logsum);
-    xf = flogsum<false>(xf, (float)log((double)xs[2]) + lld, logsum);
+    xf = flogsum_g(xf, (float)log((double)xs[4]) + lld, logsum);
+    xf = flogsum_g(xf, (float)log((double)xs[2]) + lld, logsum);
     float v = -INFINITY;
     for (int k = 1; k < M; k++) {
-      v = flogsum<false>(v, ((float)log((double)cs[(size_t)k * 8 + 2]) + lld) + amino[(size_t)x * pitch + k], logsum);
-      v = flogsum<false>(v, (float)log((double)cs[(size_t)k * 8 + 1]) + lld, logsum);
+      v = flogsum_g(v, ((float)log((double)cs[(size_t)k * 8 + 2]) + lld) + amino[(size_t)x * pitch + k], logsum);
+      v = flogsum_g(v, (float)log((double)cs[(size_t)k * 8 + 1]) + lld, logsum);
     }
-    v = flogsum<false>(v, ((float)log((double)cs[(size_t)M * 8 + 2]) + lld) + amino[(size_t)x * pitch + M], logsum);
-    v = flogsum<false>(v, xf, logsum);
+    v = flogsum_g(v, ((float)log((double)cs[(size_t)M * 8 + 2]) + lld) + amino[(size_t)x * pitch + M], logsum);
+    v = flogsum_g(v, xf, logsum);
     res[x] = expf(v);
     out[x] = res[x];
   }
@@ -1543,7 +1572,7 @@ __global__ __launch_bounds__(64) void fs_regions_kernel(int64_t n, const int32_t
   int32_t *out = regions + w * (1 + 3 * kMaxRegions);
   int nreg = 0;
   if (L < 6) { if (lane == 0) out[0] = 0; return; }
-  const float Z = flogsum<false>(B[0 * 5 + XN], flogsum<false>(B[1 * 5 + XN], B[2 * 5 + XN], tbl), tbl);
+  const float Z = flogsum_g(B[0 * 5 + XN], flogsum_g(B[1 * 5 + XN], B[2 * 5 + XN], tbl), tbl);
   if (!(Z > -INFINITY)) { if (lane == 0) out[0] = -1; return; }               // Backward underflow: the window is skipped (p7_pipeline.c:1471)
   auto em = [&](int s, int a, int b) { return expf(F[(size_t)a * 5 + s] + B[(size_t)b * 5 + s] + loop - Z); };
   for (int i = lane; i <= L; i += 64) {
