@@ -126,6 +126,7 @@ struct bath_hip_ctx {
   void span_end(int idx, hipStream_t s) { if (idx >= 0) (void)hipEventRecord(spans[(size_t)idx].b, s); }
   // worker lanes: contexts with their own stream and scratch, used by the pipeline to run parts of a block concurrently
   std::vector<bath_hip_ctx *> lanes;
+  bath_hip_ctx *aux = nullptr;   // a context of its own (stream, scratch) for the standard-branch domains that run beside the frameshift branch
 };
 
 // Device view of a sequence block.

@@ -20,6 +20,7 @@
 // The reference carries om_fs5's length configuration from one window to the next; here the domain decoding always uses
 // the configuration bathsearch starts with (L = 100 residues, multihit; bathsearch.c:797).
 #include <algorithm>
+#include <atomic>
 #include <cfloat>
 #include <chrono>
 #include <cmath>
@@ -42,13 +43,30 @@ const double kLn2 = 0.69314718055994529;
 
 double exp_logsurv(double x, double mu, double lambda) { return x < mu ? 0.0 : -lambda * (x - mu); }
 
-// run work(first, step) on up to 16 host threads (regions of one block are independent)
-template <class F>
-void run_striped(int64_t n, F &&work) {
-  const int T = (int)std::min<int64_t>(std::min<int64_t>(n, 16), std::max(1u, std::thread::hardware_concurrency()));
+// Host threads for the regions of one block (independent of each other).  work(first, step) handles items first, first + step,
+// ...; the threads draw single items from a shared counter, heaviest first (<weight>), so that the threads finish together.
+// Thread count: a quarter of the hardware threads, at most 64 (BATH_HIP_HOST_THREADS overrides; one process per GPU shares
+// the node's cores with the other ranks).
+inline int host_thread_count() {
+  static const int T = [] {
+    const char *e = std::getenv("BATH_HIP_HOST_THREADS");
+    if (e && std::atoi(e) > 0) return std::atoi(e);
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    return (int)std::min(64u, std::max(std::min(hw, 16u), hw / 4));
+  }();
+  return T;
+}
+template <class F, class W>
+void run_striped(int64_t n, F &&work, W &&weight) {
+  const int T = (int)std::min<int64_t>(n, host_thread_count());
   if (T <= 1) { work(0, 1); return; }
+  std::vector<int64_t> order((size_t)n);
+  for (int64_t i = 0; i < n; i++) order[(size_t)i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return weight(a) > weight(b); });
+  std::atomic<int64_t> next{0};
   std::vector<std::thread> th;
-  for (int k = 0; k < T; k++) th.emplace_back([&work, k, T] { work(k, T); });
+  for (int k = 0; k < T; k++)
+    th.emplace_back([&] { for (int64_t j = next.fetch_add(1); j < n; j = next.fetch_add(1)) work(order[(size_t)j], n); });
   for (std::thread &t : th) t.join();
 }
 
@@ -128,6 +146,37 @@ static int fs_branch_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, con
     sel.push_back((int)i); regs.push_back(d);
   }
   if (sel.empty()) return BATH_OK;
+  // ---- the standard branch of the other windows (p7_pipeline.c:1479-1510) needs nothing from the frameshift branch.  The
+  // stages below are chains of latency-bound kernels, a PCIe-bound one and host work that leave most of the GPU idle, so the
+  // standard-branch domains run beside them: own host thread, own context (stream, scratch, page-locked buffers), reading the
+  // cascade's residue pool.  Their domains are put in front of the frameshift branch's, as when they ran first.
+  std::thread std_thread;
+  int std_rc = BATH_OK;
+  int64_t std_nskip = 0;
+  const char *ser = std::getenv("BATH_HIP_FS_STD_SERIAL");
+  if (std_skipped && !ctx->fs_std_orfs.empty() && !(ser && ser[0] == '1')) {
+    if (!ctx->aux && (st = bath_hip_init(ctx->device, &ctx->aux)) != BATH_OK) { ctx->set_error("cannot create the context of the standard branch"); return st; }
+    if ((st = om->ensure_len_tables(dna->maxlen / 3 + 1)) != BATH_OK) return st;      // the profile's mutable state: fill it before the thread starts
+    bath_hip_ctx *aux = ctx->aux;
+    aux->fs_domains.clear(); aux->cigars.clear();
+    const int64_t nres = st_local.nres;
+    std_thread = std::thread([&, aux, nres] {
+      if (hipSetDevice(ctx->device) != hipSuccess) { std_rc = BATH_EFAIL; return; }
+      std_rc = std_domains(aux, om, dna, ctx->fs_std_orfs, ctx->fs_std_pool, nres, E_report, &std_nskip);
+    });
+  }
+  struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } };
+  Joiner std_joiner{std_thread};                                              // also on error returns
+  auto finish_std = [&]() -> int {
+    if (!std_thread.joinable()) return BATH_OK;
+    std_thread.join();
+    if (std_rc != BATH_OK) { ctx->set_error(ctx->aux->err); return std_rc; }
+    const int64_t shift = (int64_t)ctx->cigars.size();
+    for (bath_fs_domain dm : ctx->aux->fs_domains) { dm.cigar_off += shift; ctx->fs_domains.push_back(dm); }
+    ctx->cigars += ctx->aux->cigars;
+    *std_skipped = std_nskip;
+    return BATH_OK;
+  };
   OrfTablesDev tt{};
   if ((st = orf_tables_upload(ctx, prm->ncbi_table, &tt)) != BATH_OK) return st;
   const int nsel = (int)sel.size();
@@ -199,11 +248,11 @@ static int fs_branch_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, con
         }
       };
       StageClock eclk;
-      run_striped((int64_t)mregs.size(), work);
+      run_striped((int64_t)mregs.size(), work, [&](int64_t e) { return rregs[(size_t)e].len; });
       eclk.lap("fs:   (ensemble threads, start to end)");
     });
   }
-  struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{ensembles};      // also on error returns
+  Joiner joiner{ensembles};                                                  // also on error returns
 
   // ---- envelopes: Forward, Backward, decoding, optimal accuracy, null2 on the GPU (unihit, length Ld/3)
   std::vector<FsWinDev> eregs;
@@ -267,17 +316,13 @@ static int fs_branch_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, con
     done = n_single;
     clk.lap("fs: envelope kernels + traces (single-domain regions)");
   }
-  if (std_skipped && ensembles.joinable()) {
-    int64_t nskip_std = 0;
-    if ((st = std_domains(ctx, om, dna, ctx->fs_std_orfs, ctx->fs_std_pool, st_local.nres, E_report, &nskip_std)) != BATH_OK) return st;
-    *std_skipped = nskip_std;
-    clk.lap("fs: standard-branch domains (during the ensembles)");
-  }
   if (ensembles.joinable()) {
     ensembles.join();
     for (size_t e = 0; e < mregs.size(); e++) envs.insert(envs.end(), found[e].begin(), found[e].end());
-    clk.lap("fs: ensembles (host threads), remainder after the overlap");
+    clk.lap("fs: ensembles (host threads)");
   }
+  if ((st = finish_std()) != BATH_OK) return st;
+  clk.lap("fs: standard-branch domains (own thread and stream), remainder");
   const int nenv = (int)envs.size();
   if (nenv == 0) return BATH_OK;
   if (nenv > done && (st = run_envelopes(done, nenv)) != BATH_OK) return st;
@@ -933,7 +978,7 @@ static int std_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bat
         }
       }
     };
-    run_striped(nm, work);
+    run_striped(nm, work, [&](int64_t e) { return mv.h_len[(size_t)e]; });
     for (int64_t e = 0; e < nm; e++) envs.insert(envs.end(), found[(size_t)e].begin(), found[(size_t)e].end());
     clk.lap("std:   ensembles (host threads)");
   }

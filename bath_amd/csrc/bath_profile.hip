@@ -127,6 +127,7 @@ extern "C" void bath_hip_finalize(bath_hip_ctx *ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   for (bath_hip_ctx *lane : ctx->lanes) bath_hip_finalize(lane);
   ctx->lanes.clear();
+  if (ctx->aux) { bath_hip_finalize(ctx->aux); ctx->aux = nullptr; }
   for (auto &b : ctx->scratch) b.release();
   for (auto &b : ctx->pinned) b.release();
   ctx->results_pinned.release();

@@ -11,7 +11,7 @@ rm -rf $OUT; mkdir -p $OUT
 BATH_HIP_TIMING=1 python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline > $OUT/bench_plain.json 2> $OUT/bench_stage_laps.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline > $OUT/bench_under_prof.log 2>&1
 export BATH_HIP_LANES=1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats1 -o bench1 -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-fs > $OUT/bench_under_prof_1lane.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats1 -o bench1 -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-fs --no-streamed > $OUT/bench_under_prof_1lane.log 2>&1
 P="python3 bench.py --steps 2 --warmup 0 --no-cpu-baseline --windows 200000 --fs-windows 200000"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $P > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $P > $OUT/pmc_write.log 2>&1
