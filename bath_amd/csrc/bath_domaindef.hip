@@ -27,6 +27,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <sched.h>
 #include <thread>
 #include <vector>
 
@@ -45,14 +46,17 @@ double exp_logsurv(double x, double mu, double lambda) { return x < mu ? 0.0 : -
 
 // Host threads for the regions of one block (independent of each other).  work(first, step) handles items first, first + step,
 // ...; the threads draw single items from a shared counter, heaviest first (<weight>), so that the threads finish together.
-// Thread count: a quarter of the hardware threads, at most 64 (BATH_HIP_HOST_THREADS overrides; one process per GPU shares
-// the node's cores with the other ranks).
+// Thread count: the CPUs this process may run on (its affinity mask, not the machine's thread count: a GPU box hands a job a
+// slice of its cores), at most 64; BATH_HIP_HOST_THREADS overrides.
 inline int host_thread_count() {
   static const int T = [] {
     const char *e = std::getenv("BATH_HIP_HOST_THREADS");
     if (e && std::atoi(e) > 0) return std::atoi(e);
-    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-    return (int)std::min(64u, std::max(std::min(hw, 16u), hw / 4));
+    int usable = 0;
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) usable = CPU_COUNT(&set);
+    if (usable <= 0) usable = (int)std::max(1u, std::thread::hardware_concurrency());
+    return std::min(64, std::max(1, usable));
   }();
   return T;
 }

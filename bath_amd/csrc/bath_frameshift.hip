@@ -923,8 +923,11 @@ __global__ __launch_bounds__(256) void fs5_oa_kernel(SeqView dna, int M, const f
 // two.  Lanes own C contiguous nodes (the OA recursion's layout); the row's normalising sum is a wave reduction; null2's
 // column sums stay in registers (C <= 4) and are written once per envelope.
 // ---------------------------------------------------------------------------------------------
+#ifndef BATH_FS_OA_WAVES
+#define BATH_FS_OA_WAVES 2
+#endif
 template <int C>
-__global__ __launch_bounds__(256) void fs5_decode_oa_kernel(SeqView dna, int M, const float *__restrict__ tf, const float *__restrict__ loop_tab, const float *__restrict__ bcksc,
+__global__ __launch_bounds__(256, (C <= 3 ? BATH_FS_OA_WAVES : 1)) void fs5_decode_oa_kernel(SeqView dna, int M, const float *__restrict__ tf, const float *__restrict__ loop_tab, const float *__restrict__ bcksc,
                                                             float *__restrict__ fwd, const int64_t *__restrict__ fwd_off, float *__restrict__ fx, const int64_t *__restrict__ x_off,
                                                             const float *__restrict__ bck, const int64_t *__restrict__ bck_off, const float *__restrict__ bx,
                                                             float *__restrict__ colsum /* [n][(M+1)*8 + 8], zeroed */, float *__restrict__ oa, float *__restrict__ oasc,

@@ -909,6 +909,23 @@ static int run_filters_lanes(bath_hip_ctx *ctx, const bath_hip_oprofile *om, con
   return BATH_OK;
 }
 
+// experiment: every lane runs its part <reps> times back to back (what a pipelined block loop would look like in steady state)
+extern "C" int bath_hip_pipeline_filters_repeat(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bath_hip_seqs *dna,
+                                                const bath_pipeline_params *prm, int reps, bath_pipeline_stats *stats) {
+  std::vector<FilterState> states;
+  int st = run_filters_lanes(ctx, om, dna, prm, stats, nullptr, nullptr, &states,
+                             [&](int, bath_hip_ctx *lane, const bath_hip_seqs *part, const FilterState &) {
+                               for (int r = 1; r < reps; r++) {
+                                 bath_pipeline_stats s2{};
+                                 int64_t n2 = 0;
+                                 const int rc = run_filters(lane, om, part, prm, &s2, nullptr, &n2, nullptr);
+                                 if (rc != BATH_OK) return rc;
+                               }
+                               return (int)BATH_OK;
+                             });
+  return st;
+}
+
 extern "C" int bath_hip_pipeline_filters(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bath_hip_seqs *dna,
                                          const bath_pipeline_params *prm, bath_pipeline_stats *stats,
                                          const bath_orf_result **results, int64_t *n_results) {
