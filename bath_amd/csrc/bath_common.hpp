@@ -50,12 +50,16 @@ struct DevBuf {
 struct HostBuf {
   void *p = nullptr;
   size_t cap = 0;
-  hipError_t reserve(size_t bytes) {
-    if (bytes <= cap) return hipSuccess;
+  // coherent: fine-grained memory, for buffers a KERNEL writes and the host reads while the kernel is still running (device
+  // stores go straight out instead of sitting in L2 until the end of the kernel; __threadfence_system() orders them)
+  bool coherent = false;
+  hipError_t reserve(size_t bytes, bool want_coherent = false) {
+    if (bytes <= cap && (coherent || !want_coherent)) return hipSuccess;
     if (p) (void)hipHostFree(p);
     p = nullptr; cap = 0;
+    coherent = coherent || want_coherent;
     size_t want = bytes + bytes / 4 + 256;
-    hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+    hipError_t e = hipHostMalloc(&p, want, coherent ? (hipHostMallocCoherent | hipHostMallocMapped | hipHostMallocPortable) : hipHostMallocDefault);
     if (e == hipSuccess) cap = want;
     return e;
   }

@@ -214,6 +214,7 @@ static int fs_branch_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, con
   // ---- multi-domain regions (p7_domaindef.c:396-455): Forward of the region in the multihit configuration (GPU), ensemble of
   // stochastic tracebacks and clustering (host, bath_ensemble.hip); every cluster is an envelope
   std::thread ensembles;
+  Joiner joiner{ensembles};                                                  // also on error returns
   std::vector<std::vector<Env>> found;
   if (!mregs.empty()) {
     std::vector<FsWinDev> rregs(mregs.size());
@@ -223,26 +224,31 @@ static int fs_branch_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, con
       rregs[e] = d;
     }
     const float *h_f = nullptr, *h_x = nullptr;                              // pinned buffers of the context
+    const int *h_done = nullptr;
+    const float *h_sc_live = nullptr;
     std::vector<float> h_sc;
     std::vector<int64_t> foff, xoff;
     {
       bath_hip_seqs view;
       if ((st = fs_gather_view(ctx, dna, rregs, tt.comp, &view, nullptr)) != BATH_OK) return st;
-      st = fs5_region_forward(ctx, om_fs5, &view, 100, &h_f, &foff, &h_x, &xoff, &h_sc);      // saveL: the configuration bathsearch starts with
+      // returns after the launch: a region's ensemble starts as soon as ITS matrix has landed in host memory (h_done[e]), so the
+      // tracebacks run while the kernel is still streaming the other regions over PCIe (longest regions first, on both sides)
+      st = fs5_region_forward(ctx, om_fs5, &view, 100, &h_f, &foff, &h_x, &xoff, &h_sc, &h_done, &h_sc_live);      // saveL: the configuration bathsearch starts with
       view.d_data = nullptr; view.d_off = nullptr; view.d_len = nullptr;
       if (st != BATH_OK) return st;
     }
-    clk.lap("fs: region Forward + copy to host");
     const float pm = (2.0f + 1.0f) / (100.0f + 2.0f + 1.0f);                 // p7_fs_ReconfigLength(L = 100), multihit (nj = 1)
     const float xNL = (float)std::log((double)(1.0f - pm)), xNM = (float)std::log((double)pm), xE = (float)-kLn2;
     found.assign(mregs.size(), {});
     // The ensembles are host work (200 dependent tracebacks per region from one random-number stream); the envelopes of the
     // single-domain regions do not depend on them, so their kernels run on the GPU meanwhile.
-    ensembles = std::thread([&, h_f, h_x, xNL, xNM, xE, foff, xoff, h_sc, rregs] {
+    { const char *lv = std::getenv("BATH_HIP_FS_LIVE"); if (lv && lv[0] == '0') (void)hipStreamSynchronize(ctx->stream); }
+    ensembles = std::thread([&, h_f, h_x, xNL, xNM, xE, foff, xoff, h_done, h_sc_live, rregs] {
       auto work = [&](int64_t first, int64_t step) {
         std::vector<std::pair<int, int>> cl;
         for (size_t e = (size_t)first; e < mregs.size(); e += (size_t)step) {
-          if (!(h_sc[e] > -INFINITY)) continue;                               // Forward underflow: no valid traces for this region (:413)
+          while (!__atomic_load_n(h_done + e, __ATOMIC_ACQUIRE)) std::this_thread::yield();      // this region's matrix is still on its way
+          if (!(h_sc_live[e] > -INFINITY)) continue;                          // Forward underflow: no valid traces for this region (:413)
           const int Lr = rregs[e].len;
           if (fs_region_trace_ensemble(h5.M, h5.tsc, xNL, xNM, xE, mregs[e].i, Lr, h_f + foff[e], h_x + xoff[e], &cl) != BATH_OK) continue;
           for (const auto &c : cl) {
@@ -252,11 +258,20 @@ static int fs_branch_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, con
         }
       };
       StageClock eclk;
-      run_striped((int64_t)mregs.size(), work, [&](int64_t e) { return rregs[(size_t)e].len; });
+      // shortest region first: that is the order in which their matrices finish arriving (all regions advance together, a wave
+      // each, sharing the PCIe link), so a thread rarely waits for the region it drew
+      run_striped((int64_t)mregs.size(), work, [&](int64_t e) { return -rregs[(size_t)e].len; });
       eclk.lap("fs:   (ensemble threads, start to end)");
     });
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) {                    // the region Forward itself (the ensembles are already at work)
+      for (size_t e = 0; e < mregs.size(); e++) {                             // release the threads waiting for matrices that will not come
+        const_cast<float *>(h_sc_live)[e] = -INFINITY;
+        __atomic_store_n(const_cast<int *>(h_done) + e, 1, __ATOMIC_RELEASE);
+      }
+      ctx->set_error("region Forward failed"); return BATH_EFAIL;
+    }
+    clk.lap("fs: region Forward -> host memory");
   }
-  Joiner joiner{ensembles};                                                  // also on error returns
 
   // ---- envelopes: Forward, Backward, decoding, optimal accuracy, null2 on the GPU (unihit, length Ld/3)
   std::vector<FsWinDev> eregs;

@@ -351,7 +351,8 @@ template <int C, int MODE>
 __global__ __launch_bounds__(kFsBlock) void fs5_fwd_kernel(SeqView dna, FsDev p, const float *__restrict__ loop_tab, const float *__restrict__ move_tab,
                                                       float tEL, float tEM, int c5_compat, float *__restrict__ sc,
                                                       float *__restrict__ fwd, const int64_t *__restrict__ fwd_off, float *__restrict__ xmx, const int64_t *__restrict__ xmx_off,
-                                                      int cfg_len /* >= 0: the amino length the model is configured for, instead of L/3 */, FsJobs jobs) {
+                                                      int cfg_len /* >= 0: the amino length the model is configured for, instead of L/3 */, FsJobs jobs,
+                                                      int *__restrict__ done = nullptr /* host-visible: done[job] = 1 once the job's matrix and score have landed */) {
   constexpr bool EXACT = (MODE == 1), STRICT = (MODE == 2);   // 0: table + scans, 1: exact log-sums, 2: table in the reference's serial order
   extern __shared__ __attribute__((aligned(16))) char lds[];
   float *s_tbl = reinterpret_cast<float *>(lds);
@@ -367,7 +368,11 @@ __global__ __launch_bounds__(kFsBlock) void fs5_fwd_kernel(SeqView dna, FsDev p,
     const uint8_t *d = dna.data + dna.off[job];
     float *fo = fwd + fwd_off[job];
     float *xo = xmx + xmx_off[job];
-    if (L < 5) { if (lane == 0) sc[job] = -INFINITY; continue; }
+    if (L < 5) {
+      if (lane == 0) sc[job] = -INFINITY;
+      if (done) { __threadfence_system(); if (lane == 0) __hip_atomic_store(done + job, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+      continue;
+    }
     const int Lc = cfg_len >= 0 ? cfg_len : L / 3;
     const float tNL = loop_tab[Lc], tNM = move_tab[Lc], tJL = tNL, tJM = tNM, tCL = tNL, tCM = tNM;
     float Mr[3][C], Ir[3][C], Dr1[C], iv[4][C];       // M,I of rows i-1..i-3 (C0 totals); D of row i-1; IVX(i-1..i-4)
@@ -484,6 +489,10 @@ __global__ __launch_bounds__(kFsBlock) void fs5_fwd_kernel(SeqView dna, FsDev p,
       }
     }
     if (lane == 0) sc[job] = LS(cL, LS(cL1 + tCL, cL2 + tCL)) + tCM;
+    if (done) {                                                  // every lane's stores first (system scope), then the flag
+      __threadfence_system();
+      if (lane == 0) __hip_atomic_store(done + job, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
 #undef LS
 }
@@ -1751,7 +1760,7 @@ extern "C" int bath_hip_fs5_forward_full(bath_hip_ctx *ctx, const bath_hip_fspro
   const float *h_f = nullptr, *h_x = nullptr;
   std::vector<int64_t> foff, xoff;
   std::vector<float> h_sc;
-  const int st = bath::fs5_region_forward(ctx, om, dna, cfg_len_amino, &h_f, &foff, &h_x, &xoff, &h_sc);
+  const int st = bath::fs5_region_forward(ctx, om, dna, cfg_len_amino, &h_f, &foff, &h_x, &xoff, &h_sc, nullptr, nullptr);
   if (st != BATH_OK) return st;
   std::memcpy(sc, h_sc.data(), (size_t)dna->n * sizeof(float));
   if (fwd) std::memcpy(fwd, h_f, (size_t)foff[(size_t)dna->n] * sizeof(float));
@@ -1886,7 +1895,10 @@ int bath::fs5_envelopes_ex(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, cons
 // saved length), matrices and special-state rows copied to the host for the stochastic-trace ensemble (bath_ensemble.hip).
 // fwd: (L+1) x (M+1) x {D, I, M_C0, M_C1..M_C5}; xmx: (L+1) x {E,N,J,B,C}.  sc[e] = -inf: no path (the region is dropped).
 int bath::fs5_region_forward(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, const bath_hip_seqs *dna, int cfg_len_amino,
-                             const float **fwd, std::vector<int64_t> *fwd_off, const float **xmx, std::vector<int64_t> *xmx_off, std::vector<float> *sc) {
+                             const float **fwd, std::vector<int64_t> *fwd_off, const float **xmx, std::vector<int64_t> *xmx_off, std::vector<float> *sc,
+                             const int **done_flags, const float **sc_live) {
+  // done_flags != nullptr: return right after the launch.  *done_flags (page-locked, one int per region) turns 1 when that region's
+  // matrix, rows and score (*sc_live) have landed in host memory; the caller synchronises the stream before it reuses the buffers.
   const int64_t n = dna->n;
   const int M = om->M;
   int st = om->ensure_len(std::max(dna->maxlen / 3 + 1, cfg_len_amino));
@@ -1901,7 +1913,8 @@ int bath::fs5_region_forward(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, co
   // The matrices are for the host (the ensembles' tracebacks).  The kernel is bound by its row chain, not by where its stores
   // go, so it writes them straight into page-locked host memory: the transfer rides along with the computation (32 B/cell,
   // ~27 GB/s on the bench block) instead of following it as a copy of its own.  BATH_HIP_FS_REGION_COPY=1: HBM first, then copy.
-  BATH_HIP_TRY(ctx, ctx->pinned[2].reserve((size_t)foff[(size_t)n] * 4 + 64)); BATH_HIP_TRY(ctx, ctx->pinned[3].reserve((size_t)xoff[(size_t)n] * 4 + 64));
+  const size_t x_bytes = ((size_t)xoff[(size_t)n] * 4 + 255) / 256 * 256;     // then: done flags [n], scores [n]
+  BATH_HIP_TRY(ctx, ctx->pinned[2].reserve((size_t)foff[(size_t)n] * 4 + 64, true)); BATH_HIP_TRY(ctx, ctx->pinned[3].reserve(x_bytes + (size_t)n * 8 + 64, true));
   float *d_f = nullptr, *d_fx = nullptr;
   {
     const char *e = std::getenv("BATH_HIP_FS_REGION_COPY");
@@ -1911,6 +1924,13 @@ int bath::fs5_region_forward(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, co
     } else (void)hipGetLastError();
   }
   const bool direct = d_f != nullptr;
+  int *h_done = reinterpret_cast<int *>(static_cast<char *>(ctx->pinned[3].p) + x_bytes);
+  float *h_sc = reinterpret_cast<float *>(h_done + n);
+  const bool live = direct && done_flags != nullptr;
+  if (done_flags) { *done_flags = h_done; *sc_live = h_sc; }
+  for (int64_t i = 0; i < n; i++) h_done[i] = 0;
+  int *d_done = live ? reinterpret_cast<int *>(reinterpret_cast<char *>(d_fx) + x_bytes) : nullptr;
+  float *d_sc_out = live ? reinterpret_cast<float *>(d_done + n) : b_sc.as<float>();
   if (!direct) {
     BATH_HIP_TRY(ctx, b_f.reserve((size_t)foff[(size_t)n] * 4 + 64)); BATH_HIP_TRY(ctx, b_fx.reserve((size_t)xoff[(size_t)n] * 4 + 64));
     d_f = b_f.as<float>(); d_fx = b_fx.as<float>();
@@ -1930,18 +1950,20 @@ int bath::fs5_region_forward(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, co
   BATH_FS_SWITCH(Cv, BATH_FS_MODE(mode, {
     if ((st = fs_set_shmem(ctx, fs5_fwd_kernel<CC, MD>, shmem)) != BATH_OK) return st;
     const int s1 = ctx->span_begin("fs5_fwd_kernel(regions)", ctx->stream, (double)(foff[(size_t)n] / 8), (double)(foff[(size_t)n] / 8) * 32.0);
-    hipLaunchKernelGGL((fs5_fwd_kernel<CC, MD>), dim3(grid_dp), dim3(kFsBlock), shmem, ctx->stream, dna->view(), fsdev(om), om->d_loop[0], om->d_move[0], tE, tE, 0, b_sc.as<float>(),
-                       d_f, d_foff, d_fx, d_xoff, cfg_len_amino, jq[0]);
+    hipLaunchKernelGGL((fs5_fwd_kernel<CC, MD>), dim3(grid_dp), dim3(kFsBlock), shmem, ctx->stream, dna->view(), fsdev(om), om->d_loop[0], om->d_move[0], tE, tE, 0, d_sc_out,
+                       d_f, d_foff, d_fx, d_xoff, cfg_len_amino, jq[0], d_done);
     ctx->span_end(s1, ctx->stream);
   }))
   BATH_HIP_TRY(ctx, hipGetLastError());
   sc->resize((size_t)n);
   *fwd = ctx->pinned[2].as<float>(); *xmx = ctx->pinned[3].as<float>();      // page-locked: the matrices are a few MB per region
+  if (live) return BATH_OK;                                                  // the flags tell the rest
   if (!direct) {
     BATH_HIP_TRY(ctx, hipMemcpyAsync(ctx->pinned[2].p, b_f.p, (size_t)foff[(size_t)n] * 4, hipMemcpyDeviceToHost, ctx->stream));
     BATH_HIP_TRY(ctx, hipMemcpyAsync(ctx->pinned[3].p, b_fx.p, (size_t)xoff[(size_t)n] * 4, hipMemcpyDeviceToHost, ctx->stream));
   }
   BATH_HIP_TRY(ctx, hipMemcpyAsync(sc->data(), b_sc.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
   BATH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (done_flags) for (int64_t i = 0; i < n; i++) { h_sc[i] = (*sc)[(size_t)i]; h_done[i] = 1; }
   return BATH_OK;
 }

@@ -100,7 +100,8 @@ int region_trace_ensemble(const bath_hip_oprofile *om, int cfg_L, const uint8_t 
 int fs_region_trace_ensemble(int M, const float *tsc, float xNL, float xNM, float xE, int ireg, int Lr, const float *fwd, const float *fx,
                              std::vector<std::pair<int, int>> *env);
 int fs5_region_forward(bath_hip_ctx *ctx, const bath_hip_fsprofile *om5, const bath_hip_seqs *dna, int cfg_len_amino,
-                       const float **fwd, std::vector<int64_t> *fwd_off, const float **xmx, std::vector<int64_t> *xmx_off, std::vector<float> *sc);
+                       const float **fwd, std::vector<int64_t> *fwd_off, const float **xmx, std::vector<int64_t> *xmx_off, std::vector<float> *sc,
+                       const int **done_flags, const float **sc_live);
 
 // ---- six-frame translation + ORF work list (bath_orfs.hip)
 struct OrfRec {                   // one ORF of the length-sorted work list
