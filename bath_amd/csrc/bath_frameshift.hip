@@ -347,7 +347,7 @@ __global__ __launch_bounds__(kFsBlock, fs_min_waves(C)) void fs3_fwd_kernel(SeqV
 // IVX(i,k) collects the paths leaving row i-1; codon length c reads IVX(i-c+1).
 // c5_compat selects the ring slot the generic reference reads for 5-nt codons.
 // ---------------------------------------------------------------------------------------------
-template <int C, int MODE>
+template <int C, int MODE, bool UNIHIT = false>
 __global__ __launch_bounds__(kFsBlock) void fs5_fwd_kernel(SeqView dna, FsDev p, const float *__restrict__ loop_tab, const float *__restrict__ move_tab,
                                                       float tEL, float tEM, int c5_compat, float *__restrict__ sc,
                                                       float *__restrict__ fwd, const int64_t *__restrict__ fwd_off, float *__restrict__ xmx, const int64_t *__restrict__ xmx_off,
@@ -473,6 +473,12 @@ __global__ __launch_bounds__(kFsBlock) void fs5_fwd_kernel(SeqView dna, FsDev p,
       else {
         nN = xN[2] + tNL; nJ = LS(xJ[2] + tJL, xE + tEL); nC = LS(xC[2] + tCL, xE + tEM);
         nB = LS(nN + tNM, nJ + tJM);
+      }
+      if constexpr (UNIHIT) {
+        // unihit (tEL = -inf): J is unreachable, J(i) = -inf and B(i) = N(i) + tNM -- the values above, said without reading E(i).
+        // The row's E reduction (C log-sums per lane + 6 across the wave) then feeds C(i) only and leaves the chain that the
+        // next row waits for.
+        nJ = -INFINITY; nB = nN + tNM;
       }
       if (lane == 0) { xo[i * 5 + 0] = xE; xo[i * 5 + 1] = nN; xo[i * 5 + 2] = nJ; xo[i * 5 + 3] = nB; xo[i * 5 + 4] = nC; }
       xN[2] = xN[1]; xN[1] = xN[0]; xN[0] = nN;
@@ -640,7 +646,10 @@ __global__ __launch_bounds__(kFsBlock, fs_min_waves(C)) void fs_bwd_kernel(SeqVi
         }
         if (tail) { xJn = xBn + tJM; xNn = xBn + tNM; xCn = tCL + tCM; }
         else { xJn = LS(xJ3[2] + tJL, xBn + tJM); xCn = xC3[2] + tCL; xNn = LS(xN3[2] + tNL, xBn + tNM); }
-        xE = LS(xJn + tEL, xCn + tEM);
+        // NCOD = 5 is the envelopes' kernel, always unihit (tEL = -inf): E(i) = C(i) + tEM, said without reading J(i) -- so the row's
+        // B reduction feeds N(i) and J(i) only and leaves the chain M/D/I wait for
+        if constexpr (FIVE) xE = xCn + tEM;
+        else xE = LS(xJn + tEL, xCn + tEM);
         // ivx at node+1 for every node of the lane
         float ivNext = __shfl_down(ivx[0], 1, 64);
         if (lane == 63) ivNext = -INFINITY;
@@ -1814,10 +1823,10 @@ int bath::fs5_envelopes_ex(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, cons
   if ((st = fs_fork(ctx)) != BATH_OK) return st;                                // Backward on the side stream, concurrently with Forward
   BATH_FS_SWITCH(Cv, {
     BATH_FS_MODE(logsum_mode, {
-      if ((st = fs_set_shmem(ctx, fs5_fwd_kernel<CC, MD>, shmem)) != BATH_OK) return st;
+      if ((st = fs_set_shmem(ctx, fs5_fwd_kernel<CC, MD, true>, shmem)) != BATH_OK) return st;
       if ((st = fs_set_shmem(ctx, fs_bwd_kernel<CC, 5, MD>, shmem)) != BATH_OK) return st;
       const int s1 = ctx->span_begin("fs5_fwd_kernel", ctx->stream, cells5, cells5 * 32.0);
-      hipLaunchKernelGGL((fs5_fwd_kernel<CC, MD>), dim3(grid_dp), dim3(kFsBlock), shmem, ctx->stream, dna->view(), fsdev(om), om->d_loop[1], om->d_move[1], tEL, tEM, c5_compat, d_fsc, b_f.as<float>(), d_foff, b_fx.as<float>(), d_xoff, -1, jq[0]);
+      hipLaunchKernelGGL((fs5_fwd_kernel<CC, MD, true>), dim3(grid_dp), dim3(kFsBlock), shmem, ctx->stream, dna->view(), fsdev(om), om->d_loop[1], om->d_move[1], tEL, tEM, c5_compat, d_fsc, b_f.as<float>(), d_foff, b_fx.as<float>(), d_xoff, -1, jq[0]);
       ctx->span_end(s1, ctx->stream);
       const int s2 = ctx->span_begin("fs_bwd_kernel<5>", ctx->side_stream, cells5, cells5 * 12.0);
       hipLaunchKernelGGL((fs_bwd_kernel<CC, 5, MD>), dim3(grid_dp), dim3(kFsBlock), shmem, ctx->side_stream, dna->view(), fsdev(om), om->d_loop[1], om->d_move[1], tEL, tEM, d_bsc, b_b.as<float>(), d_boff, b_bx.as<float>(), d_xoff, jq[1]);
