@@ -49,16 +49,13 @@ double exp_logsurv(double x, double mu, double lambda) { return x < mu ? 0.0 : -
 // Thread count: the CPUs this process may run on (its affinity mask, not the machine's thread count: a GPU box hands a job a
 // slice of its cores), at most 64; BATH_HIP_HOST_THREADS overrides.
 inline int host_thread_count() {
-  static const int T = [] {
-    const char *e = std::getenv("BATH_HIP_HOST_THREADS");
-    if (e && std::atoi(e) > 0) return std::atoi(e);
-    int usable = 0;
-    cpu_set_t set;
-    if (sched_getaffinity(0, sizeof set, &set) == 0) usable = CPU_COUNT(&set);
-    if (usable <= 0) usable = (int)std::max(1u, std::thread::hardware_concurrency());
-    return std::min(64, std::max(1, usable));
-  }();
-  return T;
+  const char *e = std::getenv("BATH_HIP_HOST_THREADS");
+  if (e && std::atoi(e) > 0) return std::atoi(e);
+  int usable = 0;
+  cpu_set_t set;
+  if (sched_getaffinity(0, sizeof set, &set) == 0) usable = CPU_COUNT(&set);
+  if (usable <= 0) usable = (int)std::max(1u, std::thread::hardware_concurrency());
+  return std::min(64, std::max(1, usable));
 }
 template <class F, class W>
 void run_striped(int64_t n, F &&work, W &&weight) {

@@ -323,3 +323,29 @@ def test_cascade_lanes_give_the_same_frameshift_hits(gpu_ctx, monkeypatch):
     assert out[0] == out[1] == out[2]
     assert len(out[0][2]) >= 20 and len(out[0][3]) >= 10
     assert {w[7] for w in out[0][2]} == {1, 2}                      # both branches taken: the standard branch reads the lanes' residue pools
+
+
+@pytest.mark.parametrize("switch", ["BATH_HIP_FS_STD_SERIAL", "BATH_HIP_FS_REGION_COPY", "BATH_HIP_FS_TWO_BATCHES", "BATH_HIP_FS_LIVE", "BATH_HIP_HOST_THREADS"])
+def test_scheduling_switches_do_not_change_the_hits(gpu_ctx, monkeypatch, switch):
+    """How the domain stage is scheduled -- the standard branch on its own thread and stream or afterwards, the region Forward
+    written straight to page-locked memory or copied, one envelope batch or two, ensembles started per region or after the whole
+    region Forward, the number of ensemble threads -- must not change a single hit."""
+    rng = np.random.default_rng(79)
+    path = ol.GOLDEN + "/PTH2.bhmm"
+    model = ol.Model(path, 0)
+    wins = frameshifted_windows(rng, model, n=30)
+    hmm = ba.HMM(path, 0)
+    om = ba.OProfile(gpu_ctx, ba.Profile(hmm))
+    om3 = ba.FSOProfile(gpu_ctx, ba.FSProfile(hmm, 3, ncbi_table=hmm.ct))
+    om5 = ba.FSOProfile(gpu_ctx, ba.FSProfile(hmm, 5, ncbi_table=hmm.ct))
+    pipe = ba.Pipeline(gpu_ctx, om, fs_pipe=True, ncbi_table=hmm.ct)
+    out = []
+    for value in (None, "0" if switch == "BATH_HIP_FS_LIVE" else "1"):
+        if value is None:
+            monkeypatch.delenv(switch, raising=False)
+        else:
+            monkeypatch.setenv(switch, value)
+        _, fw, dm, nskip = pipe.run_frameshift_domains(om3, om5, ba.SeqBlock(gpu_ctx, wins))
+        out.append((nskip, sorted((d.window, d.fs_window, d.ienv, d.jenv, d.iali, d.jali, d.ihmm, d.jhmm, d.envsc, d.oasc, d.domcorrection, d.bitscore, d.lnP,
+                                   d.n_shifted_codons, d.n_stops, d.pid, d.cigar) for d in dm)))
+    assert out[0] == out[1] and len(out[0][1]) >= 10 and out[0][0] >= 1        # at least one clustered region went through the ensembles
