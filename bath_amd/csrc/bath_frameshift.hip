@@ -1658,7 +1658,7 @@ namespace bath {
 int fs_max_regions() { return kMaxRegions; }
 // Forward and Backward of a batch are independent and, with few windows, each is bound by the latency of its longest window's
 // row chain: run Backward on the context's side stream while Forward runs on the main one.
-static int fs_fork(bath_hip_ctx *ctx) {
+int fs_fork(bath_hip_ctx *ctx) {
   if (!ctx->side_stream) {
     BATH_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
     BATH_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
@@ -1668,7 +1668,7 @@ static int fs_fork(bath_hip_ctx *ctx) {
   BATH_HIP_TRY(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->ev_fork, 0));
   return BATH_OK;
 }
-static int fs_join(bath_hip_ctx *ctx) {
+int fs_join(bath_hip_ctx *ctx) {
   BATH_HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->side_stream));
   BATH_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
   return BATH_OK;

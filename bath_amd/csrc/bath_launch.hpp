@@ -75,6 +75,8 @@ int fs_gather_view(bath_hip_ctx *ctx, const bath_hip_seqs *dna, std::vector<FsWi
 float flogsum_host(float a, float b);                          // p7_FLogsum with its table, on the host
 
 // ---- frameshift helpers for the pipeline (bath_frameshift.hip)
+int fs_fork(bath_hip_ctx *ctx);   // the context's side stream waits for what the main stream holds so far
+int fs_join(bath_hip_ctx *ctx);   // ... and the main stream for the side stream
 int fs3_forward_scores(bath_hip_ctx *ctx, const bath_hip_fsprofile *om3, const bath_hip_seqs *dna, float *sc);   // table log-sum, host array out
 const float *fsprofile_evparam(const bath_hip_fsprofile *om);
 int fs_max_regions();

@@ -1310,11 +1310,13 @@ extern "C" int bath_hip_pipeline_frameshift(bath_hip_ctx *ctx, const bath_hip_op
     const FsWinDev *d_desc = nullptr;
     if ((st = fs_gather_view(ctx, dna, dev, S.tt.comp, &view, &d_desc)) != BATH_OK) return st;
     BATH_HIP_TRY(ctx, b_out.reserve((size_t)nw * 6 * sizeof(float) + 64));
-    hipLaunchKernelGGL(fs_bias_kernel, dim3((unsigned)((2 * nw + 63) / 64)), dim3(64), 0, ctx->stream, view.d_data, d_desc, nw, S.tt.full, M, om->d_bias_eo,
+    // the bias filter (a lane per window and pass, serial over the window) and the Forward parser are independent: the bias
+    // kernel goes to the side stream, behind the gather
+    if ((st = fs_fork(ctx)) != BATH_OK) return st;
+    hipLaunchKernelGGL(fs_bias_kernel, dim3((unsigned)((2 * nw + 63) / 64)), dim3(64), 0, ctx->side_stream, view.d_data, d_desc, nw, S.tt.full, M, om->d_bias_eo,
                        S.d_ssvsc, (int)om->base_b, om->scale_b, S.d_bgf, b_out.as<float>());
     BATH_HIP_TRY(ctx, hipGetLastError());
     std::vector<float> h_bias((size_t)nw * 6);
-    BATH_HIP_TRY(ctx, hipMemcpyAsync(h_bias.data(), b_out.p, h_bias.size() * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     std::vector<float> h_fsc((size_t)nw);
     ctx->fs_regions_all.clear();
     if (ctx->fs_want_regions && nw <= (int64_t)ctx->prop.multiProcessorCount * 16) {
@@ -1331,6 +1333,8 @@ extern "C" int bath_hip_pipeline_frameshift(bath_hip_ctx *ctx, const bath_hip_op
     st = fs3_forward_scores(ctx, om_fs3, &view, h_fsc.data());
     view.d_data = nullptr; view.d_off = nullptr; view.d_len = nullptr;     // borrowed pointers: nothing for a destructor to free
     if (st != BATH_OK) return st;
+    BATH_HIP_TRY(ctx, hipMemcpyAsync(h_bias.data(), b_out.p, h_bias.size() * sizeof(float), hipMemcpyDeviceToHost, ctx->side_stream));
+    BATH_HIP_TRY(ctx, hipStreamSynchronize(ctx->side_stream));
     BATH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     clk.lap("fs:   gather + bias + 3-codon Forward");
 
