@@ -268,3 +268,23 @@ def test_cascade_lanes_give_the_same_hits(ctx, monkeypatch):
         out.append((st.n_past_fwd, st.pos_past_fwd, nskip,
                     sorted((d.window, d.strand, d.ienv, d.jenv, d.iali, d.jali, d.ihmm, d.jhmm, d.envsc, d.oasc, d.ali_columns, d.pid, d.cigar, d.domcorrection, d.bitscore) for d in dm)))
     assert out[0] == out[1] == out[2] and len(out[0][3]) >= 20
+
+
+def test_cascade_lanes_with_an_empty_part(ctx, monkeypatch):
+    """A lane whose part of the block has no ORF at all (stop codons in every frame) contributes nothing and breaks nothing:
+    candidate ids, windows and residue addresses of the other lane's survivors are unaffected."""
+    path = ol.GOLDEN + "/Caudal_act.bhmm"
+    model = ol.Model(path, 0)
+    rng = np.random.default_rng(103)
+    genes = []
+    for i, aa in enumerate(common.emit_from_model(rng, model, 12, flank=4, sharpen=2.0)):
+        nt = np.array(common.revtranslate(rng, aa, model.basic), dtype=np.uint8)
+        genes.append(np.concatenate([rng.integers(0, 4, size=40).astype(np.uint8), nt, rng.integers(0, 4, size=40).astype(np.uint8)]))
+    stops = [np.tile(np.array([3, 0, 0, 3, 3, 0, 3, 0, 0, 3], dtype=np.uint8), 100) for _ in range(14)]    # TAATTATAAT...: stops in all six frames
+    for wins in (genes + stops, stops + genes):
+        out = []
+        for lanes in ("1", "2"):
+            monkeypatch.setenv("BATH_HIP_LANES", lanes)
+            st, dm, nskip = gpu_hits(ctx, path, 0, wins)
+            out.append((st.n_orfs, st.n_past_fwd, nskip, sorted((d.window, d.strand, d.ienv, d.jenv, d.iali, d.jali, d.ihmm, d.jhmm, d.envsc, d.oasc, d.cigar, d.bitscore) for d in dm)))
+        assert out[0] == out[1] and len(out[0][3]) >= 8
