@@ -154,6 +154,8 @@ def main():
     ap.add_argument("--no-fs", action="store_true", help="skip the configs[2] (--fs) leg")
     ap.add_argument("--fs-windows", type=int, default=1_000_000)
     ap.add_argument("--no-streamed", action="store_true", help="skip the host-fed (PCIe-inclusive) leg")
+    ap.add_argument("--no-one-part", action="store_true",
+                    help="skip the whole-block-as-one-part passes behind roofline.valu (profiling: every ssv_orf_kernel launch is then a timed-step launch)")
     ap.add_argument("--plumbing-only", action="store_true",
                     help="CPU test hook: launcher, broadcast, reduce and gather over gloo with fabricated counters; no kernels, value 0")
     args = ap.parse_args()
@@ -297,15 +299,16 @@ def main():
         algo_bytes = (orf_res + 16.0 * stats.n_orfs + 34.0 * stats.n_past_msv) / lanes
         achieved = algo_bytes / (k_ms * 1e-3) / 1e9
         # the same kernel alone on the chip: one part, nothing overlapping it (outside the timed region)
-        os.environ["BATH_HIP_LANES"] = "1"
-        pipe.run(dna, want_results=False)
         one = []
-        for _ in range(3):
+        if not args.no_one_part:
+            os.environ["BATH_HIP_LANES"] = "1"
             pipe.run(dna, want_results=False)
-            one.append({n: ms for n, ms, _ in pipe.timings()})
-        del os.environ["BATH_HIP_LANES"]
-        k1_ms = float(np.mean([o["ssv_f1"] for o in one]))
-        tc1 = stats.cells_msv / (k1_ms * 1e-3) / 1e12
+            for _ in range(3):
+                pipe.run(dna, want_results=False)
+                one.append({n: ms for n, ms, _ in pipe.timings()})
+            del os.environ["BATH_HIP_LANES"]
+        k1_ms = float(np.mean([o["ssv_f1"] for o in one])) if one else float("nan")
+        tc1 = stats.cells_msv / (k1_ms * 1e-3) / 1e12 if one else float("nan")
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "r02_ssv_orf_pmc.json")
         if os.path.exists(pmc):
@@ -325,9 +328,12 @@ def main():
                      "peak_at_this_occupancy_tcells_per_s": 37.9, "frac_at_this_occupancy": tc1 / 37.9,
                      "how": "whole block as ONE part (BATH_HIP_LANES=1), nothing overlapping the kernel; HIP events on its stream",
                      "peak_source": "measured packed-op issue rate, tools/valu_rate.hip, profiles/r01_valu_rate.txt"},
-            "one_part_stage_ms": {k: float(np.mean([o[k] for o in one])) for k in one[0]},
+            "one_part_stage_ms": {k: float(np.mean([o[k] for o in one])) for k in one[0]} if one else None,
         }
-        out["one_part_kernel_sum_ms"] = float(sum(out["roofline"]["one_part_stage_ms"].values()))
+        if not one:
+            out["roofline"]["valu"] = None
+        else:
+            out["one_part_kernel_sum_ms"] = float(sum(out["roofline"]["one_part_stage_ms"].values()))
         if base is not None:
             out["cpu_baseline"] = base
             # the CPU leg scored windows [0, cpu_covered) of this very block: compare every counter with the GPU's over the same windows

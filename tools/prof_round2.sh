@@ -9,6 +9,12 @@ export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/round2
 rm -rf $OUT; mkdir -p $OUT
 BATH_HIP_TIMING=1 python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline > $OUT/bench_plain.json 2> $OUT/bench_stage_laps.txt
+# 1a: the cascade alone, every ssv_orf_kernel launch a half-block launch of a step (its average is what roofline.kernel_ms of that run says)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats0 -o bench0 -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-fs --no-streamed --no-one-part > $OUT/bench_under_prof_cascade.log 2>&1
+grep '^{"metric"' $OUT/bench_under_prof_cascade.log > $OUT/bench_under_prof_cascade.json
+find $OUT/stats0 -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats_cascade.csv \;
+rm -rf $OUT/stats0
+# 1b: the whole default command (all legs)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline > $OUT/bench_under_prof.log 2>&1
 export BATH_HIP_LANES=1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats1 -o bench1 -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-fs --no-streamed > $OUT/bench_under_prof_1lane.log 2>&1
