@@ -40,6 +40,7 @@ enum { FLAG_VIT_RUN = 1, FLAG_HAS_WIN = 2 };
 
 struct Counters {                     // device-side counters, one struct per pipeline call
   int cand_count, todo_msv, todo_vit, todo_ssvb, todo_vit2, todo_fwd, win_count, overflow;
+  int todo_lb, pad_;                                        // candidates that need the local-composition bias filter
   unsigned long long n_orfs, orf_res;                       // ORFs >= minlen, their total aa
   unsigned long long n_past_msv, n_past_bias, n_past_vit, n_past_fwd;
   unsigned long long pos_past_msv, pos_past_bias, pos_past_vit, pos_past_fwd;
@@ -295,17 +296,25 @@ __global__ __launch_bounds__(256) void ssv_bath_kernel(Cand cand, const Counters
 }
 
 // p7_pli_ComputeLocalCompo (p7_pipeline.c:427-458) + p7_bg_SetFilter + esl_hmm_Configure for one candidate
-__device__ void local_compo_eo(const uint8_t *ssv_scores, int M, int base_b, float scale_b, const float *bgf, int k_start, int k_end, float *eo /* [Kp][2] */) {
-  float compo[20];
+// p7_pli_ComputeLocalCompo's sum for ONE residue x over the (widened) node range: the 20 sums are independent of each other
+__device__ __forceinline__ float local_compo_x(const uint8_t *ssv_scores, int M, int base_b, float scale_b, const float *bgf, int k_start, int k_end, int x) {
   const int k_len = k_end - k_start + 1;
   if (k_len < 20) { k_start -= (20 - k_len) / 2; k_end += (20 - k_len) / 2; }
   k_start = max(1, k_start); k_end = min(M, k_end);
-  for (int x = 0; x < 20; x++) compo[x] = 0.0f;
-  for (int k = k_start; k <= k_end; k++)
-    for (int x = 0; x < 20; x++) {
-      const float lo = ((float)base_b - (float)ssv_scores[(size_t)k * kKp + x]) / scale_b;
-      compo[x] += bgf[x] * expf(lo);
-    }
+  float acc = 0.0f;
+  for (int k = k_start; k <= k_end; k++) {
+    const float lo = ((float)base_b - (float)ssv_scores[(size_t)k * kKp + x]) / scale_b;
+    acc += bgf[x] * expf(lo);
+  }
+  return acc;
+}
+__device__ void local_compo_finish(float *compo /* [20], the sums */, const float *bgf, float *eo /* [Kp][2] */);
+__device__ void local_compo_eo(const uint8_t *ssv_scores, int M, int base_b, float scale_b, const float *bgf, int k_start, int k_end, float *eo /* [Kp][2] */) {
+  float compo[20];
+  for (int x = 0; x < 20; x++) compo[x] = local_compo_x(ssv_scores, M, base_b, scale_b, bgf, k_start, k_end, x);
+  local_compo_finish(compo, bgf, eo);
+}
+__device__ void local_compo_finish(float *compo, const float *bgf, float *eo) {
   float sum = 0.f, cc = 0.f;
   for (int x = 0; x < 20; x++) { const float y = compo[x] - cc; const float t = sum + y; cc = (t - sum) - y; sum = t; }
   if (sum != 0.0f) for (int x = 0; x < 20; x++) compo[x] /= sum;
@@ -328,50 +337,77 @@ __device__ void local_compo_eo(const uint8_t *ssv_scores, int M, int base_b, flo
 }
 
 // after Viterbi / SSV windows: F2 test, local-composition re-filter (p7_pipeline.c:1672-1718)
-__global__ void post_vit_kernel(Cand cand, int cand_cap, Counters *__restrict__ ctr, Params p, const uint8_t *__restrict__ pool, int M,
-                                const uint8_t *__restrict__ ssv_scores, int base_b, float scale_b, const float *__restrict__ bgf,
-                                const float *__restrict__ p1_tab, const float *__restrict__ lt1_tab, const float *__restrict__ lt2_tab,
-                                int32_t *__restrict__ todo_vit2, int32_t *__restrict__ todo_fwd) {
+__global__ void post_vit_kernel(Cand cand, int cand_cap, Counters *__restrict__ ctr, Params p, int32_t *__restrict__ todo_lb, int32_t *__restrict__ todo_fwd) {
   const int ncand = min(ctr->cand_count, cand_cap);
   for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < ncand; c += gridDim.x * blockDim.x) {
     if (cand.stage[c] != 2) continue;
     const int L = cand.len[c];
-    const float usc = cand.usc[c];
-    float filtersc = cand.filtersc[c];
-    float vfsc = cand.vfsc[c];
-    double P = cand.P[c];
     if (cand.flags[c] & FLAG_VIT_RUN) {
-      const float seqsc = (float)((double)(vfsc - filtersc) / kLog2);
-      P = d_gumbel_surv(seqsc, p.evparam[2], p.evparam[3]);
+      const float seqsc = (float)((double)(cand.vfsc[c] - cand.filtersc[c]) / kLog2);
+      const double P = d_gumbel_surv(seqsc, p.evparam[2], p.evparam[3]);
       cand.P[c] = P;
       if (P > p.F2) { cand.kminmax[2 * c] = 1 << 30; cand.kminmax[2 * c + 1] = 0; continue; }
-    } else vfsc = -INFINITY;
+    }
     atomicAdd(&ctr->n_past_vit, 1ull); atomicAdd(&ctr->pos_past_vit, (unsigned long long)L * 3ull);
-    const int kmin = cand.kminmax[2 * c], kmax = cand.kminmax[2 * c + 1];
-    if (p.do_bias && kmin <= kmax) {
+    if (p.do_bias && cand.kminmax[2 * c] <= cand.kminmax[2 * c + 1]) {
+      // the local-composition bias filter (p7_pipeline.c:1688-1712) is ~10^3 times the work of everything else here and only the
+      // few per cent of candidates that passed Viterbi with a hit window need it: they go to a list and a dense kernel
+      // (post_vit_local_kernel); done in place, every wave of this kernel would walk the long path for one or two of its lanes
       cand.flags[c] |= FLAG_HAS_WIN;
-      float eo[kKp * 2];
-      local_compo_eo(ssv_scores, M, base_b, scale_b, bgf, kmin, kmax, eo);
-      float lf = bias_forward(pool + cand.off[c], L, M, eo, p1_tab[L]);
+      todo_lb[atomicAdd(&ctr->todo_lb, 1)] = c;
+      continue;
+    }
+    cand.stage[c] = 3;
+    todo_fwd[atomicAdd(&ctr->todo_fwd, 1)] = c; atomicAdd(&ctr->res_fwd, (unsigned long long)L);
+  }
+}
+
+// Three candidates per wave: lanes 20g..20g+19 each accumulate the local composition of one residue over the window's nodes (the
+// 20 sums of p7_pli_ComputeLocalCompo are independent; each still adds its terms in ascending k), then the group's first lane
+// does the serial rest -- normalisation, the 2-state filter HMM over the ORF, the decisions -- with its emission odds in LDS.
+__global__ __launch_bounds__(64) void post_vit_local_kernel(Cand cand, Counters *__restrict__ ctr, Params p, const uint8_t *__restrict__ pool, int M,
+                                                            const uint8_t *__restrict__ ssv_scores, int base_b, float scale_b, const float *__restrict__ bgf,
+                                                            const float *__restrict__ p1_tab, const float *__restrict__ lt1_tab, const float *__restrict__ lt2_tab,
+                                                            const int32_t *__restrict__ todo_lb, int32_t *__restrict__ todo_vit2, int32_t *__restrict__ todo_fwd) {
+  __shared__ float s_compo[3][20];
+  __shared__ float s_eo[3][kKp * 2];
+  const int lane = threadIdx.x, g = lane / 20, x = lane % 20;
+  const int ntodo = ctr->todo_lb;
+  for (int base = blockIdx.x * 3; base < ntodo; base += gridDim.x * 3) {
+    const int job = base + g;
+    const bool live = g < 3 && job < ntodo;
+    const int c = live ? todo_lb[job] : 0;
+    if (live) s_compo[g][x] = local_compo_x(ssv_scores, M, base_b, scale_b, bgf, cand.kminmax[2 * c], cand.kminmax[2 * c + 1], x);
+    __syncthreads();
+    if (live && x == 0) {
+      const int L = cand.len[c];
+      const float usc = cand.usc[c];
+      float filtersc = cand.filtersc[c];
+      const float vfsc = (cand.flags[c] & FLAG_VIT_RUN) ? cand.vfsc[c] : -INFINITY;
+      float compo[20];
+      for (int y = 0; y < 20; y++) compo[y] = s_compo[g][y];
+      local_compo_finish(compo, bgf, s_eo[g]);
+      float lf = bias_forward(pool + cand.off[c], L, M, s_eo[g], p1_tab[L]);
       lf = (lf + lt1_tab[L]) + lt2_tab[L];
+      bool to_fwd = true;
       if (lf > filtersc) {
         filtersc = lf;
         cand.filtersc[c] = filtersc;
         if (vfsc == -INFINITY) {
           const float seqsc = (float)((double)(usc - filtersc) / kLog2);
-          P = d_gumbel_surv(seqsc, p.evparam[0], p.evparam[1]);
+          const double P = d_gumbel_surv(seqsc, p.evparam[0], p.evparam[1]);
           cand.P[c] = P;
-          if (P > p.F2) { cand.stage[c] = 5; todo_vit2[atomicAdd(&ctr->todo_vit2, 1)] = c; atomicAdd(&ctr->res_vit, (unsigned long long)L); continue; }
+          if (P > p.F2) { cand.stage[c] = 5; todo_vit2[atomicAdd(&ctr->todo_vit2, 1)] = c; atomicAdd(&ctr->res_vit, (unsigned long long)L); to_fwd = false; }
         } else {
           const float seqsc = (float)((double)(vfsc - filtersc) / kLog2);
-          P = d_gumbel_surv(seqsc, p.evparam[2], p.evparam[3]);
+          const double P = d_gumbel_surv(seqsc, p.evparam[2], p.evparam[3]);
           cand.P[c] = P;
-          if (P > p.F2) continue;                          // rejected; stays at stage 2 (the reference has already counted it past Vit)
+          if (P > p.F2) to_fwd = false;                    // rejected; stays at stage 2 (the reference has already counted it past Vit)
         }
       }
+      if (to_fwd) { cand.stage[c] = 3; todo_fwd[atomicAdd(&ctr->todo_fwd, 1)] = c; atomicAdd(&ctr->res_fwd, (unsigned long long)L); }
     }
-    cand.stage[c] = 3;
-    todo_fwd[atomicAdd(&ctr->todo_fwd, 1)] = c; atomicAdd(&ctr->res_fwd, (unsigned long long)L);
+    __syncthreads();
   }
 }
 
@@ -704,8 +740,9 @@ static int run_filters(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bat
     BATH_HIP_TRY(ctx, hipGetLastError());
     BATH_HIP_TRY(ctx, hipEventRecord(ev[e++], ctx->stream));
     // 5. F2, local composition re-filter, optional plain Viterbi re-run
-    hipLaunchKernelGGL(post_vit_kernel, dim3(dec_blocks), dim3(256), 0, ctx->stream, W.cand, W.cand_cap, W.ctr, P, W.pool, M, d_ssvsc, (int)om->base_b,
-                       om->scale_b, d_bgf, om->lt.d_p1, om->lt.d_lt1, om->lt.d_lt2, W.todo_vit2, W.todo_fwd);
+    hipLaunchKernelGGL(post_vit_kernel, dim3(dec_blocks), dim3(256), 0, ctx->stream, W.cand, W.cand_cap, W.ctr, P, W.todo_msv /* free by now */, W.todo_fwd);
+    hipLaunchKernelGGL(post_vit_local_kernel, dim3(16384), dim3(64), 0, ctx->stream, W.cand, W.ctr, P, W.pool, M, d_ssvsc, (int)om->base_b,
+                       om->scale_b, d_bgf, om->lt.d_p1, om->lt.d_lt1, om->lt.d_lt2, W.todo_msv, W.todo_vit2, W.todo_fwd);
     BATH_HIP_TRY(ctx, hipGetLastError());
     if ((st = launch_vit_wave(ctx, om, cv, W.todo_vit2, cap, W.cand.vfsc, W.cand.vit_status, nullptr, &W.ctr->todo_vit2)) != BATH_OK) return st;
     hipLaunchKernelGGL(post_vit2_kernel, dim3(64), dim3(256), 0, ctx->stream, W.cand, W.ctr, P, W.todo_vit2, W.todo_fwd);
