@@ -63,6 +63,22 @@ __device__ __forceinline__ int orf_bin(int len) { return min(len, kOrfBins - 1);
 
 __device__ __forceinline__ int half_shfl_up(int v, int d) { return __shfl_up(v, d, kTileLanes); }
 
+// Exclusive running maximum over the lanes of a 32-lane half wave (lane 0 of a half gets <ident>), by DPP: one lane shift, then
+// row_shr 1/2/4/8 inside the 16-lane rows and row_bcast:15 into the upper row of each half.  ~11 VALU instructions; the ballot
+// form this replaces cost 7 per codon of the chunk.
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ int dpp_or_ident(int v, int ident) { return __builtin_amdgcn_update_dpp(ident, v, CTRL, ROW_MASK, 0xf, false); }
+__device__ __forceinline__ int half_excl_max_scan(int v, int ident, bool first_lane_of_half) {
+  int x = dpp_or_ident<0x138>(v, ident);                           // wave_shr:1
+  x = first_lane_of_half ? ident : x;
+  x = max(x, dpp_or_ident<0x111>(x, ident));                       // row_shr:1
+  x = max(x, dpp_or_ident<0x112>(x, ident));                       // row_shr:2
+  x = max(x, dpp_or_ident<0x114>(x, ident));                       // row_shr:4
+  x = max(x, dpp_or_ident<0x118>(x, ident));                       // row_shr:8
+  x = max(x, dpp_or_ident<0x142, 0xa>(x, ident));                  // row_bcast:15 into rows 1 and 3
+  return x;
+}
+
 __global__ __launch_bounds__(256) void orf_tile_kernel(SeqView dna, OrfTiles tiles, OrfScanTables tabs, OrfScanOut out, int minlen) {
   __shared__ int s_hist[kOrfBins];
   __shared__ __attribute__((aligned(16))) uint8_t s_full[5832 + 8];
@@ -77,8 +93,6 @@ __global__ __launch_bounds__(256) void orf_tile_kernel(SeqView dna, OrfTiles til
   __syncthreads();
   const int hw = threadIdx.x / kTileLanes;                     // half wave within the block
   const int i = threadIdx.x % kTileLanes;                      // lane within the tile
-  const bool hi_half = (threadIdx.x & 32) != 0;
-  const unsigned lt_mask = (1u << i) - 1u;
   const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   unsigned my_orfs = 0, my_res = 0;
@@ -166,13 +180,8 @@ __global__ __launch_bounds__(256) void orf_tile_kernel(SeqView dna, OrfTiles til
       }
       // ---- length of the stop-free run entering this lane's four codons: scan position of the last stop before them in
       // the tile, from four wave ballots (one per codon of the chunk; a wave holds two tiles, one per 32-lane half)
-      int last = -4;
-#pragma unroll
-      for (int c = 0; c < 4; c++) {
-        const unsigned long long B = __ballot((m >> c) & 1u);
-        const unsigned below = (hi_half ? (unsigned)(B >> 32) : (unsigned)B) & lt_mask;
-        last = max(last, 4 * (31 - (int)__clz(below)) + c);                // no stop in lanes below: 4*(-1)+c < 0
-      }
+      const int mine = m ? 4 * i + (31 - (int)__clz(m)) : -4;             // scan position of this lane's last stop
+      const int last = half_excl_max_scan(mine, -4, i == 0);
       bool open = last < 0;                                               // no stop in the tile before this lane
       const int run_in = open ? 4 * i : 4 * i - 1 - last;
       const int64_t e = tile * 6 + sf;
