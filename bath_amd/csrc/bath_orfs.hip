@@ -82,12 +82,16 @@ __device__ __forceinline__ int half_excl_max_scan(int v, int ident, bool first_l
 __global__ __launch_bounds__(256) void orf_tile_kernel(SeqView dna, OrfTiles tiles, OrfScanTables tabs, OrfScanOut out, int minlen) {
   __shared__ int s_hist[kOrfBins];
   __shared__ __attribute__((aligned(16))) uint8_t s_full[5832 + 8];
-  __shared__ uint8_t s_fwd[64], s_rev[64], s_comp[32];
+  __shared__ uint16_t s_fr[64];                                // canonical codon -> forward amino acid | reverse-strand amino acid << 8, bit 7 of each = stop
+  __shared__ uint8_t s_comp[32];
   __shared__ unsigned s_red[2];
   __shared__ int s_cnt[8];                                     // per half wave: ORFs recorded in the current tile
   for (int i = threadIdx.x; i < kOrfBins; i += blockDim.x) s_hist[i] = 0;
   for (int i = threadIdx.x; i < 5832; i += blockDim.x) s_full[i] = tabs.aa_full[i];
-  if (threadIdx.x < 64) { s_fwd[threadIdx.x] = tabs.aa64_fwd[threadIdx.x]; s_rev[threadIdx.x] = tabs.aa64_rev[threadIdx.x]; }
+  if (threadIdx.x < 64) {
+    const unsigned f = tabs.aa64_fwd[threadIdx.x], r = tabs.aa64_rev[threadIdx.x];
+    s_fr[threadIdx.x] = (uint16_t)((f | (f == kStop ? 0x80u : 0u)) | ((r | (r == kStop ? 0x80u : 0u)) << 8));
+  }
   if (threadIdx.x < 18) s_comp[threadIdx.x] = tabs.comp[threadIdx.x];
   if (threadIdx.x < 2) s_red[threadIdx.x] = 0;
   __syncthreads();
@@ -141,81 +145,92 @@ __global__ __launch_bounds__(256) void orf_tile_kernel(SeqView dna, OrfTiles til
         const unsigned t = (k % 4 == 0) ? D[k / 4] : __builtin_amdgcn_alignbyte(D[k / 4 + 1], D[k / 4], k % 4);
         // bytes x0,x1,x2 < 4 at bits 0,8,16: t * (2^20 + 2^10 + 1) has x0<<4|x1<<2|x2 at bits 16..21 and nothing else there
         const unsigned idx = (__umul24(t, 0x100401u) >> 16) & 63u;
-        af[k] = s_fwd[idx]; ar[k] = s_rev[idx];
+        const unsigned e = s_fr[idx];
+        af[k] = (int)(e & 0xffu); ar[k] = (int)(e >> 8);
       }
     } else {
 #pragma unroll
       for (int k = 0; k < 12; k++) {
         const unsigned t = (k % 4 == 0) ? D[k / 4] : __builtin_amdgcn_alignbyte(D[k / 4 + 1], D[k / 4], k % 4);
         const int x0 = min((int)(t & 0xffu), 17), x1 = min((int)((t >> 8) & 0xffu), 17), x2 = min((int)((t >> 16) & 0xffu), 17);
-        af[k] = s_full[(x0 * 18 + x1) * 18 + x2];
-        ar[k] = s_full[((int)s_comp[x2] * 18 + (int)s_comp[x1]) * 18 + (int)s_comp[x0]];
+        const int f = s_full[(x0 * 18 + x1) * 18 + x2];
+        const int r = s_full[((int)s_comp[x2] * 18 + (int)s_comp[x1]) * 18 + (int)s_comp[x0]];
+        af[k] = f | (f == kStop ? 0x80 : 0); ar[k] = r | (r == kStop ? 0x80 : 0);
       }
     }
     const int nvalid = live ? min(max(n - 2 - p0, 0), 12) : 0;            // positions p0 .. p0+nvalid-1 start a codon inside the window
     const int pitch = orf_stream_pitch(n);
     uint8_t *const abase = out.aa + (2 * off + 96 * (int64_t)w);
     const int u0 = kTileCodons * T + 4 * i;                              // scan index of the lane's first codon, every stream
+    // af[], ar[] carry a stop flag in bit 7.  A stream's four codons packed into a dword give its stops as the flag bits 7, 15,
+    // 23, 31 with one AND; codons past the end of the stream count as stops: cv = how many of the four exist (x / 3 = x * 11 >> 5
+    // for x < 15), the others' flags are forced.
+    unsigned inv[3];
+    int cv[3];
+#pragma unroll
+    for (int ph = 0; ph < 3; ph++) {
+      cv[ph] = (max(nvalid - ph + 2, 0) * 11) >> 5;
+      inv[ph] = cv[ph] >= 4 ? 0u : (0x80808080u << (8 * cv[ph]));
+    }
+    // n = 3 q3 + r3 once per tile: the reverse frame of phase ph is (r3 - ph) mod 3 and that stream has q3 - (r3 < ph) codons,
+    // without a division per stream
+    const int q3 = n / 3, r3 = n - 3 * q3;
+    uint2 *const slots = out.slots + tile * out.cap;                     // per tile, not per stream
+    int *const prefix6 = out.prefix + tile * 6, *const suffix6 = out.suffix + tile * 6;
 #pragma unroll
     for (int st = 0; st < 6; st++) {                                      // st: phase 0..2 forward, 3..5 the same phases on the other strand
       const int ph = st % 3;
       const bool rev = st >= 3;
-      const int fr = (n - ph + 3) % 3;                                    // reverse frame of phase ph in this window
+      const int fr = r3 - ph + (r3 < ph ? 3 : 0);                         // reverse frame of phase ph in this window: (n - ph) mod 3
       const int sf = rev ? 3 + fr : ph;                                   // strand*3 + frame as reported
-      const int C = (n - 3 - fr - ph) / 3;                                // reverse stream: codon index j = C - u
-      int aa4[4];
-#pragma unroll
-      for (int c = 0; c < 4; c++) aa4[c] = rev ? ar[ph + 3 * c] : af[ph + 3 * c];
-      unsigned m = 0;                                                     // stops, counting positions past the end of the stream
-#pragma unroll
-      for (int c = 0; c < 4; c++) m |= ((aa4[c] == kStop) || (ph + 3 * c >= nvalid)) ? (1u << c) : 0u;
+      const int C = q3 - 1 - (r3 < ph ? 1 : 0);                           // (n - 3 - fr - ph) / 3; reverse stream: codon index j = C - u
+      const int *a = rev ? ar : af;
+      const unsigned pk = (unsigned)a[ph] | ((unsigned)a[ph + 3] << 8) | ((unsigned)a[ph + 6] << 16) | ((unsigned)a[ph + 9] << 24);
+      const unsigned mf = (pk & 0x80808080u) | inv[ph];                   // stops, counting positions past the end of the stream
       // ---- residues out: one dword per lane when all four codons exist, bytes otherwise
-      uint8_t *const stream = abase + (int64_t)sf * pitch;
-      if (ph + 9 < nvalid) {
-        if (!rev) *reinterpret_cast<uint32_t *>(stream + u0) = (unsigned)aa4[0] | ((unsigned)aa4[1] << 8) | ((unsigned)aa4[2] << 16) | ((unsigned)aa4[3] << 24);
-        else *reinterpret_cast<uint32_t *>(stream + (C - u0 - 3)) = (unsigned)aa4[3] | ((unsigned)aa4[2] << 8) | ((unsigned)aa4[1] << 16) | ((unsigned)aa4[0] << 24);
+      const int so = sf * pitch + (rev ? C - u0 - 3 : u0);                // 32-bit offset of the lane's dword in this tile's window
+      if (cv[ph] == 4) {
+        *reinterpret_cast<uint32_t *>(abase + so) = rev ? __builtin_amdgcn_perm(0u, pk & 0x7f7f7f7fu, 0x00010203u) /* bytes reversed */ : (pk & 0x7f7f7f7fu);
       } else {
 #pragma unroll
-        for (int c = 0; c < 4; c++) if (ph + 3 * c < nvalid) stream[rev ? C - u0 - c : u0 + c] = (uint8_t)aa4[c];
+        for (int c = 0; c < 4; c++) if (c < cv[ph]) abase[so + (rev ? 3 - c : c)] = (uint8_t)(a[ph + 3 * c] & 0x7f);
       }
-      // ---- length of the stop-free run entering this lane's four codons: scan position of the last stop before them in
-      // the tile, from four wave ballots (one per codon of the chunk; a wave holds two tiles, one per 32-lane half)
-      const int mine = m ? 4 * i + (31 - (int)__clz(m)) : -4;             // scan position of this lane's last stop
+      // ---- length of the stop-free run entering this lane's four codons: scan position of the last stop before them in the tile
+      const int mine = mf ? 4 * i + ((31 - (int)__clz(mf)) >> 3) : -4;    // scan position of this lane's last stop
       const int last = half_excl_max_scan(mine, -4, i == 0);
       bool open = last < 0;                                               // no stop in the tile before this lane
       const int run_in = open ? 4 * i : 4 * i - 1 - last;
-      const int64_t e = tile * 6 + sf;
       auto record = [&](int u_stop, int len) {
         const int k = atomicAdd(&s_cnt[hw], 1);
-        out.slots[tile * out.cap + k] = make_uint2((unsigned)(rev ? C - u_stop + 1 : u_stop - len), (unsigned)len | ((unsigned)sf << 28));
+        slots[k] = make_uint2((unsigned)(rev ? C - u_stop + 1 : u_stop - len), (unsigned)len | ((unsigned)sf << 28));
         atomicAdd(&s_hist[orf_bin(len)], 1);
         my_orfs++; my_res += (unsigned)len;
       };
       if (minlen > 2) {
         // a run that starts after a stop inside these four codons is at most 2 long: only the chunk's first stop can close an ORF
-        if (m != 0u) {
-          const int first = __ffs((int)m) - 1;
+        if (mf != 0u) {
+          const int first = (__ffs((int)mf) - 1) >> 3;
           const int len = run_in + first;
-          if (open) { if (live) out.prefix[e] = len; }
+          if (open) { if (live) prefix6[sf] = len; }
           else if (live && len >= minlen) record(u0 + first, len);
         }
         if (live && i == kTileLanes - 1) {
-          out.suffix[e] = m ? (int)__clz(m) - 28 : run_in + 4;             // the run open at the tile's right edge
-          if (open && m == 0u) out.prefix[e] = kTileCodons;                // no stop anywhere in the tile
+          suffix6[sf] = mf ? (int)__clz(mf) >> 3 : run_in + 4;             // the run open at the tile's right edge
+          if (open && mf == 0u) prefix6[sf] = kTileCodons;                 // no stop anywhere in the tile
         }
       } else {
         int len = run_in;
 #pragma unroll
         for (int c = 0; c < 4; c++) {
-          if ((m >> c) & 1u) {
-            if (open) { if (live) out.prefix[e] = len; open = false; }
+          if ((mf >> (8 * c + 7)) & 1u) {
+            if (open) { if (live) prefix6[sf] = len; open = false; }
             else if (live && len >= minlen) record(u0 + c, len);
             len = 0;
           } else len++;
         }
         if (live && i == kTileLanes - 1) {
-          out.suffix[e] = len;
-          if (open) out.prefix[e] = kTileCodons;
+          suffix6[sf] = len;
+          if (open) prefix6[sf] = kTileCodons;
         }
       }
     }

@@ -362,52 +362,71 @@ __global__ void post_vit_kernel(Cand cand, int cand_cap, Counters *__restrict__ 
   }
 }
 
-// Three candidates per wave: lanes 20g..20g+19 each accumulate the local composition of one residue over the window's nodes (the
-// 20 sums of p7_pli_ComputeLocalCompo are independent; each still adds its terms in ascending k), then the group's first lane
-// does the serial rest -- normalisation, the 2-state filter HMM over the ORF, the decisions -- with its emission odds in LDS.
-__global__ __launch_bounds__(64) void post_vit_local_kernel(Cand cand, Counters *__restrict__ ctr, Params p, const uint8_t *__restrict__ pool, int M,
-                                                            const uint8_t *__restrict__ ssv_scores, int base_b, float scale_b, const float *__restrict__ bgf,
-                                                            const float *__restrict__ p1_tab, const float *__restrict__ lt1_tab, const float *__restrict__ lt2_tab,
-                                                            const int32_t *__restrict__ todo_lb, int32_t *__restrict__ todo_vit2, int32_t *__restrict__ todo_fwd) {
-  __shared__ float s_compo[3][20];
-  __shared__ float s_eo[3][kKp * 2];
+// The local-composition bias filter in three dense steps.  (1) compo_terms_kernel, once per call: the 20 x 256 possible terms
+// bg_f[x] * exp((base_b - s) / scale_b) of p7_pli_ComputeLocalCompo (s: a byte score).  (2) local_compo_kernel: three candidates per
+// wave, lanes 20g..20g+19 each add the terms of one residue over the window's nodes (the 20 sums are independent; each still adds in
+// ascending k).  (3) post_vit_local_kernel: a lane per candidate does the serial rest -- normalisation, the 2-state filter HMM
+// over the ORF, the decisions -- with its emission odds in LDS.
+__global__ void compo_terms_kernel(const float *__restrict__ bgf, int base_b, float scale_b, float *__restrict__ terms /* [20][256] */) {
+  const int x = blockIdx.x, sc = threadIdx.x;
+  const float lo = ((float)base_b - (float)sc) / scale_b;
+  terms[x * 256 + sc] = bgf[x] * expf(lo);
+}
+
+__global__ __launch_bounds__(64) void local_compo_kernel(Cand cand, const Counters *__restrict__ ctr, int M, const uint8_t *__restrict__ ssv_scores,
+                                                         const float *__restrict__ terms, const int32_t *__restrict__ todo_lb, float *__restrict__ compo_out /* [todo_lb][20] */) {
   const int lane = threadIdx.x, g = lane / 20, x = lane % 20;
   const int ntodo = ctr->todo_lb;
   for (int base = blockIdx.x * 3; base < ntodo; base += gridDim.x * 3) {
     const int job = base + g;
-    const bool live = g < 3 && job < ntodo;
-    const int c = live ? todo_lb[job] : 0;
-    if (live) s_compo[g][x] = local_compo_x(ssv_scores, M, base_b, scale_b, bgf, cand.kminmax[2 * c], cand.kminmax[2 * c + 1], x);
-    __syncthreads();
-    if (live && x == 0) {
-      const int L = cand.len[c];
-      const float usc = cand.usc[c];
-      float filtersc = cand.filtersc[c];
-      const float vfsc = (cand.flags[c] & FLAG_VIT_RUN) ? cand.vfsc[c] : -INFINITY;
-      float compo[20];
-      for (int y = 0; y < 20; y++) compo[y] = s_compo[g][y];
-      local_compo_finish(compo, bgf, s_eo[g]);
-      float lf = bias_forward(pool + cand.off[c], L, M, s_eo[g], p1_tab[L]);
-      lf = (lf + lt1_tab[L]) + lt2_tab[L];
-      bool to_fwd = true;
-      if (lf > filtersc) {
-        filtersc = lf;
-        cand.filtersc[c] = filtersc;
-        if (vfsc == -INFINITY) {
-          const float seqsc = (float)((double)(usc - filtersc) / kLog2);
-          const double P = d_gumbel_surv(seqsc, p.evparam[0], p.evparam[1]);
-          cand.P[c] = P;
-          if (P > p.F2) { cand.stage[c] = 5; todo_vit2[atomicAdd(&ctr->todo_vit2, 1)] = c; atomicAdd(&ctr->res_vit, (unsigned long long)L); to_fwd = false; }
-        } else {
-          const float seqsc = (float)((double)(vfsc - filtersc) / kLog2);
-          const double P = d_gumbel_surv(seqsc, p.evparam[2], p.evparam[3]);
-          cand.P[c] = P;
-          if (P > p.F2) to_fwd = false;                    // rejected; stays at stage 2 (the reference has already counted it past Vit)
-        }
+    if (g >= 3 || job >= ntodo) continue;
+    const int c = todo_lb[job];
+    int k_start = cand.kminmax[2 * c], k_end = cand.kminmax[2 * c + 1];
+    const int k_len = k_end - k_start + 1;
+    if (k_len < 20) { k_start -= (20 - k_len) / 2; k_end += (20 - k_len) / 2; }
+    k_start = max(1, k_start); k_end = min(M, k_end);
+    const float *tx = terms + x * 256;
+    float acc = 0.0f;
+    for (int k = k_start; k <= k_end; k++) acc += tx[ssv_scores[(size_t)k * kKp + x]];
+    compo_out[(size_t)job * 20 + x] = acc;
+  }
+}
+
+__global__ __launch_bounds__(64) void post_vit_local_kernel(Cand cand, Counters *__restrict__ ctr, Params p, const uint8_t *__restrict__ pool, int M,
+                                                            const float *__restrict__ bgf, const float *__restrict__ compo_in,
+                                                            const float *__restrict__ p1_tab, const float *__restrict__ lt1_tab, const float *__restrict__ lt2_tab,
+                                                            const int32_t *__restrict__ todo_lb, int32_t *__restrict__ todo_vit2, int32_t *__restrict__ todo_fwd) {
+  __shared__ float s_eo[64][kKp * 2 + 1];
+  const int ntodo = ctr->todo_lb;
+  for (int job = blockIdx.x * blockDim.x + threadIdx.x; job < ntodo; job += gridDim.x * blockDim.x) {
+    const int c = todo_lb[job];
+    const int L = cand.len[c];
+    const float usc = cand.usc[c];
+    float filtersc = cand.filtersc[c];
+    const float vfsc = (cand.flags[c] & FLAG_VIT_RUN) ? cand.vfsc[c] : -INFINITY;
+    float compo[20];
+    for (int y = 0; y < 20; y++) compo[y] = compo_in[(size_t)job * 20 + y];
+    float *eo = s_eo[threadIdx.x];
+    local_compo_finish(compo, bgf, eo);
+    float lf = bias_forward(pool + cand.off[c], L, M, eo, p1_tab[L]);
+    lf = (lf + lt1_tab[L]) + lt2_tab[L];
+    bool to_fwd = true;
+    if (lf > filtersc) {
+      filtersc = lf;
+      cand.filtersc[c] = filtersc;
+      if (vfsc == -INFINITY) {
+        const float seqsc = (float)((double)(usc - filtersc) / kLog2);
+        const double P = d_gumbel_surv(seqsc, p.evparam[0], p.evparam[1]);
+        cand.P[c] = P;
+        if (P > p.F2) { cand.stage[c] = 5; todo_vit2[atomicAdd(&ctr->todo_vit2, 1)] = c; atomicAdd(&ctr->res_vit, (unsigned long long)L); to_fwd = false; }
+      } else {
+        const float seqsc = (float)((double)(vfsc - filtersc) / kLog2);
+        const double P = d_gumbel_surv(seqsc, p.evparam[2], p.evparam[3]);
+        cand.P[c] = P;
+        if (P > p.F2) to_fwd = false;                      // rejected; stays at stage 2 (the reference has already counted it past Vit)
       }
-      if (to_fwd) { cand.stage[c] = 3; todo_fwd[atomicAdd(&ctr->todo_fwd, 1)] = c; atomicAdd(&ctr->res_fwd, (unsigned long long)L); }
     }
-    __syncthreads();
+    if (to_fwd) { cand.stage[c] = 3; todo_fwd[atomicAdd(&ctr->todo_fwd, 1)] = c; atomicAdd(&ctr->res_fwd, (unsigned long long)L); }
   }
 }
 
@@ -741,8 +760,15 @@ static int run_filters(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bat
     BATH_HIP_TRY(ctx, hipEventRecord(ev[e++], ctx->stream));
     // 5. F2, local composition re-filter, optional plain Viterbi re-run
     hipLaunchKernelGGL(post_vit_kernel, dim3(dec_blocks), dim3(256), 0, ctx->stream, W.cand, W.cand_cap, W.ctr, P, W.todo_msv /* free by now */, W.todo_fwd);
-    hipLaunchKernelGGL(post_vit_local_kernel, dim3(16384), dim3(64), 0, ctx->stream, W.cand, W.ctr, P, W.pool, M, d_ssvsc, (int)om->base_b,
-                       om->scale_b, d_bgf, om->lt.d_p1, om->lt.d_lt1, om->lt.d_lt2, W.todo_msv, W.todo_vit2, W.todo_fwd);
+    if (P.do_bias) {
+      DevBuf &b_compo = ctx->scratch[36];                                       // 20 x 256 terms, then 20 sums per candidate
+      BATH_HIP_TRY(ctx, b_compo.reserve((size_t)20 * 256 * 4 + (size_t)W.cand_cap * 20 * 4 + 256));
+      float *d_terms = b_compo.as<float>(), *d_compo = d_terms + 20 * 256;
+      hipLaunchKernelGGL(compo_terms_kernel, dim3(20), dim3(256), 0, ctx->stream, d_bgf, (int)om->base_b, om->scale_b, d_terms);
+      hipLaunchKernelGGL(local_compo_kernel, dim3(16384), dim3(64), 0, ctx->stream, W.cand, W.ctr, M, d_ssvsc, d_terms, W.todo_msv, d_compo);
+      hipLaunchKernelGGL(post_vit_local_kernel, dim3(std::max(1, dec_blocks)), dim3(64), 0, ctx->stream, W.cand, W.ctr, P, W.pool, M, d_bgf, d_compo,
+                         om->lt.d_p1, om->lt.d_lt1, om->lt.d_lt2, W.todo_msv, W.todo_vit2, W.todo_fwd);
+    }
     BATH_HIP_TRY(ctx, hipGetLastError());
     if ((st = launch_vit_wave(ctx, om, cv, W.todo_vit2, cap, W.cand.vfsc, W.cand.vit_status, nullptr, &W.ctr->todo_vit2)) != BATH_OK) return st;
     hipLaunchKernelGGL(post_vit2_kernel, dim3(64), dim3(256), 0, ctx->stream, W.cand, W.ctr, P, W.todo_vit2, W.todo_fwd);
