@@ -284,7 +284,8 @@ int launch_vit_lane(bath_hip_ctx *ctx, const bath_hip_oprofile *om, SeqView v, c
                        ntodo_dev, skip_dev, d_sc, d_status, fsc, ssv, wins, wc, cap, kmm);                                                       \
     launched = true;                                                                                                                   \
   }
-  BATH_VITL_CASE(16) BATH_VITL_CASE(32) BATH_VITL_CASE(48) BATH_VITL_CASE(64) BATH_VITL_CASE(80) BATH_VITL_CASE(96) BATH_VITL_CASE(112)
+  BATH_VITL_CASE(16) BATH_VITL_CASE(32) BATH_VITL_CASE(48) BATH_VITL_CASE(64) BATH_VITL_CASE(68) BATH_VITL_CASE(72) BATH_VITL_CASE(76) BATH_VITL_CASE(80)
+  BATH_VITL_CASE(96) BATH_VITL_CASE(112)
 #undef BATH_VITL_CASE
   if (!launched) { ctx->set_error("lane-per-target Viterbi kernel: unsupported model length"); return BATH_EINVAL; }
   BATH_HIP_TRY(ctx, hipGetLastError());
