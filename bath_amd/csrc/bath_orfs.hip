@@ -23,6 +23,7 @@
 //                     sort: one global atomic per block and non-empty length bin).
 // Amino stream of (w, sf):  aa + 2*off[w] + 96*w + sf*pitch(n),  pitch(n) = (n/3 + 16) & ~15   (closed form: no prefix sums)
 #include <algorithm>
+#include <climits>
 #include <cstring>
 
 #include "bath_common.hpp"
@@ -196,8 +197,9 @@ __global__ __launch_bounds__(256) void orf_tile_kernel(SeqView dna, OrfTiles til
         for (int c = 0; c < 4; c++) if (c < cv[ph]) abase[so + (rev ? 3 - c : c)] = (uint8_t)(a[ph + 3 * c] & 0x7f);
       }
       // ---- length of the stop-free run entering this lane's four codons: scan position of the last stop before them in the tile
-      const int mine = mf ? 4 * i + ((31 - (int)__clz(mf)) >> 3) : -4;    // scan position of this lane's last stop
-      const int last = half_excl_max_scan(mine, -4, i == 0);
+      // (identity INT_MIN: the compiler then folds each step into one v_max_i32_dpp; with another identity it emits mov + dpp-mov + max)
+      const int mine = mf ? 4 * i + ((31 - (int)__clz(mf)) >> 3) : INT_MIN;    // scan position of this lane's last stop
+      const int last = half_excl_max_scan(mine, INT_MIN, i == 0);
       bool open = last < 0;                                               // no stop in the tile before this lane
       const int run_in = open ? 4 * i : 4 * i - 1 - last;
       auto record = [&](int u_stop, int len) {
