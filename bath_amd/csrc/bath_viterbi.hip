@@ -6,8 +6,14 @@
 // per block of 10^6 windows and they are short (mean ~45 aa), so the wave-per-target kernel
 // (vit_wave_kernel, bath_filters.hip) spends its time in cross-lane shuffles.  Here the three DP rows
 // (M, I, D) of a target live in one lane's VGPRs as packed int16, 64 targets per wavefront advance in
-// lock step (targets are bucketed by length first), and the serial D->D chain is simply a serial loop
-// inside the lane: no shuffles, no reductions.  All arithmetic is the reference's: saturating 16-bit adds
+// lock step (targets are bucketed by length first): no shuffles, no reductions.
+// Register r holds nodes r+1 (low half) and NR+r+1 (high half), so "the node to the left" is the previous register for both
+// halves and the D->D chain D(k+1) = max(M(k)+tMD(k), D(k)+tDD(k)) runs down the registers as TWO chains in one packed
+// add + max.  The high chain starts at node NR+1, whose D is the low chain's last value: it is run from -inf first and the
+// paths that enter through node NR+1 are added in a second packed pass, max(D, D(NR+1) + sum of tDD up to the node) -- equal to
+// the serial chain because every tDD is <= 0 (a saturating add of a sum of non-positive terms is the chain of saturating adds).
+// Round 2 started with adjacent nodes per register (three v_alignbit per pair for the left neighbours and the D chain as
+// ~10 unpacked instructions per pair): 28 instructions per pair, now 17.  All arithmetic is the reference's: saturating 16-bit adds
 // (v_pk_add_i16 clamp == adds_epi16), int16 wrap-around for the special states.
 // The D row is evaluated exactly on every row; the reference's lazy-F test only skips D->D work that
 // cannot reach any M cell (vitfilter.c:183-196), so M rows, xE and the score are identical.
@@ -29,9 +35,9 @@ __device__ __forceinline__ unsigned as_u(s16x2 v) { return __builtin_bit_cast(un
 struct VitLaneTables {
   const int16_t *rw;      // [30][pitch] emission words, node k at index k-1, padding -32768; row 29 = all -32768
   int rw_pitch_bytes;
-  const uint32_t *tw2;    // [NR][8] packed pairs (node 2r+1 | node 2r+2 << 16), order MM IM DM BM MD DD MI II
-  const int32_t *tdd;     // [2*NR] tDD(node) sign-extended, index node-1
-  const int16_t *rank;    // [2*NR] striped visiting rank of node (vitfilter.c:390-396), 32767 for padding
+  const uint32_t *tw2;    // [NR][8] packed pairs (node r+1 | node NR+r+1 << 16), order MM IM DM BM MD DD MI II
+  const uint32_t *cum;    // [NR + 16] (0 | sum of tDD(NR+1 .. NR+r), clamped to int16, << 16): what D(NR+1) loses on its way to node NR+r+1
+  const int16_t *rank;    // [2*NR] visiting rank (vitfilter.c:390-396) of node r+1 at 2r, of node NR+r+1 at 2r+1; 32767 for padding
 };
 
 struct VitLaneConsts {
@@ -104,8 +110,9 @@ __global__ __launch_bounds__(256, 1) void vit_lane_kernel(SeqView sq, VitLaneTab
       // one ascending pass, in place.  The previous row's values of the pair to the left are carried in three
       // registers (they are overwritten before the next pair needs them); the D->D chain rides along in <d>.
       // Transition pairs are wave-uniform: read straight from global memory so that they arrive by scalar loads.
-      unsigned pM = 0x80008000u, pI = 0x80008000u, pD = 0x80008000u;
-      int d = -32768;                                                            // D(1)
+      // left neighbours of register 0: node 0 (nothing) for the low half, node NR = the low half of register NR-1 for the high half
+      unsigned pM = (as_u(Mr[NR - 1]) << 16) | 0x8000u, pI = (as_u(Ir[NR - 1]) << 16) | 0x8000u, pD = (as_u(Dr[NR - 1]) << 16) | 0x8000u;
+      s16x2 dpk = NEG;                                                           // D(1) | D(NR+1) without the paths through node NR
       int twz = 0;
       asm volatile("" : "+s"(twz));                                              // opaque zero: keeps the (row-invariant) loads inside the row loop
       const uint32_t *tw = tw2g + twz;
@@ -131,9 +138,7 @@ __global__ __launch_bounds__(256, 1) void vit_lane_kernel(SeqView sq, VitLaneTab
           const unsigned tMM = t_c[8 * q + 0], tIM = t_c[8 * q + 1], tDM = t_c[8 * q + 2], tBM = t_c[8 * q + 3];
           const unsigned tMD = t_c[8 * q + 4], tDD = t_c[8 * q + 5], tMI = t_c[8 * q + 6], tII = t_c[8 * q + 7];
           const unsigned oM = as_u(Mr[rr]), oI = as_u(Ir[rr]), oD = as_u(Dr[rr]);
-          const s16x2 ms = as_s2(__builtin_amdgcn_alignbit(oM, pM, 16));
-          const s16x2 is = as_s2(__builtin_amdgcn_alignbit(oI, pI, 16));
-          const s16x2 ds = as_s2(__builtin_amdgcn_alignbit(oD, pD, 16));
+          const s16x2 ms = as_s2(pM), is = as_s2(pI), ds = as_s2(pD);
           s16x2 sv = pk_adds(xBv, as_s2(tBM));
           sv = pk_max(sv, pk_adds(ms, as_s2(tMM)));
           sv = pk_max(sv, pk_adds(is, as_s2(tIM)));
@@ -143,20 +148,27 @@ __global__ __launch_bounds__(256, 1) void vit_lane_kernel(SeqView sq, VitLaneTab
           const s16x2 dcv = pk_adds(sv, as_s2(tMD));                             // M(node)+tMD(node): the M->D part of D(node+1)
           xEv = pk_max(xEv, sv);
           Mr[rr] = sv;
-          // D(2r+1) = d;  D(2r+2) = max(dcv.lo, D(2r+1)+tDD(2r+1));  D(2r+3) = max(dcv.hi, D(2r+2)+tDD(2r+2))
-          const int tdd_lo = (int)(short)(tDD & 0xffffu), tdd_hi = (int)tDD >> 16;
-          const int dlo = d;
-          const int dhi = max((int)dcv.x, sat16(dlo + tdd_lo));
-          d = max((int)dcv.y, sat16(dhi + tdd_hi));
-          const s16x2 nd = {(short)dlo, (short)dhi};
-          Dr[rr] = nd;
+          // both D chains: D(node+1) = max(M(node)+tMD(node), D(node)+tDD(node))
+          Dr[rr] = dpk;
+          dpk = pk_max(dcv, pk_adds(dpk, as_s2(tDD)));
           pM = oM; pI = oI; pD = oD;
         }
         if (r + 2 < NR) t_c = t_n;
         if ((r & 3) == 2 && r + 2 < NR) e_c = e_n;
         // pin this unit's results here: pure arithmetic otherwise floats past the barrier and drags its scalars along
-        asm volatile("" : "+v"(Mr[r]), "+v"(Mr[r + 1]), "+v"(Ir[r]), "+v"(Ir[r + 1]), "+v"(Dr[r]), "+v"(Dr[r + 1]), "+v"(d), "+v"(xEv));
+        asm volatile("" : "+v"(Mr[r]), "+v"(Mr[r + 1]), "+v"(Ir[r]), "+v"(Ir[r + 1]), "+v"(Dr[r]), "+v"(Dr[r + 1]), "+v"(dpk), "+v"(xEv));
         __builtin_amdgcn_sched_barrier(0);
+      }
+      {
+        // the paths into the high chain through node NR+1: D(NR+1) = dpk.lo (the low chain's value past its last node)
+        const s16x2 epk = {(short)-32768, dpk.x};
+        if (__builtin_amdgcn_ballot_w64((int)dpk.x > -32768) != 0ull) {
+          int cz = 0;
+          asm volatile("" : "+s"(cz));                                           // as for the transitions: keep the loads in the row loop
+          const uint32_t *cu = tb.cum + cz;
+#pragma unroll
+          for (int r = 0; r < NR; r++) Dr[r] = pk_max(Dr[r], pk_adds(epk, as_s2(cu[r])));
+        }
       }
       if (on) {
         const int xE = max((int)xEv.x, (int)xEv.y);
@@ -268,7 +280,7 @@ int launch_len_sort(bath_hip_ctx *ctx, const int32_t *d_todo, const int *d_ntodo
 int launch_vit_lane(bath_hip_ctx *ctx, const bath_hip_oprofile *om, SeqView v, const int32_t *d_todo, int64_t ntodo, const int *ntodo_dev,
                     float *d_sc, int32_t *d_status, const VitWindowArgs *wa, const int *skip_dev) {
   if (ntodo == 0) return BATH_OK;
-  VitLaneTables tb{om->d_vit_rw, om->vit_rw_pitch, om->d_vit_tw2, om->d_vit_tdd, om->d_vit_rank};
+  VitLaneTables tb{om->d_vit_rw, om->vit_rw_pitch, om->d_vit_tw2, om->d_vit_cum, om->d_vit_rank};
   VitLaneConsts c{};
   c.M = om->M; c.base_w = om->base_w; c.xwE_loop = om->xw_E[0]; c.xwE_move = om->xw_E[1]; c.Q8 = std::max(2, ((om->M - 1) / 8) + 1);
   c.scale_w = om->scale_w; c.scale_b = om->scale_b; c.base_b = om->base_b; c.tec_b = om->tec_b; c.bias_b = om->bias_b;
