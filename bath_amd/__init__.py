@@ -22,7 +22,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
-LIB_PATH = os.path.join(_HERE, "libbathhip.so")
+LIB_PATH = os.environ.get("BATH_HIP_LIBRARY") or os.path.join(_HERE, "libbathhip.so")   # the override is for A/B timing of two builds
 
 OK, ERANGE, ENORESULT = 0, 16, 19
 KP, K, NEVPARAM = 29, 20, 8

@@ -86,6 +86,7 @@ struct PipelineSurvivor {
 struct bath_hip_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t tail_stream = nullptr;    // BATH_HIP_TAIL_PRIO=1 (experiment): the cascade's kernels after SSV, highest priority
   hipStream_t side_stream = nullptr;    // created on first use: kernels that may overlap the main stream's (pipeline)
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   hipStream_t copy_stream = nullptr;    // created on first use: host -> device uploads of packed blocks (bath_hip_seqs_upload_packed)

@@ -61,8 +61,11 @@ template <int NR, int G>
 __global__ __launch_bounds__(256, (NR <= 76 ? 4 : 1)) void ssv_orf_kernel(const uint8_t *__restrict__ aa, const OrfRec *__restrict__ orfs, const int *__restrict__ n_orfs_dev,
                                                       SeqView dna, const int16_t *__restrict__ cost_tab, int row_bytes,
                                                       const int16_t *__restrict__ emit_thresh, int thresh_max,
-                                                      Cand cand, int cand_cap, Counters *__restrict__ ctr) {
+                                                      Cand cand, int cand_cap, Counters *__restrict__ ctr, int chunk) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
+  // chunk > 0: not persistent -- a wave scores <chunk> consecutive groups of the list and exits, so that wave slots come free
+  // all the time and kernels of higher-priority streams get onto the chip while this one is running
+  if (chunk > 0 && (int64_t)blockIdx.x * (blockDim.x >> 6) * chunk * (64 / G) >= (int64_t)*n_orfs_dev) return;
   {
     const int n32 = kSsvRows * row_bytes / 4;
     const uint32_t *src = reinterpret_cast<const uint32_t *>(cost_tab);
@@ -79,7 +82,9 @@ __global__ __launch_bounds__(256, (NR <= 76 ? 4 : 1)) void ssv_orf_kernel(const 
   const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   const s16x2 fl = {0, 0};                                      // the begin score
-  for (int64_t tb = wave0 * TPW; tb < n_orfs; tb += nwaves * TPW) {
+  const int64_t tb_first = chunk > 0 ? wave0 * chunk * TPW : wave0 * TPW, tb_step = chunk > 0 ? TPW : nwaves * TPW;
+  const int64_t tb_end = chunk > 0 ? (tb_first + (int64_t)chunk * TPW < n_orfs ? tb_first + (int64_t)chunk * TPW : n_orfs) : n_orfs;
+  for (int64_t tb = tb_first; tb < tb_end; tb += tb_step) {
     const int64_t t = tb + lane / G;
     const bool live = t < n_orfs;
     OrfRec rec{0, 0, 0};
@@ -686,13 +691,15 @@ static int run_filters(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bat
     BATH_HIP_TRY(ctx, hipEventRecord(ev[e++], ctx->stream));
     // 2. SSV + F1 threshold, lane per ORF
     {
-      const int blocks = ctx->prop.multiProcessorCount * 4;
+      static const int ssv_chunk = [] { const char *e = std::getenv("BATH_HIP_SSV_CHUNK"); return e ? std::atoi(e) : 0; }();
+      int blocks = ctx->prop.multiProcessorCount * 4;
+      if (ssv_chunk > 0) blocks = (int)std::min<int64_t>((max_orfs + (int64_t)4 * (64 / om->G) * ssv_chunk - 1) / ((int64_t)4 * (64 / om->G) * ssv_chunk), 1 << 30);
       bool launched = false;
 #define BATH_ORF_CASE(N, GG)                                                                                                     \
   if (!launched && NRk == N && om->G == GG) {                                                                                    \
     if (ssv_shmem > 64 * 1024) (void)hipFuncSetAttribute((const void *)ssv_orf_kernel<N, GG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ssv_shmem); \
     hipLaunchKernelGGL((ssv_orf_kernel<N, GG>), dim3(blocks), dim3(256), ssv_shmem, ctx->stream, W.pool, ob.sorted, ob.ntotal,                  \
-                       dna->view(), om->d_ssv, om->ssv_row_bytes, d_emit, max_orf, W.cand, W.cand_cap, W.ctr);                   \
+                       dna->view(), om->d_ssv, om->ssv_row_bytes, d_emit, max_orf, W.cand, W.cand_cap, W.ctr, ssv_chunk);        \
     launched = true;                                                                                                             \
   }
       BATH_SSV_SHAPES(BATH_ORF_CASE)
@@ -701,6 +708,14 @@ static int run_filters(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bat
       BATH_HIP_TRY(ctx, hipGetLastError());
     }
     BATH_HIP_TRY(ctx, hipEventRecord(ev[e++], ctx->stream));
+    // everything after SSV works on a few 10^5 survivors in chains of latency-bound kernels: on a stream of its own with the
+    // highest priority, so that (with a non-persistent SSV) it runs while another part's translation + SSV fill the chip
+    hipStream_t bulk_stream = ctx->stream;
+    struct StreamRestore { bath_hip_ctx *c; hipStream_t s; ~StreamRestore() { c->stream = s; } } stream_restore{ctx, bulk_stream};
+    if (ctx->tail_stream) {
+      BATH_HIP_TRY(ctx, hipStreamWaitEvent(ctx->tail_stream, ev[e - 1], 0));
+      ctx->stream = ctx->tail_stream;
+    }
     // 3. SSV status; full MSV for the undecided
     hipLaunchKernelGGL(classify_kernel, dim3(dec_blocks), dim3(256), 0, ctx->stream, W.cand, W.cand_cap, W.ctr, om->lt.d_tjb, mc, W.todo_msv);
     BATH_HIP_TRY(ctx, hipGetLastError());
@@ -912,8 +927,12 @@ static int run_filters_lanes(bath_hip_ctx *ctx, const bath_hip_oprofile *om, con
       int lo = 0, hi = 0;
       if (hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi) {
         (void)hipStreamDestroy(lane->stream);
-        const int prio = ctx->lanes.empty() ? hi : lo;           // hi is numerically the smallest value = highest priority
+        const char *te = std::getenv("BATH_HIP_TAIL_PRIO");
+        const bool tails = te && te[0] == '1';
+        // hi is numerically the smallest value = highest priority.  With tail streams: tails highest, the first part's bulk work in the middle
+        const int prio = tails ? (ctx->lanes.empty() ? std::min(lo, hi + 1) : lo) : (ctx->lanes.empty() ? hi : lo);
         if (hipStreamCreateWithPriority(&lane->stream, hipStreamNonBlocking, prio) != hipSuccess) { ctx->set_error("hipStreamCreateWithPriority"); return BATH_EFAIL; }
+        if (tails && hipStreamCreateWithPriority(&lane->tail_stream, hipStreamNonBlocking, hi) != hipSuccess) { ctx->set_error("hipStreamCreateWithPriority"); return BATH_EFAIL; }
       }
     }
     ctx->lanes.push_back(lane);
