@@ -729,6 +729,25 @@ static int run_filters(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bat
     // 4. Viterbi filter with windows (P > F2) / SSV windows (P <= F2)
     wa.d_filtersc = W.cand.filtersc; wa.d_ssv_scores = d_ssvsc; wa.d_wins = W.wins; wa.d_win_count = &W.ctr->win_count; wa.win_cap = W.win_cap;
     wa.d_kminmax = W.cand.kminmax;
+    // p7_SSVFilter_BATH's windows for the candidates with P <= F2: other candidates than the Viterbi kernels', so it runs beside them
+    auto launch_ssvb = [&](hipStream_t stream) -> int {
+      const int Cc = (M + 63) / 64;
+      int Cs = -1;
+      for (int opt : {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 52}) if (Cc <= opt) { Cs = opt; break; }
+#define BATH_SSVB_CASE(N)                                                                                                          \
+  case N:                                                                                                                          \
+    hipLaunchKernelGGL(ssv_bath_kernel<N>, dim3(wave_grid_blocks(ctx) / 4), dim3(256), 0, stream, W.cand, W.ctr, W.todo_ssvb, W.pool, M,      \
+                       om->d_rb, om->rb_stride, d_ssvsc, om->lt.d_tjb, om->lt.d_nullsc, mc, invP_f1, W.wins, W.win_cap, W.ctr);    \
+    break;
+      switch (Cs) {
+        BATH_SSVB_CASE(1) BATH_SSVB_CASE(2) BATH_SSVB_CASE(3) BATH_SSVB_CASE(4) BATH_SSVB_CASE(6) BATH_SSVB_CASE(8)
+        BATH_SSVB_CASE(12) BATH_SSVB_CASE(16) BATH_SSVB_CASE(24) BATH_SSVB_CASE(32) BATH_SSVB_CASE(52)
+        default: ctx->set_error("model too long for the SSV window kernel"); return BATH_EINVAL;
+      }
+#undef BATH_SSVB_CASE
+      return BATH_OK;
+    };
+    bool ssvb_done = false;
     if (vit_lane_supported(om)) {       // lane per ORF, ORFs bucketed by length (bath_viterbi.hip)
       if ((st = launch_len_sort(ctx, W.todo_vit, &W.ctr->todo_vit, W.cand.len, W.len_bins, W.todo_sorted)) != BATH_OK) return st;
       // The lane kernel runs one wave per SIMD and a wave takes as long as its longest ORF (3.6 us per residue): the few
@@ -749,28 +768,15 @@ static int run_filters(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bat
         st = launch_vit_wave(ctx, om, cv, W.todo_sorted, cap, W.cand.vfsc, W.cand.vit_status, &wa, d_nlong);
         ctx->stream = main_stream;
         if (st != BATH_OK) return st;
+        if ((st = launch_ssvb(ctx->side_stream)) != BATH_OK) return st;      // ... and the SSV windows, all under the lane kernel
+        ssvb_done = true;
       }
       BATH_HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->side_stream));
       if ((st = launch_vit_lane(ctx, om, cv, W.todo_sorted, cap, &W.ctr->todo_vit, W.cand.vfsc, W.cand.vit_status, &wa, d_nlong)) != BATH_OK) return st;
       BATH_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
     } else if ((st = launch_vit_wave(ctx, om, cv, W.todo_vit, cap, W.cand.vfsc, W.cand.vit_status, &wa, &W.ctr->todo_vit)) != BATH_OK) return st;
     BATH_HIP_TRY(ctx, hipEventRecord(ev[e++], ctx->stream));
-    {
-      const int Cc = (M + 63) / 64;
-      int Cs = -1;
-      for (int opt : {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 52}) if (Cc <= opt) { Cs = opt; break; }
-#define BATH_SSVB_CASE(N)                                                                                                          \
-  case N:                                                                                                                          \
-    hipLaunchKernelGGL(ssv_bath_kernel<N>, dim3(wave_grid_blocks(ctx) / 4), dim3(256), 0, ctx->stream, W.cand, W.ctr, W.todo_ssvb, W.pool, M, \
-                       om->d_rb, om->rb_stride, d_ssvsc, om->lt.d_tjb, om->lt.d_nullsc, mc, invP_f1, W.wins, W.win_cap, W.ctr);    \
-    break;
-      switch (Cs) {
-        BATH_SSVB_CASE(1) BATH_SSVB_CASE(2) BATH_SSVB_CASE(3) BATH_SSVB_CASE(4) BATH_SSVB_CASE(6) BATH_SSVB_CASE(8)
-        BATH_SSVB_CASE(12) BATH_SSVB_CASE(16) BATH_SSVB_CASE(24) BATH_SSVB_CASE(32) BATH_SSVB_CASE(52)
-        default: ctx->set_error("model too long for the SSV window kernel"); return BATH_EINVAL;
-      }
-#undef BATH_SSVB_CASE
-    }
+    if (!ssvb_done && (st = launch_ssvb(ctx->stream)) != BATH_OK) return st;
     BATH_HIP_TRY(ctx, hipGetLastError());
     BATH_HIP_TRY(ctx, hipEventRecord(ev[e++], ctx->stream));
     // 5. F2, local composition re-filter, optional plain Viterbi re-run
