@@ -227,7 +227,7 @@ struct bath_hip_oprofile {
   float *d_bias_eo = nullptr;   // [Kp][2] emission odds of the 2-state bias filter HMM for om->compo
   // lane-per-target Viterbi kernel tables (bath_viterbi.hip); vit_NR == 0 when the model is too long for it
   int vit_NR = 0, vit_rw_pitch = 0;
-  int16_t *d_vit_rw = nullptr; uint32_t *d_vit_tw2 = nullptr; uint32_t *d_vit_cum = nullptr; int16_t *d_vit_rank = nullptr;
+  int16_t *d_vit_rw = nullptr; uint32_t *d_vit_tw2 = nullptr; int16_t *d_vit_rank = nullptr;
   mutable LenTables lt;
   // SSV emission thresholds per ORF length for the pipeline (bath_pipeline.hip: build_emit_table), cached per F1
   mutable int16_t *d_emit = nullptr;

@@ -174,7 +174,7 @@ extern "C" int bath_hip_set_fs_strict(bath_hip_ctx *ctx, int on) {
 extern "C" void bath_hip_oprofile_destroy(bath_hip_oprofile *om) {
   if (!om) return;
   for (void *p : {(void *)om->d_emit, (void *)om->d_ssv, (void *)om->d_rb, (void *)om->d_rw, (void *)om->d_tw, (void *)om->d_rf, (void *)om->d_tf,
-                  (void *)om->d_bias_eo, (void *)om->d_vit_rw, (void *)om->d_vit_tw2, (void *)om->d_vit_cum, (void *)om->d_vit_rank, (void *)om->lt.d_tjb, (void *)om->lt.d_xwmove, (void *)om->lt.d_pmove,
+                  (void *)om->d_bias_eo, (void *)om->d_vit_rw, (void *)om->d_vit_tw2, (void *)om->d_vit_rank, (void *)om->lt.d_tjb, (void *)om->lt.d_xwmove, (void *)om->lt.d_pmove,
                   (void *)om->lt.d_nullsc, (void *)om->lt.d_lt1, (void *)om->lt.d_lt2, (void *)om->lt.d_p1, (void *)om->d_cons, (void *)om->d_msc, (void *)om->d_tsc, (void *)om->d_rfb, (void *)om->d_tfb})
     if (p) (void)hipFree(p);
   delete om;
@@ -324,23 +324,14 @@ extern "C" int bath_hip_oprofile_convert(bath_hip_ctx *ctx, const bath_profile *
       for (int x = 0; x < kKp; x++)
         for (int k = 1; k <= M; k++) rwt[x * rowsz + slot(k)] = om->rw[x * W + k];
       std::vector<uint32_t> tw2((size_t)NRv * 8);
-      std::vector<uint32_t> cum((size_t)NRv + 16, 0u);
       std::vector<int16_t> rank((size_t)2 * NRv, (int16_t)32767);
       const int Q8 = std::max(2, ((M - 1) / 8) + 1);
       auto twv = [&](int node, int s) -> int { return node <= M ? (int)om->tw[(size_t)node * 8 + s] : -32768; };
       for (int r = 0; r < NRv; r++)
         for (int s = 0; s < 8; s++) tw2[(size_t)r * 8 + s] = ((uint32_t)(uint16_t)twv(r + 1, s)) | ((uint32_t)(uint16_t)twv(NRv + r + 1, s) << 16);
-      {
-        int64_t acc = 0;                                        // sum of tDD(NRv+1 .. NRv+r): what D(NRv+1) loses on its way to node NRv+r+1
-        for (int r = 0; r < NRv; r++) {
-          cum[(size_t)r] = (uint32_t)(uint16_t)(int16_t)std::max<int64_t>(acc, -32768) << 16;
-          acc += twv(NRv + r + 1, DD);
-        }
-      }
       for (int node = 1; node <= M; node++) rank[(size_t)slot(node)] = (int16_t)(((node - 1) % Q8) * 8 + (node - 1) / Q8);
       BATH_HIP_TRY(ctx, upload(&om->d_vit_rw, rwt.data(), rwt.size(), ctx->stream));
       BATH_HIP_TRY(ctx, upload(&om->d_vit_tw2, tw2.data(), tw2.size(), ctx->stream));
-      BATH_HIP_TRY(ctx, upload(&om->d_vit_cum, cum.data(), cum.size(), ctx->stream));
       BATH_HIP_TRY(ctx, upload(&om->d_vit_rank, rank.data(), rank.size(), ctx->stream));
     }
   }

@@ -10,8 +10,9 @@
 // Register r holds nodes r+1 (low half) and NR+r+1 (high half), so "the node to the left" is the previous register for both
 // halves and the D->D chain D(k+1) = max(M(k)+tMD(k), D(k)+tDD(k)) runs down the registers as TWO chains in one packed
 // add + max.  The high chain starts at node NR+1, whose D is the low chain's last value: it is run from -inf first and the
-// paths that enter through node NR+1 are added in a second packed pass, max(D, D(NR+1) + sum of tDD up to the node) -- equal to
-// the serial chain because every tDD is <= 0 (a saturating add of a sum of non-positive terms is the chain of saturating adds).
+// paths that enter through node NR+1 are added where the row is read again (the next row's pass), max(D, D(NR+1) + running sum of
+// tDD) -- equal to the serial chain because every tDD is <= 0 (a saturating add of a sum of non-positive terms is the chain of
+// saturating adds).
 // Round 2 started with adjacent nodes per register (three v_alignbit per pair for the left neighbours and the D chain as
 // ~10 unpacked instructions per pair): 28 instructions per pair, now 17.  All arithmetic is the reference's: saturating 16-bit adds
 // (v_pk_add_i16 clamp == adds_epi16), int16 wrap-around for the special states.
@@ -36,7 +37,6 @@ struct VitLaneTables {
   const int16_t *rw;      // [30][pitch] emission words, node k at index k-1, padding -32768; row 29 = all -32768
   int rw_pitch_bytes;
   const uint32_t *tw2;    // [NR][8] packed pairs (node r+1 | node NR+r+1 << 16), order MM IM DM BM MD DD MI II
-  const uint32_t *cum;    // [NR + 16] (0 | sum of tDD(NR+1 .. NR+r), clamped to int16, << 16): what D(NR+1) loses on its way to node NR+r+1
   const int16_t *rank;    // [2*NR] visiting rank (vitfilter.c:390-396) of node r+1 at 2r, of node NR+r+1 at 2r+1; 32767 for padding
 };
 
@@ -93,6 +93,7 @@ __global__ __launch_bounds__(256, 1) void vit_lane_kernel(SeqView sq, VitLaneTab
   int xB = (int16_t)(xN + xw_move);
   int xJ = -32768, xC = -32768;
   bool overflow = false;
+  short ePrev = -32768;                                                          // D(NR+1) of the previous row
 
   uint32_t wnext = (0 < L) ? *reinterpret_cast<const uint32_t *>(s) : 0x1d1d1d1du;
   for (int i0 = 0; i0 < Lw; i0 += 4) {
@@ -111,8 +112,13 @@ __global__ __launch_bounds__(256, 1) void vit_lane_kernel(SeqView sq, VitLaneTab
       // registers (they are overwritten before the next pair needs them); the D->D chain rides along in <d>.
       // Transition pairs are wave-uniform: read straight from global memory so that they arrive by scalar loads.
       // left neighbours of register 0: node 0 (nothing) for the low half, node NR = the low half of register NR-1 for the high half
-      unsigned pM = (as_u(Mr[NR - 1]) << 16) | 0x8000u, pI = (as_u(Ir[NR - 1]) << 16) | 0x8000u, pD = (as_u(Dr[NR - 1]) << 16) | 0x8000u;
+      unsigned pM = (as_u(Mr[NR - 1]) << 16) | 0x8000u, pI = (as_u(Ir[NR - 1]) << 16) | 0x8000u, pD = (as_u(Dr[NR - 1]) << 16) | 0x8000u;   // (low halves: never corrected)
       s16x2 dpk = NEG;                                                           // D(1) | D(NR+1) without the paths through node NR
+      // The previous row's D is stored WITHOUT the paths that enter the high chain through node NR+1; they are added here, where
+      // that row is read: max(D, D(NR+1) + tDD(NR+1) + ... ) with the running sum of the high chain's tDD (the low halves see
+      // -32768 + something = -32768, no effect).  No second pass over the registers, no table.
+      const s16x2 epk = {(short)-32768, ePrev};
+      s16x2 cpk = {0, 0};
       int twz = 0;
       asm volatile("" : "+s"(twz));                                              // opaque zero: keeps the (row-invariant) loads inside the row loop
       const uint32_t *tw = tw2g + twz;
@@ -137,7 +143,9 @@ __global__ __launch_bounds__(256, 1) void vit_lane_kernel(SeqView sq, VitLaneTab
           // MM IM DM BM | MD DD MI II
           const unsigned tMM = t_c[8 * q + 0], tIM = t_c[8 * q + 1], tDM = t_c[8 * q + 2], tBM = t_c[8 * q + 3];
           const unsigned tMD = t_c[8 * q + 4], tDD = t_c[8 * q + 5], tMI = t_c[8 * q + 6], tII = t_c[8 * q + 7];
-          const unsigned oM = as_u(Mr[rr]), oI = as_u(Ir[rr]), oD = as_u(Dr[rr]);
+          const unsigned oM = as_u(Mr[rr]), oI = as_u(Ir[rr]);
+          const unsigned oD = as_u(pk_max(Dr[rr], pk_adds(epk, cpk)));
+          cpk = pk_adds(cpk, as_s2(tDD));
           const s16x2 ms = as_s2(pM), is = as_s2(pI), ds = as_s2(pD);
           s16x2 sv = pk_adds(xBv, as_s2(tBM));
           sv = pk_max(sv, pk_adds(ms, as_s2(tMM)));
@@ -156,20 +164,10 @@ __global__ __launch_bounds__(256, 1) void vit_lane_kernel(SeqView sq, VitLaneTab
         if (r + 2 < NR) t_c = t_n;
         if ((r & 3) == 2 && r + 2 < NR) e_c = e_n;
         // pin this unit's results here: pure arithmetic otherwise floats past the barrier and drags its scalars along
-        asm volatile("" : "+v"(Mr[r]), "+v"(Mr[r + 1]), "+v"(Ir[r]), "+v"(Ir[r + 1]), "+v"(Dr[r]), "+v"(Dr[r + 1]), "+v"(dpk), "+v"(xEv));
+        asm volatile("" : "+v"(Mr[r]), "+v"(Mr[r + 1]), "+v"(Ir[r]), "+v"(Ir[r + 1]), "+v"(Dr[r]), "+v"(Dr[r + 1]), "+v"(dpk), "+v"(cpk), "+v"(xEv));
         __builtin_amdgcn_sched_barrier(0);
       }
-      {
-        // the paths into the high chain through node NR+1: D(NR+1) = dpk.lo (the low chain's value past its last node)
-        const s16x2 epk = {(short)-32768, dpk.x};
-        if (__builtin_amdgcn_ballot_w64((int)dpk.x > -32768) != 0ull) {
-          int cz = 0;
-          asm volatile("" : "+s"(cz));                                           // as for the transitions: keep the loads in the row loop
-          const uint32_t *cu = tb.cum + cz;
-#pragma unroll
-          for (int r = 0; r < NR; r++) Dr[r] = pk_max(Dr[r], pk_adds(epk, as_s2(cu[r])));
-        }
-      }
+      ePrev = dpk.x;                                                             // D(NR+1) of this row: the next row adds the paths through it
       if (on) {
         const int xE = max((int)xEv.x, (int)xEv.y);
         if (xE >= 32767) overflow = true;
@@ -280,7 +278,7 @@ int launch_len_sort(bath_hip_ctx *ctx, const int32_t *d_todo, const int *d_ntodo
 int launch_vit_lane(bath_hip_ctx *ctx, const bath_hip_oprofile *om, SeqView v, const int32_t *d_todo, int64_t ntodo, const int *ntodo_dev,
                     float *d_sc, int32_t *d_status, const VitWindowArgs *wa, const int *skip_dev) {
   if (ntodo == 0) return BATH_OK;
-  VitLaneTables tb{om->d_vit_rw, om->vit_rw_pitch, om->d_vit_tw2, om->d_vit_cum, om->d_vit_rank};
+  VitLaneTables tb{om->d_vit_rw, om->vit_rw_pitch, om->d_vit_tw2, om->d_vit_rank};
   VitLaneConsts c{};
   c.M = om->M; c.base_w = om->base_w; c.xwE_loop = om->xw_E[0]; c.xwE_move = om->xw_E[1]; c.Q8 = std::max(2, ((om->M - 1) / 8) + 1);
   c.scale_w = om->scale_w; c.scale_b = om->scale_b; c.base_b = om->base_b; c.tec_b = om->tec_b; c.bias_b = om->bias_b;
