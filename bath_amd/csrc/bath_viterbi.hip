@@ -51,7 +51,10 @@ struct VitLaneConsts {
 typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
 
 template <int NR>
-__global__ __launch_bounds__(256, 1) void vit_lane_kernel(SeqView sq, VitLaneTables tb, const uint32_t *__restrict__ tw2g, VitLaneConsts c, const int16_t *__restrict__ xwmove_tab,
+#ifndef BATH_VIT_WAVES
+#define BATH_VIT_WAVES 1
+#endif
+__global__ __launch_bounds__(256, (NR <= 76 ? BATH_VIT_WAVES : 1)) void vit_lane_kernel(SeqView sq, VitLaneTables tb, const uint32_t *__restrict__ tw2g, VitLaneConsts c, const int16_t *__restrict__ xwmove_tab,
                                                           const uint8_t *__restrict__ tjb_tab, const int32_t *__restrict__ todo, int64_t ntodo,
                                                           const int *__restrict__ ntodo_dev, const int *__restrict__ skip_dev, float *__restrict__ sc, int32_t *__restrict__ status,
                                                           const float *__restrict__ filtersc, const uint8_t *__restrict__ ssv_scores,
