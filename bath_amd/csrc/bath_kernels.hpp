@@ -167,14 +167,25 @@ __device__ __forceinline__ float bias_forward(const uint8_t *s, int L, int M, co
   float mx = fmaxf(fmaxf(d0, 0.0f), d1);
   d0 /= mx; d1 /= mx;
   logsc += (float)log((double)mx);
-  for (int i = 1; i < L; i++) {
-    x = min((int)s[i], 28);
-    float n0 = 0.0f + d0 * t00; n0 = n0 + d1 * t10; n0 *= e[2 * x];
-    float n1 = 0.0f + d0 * t01; n1 = n1 + d1 * t11; n1 *= e[2 * x + 1];
+  // Residues four at a time with the next four in flight: taken a byte per step, every residue is a trip to L2 (the byte, then the
+  // emission pair it selects) in front of the step's arithmetic, ~0.4 us per residue with nothing to hide it behind.  The caller
+  // keeps <e> in LDS where it can.  Only whole dwords inside the sequence are read (its last 1-3 residues go byte by byte).
+  auto step = [&](int xx) {
+    float n0 = 0.0f + d0 * t00; n0 = n0 + d1 * t10; n0 *= e[2 * xx];
+    float n1 = 0.0f + d0 * t01; n1 = n1 + d1 * t11; n1 *= e[2 * xx + 1];
     mx = fmaxf(fmaxf(n0, 0.0f), n1);
     d0 = n0 / mx; d1 = n1 / mx;
     logsc += (float)log((double)mx);
+  };
+  int i = 1;
+  uint32_t wnext = (i + 4 <= L) ? *reinterpret_cast<const uint32_t *>(s + i) : 0u;
+  for (; i + 4 <= L; i += 4) {
+    const uint32_t w = wnext;
+    if (i + 8 <= L) wnext = *reinterpret_cast<const uint32_t *>(s + i + 4);
+#pragma unroll
+    for (int j = 0; j < 4; j++) step(min((int)((w >> (8 * j)) & 0xffu), 28));
   }
+  for (; i < L; i++) step(min((int)s[i], 28));
   float end = 0.0f + d0 * 1.0f; end = end + d1 * 1.0f;
   logsc += (float)log((double)end);
   return logsc;

@@ -181,6 +181,9 @@ __global__ void f1_bias_kernel(Cand cand, int cand_cap, Counters *__restrict__ c
                                const float *__restrict__ eo, const float *__restrict__ nullsc_tab, const float *__restrict__ p1_tab,
                                const float *__restrict__ lt1_tab, const float *__restrict__ lt2_tab,
                                int32_t *__restrict__ todo_vit, int32_t *__restrict__ todo_ssvb) {
+  __shared__ float s_eo[kKp * 2];                          // the filter HMM's emission odds: read once per residue, from LDS
+  for (int i = threadIdx.x; i < kKp * 2; i += blockDim.x) s_eo[i] = eo[i];
+  __syncthreads();
   const int ncand = min(ctr->cand_count, cand_cap);
   for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < ncand; c += gridDim.x * blockDim.x) {
     const int L = cand.len[c];
@@ -195,7 +198,7 @@ __global__ void f1_bias_kernel(Cand cand, int cand_cap, Counters *__restrict__ c
     cand.stage[c] = 1;
     float filtersc = nullsc;
     if (p.do_bias) {
-      filtersc = bias_forward(pool + cand.off[c], L, M, eo, p1_tab[L]);
+      filtersc = bias_forward(pool + cand.off[c], L, M, s_eo, p1_tab[L]);
       filtersc = (filtersc + lt1_tab[L]) + lt2_tab[L];
       seqsc = (float)((double)(usc - filtersc) / kLog2);
       P = d_gumbel_surv(seqsc, p.evparam[0], p.evparam[1]);
