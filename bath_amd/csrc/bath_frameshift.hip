@@ -105,11 +105,33 @@ __device__ __forceinline__ void fs_load_logsum_table(float *s_tbl, const float *
   for (int i = threadIdx.x; i < 16000; i += blockDim.x) s_tbl[i] = (i < 15700) ? g_tbl[i] : 0.f;
 }
 
+// Cross-lane moves by DPP instead of ds_bpermute (__shfl_*): these kernels are chains of dependent operations, and a shuffle through
+// the LDS crossbar costs ~100+ cycles of that chain where a DPP operand costs a VALU instruction.  <old> is what a lane without a
+// source keeps: the identity of the combining operation, so that such lanes need no select.
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp_f(float v, float old) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float wave_shr1(float v, float fill) { return dpp_f<0x138>(v, fill); }          // lane l <- lane l-1, lane 0 <- fill
+__device__ __forceinline__ float wave_bcast_last(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63)); }
+
+// log-sum of a value per lane, result in every lane: an inclusive scan in lane order (row_shr 1/2/4/8, row_bcast 15/31), lane 63
+// broadcast.  BATH_FS_BPERMUTE: the xor butterfly through ds_bpermute this replaced.
 template <bool EXACT>
 __device__ __forceinline__ float wave_logsum(float v, const float *tbl) {
+#ifdef BATH_FS_BPERMUTE
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) v = flogsum<EXACT>(v, __shfl_xor(v, d, 64), tbl);
   return v;
+#else
+  v = flogsum<EXACT>(v, dpp_f<0x111>(v, -INFINITY), tbl);
+  v = flogsum<EXACT>(v, dpp_f<0x112>(v, -INFINITY), tbl);
+  v = flogsum<EXACT>(v, dpp_f<0x114>(v, -INFINITY), tbl);
+  v = flogsum<EXACT>(v, dpp_f<0x118>(v, -INFINITY), tbl);
+  v = flogsum<EXACT>(v, dpp_f<0x142, 0xa>(v, -INFINITY), tbl);
+  v = flogsum<EXACT>(v, dpp_f<0x143, 0xc>(v, -INFINITY), tbl);
+  return wave_bcast_last(v);
+#endif
 }
 
 __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
@@ -134,6 +156,7 @@ __device__ __forceinline__ void d_chain_fwd(const float (&md)[C], const float (&
   float A = -INFINITY, B = 0.f;
 #pragma unroll
   for (int c = 0; c < C; c++) { A = flogsum<EXACT>(md[c], A + dd[c], tbl); B += dd[c]; }
+#ifdef BATH_FS_BPERMUTE
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
     const float Ap = __shfl_up(A, d, 64), Bp = __shfl_up(B, d, 64);
@@ -142,6 +165,15 @@ __device__ __forceinline__ void d_chain_fwd(const float (&md)[C], const float (&
   }
   float din = __shfl_up(A, 1, 64);
   if (lane == 0) din = -INFINITY;
+#else
+  // lanes without a source see the identity map (A = -inf, B = 0): LS(A, -inf + B) = A, B + 0 = B
+#define BATH_DCHAIN_STEP(CTRL, MASK) { const float Ap = dpp_f<CTRL, MASK>(A, -INFINITY), Bp = dpp_f<CTRL, MASK>(B, 0.f); A = flogsum<EXACT>(A, Ap + B, tbl); B = B + Bp; }
+  BATH_DCHAIN_STEP(0x111, 0xf) BATH_DCHAIN_STEP(0x112, 0xf) BATH_DCHAIN_STEP(0x114, 0xf) BATH_DCHAIN_STEP(0x118, 0xf)
+  BATH_DCHAIN_STEP(0x142, 0xa) BATH_DCHAIN_STEP(0x143, 0xc)
+#undef BATH_DCHAIN_STEP
+  const float din = wave_shr1(A, -INFINITY);
+  (void)lane;
+#endif
   Dout[0] = din;
 #pragma unroll
   for (int c = 1; c < C; c++) Dout[c] = flogsum<EXACT>(md[c - 1], Dout[c - 1] + dd[c - 1], tbl);
@@ -283,8 +315,7 @@ __global__ __launch_bounds__(kFsBlock, fs_min_waves(C)) void fs3_fwd_kernel(SeqV
       for (int c = 0; c < C; c++) { e2[c] = e2n[c]; e3[c] = e3n[c]; e4[c] = e4n[c]; }
       if (i < L) { xn = (d[i] < 4) ? d[i] : 338; fetch(xn, x, w, v); }
       // values of row i-2 at node-1 for the lane's first node
-      float mIn = __shfl_up(Mr[1][C - 1], 1, 64), iIn = __shfl_up(Ir[1][C - 1], 1, 64), dIn = __shfl_up(Dr[1][C - 1], 1, 64);
-      if (lane == 0) mIn = iIn = dIn = -INFINITY;
+      const float mIn = wave_shr1(Mr[1][C - 1], -INFINITY), iIn = wave_shr1(Ir[1][C - 1], -INFINITY), dIn = wave_shr1(Dr[1][C - 1], -INFINITY);
       float Mc[C], Ic[C], ivc[C], md[C], dd[C];
       float eloc = -INFINITY;
       // nodes beyond M read the all -inf transition row M+1 and -inf emissions: every value below comes out -inf without a
@@ -398,8 +429,7 @@ __global__ __launch_bounds__(kFsBlock) void fs5_fwd_kernel(SeqView dna, FsDev p,
       const float *r3 = p.rsc + (size_t)imin(x * 341 + w * 85 + v * 21 + 2, 1364) * p.pitch;
       const float *r4 = p.rsc + (size_t)imin(x * 341 + w * 85 + v * 21 + u * 5 + 3, 1365) * p.pitch;
       const float *r5 = p.rsc + (size_t)imin(x * 341 + w * 85 + v * 21 + u * 5 + t + 4, 1366) * p.pitch;
-      float mIn = __shfl_up(Mr[0][C - 1], 1, 64), iIn = __shfl_up(Ir[0][C - 1], 1, 64), dIn = __shfl_up(Dr1[C - 1], 1, 64);
-      if (lane == 0) mIn = iIn = dIn = -INFINITY;
+      const float mIn = wave_shr1(Mr[0][C - 1], -INFINITY), iIn = wave_shr1(Ir[0][C - 1], -INFINITY), dIn = wave_shr1(Dr1[C - 1], -INFINITY);
       float Mc[C], Ic[C], ivc[C], md[C], dd[C];
       float *row = fo + (size_t)i * (M + 1) * 8;
       if (lane == 0) {
