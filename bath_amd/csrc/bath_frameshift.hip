@@ -217,7 +217,7 @@ __device__ __forceinline__ float bwd_bsum_strict(const float (&term)[C], int lan
   const int nl = (M + C - 1) / C;
   float b = -INFINITY;
   for (int l = 0; l < nl; l++) {
-    const float bin = (l == 0) ? -INFINITY : __shfl(b, l - 1, 64);
+    const float bin = (l == 0) ? -INFINITY : __shfl(b, 63 - (l - 1), 64);      // (Backward's lanes are in descending order: logical l = physical 63 - l)
     if (lane == l) {
       float cur = bin;
 #pragma unroll
@@ -228,7 +228,7 @@ __device__ __forceinline__ float bwd_bsum_strict(const float (&term)[C], int lan
       b = cur;
     }
   }
-  return __shfl(b, nl - 1, 64);
+  return __shfl(b, 63 - (nl - 1), 64);
 }
 
 // ... and the descending D chain: dstep(c, node, D(node+1)) -> D(node) is the row's own formula; returns D at the first node of
@@ -238,7 +238,7 @@ __device__ __forceinline__ float bwd_dnext_strict(F &&dstep, int lane, int M) {
   const int nl = (M + C - 1) / C;
   float dfirst = -INFINITY;
   for (int l = nl - 1; l >= 0; l--) {
-    const float dn_in = (l == nl - 1) ? -INFINITY : __shfl(dfirst, l + 1, 64);
+    const float dn_in = (l == nl - 1) ? -INFINITY : __shfl(dfirst, 63 - (l + 1), 64);
     if (lane == l) {
       float dn = dn_in;
 #pragma unroll
@@ -249,7 +249,7 @@ __device__ __forceinline__ float bwd_dnext_strict(F &&dstep, int lane, int M) {
       dfirst = dn;
     }
   }
-  float dnext = __shfl_down(dfirst, 1, 64);
+  float dnext = wave_shr1(dfirst, -INFINITY);                                 // from the logical lane above = the physical lane below
   if (lane >= nl - 1) dnext = -INFINITY;
   return dnext;
 }
@@ -554,9 +554,12 @@ __global__ __launch_bounds__(kFsBlock, fs_min_waves(C)) void fs_bwd_kernel(SeqVi
   constexpr int DEG = FIVE ? 1367 : 338;
   constexpr int NR = 5;                             // rows i+1..i+5 of M kept in registers
   const int M = p.M;
-  const int lane = threadIdx.x & 63;
+  // Lanes own their nodes in DESCENDING order (logical lane = 63 - physical lane): Backward's chains run from node M down, and with
+  // this order "the lane holding the next nodes" is the physical lane below, so the chains are the same upward DPP scans as Forward's
+  const int plane = threadIdx.x & 63;
+  const int lane = 63 - plane;
 #define LS(a, b) flogsum<EXACT>((a), (b), s_tbl)
-  for (int64_t job = fs_next_job(jobs, dna.n, lane); job >= 0; job = fs_next_job(jobs, dna.n, lane)) {
+  for (int64_t job = fs_next_job(jobs, dna.n, plane); job >= 0; job = fs_next_job(jobs, dna.n, plane)) {
     const int L = dna.len[job];
     const uint8_t *d = dna.data + dna.off[job];
     float *bo = bck ? bck + bck_off[job] : nullptr;
@@ -601,14 +604,12 @@ __global__ __launch_bounds__(kFsBlock, fs_min_waves(C)) void fs_bwd_kernel(SeqVi
             const float An = LS(xE, A + tdd);
             A = (node <= M) ? An : A; B = (node <= M) ? B + tdd : B;
           }
-#pragma unroll
-          for (int dlt = 1; dlt < 64; dlt <<= 1) {
-            const float An = __shfl_down(A, dlt, 64), Bn = __shfl_down(B, dlt, 64);
-            const float Am = LS(A, An + B);
-            A = (lane + dlt < 64) ? Am : A; B = (lane + dlt < 64) ? B + Bn : B;
-          }
-          dnext = __shfl_down(A, 1, 64);
-          if (lane == 63) dnext = -INFINITY;
+          // lanes without a source see the identity map (A = -inf, B = 0)
+#define BATH_BCHAIN_STEP(CTRL, MASK) { const float An = dpp_f<CTRL, MASK>(A, -INFINITY), Bn = dpp_f<CTRL, MASK>(B, 0.f); A = LS(A, An + B); B = B + Bn; }
+          BATH_BCHAIN_STEP(0x111, 0xf) BATH_BCHAIN_STEP(0x112, 0xf) BATH_BCHAIN_STEP(0x114, 0xf) BATH_BCHAIN_STEP(0x118, 0xf)
+          BATH_BCHAIN_STEP(0x142, 0xa) BATH_BCHAIN_STEP(0x143, 0xc)
+#undef BATH_BCHAIN_STEP
+          dnext = wave_shr1(A, -INFINITY);
         }
 #pragma unroll
         for (int c = C - 1; c >= 0; c--) {
@@ -681,8 +682,7 @@ __global__ __launch_bounds__(kFsBlock, fs_min_waves(C)) void fs_bwd_kernel(SeqVi
         if constexpr (FIVE) xE = xCn + tEM;
         else xE = LS(xJn + tEL, xCn + tEM);
         // ivx at node+1 for every node of the lane
-        float ivNext = __shfl_down(ivx[0], 1, 64);
-        if (lane == 63) ivNext = -INFINITY;
+        const float ivNext = wave_shr1(ivx[0], -INFINITY);
         // D chain (descending): D(k) = LS(LS(E, D(k+1)+tDD(k)), ivx(k+1)+tDM(k)); a(k) := LS(E, ivx(k+1)+tDM(k)) up to association
         float A = -INFINITY, B = 0.f;
         float base[C];
@@ -706,14 +706,12 @@ __global__ __launch_bounds__(kFsBlock, fs_min_waves(C)) void fs_bwd_kernel(SeqVi
             return (!FIVE && !mainrow && !tail) ? LS(dn + tdd, LS(xE, base[c])) : LS(LS(xE, dn + tdd), base[c]);
           }, lane, M);
         } else {
-#pragma unroll
-          for (int dlt = 1; dlt < 64; dlt <<= 1) {
-            const float An = __shfl_down(A, dlt, 64), Bn = __shfl_down(B, dlt, 64);
-            const float Am = LS(A, An + B);
-            A = (lane + dlt < 64) ? Am : A; B = (lane + dlt < 64) ? B + Bn : B;
-          }
-          dnext = __shfl_down(A, 1, 64);
-          if (lane == 63) dnext = -INFINITY;
+          // lanes without a source see the identity map (A = -inf, B = 0)
+#define BATH_BCHAIN_STEP(CTRL, MASK) { const float An = dpp_f<CTRL, MASK>(A, -INFINITY), Bn = dpp_f<CTRL, MASK>(B, 0.f); A = LS(A, An + B); B = B + Bn; }
+          BATH_BCHAIN_STEP(0x111, 0xf) BATH_BCHAIN_STEP(0x112, 0xf) BATH_BCHAIN_STEP(0x114, 0xf) BATH_BCHAIN_STEP(0x118, 0xf)
+          BATH_BCHAIN_STEP(0x142, 0xa) BATH_BCHAIN_STEP(0x143, 0xc)
+#undef BATH_BCHAIN_STEP
+          dnext = wave_shr1(A, -INFINITY);
         }
 #pragma unroll
         for (int c = C - 1; c >= 0; c--) {
