@@ -875,8 +875,7 @@ __global__ __launch_bounds__(256) void fs5_oa_kernel(SeqView dna, int M, const f
       float mIn[5], iIn[5], dIn[5];
 #pragma unroll
       for (int r = 0; r < 5; r++) {
-        mIn[r] = __shfl_up(Mr[r][C - 1], 1, 64); iIn[r] = __shfl_up(Ir[r][C - 1], 1, 64); dIn[r] = __shfl_up(Dr[r][C - 1], 1, 64);
-        if (lane == 0) mIn[r] = iIn[r] = dIn[r] = -INFINITY;
+        mIn[r] = wave_shr1(Mr[r][C - 1], -INFINITY); iIn[r] = wave_shr1(Ir[r][C - 1], -INFINITY); dIn[r] = wave_shr1(Dr[r][C - 1], -INFINITY);
       }
       float Mc[C], Ic[C], am[C], bm[C];
       float eloc = -INFINITY;
@@ -918,13 +917,11 @@ __global__ __launch_bounds__(256) void fs5_oa_kernel(SeqView dna, int M, const f
       float A = -INFINITY, Bm = 1.0f;
 #pragma unroll
       for (int c = 0; c < C; c++) { A = fmaxf(am[c], bm[c] * A); Bm *= bm[c]; }
-#pragma unroll
-      for (int dlt = 1; dlt < 64; dlt <<= 1) {
-        const float Ap = __shfl_up(A, dlt, 64), Bp = __shfl_up(Bm, dlt, 64);
-        if (lane >= dlt) { A = fmaxf(A, Bm * Ap); Bm *= Bp; }
-      }
-      float din = __shfl_up(A, 1, 64);
-      if (lane == 0) din = -INFINITY;
+      // lanes without a source see the identity map (A = -inf, B = 1); fmaxf ignores the NaN of 0 * -inf when B has underflowed
+#define BATH_OA_STEP(CTRL, MASK) { const float Ap = dpp_f<CTRL, MASK>(A, -INFINITY), Bp = dpp_f<CTRL, MASK>(Bm, 1.0f); A = fmaxf(A, Bm * Ap); Bm *= Bp; }
+      BATH_OA_STEP(0x111, 0xf) BATH_OA_STEP(0x112, 0xf) BATH_OA_STEP(0x114, 0xf) BATH_OA_STEP(0x118, 0xf) BATH_OA_STEP(0x142, 0xa) BATH_OA_STEP(0x143, 0xc)
+#undef BATH_OA_STEP
+      const float din = wave_shr1(A, -INFINITY);
       float Dc[C];
       Dc[0] = din;
 #pragma unroll
@@ -936,9 +933,10 @@ __global__ __launch_bounds__(256) void fs5_oa_kernel(SeqView dna, int M, const f
         orow[(size_t)node * 3 + 0] = Dc[c]; orow[(size_t)node * 3 + 1] = Ic[c]; orow[(size_t)node * 3 + 2] = Mc[c];
         eloc = fmaxf(eloc, (node < M) ? Mc[c] : fmaxf(Mc[c], Dc[c]));
       }
-      float xE = eloc;
-#pragma unroll
-      for (int dlt = 32; dlt >= 1; dlt >>= 1) xE = fmaxf(xE, __shfl_xor(xE, dlt, 64));
+      float xE = eloc;                                      // wave maximum: running maximum by DPP, last lane broadcast (max is exact in any order)
+      xE = fmaxf(xE, dpp_f<0x111>(xE, -INFINITY)); xE = fmaxf(xE, dpp_f<0x112>(xE, -INFINITY)); xE = fmaxf(xE, dpp_f<0x114>(xE, -INFINITY));
+      xE = fmaxf(xE, dpp_f<0x118>(xE, -INFINITY)); xE = fmaxf(xE, dpp_f<0x142, 0xa>(xE, -INFINITY)); xE = fmaxf(xE, dpp_f<0x143, 0xc>(xE, -INFINITY));
+      xE = wave_bcast_last(xE);
       float nN, nJ, nC;
       if (i <= 2) { nJ = ej * xE; nC = ec * xE; nN = X[i * 5 + 1]; }
       else { nJ = fmaxf(Jh[2] + X[i * 5 + 2], ej * xE); nC = fmaxf(Ch[2] + X[i * 5 + 4], ec * xE); nN = Nh[2] + X[i * 5 + 1]; }
@@ -1084,8 +1082,7 @@ __global__ __launch_bounds__(256, (C <= 3 ? BATH_FS_OA_WAVES : 1)) void fs5_deco
       float mIn[5], iIn[5], dIn[5];
 #pragma unroll
       for (int r = 0; r < 5; r++) {
-        mIn[r] = __shfl_up(Mr[r][C - 1], 1, 64); iIn[r] = __shfl_up(Ir[r][C - 1], 1, 64); dIn[r] = __shfl_up(Dr[r][C - 1], 1, 64);
-        if (lane == 0) mIn[r] = iIn[r] = dIn[r] = -INFINITY;
+        mIn[r] = wave_shr1(Mr[r][C - 1], -INFINITY); iIn[r] = wave_shr1(Ir[r][C - 1], -INFINITY); dIn[r] = wave_shr1(Dr[r][C - 1], -INFINITY);
       }
       float Mc[C], Ic[C], am[C], bmul[C];
       float eloc = -INFINITY;
@@ -1123,13 +1120,11 @@ __global__ __launch_bounds__(256, (C <= 3 ? BATH_FS_OA_WAVES : 1)) void fs5_deco
       float A = -INFINITY, Bm = 1.0f;
 #pragma unroll
       for (int c = 0; c < C; c++) { A = fmaxf(am[c], bmul[c] * A); Bm *= bmul[c]; }
-#pragma unroll
-      for (int dlt = 1; dlt < 64; dlt <<= 1) {
-        const float Ap = __shfl_up(A, dlt, 64), Bp = __shfl_up(Bm, dlt, 64);
-        if (lane >= dlt) { A = fmaxf(A, Bm * Ap); Bm *= Bp; }
-      }
-      float din = __shfl_up(A, 1, 64);
-      if (lane == 0) din = -INFINITY;
+      // lanes without a source see the identity map (A = -inf, B = 1); fmaxf ignores the NaN of 0 * -inf when B has underflowed
+#define BATH_OA_STEP(CTRL, MASK) { const float Ap = dpp_f<CTRL, MASK>(A, -INFINITY), Bp = dpp_f<CTRL, MASK>(Bm, 1.0f); A = fmaxf(A, Bm * Ap); Bm *= Bp; }
+      BATH_OA_STEP(0x111, 0xf) BATH_OA_STEP(0x112, 0xf) BATH_OA_STEP(0x114, 0xf) BATH_OA_STEP(0x118, 0xf) BATH_OA_STEP(0x142, 0xa) BATH_OA_STEP(0x143, 0xc)
+#undef BATH_OA_STEP
+      const float din = wave_shr1(A, -INFINITY);
       float Dc[C];
       Dc[0] = din;
 #pragma unroll
@@ -1141,9 +1136,10 @@ __global__ __launch_bounds__(256, (C <= 3 ? BATH_FS_OA_WAVES : 1)) void fs5_deco
         orow[(size_t)node * 3 + 0] = Dc[c]; orow[(size_t)node * 3 + 1] = Ic[c]; orow[(size_t)node * 3 + 2] = Mc[c];
         eloc = fmaxf(eloc, (node < M) ? Mc[c] : fmaxf(Mc[c], Dc[c]));
       }
-      float xE = eloc;
-#pragma unroll
-      for (int dlt = 32; dlt >= 1; dlt >>= 1) xE = fmaxf(xE, __shfl_xor(xE, dlt, 64));
+      float xE = eloc;                                      // wave maximum: running maximum by DPP, last lane broadcast (max is exact in any order)
+      xE = fmaxf(xE, dpp_f<0x111>(xE, -INFINITY)); xE = fmaxf(xE, dpp_f<0x112>(xE, -INFINITY)); xE = fmaxf(xE, dpp_f<0x114>(xE, -INFINITY));
+      xE = fmaxf(xE, dpp_f<0x118>(xE, -INFINITY)); xE = fmaxf(xE, dpp_f<0x142, 0xa>(xE, -INFINITY)); xE = fmaxf(xE, dpp_f<0x143, 0xc>(xE, -INFINITY));
+      xE = wave_bcast_last(xE);
       float nN, nJ, nC;
       if (i <= 2) { nJ = ej * xE; nC = ec * xE; nN = pn; }
       else { nJ = fmaxf(Jh[2] + pj, ej * xE); nC = fmaxf(Ch[2] + pc, ec * xE); nN = Nh[2] + pn; }
