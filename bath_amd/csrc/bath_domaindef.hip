@@ -501,6 +501,7 @@ struct StdEnvOut { int32_t i1, k1, i2, k2, ok; float oasc, domcorrection; int32_
 
 // p7_Decoding + p7_OptimalAccuracy + p7_OATrace + p7_Null2_ByExpectation on one envelope per lane (unihit model).
 // fwd / bck: (L+1) x (M+1) x {M, D, I}; on return bck holds the posteriors and fwd the OA matrix, as in the reference.
+constexpr int kStdTraceSpread = 64;
 __global__ void std_envelope_kernel(SeqView sq, int M, const float *__restrict__ tf, const float *__restrict__ rf, float *__restrict__ fwd, float *__restrict__ bck,
                                     const int64_t *__restrict__ dp_off, const float *__restrict__ fx, const float *__restrict__ bx, const int64_t *__restrict__ x_off,
                                     float *__restrict__ ppx_all, float *__restrict__ oax_all, float *__restrict__ em_all /* [n][2*(M+1)] */, StdEnvOut *__restrict__ out,
@@ -509,7 +510,10 @@ __global__ void std_envelope_kernel(SeqView sq, int M, const float *__restrict__
                                     const float *__restrict__ msc /* [Kp][M+1] log-odds */, const float *__restrict__ tsc /* [M][8] log */,
                                     const uint8_t *__restrict__ nt /* the DNA block */, const int64_t *__restrict__ nt_base, const int64_t *__restrict__ nt_dir,
                                     float *__restrict__ null2_out = nullptr /* optional [n][Kp]: the null2 vector itself (filled == 0 only) */) {
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // one envelope per wave: the traceback is a state machine and lanes in different states run one after the other (see
+  // fs5_trace_kernel); the chip has room for a wave per envelope
+  if (threadIdx.x % kStdTraceSpread) return;
+  const int64_t t = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / kStdTraceSpread;
   if (t >= sq.n) return;
   enum { XE = 0, XN, XJ, XB, XC, XS };
   enum { cM = 0, cD = 1, cI = 2 };
@@ -1055,7 +1059,7 @@ static int std_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bat
 #undef BATH_FILL
     BATH_HIP_TRY(ctx, hipGetLastError());
   }
-  hipLaunchKernelGGL(std_envelope_kernel, dim3((unsigned)((ne + 63) / 64)), dim3(64), 0, ctx->stream, ev.view(), M, om->d_tf, om->d_rf, b_f.as<float>(), b_b.as<float>(), b_dpo.as<int64_t>(),
+  hipLaunchKernelGGL(std_envelope_kernel, dim3((unsigned)((ne * kStdTraceSpread + 63) / 64)), dim3(64), 0, ctx->stream, ev.view(), M, om->d_tf, om->d_rf, b_f.as<float>(), b_b.as<float>(), b_dpo.as<int64_t>(),
                      b_fx.as<float>(), b_bx.as<float>(), d_exoff, b_px.as<float>(), b_ox.as<float>(), b_em.as<float>(), b_out.as<StdEnvOut>(),
                      om->d_cons, b_tb.as<uint8_t>(), b_toff.as<int64_t>(), filled,
                      om->d_msc, om->d_tsc, dna->d_data, b_toff.as<int64_t>() + ne + 1, b_toff.as<int64_t>() + 2 * ne + 1);
@@ -1231,7 +1235,7 @@ extern "C" int bath_hip_std_envelopes(bath_hip_ctx *ctx, const bath_hip_oprofile
   if ((st = launch_bwd_wave(ctx, om, sq->view(), n, b_fx.as<float>(), d_xo, d_sc + n, d_st + n, b_bx.as<float>(), b_b.as<float>(), d_dpo, 1)) != BATH_OK) return st;
   // p7_Decoding, p7_OptimalAccuracy, p7_Null2_ByExpectation (and the traceback, unused here), a lane per envelope: posteriors
   // overwrite Backward, the OA matrix overwrites Forward, as in the reference
-  hipLaunchKernelGGL(std_envelope_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, sq->view(), M, om->d_tf, om->d_rf, b_f.as<float>(), b_b.as<float>(), d_dpo,
+  hipLaunchKernelGGL(std_envelope_kernel, dim3((unsigned)((n * kStdTraceSpread + 63) / 64)), dim3(64), 0, ctx->stream, sq->view(), M, om->d_tf, om->d_rf, b_f.as<float>(), b_b.as<float>(), d_dpo,
                      b_fx.as<float>(), b_bx.as<float>(), d_xo, b_px.as<float>(), b_ox.as<float>(), b_em.as<float>(), b_out.as<StdEnvOut>(),
                      (const uint8_t *)nullptr, b_tb.as<uint8_t>(), d_to, 0, (const float *)nullptr, (const float *)nullptr, (const uint8_t *)nullptr,
                      (const int64_t *)nullptr, (const int64_t *)nullptr, b_n2.as<float>());

@@ -1183,13 +1183,22 @@ __global__ __launch_bounds__(256, (C <= 3 ? BATH_FS_OA_WAVES : 1)) void fs5_deco
 // (rescore_isolated_domain_frameshift, p7_domaindef.c:1086-1147), one LANE per envelope: the walk is serial (at most L+M
 // steps of a few dependent loads), envelopes are independent, and doing it here means the posterior and OA matrices
 // (>1 MB per envelope) never leave the device.  The trace is written backwards into <tbuf> and read forwards again.
+#ifndef BATH_TRACE_SPREAD
+#define BATH_TRACE_SPREAD 64
+#endif
+constexpr int kTraceSpread = BATH_TRACE_SPREAD;
 __global__ void fs5_trace_kernel(SeqView dna, int M, int maxcodons, const float *__restrict__ tf, const uint8_t *__restrict__ codons,
                                  const float *__restrict__ pp, const int64_t *__restrict__ pp_off, const float *__restrict__ px, const int64_t *__restrict__ x_off,
                                  const float *__restrict__ oa, const int64_t *__restrict__ oa_off, const float *__restrict__ ox,
                                  const float *__restrict__ null2 /* [n][Kp] */, uint2 *__restrict__ tbuf, const int64_t *__restrict__ t_off, FsTraceOut *__restrict__ out,
                                  const uint8_t *__restrict__ indel_tab, const uint8_t *__restrict__ cons, uint16_t *__restrict__ steps,
                                  const float *__restrict__ amino /* rsc + maxcodons*pitch: the amino rows */, int pitch) {
-  const int64_t job = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // One envelope per WAVE (kTraceSpread = 64 lanes apart): the walk is a state machine whose lanes diverge at every step (each
+  // state's loads and compares run under their own exec mask, one after the other), so a wave holding 64 envelopes pays for
+  // every state present among them at every step.  The chip has room for a wave per envelope: 2.77 -> 1.15 ms on the bench's
+  // 4.8 k envelopes (8 per wave: 1.53, 4 per wave: 1.36).
+  if (threadIdx.x % kTraceSpread) return;
+  const int64_t job = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / kTraceSpread;
   if (job >= dna.n) return;
   enum { sS = 0, sN, sB, sM, sD, sI, sE, sJ, sC, sT };
   enum { XE = 0, XN, XJ, XB, XC };
@@ -1895,7 +1904,7 @@ int bath::fs5_envelopes_ex(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, cons
     int64_t *d_toff = reinterpret_cast<int64_t *>(b_tb.as<char>() + ((size_t)toff[(size_t)n] * sizeof(uint2) + 255) / 256 * 256);
     BATH_HIP_TRY(ctx, hipMemcpyAsync(d_toff, toff.data(), (size_t)(n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
     const int s6 = ctx->span_begin("fs5_trace_kernel", ctx->stream, (double)toff[(size_t)n], 0.0);
-    hipLaunchKernelGGL(fs5_trace_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, dna->view(), M, om->maxcodons, om->d_tf, om->d_codons,
+    hipLaunchKernelGGL(fs5_trace_kernel, dim3((unsigned)((n * kTraceSpread + 63) / 64)), dim3(64), 0, ctx->stream, dna->view(), M, om->maxcodons, om->d_tf, om->d_codons,
                        b_f.as<float>(), d_foff, b_fx.as<float>(), d_xoff, b_o.as<float>(), d_boff, b_ox.as<float>(), b_n2.as<float>(), b_tb.as<uint2>(), d_toff,
                        b_to.as<FsTraceOut>(), om->d_indel, cons, steps ? b_steps.as<uint16_t>() : nullptr,
                        om->d_rsc + (size_t)om->maxcodons * om->pitch, om->pitch);
