@@ -497,6 +497,70 @@ __global__ void std_regions_kernel(int64_t n, const int32_t *__restrict__ len, c
   out[0] = nreg;                           // may exceed kStdMaxRegions: the host checks
 }
 
+// The same with a WAVE per ORF and the rows in LDS (ORFs up to Lcap residues; the lane kernel above takes longer ones).  The per-row
+// terms are elementwise (64 lanes); what the reference accumulates in sequence -- the running scale product, btot, etot -- one lane
+// accumulates in that order from LDS; the region scan runs uniformly on all lanes with the inner "best split" maximum spread over
+// them (a maximum does not care about order).  Same operations in the same order as the lane kernel: identical regions.  The lane
+// kernel walked its ORF alone, every row a trip to L2: 1.2 ms for the bench block's 7.6 k ORFs against ~0.1 ms.
+__global__ __launch_bounds__(64) void std_regions_wave_kernel(int64_t n, const int32_t *__restrict__ len, const float *__restrict__ fx, const float *__restrict__ bx,
+                                                              const int64_t *__restrict__ x_off, const float *__restrict__ pmove_tab, int Lcap,
+                                                              int32_t *__restrict__ regions /* [n][1 + 3*kStdMaxRegions] */) {
+  extern __shared__ float sm[];                                              // sp, btot, etot, mocc: (Lcap + 1) floats each
+  enum { XE = 0, XN, XJ, XB, XC, XS };
+  const int lane = threadIdx.x;
+  float *ssp = sm, *sb = sm + (Lcap + 1), *se = sb + (Lcap + 1), *smo = se + (Lcap + 1);
+  for (int64_t t = blockIdx.x; t < n; t += gridDim.x) {
+    const int L = len[t];
+    if (L > Lcap) continue;
+    const float *F = fx + x_off[t], *B = bx + x_off[t];
+    int32_t *out = regions + t * (1 + 3 * kStdMaxRegions);
+    const float ploop = 1.0f - pmove_tab[L];
+    __syncthreads();                                                         // the previous ORF's readers are done
+    for (int i = 1 + lane; i <= L; i += 64) smo[i] = F[(size_t)(i - 1) * 6 + XS] / B[(size_t)(i - 1) * 6 + XS];
+    __syncthreads();
+    if (lane == 0) {                                                         // scaleproduct after row i (before row i+1)
+      float sp = (float)(1.0 / (double)B[XN]);
+      ssp[0] = sp;
+      for (int i = 1; i <= L; i++) { sp *= smo[i]; ssp[i] = sp; }
+    }
+    __syncthreads();
+    for (int i = 1 + lane; i <= L; i += 64) {
+      const float spb = ssp[i - 1], spa = ssp[i];
+      sb[i] = F[(size_t)(i - 1) * 6 + XB] * B[(size_t)(i - 1) * 6 + XB] * F[(size_t)(i - 1) * 6 + XS] * spb;
+      se[i] = F[(size_t)i * 6 + XE] * B[(size_t)i * 6 + XE] * F[(size_t)i * 6 + XS] * spa;
+      float njcp = F[(size_t)(i - 1) * 6 + XN] * B[(size_t)i * 6 + XN] * ploop * spa;
+      njcp += F[(size_t)(i - 1) * 6 + XJ] * B[(size_t)i * 6 + XJ] * ploop * spa;
+      njcp += F[(size_t)(i - 1) * 6 + XC] * B[(size_t)i * 6 + XC] * ploop * spa;
+      smo[i] = (float)(1. - njcp);
+    }
+    __syncthreads();
+    if (lane == 0) {                                                         // btot, etot: sums in the reference's order
+      sb[0] = se[0] = smo[0] = 0.f;
+      float b = 0.f, e = 0.f;
+      for (int i = 1; i <= L; i++) { b = b + sb[i]; sb[i] = b; e = e + se[i]; se[i] = e; }
+    }
+    __syncthreads();
+    const float rt1 = 0.25f, rt2 = 0.10f, rt3 = 0.20f;
+    int i = -1, nreg = 0;
+    bool triggered = false;
+    for (int j = 1; j <= L; j++) {                                           // uniform over the wave: every lane reads the same LDS words
+      if (!triggered) {
+        if (smo[j] - (sb[j] - sb[j - 1]) < rt2) i = j;
+        else if (i == -1) i = j;
+        if (smo[j] >= rt1) triggered = true;
+      } else if (smo[j] - (se[j] - se[j - 1]) < rt2) {
+        float best = -1.0f;
+        for (int z = i + lane; z <= j; z += 64) best = fmaxf(best, fminf(se[z] - se[i - 1], sb[j] - sb[z - 1]));
+        for (int d = 32; d >= 1; d >>= 1) best = fmaxf(best, __shfl_xor(best, d, 64));
+        if (lane == 0 && nreg < kStdMaxRegions) { out[1 + 3 * nreg] = i; out[2 + 3 * nreg] = j; out[3 + 3 * nreg] = best >= rt3 ? 1 : 0; }
+        nreg++;
+        i = -1; triggered = false;
+      }
+    }
+    if (lane == 0) out[0] = nreg;                                            // may exceed kStdMaxRegions: the host checks
+  }
+}
+
 struct StdEnvOut { int32_t i1, k1, i2, k2, ok; float oasc, domcorrection; int32_t ncol, exact; float aliscore; };
 
 // p7_Decoding + p7_OptimalAccuracy + p7_OATrace + p7_Null2_ByExpectation on one envelope per lane (unihit model).
@@ -918,8 +982,17 @@ static int std_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bat
   BATH_HIP_TRY(ctx, b_reg.reserve((size_t)ns * RS * 4 + 64));
   if ((st = launch_fwd_wave(ctx, om, view.view(), nullptr, ns, b_sc.as<float>(), b_st.as<int32_t>(), nullptr, b_fx.as<float>(), d_xoff)) != BATH_OK) return st;
   if ((st = launch_bwd_wave(ctx, om, view.view(), ns, b_fx.as<float>(), d_xoff, b_sc.as<float>() + ns, b_st.as<int32_t>() + ns, b_bx.as<float>())) != BATH_OK) return st;
-  hipLaunchKernelGGL(std_regions_kernel, dim3((unsigned)((ns + 63) / 64)), dim3(64), 0, ctx->stream, ns, view.d_len, b_fx.as<float>(), b_bx.as<float>(), d_xoff, om->lt.d_pmove,
-                     b_work.as<float>(), b_reg.as<int32_t>());
+  {
+    const char *e = std::getenv("BATH_HIP_STD_SERIAL");
+    const size_t shm = (size_t)4 * ((size_t)view.maxlen + 1) * sizeof(float);
+    if (shm <= (size_t)128 * 1024 && !(e && e[0] == '1')) {                     // a wave per ORF, rows in LDS
+      if (shm > 64 * 1024) BATH_HIP_TRY(ctx, hipFuncSetAttribute((const void *)std_regions_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+      hipLaunchKernelGGL(std_regions_wave_kernel, dim3((unsigned)std::min<int64_t>(ns, 65535)), dim3(64), shm, ctx->stream, ns, view.d_len, b_fx.as<float>(), b_bx.as<float>(),
+                         d_xoff, om->lt.d_pmove, view.maxlen, b_reg.as<int32_t>());
+    } else
+      hipLaunchKernelGGL(std_regions_kernel, dim3((unsigned)((ns + 63) / 64)), dim3(64), 0, ctx->stream, ns, view.d_len, b_fx.as<float>(), b_bx.as<float>(), d_xoff, om->lt.d_pmove,
+                         b_work.as<float>(), b_reg.as<int32_t>());
+  }
   BATH_HIP_TRY(ctx, hipGetLastError());
   std::vector<int32_t> regions((size_t)ns * RS);
   BATH_HIP_TRY(ctx, hipMemcpyAsync(regions.data(), b_reg.p, regions.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
