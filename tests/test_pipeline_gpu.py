@@ -189,14 +189,14 @@ def test_streamed_packed_blocks_equal_resident_blocks(gpu_ctx):
     om = ba.OProfile(gpu_ctx, ba.Profile(hmm))
     pipe = ba.Pipeline(gpu_ctx, om, fs_pipe=False)
     rng = np.random.default_rng(17)
-    lens = [1000, 997, 15, 1, 0, 1003, 64, 4099] + [int(x) for x in rng.integers(200, 1400, size=40)]
+    lens = [1000, 997, 15, 1, 0, 1003, 64, 4099, 70001, 131072 + 5] + [int(x) for x in rng.integers(200, 1400, size=40)]   # two longer than a wave's 64 k nt share
 
     def content(seed):
         r = np.random.default_rng(seed)
         seqs = [r.integers(0, 4, size=L).astype(np.uint8) for L in lens]
         for i, aa in enumerate(common.emit_from_model(r, model, 12, flank=5)):
             nt = common.revtranslate(r, aa, model.basic)
-            j = 8 + i
+            j = 10 + i
             k = min(len(nt), len(seqs[j]))
             seqs[j][:k] = nt[:k]
         for j in (0, 5, 9, 20):                                   # degenerate nucleotides -> exception list
