@@ -1,5 +1,6 @@
 // bath_kernels.hpp -- device helpers shared by the kernels (gfx950, wave64).
 #pragma once
+#include <climits>
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -10,15 +11,20 @@ namespace bath {
 
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 
+// Wave maximum / minimum by DPP: a running maximum in lane order (row_shr 1/2/4/8, row_bcast 15/31: six v_max_i32_dpp, the
+// identity as the value a lane without a source sees), the last lane broadcast with v_readlane.  The xor butterfly through
+// ds_bpermute this replaces cost a trip through the LDS crossbar per step in the middle of the callers' dependent chains.
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ int dpp_i(int v, int old) { return __builtin_amdgcn_update_dpp(old, v, CTRL, ROW_MASK, 0xf, false); }
 __device__ __forceinline__ int wave_max_i32(int v) {
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) v = max(v, __shfl_xor(v, d, 64));
-  return v;
+  v = max(v, dpp_i<0x111>(v, INT_MIN)); v = max(v, dpp_i<0x112>(v, INT_MIN)); v = max(v, dpp_i<0x114>(v, INT_MIN));
+  v = max(v, dpp_i<0x118>(v, INT_MIN)); v = max(v, dpp_i<0x142, 0xa>(v, INT_MIN)); v = max(v, dpp_i<0x143, 0xc>(v, INT_MIN));
+  return __builtin_amdgcn_readlane(v, 63);
 }
 __device__ __forceinline__ int wave_min_i32(int v) {
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) v = min(v, __shfl_xor(v, d, 64));
-  return v;
+  v = min(v, dpp_i<0x111>(v, INT_MAX)); v = min(v, dpp_i<0x112>(v, INT_MAX)); v = min(v, dpp_i<0x114>(v, INT_MAX));
+  v = min(v, dpp_i<0x118>(v, INT_MAX)); v = min(v, dpp_i<0x142, 0xa>(v, INT_MAX)); v = min(v, dpp_i<0x143, 0xc>(v, INT_MAX));
+  return __builtin_amdgcn_readlane(v, 63);
 }
 __device__ __forceinline__ float wave_sum_f32(float v) {
 #pragma unroll
