@@ -551,7 +551,7 @@ __global__ __launch_bounds__(64) void std_regions_wave_kernel(int64_t n, const i
       } else if (smo[j] - (se[j] - se[j - 1]) < rt2) {
         float best = -1.0f;
         for (int z = i + lane; z <= j; z += 64) best = fmaxf(best, fminf(se[z] - se[i - 1], sb[j] - sb[z - 1]));
-        for (int d = 32; d >= 1; d >>= 1) best = fmaxf(best, __shfl_xor(best, d, 64));
+        best = wave_max_f32(best);
         if (lane == 0 && nreg < kStdMaxRegions) { out[1 + 3 * nreg] = i; out[2 + 3 * nreg] = j; out[3 + 3 * nreg] = best >= rt3 ? 1 : 0; }
         nreg++;
         i = -1; triggered = false;
@@ -843,8 +843,7 @@ __global__ __launch_bounds__(256) void std_envelope_fill_kernel(SeqView sq, int 
       if (i == 1) { sN = pxN; sC = pxC; sJ = pxJ; } else { sN += pxN; sC += pxC; sJ += pxJ; }
       scaleproduct *= FX[(size_t)i * 6 + XS] / BX[(size_t)i * 6 + XS];
       // optimal-accuracy row (p7_OptimalAccuracy)
-      float mIn = __shfl_up(pvM[C - 1], 1, 64), iIn = __shfl_up(pvI[C - 1], 1, 64), dIn = __shfl_up(pvD[C - 1], 1, 64);
-      if (lane == 0) mIn = iIn = dIn = -INFINITY;
+      const float mIn = wave_shr1_f32(pvM[C - 1], -INFINITY), iIn = wave_shr1_f32(pvI[C - 1], -INFINITY), dIn = wave_shr1_f32(pvD[C - 1], -INFINITY);
       float cuM[C], cuI[C], cuD[C];
       float fc = -INFINITY; bool fpass = true;                              // the lane's composite D-chain function
       float xE = -INFINITY;
@@ -888,8 +887,7 @@ __global__ __launch_bounds__(256) void std_envelope_fill_kernel(SeqView sq, int 
         } else cuD[c] = -INFINITY;
         pvM[c] = cuM[c]; pvI[c] = cuI[c]; pvD[c] = cuD[c];
       }
-#pragma unroll
-      for (int d = 32; d >= 1; d >>= 1) xE = fmaxf(xE, __shfl_xor(xE, d, 64));
+      xE = wave_max_f32(xE);
       oxJ = fmaxf(oxJ + pxJ, 0.0f);
       oxC = fmaxf(oxC + pxC, xE);
       oxN = oxN + pxN;

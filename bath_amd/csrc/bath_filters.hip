@@ -119,8 +119,7 @@ __global__ __launch_bounds__(256) void msv_wave_kernel(SeqView sq, int M, const 
     for (int i = 0; i < L; i++) {
       const int x = min((int)s[i], kKp - 1);
       const uint8_t *row = rb + (size_t)x * rb_stride;
-      int prev = __shfl_up(dp[C - 1], 1, 64);
-      if (lane == 0) prev = 0;
+      int prev = wave_shr1_i32(dp[C - 1], 0);
       int xE = 0;
 #pragma unroll
       for (int k = 0; k < C; k++) {
@@ -213,8 +212,7 @@ __global__ __launch_bounds__(256) void vit_wave_kernel(SeqView sq, int M, const 
     for (int i = 1; i <= L; i++) {
       const int x = min((int)s[i - 1], kKp - 1);
       const int16_t *rw = s_rw + (size_t)x * (M + 1);
-      int mIn = __shfl_up(Mp[C - 1], 1, 64), iIn = __shfl_up(Ip[C - 1], 1, 64), dIn = __shfl_up(Dp[C - 1], 1, 64);
-      if (lane == 0) mIn = iIn = dIn = -32768;
+      const int mIn = wave_shr1_i32(Mp[C - 1], -32768), iIn = wave_shr1_i32(Ip[C - 1], -32768), dIn = wave_shr1_i32(Dp[C - 1], -32768);
       int Mc[C], Ic[C], dcv[C], tdd[C];
       int xEl = -32768;
 #pragma unroll
@@ -281,13 +279,11 @@ __global__ __launch_bounds__(256) void vit_wave_kernel(SeqView sq, int M, const 
 #pragma unroll
       for (int k = 0; k < C; k++) { A = max(dcv[k], A + tdd[k]); B += tdd[k]; A = max(A, -(1 << 28)); }
       // inclusive scan of f_l(x) = max(A_l, x + B_l)
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const int Ap = __shfl_up(A, d, 64), Bp = __shfl_up(B, d, 64);
-        if (lane >= d) { A = max(A, max(Ap, -(1 << 28)) + B); B = max(B + Bp, -(1 << 28)); }
-      }
-      int din = __shfl_up(A, 1, 64);
-      if (lane == 0) din = -32768;
+      // by DPP; lanes without a source see the identity map (A = -2^28, B = 0).  Integer (max,+): any scan order gives the same D row
+#define BATH_VIT_STEP(CTRL, MASK) { const int Ap = dpp_i<CTRL, MASK>(A, -(1 << 28)), Bp = dpp_i<CTRL, MASK>(B, 0); A = max(A, max(Ap, -(1 << 28)) + B); B = max(B + Bp, -(1 << 28)); }
+      BATH_VIT_STEP(0x111, 0xf) BATH_VIT_STEP(0x112, 0xf) BATH_VIT_STEP(0x114, 0xf) BATH_VIT_STEP(0x118, 0xf) BATH_VIT_STEP(0x142, 0xa) BATH_VIT_STEP(0x143, 0xc)
+#undef BATH_VIT_STEP
+      int din = wave_shr1_i32(A, -32768);
       din = max(din, -32768);
       int Dc[C];
       Dc[0] = din;
@@ -357,8 +353,7 @@ __global__ __launch_bounds__(256) void fwd_wave_kernel(SeqView sq, int M, const 
     for (int i = 1; i <= L; i++) {
       const int x = min((int)s[i - 1], kKp - 1);
       const float *rf = s_rf + (size_t)x * (M + 1);
-      float mIn = __shfl_up(Mp[C - 1], 1, 64), iIn = __shfl_up(Ip[C - 1], 1, 64), dIn = __shfl_up(Dp[C - 1], 1, 64);
-      if (lane == 0) mIn = iIn = dIn = 0.f;
+      const float mIn = wave_shr1_f32(Mp[C - 1], 0.f), iIn = wave_shr1_f32(Ip[C - 1], 0.f), dIn = wave_shr1_f32(Dp[C - 1], 0.f);
       float Mc[C], Ic[C], md[C], tdd[C];
       float sumE = 0.f;
 #pragma unroll

@@ -16,6 +16,18 @@ typedef short s16x2 __attribute__((ext_vector_type(2)));
 // ds_bpermute this replaces cost a trip through the LDS crossbar per step in the middle of the callers' dependent chains.
 template <int CTRL, int ROW_MASK = 0xf>
 __device__ __forceinline__ int dpp_i(int v, int old) { return __builtin_amdgcn_update_dpp(old, v, CTRL, ROW_MASK, 0xf, false); }
+// lane l <- lane l-1, lane 0 <- fill (wave_shr:1)
+__device__ __forceinline__ int wave_shr1_i32(int v, int fill) { return dpp_i<0x138>(v, fill); }
+__device__ __forceinline__ float wave_shr1_f32(float v, float fill) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, fill), __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float wave_max_f32(float v) {                     // a maximum is exact in any order
+  const int ninf = (int)0xff800000;
+#define BATH_FMAX_STEP(CTRL, MASK) v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(ninf, __builtin_bit_cast(int, v), CTRL, MASK, 0xf, false)));
+  BATH_FMAX_STEP(0x111, 0xf) BATH_FMAX_STEP(0x112, 0xf) BATH_FMAX_STEP(0x114, 0xf) BATH_FMAX_STEP(0x118, 0xf) BATH_FMAX_STEP(0x142, 0xa) BATH_FMAX_STEP(0x143, 0xc)
+#undef BATH_FMAX_STEP
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
 __device__ __forceinline__ int wave_max_i32(int v) {
   v = max(v, dpp_i<0x111>(v, INT_MIN)); v = max(v, dpp_i<0x112>(v, INT_MIN)); v = max(v, dpp_i<0x114>(v, INT_MIN));
   v = max(v, dpp_i<0x118>(v, INT_MIN)); v = max(v, dpp_i<0x142, 0xa>(v, INT_MIN)); v = max(v, dpp_i<0x143, 0xc>(v, INT_MIN));

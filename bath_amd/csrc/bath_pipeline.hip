@@ -245,8 +245,7 @@ __global__ __launch_bounds__(256) void ssv_bath_kernel(Cand cand, const Counters
     for (int i = 1; i <= L; i++) {
       const int x = min((int)s[i - 1], kKp - 1);
       const uint8_t *row = rb + (size_t)x * rb_stride;
-      int prev = __shfl_up(dp[C - 1], 1, 64);
-      if (lane == 0) prev = 0;
+      int prev = wave_shr1_i32(dp[C - 1], 0);
       int xE = 0;
 #pragma unroll
       for (int k = 0; k < C; k++) {
