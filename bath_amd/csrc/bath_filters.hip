@@ -381,13 +381,13 @@ __global__ __launch_bounds__(256) void fwd_wave_kernel(SeqView sq, int M, const 
       float A = 0.f, B = 1.f;
 #pragma unroll
       for (int k = 0; k < C; k++) { A = md[k] + A * tdd[k]; B *= tdd[k]; }
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const float Ap = __shfl_up(A, d, 64), Bp = __shfl_up(B, d, 64);
-        if (lane >= d) { A = A + Ap * B; B = B * Bp; }
-      }
-      float din = __shfl_up(A, 1, 64);
-      if (lane == 0) din = 0.f;
+      // by DPP; lanes without a source see the identity map (A = 0, B = 1): A + 0 * B = A, B * 1 = B
+#define BATH_FWD_STEP(CTRL, MASK) { const float Ap = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, A), CTRL, MASK, 0xf, false)), \
+                                                 Bp = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0x3f800000, __builtin_bit_cast(int, B), CTRL, MASK, 0xf, false)); \
+                                    A = A + Ap * B; B = B * Bp; }
+      BATH_FWD_STEP(0x111, 0xf) BATH_FWD_STEP(0x112, 0xf) BATH_FWD_STEP(0x114, 0xf) BATH_FWD_STEP(0x118, 0xf) BATH_FWD_STEP(0x142, 0xa) BATH_FWD_STEP(0x143, 0xc)
+#undef BATH_FWD_STEP
+      const float din = wave_shr1_f32(A, 0.f);
       float Dc[C];
       Dc[0] = din;
 #pragma unroll

@@ -38,10 +38,19 @@ __device__ __forceinline__ int wave_min_i32(int v) {
   v = min(v, dpp_i<0x118>(v, INT_MAX)); v = min(v, dpp_i<0x142, 0xa>(v, INT_MAX)); v = min(v, dpp_i<0x143, 0xc>(v, INT_MAX));
   return __builtin_amdgcn_readlane(v, 63);
 }
+// Wave sum: a running sum in lane order by DPP, the last lane broadcast.  (Another association of the 64 terms than the xor
+// butterfly it replaces: a float sum may differ in its last bit.)
 __device__ __forceinline__ float wave_sum_f32(float v) {
+#ifdef BATH_SUM_BPERMUTE
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
   return v;
+#else
+#define BATH_FSUM_STEP(CTRL, MASK) v = v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, MASK, 0xf, false));
+  BATH_FSUM_STEP(0x111, 0xf) BATH_FSUM_STEP(0x112, 0xf) BATH_FSUM_STEP(0x114, 0xf) BATH_FSUM_STEP(0x118, 0xf) BATH_FSUM_STEP(0x142, 0xa) BATH_FSUM_STEP(0x143, 0xc)
+#undef BATH_FSUM_STEP
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+#endif
 }
 __device__ __forceinline__ int sat16(int v) { return min(max(v, -32768), 32767); }
 __device__ __forceinline__ int satu8(int v) { return min(max(v, 0), 255); }
