@@ -447,7 +447,8 @@ __global__ __launch_bounds__(256) void bwd_wave_kernel(SeqView sq, int M, const 
     for (int i = threadIdx.x; i < kKp * (M + 2); i += blockDim.x) { const int x = i / (M + 2), k = i - x * (M + 2); w_rf[i] = (k <= M) ? g_rf[(size_t)x * (M + 1) + k] : 0.f; }
     __syncthreads();
   }
-  const int lane = threadIdx.x & 63;
+  // lanes own their nodes in DESCENDING order (logical lane = 63 - physical): the chains towards node M are then upward DPP scans
+  const int lane = 63 - (threadIdx.x & 63);
   const int64_t wid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
   for (int64_t sid = wid; sid < ntodo; sid += nw) {
@@ -464,13 +465,13 @@ __global__ __launch_bounds__(256) void bwd_wave_kernel(SeqView sq, int M, const 
       float A = 0.f, B = 1.f;                              // D(k) = xE + D(k+1)*tDD(k)
 #pragma unroll
       for (int k = C - 1; k >= 0; k--) { const int node = lane * C + k + 1; const float tdd = (node <= M) ? s_tf[(size_t)node * 8 + 5] : 0.f; A = ((node <= M) ? xE : 0.f) + A * tdd; B *= tdd; }
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const float An = __shfl_down(A, d, 64), Bn = __shfl_down(B, d, 64);
-        if (lane + d < 64) { A = A + An * B; B = B * Bn; }
-      }
-      float dnext = __shfl_down(A, 1, 64);                 // D of the first node of the lane to the right
-      if (lane == 63) dnext = 0.f;
+      // lanes without a source see the identity map (A = 0, B = 1)
+#define BATH_BWD_STEP(CTRL, MASK) { const float An = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, A), CTRL, MASK, 0xf, false)), \
+                                                 Bn = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0x3f800000, __builtin_bit_cast(int, B), CTRL, MASK, 0xf, false)); \
+                                    A = A + An * B; B = B * Bn; }
+      BATH_BWD_STEP(0x111, 0xf) BATH_BWD_STEP(0x112, 0xf) BATH_BWD_STEP(0x114, 0xf) BATH_BWD_STEP(0x118, 0xf) BATH_BWD_STEP(0x142, 0xa) BATH_BWD_STEP(0x143, 0xc)
+#undef BATH_BWD_STEP
+      float dnext = wave_shr1_f32(A, 0.f);                 // D of the first node of the logical lane above (the physical lane below)
 #pragma unroll
       for (int k = C - 1; k >= 0; k--) {
         const int node = lane * C + k + 1;
@@ -518,8 +519,7 @@ __global__ __launch_bounds__(256) void bwd_wave_kernel(SeqView sq, int M, const 
       xN = (xB * pmove) + (xN * ploop);
       xE = (xC * c.xfE_move) + (xJ * c.xfE_loop);
       // the node to the right of each lane's block
-      float meR = __shfl_down(me[0], 1, 64);
-      if (lane == 63) meR = 0.f;
+      const float meR = wave_shr1_f32(me[0], 0.f);
       float mnext[C];                                      // M(i+1,k+1) * e(k+1)
 #pragma unroll
       for (int k = 0; k < C; k++) mnext[k] = (k + 1 < C) ? me[k + 1] : meR;
@@ -535,13 +535,12 @@ __global__ __launch_bounds__(256) void bwd_wave_kernel(SeqView sq, int M, const 
         // reference order (:608-612 restated): Dc = mnext*tdm + Dc[k+1]*tdd + xE
         A = in ? ((dconst[k] + A * tddv[k]) + xE) : 0.f; B = in ? B * tddv[k] : 0.f;
       }
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const float An = __shfl_down(A, d, 64), Bn = __shfl_down(B, d, 64);
-        if (lane + d < 64) { A = A + An * B; B = B * Bn; }
-      }
-      float dnext = __shfl_down(A, 1, 64);
-      if (lane == 63) dnext = 0.f;
+#define BATH_BWD_STEP(CTRL, MASK) { const float An = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, A), CTRL, MASK, 0xf, false)), \
+                                                 Bn = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0x3f800000, __builtin_bit_cast(int, B), CTRL, MASK, 0xf, false)); \
+                                    A = A + An * B; B = B * Bn; }
+      BATH_BWD_STEP(0x111, 0xf) BATH_BWD_STEP(0x112, 0xf) BATH_BWD_STEP(0x114, 0xf) BATH_BWD_STEP(0x118, 0xf) BATH_BWD_STEP(0x142, 0xa) BATH_BWD_STEP(0x143, 0xc)
+#undef BATH_BWD_STEP
+      float dnext = wave_shr1_f32(A, 0.f);
       float Mc[C], Ic[C], Dc[C];
 #pragma unroll
       for (int k = C - 1; k >= 0; k--) {
