@@ -867,15 +867,14 @@ __global__ __launch_bounds__(256) void std_envelope_fill_kernel(SeqView sq, int 
         } else { cuM[c] = cuI[c] = -INFINITY; }
       }
       // inclusive scan of the lanes' functions, then the value entering each lane: D(first node of the lane)
-      float sc_c = fc; bool sc_p = fpass;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const float oc = __shfl_up(sc_c, d, 64);
-        const int op = __shfl_up((int)sc_p, d, 64);
-        if (lane >= d && sc_p) { sc_c = fmaxf(sc_c, oc); sc_p = op != 0; }
-      }
-      float din = __shfl_up(sc_c, 1, 64);                                   // prefix over lanes 0..lane-1 applied to D(1) = -inf
-      if (lane == 0) din = -INFINITY;
+      // by DPP; lanes without a source see the identity function (c = -inf, pass): max and select only, any scan order gives the same
+      float sc_c = fc; int sc_p = fpass ? 1 : 0;
+#define BATH_OAS_STEP(CTRL, MASK) { const float oc = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp((int)0xff800000, __builtin_bit_cast(int, sc_c), CTRL, MASK, 0xf, false)); \
+                                    const int op = __builtin_amdgcn_update_dpp(1, sc_p, CTRL, MASK, 0xf, false); \
+                                    if (sc_p) { sc_c = fmaxf(sc_c, oc); sc_p = op; } }
+      BATH_OAS_STEP(0x111, 0xf) BATH_OAS_STEP(0x112, 0xf) BATH_OAS_STEP(0x114, 0xf) BATH_OAS_STEP(0x118, 0xf) BATH_OAS_STEP(0x142, 0xa) BATH_OAS_STEP(0x143, 0xc)
+#undef BATH_OAS_STEP
+      float din = wave_shr1_f32(sc_c, -INFINITY);                           // prefix over lanes 0..lane-1 applied to D(1) = -inf
 #pragma unroll
       for (int c = 0; c < C; c++) {
         const int node = lane * C + c + 1;
