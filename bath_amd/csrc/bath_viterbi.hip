@@ -118,10 +118,9 @@ __global__ __launch_bounds__(256, (NR <= 76 ? BATH_VIT_WAVES : 1)) void vit_lane
       unsigned pM = (as_u(Mr[NR - 1]) << 16) | 0x8000u, pI = (as_u(Ir[NR - 1]) << 16) | 0x8000u, pD = (as_u(Dr[NR - 1]) << 16) | 0x8000u;   // (low halves: never corrected)
       s16x2 dpk = NEG;                                                           // D(1) | D(NR+1) without the paths through node NR
       // The previous row's D is stored WITHOUT the paths that enter the high chain through node NR+1; they are added here, where
-      // that row is read: max(D, D(NR+1) + tDD(NR+1) + ... ) with the running sum of the high chain's tDD (the low halves see
-      // -32768 + something = -32768, no effect).  No second pass over the registers, no table.
-      const s16x2 epk = {(short)-32768, ePrev};
-      s16x2 cpk = {0, 0};
+      // that row is read: max(D, D(NR+1) + tDD(NR+1) + ... ), the right-hand side carried along as one saturating running sum (the
+      // low halves hold -32768 throughout: no effect).  No second pass over the registers, no table.
+      s16x2 cpk = {(short)-32768, ePrev};                                        // D(NR+1) of the previous row, less the tDD passed so far (low half: stays -32768)
       int twz = 0;
       asm volatile("" : "+s"(twz));                                              // opaque zero: keeps the (row-invariant) loads inside the row loop
       const uint32_t *tw = tw2g + twz;
@@ -147,7 +146,7 @@ __global__ __launch_bounds__(256, (NR <= 76 ? BATH_VIT_WAVES : 1)) void vit_lane
           const unsigned tMM = t_c[8 * q + 0], tIM = t_c[8 * q + 1], tDM = t_c[8 * q + 2], tBM = t_c[8 * q + 3];
           const unsigned tMD = t_c[8 * q + 4], tDD = t_c[8 * q + 5], tMI = t_c[8 * q + 6], tII = t_c[8 * q + 7];
           const unsigned oM = as_u(Mr[rr]), oI = as_u(Ir[rr]);
-          const unsigned oD = as_u(pk_max(Dr[rr], pk_adds(epk, cpk)));
+          const unsigned oD = as_u(pk_max(Dr[rr], cpk));
           cpk = pk_adds(cpk, as_s2(tDD));
           const s16x2 ms = as_s2(pM), is = as_s2(pI), ds = as_s2(pD);
           s16x2 sv = pk_adds(xBv, as_s2(tBM));
