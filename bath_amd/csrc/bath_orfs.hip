@@ -14,7 +14,7 @@
 //                     so reverse frames are scanned in memory order too).  Canonical ACGT codons are decoded by one
 //                     24-bit multiply + bit-field extract + a 64-entry LDS table per strand, degenerate codes by the
 //                     general 18^3 table.  Per stream, the length of the stop-free run entering each lane's four codons
-//                     comes from four wave ballots (the last stop before the lane); runs closed by two stops inside the tile are recorded as ORFs
+//                     comes from a DPP running maximum over the half wave (the last stop before the lane); runs closed by two stops inside the tile are recorded as ORFs
 //                     at once, the run touching the tile's left edge ("prefix") and the one open at its right edge
 //                     ("suffix") are left in the tile summary.  Positions past the end of a stream count as stops.
 //   orf_stitch_kernel one lane per (window, frame) walks the tile summaries and records the ORFs that cross tiles.
