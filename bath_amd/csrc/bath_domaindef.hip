@@ -210,9 +210,9 @@ static int fs_branch_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, con
 
   // ---- multi-domain regions (p7_domaindef.c:396-455): Forward of the region in the multihit configuration (GPU), ensemble of
   // stochastic tracebacks and clustering (host, bath_ensemble.hip); every cluster is an envelope
+  std::vector<std::vector<Env>> found;                                       // written by the ensemble threads: declared BEFORE the joiner, so it outlives the join on every return
   std::thread ensembles;
   Joiner joiner{ensembles};                                                  // also on error returns
-  std::vector<std::vector<Env>> found;
   if (!mregs.empty()) {
     std::vector<FsWinDev> rregs(mregs.size());
     for (size_t e = 0; e < mregs.size(); e++) {

@@ -27,125 +27,9 @@
 
 using namespace bath;
 
-struct bath_hip_fsprofile {
-  bath_hip_ctx *ctx = nullptr;
-  int M = 0, codon_lengths = 0, maxcodons = 0, max_length = 0;
-  int pitch = 0;                 // floats per emission row (M+1 rounded up to 4)
-  float fsprob = 0.f;
-  float evparam[BATH_NEVPARAM];
-  float *d_rsc = nullptr;        // [(maxcodons+Kp)][pitch]
-  float *d_tf = nullptr;         // [(M+2)][8] forward-ordered transitions per node
-  float *d_tb = nullptr;         // [(M+2)][8] backward-ordered transitions per node
-  float *d_logsum = nullptr;     // [16000]
-  std::vector<float> h_tsc;      // [M*8] generic log transitions (OA traceback deltas on the host)
-  std::vector<uint8_t> h_codons; // [(M+1)*maxcodons] best amino acid per (node, quasi-codon) (null2 along a trace)
-  uint8_t *d_codons = nullptr;   // the same on the device (5-codon profiles)
-  uint8_t *d_indel = nullptr;    // [(M+1)*maxcodons] indel-type label of that choice (hmmer.h:259-276), for the alignment display
-  // length model: xsc[N|C|J][LOOP|MOVE] for L_amino, multihit (nj=1) and unihit (nj=0); host libm log()
-  mutable int maxL = -1;
-  mutable float *d_loop[2] = {nullptr, nullptr}, *d_move[2] = {nullptr, nullptr};
-  int ensure_len(int maxL_amino) const;
-};
+#include "bath_fs_device.hpp"
 
 namespace bath {
-
-constexpr int kLogsumTbl = 16000;
-// threads per block of the DP kernels that hold p7_FLogsum's 64 KB table in LDS: 8 waves share one copy, so two blocks = 16 waves
-// fit a CU (4 per SIMD); with 4 waves per block the table limited a CU to 8 waves, and these kernels live on latency hiding
-#ifndef BATH_FS_BLOCK
-#define BATH_FS_BLOCK 512
-#endif
-#ifndef BATH_FS_WAVES           /* waves per SIMD the compiler must leave room for when a lane holds <= 3 nodes (0: no constraint) */
-#define BATH_FS_WAVES 4
-#endif
-constexpr int kFsBlock = BATH_FS_BLOCK;
-// Two 512-thread blocks (one 64 KB table each) fit a CU's LDS: 4 waves per SIMD if a wave keeps to 128 VGPRs.  Left alone the
-// compiler takes 134-161 for the straight-line rows (one block per CU, 2 waves per SIMD); told to stay within 128 it spills
-// 7-39 registers.  Measured on the bench's --fs pass (tools/fs_variants.sh): the parsers and Backward gain from the
-// cap (fs3_fwd 9.5 -> 7.6 ms, fs_bwd<3> 7.1 -> 5.4, fs_bwd<5> 6.0 -> 5.4), the 5-codon Forward loses (3.7 -> 5.4: 39 spills
-// in its row chain) and is left uncapped.  Models with more than 3 nodes per lane need the registers.
-constexpr int fs_min_waves(int C) { return (C <= 3 && BATH_FS_WAVES > 0) ? BATH_FS_WAVES : 1; }
-
-struct FsDev {
-  int M, pitch, maxcodons;
-  const float *rsc, *tf, *tb, *logsum;
-};
-
-// p7_FLogsum (logsum.c:105-111): truncating table lookup, or the exact form (logsum.c:109)
-// Straight-line code: the table is read unconditionally at a clamped index and the early-out cases are a select.  With the
-// obvious `if (...) return mx;` every log-sum became its own exec-masked basic block (165 branches in the 3-codon Forward
-// kernel) and the compiler could not overlap the independent log-sums of a lane's nodes; the values are identical.
-template <bool EXACT>
-__device__ __forceinline__ float flogsum(float a, float b, const float *tbl) {
-  const float mx = fmaxf(a, b), mn = fminf(a, b);
-  if (EXACT) {
-    if (mn == -INFINITY || (mx - mn) >= 15.7f) return mx;
-    return mx + log1pf(expf(mn - mx));
-  }
-  // <tbl> is the kernels' LDS copy of the table, ZERO from entry 15700 on (fs_load_logsum_table): the reference's early outs
-  // "mn == -inf or mx - mn >= 15.7 -> mx" are then the look-up itself (mx + 0), and a log-sum is max, |a - b|, min, mul, cvt,
-  // shift, ds_read, add.  (int)(d * 1000.f) >= 15700 exactly when d >= 15.7f: 15.7f * 1000.f rounds to 15700.0f and the float
-  // below 15.7f to 15699.999.  a = b = -inf: |NaN| -> v_min returns 15.999 -> -inf + 0.
-  (void)mn;
-  const float dc = fminf(fabsf(a - b), 15.999f);
-  return mx + tbl[(int)(dc * 1000.f)];
-}
-
-// the same on the unpadded table in global memory (kernels that take a few log-sums per target)
-__device__ __forceinline__ float flogsum_g(float a, float b, const float *tbl) {
-  const float mx = fmaxf(a, b), mn = fminf(a, b);
-  const float d = mx - mn;                                    // +inf when mn = -inf, NaN when both are
-  const float dc = fminf(d, 15.999f);                         // (v_min_f32 returns the number when one operand is NaN)
-  const float t = tbl[(int)(dc * 1000.f)];
-  return (mn == -INFINITY || d >= 15.7f) ? mx : mx + t;
-}
-
-// p7_FLogsum's table into LDS, its entries for differences >= 15.7 (which the reference never reads) zeroed
-__device__ __forceinline__ void fs_load_logsum_table(float *s_tbl, const float *g_tbl) {
-  for (int i = threadIdx.x; i < 16000; i += blockDim.x) s_tbl[i] = (i < 15700) ? g_tbl[i] : 0.f;
-}
-
-// Cross-lane moves by DPP instead of ds_bpermute (__shfl_*): these kernels are chains of dependent operations, and a shuffle through
-// the LDS crossbar costs ~100+ cycles of that chain where a DPP operand costs a VALU instruction.  <old> is what a lane without a
-// source keeps: the identity of the combining operation, so that such lanes need no select.
-template <int CTRL, int ROW_MASK = 0xf>
-__device__ __forceinline__ float dpp_f(float v, float old) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
-}
-__device__ __forceinline__ float wave_shr1(float v, float fill) { return dpp_f<0x138>(v, fill); }          // lane l <- lane l-1, lane 0 <- fill
-__device__ __forceinline__ float wave_bcast_last(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63)); }
-
-// log-sum of a value per lane, result in every lane: an inclusive scan in lane order (row_shr 1/2/4/8, row_bcast 15/31), lane 63
-// broadcast.  BATH_FS_BPERMUTE: the xor butterfly through ds_bpermute this replaced.
-template <bool EXACT>
-__device__ __forceinline__ float wave_logsum(float v, const float *tbl) {
-#ifdef BATH_FS_BPERMUTE
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) v = flogsum<EXACT>(v, __shfl_xor(v, d, 64), tbl);
-  return v;
-#else
-  v = flogsum<EXACT>(v, dpp_f<0x111>(v, -INFINITY), tbl);
-  v = flogsum<EXACT>(v, dpp_f<0x112>(v, -INFINITY), tbl);
-  v = flogsum<EXACT>(v, dpp_f<0x114>(v, -INFINITY), tbl);
-  v = flogsum<EXACT>(v, dpp_f<0x118>(v, -INFINITY), tbl);
-  v = flogsum<EXACT>(v, dpp_f<0x142, 0xa>(v, -INFINITY), tbl);
-  v = flogsum<EXACT>(v, dpp_f<0x143, 0xc>(v, -INFINITY), tbl);
-  return wave_bcast_last(v);
-#endif
-}
-
-__device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
-
-// Work distribution of the wave-per-window kernels.  Their duration is the longest chain of rows any one wave walks, so the
-// windows are handed out longest first from a shared counter (<order> lists them by decreasing length): a wave that drew a
-// long window early draws fewer later, instead of every wave taking windows wid, wid + nwaves, ... whatever their lengths.
-struct FsJobs { const int32_t *order; unsigned *counter; };
-__device__ __forceinline__ int64_t fs_next_job(const FsJobs &q, int64_t n, int lane) {
-  unsigned j = 0;
-  if (lane == 0) j = atomicAdd(q.counter, 1u);
-  j = (unsigned)__shfl((int)j, 0, 64);
-  return (int64_t)j < n ? (int64_t)q.order[j] : (int64_t)-1;
-}
 
 // D(i,k) = LS(M(i,k-1)+tMD(k-1), D(i,k-1)+tDD(k-1)) for this lane's nodes, chained across lanes.
 // md[c] = M(i,node_c)+tMD(node_c) and dd[c] = tDD(node_c) describe the step OUT of node c.
@@ -1555,7 +1439,8 @@ static int fs_schedule(bath_hip_ctx *ctx, const bath_hip_seqs *dna, int k, FsJob
   std::vector<int32_t> order((size_t)n);
   for (int64_t i = 0; i < n; i++) order[(size_t)i] = (int32_t)i;
   std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return dna->h_len[(size_t)a] > dna->h_len[(size_t)b]; });
-  DevBuf &b = ctx->scratch[36];
+  if (k > 64) { ctx->set_error("fs_schedule: more than 64 job counters"); return BATH_EINVAL; }
+  DevBuf &b = ctx->scratch[40];                                    // its own slot: the cascade's local-composition terms live in 36
   BATH_HIP_TRY(ctx, b.reserve(256 + (size_t)n * sizeof(int32_t) + 64));
   BATH_HIP_TRY(ctx, hipMemsetAsync(b.p, 0, 256, ctx->stream));
   BATH_HIP_TRY(ctx, hipMemcpyAsync(b.as<char>() + 256, order.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
@@ -1851,19 +1736,29 @@ int bath::fs5_envelopes_ex(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, cons
   const float tEL = -INFINITY, tEM = 0.0f;                                      // unihit: p7_fs_ReconfigUnihit, modelconfig.c:868
   if (logsum_mode == BATH_LOGSUM_TABLE && ctx->fs_strict) logsum_mode = BATH_LOGSUM_TABLE_SERIAL;
   const double cells5 = (double)(foff[(size_t)n] / 8);                          // (L+1) x (M+1) cells of all envelopes
-  FsJobs jq[3];
-  if ((st = fs_schedule(ctx, dna, 3, jq)) != BATH_OK) return st;
+  FsJobs jq[4];
+  if ((st = fs_schedule(ctx, dna, 4, jq)) != BATH_OK) return st;
   if ((st = fs_fork(ctx)) != BATH_OK) return st;                                // Backward on the side stream, concurrently with Forward
   BATH_FS_SWITCH(Cv, {
     BATH_FS_MODE(logsum_mode, {
       if ((st = fs_set_shmem(ctx, fs5_fwd_kernel<CC, MD, true>, shmem)) != BATH_OK) return st;
       if ((st = fs_set_shmem(ctx, fs_bwd_kernel<CC, 5, MD>, shmem)) != BATH_OK) return st;
+      // Forward: the row-per-lane wavefront (bath_fs_wavefront.hip), the reference's order of every sum in every mode;
+      // BATH_HIP_FS_NODE_LANES=1 keeps the node-per-lane kernel (scans, or the 64-step hand-off in strict mode) for A/B runs
+      static const int wf_env = [] { const char *e = std::getenv("BATH_HIP_FS_NODE_LANES"); return e ? std::atoi(e) : -1; }();
+      const bool node_lanes = wf_env >= 0 ? wf_env == 1 : MD == 0;
       const int s1 = ctx->span_begin("fs5_fwd_kernel", ctx->stream, cells5, cells5 * 32.0);
-      hipLaunchKernelGGL((fs5_fwd_kernel<CC, MD, true>), dim3(grid_dp), dim3(kFsBlock), shmem, ctx->stream, dna->view(), fsdev(om), om->d_loop[1], om->d_move[1], tEL, tEM, c5_compat, d_fsc, b_f.as<float>(), d_foff, b_fx.as<float>(), d_xoff, -1, jq[0]);
+      if (node_lanes)
+        hipLaunchKernelGGL((fs5_fwd_kernel<CC, MD, true>), dim3(grid_dp), dim3(kFsBlock), shmem, ctx->stream, dna->view(), fsdev(om), om->d_loop[1], om->d_move[1], tEL, tEM, c5_compat, d_fsc, b_f.as<float>(), d_foff, b_fx.as<float>(), d_xoff, -1, jq[0]);
+      else if ((st = launch_fs5_fwd_wf(ctx, ctx->stream, om, dna, MD == 1, c5_compat, d_fsc, b_f.as<float>(), d_foff, b_fx.as<float>(), d_xoff, ctx->scratch[41], jq[0])) != BATH_OK) return st;
       ctx->span_end(s1, ctx->stream);
-      const int s2 = ctx->span_begin("fs_bwd_kernel<5>", ctx->side_stream, cells5, cells5 * 12.0);
-      hipLaunchKernelGGL((fs_bwd_kernel<CC, 5, MD>), dim3(grid_dp), dim3(kFsBlock), shmem, ctx->side_stream, dna->view(), fsdev(om), om->d_loop[1], om->d_move[1], tEL, tEM, d_bsc, b_b.as<float>(), d_boff, b_bx.as<float>(), d_xoff, jq[1]);
-      ctx->span_end(s2, ctx->side_stream);
+      static const bool serial = [] { const char *e = std::getenv("BATH_HIP_FS_SERIAL"); return e && e[0] == '1'; }();   // timing probes: Backward after Forward
+      hipStream_t bs = serial ? ctx->stream : ctx->side_stream;
+      const int s2 = ctx->span_begin("fs_bwd_kernel<5>", bs, cells5, cells5 * 12.0);
+      if (node_lanes)
+        hipLaunchKernelGGL((fs_bwd_kernel<CC, 5, MD>), dim3(grid_dp), dim3(kFsBlock), shmem, bs, dna->view(), fsdev(om), om->d_loop[1], om->d_move[1], tEL, tEM, d_bsc, b_b.as<float>(), d_boff, b_bx.as<float>(), d_xoff, jq[1]);
+      else if ((st = launch_fs5_bwd_wf(ctx, bs, om, dna, MD == 1, d_bsc, b_b.as<float>(), d_boff, b_bx.as<float>(), d_xoff, ctx->scratch[42], ctx->scratch[43], ctx->scratch[44], jq[1], jq[3])) != BATH_OK) return st;
+      ctx->span_end(s2, bs);
     })
     if ((st = fs_join(ctx)) != BATH_OK) return st;
     BATH_HIP_TRY(ctx, hipMemsetAsync(b_cs.p, 0, (size_t)n * cs_stride * sizeof(float), ctx->stream));

@@ -1,0 +1,456 @@
+// bath_fs_wavefront.hip -- the 5-codon Forward / Backward of the ENVELOPES (unihit configuration) as a systolic wavefront:
+// one wave per envelope, one LANE PER ROW, every lane sweeping the model's nodes one after the other.
+//
+//   fs5_fwd_wf_kernel <- p7_Forward_Frameshift   generic_fwdback_frameshift.c:64   (SIMD twin impl_sse/fwdback_fs.c:2054)
+//   fs5_bwd_wf_kernel <- p7_Backward_Frameshift  generic_fwdback_frameshift.c:1035 (SIMD twin impl_sse/fwdback_fs.c:2634)
+//   fs5_bwd_x_kernel  <- the B(i) sums and the N / J rows of the same function (:1279-1283, :1290-1300)
+//
+// Why this shape.  p7_FLogsum's table truncates, so log-sum is not associative and a score is the reference's only if every
+// sum along the model -- the D chain D(i,k) <- D(i,k-1), the E sum, Backward's D chain and B sum -- runs node by node in the
+// reference's order.  With lanes owning NODES (bath_frameshift.hip) that order is a 64-step hand-off per row; with lanes owning
+// ROWS it is a lane's own loop and costs nothing.  What makes rows independent enough: in the unihit configuration
+// (p7_fs_ReconfigUnihit, modelconfig.c:868: E->J impossible) B(i) = N(i) + tNM does not read E(i), so cell (i,k) needs only
+// (i,k-1) and cells of rows i-1..i-5 at nodes k-1 and k: lane l works on row i at node k while lane l+1 works on row i+1 at
+// node k-1, and everything a lane needs from the rows above arrives from its neighbour lane by one DPP move per value:
+//   IVX(i+1,k)            "paths leaving row i" (generic :332-335), computed by row i's lane from its node k-1 cells;
+//   IVX(i..i-3,k)         passed on, a shift register along the lanes (codon lengths 2..5 read IVX(i-1..i-4,k));
+//   I(i+3,k) = LS(M(i,k)+tMI, I(i,k)+tII)  computed by row i's lane, passed on twice.
+// Lane l owns rows l+1, l+65, l+129, ...; lane 0 picks up what lane 63 left M-63 steps earlier from a ring indexed by node
+// (LDS when it fits, global memory otherwise).  Every log-sum has the reference's operands in the reference's order, in every
+// mode: the envelope scores, matrices and special-state rows are BIT-IDENTICAL to generic_fwdback_frameshift.c, and the pass is
+// bound by instructions issued (about 11 table log-sums per cell) instead of by a 30-log-sum dependent chain per row.
+#include <cstring>
+
+#include "bath_fs_device.hpp"
+
+namespace bath {
+
+constexpr int kWfBlock = 1024;                 // one block per CU: 16 waves share one 64 KB log-sum table
+constexpr int kWfWaves = kWfBlock / 64;
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Forward.  fwd[(i*(M+1)+k)*8 + {D,I,C0..C5}], xmx[i*5 + {E,N,J,B,C}] as fs5_fwd_kernel writes them.
+// tf[node] = {tMM(k-1), tIM(k-1), tDM(k-1), tBM(k-1), tMD(k), tDD(k), tMI(k), tII(k)}
+// ---------------------------------------------------------------------------------------------------------------------------
+template <bool EXACT, bool RING_G>
+__global__ __launch_bounds__(kWfBlock) void fs5_fwd_wf_kernel(SeqView dna, FsDev p, const float *__restrict__ loop_tab, const float *__restrict__ move_tab,
+                                                              int c5_compat, float *__restrict__ sc, float *__restrict__ fwd, const int64_t *__restrict__ fwd_off,
+                                                              float *__restrict__ xmx, const int64_t *__restrict__ xmx_off,
+                                                              float *ring_g /* [waves][(M+2)*8] or null: the ring lives in LDS */, FsJobs jobs, int dbg) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  float *s_tbl = reinterpret_cast<float *>(lds);
+  float *s_tf = s_tbl + kLogsumTbl;
+  const int M = p.M;
+  fs_load_logsum_table(s_tbl, p.logsum);
+  for (int i = threadIdx.x; i < (M + 2) * 8; i += blockDim.x) s_tf[i] = p.tf[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int rstride = (M + 2) * 8;
+  // the ring: lane 63 leaves what lane 0 will need for the next row, indexed by node.  One wave writes and reads it, in program
+  // order (LDS operations of a wave execute in order; global memory is coherent within a CU), so plain accesses do
+  float4 *ring_l = reinterpret_cast<float4 *>(s_tf + (M + 2) * 8 + (size_t)wv * rstride);
+  float4 *ring_gl = RING_G ? reinterpret_cast<float4 *>(ring_g + ((size_t)blockIdx.x * kWfWaves + wv) * rstride) : nullptr;
+  const int Mp = M > 64 ? M : 64;                 // steps between two rows of a lane
+#define LS(a, b) flogsum<EXACT>((a), (b), s_tbl)
+  for (int64_t job = fs_next_job(jobs, dna.n, lane); job >= 0; job = fs_next_job(jobs, dna.n, lane)) {
+    const int L = dna.len[job];
+    const uint8_t *d = dna.data + dna.off[job];
+    float *fo = static_cast<float *>(__builtin_assume_aligned(fwd + fwd_off[job], 32));       // rows of (M+1) x 8 floats: every cell is 32-byte aligned
+    float *xo = xmx + xmx_off[job];
+    if (L < 5) { if (lane == 0) sc[job] = -INFINITY; continue; }
+    const float tNL = loop_tab[L / 3], tNM = move_tab[L / 3], tCL = tNL, tCM = tNM;
+    // ---- row 0 and the rows of N, J, B: N(i) = N(i-3) + tNL (a chain of float additions per residue class), J = -inf,
+    //      B(i) = N(i) + tNM (unihit; generic :265-277 with tEL = -inf)
+    for (int k = lane; k <= M; k += 64) {
+      float4 *c = reinterpret_cast<float4 *>(fo + (size_t)k * 8);
+      c[0] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY); c[1] = c[0];
+    }
+    if (lane == 0) { xo[0] = -INFINITY; xo[4] = -INFINITY; }
+    if (lane < 3) {
+      float n = 0.f;
+      for (int i = lane; i <= L; i += 3) {
+        if (i >= 3) n += tNL;
+        xo[i * 5 + 1] = n; xo[i * 5 + 2] = -INFINITY; xo[i * 5 + 3] = n + tNM;
+      }
+    }
+    __threadfence_block();
+    // ---- per-lane state
+    int row = 1 + lane, k = 1 - lane;                                   // k <= 0: the lane has not started yet
+    float dch = -INFINITY, ech = -INFINITY, pM = -INFINITY, pI = -INFINITY, pD = -INFINITY;
+    float oP = -INFINITY, o0 = -INFINITY, o1 = -INFINITY, o2 = -INFINITY, o3 = -INFINITY, oQ = -INFINITY, oqa = -INFINITY, oqb = -INFINITY;
+    float cfin = -INFINITY;                                             // C of the lane's last finished row
+    int r1, r2, r3, r4, r5;                                             // emission rows of the lane's current row (times pitch)
+    float Bcur;
+    // x_i as the kernels index codons: 0..3, or 1367 = p7P_MAXCODONS5 for a degenerate nucleotide / a position before the start
+    auto code = [](int byte, bool inside) -> int { return (inside && byte < 4) ? byte : 1367; };
+    auto codon_rows = [&](int x, int w, int v, int u, int t, int &q1, int &q2, int &q3, int &q4, int &q5) {
+      q1 = imin(x * 341, 1366) * p.pitch;
+      q2 = imin(x * 341 + w * 85 + 1, 1365) * p.pitch;
+      q3 = imin(x * 341 + w * 85 + v * 21 + 2, 1364) * p.pitch;
+      q4 = imin(x * 341 + w * 85 + v * 21 + u * 5 + 3, 1365) * p.pitch;
+      q5 = imin(x * 341 + w * 85 + v * 21 + u * 5 + t + 4, 1366) * p.pitch;
+    };
+    {
+      const int rr = imin(row, L);
+      auto at = [&](int i) { return code((int)d[(i >= 1 ? i : 1) - 1], i >= 1); };
+      codon_rows(at(rr), at(rr - 1), at(rr - 2), at(rr - 3), at(rr - 4), r1, r2, r3, r4, r5);
+      Bcur = xo[(size_t)rr * 5 + 3];
+    }
+    // what the lane's NEXT row needs is fetched a round ahead, raw: nothing waits for these loads where they are issued
+    int nb0; unsigned nbw; float Bnext;                                  // x_i, and x_{i-4}..x_{i-1} as one (unaligned) dword, unpacked where they are used
+    auto prefetch_row = [&](int nrow) {                                 // nrow >= 65
+      const int rr = imin(nrow, L);
+      nb0 = d[rr - 1]; __builtin_memcpy(&nbw, d + rr - 5, 4);
+      Bnext = xo[(size_t)rr * 5 + 3];
+    };
+    prefetch_row(row + 64);
+    const int T = ((L - 1) / 64) * Mp + ((L - 1) % 64) + M;
+    // the emission scores of a step are loaded during the step before
+    float e1, e2, e3, e4, e5;
+    { e1 = p.rsc[(size_t)r1 + 1]; e2 = p.rsc[(size_t)r2 + 1]; e3 = p.rsc[(size_t)r3 + 1]; e4 = p.rsc[(size_t)r4 + 1]; e5 = p.rsc[(size_t)r5 + 1]; }
+    for (int t = 0; t < T; t++) {
+      const bool act = (k >= 1) && (k <= M) && (row <= L);
+      const int kk = k < 1 ? 1 : (k > M ? M : k);
+      const float4 ta = *reinterpret_cast<const float4 *>(s_tf + kk * 8);
+      const float4 tb = *reinterpret_cast<const float4 *>(s_tf + kk * 8 + 4);
+      // ---- what the row above hands down (lane 0: from the ring, or the boundary of row 1)
+      float v0 = wave_shr1(oP, -INFINITY), v1 = wave_shr1(o0, -INFINITY), v2 = wave_shr1(o1, -INFINITY), v3 = wave_shr1(o2, -INFINITY), v4 = wave_shr1(o3, -INFINITY);
+      float Ik = wave_shr1(oqb, -INFINITY), qa = wave_shr1(oQ, -INFINITY), qb = wave_shr1(oqa, -INFINITY);
+      if (lane == 0) {
+        if (row == 1) v0 = tNM + ta.w;                                  // IVX(1,k) = B(0) + tBM(k-1) (:109)
+        else {
+          float4 a, b;
+          if constexpr (RING_G) { a = ring_gl[(size_t)kk * 2]; b = ring_gl[(size_t)kk * 2 + 1]; } else { a = ring_l[(size_t)kk * 2]; b = ring_l[(size_t)kk * 2 + 1]; }
+          v0 = a.x; v1 = a.y; v2 = a.z; v3 = a.w; v4 = b.x; Ik = b.y; qa = b.z; qb = b.w;
+        }
+      }
+      // ---- cell (row, k)
+      const float c1 = v0 + e1, c2 = v1 + e2, c3 = v2 + e3, c4 = v3 + e4;
+      const float c5 = (c5_compat ? (row >= 5 ? v0 : -INFINITY) : v4) + e5;
+      float Mk = LS(LS(c1, LS(c2, c3)), LS(c4, c5));                    // :337-339
+      if (row == 4) Mk = LS(c1, LS(c2, LS(c3, c4)));                    // rows 3, 4 associate differently (:222-225); for row 3 (c4 = -inf) the two forms agree
+      const float Dk = dch;
+      // ---- where the lane will be at the next step, and that step's emission scores (in flight while the chains below run)
+      int kn = k + 1, rown = row, q1 = r1, q2 = r2, q3 = r3, q4 = r4, q5 = r5;
+      float Bn = Bcur;
+      const bool wrap = kn > Mp;
+      if (wrap) {
+        kn = 1; rown = row + 64;
+        codon_rows(code(nb0, true), code((int)(nbw >> 24), true), code((int)((nbw >> 16) & 255u), true), code((int)((nbw >> 8) & 255u), true), code((int)(nbw & 255u), true), q1, q2, q3, q4, q5);
+        Bn = Bnext;
+        prefetch_row(rown + 64);
+      }
+      {
+        const int kq = kn < 1 ? 1 : (kn > M ? M : kn);
+        if (!(dbg & 1)) { e1 = p.rsc[(size_t)q1 + kq]; e2 = p.rsc[(size_t)q2 + kq]; e3 = p.rsc[(size_t)q3 + kq]; e4 = p.rsc[(size_t)q4 + kq]; e5 = p.rsc[(size_t)q5 + kq]; }
+      }
+      // the cell goes out after the loads above were issued: what the next step waits for is then a step old
+      if (act && !(dbg & 2)) {
+        float4 *cell = reinterpret_cast<float4 *>(fo + ((size_t)row * (M + 1) + k) * 8);
+        if (k == 1) { cell[-2] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY); cell[-1] = cell[-2]; }
+        cell[0] = make_float4(Dk, Ik, Mk, c1);
+        cell[1] = make_float4(c2, c3, c4, c5);
+      }
+      // E(i) <- LS(M, LS(D, E)) for k < M and for rows 1..4; rows >= 5 pair M and D first at node M (:392-394)
+      const bool pairMD = (k == M) && (row >= 5);
+      const float ea = pairMD ? Mk : ech, eb = pairMD ? ech : Mk;
+      const float enew = LS(eb, LS(Dk, ea));
+      const float dnew = LS(Mk + tb.x, Dk + tb.y);                      // D(i,k+1) (:349-350)
+      const float Q = LS(Mk + tb.z, Ik + tb.w);                         // I(i+3,k) (:345-346); -inf at node M by tMI(M) = tII(M) = -inf
+      // IVX(i+1,k): the paths leaving row i through node k-1 (:332-335); row 2 takes B(1) only (:150)
+      float P = LS(pM + ta.x, LS(pI + ta.y, LS(pD + ta.z, Bcur + ta.w)));
+      if (row == 1) P = Bcur + ta.w;
+      oP = P; o3 = v3; o2 = v2; o1 = v1; o0 = v0; oQ = Q; oqa = qa; oqb = qb;
+      if (lane == 63 && act) {
+        const float4 a = make_float4(oP, o0, o1, o2), b = make_float4(o3, oqb, oQ, oqa);
+        if constexpr (RING_G) { ring_gl[(size_t)k * 2] = a; ring_gl[(size_t)k * 2 + 1] = b; } else { ring_l[(size_t)k * 2] = a; ring_l[(size_t)k * 2 + 1] = b; }
+      }
+      // ---- end of a row: E(i), C(i) = LS(C(i-3) + tCL, E(i) + tEM) with tEM = 0 (:397-398; rows 1, 2: C(<=0) = -inf gives E(i))
+      const float cprev = __shfl(cfin, (lane + 61) & 63, 64);
+      if (act && k == M) {
+        const float cnew = LS(cprev + tCL, enew + 0.0f);
+        cfin = cnew;
+        xo[(size_t)row * 5 + 0] = enew; xo[(size_t)row * 5 + 4] = cnew;
+      }
+      const bool carry = (k >= 1) && !wrap;                             // a lane that has not started, or starts a new row, has its chains at -inf
+      pM = carry ? Mk : -INFINITY; pI = carry ? Ik : -INFINITY; pD = carry ? Dk : -INFINITY;
+      dch = carry ? dnew : -INFINITY; ech = carry ? enew : -INFINITY;
+      k = kn; row = rown; r1 = q1; r2 = q2; r3 = q3; r4 = q4; r5 = q5; Bcur = Bn;
+    }
+    const float cL = __shfl(cfin, (L - 1) & 63, 64), cL1 = __shfl(cfin, (L - 2) & 63, 64), cL2 = __shfl(cfin, (L - 3) & 63, 64);
+    if (lane == 0) sc[job] = LS(cL, LS(cL1 + tCL, cL2 + tCL)) + tCM;
+  }
+#undef LS
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Backward.  bck[(i*(M+1)+k)*3 + {D,I,M}]; lane l owns rows L-l, L-l-64, ... and sweeps the nodes M..1 (the D chain of a row
+// runs towards node 1, generic :1296-1316).  Cell (i,k) needs ivx(i,k+1) = logsum_c M(i+c,k+1) + e_c(k+1) and D(i,k+1) --
+// the lane's own previous step -- and I(i+3,k); ivx(i,k) needs M(i+1..i+5,k): the shift register M(i..i+4,k) and
+// I(i..i+2,k) moves down the lanes as in Forward.  E(i) = C(i) + tEM with C(i) = C(i+3) + tCL does not read the row (unihit).
+// B(i) = logsum_k ivx(i,k) + tBM(k-1) runs over k ASCENDING in the reference (:1279-1283) while the sweep descends: the terms
+// are left in a scratch array indexed by (step, lane) -- coalesced -- and fs5_bwd_x_kernel adds them up in the reference's order,
+// then walks the N and J rows and the score.
+// tb[node] = {tMD(k), tMI(k), tMM(k), tDD(k), tDM(k), tII(k), tIM(k), tBM(k-1)}
+// ---------------------------------------------------------------------------------------------------------------------------
+__host__ __device__ inline int fs_wf_period(int M) { return M > 64 ? M : 64; }
+__host__ __device__ inline int64_t fs_bwd_wf_steps(int L, int M) { return (int64_t)(L / 64) * fs_wf_period(M) + (L % 64) + M; }   // rows L..0
+
+template <bool EXACT, bool RING_G>
+__global__ __launch_bounds__(kWfBlock) void fs5_bwd_wf_kernel(SeqView dna, FsDev p, const float *__restrict__ loop_tab, const float *__restrict__ move_tab,
+                                                              float *__restrict__ bck, const int64_t *__restrict__ bck_off, float *__restrict__ xmx, const int64_t *__restrict__ xmx_off,
+                                                              float *__restrict__ terms, const int64_t *__restrict__ term_off, float *ring_g, FsJobs jobs) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  float *s_tbl = reinterpret_cast<float *>(lds);
+  float *s_tb = s_tbl + kLogsumTbl;
+  const int M = p.M;
+  fs_load_logsum_table(s_tbl, p.logsum);
+  for (int i = threadIdx.x; i < (M + 2) * 8; i += blockDim.x) s_tb[i] = p.tb[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int rstride = (M + 2) * 8;
+  float4 *ring_l = reinterpret_cast<float4 *>(s_tb + (M + 2) * 8 + (size_t)wv * rstride);
+  float4 *ring_gl = RING_G ? reinterpret_cast<float4 *>(ring_g + ((size_t)blockIdx.x * kWfWaves + wv) * rstride) : nullptr;
+  const int Mp = fs_wf_period(M);
+#define LS(a, b) flogsum<EXACT>((a), (b), s_tbl)
+  for (int64_t job = fs_next_job(jobs, dna.n, lane); job >= 0; job = fs_next_job(jobs, dna.n, lane)) {
+    const int L = dna.len[job];
+    if (L < 5) continue;                                               // fs5_bwd_x_kernel reports -inf
+    const uint8_t *d = dna.data + dna.off[job];
+    float *bo = bck + bck_off[job];
+    float *xo = xmx + xmx_off[job];
+    float *tm = terms + term_off[job];
+    const float tCL = loop_tab[L / 3], tCM = move_tab[L / 3];
+    // ---- the rows of C and E: C(L) = tCM, C(L-1) = C(L-2) = tCL + tCM, C(i) = C(i+3) + tCL; E(i) = C(i) + tEM, tEM = 0 (:1054-1073, :1290-1294)
+    if (lane < 3) {
+      float c = (lane == 0) ? tCM : tCL + tCM;
+      for (int i = L - lane; i >= 1; i -= 3) {
+        if (i <= L - 3) c = c + tCL;
+        xo[(size_t)i * 5 + 4] = c; xo[(size_t)i * 5 + 0] = c + 0.0f;
+      }
+    }
+    __threadfence_block();
+    int j = lane, k = 1 - lane;                                         // j = L - row; k = position in the row's sweep (node = M + 1 - k); k <= 0: not started
+    float dprev = -INFINITY, ivprev = -INFINITY;
+    float oM = -INFINITY, om1 = -INFINITY, om2 = -INFINITY, om3 = -INFINITY, om4 = -INFINITY, oI = -INFINITY, oj1 = -INFINITY, oj2 = -INFINITY;
+    int r1, r2, r3, r4, r5;
+    float xE;
+    auto code = [](int byte, bool inside) -> int { return (inside && byte < 4) ? byte : 1367; };
+    // row i emits codons that START at nucleotide i+1: x = x_{i+1}, w = x_{i+2}, ...; the codon's last base is the most significant digit (:1260-1270)
+    auto codon_rows = [&](int x, int w, int v, int u, int t, int &q1, int &q2, int &q3, int &q4, int &q5) {
+      q1 = imin(x * 341, 1366) * p.pitch;
+      q2 = imin(w * 341 + x * 85 + 1, 1365) * p.pitch;
+      q3 = imin(v * 341 + w * 85 + x * 21 + 2, 1364) * p.pitch;
+      q4 = imin(u * 341 + v * 85 + w * 21 + x * 5 + 3, 1365) * p.pitch;
+      q5 = imin(t * 341 + u * 85 + v * 21 + w * 5 + x + 4, 1366) * p.pitch;
+    };
+    {
+      const int i = L - imin(j, L);
+      auto at = [&](int q) { return code((int)d[imin(q, L) - 1], q <= L); };     // x_q
+      codon_rows(at(i + 1), at(i + 2), at(i + 3), at(i + 4), at(i + 5), r1, r2, r3, r4, r5);
+      xE = xo[(size_t)(i > 0 ? i : 1) * 5 + 0];
+    }
+    int nb0; unsigned nbw; float xEn;                                    // next row's x_{i+1}, x_{i+2..i+5} (one unaligned dword), E(i): fetched a round ahead
+    auto prefetch_row = [&](int jn) {                                    // jn >= 64: all five nucleotides exist
+      const int i = L - imin(jn, L);
+      nb0 = d[i]; __builtin_memcpy(&nbw, d + i + 1, 4);
+      xEn = xo[(size_t)(i > 0 ? i : 1) * 5 + 0];
+    };
+    if (L >= 64) prefetch_row(j + 64); else { nb0 = 0; nbw = 0; xEn = 0.f; }
+    const int T = (int)fs_bwd_wf_steps(L, M);
+    float e1, e2, e3, e4, e5;
+    { e1 = p.rsc[(size_t)r1 + M]; e2 = p.rsc[(size_t)r2 + M]; e3 = p.rsc[(size_t)r3 + M]; e4 = p.rsc[(size_t)r4 + M]; e5 = p.rsc[(size_t)r5 + M]; }
+    for (int t = 0; t < T; t++) {
+      const bool act = (k >= 1) && (k <= M) && (j <= L);
+      const int kk = k < 1 ? 1 : (k > M ? M : k);
+      const int node = M + 1 - kk;
+      const float4 t0 = *reinterpret_cast<const float4 *>(s_tb + node * 8);          // tMD tMI tMM tDD
+      const float4 t1 = *reinterpret_cast<const float4 *>(s_tb + node * 8 + 4);      // tDM tII tIM tBM(k-1)
+      // ---- from the row below (lane 0: the ring; nothing below row L)
+      float m1 = wave_shr1(oM, -INFINITY), m2 = wave_shr1(om1, -INFINITY), m3 = wave_shr1(om2, -INFINITY), m4 = wave_shr1(om3, -INFINITY), m5 = wave_shr1(om4, -INFINITY);
+      float j1 = wave_shr1(oI, -INFINITY), j2 = wave_shr1(oj1, -INFINITY), I3 = wave_shr1(oj2, -INFINITY);
+      if (lane == 0 && j > 0) {
+        float4 a, b;
+        if constexpr (RING_G) { a = ring_gl[(size_t)node * 2]; b = ring_gl[(size_t)node * 2 + 1]; } else { a = ring_l[(size_t)node * 2]; b = ring_l[(size_t)node * 2 + 1]; }
+        m1 = a.x; m2 = a.y; m3 = a.z; m4 = a.w; m5 = b.x; j1 = b.y; j2 = b.z; I3 = b.w;
+      }
+      // ---- cell (i, node) from ivx(i, node+1), D(i, node+1), I(i+3, node)
+      const float dn = dprev, ivn = ivprev;
+      const float base = ivn + t1.x;
+      float mv = LS(LS(dn + t0.x, LS(I3 + t0.y, ivn + t0.z)), xE);       // :1303-1306
+      if (j < 3) mv = LS(dn + t0.x, LS(ivn + t0.z, xE));                 // rows L, L-1, L-2: no row i+3 (:1083-1085, :1135-1137)
+      float dv = LS(LS(xE, dn + t0.w), base);                            // :1313-1315
+      float iv_ = LS(I3 + t1.y, ivn + t1.z);                             // :1308-1310
+      if (j >= L) { mv = -INFINITY; dv = -INFINITY; iv_ = -INFINITY; }    // row 0 holds no cells (:1376-1380)
+      // ---- ivx(i, node) = logsum_c M(i+c, node) + e_c(node); the rows L-1..L-4 add their codons left to right (:1101-1120)
+      const float s1 = m1 + e1, s2 = m2 + e2, s3 = m3 + e3, s4 = m4 + e4, s5 = m5 + e5;
+      float a = LS(s1, LS(s2, LS(s3, LS(s4, s5))));                       // :1272-1276
+      if (j < 5) a = LS(LS(LS(s1, s2), s3), s4);
+      // ---- where the lane will be at the next step, and that step's emission scores
+      int kn = k + 1, jn = j, q1 = r1, q2 = r2, q3 = r3, q4 = r4, q5 = r5;
+      float xEq = xE;
+      const bool wrap = kn > Mp;
+      if (wrap) {
+        kn = 1; jn = j + 64;
+        codon_rows(code(nb0, true), code((int)(nbw & 255u), true), code((int)((nbw >> 8) & 255u), true), code((int)((nbw >> 16) & 255u), true), code((int)(nbw >> 24), true),
+                   q1, q2, q3, q4, q5);
+        xEq = xEn;
+        if (jn + 64 <= L) prefetch_row(jn + 64);
+      }
+      {
+        const int kq = kn < 1 ? 1 : (kn > M ? M : kn);
+        const int nq = M + 1 - kq;
+        e1 = p.rsc[(size_t)q1 + nq]; e2 = p.rsc[(size_t)q2 + nq]; e3 = p.rsc[(size_t)q3 + nq]; e4 = p.rsc[(size_t)q4 + nq]; e5 = p.rsc[(size_t)q5 + nq];
+      }
+      if (act) {
+        float *cell = bo + ((size_t)(L - j) * (M + 1) + node) * 3;
+        cell[0] = dv; cell[1] = iv_; cell[2] = mv;
+        if (node == 1) { cell[-3] = -INFINITY; cell[-2] = -INFINITY; cell[-1] = -INFINITY; }
+      }
+      tm[(size_t)t * 64 + lane] = a + t1.w;                              // B(i)'s term of this node, summed by fs5_bwd_x_kernel
+      if (lane == 63 && act) {
+        const float4 ra = make_float4(mv, m1, m2, m3), rb = make_float4(m4, iv_, j1, j2);
+        if constexpr (RING_G) { ring_gl[(size_t)node * 2] = ra; ring_gl[(size_t)node * 2 + 1] = rb; } else { ring_l[(size_t)node * 2] = ra; ring_l[(size_t)node * 2 + 1] = rb; }
+      }
+      oM = mv; om1 = m1; om2 = m2; om3 = m3; om4 = m4; oI = iv_; oj1 = j1; oj2 = j2;
+      const bool carry = (k >= 1) && !wrap;
+      dprev = carry ? dv : -INFINITY; ivprev = carry ? a : -INFINITY;
+      k = kn; j = jn; r1 = q1; r2 = q2; r3 = q3; r4 = q4; r5 = q5; xE = xEq;
+    }
+  }
+#undef LS
+}
+
+// B(i) = logsum over the nodes 1..M, ascending, of the terms fs5_bwd_wf_kernel left (generic :1279-1283); then the rows of N and J
+// from row L down (:1054-1073 for the rows without an emitted codon, :1284-1289) and the score logsum(N(0), N(1), N(2)) (:1383-1385).
+// One wave per envelope; lane l adds up the rows it owned in the sweep, reading the scratch array slot by slot (coalesced).
+template <bool EXACT>
+__global__ __launch_bounds__(kFsBlock) void fs5_bwd_x_kernel(SeqView dna, int M, const float *__restrict__ logsum_g, const float *__restrict__ loop_tab, const float *__restrict__ move_tab,
+                                                             float *__restrict__ xmx, const int64_t *__restrict__ xmx_off, const float *__restrict__ terms, const int64_t *__restrict__ term_off,
+                                                             float *__restrict__ sc, FsJobs jobs) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  float *s_tbl = reinterpret_cast<float *>(lds);
+  fs_load_logsum_table(s_tbl, logsum_g);
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int Mp = fs_wf_period(M);
+#define LS(a, b) flogsum<EXACT>((a), (b), s_tbl)
+  for (int64_t job = fs_next_job(jobs, dna.n, lane); job >= 0; job = fs_next_job(jobs, dna.n, lane)) {
+    const int L = dna.len[job];
+    if (L < 5) { if (lane == 0) sc[job] = -INFINITY; continue; }
+    float *xo = xmx + xmx_off[job];
+    const float *tm = terms + term_off[job];
+    const float tNL = loop_tab[L / 3], tNM = move_tab[L / 3], tJL = tNL, tJM = tNM;
+    for (int pr = 0; pr * 64 <= L; pr++) {
+      const int j = pr * 64 + lane;                                     // this lane's row of the round: i = L - j
+      float b = -INFINITY;
+      const int t_lo = pr * Mp, t_hi = pr * Mp + 63 + M - 1;
+      for (int t = t_hi; t >= t_lo; t--) {                              // the lane's node at step t: M - (t - t_lo - lane); node 1 comes first
+        const int node = M - (t - t_lo - lane);
+        if (node >= 1 && node <= M && j <= L) {
+          const float v = tm[(size_t)t * 64 + lane];
+          b = (node == 1) ? v : LS(b, v);
+        }
+      }
+      if (j <= L) xo[(size_t)(L - j) * 5 + 3] = (j == 0) ? -INFINITY : b;   // row L: no codon starts there, B(L) = -inf
+    }
+    __threadfence_block();
+    float nfin = -INFINITY;                                             // N of the chain's last row (i = 0, 1 or 2)
+    if (lane < 3) {
+      float n = -INFINITY, jj = -INFINITY;
+      for (int i = L - lane; i >= 0; i -= 3) {
+        const float B = xo[(size_t)i * 5 + 3];
+        if (i == L) { n = -INFINITY; jj = -INFINITY; }
+        else if (L - i < 3) { jj = B + tJM; n = B + tNM; }              // :1135-1140
+        else { jj = LS(jj + tJL, B + tJM); n = LS(n + tNL, B + tNM); }  // :1284-1289
+        if (i > 0) { xo[(size_t)i * 5 + 1] = n; xo[(size_t)i * 5 + 2] = jj; }
+        else { xo[0] = -INFINITY; xo[1] = n; xo[2] = -INFINITY; xo[4] = -INFINITY; }      // row 0 as fs_bwd_kernel leaves it
+      }
+      nfin = n;
+    }
+    const float n0 = __shfl(nfin, L % 3, 64), n1 = __shfl(nfin, (L - 1) % 3, 64), n2 = __shfl(nfin, (L - 2) % 3, 64);
+    if (lane == 0) sc[job] = LS(n0, LS(n1, n2));
+  }
+#undef LS
+}
+
+size_t fs_wf_ring_floats(int M) { return (size_t)(M + 2) * 8; }
+
+// Launch the wavefront Forward over all envelopes of <dna> on <stream>.  <ring_scratch>: a context scratch buffer for the ring
+// when it does not fit into LDS next to the table.
+int launch_fs5_fwd_wf(bath_hip_ctx *ctx, hipStream_t stream, const bath_hip_fsprofile *om, const bath_hip_seqs *dna, int exact, int c5_compat,
+                      float *d_sc, float *d_fwd, const int64_t *d_foff, float *d_xmx, const int64_t *d_xoff, DevBuf &ring_scratch, FsJobs jobs) {
+  const int M = om->M;
+  const int64_t n = dna->n;
+  static const int dbg = [] { const char *e = std::getenv("BATH_HIP_WF_DBG"); return e ? std::atoi(e) : 0; }();
+  const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((n + kWfWaves - 1) / kWfWaves, (int64_t)ctx->prop.multiProcessorCount));
+  const size_t base = (size_t)(kLogsumTbl + (M + 2) * 8) * sizeof(float);
+  const size_t ring_b = fs_wf_ring_floats(M) * sizeof(float) * kWfWaves;
+  const bool lds_ring = base + ring_b <= (size_t)ctx->prop.sharedMemPerBlock && base + ring_b <= 160 * 1024;
+  float *ring_g = nullptr;
+  if (!lds_ring) {
+    BATH_HIP_TRY(ctx, ring_scratch.reserve(ring_b * (size_t)grid + 64));
+    ring_g = ring_scratch.as<float>();
+  }
+  const size_t shmem = base + (lds_ring ? ring_b : 0);
+  FsDev dev{om->M, om->pitch, om->maxcodons, om->d_rsc, om->d_tf, om->d_tb, om->d_logsum};
+#define BATH_WF_LAUNCH(EX, RG)                                                                                                     \
+  do {                                                                                                                             \
+    if (shmem > 64 * 1024) BATH_HIP_TRY(ctx, hipFuncSetAttribute((const void *)fs5_fwd_wf_kernel<EX, RG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
+    hipLaunchKernelGGL((fs5_fwd_wf_kernel<EX, RG>), dim3(grid), dim3(kWfBlock), shmem, stream, dna->view(), dev, om->d_loop[1], om->d_move[1], c5_compat, d_sc, d_fwd, \
+                       d_foff, d_xmx, d_xoff, ring_g, jobs, dbg);                                                                       \
+  } while (0)
+  if (exact) { if (lds_ring) BATH_WF_LAUNCH(true, false); else BATH_WF_LAUNCH(true, true); }
+  else { if (lds_ring) BATH_WF_LAUNCH(false, false); else BATH_WF_LAUNCH(false, true); }
+#undef BATH_WF_LAUNCH
+  BATH_HIP_TRY(ctx, hipGetLastError());
+  return BATH_OK;
+}
+
+
+// Backward of all envelopes: the sweep, then the B sums / N, J rows / scores.  <term_off_h>: per envelope the offset of its
+// (steps x 64) term array in <terms_scratch>, built here.
+int launch_fs5_bwd_wf(bath_hip_ctx *ctx, hipStream_t stream, const bath_hip_fsprofile *om, const bath_hip_seqs *dna, int exact,
+                      float *d_sc, float *d_bck, const int64_t *d_boff, float *d_xmx, const int64_t *d_xoff, DevBuf &ring_scratch, DevBuf &terms_scratch, DevBuf &toff_scratch,
+                      FsJobs jobs_sweep, FsJobs jobs_x) {
+  const int M = om->M;
+  const int64_t n = dna->n;
+  std::vector<int64_t> toff((size_t)n + 1, 0);
+  for (int64_t e = 0; e < n; e++) toff[(size_t)e + 1] = toff[(size_t)e] + (dna->h_len[(size_t)e] >= 5 ? fs_bwd_wf_steps(dna->h_len[(size_t)e], M) * 64 : 0);
+  BATH_HIP_TRY(ctx, terms_scratch.reserve((size_t)toff[(size_t)n] * sizeof(float) + 256));
+  BATH_HIP_TRY(ctx, toff_scratch.reserve((size_t)(n + 1) * sizeof(int64_t)));
+  BATH_HIP_TRY(ctx, hipMemcpyAsync(toff_scratch.p, toff.data(), (size_t)(n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, stream));
+  BATH_HIP_TRY(ctx, hipStreamSynchronize(stream));                    // <toff> is a local
+  const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((n + kWfWaves - 1) / kWfWaves, (int64_t)ctx->prop.multiProcessorCount));
+  const size_t base = (size_t)(kLogsumTbl + (M + 2) * 8) * sizeof(float);
+  const size_t ring_b = fs_wf_ring_floats(M) * sizeof(float) * kWfWaves;
+  const bool lds_ring = base + ring_b <= 160 * 1024;
+  float *ring_g = nullptr;
+  if (!lds_ring) {
+    BATH_HIP_TRY(ctx, ring_scratch.reserve(ring_b * (size_t)grid + 64));
+    ring_g = ring_scratch.as<float>();
+  }
+  const size_t shmem = base + (lds_ring ? ring_b : 0);
+  FsDev dev{om->M, om->pitch, om->maxcodons, om->d_rsc, om->d_tf, om->d_tb, om->d_logsum};
+#define BATH_WF_LAUNCH(EX, RG)                                                                                                     \
+  do {                                                                                                                             \
+    if (shmem > 64 * 1024) BATH_HIP_TRY(ctx, hipFuncSetAttribute((const void *)fs5_bwd_wf_kernel<EX, RG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
+    hipLaunchKernelGGL((fs5_bwd_wf_kernel<EX, RG>), dim3(grid), dim3(kWfBlock), shmem, stream, dna->view(), dev, om->d_loop[1], om->d_move[1], d_bck, d_boff, d_xmx, d_xoff, \
+                       terms_scratch.as<float>(), toff_scratch.as<int64_t>(), ring_g, jobs_sweep);                                 \
+  } while (0)
+  if (exact) { if (lds_ring) BATH_WF_LAUNCH(true, false); else BATH_WF_LAUNCH(true, true); }
+  else { if (lds_ring) BATH_WF_LAUNCH(false, false); else BATH_WF_LAUNCH(false, true); }
+#undef BATH_WF_LAUNCH
+  BATH_HIP_TRY(ctx, hipGetLastError());
+  const int xwaves = kFsBlock / 64;
+  const int xgrid = (int)std::max<int64_t>(1, std::min<int64_t>((n + xwaves - 1) / xwaves, (int64_t)ctx->prop.multiProcessorCount * 2));
+  const size_t xshmem = (size_t)kLogsumTbl * sizeof(float);
+  if (exact) hipLaunchKernelGGL((fs5_bwd_x_kernel<true>), dim3(xgrid), dim3(kFsBlock), xshmem, stream, dna->view(), M, om->d_logsum, om->d_loop[1], om->d_move[1], d_xmx, d_xoff,
+                                terms_scratch.as<float>(), toff_scratch.as<int64_t>(), d_sc, jobs_x);
+  else hipLaunchKernelGGL((fs5_bwd_x_kernel<false>), dim3(xgrid), dim3(kFsBlock), xshmem, stream, dna->view(), M, om->d_logsum, om->d_loop[1], om->d_move[1], d_xmx, d_xoff,
+                          terms_scratch.as<float>(), toff_scratch.as<int64_t>(), d_sc, jobs_x);
+  BATH_HIP_TRY(ctx, hipGetLastError());
+  return BATH_OK;
+}
+
+}  // namespace bath
