@@ -1475,8 +1475,10 @@ static int fs3_parser(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, const bat
   FsJobs jq[1];
   if ((st = fs_schedule(ctx, dna, 1, jq)) != BATH_OK) return st;
   const int sp = ctx->span_begin(backward ? "fs_bwd_kernel<3>" : "fs3_fwd_kernel", ctx->stream, (double)dna->total * om->M, (double)dna->total * (xmx ? 21.0 : 1.0));
-  if (logsum_mode == BATH_LOGSUM_TABLE_SERIAL && !backward && fs_chain_enabled()) {
-    if ((st = launch_fs3_fwd_chain(ctx, ctx->stream, om, dna, Cv, tE, tE, b_sc.as<float>(), d_x, b_off.as<int64_t>(), jq[0])) != BATH_OK) return st;
+  if (logsum_mode == BATH_LOGSUM_TABLE_SERIAL && fs_chain_enabled()) {
+    if (!backward) st = launch_fs3_fwd_chain(ctx, ctx->stream, om, dna, Cv, tE, tE, b_sc.as<float>(), d_x, b_off.as<int64_t>(), jq[0]);
+    else st = launch_fs3_bwd_chain(ctx, ctx->stream, om, dna, Cv, tE, tE, b_sc.as<float>(), d_x, b_off.as<int64_t>(), jq[0]);
+    if (st != BATH_OK) return st;
   } else
   BATH_FS_SWITCH(Cv, BATH_FS_MODE(logsum_mode, {
     if (!backward) {
@@ -1634,6 +1636,9 @@ int fs3_regions(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, const bath_hip_
     ctx->span_end(s1, ctx->stream);
     if ((st = fs_set_shmem(ctx, fs_bwd_kernel<CC, 3, MD>, shmem)) != BATH_OK) return st;
     const int s2 = ctx->span_begin("fs_bwd_kernel<3>", ctx->side_stream, cells3, bytes3);
+    if (MD == 2 && fs_chain_enabled()) {
+      if ((st = launch_fs3_bwd_chain(ctx, ctx->side_stream, om, dna, Cv, tE, tE, b_sc.as<float>() + n, b_bx.as<float>(), b_off.as<int64_t>(), jq[1])) != BATH_OK) return st;
+    } else
     hipLaunchKernelGGL((fs_bwd_kernel<CC, 3, MD>), dim3(grid_dp), dim3(kFsBlock), shmem, ctx->side_stream, dna->view(), fsdev(om), om->d_loop[0], om->d_move[0], tE, tE, b_sc.as<float>() + n, (float *)nullptr, (const int64_t *)nullptr, b_bx.as<float>(), b_off.as<int64_t>(), jq[1]);
     ctx->span_end(s2, ctx->side_stream);
   }))

@@ -167,6 +167,168 @@ __global__ __launch_bounds__(chain_threads(C)) void fs3_fwd_chain_kernel(SeqView
 #undef LS
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// 3-codon Backward parser, multihit, strict.  tb[node] = {tMD(k), tMI(k), tMM(k), tDD(k), tDM(k), tII(k), tIM(k), tBM(k-1)}
+// Rows come in pairs from the END of each window: pair q holds the rows L-2q and L-2q-1 (they do not read each other: row i
+// reads M(i+2..i+4) and I(i+3)), so the row TYPE -- no codon fits yet / fewer than the three codon lengths fit / main
+// recursion (generic :1442-1677) -- is the same for every window of the block at a given q.  Per pair:
+//   1. window waves: ivx(i,k) = logsum_c M(i+c,k) + e_c(k) for both rows, parallel over the nodes, into LDS;
+//   2. the chain wave, a lane per row: B(i) = logsum_k ivx(i,k) + tBM(k-1) over k ascending (:1561-1565), the special states
+//      of the row (they need B(i) and the rows i+3 of the other slot: a neighbour lane), then the D chain descending
+//      (:1596-1599), leaving D(i,k) in place of ivx(i,k);
+//   3. window waves: M(i,k), I(i,k) from D(i,k+1), ivx(i,k+1), I(i+3,k), E(i).
+// ---------------------------------------------------------------------------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(chain_threads(C)) void fs3_bwd_chain_kernel(SeqView dna, FsDev p, const float *__restrict__ loop_tab, const float *__restrict__ move_tab,
+                                                             float tEL, float tEM, float *__restrict__ sc, float *__restrict__ xmx, const int64_t *__restrict__ xmx_off, FsJobs jobs) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  float *s_tbl = reinterpret_cast<float *>(lds);
+  float *s_tb = s_tbl + kLogsumTbl;
+  const int M = p.M;
+  const int W = blockDim.x >> 6;
+  const int stride = fs_chain_stride(C);
+  float *s_stage = s_tb + (M + 2) * 8;                          // [W][2][stride]: ivx(i,k) in, D(i,k) out
+  float *s_e = s_stage + (size_t)W * 2 * stride;                // [W][2] E(i) of the pair's rows
+  int *s_ctl = reinterpret_cast<int *>(s_e + 2 * kChainMaxWaves);   // [0]: first job of the block's batch
+  fs_load_logsum_table(s_tbl, p.logsum);
+  for (int i = threadIdx.x; i < (M + 2) * 8; i += blockDim.x) s_tb[i] = p.tb[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  // Lanes own their nodes in DESCENDING order (logical lane = 63 - physical lane), as in fs_bwd_kernel: "the lane holding the
+  // next nodes" is then the physical lane below and the neighbour move is the same wave_shr1
+  const int ll = 63 - lane;
+#define LS(a, b) flogsum<false>((a), (b), s_tbl)
+  for (;;) {
+    if (threadIdx.x == 0) s_ctl[0] = (int)atomicAdd(jobs.counter, (unsigned)W);
+    __syncthreads();
+    const int64_t base = s_ctl[0];
+    if (base >= dna.n) break;
+    const int64_t job = (base + wv < dna.n) ? (int64_t)jobs.order[base + wv] : (int64_t)-1;
+    const int Lmax = dna.len[jobs.order[base]];
+    const int L = job >= 0 ? dna.len[job] : 0;
+    const bool live = job >= 0 && L >= 5;                       // shorter windows report -inf (fs_bwd_kernel does)
+    const uint8_t *d = job >= 0 ? dna.data + dna.off[job] : dna.data;
+    // ---- the chain wave's lanes: lane c serves slot (c & 1) of window (c >> 1)
+    const int cw = lane >> 1, cs = lane & 1;
+    const bool chain_lane = (wv == 0) && (lane < 2 * W);
+    int64_t cjob = -1; int cL = 0; float *cxo = nullptr;
+    float ctNL = 0.f, ctNM = 0.f;
+    if (chain_lane && base + cw < dna.n) {
+      cjob = jobs.order[base + cw]; cL = dna.len[cjob];
+      if (xmx) cxo = xmx + xmx_off[cjob];
+      ctNL = loop_tab[cL / 3]; ctNM = move_tab[cL / 3];
+    }
+    const bool clive = cjob >= 0 && cL >= 5;
+    float hN1 = -INFINITY, hN2 = -INFINITY, hJ1 = -INFINITY, hJ2 = -INFINITY, hC1 = -INFINITY, hC2 = -INFINITY;   // N, J, C of the slot's rows one and two pairs ago
+    // ---- the window wave: M(i+1..i+4) and I(i+1..i+3) for the lane's nodes
+    float R1[C], R2[C], R3[C], R4[C], J1[C], J2[C], J3[C];
+#pragma unroll
+    for (int c = 0; c < C; c++) R1[c] = R2[c] = R3[c] = R4[c] = J1[c] = J2[c] = J3[c] = -INFINITY;
+    auto nuc = [&](int i) -> int { return (i >= 1 && i <= L) ? ((d[i - 1] < 4) ? (int)d[i - 1] : 338) : 338; };
+    const int npairs = Lmax / 2 + 1;                            // rows Lmax .. 0 of the longest window
+    for (int q = 0; q < npairs; q++) {
+      const int iA = L - 2 * q, iB = iA - 1;                    // this window's rows of the pair; avail = 2q and 2q + 1 for every window
+      const bool mainA = 2 * q >= 5, mainB = 2 * q + 1 >= 5;
+      // codons that START at x_{i+1}: x = x_{i+1}, w = x_{i+2}, v = x_{i+3}, u = x_{i+4}; the last base is the most significant digit (:1539-1550)
+      const int x0 = nuc(iA), x1 = nuc(iA + 1), x2 = nuc(iA + 2), x3 = nuc(iA + 3), x4 = nuc(iA + 4);
+      const float *qa2 = p.rsc + (size_t)imin(x2 * 84 + x1 * 21, 337) * p.pitch;
+      const float *qa3 = p.rsc + (size_t)imin(x3 * 84 + x2 * 21 + x1 * 5 + 1, 336) * p.pitch;
+      const float *qa4 = p.rsc + (size_t)imin(x4 * 84 + x3 * 21 + x2 * 5 + x1 + 2, 337) * p.pitch;
+      const float *qb2 = p.rsc + (size_t)imin(x1 * 84 + x0 * 21, 337) * p.pitch;
+      const float *qb3 = p.rsc + (size_t)imin(x2 * 84 + x1 * 21 + x0 * 5 + 1, 336) * p.pitch;
+      const float *qb4 = p.rsc + (size_t)imin(x3 * 84 + x2 * 21 + x1 * 5 + x0 + 2, 337) * p.pitch;
+      // ---- 1. ivx of both rows
+      float ivA[C], ivB[C];
+#pragma unroll
+      for (int c = 0; c < C; c++) {
+        const int node = ll * C + c + 1, ne = imin(node, M);
+        const bool in = node <= M;
+        const float sa2 = R2[c] + qa2[ne], sa3 = R3[c] + qa3[ne], sa4 = R4[c] + qa4[ne];
+        const float sb2 = R1[c] + qb2[ne], sb3 = R2[c] + qb3[ne], sb4 = R3[c] + qb4[ne];
+        const float a = mainA ? LS(sa2, LS(sa3, sa4)) : LS(LS(sa2, sa3), sa4);       // :1552-1553; the rows near the end add their codons left to right (:1483, :1517-1518)
+        const float b = mainB ? LS(sb2, LS(sb3, sb4)) : LS(LS(sb2, sb3), sb4);
+        ivA[c] = in ? a : -INFINITY; ivB[c] = in ? b : -INFINITY;
+        if (in) { s_stage[((size_t)wv * 2 + 0) * stride + node] = ivA[c]; s_stage[((size_t)wv * 2 + 1) * stride + node] = ivB[c]; }
+      }
+      __syncthreads();
+      // ---- 2. the serial part
+      if (chain_lane) {
+        float *st = s_stage + (size_t)lane * stride;
+        const int avail = 2 * q + cs, irow = cL - avail;
+        float b = -INFINITY;
+        for (int k = 1; k <= M; k++) {
+          const float v = st[k] + s_tb[k * 8 + 7];
+          b = (k == 1) ? v : LS(b, v);
+        }
+        // N, J, C of row i+3: the other slot's row of two pairs ago (slot 0) or of the previous pair (slot 1)
+        const float pN1 = __shfl_xor(hN1, 1, 64), pN2 = __shfl_xor(hN2, 1, 64), pJ1 = __shfl_xor(hJ1, 1, 64), pJ2 = __shfl_xor(hJ2, 1, 64);
+        const float pC1 = __shfl_xor(hC1, 1, 64), pC2 = __shfl_xor(hC2, 1, 64);
+        const float uN = cs ? pN1 : pN2, uJ = cs ? pJ1 : pJ2, uC = cs ? pC1 : pC2;
+        float xJ, xN, xC;
+        if (avail < 3) { xJ = b + ctNM; xN = b + ctNM; xC = (avail == 0) ? ctNM : ctNL + ctNM; }      // :1442-1465, :1506-1511 (tJM = tNM = tCM, tCL = tNL)
+        else { xJ = LS(uJ + ctNL, b + ctNM); xC = uC + ctNL; xN = LS(uN + ctNL, b + ctNM); }           // :1566-1571
+        const float xE = LS(xJ + tEL, xC + tEM);
+        const bool mid = (avail == 3) || (avail == 4);            // rows L-3, L-4 associate the D chain differently (:1524-1526)
+        float dn = -INFINITY, ivn = -INFINITY;
+        for (int k = M; k >= 1; k--) {
+          const float tdd = s_tb[k * 8 + 3], tdm = s_tb[k * 8 + 4];
+          const float bs = ivn + tdm;
+          const float dv = mid ? LS(dn + tdd, LS(xE, bs)) : LS(LS(xE, dn + tdd), bs);
+          ivn = st[k];
+          st[k] = dv;
+          dn = dv;
+        }
+        s_e[lane] = xE;
+        const float partnerN = __shfl_xor(xN, 1, 64);
+        if (clive && irow >= 0) {
+          if (cxo) {
+            float *r = cxo + (size_t)irow * 5;
+            if (irow > 0) { r[0] = xE; r[1] = xN; r[2] = xJ; r[3] = b; r[4] = xC; }
+            else { r[0] = -INFINITY; r[1] = xN; r[2] = -INFINITY; r[3] = b; r[4] = -INFINITY; }          // :1660-1664
+          }
+          if (irow == 0) {                                        // rows 1 and 2: the other slot's row of this pair (slot 1) or of the previous one, and this slot's previous row
+            const float n1 = cs ? partnerN : pN1, n2 = hN1;
+            sc[cjob] = LS(xN, LS(n1, n2));
+          }
+        }
+        hN2 = hN1; hN1 = xN; hJ2 = hJ1; hJ1 = xJ; hC2 = hC1; hC1 = xC;
+      }
+      __syncthreads();
+      // ---- 3. the cells of both rows (:1574-1600)
+      const float EA = s_e[wv * 2 + 0], EB = s_e[wv * 2 + 1];
+      const float ivNextA = wave_shr1(ivA[0], -INFINITY), ivNextB = wave_shr1(ivB[0], -INFINITY);
+      float MA[C], IA[C], MB[C], IB[C];
+#pragma unroll
+      for (int c = C - 1; c >= 0; c--) {
+        const int node = ll * C + c + 1, nd = imin(node, M + 1);
+        const bool in = node <= M;
+        const float4 t0 = *reinterpret_cast<const float4 *>(s_tb + nd * 8);            // tMD tMI tMM tDD
+        const float tii = s_tb[nd * 8 + 5], tim = s_tb[nd * 8 + 6];
+        const float dnA = (node < M) ? s_stage[((size_t)wv * 2 + 0) * stride + node + 1] : -INFINITY;
+        const float dnB = (node < M) ? s_stage[((size_t)wv * 2 + 1) * stride + node + 1] : -INFINITY;
+        const float inA = (c == C - 1) ? ivNextA : ivA[c + 1], inB = (c == C - 1) ? ivNextB : ivB[c + 1];
+        float mvA, ivoA, mvB, ivoB;
+        // row A: avail = 2q
+        if (2 * q < 3) { mvA = LS(dnA + t0.x, LS(inA + t0.z, EA)); ivoA = inA + tim; }
+        else if (!mainA) { mvA = LS(dnA + t0.x, LS(J3[c] + t0.y, LS(inA + t0.z, EA))); ivoA = LS(J3[c] + tii, inA + tim); }
+        else { mvA = LS(LS(dnA + t0.x, LS(J3[c] + t0.y, inA + t0.z)), EA); ivoA = LS(J3[c] + tii, inA + tim); }
+        // row B: avail = 2q + 1
+        if (2 * q + 1 < 3) { mvB = LS(dnB + t0.x, LS(inB + t0.z, EB)); ivoB = inB + tim; }
+        else if (!mainB) { mvB = LS(dnB + t0.x, LS(J2[c] + t0.y, LS(inB + t0.z, EB))); ivoB = LS(J2[c] + tii, inB + tim); }
+        else { mvB = LS(LS(dnB + t0.x, LS(J2[c] + t0.y, inB + t0.z)), EB); ivoB = LS(J2[c] + tii, inB + tim); }
+        MA[c] = in ? mvA : -INFINITY; IA[c] = in ? ivoA : -INFINITY; MB[c] = in ? mvB : -INFINITY; IB[c] = in ? ivoB : -INFINITY;
+      }
+      if (live && iB >= 0) {
+#pragma unroll
+        for (int c = 0; c < C; c++) { R4[c] = R2[c]; R3[c] = R1[c]; R2[c] = MA[c]; R1[c] = MB[c]; J3[c] = J1[c]; J2[c] = IA[c]; J1[c] = IB[c]; }
+      }
+    }
+    if (job >= 0 && !live && lane == 0) sc[job] = -INFINITY;
+    __syncthreads();
+  }
+#undef LS
+}
+
 static int chain_waves(int M, int C, size_t *shmem_out) {
   // as many windows per block as LDS holds next to the table and the transitions (one block per CU)
   const size_t fixed = (size_t)(kLogsumTbl + (M + 2) * 8 + 2 * kChainMaxWaves + 16) * sizeof(float);
@@ -200,6 +362,22 @@ int launch_fs3_fwd_chain(bath_hip_ctx *ctx, hipStream_t stream, const bath_hip_f
   BATH_CHAIN_SWITCH(Cv, {
     BATH_HIP_TRY(ctx, hipFuncSetAttribute((const void *)fs3_fwd_chain_kernel<CC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     hipLaunchKernelGGL((fs3_fwd_chain_kernel<CC>), dim3(grid), dim3(64 * W), shmem, stream, dna->view(), dev, om->d_loop[0], om->d_move[0], tEL, tEM, d_sc, d_xmx, d_xoff, jobs);
+  })
+  BATH_HIP_TRY(ctx, hipGetLastError());
+  return BATH_OK;
+}
+
+int launch_fs3_bwd_chain(bath_hip_ctx *ctx, hipStream_t stream, const bath_hip_fsprofile *om, const bath_hip_seqs *dna, int Cv, float tEL, float tEM,
+                         float *d_sc, float *d_xmx, const int64_t *d_xoff, FsJobs jobs) {
+  const int M = om->M;
+  size_t shmem = 0;
+  const int W = chain_waves(M, Cv, &shmem);
+  const int64_t n = dna->n;
+  const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((n + W - 1) / W, (int64_t)ctx->prop.multiProcessorCount));
+  FsDev dev{om->M, om->pitch, om->maxcodons, om->d_rsc, om->d_tf, om->d_tb, om->d_logsum};
+  BATH_CHAIN_SWITCH(Cv, {
+    BATH_HIP_TRY(ctx, hipFuncSetAttribute((const void *)fs3_bwd_chain_kernel<CC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    hipLaunchKernelGGL((fs3_bwd_chain_kernel<CC>), dim3(grid), dim3(64 * W), shmem, stream, dna->view(), dev, om->d_loop[0], om->d_move[0], tEL, tEM, d_sc, d_xmx, d_xoff, jobs);
   })
   BATH_HIP_TRY(ctx, hipGetLastError());
   return BATH_OK;
