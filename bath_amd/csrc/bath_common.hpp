@@ -103,6 +103,7 @@ struct bath_hip_ctx {
   std::vector<bath_orf> orfs;             // bath_hip_translate_orfs output
   std::vector<bath_fs_window> fs_windows; // bath_hip_pipeline_frameshift output
   bool fs_want_regions = false;           // set by the domain stage: the decision stage also runs the Backward parser and the region heuristics
+  std::vector<int64_t> fs_keep_xoff;      // the decision stage's Forward parser rows stay on the device (scratch[45]): offsets per DNA window, in floats
   std::vector<int32_t> fs_regions_all;    // ... for every DNA window: 1 + 3*fs_max_regions() ints each (bath_frameshift.hip: fs3_regions)
   std::vector<bath_fs_domain> fs_domains; // bath_hip_pipeline_frameshift_domains output
   std::string cigars;                     // NUL-terminated CIGAR strings of fs_domains (bath_fs_domain.cigar_off)

@@ -190,7 +190,7 @@ static int fs_branch_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, con
   } else {
     bath_hip_seqs view;
     if ((st = fs_gather_view(ctx, dna, regs, tt.comp, &view, nullptr)) != BATH_OK) return st;
-    st = fs3_regions(ctx, om_fs3, &view, loop, regions.data());               // parsers, domain decoding, region heuristics: all on the device
+    st = fs3_regions(ctx, om_fs3, &view, loop, regions.data(), nullptr, sel.data());   // Backward parser (Forward's rows are the decision stage's), domain decoding, region heuristics: all on the device
     view.d_data = nullptr; view.d_off = nullptr; view.d_len = nullptr;
     if (st != BATH_OK) return st;
     clk.lap("fs: parsers + regions");

@@ -1452,7 +1452,7 @@ static int fs_schedule(bath_hip_ctx *ctx, const bath_hip_seqs *dna, int k, FsJob
 }  // namespace bath
 
 static int fs3_parser(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, const bath_hip_seqs *dna, int logsum_mode, float *sc, float *xmx,
-                      const int64_t *xmx_off, bool backward) {
+                      const int64_t *xmx_off, bool backward, DevBuf *keep = nullptr /* the rows stay in this device buffer instead of going to <xmx> */) {
   if (!ctx || !om || !dna || om->codon_lengths != 3) { if (ctx) ctx->set_error("fs3 parser needs a 3-codon profile"); return BATH_EINVAL; }
   BATH_HIP_TRY(ctx, hipSetDevice(ctx->device));
   const int64_t n = dna->n;
@@ -1462,10 +1462,11 @@ static int fs3_parser(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, const bat
   DevBuf &b_sc = ctx->scratch[12], &b_x = ctx->scratch[13], &b_off = ctx->scratch[14];
   BATH_HIP_TRY(ctx, b_sc.reserve((size_t)n * sizeof(float)));
   float *d_x = nullptr;
-  if (xmx) {
-    BATH_HIP_TRY(ctx, b_x.reserve((size_t)xmx_off[n] * sizeof(float) + 64));
+  if (xmx || keep) {
+    DevBuf &bx = keep ? *keep : b_x;
+    BATH_HIP_TRY(ctx, bx.reserve((size_t)xmx_off[n] * sizeof(float) + 64));
     if ((st = upload_offsets(ctx, b_off, xmx_off, n)) != BATH_OK) return st;
-    d_x = b_x.as<float>();
+    d_x = bx.as<float>();
   }
   const int Cv = fs_columns(om->M);
   const size_t shmem = (size_t)(kLogsumTbl + (om->M + 2) * 8) * sizeof(float);
@@ -1474,7 +1475,7 @@ static int fs3_parser(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, const bat
   const int grid_dp = fs_grid_dp(ctx, n);
   FsJobs jq[1];
   if ((st = fs_schedule(ctx, dna, 1, jq)) != BATH_OK) return st;
-  const int sp = ctx->span_begin(backward ? "fs_bwd_kernel<3>" : "fs3_fwd_kernel", ctx->stream, (double)dna->total * om->M, (double)dna->total * (xmx ? 21.0 : 1.0));
+  const int sp = ctx->span_begin(backward ? "fs_bwd_kernel<3>" : "fs3_fwd_kernel", ctx->stream, (double)dna->total * om->M, (double)dna->total * ((xmx || keep) ? 21.0 : 1.0));
   if (logsum_mode == BATH_LOGSUM_TABLE_SERIAL && fs_chain_enabled()) {
     if (!backward) st = launch_fs3_fwd_chain(ctx, ctx->stream, om, dna, Cv, tE, tE, b_sc.as<float>(), d_x, b_off.as<int64_t>(), jq[0]);
     else st = launch_fs3_bwd_chain(ctx, ctx->stream, om, dna, Cv, tE, tE, b_sc.as<float>(), d_x, b_off.as<int64_t>(), jq[0]);
@@ -1504,14 +1505,15 @@ static int fs3_parser(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, const bat
 // reference's own order of additions.  Only the regions (a few integers per window) travel to the host.
 constexpr int kMaxRegions = 64;       // regions kept per DNA window; a window with more reports the true count and the call fails loudly (the reference has no cap)
 __global__ __launch_bounds__(64) void fs_regions_kernel(int64_t n, const int32_t *__restrict__ len, const float *__restrict__ fx, const float *__restrict__ bx,
-                                  const int64_t *__restrict__ x_off, const float *__restrict__ tbl, float loop, float *__restrict__ work /* 3 floats per xmx row */,
+                                  const int64_t *__restrict__ x_off, const int64_t *__restrict__ fx_off /* where the Forward rows start (they may live in another buffer) */,
+                                  const float *__restrict__ tbl, float loop, float *__restrict__ work /* 3 floats per xmx row */,
                                   int32_t *__restrict__ regions /* [n][1 + 3*kMaxRegions]: count, then {i, j, multidomain} */) {
   const int64_t w = blockIdx.x;
   const int lane = threadIdx.x;
   if (w >= n) return;
   enum { XE = 0, XN, XJ, XB, XC };
   const int L = len[w];
-  const float *F = fx + x_off[w], *B = bx + x_off[w];
+  const float *F = fx + fx_off[w], *B = bx + x_off[w];
   float *btot = work + (x_off[w] / 5) * 3, *etot = btot + (L + 1), *mocc = etot + (L + 1);
   int32_t *out = regions + w * (1 + 3 * kMaxRegions);
   int nreg = 0;
@@ -1597,7 +1599,7 @@ int fs_join(bath_hip_ctx *ctx) {
   return BATH_OK;
 }
 
-int fs3_regions(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, const bath_hip_seqs *dna, float loop, int32_t *regions_out, float *fwd_sc_out) {
+int fs3_regions(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, const bath_hip_seqs *dna, float loop, int32_t *regions_out, float *fwd_sc_out, const int32_t *kept) {
   if (!ctx || !om || !dna || om->codon_lengths != 3) { if (ctx) ctx->set_error("fs3 parser needs a 3-codon profile"); return BATH_EINVAL; }
   BATH_HIP_TRY(ctx, hipSetDevice(ctx->device));
   const int64_t n = dna->n;
@@ -1614,6 +1616,20 @@ int fs3_regions(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, const bath_hip_
   const size_t reg_ints = (size_t)n * (1 + 3 * kMaxRegions);
   BATH_HIP_TRY(ctx, b_reg.reserve(reg_ints * sizeof(int32_t) + 64));
   if ((st = upload_offsets(ctx, b_off, xoff.data(), n)) != BATH_OK) return st;
+  // <kept>: window q of <dna> is window kept[q] of the block whose Forward rows fs3_forward_scores left on the device -- the
+  // reference runs the Forward parser once per window too (p7_pipeline.c:1450, rows kept in pli->oxf)
+  const bool reuse = kept && !ctx->fs_keep_xoff.empty() && fwd_sc_out == nullptr;
+  DevBuf &b_foff = ctx->scratch[46];
+  const float *d_fx = b_fx.as<float>();
+  const int64_t *d_fxoff = b_off.as<int64_t>();
+  std::vector<int64_t> fsel;
+  if (reuse) {
+    fsel.resize((size_t)n);
+    for (int64_t q = 0; q < n; q++) fsel[(size_t)q] = ctx->fs_keep_xoff[(size_t)kept[q]];
+    BATH_HIP_TRY(ctx, b_foff.reserve((size_t)n * sizeof(int64_t)));
+    BATH_HIP_TRY(ctx, hipMemcpyAsync(b_foff.p, fsel.data(), (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+    d_fx = ctx->scratch[45].as<float>(); d_fxoff = b_foff.as<int64_t>();
+  }
   const int Cv = fs_columns(om->M);
   const size_t shmem = (size_t)(kLogsumTbl + (om->M + 2) * 8) * sizeof(float);
   const float tE = (float)-0.69314718055994529;
@@ -1628,8 +1644,9 @@ int fs3_regions(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, const bath_hip_
   const double bytes3 = (double)(xoff[(size_t)n] / 5) * 21.0;
   BATH_FS_SWITCH(Cv, BATH_FS_MODE(mode, {
     if ((st = fs_set_shmem(ctx, fs3_fwd_kernel<CC, MD>, shmem)) != BATH_OK) return st;
-    const int s1 = ctx->span_begin("fs3_fwd_kernel", ctx->stream, cells3, bytes3);
-    if (MD == 2 && fs_chain_enabled()) {
+    const int s1 = reuse ? -1 : ctx->span_begin("fs3_fwd_kernel", ctx->stream, cells3, bytes3);
+    if (reuse) {
+    } else if (MD == 2 && fs_chain_enabled()) {
       if ((st = launch_fs3_fwd_chain(ctx, ctx->stream, om, dna, Cv, tE, tE, b_sc.as<float>(), b_fx.as<float>(), b_off.as<int64_t>(), jq[0])) != BATH_OK) return st;
     } else
     hipLaunchKernelGGL((fs3_fwd_kernel<CC, MD>), dim3(grid_dp), dim3(kFsBlock), shmem, ctx->stream, dna->view(), fsdev(om), om->d_loop[0], om->d_move[0], tE, tE, b_sc.as<float>(), b_fx.as<float>(), b_off.as<int64_t>(), jq[0]);
@@ -1644,7 +1661,7 @@ int fs3_regions(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, const bath_hip_
   }))
   if ((st = fs_join(ctx)) != BATH_OK) return st;
   const int s3 = ctx->span_begin("fs_regions_kernel", ctx->stream, (double)(xoff[(size_t)n] / 5), (double)(xoff[(size_t)n] / 5) * 52.0);
-  hipLaunchKernelGGL(fs_regions_kernel, dim3((unsigned)n), dim3(64), 0, ctx->stream, n, dna->d_len, b_fx.as<float>(), b_bx.as<float>(), b_off.as<int64_t>(), om->d_logsum, loop,
+  hipLaunchKernelGGL(fs_regions_kernel, dim3((unsigned)n), dim3(64), 0, ctx->stream, n, dna->d_len, d_fx, b_bx.as<float>(), b_off.as<int64_t>(), d_fxoff, om->d_logsum, loop,
                      b_work.as<float>(), b_reg.as<int32_t>());
   ctx->span_end(s3, ctx->stream);
   BATH_HIP_TRY(ctx, hipGetLastError());
@@ -1658,7 +1675,16 @@ int fs3_regions(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, const bath_hip_
 namespace bath {
 // used by the pipeline's frameshift stage (bath_pipeline.hip)
 int fs3_forward_scores(bath_hip_ctx *ctx, const bath_hip_fsprofile *om3, const bath_hip_seqs *dna, float *sc) {
-  return fs3_parser(ctx, om3, dna, ctx->fs_strict ? BATH_LOGSUM_TABLE_SERIAL : BATH_LOGSUM_TABLE, sc, nullptr, nullptr, false);
+  ctx->fs_keep_xoff.clear();
+  const int mode = ctx->fs_strict ? BATH_LOGSUM_TABLE_SERIAL : BATH_LOGSUM_TABLE;
+  if (!ctx->fs_want_regions) return fs3_parser(ctx, om3, dna, mode, sc, nullptr, nullptr, false);
+  // the domain stage follows: the special-state rows of every window stay on the device (20 B per nucleotide), so that the
+  // windows that take the frameshift branch need the Backward parser only
+  std::vector<int64_t> xoff((size_t)dna->n + 1, 0);
+  for (int64_t i = 0; i < dna->n; i++) xoff[(size_t)i + 1] = xoff[(size_t)i] + ((int64_t)dna->h_len[(size_t)i] + 1) * 5;
+  const int st = fs3_parser(ctx, om3, dna, mode, sc, nullptr, xoff.data(), false, &ctx->scratch[45]);
+  if (st == BATH_OK) ctx->fs_keep_xoff = std::move(xoff);
+  return st;
 }
 const float *fsprofile_evparam(const bath_hip_fsprofile *om) { return om->evparam; }
 int fsprofile_codon_lengths(const bath_hip_fsprofile *om) { return om->codon_lengths; }
@@ -1895,6 +1921,11 @@ int bath::fs5_region_forward(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, co
   const int mode = ctx->fs_strict ? BATH_LOGSUM_TABLE_SERIAL : BATH_LOGSUM_TABLE;
   FsJobs jq[1];
   if ((st = fs_schedule(ctx, dna, 1, jq)) != BATH_OK) return st;
+  if (mode == BATH_LOGSUM_TABLE_SERIAL && fs_chain_enabled()) {
+    const int s1 = ctx->span_begin("fs5_fwd_kernel(regions)", ctx->stream, (double)(foff[(size_t)n] / 8), (double)(foff[(size_t)n] / 8) * 32.0);
+    if ((st = launch_fs5_fwd_chain(ctx, ctx->stream, om, dna, Cv, tE, tE, 0, d_sc_out, d_f, d_foff, d_fx, d_xoff, cfg_len_amino, jq[0], d_done)) != BATH_OK) return st;
+    ctx->span_end(s1, ctx->stream);
+  } else
   BATH_FS_SWITCH(Cv, BATH_FS_MODE(mode, {
     if ((st = fs_set_shmem(ctx, fs5_fwd_kernel<CC, MD>, shmem)) != BATH_OK) return st;
     const int s1 = ctx->span_begin("fs5_fwd_kernel(regions)", ctx->stream, (double)(foff[(size_t)n] / 8), (double)(foff[(size_t)n] / 8) * 32.0);

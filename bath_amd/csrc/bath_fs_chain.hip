@@ -121,9 +121,14 @@ __global__ __launch_bounds__(chain_threads(C)) void fs3_fwd_chain_kernel(SeqView
       if (wv == 0 && lane < 2 * W) {
         float *st = s_stage + (size_t)lane * stride;
         float dch = -INFINITY, ech = -INFINITY;
+        // the loop's own loads (M(i,k), the transitions) are a node ahead: what a node waits for is the chain's log-sums only
+        float Mn = st[1];
+        float2 tn = *reinterpret_cast<const float2 *>(s_tf + 1 * 8 + 4);           // tMD(k), tDD(k)
         for (int k = 1; k <= M; k++) {
-          const float Mk = st[k];
-          const float2 t = *reinterpret_cast<const float2 *>(s_tf + k * 8 + 4);   // tMD(k), tDD(k)
+          const float Mk = Mn;
+          const float2 t = tn;
+          Mn = st[k + 1];                                        // (slot M+1 exists: the stride is at least M+2)
+          tn = *reinterpret_cast<const float2 *>(s_tf + (k + 1) * 8 + 4);
           st[k] = dch;
           ech = LS(Mk, LS(dch, ech));
           dch = LS(Mk + t.x, dch + t.y);
@@ -255,10 +260,12 @@ __global__ __launch_bounds__(chain_threads(C)) void fs3_bwd_chain_kernel(SeqView
       if (chain_lane) {
         float *st = s_stage + (size_t)lane * stride;
         const int avail = 2 * q + cs, irow = cL - avail;
-        float b = -INFINITY;
-        for (int k = 1; k <= M; k++) {
-          const float v = st[k] + s_tb[k * 8 + 7];
-          b = (k == 1) ? v : LS(b, v);
+        float b = st[1] + s_tb[1 * 8 + 7];
+        float vn = st[2] + s_tb[2 * 8 + 7];                       // the terms are read a node ahead of the chain
+        for (int k = 2; k <= M; k++) {
+          const float v = vn;
+          vn = st[k + 1] + s_tb[(k + 1) * 8 + 7];
+          b = LS(b, v);
         }
         // N, J, C of row i+3: the other slot's row of two pairs ago (slot 0) or of the previous pair (slot 1)
         const float pN1 = __shfl_xor(hN1, 1, 64), pN2 = __shfl_xor(hN2, 1, 64), pJ1 = __shfl_xor(hJ1, 1, 64), pJ2 = __shfl_xor(hJ2, 1, 64);
@@ -269,13 +276,20 @@ __global__ __launch_bounds__(chain_threads(C)) void fs3_bwd_chain_kernel(SeqView
         else { xJ = LS(uJ + ctNL, b + ctNM); xC = uC + ctNL; xN = LS(uN + ctNL, b + ctNM); }           // :1566-1571
         const float xE = LS(xJ + tEL, xC + tEM);
         const bool mid = (avail == 3) || (avail == 4);            // rows L-3, L-4 associate the D chain differently (:1524-1526)
+        // D(i,k) = LS(LS(E, D(i,k+1) + tDD), ivx(i,k+1) + tDM); the rows L-3, L-4 pair E with the ivx term first (:1524-1526).
+        // Log-sum is symmetric, so both are LS(LS(E, p1), p2) with the operands swapped: no branch in the loop
         float dn = -INFINITY, ivn = -INFINITY;
+        float ivq = st[M];                                        // ivx(i,k), read a node ahead
+        float2 tq = make_float2(s_tb[M * 8 + 3], s_tb[M * 8 + 4]);        // tDD(k), tDM(k)
         for (int k = M; k >= 1; k--) {
-          const float tdd = s_tb[k * 8 + 3], tdm = s_tb[k * 8 + 4];
-          const float bs = ivn + tdm;
-          const float dv = mid ? LS(dn + tdd, LS(xE, bs)) : LS(LS(xE, dn + tdd), bs);
-          ivn = st[k];
+          const float2 t = tq;
+          const float ivk = ivq;
+          ivq = st[k - 1];
+          tq = make_float2(s_tb[(k - 1) * 8 + 3], s_tb[(k - 1) * 8 + 4]);
+          const float bs = ivn + t.y, u = dn + t.x;
+          const float dv = LS(LS(xE, mid ? bs : u), mid ? u : bs);
           st[k] = dv;
+          ivn = ivk;
           dn = dv;
         }
         s_e[lane] = xE;
@@ -324,6 +338,163 @@ __global__ __launch_bounds__(chain_threads(C)) void fs3_bwd_chain_kernel(SeqView
       }
     }
     if (job >= 0 && !live && lane == 0) sc[job] = -INFINITY;
+    __syncthreads();
+  }
+#undef LS
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// 5-codon Forward, full matrix, MULTIHIT (the regions of p7_domaindef.c:396-455), strict.  IVX(i,k) collects the paths leaving
+// row i-1 and B(i-1), so rows cannot be paired: one row per step, W windows per block, the D chain and the E sum of all W rows
+// in one wave.  fwd[(i*(M+1)+k)*8 + {D,I,C0..C5}], xmx[i*5 + {E,N,J,B,C}]; done[job] = 1 (system scope) once the matrix has landed.
+// ---------------------------------------------------------------------------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(chain_threads(C)) void fs5_fwd_chain_kernel(SeqView dna, FsDev p, const float *__restrict__ loop_tab, const float *__restrict__ move_tab,
+                                                             float tEL, float tEM, int c5_compat, float *__restrict__ sc, float *__restrict__ fwd, const int64_t *__restrict__ fwd_off,
+                                                             float *__restrict__ xmx, const int64_t *__restrict__ xmx_off, int cfg_len, FsJobs jobs, int *__restrict__ done) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  float *s_tbl = reinterpret_cast<float *>(lds);
+  float *s_tf = s_tbl + kLogsumTbl;
+  const int M = p.M;
+  const int W = blockDim.x >> 6;
+  const int stride = fs_chain_stride(C);
+  float *s_stage = s_tf + (M + 2) * 8;                          // [W][2][stride]; row 0 of each pair of slots is used
+  float *s_e = s_stage + (size_t)W * 2 * stride;
+  int *s_ctl = reinterpret_cast<int *>(s_e + 2 * kChainMaxWaves);
+  fs_load_logsum_table(s_tbl, p.logsum);
+  for (int i = threadIdx.x; i < (M + 2) * 8; i += blockDim.x) s_tf[i] = p.tf[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#define LS(a, b) flogsum<false>((a), (b), s_tbl)
+  for (;;) {
+    if (threadIdx.x == 0) s_ctl[0] = (int)atomicAdd(jobs.counter, (unsigned)W);
+    __syncthreads();
+    const int64_t base = s_ctl[0];
+    if (base >= dna.n) break;
+    const int64_t job = (base + wv < dna.n) ? (int64_t)jobs.order[base + wv] : (int64_t)-1;
+    const int Lmax = dna.len[jobs.order[base]];
+    const int L = job >= 0 ? dna.len[job] : 0;
+    const bool live = job >= 0 && L >= 5;
+    const uint8_t *d = job >= 0 ? dna.data + dna.off[job] : dna.data;
+    float *fo = job >= 0 ? fwd + fwd_off[job] : fwd;
+    float *xo = job >= 0 ? xmx + xmx_off[job] : xmx;
+    const int Lc = cfg_len >= 0 ? cfg_len : L / 3;
+    const float tNL = loop_tab[Lc], tNM = move_tab[Lc], tJL = tNL, tJM = tNM, tCL = tNL, tCM = tNM;
+    float Mr0[C], Mr1[C], Mr2[C], Ir0[C], Ir1[C], Ir2[C], Dr1[C], iv0[C], iv1[C], iv2[C], iv3[C];   // M, I of rows i-1..i-3; D of row i-1; IVX(i-1..i-4)
+#pragma unroll
+    for (int c = 0; c < C; c++) Mr0[c] = Mr1[c] = Mr2[c] = Ir0[c] = Ir1[c] = Ir2[c] = Dr1[c] = iv0[c] = iv1[c] = iv2[c] = iv3[c] = -INFINITY;
+    if (live) {
+      for (int k = lane; k <= M; k += 64)
+#pragma unroll
+        for (int q = 0; q < 8; q++) fo[(size_t)k * 8 + q] = -INFINITY;
+      if (lane == 0) { xo[0] = -INFINITY; xo[1] = 0.f; xo[2] = -INFINITY; xo[3] = tNM; xo[4] = -INFINITY; }
+    }
+    float xN0 = 0.f, xN1 = 0.f, xN2 = 0.f, xJ0 = -INFINITY, xJ1 = -INFINITY, xJ2 = -INFINITY, xC0 = -INFINITY, xC1 = -INFINITY, xC2 = -INFINITY;   // rows i-1, i-2, i-3
+    float xBprev = tNM;
+    auto nuc = [&](int i) -> int { return (i >= 1 && i <= L) ? ((d[i - 1] < 4) ? (int)d[i - 1] : 1367) : 1367; };
+    for (int i = 1; i <= Lmax; i++) {
+      const bool act = live && i <= L;
+      const int x = nuc(i), w = nuc(i - 1), v = nuc(i - 2), u = nuc(i - 3), t = nuc(i - 4);
+      const float *r1 = p.rsc + (size_t)imin(x * 341, 1366) * p.pitch;
+      const float *r2 = p.rsc + (size_t)imin(x * 341 + w * 85 + 1, 1365) * p.pitch;
+      const float *r3 = p.rsc + (size_t)imin(x * 341 + w * 85 + v * 21 + 2, 1364) * p.pitch;
+      const float *r4 = p.rsc + (size_t)imin(x * 341 + w * 85 + v * 21 + u * 5 + 3, 1365) * p.pitch;
+      const float *r5 = p.rsc + (size_t)imin(x * 341 + w * 85 + v * 21 + u * 5 + t + 4, 1366) * p.pitch;
+      const float mIn = wave_shr1(Mr0[C - 1], -INFINITY), iIn = wave_shr1(Ir0[C - 1], -INFINITY), dIn = wave_shr1(Dr1[C - 1], -INFINITY);
+      float Mc[C], Ic[C], ivc[C];
+      float *row = fo + (size_t)(act ? i : 0) * (M + 1) * 8;
+      if (act && lane == 0) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) row[q] = -INFINITY;
+      }
+#pragma unroll
+      for (int c = 0; c < C; c++) {
+        const int node = lane * C + c + 1, nd = imin(node, M + 1), ne = imin(node, M);
+        const float4 ta = *reinterpret_cast<const float4 *>(s_tf + nd * 8);
+        const float4 tb = *reinterpret_cast<const float4 *>(s_tf + nd * 8 + 4);
+        const float m1 = (c == 0) ? mIn : Mr0[c - 1], i1 = (c == 0) ? iIn : Ir0[c - 1], d1 = (c == 0) ? dIn : Dr1[c - 1];
+        float ivn;
+        if (i <= 2) ivn = xBprev + ta.w;                                          // rows 1, 2: only B(i-1) enters (:109, :150)
+        else ivn = LS(m1 + ta.x, LS(i1 + ta.y, LS(d1 + ta.z, xBprev + ta.w)));    // :332-335
+        ivc[c] = ivn;
+        const float c1 = ivn + r1[ne];
+        const float c2 = (i >= 2) ? iv0[c] + r2[ne] : -INFINITY;
+        const float c3 = (i >= 3) ? iv1[c] + r3[ne] : -INFINITY;
+        const float c4 = (i >= 4) ? iv2[c] + r4[ne] : -INFINITY;
+        const float c5 = (i >= 5) ? (c5_compat ? ivn : iv3[c]) + r5[ne] : -INFINITY;
+        float c0;
+        if (i == 1) c0 = c1;
+        else if (i == 2) c0 = LS(c1, c2);
+        else if (i < 5) c0 = LS(c1, LS(c2, LS(c3, c4)));
+        else c0 = LS(LS(c1, LS(c2, c3)), LS(c4, c5));
+        Mc[c] = c0;
+        const float ins = LS(Mr2[c] + tb.z, Ir2[c] + tb.w);
+        Ic[c] = (i >= 3 && node < M) ? ins : -INFINITY;
+        if (node <= M) {
+          s_stage[((size_t)wv * 2) * stride + node] = c0;
+          if (act) {
+            float *cell = row + (size_t)node * 8;
+            cell[1] = Ic[c]; cell[2] = c0; cell[3] = c1; cell[4] = c2; cell[5] = c3; cell[6] = c4; cell[7] = c5;
+          }
+        }
+      }
+      __syncthreads();
+      // ---- the serial part, a lane per window: D(i,k), E(i) in the reference's order; rows >= 5 pair M(i,M) and D(i,M) first (:392-394)
+      if (wv == 0 && lane < W) {
+        float *st = s_stage + (size_t)lane * 2 * stride;
+        float dch = -INFINITY, ech = -INFINITY;
+        float Mn = st[1];
+        float2 tn = *reinterpret_cast<const float2 *>(s_tf + 1 * 8 + 4);           // tMD(k), tDD(k)
+        for (int k = 1; k < M; k++) {
+          const float Mk = Mn;
+          const float2 t2 = tn;
+          Mn = st[k + 1];
+          tn = *reinterpret_cast<const float2 *>(s_tf + (k + 1) * 8 + 4);
+          st[k] = dch;
+          ech = LS(Mk, LS(dch, ech));
+          dch = LS(Mk + t2.x, dch + t2.y);
+        }
+        st[M] = dch;
+        ech = (i >= 5) ? LS(LS(Mn, dch), ech) : LS(Mn, LS(dch, ech));
+        s_e[lane] = ech;
+      }
+      __syncthreads();
+      float Dc[C];
+#pragma unroll
+      for (int c = 0; c < C; c++) {
+        const int node = lane * C + c + 1, ne = imin(node, M);
+        const float dv = s_stage[((size_t)wv * 2) * stride + ne];
+        Dc[c] = (node <= M) ? dv : -INFINITY;
+        if (act && node <= M) row[(size_t)node * 8] = Dc[c];
+      }
+      const float xE = s_e[wv];
+      float nN, nJ, nC, nB;
+      if (i <= 2) { nN = 0.f; nJ = xE + tEL; nC = xE + tEM; nB = tNM; }           // :126-132, :166-167
+      else {
+        nN = xN2 + tNL; nJ = LS(xJ2 + tJL, xE + tEL); nC = LS(xC2 + tCL, xE + tEM);
+        nB = LS(nN + tNM, nJ + tJM);
+      }
+      if (act) {
+        if (lane == 0) { xo[i * 5 + 0] = xE; xo[i * 5 + 1] = nN; xo[i * 5 + 2] = nJ; xo[i * 5 + 3] = nB; xo[i * 5 + 4] = nC; }
+        xN2 = xN1; xN1 = xN0; xN0 = nN; xJ2 = xJ1; xJ1 = xJ0; xJ0 = nJ; xC2 = xC1; xC1 = xC0; xC0 = nC;
+        xBprev = nB;
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+          Mr2[c] = Mr1[c]; Mr1[c] = Mr0[c]; Mr0[c] = Mc[c];
+          Ir2[c] = Ir1[c]; Ir1[c] = Ir0[c]; Ir0[c] = Ic[c];
+          Dr1[c] = Dc[c];
+          iv3[c] = iv2[c]; iv2[c] = iv1[c]; iv1[c] = iv0[c]; iv0[c] = ivc[c];
+        }
+        if (i == L) {                                             // this window is complete: score, then the flag the host waits for
+          if (lane == 0) sc[job] = LS(xC0, LS(xC1 + tCL, xC2 + tCL)) + tCM;
+          if (done) { __threadfence_system(); if (lane == 0) __hip_atomic_store(done + job, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+        }
+      }
+    }
+    if (job >= 0 && !live) {
+      if (lane == 0) sc[job] = -INFINITY;
+      if (done) { __threadfence_system(); if (lane == 0) __hip_atomic_store(done + job, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+    }
     __syncthreads();
   }
 #undef LS
@@ -378,6 +549,23 @@ int launch_fs3_bwd_chain(bath_hip_ctx *ctx, hipStream_t stream, const bath_hip_f
   BATH_CHAIN_SWITCH(Cv, {
     BATH_HIP_TRY(ctx, hipFuncSetAttribute((const void *)fs3_bwd_chain_kernel<CC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     hipLaunchKernelGGL((fs3_bwd_chain_kernel<CC>), dim3(grid), dim3(64 * W), shmem, stream, dna->view(), dev, om->d_loop[0], om->d_move[0], tEL, tEM, d_sc, d_xmx, d_xoff, jobs);
+  })
+  BATH_HIP_TRY(ctx, hipGetLastError());
+  return BATH_OK;
+}
+
+int launch_fs5_fwd_chain(bath_hip_ctx *ctx, hipStream_t stream, const bath_hip_fsprofile *om, const bath_hip_seqs *dna, int Cv, float tEL, float tEM, int c5_compat,
+                         float *d_sc, float *d_fwd, const int64_t *d_foff, float *d_xmx, const int64_t *d_xoff, int cfg_len, FsJobs jobs, int *d_done) {
+  const int M = om->M;
+  size_t shmem = 0;
+  const int W = chain_waves(M, Cv, &shmem);
+  const int64_t n = dna->n;
+  const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((n + W - 1) / W, (int64_t)ctx->prop.multiProcessorCount));
+  FsDev dev{om->M, om->pitch, om->maxcodons, om->d_rsc, om->d_tf, om->d_tb, om->d_logsum};
+  BATH_CHAIN_SWITCH(Cv, {
+    BATH_HIP_TRY(ctx, hipFuncSetAttribute((const void *)fs5_fwd_chain_kernel<CC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    hipLaunchKernelGGL((fs5_fwd_chain_kernel<CC>), dim3(grid), dim3(64 * W), shmem, stream, dna->view(), dev, om->d_loop[0], om->d_move[0], tEL, tEM, c5_compat, d_sc, d_fwd, d_foff,
+                       d_xmx, d_xoff, cfg_len, jobs, d_done);
   })
   BATH_HIP_TRY(ctx, hipGetLastError());
   return BATH_OK;

@@ -80,7 +80,7 @@ int fs_join(bath_hip_ctx *ctx);   // ... and the main stream for the side stream
 int fs3_forward_scores(bath_hip_ctx *ctx, const bath_hip_fsprofile *om3, const bath_hip_seqs *dna, float *sc);   // table log-sum, host array out
 const float *fsprofile_evparam(const bath_hip_fsprofile *om);
 int fs_max_regions();
-int fs3_regions(bath_hip_ctx *ctx, const bath_hip_fsprofile *om3, const bath_hip_seqs *dna, float loop, int32_t *regions_out, float *fwd_sc_out = nullptr);   // parsers + domain decoding + region heuristics (+ the Forward scores)
+int fs3_regions(bath_hip_ctx *ctx, const bath_hip_fsprofile *om3, const bath_hip_seqs *dna, float loop, int32_t *regions_out, float *fwd_sc_out = nullptr, const int32_t *kept = nullptr);   // parsers + domain decoding + region heuristics (+ the Forward scores)
 int fsprofile_codon_lengths(const bath_hip_fsprofile *om);
 struct FsHostTables { int M, max_length, maxcodons; const float *tsc; const uint8_t *codons; const float *evparam; };
 const FsHostTables fsprofile_host(const bath_hip_fsprofile *om);

@@ -1409,6 +1409,7 @@ extern "C" int bath_hip_pipeline_frameshift(bath_hip_ctx *ctx, const bath_hip_op
     std::vector<float> h_bias((size_t)nw * 6);
     std::vector<float> h_fsc((size_t)nw);
     ctx->fs_regions_all.clear();
+    ctx->fs_keep_xoff.clear();
     if (ctx->fs_want_regions && nw <= (int64_t)ctx->prop.multiProcessorCount * 16) {
       // The domain stage follows: its Backward parser, domain decoding and region heuristics run here, for every window,
       // next to the Forward parser whose score decides the branch.  These kernels are bound by the row chain of the longest

@@ -223,3 +223,37 @@ def test_fs5_envelopes(setup, c5_compat, mode, request):
         assert np.allclose(got["null2"][i], r[3], rtol=2e-3 if strict else 5e-3, atol=1e-4)        # null2_fs.c:193 uses 0.001..0.2; its log-sums run over column sums whose last bits differ (expf), so a table index may flip
     if not c5_compat:
         assert close(got["fwdsc"], got["bcksc"], 1e-4, 2e-2)                   # Forward == Backward
+
+
+def test_fs5_multihit_forward_strict_is_bit_identical(setup):
+    """p7_Forward_Frameshift in the MULTIHIT configuration of the model's saved length -- what p7_domaindef.c:411-414 runs on a
+    multi-domain region before the stochastic tracebacks -- with strict log-sums: score, the whole matrix (8 cells per node) and
+    the special-state rows must be the oracle's bit for bit, so that both sides draw the same samples."""
+    ctx, model, om3, om5, wins, blk = setup
+    env = [w for w in wins if len(w) >= 15]
+    eb = ba.SeqBlock(ctx, env)
+    M = model.M
+    foff = np.zeros(len(env) + 1, np.int64); np.cumsum([(len(w) + 1) * (M + 1) * 8 for w in env], out=foff[1:])
+    xoff = np.zeros(len(env) + 1, np.int64); np.cumsum([(len(w) + 1) * 5 for w in env], out=xoff[1:])
+    sc = np.zeros(len(env), np.float32); fwd = np.zeros(int(foff[-1]), np.float32); xmx = np.zeros(int(xoff[-1]), np.float32)
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+    ctx.set_fs_strict(True)
+    try:
+        ctx._check(ba.lib().bath_hip_fs5_forward_full(ctx._h, om5._h, eb._h, 100, fp(sc), fp(fwd), fp(xmx)), "fs5_forward_full")
+    finally:
+        ctx.set_fs_strict(False)
+    L_ = ol.lib()
+    gm5 = model.fs(5)
+    L_.bo_fs_profile_reconfig_multihit(gm5, 100)
+    f = C.c_float()
+    for e, w in enumerate(env):
+        L = len(w)
+        g8 = L_.bo_gmx_create(M, L + 1, L, 8)
+        assert L_.bo_gforward_fs(ol.u8(ol.dsq_from(w)), L, gm5, g8, 0, C.byref(f)) == 0
+        dp = np.ctypeslib.as_array(g8.contents.dp, shape=(L + 1, M + 1, 8)).copy()
+        ox = np.ctypeslib.as_array(g8.contents.xmx, shape=(L + 1, 5)).copy()
+        L_.bo_gmx_free(g8)
+        assert identical(np.float32(sc[e]), np.float32(f.value)), (e, sc[e], f.value)
+        assert identical(xmx[xoff[e]:xoff[e + 1]].reshape(L + 1, 5), ox), e
+        got = fwd[foff[e]:foff[e + 1]].reshape(L + 1, M + 1, 8)
+        assert identical(got[1:, 1:, :], dp[1:, 1:, :]), e
