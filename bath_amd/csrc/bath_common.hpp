@@ -133,6 +133,7 @@ struct bath_hip_ctx {
   // worker lanes: contexts with their own stream and scratch, used by the pipeline to run parts of a block concurrently
   std::vector<bath_hip_ctx *> lanes;
   bath_hip_ctx *aux = nullptr;   // a context of its own (stream, scratch) for the standard-branch domains that run beside the frameshift branch
+  bath_hip_ctx *aux2 = nullptr;  // ... and one for the multi-domain regions' Forward, which runs beside the first batch of envelopes (strict mode)
 };
 
 // Device view of a sequence block.

@@ -208,68 +208,6 @@ static int fs_branch_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, con
   }
   if (n_skipped_regions) *n_skipped_regions = (int64_t)mregs.size();          // regions resolved by clustering (ddef->nclustered)
 
-  // ---- multi-domain regions (p7_domaindef.c:396-455): Forward of the region in the multihit configuration (GPU), ensemble of
-  // stochastic tracebacks and clustering (host, bath_ensemble.hip); every cluster is an envelope
-  std::vector<std::vector<Env>> found;                                       // written by the ensemble threads: declared BEFORE the joiner, so it outlives the join on every return
-  std::thread ensembles;
-  Joiner joiner{ensembles};                                                  // also on error returns
-  if (!mregs.empty()) {
-    std::vector<FsWinDev> rregs(mregs.size());
-    for (size_t e = 0; e < mregs.size(); e++) {
-      FsWinDev d = regs[(size_t)mregs[e].sel];
-      d.start = regs[(size_t)mregs[e].sel].start + mregs[e].i - 1; d.len = mregs[e].j - mregs[e].i + 1;
-      rregs[e] = d;
-    }
-    const float *h_f = nullptr, *h_x = nullptr;                              // pinned buffers of the context
-    const int *h_done = nullptr;
-    const float *h_sc_live = nullptr;
-    std::vector<float> h_sc;
-    std::vector<int64_t> foff, xoff;
-    {
-      bath_hip_seqs view;
-      if ((st = fs_gather_view(ctx, dna, rregs, tt.comp, &view, nullptr)) != BATH_OK) return st;
-      // returns after the launch: a region's ensemble starts as soon as ITS matrix has landed in host memory (h_done[e]), so the
-      // tracebacks run while the kernel is still streaming the other regions over PCIe (longest regions first, on both sides)
-      st = fs5_region_forward(ctx, om_fs5, &view, 100, &h_f, &foff, &h_x, &xoff, &h_sc, &h_done, &h_sc_live);      // saveL: the configuration bathsearch starts with
-      view.d_data = nullptr; view.d_off = nullptr; view.d_len = nullptr;
-      if (st != BATH_OK) return st;
-    }
-    const float pm = (2.0f + 1.0f) / (100.0f + 2.0f + 1.0f);                 // p7_fs_ReconfigLength(L = 100), multihit (nj = 1)
-    const float xNL = (float)std::log((double)(1.0f - pm)), xNM = (float)std::log((double)pm), xE = (float)-kLn2;
-    found.assign(mregs.size(), {});
-    // The ensembles are host work (200 dependent tracebacks per region from one random-number stream); the envelopes of the
-    // single-domain regions do not depend on them, so their kernels run on the GPU meanwhile.
-    { const char *lv = std::getenv("BATH_HIP_FS_LIVE"); if (lv && lv[0] == '0') (void)hipStreamSynchronize(ctx->stream); }
-    ensembles = std::thread([&, h_f, h_x, xNL, xNM, xE, foff, xoff, h_done, h_sc_live, rregs] {
-      auto work = [&](int64_t first, int64_t step) {
-        std::vector<std::pair<int, int>> cl;
-        for (size_t e = (size_t)first; e < mregs.size(); e += (size_t)step) {
-          while (!__atomic_load_n(h_done + e, __ATOMIC_ACQUIRE)) std::this_thread::yield();      // this region's matrix is still on its way
-          if (!(h_sc_live[e] > -INFINITY)) continue;                          // Forward underflow: no valid traces for this region (:413)
-          const int Lr = rregs[e].len;
-          if (fs_region_trace_ensemble(h5.M, h5.tsc, xNL, xNM, xE, mregs[e].i, Lr, h_f + foff[e], h_x + xoff[e], &cl) != BATH_OK) continue;
-          for (const auto &c : cl) {
-            const int i2 = std::max(1, c.first), j2 = c.second;               // :449
-            if (j2 - i2 + 1 >= 15) found[e].push_back(Env{mregs[e].sel, i2, j2});
-          }
-        }
-      };
-      StageClock eclk;
-      // shortest region first: that is the order in which their matrices finish arriving (all regions advance together, a wave
-      // each, sharing the PCIe link), so a thread rarely waits for the region it drew
-      run_striped((int64_t)mregs.size(), work, [&](int64_t e) { return -rregs[(size_t)e].len; });
-      eclk.lap("fs:   (ensemble threads, start to end)");
-    });
-    if (hipStreamSynchronize(ctx->stream) != hipSuccess) {                    // the region Forward itself (the ensembles are already at work)
-      for (size_t e = 0; e < mregs.size(); e++) {                             // release the threads waiting for matrices that will not come
-        const_cast<float *>(h_sc_live)[e] = -INFINITY;
-        __atomic_store_n(const_cast<int *>(h_done) + e, 1, __ATOMIC_RELEASE);
-      }
-      ctx->set_error("region Forward failed"); return BATH_EFAIL;
-    }
-    clk.lap("fs: region Forward -> host memory");
-  }
-
   // ---- envelopes: Forward, Backward, decoding, optimal accuracy, null2 on the GPU (unihit, length Ld/3)
   std::vector<FsWinDev> eregs;
   std::vector<bath_fs5_result> res;
@@ -318,16 +256,99 @@ static int fs_branch_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, con
     step_off[(size_t)e_end] = (int64_t)steps.size();
     return BATH_OK;
   };
+  const int n_single = (int)envs.size();
+  const int n_single_early = n_single;
+  int done = 0;
+
+  // ---- multi-domain regions (p7_domaindef.c:396-455): Forward of the region in the multihit configuration (GPU), ensemble of
+  // stochastic tracebacks and clustering (host, bath_ensemble.hip); every cluster is an envelope
+  std::vector<std::vector<Env>> found;                                       // written by the ensemble threads: declared BEFORE the joiner, so it outlives the join on every return
+  bath_hip_ctx *rctx = ctx;                                                  // where the regions' Forward runs
+  std::thread ensembles;
+  Joiner joiner{ensembles};                                                  // also on error returns
+  if (!mregs.empty()) {
+    std::vector<FsWinDev> rregs(mregs.size());
+    for (size_t e = 0; e < mregs.size(); e++) {
+      FsWinDev d = regs[(size_t)mregs[e].sel];
+      d.start = regs[(size_t)mregs[e].sel].start + mregs[e].i - 1; d.len = mregs[e].j - mregs[e].i + 1;
+      rregs[e] = d;
+    }
+    const float *h_f = nullptr, *h_x = nullptr;                              // pinned buffers of the context
+    const int *h_done = nullptr;
+    const float *h_sc_live = nullptr;
+    std::vector<float> h_sc;
+    std::vector<int64_t> foff, xoff;
+    {
+      // Strict mode: the regions' Forward is a chain of L x 2M dependent log-sums per region on a few CUs (bath_fs_chain.hip) and
+      // the envelope kernels are bound by throughput (bath_fs_wavefront.hip), so the envelopes of the single-domain regions go
+      // through the chip WHILE the regions' Forward runs: it gets a context of its own (stream, gather pool, offsets, job list).
+      if (ctx->fs_strict && !ctx->aux2) {
+        if ((st = bath_hip_init(ctx->device, &ctx->aux2)) != BATH_OK) { ctx->set_error("cannot create the context of the regions' Forward"); return st; }
+      }
+      rctx = ctx->fs_strict ? ctx->aux2 : ctx;
+      if (rctx != ctx) { rctx->fs_strict = ctx->fs_strict; rctx->spans_reset(); }
+      bath_hip_seqs view;
+      if ((st = fs_gather_view(rctx, dna, rregs, tt.comp, &view, nullptr)) != BATH_OK) { if (rctx != ctx) ctx->set_error(rctx->err); return st; }
+      // returns after the launch: a region's ensemble starts as soon as ITS matrix has landed in host memory (h_done[e]), so the
+      // tracebacks run while the kernel is still streaming the other regions over PCIe (longest regions first, on both sides)
+      st = fs5_region_forward(rctx, om_fs5, &view, 100, &h_f, &foff, &h_x, &xoff, &h_sc, &h_done, &h_sc_live);      // saveL: the configuration bathsearch starts with
+      view.d_data = nullptr; view.d_off = nullptr; view.d_len = nullptr;
+      if (st != BATH_OK) { if (rctx != ctx) ctx->set_error(rctx->err); return st; }
+    }
+    const float pm = (2.0f + 1.0f) / (100.0f + 2.0f + 1.0f);                 // p7_fs_ReconfigLength(L = 100), multihit (nj = 1)
+    const float xNL = (float)std::log((double)(1.0f - pm)), xNM = (float)std::log((double)pm), xE = (float)-kLn2;
+    found.assign(mregs.size(), {});
+    // The ensembles are host work (200 dependent tracebacks per region from one random-number stream); the envelopes of the
+    // single-domain regions do not depend on them, so their kernels run on the GPU meanwhile.
+    { const char *lv = std::getenv("BATH_HIP_FS_LIVE"); if (lv && lv[0] == '0') (void)hipStreamSynchronize(rctx->stream); }
+    ensembles = std::thread([&, h_f, h_x, xNL, xNM, xE, foff, xoff, h_done, h_sc_live, rregs] {
+      auto work = [&](int64_t first, int64_t step) {
+        std::vector<std::pair<int, int>> cl;
+        for (size_t e = (size_t)first; e < mregs.size(); e += (size_t)step) {
+          while (!__atomic_load_n(h_done + e, __ATOMIC_ACQUIRE)) std::this_thread::yield();      // this region's matrix is still on its way
+          if (!(h_sc_live[e] > -INFINITY)) continue;                          // Forward underflow: no valid traces for this region (:413)
+          const int Lr = rregs[e].len;
+          if (fs_region_trace_ensemble(h5.M, h5.tsc, xNL, xNM, xE, mregs[e].i, Lr, h_f + foff[e], h_x + xoff[e], &cl) != BATH_OK) continue;
+          for (const auto &c : cl) {
+            const int i2 = std::max(1, c.first), j2 = c.second;               // :449
+            if (j2 - i2 + 1 >= 15) found[e].push_back(Env{mregs[e].sel, i2, j2});
+          }
+        }
+      };
+      StageClock eclk;
+      // shortest region first: that is the order in which their matrices finish arriving (all regions advance together, a wave
+      // each, sharing the PCIe link), so a thread rarely waits for the region it drew
+      run_striped((int64_t)mregs.size(), work, [&](int64_t e) { return -rregs[(size_t)e].len; });
+      eclk.lap("fs:   (ensemble threads, start to end)");
+    });
+    // strict mode: the first batch of envelopes goes through now, beside the regions' Forward (which runs on its own context)
+    if (rctx != ctx && n_single_early > 0) {
+      if ((st = run_envelopes(0, n_single_early)) != BATH_OK) {
+        (void)hipStreamSynchronize(rctx->stream);
+        for (size_t e = 0; e < mregs.size(); e++) { const_cast<float *>(h_sc_live)[e] = -INFINITY; __atomic_store_n(const_cast<int *>(h_done) + e, 1, __ATOMIC_RELEASE); }
+        return st;
+      }
+      done = n_single_early;
+      clk.lap("fs: envelope kernels + traces (single-domain regions, beside the regions' Forward)");
+    }
+    if (hipStreamSynchronize(rctx->stream) != hipSuccess) {                   // the region Forward itself (the ensembles are already at work)
+      for (size_t e = 0; e < mregs.size(); e++) {                             // release the threads waiting for matrices that will not come
+        const_cast<float *>(h_sc_live)[e] = -INFINITY;
+        __atomic_store_n(const_cast<int *>(h_done) + e, 1, __ATOMIC_RELEASE);
+      }
+      ctx->set_error("region Forward failed"); return BATH_EFAIL;
+    }
+    clk.lap("fs: region Forward -> host memory");
+  }
+
   // Order of the work.  The ensembles are host threads; the standard branch of the other windows (p7_pipeline.c:1479-1510)
   // needs nothing from them, so its kernels and host work run meanwhile.  Then ALL envelopes -- of the single-domain regions
   // and of the clusters -- go through the envelope kernels as one batch: those kernels last as long as their longest
   // envelope whatever the number of envelopes (one wave each), so two batches cost two such chains (14.3 + 9.4 ms on the
   // bench block) and one batch costs one.  BATH_HIP_FS_TWO_BATCHES=1: the single-domain regions first, during the ensembles.
-  const int n_single = (int)envs.size();
   const char *tb = std::getenv("BATH_HIP_FS_TWO_BATCHES");
   const bool two_batches = tb && tb[0] == '1';
-  int done = 0;
-  if (ensembles.joinable() && two_batches && n_single > 0) {
+  if (ensembles.joinable() && two_batches && n_single > 0 && done == 0) {
     if ((st = run_envelopes(0, n_single)) != BATH_OK) return st;
     done = n_single;
     clk.lap("fs: envelope kernels + traces (single-domain regions)");

@@ -901,11 +901,32 @@ __global__ __launch_bounds__(256, (C <= 3 ? BATH_FS_OA_WAVES : 1)) void fs5_deco
 #pragma unroll
         for (int q = 0; q < 7; q++) csum[c][q] = 0.f;
     }
+    // Row i+1's Forward and Backward cells and special states are fetched while row i is worked on: a row's trip to HBM then
+    // overlaps the previous row's chain (exp, the row sum, the optimal-accuracy scan) instead of heading this one's
+    float4 fa_n[C], fb_n[C]; float bm_n[C], bi_n[C];
+    float xn1 = 0.f, xn2 = 0.f, xn4 = 0.f, yn1 = 0.f, yn2 = 0.f, yn4 = 0.f;
+    auto fetch_row = [&](int r) {
+      const float *fq = F + (size_t)r * (M + 1) * 8;
+      const float *bq = Bk + (size_t)r * (M + 1) * 3;
+#pragma unroll
+      for (int c = 0; c < C; c++) {
+        const int node = imin(lane * C + c + 1, M);
+        fa_n[c] = *reinterpret_cast<const float4 *>(fq + (size_t)node * 8);
+        fb_n[c] = *reinterpret_cast<const float4 *>(fq + (size_t)node * 8 + 4);
+        bm_n[c] = bq[(size_t)node * 3 + 2]; bi_n[c] = bq[(size_t)node * 3 + 1];
+      }
+      xn1 = X[r * 5 + 1]; xn2 = X[r * 5 + 2]; xn4 = X[r * 5 + 4]; yn1 = Y[r * 5 + 1]; yn2 = Y[r * 5 + 2]; yn4 = Y[r * 5 + 4];
+    };
+    fetch_row(1);
     for (int i = 1; i <= L; i++) {
       N3 = N2; N2 = N1; N1 = N0; J3 = J2; J2 = J1; J1 = J0; C3 = C2; C2 = C1; C1 = C0;
       float *fr = F + (size_t)i * (M + 1) * 8;
-      const float *br = Bk + (size_t)i * (M + 1) * 3;
       float *orow = O + (size_t)i * (M + 1) * 3;
+      float4 fa[C], fb[C]; float bmv[C], biv[C];
+#pragma unroll
+      for (int c = 0; c < C; c++) { fa[c] = fa_n[c]; fb[c] = fb_n[c]; bmv[c] = bm_n[c]; biv[c] = bi_n[c]; }
+      const float x1 = xn1, x2 = xn2, x4 = xn4, y1 = yn1, y2 = yn2, y4 = yn4;
+      if (i < L) fetch_row(i + 1);
       // ---- decoding of row i (generic_decoding_frameshift.c:62-150): exp(F + B - overall), then the row normalised to sum 1
       float pI[C], pC[C][6];
       float dloc = 0.f;
@@ -913,9 +934,9 @@ __global__ __launch_bounds__(256, (C <= 3 ? BATH_FS_OA_WAVES : 1)) void fs5_deco
       for (int c = 0; c < C; c++) {
         const int node = lane * C + c + 1;
         if (node <= M) {
-          const float4 a = *reinterpret_cast<const float4 *>(fr + (size_t)node * 8);
-          const float4 b = *reinterpret_cast<const float4 *>(fr + (size_t)node * 8 + 4);
-          const float bm = br[(size_t)node * 3 + 2], bi = br[(size_t)node * 3 + 1];
+          const float4 a = fa[c];
+          const float4 b = fb[c];
+          const float bm = bmv[c], bi = biv[c];
           pC[c][0] = expf(a.z + bm - overall); pC[c][1] = expf(a.w + bm - overall);
           pC[c][2] = expf(b.x + bm - overall); pC[c][3] = expf(b.y + bm - overall); pC[c][4] = expf(b.z + bm - overall); pC[c][5] = expf(b.w + bm - overall);
           dloc += pC[c][0];
@@ -926,13 +947,13 @@ __global__ __launch_bounds__(256, (C <= 3 ? BATH_FS_OA_WAVES : 1)) void fs5_deco
           for (int q = 0; q < 6; q++) pC[c][q] = 0.f;
         }
       }
-      N0 = X[i * 5 + 1]; J0 = X[i * 5 + 2]; C0 = X[i * 5 + 4];
+      N0 = x1; J0 = x2; C0 = x4;
       float pn, pc, pj;
       if (i > 2) {
-        pn = expf(N3 + Y[i * 5 + 1] + tL - overall);
-        pc = expf(C3 + Y[i * 5 + 4] + tL - overall);
-        pj = expf(J3 + Y[i * 5 + 2] + tL - overall);
-      } else { pn = expf(Y[i * 5 + 1] - overall); pc = 0.f; pj = 0.f; }
+        pn = expf(N3 + y1 + tL - overall);
+        pc = expf(C3 + y4 + tL - overall);
+        pj = expf(J3 + y2 + tL - overall);
+      } else { pn = expf(y1 - overall); pc = 0.f; pj = 0.f; }
       float denom = wave_sum_f32(dloc) + ((i > 2) ? (pn + pj + pc) : pn);
       denom = (float)(1.0 / (double)denom);
       pn *= denom; pc *= denom; pj *= denom;

@@ -28,6 +28,11 @@ constexpr int kChainMaxWaves = 16;
 // budget per wave grows with C while LDS (two staged rows per window) limits the windows per block anyway
 constexpr int chain_threads(int C) { return C <= 3 ? 1024 : (C <= 8 ? 512 : 256); }
 
+// The waves of a block exchange rows through LDS only.  __syncthreads() is also a fence for GLOBAL memory: it would make every
+// wave wait, twice per row, until its stores of that row (special-state rows; the regions' matrices, which go to page-locked
+// host memory over PCIe) have been acknowledged.  This barrier waits for the LDS operations alone.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // staged rows: [wave][row of the pair][stride]; stride odd, so that the chain lanes (one row each) read different banks
 __host__ __device__ inline int fs_chain_stride(int C) { return C * 64 + 1; }
 
@@ -116,7 +121,7 @@ __global__ __launch_bounds__(chain_threads(C)) void fs3_fwd_chain_kernel(SeqView
         IB[c] = (node < M) ? insB : -INFINITY;
         if (in) { s_stage[((size_t)wv * 2 + 0) * stride + node] = mv; s_stage[((size_t)wv * 2 + 1) * stride + node] = mw; }
       }
-      __syncthreads();
+      lds_barrier();
       // ---- 2. the serial part, a lane per row: D(i,k) = LS(M(i,k-1) + tMD, D(i,k-1) + tDD), E(i) = LS(M(i,k), LS(D(i,k), E)) (:577-590)
       if (wv == 0 && lane < 2 * W) {
         float *st = s_stage + (size_t)lane * stride;
@@ -135,7 +140,7 @@ __global__ __launch_bounds__(chain_threads(C)) void fs3_fwd_chain_kernel(SeqView
         }
         s_e[lane] = ech;
       }
-      __syncthreads();
+      lds_barrier();
       // ---- 3. D and E back to the window's wave; special states of both rows (:592-603)
       float DA[C], DB[C];
 #pragma unroll
@@ -255,7 +260,7 @@ __global__ __launch_bounds__(chain_threads(C)) void fs3_bwd_chain_kernel(SeqView
         ivA[c] = in ? a : -INFINITY; ivB[c] = in ? b : -INFINITY;
         if (in) { s_stage[((size_t)wv * 2 + 0) * stride + node] = ivA[c]; s_stage[((size_t)wv * 2 + 1) * stride + node] = ivB[c]; }
       }
-      __syncthreads();
+      lds_barrier();
       // ---- 2. the serial part
       if (chain_lane) {
         float *st = s_stage + (size_t)lane * stride;
@@ -307,7 +312,7 @@ __global__ __launch_bounds__(chain_threads(C)) void fs3_bwd_chain_kernel(SeqView
         }
         hN2 = hN1; hN1 = xN; hJ2 = hJ1; hJ1 = xJ; hC2 = hC1; hC1 = xC;
       }
-      __syncthreads();
+      lds_barrier();
       // ---- 3. the cells of both rows (:1574-1600)
       const float EA = s_e[wv * 2 + 0], EB = s_e[wv * 2 + 1];
       const float ivNextA = wave_shr1(ivA[0], -INFINITY), ivNextB = wave_shr1(ivB[0], -INFINITY);
@@ -438,7 +443,7 @@ __global__ __launch_bounds__(chain_threads(C)) void fs5_fwd_chain_kernel(SeqView
           }
         }
       }
-      __syncthreads();
+      lds_barrier();
       // ---- the serial part, a lane per window: D(i,k), E(i) in the reference's order; rows >= 5 pair M(i,M) and D(i,M) first (:392-394)
       if (wv == 0 && lane < W) {
         float *st = s_stage + (size_t)lane * 2 * stride;
@@ -458,7 +463,7 @@ __global__ __launch_bounds__(chain_threads(C)) void fs5_fwd_chain_kernel(SeqView
         ech = (i >= 5) ? LS(LS(Mn, dch), ech) : LS(Mn, LS(dch, ech));
         s_e[lane] = ech;
       }
-      __syncthreads();
+      lds_barrier();
       float Dc[C];
 #pragma unroll
       for (int c = 0; c < C; c++) {

@@ -25,7 +25,10 @@
 
 namespace bath {
 
-constexpr int kWfBlock = 1024;                 // one block per CU: 16 waves share one 64 KB log-sum table
+#ifndef BATH_WF_BLOCK
+#define BATH_WF_BLOCK 1024
+#endif
+constexpr int kWfBlock = BATH_WF_BLOCK;        // 1024: one block per CU, 16 waves share one 64 KB log-sum table
 constexpr int kWfWaves = kWfBlock / 64;
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -383,10 +386,12 @@ int launch_fs5_fwd_wf(bath_hip_ctx *ctx, hipStream_t stream, const bath_hip_fspr
   const int M = om->M;
   const int64_t n = dna->n;
   static const int dbg = [] { const char *e = std::getenv("BATH_HIP_WF_DBG"); return e ? std::atoi(e) : 0; }();
-  const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((n + kWfWaves - 1) / kWfWaves, (int64_t)ctx->prop.multiProcessorCount));
+  const int grid_cap = ctx->prop.multiProcessorCount * ((kWfBlock <= 512) ? 2 : 1);      // 512-thread blocks with the ring in global memory fit a CU twice
+  const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((n + kWfWaves - 1) / kWfWaves, (int64_t)grid_cap));
   const size_t base = (size_t)(kLogsumTbl + (M + 2) * 8) * sizeof(float);
   const size_t ring_b = fs_wf_ring_floats(M) * sizeof(float) * kWfWaves;
-  const bool lds_ring = base + ring_b <= (size_t)ctx->prop.sharedMemPerBlock && base + ring_b <= 160 * 1024;
+  static const bool ring_global = [] { const char *e = std::getenv("BATH_HIP_WF_RING_G"); return e && e[0] == '1'; }();
+  const bool lds_ring = !ring_global && base + ring_b <= 160 * 1024;
   float *ring_g = nullptr;
   if (!lds_ring) {
     BATH_HIP_TRY(ctx, ring_scratch.reserve(ring_b * (size_t)grid + 64));
@@ -421,10 +426,12 @@ int launch_fs5_bwd_wf(bath_hip_ctx *ctx, hipStream_t stream, const bath_hip_fspr
   BATH_HIP_TRY(ctx, toff_scratch.reserve((size_t)(n + 1) * sizeof(int64_t)));
   BATH_HIP_TRY(ctx, hipMemcpyAsync(toff_scratch.p, toff.data(), (size_t)(n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, stream));
   BATH_HIP_TRY(ctx, hipStreamSynchronize(stream));                    // <toff> is a local
-  const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((n + kWfWaves - 1) / kWfWaves, (int64_t)ctx->prop.multiProcessorCount));
+  const int grid_cap = ctx->prop.multiProcessorCount * ((kWfBlock <= 512) ? 2 : 1);      // 512-thread blocks with the ring in global memory fit a CU twice
+  const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((n + kWfWaves - 1) / kWfWaves, (int64_t)grid_cap));
   const size_t base = (size_t)(kLogsumTbl + (M + 2) * 8) * sizeof(float);
   const size_t ring_b = fs_wf_ring_floats(M) * sizeof(float) * kWfWaves;
-  const bool lds_ring = base + ring_b <= 160 * 1024;
+  static const bool ring_global = [] { const char *e = std::getenv("BATH_HIP_WF_RING_G"); return e && e[0] == '1'; }();
+  const bool lds_ring = !ring_global && base + ring_b <= 160 * 1024;
   float *ring_g = nullptr;
   if (!lds_ring) {
     BATH_HIP_TRY(ctx, ring_scratch.reserve(ring_b * (size_t)grid + 64));

@@ -128,6 +128,7 @@ extern "C" void bath_hip_finalize(bath_hip_ctx *ctx) {
   for (bath_hip_ctx *lane : ctx->lanes) bath_hip_finalize(lane);
   ctx->lanes.clear();
   if (ctx->aux) { bath_hip_finalize(ctx->aux); ctx->aux = nullptr; }
+  if (ctx->aux2) { bath_hip_finalize(ctx->aux2); ctx->aux2 = nullptr; }
   for (auto &b : ctx->scratch) b.release();
   for (auto &b : ctx->pinned) b.release();
   ctx->results_pinned.release();
@@ -152,13 +153,16 @@ extern "C" void *bath_hip_stream(bath_hip_ctx *ctx) { return (void *)ctx->stream
 extern "C" int bath_hip_kernel_times(bath_hip_ctx *ctx, int max, bath_kernel_time *out) {
   if (!ctx || !out) return 0;
   int n = 0;
-  for (const bath::KernelSpan &k : ctx->spans) {
-    float ms = 0.f;
-    if (hipEventSynchronize(k.b) != hipSuccess || hipEventElapsedTime(&ms, k.a, k.b) != hipSuccess) continue;
-    int i = 0;
-    while (i < n && out[i].name != k.name) i++;
-    if (i == n) { if (n == max) continue; out[n++] = bath_kernel_time{k.name, 0.f, 0, 0.0, 0.0}; }
-    out[i].ms += ms; out[i].launches++; out[i].cells += k.cells; out[i].bytes += k.bytes;
+  for (const bath_hip_ctx *c : {(const bath_hip_ctx *)ctx, (const bath_hip_ctx *)ctx->aux2}) {     // the regions' Forward runs on a context of its own
+    if (!c) continue;
+    for (const bath::KernelSpan &k : c->spans) {
+      float ms = 0.f;
+      if (hipEventSynchronize(k.b) != hipSuccess || hipEventElapsedTime(&ms, k.a, k.b) != hipSuccess) continue;
+      int i = 0;
+      while (i < n && out[i].name != k.name) i++;
+      if (i == n) { if (n == max) continue; out[n++] = bath_kernel_time{k.name, 0.f, 0, 0.0, 0.0}; }
+      out[i].ms += ms; out[i].launches++; out[i].cells += k.cells; out[i].bytes += k.bytes;
+    }
   }
   return n;
 }
