@@ -26,7 +26,7 @@ LIB_PATH = os.environ.get("BATH_HIP_LIBRARY") or os.path.join(_HERE, "libbathhip
 
 OK, ERANGE, ENORESULT = 0, 16, 19
 KP, K, NEVPARAM = 29, 20, 8
-LOGSUM_TABLE, LOGSUM_EXACT, LOGSUM_TABLE_SERIAL = 0, 1, 2
+LOGSUM_TABLE, LOGSUM_EXACT, LOGSUM_TABLE_SERIAL, LOGSUM_CONTEXT = 0, 1, 2, 3
 
 DNA_SYMS = "ACGT-RYMKSWHBVDN*~"
 AMINO_SYMS = "ACDEFGHIKLMNPQRSTVWY-BJZOUX*~"
@@ -366,7 +366,8 @@ class Context:
         self._check(lib().bath_hip_synchronize(self._h), "synchronize")
 
     def set_fs_strict(self, on=True):
-        """Frameshift log-sums along the model in the reference's serial order (bit-identical to the generic reference)."""
+        """True (the library's default): frameshift log-sums along the model in the reference's serial order, bit-identical to the
+        generic reference.  False: the fast mode (wavefront scans, scores within O(1e-3) nats)."""
         self._check(lib().bath_hip_set_fs_strict(self._h, 1 if on else 0), "set_fs_strict")
 
     @property

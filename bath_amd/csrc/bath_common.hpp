@@ -91,7 +91,7 @@ struct bath_hip_ctx {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   hipStream_t copy_stream = nullptr;    // created on first use: host -> device uploads of packed blocks (bath_hip_seqs_upload_packed)
   hipDeviceProp_t prop{};
-  int fs_strict = 0;                    // bath_hip_set_fs_strict: frameshift log-sums along the model in the reference's serial order
+  int fs_strict = 1;                    // frameshift log-sums along the model in the reference's serial order (bit-identical); bath_hip_set_fs_strict(ctx, 0): wavefront scans
   std::string err;
   void set_error(const std::string &m) { err = m; }
   // scratch owned by the context (reused across calls)

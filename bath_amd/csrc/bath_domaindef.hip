@@ -245,7 +245,7 @@ static int fs_branch_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, con
       bath_hip_seqs view;
       int st2 = fs_gather_view(ctx, dna, chunk, tt.comp, &view, nullptr);
       if (st2 != BATH_OK) return st2;
-      st2 = fs5_envelopes_ex(ctx, om_fs5, &view, BATH_LOGSUM_TABLE, 0, res.data() + e0, nullptr, nullptr, nullptr, nullptr, traces.data() + e0, om->d_cons, &csteps, &coff);
+      st2 = fs5_envelopes_ex(ctx, om_fs5, &view, BATH_LOGSUM_CONTEXT, 0, res.data() + e0, nullptr, nullptr, nullptr, nullptr, traces.data() + e0, om->d_cons, &csteps, &coff);
       view.d_data = nullptr; view.d_off = nullptr; view.d_len = nullptr;
       if (st2 != BATH_OK) return st2;
       const int64_t base = (int64_t)steps.size();

@@ -1476,6 +1476,7 @@ static int fs3_parser(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, const bat
                       const int64_t *xmx_off, bool backward, DevBuf *keep = nullptr /* the rows stay in this device buffer instead of going to <xmx> */) {
   if (!ctx || !om || !dna || om->codon_lengths != 3) { if (ctx) ctx->set_error("fs3 parser needs a 3-codon profile"); return BATH_EINVAL; }
   BATH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (logsum_mode == BATH_LOGSUM_CONTEXT) logsum_mode = ctx->fs_strict ? BATH_LOGSUM_TABLE_SERIAL : BATH_LOGSUM_TABLE;
   const int64_t n = dna->n;
   if (n == 0) return BATH_OK;
   int st = om->ensure_len(dna->maxlen / 3 + 1);
@@ -1792,7 +1793,7 @@ int bath::fs5_envelopes_ex(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, cons
   [[maybe_unused]] const int grid = fs_grid(ctx, n);
   const int grid_dp = fs_grid_dp(ctx, n);
   const float tEL = -INFINITY, tEM = 0.0f;                                      // unihit: p7_fs_ReconfigUnihit, modelconfig.c:868
-  if (logsum_mode == BATH_LOGSUM_TABLE && ctx->fs_strict) logsum_mode = BATH_LOGSUM_TABLE_SERIAL;
+  if (logsum_mode == BATH_LOGSUM_CONTEXT) logsum_mode = ctx->fs_strict ? BATH_LOGSUM_TABLE_SERIAL : BATH_LOGSUM_TABLE;
   const double cells5 = (double)(foff[(size_t)n] / 8);                          // (L+1) x (M+1) cells of all envelopes
   FsJobs jq[4];
   if ((st = fs_schedule(ctx, dna, 4, jq)) != BATH_OK) return st;

@@ -234,7 +234,7 @@ static int ih_fs3(int backward, const ESL_DSQ *dsq, int L, const P7_FS_OPROFILE 
   float *x5 = malloc(sizeof(float) * (size_t)(L + 1) * 5);
   if (!x5) return eslEMEM;
   if (ih_block(dsq, L, &sq) != eslOK) { free(x5); return eslFAIL; }
-  const int st = (backward ? bath_hip_fs3_backward_parser : bath_hip_fs3_forward_parser)(impl_hip_context(), om_fs->dev, sq, BATH_LOGSUM_TABLE, &sc, x5, xoff);
+  const int st = (backward ? bath_hip_fs3_backward_parser : bath_hip_fs3_forward_parser)(impl_hip_context(), om_fs->dev, sq, BATH_LOGSUM_CONTEXT, &sc, x5, xoff);
   bath_hip_seqs_destroy(sq);
   if (st != BATH_OK) { free(x5); ESL_EXCEPTION(eslFAIL, "impl_hip: %s", bath_hip_last_error(impl_hip_context())); }
   for (int i = 0; i <= L; i++) {                    /* {E,N,J,B,C} -> the six-cell rows of P7_OMX */
@@ -549,7 +549,7 @@ int p7_Forward_Frameshift(const ESL_DSQ *dsq, int L, const P7_FS_OPROFILE *om_fs
     p->pp = malloc(sizeof(float) * ncell * 8); p->oa = malloc(sizeof(float) * ncell * 3);
     p->ppx = malloc(sizeof(float) * rows * 5); p->oax = malloc(sizeof(float) * rows * 5);
     if (!p->pp || !p->oa || !p->ppx || !p->oax) { bath_hip_seqs_destroy(sq); impl_hip_pass_release(p); return eslEMEM; }
-    st = bath_hip_fs5_envelopes_x(impl_hip_context(), om_fs->dev, sq, BATH_LOGSUM_TABLE, 0, &r, p->pp, p->oa, p->ppx, p->oax);
+    st = bath_hip_fs5_envelopes_x(impl_hip_context(), om_fs->dev, sq, BATH_LOGSUM_CONTEXT, 0, &r, p->pp, p->oa, p->ppx, p->oax);
     if (st == BATH_OK) { p->fwdsc = r.fwdsc; p->bcksc = r.bcksc; p->oasc = r.oasc; p->ok = 1; memcpy(p->null2, r.null2, sizeof(float) * IH_KP); }
   } else {                                          /* multihit region in the configuration of amino length om_fs->L (:411-414) */
     p->fwd = malloc(sizeof(float) * ncell * 8); p->fx = malloc(sizeof(float) * rows * 5);

@@ -107,10 +107,11 @@ void        bath_hip_finalize(bath_hip_ctx *ctx);
 const char *bath_hip_last_error(const bath_hip_ctx *ctx);
 int         bath_hip_synchronize(bath_hip_ctx *ctx);
 void       *bath_hip_stream(bath_hip_ctx *ctx);                      /* hipStream_t, for event timing */
-/* Frameshift recursions: 0 (default) sums D(i,k) and E(i) along the model with wavefront scans -- the same table log-sums as
- * the reference in a different association, scores within O(1e-3) nats; 1 = the reference's serial order
- * (generic_fwdback_frameshift.c:340-365), bit-identical to the generic reference, several times slower.  Applies to the
- * pipeline entry points; the batched kernels take it as logsum_mode = BATH_LOGSUM_TABLE_SERIAL. */
+/* Frameshift recursions.  1 (the default): every sum along the model -- D(i,k), E(i), Backward's B(i) -- runs node by node in the
+ * reference's order (generic_fwdback_frameshift.c:340-365, :577-590, :1279-1283), so every table log-sum has the reference's
+ * operands: scores, special-state rows and matrices are BIT-IDENTICAL to the generic reference (the north star's 1e-4 with
+ * room to spare).  0 = "fast": the same table log-sums associated by wavefront scans, scores within O(1e-3) nats of the
+ * reference, ~1.7x faster on the bench's --fs pass.  Applies to the pipeline entry points and to BATH_LOGSUM_CONTEXT. */
 int         bath_hip_set_fs_strict(bath_hip_ctx *ctx, int on);
 
 /* ------------------------------------------------------------------------------------------
@@ -385,6 +386,7 @@ int64_t bath_tophits_tabular_targets(const bath_tophits *th, const char *qname, 
 #define BATH_LOGSUM_TABLE 0   /* emulate p7_FLogsum's 0.001-nat truncating table (logsum.c:105) */
 #define BATH_LOGSUM_EXACT 1   /* exact log(1+exp(x))                                            */
 #define BATH_LOGSUM_TABLE_SERIAL 2 /* the table, sums along the model in the reference's serial order: bit-identical to generic_fwdback_frameshift.c */
+#define BATH_LOGSUM_CONTEXT 3 /* whatever bath_hip_set_fs_strict selected for the context: TABLE_SERIAL unless switched to the fast mode */
 
 int  bath_hip_fsprofile_convert(bath_hip_ctx *ctx, const bath_fs_profile *gm_fs, bath_hip_fsprofile **ret); /* p7_fs_oprofile_Convert, p7_fs_oprofile.c:221 */
 void bath_hip_fsprofile_destroy(bath_hip_fsprofile *om);

@@ -330,6 +330,7 @@ int  bo_forward_full(const uint8_t *dsq, int L, const bo_oprofile *om, float *dp
 int  bo_backward_full(const uint8_t *dsq, int L, const bo_oprofile *om, const float *fwd_xmx, float *dpb, float *bck_xmx, float *ret_sc, int *own_scales); /* :196 */
 void bo_oprofile_reconfig_unihit(bo_oprofile *om, int L);       /* p7_oprofile.c:1418 */
 void bo_oprofile_reconfig_multihit(bo_oprofile *om, int L);     /* p7_oprofile.c:1395 */
+int  bo_std_envelope_trace(bo_oprofile *om, const uint8_t *dsq, int L, int *path_st, int *path_k, int *path_i, float *oasc_out);   /* test hook: optacc.c:225 on one envelope */
 int  bo_domain_decoding(const bo_oprofile *om, const float *fx, const float *bx, int L, int own_scales, float *btot, float *etot, float *mocc); /* decoding.c:155 */
 int  bo_domaindef_std(bo_pipeline *pli, bo_oprofile *om, bo_bg *bg, const uint8_t *dsq, int n, int orf_start, int win_start,
                       int complementarity, int seq_n, bo_fsdomain **doms, int *ndom, int *dalloc, int *nskipped, const uint8_t *strand_dsq);

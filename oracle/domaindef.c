@@ -313,6 +313,33 @@ static void rescore_envelope(bo_oprofile *om, const uint8_t *dsq, int i, int j, 
   free(fwd); free(bck); free(efx); free(ebx); free(ppx); free(oax);
 }
 
+/* Test hook: the optimal-accuracy trace of one envelope, the calls of rescore_isolated_domain_bath (p7_domaindef.c:1206-1262):
+ * p7_Forward, p7_Backward, p7_Decoding, p7_OptimalAccuracy, p7_OATrace on dsq[1..L] in the unihit configuration of length L.
+ * path_*: the trace's M/D/I columns from the LAST to the first (oa_trace's order); returns their number or -1. */
+int bo_std_envelope_trace(bo_oprofile *om, const uint8_t *dsq, int L, int *path_st, int *path_k, int *path_i, float *oasc_out)
+{
+  const int M = om->M;
+  const size_t W = (size_t)(M + 1) * 3;
+  bo_oprofile_reconfig_unihit(om, L);
+  float *fwd = calloc((size_t)(L + 1) * W, sizeof(float)), *bck = calloc((size_t)(L + 1) * W, sizeof(float));
+  float *efx = calloc((size_t)(L + 1) * 6, sizeof(float)), *ebx = calloc((size_t)(L + 1) * 6, sizeof(float));
+  float *ppx = calloc((size_t)(L + 1) * 5, sizeof(float)), *oax = calloc((size_t)(L + 1) * 5, sizeof(float));
+  float envsc, bcksc;
+  int eown = 0, pn = -1;
+  bo_forward_full(dsq, L, om, fwd, efx, &envsc);
+  bo_backward_full(dsq, L, om, efx, bck, ebx, &bcksc, &eown);
+  if (decoding(om, L, fwd, efx, bck, ebx, eown, ppx) != BO_ERANGE) {
+    const float oasc = optimal_accuracy(om, L, bck, ppx, fwd, oax);
+    int i1, k1, i2, k2;
+    if (oasc_out) *oasc_out = oasc;
+    pn = 0;
+    if (oa_trace(om, L, bck, ppx, fwd, oax, &i1, &k1, &i2, &k2, path_st, path_k, path_i, &pn) != BO_OK) pn = -1;
+  }
+  free(fwd); free(bck); free(efx); free(ebx); free(ppx); free(oax);
+  bo_oprofile_reconfig_multihit(om, L);
+  return pn;
+}
+
 /* p7_domaindef_ByPosteriorHeuristics_BATH + p7_pli_postDomainDef_BATH for one ORF that passed the Forward filter.
  * dsq[1..n]: the ORF; orf_start: first nucleotide of the ORF on the strand being read; win_start: windowsq->start on
  * that strand (= orf_start in the plain pipeline, the DNA window's start in the frameshift pipeline's standard branch);

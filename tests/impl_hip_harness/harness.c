@@ -158,6 +158,25 @@ int hs_filters(const char *path, int idx, const uint8_t *dsq1, int L, float filt
   return eslOK;
 }
 
+/* p7_domaindef's parser calls and p7_DomainDecoding on one ORF (p7_domaindef.c:513-520): the rows the decoding reads and its three arrays */
+int hs_std_decoding(const char *path, int idx, const uint8_t *dsq1, int L, float *fx, float *bx, float *btot, float *etot, float *mocc)
+{
+  HS_MODEL m;
+  if (hs_model_open(path, idx, &m) != eslOK) return eslFAIL;
+  P7_OMX *ox = p7_omx_Create(m.gm.M, 0, L), *oxb = p7_omx_Create(m.gm.M, 0, L);
+  P7_DOMAINDEF ddef = { mocc, btot, etot, 0, L + 1, NULL };
+  float f = 0.f, b = 0.f;
+  p7_oprofile_ReconfigLength(m.om, L);
+  int st = p7_ForwardParser(dsq1, L, m.om, ox, &f);
+  if (st == eslOK) st = p7_BackwardParser(dsq1, L, m.om, ox, oxb, &b);
+  if (st == eslOK) st = p7_DomainDecoding(m.om, ox, oxb, &ddef);
+  memcpy(fx, ox->xmx, sizeof(float) * (size_t)(L + 1) * 6);
+  memcpy(bx, oxb->xmx, sizeof(float) * (size_t)(L + 1) * 6);
+  p7_omx_Destroy(ox); p7_omx_Destroy(oxb);
+  hs_model_close(&m);
+  return st;
+}
+
 /* rescore_isolated_domain_bath's calls on one envelope (p7_domaindef.c:1206-1262): out = {envsc, bcksc, oasc}; null2[29];
  * the OA trace in tst/tk/ti/tpp (cap tcap), its length returned */
 int hs_std_envelope(const char *path, int idx, const uint8_t *dsq1, int L, float *out, float *null2, char *tst, int *tk, int *ti, float *tpp, int tcap)

@@ -16,6 +16,16 @@ import oracle_lib as ol
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["strict", "fast"])
+def fs_mode(request, gpu_ctx):
+    """Every test of this file runs in both modes of the frameshift recursions: strict (the library's default; the exact
+    comparisons of tests/test_fs_strict_gpu.py apply to it as well) and fast (wavefront scans), whose scores carry the
+    tolerances stated below."""
+    gpu_ctx.set_fs_strict(request.param == "strict")
+    yield request.param
+    gpu_ctx.set_fs_strict(True)
+
+
 def frameshifted_windows(rng, model, n=40, L_flank=250):
     """Planted genes, most of them with 1-3 single-nucleotide insertions or deletions, on either strand."""
     wins = []

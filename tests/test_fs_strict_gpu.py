@@ -1,0 +1,121 @@
+"""The --fs pipeline in its default (strict) mode against the oracle with NO allowance on the frameshift branch.
+
+In strict mode every sum along the model runs in the reference's serial order (bath_fs_chain.hip, bath_fs_wavefront.hip), so the
+3-codon parsers' scores and special-state rows, the regions' Forward matrices and the envelopes' Forward/Backward matrices are
+the oracle's bit for bit.  What follows from bit-identical inputs must be identical too:
+  * every DNA window: coordinates, the frameshift Forward score (bitwise), its P-values, the branch it takes;
+  * every domain of the frameshift branch: envelope, alignment and model coordinates and the shifted-codon count EXACTLY -- no
+    "an envelope end may move one step", and the clustered regions sample for sample (the stochastic tracebacks walk identical
+    matrices with the same random-number stream) -- and the envelope score bitwise.
+The domains of the standard branch (windows the decision sends to p7_Forward/p7_Backward in fp32 odds-ratio arithmetic,
+p7_pipeline.c:1479-1510) keep the tolerances of tests/test_fs_pipeline_gpu.py: that arithmetic is not table log-sums."""
+import numpy as np
+import pytest
+
+import bath_amd as ba
+import common
+import oracle_lib as ol
+import test_fs_pipeline_gpu as P
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(x):
+    return int(np.float32(x).view(np.uint32))
+
+
+def run(ctx, path, wins):
+    ctx.set_fs_strict(True)
+    hmm = ba.HMM(path, 0)
+    om = ba.OProfile(ctx, ba.Profile(hmm))
+    om3 = ba.FSOProfile(ctx, ba.FSProfile(hmm, 3, ncbi_table=hmm.ct))
+    om5 = ba.FSOProfile(ctx, ba.FSProfile(hmm, 5, ncbi_table=hmm.ct))
+    pipe = ba.Pipeline(ctx, om, fs_pipe=True, ncbi_table=hmm.ct)
+    stats, fw, dm, nskip = pipe.run_frameshift_domains(om3, om5, ba.SeqBlock(ctx, wins))
+    model = ol.Model(path, 0)
+    pli, ofw, per_w, odm, per_d, oskip = model.run_pipeline_fsdom(wins)
+    return model, stats, fw, dm, nskip, pli, ofw, per_w, odm, per_d, oskip
+
+
+def check_exact(model, stats, fw, dm, nskip, pli, ofw, per_w, odm, per_d, oskip):
+    # ---- DNA windows
+    want = sorted(((w, o) for w, (a, b) in enumerate(per_w) for o in ofw[a:b]), key=lambda t: (t[0], t[1].strand, t[1].n))
+    got = sorted(fw, key=lambda g: (g.window, g.strand, g.n))
+    assert len(got) == len(want)
+    for g, (w, o) in zip(got, want):
+        assert (g.window, g.strand, g.n, g.length, g.orf_cnt, g.k_min, g.k_max) == (w, o.strand, o.n, o.length, o.orf_cnt, o.k_min, o.k_max)
+        assert bits(g.fwdsc) == bits(o.fwdsc), (w, g.fwdsc, o.fwdsc)                      # p7_ForwardParser_Frameshift_3Codons, bit for bit
+        assert abs(g.filtersc - o.filtersc) <= 1e-4 * max(1.0, abs(o.filtersc))             # the bias filter is an fp32 Forward of a 2-state HMM
+        borderline = abs(o.P_null - o.P_tot) <= 1e-3 * max(o.P_null, o.P_tot)               # P_tot sums fp32 odds-ratio Forward scores (1e-4)
+        if not borderline:
+            assert g.branch == o.branch, (w, g.P_fs, o.P_fs)
+    assert nskip == oskip
+    # ---- domains: the frameshift branch exactly, the standard branch at the tolerances of its fp32 arithmetic
+    key = lambda w, d: (w, d.ienv, d.jenv, d.iali, d.jali, d.ihmm, d.jhmm, d.n_shifted_codons)
+    g_fs = [d for d in dm if fw[d.fs_window].branch == 1]
+    g_std = [d for d in dm if fw[d.fs_window].branch != 1]
+    o_all = [(w, o) for w, (a, b) in enumerate(per_d) for o in odm[a:b]]
+    assert len(dm) == len(o_all)
+    omap = {}
+    for w, o in o_all:
+        omap.setdefault(key(w, o), []).append(o)
+    used = set()
+    for d in g_fs:
+        lst = omap.get(key(d.window, d))
+        assert lst, ("a frameshift-branch domain the oracle does not have", key(d.window, d))
+        o = lst.pop()
+        used.add(id(o))
+        assert bits(d.envsc) == bits(o.envsc), (d.window, d.envsc, o.envsc)                 # p7_Forward_Frameshift of the envelope, bit for bit
+        assert abs(d.oasc - o.oasc) <= 5e-4 + 1e-4 * abs(o.oasc)                             # posteriors differ by expf's last bit
+        assert abs(d.bitscore - o.bitscore) <= 2e-3 and abs(d.domcorrection - o.domcorrection) <= 2e-3 + 2e-3 * abs(o.domcorrection)
+    # what is left on both sides are the standard branch's domains
+    odm_rest, per_rest = [], []
+    for w, (a, b) in enumerate(per_d):
+        lo = len(odm_rest)
+        odm_rest += [o for o in odm[a:b] if id(o) not in used]
+        per_rest.append((lo, len(odm_rest)))
+    assert len(odm_rest) == len(g_std)
+    if g_std:
+        P.compare_domains(model, g_std, odm_rest, per_rest, nskip)
+    return len(g_fs), len(g_std), len(dm)
+
+
+@pytest.mark.parametrize("name", ["Caudal_act.bhmm", "PTH2.bhmm", "2OG-FeII_Oxy_3.bhmm"])
+def test_strict_pipeline_is_exact_on_planted_frameshifted_genes(gpu_ctx, name):
+    rng = np.random.default_rng(41)
+    path = ol.GOLDEN + "/" + name
+    wins = P.frameshifted_windows(rng, ol.Model(path, 0), n=24)
+    out = run(gpu_ctx, path, wins)
+    n_fs, n_std, n_all = check_exact(*out)
+    assert n_fs >= 3 and n_std >= 1                        # both branches produced domains
+
+
+def test_strict_pipeline_is_exact_on_clustered_regions(gpu_ctx):
+    """Windows carrying two copies of a gene a short spacer apart: multi-domain regions, resolved by 200 stochastic tracebacks
+    through the region's multihit Forward matrix (p7_domaindef.c:396-455).  With identical matrices both sides draw the same
+    samples: the clusters' envelopes are identical, not merely near."""
+    rng = np.random.default_rng(7)
+    path = ol.GOLDEN + "/PTH2.bhmm"
+    model = ol.Model(path, 0)
+    genes = common.emit_from_model(rng, model, 12, flank=3, sharpen=2.0)
+    wins = []
+    for a, b in zip(genes[::2], genes[1::2]):
+        nt = [list(common.revtranslate(rng, g, model.basic)) for g in (a, b)]
+        for seq in nt:
+            p = int(rng.integers(10, len(seq) - 10))
+            del seq[p]                                         # one frameshift per copy
+        wins.append(np.array(nt[0] + list(rng.integers(0, 4, size=int(rng.integers(20, 60)))) + nt[1], dtype=np.uint8))
+    out = run(gpu_ctx, path, wins)
+    assert out[4] >= 1, "no clustered region in this input"
+    n_fs, n_std, n_all = check_exact(*out)
+    assert n_fs >= 4
+
+
+def test_strict_pipeline_is_exact_with_a_1024_node_model(gpu_ctx, tmp_path):
+    """BASELINE configs[4]'s model size: 16 nodes per lane in the chain kernels, the wavefront's ring in global memory."""
+    path = common.write_synthetic_bhmm(str(tmp_path / "s1024.bhmm"), 1024, seed=1024)
+    rng = np.random.default_rng(12)
+    wins = P.frameshifted_windows(rng, ol.Model(path, 0), n=8, L_flank=60)[:10] + common.random_dna(rng, 4, 1200)
+    out = run(gpu_ctx, path, wins)
+    n_fs, n_std, n_all = check_exact(*out)
+    assert n_fs >= 2
