@@ -84,3 +84,68 @@ def dna_windows(n_windows, length, seed, hmm=None, planted_frac=0.01, ncbi_table
             flat[w, pos:pos + len(nt)] = nt
     offsets = np.arange(n_windows + 1, dtype=np.int64) * length
     return flat.reshape(-1), offsets, planted
+
+
+BG = np.array([0.0787945, 0.0151600, 0.0535222, 0.0668298, 0.0397062, 0.0695071, 0.0229198, 0.0590092,
+               0.0594422, 0.0963728, 0.0237718, 0.0414386, 0.0482904, 0.0395639, 0.0540978, 0.0683364,
+               0.0540687, 0.0673417, 0.0114135, 0.0304133])
+
+
+def write_synthetic_bhmm(path, M, seed=1, name="synth", evparam_from=None):
+    """A synthetic BATH3/f model in the spirit of p7_hmm_Sample (p7_hmm.c): Dirichlet-ish match emissions, sampled
+    transitions; E-value parameters copied from a real model (BASELINE configs[4]: 'synthetic 1024-state HMM')."""
+    rng = np.random.default_rng(seed)
+    ev = evparam_from if evparam_from is not None else [-10.3292, 0.71002, -11.3545, 0.71002, -3.7358, 0.71002, -4.1064, -3.2990]
+    ins = BG / BG.sum()
+
+    def line(vals):
+        return "  ".join("%.5f" % (-np.log(max(v, 1e-30))) if v > 0 else "      *" for v in vals)
+
+    out = ["BATH3/f", "NAME  %s" % name, "LENG  %d" % M, "MAXL  %d" % int(M * 1.6 + 50), "ALPH  amino", "RF    no", "MM    no",
+           "CONS  yes", "CS    no", "MAP   no", "NSEQ  1", "EFFN  1.000000",
+           "STATS LOCAL MSV       %9.4f  %7.5f" % (ev[0], ev[1]), "STATS LOCAL VITERBI   %9.4f  %7.5f" % (ev[2], ev[3]),
+           "STATS LOCAL FORWARD   %9.4f  %7.5f" % (ev[4], ev[5]), "STATS LOCAL FS3 FORWARD  %8.4f  %7.5f" % (ev[6], ev[5]),
+           "STATS LOCAL FS5 FORWARD  %8.4f  %7.5f" % (ev[7], ev[5]), "FRAMESHIFT PROB    0.0100", "CODON TABLE  1",
+           "HMM          " + "        ".join("ACDEFGHIKLMNPQRSTVWY"), "            m->m     m->i     m->d     i->m     i->i     d->m     d->d"]
+    mats, trans = [], []
+    for k in range(M + 1):
+        e = rng.dirichlet(0.3 * np.ones(20)) * 0.7 + 0.3 * ins
+        mats.append(e / e.sum())
+        tm = rng.dirichlet([30.0, 1.0, 1.0]); ti = rng.dirichlet([2.0, 1.5]); td = rng.dirichlet([1.5, 1.0])
+        trans.append([tm[0], tm[1], tm[2], ti[0], ti[1], td[0], td[1]])
+    trans[0][5], trans[0][6] = 1.0, 0.0
+    trans[M] = [trans[M][0] / (trans[M][0] + trans[M][1]), trans[M][1] / (trans[M][0] + trans[M][1]), 0.0, trans[M][3], trans[M][4], 1.0, 0.0]
+    compo = np.mean(mats[1:], axis=0)
+    out.append("  COMPO   " + line(compo))
+    out.append("          " + line(ins))
+    out.append("          " + line(trans[0]))
+    for k in range(1, M + 1):
+        cons = "ACDEFGHIKLMNPQRSTVWY"[int(np.argmax(mats[k]))].lower()
+        out.append("%7d   %s %6d %s - -" % (k, line(mats[k]), k, cons))
+        out.append("          " + line(ins))
+        out.append("          " + line(trans[k]))
+    out.append("//")
+    with open(path, "w") as fh:
+        fh.write("\n".join(out) + "\n")
+    return path
+
+
+def genome(n_nt, seed, hmms=(), genes_per_model=0, ncbi_table=1, frameshift=False):
+    """One iid ACGT target of <n_nt> nucleotides with <genes_per_model> genes sampled from each model's match emissions planted
+    on either strand (BASELINE configs[3] / [4]).  Returns (codes, [(model index, position, length)])."""
+    rng = np.random.default_rng(seed)
+    g = rng.integers(0, 4, size=n_nt, dtype=np.uint8)
+    basic = gencode_basic(ncbi_table)
+    planted = []
+    for q, hmm in enumerate(hmms):
+        mat = hmm_match_emissions(hmm)
+        for j in range(genes_per_model):
+            nt = reverse_translate(rng, sample_domain(rng, mat), basic)
+            if frameshift:
+                nt = frameshift_mutations(rng, nt)
+            if rng.random() < 0.5:
+                nt = (3 - nt[::-1]).astype(np.uint8)
+            p = int(rng.integers(0, n_nt - len(nt)))
+            g[p:p + len(nt)] = nt
+            planted.append((q, p, len(nt)))
+    return g, planted

@@ -118,6 +118,160 @@ def cpu_baseline(flat, length, n_windows, budget_s=30.0):
     return base, tot, covered
 
 
+# ------------------------------------------------------------------------------------------------ configs[3] / configs[4], one-GPU slices
+
+DB = os.path.join(ROOT, "tests", "golden", "tRNA-proteins.bhmm")      # the reference's tutorial/tRNA-proteins.bhmm: 12 query models, M = 56..459
+C5_M = 1024
+
+
+def c5_model_path():
+    from bath_amd import synth
+    path = "/tmp/bath_bench_synth%d.bhmm" % C5_M
+    if not os.path.exists(path):
+        synth.write_synthetic_bhmm(path, C5_M, seed=C5_M, name="synth%d" % C5_M)
+    return path
+
+
+def c4_genome(ba, synth, n_nt):
+    hmms = [ba.HMM(DB, q) for q in range(ba.HMM.count(DB))]
+    g, planted = synth.genome(n_nt, seed=4300, hmms=hmms, genes_per_model=max(4, n_nt // 400_000))
+    return hmms, g, planted
+
+
+def c5_genome(ba, synth, n_nt):
+    hmm = ba.HMM(c5_model_path())
+    g, planted = synth.genome(n_nt, seed=4400, hmms=[hmm], genes_per_model=max(8, n_nt // 400_000), frameshift=True)
+    return hmm, g, planted
+
+
+def c45_cpu_samples(args):
+    """Before any GPU initialisation: the oracle's pipeline on the SSE2 striped kernels over the FIRST windows of both genomes --
+    the counters bench's GPU legs must reproduce on the same windows (parity_check of c4 and c5)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ctypes as C
+    import bath_amd as ba
+    import oracle_lib as ol
+    from bath_amd import dist as bdist, synth
+    L_ = ol.lib()
+    L_.bo_pipeline_use_sse(1)
+    out = {"c4": [], "c5": None}
+    hmms, g, _ = c4_genome(ba, synth, int(args.c4_mb * 1e6))
+    t0 = time.perf_counter()
+    for q, hmm in enumerate(hmms):
+        wins = bdist.split_targets([len(g)], hmm.max_length)[:args.c45_sample_windows]
+        model = ol.Model(DB, q)
+        pli, odm, per_d, oskip = model.run_pipeline_hits([g[s_:s_ + n] for _, s_, n, _ in wins], contexts=[c for _, _, _, c in wins])
+        out["c4"].append({f: int(getattr(pli, f)) for f in COUNTERS})
+    out["c4_seconds"] = time.perf_counter() - t0
+    hmm5, g5, _ = c5_genome(ba, synth, int(args.c5_mb * 1e6))
+    wins = bdist.split_targets([len(g5)], hmm5.max_length)[:1]
+    t0 = time.perf_counter()
+    model = ol.Model(c5_model_path(), 0)
+    pli, ores, per_seq, ofw, per_seq_w = model.run_pipeline_fs([g5[s_:s_ + n] for _, s_, n, _ in wins])
+    out["c5"] = {f: int(getattr(pli, f)) for f in COUNTERS}
+    out["c5_seconds"] = time.perf_counter() - t0
+    L_.bo_pipeline_use_sse(0)
+    return out
+
+
+def c4_leg(ba, synth, bdist, ctx, args, cpu):
+    """BASELINE configs[3] at its one-GPU slice: the 12 query models of tRNA-proteins.bhmm, one after the other (the loop per
+    query of bathsearch.c:737), against a genome cut into the reference's windows with context (dist.split_targets): the
+    plain pipeline through domain definition to hits."""
+    hmms, g, planted = c4_genome(ba, synth, int(args.c4_mb * 1e6))
+    per_model, tot_ms, tot_res, tot_cells, tot_hits = [], 0.0, 0, 0, 0
+    parity = []
+    for q, hmm in enumerate(hmms):
+        om = ba.OProfile(ctx, ba.Profile(hmm))
+        pipe = ba.Pipeline(ctx, om, fs_pipe=False, ncbi_table=hmm.ct)
+        wins = bdist.split_targets([len(g)], hmm.max_length)
+        seqs = [g[s_:s_ + n] for _, s_, n, _ in wins]
+        ctxs = [c for _, _, _, c in wins]
+        if cpu is not None:                                     # the windows the CPU leg scored, counter by counter
+            k = min(args.c45_sample_windows, len(wins))
+            sub = ba.SeqBlock(ctx, seqs[:k]); sub.set_context(ctxs[:k])
+            st, _, _ = pipe.run_hits(sub)
+            parity.append(all(int(getattr(st, f)) == cpu["c4"][q][f] for f in COUNTERS))
+        block = ba.SeqBlock(ctx, seqs); block.set_context(ctxs)
+        pipe.run_hits(block)
+        steps = 2
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            st, dm, nskip = pipe.run_hits(block)
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        pipe.run(block, want_results=False)
+        stage = {n_: round(ms_, 3) for n_, ms_, _ in pipe.timings()}
+        found = sum(1 for qq, p_, ln in planted if qq == q and any(d.reported and min(d.iali, d.jali) + wins[d.window][1] < p_ + ln and
+                                                                   max(d.iali, d.jali) + wins[d.window][1] > p_ for d in dm))
+        cells = st.cells_msv + st.cells_vit + st.cells_fwd
+        per_model.append({"name": hmm.name, "M": hmm.M, "ms": ms, "hits": int(sum(d.reported for d in dm)), "planted_found": found,
+                          "planted": sum(1 for qq, _, _ in planted if qq == q), "clustered_regions": int(nskip), "cascade_stage_ms": stage})
+        tot_ms += ms; tot_res += st.nres; tot_cells += cells; tot_hits += int(sum(d.reported for d in dm))
+    return {"workload": "tRNA-proteins.bhmm (12 query models, M = 56..459), each against a %.1f Mb synthetic genome (1/8 of configs[3]'s 100 Mb) cut into "
+                        "%d-nt windows with 3*max_length context; cascade + domain definition + hits per model" % (args.c4_mb, bdist.BLOCK_LENGTH),
+            "ms_per_database_pass": tot_ms, "residues_per_s": tot_res / (tot_ms * 1e-3), "gcells_per_s": tot_cells / (tot_ms * 1e-3) / 1e9,
+            "hits": tot_hits, "models": per_model,
+            "parity_check": None if cpu is None else {"what": "the 10 pipeline counters of the first %d windows of every model against the SSE2 striped CPU pipeline" % args.c45_sample_windows,
+                                                      "all_equal": all(parity), "per_model": parity, "cpu_seconds": cpu["c4_seconds"]}}
+
+
+def c5_leg(ba, synth, bdist, ctx, args, cpu):
+    """BASELINE configs[4] at its one-GPU slice: a synthetic 1024-node model with --fs (16 nodes per lane in the frameshift
+    kernels, SSV split over several lanes per ORF, the wavefront's ring in global memory) against 1/8 of the 1 Gb genome."""
+    hmm, g, planted = c5_genome(ba, synth, int(args.c5_mb * 1e6))
+    om = ba.OProfile(ctx, ba.Profile(hmm))
+    om3 = ba.FSOProfile(ctx, ba.FSProfile(hmm, 3, ncbi_table=hmm.ct))
+    om5 = ba.FSOProfile(ctx, ba.FSProfile(hmm, 5, ncbi_table=hmm.ct))
+    wins = bdist.split_targets([len(g)], hmm.max_length)
+    seqs = [g[s_:s_ + n] for _, s_, n, _ in wins]
+    ctxs = [c for _, _, _, c in wins]
+    pipe = ba.Pipeline(ctx, om, fs_pipe=True, ncbi_table=hmm.ct)
+    parity = None
+    if cpu is not None:
+        st, _, fw0 = pipe.run_frameshift(om3, ba.SeqBlock(ctx, seqs[:1]))
+        parity = {f: (int(getattr(st, f)), cpu["c5"][f]) for f in COUNTERS}
+    block = ba.SeqBlock(ctx, seqs); block.set_context(ctxs)
+    pipe.run_frameshift_domains(om3, om5, block, arrays=True)
+    steps = 2
+    kt = {}
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        stats, fw, dm, nskip = pipe.run_frameshift_domains(om3, om5, block, arrays=True)
+        for name, (ms, nl, cells, nbytes) in pipe.kernel_times().items():
+            k = kt.setdefault(name, {"ms": 0.0, "launches": 0.0})
+            k["ms"] += ms / steps; k["launches"] += nl / steps
+    dt = (time.perf_counter() - t0) / steps
+    summary = {"fs_windows": int(len(fw)), "fs_branch": int((fw["branch"] == 1).sum()), "domains": int(len(dm)), "reported": int(dm["reported"].sum()),
+               "clustered_regions": int(nskip), "shifted_codons_found": int(dm["n_shifted_codons"].sum()), "planted": len(planted)}
+    ctx.set_fs_strict(False)
+    pipe.run_frameshift_domains(om3, om5, block, arrays=True)
+    t0 = time.perf_counter()
+    pipe.run_frameshift_domains(om3, om5, block, arrays=True)
+    dtf = time.perf_counter() - t0
+    ctx.set_fs_strict(True)
+    # the cascade alone (F4 thresholds of the --fs pipeline), stage by stage
+    casc = ba.Pipeline(ctx, om, fs_pipe=True, ncbi_table=hmm.ct)
+    casc.run(block, want_results=False)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        cst, _ = casc.run(block, want_results=False)
+    cms = (time.perf_counter() - t0) / 3 * 1e3
+    stage = {n_: round(ms_, 3) for n_, ms_, _ in casc.timings()}
+    ssv_ms = stage.get("ssv_f1", float("nan"))
+    return {"workload": "synthetic %d-node model (bath_amd.synth.write_synthetic_bhmm, seed %d) --fs vs a %.0f Mb synthetic genome (1/8 of configs[4]'s 1 Gb), %d "
+                        "windows of %d nt with context, %d planted frameshifted genes" % (C5_M, C5_M, args.c5_mb, len(wins), bdist.BLOCK_LENGTH, len(planted)),
+            "ms_per_pass": dt * 1e3, "residues_per_s": stats.nres / dt, "mode": "strict (bit-identical frameshift recursions)",
+            "fast": {"ms_per_pass": dtf * 1e3, "residues_per_s": stats.nres / dtf},
+            **summary, "kernels_ms": {k: round(v["ms"], 3) for k, v in sorted(kt.items(), key=lambda kv: -kv[1]["ms"])},
+            "cascade": {"ms": cms, "residues_per_s": cst.nres / (cms * 1e-3), "gcells_per_s": (cst.cells_msv + cst.cells_vit + cst.cells_fwd) / (cms * 1e-3) / 1e9,
+                        "stage_ms": stage, "ssv_tcells_per_s": cst.cells_msv / (ssv_ms * 1e-3) / 1e12, "ssv_frac_of_packed_issue_peak": cst.cells_msv / (ssv_ms * 1e-3) / 1e12 / 44.4},
+            "parity_check": None if parity is None else {"what": "the 10 pipeline counters of the first window (262144 nt, --fs thresholds) against the SSE2 striped CPU pipeline",
+                                                         "all_equal": all(a == b for a, b in parity.values()),
+                                                         "mismatches": {k: {"gpu": a, "cpu": b} for k, (a, b) in parity.items() if a != b}, "cpu_seconds": cpu["c5_seconds"]}}
+
+
 # ------------------------------------------------------------------------------------------------ launcher
 
 def free_port():
@@ -154,6 +308,10 @@ def main():
     ap.add_argument("--no-fs", action="store_true", help="skip the configs[2] (--fs) leg")
     ap.add_argument("--fs-windows", type=int, default=1_000_000)
     ap.add_argument("--no-streamed", action="store_true", help="skip the host-fed (PCIe-inclusive) leg")
+    ap.add_argument("--no-c45", action="store_true", help="skip the configs[3] / configs[4] legs (multi-HMM database; 1024-node model with --fs)")
+    ap.add_argument("--c4-mb", type=float, default=12.5, help="genome of the configs[3] leg, Mb (100 Mb over 8 GPUs)")
+    ap.add_argument("--c5-mb", type=float, default=125.0, help="genome of the configs[4] leg, Mb (1 Gb over 8 GPUs)")
+    ap.add_argument("--c45-sample-windows", type=int, default=2, help="windows per model the CPU pipeline scores for the c4 parity check")
     ap.add_argument("--no-one-part", action="store_true",
                     help="skip the whole-block-as-one-part passes behind roofline.valu (profiling: every ssv_orf_kernel launch is then a timed-step launch)")
     ap.add_argument("--plumbing-only", action="store_true",
@@ -181,7 +339,7 @@ def main():
     # ---- before any GPU initialisation: the model, the synthetic block, the CPU baseline (forks workers)
     hmm0 = ba.HMM(MODEL)
     flat = offsets = None
-    base = cpu_counters = None
+    base = cpu_counters = c45_cpu = None
     cpu_covered = 0
     if not args.plumbing_only:
         if args.scaling == "strong":                      # one block for the whole job: every rank generates it and keeps its shard
@@ -193,6 +351,8 @@ def main():
         offsets = np.arange(n_mine + 1, dtype=np.int64) * args.length
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             base, cpu_counters, cpu_covered = cpu_baseline(flat, args.length, n_mine)
+            if not args.no_c45:
+                c45_cpu = c45_cpu_samples(args)
 
     import torch
     import torch.distributed as dist
@@ -351,6 +511,9 @@ def main():
             out.update(streamed_leg(ba, ctx, pipe, flat, offsets, args, stats))
         if not args.no_fs and world == 1:
             out["fs"] = fs_leg(ba, synth, ctx, hmm, om, args)
+        if not args.no_c45 and world == 1:
+            out["c4"] = c4_leg(ba, synth, bdist, ctx, args, c45_cpu)
+            out["c5"] = c5_leg(ba, synth, bdist, ctx, args, c45_cpu)
     if rank == 0:
         print(json.dumps(out))
         sys.stdout.flush()

@@ -119,3 +119,53 @@ def test_strict_pipeline_is_exact_with_a_1024_node_model(gpu_ctx, tmp_path):
     out = run(gpu_ctx, path, wins)
     n_fs, n_std, n_all = check_exact(*out)
     assert n_fs >= 2
+
+
+def test_fast_mode_errors_on_scores_that_reach_output(gpu_ctx):
+    """The fast mode (bath_hip_set_fs_strict(0): wavefront scans) is not the parity mode: its sums differ from the reference's by
+    O(1e-3) nats, which is more than 1e-4 RELATIVE for scores near zero (tests/test_frameshift_gpu.py records up to 2.9e-4 over
+    all scores above one nat).  The scores that can reach output are larger: the frameshift Forward score of every DNA window
+    that passes F3 and the envelope score of every reported frameshift-branch domain must be within the north star's 1e-4
+    relative of the oracle's; the worst cases go to gpurun_out/fs_fast_errors.json (committed as profiles/r03_fs_fast_errors.json)."""
+    import json, os
+    worst = {"window_fwdsc": {"n": 0, "max_rel": 0.0, "max_abs_nats": 0.0, "min_score_nats": 1e30},
+             "reported_envsc": {"n": 0, "max_rel": 0.0, "max_abs_nats": 0.0, "min_score_nats": 1e30}}
+    gpu_ctx.set_fs_strict(False)
+    try:
+        for name in ("Caudal_act.bhmm", "PTH2.bhmm", "2OG-FeII_Oxy_3.bhmm"):
+            rng = np.random.default_rng(43)
+            path = ol.GOLDEN + "/" + name
+            model = ol.Model(path, 0)
+            wins = P.frameshifted_windows(rng, model, n=40)
+            hmm = ba.HMM(path, 0)
+            om = ba.OProfile(gpu_ctx, ba.Profile(hmm))
+            om3 = ba.FSOProfile(gpu_ctx, ba.FSProfile(hmm, 3, ncbi_table=hmm.ct))
+            om5 = ba.FSOProfile(gpu_ctx, ba.FSProfile(hmm, 5, ncbi_table=hmm.ct))
+            pipe = ba.Pipeline(gpu_ctx, om, fs_pipe=True, ncbi_table=hmm.ct)
+            stats, fw, dm, nskip = pipe.run_frameshift_domains(om3, om5, ba.SeqBlock(gpu_ctx, wins))
+            pli, ofw, per_w, odm, per_d, oskip = model.run_pipeline_fsdom(wins)
+            omap = {(w, o.strand, o.n): o for w, (a, b) in enumerate(per_w) for o in ofw[a:b]}
+            for g in fw:
+                o = omap.get((g.window, g.strand, g.n))
+                if o is None or o.P_fs > 1e-5:
+                    continue
+                e = worst["window_fwdsc"]
+                e["n"] += 1; e["max_abs_nats"] = max(e["max_abs_nats"], abs(g.fwdsc - o.fwdsc)); e["min_score_nats"] = min(e["min_score_nats"], abs(o.fwdsc))
+                e["max_rel"] = max(e["max_rel"], abs(g.fwdsc - o.fwdsc) / abs(o.fwdsc))
+            key = lambda w, d: (w, d.ienv, d.jenv, d.iali, d.jali, d.ihmm, d.jhmm)
+            dmap = {key(w, o): o for w, (a, b) in enumerate(per_d) for o in odm[a:b]}
+            for d in dm:
+                o = dmap.get(key(d.window, d))
+                if o is None or not o.reported or fw[d.fs_window].branch != 1:
+                    continue
+                e = worst["reported_envsc"]
+                e["n"] += 1; e["max_abs_nats"] = max(e["max_abs_nats"], abs(d.envsc - o.envsc)); e["min_score_nats"] = min(e["min_score_nats"], abs(o.envsc))
+                e["max_rel"] = max(e["max_rel"], abs(d.envsc - o.envsc) / abs(o.envsc))
+    finally:
+        gpu_ctx.set_fs_strict(True)
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    json.dump({"mode": "fast (bath_hip_set_fs_strict(0))", "contract": "1e-4 relative (BASELINE.json north_star)", **worst}, open(os.path.join(out, "fs_fast_errors.json"), "w"), indent=1)
+    print("fast-mode errors", worst)
+    assert worst["window_fwdsc"]["n"] >= 30 and worst["reported_envsc"]["n"] >= 15
+    assert worst["reported_envsc"]["max_rel"] <= 1e-4 and worst["window_fwdsc"]["max_rel"] <= 1e-4
