@@ -188,6 +188,8 @@ ABI = {
                                               C.POINTER(C.POINTER(OrfResult)), _i64p, C.POINTER(C.POINTER(FsWindow)), _i64p]),
     "bath_hip_oprofile_set_consensus": (C.c_int, [_vp, C.c_char_p]),
     "bath_hip_domain_cigars": (C.c_void_p, [_vp]),
+    "bath_selftest_rng_stream": (C.c_int, [C.c_uint32, C.c_int, C.POINTER(C.c_double)]),
+    "bath_selftest_fchoose": (C.c_int, [C.c_uint32, _f32p, C.c_int, C.c_int, _i32p]),
     "bath_tophits_create": (_vp, []),
     "bath_tophits_destroy": (None, [_vp]),
     "bath_tophits_add": (C.c_int, [_vp, C.POINTER(FsDomain), C.c_int64, C.c_void_p, C.c_int64, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p),

@@ -391,3 +391,26 @@ int bath::fs_region_trace_ensemble(int M, const float *tsc, float xNL, float xNM
   cluster_segments(sp, nsamples, true, env);
   return BATH_OK;
 }
+
+
+// ---- self-test hooks (include/bath_hip.h): the restated easel pieces, callable without a GPU
+extern "C" int bath_selftest_rng_stream(uint32_t seed, int n, double *out) {
+  if (!out || n < 0) return BATH_EINVAL;
+  FastRng rng(seed);
+  for (int i = 0; i < n; i++) out[i] = rng.next();
+  return BATH_OK;
+}
+extern "C" int bath_selftest_fchoose(uint32_t seed, const float *p, int n, int draws, int32_t *out) {
+  if (!p || !out || n < 1 || n > 8 || draws < 0) return BATH_EINVAL;
+  FastRng rng(seed);
+  for (int d = 0; d < draws; d++) {
+    int r = 0;
+    switch (n) {
+#define BATH_ST_CASE(N) case N: { float v[N]; for (int q = 0; q < N; q++) v[q] = p[q]; r = choose<N>(rng, v); } break;
+      BATH_ST_CASE(1) BATH_ST_CASE(2) BATH_ST_CASE(3) BATH_ST_CASE(4) BATH_ST_CASE(5) BATH_ST_CASE(6) BATH_ST_CASE(7) BATH_ST_CASE(8)
+#undef BATH_ST_CASE
+    }
+    out[d] = r;
+  }
+  return BATH_OK;
+}

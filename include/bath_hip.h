@@ -422,6 +422,15 @@ int bath_hip_fs5_envelopes_x(bath_hip_ctx *ctx, const bath_hip_fsprofile *om5, c
 int bath_hip_fs5_forward_full(bath_hip_ctx *ctx, const bath_hip_fsprofile *om5, const bath_hip_seqs *dna, int cfg_len_amino,
                               float *sc, float *fwd, float *xmx);
 
+/* ------------------------------------------------------------------------------------------
+ * Self-test hooks (host only, no GPU): the pieces of easel the multi-domain branch restates -- esl_randomness_CreateFast /
+ * esl_random (p7_pipeline.c:140: the "fast" generator, x <- 69069 x + 1 on a Jenkins-mixed seed) and esl_vec_FNorm +
+ * esl_rnd_FChoose as p7_StochasticTrace calls them (stotrace.c:165-300) -- so that tests can hold them against independent
+ * implementations of the published algorithms.
+ * ------------------------------------------------------------------------------------------ */
+int bath_selftest_rng_stream(uint32_t seed, int n, double *out);                          /* the first n values of esl_random() after seeding */
+int bath_selftest_fchoose(uint32_t seed, const float *p, int n, int draws, int32_t *out); /* draws x (copy p, esl_vec_FNorm, esl_rnd_FChoose) from one stream */
+
 #ifdef __cplusplus
 }
 #endif
