@@ -6,7 +6,11 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "bath_hip.h"
@@ -65,6 +69,43 @@ struct HostBuf {
   }
   void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
   template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+// Host threads that stay alive across pipeline calls: one per concurrent part (lane) of a block.  run(k, f) has workers 0..k-1
+// call f(worker) and returns when all have finished.
+struct LanePool {
+  std::mutex m;
+  std::condition_variable cv_work, cv_done;
+  std::vector<std::thread> th;
+  std::function<void(int)> fn;
+  int gen = 0, pending = 0, K = 0;
+  bool stop = false;
+  void loop(int id) {
+    int seen = 0;
+    for (;;) {
+      std::function<void(int)> f;
+      {
+        std::unique_lock<std::mutex> l(m);
+        cv_work.wait(l, [&] { return stop || (gen != seen && id < K); });
+        if (stop) return;
+        seen = gen; f = fn;
+      }
+      f(id);
+      { std::lock_guard<std::mutex> l(m); if (--pending == 0) cv_done.notify_all(); }
+    }
+  }
+  void run(int k, std::function<void(int)> f) {
+    while ((int)th.size() < k) { const int id = (int)th.size(); th.emplace_back([this, id] { loop(id); }); }
+    { std::lock_guard<std::mutex> l(m); fn = std::move(f); K = k; pending = k; gen++; }
+    cv_work.notify_all();
+    std::unique_lock<std::mutex> l(m);
+    cv_done.wait(l, [&] { return pending == 0; });
+  }
+  ~LanePool() {
+    { std::lock_guard<std::mutex> l(m); stop = true; }
+    cv_work.notify_all();
+    for (std::thread &t : th) t.join();
+  }
 };
 
 struct StageTiming { const char *name; float ms; int64_t launches; };
@@ -132,6 +173,8 @@ struct bath_hip_ctx {
   void span_end(int idx, hipStream_t s) { if (idx >= 0) (void)hipEventRecord(spans[(size_t)idx].b, s); }
   // worker lanes: contexts with their own stream and scratch, used by the pipeline to run parts of a block concurrently
   std::vector<bath_hip_ctx *> lanes;
+  bath::LanePool *lane_pool = nullptr;   // the lanes' host threads, kept across calls
+  hipEvent_t ev_lanes = nullptr;         // orders the lanes' streams after what the context's stream holds (uploads, expansion kernels)
   bath_hip_ctx *aux = nullptr;   // a context of its own (stream, scratch) for the standard-branch domains that run beside the frameshift branch
   bath_hip_ctx *aux2 = nullptr;  // ... and one for the multi-domain regions' Forward, which runs beside the first batch of envelopes (strict mode)
 };
@@ -231,6 +274,11 @@ struct bath_hip_oprofile {
   int vit_NR = 0, vit_rw_pitch = 0;
   int16_t *d_vit_rw = nullptr; uint32_t *d_vit_tw2 = nullptr; int16_t *d_vit_rank = nullptr;
   mutable LenTables lt;
+  // The per-length tables and the emission thresholds grow on demand and the profile is shared by the clones of several host
+  // threads (p7_oprofile_Clone): growth is serialised, and a replaced table is kept until the profile dies -- a kernel of
+  // another thread may still be reading it.
+  mutable std::mutex grow_mu;
+  mutable std::vector<void *> retired;
   // SSV emission thresholds per ORF length for the pipeline (bath_pipeline.hip: build_emit_table), cached per F1
   mutable int16_t *d_emit = nullptr;
   mutable double emit_F1 = -1.0;

@@ -47,7 +47,8 @@ double exp_logsurv(double x, double mu, double lambda) { return x < mu ? 0.0 : -
 // Host threads for the regions of one block (independent of each other).  work(first, step) handles items first, first + step,
 // ...; the threads draw single items from a shared counter, heaviest first (<weight>), so that the threads finish together.
 // Thread count: the CPUs this process may run on (its affinity mask, not the machine's thread count: a GPU box hands a job a
-// slice of its cores), at most 64; BATH_HIP_HOST_THREADS overrides.
+// slice of its cores), at most 64, divided by the ranks that share the node -- LOCAL_WORLD_SIZE, which torch.distributed.run
+// exports: one process per GPU, each with its own ensembles; BATH_HIP_HOST_THREADS overrides.
 inline int host_thread_count() {
   const char *e = std::getenv("BATH_HIP_HOST_THREADS");
   if (e && std::atoi(e) > 0) return std::atoi(e);
@@ -55,7 +56,9 @@ inline int host_thread_count() {
   cpu_set_t set;
   if (sched_getaffinity(0, sizeof set, &set) == 0) usable = CPU_COUNT(&set);
   if (usable <= 0) usable = (int)std::max(1u, std::thread::hardware_concurrency());
-  return std::min(64, std::max(1, usable));
+  int ranks = 1;
+  if (const char *lw = std::getenv("LOCAL_WORLD_SIZE")) ranks = std::max(1, std::atoi(lw));
+  return std::min(64, std::max(1, usable / ranks));
 }
 template <class F, class W>
 void run_striped(int64_t n, F &&work, W &&weight) {

@@ -1405,7 +1405,7 @@ namespace bath {
 
 static int fs_columns(int M) {
   const int c = (M + 63) / 64;
-  for (int opt : {1, 2, 3, 4, 6, 8, 12, 16}) if (c <= opt) return opt;
+  for (int opt : {1, 2, 3, 4, 6, 8, 12, 16, 20}) if (c <= opt) return opt;
   return -1;
 }
 
@@ -1419,7 +1419,8 @@ static int fs_columns(int M) {
     case 8: { constexpr int CC = 8; BODY } break;         \
     case 12: { constexpr int CC = 12; BODY } break;       \
     case 16: { constexpr int CC = 16; BODY } break;       \
-    default: ctx->set_error("frameshift kernels support models up to 1024 nodes"); return BATH_EINVAL; \
+    case 20: { constexpr int CC = 20; BODY } break;       \
+    default: ctx->set_error("frameshift kernels support models up to 1280 nodes"); return BATH_EINVAL; \
   }
 
 // logsum_mode -> kernel MODE: 0 table + wavefront scans, 1 exact log-sums, 2 table in the reference's serial order ("strict")

@@ -524,7 +524,8 @@ static int chain_waves(int M, int C, size_t *shmem_out) {
     case 8: { constexpr int CC = 8; BODY } break;         \
     case 12: { constexpr int CC = 12; BODY } break;       \
     case 16: { constexpr int CC = 16; BODY } break;       \
-    default: ctx->set_error("frameshift kernels support models up to 1024 nodes"); return BATH_EINVAL; \
+    case 20: { constexpr int CC = 20; BODY } break;       \
+    default: ctx->set_error("frameshift kernels support models up to 1280 nodes"); return BATH_EINVAL; \
   }
 
 int launch_fs3_fwd_chain(bath_hip_ctx *ctx, hipStream_t stream, const bath_hip_fsprofile *om, const bath_hip_seqs *dna, int Cv, float tEL, float tEM,

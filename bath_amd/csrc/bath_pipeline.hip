@@ -519,10 +519,11 @@ static void build_emit_table(const bath_hip_oprofile *om, double F1, int maxlen,
 
 // The table depends on the model, F1 and the longest ORF only: kept with the profile (host and device) between calls.
 static int ensure_emit_table(bath_hip_ctx *ctx, const bath_hip_oprofile *om, double F1, int maxlen) {
+  std::lock_guard<std::mutex> lock(om->grow_mu);
   if (om->emit_F1 == F1 && om->emit_maxlen >= maxlen && om->d_emit) return BATH_OK;
   std::vector<int16_t> tab;
   build_emit_table(om, F1, maxlen, tab);
-  if (om->d_emit) (void)hipFree(om->d_emit);
+  if (om->d_emit) om->retired.push_back(om->d_emit);            // freed with the profile (bath_hip_oprofile_destroy)
   om->d_emit = nullptr;
   BATH_HIP_TRY(ctx, hipMalloc((void **)&om->d_emit, tab.size() * sizeof(int16_t) + 64));
   BATH_HIP_TRY(ctx, hipMemcpy(om->d_emit, tab.data(), tab.size() * sizeof(int16_t), hipMemcpyHostToDevice));
@@ -838,6 +839,8 @@ static int run_filters(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bat
     // there: bath_hip_pipeline_filters copies every part's records straight into their place in one page-locked array.
     bath_orf_result *d_rec = nullptr;
     int64_t nrec = 0;
+    // the records' sort key holds the window in 32 bits and the ORF's first codon in 28 (bath_records.hip)
+    if (dna->n > (int64_t)UINT32_MAX || dna->maxlen / 3 >= (1 << 28)) { ctx->set_error("block too large for the ORF records' sort key (2^32 windows, 805 Mnt per window)"); return BATH_ERANGE; }
     if ((st = build_orf_records(ctx, W.cand, hc.cand_count, dna->is_part ? dna->first_window : 0, &d_rec, &nrec)) != BATH_OK) return st;
     ctx->d_records = d_rec; ctx->n_records = nrec;
     if (!dna->is_part) {
@@ -864,7 +867,12 @@ static int pipeline_lane_count(const bath_hip_seqs *dna) {
   if (dna->is_part || dna->n < 8) return 1;
   // measured on MI355X, 10^6 x 1 kb: 1 lane 17.2 ms, 2 lanes 15.5 ms per pass; 3 lanes 15.4-19.3 ms depending on how the
   // persistent grids of the three parts happen to interleave, 4 lanes 19.7 ms: two lanes is the robust choice
-  return (dna->total >= ((int64_t)1 << 28)) ? 2 : 1;           // blocks under 256 MB: one launch sequence is short enough
+  int K = (dna->total >= ((int64_t)1 << 28)) ? 2 : 1;           // blocks under 256 MB: one launch sequence is short enough
+  // ... and as many parts as it takes to keep a part's ORF list within 32-bit indices (run_filters: ~1 ORF per 27 nt on both
+  // strands of iid DNA; a part of 16 GB holds ~6e8): a larger block is cut into more parts instead of being refused
+  const int64_t by_size = (dna->total + ((int64_t)1 << 34) - 1) >> 34;
+  if (by_size > K) K = (int)std::min<int64_t>(by_size, std::max<int64_t>(dna->n, 1));
+  return K;
 }
 
 static int ensure_parts(bath_hip_ctx *ctx, const bath_hip_seqs *dna, int K) {
@@ -952,14 +960,17 @@ static int run_filters_lanes(bath_hip_ctx *ctx, const bath_hip_oprofile *om, con
   std::vector<int64_t> pn((size_t)K, 0);
   std::vector<int> rc((size_t)K, BATH_OK);
   states->assign((size_t)K, FilterState{});
-  std::vector<std::thread> th;
-  for (int k = 0; k < K; k++)
-    th.emplace_back([&, k] {
-      bath_hip_ctx *lane = ctx->lanes[(size_t)k];
-      rc[(size_t)k] = run_filters(lane, om, dna->parts[(size_t)k], prm, &pst[(size_t)k], results ? &pres[(size_t)k] : nullptr, &pn[(size_t)k], &(*states)[(size_t)k]);
-      if (rc[(size_t)k] == BATH_OK) rc[(size_t)k] = after(k, lane, dna->parts[(size_t)k], (*states)[(size_t)k]);
-    });
-  for (std::thread &t : th) t.join();
+  // The lanes' streams are non-blocking streams of their own: nothing orders them after the context's stream, which may still
+  // hold the block's upload and expansion kernels (bath_hip_seqs_upload_packed / _upload_wait) or the part offsets copied above.
+  if (!ctx->ev_lanes) BATH_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_lanes, hipEventDisableTiming));
+  BATH_HIP_TRY(ctx, hipEventRecord(ctx->ev_lanes, ctx->stream));
+  for (int k = 0; k < K; k++) BATH_HIP_TRY(ctx, hipStreamWaitEvent(ctx->lanes[(size_t)k]->stream, ctx->ev_lanes, 0));
+  if (!ctx->lane_pool) ctx->lane_pool = new LanePool();            // the lanes' host threads live as long as the context
+  ctx->lane_pool->run(K, [&](int k) {
+    bath_hip_ctx *lane = ctx->lanes[(size_t)k];
+    rc[(size_t)k] = run_filters(lane, om, dna->parts[(size_t)k], prm, &pst[(size_t)k], results ? &pres[(size_t)k] : nullptr, &pn[(size_t)k], &(*states)[(size_t)k]);
+    if (rc[(size_t)k] == BATH_OK) rc[(size_t)k] = after(k, lane, dna->parts[(size_t)k], (*states)[(size_t)k]);
+  });
   for (int k = 0; k < K; k++)
     if (rc[(size_t)k] != BATH_OK) { ctx->set_error(ctx->lanes[(size_t)k]->err); return rc[(size_t)k]; }
 
@@ -1205,12 +1216,13 @@ static int select_survivors(bath_hip_ctx *lane, const FilterState &S, bool want_
 static int filters_with_survivors(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bath_hip_seqs *dna, const bath_pipeline_params *prm,
                                   bath_pipeline_stats *stats, const bath_orf_result **results, int64_t *n_results, bool want_wins, SurvivorSet *out) {
   std::vector<FilterState> states;
-  std::vector<std::vector<FsCandRec>> lsel(8);
-  std::vector<std::vector<WindowRec>> lwin(8);
-  std::vector<int64_t> first(8, 0);
+  const size_t nl = (size_t)std::max(1, pipeline_lane_count(dna));
+  std::vector<std::vector<FsCandRec>> lsel(nl);
+  std::vector<std::vector<WindowRec>> lwin(nl);
+  std::vector<int64_t> first(nl, 0);
   int st = run_filters_lanes(ctx, om, dna, prm, stats, results, n_results, &states,
                              [&](int k, bath_hip_ctx *lane, const bath_hip_seqs *part, const FilterState &S) {
-                               if (k >= 8) return (int)BATH_EFAIL;
+                               if ((size_t)k >= nl) { lane->set_error("more pipeline lanes than the survivor merge was sized for"); return (int)BATH_EFAIL; }
                                first[(size_t)k] = part->is_part ? part->first_window : 0;
                                return select_survivors(lane, S, want_wins, &lsel[(size_t)k], &lwin[(size_t)k]);
                              });

@@ -68,12 +68,14 @@ static hipError_t upload(T **dst, const T *src, size_t n, hipStream_t st) {
 }
 
 int build_len_tables(const bath_hip_oprofile *om, int maxL) {
+  std::lock_guard<std::mutex> lock(om->grow_mu);
   LenTables &lt = om->lt;
   if (maxL <= lt.maxL) return BATH_OK;
   bath_hip_ctx *ctx = om->ctx;
   int n = std::max(maxL, 4096) + 1;
   for (void *p : {(void *)lt.d_tjb, (void *)lt.d_xwmove, (void *)lt.d_pmove, (void *)lt.d_nullsc, (void *)lt.d_lt1, (void *)lt.d_lt2, (void *)lt.d_p1})
-    if (p) (void)hipFree(p);
+    if (p) om->retired.push_back(p);                            // freed with the profile: another thread's kernel may be reading it
+  lt.d_tjb = nullptr; lt.d_xwmove = nullptr; lt.d_pmove = nullptr; lt.d_nullsc = nullptr; lt.d_lt1 = nullptr; lt.d_lt2 = nullptr; lt.d_p1 = nullptr;
   lt.h_tjb.resize(n); lt.h_xwmove.resize(n); lt.h_pmove.resize(n); lt.h_nullsc.resize(n);
   std::vector<float> lt1(n), lt2(n), p1v(n);
   for (int L = 0; L < n; L++) {
@@ -125,8 +127,11 @@ extern "C" void bath_hip_finalize(bath_hip_ctx *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
+  delete ctx->lane_pool; ctx->lane_pool = nullptr;                 // joins the lanes' host threads
   for (bath_hip_ctx *lane : ctx->lanes) bath_hip_finalize(lane);
   ctx->lanes.clear();
+  if (ctx->ev_lanes) (void)hipEventDestroy(ctx->ev_lanes);
+  if (ctx->tail_stream) (void)hipStreamDestroy(ctx->tail_stream);
   if (ctx->aux) { bath_hip_finalize(ctx->aux); ctx->aux = nullptr; }
   if (ctx->aux2) { bath_hip_finalize(ctx->aux2); ctx->aux2 = nullptr; }
   for (auto &b : ctx->scratch) b.release();
@@ -181,6 +186,7 @@ extern "C" void bath_hip_oprofile_destroy(bath_hip_oprofile *om) {
                   (void *)om->d_bias_eo, (void *)om->d_vit_rw, (void *)om->d_vit_tw2, (void *)om->d_vit_rank, (void *)om->lt.d_tjb, (void *)om->lt.d_xwmove, (void *)om->lt.d_pmove,
                   (void *)om->lt.d_nullsc, (void *)om->lt.d_lt1, (void *)om->lt.d_lt2, (void *)om->lt.d_p1, (void *)om->d_cons, (void *)om->d_msc, (void *)om->d_tsc, (void *)om->d_rfb, (void *)om->d_tfb})
     if (p) (void)hipFree(p);
+  for (void *p : om->retired) (void)hipFree(p);
   delete om;
 }
 
@@ -543,10 +549,14 @@ extern "C" int bath_hip_seqs_create_packed(bath_hip_ctx *ctx, const int64_t *off
   std::vector<int64_t> poff((size_t)n + 1, 0);
   for (int64_t i = 0; i < n; i++) poff[(size_t)i + 1] = poff[(size_t)i] + (sq->h_len[(size_t)i] + 3) / 4;
   sq->packed_bytes = poff[(size_t)n];
-  BATH_HIP_TRY(ctx, hipMalloc((void **)&sq->d_packed, (size_t)sq->packed_bytes + 64));
-  BATH_HIP_TRY(ctx, hipMalloc((void **)&sq->d_poff, (size_t)(n + 1) * sizeof(int64_t)));
-  BATH_HIP_TRY(ctx, hipMemcpy(sq->d_poff, poff.data(), (size_t)(n + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
-  BATH_HIP_TRY(ctx, hipEventCreateWithFlags(&sq->ev_upload, hipEventDisableTiming));
+  auto packed_parts = [&]() -> int {
+    BATH_HIP_TRY(ctx, hipMalloc((void **)&sq->d_packed, (size_t)sq->packed_bytes + 64));
+    BATH_HIP_TRY(ctx, hipMalloc((void **)&sq->d_poff, (size_t)(n + 1) * sizeof(int64_t)));
+    BATH_HIP_TRY(ctx, hipMemcpy(sq->d_poff, poff.data(), (size_t)(n + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+    BATH_HIP_TRY(ctx, hipEventCreateWithFlags(&sq->ev_upload, hipEventDisableTiming));
+    return BATH_OK;
+  };
+  if ((st = packed_parts()) != BATH_OK) { bath_hip_seqs_destroy(sq); return st; }      // nothing of a half-built block is left behind
   *ret = sq;
   return BATH_OK;
 }

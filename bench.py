@@ -514,6 +514,10 @@ def main():
         if not args.no_c45 and world == 1:
             out["c4"] = c4_leg(ba, synth, bdist, ctx, args, c45_cpu)
             out["c5"] = c5_leg(ba, synth, bdist, ctx, args, c45_cpu)
+    if world > 1 and not args.no_fs:                        # every rank takes part; rank 0 reports
+        fs_multi = fs_leg_ranks(ba, synth, bdist, dist, ctx if on_gpu else None, hmm, om if on_gpu else None, args, rank, world, dev, on_gpu, sync)
+        if rank == 0:
+            out["fs"] = fs_multi
     if rank == 0:
         print(json.dumps(out))
         sys.stdout.flush()
@@ -562,6 +566,45 @@ def streamed_leg(ba, ctx, pipe, flat, offsets, args, stats_resident):
                                  "stream, upload of block k+1 overlapping the cascade of block k, expansion kernel on the device, surviving ORF records "
                                  "copied to the host inside the step (with_records)" % (len(packed) / 1e6, len(flat) / 1e6),
                          "steps": steps, "upload_and_expand_ms_unoverlapped": upload_ms, **out}}
+
+
+def fs_leg_ranks(ba, synth, bdist, dist, ctx, hmm, om, args, rank, world, dev, on_gpu, sync):
+    """BASELINE configs[2] under --gpus N: ONE block of --fs-windows windows dealt to the ranks in contiguous shards (strong scaling,
+    what the reference's block queue does); every rank runs the whole --fs path on its shard, the counters are reduced and the
+    domains -- records and CIGAR strings -- gathered on rank 0 (dist.gather_domains), inside the timed region."""
+    lo, hi = bdist.shard_range(args.fs_windows, rank, world)
+    if on_gpu:
+        flat, offsets, _ = synth.dna_windows(args.fs_windows, args.length, seed=4242, hmm=hmm, frameshift=True)
+        mine = flat[lo * args.length:hi * args.length].copy()
+        del flat
+        dna = ba.SeqBlock(ctx, mine, np.arange(hi - lo + 1, dtype=np.int64) * args.length)
+        om3 = ba.FSOProfile(ctx, ba.FSProfile(hmm, 3, ncbi_table=hmm.ct))
+        om5 = ba.FSOProfile(ctx, ba.FSProfile(hmm, 5, ncbi_table=hmm.ct))
+        pipe = ba.Pipeline(ctx, om, fs_pipe=True, ncbi_table=hmm.ct)
+        pipe.run_frameshift_domains(om3, om5, dna)
+    steps = 2
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        if on_gpu:
+            stats, fw, dm, nskip = pipe.run_frameshift_domains(om3, om5, dna)
+        else:                                              # --plumbing-only: fabricated records, the collectives are what runs
+            stats = ba.PipelineStats(); stats.nres = 2 * (hi - lo) * args.length
+            dm = []
+            for w in range(min(hi - lo, 3)):
+                d = ba.FsDomain(); d.window = w; d.reported = 1; d.cigar = "%dM" % (w + 1)
+                dm.append(d)
+        gathered = bdist.gather_domains(dm, lo, 0, dev)
+        merged = bdist.reduce_stats(stats, dev)
+    sync()
+    dt = bdist.max_over_ranks((time.perf_counter() - t0) / steps, dev)
+    if rank != 0:
+        return None
+    return {"workload": "Caudal_act.bhmm --fs vs %d x %d nt windows in total, sharded over %d GPUs (strong scaling); domains gathered on rank 0 inside the timed region"
+                        % (args.fs_windows, args.length, world),
+            "ms_per_pass": dt * 1e3, "residues_per_s": merged["nres"] / dt, "scaling": "strong", "n_gpus": world,
+            "domains_gathered": len(gathered), "windows_of_gathered_domains_are_global": bool(all(0 <= d.window < args.fs_windows for d in gathered)),
+            "mode": "strict (the library's default)"}
 
 
 def fs_leg(ba, synth, ctx, hmm, om, args):

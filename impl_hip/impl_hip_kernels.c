@@ -176,8 +176,9 @@ int p7_ForwardParser(const ESL_DSQ *dsq, int L, const P7_OPROFILE *om, P7_OMX *f
   if (!om->dev) ESL_EXCEPTION(eslEINVAL, "profile not converted");
   if (fwd->allocXR < L + 1) ESL_EXCEPTION(eslEINVAL, "matrix too small");
   struct impl_hip_pass *p = ih_pass_new(IH_STD_PARSER, dsq, L, om->M);
-  if (!p || !(p->bx = malloc(sizeof(float) * (size_t)(L + 1) * 6))) return eslEMEM;
-  if (ih_block(dsq, L, &sq) != eslOK) return eslFAIL;
+  if (!p) return eslEMEM;
+  if (!(p->bx = malloc(sizeof(float) * (size_t)(L + 1) * 6))) { impl_hip_pass_release(p); return eslEMEM; }
+  if (ih_block(dsq, L, &sq) != eslOK) { impl_hip_pass_release(p); return eslFAIL; }
   const int st = bath_hip_fwdback_parser(impl_hip_context(), om->dev, sq, xoff, &fsc, &bsc, &fst, &bst, fwd->xmx, p->bx);
   bath_hip_seqs_destroy(sq);
   if (st != BATH_OK) { impl_hip_pass_release(p); ESL_EXCEPTION(eslFAIL, "impl_hip: %s", bath_hip_last_error(impl_hip_context())); }

@@ -103,7 +103,7 @@ def test_bench_launcher_starts_the_ranks(scaling):
     import json
     import subprocess
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--plumbing-only", "--windows", "1001", "--scaling", scaling],
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--plumbing-only", "--windows", "1001", "--fs-windows", "1001", "--scaling", scaling],
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
@@ -113,3 +113,6 @@ def test_bench_launcher_starts_the_ranks(scaling):
     total = 1001 if scaling == "strong" else 2002                    # strong: one block sharded; weak: a block per rank
     assert out["residues_per_step"] == 2 * 1000 * total              # counters reduced over both ranks
     assert out["survivors"]["n_past_msv"] == total
+    # the --fs leg stays under --gpus N: one block sharded over the ranks, counters reduced, domains gathered on rank 0
+    fs = out["fs"]
+    assert fs["n_gpus"] == 2 and fs["scaling"] == "strong" and fs["domains_gathered"] == 6 and fs["windows_of_gathered_domains_are_global"]

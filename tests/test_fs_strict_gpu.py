@@ -111,9 +111,11 @@ def test_strict_pipeline_is_exact_on_clustered_regions(gpu_ctx):
     assert n_fs >= 4
 
 
-def test_strict_pipeline_is_exact_with_a_1024_node_model(gpu_ctx, tmp_path):
-    """BASELINE configs[4]'s model size: 16 nodes per lane in the chain kernels, the wavefront's ring in global memory."""
-    path = common.write_synthetic_bhmm(str(tmp_path / "s1024.bhmm"), 1024, seed=1024)
+@pytest.mark.parametrize("M", [1024, 1200])
+def test_strict_pipeline_is_exact_with_a_long_model(gpu_ctx, tmp_path, M):
+    """BASELINE configs[4]'s model size (16 nodes per lane in the chain kernels, the wavefront's ring in global memory) and one
+    beyond it (1200 nodes: the 20-nodes-per-lane instantiation -- configs[4] is not the edge of what the kernels take)."""
+    path = common.write_synthetic_bhmm(str(tmp_path / ("s%d.bhmm" % M)), M, seed=M)
     rng = np.random.default_rng(12)
     wins = P.frameshifted_windows(rng, ol.Model(path, 0), n=8, L_flank=60)[:10] + common.random_dna(rng, 4, 1200)
     out = run(gpu_ctx, path, wins)
