@@ -178,6 +178,161 @@ __global__ __launch_bounds__(chain_threads(C)) void fs3_fwd_chain_kernel(SeqView
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
+// The same for models of up to 32 x CH nodes with HALF a wave per window: 32 windows per block instead of 16, so the 7.6 k DNA
+// windows of a bench block are all resident at once (the parsers are chains of rows: a second round of windows costs the first
+// one's duration again) and every lane of the chain wave carries a row.  The special states move into the chain lanes (as in the
+// Backward kernel: a lane keeps N, J, C of its slot's last rows and gets row i-3 from its neighbour), so a window lane holds
+// nothing per window but its DP rows.
+// ---------------------------------------------------------------------------------------------------------------------------
+template <int CH>
+__global__ __launch_bounds__(1024) void fs3_fwd_chain_half_kernel(SeqView dna, FsDev p, const float *__restrict__ loop_tab, const float *__restrict__ move_tab,
+                                                                  float tEL, float tEM, float *__restrict__ sc, float *__restrict__ xmx, const int64_t *__restrict__ xmx_off, FsJobs jobs) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  float *s_tbl = reinterpret_cast<float *>(lds);
+  float *s_tf = s_tbl + kLogsumTbl;
+  const int M = p.M;
+  constexpr int W = 32;                                         // windows per block: two per wave
+  constexpr int stride = CH * 32 + 1;
+  float *s_stage = s_tf + (M + 2) * 8;                          // [W][2][stride]
+  float *s_b = s_stage + (size_t)W * 2 * stride;                // [W][2] B(i) of the pair's rows, from the chain lanes
+  int *s_ctl = reinterpret_cast<int *>(s_b + 2 * W);
+  fs_load_logsum_table(s_tbl, p.logsum);
+  for (int i = threadIdx.x; i < (M + 2) * 8; i += blockDim.x) s_tf[i] = p.tf[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int hl = lane & 31, win = wv * 2 + (lane >> 5);          // lane within its window's half wave; the window's slot in the block
+#define LS(a, b) flogsum<false>((a), (b), s_tbl)
+  auto shr1 = [&](float v) { const float r = wave_shr1(v, -INFINITY); return hl == 0 ? -INFINITY : r; };   // the neighbour move stays inside the half wave
+  for (;;) {
+    if (threadIdx.x == 0) s_ctl[0] = (int)atomicAdd(jobs.counter, (unsigned)W);
+    __syncthreads();
+    const int64_t base = s_ctl[0];
+    if (base >= dna.n) break;
+    const int64_t job = (base + win < dna.n) ? (int64_t)jobs.order[base + win] : (int64_t)-1;
+    const int Lmax = dna.len[jobs.order[base]];
+    const int L = job >= 0 ? dna.len[job] : 0;
+    const uint8_t *d = job >= 0 ? dna.data + dna.off[job] : dna.data;
+    // ---- the chain wave's lanes: lane c serves row slot (c & 1) of window (c >> 1)
+    const bool chain_lane = (wv == 0);
+    const int cw = lane >> 1, cs = lane & 1;
+    int64_t cjob = -1; int cL = 0; float *cxo = nullptr;
+    float ctNL = 0.f, ctNM = 0.f;
+    if (chain_lane && base + cw < dna.n) {
+      cjob = jobs.order[base + cw]; cL = dna.len[cjob];
+      if (xmx) cxo = xmx + xmx_off[cjob];
+      ctNL = loop_tab[cL / 3]; ctNM = move_tab[cL / 3];
+      if (cxo && cs == 0 && cL >= 3)
+        for (int i = 0; i < 2; i++) { cxo[i * 5 + 0] = -INFINITY; cxo[i * 5 + 1] = 0.f; cxo[i * 5 + 2] = -INFINITY; cxo[i * 5 + 3] = ctNM; cxo[i * 5 + 4] = -INFINITY; }
+    }
+    const bool clive = cjob >= 0 && cL >= 3;
+    float hN1 = 0.f, hN2 = 0.f, hJ1 = -INFINITY, hJ2 = -INFINITY, hC1 = -INFINITY, hC2 = -INFINITY;   // N, J, C of the slot's rows one and two pairs ago (rows 0, 1: N = 0)
+    float cfin1 = -INFINITY, cfin2 = -INFINITY, cfin3 = -INFINITY;                                      // C of the window's last three rows (slot 0's lane keeps them)
+    if (chain_lane) { s_b[lane] = ctNM; }                         // B(0) = B(1) = tNM
+    float M1[CH], I1[CH], D1[CH], M2[CH], I2[CH], D2[CH], M3[CH], I3[CH], iv_1[CH], iv_2[CH];
+#pragma unroll
+    for (int c = 0; c < CH; c++) M1[c] = I1[c] = D1[c] = M2[c] = I2[c] = D2[c] = M3[c] = I3[c] = iv_1[c] = iv_2[c] = -INFINITY;
+    auto nuc = [&](int i) -> int { return (i >= 1 && i <= L) ? ((d[i - 1] < 4) ? (int)d[i - 1] : 338) : 338; };
+    __syncthreads();
+    for (int i = 2; i <= Lmax; i += 2) {
+      const bool actB = job >= 0 && L >= 3 && i + 1 <= L;
+      const float B2 = s_b[win * 2 + 0], B1 = s_b[win * 2 + 1];   // B(i-2), B(i-1): the previous pair's rows
+      const int xa = nuc(i), wa = nuc(i - 1), va = nuc(i - 2), ua = nuc(i - 3), xb = nuc(i + 1);
+      const float *qa2 = p.rsc + (size_t)imin(xa * 84 + wa * 21, 337) * p.pitch;
+      const float *qa3 = p.rsc + (size_t)imin(xa * 84 + wa * 21 + va * 5 + 1, 336) * p.pitch;
+      const float *qa4 = p.rsc + (size_t)imin(xa * 84 + wa * 21 + va * 5 + ua + 2, 337) * p.pitch;
+      const float *qb2 = p.rsc + (size_t)imin(xb * 84 + xa * 21, 337) * p.pitch;
+      const float *qb3 = p.rsc + (size_t)imin(xb * 84 + xa * 21 + wa * 5 + 1, 336) * p.pitch;
+      const float *qb4 = p.rsc + (size_t)imin(xb * 84 + xa * 21 + wa * 5 + va + 2, 337) * p.pitch;
+      const float mInA = shr1(M2[CH - 1]), iInA = shr1(I2[CH - 1]), dInA = shr1(D2[CH - 1]);
+      const float mInB = shr1(M1[CH - 1]), iInB = shr1(I1[CH - 1]), dInB = shr1(D1[CH - 1]);
+      float MA[CH], IA[CH], ivA[CH], MB[CH], IB[CH], ivB[CH];
+#pragma unroll
+      for (int c = 0; c < CH; c++) {
+        const int node = hl * CH + c + 1, nd = imin(node, M + 1), ne = imin(node, M);
+        const float4 ta = *reinterpret_cast<const float4 *>(s_tf + nd * 8);
+        const float4 tb = *reinterpret_cast<const float4 *>(s_tf + nd * 8 + 4);
+        const bool in = node <= M;
+        const float ea2 = in ? qa2[ne] : -INFINITY, ea3 = in ? qa3[ne] : -INFINITY, ea4 = in ? qa4[ne] : -INFINITY;
+        const float eb2 = in ? qb2[ne] : -INFINITY, eb3 = in ? qb3[ne] : -INFINITY, eb4 = in ? qb4[ne] : -INFINITY;
+        const float mA = (c == 0) ? mInA : M2[c - 1], iA = (c == 0) ? iInA : I2[c - 1], dA = (c == 0) ? dInA : D2[c - 1];
+        float a = LS(mA + ta.x, LS(iA + ta.y, LS(dA + ta.z, B2 + ta.w)));
+        if (i == 2) a = B2 + ta.w;
+        ivA[c] = a;
+        float mv = a + ea2;
+        if (i > 2) { mv = LS(mv, iv_1[c] + ea3); mv = LS(mv, iv_2[c] + ea4); }
+        MA[c] = mv;
+        const float insA = LS(M3[c] + tb.z, I3[c] + tb.w);
+        IA[c] = (i > 2 && node < M) ? insA : -INFINITY;
+        const float mB = (c == 0) ? mInB : M1[c - 1], iB = (c == 0) ? iInB : I1[c - 1], dB = (c == 0) ? dInB : D1[c - 1];
+        const float b = LS(mB + ta.x, LS(iB + ta.y, LS(dB + ta.z, B1 + ta.w)));
+        ivB[c] = b;
+        float mw = b + eb2;
+        mw = LS(mw, a + eb3); mw = LS(mw, iv_1[c] + eb4);
+        MB[c] = mw;
+        const float insB = LS(M2[c] + tb.z, I2[c] + tb.w);
+        IB[c] = (node < M) ? insB : -INFINITY;
+        if (in) { s_stage[((size_t)win * 2 + 0) * stride + node] = mv; s_stage[((size_t)win * 2 + 1) * stride + node] = mw; }
+      }
+      lds_barrier();
+      // ---- the serial part: all 64 lanes of wave 0, a row each
+      if (chain_lane) {
+        float *st = s_stage + (size_t)lane * stride;
+        float dch = -INFINITY, ech = -INFINITY;
+        float Mn = st[1];
+        float2 tn = *reinterpret_cast<const float2 *>(s_tf + 1 * 8 + 4);
+        for (int k = 1; k <= M; k++) {
+          const float Mk = Mn;
+          const float2 t = tn;
+          Mn = st[k + 1];
+          tn = *reinterpret_cast<const float2 *>(s_tf + (k + 1) * 8 + 4);
+          st[k] = dch;
+          ech = LS(Mk, LS(dch, ech));
+          dch = LS(Mk + t.x, dch + t.y);
+        }
+        // special states of row i + cs (:592-603); row i-3 is the other slot's row of two pairs ago (slot 0) or of the previous pair (slot 1)
+        const float pN1 = __shfl_xor(hN1, 1, 64), pN2 = __shfl_xor(hN2, 1, 64), pJ1 = __shfl_xor(hJ1, 1, 64), pJ2 = __shfl_xor(hJ2, 1, 64);
+        const float pC1 = __shfl_xor(hC1, 1, 64), pC2 = __shfl_xor(hC2, 1, 64);
+        const float uN = cs ? pN1 : pN2, uJ = cs ? pJ1 : pJ2, uC = cs ? pC1 : pC2;
+        const int irow = i + cs;
+        float xN, xJ, xC;
+        if (irow == 2) { xN = 0.f; xJ = ech + tEL; xC = ech + tEM; }
+        else { xN = uN + ctNL; xJ = LS(uJ + ctNL, ech + tEL); xC = LS(uC + ctNL, ech + tEM); }
+        const float xB = LS(xN + ctNM, xJ + ctNM);
+        s_b[lane] = xB;
+        const bool arow = clive && irow <= cL;
+        if (arow && cxo) { float *r = cxo + (size_t)irow * 5; r[0] = ech; r[1] = xN; r[2] = xJ; r[3] = xB; r[4] = xC; }
+        hN2 = hN1; hN1 = xN; hJ2 = hJ1; hJ1 = xJ; hC2 = hC1; hC1 = xC;
+        // C(L), C(L-1), C(L-2) for the score: both slots' C in row order, kept by slot 0's lane
+        const float cB = __shfl_xor(xC, 1, 64);                   // the other slot's C of this pair
+        if (cs == 0 && clive) {
+          if (i <= cL) { cfin3 = cfin2; cfin2 = cfin1; cfin1 = xC; }
+          if (i + 1 <= cL) { cfin3 = cfin2; cfin2 = cfin1; cfin1 = cB; }
+          if (i == cL || i + 1 == cL) sc[cjob] = LS(cfin1, LS(cfin2 + ctNL, cfin3 + ctNL)) + ctNM;
+        }
+      }
+      lds_barrier();
+      float DA[CH], DB[CH];
+#pragma unroll
+      for (int c = 0; c < CH; c++) {
+        const int node = hl * CH + c + 1, ne = imin(node, M);
+        const float da = s_stage[((size_t)win * 2 + 0) * stride + ne], db = s_stage[((size_t)win * 2 + 1) * stride + ne];
+        DA[c] = (node <= M) ? da : -INFINITY; DB[c] = (node <= M) ? db : -INFINITY;
+      }
+      if (actB) {
+#pragma unroll
+        for (int c = 0; c < CH; c++) {
+          M3[c] = M1[c]; I3[c] = I1[c]; M2[c] = MA[c]; I2[c] = IA[c]; D2[c] = DA[c]; M1[c] = MB[c]; I1[c] = IB[c]; D1[c] = DB[c];
+          iv_2[c] = ivA[c]; iv_1[c] = ivB[c];
+        }
+      }
+    }
+    if (chain_lane && cs == 0 && cjob >= 0 && cL < 3) sc[cjob] = -INFINITY;
+    __syncthreads();
+  }
+#undef LS
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
 // 3-codon Backward parser, multihit, strict.  tb[node] = {tMD(k), tMI(k), tMM(k), tDD(k), tDM(k), tII(k), tIM(k), tBM(k-1)}
 // Rows come in pairs from the END of each window: pair q holds the rows L-2q and L-2q-1 (they do not read each other: row i
 // reads M(i+2..i+4) and I(i+3)), so the row TYPE -- no codon fits yet / fewer than the three codon lengths fit / main
@@ -532,10 +687,25 @@ int launch_fs3_fwd_chain(bath_hip_ctx *ctx, hipStream_t stream, const bath_hip_f
                          float *d_sc, float *d_xmx, const int64_t *d_xoff, FsJobs jobs) {
   const int M = om->M;
   size_t shmem = 0;
-  const int W = chain_waves(M, Cv, &shmem);
   const int64_t n = dna->n;
-  const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((n + W - 1) / W, (int64_t)ctx->prop.multiProcessorCount));
   FsDev dev{om->M, om->pitch, om->maxcodons, om->d_rsc, om->d_tf, om->d_tb, om->d_logsum};
+  // half a wave per window when the model fits 32 lanes x 6 nodes and there are more windows than a wave each would keep resident
+  static const bool no_half = [] { const char *e = std::getenv("BATH_HIP_FS_FULLWAVE"); return e && e[0] == '1'; }();
+  const int CH = (M + 31) / 32;
+  static const bool force_half = [] { const char *e = std::getenv("BATH_HIP_FS_HALFWAVE"); return e && e[0] == '1'; }();     // tests: also for a handful of windows
+  if (!no_half && CH <= 6 && (force_half || n > (int64_t)ctx->prop.multiProcessorCount * 8)) {
+    const size_t hs = (size_t)(kLogsumTbl + (M + 2) * 8 + 32 * 2 * (CH * 32 + 1) + 64 + 16) * sizeof(float);
+    const int hgrid = (int)std::max<int64_t>(1, std::min<int64_t>((n + 31) / 32, (int64_t)ctx->prop.multiProcessorCount));
+#define BATH_HALF(C_)                                                                                                              \
+    case C_: BATH_HIP_TRY(ctx, hipFuncSetAttribute((const void *)fs3_fwd_chain_half_kernel<C_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hs)); \
+             hipLaunchKernelGGL((fs3_fwd_chain_half_kernel<C_>), dim3(hgrid), dim3(1024), hs, stream, dna->view(), dev, om->d_loop[0], om->d_move[0], tEL, tEM, d_sc, d_xmx, d_xoff, jobs); break;
+    switch (CH) { BATH_HALF(1) BATH_HALF(2) BATH_HALF(3) BATH_HALF(4) BATH_HALF(5) BATH_HALF(6) }
+#undef BATH_HALF
+    BATH_HIP_TRY(ctx, hipGetLastError());
+    return BATH_OK;
+  }
+  const int W = chain_waves(M, Cv, &shmem);
+  const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((n + W - 1) / W, (int64_t)ctx->prop.multiProcessorCount));
   BATH_CHAIN_SWITCH(Cv, {
     BATH_HIP_TRY(ctx, hipFuncSetAttribute((const void *)fs3_fwd_chain_kernel<CC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     hipLaunchKernelGGL((fs3_fwd_chain_kernel<CC>), dim3(grid), dim3(64 * W), shmem, stream, dna->view(), dev, om->d_loop[0], om->d_move[0], tEL, tEM, d_sc, d_xmx, d_xoff, jobs);
