@@ -287,6 +287,16 @@ static int fs_branch_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, con
       // through the chip WHILE the regions' Forward runs: it gets a context of its own (stream, gather pool, offsets, job list).
       if (ctx->fs_strict && !ctx->aux2) {
         if ((st = bath_hip_init(ctx->device, &ctx->aux2)) != BATH_OK) { ctx->set_error("cannot create the context of the regions' Forward"); return st; }
+        // HIP multiplexes its streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default) and two streams that land on one
+        // queue run their kernels one after the other: with a dozen streams alive (lanes, side, copy, the standard branch) the
+        // regions' Forward ended up behind the envelope kernels it is meant to run beside (+13 ms per pass in bench.py's process).
+        // Streams of another priority get queues of their own; the regions' Forward is the critical path of this stage anyway.
+        int lo = 0, hi = 0;
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi) {
+          hipStream_t ps = nullptr;
+          if (hipStreamCreateWithPriority(&ps, hipStreamNonBlocking, hi) == hipSuccess) { (void)hipStreamDestroy(ctx->aux2->stream); ctx->aux2->stream = ps; }
+          else (void)hipGetLastError();
+        }
       }
       rctx = ctx->fs_strict ? ctx->aux2 : ctx;
       if (rctx != ctx) { rctx->fs_strict = ctx->fs_strict; rctx->spans_reset(); }
