@@ -660,11 +660,18 @@ __global__ __launch_bounds__(chain_threads(C)) void fs5_fwd_chain_kernel(SeqView
 #undef LS
 }
 
-static int chain_waves(int M, int C, size_t *shmem_out) {
-  // as many windows per block as LDS holds next to the table and the transitions (one block per CU)
+static int chain_waves(bath_hip_ctx *ctx, int64_t n, int M, int C, size_t *shmem_out) {
+  // as many windows per block as LDS holds next to the table and the transitions ...
   const size_t fixed = (size_t)(kLogsumTbl + (M + 2) * 8 + 2 * kChainMaxWaves + 16) * sizeof(float);
   int W = chain_threads(C) / 64;
   while (W > 1 && fixed + (size_t)W * 2 * fs_chain_stride(C) * sizeof(float) > 160 * 1024) W >>= 1;
+  // ... but no more than it takes to give every block a CU of its own: the waves of a block go through the parallel part of a
+  // row one after the other on the CU's four SIMDs, which is time on top of the chain's, so with few windows (the regions: a
+  // couple of hundred) a block holds one or two.  Two blocks on one CU is worse than one twice the size: the chain wave of one
+  // then shares its SIMD with the other's parallel part and every dependent log-sum waits for an issue slot (measured: the
+  // Backward parser of 2.5 k windows 14.8 ms as 157 blocks of 16, 17.8 ms as 313 blocks of 8).
+  const int64_t slots = (int64_t)ctx->prop.multiProcessorCount;
+  while (W > 1 && (int64_t)(W / 2) * slots >= n) W >>= 1;
   *shmem_out = fixed + (size_t)W * 2 * fs_chain_stride(C) * sizeof(float);
   return W;
 }
@@ -704,7 +711,7 @@ int launch_fs3_fwd_chain(bath_hip_ctx *ctx, hipStream_t stream, const bath_hip_f
     BATH_HIP_TRY(ctx, hipGetLastError());
     return BATH_OK;
   }
-  const int W = chain_waves(M, Cv, &shmem);
+  const int W = chain_waves(ctx, dna->n, M, Cv, &shmem);
   const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((n + W - 1) / W, (int64_t)ctx->prop.multiProcessorCount));
   BATH_CHAIN_SWITCH(Cv, {
     BATH_HIP_TRY(ctx, hipFuncSetAttribute((const void *)fs3_fwd_chain_kernel<CC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
@@ -718,7 +725,7 @@ int launch_fs3_bwd_chain(bath_hip_ctx *ctx, hipStream_t stream, const bath_hip_f
                          float *d_sc, float *d_xmx, const int64_t *d_xoff, FsJobs jobs) {
   const int M = om->M;
   size_t shmem = 0;
-  const int W = chain_waves(M, Cv, &shmem);
+  const int W = chain_waves(ctx, dna->n, M, Cv, &shmem);
   const int64_t n = dna->n;
   const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((n + W - 1) / W, (int64_t)ctx->prop.multiProcessorCount));
   FsDev dev{om->M, om->pitch, om->maxcodons, om->d_rsc, om->d_tf, om->d_tb, om->d_logsum};
@@ -734,7 +741,7 @@ int launch_fs5_fwd_chain(bath_hip_ctx *ctx, hipStream_t stream, const bath_hip_f
                          float *d_sc, float *d_fwd, const int64_t *d_foff, float *d_xmx, const int64_t *d_xoff, int cfg_len, FsJobs jobs, int *d_done) {
   const int M = om->M;
   size_t shmem = 0;
-  const int W = chain_waves(M, Cv, &shmem);
+  const int W = chain_waves(ctx, dna->n, M, Cv, &shmem);
   const int64_t n = dna->n;
   const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((n + W - 1) / W, (int64_t)ctx->prop.multiProcessorCount));
   FsDev dev{om->M, om->pitch, om->maxcodons, om->d_rsc, om->d_tf, om->d_tb, om->d_logsum};
