@@ -30,13 +30,21 @@ namespace bath {
 #endif
 constexpr int kWfBlock = BATH_WF_BLOCK;        // 1024: one block per CU, 16 waves share one 64 KB log-sum table
 constexpr int kWfWaves = kWfBlock / 64;
+// a barrier that waits for LDS operations only: the waves of a multi-wave sweep exchange through LDS; their stores to the
+// matrices need not have landed
+__device__ __forceinline__ void lds_wf_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // Forward.  fwd[(i*(M+1)+k)*8 + {D,I,C0..C5}], xmx[i*5 + {E,N,J,B,C}] as fs5_fwd_kernel writes them.
 // tf[node] = {tMM(k-1), tIM(k-1), tDM(k-1), tBM(k-1), tMD(k), tDD(k), tMI(k), tII(k)}
 // ---------------------------------------------------------------------------------------------------------------------------
-template <bool EXACT, bool RING_G>
-__global__ __launch_bounds__(kWfBlock) void fs5_fwd_wf_kernel(SeqView dna, FsDev p, const float *__restrict__ loop_tab, const float *__restrict__ move_tab,
+// W: waves per envelope.  W = 1: every wave of a 1024-thread block draws its own envelopes (the throughput configuration: thousands
+// of envelopes).  W > 1: a block of W waves works on ONE envelope with 64 W rows in flight -- for a few long envelopes (the
+// clusters' batch of a pass; the 1024-node model of configs[4]) the sweep is L / (64 W) rounds instead of L / 64.  Lane 0 of wave
+// w takes over from lane 63 of wave w-1 through a two-slot LDS mailbox, the last wave's lane 63 feeds the ring; one LDS-only
+// barrier per step keeps the waves in step.
+template <bool EXACT, bool RING_G, int W>
+__global__ __launch_bounds__(W == 1 ? kWfBlock : 64 * W) void fs5_fwd_wf_kernel(SeqView dna, FsDev p, const float *__restrict__ loop_tab, const float *__restrict__ move_tab,
                                                               int c5_compat, float *__restrict__ sc, float *__restrict__ fwd, const int64_t *__restrict__ fwd_off,
                                                               float *__restrict__ xmx, const int64_t *__restrict__ xmx_off,
                                                               float *ring_g /* [waves][(M+2)*8] or null: the ring lives in LDS */, FsJobs jobs, int dbg) {
@@ -48,40 +56,57 @@ __global__ __launch_bounds__(kWfBlock) void fs5_fwd_wf_kernel(SeqView dna, FsDev
   for (int i = threadIdx.x; i < (M + 2) * 8; i += blockDim.x) s_tf[i] = p.tf[i];
   __syncthreads();
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  constexpr int RW = 64 * W;                      // rows in flight
+  const int gl = (W == 1) ? lane : (int)threadIdx.x;   // the lane's place in the pipeline of rows
   const int rstride = (M + 2) * 8;
-  // the ring: lane 63 leaves what lane 0 will need for the next row, indexed by node.  One wave writes and reads it, in program
-  // order (LDS operations of a wave execute in order; global memory is coherent within a CU), so plain accesses do
-  float4 *ring_l = reinterpret_cast<float4 *>(s_tf + (M + 2) * 8 + (size_t)wv * rstride);
-  float4 *ring_gl = RING_G ? reinterpret_cast<float4 *>(ring_g + ((size_t)blockIdx.x * kWfWaves + wv) * rstride) : nullptr;
-  const int Mp = M > 64 ? M : 64;                 // steps between two rows of a lane
+  // the ring: the last lane leaves what lane 0 will need for the next row, indexed by node.  W = 1: one wave writes and reads it,
+  // in program order (LDS operations of a wave execute in order; global memory is coherent within a CU), so plain accesses do
+  const int nrings = (W == 1) ? kWfWaves : 1;
+  float4 *ring_l = reinterpret_cast<float4 *>(s_tf + (M + 2) * 8 + (size_t)(W == 1 ? wv : 0) * rstride);
+  float4 *ring_gl = RING_G ? reinterpret_cast<float4 *>(ring_g + ((size_t)blockIdx.x * nrings + (W == 1 ? wv : 0)) * rstride) : nullptr;
+  // W > 1: mailboxes between consecutive waves [W][2 slots][2 float4], the C values of every wave's lanes 61..63, all lanes' last C, the job
+  float4 *s_mb = reinterpret_cast<float4 *>(s_tf + (M + 2) * 8 + (RING_G ? 0 : (size_t)nrings * rstride));
+  float *s_cpub = reinterpret_cast<float *>(s_mb + (size_t)W * 4);
+  float *s_cfin = s_cpub + W * 4;
+  int *s_job = reinterpret_cast<int *>(s_cfin + RW);
+  const int Mp = M > RW ? M : RW;                 // steps between two rows of a lane
 #define LS(a, b) flogsum<EXACT>((a), (b), s_tbl)
-  for (int64_t job = fs_next_job(jobs, dna.n, lane); job >= 0; job = fs_next_job(jobs, dna.n, lane)) {
+  auto next_job = [&]() -> int64_t {                // W > 1: one envelope per block
+    if (W == 1) return fs_next_job(jobs, dna.n, lane);
+    if (threadIdx.x == 0) { const unsigned q = atomicAdd(jobs.counter, 1u); s_job[0] = (int64_t)q < dna.n ? (int)jobs.order[q] : -1; }
+    __syncthreads();
+    const int64_t job = s_job[0];
+    __syncthreads();
+    return job;
+  };
+  for (int64_t job = next_job(); job >= 0; job = next_job()) {
     const int L = dna.len[job];
     const uint8_t *d = dna.data + dna.off[job];
     float *fo = static_cast<float *>(__builtin_assume_aligned(fwd + fwd_off[job], 32));       // rows of (M+1) x 8 floats: every cell is 32-byte aligned
     float *xo = xmx + xmx_off[job];
-    if (L < 5) { if (lane == 0) sc[job] = -INFINITY; continue; }
+    if (L < 5) { if (gl == 0) sc[job] = -INFINITY; continue; }
     const float tNL = loop_tab[L / 3], tNM = move_tab[L / 3], tCL = tNL, tCM = tNM;
     // ---- row 0 and the rows of N, J, B: N(i) = N(i-3) + tNL (a chain of float additions per residue class), J = -inf,
     //      B(i) = N(i) + tNM (unihit; generic :265-277 with tEL = -inf)
-    for (int k = lane; k <= M; k += 64) {
+    for (int k = gl; k <= M; k += RW) {
       float4 *c = reinterpret_cast<float4 *>(fo + (size_t)k * 8);
       c[0] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY); c[1] = c[0];
     }
-    if (lane == 0) { xo[0] = -INFINITY; xo[4] = -INFINITY; }
-    if (lane < 3) {
+    if (gl == 0) { xo[0] = -INFINITY; xo[4] = -INFINITY; }
+    if (gl < 3) {
       float n = 0.f;
-      for (int i = lane; i <= L; i += 3) {
+      for (int i = gl; i <= L; i += 3) {
         if (i >= 3) n += tNL;
         xo[i * 5 + 1] = n; xo[i * 5 + 2] = -INFINITY; xo[i * 5 + 3] = n + tNM;
       }
     }
-    __threadfence_block();
+    if (W == 1) __threadfence_block(); else __syncthreads();            // the other waves read these rows from global memory
     // ---- per-lane state
-    int row = 1 + lane, k = 1 - lane;                                   // k <= 0: the lane has not started yet
+    int row = 1 + gl, k = 1 - gl;                                       // k <= 0: the lane has not started yet
     float dch = -INFINITY, ech = -INFINITY, pM = -INFINITY, pI = -INFINITY, pD = -INFINITY;
     float oP = -INFINITY, o0 = -INFINITY, o1 = -INFINITY, o2 = -INFINITY, o3 = -INFINITY, oQ = -INFINITY, oqa = -INFINITY, oqb = -INFINITY;
     float cfin = -INFINITY;                                             // C of the lane's last finished row
+    if (W > 1 && lane >= 61) s_cpub[wv * 4 + (lane - 61)] = -INFINITY;
     int r1, r2, r3, r4, r5;                                             // emission rows of the lane's current row (times pitch)
     float Bcur;
     // x_i as the kernels index codons: 0..3, or 1367 = p7P_MAXCODONS5 for a degenerate nucleotide / a position before the start
@@ -106,8 +131,8 @@ __global__ __launch_bounds__(kWfBlock) void fs5_fwd_wf_kernel(SeqView dna, FsDev
       nb0 = d[rr - 1]; __builtin_memcpy(&nbw, d + rr - 5, 4);
       Bnext = xo[(size_t)rr * 5 + 3];
     };
-    prefetch_row(row + 64);
-    const int T = ((L - 1) / 64) * Mp + ((L - 1) % 64) + M;
+    prefetch_row(row + RW);
+    const int T = ((L - 1) / RW) * Mp + ((L - 1) % RW) + M;
     // the emission scores of a step are loaded during the step before
     float e1, e2, e3, e4, e5;
     { e1 = p.rsc[(size_t)r1 + 1]; e2 = p.rsc[(size_t)r2 + 1]; e3 = p.rsc[(size_t)r3 + 1]; e4 = p.rsc[(size_t)r4 + 1]; e5 = p.rsc[(size_t)r5 + 1]; }
@@ -120,7 +145,10 @@ __global__ __launch_bounds__(kWfBlock) void fs5_fwd_wf_kernel(SeqView dna, FsDev
       float v0 = wave_shr1(oP, -INFINITY), v1 = wave_shr1(o0, -INFINITY), v2 = wave_shr1(o1, -INFINITY), v3 = wave_shr1(o2, -INFINITY), v4 = wave_shr1(o3, -INFINITY);
       float Ik = wave_shr1(oqb, -INFINITY), qa = wave_shr1(oQ, -INFINITY), qb = wave_shr1(oqa, -INFINITY);
       if (lane == 0) {
-        if (row == 1) v0 = tNM + ta.w;                                  // IVX(1,k) = B(0) + tBM(k-1) (:109)
+        if (W > 1 && wv > 0) {                                          // from the wave above: what its lane 63 left at the previous step
+          const float4 a = s_mb[((size_t)(wv - 1) * 2 + ((t + 1) & 1)) * 2], b = s_mb[((size_t)(wv - 1) * 2 + ((t + 1) & 1)) * 2 + 1];
+          v0 = a.x; v1 = a.y; v2 = a.z; v3 = a.w; v4 = b.x; Ik = b.y; qa = b.z; qb = b.w;
+        } else if (row == 1) v0 = tNM + ta.w;                            // IVX(1,k) = B(0) + tBM(k-1) (:109)
         else {
           float4 a, b;
           if constexpr (RING_G) { a = ring_gl[(size_t)kk * 2]; b = ring_gl[(size_t)kk * 2 + 1]; } else { a = ring_l[(size_t)kk * 2]; b = ring_l[(size_t)kk * 2 + 1]; }
@@ -138,10 +166,10 @@ __global__ __launch_bounds__(kWfBlock) void fs5_fwd_wf_kernel(SeqView dna, FsDev
       float Bn = Bcur;
       const bool wrap = kn > Mp;
       if (wrap) {
-        kn = 1; rown = row + 64;
+        kn = 1; rown = row + RW;
         codon_rows(code(nb0, true), code((int)(nbw >> 24), true), code((int)((nbw >> 16) & 255u), true), code((int)((nbw >> 8) & 255u), true), code((int)(nbw & 255u), true), q1, q2, q3, q4, q5);
         Bn = Bnext;
-        prefetch_row(rown + 64);
+        prefetch_row(rown + RW);
       }
       {
         const int kq = kn < 1 ? 1 : (kn > M ? M : kn);
@@ -164,24 +192,36 @@ __global__ __launch_bounds__(kWfBlock) void fs5_fwd_wf_kernel(SeqView dna, FsDev
       float P = LS(pM + ta.x, LS(pI + ta.y, LS(pD + ta.z, Bcur + ta.w)));
       if (row == 1) P = Bcur + ta.w;
       oP = P; o3 = v3; o2 = v2; o1 = v1; o0 = v0; oQ = Q; oqa = qa; oqb = qb;
-      if (lane == 63 && act) {
+      if (lane == 63) {
         const float4 a = make_float4(oP, o0, o1, o2), b = make_float4(o3, oqb, oQ, oqa);
-        if constexpr (RING_G) { ring_gl[(size_t)k * 2] = a; ring_gl[(size_t)k * 2 + 1] = b; } else { ring_l[(size_t)k * 2] = a; ring_l[(size_t)k * 2 + 1] = b; }
+        if (W > 1 && wv < W - 1) { s_mb[((size_t)wv * 2 + (t & 1)) * 2] = a; s_mb[((size_t)wv * 2 + (t & 1)) * 2 + 1] = b; }      // to the wave below, read at the next step
+        else if (act) {
+          if constexpr (RING_G) { ring_gl[(size_t)k * 2] = a; ring_gl[(size_t)k * 2 + 1] = b; } else { ring_l[(size_t)k * 2] = a; ring_l[(size_t)k * 2 + 1] = b; }
+        }
       }
       // ---- end of a row: E(i), C(i) = LS(C(i-3) + tCL, E(i) + tEM) with tEM = 0 (:397-398; rows 1, 2: C(<=0) = -inf gives E(i))
-      const float cprev = __shfl(cfin, (lane + 61) & 63, 64);
+      float cprev = __shfl(cfin, (lane + 61) & 63, 64);
+      if (W > 1 && lane < 3) cprev = s_cpub[((wv + W - 1) % W) * 4 + lane];          // rows i-3 of the first three lanes live in the wave above
       if (act && k == M) {
         const float cnew = LS(cprev + tCL, enew + 0.0f);
         cfin = cnew;
         xo[(size_t)row * 5 + 0] = enew; xo[(size_t)row * 5 + 4] = cnew;
       }
+      if (W > 1 && lane >= 61) s_cpub[wv * 4 + (lane - 61)] = cfin;
       const bool carry = (k >= 1) && !wrap;                             // a lane that has not started, or starts a new row, has its chains at -inf
       pM = carry ? Mk : -INFINITY; pI = carry ? Ik : -INFINITY; pD = carry ? Dk : -INFINITY;
       dch = carry ? dnew : -INFINITY; ech = carry ? enew : -INFINITY;
       k = kn; row = rown; r1 = q1; r2 = q2; r3 = q3; r4 = q4; r5 = q5; Bcur = Bn;
+      if (W > 1) lds_wf_barrier();                                      // mailboxes, ring and C values of this step are in place
     }
-    const float cL = __shfl(cfin, (L - 1) & 63, 64), cL1 = __shfl(cfin, (L - 2) & 63, 64), cL2 = __shfl(cfin, (L - 3) & 63, 64);
-    if (lane == 0) sc[job] = LS(cL, LS(cL1 + tCL, cL2 + tCL)) + tCM;
+    if (W == 1) {
+      const float cL = __shfl(cfin, (L - 1) & 63, 64), cL1 = __shfl(cfin, (L - 2) & 63, 64), cL2 = __shfl(cfin, (L - 3) & 63, 64);
+      if (lane == 0) sc[job] = LS(cL, LS(cL1 + tCL, cL2 + tCL)) + tCM;
+    } else {
+      s_cfin[gl] = cfin;
+      __syncthreads();
+      if (gl == 0) sc[job] = LS(s_cfin[(L - 1) % RW], LS(s_cfin[(L - 2) % RW] + tCL, s_cfin[(L - 3) % RW] + tCL)) + tCM;
+    }
   }
 #undef LS
 }
@@ -196,11 +236,11 @@ __global__ __launch_bounds__(kWfBlock) void fs5_fwd_wf_kernel(SeqView dna, FsDev
 // then walks the N and J rows and the score.
 // tb[node] = {tMD(k), tMI(k), tMM(k), tDD(k), tDM(k), tII(k), tIM(k), tBM(k-1)}
 // ---------------------------------------------------------------------------------------------------------------------------
-__host__ __device__ inline int fs_wf_period(int M) { return M > 64 ? M : 64; }
-__host__ __device__ inline int64_t fs_bwd_wf_steps(int L, int M) { return (int64_t)(L / 64) * fs_wf_period(M) + (L % 64) + M; }   // rows L..0
+__host__ __device__ inline int fs_wf_period(int M, int RW) { return M > RW ? M : RW; }      // RW = 64 W rows in flight
+__host__ __device__ inline int64_t fs_bwd_wf_steps(int L, int M, int RW) { return (int64_t)(L / RW) * fs_wf_period(M, RW) + (L % RW) + M; }   // rows L..0
 
-template <bool EXACT, bool RING_G>
-__global__ __launch_bounds__(kWfBlock) void fs5_bwd_wf_kernel(SeqView dna, FsDev p, const float *__restrict__ loop_tab, const float *__restrict__ move_tab,
+template <bool EXACT, bool RING_G, int W>
+__global__ __launch_bounds__(W == 1 ? kWfBlock : 64 * W) void fs5_bwd_wf_kernel(SeqView dna, FsDev p, const float *__restrict__ loop_tab, const float *__restrict__ move_tab,
                                                               float *__restrict__ bck, const int64_t *__restrict__ bck_off, float *__restrict__ xmx, const int64_t *__restrict__ xmx_off,
                                                               float *__restrict__ terms, const int64_t *__restrict__ term_off, float *ring_g, FsJobs jobs) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -211,12 +251,25 @@ __global__ __launch_bounds__(kWfBlock) void fs5_bwd_wf_kernel(SeqView dna, FsDev
   for (int i = threadIdx.x; i < (M + 2) * 8; i += blockDim.x) s_tb[i] = p.tb[i];
   __syncthreads();
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  constexpr int RW = 64 * W;
+  const int gl = (W == 1) ? lane : (int)threadIdx.x;
   const int rstride = (M + 2) * 8;
-  float4 *ring_l = reinterpret_cast<float4 *>(s_tb + (M + 2) * 8 + (size_t)wv * rstride);
-  float4 *ring_gl = RING_G ? reinterpret_cast<float4 *>(ring_g + ((size_t)blockIdx.x * kWfWaves + wv) * rstride) : nullptr;
-  const int Mp = fs_wf_period(M);
+  const int nrings = (W == 1) ? kWfWaves : 1;
+  float4 *ring_l = reinterpret_cast<float4 *>(s_tb + (M + 2) * 8 + (size_t)(W == 1 ? wv : 0) * rstride);
+  float4 *ring_gl = RING_G ? reinterpret_cast<float4 *>(ring_g + ((size_t)blockIdx.x * nrings + (W == 1 ? wv : 0)) * rstride) : nullptr;
+  float4 *s_mb = reinterpret_cast<float4 *>(s_tb + (M + 2) * 8 + (RING_G ? 0 : (size_t)nrings * rstride));   // W > 1: mailboxes between consecutive waves
+  int *s_job = reinterpret_cast<int *>(s_mb + (size_t)W * 4);
+  const int Mp = fs_wf_period(M, RW);
 #define LS(a, b) flogsum<EXACT>((a), (b), s_tbl)
-  for (int64_t job = fs_next_job(jobs, dna.n, lane); job >= 0; job = fs_next_job(jobs, dna.n, lane)) {
+  auto next_job = [&]() -> int64_t {                // W > 1: one envelope per block
+    if (W == 1) return fs_next_job(jobs, dna.n, lane);
+    if (threadIdx.x == 0) { const unsigned q = atomicAdd(jobs.counter, 1u); s_job[0] = (int64_t)q < dna.n ? (int)jobs.order[q] : -1; }
+    __syncthreads();
+    const int64_t job = s_job[0];
+    __syncthreads();
+    return job;
+  };
+  for (int64_t job = next_job(); job >= 0; job = next_job()) {
     const int L = dna.len[job];
     if (L < 5) continue;                                               // fs5_bwd_x_kernel reports -inf
     const uint8_t *d = dna.data + dna.off[job];
@@ -225,15 +278,15 @@ __global__ __launch_bounds__(kWfBlock) void fs5_bwd_wf_kernel(SeqView dna, FsDev
     float *tm = terms + term_off[job];
     const float tCL = loop_tab[L / 3], tCM = move_tab[L / 3];
     // ---- the rows of C and E: C(L) = tCM, C(L-1) = C(L-2) = tCL + tCM, C(i) = C(i+3) + tCL; E(i) = C(i) + tEM, tEM = 0 (:1054-1073, :1290-1294)
-    if (lane < 3) {
-      float c = (lane == 0) ? tCM : tCL + tCM;
-      for (int i = L - lane; i >= 1; i -= 3) {
+    if (gl < 3) {
+      float c = (gl == 0) ? tCM : tCL + tCM;
+      for (int i = L - gl; i >= 1; i -= 3) {
         if (i <= L - 3) c = c + tCL;
         xo[(size_t)i * 5 + 4] = c; xo[(size_t)i * 5 + 0] = c + 0.0f;
       }
     }
-    __threadfence_block();
-    int j = lane, k = 1 - lane;                                         // j = L - row; k = position in the row's sweep (node = M + 1 - k); k <= 0: not started
+    if (W == 1) __threadfence_block(); else __syncthreads();
+    int j = gl, k = 1 - gl;                                             // j = L - row; k = position in the row's sweep (node = M + 1 - k); k <= 0: not started
     float dprev = -INFINITY, ivprev = -INFINITY;
     float oM = -INFINITY, om1 = -INFINITY, om2 = -INFINITY, om3 = -INFINITY, om4 = -INFINITY, oI = -INFINITY, oj1 = -INFINITY, oj2 = -INFINITY;
     int r1, r2, r3, r4, r5;
@@ -254,13 +307,13 @@ __global__ __launch_bounds__(kWfBlock) void fs5_bwd_wf_kernel(SeqView dna, FsDev
       xE = xo[(size_t)(i > 0 ? i : 1) * 5 + 0];
     }
     int nb0; unsigned nbw; float xEn;                                    // next row's x_{i+1}, x_{i+2..i+5} (one unaligned dword), E(i): fetched a round ahead
-    auto prefetch_row = [&](int jn) {                                    // jn >= 64: all five nucleotides exist
+    auto prefetch_row = [&](int jn) {                                    // jn >= 64 W: all five nucleotides exist
       const int i = L - imin(jn, L);
       nb0 = d[i]; __builtin_memcpy(&nbw, d + i + 1, 4);
       xEn = xo[(size_t)(i > 0 ? i : 1) * 5 + 0];
     };
-    if (L >= 64) prefetch_row(j + 64); else { nb0 = 0; nbw = 0; xEn = 0.f; }
-    const int T = (int)fs_bwd_wf_steps(L, M);
+    if (L >= RW) prefetch_row(j + RW); else { nb0 = 0; nbw = 0; xEn = 0.f; }
+    const int T = (int)fs_bwd_wf_steps(L, M, RW);
     float e1, e2, e3, e4, e5;
     { e1 = p.rsc[(size_t)r1 + M]; e2 = p.rsc[(size_t)r2 + M]; e3 = p.rsc[(size_t)r3 + M]; e4 = p.rsc[(size_t)r4 + M]; e5 = p.rsc[(size_t)r5 + M]; }
     for (int t = 0; t < T; t++) {
@@ -272,7 +325,10 @@ __global__ __launch_bounds__(kWfBlock) void fs5_bwd_wf_kernel(SeqView dna, FsDev
       // ---- from the row below (lane 0: the ring; nothing below row L)
       float m1 = wave_shr1(oM, -INFINITY), m2 = wave_shr1(om1, -INFINITY), m3 = wave_shr1(om2, -INFINITY), m4 = wave_shr1(om3, -INFINITY), m5 = wave_shr1(om4, -INFINITY);
       float j1 = wave_shr1(oI, -INFINITY), j2 = wave_shr1(oj1, -INFINITY), I3 = wave_shr1(oj2, -INFINITY);
-      if (lane == 0 && j > 0) {
+      if (lane == 0 && W > 1 && wv > 0) {                                // from the wave above: what its lane 63 left at the previous step
+        const float4 a = s_mb[((size_t)(wv - 1) * 2 + ((t + 1) & 1)) * 2], b = s_mb[((size_t)(wv - 1) * 2 + ((t + 1) & 1)) * 2 + 1];
+        m1 = a.x; m2 = a.y; m3 = a.z; m4 = a.w; m5 = b.x; j1 = b.y; j2 = b.z; I3 = b.w;
+      } else if (lane == 0 && j > 0) {
         float4 a, b;
         if constexpr (RING_G) { a = ring_gl[(size_t)node * 2]; b = ring_gl[(size_t)node * 2 + 1]; } else { a = ring_l[(size_t)node * 2]; b = ring_l[(size_t)node * 2 + 1]; }
         m1 = a.x; m2 = a.y; m3 = a.z; m4 = a.w; m5 = b.x; j1 = b.y; j2 = b.z; I3 = b.w;
@@ -294,11 +350,11 @@ __global__ __launch_bounds__(kWfBlock) void fs5_bwd_wf_kernel(SeqView dna, FsDev
       float xEq = xE;
       const bool wrap = kn > Mp;
       if (wrap) {
-        kn = 1; jn = j + 64;
+        kn = 1; jn = j + RW;
         codon_rows(code(nb0, true), code((int)(nbw & 255u), true), code((int)((nbw >> 8) & 255u), true), code((int)((nbw >> 16) & 255u), true), code((int)(nbw >> 24), true),
                    q1, q2, q3, q4, q5);
         xEq = xEn;
-        if (jn + 64 <= L) prefetch_row(jn + 64);
+        if (jn + RW <= L) prefetch_row(jn + RW);
       }
       {
         const int kq = kn < 1 ? 1 : (kn > M ? M : kn);
@@ -310,15 +366,19 @@ __global__ __launch_bounds__(kWfBlock) void fs5_bwd_wf_kernel(SeqView dna, FsDev
         cell[0] = dv; cell[1] = iv_; cell[2] = mv;
         if (node == 1) { cell[-3] = -INFINITY; cell[-2] = -INFINITY; cell[-1] = -INFINITY; }
       }
-      tm[(size_t)t * 64 + lane] = a + t1.w;                              // B(i)'s term of this node, summed by fs5_bwd_x_kernel
-      if (lane == 63 && act) {
+      tm[(size_t)t * RW + gl] = a + t1.w;                                // B(i)'s term of this node, summed by fs5_bwd_x_kernel
+      if (lane == 63) {
         const float4 ra = make_float4(mv, m1, m2, m3), rb = make_float4(m4, iv_, j1, j2);
-        if constexpr (RING_G) { ring_gl[(size_t)node * 2] = ra; ring_gl[(size_t)node * 2 + 1] = rb; } else { ring_l[(size_t)node * 2] = ra; ring_l[(size_t)node * 2 + 1] = rb; }
+        if (W > 1 && wv < W - 1) { s_mb[((size_t)wv * 2 + (t & 1)) * 2] = ra; s_mb[((size_t)wv * 2 + (t & 1)) * 2 + 1] = rb; }
+        else if (act) {
+          if constexpr (RING_G) { ring_gl[(size_t)node * 2] = ra; ring_gl[(size_t)node * 2 + 1] = rb; } else { ring_l[(size_t)node * 2] = ra; ring_l[(size_t)node * 2 + 1] = rb; }
+        }
       }
       oM = mv; om1 = m1; om2 = m2; om3 = m3; om4 = m4; oI = iv_; oj1 = j1; oj2 = j2;
       const bool carry = (k >= 1) && !wrap;
       dprev = carry ? dv : -INFINITY; ivprev = carry ? a : -INFINITY;
       k = kn; j = jn; r1 = q1; r2 = q2; r3 = q3; r4 = q4; r5 = q5; xE = xEq;
+      if (W > 1) lds_wf_barrier();
     }
   }
 #undef LS
@@ -330,13 +390,13 @@ __global__ __launch_bounds__(kWfBlock) void fs5_bwd_wf_kernel(SeqView dna, FsDev
 template <bool EXACT>
 __global__ __launch_bounds__(kFsBlock) void fs5_bwd_x_kernel(SeqView dna, int M, const float *__restrict__ logsum_g, const float *__restrict__ loop_tab, const float *__restrict__ move_tab,
                                                              float *__restrict__ xmx, const int64_t *__restrict__ xmx_off, const float *__restrict__ terms, const int64_t *__restrict__ term_off,
-                                                             float *__restrict__ sc, FsJobs jobs) {
+                                                             float *__restrict__ sc, FsJobs jobs, int RW /* rows the sweep had in flight: 64 x its waves per envelope */) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   float *s_tbl = reinterpret_cast<float *>(lds);
   fs_load_logsum_table(s_tbl, logsum_g);
   __syncthreads();
   const int lane = threadIdx.x & 63;
-  const int Mp = fs_wf_period(M);
+  const int Mp = fs_wf_period(M, RW);
 #define LS(a, b) flogsum<EXACT>((a), (b), s_tbl)
   for (int64_t job = fs_next_job(jobs, dna.n, lane); job >= 0; job = fs_next_job(jobs, dna.n, lane)) {
     const int L = dna.len[job];
@@ -344,14 +404,15 @@ __global__ __launch_bounds__(kFsBlock) void fs5_bwd_x_kernel(SeqView dna, int M,
     float *xo = xmx + xmx_off[job];
     const float *tm = terms + term_off[job];
     const float tNL = loop_tab[L / 3], tNM = move_tab[L / 3], tJL = tNL, tJM = tNM;
-    for (int pr = 0; pr * 64 <= L; pr++) {
-      const int j = pr * 64 + lane;                                     // this lane's row of the round: i = L - j
+    for (int g0 = 0; g0 <= L; g0 += 64) {                               // 64 rows at a time: the rows a wave of the sweep owned in one round
+      const int j = g0 + lane;                                          // this lane's row: i = L - j
+      const int pr = g0 / RW, gl = (g0 % RW) + lane;                    // its round and its place in the sweep's pipeline
       float b = -INFINITY;
-      const int t_lo = pr * Mp, t_hi = pr * Mp + 63 + M - 1;
+      const int t_lo = pr * Mp + (g0 % RW), t_hi = t_lo + 63 + M - 1;
       for (int t = t_hi; t >= t_lo; t--) {                              // the lane's node at step t: M - (t - t_lo - lane); node 1 comes first
         const int node = M - (t - t_lo - lane);
         if (node >= 1 && node <= M && j <= L) {
-          const float v = tm[(size_t)t * 64 + lane];
+          const float v = tm[(size_t)t * RW + gl];
           b = (node == 1) ? v : LS(b, v);
         }
       }
@@ -379,83 +440,105 @@ __global__ __launch_bounds__(kFsBlock) void fs5_bwd_x_kernel(SeqView dna, int M,
 
 size_t fs_wf_ring_floats(int M) { return (size_t)(M + 2) * 8; }
 
+// waves per envelope: 1 when there are envelopes for every wave slot; with few envelopes (at most two per CU) as many waves as
+// the model keeps busy (64 W rows in flight need M >= 64 W steps per row to be fully used), at least 2
+static int fs_wf_waves(bath_hip_ctx *ctx, int64_t n, int M) {
+  static const int forced = [] { const char *e = std::getenv("BATH_HIP_WF_WAVES"); return e ? std::atoi(e) : 0; }();
+  if (forced == 1 || forced == 2 || forced == 4 || forced == 8) return forced;
+  if (n > (int64_t)ctx->prop.multiProcessorCount * 2) return 1;
+  int W = 2;
+  while (W < 8 && 64 * W * 2 <= M) W *= 2;
+  return W;
+}
+
+struct WfGeom { int W, grid, block; bool lds_ring; size_t shmem; float *ring_g; };
+static int fs_wf_geometry(bath_hip_ctx *ctx, int64_t n, int M, DevBuf &ring_scratch, WfGeom *g) {
+  static const bool ring_global = [] { const char *e = std::getenv("BATH_HIP_WF_RING_G"); return e && e[0] == '1'; }();
+  const int W = fs_wf_waves(ctx, n, M);
+  const size_t base = (size_t)(kLogsumTbl + (M + 2) * 8) * sizeof(float);
+  const int nrings = (W == 1) ? kWfWaves : 1;
+  const size_t ring_b = fs_wf_ring_floats(M) * sizeof(float) * nrings;
+  const size_t extra = (W == 1) ? 0 : (size_t)W * 64 + (size_t)W * 16 + (size_t)64 * W * 4 + 64;      // mailboxes, C values, job
+  g->W = W;
+  g->lds_ring = !ring_global && base + ring_b + extra <= 160 * 1024;
+  g->shmem = base + (g->lds_ring ? ring_b : 0) + extra;
+  g->block = (W == 1) ? kWfBlock : 64 * W;
+  const int per_cu = (W == 1) ? ((kWfBlock <= 512) ? 2 : 1) : (int)std::max<size_t>(1, std::min<size_t>(2, (160 * 1024) / g->shmem));
+  const int64_t jobs_per_block = (W == 1) ? kWfWaves : 1;
+  g->grid = (int)std::max<int64_t>(1, std::min<int64_t>((n + jobs_per_block - 1) / jobs_per_block, (int64_t)ctx->prop.multiProcessorCount * per_cu));
+  g->ring_g = nullptr;
+  if (!g->lds_ring) {
+    BATH_HIP_TRY(ctx, ring_scratch.reserve(ring_b * (size_t)g->grid + 64));
+    g->ring_g = ring_scratch.as<float>();
+  }
+  return BATH_OK;
+}
+
+#define BATH_WF_DISPATCH(KERNEL, ...)                                                                                            \
+  do {                                                                                                                           \
+    auto go = [&](auto kfn) -> int {                                                                                             \
+      if (g.shmem > 64 * 1024) BATH_HIP_TRY(ctx, hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.shmem)); \
+      hipLaunchKernelGGL(kfn, dim3(g.grid), dim3(g.block), g.shmem, stream, __VA_ARGS__);                                         \
+      return BATH_OK;                                                                                                            \
+    };                                                                                                                           \
+    int rc_ = BATH_OK;                                                                                                           \
+    const int key_ = (exact ? 1 : 0) | (g.lds_ring ? 0 : 2);                                                                     \
+    switch (g.W * 4 + key_) {                                                                                                    \
+      case 4 + 0: rc_ = go(KERNEL<false, false, 1>); break;  case 4 + 1: rc_ = go(KERNEL<true, false, 1>); break;                  \
+      case 4 + 2: rc_ = go(KERNEL<false, true, 1>); break;   case 4 + 3: rc_ = go(KERNEL<true, true, 1>); break;                   \
+      case 8 + 0: rc_ = go(KERNEL<false, false, 2>); break;  case 8 + 1: rc_ = go(KERNEL<true, false, 2>); break;                  \
+      case 8 + 2: rc_ = go(KERNEL<false, true, 2>); break;   case 8 + 3: rc_ = go(KERNEL<true, true, 2>); break;                   \
+      case 16 + 0: rc_ = go(KERNEL<false, false, 4>); break; case 16 + 1: rc_ = go(KERNEL<true, false, 4>); break;                 \
+      case 16 + 2: rc_ = go(KERNEL<false, true, 4>); break;  case 16 + 3: rc_ = go(KERNEL<true, true, 4>); break;                  \
+      case 32 + 0: rc_ = go(KERNEL<false, false, 8>); break; case 32 + 1: rc_ = go(KERNEL<true, false, 8>); break;                 \
+      case 32 + 2: rc_ = go(KERNEL<false, true, 8>); break;  case 32 + 3: rc_ = go(KERNEL<true, true, 8>); break;                  \
+      default: rc_ = BATH_EINVAL;                                                                                                \
+    }                                                                                                                            \
+    if (rc_ != BATH_OK) return rc_;                                                                                              \
+  } while (0)
+
 // Launch the wavefront Forward over all envelopes of <dna> on <stream>.  <ring_scratch>: a context scratch buffer for the ring
 // when it does not fit into LDS next to the table.
 int launch_fs5_fwd_wf(bath_hip_ctx *ctx, hipStream_t stream, const bath_hip_fsprofile *om, const bath_hip_seqs *dna, int exact, int c5_compat,
                       float *d_sc, float *d_fwd, const int64_t *d_foff, float *d_xmx, const int64_t *d_xoff, DevBuf &ring_scratch, FsJobs jobs) {
   const int M = om->M;
-  const int64_t n = dna->n;
   static const int dbg = [] { const char *e = std::getenv("BATH_HIP_WF_DBG"); return e ? std::atoi(e) : 0; }();
-  const int grid_cap = ctx->prop.multiProcessorCount * ((kWfBlock <= 512) ? 2 : 1);      // 512-thread blocks with the ring in global memory fit a CU twice
-  const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((n + kWfWaves - 1) / kWfWaves, (int64_t)grid_cap));
-  const size_t base = (size_t)(kLogsumTbl + (M + 2) * 8) * sizeof(float);
-  const size_t ring_b = fs_wf_ring_floats(M) * sizeof(float) * kWfWaves;
-  static const bool ring_global = [] { const char *e = std::getenv("BATH_HIP_WF_RING_G"); return e && e[0] == '1'; }();
-  const bool lds_ring = !ring_global && base + ring_b <= 160 * 1024;
-  float *ring_g = nullptr;
-  if (!lds_ring) {
-    BATH_HIP_TRY(ctx, ring_scratch.reserve(ring_b * (size_t)grid + 64));
-    ring_g = ring_scratch.as<float>();
-  }
-  const size_t shmem = base + (lds_ring ? ring_b : 0);
+  WfGeom g{};
+  int st = fs_wf_geometry(ctx, dna->n, M, ring_scratch, &g);
+  if (st != BATH_OK) return st;
   FsDev dev{om->M, om->pitch, om->maxcodons, om->d_rsc, om->d_tf, om->d_tb, om->d_logsum};
-#define BATH_WF_LAUNCH(EX, RG)                                                                                                     \
-  do {                                                                                                                             \
-    if (shmem > 64 * 1024) BATH_HIP_TRY(ctx, hipFuncSetAttribute((const void *)fs5_fwd_wf_kernel<EX, RG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
-    hipLaunchKernelGGL((fs5_fwd_wf_kernel<EX, RG>), dim3(grid), dim3(kWfBlock), shmem, stream, dna->view(), dev, om->d_loop[1], om->d_move[1], c5_compat, d_sc, d_fwd, \
-                       d_foff, d_xmx, d_xoff, ring_g, jobs, dbg);                                                                       \
-  } while (0)
-  if (exact) { if (lds_ring) BATH_WF_LAUNCH(true, false); else BATH_WF_LAUNCH(true, true); }
-  else { if (lds_ring) BATH_WF_LAUNCH(false, false); else BATH_WF_LAUNCH(false, true); }
-#undef BATH_WF_LAUNCH
+  BATH_WF_DISPATCH(fs5_fwd_wf_kernel, dna->view(), dev, om->d_loop[1], om->d_move[1], c5_compat, d_sc, d_fwd, d_foff, d_xmx, d_xoff, g.ring_g, jobs, dbg);
   BATH_HIP_TRY(ctx, hipGetLastError());
   return BATH_OK;
 }
 
-
-// Backward of all envelopes: the sweep, then the B sums / N, J rows / scores.  <term_off_h>: per envelope the offset of its
-// (steps x 64) term array in <terms_scratch>, built here.
+// Backward of all envelopes: the sweep, then the B sums / N, J rows / scores.  The offsets of the envelopes' (steps x rows in
+// flight) term arrays in <terms_scratch> are built here.
 int launch_fs5_bwd_wf(bath_hip_ctx *ctx, hipStream_t stream, const bath_hip_fsprofile *om, const bath_hip_seqs *dna, int exact,
                       float *d_sc, float *d_bck, const int64_t *d_boff, float *d_xmx, const int64_t *d_xoff, DevBuf &ring_scratch, DevBuf &terms_scratch, DevBuf &toff_scratch,
                       FsJobs jobs_sweep, FsJobs jobs_x) {
   const int M = om->M;
   const int64_t n = dna->n;
+  WfGeom g{};
+  int st = fs_wf_geometry(ctx, n, M, ring_scratch, &g);
+  if (st != BATH_OK) return st;
+  const int RW = 64 * g.W;
   std::vector<int64_t> toff((size_t)n + 1, 0);
-  for (int64_t e = 0; e < n; e++) toff[(size_t)e + 1] = toff[(size_t)e] + (dna->h_len[(size_t)e] >= 5 ? fs_bwd_wf_steps(dna->h_len[(size_t)e], M) * 64 : 0);
+  for (int64_t e = 0; e < n; e++) toff[(size_t)e + 1] = toff[(size_t)e] + (dna->h_len[(size_t)e] >= 5 ? fs_bwd_wf_steps(dna->h_len[(size_t)e], M, RW) * RW : 0);
   BATH_HIP_TRY(ctx, terms_scratch.reserve((size_t)toff[(size_t)n] * sizeof(float) + 256));
   BATH_HIP_TRY(ctx, toff_scratch.reserve((size_t)(n + 1) * sizeof(int64_t)));
   BATH_HIP_TRY(ctx, hipMemcpyAsync(toff_scratch.p, toff.data(), (size_t)(n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, stream));
   BATH_HIP_TRY(ctx, hipStreamSynchronize(stream));                    // <toff> is a local
-  const int grid_cap = ctx->prop.multiProcessorCount * ((kWfBlock <= 512) ? 2 : 1);      // 512-thread blocks with the ring in global memory fit a CU twice
-  const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((n + kWfWaves - 1) / kWfWaves, (int64_t)grid_cap));
-  const size_t base = (size_t)(kLogsumTbl + (M + 2) * 8) * sizeof(float);
-  const size_t ring_b = fs_wf_ring_floats(M) * sizeof(float) * kWfWaves;
-  static const bool ring_global = [] { const char *e = std::getenv("BATH_HIP_WF_RING_G"); return e && e[0] == '1'; }();
-  const bool lds_ring = !ring_global && base + ring_b <= 160 * 1024;
-  float *ring_g = nullptr;
-  if (!lds_ring) {
-    BATH_HIP_TRY(ctx, ring_scratch.reserve(ring_b * (size_t)grid + 64));
-    ring_g = ring_scratch.as<float>();
-  }
-  const size_t shmem = base + (lds_ring ? ring_b : 0);
   FsDev dev{om->M, om->pitch, om->maxcodons, om->d_rsc, om->d_tf, om->d_tb, om->d_logsum};
-#define BATH_WF_LAUNCH(EX, RG)                                                                                                     \
-  do {                                                                                                                             \
-    if (shmem > 64 * 1024) BATH_HIP_TRY(ctx, hipFuncSetAttribute((const void *)fs5_bwd_wf_kernel<EX, RG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
-    hipLaunchKernelGGL((fs5_bwd_wf_kernel<EX, RG>), dim3(grid), dim3(kWfBlock), shmem, stream, dna->view(), dev, om->d_loop[1], om->d_move[1], d_bck, d_boff, d_xmx, d_xoff, \
-                       terms_scratch.as<float>(), toff_scratch.as<int64_t>(), ring_g, jobs_sweep);                                 \
-  } while (0)
-  if (exact) { if (lds_ring) BATH_WF_LAUNCH(true, false); else BATH_WF_LAUNCH(true, true); }
-  else { if (lds_ring) BATH_WF_LAUNCH(false, false); else BATH_WF_LAUNCH(false, true); }
-#undef BATH_WF_LAUNCH
+  BATH_WF_DISPATCH(fs5_bwd_wf_kernel, dna->view(), dev, om->d_loop[1], om->d_move[1], d_bck, d_boff, d_xmx, d_xoff, terms_scratch.as<float>(), toff_scratch.as<int64_t>(), g.ring_g, jobs_sweep);
   BATH_HIP_TRY(ctx, hipGetLastError());
   const int xwaves = kFsBlock / 64;
   const int xgrid = (int)std::max<int64_t>(1, std::min<int64_t>((n + xwaves - 1) / xwaves, (int64_t)ctx->prop.multiProcessorCount * 2));
   const size_t xshmem = (size_t)kLogsumTbl * sizeof(float);
   if (exact) hipLaunchKernelGGL((fs5_bwd_x_kernel<true>), dim3(xgrid), dim3(kFsBlock), xshmem, stream, dna->view(), M, om->d_logsum, om->d_loop[1], om->d_move[1], d_xmx, d_xoff,
-                                terms_scratch.as<float>(), toff_scratch.as<int64_t>(), d_sc, jobs_x);
+                                terms_scratch.as<float>(), toff_scratch.as<int64_t>(), d_sc, jobs_x, RW);
   else hipLaunchKernelGGL((fs5_bwd_x_kernel<false>), dim3(xgrid), dim3(kFsBlock), xshmem, stream, dna->view(), M, om->d_logsum, om->d_loop[1], om->d_move[1], d_xmx, d_xoff,
-                          terms_scratch.as<float>(), toff_scratch.as<int64_t>(), d_sc, jobs_x);
+                          terms_scratch.as<float>(), toff_scratch.as<int64_t>(), d_sc, jobs_x, RW);
   BATH_HIP_TRY(ctx, hipGetLastError());
   return BATH_OK;
 }
