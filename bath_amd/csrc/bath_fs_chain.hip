@@ -37,6 +37,82 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 __host__ __device__ inline int fs_chain_stride(int C) { return C * 64 + 1; }
 
 // ---------------------------------------------------------------------------------------------------------------------------
+// The chain loops, scheduled by hand.  A chain lane's node is two DEPENDENT table log-sums (E <- LS(M_k, LS(D_k, E))) with a third
+// beside them (D_{k+1}); a wave issues in order, so what the compiler puts between the instructions of the dependent pair is time
+// on the chain: it left the quieting v_max of every operand, register moves and the D chain's arithmetic in front of the
+// look-ups (145 ns per node at M = 145; the two log-sums alone are 2 x (5 VALU + ds_read + add) ~ 75 ns).  Here every
+// instruction that is not on the E path sits in the shadow of a table look-up: the D chain's log-sum and the store of D_k behind
+// the first look-up; the loads for node k+1, D_{k+1} and the address arithmetic behind the second.  LDS operations of a wave
+// return in order, so the waits count them: lgkmcnt(n) = "all but the youngest n".
+//   e, d      E so far, D_k           (in/out)
+//   st        LDS byte address of the row's slot k: M_k is read there a node ahead, D_k is left there
+//   tp        LDS byte address of {tMD, tDD}(k+1)
+//   set A     M_k, tMD(k), tDD(k) on entry; the asm covers TWO nodes and leaves set A for node k+2
+// ---------------------------------------------------------------------------------------------------------------------------
+#define BATH_LS_INDEX(a, x, y)                      \
+  "v_sub_f32 " a ", " x ", " y "\n\t"               \
+  "v_min_f32_e64 " a ", |" a "|, %[c15]\n\t"        \
+  "v_mul_f32 " a ", 0x447a0000, " a "\n\t"          \
+  "v_cvt_i32_f32 " a ", " a "\n\t"                  \
+  "v_lshl_add_u32 " a ", " a ", 2, %[tbl]\n\t"      \
+  "ds_read_b32 " a ", " a "\n\t"
+
+#define BATH_FWD_NODE(MK, TX, TY, MN, UX, UY)                                                                 \
+  BATH_LS_INDEX("%[a1]", "%[d]", "%[e]")                        /* L1: LS(D_k, E) */                          \
+  "s_waitcnt lgkmcnt(1)\n\t"                                    /* the loads of this node's M, tMD, tDD */    \
+  "v_add_f32 %[u], " MK ", " TX "\n\t"                                                                        \
+  "v_add_f32 %[w], %[d], " TY "\n\t"                                                                          \
+  "ds_write_b32 %[st], %[d]\n\t"                                /* W: D_k */                                  \
+  BATH_LS_INDEX("%[a2]", "%[u]", "%[w]")                        /* L2: D_{k+1} */                             \
+  "v_max_f32 %[mx1], %[d], %[e]\n\t"                                                                          \
+  "v_max_f32 %[mxd], %[u], %[w]\n\t"                                                                          \
+  "s_waitcnt lgkmcnt(2)\n\t"                                    /* L1 */                                      \
+  "v_add_f32 %[x], %[mx1], %[a1]\n\t"                                                                         \
+  BATH_LS_INDEX("%[a1]", MK, "%[x]")                            /* L3: LS(M_k, .) */                          \
+  "ds_read_b32 " MN ", %[st] offset:4\n\t"                                                                    \
+  "ds_read_b32 " UX ", %[tp]\n\t"                                                                             \
+  "ds_read_b32 " UY ", %[tp] offset:4\n\t"                                                                    \
+  "v_max_f32 %[mx1], " MK ", %[x]\n\t"                                                                        \
+  "s_waitcnt lgkmcnt(4)\n\t"                                    /* W, L2 */                                   \
+  "v_add_f32 %[d], %[mxd], %[a2]\n\t"                                                                         \
+  "v_add_u32 %[st], 4, %[st]\n\t"                                                                             \
+  "v_add_u32 %[tp], 32, %[tp]\n\t"                                                                            \
+  "s_waitcnt lgkmcnt(3)\n\t"                                    /* L3 */                                      \
+  "v_add_f32 %[e], %[mx1], %[a1]\n\t"
+
+struct FwdChainRegs { float e, d, Mk, tx, ty; unsigned st, tp; };
+
+// <n> nodes of a Forward chain from the state in <r>; on return r.Mk, r.tx, r.ty belong to the node after the last one
+__device__ __forceinline__ void fwd_chain_nodes(FwdChainRegs &r, int n, unsigned tbl, float c15) {
+  float Mn, ux, uy, a1, a2, u, w, mx1, mxd, x;
+  int k = 0;
+  for (; k + 2 <= n; k += 2)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\t"
+                 BATH_FWD_NODE("%[Mk]", "%[tx]", "%[ty]", "%[Mn]", "%[ux]", "%[uy]")
+                 BATH_FWD_NODE("%[Mn]", "%[ux]", "%[uy]", "%[Mk]", "%[tx]", "%[ty]")
+                 "s_waitcnt lgkmcnt(0)"
+                 : [e] "+v"(r.e), [d] "+v"(r.d), [Mk] "+v"(r.Mk), [tx] "+v"(r.tx), [ty] "+v"(r.ty), [st] "+v"(r.st), [tp] "+v"(r.tp),
+                   [Mn] "=&v"(Mn), [ux] "=&v"(ux), [uy] "=&v"(uy), [a1] "=&v"(a1), [a2] "=&v"(a2), [u] "=&v"(u), [w] "=&v"(w),
+                   [mx1] "=&v"(mx1), [mxd] "=&v"(mxd), [x] "=&v"(x)
+                 : [tbl] "s"(tbl), [c15] "s"(c15)
+                 : "memory");
+  if (k < n) {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\t"
+                 BATH_FWD_NODE("%[Mk]", "%[tx]", "%[ty]", "%[Mn]", "%[ux]", "%[uy]")
+                 "s_waitcnt lgkmcnt(0)"
+                 : [e] "+v"(r.e), [d] "+v"(r.d), [st] "+v"(r.st), [tp] "+v"(r.tp),
+                   [Mn] "=&v"(Mn), [ux] "=&v"(ux), [uy] "=&v"(uy), [a1] "=&v"(a1), [a2] "=&v"(a2), [u] "=&v"(u), [w] "=&v"(w),
+                   [mx1] "=&v"(mx1), [mxd] "=&v"(mxd), [x] "=&v"(x)
+                 : [Mk] "v"(r.Mk), [tx] "v"(r.tx), [ty] "v"(r.ty), [tbl] "s"(tbl), [c15] "s"(c15)
+                 : "memory");
+    r.Mk = Mn; r.tx = ux; r.ty = uy;
+  }
+}
+
+// LDS byte address of a pointer into the block's dynamic shared memory (the low half of its flat address)
+__device__ __forceinline__ unsigned lds_addr(const void *p) { return (unsigned)(size_t)p; }
+
+// ---------------------------------------------------------------------------------------------------------------------------
 // 3-codon Forward parser, multihit, strict.  tf[node] = {tMM(k-1), tIM(k-1), tDM(k-1), tBM(k-1), tMD(k), tDD(k), tMI(k), tII(k)}
 // xmx (optional): (L+1) x {E,N,J,B,C}
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -127,17 +203,10 @@ __global__ __launch_bounds__(chain_threads(C)) void fs3_fwd_chain_kernel(SeqView
         float *st = s_stage + (size_t)lane * stride;
         float dch = -INFINITY, ech = -INFINITY;
         // the loop's own loads (M(i,k), the transitions) are a node ahead: what a node waits for is the chain's log-sums only
-        float Mn = st[1];
-        float2 tn = *reinterpret_cast<const float2 *>(s_tf + 1 * 8 + 4);           // tMD(k), tDD(k)
-        for (int k = 1; k <= M; k++) {
-          const float Mk = Mn;
-          const float2 t = tn;
-          Mn = st[k + 1];                                        // (slot M+1 exists: the stride is at least M+2)
-          tn = *reinterpret_cast<const float2 *>(s_tf + (k + 1) * 8 + 4);
-          st[k] = dch;
-          ech = LS(Mk, LS(dch, ech));
-          dch = LS(Mk + t.x, dch + t.y);
-        }
+        // (slot M+1 of the row and of the transitions exists: the loads run a node ahead)
+        FwdChainRegs r{ech, dch, st[1], s_tf[1 * 8 + 4], s_tf[1 * 8 + 5], lds_addr(st + 1), lds_addr(s_tf + 2 * 8 + 4)};   // tMD(k), tDD(k)
+        fwd_chain_nodes(r, M, lds_addr(s_tbl), 15.999f);
+        ech = r.e; dch = r.d;
         s_e[lane] = ech;
       }
       lds_barrier();
@@ -278,17 +347,9 @@ __global__ __launch_bounds__(1024) void fs3_fwd_chain_half_kernel(SeqView dna, F
       if (chain_lane) {
         float *st = s_stage + (size_t)lane * stride;
         float dch = -INFINITY, ech = -INFINITY;
-        float Mn = st[1];
-        float2 tn = *reinterpret_cast<const float2 *>(s_tf + 1 * 8 + 4);
-        for (int k = 1; k <= M; k++) {
-          const float Mk = Mn;
-          const float2 t = tn;
-          Mn = st[k + 1];
-          tn = *reinterpret_cast<const float2 *>(s_tf + (k + 1) * 8 + 4);
-          st[k] = dch;
-          ech = LS(Mk, LS(dch, ech));
-          dch = LS(Mk + t.x, dch + t.y);
-        }
+        FwdChainRegs r{ech, dch, st[1], s_tf[1 * 8 + 4], s_tf[1 * 8 + 5], lds_addr(st + 1), lds_addr(s_tf + 2 * 8 + 4)};   // tMD(k), tDD(k)
+        fwd_chain_nodes(r, M, lds_addr(s_tbl), 15.999f);
+        ech = r.e; dch = r.d;
         // special states of row i + cs (:592-603); row i-3 is the other slot's row of two pairs ago (slot 0) or of the previous pair (slot 1)
         const float pN1 = __shfl_xor(hN1, 1, 64), pN2 = __shfl_xor(hN2, 1, 64), pJ1 = __shfl_xor(hJ1, 1, 64), pJ2 = __shfl_xor(hJ2, 1, 64);
         const float pC1 = __shfl_xor(hC1, 1, 64), pC2 = __shfl_xor(hC2, 1, 64);
@@ -603,17 +664,10 @@ __global__ __launch_bounds__(chain_threads(C)) void fs5_fwd_chain_kernel(SeqView
       if (wv == 0 && lane < W) {
         float *st = s_stage + (size_t)lane * 2 * stride;
         float dch = -INFINITY, ech = -INFINITY;
-        float Mn = st[1];
-        float2 tn = *reinterpret_cast<const float2 *>(s_tf + 1 * 8 + 4);           // tMD(k), tDD(k)
-        for (int k = 1; k < M; k++) {
-          const float Mk = Mn;
-          const float2 t2 = tn;
-          Mn = st[k + 1];
-          tn = *reinterpret_cast<const float2 *>(s_tf + (k + 1) * 8 + 4);
-          st[k] = dch;
-          ech = LS(Mk, LS(dch, ech));
-          dch = LS(Mk + t2.x, dch + t2.y);
-        }
+        FwdChainRegs r{ech, dch, st[1], s_tf[1 * 8 + 4], s_tf[1 * 8 + 5], lds_addr(st + 1), lds_addr(s_tf + 2 * 8 + 4)};   // tMD(k), tDD(k)
+        fwd_chain_nodes(r, M - 1, lds_addr(s_tbl), 15.999f);
+        ech = r.e; dch = r.d;
+        const float Mn = r.Mk;                                    // M(i,M)
         st[M] = dch;
         ech = (i >= 5) ? LS(LS(Mn, dch), ech) : LS(Mn, LS(dch, ech));
         s_e[lane] = ech;
