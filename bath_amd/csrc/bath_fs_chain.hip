@@ -18,6 +18,7 @@
 // The pair's duration is the chain's: 2M dependent log-sums; the 64-step lane hand-off this replaces paid a trip through the
 // LDS crossbar per lane and ran every window's chain as its own wave-wide instruction stream.
 #include <cstring>
+#include <type_traits>
 
 #include "bath_fs_device.hpp"
 
@@ -174,15 +175,18 @@ __global__ __launch_bounds__(chain_threads(C)) void fs3_fwd_chain_kernel(SeqView
         const float4 ta = *reinterpret_cast<const float4 *>(s_tf + nd * 8);
         const float4 tb = *reinterpret_cast<const float4 *>(s_tf + nd * 8 + 4);
         const bool in = node <= M;
-        const float ea2 = in ? qa2[ne] : -INFINITY, ea3 = in ? qa3[ne] : -INFINITY, ea4 = in ? qa4[ne] : -INFINITY;
-        const float eb2 = in ? qb2[ne] : -INFINITY, eb3 = in ? qb3[ne] : -INFINITY, eb4 = in ? qb4[ne] : -INFINITY;
+        // (no branches in this loop: loads and stores are unconditional -- the slots past node M exist -- so that the log-sums of
+        // a lane's C nodes, independent of each other, can be interleaved)
+        const float la2 = qa2[ne], la3 = qa3[ne], la4 = qa4[ne], lb2 = qb2[ne], lb3 = qb3[ne], lb4 = qb4[ne];
+        const float ea2 = in ? la2 : -INFINITY, ea3 = in ? la3 : -INFINITY, ea4 = in ? la4 : -INFINITY;
+        const float eb2 = in ? lb2 : -INFINITY, eb3 = in ? lb3 : -INFINITY, eb4 = in ? lb4 : -INFINITY;
         // row A = i: from row i-2 and B(i-2) (:562-569); row 2 takes B(0) only (:503)
         const float mA = (c == 0) ? mInA : M2[c - 1], iA = (c == 0) ? iInA : I2[c - 1], dA = (c == 0) ? dInA : D2[c - 1];
         float a = LS(mA + ta.x, LS(iA + ta.y, LS(dA + ta.z, B2 + ta.w)));
-        if (i == 2) a = B2 + ta.w;
+        // (row 2 takes B(0) only (:503): rows 0 and 1 are -inf, and LS(-inf, x) = x exactly)
         ivA[c] = a;
         float mv = a + ea2;
-        if (i > 2) { mv = LS(mv, iv_1[c] + ea3); mv = LS(mv, iv_2[c] + ea4); }   // :571-574
+        mv = LS(mv, iv_1[c] + ea3); mv = LS(mv, iv_2[c] + ea4);      // :571-574 (row 2: the IVX of rows 1, 0 are -inf)
         MA[c] = mv;
         const float insA = LS(M3[c] + tb.z, I3[c] + tb.w);
         IA[c] = (i > 2 && node < M) ? insA : -INFINITY;
@@ -195,7 +199,7 @@ __global__ __launch_bounds__(chain_threads(C)) void fs3_fwd_chain_kernel(SeqView
         MB[c] = mw;
         const float insB = LS(M2[c] + tb.z, I2[c] + tb.w);
         IB[c] = (node < M) ? insB : -INFINITY;
-        if (in) { s_stage[((size_t)wv * 2 + 0) * stride + node] = mv; s_stage[((size_t)wv * 2 + 1) * stride + node] = mw; }
+        s_stage[((size_t)wv * 2 + 0) * stride + node] = mv; s_stage[((size_t)wv * 2 + 1) * stride + node] = mw;
       }
       lds_barrier();
       // ---- 2. the serial part, a lane per row: D(i,k) = LS(M(i,k-1) + tMD, D(i,k-1) + tDD), E(i) = LS(M(i,k), LS(D(i,k), E)) (:577-590)
@@ -321,14 +325,17 @@ __global__ __launch_bounds__(1024) void fs3_fwd_chain_half_kernel(SeqView dna, F
         const float4 ta = *reinterpret_cast<const float4 *>(s_tf + nd * 8);
         const float4 tb = *reinterpret_cast<const float4 *>(s_tf + nd * 8 + 4);
         const bool in = node <= M;
-        const float ea2 = in ? qa2[ne] : -INFINITY, ea3 = in ? qa3[ne] : -INFINITY, ea4 = in ? qa4[ne] : -INFINITY;
-        const float eb2 = in ? qb2[ne] : -INFINITY, eb3 = in ? qb3[ne] : -INFINITY, eb4 = in ? qb4[ne] : -INFINITY;
+        // (no branches in this loop: loads and stores are unconditional -- the slots past node M exist -- so that the log-sums of
+        // a lane's C nodes, independent of each other, can be interleaved)
+        const float la2 = qa2[ne], la3 = qa3[ne], la4 = qa4[ne], lb2 = qb2[ne], lb3 = qb3[ne], lb4 = qb4[ne];
+        const float ea2 = in ? la2 : -INFINITY, ea3 = in ? la3 : -INFINITY, ea4 = in ? la4 : -INFINITY;
+        const float eb2 = in ? lb2 : -INFINITY, eb3 = in ? lb3 : -INFINITY, eb4 = in ? lb4 : -INFINITY;
         const float mA = (c == 0) ? mInA : M2[c - 1], iA = (c == 0) ? iInA : I2[c - 1], dA = (c == 0) ? dInA : D2[c - 1];
         float a = LS(mA + ta.x, LS(iA + ta.y, LS(dA + ta.z, B2 + ta.w)));
-        if (i == 2) a = B2 + ta.w;
+        // (row 2 takes B(0) only (:503): rows 0 and 1 are -inf, and LS(-inf, x) = x exactly)
         ivA[c] = a;
         float mv = a + ea2;
-        if (i > 2) { mv = LS(mv, iv_1[c] + ea3); mv = LS(mv, iv_2[c] + ea4); }
+        mv = LS(mv, iv_1[c] + ea3); mv = LS(mv, iv_2[c] + ea4);
         MA[c] = mv;
         const float insA = LS(M3[c] + tb.z, I3[c] + tb.w);
         IA[c] = (i > 2 && node < M) ? insA : -INFINITY;
@@ -340,7 +347,7 @@ __global__ __launch_bounds__(1024) void fs3_fwd_chain_half_kernel(SeqView dna, F
         MB[c] = mw;
         const float insB = LS(M2[c] + tb.z, I2[c] + tb.w);
         IB[c] = (node < M) ? insB : -INFINITY;
-        if (in) { s_stage[((size_t)win * 2 + 0) * stride + node] = mv; s_stage[((size_t)win * 2 + 1) * stride + node] = mw; }
+        s_stage[((size_t)win * 2 + 0) * stride + node] = mv; s_stage[((size_t)win * 2 + 1) * stride + node] = mw;
       }
       lds_barrier();
       // ---- the serial part: all 64 lanes of wave 0, a row each
@@ -474,7 +481,7 @@ __global__ __launch_bounds__(chain_threads(C)) void fs3_bwd_chain_kernel(SeqView
         const float a = mainA ? LS(sa2, LS(sa3, sa4)) : LS(LS(sa2, sa3), sa4);       // :1552-1553; the rows near the end add their codons left to right (:1483, :1517-1518)
         const float b = mainB ? LS(sb2, LS(sb3, sb4)) : LS(LS(sb2, sb3), sb4);
         ivA[c] = in ? a : -INFINITY; ivB[c] = in ? b : -INFINITY;
-        if (in) { s_stage[((size_t)wv * 2 + 0) * stride + node] = ivA[c]; s_stage[((size_t)wv * 2 + 1) * stride + node] = ivB[c]; }
+        s_stage[((size_t)wv * 2 + 0) * stride + node] = ivA[c]; s_stage[((size_t)wv * 2 + 1) * stride + node] = ivB[c];
       }
       lds_barrier();
       // ---- 2. the serial part
@@ -628,34 +635,46 @@ __global__ __launch_bounds__(chain_threads(C)) void fs5_fwd_chain_kernel(SeqView
 #pragma unroll
         for (int q = 0; q < 8; q++) row[q] = -INFINITY;
       }
+      // The cells of the row, then their stores.  Rows >= 5 (all but four of a window) go through a loop without branches, so that
+      // the log-sums of a lane's C nodes -- independent of each other -- are interleaved; the first rows take the general form.
+      float q1[C], q2[C], q3[C], q4[C], q5[C];
+      auto cells = [&](auto early_tag) {
+        constexpr bool EARLY = decltype(early_tag)::value;
 #pragma unroll
-      for (int c = 0; c < C; c++) {
-        const int node = lane * C + c + 1, nd = imin(node, M + 1), ne = imin(node, M);
-        const float4 ta = *reinterpret_cast<const float4 *>(s_tf + nd * 8);
-        const float4 tb = *reinterpret_cast<const float4 *>(s_tf + nd * 8 + 4);
-        const float m1 = (c == 0) ? mIn : Mr0[c - 1], i1 = (c == 0) ? iIn : Ir0[c - 1], d1 = (c == 0) ? dIn : Dr1[c - 1];
-        float ivn;
-        if (i <= 2) ivn = xBprev + ta.w;                                          // rows 1, 2: only B(i-1) enters (:109, :150)
-        else ivn = LS(m1 + ta.x, LS(i1 + ta.y, LS(d1 + ta.z, xBprev + ta.w)));    // :332-335
-        ivc[c] = ivn;
-        const float c1 = ivn + r1[ne];
-        const float c2 = (i >= 2) ? iv0[c] + r2[ne] : -INFINITY;
-        const float c3 = (i >= 3) ? iv1[c] + r3[ne] : -INFINITY;
-        const float c4 = (i >= 4) ? iv2[c] + r4[ne] : -INFINITY;
-        const float c5 = (i >= 5) ? (c5_compat ? ivn : iv3[c]) + r5[ne] : -INFINITY;
-        float c0;
-        if (i == 1) c0 = c1;
-        else if (i == 2) c0 = LS(c1, c2);
-        else if (i < 5) c0 = LS(c1, LS(c2, LS(c3, c4)));
-        else c0 = LS(LS(c1, LS(c2, c3)), LS(c4, c5));
-        Mc[c] = c0;
-        const float ins = LS(Mr2[c] + tb.z, Ir2[c] + tb.w);
-        Ic[c] = (i >= 3 && node < M) ? ins : -INFINITY;
-        if (node <= M) {
-          s_stage[((size_t)wv * 2) * stride + node] = c0;
-          if (act) {
+        for (int c = 0; c < C; c++) {
+          const int node = lane * C + c + 1, nd = imin(node, M + 1), ne = imin(node, M);
+          const float4 ta = *reinterpret_cast<const float4 *>(s_tf + nd * 8);
+          const float4 tb = *reinterpret_cast<const float4 *>(s_tf + nd * 8 + 4);
+          const float m1 = (c == 0) ? mIn : Mr0[c - 1], i1 = (c == 0) ? iIn : Ir0[c - 1], d1 = (c == 0) ? dIn : Dr1[c - 1];
+          const float e1 = r1[ne], e2 = r2[ne], e3 = r3[ne], e4 = r4[ne], e5 = r5[ne];
+          float ivn = LS(m1 + ta.x, LS(i1 + ta.y, LS(d1 + ta.z, xBprev + ta.w)));  // :332-335
+          if (EARLY && i <= 2) ivn = xBprev + ta.w;                                  // rows 1, 2: only B(i-1) enters (:109, :150)
+          ivc[c] = ivn;
+          const float c1 = ivn + e1;
+          const float c2 = (!EARLY || i >= 2) ? iv0[c] + e2 : -INFINITY;
+          const float c3 = (!EARLY || i >= 3) ? iv1[c] + e3 : -INFINITY;
+          const float c4 = (!EARLY || i >= 4) ? iv2[c] + e4 : -INFINITY;
+          const float c5 = !EARLY ? (c5_compat ? ivn : iv3[c]) + e5 : -INFINITY;
+          float c0;
+          if (!EARLY) c0 = LS(LS(c1, LS(c2, c3)), LS(c4, c5));
+          else if (i == 1) c0 = c1;
+          else if (i == 2) c0 = LS(c1, c2);
+          else c0 = LS(c1, LS(c2, LS(c3, c4)));
+          Mc[c] = c0;
+          const float ins = LS(Mr2[c] + tb.z, Ir2[c] + tb.w);
+          Ic[c] = ((!EARLY || i >= 3) && node < M) ? ins : -INFINITY;
+          q1[c] = c1; q2[c] = c2; q3[c] = c3; q4[c] = c4; q5[c] = c5;
+          s_stage[((size_t)wv * 2) * stride + node] = c0;           // (the slots past node M exist)
+        }
+      };
+      if (i >= 5) cells(std::false_type{}); else cells(std::true_type{});
+      if (act) {
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+          const int node = lane * C + c + 1;
+          if (node <= M) {
             float *cell = row + (size_t)node * 8;
-            cell[1] = Ic[c]; cell[2] = c0; cell[3] = c1; cell[4] = c2; cell[5] = c3; cell[6] = c4; cell[7] = c5;
+            cell[1] = Ic[c]; cell[2] = Mc[c]; cell[3] = q1[c]; cell[4] = q2[c]; cell[5] = q3[c]; cell[6] = q4[c]; cell[7] = q5[c];
           }
         }
       }
@@ -714,7 +733,7 @@ __global__ __launch_bounds__(chain_threads(C)) void fs5_fwd_chain_kernel(SeqView
 #undef LS
 }
 
-static int chain_waves(bath_hip_ctx *ctx, int64_t n, int M, int C, size_t *shmem_out) {
+static int chain_waves(bath_hip_ctx *ctx, int64_t n, int M, int C, size_t *shmem_out, int cu_share = 1) {
   // as many windows per block as LDS holds next to the table and the transitions ...
   const size_t fixed = (size_t)(kLogsumTbl + (M + 2) * 8 + 2 * kChainMaxWaves + 16) * sizeof(float);
   int W = chain_threads(C) / 64;
@@ -724,7 +743,10 @@ static int chain_waves(bath_hip_ctx *ctx, int64_t n, int M, int C, size_t *shmem
   // couple of hundred) a block holds one or two.  Two blocks on one CU is worse than one twice the size: the chain wave of one
   // then shares its SIMD with the other's parallel part and every dependent log-sum waits for an issue slot (measured: the
   // Backward parser of 2.5 k windows 14.8 ms as 157 blocks of 16, 17.8 ms as 313 blocks of 8).
-  const int64_t slots = (int64_t)ctx->prop.multiProcessorCount;
+  // <cu_share>: the launch is to leave the rest of the chip to kernels running beside it (the regions' Forward: the envelope
+  // kernels of the single-domain regions run on another stream, and their blocks -- a 64 KB table and the rings -- do not fit
+  // into a CU's LDS next to a block of this kernel: spread over every CU it would hold them back until it ends)
+  const int64_t slots = std::max<int64_t>(1, (int64_t)ctx->prop.multiProcessorCount / cu_share);
   while (W > 1 && (int64_t)(W / 2) * slots >= n) W >>= 1;
   *shmem_out = fixed + (size_t)W * 2 * fs_chain_stride(C) * sizeof(float);
   return W;
@@ -795,7 +817,8 @@ int launch_fs5_fwd_chain(bath_hip_ctx *ctx, hipStream_t stream, const bath_hip_f
                          float *d_sc, float *d_fwd, const int64_t *d_foff, float *d_xmx, const int64_t *d_xoff, int cfg_len, FsJobs jobs, int *d_done) {
   const int M = om->M;
   size_t shmem = 0;
-  const int W = chain_waves(ctx, dna->n, M, Cv, &shmem);
+  static const int share = [] { const char *e = std::getenv("BATH_HIP_FS_REGION_CU_SHARE"); return e ? std::max(1, std::atoi(e)) : 1; }();
+  const int W = chain_waves(ctx, dna->n, M, Cv, &shmem, share);
   const int64_t n = dna->n;
   const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((n + W - 1) / W, (int64_t)ctx->prop.multiProcessorCount));
   FsDev dev{om->M, om->pitch, om->maxcodons, om->d_rsc, om->d_tf, om->d_tb, om->d_logsum};

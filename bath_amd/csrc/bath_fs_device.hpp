@@ -56,10 +56,19 @@ struct FsDev {
 // Straight-line code: the table is read unconditionally at a clamped index and the early-out cases are a select.  With the
 // obvious `if (...) return mx;` every log-sum became its own exec-masked basic block (165 branches in the 3-codon Forward
 // kernel) and the compiler could not overlap the independent log-sums of a lane's nodes; the values are identical.
+// v_max_f32 as the instruction: fmaxf() first quiets each operand the compiler cannot prove canonical (a loaded value, a DPP
+// move) with a v_max_f32 x, x of its own -- two of the ten instructions of a table log-sum, in kernels that are chains of them.
+// The operands here are never NaN (scores are finite or -inf).
+__device__ __forceinline__ float vmax_raw(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 template <bool EXACT>
 __device__ __forceinline__ float flogsum(float a, float b, const float *tbl) {
-  const float mx = fmaxf(a, b), mn = fminf(a, b);
   if (EXACT) {
+    const float mx = fmaxf(a, b), mn = fminf(a, b);
     if (mn == -INFINITY || (mx - mn) >= 15.7f) return mx;
     return mx + log1pf(expf(mn - mx));
   }
@@ -67,9 +76,8 @@ __device__ __forceinline__ float flogsum(float a, float b, const float *tbl) {
   // "mn == -inf or mx - mn >= 15.7 -> mx" are then the look-up itself (mx + 0), and a log-sum is max, |a - b|, min, mul, cvt,
   // shift, ds_read, add.  (int)(d * 1000.f) >= 15700 exactly when d >= 15.7f: 15.7f * 1000.f rounds to 15700.0f and the float
   // below 15.7f to 15699.999.  a = b = -inf: |NaN| -> v_min returns 15.999 -> -inf + 0.
-  (void)mn;
   const float dc = fminf(fabsf(a - b), 15.999f);
-  return mx + tbl[(int)(dc * 1000.f)];
+  return vmax_raw(a, b) + tbl[(int)(dc * 1000.f)];
 }
 
 // the same on the unpadded table in global memory (kernels that take a few log-sums per target)
