@@ -110,6 +110,97 @@ __device__ __forceinline__ void fwd_chain_nodes(FwdChainRegs &r, int n, unsigned
   }
 }
 
+// ---- the Backward chains the same way.  B(i) = LS over the nodes, ascending, of ivx(i,k) + tBM(k-1): one log-sum per node,
+// the term of node k+1 added up and the raw values of node k+2 loaded behind the look-up.
+//   b       B so far (in/out);  v: the term of this node;  sN, tN: ivx and tBM of the NEXT node, loaded by the node before
+//   st, tp  LDS byte addresses of the row's slot k and of tBM(k-1) (s_tb[k * 8 + 7])
+#define BATH_BSUM_NODE(V, VN)                                                          \
+  BATH_LS_INDEX("%[a1]", "%[b]", V)                                                    \
+  "s_waitcnt lgkmcnt(1)\n\t"                                                           \
+  "v_add_f32 " VN ", %[sN], %[tN]\n\t"                                                 \
+  "ds_read_b32 %[sN], %[st] offset:8\n\t"                                              \
+  "ds_read_b32 %[tN], %[tp] offset:64\n\t"                                             \
+  "v_max_f32 %[mx], %[b], " V "\n\t"                                                   \
+  "v_add_u32 %[st], 4, %[st]\n\t"                                                      \
+  "v_add_u32 %[tp], 32, %[tp]\n\t"                                                     \
+  "s_waitcnt lgkmcnt(2)\n\t"                                                           \
+  "v_add_f32 %[b], %[mx], %[a1]\n\t"
+
+// b = LS(b, term(k)) for k = k0 .. k0 + n - 1; on entry v = term(k0), sN/tN = the raw values of node k0 + 1, st/tp at node k0
+__device__ __forceinline__ float bwd_bsum_nodes(float b, float v, float sN, float tN, unsigned st, unsigned tp, int n, unsigned tbl, float c15) {
+  float vn, a1, mx;
+  int k = 0;
+  for (; k + 2 <= n; k += 2)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\t"
+                 BATH_BSUM_NODE("%[v]", "%[vn]")
+                 BATH_BSUM_NODE("%[vn]", "%[v]")
+                 "s_waitcnt lgkmcnt(0)"
+                 : [b] "+v"(b), [v] "+v"(v), [sN] "+v"(sN), [tN] "+v"(tN), [st] "+v"(st), [tp] "+v"(tp), [vn] "=&v"(vn), [a1] "=&v"(a1), [mx] "=&v"(mx)
+                 : [tbl] "s"(tbl), [c15] "s"(c15)
+                 : "memory");
+  if (k < n)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\t"
+                 BATH_BSUM_NODE("%[v]", "%[vn]")
+                 "s_waitcnt lgkmcnt(0)"
+                 : [b] "+v"(b), [sN] "+v"(sN), [tN] "+v"(tN), [st] "+v"(st), [tp] "+v"(tp), [vn] "=&v"(vn), [a1] "=&v"(a1), [mx] "=&v"(mx)
+                 : [v] "v"(v), [tbl] "s"(tbl), [c15] "s"(c15)
+                 : "memory");
+  return b;
+}
+
+// D(i,k) = LS(LS(E, p1), p2), nodes descending, with {p1, p2} = {D(i,k+1) + tDD(k), ivx(i,k+1) + tDM(k)} -- the rows L-3, L-4
+// (<mid>, a lane mask) take them in the other order (:1524-1526).  Two dependent look-ups per node; the loads of node k-1 sit
+// behind the first, the address arithmetic behind the second; D(i,k) is stored over ivx(i,k), which was read a node ahead.
+//   dn   D(i,k+1) (in/out);  IVN: ivx(i,k+1);  set A = {ivx(i,k), tDD(k), tDM(k)};  st at slot k-1, tp at s_tb[(k-1) * 8 + 3]
+#define BATH_BWD_D_NODE(IVN, TX, TY, IVQ, UX, UY)                                      \
+  "v_add_f32 %[u], %[dn], " TX "\n\t"                                                  \
+  "v_add_f32 %[bs], " IVN ", " TY "\n\t"                                               \
+  "v_cndmask_b32_e64 %[p1], %[u], %[bs], %[mid]\n\t"                                   \
+  "v_cndmask_b32_e64 %[p2], %[bs], %[u], %[mid]\n\t"                                   \
+  BATH_LS_INDEX("%[a1]", "%[xE]", "%[p1]")                                             \
+  "ds_read_b32 " IVQ ", %[st]\n\t"                                                     \
+  "ds_read_b32 " UX ", %[tp]\n\t"                                                      \
+  "ds_read_b32 " UY ", %[tp] offset:4\n\t"                                             \
+  "v_max_f32 %[mx1], %[xE], %[p1]\n\t"                                                 \
+  "s_waitcnt lgkmcnt(3)\n\t"                                                           \
+  "v_add_f32 %[x], %[mx1], %[a1]\n\t"                                                  \
+  BATH_LS_INDEX("%[a1]", "%[x]", "%[p2]")                                              \
+  "v_max_f32 %[mx1], %[x], %[p2]\n\t"                                                  \
+  "v_add_u32 %[st], -4, %[st]\n\t"                                                     \
+  "v_add_u32 %[tp], -32, %[tp]\n\t"                                                    \
+  "s_waitcnt lgkmcnt(0)\n\t"                                                           \
+  "v_add_f32 %[dn], %[mx1], %[a1]\n\t"                                                 \
+  "ds_write_b32 %[st], %[dn] offset:8\n\t"
+
+struct BwdChainRegs { float dn, ivn, ivk, tx, ty; unsigned st, tp; };
+
+__device__ __forceinline__ void bwd_d_nodes(BwdChainRegs &r, float xE, unsigned long long mid, int n, unsigned tbl, float c15) {
+  float ivq, ux, uy, u, bs, p1, p2, a1, mx1, x;
+  int k = 0;
+  for (; k + 2 <= n; k += 2)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\t"
+                 BATH_BWD_D_NODE("%[ivn]", "%[tx]", "%[ty]", "%[ivq]", "%[ux]", "%[uy]")
+                 BATH_BWD_D_NODE("%[ivk]", "%[ux]", "%[uy]", "%[ivk]", "%[tx]", "%[ty]")
+                 "v_mov_b32 %[ivn], %[ivq]\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : [dn] "+v"(r.dn), [ivn] "+v"(r.ivn), [ivk] "+v"(r.ivk), [tx] "+v"(r.tx), [ty] "+v"(r.ty), [st] "+v"(r.st), [tp] "+v"(r.tp),
+                   [ivq] "=&v"(ivq), [ux] "=&v"(ux), [uy] "=&v"(uy), [u] "=&v"(u), [bs] "=&v"(bs), [p1] "=&v"(p1), [p2] "=&v"(p2),
+                   [a1] "=&v"(a1), [mx1] "=&v"(mx1), [x] "=&v"(x)
+                 : [xE] "v"(xE), [mid] "s"(mid), [tbl] "s"(tbl), [c15] "s"(c15)
+                 : "memory");
+  if (k < n) {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\t"
+                 BATH_BWD_D_NODE("%[ivn]", "%[tx]", "%[ty]", "%[ivq]", "%[ux]", "%[uy]")
+                 "s_waitcnt lgkmcnt(0)"
+                 : [dn] "+v"(r.dn), [st] "+v"(r.st), [tp] "+v"(r.tp),
+                   [ivq] "=&v"(ivq), [ux] "=&v"(ux), [uy] "=&v"(uy), [u] "=&v"(u), [bs] "=&v"(bs), [p1] "=&v"(p1), [p2] "=&v"(p2),
+                   [a1] "=&v"(a1), [mx1] "=&v"(mx1), [x] "=&v"(x)
+                 : [ivn] "v"(r.ivn), [tx] "v"(r.tx), [ty] "v"(r.ty), [xE] "v"(xE), [mid] "s"(mid), [tbl] "s"(tbl), [c15] "s"(c15)
+                 : "memory");
+    r.ivn = r.ivk; r.ivk = ivq; r.tx = ux; r.ty = uy;
+  }
+}
+
 // LDS byte address of a pointer into the block's dynamic shared memory (the low half of its flat address)
 __device__ __forceinline__ unsigned lds_addr(const void *p) { return (unsigned)(size_t)p; }
 
@@ -488,13 +579,9 @@ __global__ __launch_bounds__(chain_threads(C)) void fs3_bwd_chain_kernel(SeqView
       if (chain_lane) {
         float *st = s_stage + (size_t)lane * stride;
         const int avail = 2 * q + cs, irow = cL - avail;
-        float b = st[1] + s_tb[1 * 8 + 7];
-        float vn = st[2] + s_tb[2 * 8 + 7];                       // the terms are read a node ahead of the chain
-        for (int k = 2; k <= M; k++) {
-          const float v = vn;
-          vn = st[k + 1] + s_tb[(k + 1) * 8 + 7];
-          b = LS(b, v);
-        }
+        // (the terms are read two nodes ahead of the chain: the slots M+1, M+2 of the row and of the transitions are inside the block's LDS)
+        const float b = bwd_bsum_nodes(st[1] + s_tb[1 * 8 + 7], st[2] + s_tb[2 * 8 + 7], st[3], s_tb[3 * 8 + 7], lds_addr(st + 2), lds_addr(s_tb + 2 * 8 + 7),
+                                       M - 1, lds_addr(s_tbl), 15.999f);
         // N, J, C of row i+3: the other slot's row of two pairs ago (slot 0) or of the previous pair (slot 1)
         const float pN1 = __shfl_xor(hN1, 1, 64), pN2 = __shfl_xor(hN2, 1, 64), pJ1 = __shfl_xor(hJ1, 1, 64), pJ2 = __shfl_xor(hJ2, 1, 64);
         const float pC1 = __shfl_xor(hC1, 1, 64), pC2 = __shfl_xor(hC2, 1, 64);
@@ -506,20 +593,8 @@ __global__ __launch_bounds__(chain_threads(C)) void fs3_bwd_chain_kernel(SeqView
         const bool mid = (avail == 3) || (avail == 4);            // rows L-3, L-4 associate the D chain differently (:1524-1526)
         // D(i,k) = LS(LS(E, D(i,k+1) + tDD), ivx(i,k+1) + tDM); the rows L-3, L-4 pair E with the ivx term first (:1524-1526).
         // Log-sum is symmetric, so both are LS(LS(E, p1), p2) with the operands swapped: no branch in the loop
-        float dn = -INFINITY, ivn = -INFINITY;
-        float ivq = st[M];                                        // ivx(i,k), read a node ahead
-        float2 tq = make_float2(s_tb[M * 8 + 3], s_tb[M * 8 + 4]);        // tDD(k), tDM(k)
-        for (int k = M; k >= 1; k--) {
-          const float2 t = tq;
-          const float ivk = ivq;
-          ivq = st[k - 1];
-          tq = make_float2(s_tb[(k - 1) * 8 + 3], s_tb[(k - 1) * 8 + 4]);
-          const float bs = ivn + t.y, u = dn + t.x;
-          const float dv = LS(LS(xE, mid ? bs : u), mid ? u : bs);
-          st[k] = dv;
-          ivn = ivk;
-          dn = dv;
-        }
+        BwdChainRegs r{-INFINITY, -INFINITY, st[M], s_tb[M * 8 + 3], s_tb[M * 8 + 4], lds_addr(st + M - 1), lds_addr(s_tb + (M - 1) * 8 + 3)};   // ivx(i,M), tDD(M), tDM(M)
+        bwd_d_nodes(r, xE, __builtin_amdgcn_ballot_w64(mid), M, lds_addr(s_tbl), 15.999f);
         s_e[lane] = xE;
         const float partnerN = __shfl_xor(xN, 1, 64);
         if (clive && irow >= 0) {
