@@ -651,8 +651,8 @@ __global__ __launch_bounds__(chain_threads(C)) void fs3_bwd_chain_kernel(SeqView
 // row i-1 and B(i-1), so rows cannot be paired: one row per step, W windows per block, the D chain and the E sum of all W rows
 // in one wave.  fwd[(i*(M+1)+k)*8 + {D,I,C0..C5}], xmx[i*5 + {E,N,J,B,C}]; done[job] = 1 (system scope) once the matrix has landed.
 // ---------------------------------------------------------------------------------------------------------------------------
-template <int C>
-__global__ __launch_bounds__(chain_threads(C)) void fs5_fwd_chain_kernel(SeqView dna, FsDev p, const float *__restrict__ loop_tab, const float *__restrict__ move_tab,
+template <int C, int THREADS>
+__global__ __launch_bounds__(THREADS) void fs5_fwd_chain_kernel(SeqView dna, FsDev p, const float *__restrict__ loop_tab, const float *__restrict__ move_tab,
                                                              float tEL, float tEM, int c5_compat, float *__restrict__ sc, float *__restrict__ fwd, const int64_t *__restrict__ fwd_off,
                                                              float *__restrict__ xmx, const int64_t *__restrict__ xmx_off, int cfg_len, FsJobs jobs, int *__restrict__ done) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -695,14 +695,24 @@ __global__ __launch_bounds__(chain_threads(C)) void fs5_fwd_chain_kernel(SeqView
     float xN0 = 0.f, xN1 = 0.f, xN2 = 0.f, xJ0 = -INFINITY, xJ1 = -INFINITY, xJ2 = -INFINITY, xC0 = -INFINITY, xC1 = -INFINITY, xC2 = -INFINITY;   // rows i-1, i-2, i-3
     float xBprev = tNM;
     auto nuc = [&](int i) -> int { return (i >= 1 && i <= L) ? ((d[i - 1] < 4) ? (int)d[i - 1] : 1367) : 1367; };
-    for (int i = 1; i <= Lmax; i++) {
-      const bool act = live && i <= L;
+    // the emission scores of a row are loaded during the chain of the row before: nothing in a row waits for global memory
+    float E1[C], E2[C], E3[C], E4[C], E5[C];
+    auto load_emissions = [&](int i) {
       const int x = nuc(i), w = nuc(i - 1), v = nuc(i - 2), u = nuc(i - 3), t = nuc(i - 4);
       const float *r1 = p.rsc + (size_t)imin(x * 341, 1366) * p.pitch;
       const float *r2 = p.rsc + (size_t)imin(x * 341 + w * 85 + 1, 1365) * p.pitch;
       const float *r3 = p.rsc + (size_t)imin(x * 341 + w * 85 + v * 21 + 2, 1364) * p.pitch;
       const float *r4 = p.rsc + (size_t)imin(x * 341 + w * 85 + v * 21 + u * 5 + 3, 1365) * p.pitch;
       const float *r5 = p.rsc + (size_t)imin(x * 341 + w * 85 + v * 21 + u * 5 + t + 4, 1366) * p.pitch;
+#pragma unroll
+      for (int c = 0; c < C; c++) {
+        const int ne = imin(lane * C + c + 1, M);
+        E1[c] = r1[ne]; E2[c] = r2[ne]; E3[c] = r3[ne]; E4[c] = r4[ne]; E5[c] = r5[ne];
+      }
+    };
+    load_emissions(1);
+    for (int i = 1; i <= Lmax; i++) {
+      const bool act = live && i <= L;
       const float mIn = wave_shr1(Mr0[C - 1], -INFINITY), iIn = wave_shr1(Ir0[C - 1], -INFINITY), dIn = wave_shr1(Dr1[C - 1], -INFINITY);
       float Mc[C], Ic[C], ivc[C];
       float *row = fo + (size_t)(act ? i : 0) * (M + 1) * 8;
@@ -717,11 +727,11 @@ __global__ __launch_bounds__(chain_threads(C)) void fs5_fwd_chain_kernel(SeqView
         constexpr bool EARLY = decltype(early_tag)::value;
 #pragma unroll
         for (int c = 0; c < C; c++) {
-          const int node = lane * C + c + 1, nd = imin(node, M + 1), ne = imin(node, M);
+          const int node = lane * C + c + 1, nd = imin(node, M + 1);
           const float4 ta = *reinterpret_cast<const float4 *>(s_tf + nd * 8);
           const float4 tb = *reinterpret_cast<const float4 *>(s_tf + nd * 8 + 4);
           const float m1 = (c == 0) ? mIn : Mr0[c - 1], i1 = (c == 0) ? iIn : Ir0[c - 1], d1 = (c == 0) ? dIn : Dr1[c - 1];
-          const float e1 = r1[ne], e2 = r2[ne], e3 = r3[ne], e4 = r4[ne], e5 = r5[ne];
+          const float e1 = E1[c], e2 = E2[c], e3 = E3[c], e4 = E4[c], e5 = E5[c];
           float ivn = LS(m1 + ta.x, LS(i1 + ta.y, LS(d1 + ta.z, xBprev + ta.w)));  // :332-335
           if (EARLY && i <= 2) ivn = xBprev + ta.w;                                  // rows 1, 2: only B(i-1) enters (:109, :150)
           ivc[c] = ivn;
@@ -753,6 +763,7 @@ __global__ __launch_bounds__(chain_threads(C)) void fs5_fwd_chain_kernel(SeqView
           }
         }
       }
+      load_emissions(i + 1);
       lds_barrier();
       // ---- the serial part, a lane per window: D(i,k), E(i) in the reference's order; rows >= 5 pair M(i,M) and D(i,M) first (:392-394)
       if (wv == 0 && lane < W) {
@@ -897,10 +908,18 @@ int launch_fs5_fwd_chain(bath_hip_ctx *ctx, hipStream_t stream, const bath_hip_f
   const int64_t n = dna->n;
   const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((n + W - 1) / W, (int64_t)ctx->prop.multiProcessorCount));
   FsDev dev{om->M, om->pitch, om->maxcodons, om->d_rsc, om->d_tf, om->d_tb, om->d_logsum};
+  // a couple of hundred regions are one or two per block: then the kernel built for 256 threads, whose lanes have registers for
+  // the row's cells and the next row's emission scores without spilling (a 1024-thread block leaves a lane 128)
   BATH_CHAIN_SWITCH(Cv, {
-    BATH_HIP_TRY(ctx, hipFuncSetAttribute((const void *)fs5_fwd_chain_kernel<CC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    hipLaunchKernelGGL((fs5_fwd_chain_kernel<CC>), dim3(grid), dim3(64 * W), shmem, stream, dna->view(), dev, om->d_loop[0], om->d_move[0], tEL, tEM, c5_compat, d_sc, d_fwd, d_foff,
-                       d_xmx, d_xoff, cfg_len, jobs, d_done);
+    if (64 * W <= 256) {
+      BATH_HIP_TRY(ctx, hipFuncSetAttribute((const void *)fs5_fwd_chain_kernel<CC, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+      hipLaunchKernelGGL((fs5_fwd_chain_kernel<CC, 256>), dim3(grid), dim3(64 * W), shmem, stream, dna->view(), dev, om->d_loop[0], om->d_move[0], tEL, tEM, c5_compat, d_sc, d_fwd, d_foff,
+                         d_xmx, d_xoff, cfg_len, jobs, d_done);
+    } else {
+      BATH_HIP_TRY(ctx, hipFuncSetAttribute((const void *)fs5_fwd_chain_kernel<CC, chain_threads(CC)>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+      hipLaunchKernelGGL((fs5_fwd_chain_kernel<CC, chain_threads(CC)>), dim3(grid), dim3(64 * W), shmem, stream, dna->view(), dev, om->d_loop[0], om->d_move[0], tEL, tEM, c5_compat, d_sc, d_fwd, d_foff,
+                         d_xmx, d_xoff, cfg_len, jobs, d_done);
+    }
   })
   BATH_HIP_TRY(ctx, hipGetLastError());
   return BATH_OK;
