@@ -308,6 +308,7 @@ def main():
     ap.add_argument("--no-fs", action="store_true", help="skip the configs[2] (--fs) leg")
     ap.add_argument("--fs-windows", type=int, default=1_000_000)
     ap.add_argument("--no-streamed", action="store_true", help="skip the host-fed (PCIe-inclusive) leg")
+    ap.add_argument("--no-concurrent", action="store_true", help="skip the leg with three worker contexts running blocks concurrently")
     ap.add_argument("--no-c45", action="store_true", help="skip the configs[3] / configs[4] legs (multi-HMM database; 1024-node model with --fs)")
     ap.add_argument("--c4-mb", type=float, default=12.5, help="genome of the configs[3] leg, Mb (100 Mb over 8 GPUs)")
     ap.add_argument("--c5-mb", type=float, default=125.0, help="genome of the configs[4] leg, Mb (1 Gb over 8 GPUs)")
@@ -511,6 +512,8 @@ def main():
                                    "mismatches": {k: {"gpu": v[0], "cpu": v[1]} for k, v in diff.items()}}
         if world == 1 and not args.no_streamed:
             out.update(streamed_leg(ba, ctx, pipe, flat, offsets, args, stats))
+        if world == 1 and not args.no_concurrent:
+            out["concurrent_blocks"] = concurrent_leg(ba, hmm, flat, offsets, args, stats, ms_step)
         if not args.no_fs and world == 1:
             out["fs"] = fs_leg(ba, synth, ctx, hmm, om, args)
         if not args.no_c45 and world == 1:
@@ -526,6 +529,48 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def concurrent_leg(ba, hmm, flat, offsets, args, stats_one, ms_one, workers=3):
+    """The reference's threading model on one GPU (bathsearch.c thread_loop: every worker thread owns a block and a pipeline
+    object): <workers> contexts, each running the cascade over its own resident block at the same time, so that one block's
+    translation (head) and survivor kernels (tail) run beside another block's SSV.  Outside the headline's timed region."""
+    import threading
+    objs = []
+    for _ in range(workers):
+        c = ba.Context(0)
+        o = ba.OProfile(c, ba.Profile(hmm))
+        d = ba.SeqBlock(c, flat, offsets)
+        p = ba.Pipeline(c, o, fs_pipe=False, ncbi_table=hmm.ct)
+        p.run(d, want_results=False)
+        objs.append((c, o, d, p))
+    per = max(2, args.steps)
+    got = [None] * workers
+
+    def work(w):
+        c, _, d, p = objs[w]
+        for _ in range(per):
+            got[w], _ = p.run(d, want_results=False)
+        c.synchronize()
+
+    for c, _, _, _ in objs:
+        c.synchronize()
+    t0 = time.perf_counter()
+    th = [threading.Thread(target=work, args=(w,)) for w in range(workers)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    dt = time.perf_counter() - t0
+    same = all(int(getattr(g, f)) == int(getattr(stats_one, f)) for g in got for f in COUNTERS)
+    ms = dt * 1e3 / (per * workers)
+    for c, _, _, _ in objs:
+        c.close()
+    return {"what": "%d worker contexts, each a block of the headline's size resident in HBM and its own pipeline object, cascades running "
+                    "concurrently (heads and tails of one block beside the SSV of another)" % workers,
+            "workers": workers, "blocks": per * workers, "ms_per_block": ms, "residues_per_s": stats_one.nres / (ms * 1e-3),
+            "vs_one_worker": ms_one / ms, "counters_equal_to_one_worker": bool(same),
+            "note": "the gain is bounded by the SSV kernel, which saturates the packed-16-bit VALU issue rate whatever runs beside it (roofline.valu)"}
 
 
 def streamed_leg(ba, ctx, pipe, flat, offsets, args, stats_resident):

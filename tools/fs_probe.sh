@@ -3,7 +3,7 @@
 mkdir -p gpurun_out
 python -m pytest tests/test_frameshift_gpu.py -x -q -m gpu > gpurun_out/fs_tests.log 2>&1; echo "pytest rc=$?" >> gpurun_out/fs_tests.log
 tail -15 gpurun_out/fs_tests.log
-BATH_HIP_TIMING=1 timeout 900 python bench.py --no-cpu-baseline --no-streamed --no-one-part --steps 2 --warmup 1 > gpurun_out/fs_probe.json 2> gpurun_out/fs_probe.err
+BATH_HIP_TIMING=1 timeout 900 python bench.py --no-cpu-baseline --no-streamed --no-concurrent --no-one-part --steps 2 --warmup 1 > gpurun_out/fs_probe.json 2> gpurun_out/fs_probe.err
 python - <<'PY'
 import json
 d = json.loads(open("gpurun_out/fs_probe.json").read().strip().splitlines()[-1])

@@ -10,7 +10,7 @@ rm -rf $OUT; mkdir -p $OUT
 # 0: the bench line itself, with the stage laps of the --fs pass (strict first, then the fast mode)
 BATH_HIP_TIMING=1 python3 bench.py --steps 5 --warmup 1 > $OUT/bench_plain.json 2> $OUT/bench_stage_laps.txt
 # 1a: the cascade alone: every ssv_orf_kernel launch is a half-block launch of a timed step
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats0 -o bench0 -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-fs --no-streamed --no-one-part --no-c45 > $OUT/bench_under_prof_cascade.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats0 -o bench0 -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-fs --no-streamed --no-concurrent --no-one-part --no-c45 > $OUT/bench_under_prof_cascade.log 2>&1
 grep '^{"metric"' $OUT/bench_under_prof_cascade.log > $OUT/bench_under_prof_cascade.json
 find $OUT/stats0 -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats_cascade.csv \;
 rm -rf $OUT/stats0
@@ -26,12 +26,12 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats3 -o fs -- pyt
 find $OUT/stats3 -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats_fs_fast.csv \;
 rm -rf $OUT/stats3
 # 1d: configs[3] / configs[4] legs alone (a small main block keeps the rest of the command short)
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats4 -o c45 -- python3 bench.py --steps 2 --warmup 1 --windows 20000 --no-cpu-baseline --no-fs --no-streamed --no-one-part > $OUT/c45_under_prof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats4 -o c45 -- python3 bench.py --steps 2 --warmup 1 --windows 20000 --no-cpu-baseline --no-fs --no-streamed --no-concurrent --no-one-part > $OUT/c45_under_prof.log 2>&1
 find $OUT/stats4 -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats_c4_c5.csv \;
 rm -rf $OUT/stats4
 # 2: PMC passes, one counter set per run, one lane, on 200000-window blocks (both legs; the --fs leg runs strict then fast)
 export BATH_HIP_LANES=1
-P="python3 bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-streamed --no-one-part --no-c45 --windows 200000 --fs-windows 200000"
+P="python3 bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-streamed --no-concurrent --no-one-part --no-c45 --windows 200000 --fs-windows 200000"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $P > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $P > $OUT/pmc_write.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/pmc_sq1 -- $P > $OUT/pmc_sq1.log 2>&1
