@@ -133,10 +133,47 @@ __global__ __launch_bounds__(W == 1 ? kWfBlock : 64 * W) void fs5_fwd_wf_kernel(
     };
     prefetch_row(row + RW);
     const int T = ((L - 1) / RW) * Mp + ((L - 1) % RW) + M;
-    // the emission scores of a step are loaded during the step before
-    float e1, e2, e3, e4, e5;
-    { e1 = p.rsc[(size_t)r1 + 1]; e2 = p.rsc[(size_t)r2 + 1]; e3 = p.rsc[(size_t)r3 + 1]; e4 = p.rsc[(size_t)r4 + 1]; e5 = p.rsc[(size_t)r5 + 1]; }
-    for (int t = 0; t < T; t++) {
+    // The emission scores, FOUR steps at a time: a lane walks along its row, so the scores of its next four nodes are 16
+    // contiguous bytes of each of its five codon rows -- one request per codon row and four steps instead of four (the kernel
+    // is bound by the number of memory requests, not by bytes).  A block of four steps is loaded while the block before runs.
+    // A lane whose four steps straddle the end of its row (or its start) fetches the four scores one by one: a couple of
+    // lanes per block.  <kb>: the lane's node at the block's first step, counted on from the lane's state at the time of the
+    // call (past Mp: the lane's next row, whose nucleotides are already here).
+    float4 cu1, cu2, cu3, cu4, cu5, nx1, nx2, nx3, nx4, nx5;
+    auto load_block = [&](int kb, float4 &d1, float4 &d2, float4 &d3, float4 &d4, float4 &d5) {
+      int b1, b2, b3, b4, b5;                                          // codon rows of the lane's next row
+      codon_rows(code(nb0, true), code((int)(nbw >> 24), true), code((int)((nbw >> 16) & 255u), true), code((int)((nbw >> 8) & 255u), true), code((int)(nbw & 255u), true), b1, b2, b3, b4, b5);
+      const bool inA = kb >= 1 && kb + 3 <= imin(Mp, M), inB = kb > Mp && kb - Mp + 3 <= M;
+      if (inA || inB) {
+        const int n0 = inA ? kb : kb - Mp;
+        const float *s1 = p.rsc + (size_t)(inA ? r1 : b1) + n0, *s2 = p.rsc + (size_t)(inA ? r2 : b2) + n0, *s3 = p.rsc + (size_t)(inA ? r3 : b3) + n0;
+        const float *s4 = p.rsc + (size_t)(inA ? r4 : b4) + n0, *s5 = p.rsc + (size_t)(inA ? r5 : b5) + n0;
+        __builtin_memcpy(&d1, s1, 16); __builtin_memcpy(&d2, s2, 16); __builtin_memcpy(&d3, s3, 16); __builtin_memcpy(&d4, s4, 16); __builtin_memcpy(&d5, s5, 16);
+      } else {
+        float o1[4], o2[4], o3[4], o4[4], o5[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const int kj = kb + j;
+          const bool nxt = kj > Mp;
+          const int nd = nxt ? kj - Mp : kj, nq = nd < 1 ? 1 : (nd > M ? M : nd);
+          o1[j] = p.rsc[(size_t)(nxt ? b1 : r1) + nq]; o2[j] = p.rsc[(size_t)(nxt ? b2 : r2) + nq]; o3[j] = p.rsc[(size_t)(nxt ? b3 : r3) + nq];
+          o4[j] = p.rsc[(size_t)(nxt ? b4 : r4) + nq]; o5[j] = p.rsc[(size_t)(nxt ? b5 : r5) + nq];
+        }
+        d1 = make_float4(o1[0], o1[1], o1[2], o1[3]); d2 = make_float4(o2[0], o2[1], o2[2], o2[3]); d3 = make_float4(o3[0], o3[1], o3[2], o3[3]);
+        d4 = make_float4(o4[0], o4[1], o4[2], o4[3]); d5 = make_float4(o5[0], o5[1], o5[2], o5[3]);
+      }
+    };
+    cu1 = cu2 = cu3 = cu4 = cu5 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!(dbg & 1)) load_block(k, cu1, cu2, cu3, cu4, cu5);
+    for (int t0 = 0; t0 < T; t0 += 4) {
+     nx1 = cu1; nx2 = cu2; nx3 = cu3; nx4 = cu4; nx5 = cu5;
+     if (!(dbg & 1)) load_block(k + 4, nx1, nx2, nx3, nx4, nx5);
+#pragma unroll
+     for (int ts = 0; ts < 4; ts++) {
+      const int t = t0 + ts;
+      const float e1 = (ts == 0) ? cu1.x : (ts == 1) ? cu1.y : (ts == 2) ? cu1.z : cu1.w, e2 = (ts == 0) ? cu2.x : (ts == 1) ? cu2.y : (ts == 2) ? cu2.z : cu2.w;
+      const float e3 = (ts == 0) ? cu3.x : (ts == 1) ? cu3.y : (ts == 2) ? cu3.z : cu3.w, e4 = (ts == 0) ? cu4.x : (ts == 1) ? cu4.y : (ts == 2) ? cu4.z : cu4.w;
+      const float e5 = (ts == 0) ? cu5.x : (ts == 1) ? cu5.y : (ts == 2) ? cu5.z : cu5.w;
       const bool act = (k >= 1) && (k <= M) && (row <= L);
       const int kk = k < 1 ? 1 : (k > M ? M : k);
       const float4 ta = *reinterpret_cast<const float4 *>(s_tf + kk * 8);
@@ -170,10 +207,6 @@ __global__ __launch_bounds__(W == 1 ? kWfBlock : 64 * W) void fs5_fwd_wf_kernel(
         codon_rows(code(nb0, true), code((int)(nbw >> 24), true), code((int)((nbw >> 16) & 255u), true), code((int)((nbw >> 8) & 255u), true), code((int)(nbw & 255u), true), q1, q2, q3, q4, q5);
         Bn = Bnext;
         prefetch_row(rown + RW);
-      }
-      {
-        const int kq = kn < 1 ? 1 : (kn > M ? M : kn);
-        if (!(dbg & 1)) { e1 = p.rsc[(size_t)q1 + kq]; e2 = p.rsc[(size_t)q2 + kq]; e3 = p.rsc[(size_t)q3 + kq]; e4 = p.rsc[(size_t)q4 + kq]; e5 = p.rsc[(size_t)q5 + kq]; }
       }
       // the cell goes out after the loads above were issued: what the next step waits for is then a step old
       if (act && !(dbg & 2)) {
@@ -213,6 +246,8 @@ __global__ __launch_bounds__(W == 1 ? kWfBlock : 64 * W) void fs5_fwd_wf_kernel(
       dch = carry ? dnew : -INFINITY; ech = carry ? enew : -INFINITY;
       k = kn; row = rown; r1 = q1; r2 = q2; r3 = q3; r4 = q4; r5 = q5; Bcur = Bn;
       if (W > 1) lds_wf_barrier();                                      // mailboxes, ring and C values of this step are in place
+     }
+     cu1 = nx1; cu2 = nx2; cu3 = nx3; cu4 = nx4; cu5 = nx5;
     }
     if (W == 1) {
       const float cL = __shfl(cfin, (L - 1) & 63, 64), cL1 = __shfl(cfin, (L - 2) & 63, 64), cL2 = __shfl(cfin, (L - 3) & 63, 64);
@@ -314,9 +349,40 @@ __global__ __launch_bounds__(W == 1 ? kWfBlock : 64 * W) void fs5_bwd_wf_kernel(
     };
     if (L >= RW) prefetch_row(j + RW); else { nb0 = 0; nbw = 0; xEn = 0.f; }
     const int T = (int)fs_bwd_wf_steps(L, M, RW);
-    float e1, e2, e3, e4, e5;
-    { e1 = p.rsc[(size_t)r1 + M]; e2 = p.rsc[(size_t)r2 + M]; e3 = p.rsc[(size_t)r3 + M]; e4 = p.rsc[(size_t)r4 + M]; e5 = p.rsc[(size_t)r5 + M]; }
-    for (int t = 0; t < T; t++) {
+    // the emission scores four steps at a time, as in Forward: the sweep descends, so the block's first step is the vector's LAST component
+    float4 cu1, cu2, cu3, cu4, cu5, nx1, nx2, nx3, nx4, nx5;
+    auto load_block = [&](int kb, float4 &d1, float4 &d2, float4 &d3, float4 &d4, float4 &d5) {
+      int b1, b2, b3, b4, b5;                                          // codon rows of the lane's next row
+      codon_rows(code(nb0, true), code((int)(nbw & 255u), true), code((int)((nbw >> 8) & 255u), true), code((int)((nbw >> 16) & 255u), true), code((int)(nbw >> 24), true), b1, b2, b3, b4, b5);
+      const bool inA = kb >= 1 && kb + 3 <= imin(Mp, M), inB = kb > Mp && kb - Mp + 3 <= M;
+      if (inA || inB) {
+        const int n0 = M - 2 - (inA ? kb : kb - Mp);                   // the node of the block's last step
+        const float *s1 = p.rsc + (size_t)(inA ? r1 : b1) + n0, *s2 = p.rsc + (size_t)(inA ? r2 : b2) + n0, *s3 = p.rsc + (size_t)(inA ? r3 : b3) + n0;
+        const float *s4 = p.rsc + (size_t)(inA ? r4 : b4) + n0, *s5 = p.rsc + (size_t)(inA ? r5 : b5) + n0;
+        __builtin_memcpy(&d1, s1, 16); __builtin_memcpy(&d2, s2, 16); __builtin_memcpy(&d3, s3, 16); __builtin_memcpy(&d4, s4, 16); __builtin_memcpy(&d5, s5, 16);
+      } else {
+        float o1[4], o2[4], o3[4], o4[4], o5[4];
+#pragma unroll
+        for (int jj = 0; jj < 4; jj++) {
+          const int kj = kb + jj;
+          const bool nxt = kj > Mp;
+          const int ps = nxt ? kj - Mp : kj, nq = M + 1 - (ps < 1 ? 1 : (ps > M ? M : ps));
+          o1[3 - jj] = p.rsc[(size_t)(nxt ? b1 : r1) + nq]; o2[3 - jj] = p.rsc[(size_t)(nxt ? b2 : r2) + nq]; o3[3 - jj] = p.rsc[(size_t)(nxt ? b3 : r3) + nq];
+          o4[3 - jj] = p.rsc[(size_t)(nxt ? b4 : r4) + nq]; o5[3 - jj] = p.rsc[(size_t)(nxt ? b5 : r5) + nq];
+        }
+        d1 = make_float4(o1[0], o1[1], o1[2], o1[3]); d2 = make_float4(o2[0], o2[1], o2[2], o2[3]); d3 = make_float4(o3[0], o3[1], o3[2], o3[3]);
+        d4 = make_float4(o4[0], o4[1], o4[2], o4[3]); d5 = make_float4(o5[0], o5[1], o5[2], o5[3]);
+      }
+    };
+    load_block(k, cu1, cu2, cu3, cu4, cu5);
+    for (int t0 = 0; t0 < T; t0 += 4) {
+     load_block(k + 4, nx1, nx2, nx3, nx4, nx5);
+#pragma unroll
+     for (int ts = 0; ts < 4; ts++) {
+      const int t = t0 + ts;
+      const float e1 = (ts == 0) ? cu1.w : (ts == 1) ? cu1.z : (ts == 2) ? cu1.y : cu1.x, e2 = (ts == 0) ? cu2.w : (ts == 1) ? cu2.z : (ts == 2) ? cu2.y : cu2.x;
+      const float e3 = (ts == 0) ? cu3.w : (ts == 1) ? cu3.z : (ts == 2) ? cu3.y : cu3.x, e4 = (ts == 0) ? cu4.w : (ts == 1) ? cu4.z : (ts == 2) ? cu4.y : cu4.x;
+      const float e5 = (ts == 0) ? cu5.w : (ts == 1) ? cu5.z : (ts == 2) ? cu5.y : cu5.x;
       const bool act = (k >= 1) && (k <= M) && (j <= L);
       const int kk = k < 1 ? 1 : (k > M ? M : k);
       const int node = M + 1 - kk;
@@ -356,11 +422,6 @@ __global__ __launch_bounds__(W == 1 ? kWfBlock : 64 * W) void fs5_bwd_wf_kernel(
         xEq = xEn;
         if (jn + RW <= L) prefetch_row(jn + RW);
       }
-      {
-        const int kq = kn < 1 ? 1 : (kn > M ? M : kn);
-        const int nq = M + 1 - kq;
-        e1 = p.rsc[(size_t)q1 + nq]; e2 = p.rsc[(size_t)q2 + nq]; e3 = p.rsc[(size_t)q3 + nq]; e4 = p.rsc[(size_t)q4 + nq]; e5 = p.rsc[(size_t)q5 + nq];
-      }
       if (act) {
         float *cell = bo + ((size_t)(L - j) * (M + 1) + node) * 3;
         cell[0] = dv; cell[1] = iv_; cell[2] = mv;
@@ -379,6 +440,8 @@ __global__ __launch_bounds__(W == 1 ? kWfBlock : 64 * W) void fs5_bwd_wf_kernel(
       dprev = carry ? dv : -INFINITY; ivprev = carry ? a : -INFINITY;
       k = kn; j = jn; r1 = q1; r2 = q2; r3 = q3; r4 = q4; r5 = q5; xE = xEq;
       if (W > 1) lds_wf_barrier();
+     }
+     cu1 = nx1; cu2 = nx2; cu3 = nx3; cu4 = nx4; cu5 = nx5;
     }
   }
 #undef LS
@@ -445,7 +508,12 @@ size_t fs_wf_ring_floats(int M) { return (size_t)(M + 2) * 8; }
 static int fs_wf_waves(bath_hip_ctx *ctx, int64_t n, int M) {
   static const int forced = [] { const char *e = std::getenv("BATH_HIP_WF_WAVES"); return e ? std::atoi(e) : 0; }();
   if (forced == 1 || forced == 2 || forced == 4 || forced == 8) return forced;
-  if (n > (int64_t)ctx->prop.multiProcessorCount * 2) return 1;
+  // Thousands of envelopes: a wave each.  Up to a dozen per CU (the single-domain regions of a bench pass: 2.5 k): at a wave each
+  // the launch would last as long as its longest envelope with most wave slots idle, and its 1024-thread blocks (the table and
+  // 16 rings: 144 KB of LDS) would wait for the CUs the regions' Forward holds beside it; two waves per envelope halve the
+  // latency, and a 128-thread block (74 KB) shares a CU with one of those.  (4800 envelopes: equal; 9600: a wave each is 1.25x faster.)
+  if (n > (int64_t)ctx->prop.multiProcessorCount * 12 || (n > (int64_t)ctx->prop.multiProcessorCount * 2 && M < 100)) return 1;
+  if (n > (int64_t)ctx->prop.multiProcessorCount * 2) return 2;
   int W = 2;
   while (W < 8 && 64 * W * 2 <= M) W *= 2;
   return W;
@@ -524,7 +592,7 @@ int launch_fs5_bwd_wf(bath_hip_ctx *ctx, hipStream_t stream, const bath_hip_fspr
   if (st != BATH_OK) return st;
   const int RW = 64 * g.W;
   std::vector<int64_t> toff((size_t)n + 1, 0);
-  for (int64_t e = 0; e < n; e++) toff[(size_t)e + 1] = toff[(size_t)e] + (dna->h_len[(size_t)e] >= 5 ? fs_bwd_wf_steps(dna->h_len[(size_t)e], M, RW) * RW : 0);
+  for (int64_t e = 0; e < n; e++) toff[(size_t)e + 1] = toff[(size_t)e] + (dna->h_len[(size_t)e] >= 5 ? ((fs_bwd_wf_steps(dna->h_len[(size_t)e], M, RW) + 3) & ~(int64_t)3) * RW : 0);   // the sweep runs in blocks of four steps
   BATH_HIP_TRY(ctx, terms_scratch.reserve((size_t)toff[(size_t)n] * sizeof(float) + 256));
   BATH_HIP_TRY(ctx, toff_scratch.reserve((size_t)(n + 1) * sizeof(int64_t)));
   BATH_HIP_TRY(ctx, hipMemcpyAsync(toff_scratch.p, toff.data(), (size_t)(n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, stream));
