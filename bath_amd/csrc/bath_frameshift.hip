@@ -1827,7 +1827,8 @@ int bath::fs5_envelopes_ex(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, cons
     if (!unfused) {
       if ((st = fs_set_shmem(ctx, fs5_decode_oa_kernel<CC>, oa_shmem)) != BATH_OK) return st;
       const int s3 = ctx->span_begin("fs5_decode_oa_kernel", ctx->stream, cells5, cells5 * 88.0);   // reads Forward 32 + Backward 12, writes posteriors 32 + OA 12 B/cell
-      hipLaunchKernelGGL((fs5_decode_oa_kernel<CC>), dim3(grid), dim3(256), oa_shmem, ctx->stream, dna->view(), M, om->d_tf, om->d_loop[1], d_bsc, b_f.as<float>(), d_foff,
+      const int oa_grid = (int)std::max<int64_t>(1, std::min<int64_t>((n + 3) / 4, (int64_t)ctx->prop.multiProcessorCount * (CC <= 3 ? BATH_FS_OA_WAVES : 1)));
+      hipLaunchKernelGGL((fs5_decode_oa_kernel<CC>), dim3(oa_grid), dim3(256), oa_shmem, ctx->stream, dna->view(), M, om->d_tf, om->d_loop[1], d_bsc, b_f.as<float>(), d_foff,
                          b_fx.as<float>(), d_xoff, b_b.as<float>(), d_boff, b_bx.as<float>(), b_cs.as<float>(), b_o.as<float>(), d_osc,
                          1.17549435e-38f /* E->J impossible in unihit mode: TSCDELTA = FLT_MIN */, 1.0f, (oax || trace) ? b_ox.as<float>() : nullptr, jq[2]);
       ctx->span_end(s3, ctx->stream);
