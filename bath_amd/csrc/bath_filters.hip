@@ -35,7 +35,7 @@ namespace bath {
 // Amino-acid targets: G adjacent lanes score sequence order[t] (or t); writes the raw maximum v in the
 // kernel's signed domain (begin score = -128), i.e. get_xE()'s byte minus 256.
 template <int NR, int G>
-__global__ __launch_bounds__(256, (NR <= 76 ? 4 : 1)) void ssv_lane_kernel(SeqView sq, const int32_t *__restrict__ order,
+__global__ __launch_bounds__((G > 1 && NR <= 76) ? 1024 : 256, (G > 1 && NR <= 76) ? 1 : (NR <= 76 ? 4 : 1)) void ssv_lane_kernel(SeqView sq, const int32_t *__restrict__ order,
                                                        const int16_t *__restrict__ cost_tab, int row_bytes,
                                                        int16_t *__restrict__ out_v) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -633,14 +633,15 @@ static int length_order(bath_hip_ctx *ctx, const bath_hip_seqs *sq, DevBuf &buf)
 int launch_ssv_lane(bath_hip_ctx *ctx, const bath_hip_oprofile *om, SeqView v, const int32_t *d_order, int16_t *d_v) {
   if (v.n == 0) return BATH_OK;
   const int G = om->G;
-  const int blocks = (int)((v.n * G + 255) / 256);
   const size_t shmem = (size_t)kSsvRows * om->ssv_row_bytes;
+  const int threads = (G > 1 && om->NR <= 76 && 4 * shmem > 160 * 1024) ? 1024 : 256;      // long models: one cost table for 16 waves (bath_pipeline.hip)
+  const int blocks = (int)((v.n * G + threads - 1) / threads);
   const int rb = om->ssv_row_bytes;
   bool launched = false;
 #define BATH_SSV_CASE(N, GG)                                                                                             \
   if (!launched && om->NR == N && G == GG) {                                                                             \
     if (shmem > 64 * 1024) (void)hipFuncSetAttribute((const void *)ssv_lane_kernel<N, GG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
-    hipLaunchKernelGGL((ssv_lane_kernel<N, GG>), dim3(blocks), dim3(256), shmem, ctx->stream, v, d_order, om->d_ssv, rb, d_v); \
+    hipLaunchKernelGGL((ssv_lane_kernel<N, GG>), dim3(blocks), dim3(threads), shmem, ctx->stream, v, d_order, om->d_ssv, rb, d_v); \
     launched = true;                                                                                                     \
   }
   BATH_SSV_SHAPES(BATH_SSV_CASE)

@@ -142,7 +142,7 @@ __device__ __forceinline__ void ssv_row_pipe(s16x2 (&reg)[NR], s16x2 &xE, s16x2 
 template <int NR, int G>
 __device__ __forceinline__ unsigned ssv_carry(const s16x2 (&reg)[NR], int grank) {
   if (G == 1) return kSsvBeginPair;
-  const unsigned up = (unsigned)__shfl_up((int)__builtin_bit_cast(unsigned, reg[NR - 1]), 1, 64);
+  const unsigned up = (unsigned)wave_shr1_i32((int)__builtin_bit_cast(unsigned, reg[NR - 1]), 0);     // lane l <- lane l-1: a DPP operand, not a trip through the LDS crossbar
   return (grank == 0) ? kSsvBeginPair : up;
 }
 // Maximum over the target's lanes, converted to the reference's signed-byte domain (begin score = -128).

@@ -9,6 +9,7 @@
   X(16, 1) X(20, 1) X(24, 1) X(28, 1) X(32, 1) X(36, 1) X(40, 1) X(44, 1) X(48, 1) X(52, 1) X(56, 1) X(60, 1) X(64, 1)     \
   X(68, 1) X(72, 1) X(76, 1) X(80, 1) X(84, 1) X(88, 1) X(92, 1) X(96, 1) X(100, 1) X(104, 1) X(108, 1) X(112, 1)           \
   X(128, 1) X(144, 1) X(160, 1) X(176, 1) X(192, 1) X(208, 1)                                                \
+  X(40, 2) X(48, 2) X(56, 2) X(64, 2) X(72, 2) X(76, 2)                                                     \
   X(112, 2) X(128, 2) X(144, 2) X(160, 2) X(176, 2) X(192, 2) X(208, 2)                                      \
   X(112, 4) X(128, 4) X(144, 4) X(160, 4) X(176, 4) X(192, 4) X(208, 4)                                      \
   X(112, 8) X(128, 8) X(144, 8) X(160, 8) X(176, 8) X(192, 8) X(208, 8)
