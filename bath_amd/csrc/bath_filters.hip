@@ -47,8 +47,9 @@ __global__ __launch_bounds__((G > 1 && NR <= 76) ? 1024 : 256, (G > 1 && NR <= 7
   }
   __syncthreads();
   const int64_t gt = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t t = gt / G;
-  const int grank = (int)(gt - t * G);
+  const int lane_ = threadIdx.x & 63;
+  const int64_t t = (gt >> 6) * (64 / G) + SsvGroups<G>::slot(lane_);       // G >= 4: a group's lanes are 64/G apart (bath_kernels.hpp)
+  const int grank = SsvGroups<G>::rank(lane_);
   const bool live = t < sq.n;
   const int64_t sid = live ? (order ? (int64_t)order[t] : t) : 0;
   const int L = live ? sq.len[sid] : 0;

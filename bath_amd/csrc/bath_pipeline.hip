@@ -78,7 +78,7 @@ __global__ __launch_bounds__((G > 1 && NR <= 76) ? 1024 : 256, (G > 1 && NR <= 7
   constexpr int TPW = 64 / G;                                   // ORFs per wave
   const int64_t n_orfs = *n_orfs_dev;
   const int lane = threadIdx.x & 63;
-  const int grank = lane % G;
+  const int grank = SsvGroups<G>::rank(lane);
   const char *tile = lds + grank * (4 * NR);
   const unsigned tile_addr = (unsigned)(size_t)(__attribute__((address_space(3))) const char *)tile;   // LDS byte address
   const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -87,7 +87,7 @@ __global__ __launch_bounds__((G > 1 && NR <= 76) ? 1024 : 256, (G > 1 && NR <= 7
   const int64_t tb_first = chunk > 0 ? wave0 * chunk * TPW : wave0 * TPW, tb_step = chunk > 0 ? TPW : nwaves * TPW;
   const int64_t tb_end = chunk > 0 ? (tb_first + (int64_t)chunk * TPW < n_orfs ? tb_first + (int64_t)chunk * TPW : n_orfs) : n_orfs;
   for (int64_t tb = tb_first; tb < tb_end; tb += tb_step) {
-    const int64_t t = tb + lane / G;
+    const int64_t t = tb + SsvGroups<G>::slot(lane);
     const bool live = t < n_orfs;
     OrfRec rec{0, 0, 0};
     if (live) rec = orfs[t];

@@ -296,19 +296,20 @@ extern "C" int bath_hip_oprofile_convert(bath_hip_ctx *ctx, const bath_profile *
   // SSV: signed costs sb = min(rb - bias, 127) (sf_conversion), stored as binary16 increments -sb * 2^-11, one row per
   // residue plus a "reset" row; columns 1..M real, padded with -1.0 (a full reset) up to 2*NR*G.  Row pitch is an odd multiple of 16 bytes so
   // that lanes holding different residues spread over the 16 sixteen-byte LDS slots on ds_read_b128.
-  // Two lanes per target from 153 nodes on: up to 304 nodes a lane's tile then stays within 76 registers and the kernel runs 4
-  // waves per SIMD, where the packed 16-bit ops issue at 4.4e11/s (with 80-152 cell registers a SIMD holds one or two waves:
-  // M = 185...247: ssv 0.30-0.38 -> 0.23-0.32 ms on a 12.5 Mb genome).  FOUR or eight lanes with narrow tiles lose, measured
-  // (M = 459: 0.54 -> 0.68 ms, M = 1024: 10.9 -> 13.5 ms): a group's lanes read consecutive 16-byte units of a row, two
-  // groups of an LDS cycle then cover 32 banks each and collide whenever their residues differ; beyond 304 nodes the
-  // round-1 rule stays: tiles of up to 208 registers before more lanes are added.  BATH_HIP_SSV_WIDE=1: one lane up to 416 nodes (rounds 1-2).
+  // Two lanes per target from 153 to 304 nodes: a lane's tile then stays within 76 registers and the kernel runs 4 waves per
+  // SIMD, where the packed 16-bit ops issue at 4.4e11/s (with 80-152 cell registers a SIMD holds one or two waves:
+  // M = 185...247: ssv 0.29-0.38 -> 0.22-0.27 ms on a 12.5 Mb genome).  Beyond 304 nodes the round-1 rule stays -- tiles of up
+  // to 208 registers before more lanes are added: two lanes x 112 registers at M = 409, four / eight lanes with narrow tiles
+  // at M = 409 / 1024 were measured and lose.  BATH_HIP_SSV_WIDE=1: one lane up to 416 nodes (rounds 1-2);
+  // BATH_HIP_SSV_G2_MAX: the upper end of the two-lane range, for A/B runs (tools/ssv_shape_probe.py).
   static const bool wide = [] { const char *e = std::getenv("BATH_HIP_SSV_WIDE"); return e && e[0] == '1'; }();
-  int G = (!wide && M > 152 && M <= 304) ? 2 : 1;             // (305...416 nodes: one lane with 156-208 registers is 1.2x faster than two with 112, measured at M = 409)
+  static const int g2max = [] { const char *e = std::getenv("BATH_HIP_SSV_G2_MAX"); return e ? std::atoi(e) : 304; }();
+  int G = (!wide && M > 152 && M <= g2max) ? 2 : 1;             // (305...416 nodes: one lane with 156-208 registers is 1.2x faster than two with 112, measured at M = 409)
   while (G < 8 && M > 416 * G) G *= 2;                        // up to 208 registers (416 nodes) per lane
   if (M > 416 * G) { ctx->set_error("model longer than 3328 nodes"); delete om; return BATH_EINVAL; }
   int NR = ((M + G - 1) / G + 1) / 2;
   if (G == 1 && NR <= 112) NR = (NR + 3) / 4 * 4;             // the shapes of BATH_SSV_SHAPES
-  else if (G > 1 && NR <= 76) NR = NR <= 40 ? 40 : (NR <= 72 ? (NR + 7) / 8 * 8 : 76);
+  else if (G == 2 && NR <= 76) NR = NR <= 40 ? 40 : (NR <= 72 ? (NR + 7) / 8 * 8 : 76);
   else NR = std::max((NR + 15) / 16 * 16, G > 1 ? 112 : 16);
   NR = std::max(NR, 16);
   om->NR = NR; om->G = G;
