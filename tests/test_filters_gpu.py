@@ -53,11 +53,12 @@ def test_ssv_bit_exact(setup):
     assert set(np.unique(ost)) >= {0}, "test set must exercise the OK branch"
 
 
-@pytest.mark.parametrize("M", [16, 33, 64, 100, 152, 153, 200, 260, 416, 417, 600, 830, 1300, 1664])
+@pytest.mark.parametrize("M", [16, 33, 64, 100, 152, 153, 200, 260, 304, 305, 416, 417, 600, 830, 1024, 1300, 1664])
 def test_ssv_every_register_tiling(gpu_ctx, tmp_path, M):
     """The lane-per-target SSV kernels are instantiated per register count (NR = 16 .. 208 in steps of 4 / 16) and lanes per
     target (G = 1, 2, 4, 8), with hand-pipelined LDS reads and a VGPR bound that depends on NR: a sweep over model lengths
-    that lands on the shapes' boundaries (152 | 153: the last NR with 4 waves per SIMD; 416 | 417: one | two lanes per target).
+    that lands on the shapes' boundaries (152 | 153: one | two lanes with narrow tiles; 304 | 305: back to one lane with a wide
+    tile; 416 | 417: one | two lanes per target; 1024: four).  A target's lanes are 64/G apart in the wave (SsvGroups).
     Both entry points: the standalone filter (ssv_lane_kernel) and the cascade (ssv_orf_kernel, through the survivors'
     MSV scores and the counters)."""
     path = common.write_synthetic_bhmm(str(tmp_path / ("s%d.bhmm" % M)), M, seed=M)
