@@ -145,19 +145,14 @@ __device__ __forceinline__ void ssv_row_pipe(s16x2 (&reg)[NR], s16x2 &xE, s16x2 
 // packed-issue ceiling; <128, 2> (M = 459) 5.2 -> 4.7 ms per 200 k windows.
 template <int G> struct SsvGroups {
   static constexpr int TPW = 64 / G;                       // targets per wave
-  static constexpr bool STRIDED = (G > 1);
-  static __device__ __forceinline__ int rank(int lane) { return STRIDED ? lane / TPW : lane % G; }
-  static __device__ __forceinline__ int slot(int lane) { return STRIDED ? lane % TPW : lane / G; }
+  static __device__ __forceinline__ int rank(int lane) { return lane / TPW; }      // which tile of its target a lane holds
+  static __device__ __forceinline__ int slot(int lane) { return lane % TPW; }      // the target's slot in the wave
 };
 template <int NR, int G>
 __device__ __forceinline__ unsigned ssv_carry(const s16x2 (&reg)[NR], int grank) {
   if (G == 1) return kSsvBeginPair;
-  if (SsvGroups<G>::STRIDED) {
-    const unsigned far = (unsigned)__shfl_up((int)__builtin_bit_cast(unsigned, reg[NR - 1]), SsvGroups<G>::TPW, 64);     // needed last in the row: its latency hides
-    return (grank == 0) ? kSsvBeginPair : far;
-  }
-  const unsigned up = (unsigned)wave_shr1_i32((int)__builtin_bit_cast(unsigned, reg[NR - 1]), 0);     // (adjacent lanes: not used any more)
-  return (grank == 0) ? kSsvBeginPair : up;
+  const unsigned far = (unsigned)__shfl_up((int)__builtin_bit_cast(unsigned, reg[NR - 1]), SsvGroups<G>::TPW, 64);     // needed last in the row: its latency hides
+  return (grank == 0) ? kSsvBeginPair : far;
 }
 // Maximum over the target's lanes, converted to the reference's signed-byte domain (begin score = -128).
 template <int G>
@@ -165,13 +160,8 @@ __device__ __forceinline__ int ssv_group_max(s16x2 xE) {
   typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
   const h16x2 h = __builtin_bit_cast(h16x2, xE);
   int v = (int)(fmaxf((float)h.x, (float)h.y) * 2048.0f) - 128;            // distance above the begin score, then begin = -128
-  if (SsvGroups<G>::STRIDED) {
 #pragma unroll
-    for (int d = SsvGroups<G>::TPW; d < 64; d <<= 1) v = max(v, __shfl_xor(v, d, 64));
-    return v;
-  }
-#pragma unroll
-  for (int d = 1; d < G; d <<= 1) v = max(v, __shfl_xor(v, d, 64));
+  for (int d = SsvGroups<G>::TPW; d < 64; d <<= 1) v = max(v, __shfl_xor(v, d, 64));      // the target's lanes are 64/G apart
   return v;
 }
 
