@@ -136,7 +136,7 @@ struct bath_hip_ctx {
   std::string err;
   void set_error(const std::string &m) { err = m; }
   // scratch owned by the context (reused across calls)
-  bath::DevBuf scratch[48];
+  bath::DevBuf scratch[50];
   bath::HostBuf pinned[4];                // [0,1]: standard-branch region matrices; [2,3]: frameshift-branch ones (read by ensemble threads)
   bath::HostBuf results_pinned;           // bath_hip_pipeline_filters output: the ORF records, page-locked
   bath_orf_result *d_records = nullptr;   // ... as the last cascade pass left them on the device (bath_records.hip)

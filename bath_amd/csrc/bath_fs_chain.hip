@@ -17,7 +17,9 @@
 //   3. every wave picks up its D and E, does the special states and moves on.
 // The pair's duration is the chain's: 2M dependent log-sums; the 64-step lane hand-off this replaces paid a trip through the
 // LDS crossbar per lane and ran every window's chain as its own wave-wide instruction stream.
+#include <algorithm>
 #include <cstring>
+#include <vector>
 #include <type_traits>
 
 #include "bath_fs_device.hpp"
@@ -350,12 +352,13 @@ __global__ __launch_bounds__(chain_threads(C)) void fs3_fwd_chain_kernel(SeqView
 // ---------------------------------------------------------------------------------------------------------------------------
 template <int CH>
 __global__ __launch_bounds__(1024) void fs3_fwd_chain_half_kernel(SeqView dna, FsDev p, const float *__restrict__ loop_tab, const float *__restrict__ move_tab,
-                                                                  float tEL, float tEM, float *__restrict__ sc, float *__restrict__ xmx, const int64_t *__restrict__ xmx_off, FsJobs jobs) {
+                                                                  float tEL, float tEM, float *__restrict__ sc, float *__restrict__ xmx, const int64_t *__restrict__ xmx_off, FsJobs jobs,
+                                                                  const int32_t *__restrict__ bstart /* [nb + 1]: batch b = windows bstart[b] .. bstart[b+1]-1 of the sorted list */, int nb) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   float *s_tbl = reinterpret_cast<float *>(lds);
   float *s_tf = s_tbl + kLogsumTbl;
   const int M = p.M;
-  constexpr int W = 32;                                         // windows per block: two per wave
+  constexpr int W = 32;                                         // window slots per block: two per wave
   constexpr int stride = CH * 32 + 1;
   float *s_stage = s_tf + (M + 2) * 8;                          // [W][2][stride]
   float *s_b = s_stage + (size_t)W * 2 * stride;                // [W][2] B(i) of the pair's rows, from the chain lanes
@@ -367,21 +370,23 @@ __global__ __launch_bounds__(1024) void fs3_fwd_chain_half_kernel(SeqView dna, F
   const int hl = lane & 31, win = wv * 2 + (lane >> 5);          // lane within its window's half wave; the window's slot in the block
 #define LS(a, b) flogsum<false>((a), (b), s_tbl)
   auto shr1 = [&](float v) { const float r = wave_shr1(v, -INFINITY); return hl == 0 ? -INFINITY : r; };   // the neighbour move stays inside the half wave
-  for (;;) {
-    if (threadIdx.x == 0) s_ctl[0] = (int)atomicAdd(jobs.counter, (unsigned)W);
-    __syncthreads();
-    const int64_t base = s_ctl[0];
-    if (base >= dna.n) break;
-    const int64_t job = (base + win < dna.n) ? (int64_t)jobs.order[base + win] : (int64_t)-1;
+  // The batches come from the host (launch_fs3_fwd_chain): a block lasts as long as its longest window times the duration of a row
+  // pair, which grows with the windows it holds -- so the batches of the longest windows are smaller, and all blocks end together.
+  (void)s_ctl;
+  for (int bb = blockIdx.x; bb < nb; bb += gridDim.x) {
+    const int64_t base = bstart[bb];
+    const int cnt = bstart[bb + 1] - bstart[bb];
+    const int64_t job = (win < cnt) ? (int64_t)jobs.order[base + win] : (int64_t)-1;
     const int Lmax = dna.len[jobs.order[base]];
     const int L = job >= 0 ? dna.len[job] : 0;
     const uint8_t *d = job >= 0 ? dna.data + dna.off[job] : dna.data;
+    const bool wave_idle = wv != 0 && wv * 2 >= cnt;            // neither of the wave's two slots holds a window: it only keeps the barriers
     // ---- the chain wave's lanes: lane c serves row slot (c & 1) of window (c >> 1)
     const bool chain_lane = (wv == 0);
     const int cw = lane >> 1, cs = lane & 1;
     int64_t cjob = -1; int cL = 0; float *cxo = nullptr;
     float ctNL = 0.f, ctNM = 0.f;
-    if (chain_lane && base + cw < dna.n) {
+    if (chain_lane && cw < cnt) {
       cjob = jobs.order[base + cw]; cL = dna.len[cjob];
       if (xmx) cxo = xmx + xmx_off[cjob];
       ctNL = loop_tab[cL / 3]; ctNM = move_tab[cL / 3];
@@ -398,6 +403,7 @@ __global__ __launch_bounds__(1024) void fs3_fwd_chain_half_kernel(SeqView dna, F
     auto nuc = [&](int i) -> int { return (i >= 1 && i <= L) ? ((d[i - 1] < 4) ? (int)d[i - 1] : 338) : 338; };
     __syncthreads();
     for (int i = 2; i <= Lmax; i += 2) {
+      if (wave_idle) { lds_barrier(); lds_barrier(); continue; }
       const bool actB = job >= 0 && L >= 3 && i + 1 <= L;
       const float B2 = s_b[win * 2 + 0], B1 = s_b[win * 2 + 1];   // B(i-2), B(i-1): the previous pair's rows
       const int xa = nuc(i), wa = nuc(i - 1), va = nuc(i - 2), ua = nuc(i - 3), xb = nuc(i + 1);
@@ -504,7 +510,8 @@ __global__ __launch_bounds__(1024) void fs3_fwd_chain_half_kernel(SeqView dna, F
 // ---------------------------------------------------------------------------------------------------------------------------
 template <int C>
 __global__ __launch_bounds__(chain_threads(C)) void fs3_bwd_chain_kernel(SeqView dna, FsDev p, const float *__restrict__ loop_tab, const float *__restrict__ move_tab,
-                                                             float tEL, float tEM, float *__restrict__ sc, float *__restrict__ xmx, const int64_t *__restrict__ xmx_off, FsJobs jobs) {
+                                                             float tEL, float tEM, float *__restrict__ sc, float *__restrict__ xmx, const int64_t *__restrict__ xmx_off, FsJobs jobs,
+                                                             const int32_t *__restrict__ bstart /* batches of the sorted list, chain_batches */, int nb) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   float *s_tbl = reinterpret_cast<float *>(lds);
   float *s_tb = s_tbl + kLogsumTbl;
@@ -522,22 +529,22 @@ __global__ __launch_bounds__(chain_threads(C)) void fs3_bwd_chain_kernel(SeqView
   // next nodes" is then the physical lane below and the neighbour move is the same wave_shr1
   const int ll = 63 - lane;
 #define LS(a, b) flogsum<false>((a), (b), s_tbl)
-  for (;;) {
-    if (threadIdx.x == 0) s_ctl[0] = (int)atomicAdd(jobs.counter, (unsigned)W);
-    __syncthreads();
-    const int64_t base = s_ctl[0];
-    if (base >= dna.n) break;
-    const int64_t job = (base + wv < dna.n) ? (int64_t)jobs.order[base + wv] : (int64_t)-1;
+  (void)s_ctl;
+  for (int bb = blockIdx.x; bb < nb; bb += gridDim.x) {
+    const int64_t base = bstart[bb];
+    const int cnt = bstart[bb + 1] - bstart[bb];                // windows of this batch (<= W): the longest windows come in smaller batches
+    const int64_t job = (wv < cnt) ? (int64_t)jobs.order[base + wv] : (int64_t)-1;
     const int Lmax = dna.len[jobs.order[base]];
     const int L = job >= 0 ? dna.len[job] : 0;
     const bool live = job >= 0 && L >= 5;                       // shorter windows report -inf (fs_bwd_kernel does)
     const uint8_t *d = job >= 0 ? dna.data + dna.off[job] : dna.data;
+    const bool wave_idle = wv != 0 && wv >= cnt;                // no window in this wave's slot: it only keeps the barriers
     // ---- the chain wave's lanes: lane c serves slot (c & 1) of window (c >> 1)
     const int cw = lane >> 1, cs = lane & 1;
     const bool chain_lane = (wv == 0) && (lane < 2 * W);
     int64_t cjob = -1; int cL = 0; float *cxo = nullptr;
     float ctNL = 0.f, ctNM = 0.f;
-    if (chain_lane && base + cw < dna.n) {
+    if (chain_lane && cw < cnt) {
       cjob = jobs.order[base + cw]; cL = dna.len[cjob];
       if (xmx) cxo = xmx + xmx_off[cjob];
       ctNL = loop_tab[cL / 3]; ctNM = move_tab[cL / 3];
@@ -551,6 +558,7 @@ __global__ __launch_bounds__(chain_threads(C)) void fs3_bwd_chain_kernel(SeqView
     auto nuc = [&](int i) -> int { return (i >= 1 && i <= L) ? ((d[i - 1] < 4) ? (int)d[i - 1] : 338) : 338; };
     const int npairs = Lmax / 2 + 1;                            // rows Lmax .. 0 of the longest window
     for (int q = 0; q < npairs; q++) {
+      if (wave_idle) { lds_barrier(); lds_barrier(); continue; }
       const int iA = L - 2 * q, iB = iA - 1;                    // this window's rows of the pair; avail = 2q and 2q + 1 for every window
       const bool mainA = 2 * q >= 5, mainB = 2 * q + 1 >= 5;
       // codons that START at x_{i+1}: x = x_{i+1}, w = x_{i+2}, v = x_{i+3}, u = x_{i+4}; the last base is the most significant digit (:1539-1550)
@@ -819,6 +827,47 @@ __global__ __launch_bounds__(THREADS) void fs5_fwd_chain_kernel(SeqView dna, FsD
 #undef LS
 }
 
+// Batches of windows for the blocks of a chain kernel.  A row pair of a block with w windows takes t(w) = t0 + w * dt (the chain
+// and the chain wave's own parallel part, plus every other window's parallel part) and a block lasts L_longest / 2 pairs: the
+// smallest T such that batches of w(L) = (2T / L - t0) / dt windows (at most <wmax>), longest windows first, need no more blocks than
+// there are CUs -- the batches of the longest windows are smaller, and all blocks end together.  <bst>: batch b = windows
+// bst[b] .. bst[b+1]-1 of the list sorted by decreasing length.  BATH_HIP_FS_BATCH=w: uniform batches of w (A/B runs).
+static int chain_batches(bath_hip_ctx *ctx, hipStream_t stream, const bath_hip_seqs *dna, double t0, double dt, int wmax, DevBuf &buf, int *nbat_out) {
+  const int64_t n = dna->n;
+  std::vector<int> ls(dna->h_len.begin(), dna->h_len.begin() + n);
+  std::sort(ls.begin(), ls.end(), [](int a, int b) { return a > b; });
+  const int cus = ctx->prop.multiProcessorCount;
+  std::vector<int32_t> bst;
+  auto batches = [&](double T, std::vector<int32_t> *out) -> int64_t {
+    int64_t q = 0, nbat = 0;
+    if (out) out->clear();
+    while (q < n) {
+      const double w = (2.0 * T / std::max(ls[(size_t)q], 2) - t0) / dt;
+      const int take = w < 1.0 ? 1 : (w > (double)wmax ? wmax : (int)w);
+      if (out) out->push_back((int32_t)q);
+      q += take; nbat++;
+    }
+    if (out) out->push_back((int32_t)n);
+    return nbat;
+  };
+  double T_lo = 0.5 * ls[0] * (t0 + dt), T_hi = 0.5 * ls[0] * (t0 + wmax * dt);
+  static const int fixed_batch = [] { const char *e = std::getenv("BATH_HIP_FS_BATCH"); return e ? std::atoi(e) : 0; }();
+  if (fixed_batch >= 1) {
+    const int fb = std::min(fixed_batch, wmax);
+    for (int64_t q = 0; q < n; q += fb) bst.push_back((int32_t)q);
+    bst.push_back((int32_t)n);
+  } else if (batches(T_hi, nullptr) > cus) batches(1e30, &bst);       // more than a round of full blocks: uniform batches of <wmax>
+  else {
+    for (int it = 0; it < 24; it++) { const double T = 0.5 * (T_lo + T_hi); if (batches(T, nullptr) <= cus) T_hi = T; else T_lo = T; }
+    batches(T_hi, &bst);
+  }
+  *nbat_out = (int)bst.size() - 1;
+  BATH_HIP_TRY(ctx, buf.reserve(bst.size() * sizeof(int32_t) + 64));
+  BATH_HIP_TRY(ctx, hipMemcpyAsync(buf.p, bst.data(), bst.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+  BATH_HIP_TRY(ctx, hipStreamSynchronize(stream));                 // <bst> is a local
+  return BATH_OK;
+}
+
 static int chain_waves(bath_hip_ctx *ctx, int64_t n, int M, int C, size_t *shmem_out, int cu_share = 1) {
   // as many windows per block as LDS holds next to the table and the transitions ...
   const size_t fixed = (size_t)(kLogsumTbl + (M + 2) * 8 + 2 * kChainMaxWaves + 16) * sizeof(float);
@@ -864,10 +913,19 @@ int launch_fs3_fwd_chain(bath_hip_ctx *ctx, hipStream_t stream, const bath_hip_f
   static const bool force_half = [] { const char *e = std::getenv("BATH_HIP_FS_HALFWAVE"); return e && e[0] == '1'; }();     // tests: also for a handful of windows
   if (!no_half && CH <= 6 && (force_half || n > (int64_t)ctx->prop.multiProcessorCount * 8)) {
     const size_t hs = (size_t)(kLogsumTbl + (M + 2) * 8 + 32 * 2 * (CH * 32 + 1) + 64 + 16) * sizeof(float);
-    const int hgrid = (int)std::max<int64_t>(1, std::min<int64_t>((n + 31) / 32, (int64_t)ctx->prop.multiProcessorCount));
+    // batches by length (chain_batches); t(w) measured at M = 145 (CH = 5): 18.0 us at 1-2 windows, 19.3 at 8, 19.8 at 16, 21.3 at 32.
+    // Bench block (7.6 k windows of 300-1000 nt, the longest 500 within 860-1000): a handful of windows in the first batches,
+    // 32 for the bulk: 10.9 -> 9.9 ms
+    int nbat = 0;
+    DevBuf &b_bst = ctx->scratch[47];
+    int stb = chain_batches(ctx, stream, dna, 0.085 * M + 3.5 + 0.4 * CH, 0.021 * CH, 32, b_bst, &nbat);
+    if (stb != BATH_OK) return stb;
+    const int cus = ctx->prop.multiProcessorCount;
+    const int hgrid = std::max(1, std::min(nbat, cus));
 #define BATH_HALF(C_)                                                                                                              \
     case C_: BATH_HIP_TRY(ctx, hipFuncSetAttribute((const void *)fs3_fwd_chain_half_kernel<C_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hs)); \
-             hipLaunchKernelGGL((fs3_fwd_chain_half_kernel<C_>), dim3(hgrid), dim3(1024), hs, stream, dna->view(), dev, om->d_loop[0], om->d_move[0], tEL, tEM, d_sc, d_xmx, d_xoff, jobs); break;
+             hipLaunchKernelGGL((fs3_fwd_chain_half_kernel<C_>), dim3(hgrid), dim3(1024), hs, stream, dna->view(), dev, om->d_loop[0], om->d_move[0], tEL, tEM, d_sc, d_xmx, d_xoff, jobs, \
+                                b_bst.as<int32_t>(), nbat); break;
     switch (CH) { BATH_HALF(1) BATH_HALF(2) BATH_HALF(3) BATH_HALF(4) BATH_HALF(5) BATH_HALF(6) }
 #undef BATH_HALF
     BATH_HIP_TRY(ctx, hipGetLastError());
@@ -888,12 +946,17 @@ int launch_fs3_bwd_chain(bath_hip_ctx *ctx, hipStream_t stream, const bath_hip_f
   const int M = om->M;
   size_t shmem = 0;
   const int W = chain_waves(ctx, dna->n, M, Cv, &shmem);
-  const int64_t n = dna->n;
-  const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((n + W - 1) / W, (int64_t)ctx->prop.multiProcessorCount));
+  // batches by length (chain_batches); t(w) measured at M = 145 (C = 3): 25.4 us per row pair at one window, 28.5 at 16
+  int nbat = 0;
+  DevBuf &b_bst = ctx->scratch[48];                                // (its own buffer: Forward's launch may be running on another stream)
+  const int stb = chain_batches(ctx, stream, dna, 0.128 * M + 6.6, 0.067 * Cv, W, b_bst, &nbat);
+  if (stb != BATH_OK) return stb;
+  const int grid = std::max(1, std::min(nbat, (int)ctx->prop.multiProcessorCount));
   FsDev dev{om->M, om->pitch, om->maxcodons, om->d_rsc, om->d_tf, om->d_tb, om->d_logsum};
   BATH_CHAIN_SWITCH(Cv, {
     BATH_HIP_TRY(ctx, hipFuncSetAttribute((const void *)fs3_bwd_chain_kernel<CC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    hipLaunchKernelGGL((fs3_bwd_chain_kernel<CC>), dim3(grid), dim3(64 * W), shmem, stream, dna->view(), dev, om->d_loop[0], om->d_move[0], tEL, tEM, d_sc, d_xmx, d_xoff, jobs);
+    hipLaunchKernelGGL((fs3_bwd_chain_kernel<CC>), dim3(grid), dim3(64 * W), shmem, stream, dna->view(), dev, om->d_loop[0], om->d_move[0], tEL, tEM, d_sc, d_xmx, d_xoff, jobs,
+                       b_bst.as<int32_t>(), nbat);
   })
   BATH_HIP_TRY(ctx, hipGetLastError());
   return BATH_OK;

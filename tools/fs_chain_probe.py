@@ -23,11 +23,13 @@ if args.dist:
     om5 = ba.FSOProfile(ctx, ba.FSProfile(hmm, 5, ncbi_table=hmm.ct))
     pipe = ba.Pipeline(ctx, om, fs_pipe=True, ncbi_table=hmm.ct)
     stats, fw, dm, nskip = pipe.run_frameshift_domains(om3, om5, dna, arrays=True)
-    ln = np.sort(np.array([w.length for w in fw]))[::-1]
-    br = np.array([w.length for w in fw if w.branch == 1])
+    ln = np.sort(np.asarray(fw["length"]))[::-1]
+    br = np.asarray(fw["length"])[np.asarray(fw["branch"]) == 1]
     print("windows", len(ln), "sum", int(ln.sum()), "max", ln[:8].tolist(), "p99 %d p90 %d p50 %d" % tuple(np.percentile(ln, [99, 90, 50])))
     if len(br): print("fs-branch windows", len(br), "max", np.sort(br)[::-1][:8].tolist(), "p50 %d" % np.percentile(br, 50))
-    for b in range(0, min(len(ln), 8192), 32 * 16): print("batch of 32 starting at", b, "longest", int(ln[b]))
+    for b in (0, 32, 64, 128, 256, 512, 1024, 2048, 4096, 7000): print("rank", b, "length", int(ln[min(b, len(ln) - 1)]))
+    bs = np.sort(br)[::-1]
+    for b in (0, 16, 64, 128, 256, 512, 1024, 2000): print("fs-branch rank", b, "length", int(bs[min(b, len(bs) - 1)]))
 rng = np.random.default_rng(7)
 fn = ba.FS3BackwardParser if args.bwd else ba.FS3ForwardParser
 for case in args.cases.split(","):
