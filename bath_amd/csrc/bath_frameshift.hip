@@ -1677,7 +1677,7 @@ int fs3_regions(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, const bath_hip_
     if ((st = fs_set_shmem(ctx, fs_bwd_kernel<CC, 3, MD>, shmem)) != BATH_OK) return st;
     const int s2 = ctx->span_begin("fs_bwd_kernel<3>", ctx->side_stream, cells3, bytes3);
     if (MD == 2 && fs_chain_enabled()) {
-      if ((st = launch_fs3_bwd_chain(ctx, ctx->side_stream, om, dna, Cv, tE, tE, b_sc.as<float>() + n, b_bx.as<float>(), b_off.as<int64_t>(), jq[1])) != BATH_OK) return st;
+      if ((st = launch_fs3_bwd_chain(ctx, ctx->side_stream, om, dna, Cv, tE, tE, b_sc.as<float>() + n, b_bx.as<float>(), b_off.as<int64_t>(), jq[1], reuse ? 1 : 2)) != BATH_OK) return st;
     } else
     hipLaunchKernelGGL((fs_bwd_kernel<CC, 3, MD>), dim3(grid_dp), dim3(kFsBlock), shmem, ctx->side_stream, dna->view(), fsdev(om), om->d_loop[0], om->d_move[0], tE, tE, b_sc.as<float>() + n, (float *)nullptr, (const int64_t *)nullptr, b_bx.as<float>(), b_off.as<int64_t>(), jq[1]);
     ctx->span_end(s2, ctx->side_stream);

@@ -832,11 +832,11 @@ __global__ __launch_bounds__(THREADS) void fs5_fwd_chain_kernel(SeqView dna, FsD
 // smallest T such that batches of w(L) = (2T / L - t0) / dt windows (at most <wmax>), longest windows first, need no more blocks than
 // there are CUs -- the batches of the longest windows are smaller, and all blocks end together.  <bst>: batch b = windows
 // bst[b] .. bst[b+1]-1 of the list sorted by decreasing length.  BATH_HIP_FS_BATCH=w: uniform batches of w (A/B runs).
-static int chain_batches(bath_hip_ctx *ctx, hipStream_t stream, const bath_hip_seqs *dna, double t0, double dt, int wmax, DevBuf &buf, int *nbat_out) {
+static int chain_batches(bath_hip_ctx *ctx, hipStream_t stream, const bath_hip_seqs *dna, double t0, double dt, int wmax, DevBuf &buf, int *nbat_out, int cu_share = 1) {
   const int64_t n = dna->n;
   std::vector<int> ls(dna->h_len.begin(), dna->h_len.begin() + n);
   std::sort(ls.begin(), ls.end(), [](int a, int b) { return a > b; });
-  const int cus = ctx->prop.multiProcessorCount;
+  const int cus = std::max(1, (int)ctx->prop.multiProcessorCount / cu_share);      // <cu_share>: another chain kernel runs beside this one (blocks of the two do not share a CU's LDS)
   std::vector<int32_t> bst;
   auto batches = [&](double T, std::vector<int32_t> *out) -> int64_t {
     int64_t q = 0, nbat = 0;
@@ -942,14 +942,14 @@ int launch_fs3_fwd_chain(bath_hip_ctx *ctx, hipStream_t stream, const bath_hip_f
 }
 
 int launch_fs3_bwd_chain(bath_hip_ctx *ctx, hipStream_t stream, const bath_hip_fsprofile *om, const bath_hip_seqs *dna, int Cv, float tEL, float tEM,
-                         float *d_sc, float *d_xmx, const int64_t *d_xoff, FsJobs jobs) {
+                         float *d_sc, float *d_xmx, const int64_t *d_xoff, FsJobs jobs, int cu_share) {
   const int M = om->M;
   size_t shmem = 0;
   const int W = chain_waves(ctx, dna->n, M, Cv, &shmem);
   // batches by length (chain_batches); t(w) measured at M = 145 (C = 3): 25.4 us per row pair at one window, 28.5 at 16
   int nbat = 0;
   DevBuf &b_bst = ctx->scratch[48];                                // (its own buffer: Forward's launch may be running on another stream)
-  const int stb = chain_batches(ctx, stream, dna, 0.128 * M + 6.6, 0.067 * Cv, W, b_bst, &nbat);
+  const int stb = chain_batches(ctx, stream, dna, 0.128 * M + 6.6, 0.067 * Cv, W, b_bst, &nbat, cu_share);
   if (stb != BATH_OK) return stb;
   const int grid = std::max(1, std::min(nbat, (int)ctx->prop.multiProcessorCount));
   FsDev dev{om->M, om->pitch, om->maxcodons, om->d_rsc, om->d_tf, om->d_tb, om->d_logsum};

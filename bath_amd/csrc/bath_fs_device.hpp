@@ -148,7 +148,7 @@ int launch_fs5_bwd_wf(bath_hip_ctx *ctx, hipStream_t stream, const bath_hip_fspr
 int launch_fs3_fwd_chain(bath_hip_ctx *ctx, hipStream_t stream, const bath_hip_fsprofile *om, const bath_hip_seqs *dna, int Cv, float tEL, float tEM,
                          float *d_sc, float *d_xmx, const int64_t *d_xoff, FsJobs jobs);
 int launch_fs3_bwd_chain(bath_hip_ctx *ctx, hipStream_t stream, const bath_hip_fsprofile *om, const bath_hip_seqs *dna, int Cv, float tEL, float tEM,
-                         float *d_sc, float *d_xmx, const int64_t *d_xoff, FsJobs jobs);
+                         float *d_sc, float *d_xmx, const int64_t *d_xoff, FsJobs jobs, int cu_share = 1 /* 2: the Forward parser runs beside it */);
 int launch_fs5_fwd_chain(bath_hip_ctx *ctx, hipStream_t stream, const bath_hip_fsprofile *om, const bath_hip_seqs *dna, int Cv, float tEL, float tEM, int c5_compat,
                          float *d_sc, float *d_fwd, const int64_t *d_foff, float *d_xmx, const int64_t *d_xoff, int cfg_len, FsJobs jobs, int *d_done);
 inline bool fs_chain_enabled() { static const bool off = [] { const char *e = std::getenv("BATH_HIP_FS_HANDOFF"); return e && e[0] == '1'; }(); return !off; }   // BATH_HIP_FS_HANDOFF=1: the 64-step lane hand-off kernels, for A/B runs
