@@ -6,6 +6,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <condition_variable>
 #include <functional>
 #include <mutex>
@@ -108,6 +109,19 @@ struct LanePool {
   }
 };
 
+// Worker contexts that run whole --fs passes on one GPU (the reference's worker threads, bathsearch.c:1119-1290) meet at the strict
+// 3-codon parsers: a chain block (bath_fs_chain.hip) takes a CU's whole register file and most of its LDS, so two such launches
+// cannot share the chip -- the second one's blocks trickle in behind the first one's and both workers end up waiting in step.
+// BATH_HIP_FS_GATE=1 makes the turn-taking explicit: one chain stage at a time per device, the other worker's cascade / envelope /
+// host stages run beside it.  Off by default: measured with the bench's --fs block, 2 workers 51.5 ms per block without and 56.4
+// with the gate (the workers fall into step: both cascades, then both Forward parsers, ...), 3 workers 66.1 / 59.9.
+inline std::mutex &chain_gate_mutex(int device) { static std::mutex g[16]; return g[device & 15]; }
+inline bool chain_gate_enabled() { static const bool on = [] { const char *e = std::getenv("BATH_HIP_FS_GATE"); return e && e[0] == '1'; }(); return on; }
+struct ChainGate {
+  std::unique_lock<std::mutex> l;
+  explicit ChainGate(int device) { if (device >= 0 && chain_gate_enabled()) l = std::unique_lock<std::mutex>(chain_gate_mutex(device)); }
+};
+
 struct StageTiming { const char *name; float ms; int64_t launches; };
 // one kernel launch of the frameshift / domain stages, timed with HIP events on the stream it was launched on
 struct KernelSpan { const char *name; hipEvent_t a, b; double cells, bytes; };
@@ -137,6 +151,16 @@ struct bath_hip_ctx {
   void set_error(const std::string &m) { err = m; }
   // scratch owned by the context (reused across calls)
   bath::DevBuf scratch[50];
+  // page-locked staging for small tables a launch uploads (job order, batch starts, offsets): an asynchronous copy from here needs
+  // no synchronize before the local it was built in goes away.  One slot per call site; a site is reused by its context only
+  // after the stage that used it has synchronized its stream.  [0] fs_schedule, [1]/[2] chain_batches (Forward / Backward), [3] wavefront Backward
+  bath::HostBuf stage[4];
+  template <class T> int stage_upload(int slot, void *dst, const T *src, size_t n, hipStream_t s) {
+    if (stage[slot].reserve(n * sizeof(T) + 64) != hipSuccess) { set_error("cannot allocate page-locked staging memory"); return BATH_EFAIL; }
+    std::memcpy(stage[slot].p, src, n * sizeof(T));
+    if (hipMemcpyAsync(dst, stage[slot].p, n * sizeof(T), hipMemcpyHostToDevice, s) != hipSuccess) { set_error("staging upload failed"); return BATH_EFAIL; }
+    return BATH_OK;
+  }
   bath::HostBuf pinned[4];                // [0,1]: standard-branch region matrices; [2,3]: frameshift-branch ones (read by ensemble threads)
   bath::HostBuf results_pinned;           // bath_hip_pipeline_filters output: the ORF records, page-locked
   bath_orf_result *d_records = nullptr;   // ... as the last cascade pass left them on the device (bath_records.hip)

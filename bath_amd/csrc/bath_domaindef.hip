@@ -15,7 +15,7 @@
 // the posterior and OA matrices (>1 MB per envelope) never leave the device; the posterior sums over the parsers'
 // special-state rows and the region heuristics run there too (fs_regions_kernel, a lane per window).  What remains for
 // the host is bookkeeping and the score arithmetic of the hit.
-// Multi-domain regions (:396-455) are resolved by stochastic-trace clustering (bath_ensemble.hip); *n_skipped_regions counts them.
+// Multi-domain regions (:396-455) are resolved by stochastic-trace clustering (bath_ensemble.hip); *n_clustered_regions counts them.
 // Not built: the "aliscore < 0" garbage rule of p7_pli_computeAliScores_BATH (:1070-1080), the printed alignment blocks.
 // The reference carries om_fs5's length configuration from one window to the next; here the domain decoding always uses
 // the configuration bathsearch starts with (L = 100 residues, multihit; bathsearch.c:797).
@@ -110,18 +110,18 @@ std::string cigar_from_columns(const uint16_t *S, int n) {
 }  // namespace
 
 static int std_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bath_hip_seqs *dna, const std::vector<PipelineSurvivor> &surv,
-                       const uint8_t *d_pool, int64_t nres, double E_report, int64_t *n_skipped_regions);
+                       const uint8_t *d_pool, int64_t nres, double E_report, int64_t *n_clustered_regions);
 
 
 static int fs_branch_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bath_hip_fsprofile *om_fs3,
                              const bath_hip_fsprofile *om_fs5, const bath_hip_seqs *dna, const bath_pipeline_params *prm,
                              double E_report, bath_pipeline_stats *stats,
                              const bath_fs_window **fs_windows, int64_t *n_fs_windows,
-                             const bath_fs_domain **domains, int64_t *n_domains, int64_t *n_skipped_regions, int64_t *std_skipped) {
+                             const bath_fs_domain **domains, int64_t *n_domains, int64_t *n_clustered_regions, int64_t *std_clustered) {
   if (!ctx || !om || !om_fs3 || !om_fs5 || !dna || !prm || !domains || !n_domains) return BATH_EINVAL;
   if (fsprofile_codon_lengths(om_fs5) != 5) { ctx->set_error("domain definition needs the 5-codon frameshift profile"); return BATH_EINVAL; }
   *domains = nullptr; *n_domains = 0;
-  if (n_skipped_regions) *n_skipped_regions = 0;
+  if (n_clustered_regions) *n_clustered_regions = 0;
   ctx->fs_domains.clear();
   ctx->cigars.clear();
   ctx->spans_reset();
@@ -156,9 +156,9 @@ static int fs_branch_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, con
   // cascade's residue pool.  Their domains are put in front of the frameshift branch's, as when they ran first.
   std::thread std_thread;
   int std_rc = BATH_OK;
-  int64_t std_nskip = 0;
+  int64_t std_nclust = 0;
   const char *ser = std::getenv("BATH_HIP_FS_STD_SERIAL");
-  if (std_skipped && !ctx->fs_std_orfs.empty() && !(ser && ser[0] == '1')) {
+  if (std_clustered && !ctx->fs_std_orfs.empty() && !(ser && ser[0] == '1')) {
     if (!ctx->aux && (st = bath_hip_init(ctx->device, &ctx->aux)) != BATH_OK) { ctx->set_error("cannot create the context of the standard branch"); return st; }
     if ((st = om->ensure_len_tables(dna->maxlen / 3 + 1)) != BATH_OK) return st;      // the profile's mutable state: fill it before the thread starts
     bath_hip_ctx *aux = ctx->aux;
@@ -166,7 +166,7 @@ static int fs_branch_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, con
     const int64_t nres = st_local.nres;
     std_thread = std::thread([&, aux, nres] {
       if (hipSetDevice(ctx->device) != hipSuccess) { std_rc = BATH_EFAIL; return; }
-      std_rc = std_domains(aux, om, dna, ctx->fs_std_orfs, ctx->fs_std_pool, nres, E_report, &std_nskip);
+      std_rc = std_domains(aux, om, dna, ctx->fs_std_orfs, ctx->fs_std_pool, nres, E_report, &std_nclust);
     });
   }
   struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } };
@@ -178,7 +178,7 @@ static int fs_branch_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, con
     const int64_t shift = (int64_t)ctx->cigars.size();
     for (bath_fs_domain dm : ctx->aux->fs_domains) { dm.cigar_off += shift; ctx->fs_domains.push_back(dm); }
     ctx->cigars += ctx->aux->cigars;
-    *std_skipped = std_nskip;
+    *std_clustered = std_nclust;
     return BATH_OK;
   };
   OrfTablesDev tt{};
@@ -209,7 +209,7 @@ static int fs_branch_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, con
       else if (j - i + 1 >= 15) envs.push_back(Env{q, i, j});                 // rescore_isolated_domain: Ld < 15 -> nothing
     }
   }
-  if (n_skipped_regions) *n_skipped_regions = (int64_t)mregs.size();          // regions resolved by clustering (ddef->nclustered)
+  if (n_clustered_regions) *n_clustered_regions = (int64_t)mregs.size();          // regions resolved by clustering (ddef->nclustered)
 
   // ---- envelopes: Forward, Backward, decoding, optimal accuracy, null2 on the GPU (unihit, length Ld/3)
   std::vector<FsWinDev> eregs;
@@ -444,21 +444,21 @@ extern "C" int bath_hip_pipeline_frameshift_domains(bath_hip_ctx *ctx, const bat
                                                     const bath_hip_fsprofile *om_fs5, const bath_hip_seqs *dna, const bath_pipeline_params *prm,
                                                     double E_report, bath_pipeline_stats *stats,
                                                     const bath_fs_window **fs_windows, int64_t *n_fs_windows,
-                                                    const bath_fs_domain **domains, int64_t *n_domains, int64_t *n_skipped_regions) {
+                                                    const bath_fs_domain **domains, int64_t *n_domains, int64_t *n_clustered_regions) {
   bath_pipeline_stats st_local{};
-  int64_t std_skipped = -1;                                                   // >= 0: the standard branch already ran, overlapped with the ensembles
-  int64_t fs_skipped = 0;
-  int st = fs_branch_domains(ctx, om, om_fs3, om_fs5, dna, prm, E_report, &st_local, fs_windows, n_fs_windows, domains, n_domains, &fs_skipped, &std_skipped);
+  int64_t std_clustered = -1;                                                   // >= 0: the standard branch already ran, overlapped with the ensembles
+  int64_t fs_clustered = 0;
+  int st = fs_branch_domains(ctx, om, om_fs3, om_fs5, dna, prm, E_report, &st_local, fs_windows, n_fs_windows, domains, n_domains, &fs_clustered, &std_clustered);
   if (st != BATH_OK) return st;
   if (stats) *stats = st_local;
-  int64_t nskip = fs_skipped;
+  int64_t nclust = fs_clustered;
   StageClock clk;
-  if (std_skipped >= 0) nskip += std_skipped;
+  if (std_clustered >= 0) nclust += std_clustered;
   else {
-    if ((st = std_domains(ctx, om, dna, ctx->fs_std_orfs, ctx->fs_std_pool, st_local.nres, E_report, &nskip)) != BATH_OK) return st;
+    if ((st = std_domains(ctx, om, dna, ctx->fs_std_orfs, ctx->fs_std_pool, st_local.nres, E_report, &nclust)) != BATH_OK) return st;
     clk.lap("fs: standard-branch domains");
   }
-  if (n_skipped_regions) *n_skipped_regions = nskip;
+  if (n_clustered_regions) *n_clustered_regions = nclust;
   *domains = ctx->fs_domains.data(); *n_domains = (int64_t)ctx->fs_domains.size();
   return BATH_OK;
 }
@@ -975,7 +975,7 @@ __global__ __launch_bounds__(256) void std_envelope_fill_kernel(SeqView sq, int 
 
 // Domain definition and hit scores for ORFs that passed the Forward filter; appends to ctx->fs_domains.
 static int std_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bath_hip_seqs *dna, const std::vector<PipelineSurvivor> &surv,
-                       const uint8_t *d_pool, int64_t nres, double E_report, int64_t *n_skipped_regions) {
+                       const uint8_t *d_pool, int64_t nres, double E_report, int64_t *n_clustered_regions) {
   int st;
   const int64_t ns = (int64_t)surv.size();
   if (ns == 0) return BATH_OK;
@@ -1038,7 +1038,7 @@ static int std_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bat
     if (r[0] > kStdMaxRegions) { ctx->set_error("an ORF has more regions than the region buffer holds"); return BATH_ERANGE; }
     for (int k = 0; k < r[0]; k++) (r[3 + 3 * k] ? mregs : envs).push_back(Env{(int)q, r[1 + 3 * k], r[2 + 3 * k], false, 0.f});
   }
-  if (n_skipped_regions) *n_skipped_regions += (int64_t)mregs.size();      // regions resolved by clustering (ddef->nclustered)
+  if (n_clustered_regions) *n_clustered_regions += (int64_t)mregs.size();      // regions resolved by clustering (ddef->nclustered)
 
   // ---- multi-domain regions (p7_domaindef.c:539-583): p7_Forward of the region with the ORF's multihit configuration on the
   // GPU, then the stochastic-trace ensemble and its clustering on the host (bath_ensemble.hip); every cluster is an envelope
@@ -1237,10 +1237,10 @@ static int std_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bat
 
 extern "C" int bath_hip_pipeline_hits(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bath_hip_seqs *dna, const bath_pipeline_params *prm_in,
                                       double E_report, bath_pipeline_stats *stats, const bath_fs_domain **domains, int64_t *n_domains,
-                                      int64_t *n_skipped_regions) {
+                                      int64_t *n_clustered_regions) {
   if (!ctx || !om || !dna || !prm_in || !domains || !n_domains) return BATH_EINVAL;
   *domains = nullptr; *n_domains = 0;
-  int64_t nskip = 0;
+  int64_t nclust = 0;
   ctx->fs_domains.clear();
   ctx->cigars.clear();
   bath_pipeline_params prm = *prm_in;
@@ -1254,8 +1254,8 @@ extern "C" int bath_hip_pipeline_hits(bath_hip_ctx *ctx, const bath_hip_oprofile
   clk.lap("std: cascade + survivors to the host");
   if (stats) *stats = st_local;
   for (PipelineSurvivor &o : surv) o.win_start = o.start;                  // windowsq is the ORF's own stretch of DNA (p7_pipeline.c:1755)
-  if ((st = std_domains(ctx, om, dna, surv, d_pool, st_local.nres, E_report, &nskip)) != BATH_OK) return st;
-  if (n_skipped_regions) *n_skipped_regions = nskip;
+  if ((st = std_domains(ctx, om, dna, surv, d_pool, st_local.nres, E_report, &nclust)) != BATH_OK) return st;
+  if (n_clustered_regions) *n_clustered_regions = nclust;
   *domains = ctx->fs_domains.data(); *n_domains = (int64_t)ctx->fs_domains.size();
   return BATH_OK;
 }

@@ -35,7 +35,7 @@ namespace bath {
 // Amino-acid targets: G adjacent lanes score sequence order[t] (or t); writes the raw maximum v in the
 // kernel's signed domain (begin score = -128), i.e. get_xE()'s byte minus 256.
 template <int NR, int G>
-__global__ __launch_bounds__((G > 1 && NR <= 76) ? 1024 : 256, (G > 1 && NR <= 76) ? 1 : (NR <= 76 ? 4 : 1)) void ssv_lane_kernel(SeqView sq, const int32_t *__restrict__ order,
+__global__ __launch_bounds__(256, NR <= 76 ? 4 : 1) void ssv_lane_kernel(SeqView sq, const int32_t *__restrict__ order,
                                                        const int16_t *__restrict__ cost_tab, int row_bytes,
                                                        int16_t *__restrict__ out_v) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -635,7 +635,7 @@ int launch_ssv_lane(bath_hip_ctx *ctx, const bath_hip_oprofile *om, SeqView v, c
   if (v.n == 0) return BATH_OK;
   const int G = om->G;
   const size_t shmem = (size_t)kSsvRows * om->ssv_row_bytes;
-  const int threads = (G > 1 && om->NR <= 76 && 4 * shmem > 160 * 1024) ? 1024 : 256;      // long models: one cost table for 16 waves (bath_pipeline.hip)
+  const int threads = 256;
   const int blocks = (int)((v.n * G + threads - 1) / threads);
   const int rb = om->ssv_row_bytes;
   bool launched = false;

@@ -419,6 +419,7 @@ __global__ __launch_bounds__(kFsBlock) void fs5_fwd_kernel(SeqView dna, FsDev p,
 
 // ---------------------------------------------------------------------------------------------
 // Backward, both codon systems (NCOD = 3: parser, no matrix stored; NCOD = 5: full, 3 cells per node).
+// Only NCOD = 3 is instantiated since round 4: the envelopes' Backward is fs5_bwd_wf_kernel (bath_fs_wavefront.hip) in every mode.
 // tb[node] = {tMD(k), tMI(k), tMM(k), tDD(k), tDM(k), tII(k), tIM(k), tBM(k-1)}
 // Row types follow the reference: rows without an emitted codon, "tail" rows with no i+3 row,
 // accumulate-left-to-right rows (L-3, L-4) and the main recursion (generic_fwdback_frameshift.c:1054-1323, 1442-1677).
@@ -1322,6 +1323,7 @@ __global__ void fs5_null2_kernel(int64_t n, const int32_t *__restrict__ len, int
 // =================================================================================================
 
 int bath_hip_fsprofile::ensure_len(int maxL_amino) const {
+  std::lock_guard<std::mutex> lock(grow_mu);
   if (maxL_amino <= maxL) return BATH_OK;
   const int n = std::max(maxL_amino, 4096) + 1;
   for (int h = 0; h < 2; h++) {
@@ -1332,12 +1334,14 @@ int bath_hip_fsprofile::ensure_len(int maxL_amino) const {
       const float ploop = 1.0f - pmove;
       lo[L] = (float)std::log((double)ploop); mv[L] = (float)std::log((double)pmove);
     }
-    if (d_loop[h]) (void)hipFree(d_loop[h]);
-    if (d_move[h]) (void)hipFree(d_move[h]);
-    BATH_HIP_TRY(ctx, hipMalloc((void **)&d_loop[h], n * sizeof(float)));
-    BATH_HIP_TRY(ctx, hipMalloc((void **)&d_move[h], n * sizeof(float)));
-    BATH_HIP_TRY(ctx, hipMemcpy(d_loop[h], lo.data(), n * sizeof(float), hipMemcpyHostToDevice));
-    BATH_HIP_TRY(ctx, hipMemcpy(d_move[h], mv.data(), n * sizeof(float), hipMemcpyHostToDevice));
+    float *nl = nullptr, *nm = nullptr;                            // complete before they are published; the old tables are freed with the profile
+    BATH_HIP_TRY(ctx, hipMalloc((void **)&nl, n * sizeof(float)));
+    BATH_HIP_TRY(ctx, hipMalloc((void **)&nm, n * sizeof(float)));
+    BATH_HIP_TRY(ctx, hipMemcpy(nl, lo.data(), n * sizeof(float), hipMemcpyHostToDevice));
+    BATH_HIP_TRY(ctx, hipMemcpy(nm, mv.data(), n * sizeof(float), hipMemcpyHostToDevice));
+    if (d_loop[h]) retired.push_back(d_loop[h]);
+    if (d_move[h]) retired.push_back(d_move[h]);
+    d_loop[h] = nl; d_move[h] = nm;
   }
   maxL = n - 1;
   return BATH_OK;
@@ -1348,6 +1352,7 @@ extern "C" void bath_hip_fsprofile_destroy(bath_hip_fsprofile *om) {
   for (void *p : {(void *)om->d_codons, (void *)om->d_indel, (void *)om->d_rsc, (void *)om->d_tf, (void *)om->d_tb, (void *)om->d_logsum, (void *)om->d_loop[0], (void *)om->d_loop[1],
                   (void *)om->d_move[0], (void *)om->d_move[1]})
     if (p) (void)hipFree(p);
+  for (void *p : om->retired) (void)hipFree(p);
   delete om;
 }
 
@@ -1465,8 +1470,7 @@ static int fs_schedule(bath_hip_ctx *ctx, const bath_hip_seqs *dna, int k, FsJob
   DevBuf &b = ctx->scratch[40];                                    // its own slot: the cascade's local-composition terms live in 36
   BATH_HIP_TRY(ctx, b.reserve(256 + (size_t)n * sizeof(int32_t) + 64));
   BATH_HIP_TRY(ctx, hipMemsetAsync(b.p, 0, 256, ctx->stream));
-  BATH_HIP_TRY(ctx, hipMemcpyAsync(b.as<char>() + 256, order.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
-  BATH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));            // <order> is a local
+  if (ctx->stage_upload(0, b.as<char>() + 256, order.data(), (size_t)n, ctx->stream) != BATH_OK) return BATH_EFAIL;   // through page-locked staging: no synchronize
   for (int i = 0; i < k; i++) jobs[i] = FsJobs{reinterpret_cast<const int32_t *>(b.as<char>() + 256), b.as<unsigned>() + i};
   return BATH_OK;
 }
@@ -1498,6 +1502,8 @@ static int fs3_parser(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, const bat
   const int grid_dp = fs_grid_dp(ctx, n);
   FsJobs jq[1];
   if ((st = fs_schedule(ctx, dna, 1, jq)) != BATH_OK) return st;
+  const bool chain = logsum_mode == BATH_LOGSUM_TABLE_SERIAL && fs_chain_enabled();
+  ChainGate gate(chain ? ctx->device : -1);                         // held until this stage's kernels have finished (the synchronize below)
   const int sp = ctx->span_begin(backward ? "fs_bwd_kernel<3>" : "fs3_fwd_kernel", ctx->stream, (double)dna->total * om->M, (double)dna->total * ((xmx || keep) ? 21.0 : 1.0));
   if (logsum_mode == BATH_LOGSUM_TABLE_SERIAL && fs_chain_enabled()) {
     if (!backward) st = launch_fs3_fwd_chain(ctx, ctx->stream, om, dna, Cv, tE, tE, b_sc.as<float>(), d_x, b_off.as<int64_t>(), jq[0]);
@@ -1661,8 +1667,9 @@ int fs3_regions(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, const bath_hip_
   BATH_HIP_TRY(ctx, b_sc.reserve((size_t)n * 2 * sizeof(float)));
   FsJobs jq[2];
   if ((st = fs_schedule(ctx, dna, 2, jq)) != BATH_OK) return st;
-  if ((st = fs_fork(ctx)) != BATH_OK) return st;
   const int mode = ctx->fs_strict ? BATH_LOGSUM_TABLE_SERIAL : BATH_LOGSUM_TABLE;
+  ChainGate gate((mode == BATH_LOGSUM_TABLE_SERIAL && fs_chain_enabled()) ? ctx->device : -1);   // held until the synchronize below
+  if ((st = fs_fork(ctx)) != BATH_OK) return st;
   const double cells3 = (double)(xoff[(size_t)n] / 5) * om->M;                // rows x nodes; algorithmic HBM bytes: 1 B/nt in + 20 B/row out
   const double bytes3 = (double)(xoff[(size_t)n] / 5) * 21.0;
   BATH_FS_SWITCH(Cv, BATH_FS_MODE(mode, {
@@ -1789,11 +1796,8 @@ int bath::fs5_envelopes_ex(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, cons
   BATH_HIP_TRY(ctx, hipMemcpyAsync(d_xoff, xoff.data(), (n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
   float *d_fsc = b_sc.as<float>(), *d_bsc = d_fsc + n, *d_osc = d_bsc + n;
   const int Cv = fs_columns(M);
-  const size_t shmem = (size_t)(kLogsumTbl + (M + 2) * 8) * sizeof(float);
   const size_t oa_shmem = (size_t)(M + 2) * 8 * sizeof(float);
   [[maybe_unused]] const int grid = fs_grid(ctx, n);
-  const int grid_dp = fs_grid_dp(ctx, n);
-  const float tEL = -INFINITY, tEM = 0.0f;                                      // unihit: p7_fs_ReconfigUnihit, modelconfig.c:868
   if (logsum_mode == BATH_LOGSUM_CONTEXT) logsum_mode = ctx->fs_strict ? BATH_LOGSUM_TABLE_SERIAL : BATH_LOGSUM_TABLE;
   const double cells5 = (double)(foff[(size_t)n] / 8);                          // (L+1) x (M+1) cells of all envelopes
   FsJobs jq[4];
@@ -1801,30 +1805,29 @@ int bath::fs5_envelopes_ex(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, cons
   if ((st = fs_fork(ctx)) != BATH_OK) return st;                                // Backward on the side stream, concurrently with Forward
   BATH_FS_SWITCH(Cv, {
     BATH_FS_MODE(logsum_mode, {
-      if ((st = fs_set_shmem(ctx, fs5_fwd_kernel<CC, MD, true>, shmem)) != BATH_OK) return st;
-      if ((st = fs_set_shmem(ctx, fs_bwd_kernel<CC, 5, MD>, shmem)) != BATH_OK) return st;
-      // Forward: the row-per-lane wavefront (bath_fs_wavefront.hip), the reference's order of every sum in every mode;
-      // BATH_HIP_FS_NODE_LANES=1 keeps the node-per-lane kernel (scans, or the 64-step hand-off in strict mode) for A/B runs
-      static const int wf_env = [] { const char *e = std::getenv("BATH_HIP_FS_NODE_LANES"); return e ? std::atoi(e) : -1; }();
-      const bool node_lanes = wf_env >= 0 ? wf_env == 1 : MD == 0;
+      // Forward and Backward: the row-per-lane wavefronts (bath_fs_wavefront.hip), the reference's order of every sum, in EVERY mode --
+      // the unihit recursion has no sum that a scan could shorten, so the fast mode's envelopes are the strict ones (the node-per-lane
+      // scan kernels this replaced in fast mode were 13 times slower at 1024 nodes and are gone)
       const int s1 = ctx->span_begin("fs5_fwd_kernel", ctx->stream, cells5, cells5 * 32.0);
-      if (node_lanes)
-        hipLaunchKernelGGL((fs5_fwd_kernel<CC, MD, true>), dim3(grid_dp), dim3(kFsBlock), shmem, ctx->stream, dna->view(), fsdev(om), om->d_loop[1], om->d_move[1], tEL, tEM, c5_compat, d_fsc, b_f.as<float>(), d_foff, b_fx.as<float>(), d_xoff, -1, jq[0]);
-      else if ((st = launch_fs5_fwd_wf(ctx, ctx->stream, om, dna, MD == 1, c5_compat, d_fsc, b_f.as<float>(), d_foff, b_fx.as<float>(), d_xoff, ctx->scratch[41], jq[0])) != BATH_OK) return st;
+      if ((st = launch_fs5_fwd_wf(ctx, ctx->stream, om, dna, MD == 1, c5_compat, d_fsc, b_f.as<float>(), d_foff, b_fx.as<float>(), d_xoff, ctx->scratch[41], jq[0])) != BATH_OK) return st;
       ctx->span_end(s1, ctx->stream);
       static const bool serial = [] { const char *e = std::getenv("BATH_HIP_FS_SERIAL"); return e && e[0] == '1'; }();   // timing probes: Backward after Forward
       hipStream_t bs = serial ? ctx->stream : ctx->side_stream;
       const int s2 = ctx->span_begin("fs_bwd_kernel<5>", bs, cells5, cells5 * 12.0);
-      if (node_lanes)
-        hipLaunchKernelGGL((fs_bwd_kernel<CC, 5, MD>), dim3(grid_dp), dim3(kFsBlock), shmem, bs, dna->view(), fsdev(om), om->d_loop[1], om->d_move[1], tEL, tEM, d_bsc, b_b.as<float>(), d_boff, b_bx.as<float>(), d_xoff, jq[1]);
-      else if ((st = launch_fs5_bwd_wf(ctx, bs, om, dna, MD == 1, d_bsc, b_b.as<float>(), d_boff, b_bx.as<float>(), d_xoff, ctx->scratch[42], ctx->scratch[43], ctx->scratch[44], jq[1], jq[3])) != BATH_OK) return st;
+      if ((st = launch_fs5_bwd_wf(ctx, bs, om, dna, MD == 1, d_bsc, b_b.as<float>(), d_boff, b_bx.as<float>(), d_xoff, ctx->scratch[42], ctx->scratch[43], ctx->scratch[44], jq[1], jq[3])) != BATH_OK) return st;
       ctx->span_end(s2, bs);
     })
     if ((st = fs_join(ctx)) != BATH_OK) return st;
     BATH_HIP_TRY(ctx, hipMemsetAsync(b_cs.p, 0, (size_t)n * cs_stride * sizeof(float), ctx->stream));
     // decoding + optimal-accuracy fill, one walk over the rows (BATH_HIP_FS_UNFUSED=1: the two separate kernels, for A/B runs)
     static const bool unfused = [] { const char *e = std::getenv("BATH_HIP_FS_UNFUSED"); return e && e[0] == '1'; }();
-    if (!unfused) {
+    int mw_nodes = 0;
+    if (!unfused && fs5_decode_oa_mw_shape(M, &mw_nodes) > 0) {        // long models: a block of waves per envelope (bath_fs_decode.hip)
+      const int s3 = ctx->span_begin("fs5_decode_oa_kernel", ctx->stream, cells5, cells5 * 88.0);
+      if ((st = launch_fs5_decode_oa_mw(ctx, ctx->stream, om, dna, d_bsc, b_f.as<float>(), d_foff, b_fx.as<float>(), d_xoff, b_b.as<float>(), d_boff, b_bx.as<float>(),
+                                        b_cs.as<float>(), b_o.as<float>(), d_osc, (oax || trace) ? b_ox.as<float>() : nullptr, jq[2])) != BATH_OK) return st;
+      ctx->span_end(s3, ctx->stream);
+    } else if (!unfused) {
       if ((st = fs_set_shmem(ctx, fs5_decode_oa_kernel<CC>, oa_shmem)) != BATH_OK) return st;
       const int s3 = ctx->span_begin("fs5_decode_oa_kernel", ctx->stream, cells5, cells5 * 88.0);   // reads Forward 32 + Backward 12, writes posteriors 32 + OA 12 B/cell
       const int oa_grid = (int)std::max<int64_t>(1, std::min<int64_t>((n + 3) / 4, (int64_t)ctx->prop.multiProcessorCount * (CC <= 3 ? BATH_FS_OA_WAVES : 1)));
@@ -1927,13 +1930,14 @@ int bath::fs5_region_forward(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, co
   const bool live = direct && done_flags != nullptr;
   if (done_flags) { *done_flags = h_done; *sc_live = h_sc; }
   for (int64_t i = 0; i < n; i++) h_done[i] = 0;
+  BATH_HIP_TRY(ctx, b_sc.reserve((size_t)n * 3 * sizeof(float)));            // BEFORE its pointer is taken: on a fresh context it is null, and a growing buffer moves
   int *d_done = live ? reinterpret_cast<int *>(reinterpret_cast<char *>(d_fx) + x_bytes) : nullptr;
   float *d_sc_out = live ? reinterpret_cast<float *>(d_done + n) : b_sc.as<float>();
   if (!direct) {
     BATH_HIP_TRY(ctx, b_f.reserve((size_t)foff[(size_t)n] * 4 + 64)); BATH_HIP_TRY(ctx, b_fx.reserve((size_t)xoff[(size_t)n] * 4 + 64));
     d_f = b_f.as<float>(); d_fx = b_fx.as<float>();
   }
-  BATH_HIP_TRY(ctx, b_off.reserve((size_t)(n + 1) * 3 * sizeof(int64_t))); BATH_HIP_TRY(ctx, b_sc.reserve((size_t)n * 3 * sizeof(float)));
+  BATH_HIP_TRY(ctx, b_off.reserve((size_t)(n + 1) * 3 * sizeof(int64_t)));
   int64_t *d_foff = b_off.as<int64_t>(), *d_xoff = d_foff + (n + 1);
   BATH_HIP_TRY(ctx, hipMemcpyAsync(d_foff, foff.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
   BATH_HIP_TRY(ctx, hipMemcpyAsync(d_xoff, xoff.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));

@@ -832,7 +832,7 @@ __global__ __launch_bounds__(THREADS) void fs5_fwd_chain_kernel(SeqView dna, FsD
 // smallest T such that batches of w(L) = (2T / L - t0) / dt windows (at most <wmax>), longest windows first, need no more blocks than
 // there are CUs -- the batches of the longest windows are smaller, and all blocks end together.  <bst>: batch b = windows
 // bst[b] .. bst[b+1]-1 of the list sorted by decreasing length.  BATH_HIP_FS_BATCH=w: uniform batches of w (A/B runs).
-static int chain_batches(bath_hip_ctx *ctx, hipStream_t stream, const bath_hip_seqs *dna, double t0, double dt, int wmax, DevBuf &buf, int *nbat_out, int cu_share = 1) {
+static int chain_batches(bath_hip_ctx *ctx, hipStream_t stream, const bath_hip_seqs *dna, double t0, double dt, int wmax, DevBuf &buf, int stage_slot, int *nbat_out, int cu_share = 1) {
   const int64_t n = dna->n;
   std::vector<int> ls(dna->h_len.begin(), dna->h_len.begin() + n);
   std::sort(ls.begin(), ls.end(), [](int a, int b) { return a > b; });
@@ -863,9 +863,7 @@ static int chain_batches(bath_hip_ctx *ctx, hipStream_t stream, const bath_hip_s
   }
   *nbat_out = (int)bst.size() - 1;
   BATH_HIP_TRY(ctx, buf.reserve(bst.size() * sizeof(int32_t) + 64));
-  BATH_HIP_TRY(ctx, hipMemcpyAsync(buf.p, bst.data(), bst.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
-  BATH_HIP_TRY(ctx, hipStreamSynchronize(stream));                 // <bst> is a local
-  return BATH_OK;
+  return ctx->stage_upload(stage_slot, buf.p, bst.data(), bst.size(), stream);   // through page-locked staging: the host does not wait for what the stream already holds
 }
 
 static int chain_waves(bath_hip_ctx *ctx, int64_t n, int M, int C, size_t *shmem_out, int cu_share = 1) {
@@ -918,7 +916,7 @@ int launch_fs3_fwd_chain(bath_hip_ctx *ctx, hipStream_t stream, const bath_hip_f
     // 32 for the bulk: 10.9 -> 9.9 ms
     int nbat = 0;
     DevBuf &b_bst = ctx->scratch[47];
-    int stb = chain_batches(ctx, stream, dna, 0.085 * M + 3.5 + 0.4 * CH, 0.021 * CH, 32, b_bst, &nbat);
+    int stb = chain_batches(ctx, stream, dna, 0.085 * M + 3.5 + 0.4 * CH, 0.021 * CH, 32, b_bst, 1, &nbat);
     if (stb != BATH_OK) return stb;
     const int cus = ctx->prop.multiProcessorCount;
     const int hgrid = std::max(1, std::min(nbat, cus));
@@ -949,7 +947,7 @@ int launch_fs3_bwd_chain(bath_hip_ctx *ctx, hipStream_t stream, const bath_hip_f
   // batches by length (chain_batches); t(w) measured at M = 145 (C = 3): 25.4 us per row pair at one window, 28.5 at 16
   int nbat = 0;
   DevBuf &b_bst = ctx->scratch[48];                                // (its own buffer: Forward's launch may be running on another stream)
-  const int stb = chain_batches(ctx, stream, dna, 0.128 * M + 6.6, 0.067 * Cv, W, b_bst, &nbat, cu_share);
+  const int stb = chain_batches(ctx, stream, dna, 0.128 * M + 6.6, 0.067 * Cv, W, b_bst, 2, &nbat, cu_share);
   if (stb != BATH_OK) return stb;
   const int grid = std::max(1, std::min(nbat, (int)ctx->prop.multiProcessorCount));
   FsDev dev{om->M, om->pitch, om->maxcodons, om->d_rsc, om->d_tf, om->d_tb, om->d_logsum};

@@ -2,6 +2,7 @@
 // p7_FLogsum with its table in LDS (logsum.c:105), DPP lane moves, the longest-first job queue, the device profile.
 #pragma once
 #include <cmath>
+#include <mutex>
 #include <vector>
 
 #include "bath_common.hpp"
@@ -23,8 +24,12 @@ struct bath_hip_fsprofile {
   uint8_t *d_codons = nullptr;   // the same on the device (5-codon profiles)
   uint8_t *d_indel = nullptr;    // [(M+1)*maxcodons] indel-type label of that choice (hmmer.h:259-276), for the alignment display
   // length model: xsc[N|C|J][LOOP|MOVE] for L_amino, multihit (nj=1) and unihit (nj=0); host libm log()
+  // (the tables grow under <grow_mu>; the old ones are retired, not freed: the profile is shared by contexts running side by side --
+  // the regions' Forward beside the envelopes, worker contexts -- and another stream's kernel may still be reading them)
   mutable int maxL = -1;
   mutable float *d_loop[2] = {nullptr, nullptr}, *d_move[2] = {nullptr, nullptr};
+  mutable std::mutex grow_mu;
+  mutable std::vector<void *> retired;
   int ensure_len(int maxL_amino) const;
 };
 
@@ -143,6 +148,12 @@ int launch_fs5_fwd_wf(bath_hip_ctx *ctx, hipStream_t stream, const bath_hip_fspr
 int launch_fs5_bwd_wf(bath_hip_ctx *ctx, hipStream_t stream, const bath_hip_fsprofile *om, const bath_hip_seqs *dna, int exact,
                       float *d_sc, float *d_bck, const int64_t *d_boff, float *d_xmx, const int64_t *d_xoff, DevBuf &ring_scratch, DevBuf &terms_scratch, DevBuf &toff_scratch,
                       FsJobs jobs_sweep, FsJobs jobs_x);
+
+// ---- decoding + optimal-accuracy fill with several waves per envelope, long models (bath_fs_decode.hip)
+int fs5_decode_oa_mw_shape(int M, int *nodes_per_lane);     // waves per envelope (0: the one-wave kernel of bath_frameshift.hip)
+int launch_fs5_decode_oa_mw(bath_hip_ctx *ctx, hipStream_t stream, const bath_hip_fsprofile *om, const bath_hip_seqs *dna, const float *d_bsc,
+                            float *d_fwd, const int64_t *d_foff, float *d_fx, const int64_t *d_xoff, const float *d_bck, const int64_t *d_boff, const float *d_bx,
+                            float *d_colsum, float *d_oa, float *d_osc, float *d_ox, FsJobs jobs);
 
 // ---- multihit recursions in the reference's serial order, chains batched per block (bath_fs_chain.hip)
 int launch_fs3_fwd_chain(bath_hip_ctx *ctx, hipStream_t stream, const bath_hip_fsprofile *om, const bath_hip_seqs *dna, int Cv, float tEL, float tEM,

@@ -595,8 +595,7 @@ int launch_fs5_bwd_wf(bath_hip_ctx *ctx, hipStream_t stream, const bath_hip_fspr
   for (int64_t e = 0; e < n; e++) toff[(size_t)e + 1] = toff[(size_t)e] + (dna->h_len[(size_t)e] >= 5 ? ((fs_bwd_wf_steps(dna->h_len[(size_t)e], M, RW) + 3) & ~(int64_t)3) * RW : 0);   // the sweep runs in blocks of four steps
   BATH_HIP_TRY(ctx, terms_scratch.reserve((size_t)toff[(size_t)n] * sizeof(float) + 256));
   BATH_HIP_TRY(ctx, toff_scratch.reserve((size_t)(n + 1) * sizeof(int64_t)));
-  BATH_HIP_TRY(ctx, hipMemcpyAsync(toff_scratch.p, toff.data(), (size_t)(n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, stream));
-  BATH_HIP_TRY(ctx, hipStreamSynchronize(stream));                    // <toff> is a local
+  if (ctx->stage_upload(3, toff_scratch.p, toff.data(), (size_t)(n + 1), stream) != BATH_OK) return BATH_EFAIL;   // through page-locked staging: no synchronize
   FsDev dev{om->M, om->pitch, om->maxcodons, om->d_rsc, om->d_tf, om->d_tb, om->d_logsum};
   BATH_WF_DISPATCH(fs5_bwd_wf_kernel, dna->view(), dev, om->d_loop[1], om->d_move[1], d_bck, d_boff, d_xmx, d_xoff, terms_scratch.as<float>(), toff_scratch.as<int64_t>(), g.ring_g, jobs_sweep);
   BATH_HIP_TRY(ctx, hipGetLastError());

@@ -57,10 +57,10 @@ struct Params {
 // ---------------------------------------------------------------------------------------------
 // 1. SSV over the length-sorted ORF list, lane per ORF (persistent waves striding over the list)
 // ---------------------------------------------------------------------------------------------
-// (G > 1 with a tile of at most 76 registers: long models, whose cost table -- a row per residue, 4 bytes per register and lane
-// of the group -- may be too big for four blocks per CU; such a launch uses 1024-thread blocks, one table for 16 waves)
+// (tiles of at most 76 registers: four 256-thread blocks per CU, 128 VGPRs each; a group of G lanes with such tiles has rows of at
+// most 4 * 76 * G bytes, so four copies of its cost table always fit a CU's LDS -- a 1024-thread variant existed and could never be chosen)
 template <int NR, int G>
-__global__ __launch_bounds__((G > 1 && NR <= 76) ? 1024 : 256, (G > 1 && NR <= 76) ? 1 : (NR <= 76 ? 4 : 1)) void ssv_orf_kernel(const uint8_t *__restrict__ aa, const OrfRec *__restrict__ orfs, const int *__restrict__ n_orfs_dev,
+__global__ __launch_bounds__(256, NR <= 76 ? 4 : 1) void ssv_orf_kernel(const uint8_t *__restrict__ aa, const OrfRec *__restrict__ orfs, const int *__restrict__ n_orfs_dev,
                                                       SeqView dna, const int16_t *__restrict__ cost_tab, int row_bytes,
                                                       const int16_t *__restrict__ emit_thresh, int thresh_max,
                                                       Cand cand, int cand_cap, Counters *__restrict__ ctr, int chunk) {
@@ -698,9 +698,7 @@ static int run_filters(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bat
     {
       static const int ssv_chunk = [] { const char *e = std::getenv("BATH_HIP_SSV_CHUNK"); return e ? std::atoi(e) : 0; }();
       int blocks = ctx->prop.multiProcessorCount * 4;
-      // four 256-thread blocks per CU when their tables fit a CU's LDS together; otherwise (long models) one 1024-thread block
-      const int ssv_threads = (om->G > 1 && NRk <= 76 && 4 * ssv_shmem > 160 * 1024) ? 1024 : 256;
-      if (ssv_threads == 1024) blocks = ctx->prop.multiProcessorCount;
+      const int ssv_threads = 256;
       const int wpb = ssv_threads / 64;
       if (ssv_chunk > 0) blocks = (int)std::min<int64_t>((max_orfs + (int64_t)wpb * (64 / om->G) * ssv_chunk - 1) / ((int64_t)wpb * (64 / om->G) * ssv_chunk), 1 << 30);
       bool launched = false;

@@ -136,6 +136,7 @@ extern "C" void bath_hip_finalize(bath_hip_ctx *ctx) {
   if (ctx->aux2) { bath_hip_finalize(ctx->aux2); ctx->aux2 = nullptr; }
   for (auto &b : ctx->scratch) b.release();
   for (auto &b : ctx->pinned) b.release();
+  for (auto &b : ctx->stage) b.release();
   ctx->results_pinned.release();
   for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
   for (auto e : ctx->span_events) (void)hipEventDestroy(e);

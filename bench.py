@@ -523,7 +523,8 @@ def main():
         out["roofline"] = {
             # what binds the kernel is the issue rate of packed 16-bit VALU ops (the "valu" object below: 0.75 of the measured ceiling);
             # achieved / peak / frac are the HBM figures the contract asks for -- a few percent by construction (0.01 B per DP cell)
-            "bound": "valu", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "hbm_frac": achieved / HBM_PEAK_GBS,
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "binding_resource": "valu (packed 16-bit issue rate; the fraction of THAT ceiling is valu.frac)",
             "traffic": traffic, "traffic_source": "rocprofv3 --pmc passes of this command, profiles/%s (static: counters cannot be read from inside the run)" % os.path.basename(pmc),
             "kernel": "ssv_orf_kernel", "kernel_ms": k_ms, "launches_per_step": lanes,
             "note": "DP rows held in VGPRs (integer scores as binary16): compulsory HBM traffic is 1 B per ORF residue, so the HBM fraction is small by "

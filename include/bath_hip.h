@@ -288,7 +288,7 @@ int  bath_hip_pipeline_frameshift(bath_hip_ctx *ctx, const bath_hip_oprofile *om
 /* ... and what the frameshift branch does next (p7_pipeline.c:1469-1476): p7_BackwardParser_Frameshift_3Codons,
  * p7_domaindef_ByPosteriorHeuristics_Frameshift_BATH (p7_domaindef.c:301) with rescore_isolated_domain_frameshift (:993)
  * for single-domain regions, and the scores p7_pli_postDomainDef_Frameshift_BATH (p7_pipeline.c:1005) gives the hit.
- * Multi-domain regions are resolved by stochastic-trace clustering (p7_domaindef.c:396-455); *n_skipped_regions counts them
+ * Multi-domain regions are resolved by stochastic-trace clustering (p7_domaindef.c:396-455); *n_clustered_regions counts them
  * (ddef->nclustered; the name predates that stage). */
 typedef struct {
   int64_t window;                  /* sequence index in the block                                              */
@@ -313,16 +313,16 @@ int  bath_hip_pipeline_frameshift_domains(bath_hip_ctx *ctx, const bath_hip_opro
                                           const bath_hip_fsprofile *om_fs5, const bath_hip_seqs *dna, const bath_pipeline_params *params,
                                           double E_report, bath_pipeline_stats *stats,
                                           const bath_fs_window **fs_windows, int64_t *n_fs_windows,
-                                          const bath_fs_domain **domains, int64_t *n_domains, int64_t *n_skipped_regions);
+                                          const bath_fs_domain **domains, int64_t *n_domains, int64_t *n_clustered_regions);
 
 /* The standard pipeline (bathsearch without --fs) after the Forward filter (p7_pipeline.c:1741-1771): p7_BackwardParser,
  * p7_domaindef_ByPosteriorHeuristics_BATH (p7_domaindef.c:491) with rescore_isolated_domain_bath (:1194) for single-domain
  * regions, p7_pli_postDomainDef_BATH (p7_pipeline.c:1172).  One bath_fs_domain per hit (fs_window = -1,
  * n_shifted_codons = 0).  Multi-domain regions are resolved by stochastic-trace clustering (p7_domaindef.c:539-583);
- * *n_skipped_regions counts them (ddef->nclustered). */
+ * *n_clustered_regions counts them (ddef->nclustered). */
 int  bath_hip_pipeline_hits(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bath_hip_seqs *dna,
                             const bath_pipeline_params *params, double E_report, bath_pipeline_stats *stats,
-                            const bath_fs_domain **domains, int64_t *n_domains, int64_t *n_skipped_regions);
+                            const bath_fs_domain **domains, int64_t *n_domains, int64_t *n_clustered_regions);
 
 /* Full-matrix forms over a block of amino-acid targets (the batched twins of impl_sse's single-target functions):
  *   bath_hip_forward_full  <- p7_Forward (fwdback.c:94): Forward matrices (L_i+1) x (M+1) x {M,D,I} (odds ratios, scaled per row

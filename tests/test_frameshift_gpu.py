@@ -257,3 +257,15 @@ def test_fs5_multihit_forward_strict_is_bit_identical(setup):
         assert identical(xmx[xoff[e]:xoff[e + 1]].reshape(L + 1, 5), ox), e
         got = fwd[foff[e]:foff[e + 1]].reshape(L + 1, M + 1, 8)
         assert identical(got[1:, 1:, :], dp[1:, 1:, :]), e
+
+
+def test_fs5_envelopes_with_the_multiwave_decode_oa_kernel():
+    """fs5_decode_oa_mw_kernel (bath_fs_decode.hip: a block of waves per envelope, what models beyond 256 nodes get) forced onto the
+    two small models with BATH_HIP_FS_OA_MW=1 (W = 2 waves at M = 145, one at M = 90): the posteriors, the whole optimal-accuracy
+    matrix, its score and null2 against the oracle, same bars as the one-wave kernel.  Fresh process: the switch is read once."""
+    import os, subprocess, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, BATH_HIP_FS_OA_MW="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.join(here, "test_frameshift_gpu.py"), "-k", "test_fs5_envelopes and strict and not multiwave"],
+                       env=env, capture_output=True, text=True, timeout=1200, cwd=os.path.dirname(here))
+    assert r.returncode == 0 and " passed" in r.stdout, (r.stdout[-3000:], r.stderr[-2000:])
