@@ -141,3 +141,90 @@ def max_over_ranks(x, device="cpu"):
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# A multi-query database over N ranks (BASELINE configs[3]).  bathsearch loops over the queries of the database, and for every
+# query hands the target's blocks to its workers, merges their hit lists and finishes the query (bathsearch.c:737-844, 868-921).
+# One process per GPU: the whole database is broadcast ONCE, the unit dealt to the ranks is a (query, group of consecutive
+# windows of the target) pair -- per query the fixed cost of a search (profile conversion, a dozen small launches, domain
+# definition) is paid by one or two ranks on a large block instead of by every rank on a small one -- and per query the hits
+# and the 14 counters travel to rank 0, which finishes each query exactly as the single-rank search does.
+# ---------------------------------------------------------------------------------------------------------------------------
+
+def query_items(n_windows_by_query, world, items_per_rank=2):
+    """[(query, lo, hi)]: each query's windows [0, n) cut into G consecutive groups, G the smallest count that gives every rank
+    about <items_per_rank> items (G = 1 while there are at least that many queries per rank)."""
+    nq = len(n_windows_by_query)
+    G = max(1, -(-items_per_rank * world // max(nq, 1)))
+    items = []
+    for q, n in enumerate(n_windows_by_query):
+        g = max(1, min(G, n))
+        for k in range(g):
+            lo, hi = shard_range(n, k, g)
+            if hi > lo:
+                items.append((q, lo, hi))
+    return items
+
+
+def deal(costs, world):
+    """Owner rank of every item: longest processing time first onto the least loaded rank (ties: lowest rank); the same on every
+    rank, no communication."""
+    order = sorted(range(len(costs)), key=lambda i: (-costs[i], i))
+    load = [0.0] * world
+    owner = [0] * len(costs)
+    for i in order:
+        r = min(range(world), key=lambda k: (load[k], k))
+        owner[i] = r
+        load[r] += costs[i]
+    return owner
+
+
+def gather_query_domains(by_query, dst=0, device="cpu"):
+    """p7_tophits_Merge per query in ONE variable-length gather: {query: [FsDomain with .cigar]} of every rank -> the union per
+    query on rank <dst> (None elsewhere).  Window indices must already be the query's own (global) window numbers."""
+    sz = C.sizeof(FsDomain)
+    blob = bytearray()
+    for q in sorted(by_query):
+        for d in by_query[q]:
+            cig = d.cigar.encode()
+            blob += int(q).to_bytes(4, "little") + bytes(d) + len(cig).to_bytes(4, "little") + cig
+    parts = gather_bytes(bytes(blob), dst, device)
+    if parts is None:
+        return None
+    out = {}
+    for part in parts:
+        p = 0
+        while p < len(part):
+            q = int.from_bytes(part[p : p + 4], "little"); p += 4
+            x = FsDomain.from_buffer_copy(part[p : p + sz]); p += sz
+            n = int.from_bytes(part[p : p + 4], "little"); p += 4
+            x.cigar = part[p : p + n].decode(); p += n
+            out.setdefault(q, []).append(x)
+    return out
+
+
+def reduce_query_stats(stats_by_query, n_queries, device="cpu"):
+    """p7_pipeline_Merge per query in one all-reduce: {query: PipelineStats (this rank's sum over its items)} -> [dict] per query."""
+    vals = torch.zeros((n_queries, len(STAT_FIELDS)), dtype=torch.int64)
+    for q, st in stats_by_query.items():
+        for j, f in enumerate(STAT_FIELDS):
+            vals[q, j] += int(getattr(st, f)) if not isinstance(st, dict) else int(st[f])
+    vals = vals.to(device)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(vals, op=dist.ReduceOp.SUM)
+    vals = vals.cpu()
+    return [dict(zip(STAT_FIELDS, [int(v) for v in vals[q]])) for q in range(n_queries)]
+
+
+def gather_floats(x, dst=0, device="cpu"):
+    """One float per rank on rank <dst> (per-rank busy times of a leg); None elsewhere."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [float(x)]
+    t = torch.tensor([float(x)], dtype=torch.float64, device=device)
+    if dist.get_rank() == dst:
+        outs = [torch.zeros(1, dtype=torch.float64, device=device) for _ in range(dist.get_world_size())]
+        dist.gather(t, outs, dst=dst)
+        return [float(o.item()) for o in outs]
+    dist.gather(t, None, dst=dst)
+    return None

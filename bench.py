@@ -118,6 +118,58 @@ def cpu_baseline(flat, length, n_windows, budget_s=30.0):
     return base, tot, covered
 
 
+def fbits(x):
+    return int(np.float32(x).view(np.uint32))
+
+
+def fs_cpu_sample(flat, length, k):
+    """Before any GPU initialisation: the oracle's --fs pipeline (generic_*_frameshift.c restated, scalar C) through domain
+    definition over the FIRST <k> windows of the fs leg's block -- the DNA windows, their 3-codon Forward scores and every domain
+    that the GPU's strict pass must reproduce on the same windows (fs.parity_check)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as ol
+    model = ol.Model(MODEL, 0)
+    t0 = time.perf_counter()
+    pli, ofw, per_w, odm, per_d, oclust = model.run_pipeline_fsdom([flat[i * length:(i + 1) * length] for i in range(k)])
+    wins = sorted((w, int(o.strand), int(o.n), int(o.length), fbits(o.fwdsc), int(o.branch)) for w, (a, b) in enumerate(per_w) for o in ofw[a:b])
+    doms = sorted((w, int(o.ienv), int(o.jenv), int(o.iali), int(o.jali), int(o.ihmm), int(o.jhmm), int(o.n_shifted_codons), fbits(o.envsc), round(float(o.bitscore), 1))
+                  for w, (a, b) in enumerate(per_d) for o in odm[a:b])
+    return {"windows": k, "fs_windows": wins, "domains": doms, "clustered": int(oclust), "cpu_seconds": time.perf_counter() - t0,
+            "counters": {f: int(getattr(pli, f)) for f in COUNTERS}}
+
+
+def fs_parity_check(ba, ctx, pipe, om3, om5, flat, length, cpu):
+    """The GPU's strict --fs pass over the windows the oracle scored: DNA windows with their Forward scores bitwise; the domains of
+    the frameshift branch with exact coordinates and bitwise envelope scores; the standard branch's (fp32 odds-ratio arithmetic,
+    its clustered regions sampled from matrices that agree to 1e-4) by coordinates with the unmatched ones counted."""
+    k = cpu["windows"]
+    blk = ba.SeqBlock(ctx, flat[:k * length], np.arange(k + 1, dtype=np.int64) * length)
+    stats, fw, dm, nclust = pipe.run_frameshift_domains(om3, om5, blk, arrays=True)
+    gw = sorted((int(r["window"]), int(r["strand"]), int(r["n"]), int(r["length"]), fbits(r["fwdsc"]), int(r["branch"])) for r in fw)
+    branch_of = {(int(r["window"]), i): int(r["branch"]) for i, r in enumerate(fw)}
+    g_all = [(int(r["window"]), int(r["ienv"]), int(r["jenv"]), int(r["iali"]), int(r["jali"]), int(r["ihmm"]), int(r["jhmm"]), int(r["n_shifted_codons"]),
+              fbits(r["envsc"]), round(float(r["bitscore"]), 1), int(fw[int(r["fs_window"])]["branch"])) for r in dm]
+    g_fs = sorted(t[:10] for t in g_all if t[10] == 1)
+    g_std = sorted(t[:8] for t in g_all if t[10] != 1)
+    c_all = list(cpu["domains"])
+    c_left = list(c_all)
+    fs_missing = 0
+    for t in g_fs:                                                     # exact key + bitwise envsc (bitscore to the printed decimal rides along)
+        m = [c for c in c_left if c[:9] == t[:9]]
+        if m:
+            c_left.remove(m[0])
+        else:
+            fs_missing += 1
+    c_std = sorted(c[:8] for c in c_left)
+    std_equal = len(set(g_std) & set(c_std))
+    return {"what": "the first %d windows through the oracle's --fs pipeline (scalar restatement of generic_*_frameshift.c) before GPU init, and through the GPU's strict pass" % k,
+            "windows": k, "fs_windows": len(gw), "fs_windows_identical_incl_forward_score_bits_and_branch": gw == cpu["fs_windows"],
+            "fs_branch_domains": len(g_fs), "fs_branch_domains_exact_incl_envsc_bits": fs_missing == 0 and len(g_fs) + len(g_std) == len(c_all),
+            "std_branch_domains": len(g_std), "std_branch_domains_with_identical_coordinates": std_equal,
+            "clustered_regions": {"gpu": int(nclust), "cpu": cpu["clustered"]},
+            "counters_equal": all(int(getattr(stats, f)) == cpu["counters"][f] for f in COUNTERS), "cpu_seconds": cpu["cpu_seconds"]}
+
+
 # ------------------------------------------------------------------------------------------------ configs[3] / configs[4], one-GPU slices
 
 DB = os.path.join(ROOT, "tests", "golden", "tRNA-proteins.bhmm")      # the reference's tutorial/tRNA-proteins.bhmm: 12 query models, M = 56..459
@@ -144,6 +196,23 @@ def c5_genome(ba, synth, n_nt):
     return hmm, g, planted
 
 
+def c5_sample_indices(wins, planted, k):
+    """The first <k> genome windows that hold a planted gene entirely (the same choice on the CPU and the GPU side)."""
+    idx = []
+    for i, (_, s0, n, c) in enumerate(wins):
+        if any(p >= s0 + c and p + ln <= s0 + n for _, p, ln in planted):
+            idx.append(i)
+            if len(idx) == k:
+                break
+    return idx
+
+
+def hit_key(w, d):
+    """A hit as the tables print it: window, envelope / alignment / model coordinates, the bit score to its printed decimal."""
+    f = (lambda k: d[k]) if isinstance(d, np.void) else (lambda k: getattr(d, k))       # a numpy record (arrays=True) or a ctypes struct
+    return (int(w),) + tuple(int(f(k)) for k in ("ienv", "jenv", "iali", "jali", "ihmm", "jhmm")) + (round(float(f("bitscore")), 1),)
+
+
 def c45_cpu_samples(args):
     """Before any GPU initialisation: the oracle's pipeline on the SSE2 striped kernels over the FIRST windows of both genomes --
     the counters bench's GPU legs must reproduce on the same windows (parity_check of c4 and c5)."""
@@ -154,7 +223,7 @@ def c45_cpu_samples(args):
     from bath_amd import dist as bdist, synth
     L_ = ol.lib()
     L_.bo_pipeline_use_sse(1)
-    out = {"c4": [], "c5": None}
+    out = {"c4": [], "c4_hits": [], "c5": None}
     hmms, g, _ = c4_genome(ba, synth, int(args.c4_mb * 1e6))
     t0 = time.perf_counter()
     for q, hmm in enumerate(hmms):
@@ -162,13 +231,17 @@ def c45_cpu_samples(args):
         model = ol.Model(DB, q)
         pli, odm, per_d, oskip = model.run_pipeline_hits([g[s_:s_ + n] for _, s_, n, _ in wins], contexts=[c for _, _, _, c in wins])
         out["c4"].append({f: int(getattr(pli, f)) for f in COUNTERS})
+        out["c4_hits"].append(sorted(hit_key(w, o) for w, (a, b) in enumerate(per_d) for o in odm[a:b]))
     out["c4_seconds"] = time.perf_counter() - t0
-    hmm5, g5, _ = c5_genome(ba, synth, int(args.c5_mb * 1e6))
-    wins = bdist.split_targets([len(g5)], hmm5.max_length)[:1]
+    hmm5, g5, planted5 = c5_genome(ba, synth, int(args.c5_mb * 1e6))
+    wins = bdist.split_targets([len(g5)], hmm5.max_length)
+    wins = [wins[i] for i in c5_sample_indices(wins, planted5, args.c5_sample_windows)]
     t0 = time.perf_counter()
     model = ol.Model(c5_model_path(), 0)
-    pli, ores, per_seq, ofw, per_seq_w = model.run_pipeline_fs([g5[s_:s_ + n] for _, s_, n, _ in wins])
+    pli, ofw, per_w, odm, per_d, oclust = model.run_pipeline_fsdom([g5[s_:s_ + n] for _, s_, n, _ in wins], contexts=[c for _, _, _, c in wins])
     out["c5"] = {f: int(getattr(pli, f)) for f in COUNTERS}
+    out["c5_windows"] = sorted((w, int(o.strand), int(o.n), int(o.length), fbits(o.fwdsc), int(o.branch)) for w, (a, b) in enumerate(per_w) for o in ofw[a:b])
+    out["c5_hits"] = sorted(hit_key(w, o) + (fbits(o.envsc),) for w, (a, b) in enumerate(per_d) for o in odm[a:b])
     out["c5_seconds"] = time.perf_counter() - t0
     L_.bo_pipeline_use_sse(0)
     return out
@@ -180,7 +253,7 @@ def c4_leg(ba, synth, bdist, ctx, args, cpu):
     plain pipeline through domain definition to hits."""
     hmms, g, planted = c4_genome(ba, synth, int(args.c4_mb * 1e6))
     per_model, tot_ms, tot_res, tot_cells, tot_hits = [], 0.0, 0, 0, 0
-    parity = []
+    parity, hits_cmp = [], []
     for q, hmm in enumerate(hmms):
         om = ba.OProfile(ctx, ba.Profile(hmm))
         pipe = ba.Pipeline(ctx, om, fs_pipe=False, ncbi_table=hmm.ct)
@@ -190,8 +263,10 @@ def c4_leg(ba, synth, bdist, ctx, args, cpu):
         if cpu is not None:                                     # the windows the CPU leg scored, counter by counter
             k = min(args.c45_sample_windows, len(wins))
             sub = ba.SeqBlock(ctx, seqs[:k]); sub.set_context(ctxs[:k])
-            st, _, _ = pipe.run_hits(sub)
+            st, sdm, _ = pipe.run_hits(sub)
             parity.append(all(int(getattr(st, f)) == cpu["c4"][q][f] for f in COUNTERS))
+            got = sorted(hit_key(d.window, d) for d in sdm)
+            hits_cmp.append({"gpu": len(got), "cpu": len(cpu["c4_hits"][q]), "identical": len(set(got) & set(cpu["c4_hits"][q]))})
         block = ba.SeqBlock(ctx, seqs); block.set_context(ctxs)
         pipe.run_hits(block)
         steps = 2
@@ -256,7 +331,10 @@ def c4_leg(ba, synth, bdist, ctx, args, cpu):
                                    "hits_equal_to_serial_loop": conc_hits == [m["hits"] for m in per_model],
                                    "what": "the 12 queries dealt out to %d worker contexts (threads), longest models first, one after the other within a worker" % nw},
             "parity_check": None if cpu is None else {"what": "the 10 pipeline counters of the first %d windows of every model against the SSE2 striped CPU pipeline" % args.c45_sample_windows,
-                                                      "all_equal": all(parity), "per_model": parity, "cpu_seconds": cpu["c4_seconds"]}}
+                                                      "all_equal": all(parity), "per_model": parity, "cpu_seconds": cpu["c4_seconds"],
+                                                      "hits": {"what": "the hits of those windows (window, envelope / alignment / model coordinates, bit score to its printed decimal): GPU vs CPU pipeline",
+                                                               "gpu": sum(h["gpu"] for h in hits_cmp), "cpu": sum(h["cpu"] for h in hits_cmp),
+                                                               "identical": sum(h["identical"] for h in hits_cmp), "per_model": hits_cmp}}}
 
 
 def c5_leg(ba, synth, bdist, ctx, args, cpu):
@@ -271,9 +349,19 @@ def c5_leg(ba, synth, bdist, ctx, args, cpu):
     ctxs = [c for _, _, _, c in wins]
     pipe = ba.Pipeline(ctx, om, fs_pipe=True, ncbi_table=hmm.ct)
     parity = None
+    c5_hits = None
     if cpu is not None:
-        st, _, fw0 = pipe.run_frameshift(om3, ba.SeqBlock(ctx, seqs[:1]))
+        sidx = c5_sample_indices(wins, planted, args.c5_sample_windows)
+        k = len(sidx)
+        sub = ba.SeqBlock(ctx, [seqs[i] for i in sidx]); sub.set_context([ctxs[i] for i in sidx])
+        st, fw0, dm0, _ = pipe.run_frameshift_domains(om3, om5, sub, arrays=True)
         parity = {f: (int(getattr(st, f)), cpu["c5"][f]) for f in COUNTERS}
+        gw = sorted((int(r["window"]), int(r["strand"]), int(r["n"]), int(r["length"]), fbits(r["fwdsc"]), int(r["branch"])) for r in fw0)
+        gh = sorted(hit_key(int(r["window"]), r) + (fbits(r["envsc"]),) for r in dm0)
+        c5_hits = {"what": "DNA windows (coordinates, 3-codon Forward score bitwise, branch) and hits (coordinates, bit score to its printed decimal, envelope score bitwise) of the "
+                           "first %d genome windows that hold a planted gene: GPU strict pass vs the oracle's --fs pipeline" % k,
+                   "fs_windows": {"gpu": len(gw), "cpu": len(cpu["c5_windows"]), "identical": gw == cpu["c5_windows"]},
+                   "hits": {"gpu": len(gh), "cpu": len(cpu["c5_hits"]), "identical": len(set(gh) & set(cpu["c5_hits"]))}}
     block = ba.SeqBlock(ctx, seqs); block.set_context(ctxs)
     pipe.run_frameshift_domains(om3, om5, block, arrays=True)
     steps = 2
@@ -310,9 +398,180 @@ def c5_leg(ba, synth, bdist, ctx, args, cpu):
             **summary, "kernels_ms": {k: round(v["ms"], 3) for k, v in sorted(kt.items(), key=lambda kv: -kv[1]["ms"])},
             "cascade": {"ms": cms, "residues_per_s": cst.nres / (cms * 1e-3), "gcells_per_s": (cst.cells_msv + cst.cells_vit + cst.cells_fwd) / (cms * 1e-3) / 1e9,
                         "stage_ms": stage, "ssv_tcells_per_s": cst.cells_msv / (ssv_ms * 1e-3) / 1e12, "ssv_frac_of_packed_issue_peak": cst.cells_msv / (ssv_ms * 1e-3) / 1e12 / 44.4},
-            "parity_check": None if parity is None else {"what": "the 10 pipeline counters of the first window (262144 nt, --fs thresholds) against the SSE2 striped CPU pipeline",
+            "parity_check": None if parity is None else {"counters": "the 10 pipeline counters of the first %d windows that hold a planted gene (262144 nt each, --fs thresholds) against the CPU pipeline (SSE2 striped cascade + the oracle's frameshift stage)" % args.c5_sample_windows,
                                                          "all_equal": all(a == b for a, b in parity.values()),
-                                                         "mismatches": {k: {"gpu": a, "cpu": b} for k, (a, b) in parity.items() if a != b}, "cpu_seconds": cpu["c5_seconds"]}}
+                                                         "mismatches": {k: {"gpu": a, "cpu": b} for k, (a, b) in parity.items() if a != b}, "cpu_seconds": cpu["c5_seconds"], **(c5_hits or {})}}
+
+
+def finish_query(ba, hmm, domains, wins, nres, genome_len):
+    """Rank 0's end of a query (bathsearch.c:868-921): window coordinates -> target coordinates, E-values with the whole search's
+    residue count, duplicates of the window overlaps removed, sorted, thresholded; returns (reported hits, --tblout text)."""
+    for d in domains:
+        off = wins[d.window][1]
+        d.ienv += off; d.jenv += off; d.iali += off; d.jali += off
+        d.window = 0
+    th = ba.TopHits()
+    th.add(domains, ["genome"], [genome_len])
+    th.finalize(int(nres), hmm.max_length)
+    return sum(1 for d, _, fl in th.hits() if d.reported), th.tblout(hmm.name, hmm.acc, hmm.M, show_cigar=True, show_header=False)
+
+
+def c4_leg_ranks(ba, synth, bdist, ctx, args, rank, world, dev, on_gpu, sync, total_mb):
+    """BASELINE configs[3] over N ranks: the 12-model database is broadcast once; (query, window group) pairs are dealt to the
+    ranks (dist.query_items / dist.deal); per query the hits and the counters are gathered on rank 0, which finishes every query
+    like the single-rank search (dist.gather_query_domains, finish_query).  Strong scaling of ONE job: <total_mb> Mb x 12 queries."""
+    import hashlib
+    blob = open(DB, "rb").read() if rank == 0 else b""
+    blob = bdist.broadcast_bytes(blob, 0, dev)                          # the whole database, once (1 MB over xGMI)
+    tmp = "/tmp/bath_bench_db_%d.bhmm" % os.getpid()
+    with open(tmp, "wb") as fh:
+        fh.write(blob)
+    hmms = [ba.HMM(tmp, q) for q in range(ba.HMM.count(tmp))]
+    os.unlink(tmp)
+    n_nt = int(total_mb * 1e6)
+    all_wins = [bdist.split_targets([n_nt], h.max_length) for h in hmms]
+    items = bdist.query_items([len(w) for w in all_wins], world)
+    owner = bdist.deal([sum(n for _, _, n, _ in all_wins[q][lo:hi]) * (hmms[q].M + 150.0) for q, lo, hi in items], world)
+    mine = [it for it, o in zip(items, owner) if o == rank]
+    if on_gpu:
+        g, planted = synth.genome(n_nt, seed=4300, hmms=hmms, genes_per_model=max(4, n_nt // 400_000))
+        jobs = []
+        for q, lo, hi in mine:
+            om = ba.OProfile(ctx, ba.Profile(hmms[q]))
+            pipe = ba.Pipeline(ctx, om, fs_pipe=False, ncbi_table=hmms[q].ct)
+            blk = ba.SeqBlock(ctx, [g[s_:s_ + n] for _, s_, n, _ in all_wins[q][lo:hi]]); blk.set_context([c for _, _, _, c in all_wins[q][lo:hi]])
+            pipe.run_hits(blk)
+            jobs.append((q, lo, om, pipe, blk))
+
+    def one_pass(my_jobs):
+        by_q, st_q = {}, {}
+        for q, lo, _, pipe, blk in my_jobs:
+            st, dm, _ = pipe.run_hits(blk)
+            for d in dm:
+                d.window += lo
+            by_q.setdefault(q, []).extend(dm)
+            acc = st_q.setdefault(q, dict.fromkeys(bdist.STAT_FIELDS, 0))
+            for f in bdist.STAT_FIELDS:
+                acc[f] += int(getattr(st, f))
+        return by_q, st_q
+
+    steps = 2
+    sync()
+    t0 = time.perf_counter()
+    busy = 0.0
+    for _ in range(steps):
+        tb = time.perf_counter()
+        if on_gpu:
+            by_q, st_q = one_pass(jobs)
+            ctx.synchronize()
+        else:                                                           # --plumbing-only: fabricated hits, the deal and the collectives are what runs
+            by_q, st_q = {}, {}
+            for q, lo, hi in mine:
+                d = ba.FsDomain(); d.window = lo; d.reported = 1; d.iali = 10 + q; d.jali = 100 + q; d.ienv = 10 + q; d.jenv = 100 + q
+                d.lnP = -50.0 - q; d.bitscore = 60.0 + q; d.cigar = "%dM" % (30 + q)
+                by_q.setdefault(q, []).append(d)
+                acc = st_q.setdefault(q, dict.fromkeys(bdist.STAT_FIELDS, 0))
+                acc["nres"] += 2 * sum(n - c for _, _, n, c in all_wins[q][lo:hi])
+        busy += time.perf_counter() - tb
+        gathered = bdist.gather_query_domains(by_q, 0, dev)
+        merged = bdist.reduce_query_stats(st_q, len(hmms), dev)
+        tables = []
+        if rank == 0:
+            for q, hmm in enumerate(hmms):                             # every query finished on rank 0, inside the timed region
+                tables.append(finish_query(ba, hmm, gathered.get(q, []), all_wins[q], merged[q]["nres"], n_nt))
+    sync()
+    dt = bdist.max_over_ranks((time.perf_counter() - t0) / steps, dev)
+    busy_all = bdist.gather_floats(busy / steps * 1e3, 0, dev)
+    if rank != 0:
+        return None
+    out = {"workload": "tRNA-proteins.bhmm (12 query models, broadcast once) vs ONE %.0f Mb synthetic genome: (query, window group) pairs dealt to %d rank(s), "
+                       "hits and counters gathered per query on rank 0 and every query finished there (strong scaling)" % (total_mb, world),
+           "n_gpus": world, "scaling": "strong", "items": len(items), "items_per_rank": [owner.count(r) for r in range(world)],
+           "ms_per_database_pass": dt * 1e3, "rank_busy_ms": busy_all,
+           "residues_per_s": sum(m["nres"] for m in merged) / dt, "hits": int(sum(t[0] for t in tables)), "hits_per_query": [t[0] for t in tables],
+           "tables_sha1": hashlib.sha1("".join(t[1] for t in tables).encode()).hexdigest()[:16]}
+    if on_gpu and world > 1:
+        # the same job on rank 0 alone (outside the timed region): the N-rank search must print the single-rank search's tables
+        solo = []
+        for q, hmm in enumerate(hmms):
+            om = ba.OProfile(ctx, ba.Profile(hmm))
+            pipe = ba.Pipeline(ctx, om, fs_pipe=False, ncbi_table=hmm.ct)
+            blk = ba.SeqBlock(ctx, [g[s_:s_ + n] for _, s_, n, _ in all_wins[q]]); blk.set_context([c for _, _, _, c in all_wins[q]])
+            st, dm, _ = pipe.run_hits(blk)
+            solo.append(finish_query(ba, hmm, dm, all_wins[q], st.nres, n_nt))
+        out["tables_equal_to_single_rank_search"] = [a[1] for a in solo] == [b[1] for b in tables]
+    return out
+
+
+def c5_leg_ranks(ba, synth, bdist, ctx, args, rank, world, dev, on_gpu, sync, total_mb):
+    """BASELINE configs[4] over N ranks: the windows of ONE <total_mb> Mb genome in contiguous shards (what the reference's block
+    queue does), the whole --fs path per rank, counters reduced and domains gathered on rank 0 (strong scaling).  The pass lasts
+    at least as long as the longest DNA window's row chains whatever N is: c5.size_sweep puts that floor on record."""
+    n_nt = int(total_mb * 1e6)
+    hmm = ba.HMM(c5_model_path())
+    wins = bdist.split_targets([n_nt], hmm.max_length)
+    lo, hi = bdist.shard_range(len(wins), rank, world)
+    if on_gpu:
+        g, planted = synth.genome(n_nt, seed=4400, hmms=[hmm], genes_per_model=max(8, n_nt // 400_000), frameshift=True)
+        om = ba.OProfile(ctx, ba.Profile(hmm))
+        om3 = ba.FSOProfile(ctx, ba.FSProfile(hmm, 3, ncbi_table=hmm.ct))
+        om5 = ba.FSOProfile(ctx, ba.FSProfile(hmm, 5, ncbi_table=hmm.ct))
+        pipe = ba.Pipeline(ctx, om, fs_pipe=True, ncbi_table=hmm.ct)
+        blk = ba.SeqBlock(ctx, [g[s_:s_ + n] for _, s_, n, _ in wins[lo:hi]]); blk.set_context([c for _, _, _, c in wins[lo:hi]])
+        del g
+        pipe.run_frameshift_domains(om3, om5, blk)
+    steps = 2
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        if on_gpu:
+            stats, fw, dm, _ = pipe.run_frameshift_domains(om3, om5, blk)
+        else:
+            stats = ba.PipelineStats(); stats.nres = 2 * sum(n - c for _, _, n, c in wins[lo:hi])
+            dm = []
+            for w in range(min(hi - lo, 2)):
+                d = ba.FsDomain(); d.window = w; d.reported = 1; d.cigar = "%dM" % (w + 1)
+                dm.append(d)
+        gathered = bdist.gather_domains(dm, lo, 0, dev)
+        merged = bdist.reduce_stats(stats, dev)
+    sync()
+    dt = bdist.max_over_ranks((time.perf_counter() - t0) / steps, dev)
+    if rank != 0:
+        return None
+    return {"workload": "synthetic %d-node model --fs vs ONE %.0f Mb synthetic genome, %d windows of %d nt with context in contiguous shards over %d rank(s); "
+                        "domains gathered on rank 0 inside the timed region (strong scaling)" % (C5_M, total_mb, len(wins), bdist.BLOCK_LENGTH, world),
+            "n_gpus": world, "scaling": "strong", "ms_per_pass": dt * 1e3, "residues_per_s": merged["nres"] / dt, "mode": "strict (the library's default)",
+            "domains_gathered": len(gathered), "reported": int(sum(d.reported for d in gathered)),
+            "windows_of_gathered_domains_are_global": bool(all(0 <= d.window < len(wins) for d in gathered))}
+
+
+def c5_size_sweep(ba, synth, bdist, ctx, sizes_mb):
+    """configs[4] on ONE GPU at growing genome sizes: the pass is bound by the row chains of its longest DNA windows (one or two
+    chain blocks per CU), so its time grows far slower than the genome until the windows outnumber the chip's chain slots --
+    the floor that window sharding over N GPUs cannot get under."""
+    hmm = ba.HMM(c5_model_path())
+    om = ba.OProfile(ctx, ba.Profile(hmm))
+    om3 = ba.FSOProfile(ctx, ba.FSProfile(hmm, 3, ncbi_table=hmm.ct))
+    om5 = ba.FSOProfile(ctx, ba.FSProfile(hmm, 5, ncbi_table=hmm.ct))
+    pipe = ba.Pipeline(ctx, om, fs_pipe=True, ncbi_table=hmm.ct)
+    out = []
+    for mb in sizes_mb:
+        n_nt = int(mb * 1e6)
+        g, planted = synth.genome(n_nt, seed=4400, hmms=[hmm], genes_per_model=max(8, n_nt // 400_000), frameshift=True)
+        wins = bdist.split_targets([n_nt], hmm.max_length)
+        blk = ba.SeqBlock(ctx, [g[s_:s_ + n] for _, s_, n, _ in wins]); blk.set_context([c for _, _, _, c in wins])
+        del g
+        pipe.run_frameshift_domains(om3, om5, blk, arrays=True)
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        stats, fw, dm, _ = pipe.run_frameshift_domains(om3, om5, blk, arrays=True)
+        dt = time.perf_counter() - t0
+        kt = pipe.kernel_times()
+        out.append({"genome_mb": mb, "ms_per_pass": dt * 1e3, "residues_per_s": stats.nres / dt, "fs_windows": int(len(fw)),
+                    "longest_fs_window_nt": int(fw["length"].max()) if len(fw) else 0, "domains": int(len(dm)), "planted": len(planted),
+                    "chain_kernels_ms": {k: round(kt[k][0], 1) for k in ("fs3_fwd_kernel", "fs_bwd_kernel<3>") if k in kt}})
+        del blk
+    return out
 
 
 # ------------------------------------------------------------------------------------------------ launcher
@@ -350,12 +609,17 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fs", action="store_true", help="skip the configs[2] (--fs) leg")
     ap.add_argument("--fs-windows", type=int, default=1_000_000)
+    ap.add_argument("--fs-parity-windows", type=int, default=20000, help="windows of the fs block the oracle's --fs pipeline scores before GPU init (fs.parity_check)")
     ap.add_argument("--no-streamed", action="store_true", help="skip the host-fed (PCIe-inclusive) leg")
     ap.add_argument("--no-concurrent", action="store_true", help="skip the leg with three worker contexts running blocks concurrently")
     ap.add_argument("--no-c45", action="store_true", help="skip the configs[3] / configs[4] legs (multi-HMM database; 1024-node model with --fs)")
     ap.add_argument("--c4-mb", type=float, default=12.5, help="genome of the configs[3] leg, Mb (100 Mb over 8 GPUs)")
     ap.add_argument("--c5-mb", type=float, default=125.0, help="genome of the configs[4] leg, Mb (1 Gb over 8 GPUs)")
-    ap.add_argument("--c45-sample-windows", type=int, default=2, help="windows per model the CPU pipeline scores for the c4 parity check")
+    ap.add_argument("--c45-sample-windows", type=int, default=6, help="windows per model the CPU pipeline scores for the c4 parity check")
+    ap.add_argument("--c5-sample-windows", type=int, default=2, help="genome windows the oracle's --fs pipeline scores for the c5 parity check")
+    ap.add_argument("--c4-total-mb", type=float, default=100.0, help="genome of configs[3] as ONE job over the ranks (strong scaling; at N=1: c4.full_job)")
+    ap.add_argument("--c5-total-mb", type=float, default=1000.0, help="genome of configs[4] as ONE job over the ranks (strong scaling, N>1)")
+    ap.add_argument("--c5-sweep", type=str, default="125,250,500,1000", help="N=1: genome sizes (Mb) of c5.size_sweep; empty to skip")
     ap.add_argument("--no-one-part", action="store_true",
                     help="skip the whole-block-as-one-part passes behind roofline.valu (profiling: every ssv_orf_kernel launch is then a timed-step launch)")
     ap.add_argument("--plumbing-only", action="store_true",
@@ -383,7 +647,7 @@ def main():
     # ---- before any GPU initialisation: the model, the synthetic block, the CPU baseline (forks workers)
     hmm0 = ba.HMM(MODEL)
     flat = offsets = None
-    base = cpu_counters = c45_cpu = None
+    base = cpu_counters = c45_cpu = fs_data = fs_cpu = None
     cpu_covered = 0
     if not args.plumbing_only:
         if args.scaling == "strong":                      # one block for the whole job: every rank generates it and keeps its shard
@@ -397,6 +661,10 @@ def main():
             base, cpu_counters, cpu_covered = cpu_baseline(flat, args.length, n_mine)
             if not args.no_c45:
                 c45_cpu = c45_cpu_samples(args)
+        if rank == 0 and world == 1 and not args.no_fs:
+            fs_data = synth.dna_windows(args.fs_windows, args.length, seed=4242, hmm=hmm0, frameshift=True)
+            if not args.no_cpu_baseline and args.fs_parity_windows > 0:
+                fs_cpu = fs_cpu_sample(fs_data[0], args.length, min(args.fs_parity_windows, args.fs_windows))
 
     import torch
     import torch.distributed as dist
@@ -559,10 +827,18 @@ def main():
         if world == 1 and not args.no_concurrent:
             out["concurrent_blocks"] = concurrent_leg(ba, hmm, flat, offsets, args, stats, ms_step)
         if not args.no_fs and world == 1:
-            out["fs"] = fs_leg(ba, synth, ctx, hmm, om, args)
+            out["fs"] = fs_leg(ba, synth, ctx, hmm, om, args, fs_data, fs_cpu)
         if not args.no_c45 and world == 1:
             out["c4"] = c4_leg(ba, synth, bdist, ctx, args, c45_cpu)
+            out["c4"]["full_job"] = c4_leg_ranks(ba, synth, bdist, ctx, args, 0, 1, dev, True, sync, args.c4_total_mb)     # the N = 1 point of the N-rank leg
             out["c5"] = c5_leg(ba, synth, bdist, ctx, args, c45_cpu)
+            if args.c5_sweep:
+                out["c5"]["size_sweep"] = c5_size_sweep(ba, synth, bdist, ctx, [float(x) for x in args.c5_sweep.split(",")])
+    if world > 1 and not args.no_c45:                       # configs[3] / configs[4] as one job over the ranks; rank 0 reports
+        c4_multi = c4_leg_ranks(ba, synth, bdist, ctx if on_gpu else None, args, rank, world, dev, on_gpu, sync, args.c4_total_mb)
+        c5_multi = c5_leg_ranks(ba, synth, bdist, ctx if on_gpu else None, args, rank, world, dev, on_gpu, sync, args.c5_total_mb)
+        if rank == 0:
+            out["c4"], out["c5"] = c4_multi, c5_multi
     if world > 1 and not args.no_fs:                        # every rank takes part; rank 0 reports
         fs_multi = fs_leg_ranks(ba, synth, bdist, dist, ctx if on_gpu else None, hmm, om if on_gpu else None, args, rank, world, dev, on_gpu, sync)
         if rank == 0:
@@ -698,13 +974,57 @@ def fs_leg_ranks(ba, synth, bdist, dist, ctx, hmm, om, args, rank, world, dev, o
             "mode": "strict (the library's default)"}
 
 
-def fs_leg(ba, synth, ctx, hmm, om, args):
+def fs_concurrent_leg(ba, hmm, flat, offsets, strict_keys, one_ms, workers=2, passes=4):
+    """The --fs pass with <workers> worker contexts on one GPU, each owning a block and running whole strict passes on it at the same
+    time (the reference's worker threads each own a block, bathsearch.c:1119-1290): one worker's cascade / envelope / host stages
+    beside another's chain kernels.  Every worker's domains must be those of the one-worker pass."""
+    import threading
+    objs = []
+    for _ in range(workers):
+        c = ba.Context(0)
+        o = ba.OProfile(c, ba.Profile(hmm))
+        o3 = ba.FSOProfile(c, ba.FSProfile(hmm, 3, ncbi_table=hmm.ct))
+        o5 = ba.FSOProfile(c, ba.FSProfile(hmm, 5, ncbi_table=hmm.ct))
+        d = ba.SeqBlock(c, flat, offsets)
+        p = ba.Pipeline(c, o, fs_pipe=True, ncbi_table=hmm.ct)
+        p.run_frameshift_domains(o3, o5, d, arrays=True)
+        objs.append((c, o, o3, o5, d, p))
+    for o in objs:
+        o[0].synchronize()
+    got = [None] * workers
+    keys = ("window", "strand", "ienv", "jenv", "iali", "jali", "ihmm", "jhmm", "n_shifted_codons")
+
+    def work(w):
+        c, _, o3, o5, d, p = objs[w]
+        for _ in range(passes):
+            _, _, dm, _ = p.run_frameshift_domains(o3, o5, d, arrays=True)
+        c.synchronize()
+        got[w] = {tuple(int(r[k]) for k in keys) + (fbits(r["envsc"]),) for r in dm}
+
+    t0 = time.perf_counter()
+    th = [threading.Thread(target=work, args=(w,)) for w in range(workers)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    ms = (time.perf_counter() - t0) * 1e3 / (workers * passes)
+    same = all(g == strict_keys for g in got)
+    for o in objs:
+        o[0].close()
+    return {"what": "%d worker contexts, each a block of the fs leg's size resident in HBM with its own pipeline object, whole strict --fs passes running "
+                    "concurrently" % workers,
+            "workers": workers, "blocks": workers * passes, "ms_per_block": ms, "vs_one_worker": one_ms / ms,
+            "domains_identical_to_one_worker_pass_incl_envsc_bits": bool(same)}
+
+
+def fs_leg(ba, synth, ctx, hmm, om, args, data=None, cpu=None):
     """BASELINE configs[2]: --fs on a block whose planted domains are frameshifted."""
-    flat, offsets, planted = synth.dna_windows(args.fs_windows, args.length, seed=4242, hmm=hmm, frameshift=True)
+    flat, offsets, planted = data if data is not None else synth.dna_windows(args.fs_windows, args.length, seed=4242, hmm=hmm, frameshift=True)
     dna = ba.SeqBlock(ctx, flat, offsets)
     om3 = ba.FSOProfile(ctx, ba.FSProfile(hmm, 3, ncbi_table=hmm.ct))
     om5 = ba.FSOProfile(ctx, ba.FSProfile(hmm, 5, ncbi_table=hmm.ct))
     pipe = ba.Pipeline(ctx, om, fs_pipe=True, ncbi_table=hmm.ct)
+    parity = fs_parity_check(ba, ctx, pipe, om3, om5, flat, args.length, cpu) if cpu is not None else None
     pipe.run_frameshift_domains(om3, om5, dna, arrays=True)
     steps = 3
     kt = {}
@@ -729,6 +1049,8 @@ def fs_leg(ba, synth, ctx, hmm, om, args):
                "shifted_codons_found": int(dm["n_shifted_codons"].sum())}
     keys = ("window", "strand", "ienv", "jenv", "iali", "jali", "ihmm", "jhmm", "n_shifted_codons")
     strict = {tuple(int(r[k]) for k in keys) for r in dm}
+    strict_bits = {tuple(int(r[k]) for k in keys) + (fbits(r["envsc"]),) for r in dm}
+    conc = None if args.no_concurrent else fs_concurrent_leg(ba, hmm, flat, offsets, strict_bits, dt * 1e3)
     # the same pass in the fast mode (sums along the model by wavefront scans: scores within O(1e-3) nats, outside the 1e-4 contract near zero)
     ctx.set_fs_strict(False)
     pipe.run_frameshift_domains(om3, om5, dna, arrays=True)
@@ -744,9 +1066,10 @@ def fs_leg(ba, synth, ctx, hmm, om, args):
                     "and in-frame stops (0.002), both strands: cascade (F4) -> DNA windows -> 3-codon parsers -> regions -> 5-codon "
                     "Forward/Backward/decoding/optimal accuracy/null2 -> traceback -> hits" % (hmm.M, args.fs_windows, args.length),
         "ms_per_pass": dt * 1e3, "residues_per_s": stats.nres / dt, "steps": steps,
+        "parity_check": parity, "concurrent_blocks": conc,
         **summary,
         "kernels": kt,
-        "roofline": {"bound": "hbm", "kernels": env, "cells": env_cells, "bytes_per_cell": env_bytes / env_cells if env_cells else None,
+        "roofline": {"bound": "hbm", "binding_resource": "memory requests issued (a lane writes its own row: 64 pieces per store instruction)", "kernels": env, "cells": env_cells, "bytes_per_cell": env_bytes / env_cells if env_cells else None,
                      "ms": env_ms, "achieved": env_bytes / (env_ms * 1e-3) / 1e9 if env_ms > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": env_bytes / (env_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if env_ms > 0 else None,
                      "note": "5-codon envelope kernels: algorithmic matrix bytes (Forward writes 32, Backward writes 12 + 4 for the B terms, the fused decoding + "

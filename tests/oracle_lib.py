@@ -344,8 +344,9 @@ class Model:
             per_d.append((d0, ndm.value))
         return pli, [dm[i] for i in range(ndm.value)], per_d, nskip.value
 
-    def run_pipeline_fsdom(self, seqs):
+    def run_pipeline_fsdom(self, seqs, contexts=None):
         """run_pipeline_fs plus domain definition and hit scores for the windows that take the frameshift branch.
+        contexts[i]: ESL_SQ.C of window i (as in run_pipeline_hits).
 
         Returns (Pipeline counters, FsWindow records, per-sequence window ranges, FsDomain records, per-sequence domain
         ranges, number of multi-domain regions skipped)."""
@@ -357,8 +358,9 @@ class Model:
         fw = C.POINTER(FsWindow)(); nfw, fwalloc = C.c_int(0), C.c_int(0)
         dm = C.POINTER(FsDomain)(); ndm, dmalloc, nskip = C.c_int(0), C.c_int(0), C.c_int(0)
         per_w, per_d = [], []
-        for codes in seqs:
+        for i, codes in enumerate(seqs):
             d = dsq_from(codes)
+            pli.context = 0 if contexts is None else int(contexts[i])
             w0, d0 = nfw.value, ndm.value
             L_.bo_pipeline_window_fsdom(C.byref(pli), self.om, gm3, gm5, self.sd, C.byref(self.bg), u8(self.basic), u8(d), len(codes),
                                         C.byref(res), C.byref(nres), C.byref(alloc), C.byref(fw), C.byref(nfw), C.byref(fwalloc),

@@ -103,7 +103,8 @@ def test_bench_launcher_starts_the_ranks(scaling):
     import json
     import subprocess
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--plumbing-only", "--windows", "1001", "--fs-windows", "1001", "--scaling", scaling],
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--plumbing-only", "--windows", "1001", "--fs-windows", "1001", "--scaling", scaling,
+                        "--c4-total-mb", "3", "--c5-total-mb", "3"],
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
@@ -116,3 +117,81 @@ def test_bench_launcher_starts_the_ranks(scaling):
     # the --fs leg stays under --gpus N: one block sharded over the ranks, counters reduced, domains gathered on rank 0
     fs = out["fs"]
     assert fs["n_gpus"] == 2 and fs["scaling"] == "strong" and fs["domains_gathered"] == 6 and fs["windows_of_gathered_domains_are_global"]
+    # configs[3] under --gpus N: the 12-model database broadcast once, (query, window group) pairs dealt to the ranks, hits gathered
+    # per query on rank 0 and every query finished there; configs[4]: window shards, domains gathered
+    c4 = out["c4"]
+    assert c4["n_gpus"] == 2 and c4["items"] == 12 and c4["items_per_rank"] == [6, 6] and len(c4["rank_busy_ms"]) == 2
+    assert c4["hits_per_query"] == [1] * 12 and c4["hits"] == 12
+    c5 = out["c5"]
+    assert c5["n_gpus"] == 2 and c5["domains_gathered"] == 4 and c5["windows_of_gathered_domains_are_global"]
+
+
+def _query_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    import bath_amd as ba
+    from bath_amd import dist as bd
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    nwin = [5, 3, 8]                                            # three queries, their windows
+    items = bd.query_items(nwin, world, items_per_rank=3)       # G = 2 groups per query
+    owner = bd.deal([(hi - lo) * (q + 1.0) for q, lo, hi in items], world)
+    by_q, st_q = {}, {}
+    for (qq, lo, hi), o in zip(items, owner):
+        if o != rank:
+            continue
+        for w in range(lo, hi):                                 # one hit per window, tagged with its query and global window
+            d = ba.FsDomain()
+            d.window, d.iali, d.jali, d.reported = w, 100 * qq + w, 100 * qq + w + 50, 1
+            d.cigar = "%dM" % (10 * qq + w + 1)
+            by_q.setdefault(qq, []).append(d)
+        acc = st_q.setdefault(qq, dict.fromkeys(bd.STAT_FIELDS, 0))
+        acc["nres"] += 1000 * (hi - lo); acc["n_orfs"] += hi - lo
+    got = bd.gather_query_domains(by_q, 0)
+    merged = bd.reduce_query_stats(st_q, len(nwin))
+    busy = bd.gather_floats(1.0 + rank, 0)
+    q.put((rank, items, owner, None if got is None else {k: sorted((d.window, d.iali, d.cigar) for d in v) for k, v in got.items()},
+           [(m["nres"], m["n_orfs"]) for m in merged], busy))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_query_deal_and_gather():
+    """configs[3]'s exchange: (query, window group) items dealt identically on every rank, each rank's hits tagged by query arrive
+    on rank 0 in one gather, the per-query counters in one all-reduce."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_query_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    nwin = [5, 3, 8]
+    assert outs[0][1] == outs[1][1] and outs[0][2] == outs[1][2]                   # the same deal on both ranks
+    items, owner = outs[0][1], outs[0][2]
+    assert len(items) == 6 and set(owner) == {0, 1}
+    for qq, n in enumerate(nwin):                                                   # every query's windows covered exactly once
+        spans = sorted((lo, hi) for q_, lo, hi in items if q_ == qq)
+        assert spans[0][0] == 0 and spans[-1][1] == n and all(spans[i][1] == spans[i + 1][0] for i in range(len(spans) - 1))
+    got = outs[0][3]
+    assert outs[1][3] is None
+    for qq, n in enumerate(nwin):
+        assert got[qq] == [(w, 100 * qq + w, "%dM" % (10 * qq + w + 1)) for w in range(n)]
+    assert outs[0][4] == outs[1][4] == [(1000 * n, n) for n in nwin]               # p7_pipeline_Merge per query
+    assert outs[0][5] == [1.0, 2.0] and outs[1][5] is None
+
+
+def test_deal_is_balanced_and_deterministic():
+    from bath_amd.dist import deal, query_items
+    costs = [459, 247, 238, 192, 185, 136, 131, 121, 100, 90, 78, 56]
+    for world in (1, 2, 4, 8):
+        owner = deal(costs, world)
+        assert owner == deal(list(costs), world)
+        load = [sum(c for c, o in zip(costs, owner) if o == r) for r in range(world)]
+        assert max(load) <= sum(costs) / world + max(costs)                         # LPT bound
+        items = query_items([382] * 12, world)
+        assert len(items) >= min(2 * world, 12) and all(hi > lo for _, lo, hi in items)
