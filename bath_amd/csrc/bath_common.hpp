@@ -10,6 +10,7 @@
 #include <condition_variable>
 #include <functional>
 #include <mutex>
+#include <shared_mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -110,16 +111,29 @@ struct LanePool {
 };
 
 // Worker contexts that run whole --fs passes on one GPU (the reference's worker threads, bathsearch.c:1119-1290) meet at the strict
-// 3-codon parsers: a chain block (bath_fs_chain.hip) takes a CU's whole register file and most of its LDS, so two such launches
-// cannot share the chip -- the second one's blocks trickle in behind the first one's and both workers end up waiting in step.
-// BATH_HIP_FS_GATE=1 makes the turn-taking explicit: one chain stage at a time per device, the other worker's cascade / envelope /
-// host stages run beside it.  Off by default: measured with the bench's --fs block, 2 workers 51.5 ms per block without and 56.4
-// with the gate (the workers fall into step: both cascades, then both Forward parsers, ...), 3 workers 66.1 / 59.9.
-inline std::mutex &chain_gate_mutex(int device) { static std::mutex g[16]; return g[device & 15]; }
-inline bool chain_gate_enabled() { static const bool on = [] { const char *e = std::getenv("BATH_HIP_FS_GATE"); return e && e[0] == '1'; }(); return on; }
-struct ChainGate {
-  std::unique_lock<std::mutex> l;
-  explicit ChainGate(int device) { if (device >= 0 && chain_gate_enabled()) l = std::unique_lock<std::mutex>(chain_gate_mutex(device)); }
+// 3-codon parsers: a chain block (bath_fs_chain.hip) takes a CU's whole register file and most of its LDS, the Forward parser's
+// launch takes nearly every CU, and whatever holds CUs when it starts pushes part of its blocks into a second round (a launch
+// lasts as long as its longest window: a second round doubles it).  BATH_HIP_FS_GATE makes the turn-taking explicit, per device:
+//   0 (default)  no gate: the hardware queues interleave the workers' kernels
+//   1            one chain stage (Forward or Backward parser) at a time
+//   2            one Forward parser at a time; the Backward parser (half the CUs or fewer) runs beside anything
+//   3            the Forward parser alone on the chip: it waits for the other workers' cascades and envelope stages, and they for it
+// Measured with the bench's --fs block (tools/fs_workers_probe.py), ms per block: DESIGN.md 4.6c.
+inline std::shared_mutex &stage_gate_mutex(int device) { static std::shared_mutex g[16]; return g[device & 15]; }
+inline int stage_gate_mode() { static const int m = [] { const char *e = std::getenv("BATH_HIP_FS_GATE"); return e ? std::atoi(e) : 0; }(); return m; }
+struct StageGate {
+  enum Kind { kFwdChain, kBwdChain, kCascade, kEnvelopes, kNone };
+  std::unique_lock<std::shared_mutex> ex;
+  std::shared_lock<std::shared_mutex> sh;
+  StageGate(int device, Kind kind) {
+    const int m = stage_gate_mode();
+    if (device < 0 || m <= 0 || kind == kNone) return;
+    const bool exclusive = (kind == kFwdChain) || (kind == kBwdChain && m == 1);
+    const bool shared = m == 3 && (kind == kCascade || kind == kEnvelopes);
+    if (exclusive) ex = std::unique_lock<std::shared_mutex>(stage_gate_mutex(device));
+    else if (shared) sh = std::shared_lock<std::shared_mutex>(stage_gate_mutex(device));
+  }
+  void release() { if (ex.owns_lock()) ex.unlock(); if (sh.owns_lock()) sh.unlock(); }
 };
 
 struct StageTiming { const char *name; float ms; int64_t launches; };

@@ -1503,7 +1503,7 @@ static int fs3_parser(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, const bat
   FsJobs jq[1];
   if ((st = fs_schedule(ctx, dna, 1, jq)) != BATH_OK) return st;
   const bool chain = logsum_mode == BATH_LOGSUM_TABLE_SERIAL && fs_chain_enabled();
-  ChainGate gate(chain ? ctx->device : -1);                         // held until this stage's kernels have finished (the synchronize below)
+  StageGate gate(chain ? ctx->device : -1, backward ? StageGate::kBwdChain : StageGate::kFwdChain);   // held until this stage's kernels have finished (the synchronize below)
   const int sp = ctx->span_begin(backward ? "fs_bwd_kernel<3>" : "fs3_fwd_kernel", ctx->stream, (double)dna->total * om->M, (double)dna->total * ((xmx || keep) ? 21.0 : 1.0));
   if (logsum_mode == BATH_LOGSUM_TABLE_SERIAL && fs_chain_enabled()) {
     if (!backward) st = launch_fs3_fwd_chain(ctx, ctx->stream, om, dna, Cv, tE, tE, b_sc.as<float>(), d_x, b_off.as<int64_t>(), jq[0]);
@@ -1668,7 +1668,7 @@ int fs3_regions(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, const bath_hip_
   FsJobs jq[2];
   if ((st = fs_schedule(ctx, dna, 2, jq)) != BATH_OK) return st;
   const int mode = ctx->fs_strict ? BATH_LOGSUM_TABLE_SERIAL : BATH_LOGSUM_TABLE;
-  ChainGate gate((mode == BATH_LOGSUM_TABLE_SERIAL && fs_chain_enabled()) ? ctx->device : -1);   // held until the synchronize below
+  StageGate gate((mode == BATH_LOGSUM_TABLE_SERIAL && fs_chain_enabled()) ? ctx->device : -1, reuse ? StageGate::kBwdChain : StageGate::kFwdChain);   // held until the synchronize below
   if ((st = fs_fork(ctx)) != BATH_OK) return st;
   const double cells3 = (double)(xoff[(size_t)n] / 5) * om->M;                // rows x nodes; algorithmic HBM bytes: 1 B/nt in + 20 B/row out
   const double bytes3 = (double)(xoff[(size_t)n] / 5) * 21.0;
@@ -1802,6 +1802,7 @@ int bath::fs5_envelopes_ex(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, cons
   const double cells5 = (double)(foff[(size_t)n] / 8);                          // (L+1) x (M+1) cells of all envelopes
   FsJobs jq[4];
   if ((st = fs_schedule(ctx, dna, 4, jq)) != BATH_OK) return st;
+  StageGate gate(ctx->device, StageGate::kEnvelopes);                           // (BATH_HIP_FS_GATE=3: not while another worker's Forward parser has the chip)
   if ((st = fs_fork(ctx)) != BATH_OK) return st;                                // Backward on the side stream, concurrently with Forward
   BATH_FS_SWITCH(Cv, {
     BATH_FS_MODE(logsum_mode, {

@@ -655,6 +655,148 @@ __global__ __launch_bounds__(chain_threads(C)) void fs3_bwd_chain_kernel(SeqView
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
+// The same with HALF a wave per window (models of up to 32 x CH nodes), 32 windows per block: every lane of the chain wave
+// carries a row (the full-wave kernel's 16 windows fill half of it), so a batch of windows needs half as many CUs for the same
+// duration -- what matters when another worker's kernels are waiting for CUs (a chain block takes a CU's registers and most of
+// its LDS whatever it does with them).  Lanes own their nodes in descending order inside each half wave.
+// ---------------------------------------------------------------------------------------------------------------------------
+template <int CH>
+__global__ __launch_bounds__(1024) void fs3_bwd_chain_half_kernel(SeqView dna, FsDev p, const float *__restrict__ loop_tab, const float *__restrict__ move_tab,
+                                                                  float tEL, float tEM, float *__restrict__ sc, float *__restrict__ xmx, const int64_t *__restrict__ xmx_off, FsJobs jobs,
+                                                                  const int32_t *__restrict__ bstart, int nb) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  float *s_tbl = reinterpret_cast<float *>(lds);
+  float *s_tb = s_tbl + kLogsumTbl;
+  const int M = p.M;
+  constexpr int W = 32;                                         // window slots per block: two per wave
+  constexpr int stride = CH * 32 + 1;
+  float *s_stage = s_tb + (M + 2) * 8;                          // [W][2][stride]: ivx(i,k) in, D(i,k) out
+  float *s_e = s_stage + (size_t)W * 2 * stride;                // [W][2] E(i) of the pair's rows
+  fs_load_logsum_table(s_tbl, p.logsum);
+  for (int i = threadIdx.x; i < (M + 2) * 8; i += blockDim.x) s_tb[i] = p.tb[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int hl = lane & 31, win = wv * 2 + (lane >> 5);          // lane within its window's half wave; the window's slot in the block
+  const int ll = 31 - hl;                                       // nodes in descending order: the lane holding the next nodes is the physical lane below
+#define LS(a, b) flogsum<false>((a), (b), s_tbl)
+  auto shr1 = [&](float v) { const float r = wave_shr1(v, -INFINITY); return hl == 0 ? -INFINITY : r; };   // the neighbour move stays inside the half wave
+  for (int bb = blockIdx.x; bb < nb; bb += gridDim.x) {
+    const int64_t base = bstart[bb];
+    const int cnt = bstart[bb + 1] - bstart[bb];                // windows of this batch (<= 32)
+    const int64_t job = (win < cnt) ? (int64_t)jobs.order[base + win] : (int64_t)-1;
+    const int Lmax = dna.len[jobs.order[base]];
+    const int L = job >= 0 ? dna.len[job] : 0;
+    const bool live = job >= 0 && L >= 5;
+    const uint8_t *d = job >= 0 ? dna.data + dna.off[job] : dna.data;
+    const bool wave_idle = wv != 0 && wv * 2 >= cnt;            // neither of the wave's two slots holds a window: it only keeps the barriers
+    // ---- the chain wave's lanes: lane c serves slot (c & 1) of window (c >> 1)
+    const int cw = lane >> 1, cs = lane & 1;
+    const bool chain_lane = (wv == 0);
+    int64_t cjob = -1; int cL = 0; float *cxo = nullptr;
+    float ctNL = 0.f, ctNM = 0.f;
+    if (chain_lane && cw < cnt) {
+      cjob = jobs.order[base + cw]; cL = dna.len[cjob];
+      if (xmx) cxo = xmx + xmx_off[cjob];
+      ctNL = loop_tab[cL / 3]; ctNM = move_tab[cL / 3];
+    }
+    const bool clive = cjob >= 0 && cL >= 5;
+    float hN1 = -INFINITY, hN2 = -INFINITY, hJ1 = -INFINITY, hJ2 = -INFINITY, hC1 = -INFINITY, hC2 = -INFINITY;
+    float R1[CH], R2[CH], R3[CH], R4[CH], J1[CH], J2[CH], J3[CH];
+#pragma unroll
+    for (int c = 0; c < CH; c++) R1[c] = R2[c] = R3[c] = R4[c] = J1[c] = J2[c] = J3[c] = -INFINITY;
+    auto nuc = [&](int i) -> int { return (i >= 1 && i <= L) ? ((d[i - 1] < 4) ? (int)d[i - 1] : 338) : 338; };
+    const int npairs = Lmax / 2 + 1;
+    for (int q = 0; q < npairs; q++) {
+      if (wave_idle) { lds_barrier(); lds_barrier(); continue; }
+      const int iA = L - 2 * q, iB = iA - 1;
+      const bool mainA = 2 * q >= 5, mainB = 2 * q + 1 >= 5;
+      const int x0 = nuc(iA), x1 = nuc(iA + 1), x2 = nuc(iA + 2), x3 = nuc(iA + 3), x4 = nuc(iA + 4);
+      const float *qa2 = p.rsc + (size_t)imin(x2 * 84 + x1 * 21, 337) * p.pitch;
+      const float *qa3 = p.rsc + (size_t)imin(x3 * 84 + x2 * 21 + x1 * 5 + 1, 336) * p.pitch;
+      const float *qa4 = p.rsc + (size_t)imin(x4 * 84 + x3 * 21 + x2 * 5 + x1 + 2, 337) * p.pitch;
+      const float *qb2 = p.rsc + (size_t)imin(x1 * 84 + x0 * 21, 337) * p.pitch;
+      const float *qb3 = p.rsc + (size_t)imin(x2 * 84 + x1 * 21 + x0 * 5 + 1, 336) * p.pitch;
+      const float *qb4 = p.rsc + (size_t)imin(x3 * 84 + x2 * 21 + x1 * 5 + x0 + 2, 337) * p.pitch;
+      // ---- 1. ivx of both rows
+      float ivA[CH], ivB[CH];
+#pragma unroll
+      for (int c = 0; c < CH; c++) {
+        const int node = ll * CH + c + 1, ne = imin(node, M);
+        const bool in = node <= M;
+        const float sa2 = R2[c] + qa2[ne], sa3 = R3[c] + qa3[ne], sa4 = R4[c] + qa4[ne];
+        const float sb2 = R1[c] + qb2[ne], sb3 = R2[c] + qb3[ne], sb4 = R3[c] + qb4[ne];
+        const float a = mainA ? LS(sa2, LS(sa3, sa4)) : LS(LS(sa2, sa3), sa4);
+        const float b = mainB ? LS(sb2, LS(sb3, sb4)) : LS(LS(sb2, sb3), sb4);
+        ivA[c] = in ? a : -INFINITY; ivB[c] = in ? b : -INFINITY;
+        s_stage[((size_t)win * 2 + 0) * stride + node] = ivA[c]; s_stage[((size_t)win * 2 + 1) * stride + node] = ivB[c];
+      }
+      lds_barrier();
+      // ---- 2. the serial part: all 64 lanes of wave 0, a row each
+      if (chain_lane) {
+        float *st = s_stage + (size_t)lane * stride;
+        const int avail = 2 * q + cs, irow = cL - avail;
+        const float b = bwd_bsum_nodes(st[1] + s_tb[1 * 8 + 7], st[2] + s_tb[2 * 8 + 7], st[3], s_tb[3 * 8 + 7], lds_addr(st + 2), lds_addr(s_tb + 2 * 8 + 7),
+                                       M - 1, lds_addr(s_tbl), 15.999f);
+        const float pN1 = __shfl_xor(hN1, 1, 64), pN2 = __shfl_xor(hN2, 1, 64), pJ1 = __shfl_xor(hJ1, 1, 64), pJ2 = __shfl_xor(hJ2, 1, 64);
+        const float pC1 = __shfl_xor(hC1, 1, 64), pC2 = __shfl_xor(hC2, 1, 64);
+        const float uN = cs ? pN1 : pN2, uJ = cs ? pJ1 : pJ2, uC = cs ? pC1 : pC2;
+        float xJ, xN, xC;
+        if (avail < 3) { xJ = b + ctNM; xN = b + ctNM; xC = (avail == 0) ? ctNM : ctNL + ctNM; }
+        else { xJ = LS(uJ + ctNL, b + ctNM); xC = uC + ctNL; xN = LS(uN + ctNL, b + ctNM); }
+        const float xE = LS(xJ + tEL, xC + tEM);
+        const bool mid = (avail == 3) || (avail == 4);
+        BwdChainRegs r{-INFINITY, -INFINITY, st[M], s_tb[M * 8 + 3], s_tb[M * 8 + 4], lds_addr(st + M - 1), lds_addr(s_tb + (M - 1) * 8 + 3)};
+        bwd_d_nodes(r, xE, __builtin_amdgcn_ballot_w64(mid), M, lds_addr(s_tbl), 15.999f);
+        s_e[lane] = xE;
+        const float partnerN = __shfl_xor(xN, 1, 64);
+        if (clive && irow >= 0) {
+          if (cxo) {
+            float *r = cxo + (size_t)irow * 5;
+            if (irow > 0) { r[0] = xE; r[1] = xN; r[2] = xJ; r[3] = b; r[4] = xC; }
+            else { r[0] = -INFINITY; r[1] = xN; r[2] = -INFINITY; r[3] = b; r[4] = -INFINITY; }
+          }
+          if (irow == 0) {
+            const float n1 = cs ? partnerN : pN1, n2 = hN1;
+            sc[cjob] = LS(xN, LS(n1, n2));
+          }
+        }
+        hN2 = hN1; hN1 = xN; hJ2 = hJ1; hJ1 = xJ; hC2 = hC1; hC1 = xC;
+      }
+      lds_barrier();
+      // ---- 3. the cells of both rows (:1574-1600)
+      const float EA = s_e[win * 2 + 0], EB = s_e[win * 2 + 1];
+      const float ivNextA = shr1(ivA[0]), ivNextB = shr1(ivB[0]);
+      float MA[CH], IA[CH], MB[CH], IB[CH];
+#pragma unroll
+      for (int c = CH - 1; c >= 0; c--) {
+        const int node = ll * CH + c + 1, nd = imin(node, M + 1);
+        const bool in = node <= M;
+        const float4 t0 = *reinterpret_cast<const float4 *>(s_tb + nd * 8);            // tMD tMI tMM tDD
+        const float tii = s_tb[nd * 8 + 5], tim = s_tb[nd * 8 + 6];
+        const float dnA = (node < M) ? s_stage[((size_t)win * 2 + 0) * stride + node + 1] : -INFINITY;
+        const float dnB = (node < M) ? s_stage[((size_t)win * 2 + 1) * stride + node + 1] : -INFINITY;
+        const float inA = (c == CH - 1) ? ivNextA : ivA[c + 1], inB = (c == CH - 1) ? ivNextB : ivB[c + 1];
+        float mvA, ivoA, mvB, ivoB;
+        if (2 * q < 3) { mvA = LS(dnA + t0.x, LS(inA + t0.z, EA)); ivoA = inA + tim; }
+        else if (!mainA) { mvA = LS(dnA + t0.x, LS(J3[c] + t0.y, LS(inA + t0.z, EA))); ivoA = LS(J3[c] + tii, inA + tim); }
+        else { mvA = LS(LS(dnA + t0.x, LS(J3[c] + t0.y, inA + t0.z)), EA); ivoA = LS(J3[c] + tii, inA + tim); }
+        if (2 * q + 1 < 3) { mvB = LS(dnB + t0.x, LS(inB + t0.z, EB)); ivoB = inB + tim; }
+        else if (!mainB) { mvB = LS(dnB + t0.x, LS(J2[c] + t0.y, LS(inB + t0.z, EB))); ivoB = LS(J2[c] + tii, inB + tim); }
+        else { mvB = LS(LS(dnB + t0.x, LS(J2[c] + t0.y, inB + t0.z)), EB); ivoB = LS(J2[c] + tii, inB + tim); }
+        MA[c] = in ? mvA : -INFINITY; IA[c] = in ? ivoA : -INFINITY; MB[c] = in ? mvB : -INFINITY; IB[c] = in ? ivoB : -INFINITY;
+      }
+      if (live && iB >= 0) {
+#pragma unroll
+        for (int c = 0; c < CH; c++) { R4[c] = R2[c]; R3[c] = R1[c]; R2[c] = MA[c]; R1[c] = MB[c]; J3[c] = J1[c]; J2[c] = IA[c]; J1[c] = IB[c]; }
+      }
+    }
+    if (job >= 0 && !live && hl == 0) sc[job] = -INFINITY;
+    __syncthreads();
+  }
+#undef LS
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
 // 5-codon Forward, full matrix, MULTIHIT (the regions of p7_domaindef.c:396-455), strict.  IVX(i,k) collects the paths leaving
 // row i-1 and B(i-1), so rows cannot be paired: one row per step, W windows per block, the D chain and the E sum of all W rows
 // in one wave.  fwd[(i*(M+1)+k)*8 + {D,I,C0..C5}], xmx[i*5 + {E,N,J,B,C}]; done[job] = 1 (system scope) once the matrix has landed.
@@ -943,6 +1085,30 @@ int launch_fs3_bwd_chain(bath_hip_ctx *ctx, hipStream_t stream, const bath_hip_f
                          float *d_sc, float *d_xmx, const int64_t *d_xoff, FsJobs jobs, int cu_share) {
   const int M = om->M;
   size_t shmem = 0;
+  // half a wave per window when the model fits 32 lanes x 6 nodes and the windows would otherwise take more than half the chip:
+  // the same duration on half the CUs (BATH_HIP_FS_BWD_HALFWAVE=1 / =0: always / never, for tests and A/B runs)
+  {
+    static const int half_env = [] { const char *e = std::getenv("BATH_HIP_FS_BWD_HALFWAVE"); return e ? std::atoi(e) : -1; }();
+    const int CH = (M + 31) / 32;
+    const int64_t n = dna->n;
+    if (half_env != 0 && CH <= 6 && (half_env == 1 || n > (int64_t)ctx->prop.multiProcessorCount * 8)) {
+      const size_t hs = (size_t)(kLogsumTbl + (M + 2) * 8 + 32 * 2 * (CH * 32 + 1) + 64 + 16) * sizeof(float);
+      int nbat = 0;
+      DevBuf &b_bst = ctx->scratch[48];
+      const int stb = chain_batches(ctx, stream, dna, 0.128 * M + 6.6 + 0.5 * CH, 0.03 * CH, 32, b_bst, 2, &nbat, cu_share);
+      if (stb != BATH_OK) return stb;
+      const int hgrid = std::max(1, std::min(nbat, (int)ctx->prop.multiProcessorCount));
+      FsDev dev{om->M, om->pitch, om->maxcodons, om->d_rsc, om->d_tf, om->d_tb, om->d_logsum};
+#define BATH_BHALF(C_)                                                                                                              \
+      case C_: BATH_HIP_TRY(ctx, hipFuncSetAttribute((const void *)fs3_bwd_chain_half_kernel<C_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hs)); \
+               hipLaunchKernelGGL((fs3_bwd_chain_half_kernel<C_>), dim3(hgrid), dim3(1024), hs, stream, dna->view(), dev, om->d_loop[0], om->d_move[0], tEL, tEM, d_sc, d_xmx, d_xoff, jobs, \
+                                  b_bst.as<int32_t>(), nbat); break;
+      switch (CH) { BATH_BHALF(1) BATH_BHALF(2) BATH_BHALF(3) BATH_BHALF(4) BATH_BHALF(5) BATH_BHALF(6) }
+#undef BATH_BHALF
+      BATH_HIP_TRY(ctx, hipGetLastError());
+      return BATH_OK;
+    }
+  }
   const int W = chain_waves(ctx, dna->n, M, Cv, &shmem);
   // batches by length (chain_batches); t(w) measured at M = 145 (C = 3): 25.4 us per row pair at one window, 28.5 at 16
   int nbat = 0;

@@ -212,8 +212,18 @@ __global__ __launch_bounds__(W == 1 ? kWfBlock : 64 * W) void fs5_fwd_wf_kernel(
       if (act && !(dbg & 2)) {
         float4 *cell = reinterpret_cast<float4 *>(fo + ((size_t)row * (M + 1) + k) * 8);
         if (k == 1) { cell[-2] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY); cell[-1] = cell[-2]; }
+        if (dbg & 4) {
+          // BATH_HIP_WF_DBG=4, a timing probe (the results are wrong): the four lanes of a quad write 64 contiguous bytes instead of 16
+          // bytes in four rows.  Round 4, 4800 envelopes, a wave each (16 waves per CU): 4.7 -> 2.5 ms (1.9 without any store) --
+          // the address shape is most of the stores' cost there; 2400 envelopes, two waves each (4 waves per CU): 2.49 -> 2.47, the
+          // step's latency is what counts.  Staging the cells through LDS to get that shape (80 B per lane: the ring must then move
+          // to global memory) was built and measured: 4.6 -> 4.1 ms a wave each, 2.5 -> 2.85 two waves each; not kept.
+          float4 *q = reinterpret_cast<float4 *>(fo + ((size_t)(row - (lane & 3)) * (M + 1) + (k + (lane & 3))) * 8) + (lane & 3);
+          q[0] = make_float4(Dk, Ik, Mk, c1); q[4] = make_float4(c2, c3, c4, c5);
+        } else {
         cell[0] = make_float4(Dk, Ik, Mk, c1);
         cell[1] = make_float4(c2, c3, c4, c5);
+        }
       }
       // E(i) <- LS(M, LS(D, E)) for k < M and for rows 1..4; rows >= 5 pair M and D first at node M (:392-394)
       const bool pairMD = (k == M) && (row >= 5);

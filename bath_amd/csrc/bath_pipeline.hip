@@ -1224,12 +1224,14 @@ static int filters_with_survivors(bath_hip_ctx *ctx, const bath_hip_oprofile *om
   std::vector<std::vector<FsCandRec>> lsel(nl);
   std::vector<std::vector<WindowRec>> lwin(nl);
   std::vector<int64_t> first(nl, 0);
+  StageGate gate(prm->fs_pipe ? ctx->device : -1, StageGate::kCascade);      // (BATH_HIP_FS_GATE=3: not while another worker's Forward parser has the chip)
   int st = run_filters_lanes(ctx, om, dna, prm, stats, results, n_results, &states,
                              [&](int k, bath_hip_ctx *lane, const bath_hip_seqs *part, const FilterState &S) {
                                if ((size_t)k >= nl) { lane->set_error("more pipeline lanes than the survivor merge was sized for"); return (int)BATH_EFAIL; }
                                first[(size_t)k] = part->is_part ? part->first_window : 0;
                                return select_survivors(lane, S, want_wins, &lsel[(size_t)k], &lwin[(size_t)k]);
                              });
+  gate.release();
   if (st != BATH_OK) return st;
   out->sel.clear(); out->wins.clear(); out->nc_total = 0;
   out->S0 = states.empty() ? FilterState{} : states[0];

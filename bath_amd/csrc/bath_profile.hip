@@ -114,6 +114,17 @@ extern "C" int bath_hip_init(int device, bath_hip_ctx **out) {
   if (device < 0 || device >= ndev) return BATH_EINVAL;
   bath_hip_ctx *ctx = new bath_hip_ctx();
   ctx->device = device;
+  // BATH_HIP_SYNC=block|yield: how a host thread waits in hipStreamSynchronize (the runtime's default spins: with several worker
+  // contexts, each with lanes and side threads, the waiting threads then take cores from the ensembles' host threads)
+  if (const char *e = std::getenv("BATH_HIP_SYNC")) {
+    static const bool once = [&] {
+      (void)hipSetDevice(device);
+      const unsigned fl = (e[0] == 'b') ? hipDeviceScheduleBlockingSync : (e[0] == 'y') ? hipDeviceScheduleYield : hipDeviceScheduleSpin;
+      if (hipSetDeviceFlags(fl) != hipSuccess) (void)hipGetLastError();
+      return true;
+    }();
+    (void)once;
+  }
   if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&ctx->prop, device) != hipSuccess ||
       hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
     delete ctx;

@@ -138,12 +138,15 @@ print("half-wave ok", len(wins))
 """
 
 
-@pytest.mark.parametrize("batch,n_model,n_random,hi", [("", 200, 700, 420), ("3", 60, 140, 600)])
-def test_fs3_half_wave_forward_is_bit_identical(batch, n_model, n_random, hi):
-    """fs3_fwd_chain_half_kernel: 32 windows per block, every chain lane a row; default batches by length and uniform batches of 3."""
-    env = dict(os.environ, BATH_HIP_FS_HALFWAVE="1")
-    if batch:
-        env["BATH_HIP_FS_BATCH"] = batch
-    r = subprocess.run([sys.executable, "-c", HALF_SCRIPT.format(root=ROOT, seed=5 + len(batch), n_model=n_model, n_random=n_random, hi=hi)],
+@pytest.mark.parametrize("switches,n_model,n_random,hi", [
+    ({"BATH_HIP_FS_HALFWAVE": "1", "BATH_HIP_FS_BWD_HALFWAVE": "1"}, 200, 700, 420),                          # half-wave kernels, batches by length
+    ({"BATH_HIP_FS_HALFWAVE": "1", "BATH_HIP_FS_BWD_HALFWAVE": "1", "BATH_HIP_FS_BATCH": "3"}, 60, 140, 600),   # ... uniform batches of 3
+    ({"BATH_HIP_FS_FULLWAVE": "1", "BATH_HIP_FS_BWD_HALFWAVE": "0"}, 500, 1750, 380),                          # full-wave kernels at W = 16 windows per block
+])
+def test_fs3_chain_kernel_variants_are_bit_identical(switches, n_model, n_random, hi):
+    """fs3_fwd_chain_half_kernel / fs3_bwd_chain_half_kernel (32 windows per block, every chain lane a row) forced onto a few
+    hundred windows, and the full-wave kernels forced onto enough windows for 16 per block; fresh processes (static switches)."""
+    env = dict(os.environ, **switches)
+    r = subprocess.run([sys.executable, "-c", HALF_SCRIPT.format(root=ROOT, seed=5 + len(switches), n_model=n_model, n_random=n_random, hi=hi)],
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "half-wave ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
