@@ -458,7 +458,7 @@ def c4_leg_ranks(ba, synth, bdist, ctx, args, rank, world, dev, on_gpu, sync, to
     steps = 2
     sync()
     t0 = time.perf_counter()
-    busy = 0.0
+    busy = t_gather = t_finish = 0.0
     for _ in range(steps):
         tb = time.perf_counter()
         if on_gpu:
@@ -473,12 +473,16 @@ def c4_leg_ranks(ba, synth, bdist, ctx, args, rank, world, dev, on_gpu, sync, to
                 acc = st_q.setdefault(q, dict.fromkeys(bdist.STAT_FIELDS, 0))
                 acc["nres"] += 2 * sum(n - c for _, _, n, c in all_wins[q][lo:hi])
         busy += time.perf_counter() - tb
+        tg = time.perf_counter()
         gathered = bdist.gather_query_domains(by_q, 0, dev)
         merged = bdist.reduce_query_stats(st_q, len(hmms), dev)
+        t_gather += time.perf_counter() - tg
         tables = []
         if rank == 0:
+            tf = time.perf_counter()
             for q, hmm in enumerate(hmms):                             # every query finished on rank 0, inside the timed region
                 tables.append(finish_query(ba, hmm, gathered.get(q, []), all_wins[q], merged[q]["nres"], n_nt))
+            t_finish += time.perf_counter() - tf
     sync()
     dt = bdist.max_over_ranks((time.perf_counter() - t0) / steps, dev)
     busy_all = bdist.gather_floats(busy / steps * 1e3, 0, dev)
@@ -487,7 +491,7 @@ def c4_leg_ranks(ba, synth, bdist, ctx, args, rank, world, dev, on_gpu, sync, to
     out = {"workload": "tRNA-proteins.bhmm (12 query models, broadcast once) vs ONE %.0f Mb synthetic genome: (query, window group) pairs dealt to %d rank(s), "
                        "hits and counters gathered per query on rank 0 and every query finished there (strong scaling)" % (total_mb, world),
            "n_gpus": world, "scaling": "strong", "items": len(items), "items_per_rank": [owner.count(r) for r in range(world)],
-           "ms_per_database_pass": dt * 1e3, "rank_busy_ms": busy_all,
+           "ms_per_database_pass": dt * 1e3, "rank_busy_ms": busy_all, "rank0_gather_ms": t_gather / steps * 1e3, "rank0_finish_ms": t_finish / steps * 1e3,
            "residues_per_s": sum(m["nres"] for m in merged) / dt, "hits": int(sum(t[0] for t in tables)), "hits_per_query": [t[0] for t in tables],
            "tables_sha1": hashlib.sha1("".join(t[1] for t in tables).encode()).hexdigest()[:16]}
     if on_gpu and world > 1:
@@ -974,7 +978,7 @@ def fs_leg_ranks(ba, synth, bdist, dist, ctx, hmm, om, args, rank, world, dev, o
             "mode": "strict (the library's default)"}
 
 
-def fs_concurrent_leg(ba, hmm, flat, offsets, strict_keys, one_ms, workers=2, passes=4):
+def fs_concurrent_leg(ba, hmm, flat, offsets, strict_keys, one_ms, workers=2, passes=6):
     """The --fs pass with <workers> worker contexts on one GPU, each owning a block and running whole strict passes on it at the same
     time (the reference's worker threads each own a block, bathsearch.c:1119-1290): one worker's cascade / envelope / host stages
     beside another's chain kernels.  Every worker's domains must be those of the one-worker pass."""
@@ -999,7 +1003,7 @@ def fs_concurrent_leg(ba, hmm, flat, offsets, strict_keys, one_ms, workers=2, pa
         for _ in range(passes):
             _, _, dm, _ = p.run_frameshift_domains(o3, o5, d, arrays=True)
         c.synchronize()
-        got[w] = {tuple(int(r[k]) for k in keys) + (fbits(r["envsc"]),) for r in dm}
+        got[w] = dm                                             # (a view of the library's records: compared after the clock stops)
 
     t0 = time.perf_counter()
     th = [threading.Thread(target=work, args=(w,)) for w in range(workers)]
@@ -1008,7 +1012,7 @@ def fs_concurrent_leg(ba, hmm, flat, offsets, strict_keys, one_ms, workers=2, pa
     for t in th:
         t.join()
     ms = (time.perf_counter() - t0) * 1e3 / (workers * passes)
-    same = all(g == strict_keys for g in got)
+    same = all({tuple(int(r[k]) for k in keys) + (fbits(r["envsc"]),) for r in g} == strict_keys for g in got)
     for o in objs:
         o[0].close()
     return {"what": "%d worker contexts, each a block of the fs leg's size resident in HBM with its own pipeline object, whole strict --fs passes running "

@@ -14,6 +14,15 @@ ap.add_argument("--passes", type=int, default=4, help="passes per worker")
 ap.add_argument("--windows", type=int, default=1_000_000)
 ap.add_argument("--distinct", action="store_true", help="every worker its own block (another seed) instead of copies of one block")
 args = ap.parse_args()
+if os.environ.get("PROBE_TORCH") == "1":                        # what bench.py's process has done before its fs leg
+    import torch
+    torch.cuda.set_device(0); torch.cuda.synchronize()
+if os.environ.get("PROBE_EXTRA_CTX") == "1":                    # ... and a context with a finished pass of its own, left alive
+    _hmm = ba.HMM(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "Caudal_act.bhmm"))
+    _f, _o = synth.dna_windows(200_000, 1000, seed=1, hmm=_hmm, frameshift=True)[:2]
+    _c = ba.Context(0); _om = ba.OProfile(_c, ba.Profile(_hmm))
+    _p = ba.Pipeline(_c, _om, fs_pipe=True, ncbi_table=_hmm.ct)
+    _p.run_frameshift_domains(ba.FSOProfile(_c, ba.FSProfile(_hmm, 3, ncbi_table=_hmm.ct)), ba.FSOProfile(_c, ba.FSProfile(_hmm, 5, ncbi_table=_hmm.ct)), ba.SeqBlock(_c, _f, _o), arrays=True)
 hmm = ba.HMM(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "Caudal_act.bhmm"))
 KEYS = ("window", "strand", "ienv", "jenv", "iali", "jali", "ihmm", "jhmm", "n_shifted_codons")
 
