@@ -657,14 +657,28 @@ class Pipeline:
             wins.append(w)
         return stats, out, wins
 
-    def run_hits(self, dna, E_report=10.0):
-        """bathsearch (no --fs) through domain definition and hit scores: (stats, [FsDomain], multi-domain regions skipped)."""
+    def run_hits(self, dna, E_report=10.0, arrays=False):
+        """bathsearch (no --fs) through domain definition and hit scores: (stats, [FsDomain], multi-domain regions skipped).
+        arrays=True: (stats, HitArray, regions) -- the records as ONE numpy record array and the CIGAR strings as one bytes pool,
+        copied out of the library with two memcpys instead of a Python object per hit (what TopHits.add_arrays and
+        dist.gather_query_hits take)."""
         stats = PipelineStats()
         dm = C.POINTER(FsDomain)(); ndm = C.c_int64(0)
         nskip = C.c_int64(0)
         self.ctx._check(lib().bath_hip_pipeline_hits(self.ctx._h, self.om._h, dna._h, C.byref(self.params), E_report, C.byref(stats),
                                                      C.byref(dm), C.byref(ndm), C.byref(nskip)), "pipeline_hits")
+        if arrays:
+            return stats, self._hit_array(dm, ndm.value), nskip.value
         return stats, self._domains(dm, ndm.value), nskip.value
+
+    def _hit_array(self, dm, n):
+        if n == 0:
+            return HitArray(np.zeros(0, dtype=np.dtype(FsDomain)), b"")
+        rec = np.frombuffer((FsDomain * n).from_address(C.addressof(dm.contents)), dtype=np.dtype(FsDomain)).copy()
+        base = lib().bath_hip_domain_cigars(self.ctx._h)
+        last = int(rec["cigar_off"].max())
+        end = last + len(C.string_at(base + last)) + 1 if base else 0
+        return HitArray(rec, C.string_at(base, end) if base else b"")
 
     def _domains(self, dm, n):
         """Copies of the ctx-owned domain records, each with its --cigar string attached."""
@@ -719,6 +733,48 @@ class Pipeline:
         return [(names[i].decode(), float(ms[i]), int(launches[i])) for i in range(k)]
 
 
+class HitArray:
+    """The hits of a pipeline call as one numpy record array (dtype of FsDomain) plus the pool their cigar_off fields point into."""
+
+    def __init__(self, rec, pool):
+        self.rec, self.pool = rec, pool
+
+    def __len__(self):
+        return len(self.rec)
+
+    def to_bytes(self):
+        """[n records][pool length][records][pool]: what dist.gather_query_hits ships."""
+        return len(self.rec).to_bytes(8, "little") + len(self.pool).to_bytes(8, "little") + self.rec.tobytes() + self.pool
+
+    @staticmethod
+    def from_bytes(buf, p=0):
+        n = int.from_bytes(buf[p:p + 8], "little"); k = int.from_bytes(buf[p + 8:p + 16], "little"); p += 16
+        sz = C.sizeof(FsDomain)
+        rec = np.frombuffer(buf, dtype=np.dtype(FsDomain), count=n, offset=p).copy(); p += n * sz
+        return HitArray(rec, bytes(buf[p:p + k])), p + k
+
+    @staticmethod
+    def from_domains(domains):
+        """From FsDomain objects carrying .cigar (the object path of run_hits / run_frameshift_domains)."""
+        rec = np.zeros(len(domains), dtype=np.dtype(FsDomain))
+        pool = bytearray()
+        for i, d in enumerate(domains):
+            rec[i] = np.frombuffer(bytes(d), dtype=np.dtype(FsDomain))[0]
+            rec[i]["cigar_off"] = len(pool)
+            pool += d.cigar.encode() + b"\0"
+        return HitArray(rec, bytes(pool))
+
+    @staticmethod
+    def concat(parts):
+        """One array from several: every part's cigar offsets moved behind the pools before it."""
+        recs, pools, shift = [], [], 0
+        for h in parts:
+            r = h.rec.copy()
+            r["cigar_off"] += shift
+            recs.append(r); pools.append(h.pool); shift += len(h.pool)
+        return HitArray(np.concatenate(recs) if recs else np.zeros(0, dtype=np.dtype(FsDomain)), b"".join(pools))
+
+
 class TopHits:
     """P7_TOPHITS for this path: collect the hits of pipeline calls, finish the search (E-values, duplicates, sorting,
     thresholds; bathsearch.c:868-921) and print --tblout (p7_tophits_TabularTargets)."""
@@ -747,6 +803,22 @@ class TopHits:
         st = lib().bath_tophits_add(self._h, arr, n, C.cast(cig, C.c_void_p), seqidx0, strs(names), strs(accs), strs(descs), lens)
         if st != OK:
             raise BathError("tophits_add failed (%d)" % st)
+
+    def add_arrays(self, hits, names, lengths, seqidx0=0):
+        """add() for a HitArray: the record array and the CIGAR pool go to the library as they are."""
+        n = len(hits)
+        if n == 0:
+            return
+        rec = np.ascontiguousarray(hits.rec)
+        a = (C.c_char_p * len(names))(*[x.encode() for x in names])
+        lens = (C.c_int64 * len(lengths))(*[int(x) for x in lengths])
+        pool = C.create_string_buffer(hits.pool + b"\0")
+        st = lib().bath_tophits_add(self._h, rec.ctypes.data_as(C.POINTER(FsDomain)), n, C.cast(pool, C.c_void_p), seqidx0, a, None, None, lens)
+        if st != OK:
+            raise BathError("tophits_add failed (%d)" % st)
+
+    def reported(self):
+        return int(lib().bath_tophits_reported(self._h))
 
     def finalize(self, nres, max_length, E=10.0):
         if lib().bath_tophits_finalize(self._h, nres, max_length, E) != OK:

@@ -204,6 +204,26 @@ def gather_query_domains(by_query, dst=0, device="cpu"):
     return out
 
 
+def gather_query_hits(by_query, dst=0, device="cpu"):
+    """gather_query_domains without a Python object per hit: {query: HitArray} of every rank -> {query: HitArray} (the union, CIGAR
+    offsets rebased) on rank <dst>, None elsewhere.  A rank's payload is its record arrays and CIGAR pools as they left the library."""
+    from . import HitArray
+    blob = bytearray()
+    for q in sorted(by_query):
+        blob += int(q).to_bytes(4, "little") + by_query[q].to_bytes()
+    parts = gather_bytes(bytes(blob), dst, device)
+    if parts is None:
+        return None
+    got = {}
+    for part in parts:
+        p = 0
+        while p < len(part):
+            q = int.from_bytes(part[p : p + 4], "little")
+            h, p = HitArray.from_bytes(part, p + 4)
+            got.setdefault(q, []).append(h)
+    return {q: HitArray.concat(v) for q, v in got.items()}
+
+
 def reduce_query_stats(stats_by_query, n_queries, device="cpu"):
     """p7_pipeline_Merge per query in one all-reduce: {query: PipelineStats (this rank's sum over its items)} -> [dict] per query."""
     vals = torch.zeros((n_queries, len(STAT_FIELDS)), dtype=torch.int64)

@@ -416,6 +416,21 @@ def finish_query(ba, hmm, domains, wins, nres, genome_len):
     return sum(1 for d, _, fl in th.hits() if d.reported), th.tblout(hmm.name, hmm.acc, hmm.M, show_cigar=True, show_header=False)
 
 
+def finish_query_arrays(ba, hmm, hits, wins, nres, genome_len):
+    """finish_query on a HitArray: the coordinate shift is four vector additions, the records go to the library as one array."""
+    if hits is None or len(hits) == 0:
+        hits = ba.HitArray(np.zeros(0, dtype=np.dtype(ba.FsDomain)), b"")
+    rec = hits.rec
+    off = np.array([w[1] for w in wins], dtype=np.int64)[rec["window"]].astype(rec["ienv"].dtype) if len(rec) else 0
+    for f in ("ienv", "jenv", "iali", "jali"):
+        rec[f] += off
+    rec["window"] = 0
+    th = ba.TopHits()
+    th.add_arrays(hits, ["genome"], [genome_len])
+    th.finalize(int(nres), hmm.max_length)
+    return th.reported(), th.tblout(hmm.name, hmm.acc, hmm.M, show_cigar=True, show_header=False)
+
+
 def c4_leg_ranks(ba, synth, bdist, ctx, args, rank, world, dev, on_gpu, sync, total_mb):
     """BASELINE configs[3] over N ranks: the 12-model database is broadcast once; (query, window group) pairs are dealt to the
     ranks (dist.query_items / dist.deal); per query the hits and the counters are gathered on rank 0, which finishes every query
@@ -446,10 +461,9 @@ def c4_leg_ranks(ba, synth, bdist, ctx, args, rank, world, dev, on_gpu, sync, to
     def one_pass(my_jobs):
         by_q, st_q = {}, {}
         for q, lo, _, pipe, blk in my_jobs:
-            st, dm, _ = pipe.run_hits(blk)
-            for d in dm:
-                d.window += lo
-            by_q.setdefault(q, []).extend(dm)
+            st, dm, _ = pipe.run_hits(blk, arrays=True)                 # one record array + one CIGAR pool per item: no Python per hit
+            dm.rec["window"] += lo
+            by_q.setdefault(q, []).append(dm)
             acc = st_q.setdefault(q, dict.fromkeys(bdist.STAT_FIELDS, 0))
             for f in bdist.STAT_FIELDS:
                 acc[f] += int(getattr(st, f))
@@ -469,19 +483,19 @@ def c4_leg_ranks(ba, synth, bdist, ctx, args, rank, world, dev, on_gpu, sync, to
             for q, lo, hi in mine:
                 d = ba.FsDomain(); d.window = lo; d.reported = 1; d.iali = 10 + q; d.jali = 100 + q; d.ienv = 10 + q; d.jenv = 100 + q
                 d.lnP = -50.0 - q; d.bitscore = 60.0 + q; d.cigar = "%dM" % (30 + q)
-                by_q.setdefault(q, []).append(d)
+                by_q.setdefault(q, []).append(ba.HitArray.from_domains([d]))
                 acc = st_q.setdefault(q, dict.fromkeys(bdist.STAT_FIELDS, 0))
                 acc["nres"] += 2 * sum(n - c for _, _, n, c in all_wins[q][lo:hi])
         busy += time.perf_counter() - tb
         tg = time.perf_counter()
-        gathered = bdist.gather_query_domains(by_q, 0, dev)
+        gathered = bdist.gather_query_hits({q: ba.HitArray.concat(v) for q, v in by_q.items()}, 0, dev)
         merged = bdist.reduce_query_stats(st_q, len(hmms), dev)
         t_gather += time.perf_counter() - tg
         tables = []
         if rank == 0:
             tf = time.perf_counter()
             for q, hmm in enumerate(hmms):                             # every query finished on rank 0, inside the timed region
-                tables.append(finish_query(ba, hmm, gathered.get(q, []), all_wins[q], merged[q]["nres"], n_nt))
+                tables.append(finish_query_arrays(ba, hmm, gathered.get(q), all_wins[q], merged[q]["nres"], n_nt))
             t_finish += time.perf_counter() - tf
     sync()
     dt = bdist.max_over_ranks((time.perf_counter() - t0) / steps, dev)
@@ -786,7 +800,7 @@ def main():
         k1_ms = float(np.mean([o["ssv_f1"] for o in one])) if one else float("nan")
         tc1 = stats.cells_msv / (k1_ms * 1e-3) / 1e12 if one else float("nan")
         traffic = None
-        pmc = next((f for f in (os.path.join(ROOT, "profiles", r + "_ssv_orf_pmc.json") for r in ("r03", "r02")) if os.path.exists(f)), "")
+        pmc = next((f for f in (os.path.join(ROOT, "profiles", r + "_ssv_orf_pmc.json") for r in ("r04", "r03", "r02")) if os.path.exists(f)), "")
         if os.path.exists(pmc):
             try:
                 traffic = json.load(open(pmc)).get("hbm_bytes_per_launch_full_block") / lanes

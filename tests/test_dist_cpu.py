@@ -149,10 +149,18 @@ def _query_worker(rank, world, port, q):
         acc = st_q.setdefault(qq, dict.fromkeys(bd.STAT_FIELDS, 0))
         acc["nres"] += 1000 * (hi - lo); acc["n_orfs"] += hi - lo
     got = bd.gather_query_domains(by_q, 0)
+    # the same exchange on record arrays + CIGAR pools (no Python object per hit): what bench.py's configs[3] leg ships
+    arr = bd.gather_query_hits({k: ba.HitArray.from_domains(v) for k, v in by_q.items()}, 0)
+    arr_view = None
+    if arr is not None:
+        arr_view = {}
+        for k, h in arr.items():
+            cig = [h.pool[int(o):h.pool.index(b"\0", int(o))].decode() for o in h.rec["cigar_off"]]
+            arr_view[k] = sorted(zip([int(x) for x in h.rec["window"]], [int(x) for x in h.rec["iali"]], cig))
     merged = bd.reduce_query_stats(st_q, len(nwin))
     busy = bd.gather_floats(1.0 + rank, 0)
     q.put((rank, items, owner, None if got is None else {k: sorted((d.window, d.iali, d.cigar) for d in v) for k, v in got.items()},
-           [(m["nres"], m["n_orfs"]) for m in merged], busy))
+           [(m["nres"], m["n_orfs"]) for m in merged], busy, arr_view))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -183,6 +191,7 @@ def test_two_rank_query_deal_and_gather():
         assert got[qq] == [(w, 100 * qq + w, "%dM" % (10 * qq + w + 1)) for w in range(n)]
     assert outs[0][4] == outs[1][4] == [(1000 * n, n) for n in nwin]               # p7_pipeline_Merge per query
     assert outs[0][5] == [1.0, 2.0] and outs[1][5] is None
+    assert outs[1][6] is None and outs[0][6] == got                                   # the array path delivers the same hits and CIGAR strings
 
 
 def test_deal_is_balanced_and_deterministic():

@@ -191,3 +191,33 @@ def test_statistics_block_matches_recorded_output(outfile, hmmfile, fasta, fs):
         prm = ba.PipelineParams()
         ba.lib().bath_pipeline_params_default(C.byref(prm), 1 if fs else 0)
         assert th.statistics(st, prm, 1, hmm.M, len(seqs)) == block
+
+
+def test_add_arrays_gives_the_same_table_as_add():
+    """TopHits.add_arrays (one record array + one CIGAR pool, as Pipeline.run_hits(arrays=True) and dist.gather_query_hits deliver
+    them) against add() on the same hits, including a HitArray that went through to_bytes / from_bytes / concat."""
+    import bath_amd as ba
+    doms = []
+    for i in range(7):
+        d = ba.FsDomain()
+        d.window, d.iali, d.jali, d.ienv, d.jenv, d.ihmm, d.jhmm = i % 3, 100 + 40 * i, 400 + 40 * i, 90 + 40 * i, 410 + 40 * i, 1, 90
+        d.bitscore, d.lnP, d.reported, d.pre_score = 40.0 + 3 * i, -25.0 - 2 * i, 1, 41.0 + 3 * i
+        d.cigar = "%dM2I%dM" % (10 + i, 20 + i)
+        doms.append(d)
+    names, lens = ["a", "b", "c"], [5000, 6000, 7000]
+
+    def table(fill):
+        th = ba.TopHits()
+        fill(th)
+        th.finalize(3_000_000, 100)
+        return th.tblout("q", "", 90, show_cigar=True)
+
+    want = table(lambda th: th.add(doms, names, lens))
+    whole = ba.HitArray.from_domains(doms)
+    assert table(lambda th: th.add_arrays(whole, names, lens)) == want
+    a, b = ba.HitArray.from_domains(doms[:3]), ba.HitArray.from_domains(doms[3:])
+    buf = a.to_bytes() + b.to_bytes()
+    a2, p = ba.HitArray.from_bytes(buf, 0)
+    b2, p = ba.HitArray.from_bytes(buf, p)
+    assert p == len(buf)
+    assert table(lambda th: th.add_arrays(ba.HitArray.concat([a2, b2]), names, lens)) == want
