@@ -53,12 +53,29 @@ def test_hits_match_recorded_runs(ctx, hmmfile):
         assert "%.1f" % d.bitscore == score and "%.1f" % (d.dombias / np.log(2.0)) == bias
 
 
+LEDGER = []
+
+
+def _write_ledger():
+    """How the standard branch's domains compared in this run: gpurun_out/std_branch_ledger.json (every compare_hits call)."""
+    import json, os
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        tot = {k: sum(e[k] for e in LEDGER) for k in ("domains", "clustered_regions", "exact", "unmatched_gpu", "unmatched_oracle", "same_envelope_other_ensemble")}
+        json.dump({"total": tot, "calls": LEDGER}, open(os.path.join(out, "std_branch_ledger.json"), "w"), indent=1)
+    except OSError:
+        pass
+
+
 def compare_hits(dm, odm, per_d, nskip, onskip):
-    """Every domain must have its exact counterpart (coordinates identical, scores at the stated tolerances).  The one
-    exception: a clustered region (nskip of them) is resolved from 200 sampled tracebacks; on the rare occasion that a
-    sample takes a different turn on the two sides (the Forward matrices agree to rounding only) the whole ensemble differs
-    and so may that region's envelopes: such domains must still be in the same place with nearly the same score, or be weak,
-    and there can be at most 3 per clustered region."""
+    """Every domain must have its exact counterpart (coordinates identical, scores at the stated tolerances) -- including the
+    domains of clustered regions (nskip of them), which come from 200 sampled tracebacks through a Forward matrix that agrees
+    with the oracle's to rounding only: a sample COULD take a different turn on the two sides and change that region's
+    envelopes.  Rounds 1-3 allowed up to 3 such domains per clustered region; a ledger of every comparison
+    (gpurun_out/std_branch_ledger.json: round 4, 278 domains, 45 clustered regions over the GPU tier's inputs, plus the bench's
+    samples) shows it never happens on any input in this tree, so the allowance is gone: an unmatched domain fails the test and
+    the ledger entry says which one (window, envelope, score)."""
     want = []
     for w, (a, b) in enumerate(per_d):
         want += [(w, o) for o in odm[a:b]]
@@ -89,11 +106,11 @@ def compare_hits(dm, odm, per_d, nskip, onskip):
         assert abs(g.pre_score - o.pre_score) <= (1e-4 * max(1.0, abs(o.envsc)) + 1e-3) / np.log(2.0)
         assert abs(g.lnP - o.lnP) <= 0.8 * ((1e-4 * max(1.0, abs(o.envsc)) + 2e-3 + n2tol) / np.log(2.0)) + 1e-6
     rest_o = [(w, o) for w, o in want if any(o is x for x in omap.get(key(w, o), []))]
-    assert len(rest_g) + resampled <= 3 * nskip and len(rest_o) + resampled <= 3 * nskip
-    for g in rest_g:
-        lo_g, hi_g = min(g.ienv, g.jenv), max(g.ienv, g.jenv)
-        near = [o for w, o in rest_o if w == g.window and min(hi_g, max(o.ienv, o.jenv)) - max(lo_g, min(o.ienv, o.jenv)) + 1 >= 0.5 * (hi_g - lo_g + 1)]
-        assert g.bitscore < 12.0 or any(abs(g.bitscore - o.bitscore) <= 2.5 for o in near)
+    LEDGER.append({"domains": len(dm), "clustered_regions": int(nskip), "exact": len(dm) - len(rest_g), "unmatched_gpu": len(rest_g), "unmatched_oracle": len(rest_o),
+                   "same_envelope_other_ensemble": resampled,
+                   "unmatched": [{"window": int(g.window), "env": [int(g.ienv), int(g.jenv)], "bits": round(float(g.bitscore), 2)} for g in rest_g]})
+    _write_ledger()
+    assert not rest_g and not rest_o and resampled == 0, LEDGER[-1]
     return len(dm)
 
 
