@@ -300,6 +300,7 @@ struct bath_hip_oprofile {
   int NR = 0, G = 1;            // SSV kernel tile: NR registers (two cells each) per lane, G lanes per target (2*NR*G >= M)
   int ssv_row_bytes = 0;
   int16_t *d_ssv = nullptr;     // [kSsvRows][ssv_row_bytes/2] signed SSV costs (sf_conversion), +127 padding
+  int16_t *d_msv = nullptr;     // the same layout with MSV's increments (bias - rb) * 2^-11, unclipped (bath_msv_lane.hip); models of one lane tile <= 76 registers
   uint8_t *d_rb = nullptr;      // [Kp][rb_stride]
   int rb_stride = 0;
   int16_t *d_rw = nullptr;      // [Kp][M+1]

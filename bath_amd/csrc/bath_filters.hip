@@ -683,6 +683,10 @@ static int wave_grid(bath_hip_ctx *ctx, int64_t njobs) {
 
 int launch_msv_wave(bath_hip_ctx *ctx, const bath_hip_oprofile *om, SeqView v, const int32_t *d_todo, int64_t ntodo, float *d_sc, int32_t *d_status, const int *ntodo_dev) {
   if (ntodo == 0) return BATH_OK;
+  {                                                              // models of up to 152 nodes: a lane per target (bath_msv_lane.hip)
+    const int st = launch_msv_lane(ctx, om, v, d_todo, ntodo, d_sc, d_status, ntodo_dev);
+    if (st != BATH_ENORESULT) return st;
+  }
   const int C = columns_per_lane(om->M);
   const int grid = wave_grid(ctx, ntodo);
   BATH_C_SWITCH(C, hipLaunchKernelGGL(msv_wave_kernel<CC>, dim3(grid), dim3(256), 0, ctx->stream, v, om->M, om->d_rb, om->rb_stride,

@@ -194,7 +194,7 @@ extern "C" int bath_hip_set_fs_strict(bath_hip_ctx *ctx, int on) {
 
 extern "C" void bath_hip_oprofile_destroy(bath_hip_oprofile *om) {
   if (!om) return;
-  for (void *p : {(void *)om->d_emit, (void *)om->d_ssv, (void *)om->d_rb, (void *)om->d_rw, (void *)om->d_tw, (void *)om->d_rf, (void *)om->d_tf,
+  for (void *p : {(void *)om->d_emit, (void *)om->d_ssv, (void *)om->d_msv, (void *)om->d_rb, (void *)om->d_rw, (void *)om->d_tw, (void *)om->d_rf, (void *)om->d_tf,
                   (void *)om->d_bias_eo, (void *)om->d_vit_rw, (void *)om->d_vit_tw2, (void *)om->d_vit_rank, (void *)om->lt.d_tjb, (void *)om->lt.d_xwmove, (void *)om->lt.d_pmove,
                   (void *)om->lt.d_nullsc, (void *)om->lt.d_lt1, (void *)om->lt.d_lt2, (void *)om->lt.d_p1, (void *)om->d_cons, (void *)om->d_msc, (void *)om->d_tsc, (void *)om->d_rfb, (void *)om->d_tfb})
     if (p) (void)hipFree(p);
@@ -339,6 +339,18 @@ extern "C" int bath_hip_oprofile_convert(bath_hip_ctx *ctx, const bath_profile *
         tab[x * rowsz + (size_t)g * 2 * NR + 2 * (q % NR) + q / NR] = half_bits(-(float)cost / 2048.0f);
       }
     BATH_HIP_TRY(ctx, upload(&om->d_ssv, tab.data(), tab.size(), ctx->stream));
+    if (G == 1 && NR <= 76) {
+      // MSV (J state) with a lane per target (bath_msv_lane.hip): the same tile layout, the byte costs unclipped -- the increment of
+      // a cell is bias - rb (msvfilter.c:160-162); padding nodes and the reset row: -1.0, the cell back to 0
+      std::vector<int16_t> mtab((size_t)kSsvRows * rowsz, half_bits(-1.0f));
+      for (int x = 0; x < kKp; x++)
+        for (int k = 1; k <= M; k++) {
+          const int q = k - 1;
+          const int inc = (int)om->bias_b - (int)om->rb[x * W + k];
+          mtab[x * rowsz + 2 * (q % NR) + q / NR] = half_bits((float)inc / 2048.0f);
+        }
+      BATH_HIP_TRY(ctx, upload(&om->d_msv, mtab.data(), mtab.size(), ctx->stream));
+    }
   }
   // lane-per-target Viterbi tables (bath_viterbi.hip)
   {
