@@ -13,6 +13,7 @@ ap.add_argument("--workers", type=str, default="1,2,3")
 ap.add_argument("--passes", type=int, default=4, help="passes per worker")
 ap.add_argument("--windows", type=int, default=1_000_000)
 ap.add_argument("--distinct", action="store_true", help="every worker its own block (another seed) instead of copies of one block")
+ap.add_argument("--json", action="store_true", help="one JSON line at the end: {workers: {ms_per_block, domains_equal}} (bench.py reads it)")
 args = ap.parse_args()
 if os.environ.get("PROBE_TORCH") == "1":                        # what bench.py's process has done before its fs leg
     import torch
@@ -39,6 +40,7 @@ def block(seed):
 
 
 ref = {}
+summary = {}
 for W in [int(x) for x in args.workers.split(",")]:
     objs = []
     for w in range(W):
@@ -77,5 +79,10 @@ for W in [int(x) for x in args.workers.split(",")]:
         same.append(ref[seed] == got[w])
     print("workers %d: %d passes in %.1f ms = %.2f ms per block; domains %s; equal to first pass of that block: %s"
           % (W, W * args.passes, dt * 1e3, dt * 1e3 / (W * args.passes), [len(g) for g in got], same), flush=True)
+    summary[str(W)] = {"ms_per_block": dt * 1e3 / (W * args.passes), "blocks": W * args.passes, "domains": [len(g) for g in got],
+                       "domains_equal_to_first_pass_incl_envsc_bits": bool(all(same))}
     for o in objs:
         o[0].close()
+if args.json:
+    import json
+    print(json.dumps(summary))
