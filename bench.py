@@ -1069,18 +1069,6 @@ def fs_leg(ba, synth, ctx, hmm, om, args, data=None, cpu=None):
     strict = {tuple(int(r[k]) for k in keys) for r in dm}
     strict_bits = {tuple(int(r[k]) for k in keys) + (fbits(r["envsc"]),) for r in dm}
     conc = None if args.no_concurrent else fs_concurrent_leg(ba, hmm, flat, offsets, strict_bits, dt * 1e3)
-    if conc is not None and args.fs_windows == 1_000_000 and args.length == 1000:
-        # The same measurement in a process of its own (a child, started like any other program; this process keeps the GPU
-        # and waits): bench.py's process holds a dozen idle streams of its earlier legs, and HIP maps a process's streams onto a
-        # handful of hardware queues -- the workers' kernels then share queues with each other and with nothing useful.  A
-        # bathsearch run with two worker threads looks like the child, not like this process.
-        try:
-            r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fs_workers_probe.py"), "--workers", "1,2", "--passes", "6", "--json"],
-                               stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=600)
-            line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
-            conc["own_process"] = json.loads(line)
-        except Exception as e:                                       # the in-process figure stands
-            conc["own_process"] = {"error": repr(e)}
     # the same pass in the fast mode (sums along the model by wavefront scans: scores within O(1e-3) nats, outside the 1e-4 contract near zero)
     ctx.set_fs_strict(False)
     pipe.run_frameshift_domains(om3, om5, dna, arrays=True)
