@@ -226,6 +226,9 @@ __global__ __launch_bounds__(chain_threads(C)) void fs3_fwd_chain_kernel(SeqView
   for (int i = threadIdx.x; i < (M + 2) * 8; i += blockDim.x) s_tf[i] = p.tf[i];
   __syncthreads();
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#ifdef BATH_CHAIN_CLOCK
+  long long dbg_cyc = 0, dbg_wall = 0, dbg_n = 0;
+#endif
 #define LS(a, b) flogsum<false>((a), (b), s_tbl)
   for (;;) {
     if (threadIdx.x == 0) s_ctl[0] = (int)atomicAdd(jobs.counter, (unsigned)W);
@@ -302,7 +305,13 @@ __global__ __launch_bounds__(chain_threads(C)) void fs3_fwd_chain_kernel(SeqView
         // the loop's own loads (M(i,k), the transitions) are a node ahead: what a node waits for is the chain's log-sums only
         // (slot M+1 of the row and of the transitions exists: the loads run a node ahead)
         FwdChainRegs r{ech, dch, st[1], s_tf[1 * 8 + 4], s_tf[1 * 8 + 5], lds_addr(st + 1), lds_addr(s_tf + 2 * 8 + 4)};   // tMD(k), tDD(k)
+#ifdef BATH_CHAIN_CLOCK
+        const long long cc0 = clock64(), ww0 = wall_clock64();
+#endif
         fwd_chain_nodes(r, M, lds_addr(s_tbl), 15.999f);
+#ifdef BATH_CHAIN_CLOCK
+        dbg_cyc += clock64() - cc0; dbg_wall += wall_clock64() - ww0; dbg_n += M;
+#endif
         ech = r.e; dch = r.d;
         s_e[lane] = ech;
       }
@@ -338,6 +347,9 @@ __global__ __launch_bounds__(chain_threads(C)) void fs3_fwd_chain_kernel(SeqView
       }
     }
     if (job >= 0 && lane == 0) sc[job] = (L >= 3) ? LS(C1, LS(C2 + tCL, C3 + tCL)) + tCM : -INFINITY;
+#ifdef BATH_CHAIN_CLOCK
+    if (wv == 0 && lane == 0 && blockIdx.x == 0 && dbg_n > 0) printf("fwd chain: %.1f clock64 ticks per node, %.1f ns per node (%lld nodes)\n", (double)dbg_cyc / dbg_n, (double)dbg_wall / dbg_n * 10.0, dbg_n);
+#endif
     __syncthreads();                                            // s_ctl is rewritten at the top
   }
 #undef LS

@@ -36,6 +36,39 @@
   "v_add_f32 %[e], %[mx1], %[a1]\n\t"
 
 
+// the Backward chains of bath_fs_chain.hip (round 4: why is a Backward node 190-220 ns when its three dependent log-sums are 3 x 40?)
+#define BATH_BSUM_NODE(V, VN)                                                          \
+  BATH_LS_INDEX("%[a1]", "%[b]", V)                                                    \
+  "s_waitcnt lgkmcnt(1)\n\t"                                                           \
+  "v_add_f32 " VN ", %[sN], %[tN]\n\t"                                                 \
+  "ds_read_b32 %[sN], %[st] offset:8\n\t"                                              \
+  "ds_read_b32 %[tN], %[tp] offset:64\n\t"                                             \
+  "v_max_f32 %[mx], %[b], " V "\n\t"                                                   \
+  "v_add_u32 %[st], 4, %[st]\n\t"                                                      \
+  "v_add_u32 %[tp], 32, %[tp]\n\t"                                                     \
+  "s_waitcnt lgkmcnt(2)\n\t"                                                           \
+  "v_add_f32 %[b], %[mx], %[a1]\n\t"
+
+#define BATH_BWD_D_NODE(IVN, TX, TY, IVQ, UX, UY)                                      \
+  "v_add_f32 %[u], %[dn], " TX "\n\t"                                                  \
+  "v_add_f32 %[bs], " IVN ", " TY "\n\t"                                               \
+  "v_cndmask_b32_e64 %[p1], %[u], %[bs], %[mid]\n\t"                                   \
+  "v_cndmask_b32_e64 %[p2], %[bs], %[u], %[mid]\n\t"                                   \
+  BATH_LS_INDEX("%[a1]", "%[xE]", "%[p1]")                                             \
+  "ds_read_b32 " IVQ ", %[st]\n\t"                                                     \
+  "ds_read_b32 " UX ", %[tp]\n\t"                                                      \
+  "ds_read_b32 " UY ", %[tp] offset:4\n\t"                                             \
+  "v_max_f32 %[mx1], %[xE], %[p1]\n\t"                                                 \
+  "s_waitcnt lgkmcnt(3)\n\t"                                                           \
+  "v_add_f32 %[x], %[mx1], %[a1]\n\t"                                                  \
+  BATH_LS_INDEX("%[a1]", "%[x]", "%[p2]")                                              \
+  "v_max_f32 %[mx1], %[x], %[p2]\n\t"                                                  \
+  "v_add_u32 %[st], -4, %[st]\n\t"                                                     \
+  "v_add_u32 %[tp], -32, %[tp]\n\t"                                                    \
+  "s_waitcnt lgkmcnt(0)\n\t"                                                           \
+  "v_add_f32 %[dn], %[mx1], %[a1]\n\t"                                                 \
+  "ds_write_b32 %[st], %[dn] offset:8\n\t"
+
 template <int V>
 __global__ void k(const float *tblg, const float *xs, float *out, long long *cyc, int lanes) {
   extern __shared__ float tbl[];
@@ -91,6 +124,31 @@ __global__ void k(const float *tblg, const float *xs, float *out, long long *cyc
                  : [tbl] "s"(tb), [c15] "s"(c15)
                  : "memory");
       i++;
+    } else if (V == 9) {   // Backward's B sum, two nodes per iteration
+      float vn, a1, mx; static_cast<void>(a);
+      asm volatile("s_waitcnt lgkmcnt(0)\n\t"
+                   BATH_BSUM_NODE("%[v]", "%[vn]")
+                   BATH_BSUM_NODE("%[vn]", "%[v]")
+                   "s_waitcnt lgkmcnt(0)"
+                   : [b] "+v"(e), [v] "+v"(x), [sN] "+v"(tx), [tN] "+v"(ty), [st] "+v"(xa), [tp] "+v"(tpa), [vn] "=&v"(vn), [a1] "=&v"(a1), [mx] "=&v"(mx)
+                   : [tbl] "s"(tb), [c15] "s"(c15)
+                   : "memory");
+      i++;
+    } else if (V == 10) {  // Backward's D chain, two nodes per iteration (addresses walk down; restarted every 256 nodes)
+      float ivq, ux, uy, u, bs, p1, p2, a1, mx1, xx;
+      const unsigned long long mid = 0ull;
+      if ((i & 255) == 0) { xa = (unsigned)(size_t)(sx + 600); tpa = (unsigned)(size_t)(stf + 600 * 8); }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\t"
+                   BATH_BWD_D_NODE("%[ivn]", "%[tx]", "%[ty]", "%[ivq]", "%[ux]", "%[uy]")
+                   BATH_BWD_D_NODE("%[ivk]", "%[ux]", "%[uy]", "%[ivk]", "%[tx]", "%[ty]")
+                   "v_mov_b32 %[ivn], %[ivq]\n\t"
+                   "s_waitcnt lgkmcnt(0)"
+                   : [dn] "+v"(dd), [ivn] "+v"(x), [ivk] "+v"(e), [tx] "+v"(tx), [ty] "+v"(ty), [st] "+v"(xa), [tp] "+v"(tpa),
+                     [ivq] "=&v"(ivq), [ux] "=&v"(ux), [uy] "=&v"(uy), [u] "=&v"(u), [bs] "=&v"(bs), [p1] "=&v"(p1), [p2] "=&v"(p2),
+                     [a1] "=&v"(a1), [mx1] "=&v"(mx1), [x] "=&v"(xx)
+                   : [xE] "v"(-2.5f), [mid] "s"(mid), [tbl] "s"(tb), [c15] "s"(c15)
+                   : "memory");
+      i++;
     } else if (V == 7) { // 6 dependent VOP3 min with abs + sgpr
       asm volatile("v_min_f32_e64 %[e], |%[e]|, %[c15]\n\tv_min_f32_e64 %[e], |%[e]|, %[c15]\n\tv_min_f32_e64 %[e], |%[e]|, %[c15]\n\tv_min_f32_e64 %[e], |%[e]|, %[c15]\n\tv_min_f32_e64 %[e], |%[e]|, %[c15]\n\tv_min_f32_e64 %[e], |%[e]|, %[c15]"
                    : [e] "+v"(e) : [c15] "s"(c15) : "memory");
@@ -125,6 +183,8 @@ int main() {
     run<6>("6 dependent v_mul literal", dt, dx, dout, dc, lanes);
     run<7>("6 dependent v_min_e64 |.|,sgpr", dt, dx, dout, dc, lanes);
     run<8>("FWD_NODE (per node)", dt, dx, dout, dc, lanes);
+    run<9>("BSUM_NODE (per node)", dt, dx, dout, dc, lanes);
+    run<10>("BWD_D_NODE (per node)", dt, dx, dout, dc, lanes);
   }
   return 0;
 }
