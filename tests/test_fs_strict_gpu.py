@@ -111,10 +111,11 @@ def test_strict_pipeline_is_exact_on_clustered_regions(gpu_ctx):
     assert n_fs >= 4
 
 
-@pytest.mark.parametrize("M", [1024, 1200])
+@pytest.mark.parametrize("M", [300, 513, 1024, 1200])
 def test_strict_pipeline_is_exact_with_a_long_model(gpu_ctx, tmp_path, M):
     """BASELINE configs[4]'s model size (16 nodes per lane in the chain kernels, the wavefront's ring in global memory) and one
-    beyond it (1200 nodes: the 20-nodes-per-lane instantiation -- configs[4] is not the edge of what the kernels take)."""
+    beyond it (1200 nodes: the 20-nodes-per-lane instantiation -- configs[4] is not the edge of what the kernels take); 300 and
+    513 nodes: the multi-wave decoding + optimal-accuracy kernel with 3 and 5 waves per envelope (8 at 1024, 7 x 3 nodes at 1200)."""
     path = common.write_synthetic_bhmm(str(tmp_path / ("s%d.bhmm" % M)), M, seed=M)
     rng = np.random.default_rng(12)
     wins = P.frameshifted_windows(rng, ol.Model(path, 0), n=8, L_flank=60)[:10] + common.random_dna(rng, 4, 1200)
