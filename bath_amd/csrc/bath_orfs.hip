@@ -288,6 +288,76 @@ __global__ __launch_bounds__(256) void orf_stitch_kernel(SeqView dna, OrfTiles t
   if (threadIdx.x == 0 && s_red[0]) { atomicAdd(out.n_orfs, (unsigned long long)s_red[0]); atomicAdd(out.orf_res, (unsigned long long)s_red[1]); }
 }
 
+// The same for LONG windows (genome windows of 256 kb: ~680 tiles per window and frame), a WAVE per (window, frame): the lane
+// walk above is a chain of dependent loads, one per tile (0.26 ms for a window whatever the block holds -- a tenth of a
+// configs[3] query).  The run entering tile T comes from the nearest earlier tile that holds a stop: an exclusive running
+// maximum of "index of a tile with a stop" over the wave's 64 tiles (DPP), that tile's suffix by one ds_bpermute, 128 codons
+// for every stop-free tile in between; the run leaving the 64 tiles carries into the next 64.  Same records, same histogram.
+__device__ __forceinline__ int wave_excl_max_scan(int v, int ident) {
+  int x = dpp_or_ident<0x138>(v, ident);                           // wave_shr:1 (lane 0 gets the identity)
+  x = max(x, dpp_or_ident<0x111>(x, ident));
+  x = max(x, dpp_or_ident<0x112>(x, ident));
+  x = max(x, dpp_or_ident<0x114>(x, ident));
+  x = max(x, dpp_or_ident<0x118>(x, ident));
+  x = max(x, dpp_or_ident<0x142, 0xa>(x, ident));                  // row_bcast:15
+  x = max(x, dpp_or_ident<0x143, 0xc>(x, ident));                  // row_bcast:31
+  return x;
+}
+__global__ __launch_bounds__(256) void orf_stitch_wave_kernel(SeqView dna, OrfTiles tiles, OrfScanOut out, int minlen) {
+  __shared__ int s_hist[kOrfBins];
+  __shared__ unsigned s_red[2];
+  for (int i = threadIdx.x; i < kOrfBins; i += blockDim.x) s_hist[i] = 0;
+  if (threadIdx.x < 2) s_red[threadIdx.x] = 0;
+  __syncthreads();
+  unsigned my_orfs = 0, my_res = 0;
+  const int lane = threadIdx.x & 63;
+  const int64_t nstreams = dna.n * 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t sidx = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; sidx < nstreams; sidx += nwaves) {
+    const int64_t w = sidx / 6;
+    const int sf = (int)(sidx - w * 6);
+    const int n = dna.len[w];
+    if (n < 15) continue;
+    const int nt = (n / 3) / kTileCodons + 1;
+    const int64_t first = tiles.tile_first[w];
+    const bool rev = sf >= 3;
+    const int fr = rev ? sf - 3 : 0;
+    const int ph = rev ? (n - fr) % 3 : sf;
+    const int C = (n - 3 - fr - ph) / 3;
+    int carry_in = 0;
+    for (int T0 = 0; T0 < nt; T0 += 64) {
+      const int T = T0 + lane;
+      const bool valid = T < nt;
+      const int64_t e = (first + (valid ? T : 0)) * 6 + sf;
+      const int p = valid ? out.prefix[e] : kTileCodons;
+      const bool has = p < kTileCodons;
+      const int sfx = has ? out.suffix[e] : 0;
+      const int j = wave_excl_max_scan(has ? lane : -1, -1);           // the nearest earlier tile of these 64 that holds a stop
+      const int sfx_j = __shfl(sfx, j < 0 ? 0 : j, 64);
+      const int carry = (j >= 0) ? sfx_j + kTileCodons * (lane - j - 1) : carry_in + kTileCodons * lane;
+      if (valid) {
+        uint2 rec = make_uint2(0u, 0u);
+        if (has) {
+          const int len = carry + p;
+          if (len >= minlen) {
+            const int u_stop = kTileCodons * T + p;
+            rec = make_uint2((unsigned)(rev ? C - u_stop + 1 : u_stop - len), (unsigned)len | ((unsigned)sf << 28));
+            atomicAdd(&s_hist[orf_bin(len)], 1);
+            my_orfs++; my_res += (unsigned)len;
+          }
+        }
+        out.cross[e] = rec;
+      }
+      const int leave = has ? sfx : carry + kTileCodons;               // the run leaving this lane's tile
+      carry_in = __shfl(leave, 63, 64);
+    }
+  }
+  if (my_orfs) { atomicAdd(&s_red[0], my_orfs); atomicAdd(&s_red[1], my_res); }
+  __syncthreads();
+  for (int k = threadIdx.x; k < kOrfBins; k += blockDim.x) if (s_hist[k]) atomicAdd(&out.hist[k], s_hist[k]);
+  if (threadIdx.x == 0 && s_red[0]) { atomicAdd(out.n_orfs, (unsigned long long)s_red[0]); atomicAdd(out.orf_res, (unsigned long long)s_red[1]); }
+}
+
 // counts -> start offsets, longest first; cursor[] is the copy the sort kernel advances; total ORFs -> *n_total
 __global__ void orf_scan_bins(const int *__restrict__ hist, int *__restrict__ cursor, int *__restrict__ n_total) {
   __shared__ int tmp[kOrfBins];
@@ -440,8 +510,15 @@ int launch_orf_scan(bath_hip_ctx *ctx, const bath_hip_seqs *dna, const OrfTables
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, orf_tile_kernel, 256, 0) != hipSuccess || per_cu < 1) per_cu = 4;
   const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((ntiles + 7) / 8, (int64_t)cus * per_cu));
   hipLaunchKernelGGL(orf_tile_kernel, dim3(blocks), dim3(256), 0, ctx->stream, dna->view(), tiles, tabs, out, minlen);
+  static const int stitch_env = [] { const char *e = std::getenv("BATH_HIP_STITCH_WAVE"); return e ? std::atoi(e) : -1; }();   // 1 / 0: always / never the wave kernel (tests, A/B)
+  const bool long_windows = stitch_env >= 0 ? stitch_env == 1 : ntiles > 32 * dna->n;                   // more than 32 tiles (12 kb) per window on average
+  if (long_windows) {
+    const int wblocks = (int)std::max<int64_t>(1, std::min<int64_t>((dna->n * 6 + 3) / 4, (int64_t)cus * 8));
+    hipLaunchKernelGGL(orf_stitch_wave_kernel, dim3(wblocks), dim3(256), 0, ctx->stream, dna->view(), tiles, out, minlen);
+  } else {
   const int sblocks = (int)std::max<int64_t>(1, std::min<int64_t>((dna->n * 6 + 255) / 256, (int64_t)cus * 8));
   hipLaunchKernelGGL(orf_stitch_kernel, dim3(sblocks), dim3(256), 0, ctx->stream, dna->view(), tiles, out, minlen);
+  }
   hipLaunchKernelGGL(orf_scan_bins, dim3(1), dim3(256), 0, ctx->stream, b.hist, b.cursor, b.ntotal);
   const int per_block = 256 * kSortTilesPerThread;
   hipLaunchKernelGGL(orf_sort_kernel, dim3((unsigned)std::max<int64_t>(1, (ntiles + per_block - 1) / per_block)), dim3(256), 0, ctx->stream, dna->view(), tiles,

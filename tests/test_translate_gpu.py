@@ -107,3 +107,16 @@ def test_many_short_windows(gpu_ctx):
     rng = np.random.default_rng(9)
     n = check(gpu_ctx, [rand_dna(rng, 1000) for _ in range(400)])
     assert n > 10000
+
+
+@pytest.mark.parametrize("wave", ["1", "0"])
+def test_both_stitch_kernels_on_every_input(wave):
+    """orf_stitch_wave_kernel (a wave per (window, frame): the default for blocks of long windows) forced onto every input of this
+    file, short windows and stop-free windows included, and the lane-per-stream kernel forced onto the long windows: fresh
+    processes (the switch is read once), same ORF lists."""
+    import os, subprocess, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, BATH_HIP_STITCH_WAVE=wave)
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.join(here, "test_translate_gpu.py"), "-k", "not stitch_kernels"],
+                       env=env, capture_output=True, text=True, timeout=1200, cwd=os.path.dirname(here))
+    assert r.returncode == 0 and " passed" in r.stdout, (r.stdout[-3000:], r.stderr[-2000:])
