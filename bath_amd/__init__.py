@@ -190,6 +190,7 @@ ABI = {
     "bath_hip_domain_cigars": (C.c_void_p, [_vp]),
     "bath_selftest_rng_stream": (C.c_int, [C.c_uint32, C.c_int, C.POINTER(C.c_double)]),
     "bath_selftest_fchoose": (C.c_int, [C.c_uint32, _f32p, C.c_int, C.c_int, _i32p]),
+    "bath_selftest_fs_ensemble": (C.c_int, [C.c_int, _f32p, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, _f32p, _f32p, _i32p, C.c_int, _i32p]),
     "bath_tophits_create": (_vp, []),
     "bath_tophits_destroy": (None, [_vp]),
     "bath_tophits_add": (C.c_int, [_vp, C.POINTER(FsDomain), C.c_int64, C.c_void_p, C.c_int64, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p),

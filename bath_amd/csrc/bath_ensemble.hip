@@ -76,16 +76,50 @@ void cluster_segments(const std::vector<Seg> &sp, int nsamples, bool fs, std::ve
     return std::abs((a.j - a.m) - (b.j - b.m)) <= max_diagdiff;
   };
   const int nsp = (int)sp.size();
-  std::vector<int> assign((size_t)nsp, -1), stack;
-  int nc = 0;
-  for (int h = 0; h < nsp; h++) {
-    if (assign[(size_t)h] >= 0) continue;
-    assign[(size_t)h] = nc; stack.assign(1, h);
+  // Single linkage = connected components of the "linked" graph; a cluster's number is the order of its first segment in <sp>.
+  // 200 traces sampled from one posterior keep producing the SAME segments (a few dozen distinct (i, j, k, m) among ~400), and
+  // linked() depends on those four numbers only: the components are found on the distinct segments (a few thousand link tests
+  // instead of ~10^5, each two float divisions: half of an ensemble's host time) and handed back to the segments.
+  std::vector<int> uniq_of((size_t)nsp), first_of;              // segment -> distinct segment; distinct segment -> its first segment
+  {
+    std::vector<int> order((size_t)nsp);
+    for (int h = 0; h < nsp; h++) order[(size_t)h] = h;
+    auto key_less = [&](int a, int b) {
+      const Seg &x = sp[(size_t)a], &y = sp[(size_t)b];
+      if (x.i != y.i) return x.i < y.i;
+      if (x.j != y.j) return x.j < y.j;
+      if (x.k != y.k) return x.k < y.k;
+      if (x.m != y.m) return x.m < y.m;
+      return a < b;                                             // equal segments: in <sp> order, so that the first of a run is the earliest
+    };
+    std::sort(order.begin(), order.end(), key_less);
+    for (int z = 0; z < nsp; z++) {
+      const int h = order[(size_t)z];
+      const bool same = z > 0 && sp[(size_t)h].i == sp[(size_t)order[(size_t)z - 1]].i && sp[(size_t)h].j == sp[(size_t)order[(size_t)z - 1]].j &&
+                        sp[(size_t)h].k == sp[(size_t)order[(size_t)z - 1]].k && sp[(size_t)h].m == sp[(size_t)order[(size_t)z - 1]].m;
+      if (!same) first_of.push_back(h);
+      uniq_of[(size_t)h] = (int)first_of.size() - 1;
+    }
+  }
+  const int nu = (int)first_of.size();
+  std::vector<int> ucomp((size_t)nu, -1), stack;
+  int ncomp = 0;
+  for (int u = 0; u < nu; u++) {
+    if (ucomp[(size_t)u] >= 0) continue;
+    ucomp[(size_t)u] = ncomp; stack.assign(1, u);
     while (!stack.empty()) {
       const int a = stack.back(); stack.pop_back();
-      for (int b = 0; b < nsp; b++) if (assign[(size_t)b] < 0 && linked(sp[(size_t)a], sp[(size_t)b])) { assign[(size_t)b] = nc; stack.push_back(b); }
+      for (int b = 0; b < nu; b++)
+        if (ucomp[(size_t)b] < 0 && linked(sp[(size_t)first_of[(size_t)a]], sp[(size_t)first_of[(size_t)b]])) { ucomp[(size_t)b] = ncomp; stack.push_back(b); }
     }
-    nc++;
+    ncomp++;
+  }
+  std::vector<int> assign((size_t)nsp, -1), number((size_t)ncomp, -1);
+  int nc = 0;
+  for (int h = 0; h < nsp; h++) {                               // clusters numbered by their first segment, as the search over <sp> numbers them
+    int &id = number[(size_t)ucomp[(size_t)uniq_of[(size_t)h]]];
+    if (id < 0) id = nc++;
+    assign[(size_t)h] = id;
   }
   std::vector<Seg> sig;
   std::vector<int> epc;
@@ -249,6 +283,7 @@ int bath::fs_region_trace_ensemble(int M, const float *tsc, float xNL, float xNM
   enum { gD = 0, gI = 1, gM = 2 };
   enum { gE = 0, gN, gJ, gB, gC };
   env->clear();
+  const auto t_begin = std::chrono::steady_clock::now();
   const size_t W = (size_t)(M + 1) * 8;
   auto DP = [&](int i, int k, int s) { return fwd[(size_t)i * W + (size_t)k * 8 + s]; };
   auto X = [&](int i, int s) { return fx[(size_t)i * 5 + s]; };
@@ -388,12 +423,31 @@ int bath::fs_region_trace_ensemble(int M, const float *tsc, float xNL, float xNM
       sp.push_back(Seg{t, sqfrom + ireg - 1, sqto + ireg - 1, hmmfrom, hmmto, 0.f});
     }
   }
+  static const bool prof = [] { const char *e = std::getenv("BATH_ENS_PROF"); return e && e[0] == '1'; }();
+  const auto tc0 = std::chrono::steady_clock::now();
   cluster_segments(sp, nsamples, true, env);
+  if (prof) {
+    const auto tc1 = std::chrono::steady_clock::now();
+    fprintf(stderr, "[ens] Lr %d: traces %.3f ms (%zu segments, %zu E rows memoised), clustering %.3f ms\n", Lr,
+            std::chrono::duration<double, std::milli>(tc0 - t_begin).count(), sp.size(), mm.epool.size() / (size_t)(2 * M + 1),
+            std::chrono::duration<double, std::milli>(tc1 - tc0).count());
+  }
   return BATH_OK;
 }
 
 
-// ---- self-test hooks (include/bath_hip.h): the restated easel pieces, callable without a GPU
+// ---- self-test hooks (include/bath_hip.h): the restated easel pieces and the frameshift ensemble, callable without a GPU
+extern "C" int bath_selftest_fs_ensemble(int M, const float *tsc, float xNL, float xNM, float xE, int ireg, int Lr, const float *fwd, const float *fx,
+                                         int32_t *env, int max_env, int32_t *n_env) {
+  if (!tsc || !fwd || !fx || !env || !n_env || M < 1 || Lr < 1 || max_env < 0) return BATH_EINVAL;
+  std::vector<std::pair<int, int>> cl;
+  const int st = bath::fs_region_trace_ensemble(M, tsc, xNL, xNM, xE, ireg, Lr, fwd, fx, &cl);
+  if (st != BATH_OK) return st;
+  *n_env = (int32_t)cl.size();
+  for (size_t e = 0; e < cl.size() && (int)e < max_env; e++) { env[2 * e] = cl[e].first; env[2 * e + 1] = cl[e].second; }
+  return BATH_OK;
+}
+
 extern "C" int bath_selftest_rng_stream(uint32_t seed, int n, double *out) {
   if (!out || n < 0) return BATH_EINVAL;
   FastRng rng(seed);

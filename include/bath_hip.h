@@ -430,6 +430,11 @@ int bath_hip_fs5_forward_full(bath_hip_ctx *ctx, const bath_hip_fsprofile *om5, 
  * ------------------------------------------------------------------------------------------ */
 int bath_selftest_rng_stream(uint32_t seed, int n, double *out);                          /* the first n values of esl_random() after seeding */
 int bath_selftest_fchoose(uint32_t seed, const float *p, int n, int draws, int32_t *out); /* draws x (copy p, esl_vec_FNorm, esl_rnd_FChoose) from one stream */
+/* region_trace_ensemble_frameshift (p7_domaindef.c:891-958: 200 stochastic tracebacks through a region's multihit 5-codon Forward
+ * matrix, single-linkage clustering) as the pipeline runs it on the host, on caller-supplied matrices: fwd (Lr+1) x (M+1) x
+ * {D, I, M, C1..C5}, fx (Lr+1) x {E,N,J,B,C}, tsc the generic [M][8] log transitions; env: n_env x {i, j} in window nucleotides. */
+int bath_selftest_fs_ensemble(int M, const float *tsc, float xNL, float xNM, float xE, int ireg, int Lr, const float *fwd, const float *fx,
+                              int32_t *env, int max_env, int32_t *n_env);
 
 #ifdef __cplusplus
 }
