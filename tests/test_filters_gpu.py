@@ -90,6 +90,26 @@ def test_ssv_every_register_tiling(gpu_ctx, tmp_path, M):
         assert len(odm) >= 6 and sorted(key(d.window, d) for d in dm) == sorted(key(w, o) for w, (a, b) in enumerate(per_d) for o in odm[a:b])
 
 
+@pytest.mark.parametrize("M", [40, 46, 54, 62, 70, 78, 86, 94, 102, 110, 118, 126, 134, 142, 150])
+def test_msv_lane_every_register_tiling(gpu_ctx, tmp_path, M):
+    """msv_lane_kernel<NR> (bath_msv_lane.hip: the J-state recurrence with a lane per target, models up to 152 nodes) is instantiated
+    per register count NR = 16 .. 76 in steps of 4: every NR the other tests' models do not land on, score and status bit-exact,
+    with targets that reach the J state, targets that overflow, single residues and lengths that are no multiple of the 8-residue
+    reads."""
+    path = common.write_synthetic_bhmm(str(tmp_path / ("s%d.bhmm" % M)), M, seed=M)
+    model = ol.Model(path, 0)
+    om = ba.OProfile(gpu_ctx, ba.Profile(ba.HMM(path, 0)))
+    rng = np.random.default_rng(1000 + M)
+    seqs = common.random_aa(rng, 120, 1, 97) + common.emit_from_model(rng, model, 80) + common.emit_from_model(rng, model, 40, sharpen=3.0)
+    seqs += [np.concatenate(common.emit_from_model(rng, model, 3, sharpen=3.0)) for _ in range(6)]       # several domains in a row: J state, overflow
+    sc, st = ba.MSVFilter(gpu_ctx, om, ba.SeqBlock(gpu_ctx, seqs))
+    osc, ost = common.oracle_scores(model, seqs, "bo_msvfilter")
+    assert np.array_equal(st, ost)
+    assert _same_scores(sc, osc)
+    _, sst = common.oracle_scores(model, seqs, "bo_ssvfilter")
+    assert (sst != 0).sum() >= 5                             # targets SSV could not decide: they went through the lane kernel
+
+
 def test_msv_bit_exact(setup):
     ctx, model, om, seqs, sq = setup
     sc, st = ba.MSVFilter(ctx, om, sq)
