@@ -157,6 +157,7 @@ ABI = {
     "bath_hip_synchronize": (C.c_int, [_vp]),
     "bath_hip_stream": (_vp, [_vp]),
     "bath_hip_set_fs_strict": (C.c_int, [_vp, C.c_int]),
+    "bath_hip_trim": (C.c_int, [_vp]),
     "bath_hip_kernel_times": (C.c_int, [_vp, C.c_int, C.POINTER(KernelTime)]),
     "bath_hip_oprofile_convert": (C.c_int, [_vp, C.POINTER(_Profile), C.POINTER(_vp)]),
     "bath_hip_oprofile_destroy": (None, [_vp]),
@@ -367,6 +368,11 @@ class Context:
 
     def synchronize(self):
         self._check(lib().bath_hip_synchronize(self._h), "synchronize")
+
+    def trim(self):
+        """Release the lanes, side contexts and side streams of this context (re-created on demand): before it sits idle beside
+        worker contexts.  Arrays returned by earlier calls on this context are invalid afterwards."""
+        self._check(lib().bath_hip_trim(self._h), "trim")
 
     def set_fs_strict(self, on=True):
         """True (the library's default): frameshift log-sums along the model in the reference's serial order, bit-identical to the

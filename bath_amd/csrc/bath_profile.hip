@@ -159,6 +159,32 @@ extern "C" void bath_hip_finalize(bath_hip_ctx *ctx) {
   delete ctx;
 }
 
+// Give back what the context created lazily to run parts of a call side by side: the lanes (contexts, scratch memory, host
+// threads), the side contexts of the domain stages, the side / copy streams.  All of it is created again on demand.  For a context
+// that will sit idle while others work (a process that switches from one big block to several worker contexts): HIP maps a
+// process's streams onto a handful of hardware queues, and an idle context's dozen streams take their share of them.  Records and
+// arrays returned by earlier calls on this context are invalid afterwards.
+extern "C" int bath_hip_trim(bath_hip_ctx *ctx) {
+  if (!ctx) return BATH_EINVAL;
+  BATH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  BATH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  delete ctx->lane_pool; ctx->lane_pool = nullptr;
+  for (bath_hip_ctx *lane : ctx->lanes) bath_hip_finalize(lane);
+  ctx->lanes.clear();
+  if (ctx->aux) { bath_hip_finalize(ctx->aux); ctx->aux = nullptr; }
+  if (ctx->aux2) { bath_hip_finalize(ctx->aux2); ctx->aux2 = nullptr; }
+  if (ctx->tail_stream) { (void)hipStreamDestroy(ctx->tail_stream); ctx->tail_stream = nullptr; }
+  if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); ctx->copy_stream = nullptr; }
+  if (ctx->side_stream) {
+    (void)hipStreamSynchronize(ctx->side_stream); (void)hipStreamDestroy(ctx->side_stream); ctx->side_stream = nullptr;
+    if (ctx->ev_fork) { (void)hipEventDestroy(ctx->ev_fork); ctx->ev_fork = nullptr; }
+    if (ctx->ev_join) { (void)hipEventDestroy(ctx->ev_join); ctx->ev_join = nullptr; }
+  }
+  ctx->fs_std_orfs.clear(); ctx->fs_std_pool = nullptr; ctx->fs_keep_xoff.clear(); ctx->fs_regions_all.clear();
+  ctx->d_records = nullptr; ctx->n_records = 0;
+  return BATH_OK;
+}
+
 extern "C" const char *bath_hip_last_error(const bath_hip_ctx *ctx) { return ctx ? ctx->err.c_str() : "no context"; }
 
 extern "C" int bath_hip_synchronize(bath_hip_ctx *ctx) {

@@ -869,12 +869,14 @@ def main():
         dist.destroy_process_group()
 
 
-def concurrent_leg(ba, hmm, flat, offsets, args, stats_one, ms_one, workers=3):
+def concurrent_leg(ba, hmm, flat, offsets, args, stats_one, ms_one, workers=3, main_ctx=None):
     """The reference's threading model on one GPU (bathsearch.c thread_loop: every worker thread owns a block and a pipeline
     object): <workers> contexts, each running the cascade over its own resident block at the same time, so that one block's
     translation (head) and survivor kernels (tail) run beside another block's SSV.  Outside the headline's timed region."""
     import threading
     objs = []
+    if main_ctx is not None:
+        main_ctx.trim()                                         # (see fs_concurrent_leg)
     for _ in range(workers):
         c = ba.Context(0)
         o = ba.OProfile(c, ba.Profile(hmm))
@@ -992,12 +994,14 @@ def fs_leg_ranks(ba, synth, bdist, dist, ctx, hmm, om, args, rank, world, dev, o
             "mode": "strict (the library's default)"}
 
 
-def fs_concurrent_leg(ba, hmm, flat, offsets, strict_keys, one_ms, workers=2, passes=6):
+def fs_concurrent_leg(ba, hmm, flat, offsets, strict_keys, one_ms, workers=2, passes=6, main_ctx=None):
     """The --fs pass with <workers> worker contexts on one GPU, each owning a block and running whole strict passes on it at the same
     time (the reference's worker threads each own a block, bathsearch.c:1119-1290): one worker's cascade / envelope / host stages
     beside another's chain kernels.  Every worker's domains must be those of the one-worker pass."""
     import threading
     objs = []
+    if main_ctx is not None:
+        main_ctx.trim()                                         # the idle main context gives its lanes' and side contexts' streams back (hardware queues)
     for _ in range(workers):
         c = ba.Context(0)
         o = ba.OProfile(c, ba.Profile(hmm))
@@ -1068,7 +1072,7 @@ def fs_leg(ba, synth, ctx, hmm, om, args, data=None, cpu=None):
     keys = ("window", "strand", "ienv", "jenv", "iali", "jali", "ihmm", "jhmm", "n_shifted_codons")
     strict = {tuple(int(r[k]) for k in keys) for r in dm}
     strict_bits = {tuple(int(r[k]) for k in keys) + (fbits(r["envsc"]),) for r in dm}
-    conc = None if args.no_concurrent else fs_concurrent_leg(ba, hmm, flat, offsets, strict_bits, dt * 1e3)
+    conc = None if args.no_concurrent else fs_concurrent_leg(ba, hmm, flat, offsets, strict_bits, dt * 1e3, main_ctx=ctx if os.environ.get("BATH_BENCH_NO_TRIM") != "1" else None)
     # the same pass in the fast mode (sums along the model by wavefront scans: scores within O(1e-3) nats, outside the 1e-4 contract near zero)
     ctx.set_fs_strict(False)
     pipe.run_frameshift_domains(om3, om5, dna, arrays=True)

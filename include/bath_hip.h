@@ -106,6 +106,10 @@ int         bath_hip_init(int device, bath_hip_ctx **ctx);          /* impl_Init
 void        bath_hip_finalize(bath_hip_ctx *ctx);
 const char *bath_hip_last_error(const bath_hip_ctx *ctx);
 int         bath_hip_synchronize(bath_hip_ctx *ctx);
+/* Release the lanes, side contexts and side streams the context created lazily for the concurrency inside its calls (created
+ * again on demand).  For a context that will sit idle while other contexts of the process work: its streams hold hardware
+ * queues.  Results of earlier calls on the context are invalid afterwards. */
+int         bath_hip_trim(bath_hip_ctx *ctx);
 void       *bath_hip_stream(bath_hip_ctx *ctx);                      /* hipStream_t, for event timing */
 /* Frameshift recursions.  1 (the default): every sum along the model -- D(i,k), E(i), Backward's B(i) -- runs node by node in the
  * reference's order (generic_fwdback_frameshift.c:340-365, :577-590, :1279-1283), so every table log-sum has the reference's
