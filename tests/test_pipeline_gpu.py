@@ -225,3 +225,30 @@ def test_streamed_packed_blocks_equal_resident_blocks(gpu_ctx):
         assert len(res_s) == len(res_r) and st_s.n_past_fwd >= 3
         for f in res_s.dtype.names:
             assert np.array_equal(res_s[f], res_r[f], equal_nan=True), f
+
+
+def test_trim_releases_and_the_next_call_rebuilds(gpu_ctx):
+    """bath_hip_trim: lanes, side contexts and side streams go away; the next pipeline calls create them again and give the same
+    results (cascade counters, --fs domains)."""
+    path = ol.GOLDEN + "/Caudal_act.bhmm"
+    ctx = ba.Context(0)
+    hmm = ba.HMM(path)
+    om = ba.OProfile(ctx, ba.Profile(hmm))
+    om3 = ba.FSOProfile(ctx, ba.FSProfile(hmm, 3, ncbi_table=hmm.ct))
+    om5 = ba.FSOProfile(ctx, ba.FSProfile(hmm, 5, ncbi_table=hmm.ct))
+    rng = np.random.default_rng(3)
+    model = ol.Model(path)
+    wins = common.random_dna(rng, 40, 900) + [common.revtranslate(rng, aa, model.basic) for aa in common.emit_from_model(rng, model, 12, flank=8)]
+    blk = ba.SeqBlock(ctx, wins)
+    pipe = ba.Pipeline(ctx, om, fs_pipe=True, ncbi_table=hmm.ct)
+    key = lambda dm: sorted((d.window, d.ienv, d.jenv, d.iali, d.jali, d.ihmm, d.jhmm, np.float32(d.envsc).view(np.uint32)) for d in dm)
+    s1, _, d1, n1 = pipe.run_frameshift_domains(om3, om5, blk)
+    ctx.trim()
+    s2, _, d2, n2 = pipe.run_frameshift_domains(om3, om5, blk)
+    ctx.trim(); ctx.trim()
+    c1, _ = ba.Pipeline(ctx, om, fs_pipe=False).run(blk)
+    s3, _, d3, n3 = pipe.run_frameshift_domains(om3, om5, blk)
+    assert key(d1) == key(d2) == key(d3) and len(d1) >= 4 and n1 == n2 == n3
+    for f in ("nres", "n_orfs", "n_past_msv", "n_past_fwd", "pos_past_fwd"):
+        assert getattr(s1, f) == getattr(s2, f) == getattr(s3, f)
+    ctx.close()
