@@ -681,9 +681,9 @@ static int wave_grid(bath_hip_ctx *ctx, int64_t njobs) {
   return (int)std::max<int64_t>(1, std::min(blocks, cap));
 }
 
-int launch_msv_wave(bath_hip_ctx *ctx, const bath_hip_oprofile *om, SeqView v, const int32_t *d_todo, int64_t ntodo, float *d_sc, int32_t *d_status, const int *ntodo_dev) {
+int launch_msv_wave(bath_hip_ctx *ctx, const bath_hip_oprofile *om, SeqView v, const int32_t *d_todo, int64_t ntodo, float *d_sc, int32_t *d_status, const int *ntodo_dev, bool lane_ok) {
   if (ntodo == 0) return BATH_OK;
-  {                                                              // models of up to 152 nodes: a lane per target (bath_msv_lane.hip)
+  if (lane_ok) {                                                 // models of up to 152 nodes: a lane per target (bath_msv_lane.hip); not for a few thousand targets
     const int st = launch_msv_lane(ctx, om, v, d_todo, ntodo, d_sc, d_status, ntodo_dev);
     if (st != BATH_ENORESULT) return st;
   }

@@ -43,7 +43,7 @@ struct VitWindowArgs {            // p7_ViterbiFilter_BATH's extra inputs/output
 
 int launch_ssv_lane(bath_hip_ctx *ctx, const bath_hip_oprofile *om, SeqView v, const int32_t *d_order, int16_t *d_v);
 int launch_ssv_classify(bath_hip_ctx *ctx, const bath_hip_oprofile *om, int64_t n, const int32_t *d_len, const int16_t *d_v, float *d_sc, int32_t *d_status);
-int launch_msv_wave(bath_hip_ctx *ctx, const bath_hip_oprofile *om, SeqView v, const int32_t *d_todo, int64_t ntodo, float *d_sc, int32_t *d_status, const int *ntodo_dev);
+int launch_msv_wave(bath_hip_ctx *ctx, const bath_hip_oprofile *om, SeqView v, const int32_t *d_todo, int64_t ntodo, float *d_sc, int32_t *d_status, const int *ntodo_dev, bool lane_ok = true);
 // the same with a lane per target (bath_msv_lane.hip): BATH_OK, an error, or BATH_ENORESULT when the model does not fit a lane's tile
 int launch_msv_lane(bath_hip_ctx *ctx, const bath_hip_oprofile *om, SeqView v, const int32_t *d_todo, int64_t ntodo, float *d_sc, int32_t *d_status, const int *ntodo_dev);
 int launch_vit_wave(bath_hip_ctx *ctx, const bath_hip_oprofile *om, SeqView v, const int32_t *d_todo, int64_t ntodo, float *d_sc, int32_t *d_status,

@@ -723,10 +723,18 @@ static int run_filters(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bat
       BATH_HIP_TRY(ctx, hipStreamWaitEvent(ctx->tail_stream, ev[e - 1], 0));
       ctx->stream = ctx->tail_stream;
     }
+    // The lane-per-ORF kernels pay off when the candidates fill the chip's lanes (65 k of them): a block of 10^9 nt leaves 4 x 10^5
+    // Viterbi candidates, a 25 Mb query of configs[3] 5 x 10^3 -- 80 waves that each last as long as their longest ORF (0.7 ms whatever
+    // their number) where the wave-per-ORF kernel takes 0.2 ms.  The candidate counts live on the device; the block's size is the
+    // host's proxy.  tools/lane_crossover.py, M = 145, windows of 1 kb: Viterbi 0.72 (lane) / 0.19 (wave) ms at 12.5 k windows,
+    // 0.71 / 0.63 at 100 k, 0.75 / 1.11 at 200 k; MSV 0.19 / 0.08, 0.22 / 0.10, 0.23 / 0.13, and 1.08 / 1.41 at 400 k.
+    static const int64_t lane_min_nt = [] { const char *e = std::getenv("BATH_HIP_LANE_MIN_NT"); return e ? std::atoll(e) : (int64_t)150'000'000; }();
+    const bool few_cands = dna->total < lane_min_nt, few_msv = dna->total < 2 * lane_min_nt;
     // 3. SSV status; full MSV for the undecided
     hipLaunchKernelGGL(classify_kernel, dim3(dec_blocks), dim3(256), 0, ctx->stream, W.cand, W.cand_cap, W.ctr, om->lt.d_tjb, mc, W.todo_msv);
     BATH_HIP_TRY(ctx, hipGetLastError());
-    if ((st = launch_msv_wave(ctx, om, cv, W.todo_msv, cap, W.cand.usc, W.cand.msv_status, &W.ctr->todo_msv)) != BATH_OK) return st;
+    // (the lane-per-ORF kernels pay off when the candidates fill the chip's lanes: see few_cands at the Viterbi stage below)
+    if ((st = launch_msv_wave(ctx, om, cv, W.todo_msv, cap, W.cand.usc, W.cand.msv_status, &W.ctr->todo_msv, !few_msv)) != BATH_OK) return st;
     BATH_HIP_TRY(ctx, hipEventRecord(ev[e++], ctx->stream));
     // 3. F1 on the MSV score, bias filter
     hipLaunchKernelGGL(f1_bias_kernel, dim3(dec_blocks), dim3(256), 0, ctx->stream, W.cand, W.cand_cap, W.ctr, P, W.pool, M, om->d_bias_eo,
@@ -755,7 +763,7 @@ static int run_filters(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bat
       return BATH_OK;
     };
     bool ssvb_done = false;
-    if (vit_lane_supported(om)) {       // lane per ORF, ORFs bucketed by length (bath_viterbi.hip)
+    if (vit_lane_supported(om) && !few_cands) {       // lane per ORF, ORFs bucketed by length (bath_viterbi.hip)
       if ((st = launch_len_sort(ctx, W.todo_vit, &W.ctr->todo_vit, W.cand.len, W.len_bins, W.todo_sorted)) != BATH_OK) return st;
       // The lane kernel runs one wave per SIMD and a wave takes as long as its longest ORF (3.6 us per residue): the few
       // long ORFs at the head of the sorted list would set the duration of the whole stage.  They go to the

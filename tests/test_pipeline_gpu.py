@@ -72,6 +72,20 @@ def test_cascade_matches_oracle(gpu_ctx, name, fs):
     assert stats.n_past_fwd > 0 and stats.n_past_msv > stats.n_past_fwd      # the set exercises every stage
 
 
+def test_cascade_with_lane_kernels_forced(monkeypatch):
+    """Blocks below 150 M nt (every test block) take the wave-per-ORF MSV / Viterbi kernels since round 4 (few candidates: bath_pipeline.hip,
+    few_cands); the bench's blocks take the lane-per-ORF kernels with the length sort and the long-ORF split.  BATH_HIP_LANE_MIN_NT=0
+    (read once per process) forces that path onto the test blocks: the oracle comparisons and the reference's recorded counters
+    again, in a fresh process."""
+    import os, subprocess, sys
+    env = dict(os.environ, BATH_HIP_LANE_MIN_NT="0")
+    p = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                        "-k", "test_cascade_matches_oracle or test_reference_recorded_counters or test_concurrent_lanes"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1500,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert p.returncode == 0 and " passed" in p.stdout and "failed" not in p.stdout, p.stdout[-3000:]
+
+
 GOLDEN_RUNS = [  # (model file, index, target fasta, counters printed by the reference: p7_pli_Statistics)
     ("PTH2.bhmm", 0, "target-PTH2.fa", (6000, 1503, 1503, 1401, 1287)),
     ("AMP_N.bhmm", 0, "target-AMP_N.fa", (822, 537, 537, 393, 237)),
