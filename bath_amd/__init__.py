@@ -76,7 +76,8 @@ class OProfileScalars(C.Structure):
 
 class PipelineParams(C.Structure):
     _fields_ = [("F1", C.c_double), ("F2", C.c_double), ("F3", C.c_double), ("F4", C.c_double),
-                ("do_biasfilter", C.c_int32), ("fs_pipe", C.c_int32), ("min_orf_len", C.c_int32), ("ncbi_table", C.c_int32)]
+                ("do_biasfilter", C.c_int32), ("fs_pipe", C.c_int32), ("min_orf_len", C.c_int32), ("ncbi_table", C.c_int32),
+                ("nres_before", C.c_int64)]
 
 
 class OrfResult(C.Structure):
@@ -664,12 +665,14 @@ class Pipeline:
             wins.append(w)
         return stats, out, wins
 
-    def run_hits(self, dna, E_report=10.0, arrays=False):
+    def run_hits(self, dna, E_report=10.0, arrays=False, nres_before=0):
         """bathsearch (no --fs) through domain definition and hit scores: (stats, [FsDomain], multi-domain regions skipped).
         arrays=True: (stats, HitArray, regions) -- the records as ONE numpy record array and the CIGAR strings as one bytes pool,
         copied out of the library with two memcpys instead of a Python object per hit (what TopHits.add_arrays and
-        dist.gather_query_hits take)."""
+        dist.gather_query_hits take).  nres_before: the residues the search counted before this block's first window (both strands;
+        pli->nres on entry) -- with it a search cut into blocks reports the hits of the same search run as one block."""
         stats = PipelineStats()
+        self.params.nres_before = int(nres_before)
         dm = C.POINTER(FsDomain)(); ndm = C.c_int64(0)
         nskip = C.c_int64(0)
         self.ctx._check(lib().bath_hip_pipeline_hits(self.ctx._h, self.om._h, dna._h, C.byref(self.params), E_report, C.byref(stats),
@@ -698,11 +701,12 @@ class Pipeline:
             out.append(x)
         return out
 
-    def run_frameshift_domains(self, om_fs3, om_fs5, dna, E_report=10.0, arrays=False):
+    def run_frameshift_domains(self, om_fs3, om_fs5, dna, E_report=10.0, arrays=False, nres_before=0):
         """bathsearch --fs through domain definition: (stats, [FsWindow], [FsDomain], multi-domain regions skipped).
         arrays=True: the windows and domains as numpy record arrays viewing the library's own memory (valid until the next
-        pipeline call), without the per-record Python objects and CIGAR strings."""
+        pipeline call), without the per-record Python objects and CIGAR strings.  nres_before: as in run_hits."""
         stats = PipelineStats()
+        self.params.nres_before = int(nres_before)
         fw = C.POINTER(FsWindow)(); nfw = C.c_int64(0)
         dm = C.POINTER(FsDomain)(); ndm = C.c_int64(0)
         nskip = C.c_int64(0)

@@ -109,8 +109,25 @@ std::string cigar_from_columns(const uint16_t *S, int n) {
 
 }  // namespace
 
+// pli->nres as the reference's serial loop has it when it searches strand s of window w: every earlier window's W on both strands, this
+// window's W once (top strand) or twice (bathsearch.c:1071, :1084; windows under 15 nt are skipped before the count, :1066), on top
+// of what the search counted before this block.  pli->Z = (float) nres / (float) max_length (p7_domaindef.c:1033, p7_pipeline.c:1246).
+struct RunningZ {
+  std::vector<int64_t> before;          // [nwin] residues counted before window w
+  const bath_hip_seqs *dna;
+  RunningZ(const bath_hip_seqs *d, int64_t nres_before) : before((size_t)d->n), dna(d) {
+    int64_t acc = nres_before;
+    for (int64_t w = 0; w < d->n; w++) { before[(size_t)w] = acc; acc += 2 * W(w); }
+  }
+  int64_t W(int64_t w) const {
+    const int n = dna->h_len[(size_t)w];
+    return n < 15 ? 0 : (int64_t)(n - (dna->h_context.empty() ? 0 : dna->h_context[(size_t)w]));
+  }
+  float Z(int64_t w, int strand, int max_length) const { return (float)(before[(size_t)w] + (strand ? 2 : 1) * W(w)) / (float)max_length; }
+};
+
 static int std_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bath_hip_seqs *dna, const std::vector<PipelineSurvivor> &surv,
-                       const uint8_t *d_pool, int64_t nres, double E_report, int64_t *n_clustered_regions);
+                       const uint8_t *d_pool, int64_t nres_before, double E_report, int64_t *n_clustered_regions);
 
 
 static int fs_branch_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bath_hip_fsprofile *om_fs3,
@@ -163,10 +180,10 @@ static int fs_branch_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, con
     if ((st = om->ensure_len_tables(dna->maxlen / 3 + 1)) != BATH_OK) return st;      // the profile's mutable state: fill it before the thread starts
     bath_hip_ctx *aux = ctx->aux;
     aux->fs_domains.clear(); aux->cigars.clear();
-    const int64_t nres = st_local.nres;
-    std_thread = std::thread([&, aux, nres] {
+    const int64_t nres_before = prm->nres_before;
+    std_thread = std::thread([&, aux, nres_before] {
       if (hipSetDevice(ctx->device) != hipSuccess) { std_rc = BATH_EFAIL; return; }
-      std_rc = std_domains(aux, om, dna, ctx->fs_std_orfs, ctx->fs_std_pool, nres, E_report, &std_nclust);
+      std_rc = std_domains(aux, om, dna, ctx->fs_std_orfs, ctx->fs_std_pool, nres_before, E_report, &std_nclust);
     });
   }
   struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } };
@@ -380,13 +397,14 @@ static int fs_branch_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, con
 
   // ---- traceback, null2 along the trace, the hit's scores
   const int ml = h5.max_length;
-  const float Zf = (float)st_local.nres / (float)ml;                          // pli->Z, p7_domaindef.c:1033 (here: residues of the block)
+  const RunningZ runZ(dna, prm->nres_before);                                 // pli->Z, p7_domaindef.c:1033: the count at the hit's window and strand
   for (int e = 0; e < nenv; e++) {
     const Env &en = envs[(size_t)e];
     const bath_fs_window &win = fw[sel[(size_t)en.sel]];
     const int Ld = eregs[(size_t)e].len;
     const float envsc = res[(size_t)e].fwdsc;
     if (!(envsc > -INFINITY) || !(res[(size_t)e].bcksc > -INFINITY)) continue;
+    const float Zf = runZ.Z(win.window, win.strand, ml);
     {
       const float p1 = (float)(Ld / 3) / (float)(Ld / 3 + 1);
       const float per_frame = (float)((float)(Ld / 3) * std::log((double)p1) + std::log(1. - p1));
@@ -455,7 +473,7 @@ extern "C" int bath_hip_pipeline_frameshift_domains(bath_hip_ctx *ctx, const bat
   StageClock clk;
   if (std_clustered >= 0) nclust += std_clustered;
   else {
-    if ((st = std_domains(ctx, om, dna, ctx->fs_std_orfs, ctx->fs_std_pool, st_local.nres, E_report, &nclust)) != BATH_OK) return st;
+    if ((st = std_domains(ctx, om, dna, ctx->fs_std_orfs, ctx->fs_std_pool, prm->nres_before, E_report, &nclust)) != BATH_OK) return st;
     clk.lap("fs: standard-branch domains");
   }
   if (n_clustered_regions) *n_clustered_regions = nclust;
@@ -975,7 +993,7 @@ __global__ __launch_bounds__(256) void std_envelope_fill_kernel(SeqView sq, int 
 
 // Domain definition and hit scores for ORFs that passed the Forward filter; appends to ctx->fs_domains.
 static int std_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bath_hip_seqs *dna, const std::vector<PipelineSurvivor> &surv,
-                       const uint8_t *d_pool, int64_t nres, double E_report, int64_t *n_clustered_regions) {
+                       const uint8_t *d_pool, int64_t nres_before, double E_report, int64_t *n_clustered_regions) {
   int st;
   const int64_t ns = (int64_t)surv.size();
   if (ns == 0) return BATH_OK;
@@ -1180,13 +1198,14 @@ static int std_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bat
 
   // ---- p7_pli_postDomainDef_BATH: coordinates on the sequence, score corrections, P-value
   const int ml = om->max_length;
-  const float Zf = (float)nres / (float)ml;
+  const RunningZ runZ(dna, nres_before);                                     // pli->Z, p7_pipeline.c:1246: the count at the hit's window and strand
   for (int64_t e = 0; e < ne; e++) {
     const StdEnvOut &t = eo[(size_t)e];
     if (!t.ok) continue;
     if (t.aliscore < 0.0f) continue;                                         // p7_domaindef.c:1286: "repetitive garbage", no domain
     const Env &en = envs[(size_t)e];
     const PipelineSurvivor &o = surv[(size_t)en.s];
+    const float Zf = runZ.Z(o.window, o.strand, ml);
     const int seq_n = dna->h_len[(size_t)o.window];
     bath_fs_domain dm{};
     dm.window = o.window; dm.strand = o.strand; dm.fs_window = o.fs_window;
@@ -1254,7 +1273,7 @@ extern "C" int bath_hip_pipeline_hits(bath_hip_ctx *ctx, const bath_hip_oprofile
   clk.lap("std: cascade + survivors to the host");
   if (stats) *stats = st_local;
   for (PipelineSurvivor &o : surv) o.win_start = o.start;                  // windowsq is the ORF's own stretch of DNA (p7_pipeline.c:1755)
-  if ((st = std_domains(ctx, om, dna, surv, d_pool, st_local.nres, E_report, &nclust)) != BATH_OK) return st;
+  if ((st = std_domains(ctx, om, dna, surv, d_pool, prm.nres_before, E_report, &nclust)) != BATH_OK) return st;
   if (n_clustered_regions) *n_clustered_regions = nclust;
   *domains = ctx->fs_domains.data(); *n_domains = (int64_t)ctx->fs_domains.size();
   return BATH_OK;

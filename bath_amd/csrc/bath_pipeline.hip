@@ -582,6 +582,7 @@ static size_t layout(PipelineWork &w, char *base, int cap, int win_cap) {
 extern "C" void bath_pipeline_params_default(bath_pipeline_params *p, int fs_pipe) {   // p7_pipeline.c:219-222, bathsearch.c:104
   p->F1 = 0.02; p->F2 = 1e-3; p->F3 = 1e-5; p->F4 = 5e-4;
   p->do_biasfilter = 1; p->fs_pipe = fs_pipe; p->min_orf_len = 20; p->ncbi_table = 1;
+  p->nres_before = 0;
 }
 
 extern "C" int bath_hip_pipeline_timings(const bath_hip_ctx *ctx, int max, const char **names, float *ms, int64_t *launches) {

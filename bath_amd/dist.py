@@ -167,6 +167,24 @@ def query_items(n_windows_by_query, world, items_per_rank=2):
     return items
 
 
+def query_items_weighted(n_windows_by_query, costs_by_query, world, items_per_rank=3):
+    """[(query, lo, hi)] like query_items, but a query gets groups in proportion to its share of the work: round(share x T) of them,
+    at least one, T = max(queries, items_per_rank x world).  With worker contexts running a rank's items side by side the longest
+    item is the critical path, so the 459-node model of a 12-model database is cut in two even on one rank while the short models
+    stay whole (every extra item repeats a search's fixed cost).  The same on every rank, no communication."""
+    nq = len(n_windows_by_query)
+    total = float(sum(costs_by_query)) or 1.0
+    T = max(nq, items_per_rank * world)
+    items = []
+    for q, n in enumerate(n_windows_by_query):
+        g = max(1, min(int(costs_by_query[q] / total * T + 0.5), n))
+        for k in range(g):
+            lo, hi = shard_range(n, k, g)
+            if hi > lo:
+                items.append((q, lo, hi))
+    return items
+
+
 def deal(costs, world):
     """Owner rank of every item: longest processing time first onto the least loaded rank (ties: lowest rank); the same on every
     rank, no communication."""

@@ -445,28 +445,59 @@ def c4_leg_ranks(ba, synth, bdist, ctx, args, rank, world, dev, on_gpu, sync, to
     os.unlink(tmp)
     n_nt = int(total_mb * 1e6)
     all_wins = [bdist.split_targets([n_nt], h.max_length) for h in hmms]
-    items = bdist.query_items([len(w) for w in all_wins], world)
+    items = bdist.query_items_weighted([len(w) for w in all_wins], [sum(n for _, _, n, _ in w) * (h.M + 150.0) for w, h in zip(all_wins, hmms)], world)
     owner = bdist.deal([sum(n for _, _, n, _ in all_wins[q][lo:hi]) * (hmms[q].M + 150.0) for q, lo, hi in items], world)
     mine = [it for it, o in zip(items, owner) if o == rank]
+    # A rank's items go to worker contexts of its GPU (host threads, one context each): a query's search is a chain of small launches
+    # and host steps that leaves the chip mostly idle, so the items of a rank run side by side like the queries of c4.concurrent_queries
+    # (BATH_BENCH_C4_RANK_WORKERS, default 6; 1: one after the other on the rank's main context).
+    import threading
+    cost = lambda it: sum(n for _, _, n, _ in all_wins[it[0]][it[1]:it[2]]) * (hmms[it[0]].M + 150.0)
+    nwk = max(1, min(int(os.environ.get("BATH_BENCH_C4_RANK_WORKERS", "6")), len(mine)))
+    wctx, wjobs = [], []
     if on_gpu:
         g, planted = synth.genome(n_nt, seed=4300, hmms=hmms, genes_per_model=max(4, n_nt // 400_000))
-        jobs = []
-        for q, lo, hi in mine:
-            om = ba.OProfile(ctx, ba.Profile(hmms[q]))
-            pipe = ba.Pipeline(ctx, om, fs_pipe=False, ncbi_table=hmms[q].ct)
-            blk = ba.SeqBlock(ctx, [g[s_:s_ + n] for _, s_, n, _ in all_wins[q][lo:hi]]); blk.set_context([c for _, _, _, c in all_wins[q][lo:hi]])
-            pipe.run_hits(blk)
-            jobs.append((q, lo, om, pipe, blk))
+        wown = bdist.deal([cost(it) for it in mine], nwk)
+        for w in range(nwk):
+            c = ctx if nwk == 1 else ba.Context(dev.index or 0)
+            jobs = []
+            for (q, lo, hi), o in zip(mine, wown):
+                if o != w:
+                    continue
+                om = ba.OProfile(c, ba.Profile(hmms[q]))
+                pipe = ba.Pipeline(c, om, fs_pipe=False, ncbi_table=hmms[q].ct)
+                blk = ba.SeqBlock(c, [g[s_:s_ + n] for _, s_, n, _ in all_wins[q][lo:hi]]); blk.set_context([cc for _, _, _, cc in all_wins[q][lo:hi]])
+                before = 2 * sum(n - cc for _, _, n, cc in all_wins[q][:lo])    # what the query's search counted before this group (both strands)
+                pipe.run_hits(blk, nres_before=before)
+                jobs.append((q, lo, before, pipe, blk))
+            wctx.append(c); wjobs.append(jobs)
 
-    def one_pass(my_jobs):
-        by_q, st_q = {}, {}
-        for q, lo, _, pipe, blk in my_jobs:
-            st, dm, _ = pipe.run_hits(blk, arrays=True)                 # one record array + one CIGAR pool per item: no Python per hit
+    def worker_pass(w, out):
+        res = []
+        for q, lo, before, pipe, blk in wjobs[w]:
+            st, dm, _ = pipe.run_hits(blk, arrays=True, nres_before=before)     # one record array + one CIGAR pool per item: no Python per hit
             dm.rec["window"] += lo
-            by_q.setdefault(q, []).append(dm)
-            acc = st_q.setdefault(q, dict.fromkeys(bdist.STAT_FIELDS, 0))
-            for f in bdist.STAT_FIELDS:
-                acc[f] += int(getattr(st, f))
+            res.append((q, dm, st))
+        wctx[w].synchronize()
+        out[w] = res
+
+    def one_pass():
+        outs = [None] * nwk
+        if nwk == 1:
+            worker_pass(0, outs)
+        else:
+            th = [threading.Thread(target=worker_pass, args=(w, outs)) for w in range(nwk)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+        by_q, st_q = {}, {}
+        for res in outs:
+            for q, dm, st in res:
+                by_q.setdefault(q, []).append(dm)
+                acc = st_q.setdefault(q, dict.fromkeys(bdist.STAT_FIELDS, 0))
+                for f in bdist.STAT_FIELDS:
+                    acc[f] += int(getattr(st, f))
         return by_q, st_q
 
     steps = 2
@@ -476,8 +507,7 @@ def c4_leg_ranks(ba, synth, bdist, ctx, args, rank, world, dev, on_gpu, sync, to
     for _ in range(steps):
         tb = time.perf_counter()
         if on_gpu:
-            by_q, st_q = one_pass(jobs)
-            ctx.synchronize()
+            by_q, st_q = one_pass()
         else:                                                           # --plumbing-only: fabricated hits, the deal and the collectives are what runs
             by_q, st_q = {}, {}
             for q, lo, hi in mine:
@@ -500,11 +530,16 @@ def c4_leg_ranks(ba, synth, bdist, ctx, args, rank, world, dev, on_gpu, sync, to
     sync()
     dt = bdist.max_over_ranks((time.perf_counter() - t0) / steps, dev)
     busy_all = bdist.gather_floats(busy / steps * 1e3, 0, dev)
+    if on_gpu and nwk > 1:
+        for jobs in wjobs:
+            jobs.clear()
+        for c in wctx:
+            c.close()
     if rank != 0:
         return None
     out = {"workload": "tRNA-proteins.bhmm (12 query models, broadcast once) vs ONE %.0f Mb synthetic genome: (query, window group) pairs dealt to %d rank(s), "
                        "hits and counters gathered per query on rank 0 and every query finished there (strong scaling)" % (total_mb, world),
-           "n_gpus": world, "scaling": "strong", "items": len(items), "items_per_rank": [owner.count(r) for r in range(world)],
+           "n_gpus": world, "scaling": "strong", "items": len(items), "items_per_rank": [owner.count(r) for r in range(world)], "worker_contexts_per_rank": nwk,
            "ms_per_database_pass": dt * 1e3, "rank_busy_ms": busy_all, "rank0_gather_ms": t_gather / steps * 1e3, "rank0_finish_ms": t_finish / steps * 1e3,
            "residues_per_s": sum(m["nres"] for m in merged) / dt, "hits": int(sum(t[0] for t in tables)), "hits_per_query": [t[0] for t in tables],
            "tables_sha1": hashlib.sha1("".join(t[1] for t in tables).encode()).hexdigest()[:16]}
@@ -537,13 +572,14 @@ def c5_leg_ranks(ba, synth, bdist, ctx, args, rank, world, dev, on_gpu, sync, to
         pipe = ba.Pipeline(ctx, om, fs_pipe=True, ncbi_table=hmm.ct)
         blk = ba.SeqBlock(ctx, [g[s_:s_ + n] for _, s_, n, _ in wins[lo:hi]]); blk.set_context([c for _, _, _, c in wins[lo:hi]])
         del g
-        pipe.run_frameshift_domains(om3, om5, blk)
+        before = 2 * sum(n - c for _, _, n, c in wins[:lo])               # what the search counted before this rank's shard (both strands)
+        pipe.run_frameshift_domains(om3, om5, blk, nres_before=before)
     steps = 2
     sync()
     t0 = time.perf_counter()
     for _ in range(steps):
         if on_gpu:
-            stats, fw, dm, _ = pipe.run_frameshift_domains(om3, om5, blk)
+            stats, fw, dm, _ = pipe.run_frameshift_domains(om3, om5, blk, nres_before=before)
         else:
             stats = ba.PipelineStats(); stats.nres = 2 * sum(n - c for _, _, n, c in wins[lo:hi])
             dm = []
@@ -979,13 +1015,14 @@ def fs_leg_ranks(ba, synth, bdist, dist, ctx, hmm, om, args, rank, world, dev, o
         om3 = ba.FSOProfile(ctx, ba.FSProfile(hmm, 3, ncbi_table=hmm.ct))
         om5 = ba.FSOProfile(ctx, ba.FSProfile(hmm, 5, ncbi_table=hmm.ct))
         pipe = ba.Pipeline(ctx, om, fs_pipe=True, ncbi_table=hmm.ct)
-        pipe.run_frameshift_domains(om3, om5, dna)
+        before = 2 * args.length * lo                                      # what the search counted before this rank's shard (both strands)
+        pipe.run_frameshift_domains(om3, om5, dna, nres_before=before)
     steps = 2
     sync()
     t0 = time.perf_counter()
     for _ in range(steps):
         if on_gpu:
-            stats, fw, dm, nskip = pipe.run_frameshift_domains(om3, om5, dna)
+            stats, fw, dm, nskip = pipe.run_frameshift_domains(om3, om5, dna, nres_before=before)
         else:                                              # --plumbing-only: fabricated records, the collectives are what runs
             stats = ba.PipelineStats(); stats.nres = 2 * (hi - lo) * args.length
             dm = []

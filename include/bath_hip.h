@@ -210,6 +210,12 @@ int bath_hip_ssvfilter_bath(bath_hip_ctx *ctx, const bath_hip_oprofile *om, cons
 typedef struct {
   double  F1, F2, F3, F4;         /* p7_pipeline.c:219-222 */
   int32_t do_biasfilter, fs_pipe, min_orf_len, ncbi_table;
+  /* pli->nres on entry: the residues this search counted before the block's first window, both strands (bathsearch.c:1071,
+   * :1084, :1258, :1268 add a window's W per strand before the window is searched).  The domain stage drops / flags a hit by
+   * P * nres_running / max_length > E with the count AT THE HIT'S WINDOW AND STRAND (p7_domaindef.c:1033, p7_pipeline.c:1079,
+   * :1246), so the hits of a block do not depend on how a search is cut into blocks as long as every block is told where it
+   * starts; 0 for a search's first (or only) block. */
+  int64_t nres_before;
 } bath_pipeline_params;
 
 typedef struct {                   /* one per ORF that passed the MSV filter (P <= F1) */

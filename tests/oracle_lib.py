@@ -326,12 +326,14 @@ class Model:
         out = [res[i] for i in range(nres.value)]
         return pli, out, per_seq
 
-    def run_pipeline_hits(self, seqs, contexts=None):
+    def run_pipeline_hits(self, seqs, contexts=None, E=None):
         """The plain pipeline through domain definition: (Pipeline counters, FsDomain records, per-sequence ranges, skipped).
         contexts[i]: ESL_SQ.C of window i (leading nucleotides shared with the previous window of the same target)."""
         L_ = lib()
         pli = Pipeline()
         L_.bo_pipeline_init(C.byref(pli), 0)
+        if E is not None:
+            pli.E = E                                          # the reporting threshold (-E, p7_pipeline.c:147)
         res = C.POINTER(OrfResult)(); nres, alloc = C.c_int(0), C.c_int(0)
         dm = C.POINTER(FsDomain)(); ndm, dmalloc, nskip = C.c_int(0), C.c_int(0), C.c_int(0)
         per_d = []
@@ -344,7 +346,7 @@ class Model:
             per_d.append((d0, ndm.value))
         return pli, [dm[i] for i in range(ndm.value)], per_d, nskip.value
 
-    def run_pipeline_fsdom(self, seqs, contexts=None):
+    def run_pipeline_fsdom(self, seqs, contexts=None, E=None):
         """run_pipeline_fs plus domain definition and hit scores for the windows that take the frameshift branch.
         contexts[i]: ESL_SQ.C of window i (as in run_pipeline_hits).
 
@@ -353,6 +355,8 @@ class Model:
         L_ = lib()
         pli = Pipeline()
         L_.bo_pipeline_init(C.byref(pli), 1)
+        if E is not None:
+            pli.E = E
         gm3, gm5 = self.fs(3), self.fs(5)
         res = C.POINTER(OrfResult)(); nres, alloc = C.c_int(0), C.c_int(0)
         fw = C.POINTER(FsWindow)(); nfw, fwalloc = C.c_int(0), C.c_int(0)

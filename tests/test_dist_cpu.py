@@ -120,8 +120,9 @@ def test_bench_launcher_starts_the_ranks(scaling):
     # configs[3] under --gpus N: the 12-model database broadcast once, (query, window group) pairs dealt to the ranks, hits gathered
     # per query on rank 0 and every query finished there; configs[4]: window shards, domains gathered
     c4 = out["c4"]
-    assert c4["n_gpus"] == 2 and c4["items"] == 12 and c4["items_per_rank"] == [6, 6] and len(c4["rank_busy_ms"]) == 2
-    assert c4["hits_per_query"] == [1] * 12 and c4["hits"] == 12
+    # 13 items: the 459-node model's windows are cut in two (dist.query_items_weighted); one fabricated hit per item
+    assert c4["n_gpus"] == 2 and c4["items"] == 13 and sorted(c4["items_per_rank"]) == [6, 7] and len(c4["rank_busy_ms"]) == 2
+    assert c4["hits_per_query"] == [1, 1, 1, 2] + [1] * 8 and c4["hits"] == 13
     c5 = out["c5"]
     assert c5["n_gpus"] == 2 and c5["domains_gathered"] == 4 and c5["windows_of_gathered_domains_are_global"]
 
@@ -204,3 +205,20 @@ def test_deal_is_balanced_and_deterministic():
         assert max(load) <= sum(costs) / world + max(costs)                         # LPT bound
         items = query_items([382] * 12, world)
         assert len(items) >= min(2 * world, 12) and all(hi > lo for _, lo, hi in items)
+
+
+def test_weighted_items_cut_the_heavy_queries_and_cover_every_window():
+    from bath_amd.dist import query_items_weighted
+    M = [78, 152, 116, 459, 238, 131, 121, 185, 192, 247, 136, 56]
+    nwin = [382] * 12
+    costs = [n * (m + 150.0) for n, m in zip(nwin, M)]
+    for world in (1, 2, 4, 8):
+        items = query_items_weighted(nwin, costs, world)
+        assert items == query_items_weighted(list(nwin), list(costs), world)          # every rank computes the same list
+        for q in range(12):                                                           # a query's groups tile its windows, in order
+            mine = [(lo, hi) for qq, lo, hi in items if qq == q]
+            assert mine[0][0] == 0 and mine[-1][1] == nwin[q] and all(a[1] == b[0] for a, b in zip(mine, mine[1:]))
+        groups = [sum(1 for qq, _, _ in items if qq == q) for q in range(12)]
+        assert groups[3] == max(groups) and groups[3] >= 2 and groups[11] == 1        # the 459-node model is cut, the 56-node one never
+        assert len(items) <= max(12, 3 * world) + 6
+    assert query_items_weighted([1, 1], [5.0, 1.0], 8) == [(0, 0, 1), (1, 0, 1)]      # never more groups than windows

@@ -117,3 +117,73 @@ def test_contexts_survive_the_split_into_concurrent_parts(monkeypatch, lanes):
     pli, _, _, _ = model.run_pipeline_hits(seqs, contexts=ctxs)
     assert out[0][0] == (pli.nres, pli.n_past_msv, pli.pos_past_msv, pli.pos_past_bias, pli.pos_past_vit, pli.pos_past_fwd)
     assert pli.nres == 2 * len(genome)
+
+
+def _records(dm, lo=0):
+    return sorted((int(d.window) + lo, int(d.strand), d.ienv, d.jenv, d.iali, d.jali, d.ihmm, d.jhmm, int(d.reported),
+                   int(np.float32(d.envsc).view(np.uint32)), int(np.float32(d.bitscore).view(np.uint32)), float(d.lnP)) for d in dm)
+
+
+@pytest.mark.parametrize("hmmfile,fs", [("PTH2.bhmm", False), ("Caudal_act.bhmm", False), ("Caudal_act.bhmm", True)])
+def test_blocks_of_a_search_report_what_the_whole_search_reports(hmmfile, fs):
+    """The early E-value test of the domain stage uses pli->nres as it stands when the hit's window and strand are searched
+    (p7_pipeline.c:1246, p7_domaindef.c:1033; bathsearch.c:1071 / :1084 count a window's W before each strand): a hit that is
+    reported in the search's first windows can be dropped in its last.  bath_pipeline_params.nres_before tells a block where in the
+    search it starts, so a search cut into blocks (ranks, worker contexts: bench.py's configs[3] / configs[4] legs) gives record for
+    record -- the `reported` flag included -- the domains of the search run as one block, and both agree with the oracle's serial loop.
+    The inputs hold hits on both sides of the threshold: many weak planted fragments, E_report small enough to cut through them."""
+    ctx = ba.Context(0)
+    path = ol.GOLDEN + "/" + hmmfile
+    model = ol.Model(path, 0)
+    hmm = ba.HMM(path, 0)
+    rng = np.random.default_rng(99)
+    L = 300000
+    g = rng.integers(0, 4, size=L).astype(np.uint8)
+    frags = common.emit_from_model(rng, model, 60, flank=1, sharpen=1.5)
+    for aa, p in zip(frags, rng.integers(500, L - 3000, size=len(frags))):
+        aa = aa[: max(12, len(aa) // int(rng.integers(1, 5)))]                      # whole domains and weak pieces of them
+        nt = np.array(common.revtranslate(rng, aa, model.basic), dtype=np.uint8)
+        if fs and len(nt) > 60 and rng.integers(0, 2):                              # a frameshift: one nucleotide lost mid-gene
+            nt = np.delete(nt, len(nt) // 2 + int(rng.integers(-9, 10)))
+        if rng.integers(0, 2):
+            nt = (3 - nt[::-1]).astype(np.uint8)
+        g[p:p + len(nt)] = nt
+    wins = bd.split_targets([L], hmm.max_length, 20000)
+    seqs = [g[s:s + n] for _, s, n, _ in wins]
+    ctxs = [c for _, _, _, c in wins]
+    om = ba.OProfile(ctx, ba.Profile(hmm))
+    pipe = ba.Pipeline(ctx, om, fs_pipe=fs, ncbi_table=hmm.ct)
+    om3 = ba.FSOProfile(ctx, ba.FSProfile(hmm, 3, ncbi_table=hmm.ct)) if fs else None
+    om5 = ba.FSOProfile(ctx, ba.FSProfile(hmm, 5, ncbi_table=hmm.ct)) if fs else None
+    E = 1e-3 if hmmfile == "PTH2.bhmm" else 1e-4
+
+    def run(lo, hi, before):
+        blk = ba.SeqBlock(ctx, seqs[lo:hi]); blk.set_context(ctxs[lo:hi])
+        if fs:
+            st, _, dm, _ = pipe.run_frameshift_domains(om3, om5, blk, E_report=E, nres_before=before)
+        else:
+            st, dm, _ = pipe.run_hits(blk, E_report=E, nres_before=before)
+        return st, _records(dm, lo)
+
+    st, whole = run(0, len(wins), 0)
+    n_rep = sum(r[8] for r in whole)
+    assert len(whole) >= 20 and 5 <= n_rep <= len(whole) - 5, (len(whole), n_rep)                 # hits on both sides of the threshold
+    for G in (2, 5):
+        parts, nres = [], 0
+        for k in range(G):
+            lo, hi = bd.shard_range(len(wins), k, G)
+            stp, recs = run(lo, hi, 2 * sum(n - c for _, _, n, c in wins[:lo]))
+            parts += recs; nres += int(stp.nres)
+        assert nres == int(st.nres) and sorted(parts) == whole, G
+    # without the offset the later blocks count from zero and keep more: the flag is what differs
+    lo, hi = bd.shard_range(len(wins), 1, 2)
+    _, late = run(lo, hi, 0)
+    assert sum(r[8] for r in late) >= sum(r[8] for r in whole if r[0] >= lo)
+    # the oracle's serial loop (one pipeline object, its running count): the same flags window by window
+    if fs:
+        _, _, _, odm, per_d, _ = model.run_pipeline_fsdom(seqs, contexts=ctxs, E=E)
+    else:
+        _, odm, per_d, _ = model.run_pipeline_hits(seqs, contexts=ctxs, E=E)
+    want = sorted((w, o.ienv, o.jenv, o.iali, o.jali, o.ihmm, o.jhmm, int(o.reported)) for w, (a, b) in enumerate(per_d) for o in odm[a:b])
+    got = sorted((r[0],) + r[2:9] for r in whole)
+    assert got == want

@@ -94,6 +94,9 @@ def compare_hits(dm, odm, per_d, nskip, onskip):
         o = lst.pop()
         assert g.strand == (1 if o.ienv > o.jenv else 0)
         assert abs(g.envsc - o.envsc) <= 1e-4 * max(1.0, abs(o.envsc))
+        # the early E-value test with the running residue count of the hit's window and strand (p7_pipeline.c:1246); a P-value within
+        # its tolerance of the threshold could fall on either side
+        assert g.reported == o.reported or abs(g.lnP - o.lnP) > 0.0, (g.window, g.lnP, o.lnP)
         assert abs(g.oasc - o.oasc) <= 2e-3 + 1e-3 * abs(o.oasc)
         n2tol = 2e-3 + 1e-3 * abs(o.domcorrection)
         if abs(g.domcorrection - o.domcorrection) > n2tol:
