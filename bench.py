@@ -28,6 +28,11 @@ are reduced and the ORF records gathered on rank 0 (point to point, nothing repl
 import argparse
 import json
 import os
+# HIP maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), read once when the runtime starts.  The legs with
+# many worker contexts launching small kernels at the same time (c4.concurrent_queries, c4.full_job: 9 host threads, a dozen streams)
+# queue up behind one another on 4: 18.0 -> 14.5 ms per configs[3] database pass with 16; the cascade, the --fs pass and its two-worker
+# leg are unchanged (10.7 / 67-68 / 57-59 ms with either).  INTEGRATION.md recommends the same to a host that runs several contexts.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 import socket
 import subprocess
 import sys
@@ -283,35 +288,46 @@ def c4_leg(ba, synth, bdist, ctx, args, cpu):
         per_model.append({"name": hmm.name, "M": hmm.M, "ms": ms, "hits": int(sum(d.reported for d in dm)), "planted_found": found,
                           "planted": sum(1 for qq, _, _ in planted if qq == q), "clustered_regions": int(nskip), "cascade_stage_ms": stage})
         tot_ms += ms; tot_res += st.nres; tot_cells += cells; tot_hits += int(sum(d.reported for d in dm))
-    # The same database pass with the queries spread over four worker contexts (a query's search is a dozen small launches and
+    # The same database pass with the queries spread over worker contexts (a query's search is a dozen small launches and
     # host steps: one query at a time leaves the chip idle most of the time; bathsearch's own loop is serial per query, its
     # worker threads split the target -- on a GPU the queries are the parallelism that is left for a genome this small).
     import threading
-    nw = int(os.environ.get("BATH_BENCH_C4_WORKERS", "6"))
-    order = sorted(range(len(hmms)), key=lambda q: -hmms[q].M)      # long models first, dealt out in turn
+    nw = int(os.environ.get("BATH_BENCH_C4_WORKERS", "9"))
+    # items as in the N-rank leg: (query, group of consecutive windows), a query cut in proportion to its share of the work (the 459-node
+    # model in two), dealt longest-first onto the least loaded worker; an item carries the residue count the query's search has
+    # reached at its first window (nres_before), so its hits are those of the query searched as one block
+    all_wins = [bdist.split_targets([len(g)], h.max_length) for h in hmms]
+    qcost = [sum(n for _, _, n, _ in w) * (h.M + 150.0) for w, h in zip(all_wins, hmms)]
+    items = bdist.query_items_weighted([len(w) for w in all_wins], qcost, 1)
+    owner = bdist.deal([sum(n for _, _, n, _ in all_wins[q][lo:hi]) * (hmms[q].M + 150.0) for q, lo, hi in items], nw)
     workers = []
     for w in range(nw):
         c = ba.Context(0)
         jobs = []
-        for q in order[w::nw]:
+        for (q, lo, hi), o in zip(items, owner):
+            if o != w:
+                continue
             hmm = hmms[q]
             om = ba.OProfile(c, ba.Profile(hmm))
             pipe = ba.Pipeline(c, om, fs_pipe=False, ncbi_table=hmm.ct)
-            wins = bdist.split_targets([len(g)], hmm.max_length)
+            wins = all_wins[q][lo:hi]
             blk = ba.SeqBlock(c, [g[s_:s_ + n] for _, s_, n, _ in wins]); blk.set_context([cc for _, _, _, cc in wins])
-            pipe.run_hits(blk)
-            jobs.append((q, om, pipe, blk))
+            before = 2 * sum(n - cc for _, _, n, cc in all_wins[q][:lo])
+            pipe.run_hits(blk, nres_before=before)
+            jobs.append((q, before, pipe, blk))
         workers.append((c, jobs))
-    conc_hits = [0] * len(hmms)
     csteps = 3
+    conc_by_worker = [None] * nw
 
     def work(w):
         c, jobs = workers[w]
         for _ in range(csteps):
-            for q, _, pipe, blk in jobs:
-                _, dm, _ = pipe.run_hits(blk)
-                conc_hits[q] = int(sum(d.reported for d in dm))
+            mine = {}
+            for q, before, pipe, blk in jobs:
+                _, dm, _ = pipe.run_hits(blk, arrays=True, nres_before=before)
+                mine[q] = mine.get(q, 0) + int(dm.rec["reported"].sum())
         c.synchronize()
+        conc_by_worker[w] = mine
 
     t0 = time.perf_counter()
     th = [threading.Thread(target=work, args=(w,)) for w in range(nw)]
@@ -320,6 +336,7 @@ def c4_leg(ba, synth, bdist, ctx, args, cpu):
     for t in th:
         t.join()
     conc_ms = (time.perf_counter() - t0) / csteps * 1e3
+    conc_hits = [sum(m.get(q, 0) for m in conc_by_worker) for q in range(len(hmms))]
     for c, jobs in workers:
         jobs.clear()
         c.close()
@@ -329,7 +346,8 @@ def c4_leg(ba, synth, bdist, ctx, args, cpu):
             "hits": tot_hits, "models": per_model,
             "concurrent_queries": {"workers": nw, "ms_per_database_pass": conc_ms, "residues_per_s": tot_res / (conc_ms * 1e-3),
                                    "hits_equal_to_serial_loop": conc_hits == [m["hits"] for m in per_model],
-                                   "what": "the 12 queries dealt out to %d worker contexts (threads), longest models first, one after the other within a worker" % nw},
+                                   "items": len(items),
+                                   "what": "the 12 queries as %d (query, window group) items dealt out to %d worker contexts (threads), longest first, one after the other within a worker" % (len(items), nw)},
             "parity_check": None if cpu is None else {"what": "the 10 pipeline counters of the first %d windows of every model against the SSE2 striped CPU pipeline" % args.c45_sample_windows,
                                                       "all_equal": all(parity), "per_model": parity, "cpu_seconds": cpu["c4_seconds"],
                                                       "hits": {"what": "the hits of those windows (window, envelope / alignment / model coordinates, bit score to its printed decimal): GPU vs CPU pipeline",
