@@ -158,6 +158,7 @@ ABI = {
     "bath_hip_synchronize": (C.c_int, [_vp]),
     "bath_hip_stream": (_vp, [_vp]),
     "bath_hip_set_fs_strict": (C.c_int, [_vp, C.c_int]),
+    "bath_hip_set_fs_serial": (C.c_int, [_vp, C.c_int]),
     "bath_hip_trim": (C.c_int, [_vp]),
     "bath_hip_kernel_times": (C.c_int, [_vp, C.c_int, C.POINTER(KernelTime)]),
     "bath_hip_oprofile_convert": (C.c_int, [_vp, C.POINTER(_Profile), C.POINTER(_vp)]),
@@ -379,6 +380,10 @@ class Context:
         """True (the library's default): frameshift log-sums along the model in the reference's serial order, bit-identical to the
         generic reference.  False: the fast mode (wavefront scans, scores within O(1e-3) nats)."""
         self._check(lib().bath_hip_set_fs_strict(self._h, 1 if on else 0), "set_fs_strict")
+
+    def set_fs_serial(self, on):
+        """Measurement aid: the envelopes' Backward wavefront after the Forward one instead of beside it (bath_hip_set_fs_serial)."""
+        self._check(lib().bath_hip_set_fs_serial(self._h, -1 if on is None else (1 if on else 0)), "set_fs_serial")
 
     @property
     def stream(self):

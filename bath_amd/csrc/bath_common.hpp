@@ -161,6 +161,7 @@ struct bath_hip_ctx {
   hipStream_t copy_stream = nullptr;    // created on first use: host -> device uploads of packed blocks (bath_hip_seqs_upload_packed)
   hipDeviceProp_t prop{};
   int fs_strict = 1;                    // frameshift log-sums along the model in the reference's serial order (bit-identical); bath_hip_set_fs_strict(ctx, 0): wavefront scans
+  int fs_serial = -1;                   // envelopes' Backward after Forward on one stream instead of beside it (timing probes); -1: BATH_HIP_FS_SERIAL decides
   std::string err;
   void set_error(const std::string &m) { err = m; }
   // scratch owned by the context (reused across calls)

@@ -1812,7 +1812,8 @@ int bath::fs5_envelopes_ex(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, cons
       const int s1 = ctx->span_begin("fs5_fwd_kernel", ctx->stream, cells5, cells5 * 32.0);
       if ((st = launch_fs5_fwd_wf(ctx, ctx->stream, om, dna, MD == 1, c5_compat, d_fsc, b_f.as<float>(), d_foff, b_fx.as<float>(), d_xoff, ctx->scratch[41], jq[0])) != BATH_OK) return st;
       ctx->span_end(s1, ctx->stream);
-      static const bool serial = [] { const char *e = std::getenv("BATH_HIP_FS_SERIAL"); return e && e[0] == '1'; }();   // timing probes: Backward after Forward
+      static const bool serial_env = [] { const char *e = std::getenv("BATH_HIP_FS_SERIAL"); return e && e[0] == '1'; }();   // timing probes: Backward after Forward
+      const bool serial = ctx->fs_serial >= 0 ? ctx->fs_serial != 0 : serial_env;                                           // (bath_hip_set_fs_serial)
       hipStream_t bs = serial ? ctx->stream : ctx->side_stream;
       const int s2 = ctx->span_begin("fs_bwd_kernel<5>", bs, cells5, cells5 * 12.0);
       if ((st = launch_fs5_bwd_wf(ctx, bs, om, dna, MD == 1, d_bsc, b_b.as<float>(), d_boff, b_bx.as<float>(), d_xoff, ctx->scratch[42], ctx->scratch[43], ctx->scratch[44], jq[1], jq[3])) != BATH_OK) return st;

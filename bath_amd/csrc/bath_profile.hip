@@ -209,6 +209,12 @@ extern "C" int bath_hip_kernel_times(bath_hip_ctx *ctx, int max, bath_kernel_tim
   }
   return n;
 }
+extern "C" int bath_hip_set_fs_serial(bath_hip_ctx *ctx, int on) {
+  if (!ctx) return BATH_EINVAL;
+  ctx->fs_serial = on < 0 ? -1 : (on ? 1 : 0);
+  return BATH_OK;
+}
+
 extern "C" int bath_hip_set_fs_strict(bath_hip_ctx *ctx, int on) {
   if (!ctx) return BATH_EINVAL;
   ctx->fs_strict = on ? 1 : 0;

@@ -1105,6 +1105,46 @@ def fs_concurrent_leg(ba, hmm, flat, offsets, strict_keys, one_ms, workers=2, pa
             "domains_identical_to_one_worker_pass_incl_envsc_bits": bool(same)}
 
 
+def fs_envelopes_alone(ba, ctx, om5, flat, offsets, fw, dm, M, reps=3):
+    """The 5-codon envelope kernels with the chip to themselves: the envelopes of the pass's frameshift-branch domains as ONE batch through
+    bath_hip_fs5_envelopes, Backward after Forward (bath_hip_set_fs_serial), nothing else running -- the counterpart of roofline.valu's
+    one-part pass for the cascade.  In the pass the same kernels run side by side and beside the regions' Forward, in two batches."""
+    sel = dm[fw["branch"][dm["fs_window"]] == 1]
+    if len(sel) == 0:
+        return None
+    envs = []
+    for r in sel:
+        lo, hi = sorted((int(r["ienv"]), int(r["jenv"])))
+        e = flat[int(offsets[int(r["window"])]) + lo - 1:int(offsets[int(r["window"])]) + hi]
+        envs.append((3 - e[::-1]).astype(np.uint8) if int(r["strand"]) else e)
+    blk = ba.SeqBlock(ctx, envs)
+
+    def times():
+        arr = (ba.KernelTime * 32)()
+        n = ba.lib().bath_hip_kernel_times(ctx._h, 32, arr)
+        return {arr[i].name.decode(): (float(arr[i].ms), float(arr[i].bytes)) for i in range(n)}
+
+    ctx.set_fs_serial(True)
+    try:
+        ba.FS5Envelopes(ctx, om5, blk, logsum=ba.LOGSUM_TABLE_SERIAL)
+        t0 = times()
+        for _ in range(reps):
+            ba.FS5Envelopes(ctx, om5, blk, logsum=ba.LOGSUM_TABLE_SERIAL)
+        t1 = times()
+    finally:
+        ctx.set_fs_serial(None)
+    names = [n for n in ("fs5_fwd_kernel", "fs_bwd_kernel<5>", "fs5_decode_oa_kernel") if n in t1]
+    ms = {n: (t1[n][0] - t0.get(n, (0.0, 0.0))[0]) / reps for n in names}
+    nbytes = {n: (t1[n][1] - t0.get(n, (0.0, 0.0))[1]) / reps for n in names}
+    tot_ms, tot_b = sum(ms.values()), sum(nbytes.values())
+    L = np.array([len(e) for e in envs], dtype=np.int64)
+    return {"what": "the envelopes of the pass's frameshift-branch domains as one batch, Backward after Forward, nothing else on the chip (strict mode)",
+            "envelopes": int(len(envs)), "cells": int(((L + 1) * (M + 1)).sum()), "kernel_ms": ms, "ms": tot_ms,
+            "achieved": tot_b / (tot_ms * 1e-3) / 1e9 if tot_ms > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": tot_b / (tot_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if tot_ms > 0 else None,
+            "per_kernel_frac": {n: nbytes[n] / (ms[n] * 1e-3) / 1e9 / HBM_PEAK_GBS for n in names if ms[n] > 0}}
+
+
 def fs_leg(ba, synth, ctx, hmm, om, args, data=None, cpu=None):
     """BASELINE configs[2]: --fs on a block whose planted domains are frameshifted."""
     flat, offsets, planted = data if data is not None else synth.dna_windows(args.fs_windows, args.length, seed=4242, hmm=hmm, frameshift=True)
@@ -1135,6 +1175,7 @@ def fs_leg(ba, synth, ctx, hmm, om, args, data=None, cpu=None):
                "std_branch": int((fw["branch"] == 2).sum()), "domains": int(len(dm)), "reported": int(dm["reported"].sum()),
                "envelope_nt": int((np.abs(dm["jenv"].astype(np.int64) - dm["ienv"]) + 1).sum()), "clustered_regions": int(nskip),
                "shifted_codons_found": int(dm["n_shifted_codons"].sum())}
+    alone = fs_envelopes_alone(ba, ctx, om5, flat, offsets, fw, dm, hmm.M)
     keys = ("window", "strand", "ienv", "jenv", "iali", "jali", "ihmm", "jhmm", "n_shifted_codons")
     strict = {tuple(int(r[k]) for k in keys) for r in dm}
     strict_bits = {tuple(int(r[k]) for k in keys) + (fbits(r["envsc"]),) for r in dm}
@@ -1160,6 +1201,7 @@ def fs_leg(ba, synth, ctx, hmm, om, args, data=None, cpu=None):
         "roofline": {"bound": "hbm", "binding_resource": "memory requests issued (a lane writes its own row: 64 pieces per store instruction)", "kernels": env, "cells": env_cells, "bytes_per_cell": env_bytes / env_cells if env_cells else None,
                      "ms": env_ms, "achieved": env_bytes / (env_ms * 1e-3) / 1e9 if env_ms > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": env_bytes / (env_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if env_ms > 0 else None,
+                     "alone": alone,
                      "note": "5-codon envelope kernels: algorithmic matrix bytes (Forward writes 32, Backward writes 12 + 4 for the B terms, the fused decoding + "
                              "optimal-accuracy pass reads 44 and writes 44 per cell) / sum of their device times.  Forward and Backward are row-per-lane "
                              "wavefronts (bath_fs_wavefront.hip): a lane writes its own row, so their stores are 12-32 B pieces of 64 different lines per "

@@ -117,6 +117,10 @@ void       *bath_hip_stream(bath_hip_ctx *ctx);                      /* hipStrea
  * room to spare).  0 = "fast": the same table log-sums associated by wavefront scans, scores within O(1e-3) nats of the
  * reference, ~1.7x faster on the bench's --fs pass.  Applies to the pipeline entry points and to BATH_LOGSUM_CONTEXT. */
 int         bath_hip_set_fs_strict(bath_hip_ctx *ctx, int on);
+/* Measurement aid: 1 = the envelope stage (bath_hip_fs5_envelopes and the domain stage's batches) runs its Backward wavefront AFTER the
+ * Forward wavefront on the same stream instead of beside it, so that a kernel's HIP-event span is its time alone on the chip
+ * (bench.py: fs.roofline.alone); 0 = side by side (the default); -1 = whatever BATH_HIP_FS_SERIAL says.  Results do not change. */
+int         bath_hip_set_fs_serial(bath_hip_ctx *ctx, int on);
 
 /* ------------------------------------------------------------------------------------------
  * Optimized profile (P7_OPROFILE surface).

@@ -68,6 +68,8 @@ def check_exact(model, stats, fw, dm, nskip, pli, ofw, per_w, odm, per_d, oskip)
         assert bits(d.envsc) == bits(o.envsc), (d.window, d.envsc, o.envsc)                 # p7_Forward_Frameshift of the envelope, bit for bit
         assert abs(d.oasc - o.oasc) <= 5e-4 + 1e-4 * abs(o.oasc)                             # posteriors differ by expf's last bit
         assert abs(d.bitscore - o.bitscore) <= 2e-3 and abs(d.domcorrection - o.domcorrection) <= 2e-3 + 2e-3 * abs(o.domcorrection)
+        assert abs(d.lnP - o.lnP) <= 2e-3 and abs(d.pre_score - o.pre_score) <= 2e-3
+        assert d.reported == o.reported, (d.window, d.lnP, o.lnP)                            # the early E-value test: pli->nres at this window and strand
     # what is left on both sides are the standard branch's domains
     odm_rest, per_rest = [], []
     for w, (a, b) in enumerate(per_d):
