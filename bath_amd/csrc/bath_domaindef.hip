@@ -243,37 +243,64 @@ static int fs_branch_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, con
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b / 2 < budget) budget = std::max<size_t>(free_b / 2, (size_t)64 << 20);
   }
   if (const char *e = std::getenv("BATH_HIP_ENV_MB")) budget = (size_t)std::max(1, std::atoi(e)) << 20;
-  auto run_envelopes = [&](int e_begin, int e_end) -> int {                    // envs[e_begin, e_end) through the kernels, results appended
-    eregs.resize((size_t)e_end); res.resize((size_t)e_end); traces.resize((size_t)e_end); step_off.resize((size_t)e_end + 1, 0);
-    for (int e = e_begin; e < e_end; e++) {
-      const FsWinDev &wr = regs[(size_t)envs[(size_t)e].sel];
+  // One batch of envelopes through the kernels on context <c>, results into <out> (indexed from 0 within the batch)
+  struct EnvBatch {
+    std::vector<FsWinDev> eregs;
+    std::vector<bath_fs5_result> res;
+    std::vector<FsTraceOut> traces;
+    std::vector<uint16_t> steps;
+    std::vector<int64_t> step_off;
+  };
+  auto run_env_batch = [&](bath_hip_ctx *c, const Env *list, int n, EnvBatch &out) -> int {
+    out.eregs.resize((size_t)n); out.res.resize((size_t)n); out.traces.resize((size_t)n); out.step_off.assign((size_t)n + 1, 0);
+    out.steps.clear();
+    for (int e = 0; e < n; e++) {
+      const FsWinDev &wr = regs[(size_t)list[e].sel];
       FsWinDev d = wr;
-      d.start = wr.start + envs[(size_t)e].i - 1; d.len = envs[(size_t)e].j - envs[(size_t)e].i + 1;
-      eregs[(size_t)e] = d;
+      d.start = wr.start + list[e].i - 1; d.len = list[e].j - list[e].i + 1;
+      out.eregs[(size_t)e] = d;
     }
-    for (int e0 = e_begin; e0 < e_end;) {
+    for (int e0 = 0; e0 < n;) {
       int e1 = e0;
       size_t bytes = 0;
-      while (e1 < e_end) {
-        const size_t b = ((size_t)eregs[(size_t)e1].len + 1) * (size_t)(h5.M + 1) * 56;
+      while (e1 < n) {
+        const size_t b = ((size_t)out.eregs[(size_t)e1].len + 1) * (size_t)(h5.M + 1) * 56;
         if (e1 > e0 && bytes + b > budget) break;
         bytes += b; e1++;
       }
-      std::vector<FsWinDev> chunk(eregs.begin() + e0, eregs.begin() + e1);
+      std::vector<FsWinDev> chunk(out.eregs.begin() + e0, out.eregs.begin() + e1);
       std::vector<uint16_t> csteps;
       std::vector<int64_t> coff;
       bath_hip_seqs view;
-      int st2 = fs_gather_view(ctx, dna, chunk, tt.comp, &view, nullptr);
-      if (st2 != BATH_OK) return st2;
-      st2 = fs5_envelopes_ex(ctx, om_fs5, &view, BATH_LOGSUM_CONTEXT, 0, res.data() + e0, nullptr, nullptr, nullptr, nullptr, traces.data() + e0, om->d_cons, &csteps, &coff);
+      int st2 = fs_gather_view(c, dna, chunk, tt.comp, &view, nullptr);
+      if (st2 != BATH_OK) { if (c != ctx) ctx->set_error(c->err); return st2; }
+      st2 = fs5_envelopes_ex(c, om_fs5, &view, BATH_LOGSUM_CONTEXT, 0, out.res.data() + e0, nullptr, nullptr, nullptr, nullptr, out.traces.data() + e0, om->d_cons, &csteps, &coff);
       view.d_data = nullptr; view.d_off = nullptr; view.d_len = nullptr;
-      if (st2 != BATH_OK) return st2;
-      const int64_t base = (int64_t)steps.size();
-      for (int k = 0; k < e1 - e0; k++) step_off[(size_t)(e0 + k)] = base + coff[(size_t)k];
-      steps.insert(steps.end(), csteps.begin(), csteps.end());
+      if (st2 != BATH_OK) { if (c != ctx) ctx->set_error(c->err); return st2; }
+      const int64_t base = (int64_t)out.steps.size();
+      for (int k = 0; k < e1 - e0; k++) out.step_off[(size_t)(e0 + k)] = base + coff[(size_t)k];
+      out.steps.insert(out.steps.end(), csteps.begin(), csteps.end());
       e0 = e1;
     }
-    step_off[(size_t)e_end] = (int64_t)steps.size();
+    out.step_off[(size_t)n] = (int64_t)out.steps.size();
+    return BATH_OK;
+  };
+  auto append_batch = [&](const EnvBatch &b) {                                  // a finished batch joins the arrays the hit stage reads (envs order)
+    const int64_t base = (int64_t)steps.size();
+    if (step_off.empty()) step_off.push_back(0);
+    step_off.pop_back();
+    eregs.insert(eregs.end(), b.eregs.begin(), b.eregs.end());
+    res.insert(res.end(), b.res.begin(), b.res.end());
+    traces.insert(traces.end(), b.traces.begin(), b.traces.end());
+    for (size_t k = 0; k + 1 < b.step_off.size(); k++) step_off.push_back(base + b.step_off[k]);
+    steps.insert(steps.end(), b.steps.begin(), b.steps.end());
+    step_off.push_back((int64_t)steps.size());
+  };
+  auto run_envelopes = [&](int e_begin, int e_end) -> int {                    // envs[e_begin, e_end) on this context, results appended (e_begin = what is done so far)
+    EnvBatch b;
+    const int st2 = run_env_batch(ctx, envs.data() + e_begin, e_end - e_begin, b);
+    if (st2 != BATH_OK) return st2;
+    append_batch(b);
     return BATH_OK;
   };
   const int n_single = (int)envs.size();
@@ -283,6 +310,13 @@ static int fs_branch_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, con
   // ---- multi-domain regions (p7_domaindef.c:396-455): Forward of the region in the multihit configuration (GPU), ensemble of
   // stochastic tracebacks and clustering (host, bath_ensemble.hip); every cluster is an envelope
   std::vector<std::vector<Env>> found;                                       // written by the ensemble threads: declared BEFORE the joiner, so it outlives the join on every return
+  // Strict mode: the clusters' envelopes go through the kernels on the regions' context as soon as the last ensemble is done, from the
+  // ensembles' own thread -- beside the tail of the single-domain batch (its decoding and tracebacks) instead of after it
+  // (BATH_HIP_FS_CLUSTERS_AFTER=1: the old order).  Written by that thread, read after the join.
+  EnvBatch cl_batch;
+  std::vector<Env> cl_envs;
+  int cl_rc = BATH_OK;
+  bool cl_ran = false;
   bath_hip_ctx *rctx = ctx;                                                  // where the regions' Forward runs
   std::thread ensembles;
   Joiner joiner{ensembles};                                                  // also on error returns
@@ -350,6 +384,14 @@ static int fs_branch_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, con
       // each, sharing the PCIe link), so a thread rarely waits for the region it drew
       run_striped((int64_t)mregs.size(), work, [&](int64_t e) { return -rregs[(size_t)e].len; });
       eclk.lap("fs:   (ensemble threads, start to end)");
+      static const bool clusters_after = [] { const char *e = std::getenv("BATH_HIP_FS_CLUSTERS_AFTER"); return e && e[0] == '1'; }();
+      if (rctx != ctx && !clusters_after) {                                    // every matrix has landed: the regions' Forward is over, its context is free
+        cl_ran = true;
+        if (hipSetDevice(ctx->device) != hipSuccess || hipStreamSynchronize(rctx->stream) != hipSuccess) { cl_rc = BATH_EFAIL; return; }
+        for (size_t e = 0; e < mregs.size(); e++) cl_envs.insert(cl_envs.end(), found[e].begin(), found[e].end());
+        if (!cl_envs.empty()) cl_rc = run_env_batch(rctx, cl_envs.data(), (int)cl_envs.size(), cl_batch);
+        eclk.lap("fs:   (clusters' envelope kernels + traces, same thread)");
+      }
     });
     // strict mode: the first batch of envelopes goes through now, beside the regions' Forward (which runs on its own context)
     if (rctx != ctx && n_single_early > 0) {
@@ -392,6 +434,11 @@ static int fs_branch_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, con
   clk.lap("fs: standard-branch domains (own thread and stream), remainder");
   const int nenv = (int)envs.size();
   if (nenv == 0) return BATH_OK;
+  if (cl_ran && done == n_single) {                                          // the clusters' batch ran beside the first one (same order as envs)
+    if (cl_rc != BATH_OK) return cl_rc;
+    if (!cl_envs.empty()) append_batch(cl_batch);
+    done = nenv;
+  }
   if (nenv > done && (st = run_envelopes(done, nenv)) != BATH_OK) return st;
   clk.lap("fs: envelope kernels + traces");
 
