@@ -124,6 +124,20 @@ class FsDomain(C.Structure):
     cigar = ""       # filled by Pipeline.run_hits / run_frameshift_domains
 
 
+_DTYPES = {}
+
+
+def _np_dtype(T):
+    """numpy's record dtype of a ctypes structure, converted once (the conversion walks the fields: 70 us for FsDomain)."""
+    d = _DTYPES.get(T)
+    if d is None:
+        d = _DTYPES[T] = np.dtype(T)
+    return d
+
+
+FS_DOMAIN_DTYPE = _np_dtype(FsDomain)      # bath_fs_domain as a numpy record dtype
+
+
 class KernelTime(C.Structure):
     _fields_ = [("name", C.c_char_p), ("ms", C.c_float), ("launches", C.c_int64), ("cells", C.c_double), ("bytes", C.c_double)]
 
@@ -688,8 +702,8 @@ class Pipeline:
 
     def _hit_array(self, dm, n):
         if n == 0:
-            return HitArray(np.zeros(0, dtype=np.dtype(FsDomain)), b"")
-        rec = np.frombuffer((FsDomain * n).from_address(C.addressof(dm.contents)), dtype=np.dtype(FsDomain)).copy()
+            return HitArray(np.zeros(0, dtype=FS_DOMAIN_DTYPE), b"")
+        rec = np.frombuffer((FsDomain * n).from_address(C.addressof(dm.contents)), dtype=FS_DOMAIN_DTYPE).copy()
         base = lib().bath_hip_domain_cigars(self.ctx._h)
         last = int(rec["cigar_off"].max())
         end = last + len(C.string_at(base + last)) + 1 if base else 0
@@ -721,8 +735,8 @@ class Pipeline:
         if arrays:
             def view(ptr, n, T):
                 if n == 0:
-                    return np.zeros(0, dtype=np.dtype(T))
-                return np.frombuffer((T * n).from_address(C.addressof(ptr.contents)), dtype=np.dtype(T))
+                    return np.zeros(0, dtype=_np_dtype(T))
+                return np.frombuffer((T * n).from_address(C.addressof(ptr.contents)), dtype=_np_dtype(T))
             return stats, view(fw, nfw.value, FsWindow), view(dm, ndm.value, FsDomain), nskip.value
 
         def copies(ptr, n, T):
@@ -766,16 +780,16 @@ class HitArray:
     def from_bytes(buf, p=0):
         n = int.from_bytes(buf[p:p + 8], "little"); k = int.from_bytes(buf[p + 8:p + 16], "little"); p += 16
         sz = C.sizeof(FsDomain)
-        rec = np.frombuffer(buf, dtype=np.dtype(FsDomain), count=n, offset=p).copy(); p += n * sz
+        rec = np.frombuffer(buf, dtype=FS_DOMAIN_DTYPE, count=n, offset=p).copy(); p += n * sz
         return HitArray(rec, bytes(buf[p:p + k])), p + k
 
     @staticmethod
     def from_domains(domains):
         """From FsDomain objects carrying .cigar (the object path of run_hits / run_frameshift_domains)."""
-        rec = np.zeros(len(domains), dtype=np.dtype(FsDomain))
+        rec = np.zeros(len(domains), dtype=FS_DOMAIN_DTYPE)
         pool = bytearray()
         for i, d in enumerate(domains):
-            rec[i] = np.frombuffer(bytes(d), dtype=np.dtype(FsDomain))[0]
+            rec[i] = np.frombuffer(bytes(d), dtype=FS_DOMAIN_DTYPE)[0]
             rec[i]["cigar_off"] = len(pool)
             pool += d.cigar.encode() + b"\0"
         return HitArray(rec, bytes(pool))
@@ -783,12 +797,14 @@ class HitArray:
     @staticmethod
     def concat(parts):
         """One array from several: every part's cigar offsets moved behind the pools before it."""
+        if len(parts) == 1:
+            return parts[0]
         recs, pools, shift = [], [], 0
         for h in parts:
             r = h.rec.copy()
             r["cigar_off"] += shift
             recs.append(r); pools.append(h.pool); shift += len(h.pool)
-        return HitArray(np.concatenate(recs) if recs else np.zeros(0, dtype=np.dtype(FsDomain)), b"".join(pools))
+        return HitArray(np.concatenate(recs) if recs else np.zeros(0, dtype=FS_DOMAIN_DTYPE), b"".join(pools))
 
 
 class TopHits:

@@ -244,15 +244,14 @@ def gather_query_hits(by_query, dst=0, device="cpu"):
 
 def reduce_query_stats(stats_by_query, n_queries, device="cpu"):
     """p7_pipeline_Merge per query in one all-reduce: {query: PipelineStats (this rank's sum over its items)} -> [dict] per query."""
-    vals = torch.zeros((n_queries, len(STAT_FIELDS)), dtype=torch.int64)
+    arr = np.zeros((n_queries, len(STAT_FIELDS)), dtype=np.int64)            # filled with numpy: a torch scalar assignment costs 8 us apiece
     for q, st in stats_by_query.items():
-        for j, f in enumerate(STAT_FIELDS):
-            vals[q, j] += int(getattr(st, f)) if not isinstance(st, dict) else int(st[f])
-    vals = vals.to(device)
+        arr[q] += [int(st[f]) if isinstance(st, dict) else int(getattr(st, f)) for f in STAT_FIELDS]
     if dist.is_initialized() and dist.get_world_size() > 1:
+        vals = torch.from_numpy(arr).to(device)
         dist.all_reduce(vals, op=dist.ReduceOp.SUM)
-    vals = vals.cpu()
-    return [dict(zip(STAT_FIELDS, [int(v) for v in vals[q]])) for q in range(n_queries)]
+        arr = vals.cpu().numpy()
+    return [dict(zip(STAT_FIELDS, [int(v) for v in arr[q]])) for q in range(n_queries)]
 
 
 def gather_floats(x, dst=0, device="cpu"):

@@ -437,7 +437,7 @@ def finish_query(ba, hmm, domains, wins, nres, genome_len):
 def finish_query_arrays(ba, hmm, hits, wins, nres, genome_len):
     """finish_query on a HitArray: the coordinate shift is four vector additions, the records go to the library as one array."""
     if hits is None or len(hits) == 0:
-        hits = ba.HitArray(np.zeros(0, dtype=np.dtype(ba.FsDomain)), b"")
+        hits = ba.HitArray(np.zeros(0, dtype=ba.FS_DOMAIN_DTYPE), b"")
     rec = hits.rec
     off = np.array([w[1] for w in wins], dtype=np.int64)[rec["window"]].astype(rec["ienv"].dtype) if len(rec) else 0
     for f in ("ienv", "jenv", "iali", "jali"):
@@ -518,6 +518,8 @@ def c4_leg_ranks(ba, synth, bdist, ctx, args, rank, world, dev, on_gpu, sync, to
                     acc[f] += int(getattr(st, f))
         return by_q, st_q
 
+    from concurrent.futures import ThreadPoolExecutor
+    finish_pool = ThreadPoolExecutor(max_workers=int(os.environ.get("BATH_BENCH_FINISH_THREADS", "4")))
     steps = 2
     sync()
     t0 = time.perf_counter()
@@ -542,8 +544,9 @@ def c4_leg_ranks(ba, synth, bdist, ctx, args, rank, world, dev, on_gpu, sync, to
         tables = []
         if rank == 0:
             tf = time.perf_counter()
-            for q, hmm in enumerate(hmms):                             # every query finished on rank 0, inside the timed region
-                tables.append(finish_query_arrays(ba, hmm, gathered.get(q), all_wins[q], merged[q]["nres"], n_nt))
+            # every query finished on rank 0, inside the timed region; the twelve hit lists are independent and the work is the
+            # library's (sort, duplicates, thresholds, the table's text): a few threads, as bathsearch's output stage could
+            tables = list(finish_pool.map(lambda q: finish_query_arrays(ba, hmms[q], gathered.get(q), all_wins[q], merged[q]["nres"], n_nt), range(len(hmms))))
             t_finish += time.perf_counter() - tf
     sync()
     dt = bdist.max_over_ranks((time.perf_counter() - t0) / steps, dev)
