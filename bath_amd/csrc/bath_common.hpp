@@ -216,6 +216,7 @@ struct bath_hip_ctx {
   hipEvent_t ev_lanes = nullptr;         // orders the lanes' streams after what the context's stream holds (uploads, expansion kernels)
   bath_hip_ctx *aux = nullptr;   // a context of its own (stream, scratch) for the standard-branch domains that run beside the frameshift branch
   bath_hip_ctx *aux2 = nullptr;  // ... and one for the multi-domain regions' Forward, which runs beside the first batch of envelopes (strict mode)
+  bath_hip_ctx *aux3 = nullptr;  // ... and one for the clusters' envelopes, which run beside the tail of the single-domain batch (strict mode)
 };
 
 // Device view of a sequence block.

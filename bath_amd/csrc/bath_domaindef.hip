@@ -385,11 +385,17 @@ static int fs_branch_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, con
       run_striped((int64_t)mregs.size(), work, [&](int64_t e) { return -rregs[(size_t)e].len; });
       eclk.lap("fs:   (ensemble threads, start to end)");
       static const bool clusters_after = [] { const char *e = std::getenv("BATH_HIP_FS_CLUSTERS_AFTER"); return e && e[0] == '1'; }();
-      if (rctx != ctx && !clusters_after) {                                    // every matrix has landed: the regions' Forward is over, its context is free
+      if (rctx != ctx && !clusters_after) {
         cl_ran = true;
-        if (hipSetDevice(ctx->device) != hipSuccess || hipStreamSynchronize(rctx->stream) != hipSuccess) { cl_rc = BATH_EFAIL; return; }
+        static const bool own_ctx = [] { const char *e = std::getenv("BATH_HIP_FS_CLUSTERS_CTX"); return !(e && e[0] == '2'); }();   // 2: on the regions' context
+        if (hipSetDevice(ctx->device) != hipSuccess) { cl_rc = BATH_EFAIL; return; }
+        bath_hip_ctx *cctx = rctx;
+        if (own_ctx) {
+          if (!ctx->aux3 && bath_hip_init(ctx->device, &ctx->aux3) != BATH_OK) { cl_rc = BATH_EFAIL; return; }
+          cctx = ctx->aux3; cctx->fs_strict = ctx->fs_strict; cctx->spans_reset();
+        } else if (hipStreamSynchronize(rctx->stream) != hipSuccess) { cl_rc = BATH_EFAIL; return; }
         for (size_t e = 0; e < mregs.size(); e++) cl_envs.insert(cl_envs.end(), found[e].begin(), found[e].end());
-        if (!cl_envs.empty()) cl_rc = run_env_batch(rctx, cl_envs.data(), (int)cl_envs.size(), cl_batch);
+        if (!cl_envs.empty()) cl_rc = run_env_batch(cctx, cl_envs.data(), (int)cl_envs.size(), cl_batch);
         eclk.lap("fs:   (clusters' envelope kernels + traces, same thread)");
       }
     });

@@ -145,6 +145,7 @@ extern "C" void bath_hip_finalize(bath_hip_ctx *ctx) {
   if (ctx->tail_stream) (void)hipStreamDestroy(ctx->tail_stream);
   if (ctx->aux) { bath_hip_finalize(ctx->aux); ctx->aux = nullptr; }
   if (ctx->aux2) { bath_hip_finalize(ctx->aux2); ctx->aux2 = nullptr; }
+  if (ctx->aux3) { bath_hip_finalize(ctx->aux3); ctx->aux3 = nullptr; }
   for (auto &b : ctx->scratch) b.release();
   for (auto &b : ctx->pinned) b.release();
   for (auto &b : ctx->stage) b.release();
@@ -173,6 +174,7 @@ extern "C" int bath_hip_trim(bath_hip_ctx *ctx) {
   ctx->lanes.clear();
   if (ctx->aux) { bath_hip_finalize(ctx->aux); ctx->aux = nullptr; }
   if (ctx->aux2) { bath_hip_finalize(ctx->aux2); ctx->aux2 = nullptr; }
+  if (ctx->aux3) { bath_hip_finalize(ctx->aux3); ctx->aux3 = nullptr; }
   if (ctx->tail_stream) { (void)hipStreamDestroy(ctx->tail_stream); ctx->tail_stream = nullptr; }
   if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); ctx->copy_stream = nullptr; }
   if (ctx->side_stream) {
@@ -196,7 +198,7 @@ extern "C" void *bath_hip_stream(bath_hip_ctx *ctx) { return (void *)ctx->stream
 extern "C" int bath_hip_kernel_times(bath_hip_ctx *ctx, int max, bath_kernel_time *out) {
   if (!ctx || !out) return 0;
   int n = 0;
-  for (const bath_hip_ctx *c : {(const bath_hip_ctx *)ctx, (const bath_hip_ctx *)ctx->aux2}) {     // the regions' Forward runs on a context of its own
+  for (const bath_hip_ctx *c : {(const bath_hip_ctx *)ctx, (const bath_hip_ctx *)ctx->aux2, (const bath_hip_ctx *)ctx->aux3}) {     // the regions' Forward runs on a context of its own
     if (!c) continue;
     for (const bath::KernelSpan &k : c->spans) {
       float ms = 0.f;
