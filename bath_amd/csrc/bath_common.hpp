@@ -162,6 +162,9 @@ struct bath_hip_ctx {
   hipDeviceProp_t prop{};
   int fs_strict = 1;                    // frameshift log-sums along the model in the reference's serial order (bit-identical); bath_hip_set_fs_strict(ctx, 0): wavefront scans
   int fs_serial = -1;                   // envelopes' Backward after Forward on one stream instead of beside it (timing probes); -1: BATH_HIP_FS_SERIAL decides
+  uint64_t tabs_uid = 0;                // whose SSV score table sits in scratch[8] (bath_pipeline.hip: uploaded once per profile, not per call)
+  const void *tabs_ptr = nullptr;
+  int orf_tables_id = -1;               // the NCBI table whose codon tables sit in scratch[28] (bath_orfs.hip: built and uploaded once per context and table)
   std::string err;
   void set_error(const std::string &m) { err = m; }
   // scratch owned by the context (reused across calls)
@@ -279,6 +282,7 @@ struct LenTables {
 
 struct bath_hip_oprofile {
   bath_hip_ctx *ctx = nullptr;
+  uint64_t uid = 0;             // distinct for every profile ever created in the process (a context remembers whose per-call tables it holds)
   int M = 0, max_length = 0, L0 = 0;
   float nj = 1.f;
   float evparam[BATH_NEVPARAM];

@@ -475,6 +475,10 @@ static void build_codon_table(const uint8_t basic[64], std::vector<uint8_t> &tab
 }
 
 int orf_tables_upload(bath_hip_ctx *ctx, int ncbi_table, OrfTablesDev *t) {
+  if (ctx->orf_tables_id == ncbi_table && ctx->scratch[28].p) {     // still there from the last call: every query of a database pass asks again
+    t->full = ctx->scratch[28].as<uint8_t>(); t->fwd = t->full + 6144; t->rev = t->fwd + 64; t->comp = t->rev + 64;
+    return BATH_OK;
+  }
   uint8_t basic[64];
   if (bath_gencode_basic(ncbi_table, basic) != BATH_OK) { ctx->set_error("unknown NCBI translation table"); return BATH_EINVAL; }
   std::vector<uint8_t> host(6144 + 256, 0);
@@ -493,6 +497,7 @@ int orf_tables_upload(bath_hip_ctx *ctx, int ncbi_table, OrfTablesDev *t) {
   BATH_HIP_TRY(ctx, b.reserve(host.size()));
   BATH_HIP_TRY(ctx, hipMemcpyAsync(b.p, host.data(), host.size(), hipMemcpyHostToDevice, ctx->stream));
   BATH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->orf_tables_id = ncbi_table;
   t->full = b.as<uint8_t>(); t->fwd = t->full + 6144; t->rev = t->fwd + 64; t->comp = t->rev + 64;
   return BATH_OK;
 }

@@ -620,19 +620,23 @@ static int run_filters(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bat
   OrfTablesDev tt{};
   if ((st = orf_tables_upload(ctx, prm->ncbi_table, &tt)) != BATH_OK) return st;
   if ((st = ensure_emit_table(ctx, om, prm->F1, max_orf)) != BATH_OK) return st;
-  std::vector<uint8_t> ssv_scores((size_t)(M + 1) * kKp, 0);
-  bath_hip_oprofile_get_ssv_scores(om, ssv_scores.data());
-
   DevBuf &b_tabs = ctx->scratch[8], &b_work = ctx->scratch[9];
-  const size_t tabs_bytes = 8192 + ssv_scores.size() + 256 + 20 * 4 + 256;
+  const size_t ssv_bytes = (size_t)(M + 1) * kKp;
+  const size_t tabs_bytes = 8192 + ssv_bytes + 256 + 20 * 4 + 256;
+  if (tabs_bytes > b_tabs.cap) ctx->tabs_uid = 0;                 // the buffer is about to be replaced: whatever it held is gone
   BATH_HIP_TRY(ctx, b_tabs.reserve(tabs_bytes));
   char *tp = b_tabs.as<char>();
   const int16_t *d_emit = om->d_emit;
-  uint8_t *d_ssvsc = reinterpret_cast<uint8_t *>(tp); tp += (ssv_scores.size() + 255) / 256 * 256;
+  uint8_t *d_ssvsc = reinterpret_cast<uint8_t *>(tp); tp += (ssv_bytes + 255) / 256 * 256;
   float *d_bgf = reinterpret_cast<float *>(tp);
-  BATH_HIP_TRY(ctx, hipMemcpyAsync(d_ssvsc, ssv_scores.data(), ssv_scores.size(), hipMemcpyHostToDevice, ctx->stream));
-  BATH_HIP_TRY(ctx, hipMemcpyAsync(d_bgf, kAminoBg, 20 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-  BATH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // the host vectors above go out of scope with this call only, but be explicit
+  if (ctx->tabs_uid != om->uid || ctx->tabs_ptr != b_tabs.p) {   // once per (context, profile): a database pass of small queries repeats this call per query
+    std::vector<uint8_t> ssv_scores(ssv_bytes, 0);
+    bath_hip_oprofile_get_ssv_scores(om, ssv_scores.data());
+    BATH_HIP_TRY(ctx, hipMemcpyAsync(d_ssvsc, ssv_scores.data(), ssv_scores.size(), hipMemcpyHostToDevice, ctx->stream));
+    BATH_HIP_TRY(ctx, hipMemcpyAsync(d_bgf, kAminoBg, 20 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    BATH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // the host vector goes out of scope here
+    ctx->tabs_uid = om->uid; ctx->tabs_ptr = b_tabs.p;
+  }
 
   Params P{};
   P.F1 = prm->F1; P.F2 = prm->F2; P.F3 = prm->F3; P.F4 = prm->F4;

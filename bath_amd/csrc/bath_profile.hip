@@ -6,6 +6,7 @@
 //                                 p7_bg_SetLength/NullOne    src/p7_bg.c:189,356
 // The striped SIMD layout of the reference is an implementation detail of impl_sse; here every
 // table is indexed by model node and laid out for the kernels in bath_filters.hip.
+#include <atomic>
 #include <cctype>
 #include <cmath>
 #include <cstring>
@@ -266,6 +267,7 @@ extern "C" int bath_hip_oprofile_convert(bath_hip_ctx *ctx, const bath_profile *
   enum { MM, IM, DM, BM, MD, DD, MI, II };
 
   bath_hip_oprofile *om = new bath_hip_oprofile();
+  { static std::atomic<uint64_t> next_uid{1}; om->uid = next_uid.fetch_add(1); }
   om->ctx = ctx; om->M = M; om->max_length = gm->max_length; om->nj = gm->nj; om->L0 = gm->L;
   std::memcpy(om->evparam, gm->evparam, sizeof om->evparam);
   std::memcpy(om->compo, gm->compo, sizeof om->compo);
