@@ -1146,6 +1146,12 @@ int launch_fs5_fwd_chain(bath_hip_ctx *ctx, hipStream_t stream, const bath_hip_f
   const int W = chain_waves(ctx, dna->n, M, Cv, &shmem, share);
   const int64_t n = dna->n;
   const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((n + W - 1) / W, (int64_t)ctx->prop.multiProcessorCount));
+  // A block of one or two regions needs ~75 KB of LDS: two of them, or one and a 74 KB block of the envelope wavefronts running beside
+  // this kernel, fit into one CU -- and a chain wave that shares its SIMD with another block's waves waits for issue slots at every
+  // dependent log-sum (the kernel then lasts 18 ms instead of 16, in the passes where the dispatcher happens to pair blocks up).  With
+  // fewer blocks than CUs every block asks for enough LDS to have its CU to itself (BATH_HIP_FS_REGION_LDS_KB, 0: only what it needs).
+  static const int lds_kb = [] { const char *e = std::getenv("BATH_HIP_FS_REGION_LDS_KB"); return e ? std::atoi(e) : 100; }();
+  if (grid < ctx->prop.multiProcessorCount && 64 * W <= 256) shmem = std::max(shmem, std::min<size_t>((size_t)lds_kb * 1024, (size_t)160 * 1024));
   FsDev dev{om->M, om->pitch, om->maxcodons, om->d_rsc, om->d_tf, om->d_tb, om->d_logsum};
   // a couple of hundred regions are one or two per block: then the kernel built for 256 threads, whose lanes have registers for
   // the row's cells and the next row's emission scores without spilling (a 1024-thread block leaves a lane 128)
