@@ -14,6 +14,13 @@ kernels behind `extern "C"` entry points).  Names follow the reference's objects
 There is no CPU fallback: importing works anywhere (so the CPU test tier can check the library
 loads and exports every symbol), but creating a Context without a usable GPU raises.
 """
+import os as _os
+# HIP maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), read once when the runtime starts.  A context of this
+# library owns up to a dozen streams (lanes, side and tail streams, the standard branch, the regions' Forward, the clusters' envelopes),
+# and a host may run several contexts: with 4 queues, streams that are meant to run side by side end up one behind the other (two worker
+# contexts on whole --fs passes: 53-58 ms per block with 4, 49-51 with 16; nine contexts on configs[3]: 18.0 -> 14.5 ms per database
+# pass; one context alone: no difference).  Set before the first HIP call of the process; a value chosen by the caller is respected.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 import ctypes as C
 import os
 import subprocess
