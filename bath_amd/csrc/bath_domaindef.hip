@@ -310,9 +310,11 @@ static int fs_branch_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, con
   // ---- multi-domain regions (p7_domaindef.c:396-455): Forward of the region in the multihit configuration (GPU), ensemble of
   // stochastic tracebacks and clustering (host, bath_ensemble.hip); every cluster is an envelope
   std::vector<std::vector<Env>> found;                                       // written by the ensemble threads: declared BEFORE the joiner, so it outlives the join on every return
-  // Strict mode: the clusters' envelopes go through the kernels on the regions' context as soon as the last ensemble is done, from the
-  // ensembles' own thread -- beside the tail of the single-domain batch (its decoding and tracebacks) instead of after it
-  // (BATH_HIP_FS_CLUSTERS_AFTER=1: the old order).  Written by that thread, read after the join.
+  // BATH_HIP_FS_CLUSTERS_BESIDE=1 (strict mode; off by default): the clusters' envelopes go through the kernels on a context of their
+  // own as soon as the last ensemble is done, from the ensembles' own thread -- beside the tail of the single-domain batch (its
+  // decoding and tracebacks) instead of after it.  One pass alone gains 1.5-2.5 ms (median of 30), but the extra context's streams
+  // cost more than that as soon as other contexts are alive in the process: two workers inside bench.py 69-82 ms per block
+  // against 52, and the fast-mode passes that follow 67 against 50.  Written by that thread, read after the join.
   EnvBatch cl_batch;
   std::vector<Env> cl_envs;
   int cl_rc = BATH_OK;
@@ -384,8 +386,8 @@ static int fs_branch_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, con
       // each, sharing the PCIe link), so a thread rarely waits for the region it drew
       run_striped((int64_t)mregs.size(), work, [&](int64_t e) { return -rregs[(size_t)e].len; });
       eclk.lap("fs:   (ensemble threads, start to end)");
-      static const bool clusters_after = [] { const char *e = std::getenv("BATH_HIP_FS_CLUSTERS_AFTER"); return e && e[0] == '1'; }();
-      if (rctx != ctx && !clusters_after) {
+      static const bool clusters_beside = [] { const char *e = std::getenv("BATH_HIP_FS_CLUSTERS_BESIDE"); return e && e[0] == '1'; }();
+      if (rctx != ctx && clusters_beside) {
         cl_ran = true;
         static const bool own_ctx = [] { const char *e = std::getenv("BATH_HIP_FS_CLUSTERS_CTX"); return !(e && e[0] == '2'); }();   // 2: on the regions' context
         if (hipSetDevice(ctx->device) != hipSuccess) { cl_rc = BATH_EFAIL; return; }

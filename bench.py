@@ -1178,7 +1178,7 @@ def fs_leg(ba, synth, ctx, hmm, om, args, data=None, cpu=None):
                "std_branch": int((fw["branch"] == 2).sum()), "domains": int(len(dm)), "reported": int(dm["reported"].sum()),
                "envelope_nt": int((np.abs(dm["jenv"].astype(np.int64) - dm["ienv"]) + 1).sum()), "clustered_regions": int(nskip),
                "shifted_codons_found": int(dm["n_shifted_codons"].sum())}
-    alone = fs_envelopes_alone(ba, ctx, om5, flat, offsets, fw, dm, hmm.M)
+    alone = None if os.environ.get("BATH_BENCH_NO_ALONE") == "1" else fs_envelopes_alone(ba, ctx, om5, flat, offsets, fw, dm, hmm.M)
     keys = ("window", "strand", "ienv", "jenv", "iali", "jali", "ihmm", "jhmm", "n_shifted_codons")
     strict = {tuple(int(r[k]) for k in keys) for r in dm}
     strict_bits = {tuple(int(r[k]) for k in keys) + (fbits(r["envsc"]),) for r in dm}

@@ -7,8 +7,10 @@ cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/round4
 rm -rf $OUT; mkdir -p $OUT
-# 0: the bench line itself, with the stage laps of the --fs pass (strict first, then the fast mode)
-BATH_HIP_TIMING=1 python3 bench.py --steps 5 --warmup 1 > $OUT/bench_plain.json 2> $OUT/bench_stage_laps.txt
+# 0: the bench line itself (plain: no laps, no profiler), then the stage laps of the cascade and the --fs pass from a second, shorter run
+#    (BATH_HIP_TIMING=1 adds a host synchronisation per lap: its passes are a few ms longer than the plain ones)
+python3 bench.py --steps 5 --warmup 1 > $OUT/bench_plain.json 2> $OUT/bench_plain.err
+BATH_HIP_TIMING=1 python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-c45 --no-streamed --no-concurrent --no-one-part > /dev/null 2> $OUT/bench_stage_laps.txt
 # 1a: the cascade alone: every ssv_orf_kernel launch is a half-block launch of a timed step
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats0 -o bench0 -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-fs --no-streamed --no-concurrent --no-one-part --no-c45 > $OUT/bench_under_prof_cascade.log 2>&1
 grep '^{"metric"' $OUT/bench_under_prof_cascade.log > $OUT/bench_under_prof_cascade.json
