@@ -175,6 +175,30 @@ def test_blocks_of_a_search_report_what_the_whole_search_reports(hmmfile, fs):
             stp, recs = run(lo, hi, 2 * sum(n - c for _, _, n, c in wins[:lo]))
             parts += recs; nres += int(stp.nres)
         assert nres == int(st.nres) and sorted(parts) == whole, G
+    # the hit table of the search does not depend on the cut either, nor on the order in which the blocks' hits arrive (rank 0 of an
+    # N-rank search gathers them in rank order: bench.py's configs[3] leg)
+    if not fs:
+        def table(arrs):
+            h = ba.HitArray.concat(arrs)
+            off = np.array([w[1] for w in wins], dtype=np.int64)[h.rec["window"]].astype(h.rec["ienv"].dtype)
+            for f in ("ienv", "jenv", "iali", "jali"):
+                h.rec[f] += off
+            h.rec["window"] = 0
+            th = ba.TopHits()
+            th.add_arrays(h, ["chr"], [L])
+            th.finalize(int(st.nres), hmm.max_length)
+            return th.reported(), th.tblout(hmm.name, hmm.acc, hmm.M, show_cigar=True, show_header=False)
+
+        def arrays(lo, hi):
+            blk = ba.SeqBlock(ctx, seqs[lo:hi]); blk.set_context(ctxs[lo:hi])
+            _, a, _ = pipe.run_hits(blk, E_report=E, arrays=True, nres_before=2 * sum(n - c for _, _, n, c in wins[:lo]))
+            a.rec["window"] += lo
+            return a
+
+        t_whole = table([arrays(0, len(wins))])
+        cuts = [bd.shard_range(len(wins), k, 3) for k in range(3)]
+        assert table([arrays(lo, hi) for lo, hi in cuts]) == t_whole and table([arrays(lo, hi) for lo, hi in cuts[::-1]]) == t_whole
+        assert t_whole[0] >= 5
     # without the offset the later blocks count from zero and keep more: the flag is what differs
     lo, hi = bd.shard_range(len(wins), 1, 2)
     _, late = run(lo, hi, 0)
