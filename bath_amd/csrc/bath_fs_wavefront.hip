@@ -50,9 +50,11 @@ __global__ __launch_bounds__(W == 1 ? kWfBlock : 64 * W) void fs5_fwd_wf_kernel(
                                                               float *ring_g /* [waves][(M+2)*8] or null: the ring lives in LDS */, FsJobs jobs, int dbg) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   float *s_tbl = reinterpret_cast<float *>(lds);
-  float *s_tf = s_tbl + kLogsumTbl;
+  // (dbg & 8, a timing probe with wrong results: a table of 8000 entries, so that three blocks fit a CU -- what a compressed table would buy)
+  const int tbl_n = (dbg & 8) ? 8000 : kLogsumTbl;
+  float *s_tf = s_tbl + tbl_n;
   const int M = p.M;
-  fs_load_logsum_table(s_tbl, p.logsum);
+  for (int i = threadIdx.x; i < tbl_n; i += blockDim.x) s_tbl[i] = (i < 15700) ? p.logsum[i] : 0.f;
   for (int i = threadIdx.x; i < (M + 2) * 8; i += blockDim.x) s_tf[i] = p.tf[i];
   __syncthreads();
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -287,12 +289,13 @@ __host__ __device__ inline int64_t fs_bwd_wf_steps(int L, int M, int RW) { retur
 template <bool EXACT, bool RING_G, int W>
 __global__ __launch_bounds__(W == 1 ? kWfBlock : 64 * W) void fs5_bwd_wf_kernel(SeqView dna, FsDev p, const float *__restrict__ loop_tab, const float *__restrict__ move_tab,
                                                               float *__restrict__ bck, const int64_t *__restrict__ bck_off, float *__restrict__ xmx, const int64_t *__restrict__ xmx_off,
-                                                              float *__restrict__ terms, const int64_t *__restrict__ term_off, float *ring_g, FsJobs jobs) {
+                                                              float *__restrict__ terms, const int64_t *__restrict__ term_off, float *ring_g, FsJobs jobs, int dbg) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   float *s_tbl = reinterpret_cast<float *>(lds);
-  float *s_tb = s_tbl + kLogsumTbl;
+  const int tbl_n = (dbg & 8) ? 8000 : kLogsumTbl;                     // (the timing probe of fs5_fwd_wf_kernel)
+  float *s_tb = s_tbl + tbl_n;
   const int M = p.M;
-  fs_load_logsum_table(s_tbl, p.logsum);
+  for (int i = threadIdx.x; i < tbl_n; i += blockDim.x) s_tbl[i] = (i < 15700) ? p.logsum[i] : 0.f;
   for (int i = threadIdx.x; i < (M + 2) * 8; i += blockDim.x) s_tb[i] = p.tb[i];
   __syncthreads();
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -541,8 +544,9 @@ static int fs_wf_waves(bath_hip_ctx *ctx, int64_t n, int M) {
 struct WfGeom { int W, grid, block; bool lds_ring; size_t shmem; float *ring_g; };
 static int fs_wf_geometry(bath_hip_ctx *ctx, int64_t n, int M, DevBuf &ring_scratch, WfGeom *g) {
   static const bool ring_global = [] { const char *e = std::getenv("BATH_HIP_WF_RING_G"); return e && e[0] == '1'; }();
+  static const int dbg = [] { const char *e = std::getenv("BATH_HIP_WF_DBG"); return e ? std::atoi(e) : 0; }();
   const int W = fs_wf_waves(ctx, n, M);
-  const size_t base = (size_t)(kLogsumTbl + (M + 2) * 8) * sizeof(float);
+  const size_t base = (size_t)(((dbg & 8) ? 8000 : kLogsumTbl) + (M + 2) * 8) * sizeof(float);
   const int nrings = (W == 1) ? kWfWaves : 1;
   const size_t ring_b = fs_wf_ring_floats(M) * sizeof(float) * nrings;
   const size_t extra = (W == 1) ? 0 : (size_t)W * 64 + (size_t)W * 16 + (size_t)64 * W * 4 + 64;      // mailboxes, C values, job
@@ -550,7 +554,7 @@ static int fs_wf_geometry(bath_hip_ctx *ctx, int64_t n, int M, DevBuf &ring_scra
   g->lds_ring = !ring_global && base + ring_b + extra <= 160 * 1024;
   g->shmem = base + (g->lds_ring ? ring_b : 0) + extra;
   g->block = (W == 1) ? kWfBlock : 64 * W;
-  const int per_cu = (W == 1) ? ((kWfBlock <= 512) ? 2 : 1) : (int)std::max<size_t>(1, std::min<size_t>(2, (160 * 1024) / g->shmem));
+  const int per_cu = (W == 1) ? ((kWfBlock <= 512) ? 2 : 1) : (int)std::max<size_t>(1, std::min<size_t>((dbg & 8) ? 4 : 2, (160 * 1024) / g->shmem));
   const int64_t jobs_per_block = (W == 1) ? kWfWaves : 1;
   g->grid = (int)std::max<int64_t>(1, std::min<int64_t>((n + jobs_per_block - 1) / jobs_per_block, (int64_t)ctx->prop.multiProcessorCount * per_cu));
   g->ring_g = nullptr;
@@ -606,6 +610,7 @@ int launch_fs5_bwd_wf(bath_hip_ctx *ctx, hipStream_t stream, const bath_hip_fspr
                       FsJobs jobs_sweep, FsJobs jobs_x) {
   const int M = om->M;
   const int64_t n = dna->n;
+  static const int dbg = [] { const char *e = std::getenv("BATH_HIP_WF_DBG"); return e ? std::atoi(e) : 0; }();
   WfGeom g{};
   int st = fs_wf_geometry(ctx, n, M, ring_scratch, &g);
   if (st != BATH_OK) return st;
@@ -616,7 +621,7 @@ int launch_fs5_bwd_wf(bath_hip_ctx *ctx, hipStream_t stream, const bath_hip_fspr
   BATH_HIP_TRY(ctx, toff_scratch.reserve((size_t)(n + 1) * sizeof(int64_t)));
   if (ctx->stage_upload(3, toff_scratch.p, toff.data(), (size_t)(n + 1), stream) != BATH_OK) return BATH_EFAIL;   // through page-locked staging: no synchronize
   FsDev dev{om->M, om->pitch, om->maxcodons, om->d_rsc, om->d_tf, om->d_tb, om->d_logsum};
-  BATH_WF_DISPATCH(fs5_bwd_wf_kernel, dna->view(), dev, om->d_loop[1], om->d_move[1], d_bck, d_boff, d_xmx, d_xoff, terms_scratch.as<float>(), toff_scratch.as<int64_t>(), g.ring_g, jobs_sweep);
+  BATH_WF_DISPATCH(fs5_bwd_wf_kernel, dna->view(), dev, om->d_loop[1], om->d_move[1], d_bck, d_boff, d_xmx, d_xoff, terms_scratch.as<float>(), toff_scratch.as<int64_t>(), g.ring_g, jobs_sweep, dbg);
   BATH_HIP_TRY(ctx, hipGetLastError());
   const int xwaves = kFsBlock / 64;
   const int xgrid = (int)std::max<int64_t>(1, std::min<int64_t>((n + xwaves - 1) / xwaves, (int64_t)ctx->prop.multiProcessorCount * 2));
