@@ -49,16 +49,54 @@ double exp_logsurv(double x, double mu, double lambda) { return x < mu ? 0.0 : -
 // Thread count: the CPUs this process may run on (its affinity mask, not the machine's thread count: a GPU box hands a job a
 // slice of its cores), at most 64, divided by the ranks that share the node -- LOCAL_WORLD_SIZE, which torch.distributed.run
 // exports: one process per GPU, each with its own ensembles; BATH_HIP_HOST_THREADS overrides.
+// The cores a cgroup CPU quota leaves this process (cpu.max of cgroup v2, cpu.cfs_quota_us / cpu.cfs_period_us of v1), 0: no quota.
+// A GPU box hands a job all 256 CPUs in its affinity mask and a quota of 16 cores: 64 threads that poll for their region's matrix
+// then use the quota up within a scheduler period and the WHOLE process is throttled for the rest of it -- one --fs pass in four
+// or five ran 10-15 ms long until round 4 found that in /sys/fs/cgroup/cpu.stat (nr_throttled).
+inline int cgroup_quota_cores() {
+  auto read2 = [](const char *path, long long *a, long long *b) -> bool {
+    FILE *f = std::fopen(path, "r");
+    if (!f) return false;
+    char x[64] = {0}, y[64] = {0};
+    const int n = std::fscanf(f, "%63s %63s", x, y);
+    std::fclose(f);
+    if (n < 1 || std::strcmp(x, "max") == 0) return false;
+    *a = std::atoll(x); *b = n >= 2 ? std::atoll(y) : 0;
+    return true;
+  };
+  long long q = 0, per = 0;
+  if (read2("/sys/fs/cgroup/cpu.max", &q, &per) && q > 0 && per > 0) return (int)std::max<long long>(1, (q + per - 1) / per);
+  long long q1 = 0, p1 = 0, dummy = 0;
+  if (read2("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", &q1, &dummy) && q1 > 0 && read2("/sys/fs/cgroup/cpu/cpu.cfs_period_us", &p1, &dummy) && p1 > 0)
+    return (int)std::max<long long>(1, (q1 + p1 - 1) / p1);
+  return 0;
+}
 inline int host_thread_count() {
   const char *e = std::getenv("BATH_HIP_HOST_THREADS");
   if (e && std::atoi(e) > 0) return std::atoi(e);
-  int usable = 0;
-  cpu_set_t set;
-  if (sched_getaffinity(0, sizeof set, &set) == 0) usable = CPU_COUNT(&set);
-  if (usable <= 0) usable = (int)std::max(1u, std::thread::hardware_concurrency());
-  int ranks = 1;
-  if (const char *lw = std::getenv("LOCAL_WORLD_SIZE")) ranks = std::max(1, std::atoi(lw));
-  return std::min(64, std::max(1, usable / ranks));
+  static const int cached = [] {
+    int usable = 0;
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) usable = CPU_COUNT(&set);
+    if (usable <= 0) usable = (int)std::max(1u, std::thread::hardware_concurrency());
+    const int quota = cgroup_quota_cores();
+    // (four times the quota: the threads sleep while they wait for their region's matrix, and 150 core-ms of tracebacks per pass are far
+    // from a 16-core quota once nothing spins; 8 / 12 threads leave the ensembles on the pass's critical path: 74 / 69 ms per pass
+    // against 64-65 with 16-64, and in the fast mode, where the ensembles ARE the critical path, 32 threads cost 3 ms against 64)
+    if (quota > 0) usable = std::min(usable, std::max(2, quota * 4));
+    int ranks = 1;
+    if (const char *lw = std::getenv("LOCAL_WORLD_SIZE")) ranks = std::max(1, std::atoi(lw));
+    return std::min(64, std::max(1, usable / ranks));
+  }();
+  return cached;
+}
+// Wait for a flag another agent (a kernel writing to page-locked memory) will set: a few yields for the flag that is about to come,
+// then sleeps -- a thread that polls through sched_yield for the 5-15 ms a region's matrix takes burns a core of the quota above.
+inline void wait_for_flag(const int *flag) {
+  for (int spins = 0; !__atomic_load_n(flag, __ATOMIC_ACQUIRE); spins++) {
+    if (spins < 32) std::this_thread::yield();
+    else std::this_thread::sleep_for(std::chrono::microseconds(spins < 256 ? 20 : 100));
+  }
 }
 template <class F, class W>
 void run_striped(int64_t n, F &&work, W &&weight) {
@@ -371,7 +409,7 @@ static int fs_branch_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, con
       auto work = [&](int64_t first, int64_t step) {
         std::vector<std::pair<int, int>> cl;
         for (size_t e = (size_t)first; e < mregs.size(); e += (size_t)step) {
-          while (!__atomic_load_n(h_done + e, __ATOMIC_ACQUIRE)) std::this_thread::yield();      // this region's matrix is still on its way
+          wait_for_flag(h_done + e);                                           // this region's matrix is still on its way
           if (!(h_sc_live[e] > -INFINITY)) continue;                          // Forward underflow: no valid traces for this region (:413)
           const int Lr = rregs[e].len;
           if (fs_region_trace_ensemble(h5.M, h5.tsc, xNL, xNM, xE, mregs[e].i, Lr, h_f + foff[e], h_x + xoff[e], &cl) != BATH_OK) continue;
