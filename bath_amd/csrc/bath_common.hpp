@@ -1,5 +1,6 @@
 // bath_common.hpp -- internal types shared by the HIP translation units of libbathhip.
 #pragma once
+#include <atomic>
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -152,6 +153,13 @@ struct PipelineSurvivor {
 
 }  // namespace bath
 
+struct bath_hip_ctx;
+namespace bath {
+// contexts alive in the process, and how many of them other contexts created for their own stages: the difference is what the host holds
+extern std::atomic<int> g_ctx_total, g_ctx_internal;
+inline int host_contexts() { return g_ctx_total.load() - g_ctx_internal.load(); }
+inline void mark_internal(bath_hip_ctx *c);
+}
 struct bath_hip_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -220,7 +228,12 @@ struct bath_hip_ctx {
   bath_hip_ctx *aux = nullptr;   // a context of its own (stream, scratch) for the standard-branch domains that run beside the frameshift branch
   bath_hip_ctx *aux2 = nullptr;  // ... and one for the multi-domain regions' Forward, which runs beside the first batch of envelopes (strict mode)
   bath_hip_ctx *aux3 = nullptr;  // ... and one for the clusters' envelopes, which run beside the tail of the single-domain batch (strict mode)
+  bool internal = false;          // created by another context (a lane, the standard branch, the regions' Forward, the clusters' envelopes): not one of the host's own
 };
+
+namespace bath {
+inline void mark_internal(bath_hip_ctx *c) { if (c && !c->internal) { c->internal = true; g_ctx_internal.fetch_add(1); } }
+}
 
 // Device view of a sequence block.
 struct SeqView {

@@ -215,6 +215,7 @@ static int fs_branch_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, con
   const char *ser = std::getenv("BATH_HIP_FS_STD_SERIAL");
   if (std_clustered && !ctx->fs_std_orfs.empty() && !(ser && ser[0] == '1')) {
     if (!ctx->aux && (st = bath_hip_init(ctx->device, &ctx->aux)) != BATH_OK) { ctx->set_error("cannot create the context of the standard branch"); return st; }
+    mark_internal(ctx->aux);
     if ((st = om->ensure_len_tables(dna->maxlen / 3 + 1)) != BATH_OK) return st;      // the profile's mutable state: fill it before the thread starts
     bath_hip_ctx *aux = ctx->aux;
     aux->fs_domains.clear(); aux->cigars.clear();
@@ -348,11 +349,12 @@ static int fs_branch_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, con
   // ---- multi-domain regions (p7_domaindef.c:396-455): Forward of the region in the multihit configuration (GPU), ensemble of
   // stochastic tracebacks and clustering (host, bath_ensemble.hip); every cluster is an envelope
   std::vector<std::vector<Env>> found;                                       // written by the ensemble threads: declared BEFORE the joiner, so it outlives the join on every return
-  // BATH_HIP_FS_CLUSTERS_BESIDE=1 (strict mode; off by default): the clusters' envelopes go through the kernels on a context of their
-  // own as soon as the last ensemble is done, from the ensembles' own thread -- beside the tail of the single-domain batch (its
-  // decoding and tracebacks) instead of after it.  One pass alone gains 1.5-2.5 ms (median of 30), but the extra context's streams
-  // cost more than that as soon as other contexts are alive in the process: two workers inside bench.py 69-82 ms per block
-  // against 52, and the fast-mode passes that follow 67 against 50.  Written by that thread, read after the join.
+  // Strict mode, when this is the only context the host holds (host_contexts() == 1; BATH_HIP_FS_CLUSTERS_BESIDE=1|0 forces): the
+  // clusters' envelopes go through the kernels on a context of their own as soon as the last ensemble is done, from the ensembles'
+  // own thread -- beside the tail of the single-domain batch (its decoding and tracebacks) instead of after it: 62.2-62.5 ms per
+  // pass against 64.3-65.0.  With other contexts at work the extra context's streams cost more than that (two workers 52-59 ms per
+  // block against 48.5), and an idle one costs the fast mode 15 ms per pass (bath_hip_trim releases it; bath_hip_set_fs_strict(ctx, 0)
+  // does so itself).  Written by that thread, read after the join.
   EnvBatch cl_batch;
   std::vector<Env> cl_envs;
   int cl_rc = BATH_OK;
@@ -378,6 +380,7 @@ static int fs_branch_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, con
       // through the chip WHILE the regions' Forward runs: it gets a context of its own (stream, gather pool, offsets, job list).
       if (ctx->fs_strict && !ctx->aux2) {
         if ((st = bath_hip_init(ctx->device, &ctx->aux2)) != BATH_OK) { ctx->set_error("cannot create the context of the regions' Forward"); return st; }
+        mark_internal(ctx->aux2);
         // HIP multiplexes its streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default) and two streams that land on one
         // queue run their kernels one after the other: with a dozen streams alive (lanes, side, copy, the standard branch) the
         // regions' Forward ended up behind the envelope kernels it is meant to run beside (+13 ms per pass in bench.py's process).
@@ -424,7 +427,8 @@ static int fs_branch_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, con
       // each, sharing the PCIe link), so a thread rarely waits for the region it drew
       run_striped((int64_t)mregs.size(), work, [&](int64_t e) { return -rregs[(size_t)e].len; });
       eclk.lap("fs:   (ensemble threads, start to end)");
-      static const bool clusters_beside = [] { const char *e = std::getenv("BATH_HIP_FS_CLUSTERS_BESIDE"); return e && e[0] == '1'; }();
+      static const int beside_env = [] { const char *e = std::getenv("BATH_HIP_FS_CLUSTERS_BESIDE"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
+      const bool clusters_beside = beside_env >= 0 ? beside_env == 1 : host_contexts() == 1;      // default: when this is the host's only context
       if (rctx != ctx && clusters_beside) {
         cl_ran = true;
         static const bool own_ctx = [] { const char *e = std::getenv("BATH_HIP_FS_CLUSTERS_CTX"); return !(e && e[0] == '2'); }();   // 2: on the regions' context
@@ -432,6 +436,7 @@ static int fs_branch_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, con
         bath_hip_ctx *cctx = rctx;
         if (own_ctx) {
           if (!ctx->aux3 && bath_hip_init(ctx->device, &ctx->aux3) != BATH_OK) { cl_rc = BATH_EFAIL; return; }
+          mark_internal(ctx->aux3);
           cctx = ctx->aux3; cctx->fs_strict = ctx->fs_strict; cctx->spans_reset();
         } else if (hipStreamSynchronize(rctx->stream) != hipSuccess) { cl_rc = BATH_EFAIL; return; }
         for (size_t e = 0; e < mregs.size(); e++) cl_envs.insert(cl_envs.end(), found[e].begin(), found[e].end());

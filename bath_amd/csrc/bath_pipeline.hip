@@ -951,6 +951,7 @@ static int run_filters_lanes(bath_hip_ctx *ctx, const bath_hip_oprofile *om, con
   while ((int)ctx->lanes.size() < K) {
     bath_hip_ctx *lane = nullptr;
     if ((st = bath_hip_init(ctx->device, &lane)) != BATH_OK) { ctx->set_error("cannot create a pipeline lane"); return st; }
+    mark_internal(lane);
     // Descending stream priorities: when two parts have work ready, the earlier part's workgroups are dispatched first.  Left to
     // the hardware queues the interleaving of the parts is a race and about every third process lands on a schedule that is
     // 20% slower (13.4 vs 16 ms per step on the bench block); with priorities it is 13.2-13.9 ms every time (tools/ab_probe.py).

@@ -108,6 +108,8 @@ int bath_hip_oprofile::ensure_len_tables(int maxL) const { return bath::build_le
 
 // ------------------------------------------------------------------------------------------ context
 
+namespace bath { std::atomic<int> g_ctx_total{0}, g_ctx_internal{0}; }
+
 extern "C" int bath_hip_init(int device, bath_hip_ctx **out) {
   *out = nullptr;
   int ndev = 0;
@@ -131,12 +133,15 @@ extern "C" int bath_hip_init(int device, bath_hip_ctx **out) {
     delete ctx;
     return BATH_ENODEVICE;
   }
+  bath::g_ctx_total.fetch_add(1);
   *out = ctx;
   return BATH_OK;
 }
 
 extern "C" void bath_hip_finalize(bath_hip_ctx *ctx) {
   if (!ctx) return;
+  bath::g_ctx_total.fetch_sub(1);
+  if (ctx->internal) bath::g_ctx_internal.fetch_sub(1);
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   delete ctx->lane_pool; ctx->lane_pool = nullptr;                 // joins the lanes' host threads
@@ -221,6 +226,7 @@ extern "C" int bath_hip_set_fs_serial(bath_hip_ctx *ctx, int on) {
 extern "C" int bath_hip_set_fs_strict(bath_hip_ctx *ctx, int on) {
   if (!ctx) return BATH_EINVAL;
   ctx->fs_strict = on ? 1 : 0;
+  if (!on && ctx->aux3) { bath_hip_finalize(ctx->aux3); ctx->aux3 = nullptr; }      // the fast mode has no use for the clusters' context, and its idle streams cost it 15 ms per pass
   for (bath_hip_ctx *l : ctx->lanes) l->fs_strict = ctx->fs_strict;
   return BATH_OK;
 }
