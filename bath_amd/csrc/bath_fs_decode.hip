@@ -316,7 +316,9 @@ __global__ __launch_bounds__(64 * kOaMaxWaves) void fs5_decode_oa_mw_kernel(SeqV
 int fs5_decode_oa_mw_shape(int M, int *nodes_per_lane) {
   static const int force = [] { const char *e = std::getenv("BATH_HIP_FS_OA_MW"); return e ? std::atoi(e) : -1; }();
   if (force == 0) return 0;
-  if (force != 1 && M <= 256) return 0;                        // up to 4 nodes per lane the one-wave kernel keeps everything in registers
+  // up to 2 nodes per lane the one-wave kernel; beyond, a block of waves: at 145 nodes (3 per lane -> two waves of 2) a pass's two
+  // launches take 5.9 instead of 7.1 ms and the strict pass 1-1.5 ms less (median of 30 passes, twice: 61.9 / 63.0 against 63.2 / 64.6)
+  if (force != 1 && M <= 128) return 0;
   const int C = M <= 64 * 2 * kOaMaxWaves ? 2 : 3;
   const int W = (M + 64 * C - 1) / (64 * C);
   if (W > kOaMaxWaves) return 0;
