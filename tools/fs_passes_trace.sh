@@ -15,7 +15,7 @@ rows = list(csv.DictReader(open(f)))
 ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].replace("void ", "").replace("bath::", "")[:28]) for r in rows)
 tiles = [i for i, e in enumerate(ev) if e[2].startswith("orf_tile")]
 starts = tiles[0::2]                       # two parts per pass
-names = ["fs3_fwd_chain_half_kernel<5>", "fs3_bwd_chain_half_kernel<5>", "fs5_fwd_chain_kernel<3, 256>", "fs5_fwd_wf_kernel<false, fal", "fs5_bwd_wf_kernel<false, fal", "fs5_decode_oa_kernel<3>", "fs5_trace_kernel"]
+names = ["fs3_fwd_chain_half_kernel<5>", "fs3_bwd_chain_half_kernel<5>", "fs5_fwd_chain_kernel<3, 256>", "fs5_fwd_wf_kernel<false, fal", "fs5_bwd_wf_kernel<false, fal", "fs5_decode_oa_mw_kernel<2>", "fs5_trace_kernel"]
 print("pass   span | " + " | ".join(n[:14].ljust(20) for n in names))
 for p, s_i in enumerate(starts):
     e_i = starts[p + 1] if p + 1 < len(starts) else len(ev)
