@@ -225,6 +225,21 @@ def test_fs5_envelopes(setup, c5_compat, mode, request):
         assert close(got["fwdsc"], got["bcksc"], 1e-4, 2e-2)                   # Forward == Backward
 
 
+def test_fs_serial_switch_changes_nothing_but_the_order_of_the_launches(setup):
+    """bath_hip_set_fs_serial (bench.py's fs.roofline.alone): Backward after Forward on one stream instead of beside it -- the same bits."""
+    ctx, model, om3, om5, wins, blk = setup
+    eb = ba.SeqBlock(ctx, [w for w in wins if len(w) >= 15])
+    a = ba.FS5Envelopes(ctx, om5, eb, logsum=ba.LOGSUM_TABLE_SERIAL, want_oa=True)
+    ctx.set_fs_serial(True)
+    try:
+        b = ba.FS5Envelopes(ctx, om5, eb, logsum=ba.LOGSUM_TABLE_SERIAL, want_oa=True)
+    finally:
+        ctx.set_fs_serial(None)
+    for k in ("fwdsc", "bcksc", "oasc", "null2"):
+        assert identical(a[k], b[k]), k
+    assert all(identical(x, y) for x, y in zip(a["oa"], b["oa"]))
+
+
 def test_fs5_multihit_forward_strict_is_bit_identical(setup):
     """p7_Forward_Frameshift in the MULTIHIT configuration of the model's saved length -- what p7_domaindef.c:411-414 runs on a
     multi-domain region before the stochastic tracebacks -- with strict log-sums: score, the whole matrix (8 cells per node) and
