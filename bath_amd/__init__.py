@@ -84,7 +84,14 @@ class OProfileScalars(C.Structure):
 class PipelineParams(C.Structure):
     _fields_ = [("F1", C.c_double), ("F2", C.c_double), ("F3", C.c_double), ("F4", C.c_double),
                 ("do_biasfilter", C.c_int32), ("fs_pipe", C.c_int32), ("min_orf_len", C.c_int32), ("ncbi_table", C.c_int32),
-                ("nres_before", C.c_int64)]
+                ("nres_before", C.c_int64),
+                # option state (include/bath_hip.h): --nonull2, --fsonly, --strand, -m / -M, --incT, --seed, -T
+                ("do_null2", C.c_int32), ("std_pipe", C.c_int32), ("strands", C.c_int32), ("initiator", C.c_int32),
+                ("inc_by_E", C.c_int32), ("seed", C.c_int32), ("T", C.c_double)]
+
+
+STRAND_BOTH, STRAND_TOPONLY, STRAND_BOTTOMONLY = 0, 1, 2
+INIT_ANY, INIT_TABLE, INIT_AUG = 0, 1, 2
 
 
 class OrfResult(C.Structure):
@@ -205,6 +212,10 @@ ABI = {
     "bath_hip_bias_filter": (C.c_int, [_vp, _vp, _vp, _f32p, _f32p]),
     "bath_hip_fwdback_parser": (C.c_int, [_vp, _vp, _vp, _i64p, _f32p, _f32p, _i32p, _i32p, _f32p, _f32p]),
     "bath_hip_translate_orfs": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.POINTER(C.POINTER(Orf)), _i64p, C.POINTER(_u8p)]),
+    "bath_hip_translate_orfs_opts": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.POINTER(Orf)), _i64p, C.POINTER(_u8p)]),
+    "bath_gencode_initiators": (C.c_int, [C.c_int, C.c_int, _u8p]),
+    "bath_tophits_set_score_thresholds": (None, [_vp, C.c_int, C.c_double, C.c_int, C.c_double]),
+    "bath_search_space_residues": (C.c_int64, [C.c_int, C.c_double, C.c_int, C.c_int64]),
     "bath_pipeline_params_default": (None, [C.POINTER(PipelineParams), C.c_int]),
     "bath_hip_pipeline_filters": (C.c_int, [_vp, _vp, _vp, C.POINTER(PipelineParams), C.POINTER(PipelineStats),
                                             C.POINTER(C.POINTER(OrfResult)), _i64p]),
@@ -572,14 +583,14 @@ class StreamedBlock(SeqBlock):
         self.ctx._check(lib().bath_hip_seqs_upload_wait(self._h), "seqs_upload_wait")
 
 
-def translate_orfs(ctx, dna, ncbi_table=1, min_orf_len=20):
-    """Six-frame translation of a DNA SeqBlock (esl_gencode_Process*, bathsearch.c:384-392).
+def translate_orfs(ctx, dna, ncbi_table=1, min_orf_len=20, strands=STRAND_BOTH, initiator=INIT_ANY):
+    """Six-frame translation of a DNA SeqBlock (esl_gencode_Process*, bathsearch.c:384-392); strands / initiator: --strand, -m / -M.
 
     Returns a list of (window, strand, frame, start, end, residues[np.uint8]) sorted by window, strand, frame, start."""
     orfs = C.POINTER(Orf)()
     n = C.c_int64(0)
     aa = _u8p()
-    ctx._check(lib().bath_hip_translate_orfs(ctx._h, dna._h, ncbi_table, min_orf_len, C.byref(orfs), C.byref(n), C.byref(aa)), "translate_orfs")
+    ctx._check(lib().bath_hip_translate_orfs_opts(ctx._h, dna._h, ncbi_table, min_orf_len, strands, initiator, C.byref(orfs), C.byref(n), C.byref(aa)), "translate_orfs")
     out = []
     if n.value == 0:
         return out
@@ -858,6 +869,10 @@ class TopHits:
 
     def reported(self):
         return int(lib().bath_tophits_reported(self._h))
+
+    def set_score_thresholds(self, by_E=True, T=0.0, inc_by_E=True, incT=0.0):
+        """-T / --incT: report / include by bit score instead of E-value (p7_pli_TargetReportable / Includable)."""
+        lib().bath_tophits_set_score_thresholds(self._h, 1 if by_E else 0, T, 1 if inc_by_E else 0, incT)
 
     def finalize(self, nres, max_length, E=10.0):
         if lib().bath_tophits_finalize(self._h, nres, max_length, E) != OK:

@@ -153,19 +153,32 @@ std::string cigar_from_columns(const uint16_t *S, int n) {
 struct RunningZ {
   std::vector<int64_t> before;          // [nwin] residues counted before window w
   const bath_hip_seqs *dna;
-  RunningZ(const bath_hip_seqs *d, int64_t nres_before) : before((size_t)d->n), dna(d) {
+  int strands;                          // pli->strands: a window's W is counted once per strand SEARCHED (bathsearch.c:1069-1071, :1082-1084)
+  RunningZ(const bath_hip_seqs *d, int64_t nres_before, int strands_ = BATH_STRAND_BOTH) : before((size_t)d->n), dna(d), strands(strands_) {
     int64_t acc = nres_before;
-    for (int64_t w = 0; w < d->n; w++) { before[(size_t)w] = acc; acc += 2 * W(w); }
+    const int per_window = strands == BATH_STRAND_BOTH ? 2 : 1;
+    for (int64_t w = 0; w < d->n; w++) { before[(size_t)w] = acc; acc += per_window * W(w); }
   }
   int64_t W(int64_t w) const {
     const int n = dna->h_len[(size_t)w];
     return n < 15 ? 0 : (int64_t)(n - (dna->h_context.empty() ? 0 : dna->h_context[(size_t)w]));
   }
-  float Z(int64_t w, int strand, int max_length) const { return (float)(before[(size_t)w] + (strand ? 2 : 1) * W(w)) / (float)max_length; }
+  float Z(int64_t w, int strand, int max_length) const {
+    return (float)(before[(size_t)w] + ((strand && strands == BATH_STRAND_BOTH) ? 2 : 1) * W(w)) / (float)max_length;
+  }
+};
+
+// What the domain stage reads of the pipeline's option state (bath_pipeline_params + the -E argument)
+struct DomOpts {
+  int64_t nres_before; double E; int do_null2, inc_by_E, strands; uint32_t seed; double T;
+  DomOpts(const bath_pipeline_params &p, double E_report)
+      : nres_before(p.nres_before), E(E_report), do_null2(p.do_null2), inc_by_E(p.inc_by_E), strands(p.strands), seed((uint32_t)p.seed), T(p.T) {}
+  // p7_pipeline.c:1080, :1247: the early reporting test goes by inc_by_E (sic), against E with the running Z or against T
+  bool reportable(double lnP, float Zf, float score) const { return inc_by_E ? (std::exp(lnP) * (double)Zf <= E) : ((double)score >= T); }
 };
 
 static int std_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bath_hip_seqs *dna, const std::vector<PipelineSurvivor> &surv,
-                       const uint8_t *d_pool, int64_t nres_before, double E_report, int64_t *n_clustered_regions);
+                       const uint8_t *d_pool, const DomOpts &opt, int64_t *n_clustered_regions);
 
 
 static int fs_branch_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bath_hip_fsprofile *om_fs3,
@@ -219,10 +232,10 @@ static int fs_branch_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, con
     if ((st = om->ensure_len_tables(dna->maxlen / 3 + 1)) != BATH_OK) return st;      // the profile's mutable state: fill it before the thread starts
     bath_hip_ctx *aux = ctx->aux;
     aux->fs_domains.clear(); aux->cigars.clear();
-    const int64_t nres_before = prm->nres_before;
-    std_thread = std::thread([&, aux, nres_before] {
+    const DomOpts std_opt(*prm, E_report);
+    std_thread = std::thread([&, aux, std_opt] {
       if (hipSetDevice(ctx->device) != hipSuccess) { std_rc = BATH_EFAIL; return; }
-      std_rc = std_domains(aux, om, dna, ctx->fs_std_orfs, ctx->fs_std_pool, nres_before, E_report, &std_nclust);
+      std_rc = std_domains(aux, om, dna, ctx->fs_std_orfs, ctx->fs_std_pool, std_opt, &std_nclust);
     });
   }
   struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } };
@@ -238,7 +251,7 @@ static int fs_branch_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, con
     return BATH_OK;
   };
   OrfTablesDev tt{};
-  if ((st = orf_tables_upload(ctx, prm->ncbi_table, &tt)) != BATH_OK) return st;
+  if ((st = orf_tables_upload(ctx, prm->ncbi_table, &tt, prm->initiator)) != BATH_OK) return st;
   const int nsel = (int)sel.size();
   const int RS = 1 + 3 * fs_max_regions();
   std::vector<int32_t> regions((size_t)nsel * RS, 0);
@@ -415,7 +428,7 @@ static int fs_branch_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, con
           wait_for_flag(h_done + e);                                           // this region's matrix is still on its way
           if (!(h_sc_live[e] > -INFINITY)) continue;                          // Forward underflow: no valid traces for this region (:413)
           const int Lr = rregs[e].len;
-          if (fs_region_trace_ensemble(h5.M, h5.tsc, xNL, xNM, xE, mregs[e].i, Lr, h_f + foff[e], h_x + xoff[e], &cl) != BATH_OK) continue;
+          if (fs_region_trace_ensemble(h5.M, h5.tsc, xNL, xNM, xE, mregs[e].i, Lr, h_f + foff[e], h_x + xoff[e], &cl, (uint32_t)prm->seed) != BATH_OK) continue;
           for (const auto &c : cl) {
             const int i2 = std::max(1, c.first), j2 = c.second;               // :449
             if (j2 - i2 + 1 >= 15) found[e].push_back(Env{mregs[e].sel, i2, j2});
@@ -495,7 +508,8 @@ static int fs_branch_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, con
 
   // ---- traceback, null2 along the trace, the hit's scores
   const int ml = h5.max_length;
-  const RunningZ runZ(dna, prm->nres_before);                                 // pli->Z, p7_domaindef.c:1033: the count at the hit's window and strand
+  const DomOpts opt(*prm, E_report);
+  const RunningZ runZ(dna, prm->nres_before, prm->strands);                   // pli->Z, p7_domaindef.c:1033: the count at the hit's window and strand
   for (int e = 0; e < nenv; e++) {
     const Env &en = envs[(size_t)e];
     const bath_fs_window &win = fw[sel[(size_t)en.sel]];
@@ -508,7 +522,7 @@ static int fs_branch_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, con
       const float per_frame = (float)((float)(Ld / 3) * std::log((double)p1) + std::log(1. - p1));
       const float nullsc = (float)(per_frame + std::log(3.0));
       const float seqscore = (float)((envsc - nullsc) / kLn2);
-      if (exp_surv(seqscore, h5.evparam[7], h5.evparam[BATH_FLAMBDA]) * (double)Zf > E_report) continue;    // :1034 (FTAUFS5)
+      if (opt.inc_by_E && exp_surv(seqscore, h5.evparam[7], h5.evparam[BATH_FLAMBDA]) * (double)Zf > E_report) continue;    // :1034 (FTAUFS5)
     }
     const FsTraceOut &tq = traces[(size_t)e];
     if (!tq.ok) continue;
@@ -531,7 +545,7 @@ static int fs_branch_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, con
       bitscore += 2 * std::log(2. / (ml + 2));
       bitscore -= ((env_len - ali_len) / 3.) * std::log((double)((float)(env_len / 3.) / (float)((env_len / 3.) + 2)));
       bitscore += ((std::max(env_len, ml * 3) - ali_len) / 3.) * std::log((double)((float)ml / (float)(ml + 2)));
-      const float dom_bias = flogsum_host(0.0f, (float)(std::log(1. / 256.) + dm.domcorrection));     // bg->omega = 1/256, p7_bg.c:74
+      const float dom_bias = opt.do_null2 ? flogsum_host(0.0f, (float)(std::log(1. / 256.) + dm.domcorrection)) : 0.0f;     // :1063-1066; bg->omega = 1/256, p7_bg.c:74
       const int nl = std::max(env_len / 3, ml);
       const float p1 = (float)nl / (float)(nl + 1);
       const float per_frame = (float)((float)nl * std::log((double)p1) + std::log(1. - p1));
@@ -540,7 +554,7 @@ static int fs_branch_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, con
       dm.bitscore = (float)((bitscore - (nullsc + dom_bias)) / kLn2);
       dm.pre_score = (float)(bitscore / kLn2);
       dm.lnP = exp_logsurv(dm.bitscore, h5.evparam[7], h5.evparam[BATH_FLAMBDA]);
-      dm.reported = (std::exp(dm.lnP) * (double)Zf <= E_report) ? 1 : 0;
+      dm.reported = opt.reportable(dm.lnP, Zf, dm.bitscore) ? 1 : 0;           // :1080
     } else { dm.ienv = ienv; dm.jenv = jenv; dm.iali = iali; dm.jali = jali; dm.reported = 0; }
     dm.n_stops = tq.nstops; dm.ali_columns = tq.ncol;
     dm.pid = tq.ncol > 0 ? ((float)tq.exact / tq.ncol) * 100 : 0.f;
@@ -571,7 +585,7 @@ extern "C" int bath_hip_pipeline_frameshift_domains(bath_hip_ctx *ctx, const bat
   StageClock clk;
   if (std_clustered >= 0) nclust += std_clustered;
   else {
-    if ((st = std_domains(ctx, om, dna, ctx->fs_std_orfs, ctx->fs_std_pool, prm->nres_before, E_report, &nclust)) != BATH_OK) return st;
+    if ((st = std_domains(ctx, om, dna, ctx->fs_std_orfs, ctx->fs_std_pool, DomOpts(*prm, E_report), &nclust)) != BATH_OK) return st;
     clk.lap("fs: standard-branch domains");
   }
   if (n_clustered_regions) *n_clustered_regions = nclust;
@@ -1091,7 +1105,7 @@ __global__ __launch_bounds__(256) void std_envelope_fill_kernel(SeqView sq, int 
 
 // Domain definition and hit scores for ORFs that passed the Forward filter; appends to ctx->fs_domains.
 static int std_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bath_hip_seqs *dna, const std::vector<PipelineSurvivor> &surv,
-                       const uint8_t *d_pool, int64_t nres_before, double E_report, int64_t *n_clustered_regions) {
+                       const uint8_t *d_pool, const DomOpts &opt, int64_t *n_clustered_regions) {
   int st;
   const int64_t ns = (int64_t)surv.size();
   if (ns == 0) return BATH_OK;
@@ -1210,7 +1224,7 @@ static int std_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bat
       for (int64_t e = first; e < nm; e += step) {
         const Env &en = mregs[(size_t)e];
         const int Lr = en.j - en.i + 1;
-        if (region_trace_ensemble(om, cfg[(size_t)e], h_res + roff[(size_t)e], Lr, h_dp + mdpoff[(size_t)e], h_x + mxoff[(size_t)e], &n2sc, &cl) != BATH_OK) continue;
+        if (region_trace_ensemble(om, cfg[(size_t)e], h_res + roff[(size_t)e], Lr, h_dp + mdpoff[(size_t)e], h_x + mxoff[(size_t)e], &n2sc, &cl, opt.seed) != BATH_OK) continue;
         for (const auto &c : cl) {
           float corr = 0.f;
           for (int pos = c.first; pos <= c.second; pos++) corr += n2sc[(size_t)pos];     // null2_is_done: p7_domaindef.c:1270-1272
@@ -1296,7 +1310,7 @@ static int std_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bat
 
   // ---- p7_pli_postDomainDef_BATH: coordinates on the sequence, score corrections, P-value
   const int ml = om->max_length;
-  const RunningZ runZ(dna, nres_before);                                     // pli->Z, p7_pipeline.c:1246: the count at the hit's window and strand
+  const RunningZ runZ(dna, opt.nres_before, opt.strands);                    // pli->Z, p7_pipeline.c:1246: the count at the hit's window and strand
   for (int64_t e = 0; e < ne; e++) {
     const StdEnvOut &t = eo[(size_t)e];
     if (!t.ok) continue;
@@ -1328,14 +1342,14 @@ static int std_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bat
     bitscore += 2 * std::log(2. / (ml + 2));
     bitscore -= (env_len - ali_len) * std::log((double)((float)env_len / (float)(env_len + 2)));
     bitscore += (ml - ali_len) * std::log((double)((float)ml / (float)(ml + 2)));
-    const float dom_bias = flogsum_host(0.0f, (float)(std::log(1. / 256.) + dm.domcorrection));
+    const float dom_bias = opt.do_null2 ? flogsum_host(0.0f, (float)(std::log(1. / 256.) + dm.domcorrection)) : 0.0f;   // :1230-1233
     const float p1 = (float)ml / (float)(ml + 1);
     const float nullsc = (float)((float)ml * std::log((double)p1) + std::log(1. - p1));      // p7_bg_NullOne at max_length
     dm.dombias = dom_bias;
     dm.bitscore = (float)((bitscore - (nullsc + dom_bias)) / kLn2);
     dm.pre_score = (float)(bitscore / kLn2);
     dm.lnP = (double)(float)exp_logsurv(dm.bitscore, om->evparam[BATH_FTAU], om->evparam[BATH_FLAMBDA]);
-    dm.reported = (std::exp(dm.lnP) * (double)Zf <= E_report) ? 1 : 0;
+    dm.reported = opt.reportable(dm.lnP, Zf, dm.bitscore) ? 1 : 0;           // :1247-1248
     {                                                                        // columns were written last to first; every codon has 3 nucleotides
       const int nc = std::min<int>(t.ncol, (int)(toff[(size_t)e + 1] - toff[(size_t)e]));
       std::vector<uint16_t> cols((size_t)nc);
@@ -1371,7 +1385,7 @@ extern "C" int bath_hip_pipeline_hits(bath_hip_ctx *ctx, const bath_hip_oprofile
   clk.lap("std: cascade + survivors to the host");
   if (stats) *stats = st_local;
   for (PipelineSurvivor &o : surv) o.win_start = o.start;                  // windowsq is the ORF's own stretch of DNA (p7_pipeline.c:1755)
-  if ((st = std_domains(ctx, om, dna, surv, d_pool, prm.nres_before, E_report, &nclust)) != BATH_OK) return st;
+  if ((st = std_domains(ctx, om, dna, surv, d_pool, DomOpts(prm, E_report), &nclust)) != BATH_OK) return st;
   if (n_clustered_regions) *n_clustered_regions = nclust;
   *domains = ctx->fs_domains.data(); *n_domains = (int64_t)ctx->fs_domains.size();
   return BATH_OK;

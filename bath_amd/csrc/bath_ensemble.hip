@@ -15,6 +15,8 @@
 // esl_cluster_SingleLinkage (connected components of the link relation).  Parity of the sampled ensemble with a real
 // bathsearch run is therefore unpinned; tests compare this code with the oracle's independent restatement.
 #include <algorithm>
+#include <chrono>
+#include <atomic>
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
@@ -41,6 +43,17 @@ struct FastRng {
   }
   double next() { x = x * 69069u + 1u; return (double)x / 4294967296.0; }
 };
+
+// pli->r and ddef->do_reseeding (p7_pipeline.c:135-143; p7_domaindef.c:781, :904).  With a seed (--seed, 42 by default) every region's
+// ensemble starts from it.  Seed 0 means "an arbitrary one-time seed, no reseeding": the reference takes the time of day and lets the
+// generator run on from region to region of a worker; here every region draws a stream of its own from one per-process arbitrary
+// value -- results are not reproducible from run to run in either.
+uint32_t region_seed(uint32_t seed) {
+  if (seed != 0) return seed;
+  static const uint32_t once = (uint32_t)std::chrono::steady_clock::now().time_since_epoch().count() | 1u;
+  static std::atomic<uint32_t> counter{0};
+  return once + 0x9e3779b9u * (counter.fetch_add(1) + 1u);
+}
 
 template <int N>
 int choose(FastRng &rng, float (&p)[N]) {
@@ -161,7 +174,7 @@ void cluster_segments(const std::vector<Seg> &sp, int nsamples, bool fs, std::ve
 // model in the multihit configuration for length <cfg_L>; res[0..Lr): the region's residues.
 // Out: n2sc[0..Lr) per-residue null2 log odds; env: envelopes (1-based, region-relative), ordered by start.
 int bath::region_trace_ensemble(const bath_hip_oprofile *om, int cfg_L, const uint8_t *res, int Lr, const float *fwd, const float *fx,
-                                std::vector<float> *n2sc_out, std::vector<std::pair<int, int>> *env) {
+                                std::vector<float> *n2sc_out, std::vector<std::pair<int, int>> *env, uint32_t seed) {
   const int M = om->M, Q = std::max(2, (M - 1) / 4 + 1);
   const size_t W = (size_t)(M + 1) * 3;
   const float *tf = om->tf.data();
@@ -173,7 +186,7 @@ int bath::region_trace_ensemble(const bath_hip_oprofile *om, int cfg_L, const ui
   n2sc.assign((size_t)Lr + 1, 0.f);                       // 1-based positions of the region
   env->clear();
 
-  FastRng rng(42);
+  FastRng rng(region_seed(seed));
   std::vector<Step> tr;
   std::vector<Seg> sp;
   std::vector<float> cnt((size_t)M + 1);
@@ -279,7 +292,7 @@ int bath::region_trace_ensemble(const bath_hip_oprofile *om, int cfg_L, const ui
 // N, C, J; xE: log 1/2.  The region starts at nucleotide <ireg> of its window: segments are clustered in window coordinates
 // (the link rule divides them by 3).  env: envelopes in window nucleotides, ordered by start (empty: no valid traces).
 int bath::fs_region_trace_ensemble(int M, const float *tsc, float xNL, float xNM, float xE, int ireg, int Lr, const float *fwd, const float *fx,
-                                   std::vector<std::pair<int, int>> *env) {
+                                   std::vector<std::pair<int, int>> *env, uint32_t seed) {
   enum { gD = 0, gI = 1, gM = 2 };
   enum { gE = 0, gN, gJ, gB, gC };
   env->clear();
@@ -334,7 +347,7 @@ int bath::fs_region_trace_ensemble(int M, const float *tsc, float xNL, float xNM
     return mm.row.data() + (size_t)i * 12 + at;
   };
   const int nsamples = 200, step_cap = 4 * (Lr + M) + 64;
-  FastRng rng(42);
+  FastRng rng(region_seed(seed));
   std::vector<Seg> sp;
   struct FsStep { int8_t st, c; int32_t k, i; };
   std::vector<FsStep> tr;

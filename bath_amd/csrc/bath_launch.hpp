@@ -100,10 +100,10 @@ int fs5_envelopes_ex(bath_hip_ctx *ctx, const bath_hip_fsprofile *om5, const bat
 
 // ---- multi-domain regions (bath_ensemble.hip, host): envelopes and per-residue null2 scores from 200 stochastic tracebacks
 int region_trace_ensemble(const bath_hip_oprofile *om, int cfg_L, const uint8_t *res, int Lr, const float *fwd, const float *fx,
-                          std::vector<float> *n2sc, std::vector<std::pair<int, int>> *env);
+                          std::vector<float> *n2sc, std::vector<std::pair<int, int>> *env, uint32_t seed = 42);
 
 int fs_region_trace_ensemble(int M, const float *tsc, float xNL, float xNM, float xE, int ireg, int Lr, const float *fwd, const float *fx,
-                             std::vector<std::pair<int, int>> *env);
+                             std::vector<std::pair<int, int>> *env, uint32_t seed = 42);
 int fs5_region_forward(bath_hip_ctx *ctx, const bath_hip_fsprofile *om5, const bath_hip_seqs *dna, int cfg_len_amino,
                        const float **fwd, std::vector<int64_t> *fwd_off, const float **xmx, std::vector<int64_t> *xmx_off, std::vector<float> *sc,
                        const int **done_flags, const float **sc_live);
@@ -118,8 +118,8 @@ __host__ __device__ inline int orf_stream_pitch(int n) { return (n / 3 + 16) & ~
 size_t orf_aa_bytes(const bath_hip_seqs *dna);
 int orf_slot_cap(int minlen);                                   // ORF records reserved per tile (all six frames)
 int orf_tiles_ensure(bath_hip_ctx *ctx, const bath_hip_seqs *dna);   // fills dna->ntiles, d_tile_desc, d_tile_first
-struct OrfTablesDev { const uint8_t *full, *fwd, *rev, *comp; };   // 18^3 general table, canonical 64-entry tables per strand, complement
-int orf_tables_upload(bath_hip_ctx *ctx, int ncbi_table, OrfTablesDev *t);
+struct OrfTablesDev { const uint8_t *full, *fwd, *rev, *comp, *is_init; bool using_initiators; };   // 18^3 general table, canonical 64-entry tables per strand, complement, initiation codons
+int orf_tables_upload(bath_hip_ctx *ctx, int ncbi_table, OrfTablesDev *t, int initiator = 0);
 struct OrfBuffers {               // device buffers of one translation pass
   uint8_t *aa;                    // orf_aa_bytes()
   void *slots;                    // ntiles*orf_slot_cap() records of 8 bytes
@@ -130,6 +130,6 @@ struct OrfBuffers {               // device buffers of one translation pass
 };
 void orf_buffers_carve(OrfBuffers *ob, void *aa, void *slots, void *sorted, void *misc /* (5*nent + 2*kOrfBins + 64) ints */, size_t nent);
 int launch_orf_scan(bath_hip_ctx *ctx, const bath_hip_seqs *dna, const OrfTablesDev &tt, int minlen, const OrfBuffers &b,
-                    unsigned long long *d_n_orfs, unsigned long long *d_orf_res);
+                    unsigned long long *d_n_orfs, unsigned long long *d_orf_res, int strands = 0);
 
 }  // namespace bath

@@ -58,6 +58,16 @@ struct OrfScanOut {
   int *hist;                // [kOrfBins] ORF length histogram (lengths above the last bin are clamped into it)
   unsigned long long *n_orfs, *orf_res;
   int cap;
+  int count;                // 0: leave the histogram and the two counters alone (orf_filter_kernel recounts what it keeps)
+};
+
+// One strand only (pli->strands) and / or initiation codons (bathsearch -m / -M): applied to the records of the two scan kernels
+// before the sort.  Off in bathsearch's default configuration (both strands, any codon starts an ORF), where the pass is skipped.
+struct OrfFilter {
+  int strands;              // BATH_STRAND_*
+  int using_initiators;     // -m or -M: ORFs start at an initiation codon, translated as M
+  const uint8_t *is_init;   // [64] canonical codon (16a + 4b + c) -> may initiate
+  const uint8_t *comp;      // [18] complement
 };
 
 __device__ __forceinline__ int orf_bin(int len) { return min(len, kOrfBins - 1); }
@@ -240,6 +250,7 @@ __global__ __launch_bounds__(256) void orf_tile_kernel(SeqView dna, OrfTiles til
   }
   if (my_orfs) { atomicAdd(&s_red[0], my_orfs); atomicAdd(&s_red[1], my_res); }
   __syncthreads();
+  if (!out.count) return;
   for (int k = threadIdx.x; k < kOrfBins; k += blockDim.x) if (s_hist[k]) atomicAdd(&out.hist[k], s_hist[k]);
   if (threadIdx.x == 0 && s_red[0]) { atomicAdd(out.n_orfs, (unsigned long long)s_red[0]); atomicAdd(out.orf_res, (unsigned long long)s_red[1]); }
 }
@@ -284,6 +295,7 @@ __global__ __launch_bounds__(256) void orf_stitch_kernel(SeqView dna, OrfTiles t
   }
   if (my_orfs) { atomicAdd(&s_red[0], my_orfs); atomicAdd(&s_red[1], my_res); }
   __syncthreads();
+  if (!out.count) return;
   for (int k = threadIdx.x; k < kOrfBins; k += blockDim.x) if (s_hist[k]) atomicAdd(&out.hist[k], s_hist[k]);
   if (threadIdx.x == 0 && s_red[0]) { atomicAdd(out.n_orfs, (unsigned long long)s_red[0]); atomicAdd(out.orf_res, (unsigned long long)s_red[1]); }
 }
@@ -354,6 +366,84 @@ __global__ __launch_bounds__(256) void orf_stitch_wave_kernel(SeqView dna, OrfTi
   }
   if (my_orfs) { atomicAdd(&s_red[0], my_orfs); atomicAdd(&s_red[1], my_res); }
   __syncthreads();
+  if (!out.count) return;
+  for (int k = threadIdx.x; k < kOrfBins; k += blockDim.x) if (s_hist[k]) atomicAdd(&out.hist[k], s_hist[k]);
+  if (threadIdx.x == 0 && s_red[0]) { atomicAdd(out.n_orfs, (unsigned long long)s_red[0]); atomicAdd(out.orf_res, (unsigned long long)s_red[1]); }
+}
+
+// pli->strands and the initiation codons of -m / -M, on the records the scan kernels left (a lane per tile: its slots and its
+// six crossing records).  A record of an excluded strand is cleared.  With initiators an ORF begins at the first initiation
+// codon of its stop-free run (esl_gencode_ProcessPiece: a stop closes the frame's ORF, any other codon extends an open one, only an
+// initiator opens one) and that codon reads M: the record is cut down -- and dropped if fewer than <minlen> residues remain --
+// and the M is written into the amino-acid stream (the codons before it belong to no ORF).  A degenerate codon initiates only if
+// every codon it stands for does (esl_gencode_IsInitiator).  The kernel counts what it keeps (histogram, ORFs, residues).
+__global__ __launch_bounds__(256) void orf_filter_kernel(SeqView dna, OrfTiles tiles, OrfScanOut out, OrfFilter flt, int minlen) {
+  __shared__ int s_hist[kOrfBins];
+  __shared__ unsigned s_red[2];
+  __shared__ uint8_t s_init[64], s_comp[32];
+  for (int i = threadIdx.x; i < kOrfBins; i += blockDim.x) s_hist[i] = 0;
+  if (threadIdx.x < 64) s_init[threadIdx.x] = flt.using_initiators ? flt.is_init[threadIdx.x] : 1;
+  if (threadIdx.x < 18) s_comp[threadIdx.x] = flt.comp[threadIdx.x];
+  if (threadIdx.x < 2) s_red[threadIdx.x] = 0;
+  __syncthreads();
+  // members of a DNA code as a bit mask over A C G T ("ACGT-RYMKSWHBVDN*~")
+  auto members = [](int x) -> unsigned {
+    switch (x) {
+      case 0: return 1u; case 1: return 2u; case 2: return 4u; case 3: return 8u;
+      case 5: return 5u; case 6: return 10u; case 7: return 3u; case 8: return 12u; case 9: return 6u; case 10: return 9u;
+      case 11: return 11u; case 12: return 14u; case 13: return 7u; case 14: return 13u; case 15: return 15u;
+      default: return 0u;                                                   // gap, *, ~
+    }
+  };
+  auto initiates = [&](int a, int b, int c) -> bool {
+    if ((a | b | c) < 4) return s_init[16 * a + 4 * b + c] != 0;
+    const unsigned ma = members(a), mb = members(b), mc = members(c);
+    int n = 0;
+    for (int x = 0; x < 4; x++) if (ma >> x & 1u)
+      for (int y = 0; y < 4; y++) if (mb >> y & 1u)
+        for (int z = 0; z < 4; z++) if (mc >> z & 1u) { if (!s_init[16 * x + 4 * y + z]) return false; n++; }
+    return n > 0;
+  };
+  unsigned my_orfs = 0, my_res = 0;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < tiles.ntiles; t += (int64_t)gridDim.x * blockDim.x) {
+    const int4 dsc = tiles.desc[t];
+    const int n = dsc.y, w = dsc.z;
+    if (n < 15) continue;
+    const int64_t off = (int64_t)(uint32_t)dsc.x << 4;
+    const uint8_t *x = dna.data + off;
+    uint8_t *const abase = out.aa + (2 * off + 96 * (int64_t)w);
+    const int pitch = orf_stream_pitch(n);
+    const int c = out.cnt[t];
+    uint2 *sl = out.slots + t * out.cap;
+    for (int k = 0; k < c + 6; k++) {
+      uint2 *rp = k < c ? sl + k : out.cross + t * 6 + (k - c);
+      uint2 r = *rp;
+      int len = (int)(r.y & 0x0fffffffu);
+      if (len == 0) continue;
+      const int sf = (int)(r.y >> 28);
+      const bool rev = sf >= 3;
+      if ((flt.strands == BATH_STRAND_TOPONLY && rev) || (flt.strands == BATH_STRAND_BOTTOMONLY && !rev)) { rp->y = 0u; continue; }
+      if (flt.using_initiators) {
+        int j = (int)r.x;
+        const int jend = j + len;
+        for (; j < jend; j++) {
+          int a, b, cc;
+          if (!rev) { const int p = sf + 3 * j; a = x[p]; b = x[p + 1]; cc = x[p + 2]; }
+          else { const int q = (sf - 3) + 3 * j; a = s_comp[min((int)x[n - 1 - q], 17)]; b = s_comp[min((int)x[n - 2 - q], 17)]; cc = s_comp[min((int)x[n - 3 - q], 17)]; }
+          if (initiates(min(a, 17), min(b, 17), min(cc, 17))) break;
+        }
+        len = jend - j;
+        if (len < minlen || len <= 0) { rp->y = 0u; continue; }
+        abase[sf * pitch + j] = 10;                                          // 'M' in "ACDEFGHIKLMNPQRSTVWY": the initiation codon's residue
+        r.x = (unsigned)j; r.y = (unsigned)len | ((unsigned)sf << 28);
+        *rp = r;
+      }
+      atomicAdd(&s_hist[orf_bin(len)], 1);
+      my_orfs++; my_res += (unsigned)len;
+    }
+  }
+  if (my_orfs) { atomicAdd(&s_red[0], my_orfs); atomicAdd(&s_red[1], my_res); }
+  __syncthreads();
   for (int k = threadIdx.x; k < kOrfBins; k += blockDim.x) if (s_hist[k]) atomicAdd(&out.hist[k], s_hist[k]);
   if (threadIdx.x == 0 && s_red[0]) { atomicAdd(out.n_orfs, (unsigned long long)s_red[0]); atomicAdd(out.orf_res, (unsigned long long)s_red[1]); }
 }
@@ -386,7 +476,7 @@ __global__ __launch_bounds__(256) void orf_sort_kernel(SeqView dna, OrfTiles til
     if (t >= tiles.ntiles) break;
     const int c = cnt[t];
     const uint2 *sl = slots + t * cap;
-    for (int k = 0; k < c; k++) atomicAdd(&s_cnt[orf_bin((int)(sl[k].y & 0x0fffffffu))], 1);
+    for (int k = 0; k < c; k++) { const unsigned y = sl[k].y & 0x0fffffffu; if (y) atomicAdd(&s_cnt[orf_bin((int)y)], 1); }   // (0: cleared by orf_filter_kernel)
     for (int f = 0; f < 6; f++) { const unsigned y = cross[t * 6 + f].y & 0x0fffffffu; if (y) atomicAdd(&s_cnt[orf_bin((int)y)], 1); }
   }
   __syncthreads();
@@ -474,9 +564,11 @@ static void build_codon_table(const uint8_t basic[64], std::vector<uint8_t> &tab
   }
 }
 
-int orf_tables_upload(bath_hip_ctx *ctx, int ncbi_table, OrfTablesDev *t) {
-  if (ctx->orf_tables_id == ncbi_table && ctx->scratch[28].p) {     // still there from the last call: every query of a database pass asks again
-    t->full = ctx->scratch[28].as<uint8_t>(); t->fwd = t->full + 6144; t->rev = t->fwd + 64; t->comp = t->rev + 64;
+int orf_tables_upload(bath_hip_ctx *ctx, int ncbi_table, OrfTablesDev *t, int initiator) {
+  const int key = ncbi_table | (initiator << 16);
+  t->using_initiators = initiator != BATH_INIT_ANY;
+  if (ctx->orf_tables_id == key && ctx->scratch[28].p) {            // still there from the last call: every query of a database pass asks again
+    t->full = ctx->scratch[28].as<uint8_t>(); t->fwd = t->full + 6144; t->rev = t->fwd + 64; t->comp = t->rev + 64; t->is_init = t->comp + 32;
     return BATH_OK;
   }
   uint8_t basic[64];
@@ -493,22 +585,24 @@ int orf_tables_upload(bath_hip_ctx *ctx, int ncbi_table, OrfTablesDev *t) {
   }
   static const uint8_t kComp[18] = {3, 2, 1, 0, 4, 6, 5, 8, 7, 9, 10, 14, 13, 12, 11, 15, 16, 17};   // ACGT-RYMKSWHBVDN*~
   std::memcpy(comp, kComp, 18);
+  if (bath_gencode_initiators(ncbi_table, initiator, comp + 32) != BATH_OK) { ctx->set_error("no initiation codons for this table / initiator mode"); return BATH_EINVAL; }
   DevBuf &b = ctx->scratch[28];
   BATH_HIP_TRY(ctx, b.reserve(host.size()));
   BATH_HIP_TRY(ctx, hipMemcpyAsync(b.p, host.data(), host.size(), hipMemcpyHostToDevice, ctx->stream));
   BATH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  ctx->orf_tables_id = ncbi_table;
-  t->full = b.as<uint8_t>(); t->fwd = t->full + 6144; t->rev = t->fwd + 64; t->comp = t->rev + 64;
+  ctx->orf_tables_id = key;
+  t->full = b.as<uint8_t>(); t->fwd = t->full + 6144; t->rev = t->fwd + 64; t->comp = t->rev + 64; t->is_init = t->comp + 32;
   return BATH_OK;
 }
 
 int launch_orf_scan(bath_hip_ctx *ctx, const bath_hip_seqs *dna, const OrfTablesDev &tt, int minlen, const OrfBuffers &b,
-                    unsigned long long *d_n_orfs, unsigned long long *d_orf_res) {
+                    unsigned long long *d_n_orfs, unsigned long long *d_orf_res, int strands) {
   const int64_t ntiles = dna->ntiles;
   BATH_HIP_TRY(ctx, hipMemsetAsync(b.hist, 0, kOrfBins * sizeof(int), ctx->stream));
   OrfScanTables tabs{tt.full, tt.fwd, tt.rev, tt.comp};
   OrfTiles tiles{reinterpret_cast<const int4 *>(dna->d_tile_desc), dna->d_tile_first, ntiles};
-  OrfScanOut out{b.aa, reinterpret_cast<uint2 *>(b.slots), b.cnt, reinterpret_cast<uint2 *>(b.cross), b.prefix, b.suffix, b.hist, d_n_orfs, d_orf_res, orf_slot_cap(minlen)};
+  const bool filtered = strands != BATH_STRAND_BOTH || tt.using_initiators;   // not bathsearch's defaults: orf_filter_kernel edits the records and counts
+  OrfScanOut out{b.aa, reinterpret_cast<uint2 *>(b.slots), b.cnt, reinterpret_cast<uint2 *>(b.cross), b.prefix, b.suffix, b.hist, d_n_orfs, d_orf_res, orf_slot_cap(minlen), filtered ? 0 : 1};
   const int cus = ctx->prop.multiProcessorCount;
   // persistent blocks: exactly as many as are resident at once, so that every block gets the same share of the tiles
   int per_cu = 0;
@@ -523,6 +617,11 @@ int launch_orf_scan(bath_hip_ctx *ctx, const bath_hip_seqs *dna, const OrfTables
   } else {
   const int sblocks = (int)std::max<int64_t>(1, std::min<int64_t>((dna->n * 6 + 255) / 256, (int64_t)cus * 8));
   hipLaunchKernelGGL(orf_stitch_kernel, dim3(sblocks), dim3(256), 0, ctx->stream, dna->view(), tiles, out, minlen);
+  }
+  if (filtered) {
+    OrfFilter flt{strands, tt.using_initiators ? 1 : 0, tt.is_init, tt.comp};
+    const int fblocks = (int)std::max<int64_t>(1, std::min<int64_t>((ntiles + 255) / 256, (int64_t)cus * 8));
+    hipLaunchKernelGGL(orf_filter_kernel, dim3(fblocks), dim3(256), 0, ctx->stream, dna->view(), tiles, out, flt, minlen);
   }
   hipLaunchKernelGGL(orf_scan_bins, dim3(1), dim3(256), 0, ctx->stream, b.hist, b.cursor, b.ntotal);
   const int per_block = 256 * kSortTilesPerThread;
@@ -539,7 +638,12 @@ using namespace bath;
 // esl_gencode_Process* as driven by bathsearch.c:384-392, for a whole block: the ORF list and residues, on the host.
 extern "C" int bath_hip_translate_orfs(bath_hip_ctx *ctx, const bath_hip_seqs *dna, int ncbi_table, int min_orf_len,
                                        const bath_orf **orfs, int64_t *n_orfs, const uint8_t **aa) {
-  if (!ctx || !dna || !orfs || !n_orfs || min_orf_len < 0) return BATH_EINVAL;
+  return bath_hip_translate_orfs_opts(ctx, dna, ncbi_table, min_orf_len, BATH_STRAND_BOTH, BATH_INIT_ANY, orfs, n_orfs, aa);
+}
+
+extern "C" int bath_hip_translate_orfs_opts(bath_hip_ctx *ctx, const bath_hip_seqs *dna, int ncbi_table, int min_orf_len, int strands, int initiator,
+                                            const bath_orf **orfs, int64_t *n_orfs, const uint8_t **aa) {
+  if (!ctx || !dna || !orfs || !n_orfs || min_orf_len < 0 || strands < 0 || strands > 2 || initiator < 0 || initiator > 2) return BATH_EINVAL;
   BATH_HIP_TRY(ctx, hipSetDevice(ctx->device));
   *orfs = nullptr; *n_orfs = 0;
   if (aa) *aa = nullptr;
@@ -547,7 +651,7 @@ extern "C" int bath_hip_translate_orfs(bath_hip_ctx *ctx, const bath_hip_seqs *d
   if (dna->n == 0) return BATH_OK;
   int st;
   OrfTablesDev tt{};
-  if ((st = orf_tables_upload(ctx, ncbi_table, &tt)) != BATH_OK) return st;
+  if ((st = orf_tables_upload(ctx, ncbi_table, &tt, initiator)) != BATH_OK) return st;
   if ((st = orf_tiles_ensure(ctx, dna)) != BATH_OK) return st;
   int64_t max_orfs = 0;
   for (int64_t i = 0; i < dna->n; i++) if (dna->h_len[i] >= 15) max_orfs += 6 * (int64_t)((dna->h_len[i] / 3 + 1) / (min_orf_len + 1) + 1);
@@ -561,7 +665,7 @@ extern "C" int bath_hip_translate_orfs(bath_hip_ctx *ctx, const bath_hip_seqs *d
   orf_buffers_carve(&ob, b_aa.p, b_slots.p, b_orfs.p, b_misc.p, nent);
   unsigned long long *d_ctr = reinterpret_cast<unsigned long long *>(ob.ntotal + 2);   // two counters nobody reads here
   BATH_HIP_TRY(ctx, hipMemsetAsync(d_ctr, 0, 16, ctx->stream));
-  if ((st = launch_orf_scan(ctx, dna, tt, min_orf_len, ob, d_ctr, d_ctr + 1)) != BATH_OK) return st;
+  if ((st = launch_orf_scan(ctx, dna, tt, min_orf_len, ob, d_ctr, d_ctr + 1, strands)) != BATH_OK) return st;
   int total = 0;
   BATH_HIP_TRY(ctx, hipMemcpyAsync(&total, ob.ntotal, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   BATH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

@@ -583,6 +583,8 @@ extern "C" void bath_pipeline_params_default(bath_pipeline_params *p, int fs_pip
   p->F1 = 0.02; p->F2 = 1e-3; p->F3 = 1e-5; p->F4 = 5e-4;
   p->do_biasfilter = 1; p->fs_pipe = fs_pipe; p->min_orf_len = 20; p->ncbi_table = 1;
   p->nres_before = 0;
+  p->do_null2 = 1; p->std_pipe = 1; p->strands = BATH_STRAND_BOTH; p->initiator = BATH_INIT_ANY;   // p7_pipeline.c:107, :199; bathsearch.c:97, :718-719
+  p->inc_by_E = 1; p->seed = 42; p->T = 0.0;                                                        // p7_pipeline.c:98, :148, :165
 }
 
 extern "C" int bath_hip_pipeline_timings(const bath_hip_ctx *ctx, int max, const char **names, float *ms, int64_t *launches) {
@@ -618,7 +620,8 @@ static int run_filters(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bat
 
   // ---- per-call tables
   OrfTablesDev tt{};
-  if ((st = orf_tables_upload(ctx, prm->ncbi_table, &tt)) != BATH_OK) return st;
+  if (prm->strands < 0 || prm->strands > 2 || prm->initiator < 0 || prm->initiator > 2) { ctx->set_error("bath_pipeline_params: strands / initiator out of range"); return BATH_EINVAL; }
+  if ((st = orf_tables_upload(ctx, prm->ncbi_table, &tt, prm->initiator)) != BATH_OK) return st;
   if ((st = ensure_emit_table(ctx, om, prm->F1, max_orf)) != BATH_OK) return st;
   DevBuf &b_tabs = ctx->scratch[8], &b_work = ctx->scratch[9];
   const size_t ssv_bytes = (size_t)(M + 1) * kKp;
@@ -659,7 +662,8 @@ static int run_filters(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bat
     }
     dna->cache_minlen = prm->min_orf_len; dna->cache_nres = nres_c; dna->cache_max_orfs = max_orfs_c;
   }
-  const int64_t nres = dna->cache_nres, max_orfs = dna->cache_max_orfs;
+  const int64_t nres = prm->strands == BATH_STRAND_BOTH ? dna->cache_nres : dna->cache_nres / 2;   // W once per strand searched (bathsearch.c:1071, :1084)
+  const int64_t max_orfs = dna->cache_max_orfs;
   if (max_orfs >= (int64_t)INT32_MAX) { ctx->set_error("DNA block too large for one pipeline call (ORF list indices are 32-bit): split it"); return BATH_EINVAL; }
   int64_t cap = std::max<int64_t>(4096, (int64_t)((double)max_orfs * std::min(1.0, prm->F1 * 4.0 + 0.01)));
   cap = std::min<int64_t>(cap, std::max<int64_t>(max_orfs, 4096));
@@ -697,7 +701,7 @@ static int run_filters(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bat
     int e = 0;
     BATH_HIP_TRY(ctx, hipEventRecord(ev[e++], ctx->stream));
     // 1. six-frame translation, ORFs, length-sorted work list
-    if ((st = launch_orf_scan(ctx, dna, tt, prm->min_orf_len, ob, &W.ctr->n_orfs, &W.ctr->orf_res)) != BATH_OK) return st;
+    if ((st = launch_orf_scan(ctx, dna, tt, prm->min_orf_len, ob, &W.ctr->n_orfs, &W.ctr->orf_res, prm->strands)) != BATH_OK) return st;
     BATH_HIP_TRY(ctx, hipEventRecord(ev[e++], ctx->stream));
     // 2. SSV + F1 threshold, lane per ORF
     {
@@ -1429,7 +1433,7 @@ extern "C" int bath_hip_pipeline_frameshift(bath_hip_ctx *ctx, const bath_hip_op
         }
       }
       r.orf_cnt = orf_cnt; r.k_min = k_min; r.k_max = k_max; r.tot_orfsc = tot; r.P_min = P_min;
-      r.P_tot = exp_surv((double)tot / kLn2, om->evparam[BATH_FTAU], om->evparam[BATH_FLAMBDA]);
+      r.P_tot = prm.std_pipe ? exp_surv((double)tot / kLn2, om->evparam[BATH_FTAU], om->evparam[BATH_FLAMBDA]) : 1.0;    // :1457: --fsonly
       out.push_back(r);
       FsWinDev d{};
       d.src_off = dna->h_off[w]; d.dst_off = 0; d.seq_n = n_seq; d.start = (int32_t)dw.n; d.len = dw.length; d.strand = strand;
@@ -1519,6 +1523,7 @@ extern "C" int bath_hip_pipeline_frameshift(bath_hip_ctx *ctx, const bath_hip_op
       r.P_fs = exp_surv(seqscore, ev3[BATH_FTAUFS3], ev3[BATH_FLAMBDA]);
       r.P_null = exp_surv((r.fwdsc - r.nullsc) / kLn2, ev3[BATH_FTAUFS3], ev3[BATH_FLAMBDA]);
       if (r.P_fs <= prm.F3 && (r.P_null < r.P_tot || (r.P_null == r.P_tot && r.orf_cnt > 1) || r.P_min > prm.F3)) { r.branch = 1; pos_fwd += L; }
+      else if (!prm.std_pipe) r.branch = 0;                                                             // :1480: --fsonly has no standard branch
       else {
         r.branch = 2;
         for (int32_t z = std_begin[(size_t)i]; z < std_begin[(size_t)i + 1]; z++) {

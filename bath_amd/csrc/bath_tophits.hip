@@ -43,6 +43,8 @@ struct bath_tophits {
   std::vector<int> order;              // th->hit[]: indices into unsrt
   int64_t nreported = 0, nincluded = 0;
   double incE = 0.01;                  // pli->incE, p7_pipeline.c:166
+  int by_E = 1, inc_by_E = 1;          // pli->by_E / pli->inc_by_E, cleared by -T / --incT (:146-176)
+  double T = 0.0, incT = 0.0;
 };
 
 extern "C" bath_tophits *bath_tophits_create(void) { return new bath_tophits(); }
@@ -50,6 +52,17 @@ extern "C" void bath_tophits_destroy(bath_tophits *th) { delete th; }
 extern "C" int64_t bath_tophits_count(const bath_tophits *th) { return th ? (int64_t)th->unsrt.size() : 0; }
 extern "C" int64_t bath_tophits_reported(const bath_tophits *th) { return th ? th->nreported : 0; }
 extern "C" void bath_tophits_set_inclusion(bath_tophits *th, double incE) { if (th) th->incE = incE; }
+extern "C" void bath_tophits_set_score_thresholds(bath_tophits *th, int by_E, double T, int inc_by_E, double incT) {
+  if (!th) return;
+  th->by_E = by_E ? 1 : 0; th->T = T; th->inc_by_E = inc_by_E ? 1 : 0; th->incT = incT;
+}
+// bathsearch.c:868-881: what p7_tophits_ComputeEvalues_BATH gets as N
+extern "C" int64_t bath_search_space_residues(int Z_is_set, double Z_megabases, int strands, int64_t nres_searched) {
+  if (!Z_is_set) return nres_searched;
+  int64_t n = (int64_t)(1000000 * Z_megabases);
+  if (strands == BATH_STRAND_BOTH) n *= 2;
+  return n;
+}
 
 extern "C" int bath_tophits_add(bath_tophits *th, const bath_fs_domain *dom, int64_t n, const char *cigars, int64_t seqidx0,
                                 const char *const *seq_names, const char *const *seq_accs, const char *const *seq_descs, const int64_t *seq_lens) {
@@ -134,9 +147,11 @@ extern "C" int bath_tophits_finalize(bath_tophits *th, int64_t nres, int max_len
   th->nreported = th->nincluded = 0;
   for (Hit &h : H) {
     h.flags &= ~(IS_REPORTED | IS_INCLUDED);
-    if (!(h.flags & IS_DUPLICATE) && std::exp(h.lnP) <= E) {
+    const bool reportable = th->by_E ? std::exp(h.lnP) <= E : (double)h.score >= th->T;                  // p7_pli_TargetReportable, p7_pipeline.c:583
+    if (!(h.flags & IS_DUPLICATE) && reportable) {
       h.flags |= IS_REPORTED; th->nreported++;
-      if (std::exp(h.lnP) <= th->incE) { h.flags |= IS_INCLUDED; th->nincluded++; }      // p7_pli_TargetIncludable
+      const bool includable = th->inc_by_E ? std::exp(h.lnP) <= th->incE : (double)h.score >= th->incT;  // p7_pli_TargetIncludable, :595
+      if (includable) { h.flags |= IS_INCLUDED; th->nincluded++; }
     }
   }
   return BATH_OK;

@@ -195,6 +195,45 @@ static const char *ncbi_code(int id) {
   }
 }
 
+// Start codons of the NCBI tables (gc.prt "sncbieaa", 'M' = may initiate), TCAG order: what esl_gencode_Set leaves in
+// gcode->is_initiator and bathsearch keeps under -M only (bathsearch.c:718-719).  Easel is not in the reference tree: unpinned.
+static const char *ncbi_starts(int id) {
+  switch (id) {
+    case 1:  return "---M---------------M---------------M----------------------------";
+    case 2:  return "--------------------------------MMMM---------------M------------";
+    case 3:  return "----------------------------------MM----------------------------";
+    case 4:  return "--MM---------------M------------MMMM---------------M------------";
+    case 5:  return "---M----------------------------MMMM---------------M------------";
+    case 6:  return "-----------------------------------M----------------------------";
+    case 9:  return "-----------------------------------M---------------M------------";
+    case 10: return "-----------------------------------M----------------------------";
+    case 11: return "---M---------------M------------MMMM---------------M------------";
+    case 12: return "-------------------M---------------M----------------------------";
+    case 13: return "---M------------------------------MM---------------M------------";
+    case 14: return "-----------------------------------M----------------------------";
+    case 16: return "-----------------------------------M----------------------------";
+    case 21: return "-----------------------------------M---------------M------------";
+    case 22: return "-----------------------------------M----------------------------";
+    case 23: return "--------------------------------M--M---------------M------------";
+    case 24: return "---M---------------M---------------M---------------M------------";
+    case 25: return "---M-------------------------------M---------------M------------";
+    default: return nullptr;
+  }
+}
+
+extern "C" int bath_gencode_initiators(int ncbi_table, int initiator, uint8_t is_init[64]) {
+  if (!is_init) return BATH_EINVAL;
+  if (initiator == BATH_INIT_ANY) { std::memset(is_init, 1, 64); return BATH_OK; }     // esl_gencode_SetInitiatorAny (a stop still ends the ORF)
+  std::memset(is_init, 0, 64);
+  if (initiator == BATH_INIT_AUG) { is_init[16 * 0 + 4 * 3 + 2] = 1; return BATH_OK; } // esl_gencode_SetInitiatorOnlyAUG
+  if (initiator != BATH_INIT_TABLE) return BATH_EINVAL;
+  const char *st = ncbi_starts(ncbi_table);
+  if (!st) return BATH_EINVAL;
+  const int to_easel[4] = {3, 1, 0, 2};
+  for (int i = 0; i < 64; i++) is_init[16 * to_easel[i >> 4] + 4 * to_easel[(i >> 2) & 3] + to_easel[i & 3]] = (uint8_t)(st[i] == 'M');
+  return BATH_OK;
+}
+
 extern "C" int bath_gencode_basic(int ncbi_table, uint8_t basic[64]) {
   const char *code = ncbi_code(ncbi_table);
   if (!code) return BATH_EINVAL;

@@ -220,7 +220,28 @@ typedef struct {
    * :1246), so the hits of a block do not depend on how a search is cut into blocks as long as every block is told where it
    * starts; 0 for a search's first (or only) block. */
   int64_t nres_before;
+  /* The rest of the option state p7_pipeline_Create_BATH keeps and the hot path reads (p7_pipeline.c:94-234; bathsearch.c:718-719,
+   * :831-833).  bath_pipeline_params_default sets bathsearch's defaults; INTEGRATION.md section 4 maps each field to its pli-> member. */
+  int32_t do_null2;               /* pli->do_null2: 1; --nonull2 clears it (:199, :213).  0: a hit's bias correction is 0 (:1063-1066, :1230-1233) */
+  int32_t std_pipe;               /* pli->std_pipe: 1; --fsonly clears it (:107).  0: P_tot = 1 in the branch decision and a window that does not
+                                   * take the frameshift branch is dropped (:1457, :1480)                                                          */
+  int32_t strands;                /* pli->strands: BATH_STRAND_BOTH (0), _TOPONLY (--strand plus), _BOTTOMONLY (--strand minus); only the strands
+                                   * searched are translated and counted in nres (bathsearch.c:1069, :1082, :1256, :1267)                          */
+  int32_t initiator;              /* which codons may start an ORF (bathsearch.c:718-719): BATH_INIT_ANY (0, the default: esl_gencode_SetInitiatorAny),
+                                   * BATH_INIT_TABLE (-M: the codon table's own start codons), BATH_INIT_AUG (-m: esl_gencode_SetInitiatorOnlyAUG).
+                                   * With -m / -M the initiation codon is translated as M (esl_gencode_WorkstateCreate: using_initiators)           */
+  int32_t inc_by_E;               /* pli->inc_by_E: 1; --incT clears it (:165-175).  The domain stage's early tests go by THIS flag, not by_E:
+                                   * 1: drop / flag by P * Z > E (p7_domaindef.c:1034; :1080, :1247); 0: no early drop, flag by bit score >= T       */
+  int32_t seed;                   /* --seed (:98): 42.  Every region's stochastic-trace ensemble starts from it (do_reseeding, p7_domaindef.c:781,
+                                   * :904); 0: one arbitrary seed per process, the generator runs on from region to region (:140-143)                */
+  double  T;                      /* pli->T: -T, 0.0 when not given (:148, :155); the early test's bit-score threshold when inc_by_E is 0           */
 } bath_pipeline_params;
+#define BATH_STRAND_BOTH       0
+#define BATH_STRAND_TOPONLY    1
+#define BATH_STRAND_BOTTOMONLY 2
+#define BATH_INIT_ANY   0
+#define BATH_INIT_TABLE 1
+#define BATH_INIT_AUG   2
 
 typedef struct {                   /* one per ORF that passed the MSV filter (P <= F1) */
   int64_t window;                  /* index of the DNA window in the block                               */
@@ -253,6 +274,12 @@ typedef struct {
 /* On return *orfs (sorted by window, strand, frame, start) and *aa are owned by ctx, valid until the next call. */
 int  bath_hip_translate_orfs(bath_hip_ctx *ctx, const bath_hip_seqs *dna, int ncbi_table, int min_orf_len,
                              const bath_orf **orfs, int64_t *n_orfs, const uint8_t **aa);
+/* ... for one strand only and / or with initiation codons (bath_pipeline_params.strands, .initiator) */
+int  bath_hip_translate_orfs_opts(bath_hip_ctx *ctx, const bath_hip_seqs *dna, int ncbi_table, int min_orf_len, int strands, int initiator,
+                                  const bath_orf **orfs, int64_t *n_orfs, const uint8_t **aa);
+/* gcode->is_initiator[16 a + 4 b + c] (easel codes A C G T = 0..3) under <initiator>; the table's own start codons are NCBI's
+ * (gc.prt "sncbieaa" line); easel's copy is not in the reference tree, so BATH_INIT_TABLE is parity-unpinned */
+int  bath_gencode_initiators(int ncbi_table, int initiator, uint8_t is_init[64]);
 
 void bath_pipeline_params_default(bath_pipeline_params *p, int fs_pipe);
 /* Runs the cascade on every window of <dna>, both strands.  On return *results points to an array of
@@ -289,7 +316,7 @@ typedef struct {
   float   tot_orfsc;               /* log-sum of the ORFs' (Forward - null) scores, nats (:1408)             */
   float   nullsc, filtersc, fwdsc; /* of the DNA window: null, bias-filter and frameshift Forward scores      */
   double  P_tot, P_min, P_fs, P_null;
-  int32_t branch;                  /* 1: frameshift branch (:1464); 2: standard branch (:1479)               */
+  int32_t branch;                  /* 1: frameshift branch (:1464); 2: standard branch (:1479); 0: neither (--fsonly, :1480) */
 } bath_fs_window;
 /* <om_fs3> is the 3-codon frameshift profile.  stats->pos_past_fwd counts as the reference does in this mode
  * (:1468, :1490).  *fs_windows is owned by ctx, valid until the next call; results/n_results as in
@@ -374,6 +401,14 @@ int  bath_tophits_add(bath_tophits *th, const bath_fs_domain *dom, int64_t n, co
                       const char *const *seq_names, const char *const *seq_accs, const char *const *seq_descs, const int64_t *seq_lens);
 /* <nres>: residues searched, both strands (sum of the pipelines' nres); E: reporting threshold (-E, default 10). */
 int  bath_tophits_finalize(bath_tophits *th, int64_t nres, int max_length, double E);
+/* Reporting / inclusion by bit score (p7_pli_TargetReportable / p7_pli_TargetIncludable, p7_pipeline.c:583-603), before finalize:
+ * by_E = 0 (-T): a hit is reported when score >= T instead of exp(lnP) <= E; inc_by_E = 0 (--incT): included when score >= incT
+ * instead of exp(lnP) <= incE.  Defaults: both by E. */
+void bath_tophits_set_score_thresholds(bath_tophits *th, int by_E, double T, int inc_by_E, double incT);
+/* The residue count bathsearch hands p7_tophits_ComputeEvalues_BATH (bathsearch.c:868-881): with -Z <x> it is 1e6 * x, doubled when
+ * both strands are searched, whatever was searched; without, the sum of the workers' pli->nres.  Pass the result to
+ * bath_tophits_finalize as <nres>. */
+int64_t bath_search_space_residues(int Z_is_set, double Z_megabases, int strands, int64_t nres_searched);
 int64_t bath_tophits_count(const bath_tophits *th);       /* hits held, reported or not */
 int64_t bath_tophits_reported(const bath_tophits *th);
 #define BATH_HIT_REPORTED  1

@@ -107,6 +107,69 @@ static const char *ncbi_table(int ct)
   }
 }
 
+/* Start codons of the NCBI translation tables (the "sncbieaa" line of NCBI's gc.prt, 'M' = may initiate), TCAG order like the
+ * tables above.  esl_gencode_Set copies them into gcode->is_initiator; bathsearch keeps them only under -M (bathsearch.c:718-719).
+ * Easel is not in the reference tree, so its copy of these lines cannot be compared: PARITY UNPINNED (NCBI has added start
+ * codons to some tables over the years; these are the lines of the gc.prt generation easel's tables date from). */
+static const char *ncbi_starts(int ct)
+{
+  switch (ct) {
+  case 1:  return "---M---------------M---------------M----------------------------";
+  case 2:  return "--------------------------------MMMM---------------M------------";
+  case 3:  return "----------------------------------MM----------------------------";
+  case 4:  return "--MM---------------M------------MMMM---------------M------------";
+  case 5:  return "---M----------------------------MMMM---------------M------------";
+  case 6:  return "-----------------------------------M----------------------------";
+  case 9:  return "-----------------------------------M---------------M------------";
+  case 10: return "-----------------------------------M----------------------------";
+  case 11: return "---M---------------M------------MMMM---------------M------------";
+  case 12: return "-------------------M---------------M----------------------------";
+  case 13: return "---M------------------------------MM---------------M------------";
+  case 14: return "-----------------------------------M----------------------------";
+  case 16: return "-----------------------------------M----------------------------";
+  case 21: return "-----------------------------------M---------------M------------";
+  case 22: return "-----------------------------------M----------------------------";
+  case 23: return "--------------------------------M--M---------------M------------";
+  case 24: return "---M---------------M---------------M---------------M------------";
+  case 25: return "---M-------------------------------M---------------M------------";
+  default: return NULL;
+  }
+}
+
+int bo_gencode_initiators(int ct, int mode, uint8_t is_init[64])
+{
+  static const int tcag2acgt[4] = { 3, 1, 0, 2 };
+  if (mode == 0) { memset(is_init, 1, 64); return BO_OK; }           /* esl_gencode_SetInitiatorAny: every codon, stops included (a stop still ends the ORF) */
+  memset(is_init, 0, 64);
+  if (mode == 2) { is_init[16 * 0 + 4 * 3 + 2] = 1; return BO_OK; }  /* esl_gencode_SetInitiatorOnlyAUG */
+  const char *st = ncbi_starts(ct);
+  if (!st) return BO_EINVAL;
+  for (int a = 0; a < 4; a++)
+    for (int b = 0; b < 4; b++)
+      for (int c = 0; c < 4; c++)
+        is_init[16 * tcag2acgt[a] + 4 * tcag2acgt[b] + tcag2acgt[c]] = (uint8_t)(st[16 * a + 4 * b + c] == 'M');
+  return BO_OK;
+}
+
+/* esl_gencode_IsInitiator: a canonical codon by the table; a degenerate one only when every codon it stands for is an initiator */
+int bo_gencode_is_initiator(const uint8_t is_init[64], const uint8_t *d)
+{
+  if (d[0] < 4 && d[1] < 4 && d[2] < 4) return is_init[16 * d[0] + 4 * d[1] + d[2]];
+  int n = 0;
+  for (int x = 0; x < 4; x++) {
+    if (!bo_dna_degen(d[0], x)) continue;
+    for (int y = 0; y < 4; y++) {
+      if (!bo_dna_degen(d[1], y)) continue;
+      for (int z = 0; z < 4; z++) {
+        if (!bo_dna_degen(d[2], z)) continue;
+        if (!is_init[16 * x + 4 * y + z]) return 0;
+        n++;
+      }
+    }
+  }
+  return n > 0;
+}
+
 /* basic[16*n1+4*n2+n3] with n in easel order A,C,G,T (modelconfig.c:364) */
 int bo_gencode_basic(int ct, uint8_t basic[64])
 {

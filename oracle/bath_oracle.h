@@ -250,6 +250,16 @@ void  bo_orfblock_reuse(bo_orfblock *b);
 void  bo_orfblock_free(bo_orfblock *b);
 /* translate one strand of dsq[1..n] (already reverse-complemented by the caller for the bottom strand) */
 int   bo_translate_orfs(const uint8_t *dsq, int n, const uint8_t basic[64], int minlen, bo_orfblock *out);
+/* ... with initiation codons (bathsearch -m / -M): is_init[64] marks the canonical codons that may start an ORF
+ * (gcode->is_initiator); using_initiators != 0: the initiation codon is translated as M whatever it encodes
+ * (esl_gencode_WorkstateCreate: -m or -M).  NULL is_init = any codon (bo_translate_orfs). */
+int   bo_translate_orfs_init(const uint8_t *dsq, int n, const uint8_t basic[64], const uint8_t *is_init, int using_initiators,
+                             int minlen, bo_orfblock *out);
+/* gcode->is_initiator[16*n1+4*n2+n3] for mode 0 (any: esl_gencode_SetInitiatorAny), 1 (the NCBI table's start codons, what
+ * esl_gencode_Set leaves), 2 (AUG only: esl_gencode_SetInitiatorOnlyAUG) */
+int   bo_gencode_initiators(int ct, int mode, uint8_t is_init[64]);
+int   bo_gencode_is_initiator(const uint8_t is_init[64], const uint8_t *codon3);   /* esl_gencode_IsInitiator: every expansion of a degenerate codon must be one */
+void  bo_set_seed(uint32_t seed);              /* the stochastic-trace ensembles' generator seed (pli->r), 42 by default; 0 = no reseeding */
 
 /* ============ frameshift generic kernels (fs_*.c) ============ */
 /* GMX-like matrices: dp rows of (M+1)*nscells floats, xmx (L+1)*5 floats */
@@ -279,6 +289,19 @@ typedef struct {
   double  E;                                   /* reporting E-value threshold (p7_pipeline.c:147), 10.0 */
   int32_t context;                             /* ESL_SQ.C of the window being searched: leading nucleotides the previous window
                                                 * already covered (bathsearch.c:1099; p7_pipeline.c:1635-1637); 0 for whole sequences */
+  /* option state of p7_pipeline_Create_BATH (p7_pipeline.c:94-234) and bathsearch.c:718-719, :831-833 that the hot path reads;
+   * bo_pipeline_init sets the defaults */
+  int32_t do_null2;                            /* --nonull2 clears it (:199, :213); read at :1063, :1230                              */
+  int32_t std_pipe;                            /* --fsonly clears it (:107); read at :1457, :1480                                     */
+  int32_t strands;                             /* 0 both, 1 top only (--strand plus), 2 bottom only (minus); bathsearch.c:1069, :1082 */
+  int32_t initiator;                           /* 0 any codon (esl_gencode_SetInitiatorAny, the default), 1 the codon table's own
+                                                * initiators (-M), 2 AUG only (-m); bathsearch.c:718-719                              */
+  int32_t ct;                                  /* NCBI table id (for initiator == 1)                                                  */
+  int32_t inc_by_E;                            /* --incT clears it (:165-175); the pipeline's early tests go by it (:1080, :1247,
+                                                * p7_domaindef.c:1034), NOT by by_E                                                  */
+  double  T;                                   /* pli->T: -T, 0.0 when not given (:148, :155); the early test's bit-score threshold
+                                                * when inc_by_E is off                                                                */
+  uint32_t seed;                               /* --seed, 42 (:98); 0: no reseeding between regions (:140-143)                        */
 } bo_pipeline;
 
 typedef struct {                 /* per-ORF cascade record (what the GPU path must reproduce) */

@@ -412,14 +412,14 @@ int bo_domaindef_std(bo_pipeline *pli, bo_oprofile *om, bo_bg *bg, const uint8_t
     bitscore += 2 * log(2. / (ml + 2));
     bitscore -= (env_len - ali_len) * log((float) env_len / (float)(env_len + 2));
     bitscore += (ml - ali_len) * log((float) ml / (float)(ml + 2));
-    const float dom_bias = bo_flogsum(0.0f, (float)(log(1. / 256.) + dm->domcorrection));
+    const float dom_bias = pli->do_null2 ? bo_flogsum(0.0f, (float)(log(1. / 256.) + dm->domcorrection)) : 0.0f;   /* :1230-1233 */
     bo_bg_setlength(bg, ml);
     const float nullsc = bo_bg_nullone(bg, ml);
     const float dom_score = (float)((bitscore - (nullsc + dom_bias)) / LOG2C);
     const float lnP = (float) bo_exp_logsurv(dom_score, om->evparam[BO_FTAU], om->evparam[BO_FLAMBDA]);
     const double Z = (double)(float)((float) pli->nres / (float) ml);
     dm->dombias = dom_bias; dm->bitscore = dom_score; dm->lnP = lnP; dm->pre_score = (float)(bitscore / LOG2C);
-    dm->reported = (exp(lnP) * Z <= pli->E) ? 1 : 0;
+    dm->reported = (pli->inc_by_E ? (exp(lnP) * Z <= pli->E) : (dom_score >= pli->T)) ? 1 : 0;          /* :1247-1248 */
   }
   *ndom = kept;
   return BO_OK;

@@ -249,7 +249,7 @@ static int rescore_domain(const bo_pipeline *pli, bo_fs_profile *gm5, bo_bg *bg,
     const float seqscore = (float)((envsc - nullsc) / LOG2C);
     const double P = bo_exp_surv(seqscore, gm5->evparam[BO_FTAUFS5], gm5->evparam[BO_FLAMBDA]);
     const double Z = (double)(float)((float) pli->nres / (float) gm5->max_length);    /* pli->Z, p7_domaindef.c:1033 */
-    if (P * Z > pli->E) goto DONE;
+    if (pli->inc_by_E && P * Z > pli->E) goto DONE;            /* :1034 */
   }
   if (bo_gbackward_fs(wdsq + i - 1, Ld, gm5, bck, NULL) == BO_ERANGE) goto DONE;
   if (bo_gdecoding_fs(gm5, fwd, bck) == BO_ERANGE) { status = BO_FAIL; goto DONE; }
@@ -413,7 +413,7 @@ int bo_domaindef_fs(bo_pipeline *pli, bo_fs_profile *gm3, bo_fs_profile *gm5, bo
     bitscore += 2 * log(2. / (ml + 2));
     bitscore -= ((env_len - ali_len) / 3.) * log((float)(env_len / 3.) / (float)((env_len / 3.) + 2));
     bitscore += (((env_len > ml * 3 ? env_len : ml * 3) - ali_len) / 3.) * log((float) ml / (float)(ml + 2));
-    const float dom_bias = bo_flogsum(0.0f, (float)(log(1. / 256.) + dm->domcorrection));      /* bg->omega, p7_bg.c:74 */
+    const float dom_bias = pli->do_null2 ? bo_flogsum(0.0f, (float)(log(1. / 256.) + dm->domcorrection)) : 0.0f;   /* :1063-1066; bg->omega, p7_bg.c:74 */
     const int nl = (env_len / 3 > ml) ? env_len / 3 : ml;
     bo_bg_setlength(bg, nl);
     const float nullsc = bo_bg_fs_nullone(bg, nl);
@@ -422,7 +422,7 @@ int bo_domaindef_fs(bo_pipeline *pli, bo_fs_profile *gm3, bo_fs_profile *gm5, bo
     const double Z = (double)(float)((float) pli->nres / (float) ml);
     dm->dombias = dom_bias; dm->bitscore = dom_score; dm->lnP = lnP;
     dm->pre_score = (float)(bitscore / LOG2C);
-    dm->reported = (exp(lnP) * Z <= pli->E) ? 1 : 0;
+    dm->reported = (pli->inc_by_E ? (exp(lnP) * Z <= pli->E) : (dom_score >= pli->T)) ? 1 : 0;          /* :1080 */
   }
   return BO_OK;
 }

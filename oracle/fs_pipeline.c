@@ -124,6 +124,7 @@ int bo_pli_frameshift(bo_pipeline *pli, bo_oprofile *om, bo_fs_profile *gm3, bo_
       }
     }
     double P_tot = bo_exp_surv(tot / LOG2C, om->evparam[BO_FTAU], om->evparam[BO_FLAMBDA]);
+    if (!pli->std_pipe) P_tot = 1.0;                          /* :1457, --fsonly */
     const int L = wl[w].length;
     bo_bg_setlength(bg, L / 3);
     float nullsc = bo_bg_fs_nullone(bg, L / 3);
@@ -159,6 +160,8 @@ int bo_pli_frameshift(bo_pipeline *pli, bo_oprofile *om, bo_fs_profile *gm3, bo_
         bo_domaindef_fs(pli, gm3, gm5, bg, wdsq, L, (int) wl[w].n, complementarity, n, doms, ndom, dom_alloc, nskipped);
         r.ndom = *ndom - before;
       }
+    } else if (!pli->std_pipe) {
+      r.branch = 0;                                           /* :1480: --fsonly has no standard branch, the window is dropped */
     } else {                                                  /* :1479 std_pipe */
       r.branch = 2;
       for (int i = 0; i < norf; i++) {

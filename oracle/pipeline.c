@@ -21,6 +21,8 @@ void bo_pipeline_init(bo_pipeline *pli, int fs_pipe)      /* p7_pipeline.c:219-2
   pli->do_biasfilter = 1;
   pli->fs_pipe = fs_pipe;
   pli->minlen = 20;
+  pli->do_null2 = 1; pli->std_pipe = 1; pli->strands = 0; pli->initiator = 0; pli->ct = 1;   /* p7_pipeline.c:107, :199; bathsearch.c:97, :718 */
+  pli->inc_by_E = 1; pli->T = 0.0; pli->seed = 42;                                            /* p7_pipeline.c:98, :148, :165 */
 }
 
 /* p7_pli_ComputeLocalCompo, p7_pipeline.c:427-458 */
@@ -193,19 +195,26 @@ int bo_pipeline_window_fsdom(bo_pipeline *pli, bo_oprofile *om, bo_fs_profile *g
   bo_orfblock_init(&blk);
   bo_bg_setfilter(bg, om->M, om->compo);                      /* p7_pli_NewModel, p7_pipeline.c:635 */
   fs_stage fs = { gm3, gm5, basic, dna, n, fw, nfw, fw_alloc, doms, ndom, dom_alloc, nskipped };
+  uint8_t is_init[64];                                        /* bathsearch.c:718-719: -m, -M, or any codon */
+  if (pli->initiator && bo_gencode_initiators(pli->ct, pli->initiator, is_init) != BO_OK) return BO_EINVAL;
+  const uint8_t *ini = pli->initiator ? is_init : NULL;
+  bo_set_seed(pli->seed);
 
-  pli->nres += n - pli->context;                              /* top strand: dnaSeq->W, bathsearch.c:1258 */
-  bo_translate_orfs(dna, n, basic, pli->minlen, &blk);
-  strand_cascade(pli, om, sd, bg, &blk, 0, res, nres, res_alloc, &fs);
-  bo_orfblock_reuse(&blk);
-
-  uint8_t *rc = malloc((size_t) n + 2);                       /* bottom strand, bathsearch.c:1084-1091 */
-  bo_revcomp(dna, n, rc);
-  pli->nres += n - pli->context;
-  bo_translate_orfs(rc, n, basic, pli->minlen, &blk);
-  fs.dsq = rc;
-  strand_cascade(pli, om, sd, bg, &blk, 1, res, nres, res_alloc, &fs);
-  free(rc);
+  if (pli->strands != 2) {                                    /* bathsearch.c:1069, :1256: not p7_STRAND_BOTTOMONLY */
+    pli->nres += n - pli->context;                            /* top strand: dnaSeq->W, bathsearch.c:1258 */
+    bo_translate_orfs_init(dna, n, basic, ini, pli->initiator != 0, pli->minlen, &blk);
+    strand_cascade(pli, om, sd, bg, &blk, 0, res, nres, res_alloc, &fs);
+    bo_orfblock_reuse(&blk);
+  }
+  if (pli->strands != 1) {                                    /* :1082, :1267: not p7_STRAND_TOPONLY */
+    uint8_t *rc = malloc((size_t) n + 2);                     /* bottom strand, bathsearch.c:1084-1091 */
+    bo_revcomp(dna, n, rc);
+    pli->nres += n - pli->context;
+    bo_translate_orfs_init(rc, n, basic, ini, pli->initiator != 0, pli->minlen, &blk);
+    fs.dsq = rc;
+    strand_cascade(pli, om, sd, bg, &blk, 1, res, nres, res_alloc, &fs);
+    free(rc);
+  }
   bo_orfblock_free(&blk);
   return BO_OK;
 }

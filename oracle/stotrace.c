@@ -41,6 +41,19 @@ static uint32_t jenkins_mix3(uint32_t a, uint32_t b, uint32_t c)
   c -= a; c -= b; c ^= (b >> 15);
   return c;
 }
+/* pli->r / ddef->do_reseeding (p7_pipeline.c:140-143; p7_domaindef.c:781, :904): with a seed every region's ensemble starts
+ * from it; with seed 0 the generator is seeded once (the reference takes the time of day: "arbitrary") and runs on. */
+static uint32_t g_seed = 42;
+static bo_rng g_running;
+static int g_running_init = 0;
+void bo_set_seed(uint32_t seed) { if (seed != g_seed) g_running_init = 0; g_seed = seed; }
+static void region_rng(bo_rng *r)
+{
+  if (g_seed != 0) { bo_rng_init(r, g_seed); return; }
+  if (!g_running_init) { bo_rng_init(&g_running, 20260000u); g_running_init = 1; }
+  *r = g_running;
+}
+static void region_rng_done(const bo_rng *r) { if (g_seed == 0) g_running = *r; }
 void bo_rng_init(bo_rng *r, uint32_t seed) { r->x = jenkins_mix3(seed, 87654321, 12345678); if (r->x == 0) r->x = 42; }
 double bo_rng_next(bo_rng *r) { r->x *= 69069; r->x += 1; return (double) r->x / 4294967296.0; }
 
@@ -246,7 +259,7 @@ int bo_region_trace_ensemble(const bo_oprofile *om, const uint8_t *dsq, int ireg
   spcoord *sp = NULL;
   int nsp = 0, sp_alloc = 0;
   bo_rng rng;
-  bo_rng_init(&rng, 42);                                    /* do_reseeding: every region starts from the seed */
+  region_rng(&rng);                                         /* do_reseeding: every region starts from the seed */
   for (int pos = ireg; pos <= jreg; pos++) n2sc[pos] = 0.f;
   for (int t = 0; t < nsamples; t++) {
     const int N = bo_stochastic_trace(&rng, Lr, om, fwd, fx, st, tk, ti, cap);
@@ -287,6 +300,7 @@ int bo_region_trace_ensemble(const bo_oprofile *om, const uint8_t *dsq, int ireg
   }
   for (int pos = ireg; pos <= jreg; pos++) n2sc[pos] = logf(n2sc[pos] / (float) nsamples);
   free(st); free(tk); free(ti); free(cnt);
+  region_rng_done(&rng);
 
   return cluster_segments(sp, nsp, nsamples, Lr + M + 4, 0, env, max_env);
 }
@@ -406,7 +420,7 @@ int bo_region_trace_ensemble_fs(const bo_fs_profile *gm5, int ireg, int jreg, co
   spcoord *sp = NULL;
   int nsp = 0, sp_alloc = 0, ok = 1;
   bo_rng rng;
-  bo_rng_init(&rng, 42);
+  region_rng(&rng);
   for (int t = 0; t < nsamples && ok; t++) {
     const int N = stochastic_trace_fs(&rng, Lr, gm5, fwd, sc, st, tk, ti, tc, cap);
     if (N < 0) { ok = 0; break; }
@@ -420,6 +434,7 @@ int bo_region_trace_ensemble_fs(const bo_fs_profile *gm5, int ireg, int jreg, co
     }
   }
   free(st); free(tc); free(tk); free(ti); free(sc);
+  region_rng_done(&rng);
   if (!ok) { free(sp); return 0; }
   return cluster_segments(sp, nsp, nsamples, jreg + M + 8, 1, env, max_env);
 }

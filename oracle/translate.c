@@ -36,6 +36,15 @@ static void emit(bo_orfblock *b, const uint8_t *buf, int n, int start, int end, 
 
 int bo_translate_orfs(const uint8_t *dsq, int n, const uint8_t basic[64], int minlen, bo_orfblock *out)
 {
+  return bo_translate_orfs_init(dsq, n, basic, NULL, 0, minlen, out);
+}
+
+/* With initiation codons (esl_gencode_ProcessPiece, restated from the published esl-translate behaviour): a stop closes the
+ * frame's ORF whether or not one is open; any other codon extends an open ORF; with no ORF open it starts one only if it is
+ * an initiator, and is then translated as M when -m / -M is in force (using_initiators).  minlen counts that M. */
+int bo_translate_orfs_init(const uint8_t *dsq, int n, const uint8_t basic[64], const uint8_t *is_init, int using_initiators,
+                           int minlen, bo_orfblock *out)
+{
   uint8_t *buf[3];
   int len[3] = { 0, 0, 0 }, start[3] = { 0, 0, 0 };
   for (int f = 0; f < 3; f++) buf[f] = malloc((size_t) n / 3 + 2);
@@ -46,7 +55,11 @@ int bo_translate_orfs(const uint8_t *dsq, int n, const uint8_t basic[64], int mi
       if (len[f] >= minlen) emit(out, buf[f], len[f], start[f], p - 1, f);
       len[f] = 0;
     } else {
-      if (len[f] == 0) start[f] = p;
+      if (len[f] == 0) {
+        if (is_init && !bo_gencode_is_initiator(is_init, dsq + p)) continue;
+        start[f] = p;
+        if (is_init && using_initiators) aa = 10;   /* 'M' in "ACDEFGHIKLMNPQRSTVWY" */
+      }
       buf[f][len[f]++] = aa;
     }
   }

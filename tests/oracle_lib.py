@@ -105,7 +105,18 @@ class Pipeline(C.Structure):
                 ("n_past_vit", C.c_int64), ("n_past_fwd", C.c_int64),
                 ("pos_past_msv", C.c_int64), ("pos_past_bias", C.c_int64), ("pos_past_vit", C.c_int64),
                 ("pos_past_fwd", C.c_int64),
-                ("cells_msv", C.c_int64), ("cells_vit", C.c_int64), ("cells_fwd", C.c_int64), ("E", C.c_double), ("context", C.c_int32)]
+                ("cells_msv", C.c_int64), ("cells_vit", C.c_int64), ("cells_fwd", C.c_int64), ("E", C.c_double), ("context", C.c_int32),
+                # option state (bath_oracle.h): --nonull2, --fsonly, --strand, -m/-M (+ the codon table id), --incT, -T, --seed
+                ("do_null2", C.c_int32), ("std_pipe", C.c_int32), ("strands", C.c_int32), ("initiator", C.c_int32), ("ct", C.c_int32),
+                ("inc_by_E", C.c_int32), ("T", C.c_double), ("seed", C.c_uint32)]
+
+
+def apply_opts(pli, ct, opts):
+    """opts: dict of bo_pipeline option fields (do_null2, std_pipe, strands, initiator, inc_by_E, T, seed, F1..F4, do_biasfilter, minlen)."""
+    pli.ct = ct
+    for k, v in (opts or {}).items():
+        assert hasattr(pli, k), k
+        setattr(pli, k, v)
 
 
 class FsDomain(C.Structure):
@@ -194,6 +205,9 @@ def lib():
     L.bo_orfblock_reuse.argtypes = [C.POINTER(OrfBlock)]
     L.bo_orfblock_free.argtypes = [C.POINTER(OrfBlock)]
     L.bo_translate_orfs.argtypes = [u8p, C.c_int, u8p, C.c_int, C.POINTER(OrfBlock)]
+    L.bo_translate_orfs_init.argtypes = [u8p, C.c_int, u8p, u8p, C.c_int, C.c_int, C.POINTER(OrfBlock)]
+    L.bo_gencode_initiators.argtypes = [C.c_int, C.c_int, u8p]
+    L.bo_set_seed.argtypes = [C.c_uint32]
     L.bo_gencode_basic.argtypes = [C.c_int, u8p]
     L.bo_revcomp.argtypes = [u8p, C.c_int, u8p]
     L.bo_pipeline_init.argtypes = [C.POINTER(Pipeline), C.c_int]
@@ -309,11 +323,12 @@ class Model:
             self._fs[key] = lib().bo_fs_profile_config(self.hmm, C.byref(self.bg), u8(self.basic), codon_lengths, L_amino)
         return self._fs[key]
 
-    def run_pipeline(self, seqs, fs_pipe=False):
+    def run_pipeline(self, seqs, fs_pipe=False, opts=None):
         """seqs: list of digitized DNA code arrays. Returns (Pipeline counters, list of OrfResult copies)."""
         L_ = lib()
         pli = Pipeline()
         L_.bo_pipeline_init(C.byref(pli), 1 if fs_pipe else 0)
+        apply_opts(pli, self.hmm.contents.ct, opts)
         res = C.POINTER(OrfResult)()
         nres, alloc = C.c_int(0), C.c_int(0)
         per_seq = []
@@ -326,12 +341,13 @@ class Model:
         out = [res[i] for i in range(nres.value)]
         return pli, out, per_seq
 
-    def run_pipeline_hits(self, seqs, contexts=None, E=None):
+    def run_pipeline_hits(self, seqs, contexts=None, E=None, opts=None):
         """The plain pipeline through domain definition: (Pipeline counters, FsDomain records, per-sequence ranges, skipped).
         contexts[i]: ESL_SQ.C of window i (leading nucleotides shared with the previous window of the same target)."""
         L_ = lib()
         pli = Pipeline()
         L_.bo_pipeline_init(C.byref(pli), 0)
+        apply_opts(pli, self.hmm.contents.ct, opts)
         if E is not None:
             pli.E = E                                          # the reporting threshold (-E, p7_pipeline.c:147)
         res = C.POINTER(OrfResult)(); nres, alloc = C.c_int(0), C.c_int(0)
@@ -346,7 +362,7 @@ class Model:
             per_d.append((d0, ndm.value))
         return pli, [dm[i] for i in range(ndm.value)], per_d, nskip.value
 
-    def run_pipeline_fsdom(self, seqs, contexts=None, E=None):
+    def run_pipeline_fsdom(self, seqs, contexts=None, E=None, opts=None):
         """run_pipeline_fs plus domain definition and hit scores for the windows that take the frameshift branch.
         contexts[i]: ESL_SQ.C of window i (as in run_pipeline_hits).
 
@@ -355,6 +371,7 @@ class Model:
         L_ = lib()
         pli = Pipeline()
         L_.bo_pipeline_init(C.byref(pli), 1)
+        apply_opts(pli, self.hmm.contents.ct, opts)
         if E is not None:
             pli.E = E
         gm3, gm5 = self.fs(3), self.fs(5)
@@ -372,13 +389,14 @@ class Model:
             per_w.append((w0, nfw.value)); per_d.append((d0, ndm.value))
         return pli, [fw[i] for i in range(nfw.value)], per_w, [dm[i] for i in range(ndm.value)], per_d, nskip.value
 
-    def run_pipeline_fs(self, seqs):
+    def run_pipeline_fs(self, seqs, opts=None):
         """The cascade with fs_pipe set plus the frameshift stage (oracle/fs_pipeline.c) on every window.
 
         Returns (Pipeline counters, ORF records, per-sequence ORF ranges, FsWindow records, per-sequence window ranges)."""
         L_ = lib()
         pli = Pipeline()
         L_.bo_pipeline_init(C.byref(pli), 1)
+        apply_opts(pli, self.hmm.contents.ct, opts)
         gm3 = self.fs(3)
         res = C.POINTER(OrfResult)()
         nres, alloc = C.c_int(0), C.c_int(0)
