@@ -58,7 +58,7 @@ class _Hmm(C.Structure):
     _fields_ = [("M", C.c_int32), ("max_length", C.c_int32), ("ct", C.c_int32), ("fsprob", C.c_float),
                 ("t", C.POINTER(C.c_float)), ("mat", C.POINTER(C.c_float)), ("ins", C.POINTER(C.c_float)),
                 ("compo", C.c_float * K), ("evparam", C.c_float * NEVPARAM), ("name", C.c_char * 128),
-                ("acc", C.c_char * 64), ("consensus", C.c_char_p)]
+                ("acc", C.c_char * 64), ("consensus", C.c_char_p), ("rf", C.c_char_p), ("cs", C.c_char_p)]
 
 
 class _Profile(C.Structure):
@@ -139,6 +139,20 @@ class FsDomain(C.Structure):
 
 
 _DTYPES = {}
+
+
+class DomainTrace(C.Structure):
+    """bath_domain_trace: where a domain's trace lies in the arrays of bath_hip_domain_traces."""
+    _fields_ = [("off", C.c_int64), ("N", C.c_int32), ("win_start", C.c_int32), ("orf_start", C.c_int32), ("frameshift", C.c_int32)]
+
+
+class AliDisplayOpts(C.Structure):
+    _fields_ = [("hmm_name", C.c_char_p), ("seq_name", C.c_char_p), ("consensus", C.c_char_p), ("rf", C.c_char_p), ("cs", C.c_char_p),
+                ("M", C.c_int32), ("sqfrom", C.c_int64), ("sqto", C.c_int64), ("textw", C.c_int32), ("show_frameline", C.c_int32),
+                ("initiator", C.c_int32)]
+
+
+T_M, T_D, T_I = 1, 2, 3
 
 
 def _np_dtype(T):
@@ -223,6 +237,11 @@ ABI = {
                                               C.POINTER(C.POINTER(OrfResult)), _i64p, C.POINTER(C.POINTER(FsWindow)), _i64p]),
     "bath_hip_oprofile_set_consensus": (C.c_int, [_vp, C.c_char_p]),
     "bath_hip_domain_cigars": (C.c_void_p, [_vp]),
+    "bath_hip_domain_traces": (C.c_int, [_vp, C.POINTER(C.POINTER(DomainTrace)), _i64p, C.POINTER(C.POINTER(C.c_int8)), C.POINTER(_i32p),
+                                         C.POINTER(_i32p), C.POINTER(C.POINTER(C.c_int8)), C.POINTER(_f32p)]),
+    "bath_alidisplay_print": (C.c_int64, [C.POINTER(DomainTrace), C.POINTER(C.c_int8), _i32p, _i32p, C.POINTER(C.c_int8), _f32p,
+                                          _u8p, C.c_int32, C.POINTER(_FsProfile), C.POINTER(_Profile), _u8p, C.POINTER(AliDisplayOpts),
+                                          C.c_char_p, C.c_int64]),
     "bath_selftest_rng_stream": (C.c_int, [C.c_uint32, C.c_int, C.POINTER(C.c_double)]),
     "bath_selftest_fchoose": (C.c_int, [C.c_uint32, _f32p, C.c_int, C.c_int, _i32p]),
     "bath_selftest_fs_ensemble": (C.c_int, [C.c_int, _f32p, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, _f32p, _f32p, _i32p, C.c_int, _i32p]),
@@ -316,6 +335,8 @@ class HMM:
         self.name = p.contents.name.decode()
         self.acc = p.contents.acc.decode()
         self.consensus = p.contents.consensus.decode() if p.contents.consensus else ""
+        self.rf = p.contents.rf.decode() if p.contents.rf else None
+        self.cs = p.contents.cs.decode() if p.contents.cs else None
         self.evparam = np.array(p.contents.evparam[:], dtype=np.float32)
 
     @staticmethod
@@ -766,6 +787,22 @@ class Pipeline:
             return out
         return stats, copies(fw, nfw.value, FsWindow), self._domains(dm, ndm.value), nskip.value
 
+    def traces(self):
+        """P7_DOMAIN.tr of every domain of the last run_hits / run_frameshift_domains call (bath_hip_domain_traces): a list of
+        (DomainTrace copy, st, k, i, c, pp) with numpy copies of the five arrays, entry d for domain d of that call."""
+        tr = C.POINTER(DomainTrace)(); n = C.c_int64(0)
+        st = C.POINTER(C.c_int8)(); k = _i32p(); i = _i32p(); c = C.POINTER(C.c_int8)(); pp = _f32p()
+        self.ctx._check(lib().bath_hip_domain_traces(self.ctx._h, C.byref(tr), C.byref(n), C.byref(st), C.byref(k), C.byref(i), C.byref(c), C.byref(pp)),
+                        "domain_traces")
+        out = []
+        for d in range(n.value):
+            t = DomainTrace()
+            C.memmove(C.byref(t), C.byref(tr[d]), C.sizeof(DomainTrace))
+            sl = slice(t.off, t.off + t.N)
+            grab = lambda p, dt: np.ctypeslib.as_array(p, shape=(t.off + t.N,))[sl].astype(dt).copy() if t.N else np.zeros(0, dt)
+            out.append((t, grab(st, np.int8), grab(k, np.int32), grab(i, np.int32), grab(c, np.int8), grab(pp, np.float32)))
+        return out
+
     def kernel_times(self):
         """Per-kernel device times of the stages after the cascade in the last run_frameshift_domains call:
         {name: (ms, launches, cells, bytes)}."""
@@ -779,6 +816,30 @@ class Pipeline:
         launches = np.zeros(32, dtype=np.int64)
         k = lib().bath_hip_pipeline_timings(self.ctx._h, 32, names, _f32(ms), _i64(launches))
         return [(names[i].decode(), float(ms[i]), int(launches[i])) for i in range(k)]
+
+
+def alidisplay_print(trace, window_codes, hmm, sqfrom, sqto, seq_name, gm_fs5=None, gm=None, ncbi_table=1, textw=150, frameline=False,
+                     initiator=INIT_ANY):
+    """The alignment block of one hit (bath_alidisplay_print: p7_alidisplay_*_Create + p7_alidisplay_Print_BATH).
+    trace: one entry of Pipeline.traces() (or the same six things from another source); window_codes: the digital nucleotides of
+    windowsq (the strand read, from trace[0].win_start on); gm_fs5 / gm: FSProfile (5 codon lengths) / Profile objects."""
+    t, st, k, i, c, pp = trace
+    st = np.ascontiguousarray(st, np.int8); k = np.ascontiguousarray(k, np.int32); i = np.ascontiguousarray(i, np.int32)
+    c = np.ascontiguousarray(c, np.int8); pp = np.ascontiguousarray(pp, np.float32)
+    win = np.ascontiguousarray(window_codes, np.uint8)
+    tr = DomainTrace(0, int(t.N), int(t.win_start), int(t.orf_start), int(t.frameshift))
+    o = AliDisplayOpts(hmm.name.encode(), seq_name.encode(), hmm.consensus.encode(), hmm.rf.encode() if hmm.rf else None,
+                       hmm.cs.encode() if hmm.cs else None, hmm.M, int(sqfrom), int(sqto), textw, 1 if frameline else 0, initiator)
+    basic = gencode_basic(ncbi_table)
+    p8 = lambda a: a.ctypes.data_as(C.POINTER(C.c_int8))
+    args = [C.byref(tr), p8(st), k.ctypes.data_as(_i32p), i.ctypes.data_as(_i32p), p8(c), _f32(pp), _u8(win), len(win),
+            gm_fs5._p if gm_fs5 is not None else None, gm._p if gm is not None else None, _u8(basic), C.byref(o)]
+    n = lib().bath_alidisplay_print(*args, None, 0)
+    if n < 0:
+        raise BathError("alidisplay_print failed")
+    buf = C.create_string_buffer(n + 1)
+    lib().bath_alidisplay_print(*args, buf, n)
+    return buf.raw[:n].decode()
 
 
 class HitArray:

@@ -198,6 +198,23 @@ struct bath_hip_ctx {
   std::vector<int32_t> fs_regions_all;    // ... for every DNA window: 1 + 3*fs_max_regions() ints each (bath_frameshift.hip: fs3_regions)
   std::vector<bath_fs_domain> fs_domains; // bath_hip_pipeline_frameshift_domains output
   std::string cigars;                     // NUL-terminated CIGAR strings of fs_domains (bath_fs_domain.cigar_off)
+  // the domains' traces (P7_DOMAIN.tr, first to last match state) as the trace kernels left them, one record per entry of fs_domains;
+  // bath_hip_domain_traces expands them into the reference's arrays on demand
+  struct TraceRec { int64_t col_off; int32_t ncol, k1, i_first, win_start, orf_start, frameshift, d_i; };
+  std::vector<TraceRec> tr_recs;
+  std::vector<uint16_t> tr_codes;         // per column: state (3 M, 4 D, 5 I) | codon length << 4 | indel label << 8
+  std::vector<float> tr_pp;               // per column: the state's posterior probability
+  void traces_clear() { tr_recs.clear(); tr_codes.clear(); tr_pp.clear(); tr_valid = false; }
+  void trace_push(const uint16_t *codes, const float *pp, int ncol, int k1, int i_first, int win_start, int orf_start, int frameshift, int d_i) {
+    tr_recs.push_back(TraceRec{(int64_t)tr_codes.size(), ncol, k1, i_first, win_start, orf_start, frameshift, d_i});
+    tr_codes.insert(tr_codes.end(), codes, codes + ncol);
+    if (pp) tr_pp.insert(tr_pp.end(), pp, pp + ncol); else tr_pp.insert(tr_pp.end(), (size_t)ncol, 0.0f);
+    tr_valid = false;
+  }
+  bool tr_valid = false;                  // tr_out .. tr_pp_out hold the expansion of tr_recs
+  std::vector<bath_domain_trace> tr_out;
+  std::vector<int8_t> tr_st, tr_c;
+  std::vector<int32_t> tr_k, tr_i;
   std::vector<bath::PipelineSurvivor> fs_std_orfs;   // ORFs of the windows that take the standard branch (p7_pipeline.c:1479-1510)
   const uint8_t *fs_std_pool = nullptr;              // their residues: the amino-acid streams of the last cascade
   std::vector<uint8_t> orf_aa;

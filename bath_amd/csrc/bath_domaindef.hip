@@ -192,6 +192,7 @@ static int fs_branch_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, con
   if (n_clustered_regions) *n_clustered_regions = 0;
   ctx->fs_domains.clear();
   ctx->cigars.clear();
+  ctx->traces_clear();
   ctx->spans_reset();
   bath_pipeline_stats st_local{};
   const bath_fs_window *fw = nullptr;
@@ -231,7 +232,7 @@ static int fs_branch_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, con
     mark_internal(ctx->aux);
     if ((st = om->ensure_len_tables(dna->maxlen / 3 + 1)) != BATH_OK) return st;      // the profile's mutable state: fill it before the thread starts
     bath_hip_ctx *aux = ctx->aux;
-    aux->fs_domains.clear(); aux->cigars.clear();
+    aux->fs_domains.clear(); aux->cigars.clear(); aux->traces_clear();
     const DomOpts std_opt(*prm, E_report);
     std_thread = std::thread([&, aux, std_opt] {
       if (hipSetDevice(ctx->device) != hipSuccess) { std_rc = BATH_EFAIL; return; }
@@ -247,6 +248,8 @@ static int fs_branch_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, con
     const int64_t shift = (int64_t)ctx->cigars.size();
     for (bath_fs_domain dm : ctx->aux->fs_domains) { dm.cigar_off += shift; ctx->fs_domains.push_back(dm); }
     ctx->cigars += ctx->aux->cigars;
+    for (const bath_hip_ctx::TraceRec &t : ctx->aux->tr_recs)
+      ctx->trace_push(ctx->aux->tr_codes.data() + t.col_off, ctx->aux->tr_pp.data() + t.col_off, t.ncol, t.k1, t.i_first, t.win_start, t.orf_start, t.frameshift, t.d_i);
     *std_clustered = std_nclust;
     return BATH_OK;
   };
@@ -285,6 +288,7 @@ static int fs_branch_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, con
   std::vector<bath_fs5_result> res;
   std::vector<FsTraceOut> traces;
   std::vector<uint16_t> steps;
+  std::vector<float> pps;                                                    // tr->pp per column, parallel to steps
   std::vector<int64_t> step_off;
   // The envelope kernels keep three matrices per envelope in HBM (Forward 32 B, Backward 12 B, optimal accuracy 12 B per
   // cell): the envelopes go through in batches of at most 24 GB of matrices (BATH_HIP_ENV_MB overrides, for tests), so a block
@@ -301,11 +305,12 @@ static int fs_branch_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, con
     std::vector<bath_fs5_result> res;
     std::vector<FsTraceOut> traces;
     std::vector<uint16_t> steps;
+    std::vector<float> pps;
     std::vector<int64_t> step_off;
   };
   auto run_env_batch = [&](bath_hip_ctx *c, const Env *list, int n, EnvBatch &out) -> int {
     out.eregs.resize((size_t)n); out.res.resize((size_t)n); out.traces.resize((size_t)n); out.step_off.assign((size_t)n + 1, 0);
-    out.steps.clear();
+    out.steps.clear(); out.pps.clear();
     for (int e = 0; e < n; e++) {
       const FsWinDev &wr = regs[(size_t)list[e].sel];
       FsWinDev d = wr;
@@ -322,16 +327,18 @@ static int fs_branch_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, con
       }
       std::vector<FsWinDev> chunk(out.eregs.begin() + e0, out.eregs.begin() + e1);
       std::vector<uint16_t> csteps;
+      std::vector<float> cpps;
       std::vector<int64_t> coff;
       bath_hip_seqs view;
       int st2 = fs_gather_view(c, dna, chunk, tt.comp, &view, nullptr);
       if (st2 != BATH_OK) { if (c != ctx) ctx->set_error(c->err); return st2; }
-      st2 = fs5_envelopes_ex(c, om_fs5, &view, BATH_LOGSUM_CONTEXT, 0, out.res.data() + e0, nullptr, nullptr, nullptr, nullptr, out.traces.data() + e0, om->d_cons, &csteps, &coff);
+      st2 = fs5_envelopes_ex(c, om_fs5, &view, BATH_LOGSUM_CONTEXT, 0, out.res.data() + e0, nullptr, nullptr, nullptr, nullptr, out.traces.data() + e0, om->d_cons, &csteps, &coff, &cpps);
       view.d_data = nullptr; view.d_off = nullptr; view.d_len = nullptr;
       if (st2 != BATH_OK) { if (c != ctx) ctx->set_error(c->err); return st2; }
       const int64_t base = (int64_t)out.steps.size();
       for (int k = 0; k < e1 - e0; k++) out.step_off[(size_t)(e0 + k)] = base + coff[(size_t)k];
       out.steps.insert(out.steps.end(), csteps.begin(), csteps.end());
+      out.pps.insert(out.pps.end(), cpps.begin(), cpps.end());
       e0 = e1;
     }
     out.step_off[(size_t)n] = (int64_t)out.steps.size();
@@ -346,6 +353,7 @@ static int fs_branch_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, con
     traces.insert(traces.end(), b.traces.begin(), b.traces.end());
     for (size_t k = 0; k + 1 < b.step_off.size(); k++) step_off.push_back(base + b.step_off[k]);
     steps.insert(steps.end(), b.steps.begin(), b.steps.end());
+    pps.insert(pps.end(), b.pps.begin(), b.pps.end());
     step_off.push_back((int64_t)steps.size());
   };
   auto run_envelopes = [&](int e_begin, int e_end) -> int {                    // envs[e_begin, e_end) on this context, results appended (e_begin = what is done so far)
@@ -562,6 +570,9 @@ static int fs_branch_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, con
     ctx->cigars += cigar_from_columns(steps.data() + step_off[(size_t)e], tq.ncol);
     ctx->cigars.push_back('\0');
     ctx->fs_domains.push_back(dm);
+    // dom->tr: states z1..z2 in window coordinates (the i - 1 shift of p7_domaindef.c:1053-1054 applied to every i >= 0: a D state's 0 becomes wi - 1)
+    ctx->trace_push(steps.data() + step_off[(size_t)e], pps.size() == steps.size() ? pps.data() + step_off[(size_t)e] : nullptr, tq.ncol, tq.ihmm,
+                    wi - 1 + tq.iali, win.n, 0, 1, wi - 1);
   }
   *domains = ctx->fs_domains.data(); *n_domains = (int64_t)ctx->fs_domains.size();
   return BATH_OK;
@@ -725,7 +736,7 @@ __global__ __launch_bounds__(64) void std_regions_wave_kernel(int64_t n, const i
   }
 }
 
-struct StdEnvOut { int32_t i1, k1, i2, k2, ok; float oasc, domcorrection; int32_t ncol, exact; float aliscore; };
+struct StdEnvOut { int32_t i1, k1, i2, k2, ok; float oasc, domcorrection; int32_t ncol, exact; float aliscore; int32_t pp_off; };
 
 // p7_Decoding + p7_OptimalAccuracy + p7_OATrace + p7_Null2_ByExpectation on one envelope per lane (unihit model).
 // fwd / bck: (L+1) x (M+1) x {M, D, I}; on return bck holds the posteriors and fwd the OA matrix, as in the reference.
@@ -737,7 +748,9 @@ __global__ void std_envelope_kernel(SeqView sq, int M, const float *__restrict__
                                     int filled /* std_envelope_fill_kernel already did decoding, OA fill and null2: traceback only */,
                                     const float *__restrict__ msc /* [Kp][M+1] log-odds */, const float *__restrict__ tsc /* [M][8] log */,
                                     const uint8_t *__restrict__ nt /* the DNA block */, const int64_t *__restrict__ nt_base, const int64_t *__restrict__ nt_dir,
-                                    float *__restrict__ null2_out = nullptr /* optional [n][Kp]: the null2 vector itself (filled == 0 only) */) {
+                                    float *__restrict__ null2_out = nullptr /* optional [n][Kp]: the null2 vector itself (filled == 0 only) */,
+                                    float *__restrict__ col_pp = nullptr /* tr->pp of the alignment columns, first to last, all envelopes densely */,
+                                    int *__restrict__ col_cursor = nullptr) {
   // one envelope per wave: the traceback is a state machine and lanes in different states run one after the other (see
   // fs5_trace_kernel); the chip has room for a wave per envelope
   if (threadIdx.x % kStdTraceSpread) return;
@@ -753,7 +766,7 @@ __global__ void std_envelope_kernel(SeqView sq, int M, const float *__restrict__
   float *F = fwd + dp_off[t], *Bk = bck + dp_off[t];
   const float *FX = fx + x_off[t], *BX = bx + x_off[t];
   float *PX = ppx_all + (x_off[t] / 6) * 5, *OX = oax_all + (x_off[t] / 6) * 5;
-  StdEnvOut r{-1, -1, -1, -1, 0, 0.f, 0.f, 0, 0, 0.f};
+  StdEnvOut r{-1, -1, -1, -1, 0, 0.f, 0.f, 0, 0, 0.f, 0};
   const float ploop = 1.0f - 2.0f / ((float)L + 2.0f);                       // unihit: xf[N|J|C][LOOP]
   const float *P = Bk;
   float *O = F;
@@ -901,6 +914,21 @@ __global__ void std_envelope_kernel(SeqView sq, int M, const float *__restrict__
         prev = s;
       }
       r.aliscore = total;
+    }
+    // ---- the posterior of every column's state, first to last (p7_OATrace's get_postprob, optacc.c: M and I cells of the
+    // posterior matrix; a delete state has none), for bath_hip_domain_traces
+    if (col_pp && r.ncol <= cap && r.ncol > 0) {
+      r.pp_off = atomicAdd(col_cursor, r.ncol);
+      float *out_pp = col_pp + r.pp_off;
+      int kk = r.k1 - 1, ii = r.i1 - 1;
+      for (int idx = r.ncol - 1; idx >= 0; idx--) {
+        const int s = T[idx];
+        float v = 0.0f;
+        if (s == sM) { kk++; ii++; v = P[(size_t)ii * W + (size_t)kk * 3 + cM]; }
+        else if (s == sI) { ii++; v = P[(size_t)ii * W + (size_t)kk * 3 + cI]; }
+        else kk++;
+        out_pp[r.ncol - 1 - idx] = v;
+      }
     }
   }
   // ---- p7_Null2_ByExpectation (null2.c:50-124) and the correction over the envelope (p7_domaindef.c:1264-1272)
@@ -1271,7 +1299,13 @@ static int std_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bat
     toff[(size_t)ne + 1 + (size_t)ne + (size_t)e] = o.strand ? -1 : 1;
   }
   DevBuf &b_tb = ctx->scratch[10], &b_toff = ctx->scratch[13];
-  BATH_HIP_TRY(ctx, b_tb.reserve((size_t)toff[(size_t)ne] + 64)); BATH_HIP_TRY(ctx, b_toff.reserve(toff.size() * 8));
+  if ((size_t)toff[(size_t)ne] >= (size_t)INT32_MAX) { ctx->set_error("too many envelopes for the trace columns' 32-bit offsets"); return BATH_ERANGE; }
+  // [columns: 1 B each, per envelope] [cursor] [the columns' posteriors, densely: 4 B per column that exists]
+  const size_t tb_cols = ((size_t)toff[(size_t)ne] + 255) / 256 * 256;
+  BATH_HIP_TRY(ctx, b_tb.reserve(tb_cols + 256 + (size_t)toff[(size_t)ne] * sizeof(float) + 64)); BATH_HIP_TRY(ctx, b_toff.reserve(toff.size() * 8));
+  int *d_col_cursor = reinterpret_cast<int *>(b_tb.as<char>() + tb_cols);
+  float *d_col_pp = reinterpret_cast<float *>(b_tb.as<char>() + tb_cols + 256);
+  BATH_HIP_TRY(ctx, hipMemsetAsync(d_col_cursor, 0, sizeof(int), ctx->stream));
   BATH_HIP_TRY(ctx, hipMemcpyAsync(b_toff.p, toff.data(), toff.size() * 8, hipMemcpyHostToDevice, ctx->stream));
   BATH_HIP_TRY(ctx, b_sc.reserve((size_t)ne * 8)); BATH_HIP_TRY(ctx, b_st.reserve((size_t)ne * 8));
   BATH_HIP_TRY(ctx, hipMemcpyAsync(b_dpo.p, dpoff.data(), (size_t)(ne + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
@@ -1296,11 +1330,20 @@ static int std_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bat
   hipLaunchKernelGGL(std_envelope_kernel, dim3((unsigned)((ne * kStdTraceSpread + 63) / 64)), dim3(64), 0, ctx->stream, ev.view(), M, om->d_tf, om->d_rf, b_f.as<float>(), b_b.as<float>(), b_dpo.as<int64_t>(),
                      b_fx.as<float>(), b_bx.as<float>(), d_exoff, b_px.as<float>(), b_ox.as<float>(), b_em.as<float>(), b_out.as<StdEnvOut>(),
                      om->d_cons, b_tb.as<uint8_t>(), b_toff.as<int64_t>(), filled,
-                     om->d_msc, om->d_tsc, dna->d_data, b_toff.as<int64_t>() + ne + 1, b_toff.as<int64_t>() + 2 * ne + 1);
+                     om->d_msc, om->d_tsc, dna->d_data, b_toff.as<int64_t>() + ne + 1, b_toff.as<int64_t>() + 2 * ne + 1,
+                     nullptr, d_col_pp, d_col_cursor);
   BATH_HIP_TRY(ctx, hipGetLastError());
   std::vector<StdEnvOut> eo((size_t)ne);
   std::vector<float> envsc((size_t)ne);
   std::vector<uint8_t> tcols((size_t)toff[(size_t)ne]);
+  std::vector<float> col_pp;
+  {
+    int total = 0;
+    BATH_HIP_TRY(ctx, hipMemcpyAsync(&total, d_col_cursor, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    BATH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    col_pp.resize((size_t)total);
+    if (total > 0) BATH_HIP_TRY(ctx, hipMemcpyAsync(col_pp.data(), d_col_pp, (size_t)total * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  }
   BATH_HIP_TRY(ctx, hipMemcpyAsync(tcols.data(), b_tb.p, tcols.size(), hipMemcpyDeviceToHost, ctx->stream));
   BATH_HIP_TRY(ctx, hipMemcpyAsync(eo.data(), b_out.p, (size_t)ne * sizeof(StdEnvOut), hipMemcpyDeviceToHost, ctx->stream));
   BATH_HIP_TRY(ctx, hipMemcpyAsync(envsc.data(), b_sc.p, (size_t)ne * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -1359,6 +1402,9 @@ static int std_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bat
       dm.cigar_off = (int64_t)ctx->cigars.size();
       ctx->cigars += cigar_from_columns(cols.data(), nc);
       ctx->cigars.push_back('\0');
+      // dom->tr after p7_trace_fs_Convert (p7_trace.c:405): a residue sits on its codon's last nucleotide, start = orf_start - window_start
+      const bool have_pp = (size_t)t.pp_off + (size_t)nc <= col_pp.size() && nc == t.ncol;
+      ctx->trace_push(cols.data(), have_pp ? col_pp.data() + t.pp_off : nullptr, nc, t.k1, shift + a1 * 3 - 2, o.win_start, o.start, 0, 0);
     }
     ctx->fs_domains.push_back(dm);
   }
@@ -1374,6 +1420,7 @@ extern "C" int bath_hip_pipeline_hits(bath_hip_ctx *ctx, const bath_hip_oprofile
   int64_t nclust = 0;
   ctx->fs_domains.clear();
   ctx->cigars.clear();
+  ctx->traces_clear();
   bath_pipeline_params prm = *prm_in;
   prm.fs_pipe = 0;
   bath_pipeline_stats st_local{};
@@ -1497,3 +1544,35 @@ extern "C" int bath_hip_std_envelopes(bath_hip_ctx *ctx, const bath_hip_oprofile
 }
 
 extern "C" const char *bath_hip_domain_cigars(const bath_hip_ctx *ctx) { return ctx ? ctx->cigars.c_str() : nullptr; }
+
+// P7_DOMAIN.tr of every domain of the last pipeline call: the trace kernels' columns expanded into the reference's arrays
+extern "C" int bath_hip_domain_traces(bath_hip_ctx *ctx, const bath_domain_trace **tr, int64_t *n_traces,
+                                      const int8_t **st, const int32_t **k, const int32_t **i, const int8_t **c, const float **pp) {
+  if (!ctx || !tr || !n_traces) return BATH_EINVAL;
+  if (ctx->tr_recs.size() != ctx->fs_domains.size()) { ctx->set_error("no traces for the domains of the last call"); return BATH_EINVAL; }
+  if (!ctx->tr_valid) {
+    const size_t ncols = ctx->tr_codes.size();
+    ctx->tr_out.resize(ctx->tr_recs.size());
+    ctx->tr_st.resize(ncols); ctx->tr_c.resize(ncols); ctx->tr_k.resize(ncols); ctx->tr_i.resize(ncols);
+    for (size_t d = 0; d < ctx->tr_recs.size(); d++) {
+      const bath_hip_ctx::TraceRec &t = ctx->tr_recs[d];
+      ctx->tr_out[d] = bath_domain_trace{t.col_off, t.ncol, t.win_start, t.orf_start, t.frameshift};
+      int kk = t.k1 - 1, ii = t.i_first - 1;
+      for (int z = 0; z < t.ncol; z++) {
+        const size_t q = (size_t)t.col_off + (size_t)z;
+        const int s = ctx->tr_codes[q] & 0xf, cl = (ctx->tr_codes[q] >> 4) & 0xf;
+        if (s == 3)      { kk++; ii += cl; ctx->tr_st[q] = BATH_T_M; ctx->tr_k[q] = kk; ctx->tr_i[q] = ii; ctx->tr_c[q] = (int8_t)cl; }
+        else if (s == 5) { ii += 3;        ctx->tr_st[q] = BATH_T_I; ctx->tr_k[q] = kk; ctx->tr_i[q] = ii; ctx->tr_c[q] = 0; }
+        else             { kk++;           ctx->tr_st[q] = BATH_T_D; ctx->tr_k[q] = kk; ctx->tr_i[q] = t.d_i; ctx->tr_c[q] = 0; }
+      }
+    }
+    ctx->tr_valid = true;
+  }
+  *tr = ctx->tr_out.data(); *n_traces = (int64_t)ctx->tr_out.size();
+  if (st) *st = ctx->tr_st.data();
+  if (k) *k = ctx->tr_k.data();
+  if (i) *i = ctx->tr_i.data();
+  if (c) *c = ctx->tr_c.data();
+  if (pp) *pp = ctx->tr_pp.data();
+  return BATH_OK;
+}

@@ -1098,7 +1098,8 @@ __global__ void fs5_trace_kernel(SeqView dna, int M, int maxcodons, const float 
                                  const float *__restrict__ oa, const int64_t *__restrict__ oa_off, const float *__restrict__ ox,
                                  const float *__restrict__ null2 /* [n][Kp] */, uint2 *__restrict__ tbuf, const int64_t *__restrict__ t_off, FsTraceOut *__restrict__ out,
                                  const uint8_t *__restrict__ indel_tab, const uint8_t *__restrict__ cons, uint16_t *__restrict__ steps,
-                                 const float *__restrict__ amino /* rsc + maxcodons*pitch: the amino rows */, int pitch) {
+                                 const float *__restrict__ amino /* rsc + maxcodons*pitch: the amino rows */, int pitch,
+                                 float *__restrict__ step_pp /* posterior of every column's state (tr->pp), parallel to steps */, int *__restrict__ col_cursor) {
   // One envelope per WAVE (kTraceSpread = 64 lanes apart): the walk is a state machine whose lanes diverge at every step (each
   // state's loads and compares run under their own exec mask, one after the other), so a wave holding 64 envelopes pays for
   // every state present among them at every step.  The chip has room for a wave per envelope: 2.77 -> 1.15 ms on the bench's
@@ -1114,7 +1115,7 @@ __global__ void fs5_trace_kernel(SeqView dna, int M, int maxcodons, const float 
   const float *P = pp + pp_off[job], *PX = px + x_off[job], *O = oa + oa_off[job], *OX = ox + x_off[job];
   uint2 *T = tbuf + t_off[job];
   const int cap = (int)(t_off[job + 1] - t_off[job]);
-  FsTraceOut r{0, 0, 0, 0, 0, 0, 0.f, 0, 0, 0, 0.f};
+  FsTraceOut r{0, 0, 0, 0, 0, 0, 0.f, 0, 0, 0, 0.f, 0};
   auto dl = [&](int node, int s) { return (node >= 1 && node <= M && tf[(size_t)node * 8 + s] != -INFINITY) ? 1.0f : kTiny; };
   auto OM = [&](int i, int k) { return O[((size_t)i * (M + 1) + k) * 3 + 2]; };
   auto OI = [&](int i, int k) { return O[((size_t)i * (M + 1) + k) * 3 + 1]; };
@@ -1229,8 +1230,12 @@ __global__ void fs5_trace_kernel(SeqView dna, int M, int maxcodons, const float 
       r.domcorrection = corr;
       // what the alignment display keeps of the trace (p7_alidisplay_fs_Create, p7_alidisplay.c:700-925): per column the
       // state, codon length and indel type (for --cigar), identities with the consensus, stop codons
-      uint16_t *S = steps ? steps + t_off[job] : nullptr;
       r.ncol = z2 - z1 + 1;
+      // the columns of all envelopes lie DENSELY in <steps> / <step_pp>, each envelope's range reserved here (the host copies the
+      // columns that exist -- a third of a nucleotide per column -- instead of every envelope's worst case of L + M + 16)
+      r.col_off = steps ? atomicAdd(col_cursor, r.ncol) : 0;
+      uint16_t *S = steps ? steps + r.col_off : nullptr;
+      float *SP = (steps && step_pp) ? step_pp + r.col_off : nullptr;
       // ... and p7_pli_computeAliScores_BATH (p7_pipeline.c:781-979): per column the amino row score of the quasi-codon's best
       // amino acid plus the transition that entered the state (the last match state gets no MM: inner loops stop at z1 < z2)
       float ali = 0.f;
@@ -1268,6 +1273,8 @@ __global__ void fs5_trace_kernel(SeqView dna, int M, int maxcodons, const float 
         ali += colsc;
         prevs = s;
         if (S) S[zz - z1] = (uint16_t)code;
+        // get_postprob (generic_optacc_frameshift.c:425-440): a match state's total posterior (all codon lengths), an insert state's; 0 for D
+        if (SP) SP[zz - z1] = (s == sM) ? P[((size_t)ii * (M + 1) + kk) * 8 + 2] : (s == sI ? P[((size_t)ii * (M + 1) + kk) * 8 + 1] : 0.0f);
       }
       r.aliscore = ali;
     }
@@ -1766,7 +1773,7 @@ extern "C" int bath_hip_fs5_forward_full(bath_hip_ctx *ctx, const bath_hip_fspro
 // {E,N,J,B,C} (posterior and OA special-state rows), each packed back to back in envelope order.
 int bath::fs5_envelopes_ex(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, const bath_hip_seqs *dna, int logsum_mode, int c5_compat,
                            bath_fs5_result *res, float *pp, float *oa, float *ppx, float *oax, FsTraceOut *trace,
-                           const uint8_t *cons, std::vector<uint16_t> *steps, std::vector<int64_t> *step_off) {
+                           const uint8_t *cons, std::vector<uint16_t> *steps, std::vector<int64_t> *step_off, std::vector<float> *step_pp) {
   if (!ctx || !om || !dna || om->codon_lengths != 5) { if (ctx) ctx->set_error("fs5 envelopes need a 5-codon profile"); return BATH_EINVAL; }
   BATH_HIP_TRY(ctx, hipSetDevice(ctx->device));
   const int64_t n = dna->n;
@@ -1860,22 +1867,37 @@ int bath::fs5_envelopes_ex(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, cons
     for (int64_t i = 0; i < n; i++) toff[(size_t)i + 1] = toff[(size_t)i] + dna->h_len[(size_t)i] + M + 16;
     DevBuf &b_tb = ctx->scratch[10], &b_to = ctx->scratch[13], &b_steps = ctx->scratch[14];
     BATH_HIP_TRY(ctx, b_tb.reserve((size_t)toff[(size_t)n] * sizeof(uint2) + (size_t)(n + 1) * sizeof(int64_t) + 256));
-    if (steps) BATH_HIP_TRY(ctx, b_steps.reserve((size_t)toff[(size_t)n] * sizeof(uint16_t) + 64));
+    // dense columns: [cursor (256 B)] [pp: 4 B per column] [codes: 2 B per column], at most toff[n] columns
+    const size_t col_cap = (size_t)toff[(size_t)n];
+    if (col_cap >= (size_t)INT32_MAX) { ctx->set_error("envelope batch too large for the trace columns' 32-bit offsets: lower BATH_HIP_ENV_MB"); return BATH_ERANGE; }
+    if (steps) BATH_HIP_TRY(ctx, b_steps.reserve(256 + col_cap * (sizeof(float) + sizeof(uint16_t)) + 64));
+    int *d_cursor = steps ? b_steps.as<int>() : nullptr;
+    float *d_step_pp = steps ? reinterpret_cast<float *>(b_steps.as<char>() + 256) : nullptr;
+    uint16_t *d_steps = steps ? reinterpret_cast<uint16_t *>(d_step_pp + col_cap) : nullptr;
+    if (steps) BATH_HIP_TRY(ctx, hipMemsetAsync(d_cursor, 0, sizeof(int), ctx->stream));
     BATH_HIP_TRY(ctx, b_to.reserve((size_t)n * sizeof(FsTraceOut) + 64));
     int64_t *d_toff = reinterpret_cast<int64_t *>(b_tb.as<char>() + ((size_t)toff[(size_t)n] * sizeof(uint2) + 255) / 256 * 256);
     BATH_HIP_TRY(ctx, hipMemcpyAsync(d_toff, toff.data(), (size_t)(n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
     const int s6 = ctx->span_begin("fs5_trace_kernel", ctx->stream, (double)toff[(size_t)n], 0.0);
     hipLaunchKernelGGL(fs5_trace_kernel, dim3((unsigned)((n * kTraceSpread + 63) / 64)), dim3(64), 0, ctx->stream, dna->view(), M, om->maxcodons, om->d_tf, om->d_codons,
                        b_f.as<float>(), d_foff, b_fx.as<float>(), d_xoff, b_o.as<float>(), d_boff, b_ox.as<float>(), b_n2.as<float>(), b_tb.as<uint2>(), d_toff,
-                       b_to.as<FsTraceOut>(), om->d_indel, cons, steps ? b_steps.as<uint16_t>() : nullptr,
-                       om->d_rsc + (size_t)om->maxcodons * om->pitch, om->pitch);
+                       b_to.as<FsTraceOut>(), om->d_indel, cons, d_steps,
+                       om->d_rsc + (size_t)om->maxcodons * om->pitch, om->pitch, step_pp ? d_step_pp : nullptr, d_cursor);
     ctx->span_end(s6, ctx->stream);
     BATH_HIP_TRY(ctx, hipGetLastError());
     BATH_HIP_TRY(ctx, hipMemcpyAsync(trace, b_to.p, (size_t)n * sizeof(FsTraceOut), hipMemcpyDeviceToHost, ctx->stream));
     if (steps) {                                                // columns z1..z2 of envelope e: (*steps)[step_off[e] .. +trace[e].ncol)
-      steps->resize((size_t)toff[(size_t)n]);
-      BATH_HIP_TRY(ctx, hipMemcpyAsync(steps->data(), b_steps.p, steps->size() * sizeof(uint16_t), hipMemcpyDeviceToHost, ctx->stream));
-      *step_off = toff;
+      int total = 0;
+      BATH_HIP_TRY(ctx, hipMemcpyAsync(&total, d_cursor, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+      BATH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));     // (also: toff is a local)
+      steps->resize((size_t)total);
+      if (total > 0) BATH_HIP_TRY(ctx, hipMemcpyAsync(steps->data(), d_steps, (size_t)total * sizeof(uint16_t), hipMemcpyDeviceToHost, ctx->stream));
+      if (step_pp) {
+        step_pp->resize((size_t)total);
+        if (total > 0) BATH_HIP_TRY(ctx, hipMemcpyAsync(step_pp->data(), d_step_pp, (size_t)total * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+      }
+      step_off->assign((size_t)n + 1, (int64_t)total);
+      for (int64_t e = 0; e < n; e++) (*step_off)[(size_t)e] = trace[e].ok ? (int64_t)trace[e].col_off : (int64_t)total;
     }
     BATH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));       // toff is a local
   }

@@ -91,12 +91,14 @@ struct FsTraceOut {               // what the pipeline keeps of an envelope's OA
   int32_t ihmm, jhmm, iali, jali, nshift, ok; float domcorrection;
   int32_t ncol, exact, nstops;    // alignment display: columns (first to last match state), identities with the consensus, stop codons
   float aliscore;                 // p7_pli_computeAliScores_BATH: sum of the per-column scores; negative = the domain is dropped
+  int32_t col_off;                // where this envelope's columns start in the batch's dense column arrays
 };
 // <cons>: device array [M+1] of consensus residue codes or nullptr; <steps>/<step_off>: per alignment column
-// state | codon length << 4 | indel label << 8 (columns of envelope e start at (*step_off)[e])
+// state | codon length << 4 | indel label << 8 (the columns of all envelopes lie densely; those of envelope e start at (*step_off)[e])
 int fs5_envelopes_ex(bath_hip_ctx *ctx, const bath_hip_fsprofile *om5, const bath_hip_seqs *dna, int logsum_mode, int c5_compat,
                      bath_fs5_result *res, float *pp, float *oa, float *ppx, float *oax, FsTraceOut *trace,
-                     const uint8_t *cons = nullptr, std::vector<uint16_t> *steps = nullptr, std::vector<int64_t> *step_off = nullptr);
+                     const uint8_t *cons = nullptr, std::vector<uint16_t> *steps = nullptr, std::vector<int64_t> *step_off = nullptr,
+                     std::vector<float> *step_pp = nullptr /* tr->pp of every column, parallel to steps */);
 
 // ---- multi-domain regions (bath_ensemble.hip, host): envelopes and per-residue null2 scores from 200 stochastic tracebacks
 int region_trace_ensemble(const bath_hip_oprofile *om, int cfg_L, const uint8_t *res, int Lr, const float *fwd, const float *fx,

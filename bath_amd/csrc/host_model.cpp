@@ -78,7 +78,7 @@ extern "C" int bath_hmmfile_count(const char *path) {
 
 extern "C" void bath_hmm_destroy(bath_hmm *h) {
   if (!h) return;
-  delete[] h->t; delete[] h->mat; delete[] h->ins; delete[] h->consensus; delete h;
+  delete[] h->t; delete[] h->mat; delete[] h->ins; delete[] h->consensus; delete[] h->rf; delete[] h->cs; delete h;
 }
 
 extern "C" int bath_hmmfile_read(const char *path, int index, bath_hmm **ret) {
@@ -99,13 +99,15 @@ extern "C" int bath_hmmfile_read(const char *path, int index, bath_hmm **ret) {
   for (float &e : h->evparam) e = -99999.0f;
   auto fail = [&](int code) { bath_hmm_destroy(h); return code; };
 
-  bool body = false, has_cons = false;
+  bool body = false, has_cons = false, has_rf = false, has_cs = false;
   while (std::getline(in, line)) {
     std::istringstream ss(line);
     std::string tag; ss >> tag;
     if (tag == "NAME") { std::string v; ss >> v; std::snprintf(h->name, sizeof h->name, "%s", v.c_str()); }
     else if (tag == "ACC") { std::string v; ss >> v; std::snprintf(h->acc, sizeof h->acc, "%s", v.c_str()); }
     else if (tag == "CONS") { std::string v; ss >> v; has_cons = (v == "yes"); }
+    else if (tag == "RF") { std::string v; ss >> v; has_rf = (v == "yes"); }
+    else if (tag == "CS") { std::string v; ss >> v; has_cs = (v == "yes"); }
     else if (tag == "LENG") ss >> h->M;
     else if (tag == "MAXL") ss >> h->max_length;
     else if (tag == "ALPH") { std::string v; ss >> v; if (v != "amino") return fail(BATH_EFORMAT); }
@@ -131,6 +133,8 @@ extern "C" int bath_hmmfile_read(const char *path, int index, bath_hmm **ret) {
   h->ins = new float[(size_t)(M + 1) * 20]();
   h->consensus = new char[(size_t)M + 2]();
   h->consensus[0] = ' ';
+  if (has_rf) { h->rf = new char[(size_t)M + 2](); h->rf[0] = ' '; }      // p7_hmmfile.c:1629-1640: columns after the emissions are MAP CONS RF MM CS
+  if (has_cs) { h->cs = new char[(size_t)M + 2](); h->cs[0] = ' '; }
 
   auto read_tokens = [&](std::vector<std::string> &toks) -> bool {
     if (!std::getline(in, line)) return false;
@@ -154,6 +158,8 @@ extern "C" int bath_hmmfile_read(const char *path, int index, bath_hmm **ret) {
   for (int k = 1; k <= M; k++) {
     if (!read_tokens(tk) || tk.size() < 21 || atoi(tk[0].c_str()) != k) return fail(BATH_EFORMAT);
     for (int x = 0; x < 20; x++) h->mat[(size_t)k * 20 + x] = prob_from_token(tk[1 + x]);
+    if (has_rf) h->rf[k] = tk.size() >= 24 ? tk[23][0] : '-';
+    if (has_cs) h->cs[k] = tk.size() >= 26 ? tk[25][0] : '-';
     if (has_cons && tk.size() >= 23) h->consensus[k] = tk[22][0];             // columns after the emissions: MAP CONS RF MM CS (p7_hmmfile.c:1624-1640)
     else {                                                                    // p7_hmm_SetConsensus for an amino model
       int best = 0;

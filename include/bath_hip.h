@@ -63,6 +63,8 @@ typedef struct {
   char   *consensus;/* [M+2] consensus residue per node, consensus[0] = ' ' (P7_HMM.consensus): the file's CONS column,
                      * or p7_hmm_SetConsensus's rule when the file has none (p7_hmm.c: most probable residue,
                      * upper case if its probability is >= 0.5)                                */
+  char   *rf;       /* [M+2] reference annotation per node (P7_HMM.rf, "RF yes"), rf[0] = ' '; NULL when the model has none */
+  char   *cs;       /* [M+2] consensus structure annotation (P7_HMM.cs, "CS yes"); NULL when the model has none            */
 } bath_hmm;
 
 /* P7_PROFILE (hmmer.h:338): what p7_oprofile_Convert() reads. */
@@ -350,6 +352,60 @@ typedef struct {
   int64_t cigar_off;               /* the --cigar string starts at bath_hip_domain_cigars(ctx) + cigar_off        */
 } bath_fs_domain;
 const char *bath_hip_domain_cigars(const bath_hip_ctx *ctx);   /* NUL-terminated strings, valid until the next pipeline call */
+
+/* P7_DOMAIN.tr: the optimal-accuracy trace of every domain of the last bath_hip_pipeline_hits / _frameshift_domains call, with its
+ * posterior probabilities, as rescore_isolated_domain_frameshift / _bath keep it (p7_domaindef.c:1171, :1330) and as
+ * p7_alidisplay_fs_Create / _nonfs_Create (p7_alidisplay.c:538, :937) and p7_tophits_TabularFrameshifts read it -- what the
+ * alignment blocks of the default output and --fstblout are made from.  tr[d] belongs to domains[d] of that call.
+ * Per trace state z = tr[d].off .. tr[d].off + tr[d].N - 1, in the reference's conventions (p7_trace_fs_AppendWithPP, p7_trace.c:2303;
+ * p7_trace_fs_Convert, :405):
+ *   st[z]  BATH_T_M / BATH_T_D / BATH_T_I (p7T_M, p7T_D, p7T_I; hmmer.h:487)
+ *   k[z]   model node
+ *   i[z]   M, I: the codon's LAST nucleotide, 1-based in windowsq -- the DNA window the domain was defined on: nucleotide
+ *          win_start + i - 1 of the strand read (for a hit of the plain pipeline windowsq is the ORF's own stretch of DNA,
+ *          p7_pipeline.c:1755); D: what the reference leaves there (the envelope's start - 1 in the frameshift branch, 0 in the standard one)
+ *   c[z]   M: the (quasi-)codon's length 1..5 (always 3 in the standard branch); 0 otherwise
+ *   pp[z]  M, I: the state's posterior probability; D: 0
+ * The states are those from the first to the last match state (ad->N of them): the N / B / E / C flanks of the reference's trace carry
+ * nothing any caller on this path reads (both alidisplay constructors and TabularFrameshifts start at the first M) and are not
+ * materialised.  The arrays are owned by ctx and valid until its next pipeline call. */
+#define BATH_T_M 1
+#define BATH_T_D 2
+#define BATH_T_I 3
+typedef struct {
+  int64_t off;                     /* first state of this trace in the arrays                                           */
+  int32_t N;                       /* states (alignment columns, ad->N)                                                  */
+  int32_t win_start;               /* windowsq->start on the strand read, 1-based                                        */
+  int32_t orf_start;               /* standard branch: orfsq->start on the strand read (its first codon reads M under -m / -M); 0 in the frameshift branch */
+  int32_t frameshift;              /* 1: a domain of the frameshift branch (p7_alidisplay_fs_Create), 0: of the standard branch (_nonfs_Create) */
+} bath_domain_trace;
+int bath_hip_domain_traces(bath_hip_ctx *ctx, const bath_domain_trace **tr, int64_t *n_traces,
+                           const int8_t **st, const int32_t **k, const int32_t **i, const int8_t **c, const float **pp);
+
+/* The alignment block of a hit as the default output prints it under "Alignment:" (p7_alidisplay_fs_Create / _nonfs_Create,
+ * p7_alidisplay.c:538-1243, and p7_alidisplay_Print_BATH, :3757-4110, as p7_tophits_Domains calls it: p7_tophits.c:1394), from one
+ * trace of bath_hip_domain_traces: the optional CS / RF lines, the model's consensus, the match line, the translation, the codons
+ * (a quasi-codon's missing or extra nucleotides marked as the reference marks them), the optional frame line and the posterior
+ * probability line, in blocks of (textw - names - coordinates) / 5 columns.  Host code; nothing here touches the GPU.
+ *   st .. pp      the arrays of bath_hip_domain_traces, already offset to this trace (st + tr->off, ...)
+ *   window_dsq    windowsq: window_dsq[i - 1] is nucleotide i of the strand read (digital), <window_len> of them -- for a domain d
+ *                 of a block: the strand's nucleotides from tr->win_start on
+ *   gm_fs5 / gm   the 5-codon frameshift profile (frameshift branch) / the standard profile (standard branch); the other may be NULL
+ *   basic         the codon table (bath_gencode_basic), standard branch
+ * Returns the text's size in bytes (without a terminating NUL) and copies at most <cap> of them to <buf>; < 0 on error. */
+typedef struct {
+  const char *hmm_name, *seq_name;   /* ad->hmmname, ad->sqname (the caller substitutes accessions under --acc)            */
+  const char *consensus;             /* bath_hmm.consensus                                                                  */
+  const char *rf, *cs;               /* bath_hmm.rf / .cs or NULL                                                           */
+  int32_t M;
+  int64_t sqfrom, sqto;              /* ad->sqfrom / ad->sqto: the hit's iali / jali on the sequence                       */
+  int32_t textw;                     /* --textw (150); <= 0: one block of unlimited width (--notextw)                       */
+  int32_t show_frameline;            /* --frameline                                                                         */
+  int32_t initiator;                 /* bath_pipeline_params.initiator: under -m / -M an ORF's first codon reads M          */
+} bath_alidisplay_opts;
+int64_t bath_alidisplay_print(const bath_domain_trace *tr, const int8_t *st, const int32_t *k, const int32_t *i, const int8_t *c, const float *pp,
+                              const uint8_t *window_dsq, int32_t window_len, const bath_fs_profile *gm_fs5, const bath_profile *gm,
+                              const uint8_t basic[64], const bath_alidisplay_opts *opts, char *buf, int64_t cap);
 int  bath_hip_pipeline_frameshift_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bath_hip_fsprofile *om_fs3,
                                           const bath_hip_fsprofile *om_fs5, const bath_hip_seqs *dna, const bath_pipeline_params *params,
                                           double E_report, bath_pipeline_stats *stats,

@@ -334,7 +334,17 @@ typedef struct {                 /* P7_DOMAIN fields the frameshift branch fills
   double  lnP;
   int32_t reported;                        /* passes E * Z <= E threshold (:1080) */
   int32_t n_shifted_codons;                /* match states emitting a quasi-codon (length != 3) */
+  int32_t trace_idx;                       /* dom->tr: index for bo_traces_get */
 } bo_fsdomain;
+/* dom->tr as rescore_isolated_domain_frameshift / _bath keep it (p7_domaindef.c:1171, :1330), the states from the first to the last
+ * match state, in the reference's conventions (p7_trace_fs_AppendWithPP, p7_trace.c:2303; p7_trace_fs_Convert, :405): st 1 M / 2 D /
+ * 3 I (p7T_*), node k, i = the codon's last nucleotide in windowsq (D: envelope start - 1 in the frameshift branch, 0 in the standard
+ * one), c = codon length of a match state (else 0), pp = posterior of an M / I state.  A test-side store, reset by the caller. */
+typedef struct { int32_t N, win_start, orf_start, frameshift; int8_t *st; int32_t *k, *i; int8_t *c; float *pp; } bo_domtrace;
+void bo_traces_reset(void);
+int  bo_traces_count(void);
+const bo_domtrace *bo_traces_get(int idx);
+int  bo_traces_push(int N, int win_start, int orf_start, int frameshift);   /* returns the index; the arrays are allocated, the caller fills them */
 void bo_gdomain_decoding_fs(const bo_fs_profile *gm5, const bo_gmx *fwd, const bo_gmx *bck, float *btot, float *etot, float *mocc); /* generic_decoding_frameshift.c:204 */
 int  bo_goatrace_fs(const bo_fs_profile *gm, const bo_gmx *pp, const bo_gmx *gx, bo_trace *tr);                                  /* generic_optacc_frameshift.c:373 */
 double bo_exp_logsurv(double x, double mu, double lambda);

@@ -306,6 +306,17 @@ static void rescore_envelope(bo_oprofile *om, const uint8_t *dsq, int i, int j, 
       d.iali = start + a1 * 3 - 2; d.jali = start + a2 * 3;
       d.ienv = i; d.jenv = j; d.ihmm = k1; d.jhmm = k2;
       d.envsc = envsc; d.oasc = oasc; d.domcorrection = domcorrection > 0.f ? domcorrection : 0.f;
+      {                                                            /* dom->tr after p7_trace_fs_Convert, p7_domaindef.c:1274-1277, :1330 */
+        const int tix = bo_traces_push(pn, win_start, orf_start, 0);
+        const bo_domtrace *t = bo_traces_get(tix);
+        for (int z = 0; z < pn; z++) {                             /* pst: last to first */
+          const int q = pn - 1 - z, a = pi[z] + i - 1;
+          if (pst[z] == BO_T_M)      { t->st[q] = 1; t->k[q] = pk[z]; t->i[q] = start + a * 3; t->c[q] = 3; t->pp[q] = bck[(size_t) pi[z] * W + pk[z] * 3 + cM]; }
+          else if (pst[z] == BO_T_I) { t->st[q] = 3; t->k[q] = pk[z]; t->i[q] = start + a * 3; t->c[q] = 0; t->pp[q] = bck[(size_t) pi[z] * W + pk[z] * 3 + cI]; }
+          else                       { t->st[q] = 2; t->k[q] = pk[z]; t->i[q] = 0;             t->c[q] = 0; t->pp[q] = 0.0f; }
+        }
+        d.trace_idx = tix;
+      }
       dom_push(doms, ndom, dalloc, &d);
     }
     free(pst);

@@ -59,6 +59,27 @@ void bo_gdomain_decoding_fs(const bo_fs_profile *gm5, const bo_gmx *fwd, const b
 #undef JJC
 }
 
+/* ---- the domains' traces, kept for the tests that render alignment blocks from them */
+static bo_domtrace *g_traces = NULL;
+static int g_ntraces = 0, g_traces_alloc = 0;
+static int g_win_start = 1;                                      /* dna_window->n of the window being defined */
+void bo_traces_reset(void)
+{
+  for (int t = 0; t < g_ntraces; t++) { free(g_traces[t].st); free(g_traces[t].k); free(g_traces[t].i); free(g_traces[t].c); free(g_traces[t].pp); }
+  g_ntraces = 0;
+}
+int bo_traces_count(void) { return g_ntraces; }
+const bo_domtrace *bo_traces_get(int idx) { return (idx >= 0 && idx < g_ntraces) ? &g_traces[idx] : NULL; }
+int bo_traces_push(int N, int win_start, int orf_start, int frameshift)
+{
+  if (g_ntraces == g_traces_alloc) { g_traces_alloc = g_traces_alloc ? g_traces_alloc * 2 : 64; g_traces = realloc(g_traces, sizeof(bo_domtrace) * (size_t) g_traces_alloc); }
+  bo_domtrace *t = &g_traces[g_ntraces];
+  t->N = N; t->win_start = win_start; t->orf_start = orf_start; t->frameshift = frameshift;
+  t->st = calloc((size_t) N + 1, 1); t->c = calloc((size_t) N + 1, 1);
+  t->k = calloc((size_t) N + 1, sizeof(int32_t)); t->i = calloc((size_t) N + 1, sizeof(int32_t)); t->pp = calloc((size_t) N + 1, sizeof(float));
+  return g_ntraces++;
+}
+
 /* ---- traces */
 void bo_trace_init(bo_trace *t) { memset(t, 0, sizeof *t); }
 void bo_trace_free(bo_trace *t) { free(t->st); free(t->k); free(t->i); free(t->c); free(t->pp); memset(t, 0, sizeof *t); }
@@ -315,6 +336,17 @@ static int rescore_domain(const bo_pipeline *pli, bo_fs_profile *gm5, bo_bg *bg,
       int shifts = 0;
       for (int z = 0; z < tr->N; z++) if (tr->st[z] == BO_T_M && tr->c[z] != 3) shifts++;
       d.n_shifted_codons = shifts;
+      {                                                            /* dom->tr = p7_trace_fs_Clone(ddef->tr), p7_domaindef.c:1171 */
+        const int tix = bo_traces_push(z2 - z1 + 1, g_win_start, 0, 1);
+        const bo_domtrace *t = bo_traces_get(tix);
+        for (int z = z1; z <= z2; z++) {
+          const int q = z - z1;
+          if (tr->st[z] == BO_T_M)      { t->st[q] = 1; t->k[q] = tr->k[z]; t->i[q] = tr->i[z]; t->c[q] = (int8_t) tr->c[z]; t->pp[q] = tr->pp[z]; }
+          else if (tr->st[z] == BO_T_I) { t->st[q] = 3; t->k[q] = tr->k[z]; t->i[q] = tr->i[z]; t->c[q] = 0; t->pp[q] = tr->pp[z]; }
+          else                          { t->st[q] = 2; t->k[q] = tr->k[z]; t->i[q] = i - 1;     t->c[q] = 0; t->pp[q] = 0.0f; }   /* AppendWithPP: D has i = 0; then += i - 1 (:1053) */
+        }
+        d.trace_idx = tix;
+      }
       dom_push(doms, ndom, dalloc, &d);
     }
   }
@@ -332,6 +364,7 @@ int bo_domaindef_fs(bo_pipeline *pli, bo_fs_profile *gm3, bo_fs_profile *gm5, bo
   const float rt1 = 0.25f, rt2 = 0.10f, rt3 = 0.20f;
   const int M = gm3->M;
   const int first = *ndom;
+  g_win_start = window_start;
   bo_gmx *fx = bo_gmx_create(M, L + 1, L, 3), *bx = bo_gmx_create(M, L + 1, L, 3);
   float fsc, bsc;
   bo_fs_profile_reconfig_length(gm3, L / 3);

@@ -124,7 +124,22 @@ class FsDomain(C.Structure):
     _fields_ = [("ienv", C.c_int32), ("jenv", C.c_int32), ("iali", C.c_int32), ("jali", C.c_int32), ("ihmm", C.c_int32), ("jhmm", C.c_int32),
                 ("envsc", C.c_float), ("oasc", C.c_float), ("domcorrection", C.c_float),
                 ("dombias", C.c_float), ("bitscore", C.c_float), ("pre_score", C.c_float),
-                ("lnP", C.c_double), ("reported", C.c_int32), ("n_shifted_codons", C.c_int32)]
+                ("lnP", C.c_double), ("reported", C.c_int32), ("n_shifted_codons", C.c_int32), ("trace_idx", C.c_int32)]
+
+
+class DomTrace(C.Structure):
+    """bo_domtrace: dom->tr, first to last match state (bath_oracle.h)."""
+    _fields_ = [("N", C.c_int32), ("win_start", C.c_int32), ("orf_start", C.c_int32), ("frameshift", C.c_int32),
+                ("st", C.POINTER(C.c_int8)), ("k", C.POINTER(C.c_int32)), ("i", C.POINTER(C.c_int32)), ("c", C.POINTER(C.c_int8)),
+                ("pp", C.POINTER(C.c_float))]
+
+
+def trace_arrays(idx):
+    """(DomTrace fields, st, k, i, c, pp as numpy copies) of the oracle's trace <idx>."""
+    t = lib().bo_traces_get(idx).contents
+    n = t.N
+    arr = lambda p, dt: np.ctypeslib.as_array(p, shape=(n,)).astype(dt).copy()
+    return t, arr(t.st, np.int8), arr(t.k, np.int32), arr(t.i, np.int32), arr(t.c, np.int8), arr(t.pp, np.float32)
 
 
 class OrfResult(C.Structure):
@@ -208,6 +223,7 @@ def lib():
     L.bo_translate_orfs_init.argtypes = [u8p, C.c_int, u8p, u8p, C.c_int, C.c_int, C.POINTER(OrfBlock)]
     L.bo_gencode_initiators.argtypes = [C.c_int, C.c_int, u8p]
     L.bo_set_seed.argtypes = [C.c_uint32]
+    L.bo_traces_get.argtypes = [C.c_int]; L.bo_traces_get.restype = C.POINTER(DomTrace)
     L.bo_gencode_basic.argtypes = [C.c_int, u8p]
     L.bo_revcomp.argtypes = [u8p, C.c_int, u8p]
     L.bo_pipeline_init.argtypes = [C.POINTER(Pipeline), C.c_int]
