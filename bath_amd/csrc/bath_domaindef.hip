@@ -978,7 +978,7 @@ __global__ void std_envelope_kernel(SeqView sq, int M, const float *__restrict__
 // The lane-per-envelope fill took 35 ms for 1500 envelopes (every cell a dependent trip to HBM); this one is well under 1 ms.
 template <int C>
 __global__ __launch_bounds__(256) void std_envelope_fill_kernel(SeqView sq, int M, const float *__restrict__ tf, const float *__restrict__ rf, float *__restrict__ fwd,
-                                                                const float *__restrict__ bck, const int64_t *__restrict__ dp_off, const float *__restrict__ fx,
+                                                                float *__restrict__ bck, const int64_t *__restrict__ dp_off, const float *__restrict__ fx,
                                                                 const float *__restrict__ bx, const int64_t *__restrict__ x_off, float *__restrict__ ppx_all,
                                                                 float *__restrict__ oax_all, StdEnvOut *__restrict__ out) {
   enum { XE = 0, XN, XJ, XB, XC, XS };
@@ -993,7 +993,7 @@ __global__ __launch_bounds__(256) void std_envelope_fill_kernel(SeqView sq, int 
     const uint8_t *dsq = sq.data + sq.off[t] - 1;
     const size_t W = (size_t)(M + 1) * 3;
     float *F = fwd + dp_off[t];
-    const float *Bk = bck + dp_off[t];
+    float *Bk = bck + dp_off[t];
     const float *FX = fx + x_off[t], *BX = bx + x_off[t];
     float *PX = ppx_all + (x_off[t] / 6) * 5, *OX = oax_all + (x_off[t] / 6) * 5;
     const float ploop = 1.0f - 2.0f / ((float)L + 2.0f);
@@ -1017,8 +1017,9 @@ __global__ __launch_bounds__(256) void std_envelope_fill_kernel(SeqView sq, int 
     for (int i = 1; i <= L; i++) {
       const float totr = scaleproduct * FX[(size_t)i * 6 + XS];
       float *frow = F + (size_t)i * W;
-      const float *brow = Bk + (size_t)i * W;
-      // posteriors of this row (p7_Decoding), special states included
+      float *brow = Bk + (size_t)i * W;
+      // posteriors of this row (p7_Decoding), special states included; they replace the Backward row as in the reference
+      // (p7_Decoding(om, ox1, ox2, ox2), p7_domaindef.c:1249: the traceback kernel reads a column's posterior there)
       float pM[C], pI[C];
 #pragma unroll
       for (int c = 0; c < C; c++) {
@@ -1026,6 +1027,7 @@ __global__ __launch_bounds__(256) void std_envelope_fill_kernel(SeqView sq, int 
         if (node <= M) {
           pM[c] = frow[(size_t)node * 3 + cM] * (brow[(size_t)node * 3 + cM] * totr);
           pI[c] = frow[(size_t)node * 3 + cI] * (brow[(size_t)node * 3 + cI] * totr);
+          brow[(size_t)node * 3 + cM] = pM[c]; brow[(size_t)node * 3 + cI] = pI[c]; brow[(size_t)node * 3 + cD] = 0.0f;
         } else pM[c] = pI[c] = 0.f;
         if (i == 1) { emM[c] = pM[c]; emI[c] = pI[c]; } else { emM[c] = pM[c] + emM[c]; emI[c] = pI[c] + emI[c]; }
       }

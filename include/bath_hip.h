@@ -116,8 +116,14 @@ void       *bath_hip_stream(bath_hip_ctx *ctx);                      /* hipStrea
 /* Frameshift recursions.  1 (the default): every sum along the model -- D(i,k), E(i), Backward's B(i) -- runs node by node in the
  * reference's order (generic_fwdback_frameshift.c:340-365, :577-590, :1279-1283), so every table log-sum has the reference's
  * operands: scores, special-state rows and matrices are BIT-IDENTICAL to the generic reference (the north star's 1e-4 with
- * room to spare).  0 = "fast": the same table log-sums associated by wavefront scans, scores within O(1e-3) nats of the
- * reference, ~1.7x faster on the bench's --fs pass.  Applies to the pipeline entry points and to BATH_LOGSUM_CONTEXT. */
+ * room to spare) and every frameshift-branch domain has the reference's coordinates exactly.
+ * 0 = "fast": the same table log-sums associated by wavefront scans in the multihit recursions (3-codon parsers, the regions'
+ * Forward), ~1.3x faster on the bench's --fs pass.  WARNING: the fast mode is OUTSIDE the parity contract and CHANGES RESULTS, not
+ * only the last digits of scores: window scores move by up to ~1e-3 nats (beyond 1e-4 relative for scores near zero), so a window
+ * at a threshold may take the other branch, region boundaries may shift by a step and a clustered region's stochastic traces take
+ * other turns -- on the bench's block 89 of 4789 domains come out with OTHER COORDINATES (bench.py: fs.fast.domains_identical_to_
+ * strict_mode).  Use it for throughput estimates or pre-screening, never where hit lists are compared with the reference's.
+ * Applies to the pipeline entry points and to BATH_LOGSUM_CONTEXT. */
 int         bath_hip_set_fs_strict(bath_hip_ctx *ctx, int on);
 /* Measurement aid: 1 = the envelope stage (bath_hip_fs5_envelopes and the domain stage's batches) runs its Backward wavefront AFTER the
  * Forward wavefront on the same stream instead of beside it, so that a kernel's HIP-event span is its time alone on the chip
