@@ -109,7 +109,16 @@ def test_bench_launcher_starts_the_ranks(scaling):
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1                                           # one JSON line, from rank 0
-    out = json.loads(lines[0])
+    # stdout ends with the compact line the driver records (its tail holds 2000 characters): the contract's keys and every leg's numbers
+    line = json.loads(lines[0])
+    assert len(lines[0]) < 2000 and p.stdout.rstrip().endswith(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "fs", "c4", "c5"):
+        assert key in line, key
+    assert line["n_gpus"] == 2 and line["scaling"] == scaling and line["plumbing_only"] is True and line["fs"]["n_gpus"] == 2 and line["c4"]["n_gpus"] == 2
+    # ... and the full record goes to stderr
+    full = [l for l in p.stderr.splitlines() if l.startswith("{") and '"residues_per_step"' in l]
+    assert len(full) == 1
+    out = json.loads(full[0])
     assert out["n_gpus"] == 2 and out["scaling"] == scaling and out["plumbing_only"] is True
     total = 1001 if scaling == "strong" else 2002                    # strong: one block sharded; weak: a block per rank
     assert out["residues_per_step"] == 2 * 1000 * total              # counters reduced over both ranks
