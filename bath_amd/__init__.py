@@ -20,7 +20,23 @@ import os as _os
 # and a host may run several contexts: with 4 queues, streams that are meant to run side by side end up one behind the other (two worker
 # contexts on whole --fs passes: 53-58 ms per block with 4, 49-51 with 16; nine contexts on configs[3]: 18.0 -> 14.5 ms per database
 # pass; one context alone: no difference).  Set before the first HIP call of the process; a value chosen by the caller is respected.
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+def _hip_runtime_loaded():
+    try:
+        with open("/proc/self/maps") as fh:
+            return any("libamdhip64" in line for line in fh)
+    except OSError:
+        return False
+
+
+HW_QUEUES_SET_BY_IMPORT = "GPU_MAX_HW_QUEUES" not in _os.environ
+if HW_QUEUES_SET_BY_IMPORT:
+    # (the variable is inherited by child processes; a host that wants another value sets it before importing this module)
+    if _hip_runtime_loaded():
+        import warnings as _warnings
+        _warnings.warn("bath_amd: the HIP runtime is already loaded in this process, so GPU_MAX_HW_QUEUES=16 may come too late to take effect "
+                       "(set it in the environment before the first HIP call: several worker contexts share 4 hardware queues otherwise; "
+                       "INTEGRATION.md, 'Several contexts on one GPU')", RuntimeWarning, stacklevel=2)
+    _os.environ["GPU_MAX_HW_QUEUES"] = "16"
 import ctypes as C
 import os
 import subprocess
@@ -244,6 +260,7 @@ ABI = {
                                           C.c_char_p, C.c_int64]),
     "bath_selftest_rng_stream": (C.c_int, [C.c_uint32, C.c_int, C.POINTER(C.c_double)]),
     "bath_selftest_fchoose": (C.c_int, [C.c_uint32, _f32p, C.c_int, C.c_int, _i32p]),
+    "bath_selftest_cluster_segments": (C.c_int, [C.c_int, _i32p, _i32p, _i32p, _i32p, _i32p, C.c_int, C.c_int, _i32p, C.c_int, _i32p]),
     "bath_selftest_fs_ensemble": (C.c_int, [C.c_int, _f32p, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, _f32p, _f32p, _i32p, C.c_int, _i32p]),
     "bath_tophits_create": (_vp, []),
     "bath_tophits_destroy": (None, [_vp]),

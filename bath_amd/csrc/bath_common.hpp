@@ -1,5 +1,6 @@
 // bath_common.hpp -- internal types shared by the HIP translation units of libbathhip.
 #pragma once
+#include <set>
 #include <atomic>
 #include <hip/hip_runtime.h>
 
@@ -19,6 +20,25 @@
 #include "bath_hip.h"
 
 namespace bath {
+
+// Kernels that ask for more than 64 KB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize raised first.  The attribute
+// belongs to the KERNEL, not to a launch: worker contexts on several host threads launch the same instantiation with different sizes,
+// and a thread that lowered it between another thread's "set" and "launch" would make that launch exceed it.  So it is raised ONCE per
+// (device, kernel), under a lock, to all the LDS a workgroup can have (160 KB on gfx950, less the kernel's static share), and never touched again.
+inline hipError_t allow_max_lds(const void *fn) {
+  static std::mutex mu;
+  static std::set<std::pair<int, const void *>> done;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> g(mu);
+  if (done.count({dev, fn})) return hipSuccess;
+  hipFuncAttributes at{};
+  size_t fixed = 0;
+  if (hipFuncGetAttributes(&at, fn) == hipSuccess) fixed = at.sharedSizeBytes; else (void)hipGetLastError();
+  const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024 - (int)std::min<size_t>(fixed, 96 * 1024)));
+  if (e == hipSuccess) done.insert({dev, fn});
+  return e;
+}
 
 constexpr int kKp = BATH_KP_AMINO;       // 29 amino symbols
 constexpr int kRowReset = 29;            // extra "row" of the SSV cost table: every cost +127 (resets every diagonal)

@@ -330,11 +330,12 @@ static int fs_branch_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, con
       std::vector<float> cpps;
       std::vector<int64_t> coff;
       bath_hip_seqs view;
+      // (a batch on another context runs on another host thread: its error text stays in that context until the caller has joined)
       int st2 = fs_gather_view(c, dna, chunk, tt.comp, &view, nullptr);
-      if (st2 != BATH_OK) { if (c != ctx) ctx->set_error(c->err); return st2; }
+      if (st2 != BATH_OK) return st2;
       st2 = fs5_envelopes_ex(c, om_fs5, &view, BATH_LOGSUM_CONTEXT, 0, out.res.data() + e0, nullptr, nullptr, nullptr, nullptr, out.traces.data() + e0, om->d_cons, &csteps, &coff, &cpps);
       view.d_data = nullptr; view.d_off = nullptr; view.d_len = nullptr;
-      if (st2 != BATH_OK) { if (c != ctx) ctx->set_error(c->err); return st2; }
+      if (st2 != BATH_OK) return st2;
       const int64_t base = (int64_t)out.steps.size();
       for (int k = 0; k < e1 - e0; k++) out.step_off[(size_t)(e0 + k)] = base + coff[(size_t)k];
       out.steps.insert(out.steps.end(), csteps.begin(), csteps.end());
@@ -379,6 +380,7 @@ static int fs_branch_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, con
   EnvBatch cl_batch;
   std::vector<Env> cl_envs;
   int cl_rc = BATH_OK;
+  std::string cl_err;                                                        // that thread's error text: copied into ctx->err after the join (ctx->err is the caller thread's)
   bool cl_ran = false;
   bath_hip_ctx *rctx = ctx;                                                  // where the regions' Forward runs
   std::thread ensembles;
@@ -453,15 +455,15 @@ static int fs_branch_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, con
       if (rctx != ctx && clusters_beside) {
         cl_ran = true;
         static const bool own_ctx = [] { const char *e = std::getenv("BATH_HIP_FS_CLUSTERS_CTX"); return !(e && e[0] == '2'); }();   // 2: on the regions' context
-        if (hipSetDevice(ctx->device) != hipSuccess) { cl_rc = BATH_EFAIL; return; }
+        if (hipSetDevice(ctx->device) != hipSuccess) { cl_rc = BATH_EFAIL; cl_err = "hipSetDevice failed on the clusters' thread"; return; }
         bath_hip_ctx *cctx = rctx;
         if (own_ctx) {
-          if (!ctx->aux3 && bath_hip_init(ctx->device, &ctx->aux3) != BATH_OK) { cl_rc = BATH_EFAIL; return; }
+          if (!ctx->aux3 && bath_hip_init(ctx->device, &ctx->aux3) != BATH_OK) { cl_rc = BATH_EFAIL; cl_err = "cannot create the context of the clusters' envelopes"; return; }
           mark_internal(ctx->aux3);
           cctx = ctx->aux3; cctx->fs_strict = ctx->fs_strict; cctx->spans_reset();
-        } else if (hipStreamSynchronize(rctx->stream) != hipSuccess) { cl_rc = BATH_EFAIL; return; }
+        } else if (hipStreamSynchronize(rctx->stream) != hipSuccess) { cl_rc = BATH_EFAIL; cl_err = "the regions' stream failed"; return; }
         for (size_t e = 0; e < mregs.size(); e++) cl_envs.insert(cl_envs.end(), found[e].begin(), found[e].end());
-        if (!cl_envs.empty()) cl_rc = run_env_batch(cctx, cl_envs.data(), (int)cl_envs.size(), cl_batch);
+        if (!cl_envs.empty() && (cl_rc = run_env_batch(cctx, cl_envs.data(), (int)cl_envs.size(), cl_batch)) != BATH_OK) cl_err = cctx->err;
         eclk.lap("fs:   (clusters' envelope kernels + traces, same thread)");
       }
     });
@@ -507,7 +509,7 @@ static int fs_branch_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, con
   const int nenv = (int)envs.size();
   if (nenv == 0) return BATH_OK;
   if (cl_ran && done == n_single) {                                          // the clusters' batch ran beside the first one (same order as envs)
-    if (cl_rc != BATH_OK) return cl_rc;
+    if (cl_rc != BATH_OK) { ctx->set_error(cl_err.empty() ? "the clusters' envelope batch failed" : cl_err.c_str()); return cl_rc; }
     if (!cl_envs.empty()) append_batch(cl_batch);
     done = nenv;
   }
@@ -1177,7 +1179,7 @@ static int std_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bat
     const char *e = std::getenv("BATH_HIP_STD_SERIAL");
     const size_t shm = (size_t)4 * ((size_t)view.maxlen + 1) * sizeof(float);
     if (shm <= (size_t)128 * 1024 && !(e && e[0] == '1')) {                     // a wave per ORF, rows in LDS
-      if (shm > 64 * 1024) BATH_HIP_TRY(ctx, hipFuncSetAttribute((const void *)std_regions_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+      if (shm > 64 * 1024) BATH_HIP_TRY(ctx, bath::allow_max_lds((const void *)std_regions_wave_kernel));
       hipLaunchKernelGGL(std_regions_wave_kernel, dim3((unsigned)std::min<int64_t>(ns, 65535)), dim3(64), shm, ctx->stream, ns, view.d_len, b_fx.as<float>(), b_bx.as<float>(),
                          d_xoff, om->lt.d_pmove, view.maxlen, b_reg.as<int32_t>());
     } else

@@ -110,7 +110,10 @@ void cluster_segments(const std::vector<Seg> &sp, int nsamples, bool fs, std::ve
       const int h = order[(size_t)z];
       const bool same = z > 0 && sp[(size_t)h].i == sp[(size_t)order[(size_t)z - 1]].i && sp[(size_t)h].j == sp[(size_t)order[(size_t)z - 1]].j &&
                         sp[(size_t)h].k == sp[(size_t)order[(size_t)z - 1]].k && sp[(size_t)h].m == sp[(size_t)order[(size_t)z - 1]].m;
-      if (!same) first_of.push_back(h);
+      // Copies are one vertex only if the segment is linked to ITSELF.  The model overlap is nov = min(m) - max(k) WITHOUT the + 1
+      // (p7_spensemble.c:207, :244), so a segment of four model nodes or fewer has (m - k) / (m - k + 1) < 0.8 and is linked to
+      // nothing, its own copies included: in the reference every copy is a singleton cluster (never significant), and so it is here.
+      if (!same || !linked(sp[(size_t)h], sp[(size_t)h])) first_of.push_back(h);
       uniq_of[(size_t)h] = (int)first_of.size() - 1;
     }
   }
@@ -456,6 +459,19 @@ extern "C" int bath_selftest_fs_ensemble(int M, const float *tsc, float xNL, flo
   std::vector<std::pair<int, int>> cl;
   const int st = bath::fs_region_trace_ensemble(M, tsc, xNL, xNM, xE, ireg, Lr, fwd, fx, &cl);
   if (st != BATH_OK) return st;
+  *n_env = (int32_t)cl.size();
+  for (size_t e = 0; e < cl.size() && (int)e < max_env; e++) { env[2 * e] = cl[e].first; env[2 * e + 1] = cl[e].second; }
+  return BATH_OK;
+}
+
+// the clustering step alone on caller-supplied segments (test hook: tests/test_ensemble_cpu.py holds it against the oracle's all-pairs search)
+extern "C" int bath_selftest_cluster_segments(int n, const int32_t *idx, const int32_t *i, const int32_t *j, const int32_t *k, const int32_t *m,
+                                              int nsamples, int fs, int32_t *env, int max_env, int32_t *n_env) {
+  if (n < 0 || !n_env || (n > 0 && (!idx || !i || !j || !k || !m))) return BATH_EINVAL;
+  std::vector<Seg> sp((size_t)n);
+  for (int h = 0; h < n; h++) sp[(size_t)h] = Seg{idx[h], i[h], j[h], k[h], m[h], 0.f};
+  std::vector<std::pair<int, int>> cl;
+  cluster_segments(sp, nsamples, fs != 0, &cl);
   *n_env = (int32_t)cl.size();
   for (size_t e = 0; e < cl.size() && (int)e < max_env; e++) { env[2 * e] = cl[e].first; env[2 * e + 1] = cl[e].second; }
   return BATH_OK;

@@ -641,7 +641,7 @@ int launch_ssv_lane(bath_hip_ctx *ctx, const bath_hip_oprofile *om, SeqView v, c
   bool launched = false;
 #define BATH_SSV_CASE(N, GG)                                                                                             \
   if (!launched && om->NR == N && G == GG) {                                                                             \
-    if (shmem > 64 * 1024) (void)hipFuncSetAttribute((const void *)ssv_lane_kernel<N, GG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
+    if (shmem > 64 * 1024) (void)bath::allow_max_lds((const void *)ssv_lane_kernel<N, GG>); \
     hipLaunchKernelGGL((ssv_lane_kernel<N, GG>), dim3(blocks), dim3(threads), shmem, ctx->stream, v, d_order, om->d_ssv, rb, d_v); \
     launched = true;                                                                                                     \
   }
@@ -705,7 +705,7 @@ int launch_vit_wave(bath_hip_ctx *ctx, const bath_hip_oprofile *om, SeqView v, c
   const float *fsc = nullptr; const uint8_t *ssv = nullptr; WindowRec *wins = nullptr; int *wc = nullptr; int cap = 0; int32_t *kmm = nullptr;
   if (wa) { c.invP_vit = wa->invP_vit; c.invP_msv = wa->invP_msv; fsc = wa->d_filtersc; ssv = wa->d_ssv_scores; wins = (WindowRec *)wa->d_wins; wc = wa->d_win_count; cap = wa->win_cap; kmm = wa->d_kminmax; }
   BATH_C_SWITCH(C, {
-    if (shmem > 64 * 1024) BATH_HIP_TRY(ctx, hipFuncSetAttribute((const void *)vit_wave_kernel<CC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    if (shmem > 64 * 1024) BATH_HIP_TRY(ctx, bath::allow_max_lds((const void *)vit_wave_kernel<CC>));
     hipLaunchKernelGGL(vit_wave_kernel<CC>, dim3(grid), dim3(256), shmem, ctx->stream, v, om->M, om->d_rw, om->d_tw, om->lt.d_xwmove, om->lt.d_tjb, c,
                        d_todo, ntodo, ntodo_dev, d_sc, d_status, fsc, ssv, wins, wc, cap, kmm);
   })
@@ -727,7 +727,7 @@ int launch_fwd_wave(bath_hip_ctx *ctx, const bath_hip_oprofile *om, SeqView v, c
     })
   } else {
     BATH_C_SWITCH(C, {
-      if (shmem > 64 * 1024) BATH_HIP_TRY(ctx, hipFuncSetAttribute((const void *)fwd_wave_kernel<CC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+      if (shmem > 64 * 1024) BATH_HIP_TRY(ctx, bath::allow_max_lds((const void *)fwd_wave_kernel<CC>));
       hipLaunchKernelGGL(fwd_wave_kernel<CC>, dim3(grid), dim3(256), shmem, ctx->stream, v, om->M, om->d_rf, om->d_tf, om->lt.d_pmove, c, d_todo, ntodo, ntodo_dev, d_sc, d_status, d_xmx, d_xmx_off, d_dp, d_dp_off, unihit, d_cfg_len);
     })
   }
@@ -749,7 +749,7 @@ int launch_bwd_wave(bath_hip_ctx *ctx, const bath_hip_oprofile *om, SeqView v, i
     })
   } else {
     BATH_C_SWITCH(C, {
-      if (shmem > 64 * 1024) BATH_HIP_TRY(ctx, hipFuncSetAttribute((const void *)bwd_wave_kernel<CC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+      if (shmem > 64 * 1024) BATH_HIP_TRY(ctx, bath::allow_max_lds((const void *)bwd_wave_kernel<CC>));
       hipLaunchKernelGGL(bwd_wave_kernel<CC>, dim3(grid), dim3(256), shmem, ctx->stream, v, om->M, om->d_rf, om->d_tf, om->lt.d_pmove, c, n, d_fwd_xmx, d_xmx_off, d_sc, d_status, d_bck_xmx, d_dp, d_dp_off, unihit);
     })
   }

@@ -1455,7 +1455,7 @@ static int fs_grid_dp(bath_hip_ctx *ctx, int64_t n) {           // blocks of kFs
 
 template <class K>
 static int fs_set_shmem(bath_hip_ctx *ctx, K kernel, size_t shmem) {
-  if (shmem > 64 * 1024) BATH_HIP_TRY(ctx, hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+  if (shmem > 64 * 1024) BATH_HIP_TRY(ctx, bath::allow_max_lds((const void *)kernel));
   return BATH_OK;
 }
 

@@ -1075,7 +1075,7 @@ int launch_fs3_fwd_chain(bath_hip_ctx *ctx, hipStream_t stream, const bath_hip_f
     const int cus = ctx->prop.multiProcessorCount;
     const int hgrid = std::max(1, std::min(nbat, cus));
 #define BATH_HALF(C_)                                                                                                              \
-    case C_: BATH_HIP_TRY(ctx, hipFuncSetAttribute((const void *)fs3_fwd_chain_half_kernel<C_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hs)); \
+    case C_: BATH_HIP_TRY(ctx, bath::allow_max_lds((const void *)fs3_fwd_chain_half_kernel<C_>)); \
              hipLaunchKernelGGL((fs3_fwd_chain_half_kernel<C_>), dim3(hgrid), dim3(1024), hs, stream, dna->view(), dev, om->d_loop[0], om->d_move[0], tEL, tEM, d_sc, d_xmx, d_xoff, jobs, \
                                 b_bst.as<int32_t>(), nbat); break;
     switch (CH) { BATH_HALF(1) BATH_HALF(2) BATH_HALF(3) BATH_HALF(4) BATH_HALF(5) BATH_HALF(6) }
@@ -1086,7 +1086,7 @@ int launch_fs3_fwd_chain(bath_hip_ctx *ctx, hipStream_t stream, const bath_hip_f
   const int W = chain_waves(ctx, dna->n, M, Cv, &shmem);
   const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((n + W - 1) / W, (int64_t)ctx->prop.multiProcessorCount));
   BATH_CHAIN_SWITCH(Cv, {
-    BATH_HIP_TRY(ctx, hipFuncSetAttribute((const void *)fs3_fwd_chain_kernel<CC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    BATH_HIP_TRY(ctx, bath::allow_max_lds((const void *)fs3_fwd_chain_kernel<CC>));
     hipLaunchKernelGGL((fs3_fwd_chain_kernel<CC>), dim3(grid), dim3(64 * W), shmem, stream, dna->view(), dev, om->d_loop[0], om->d_move[0], tEL, tEM, d_sc, d_xmx, d_xoff, jobs);
   })
   BATH_HIP_TRY(ctx, hipGetLastError());
@@ -1112,7 +1112,7 @@ int launch_fs3_bwd_chain(bath_hip_ctx *ctx, hipStream_t stream, const bath_hip_f
       const int hgrid = std::max(1, std::min(nbat, (int)ctx->prop.multiProcessorCount));
       FsDev dev{om->M, om->pitch, om->maxcodons, om->d_rsc, om->d_tf, om->d_tb, om->d_logsum};
 #define BATH_BHALF(C_)                                                                                                              \
-      case C_: BATH_HIP_TRY(ctx, hipFuncSetAttribute((const void *)fs3_bwd_chain_half_kernel<C_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hs)); \
+      case C_: BATH_HIP_TRY(ctx, bath::allow_max_lds((const void *)fs3_bwd_chain_half_kernel<C_>)); \
                hipLaunchKernelGGL((fs3_bwd_chain_half_kernel<C_>), dim3(hgrid), dim3(1024), hs, stream, dna->view(), dev, om->d_loop[0], om->d_move[0], tEL, tEM, d_sc, d_xmx, d_xoff, jobs, \
                                   b_bst.as<int32_t>(), nbat); break;
       switch (CH) { BATH_BHALF(1) BATH_BHALF(2) BATH_BHALF(3) BATH_BHALF(4) BATH_BHALF(5) BATH_BHALF(6) }
@@ -1130,7 +1130,7 @@ int launch_fs3_bwd_chain(bath_hip_ctx *ctx, hipStream_t stream, const bath_hip_f
   const int grid = std::max(1, std::min(nbat, (int)ctx->prop.multiProcessorCount));
   FsDev dev{om->M, om->pitch, om->maxcodons, om->d_rsc, om->d_tf, om->d_tb, om->d_logsum};
   BATH_CHAIN_SWITCH(Cv, {
-    BATH_HIP_TRY(ctx, hipFuncSetAttribute((const void *)fs3_bwd_chain_kernel<CC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    BATH_HIP_TRY(ctx, bath::allow_max_lds((const void *)fs3_bwd_chain_kernel<CC>));
     hipLaunchKernelGGL((fs3_bwd_chain_kernel<CC>), dim3(grid), dim3(64 * W), shmem, stream, dna->view(), dev, om->d_loop[0], om->d_move[0], tEL, tEM, d_sc, d_xmx, d_xoff, jobs,
                        b_bst.as<int32_t>(), nbat);
   })
@@ -1157,11 +1157,11 @@ int launch_fs5_fwd_chain(bath_hip_ctx *ctx, hipStream_t stream, const bath_hip_f
   // the row's cells and the next row's emission scores without spilling (a 1024-thread block leaves a lane 128)
   BATH_CHAIN_SWITCH(Cv, {
     if (64 * W <= 256) {
-      BATH_HIP_TRY(ctx, hipFuncSetAttribute((const void *)fs5_fwd_chain_kernel<CC, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+      BATH_HIP_TRY(ctx, bath::allow_max_lds((const void *)fs5_fwd_chain_kernel<CC, 256>));
       hipLaunchKernelGGL((fs5_fwd_chain_kernel<CC, 256>), dim3(grid), dim3(64 * W), shmem, stream, dna->view(), dev, om->d_loop[0], om->d_move[0], tEL, tEM, c5_compat, d_sc, d_fwd, d_foff,
                          d_xmx, d_xoff, cfg_len, jobs, d_done);
     } else {
-      BATH_HIP_TRY(ctx, hipFuncSetAttribute((const void *)fs5_fwd_chain_kernel<CC, chain_threads(CC)>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+      BATH_HIP_TRY(ctx, bath::allow_max_lds((const void *)fs5_fwd_chain_kernel<CC, chain_threads(CC)>));
       hipLaunchKernelGGL((fs5_fwd_chain_kernel<CC, chain_threads(CC)>), dim3(grid), dim3(64 * W), shmem, stream, dna->view(), dev, om->d_loop[0], om->d_move[0], tEL, tEM, c5_compat, d_sc, d_fwd, d_foff,
                          d_xmx, d_xoff, cfg_len, jobs, d_done);
     }

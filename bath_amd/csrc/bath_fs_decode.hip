@@ -340,7 +340,7 @@ int launch_fs5_decode_oa_mw(bath_hip_ctx *ctx, hipStream_t stream, const bath_hi
   const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(n, (int64_t)ctx->prop.multiProcessorCount * per_cu));
 #define BATH_OA_MW(CC)                                                                                                              \
   {                                                                                                                                 \
-    if (shmem > 64 * 1024) BATH_HIP_TRY(ctx, hipFuncSetAttribute((const void *)fs5_decode_oa_mw_kernel<CC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
+    if (shmem > 64 * 1024) BATH_HIP_TRY(ctx, bath::allow_max_lds((const void *)fs5_decode_oa_mw_kernel<CC>)); \
     hipLaunchKernelGGL((fs5_decode_oa_mw_kernel<CC>), dim3(grid), dim3(64 * W), shmem, stream, dna->view(), M, om->d_tf, om->d_loop[1], d_bsc, d_fwd, d_foff, d_fx, d_xoff,      \
                        d_bck, d_boff, d_bx, d_colsum, d_oa, d_osc, 1.17549435e-38f /* E->J impossible in unihit mode: TSCDELTA = FLT_MIN */, 1.0f, d_ox, jobs);                  \
   }

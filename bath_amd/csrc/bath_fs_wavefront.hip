@@ -50,11 +50,17 @@ __global__ __launch_bounds__(W == 1 ? kWfBlock : 64 * W) void fs5_fwd_wf_kernel(
                                                               float *ring_g /* [waves][(M+2)*8] or null: the ring lives in LDS */, FsJobs jobs, int dbg) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   float *s_tbl = reinterpret_cast<float *>(lds);
+#ifdef BATH_WF_PROBES
   // (dbg & 8, a timing probe with wrong results: a table of 8000 entries, so that three blocks fit a CU -- what a compressed table would buy)
   const int tbl_n = (dbg & 8) ? 8000 : kLogsumTbl;
+  for (int i = threadIdx.x; i < tbl_n; i += blockDim.x) s_tbl[i] = (i < 15700) ? p.logsum[i] : 0.f;
+#else
+  dbg = 0;                                        // the timing probes (WRONG results) exist only in a -DBATH_WF_PROBES build: their branches fold away here
+  constexpr int tbl_n = kLogsumTbl;
+  fs_load_logsum_table(s_tbl, p.logsum);
+#endif
   float *s_tf = s_tbl + tbl_n;
   const int M = p.M;
-  for (int i = threadIdx.x; i < tbl_n; i += blockDim.x) s_tbl[i] = (i < 15700) ? p.logsum[i] : 0.f;
   for (int i = threadIdx.x; i < (M + 2) * 8; i += blockDim.x) s_tf[i] = p.tf[i];
   __syncthreads();
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -292,10 +298,16 @@ __global__ __launch_bounds__(W == 1 ? kWfBlock : 64 * W) void fs5_bwd_wf_kernel(
                                                               float *__restrict__ terms, const int64_t *__restrict__ term_off, float *ring_g, FsJobs jobs, int dbg) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   float *s_tbl = reinterpret_cast<float *>(lds);
+#ifdef BATH_WF_PROBES
   const int tbl_n = (dbg & 8) ? 8000 : kLogsumTbl;                     // (the timing probe of fs5_fwd_wf_kernel)
+  for (int i = threadIdx.x; i < tbl_n; i += blockDim.x) s_tbl[i] = (i < 15700) ? p.logsum[i] : 0.f;
+#else
+  dbg = 0;
+  constexpr int tbl_n = kLogsumTbl;
+  fs_load_logsum_table(s_tbl, p.logsum);
+#endif
   float *s_tb = s_tbl + tbl_n;
   const int M = p.M;
-  for (int i = threadIdx.x; i < tbl_n; i += blockDim.x) s_tbl[i] = (i < 15700) ? p.logsum[i] : 0.f;
   for (int i = threadIdx.x; i < (M + 2) * 8; i += blockDim.x) s_tb[i] = p.tb[i];
   __syncthreads();
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -544,7 +556,11 @@ static int fs_wf_waves(bath_hip_ctx *ctx, int64_t n, int M) {
 struct WfGeom { int W, grid, block; bool lds_ring; size_t shmem; float *ring_g; };
 static int fs_wf_geometry(bath_hip_ctx *ctx, int64_t n, int M, DevBuf &ring_scratch, WfGeom *g) {
   static const bool ring_global = [] { const char *e = std::getenv("BATH_HIP_WF_RING_G"); return e && e[0] == '1'; }();
-  static const int dbg = [] { const char *e = std::getenv("BATH_HIP_WF_DBG"); return e ? std::atoi(e) : 0; }();
+#ifdef BATH_WF_PROBES
+  static const int dbg = [] { const char *e = std::getenv("BATH_HIP_WF_DBG"); return e ? std::atoi(e) : 0; }();   // timing probes, wrong results: probe builds only
+#else
+  constexpr int dbg = 0;
+#endif
   const int W = fs_wf_waves(ctx, n, M);
   const size_t base = (size_t)(((dbg & 8) ? 8000 : kLogsumTbl) + (M + 2) * 8) * sizeof(float);
   const int nrings = (W == 1) ? kWfWaves : 1;
@@ -568,7 +584,7 @@ static int fs_wf_geometry(bath_hip_ctx *ctx, int64_t n, int M, DevBuf &ring_scra
 #define BATH_WF_DISPATCH(KERNEL, ...)                                                                                            \
   do {                                                                                                                           \
     auto go = [&](auto kfn) -> int {                                                                                             \
-      if (g.shmem > 64 * 1024) BATH_HIP_TRY(ctx, hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.shmem)); \
+      if (g.shmem > 64 * 1024) BATH_HIP_TRY(ctx, bath::allow_max_lds((const void *)kfn)); \
       hipLaunchKernelGGL(kfn, dim3(g.grid), dim3(g.block), g.shmem, stream, __VA_ARGS__);                                         \
       return BATH_OK;                                                                                                            \
     };                                                                                                                           \
@@ -593,7 +609,11 @@ static int fs_wf_geometry(bath_hip_ctx *ctx, int64_t n, int M, DevBuf &ring_scra
 int launch_fs5_fwd_wf(bath_hip_ctx *ctx, hipStream_t stream, const bath_hip_fsprofile *om, const bath_hip_seqs *dna, int exact, int c5_compat,
                       float *d_sc, float *d_fwd, const int64_t *d_foff, float *d_xmx, const int64_t *d_xoff, DevBuf &ring_scratch, FsJobs jobs) {
   const int M = om->M;
-  static const int dbg = [] { const char *e = std::getenv("BATH_HIP_WF_DBG"); return e ? std::atoi(e) : 0; }();
+#ifdef BATH_WF_PROBES
+  static const int dbg = [] { const char *e = std::getenv("BATH_HIP_WF_DBG"); return e ? std::atoi(e) : 0; }();   // timing probes, wrong results: probe builds only
+#else
+  constexpr int dbg = 0;
+#endif
   WfGeom g{};
   int st = fs_wf_geometry(ctx, dna->n, M, ring_scratch, &g);
   if (st != BATH_OK) return st;
@@ -610,7 +630,11 @@ int launch_fs5_bwd_wf(bath_hip_ctx *ctx, hipStream_t stream, const bath_hip_fspr
                       FsJobs jobs_sweep, FsJobs jobs_x) {
   const int M = om->M;
   const int64_t n = dna->n;
-  static const int dbg = [] { const char *e = std::getenv("BATH_HIP_WF_DBG"); return e ? std::atoi(e) : 0; }();
+#ifdef BATH_WF_PROBES
+  static const int dbg = [] { const char *e = std::getenv("BATH_HIP_WF_DBG"); return e ? std::atoi(e) : 0; }();   // timing probes, wrong results: probe builds only
+#else
+  constexpr int dbg = 0;
+#endif
   WfGeom g{};
   int st = fs_wf_geometry(ctx, n, M, ring_scratch, &g);
   if (st != BATH_OK) return st;

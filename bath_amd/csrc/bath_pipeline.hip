@@ -713,7 +713,7 @@ static int run_filters(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bat
       bool launched = false;
 #define BATH_ORF_CASE(N, GG)                                                                                                     \
   if (!launched && NRk == N && om->G == GG) {                                                                                    \
-    if (ssv_shmem > 64 * 1024) (void)hipFuncSetAttribute((const void *)ssv_orf_kernel<N, GG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ssv_shmem); \
+    if (ssv_shmem > 64 * 1024) (void)bath::allow_max_lds((const void *)ssv_orf_kernel<N, GG>); \
     hipLaunchKernelGGL((ssv_orf_kernel<N, GG>), dim3(blocks), dim3(ssv_threads), ssv_shmem, ctx->stream, W.pool, ob.sorted, ob.ntotal,                  \
                        dna->view(), om->d_ssv, om->ssv_row_bytes, d_emit, max_orf, W.cand, W.cand_cap, W.ctr, ssv_chunk);        \
     launched = true;                                                                                                             \

@@ -544,6 +544,9 @@ int bath_selftest_fchoose(uint32_t seed, const float *p, int n, int draws, int32
 /* region_trace_ensemble_frameshift (p7_domaindef.c:891-958: 200 stochastic tracebacks through a region's multihit 5-codon Forward
  * matrix, single-linkage clustering) as the pipeline runs it on the host, on caller-supplied matrices: fwd (Lr+1) x (M+1) x
  * {D, I, M, C1..C5}, fx (Lr+1) x {E,N,J,B,C}, tsc the generic [M][8] log transitions; env: n_env x {i, j} in window nucleotides. */
+/* p7_spensemble_Cluster + the removal of dominated clusters on caller-supplied segments (idx: the sample a segment came from) */
+int bath_selftest_cluster_segments(int n, const int32_t *idx, const int32_t *i, const int32_t *j, const int32_t *k, const int32_t *m,
+                                   int nsamples, int fs, int32_t *env, int max_env, int32_t *n_env);
 int bath_selftest_fs_ensemble(int M, const float *tsc, float xNL, float xNM, float xE, int ireg, int Lr, const float *fwd, const float *fx,
                               int32_t *env, int max_env, int32_t *n_env);
 

@@ -354,6 +354,8 @@ typedef struct { uint32_t x; } bo_rng;                 /* easel's "fast" generat
 void   bo_rng_init(bo_rng *r, uint32_t seed);
 double bo_rng_next(bo_rng *r);
 int    bo_stochastic_trace(bo_rng *rng, int L, const bo_oprofile *om, const float *fwd, const float *fx, int8_t *st, int32_t *tk, int32_t *ti, int cap);
+int    bo_selftest_cluster_segments(int n, const int32_t *idx, const int32_t *i, const int32_t *j, const int32_t *k, const int32_t *m,
+                                    int nsamples, int fs, int *env, int max_env);
 int    bo_region_trace_ensemble_fs(const bo_fs_profile *gm5, int ireg, int jreg, const bo_gmx *fwd, int *env, int max_env);
 int    bo_region_trace_ensemble(const bo_oprofile *om, const uint8_t *dsq, int ireg, int jreg, const float *fwd, const float *fx,
                                 float *n2sc, int *env, int max_env);

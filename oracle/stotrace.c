@@ -244,6 +244,20 @@ static int cluster_segments(spcoord *sp, int nsp, int nsamples, int span, int fs
 }
 
 
+/* test hook: the clustering step alone (the all-pairs single-linkage search above) on caller-supplied segments */
+int bo_selftest_cluster_segments(int n, const int32_t *idx, const int32_t *i, const int32_t *j, const int32_t *k, const int32_t *m,
+                                 int nsamples, int fs, int *env, int max_env)
+{
+  spcoord *sp = malloc(sizeof(spcoord) * (size_t)(n + 1));
+  int span = 8;
+  for (int h = 0; h < n; h++) {
+    sp[h].idx = idx[h]; sp[h].i = i[h]; sp[h].j = j[h]; sp[h].k = k[h]; sp[h].m = m[h]; sp[h].prob = 0.f;
+    if (j[h] + 8 > span) span = j[h] + 8;
+    if (m[h] + 8 > span) span = m[h] + 8;
+  }
+  return cluster_segments(sp, n, nsamples, span, fs, env, max_env);
+}
+
 /* region_trace_ensemble, p7_domaindef.c:766-850.  dsq[1..n]: the ORF; region ireg..jreg; fwd/fx: p7_Forward of the region in
  * the multihit configuration of length saveL.  n2sc[ireg..jreg] receives the null2 log odds; env[2*c], env[2*c+1] the
  * envelopes of the surviving clusters (sequence coordinates of the ORF), ordered by start. */

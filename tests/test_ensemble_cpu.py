@@ -70,3 +70,51 @@ def test_product_ensemble_equals_oracle_ensemble_on_the_oracles_matrix(name):
         n_multi += len(got) >= 2
     assert n_multi >= 3                                     # the inputs do produce several clusters per region
     print("ensembles: product %.1f ms, oracle %.1f ms for 6 regions" % (t_prod * 1e3, t_orac * 1e3))
+
+
+def _cluster_both(idx, i, j, k, m, nsamples, fs):
+    a = lambda v: np.ascontiguousarray(v, np.int32)
+    idx, i, j, k, m = a(idx), a(i), a(j), a(k), a(m)
+    p32 = lambda v: v.ctypes.data_as(C.POINTER(C.c_int32))
+    env_p = np.zeros(2 * 64, np.int32); n_p = C.c_int32(0)
+    assert ba.lib().bath_selftest_cluster_segments(len(idx), p32(idx), p32(i), p32(j), p32(k), p32(m), nsamples, fs, p32(env_p), 64, C.byref(n_p)) == 0
+    L_ = ol.lib()
+    L_.bo_selftest_cluster_segments.argtypes = [C.c_int] + [C.POINTER(C.c_int32)] * 5 + [C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int]
+    env_o = (C.c_int * 128)()
+    n_o = L_.bo_selftest_cluster_segments(len(idx), p32(idx), p32(i), p32(j), p32(k), p32(m), nsamples, fs, env_o, 64)
+    return [tuple(env_p[2 * e:2 * e + 2]) for e in range(n_p.value)], [(env_o[2 * e], env_o[2 * e + 1]) for e in range(n_o)]
+
+
+@pytest.mark.parametrize("fs", [0, 1])
+def test_identical_short_segments_are_singletons_as_in_the_reference(fs):
+    """The model overlap of p7_spensemble's link rule is min(m) - max(k) WITHOUT + 1 (p7_spensemble.c:207, :244): a segment of four
+    model nodes or fewer is not even linked to an identical copy of itself, so N copies are N singleton clusters -- never one
+    significant cluster.  (Round 4's duplicate merging assumed linked(a, a); the advisor caught it.)"""
+    n = 120                                                     # 60 % of 200 samples carry the same short segment
+    short = _cluster_both(np.arange(n), [30] * n, [41] * n, [10] * n, [13] * n, 200, fs)       # m - k + 1 = 4: 3/4 < 0.8
+    assert short[0] == short[1] == []
+    longer = _cluster_both(np.arange(n), [30] * n, [44] * n, [10] * n, [14] * n, 200, fs)      # 5 nodes: 4/5 >= 0.8, linked to itself
+    assert longer[0] == longer[1] == [(30, 44)]
+    # mixed: copies of a short segment beside a real cluster; the short ones must not join or form anything
+    idx = list(range(100)) + list(range(100))
+    i = [30] * 100 + [200] * 100; j = [41] * 100 + [500] * 100; k = [10] * 100 + [5] * 100; m = [13] * 100 + [105] * 100
+    mixed = _cluster_both(idx, i, j, k, m, 200, fs)
+    assert mixed[0] == mixed[1] == [(200, 500)]
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_clustering_of_random_segment_sets_equals_the_all_pairs_search(seed):
+    """The product clusters the DISTINCT segments and hands the components back; the oracle runs the reference's all-pairs search."""
+    rng = np.random.default_rng(seed)
+    idx, i, j, k, m = [], [], [], [], []
+    protos = [(int(rng.integers(1, 300)), int(rng.integers(2, 12))) for _ in range(int(rng.integers(2, 6)))]
+    for t in range(200):
+        for (start, klen) in protos:
+            if rng.random() < 0.7:
+                kk = int(rng.integers(1, 40)); mm = kk + klen + int(rng.integers(-1, 2)) * (rng.random() < 0.3)
+                mm = max(mm, kk)
+                ii = start + int(rng.integers(0, 3)) * (rng.random() < 0.3); jj = ii + 3 * (mm - kk + 1) + int(rng.integers(-2, 3))
+                idx.append(t); i.append(ii); j.append(max(jj, ii)); k.append(kk); m.append(mm)
+    for fs in (0, 1):
+        got, want = _cluster_both(idx, i, j, k, m, 200, fs)
+        assert got == want

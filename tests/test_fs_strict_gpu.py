@@ -174,3 +174,46 @@ def test_fast_mode_errors_on_scores_that_reach_output(gpu_ctx):
     print("fast-mode errors", worst)
     assert worst["window_fwdsc"]["n"] >= 30 and worst["reported_envsc"]["n"] >= 15
     assert worst["reported_envsc"]["max_rel"] <= 1e-4 and worst["window_fwdsc"]["max_rel"] <= 1e-4
+
+
+BESIDE_SCRIPT = r"""
+import sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, {root!r} + "/tests")
+import numpy as np
+import bath_amd as ba, common, oracle_lib as ol
+import test_fs_strict_gpu as S
+rng = np.random.default_rng(7)
+path = ol.GOLDEN + "/PTH2.bhmm"
+model = ol.Model(path, 0)
+genes = common.emit_from_model(rng, model, 12, flank=3, sharpen=2.0)
+wins = []
+for a, b in zip(genes[::2], genes[1::2]):
+    nt = [list(common.revtranslate(rng, g, model.basic)) for g in (a, b)]
+    for seq in nt:
+        del seq[int(rng.integers(10, len(seq) - 10))]
+    wins.append(np.array(nt[0] + list(rng.integers(0, 4, size=int(rng.integers(20, 60)))) + nt[1], dtype=np.uint8))
+wins += S.P.frameshifted_windows(rng, model, n=12)
+ctx = ba.Context(0)                      # the process's ONLY context, as in a production host: host_contexts() == 1
+out = S.run(ctx, path, wins)
+assert out[4] >= 1, "no clustered region"
+n_fs, n_std, n_all = S.check_exact(*out)
+assert n_fs >= 4
+out2 = S.run(ctx, path, wins)            # and again on the warm context (aux3 exists by now)
+assert S.check_exact(*out2) == (n_fs, n_std, n_all)
+print("beside ok", out[4], n_fs, n_std)
+"""
+
+
+@pytest.mark.parametrize("beside", ["1", "0", None])
+def test_clusters_envelopes_beside_the_first_batch_fresh_process(beside):
+    """The clusters' envelope batch on a context of its own, driven from the ensembles' thread beside the tail of the single-domain
+    batch: ON by default only when the host holds ONE context -- which a pytest process with module-scoped contexts never does.
+    Fresh processes with one context: forced on, forced off, and the default (on), each exact on a block with clustered regions."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.pop("BATH_HIP_FS_CLUSTERS_BESIDE", None)
+    if beside is not None:
+        env["BATH_HIP_FS_CLUSTERS_BESIDE"] = beside
+    r = subprocess.run([sys.executable, "-c", BESIDE_SCRIPT.format(root=root)], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "beside ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
