@@ -168,6 +168,11 @@ class AliDisplayOpts(C.Structure):
                 ("initiator", C.c_int32)]
 
 
+class DistItem(C.Structure):
+    """bath_dist_item: windows [lo, hi) of query <query>."""
+    _fields_ = [("query", C.c_int32), ("lo", C.c_int64), ("hi", C.c_int64)]
+
+
 T_M, T_D, T_I = 1, 2, 3
 
 
@@ -260,6 +265,21 @@ ABI = {
                                           C.c_char_p, C.c_int64]),
     "bath_selftest_rng_stream": (C.c_int, [C.c_uint32, C.c_int, C.POINTER(C.c_double)]),
     "bath_selftest_fchoose": (C.c_int, [C.c_uint32, _f32p, C.c_int, C.c_int, _i32p]),
+    "bath_hits_serialize": (C.c_int64, [C.c_void_p, C.c_int64, C.c_char_p, C.POINTER(DomainTrace), C.POINTER(C.c_int8), _i32p, _i32p, C.POINTER(C.c_int8), _f32p,
+                                        C.c_void_p, C.c_int64]),
+    "bath_hits_deserialize": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(_vp)]),
+    "bath_hits_stream_size": (C.c_int64, [C.c_void_p, C.c_int64]),
+    "bath_hits_destroy": (None, [_vp]),
+    "bath_hits_count": (C.c_int64, [_vp]),
+    "bath_hits_domains": (C.POINTER(FsDomain), [_vp]),
+    "bath_hits_cigars": (C.c_void_p, [_vp, _i64p]),
+    "bath_hits_traces": (C.c_int, [_vp, C.POINTER(C.POINTER(DomainTrace)), C.POINTER(C.POINTER(C.c_int8)), C.POINTER(_i32p), C.POINTER(_i32p),
+                                   C.POINTER(C.POINTER(C.c_int8)), C.POINTER(_f32p)]),
+    "bath_tophits_add_serialized": (C.c_int, [_vp, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p),
+                                              C.POINTER(C.c_char_p), C.POINTER(C.c_int64)]),
+    "bath_dist_shard_range": (None, [C.c_int64, C.c_int, C.c_int, _i64p, _i64p]),
+    "bath_dist_items": (C.c_int64, [_i64p, C.POINTER(C.c_double), C.c_int, C.c_int, C.c_int, C.POINTER(DistItem), C.c_int64]),
+    "bath_dist_deal": (C.c_int, [C.POINTER(C.c_double), C.c_int64, C.c_int, _i32p]),
     "bath_selftest_cluster_segments": (C.c_int, [C.c_int, _i32p, _i32p, _i32p, _i32p, _i32p, C.c_int, C.c_int, _i32p, C.c_int, _i32p]),
     "bath_selftest_fs_ensemble": (C.c_int, [C.c_int, _f32p, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, _f32p, _f32p, _i32p, C.c_int, _i32p]),
     "bath_tophits_create": (_vp, []),
@@ -869,15 +889,38 @@ class HitArray:
         return len(self.rec)
 
     def to_bytes(self):
-        """[n records][pool length][records][pool]: what dist.gather_query_hits ships."""
-        return len(self.rec).to_bytes(8, "little") + len(self.pool).to_bytes(8, "little") + self.rec.tobytes() + self.pool
+        """The library's hit stream (bath_hits_serialize: self-delimiting records in network byte order, after p7_hit_Serialize):
+        what dist.gather_query_hits ships and what a C host would ship."""
+        rec = np.ascontiguousarray(self.rec)
+        pool = self.pool if self.pool else None
+        args = (rec.ctypes.data, len(rec), pool, None, None, None, None, None, None)
+        n = lib().bath_hits_serialize(*args, None, 0)
+        if n < 0:
+            raise BathError("hits_serialize failed")
+        buf = C.create_string_buffer(n)
+        if lib().bath_hits_serialize(*args, C.addressof(buf), n) != n:
+            raise BathError("hits_serialize failed")
+        return buf.raw
 
     @staticmethod
     def from_bytes(buf, p=0):
-        n = int.from_bytes(buf[p:p + 8], "little"); k = int.from_bytes(buf[p + 8:p + 16], "little"); p += 16
-        sz = C.sizeof(FsDomain)
-        rec = np.frombuffer(buf, dtype=FS_DOMAIN_DTYPE, count=n, offset=p).copy(); p += n * sz
-        return HitArray(rec, bytes(buf[p:p + k])), p + k
+        """(HitArray, position behind the stream) from the stream that starts at buf[p] (bath_hits_deserialize)."""
+        view = bytes(buf[p:]) if p else bytes(buf)
+        size = lib().bath_hits_stream_size(view, len(view))
+        if size < 0:
+            raise BathError("not a hit stream")
+        h = _vp()
+        if lib().bath_hits_deserialize(view, size, C.byref(h)) != OK:
+            raise BathError("hits_deserialize failed")
+        try:
+            n = lib().bath_hits_count(h)
+            rec = np.frombuffer((FsDomain * n).from_address(C.addressof(lib().bath_hits_domains(h).contents)), dtype=FS_DOMAIN_DTYPE).copy() if n else np.zeros(0, dtype=FS_DOMAIN_DTYPE)
+            k = C.c_int64(0)
+            base = lib().bath_hits_cigars(h, C.byref(k))
+            pool = C.string_at(base, k.value) if base and k.value else b""
+        finally:
+            lib().bath_hits_destroy(h)
+        return HitArray(rec, pool), p + size
 
     @staticmethod
     def from_domains(domains):

@@ -14,15 +14,16 @@ import torch.distributed as dist
 import ctypes as C
 
 from . import ORF_RESULT_DTYPE, FsDomain, PipelineStats
+from . import lib as _lib
 
 STAT_FIELDS = [n for n, _ in PipelineStats._fields_]
 
 
 def shard_range(n_items, rank, world):
     """Contiguous block partition of target blocks, like the reference's block queue dealt in order."""
-    per, rem = divmod(n_items, world)
-    lo = rank * per + min(rank, rem)
-    return lo, lo + per + (1 if rank < rem else 0)
+    lo, hi = C.c_int64(0), C.c_int64(0)
+    _lib().bath_dist_shard_range(int(n_items), int(rank), int(world), C.byref(lo), C.byref(hi))    # the C surface a C host uses (include/bath_hip.h)
+    return lo.value, hi.value
 
 
 BLOCK_LENGTH = 262144        # BATH_MAX_RESIDUE_COUNT, the default --block_length (bathsearch.c:839)
@@ -155,16 +156,7 @@ def max_over_ranks(x, device="cpu"):
 def query_items(n_windows_by_query, world, items_per_rank=2):
     """[(query, lo, hi)]: each query's windows [0, n) cut into G consecutive groups, G the smallest count that gives every rank
     about <items_per_rank> items (G = 1 while there are at least that many queries per rank)."""
-    nq = len(n_windows_by_query)
-    G = max(1, -(-items_per_rank * world // max(nq, 1)))
-    items = []
-    for q, n in enumerate(n_windows_by_query):
-        g = max(1, min(G, n))
-        for k in range(g):
-            lo, hi = shard_range(n, k, g)
-            if hi > lo:
-                items.append((q, lo, hi))
-    return items
+    return _items(n_windows_by_query, None, world, items_per_rank)
 
 
 def query_items_weighted(n_windows_by_query, costs_by_query, world, items_per_rank=3):
@@ -172,30 +164,30 @@ def query_items_weighted(n_windows_by_query, costs_by_query, world, items_per_ra
     at least one, T = max(queries, items_per_rank x world).  With worker contexts running a rank's items side by side the longest
     item is the critical path, so the 459-node model of a 12-model database is cut in two even on one rank while the short models
     stay whole (every extra item repeats a search's fixed cost).  The same on every rank, no communication."""
+    return _items(n_windows_by_query, costs_by_query, world, items_per_rank)
+
+
+def _items(n_windows_by_query, costs_by_query, world, items_per_rank):
+    """bath_dist_items (libbathhip: the cut a C host computes)."""
+    from . import DistItem
     nq = len(n_windows_by_query)
-    total = float(sum(costs_by_query)) or 1.0
-    T = max(nq, items_per_rank * world)
-    items = []
-    for q, n in enumerate(n_windows_by_query):
-        g = max(1, min(int(costs_by_query[q] / total * T + 0.5), n))
-        for k in range(g):
-            lo, hi = shard_range(n, k, g)
-            if hi > lo:
-                items.append((q, lo, hi))
-    return items
+    nw = (C.c_int64 * max(nq, 1))(*[int(x) for x in n_windows_by_query])
+    costs = (C.c_double * max(nq, 1))(*[float(x) for x in costs_by_query]) if costs_by_query is not None else None
+    n = _lib().bath_dist_items(nw, costs, nq, int(world), int(items_per_rank), None, 0)
+    assert n >= 0
+    arr = (DistItem * max(n, 1))()
+    _lib().bath_dist_items(nw, costs, nq, int(world), int(items_per_rank), arr, n)
+    return [(int(arr[k].query), int(arr[k].lo), int(arr[k].hi)) for k in range(n)]
 
 
 def deal(costs, world):
     """Owner rank of every item: longest processing time first onto the least loaded rank (ties: lowest rank); the same on every
     rank, no communication."""
-    order = sorted(range(len(costs)), key=lambda i: (-costs[i], i))
-    load = [0.0] * world
-    owner = [0] * len(costs)
-    for i in order:
-        r = min(range(world), key=lambda k: (load[k], k))
-        owner[i] = r
-        load[r] += costs[i]
-    return owner
+    n = len(costs)
+    cs = (C.c_double * max(n, 1))(*[float(x) for x in costs])
+    owner = (C.c_int32 * max(n, 1))()
+    assert _lib().bath_dist_deal(cs, n, int(world), owner) == 0                   # bath_dist_deal (libbathhip)
+    return [int(owner[k]) for k in range(n)]
 
 
 def gather_query_domains(by_query, dst=0, device="cpu"):

@@ -492,6 +492,53 @@ int64_t bath_tophits_tabular_targets(const bath_tophits *th, const char *qname, 
                                      int show_cigar, int show_header, char *buf, int64_t cap);
 
 /* ------------------------------------------------------------------------------------------
+ * One search on several GPUs from a C host: the hit list as a byte stream and the division of the work.
+ * Host code; the host's own transport (MPI, RCCL, sockets) moves the bytes.
+ *
+ * Hits between processes.  The reference ships a hit as p7_hit_Serialize writes it (src/p7_hit.c:174-411; read back by
+ * p7_hit_Deserialize, :411-640): a self-delimiting record -- its own size first, every fixed-width field in NETWORK byte order, a
+ * byte of presence flags, optional strings NUL-terminated -- followed by its domain and alignment.  The same scheme here:
+ *   stream  := u32 magic "BHIT" | u32 version (1) | u64 n_hits | n_hits x hit
+ *   hit     := u32 size of this record | i64 window | i32 strand, fs_window, ienv, jenv, iali, jali, ihmm, jhmm | f32 envsc, oasc,
+ *              domcorrection, dombias, bitscore, pre_score | f64 lnP | i32 reported, n_shifted_codons, n_stops | f32 pid |
+ *              i32 ali_columns | u8 flags (1: CIGAR present, 2: trace present) | [cigar, NUL-terminated] |
+ *              [i32 N, win_start, orf_start, frameshift | N x (u8 st, u8 c, i32 k, i32 i, f32 pp)]
+ * all integers and IEEE floats big-endian (esl_hton32 / esl_hton64 as p7_hit.c applies them).
+ * bath_hits_serialize returns the stream's size in bytes and writes it to <buf> when <buf> is not NULL and <cap> suffices (-1: bad
+ * arguments or <cap> too small); <cigars> is bath_hip_domain_cigars(ctx) or NULL; <tr> .. <pp> are bath_hip_domain_traces' outputs
+ * or all NULL (hits without their traces: enough for --tblout, not for the alignment blocks).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct bath_hits bath_hits;                 /* a deserialized hit list; owns its arrays */
+int64_t bath_hits_serialize(const bath_fs_domain *dom, int64_t n, const char *cigars, const bath_domain_trace *tr,
+                            const int8_t *st, const int32_t *k, const int32_t *i, const int8_t *c, const float *pp,
+                            uint8_t *buf, int64_t cap);
+int     bath_hits_deserialize(const uint8_t *buf, int64_t nbytes, bath_hits **ret);     /* BATH_EFORMAT for a stream that is not one */
+int64_t bath_hits_stream_size(const uint8_t *buf, int64_t nbytes);   /* bytes of the stream starting at buf (streams may lie back to back in a message); -1: not a stream */
+void    bath_hits_destroy(bath_hits *h);
+int64_t bath_hits_count(const bath_hits *h);
+bath_fs_domain *bath_hits_domains(bath_hits *h);    /* cigar_off points into bath_hits_cigars(); -1: the hit came without one */
+const char *bath_hits_cigars(const bath_hits *h, int64_t *nbytes);
+int     bath_hits_traces(const bath_hits *h, const bath_domain_trace **tr, const int8_t **st, const int32_t **k, const int32_t **i,
+                         const int8_t **c, const float **pp);                           /* BATH_EINVAL when the stream carried none */
+/* p7_tophits_Merge from a byte stream (bathsearch.c:884-888): the hits of another rank join <th>.  <window_shift> is added to every
+ * hit's window index (a rank that searched windows [lo, hi) of the search numbers them from 0); the rest as bath_tophits_add. */
+int     bath_tophits_add_serialized(bath_tophits *th, const uint8_t *buf, int64_t nbytes, int64_t window_shift, int64_t seqidx0,
+                                    const char *const *seq_names, const char *const *seq_accs, const char *const *seq_descs, const int64_t *seq_lens);
+
+/* Division of the work, the same on every rank without communication.
+ * bath_dist_shard_range: rank r's contiguous share [lo, hi) of n units (windows of one search over the ranks: configs[1], [2], [4]).
+ * bath_dist_items: a multi-query job (bathsearch's loop over an HMM database, bathsearch.c:737-844; configs[3]) as (query, window
+ *   group) items: query q's windows [0, n_q) in g_q consecutive groups, g_q = round(cost_q / sum of costs x T) clipped to [1, n_q],
+ *   T = max(queries, items_per_rank x world); costs NULL: g_q = ceil(items_per_rank x world / queries) for every query.  A useful
+ *   cost is windows x (M + 150).  Returns the number of items; writes at most <cap>.
+ * bath_dist_deal: owner rank of every item, longest processing time first onto the least loaded rank (ties: earlier item, lower rank). */
+typedef struct { int32_t query; int64_t lo, hi; } bath_dist_item;
+void    bath_dist_shard_range(int64_t n, int rank, int world, int64_t *lo, int64_t *hi);
+int64_t bath_dist_items(const int64_t *n_windows_by_query, const double *costs_by_query, int n_queries, int world, int items_per_rank,
+                        bath_dist_item *items, int64_t cap);
+int     bath_dist_deal(const double *costs, int64_t n_items, int world, int32_t *owner);
+
+/* ------------------------------------------------------------------------------------------
  * Frameshift kernels (P7_FS_OPROFILE surface), batched over DNA windows.
  * ------------------------------------------------------------------------------------------ */
 #define BATH_LOGSUM_TABLE 0   /* emulate p7_FLogsum's 0.001-nat truncating table (logsum.c:105) */

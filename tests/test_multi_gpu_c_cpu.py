@@ -1,0 +1,57 @@
+"""The C surface a C host drives several GPUs with (include/bath_hip.h: bath_hits_serialize / _deserialize,
+bath_tophits_add_serialized, bath_dist_items / _deal / _shard_range), exercised FROM C: tests/c/multi_gpu_surface.c is compiled
+with gcc against the header and linked with libbathhip.so, round-trips a hit list byte for byte, merges a remote rank's stream
+into a hit list and prints its division of a 12-query job, which must be the one bath_amd.dist computes (dist.py calls the same
+functions) and the one the rule written out in Python gives.  No GPU call anywhere."""
+import os
+import subprocess
+
+import bath_amd as ba
+from bath_amd import dist as bd
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_c_host_round_trips_hits_and_divides_the_job(tmp_path):
+    exe = str(tmp_path / "multi_gpu_surface")
+    libdir = os.path.join(ROOT, "bath_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-O1", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c", "multi_gpu_surface.c"),
+                           "-L", libdir, "-lbathhip", "-Wl,-rpath," + libdir, "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "multi-GPU C surface ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+    lines = r.stdout.split("\n")
+    got = [tuple(int(x) for x in l.split()[1:]) for l in lines if l.startswith("item ")]
+    M = [78, 185, 56, 209, 218, 109, 153, 247, 220, 226, 90, 459]
+    nwin = [382] * 12
+    cost = [382.0 * (m + 150) for m in M]
+    items = bd.query_items_weighted(nwin, cost, 8, items_per_rank=3)
+    owner = bd.deal([(hi - lo) * (M[q] + 150.0) for q, lo, hi in items], 8)
+    assert got == [(q, lo, hi, o) for (q, lo, hi), o in zip(items, owner)]
+    # ... and the rule itself, written out: round(share x T) groups per query, LPT onto the least loaded rank
+    T, total = max(12, 3 * 8), sum(cost)
+    want = []
+    for q in range(12):
+        g = max(1, min(int(cost[q] / total * T + 0.5), nwin[q]))
+        per, rem = divmod(nwin[q], g)
+        for k in range(g):
+            lo = k * per + min(k, rem)
+            want.append((q, lo, lo + per + (1 if k < rem else 0)))
+    assert [x[:3] for x in got] == want and len(want) > 12
+    load = [0.0] * 8
+    for x in sorted(range(len(want)), key=lambda x: (-(want[x][2] - want[x][1]) * (M[want[x][0]] + 150.0), x)):
+        r_ = min(range(8), key=lambda k: (load[k], k))
+        assert got[x][3] == r_
+        load[r_] += (want[x][2] - want[x][1]) * (M[want[x][0]] + 150.0)
+    assert [tuple(int(x) for x in l.split()[1:]) for l in lines if l.startswith("shard ")] == [(0, 0, 4), (1, 4, 7), (2, 7, 10)]
+
+
+def test_python_hit_arrays_travel_as_the_c_stream():
+    d = ba.FsDomain(); d.window = 5; d.reported = 1; d.iali = 10; d.jali = 100; d.lnP = -50.0; d.bitscore = 60.0; d.cigar = "30M"
+    e = ba.FsDomain(); e.window = 6; e.reported = 1; e.iali = 400; e.jali = 100; e.strand = 1; e.lnP = -20.5; e.bitscore = 31.0; e.cigar = "12M3I9M"
+    h = ba.HitArray.from_domains([d, e])
+    b = h.to_bytes()
+    assert b[:4] == b"BHIT" and int.from_bytes(b[8:16], "big") == 2               # network byte order, as p7_hit_Serialize writes
+    h2, p = ba.HitArray.from_bytes(b + b"tail", 0)
+    assert p == len(b) and h2.to_bytes() == b and h2.pool == b"30M\0" + b"12M3I9M\0"
+    both = ba.HitArray.concat([h2, h])
+    assert both.to_bytes() == ba.HitArray.from_bytes(both.to_bytes())[0].to_bytes() and len(both) == 4
