@@ -30,6 +30,13 @@ constexpr int kChainMaxWaves = 16;
 // threads per block by nodes per lane: a lane holds both rows of the pair and rows i-1..i-3 for its C nodes, so the register
 // budget per wave grows with C while LDS (two staged rows per window) limits the windows per block anyway
 constexpr int chain_threads(int C) { return C <= 3 ? 1024 : (C <= 8 ? 512 : 256); }
+// Long models (more than 8 nodes per lane: M > 512), Backward parser.  LDS, not registers, limits the windows of a block there: the
+// 64 KB table, the transitions (33 KB at 1024 nodes) and 8 KB of staged rows per window left room for FOUR windows -- a quarter of a
+// chain wave's lanes carrying a row, and a 1 Gb genome's 2.6 k windows in 658 blocks, 2.6 rounds of the chip.  The chain needs three
+// transitions per node (tDD, tDM, tBM): they are kept in LDS compactly (16 B per node), the window waves read theirs from global
+// memory (33 KB that every block reads: L2-resident), and a block takes EIGHT windows (512 threads; the kernel fits 256 registers).
+constexpr bool chain_compact(int C) { return C >= 12; }
+constexpr int bwd_chain_threads(int C) { return chain_compact(C) ? 512 : chain_threads(C); }
 
 // The waves of a block exchange rows through LDS only.  __syncthreads() is also a fence for GLOBAL memory: it would make every
 // wave wait, twice per row, until its stores of that row (special-state rows; the regions' matrices, which go to page-locked
@@ -116,37 +123,43 @@ __device__ __forceinline__ void fwd_chain_nodes(FwdChainRegs &r, int n, unsigned
 // the term of node k+1 added up and the raw values of node k+2 loaded behind the look-up.
 //   b       B so far (in/out);  v: the term of this node;  sN, tN: ivx and tBM of the NEXT node, loaded by the node before
 //   st, tp  LDS byte addresses of the row's slot k and of tBM(k-1) (s_tb[k * 8 + 7])
-#define BATH_BSUM_NODE(V, VN)                                                          \
+// (TS, TS2: the transition table's stride per node in bytes and twice that: 32 / 64 for the 8-float rows of tb, 16 / 32 for the
+// compact {tDD, tDM, tBM, -} rows that long models keep in LDS)
+#define BATH_BSUM_NODE(V, VN, TS, TS2)                                                 \
   BATH_LS_INDEX("%[a1]", "%[b]", V)                                                    \
   "s_waitcnt lgkmcnt(1)\n\t"                                                           \
   "v_add_f32 " VN ", %[sN], %[tN]\n\t"                                                 \
   "ds_read_b32 %[sN], %[st] offset:8\n\t"                                              \
-  "ds_read_b32 %[tN], %[tp] offset:64\n\t"                                             \
+  "ds_read_b32 %[tN], %[tp] offset:" TS2 "\n\t"                                        \
   "v_max_f32 %[mx], %[b], " V "\n\t"                                                   \
   "v_add_u32 %[st], 4, %[st]\n\t"                                                      \
-  "v_add_u32 %[tp], 32, %[tp]\n\t"                                                     \
+  "v_add_u32 %[tp], " TS ", %[tp]\n\t"                                                 \
   "s_waitcnt lgkmcnt(2)\n\t"                                                           \
   "v_add_f32 %[b], %[mx], %[a1]\n\t"
 
 // b = LS(b, term(k)) for k = k0 .. k0 + n - 1; on entry v = term(k0), sN/tN = the raw values of node k0 + 1, st/tp at node k0
+template <bool COMPACT = false>
 __device__ __forceinline__ float bwd_bsum_nodes(float b, float v, float sN, float tN, unsigned st, unsigned tp, int n, unsigned tbl, float c15) {
   float vn, a1, mx;
   int k = 0;
-  for (; k + 2 <= n; k += 2)
-    asm volatile("s_waitcnt lgkmcnt(0)\n\t"
-                 BATH_BSUM_NODE("%[v]", "%[vn]")
-                 BATH_BSUM_NODE("%[vn]", "%[v]")
-                 "s_waitcnt lgkmcnt(0)"
-                 : [b] "+v"(b), [v] "+v"(v), [sN] "+v"(sN), [tN] "+v"(tN), [st] "+v"(st), [tp] "+v"(tp), [vn] "=&v"(vn), [a1] "=&v"(a1), [mx] "=&v"(mx)
-                 : [tbl] "s"(tbl), [c15] "s"(c15)
+#define BATH_BSUM_PAIR(TS, TS2)                                                                                                          \
+  for (; k + 2 <= n; k += 2)                                                                                                            \
+    asm volatile("s_waitcnt lgkmcnt(0)\n\t"                                                                                             \
+                 BATH_BSUM_NODE("%[v]", "%[vn]", TS, TS2)                                                                               \
+                 BATH_BSUM_NODE("%[vn]", "%[v]", TS, TS2)                                                                               \
+                 "s_waitcnt lgkmcnt(0)"                                                                                                 \
+                 : [b] "+v"(b), [v] "+v"(v), [sN] "+v"(sN), [tN] "+v"(tN), [st] "+v"(st), [tp] "+v"(tp), [vn] "=&v"(vn), [a1] "=&v"(a1), [mx] "=&v"(mx) \
+                 : [tbl] "s"(tbl), [c15] "s"(c15)                                                                                       \
+                 : "memory");                                                                                                           \
+  if (k < n)                                                                                                                            \
+    asm volatile("s_waitcnt lgkmcnt(0)\n\t"                                                                                             \
+                 BATH_BSUM_NODE("%[v]", "%[vn]", TS, TS2)                                                                               \
+                 "s_waitcnt lgkmcnt(0)"                                                                                                 \
+                 : [b] "+v"(b), [sN] "+v"(sN), [tN] "+v"(tN), [st] "+v"(st), [tp] "+v"(tp), [vn] "=&v"(vn), [a1] "=&v"(a1), [mx] "=&v"(mx) \
+                 : [v] "v"(v), [tbl] "s"(tbl), [c15] "s"(c15)                                                                           \
                  : "memory");
-  if (k < n)
-    asm volatile("s_waitcnt lgkmcnt(0)\n\t"
-                 BATH_BSUM_NODE("%[v]", "%[vn]")
-                 "s_waitcnt lgkmcnt(0)"
-                 : [b] "+v"(b), [sN] "+v"(sN), [tN] "+v"(tN), [st] "+v"(st), [tp] "+v"(tp), [vn] "=&v"(vn), [a1] "=&v"(a1), [mx] "=&v"(mx)
-                 : [v] "v"(v), [tbl] "s"(tbl), [c15] "s"(c15)
-                 : "memory");
+  if constexpr (COMPACT) { BATH_BSUM_PAIR("16", "32") } else { BATH_BSUM_PAIR("32", "64") }
+#undef BATH_BSUM_PAIR
   return b;
 }
 
@@ -154,7 +167,7 @@ __device__ __forceinline__ float bwd_bsum_nodes(float b, float v, float sN, floa
 // (<mid>, a lane mask) take them in the other order (:1524-1526).  Two dependent look-ups per node; the loads of node k-1 sit
 // behind the first, the address arithmetic behind the second; D(i,k) is stored over ivx(i,k), which was read a node ahead.
 //   dn   D(i,k+1) (in/out);  IVN: ivx(i,k+1);  set A = {ivx(i,k), tDD(k), tDM(k)};  st at slot k-1, tp at s_tb[(k-1) * 8 + 3]
-#define BATH_BWD_D_NODE(IVN, TX, TY, IVQ, UX, UY)                                      \
+#define BATH_BWD_D_NODE(IVN, TX, TY, IVQ, UX, UY, NTS)                                 \
   "v_add_f32 %[u], %[dn], " TX "\n\t"                                                  \
   "v_add_f32 %[bs], " IVN ", " TY "\n\t"                                               \
   "v_cndmask_b32_e64 %[p1], %[u], %[bs], %[mid]\n\t"                                   \
@@ -169,38 +182,42 @@ __device__ __forceinline__ float bwd_bsum_nodes(float b, float v, float sN, floa
   BATH_LS_INDEX("%[a1]", "%[x]", "%[p2]")                                              \
   "v_max_f32 %[mx1], %[x], %[p2]\n\t"                                                  \
   "v_add_u32 %[st], -4, %[st]\n\t"                                                     \
-  "v_add_u32 %[tp], -32, %[tp]\n\t"                                                    \
+  "v_add_u32 %[tp], " NTS ", %[tp]\n\t"                                                \
   "s_waitcnt lgkmcnt(0)\n\t"                                                           \
   "v_add_f32 %[dn], %[mx1], %[a1]\n\t"                                                 \
   "ds_write_b32 %[st], %[dn] offset:8\n\t"
 
 struct BwdChainRegs { float dn, ivn, ivk, tx, ty; unsigned st, tp; };
 
+template <bool COMPACT = false>
 __device__ __forceinline__ void bwd_d_nodes(BwdChainRegs &r, float xE, unsigned long long mid, int n, unsigned tbl, float c15) {
   float ivq, ux, uy, u, bs, p1, p2, a1, mx1, x;
   int k = 0;
-  for (; k + 2 <= n; k += 2)
-    asm volatile("s_waitcnt lgkmcnt(0)\n\t"
-                 BATH_BWD_D_NODE("%[ivn]", "%[tx]", "%[ty]", "%[ivq]", "%[ux]", "%[uy]")
-                 BATH_BWD_D_NODE("%[ivk]", "%[ux]", "%[uy]", "%[ivk]", "%[tx]", "%[ty]")
-                 "v_mov_b32 %[ivn], %[ivq]\n\t"
-                 "s_waitcnt lgkmcnt(0)"
-                 : [dn] "+v"(r.dn), [ivn] "+v"(r.ivn), [ivk] "+v"(r.ivk), [tx] "+v"(r.tx), [ty] "+v"(r.ty), [st] "+v"(r.st), [tp] "+v"(r.tp),
-                   [ivq] "=&v"(ivq), [ux] "=&v"(ux), [uy] "=&v"(uy), [u] "=&v"(u), [bs] "=&v"(bs), [p1] "=&v"(p1), [p2] "=&v"(p2),
-                   [a1] "=&v"(a1), [mx1] "=&v"(mx1), [x] "=&v"(x)
-                 : [xE] "v"(xE), [mid] "s"(mid), [tbl] "s"(tbl), [c15] "s"(c15)
-                 : "memory");
-  if (k < n) {
-    asm volatile("s_waitcnt lgkmcnt(0)\n\t"
-                 BATH_BWD_D_NODE("%[ivn]", "%[tx]", "%[ty]", "%[ivq]", "%[ux]", "%[uy]")
-                 "s_waitcnt lgkmcnt(0)"
-                 : [dn] "+v"(r.dn), [st] "+v"(r.st), [tp] "+v"(r.tp),
-                   [ivq] "=&v"(ivq), [ux] "=&v"(ux), [uy] "=&v"(uy), [u] "=&v"(u), [bs] "=&v"(bs), [p1] "=&v"(p1), [p2] "=&v"(p2),
-                   [a1] "=&v"(a1), [mx1] "=&v"(mx1), [x] "=&v"(x)
-                 : [ivn] "v"(r.ivn), [tx] "v"(r.tx), [ty] "v"(r.ty), [xE] "v"(xE), [mid] "s"(mid), [tbl] "s"(tbl), [c15] "s"(c15)
-                 : "memory");
-    r.ivn = r.ivk; r.ivk = ivq; r.tx = ux; r.ty = uy;
+#define BATH_BWD_D_PAIR(NTS)                                                                                                             \
+  for (; k + 2 <= n; k += 2)                                                                                                            \
+    asm volatile("s_waitcnt lgkmcnt(0)\n\t"                                                                                             \
+                 BATH_BWD_D_NODE("%[ivn]", "%[tx]", "%[ty]", "%[ivq]", "%[ux]", "%[uy]", NTS)                                           \
+                 BATH_BWD_D_NODE("%[ivk]", "%[ux]", "%[uy]", "%[ivk]", "%[tx]", "%[ty]", NTS)                                           \
+                 "v_mov_b32 %[ivn], %[ivq]\n\t"                                                                                         \
+                 "s_waitcnt lgkmcnt(0)"                                                                                                 \
+                 : [dn] "+v"(r.dn), [ivn] "+v"(r.ivn), [ivk] "+v"(r.ivk), [tx] "+v"(r.tx), [ty] "+v"(r.ty), [st] "+v"(r.st), [tp] "+v"(r.tp), \
+                   [ivq] "=&v"(ivq), [ux] "=&v"(ux), [uy] "=&v"(uy), [u] "=&v"(u), [bs] "=&v"(bs), [p1] "=&v"(p1), [p2] "=&v"(p2),       \
+                   [a1] "=&v"(a1), [mx1] "=&v"(mx1), [x] "=&v"(x)                                                                       \
+                 : [xE] "v"(xE), [mid] "s"(mid), [tbl] "s"(tbl), [c15] "s"(c15)                                                         \
+                 : "memory");                                                                                                           \
+  if (k < n) {                                                                                                                          \
+    asm volatile("s_waitcnt lgkmcnt(0)\n\t"                                                                                             \
+                 BATH_BWD_D_NODE("%[ivn]", "%[tx]", "%[ty]", "%[ivq]", "%[ux]", "%[uy]", NTS)                                           \
+                 "s_waitcnt lgkmcnt(0)"                                                                                                 \
+                 : [dn] "+v"(r.dn), [st] "+v"(r.st), [tp] "+v"(r.tp),                                                                   \
+                   [ivq] "=&v"(ivq), [ux] "=&v"(ux), [uy] "=&v"(uy), [u] "=&v"(u), [bs] "=&v"(bs), [p1] "=&v"(p1), [p2] "=&v"(p2),       \
+                   [a1] "=&v"(a1), [mx1] "=&v"(mx1), [x] "=&v"(x)                                                                       \
+                 : [ivn] "v"(r.ivn), [tx] "v"(r.tx), [ty] "v"(r.ty), [xE] "v"(xE), [mid] "s"(mid), [tbl] "s"(tbl), [c15] "s"(c15)       \
+                 : "memory");                                                                                                           \
+    r.ivn = r.ivk; r.ivk = ivq; r.tx = ux; r.ty = uy;                                                                                   \
   }
+  if constexpr (COMPACT) { BATH_BWD_D_PAIR("-16") } else { BATH_BWD_D_PAIR("-32") }
+#undef BATH_BWD_D_PAIR
 }
 
 // LDS byte address of a pointer into the block's dynamic shared memory (the low half of its flat address)
@@ -384,8 +401,13 @@ __global__ __launch_bounds__(1024) void fs3_fwd_chain_half_kernel(SeqView dna, F
   auto shr1 = [&](float v) { const float r = wave_shr1(v, -INFINITY); return hl == 0 ? -INFINITY : r; };   // the neighbour move stays inside the half wave
   // The batches come from the host (launch_fs3_fwd_chain): a block lasts as long as its longest window times the duration of a row
   // pair, which grows with the windows it holds -- so the batches of the longest windows are smaller, and all blocks end together.
-  (void)s_ctl;
-  for (int bb = blockIdx.x; bb < nb; bb += gridDim.x) {
+  // Which batch a block takes next is decided when it asks (one atomic per batch on the launch's job counter): the batches are sorted by
+  // decreasing length, so a launch of more batches than blocks is dealt longest-processing-time first instead of round-robin
+  for (;;) {
+    if (threadIdx.x == 0) s_ctl[0] = (int)atomicAdd(jobs.counter, 1u);
+    __syncthreads();
+    const int bb = s_ctl[0];
+    if (bb >= nb) break;
     const int64_t base = bstart[bb];
     const int cnt = bstart[bb + 1] - bstart[bb];
     const int64_t job = (win < cnt) ? (int64_t)jobs.order[base + win] : (int64_t)-1;
@@ -521,28 +543,43 @@ __global__ __launch_bounds__(1024) void fs3_fwd_chain_half_kernel(SeqView dna, F
 //   3. window waves: M(i,k), I(i,k) from D(i,k+1), ivx(i,k+1), I(i+3,k), E(i).
 // ---------------------------------------------------------------------------------------------------------------------------
 template <int C>
-__global__ __launch_bounds__(chain_threads(C)) void fs3_bwd_chain_kernel(SeqView dna, FsDev p, const float *__restrict__ loop_tab, const float *__restrict__ move_tab,
+__global__ __launch_bounds__(bwd_chain_threads(C)) void fs3_bwd_chain_kernel(SeqView dna, FsDev p, const float *__restrict__ loop_tab, const float *__restrict__ move_tab,
                                                              float tEL, float tEM, float *__restrict__ sc, float *__restrict__ xmx, const int64_t *__restrict__ xmx_off, FsJobs jobs,
                                                              const int32_t *__restrict__ bstart /* batches of the sorted list, chain_batches */, int nb) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
+  constexpr bool kCompact = chain_compact(C);
   float *s_tbl = reinterpret_cast<float *>(lds);
-  float *s_tb = s_tbl + kLogsumTbl;
+  float *s_tb = s_tbl + kLogsumTbl;                             // kCompact: [(M + 3)][4] = {tDD(k), tDM(k), tBM(k-1), -}; else tb's [(M + 2)][8]
   const int M = p.M;
   const int W = blockDim.x >> 6;
   const int stride = fs_chain_stride(C);
-  float *s_stage = s_tb + (M + 2) * 8;                          // [W][2][stride]: ivx(i,k) in, D(i,k) out
+  float *s_stage = s_tb + (kCompact ? (M + 3) * 4 : (M + 2) * 8);   // [W][2][stride]: ivx(i,k) in, D(i,k) out
   float *s_e = s_stage + (size_t)W * 2 * stride;                // [W][2] E(i) of the pair's rows
   int *s_ctl = reinterpret_cast<int *>(s_e + 2 * kChainMaxWaves);   // [0]: first job of the block's batch
   fs_load_logsum_table(s_tbl, p.logsum);
-  for (int i = threadIdx.x; i < (M + 2) * 8; i += blockDim.x) s_tb[i] = p.tb[i];
+  if constexpr (kCompact) {
+    for (int k = threadIdx.x; k < M + 3; k += blockDim.x) {
+      const int kk = imin(k, M + 1);
+      s_tb[k * 4 + 0] = p.tb[kk * 8 + 3]; s_tb[k * 4 + 1] = p.tb[kk * 8 + 4]; s_tb[k * 4 + 2] = p.tb[kk * 8 + 7]; s_tb[k * 4 + 3] = 0.f;
+    }
+  } else {
+    for (int i = threadIdx.x; i < (M + 2) * 8; i += blockDim.x) s_tb[i] = p.tb[i];
+  }
+  // the chain's transitions: tDD(k), tDM(k) (consecutive words), tBM(k-1)
+  auto TDD = [&](int k) -> float * { return kCompact ? s_tb + k * 4 : s_tb + k * 8 + 3; };
+  auto TBM = [&](int k) -> float * { return kCompact ? s_tb + k * 4 + 2 : s_tb + k * 8 + 7; };
+  const float *wt = kCompact ? p.tb : s_tb;                    // the window waves' transitions (all eight per node): LDS, or global memory for long models
   __syncthreads();
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   // Lanes own their nodes in DESCENDING order (logical lane = 63 - physical lane), as in fs_bwd_kernel: "the lane holding the
   // next nodes" is then the physical lane below and the neighbour move is the same wave_shr1
   const int ll = 63 - lane;
 #define LS(a, b) flogsum<false>((a), (b), s_tbl)
-  (void)s_ctl;
-  for (int bb = blockIdx.x; bb < nb; bb += gridDim.x) {
+  for (;;) {                                                    // batches dealt longest first, on request (see fs3_fwd_chain_half_kernel)
+    if (threadIdx.x == 0) s_ctl[0] = (int)atomicAdd(jobs.counter, 1u);
+    __syncthreads();
+    const int bb = s_ctl[0];
+    if (bb >= nb) break;
     const int64_t base = bstart[bb];
     const int cnt = bstart[bb + 1] - bstart[bb];                // windows of this batch (<= W): the longest windows come in smaller batches
     const int64_t job = (wv < cnt) ? (int64_t)jobs.order[base + wv] : (int64_t)-1;
@@ -600,8 +637,8 @@ __global__ __launch_bounds__(chain_threads(C)) void fs3_bwd_chain_kernel(SeqView
         float *st = s_stage + (size_t)lane * stride;
         const int avail = 2 * q + cs, irow = cL - avail;
         // (the terms are read two nodes ahead of the chain: the slots M+1, M+2 of the row and of the transitions are inside the block's LDS)
-        const float b = bwd_bsum_nodes(st[1] + s_tb[1 * 8 + 7], st[2] + s_tb[2 * 8 + 7], st[3], s_tb[3 * 8 + 7], lds_addr(st + 2), lds_addr(s_tb + 2 * 8 + 7),
-                                       M - 1, lds_addr(s_tbl), 15.999f);
+        const float b = bwd_bsum_nodes<kCompact>(st[1] + *TBM(1), st[2] + *TBM(2), st[3], *TBM(3), lds_addr(st + 2), lds_addr(TBM(2)),
+                                                 M - 1, lds_addr(s_tbl), 15.999f);
         // N, J, C of row i+3: the other slot's row of two pairs ago (slot 0) or of the previous pair (slot 1)
         const float pN1 = __shfl_xor(hN1, 1, 64), pN2 = __shfl_xor(hN2, 1, 64), pJ1 = __shfl_xor(hJ1, 1, 64), pJ2 = __shfl_xor(hJ2, 1, 64);
         const float pC1 = __shfl_xor(hC1, 1, 64), pC2 = __shfl_xor(hC2, 1, 64);
@@ -613,8 +650,8 @@ __global__ __launch_bounds__(chain_threads(C)) void fs3_bwd_chain_kernel(SeqView
         const bool mid = (avail == 3) || (avail == 4);            // rows L-3, L-4 associate the D chain differently (:1524-1526)
         // D(i,k) = LS(LS(E, D(i,k+1) + tDD), ivx(i,k+1) + tDM); the rows L-3, L-4 pair E with the ivx term first (:1524-1526).
         // Log-sum is symmetric, so both are LS(LS(E, p1), p2) with the operands swapped: no branch in the loop
-        BwdChainRegs r{-INFINITY, -INFINITY, st[M], s_tb[M * 8 + 3], s_tb[M * 8 + 4], lds_addr(st + M - 1), lds_addr(s_tb + (M - 1) * 8 + 3)};   // ivx(i,M), tDD(M), tDM(M)
-        bwd_d_nodes(r, xE, __builtin_amdgcn_ballot_w64(mid), M, lds_addr(s_tbl), 15.999f);
+        BwdChainRegs r{-INFINITY, -INFINITY, st[M], TDD(M)[0], TDD(M)[1], lds_addr(st + M - 1), lds_addr(TDD(M - 1))};   // ivx(i,M), tDD(M), tDM(M)
+        bwd_d_nodes<kCompact>(r, xE, __builtin_amdgcn_ballot_w64(mid), M, lds_addr(s_tbl), 15.999f);
         s_e[lane] = xE;
         const float partnerN = __shfl_xor(xN, 1, 64);
         if (clive && irow >= 0) {
@@ -639,8 +676,8 @@ __global__ __launch_bounds__(chain_threads(C)) void fs3_bwd_chain_kernel(SeqView
       for (int c = C - 1; c >= 0; c--) {
         const int node = ll * C + c + 1, nd = imin(node, M + 1);
         const bool in = node <= M;
-        const float4 t0 = *reinterpret_cast<const float4 *>(s_tb + nd * 8);            // tMD tMI tMM tDD
-        const float tii = s_tb[nd * 8 + 5], tim = s_tb[nd * 8 + 6];
+        const float4 t0 = *reinterpret_cast<const float4 *>(wt + nd * 8);              // tMD tMI tMM tDD
+        const float tii = wt[nd * 8 + 5], tim = wt[nd * 8 + 6];
         const float dnA = (node < M) ? s_stage[((size_t)wv * 2 + 0) * stride + node + 1] : -INFINITY;
         const float dnB = (node < M) ? s_stage[((size_t)wv * 2 + 1) * stride + node + 1] : -INFINITY;
         const float inA = (c == C - 1) ? ivNextA : ivA[c + 1], inB = (c == C - 1) ? ivNextB : ivB[c + 1];
@@ -692,7 +729,12 @@ __global__ __launch_bounds__(1024) void fs3_bwd_chain_half_kernel(SeqView dna, F
   const int ll = 31 - hl;                                       // nodes in descending order: the lane holding the next nodes is the physical lane below
 #define LS(a, b) flogsum<false>((a), (b), s_tbl)
   auto shr1 = [&](float v) { const float r = wave_shr1(v, -INFINITY); return hl == 0 ? -INFINITY : r; };   // the neighbour move stays inside the half wave
-  for (int bb = blockIdx.x; bb < nb; bb += gridDim.x) {
+  int *s_ctl = reinterpret_cast<int *>(s_e + 2 * W);
+  for (;;) {                                                    // batches dealt longest first, on request (see fs3_fwd_chain_half_kernel)
+    if (threadIdx.x == 0) s_ctl[0] = (int)atomicAdd(jobs.counter, 1u);
+    __syncthreads();
+    const int bb = s_ctl[0];
+    if (bb >= nb) break;
     const int64_t base = bstart[bb];
     const int cnt = bstart[bb + 1] - bstart[bb];                // windows of this batch (<= 32)
     const int64_t job = (win < cnt) ? (int64_t)jobs.order[base + win] : (int64_t)-1;
@@ -1020,10 +1062,10 @@ static int chain_batches(bath_hip_ctx *ctx, hipStream_t stream, const bath_hip_s
   return ctx->stage_upload(stage_slot, buf.p, bst.data(), bst.size(), stream);   // through page-locked staging: the host does not wait for what the stream already holds
 }
 
-static int chain_waves(bath_hip_ctx *ctx, int64_t n, int M, int C, size_t *shmem_out, int cu_share = 1) {
+static int chain_waves(bath_hip_ctx *ctx, int64_t n, int M, int C, size_t *shmem_out, int cu_share = 1, int threads = 0, int trans_floats = 0) {
   // as many windows per block as LDS holds next to the table and the transitions ...
-  const size_t fixed = (size_t)(kLogsumTbl + (M + 2) * 8 + 2 * kChainMaxWaves + 16) * sizeof(float);
-  int W = chain_threads(C) / 64;
+  const size_t fixed = (size_t)(kLogsumTbl + (trans_floats ? trans_floats : (M + 2) * 8) + 2 * kChainMaxWaves + 16) * sizeof(float);
+  int W = (threads ? threads : chain_threads(C)) / 64;
   while (W > 1 && fixed + (size_t)W * 2 * fs_chain_stride(C) * sizeof(float) > 160 * 1024) W >>= 1;
   // ... but no more than it takes to give every block a CU of its own: the waves of a block go through the parallel part of a
   // row one after the other on the CU's four SIMDs, which is time on top of the chain's, so with few windows (the regions: a
@@ -1121,7 +1163,7 @@ int launch_fs3_bwd_chain(bath_hip_ctx *ctx, hipStream_t stream, const bath_hip_f
       return BATH_OK;
     }
   }
-  const int W = chain_waves(ctx, dna->n, M, Cv, &shmem);
+  const int W = chain_waves(ctx, dna->n, M, Cv, &shmem, 1, bwd_chain_threads(Cv), chain_compact(Cv) ? (M + 3) * 4 : 0);
   // batches by length (chain_batches); t(w) measured at M = 145 (C = 3): 25.4 us per row pair at one window, 28.5 at 16
   int nbat = 0;
   DevBuf &b_bst = ctx->scratch[48];                                // (its own buffer: Forward's launch may be running on another stream)
