@@ -860,7 +860,10 @@ __global__ __launch_bounds__(256, (C <= 3 ? BATH_FS_OA_WAVES : 1)) void fs5_deco
                                                             float *__restrict__ fwd, const int64_t *__restrict__ fwd_off, float *__restrict__ fx, const int64_t *__restrict__ x_off,
                                                             const float *__restrict__ bck, const int64_t *__restrict__ bck_off, const float *__restrict__ bx,
                                                             float *__restrict__ colsum /* [n][(M+1)*8 + 8], zeroed */, float *__restrict__ oa, float *__restrict__ oasc,
-                                                            float ej, float ec, float *__restrict__ ox, FsJobs jobs) {
+                                                            float ej, float ec, float *__restrict__ ox, FsJobs jobs,
+                                                            int store_pp /* 0: the posterior matrix is NOT written (the pipeline reads it along the trace only: fs5_trace_kernel
+                                                                            recomputes those cells from Forward, Backward and rowden) */,
+                                                            float *__restrict__ rowden /* [rows]: 1 / (row sum) of every row, at x_off / 5; or null */) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   float *s_dl = reinterpret_cast<float *>(lds);                 // [(M+2)][8] TSCDELTA, same order as tf
   for (int i = threadIdx.x; i < (M + 2) * 8; i += blockDim.x) s_dl[i] = (tf[i] == -INFINITY) ? 1.17549435e-38f : 1.0f;
@@ -882,7 +885,8 @@ __global__ __launch_bounds__(256, (C <= 3 ? BATH_FS_OA_WAVES : 1)) void fs5_deco
     // Forward special states of rows i, i-1, i-2, i-3 (read before their rows are overwritten with posteriors)
     float N0 = X[1], J0 = X[2], C0 = X[4], N1 = 0, N2 = 0, N3 = 0, J1 = 0, J2 = 0, J3 = 0, C1 = 0, C2 = 0, C3 = 0;
     // row 0: posteriors 0, OA cells -inf
-    for (int k = lane; k < (M + 1) * 8; k += 64) F[k] = 0.f;
+    float *RD = rowden ? rowden + x_off[job] / 5 : nullptr;
+    if (store_pp) for (int k = lane; k < (M + 1) * 8; k += 64) F[k] = 0.f;
     for (int k = lane; k <= M; k += 64) { O[(size_t)k * 3] = O[(size_t)k * 3 + 1] = O[(size_t)k * 3 + 2] = -INFINITY; }
     if (lane < 5) X[lane] = 0.f;
     if (OX && lane == 0) { OX[0] = -INFINITY; OX[1] = 0.f; OX[2] = -INFINITY; OX[3] = 0.f; OX[4] = -INFINITY; }
@@ -959,8 +963,11 @@ __global__ __launch_bounds__(256, (C <= 3 ? BATH_FS_OA_WAVES : 1)) void fs5_deco
       denom = (float)(1.0 / (double)denom);
       pn *= denom; pc *= denom; pj *= denom;
       if (lane == 0) {
+        if (store_pp) {
 #pragma unroll
-        for (int q = 0; q < 8; q++) fr[q] = 0.f;
+          for (int q = 0; q < 8; q++) fr[q] = 0.f;
+        }
+        if (RD) RD[i] = denom;
         X[i * 5 + 0] = 0.f; X[i * 5 + 3] = 0.f; X[i * 5 + 1] = pn; X[i * 5 + 4] = pc; X[i * 5 + 2] = pj;
         orow[0] = orow[1] = orow[2] = -INFINITY;
       }
@@ -972,8 +979,10 @@ __global__ __launch_bounds__(256, (C <= 3 ? BATH_FS_OA_WAVES : 1)) void fs5_deco
         pI[c] *= denom;
 #pragma unroll
         for (int q = 0; q < 6; q++) pC[c][q] *= denom;
-        *reinterpret_cast<float4 *>(fr + (size_t)node * 8) = make_float4(0.f, pI[c], pC[c][0], pC[c][1]);
-        *reinterpret_cast<float4 *>(fr + (size_t)node * 8 + 4) = make_float4(pC[c][2], pC[c][3], pC[c][4], pC[c][5]);
+        if (store_pp) {
+          *reinterpret_cast<float4 *>(fr + (size_t)node * 8) = make_float4(0.f, pI[c], pC[c][0], pC[c][1]);
+          *reinterpret_cast<float4 *>(fr + (size_t)node * 8 + 4) = make_float4(pC[c][2], pC[c][3], pC[c][4], pC[c][5]);
+        }
         if (REGSUM) {
           csum[c][0] += pI[c];
 #pragma unroll
@@ -1099,7 +1108,11 @@ __global__ void fs5_trace_kernel(SeqView dna, int M, int maxcodons, const float 
                                  const float *__restrict__ null2 /* [n][Kp] */, uint2 *__restrict__ tbuf, const int64_t *__restrict__ t_off, FsTraceOut *__restrict__ out,
                                  const uint8_t *__restrict__ indel_tab, const uint8_t *__restrict__ cons, uint16_t *__restrict__ steps,
                                  const float *__restrict__ amino /* rsc + maxcodons*pitch: the amino rows */, int pitch,
-                                 float *__restrict__ step_pp /* posterior of every column's state (tr->pp), parallel to steps */, int *__restrict__ col_cursor) {
+                                 float *__restrict__ step_pp /* posterior of every column's state (tr->pp), parallel to steps */, int *__restrict__ col_cursor,
+                                 const float *__restrict__ bck /* null: <pp> holds the posterior matrix.  Else <pp> is the FORWARD matrix, untouched, and the
+                                                                    posteriors the walk reads -- a match cell's five codon lengths, a column's state -- are formed here
+                                                                    exactly as the decoding kernels form them: expf(F + B - overall) * rowden(i) */,
+                                 const int64_t *__restrict__ bck_off, const float *__restrict__ bcksc, const float *__restrict__ rowden) {
   // One envelope per WAVE (kTraceSpread = 64 lanes apart): the walk is a state machine whose lanes diverge at every step (each
   // state's loads and compares run under their own exec mask, one after the other), so a wave holding 64 envelopes pays for
   // every state present among them at every step.  The chip has room for a wave per envelope: 2.77 -> 1.15 ms on the bench's
@@ -1113,6 +1126,16 @@ __global__ void fs5_trace_kernel(SeqView dna, int M, int maxcodons, const float 
   const int L = dna.len[job];
   const uint8_t *dsq = dna.data + dna.off[job] - 1;             // dsq[1..L]
   const float *P = pp + pp_off[job], *PX = px + x_off[job], *O = oa + oa_off[job], *OX = ox + x_off[job];
+  const float *BK = bck ? bck + bck_off[job] : nullptr, *RD = bck ? rowden + x_off[job] / 5 : nullptr;
+  const float overall = bck ? bcksc[job] : 0.f;
+  // posterior of cell (i, k): q = 1: the insert state, q = 2: the match state (all codon lengths), q = 3..7: codon lengths 1..5
+  auto post = [&](int i, int k, int q) -> float {
+    const float f = P[((size_t)i * (M + 1) + k) * 8 + q];
+    if (!BK) return f;
+    if (q == 1 && k >= M) return 0.f;
+    const float b = BK[((size_t)i * (M + 1) + k) * 3 + (q == 1 ? 1 : 2)];
+    return expf(f + b - overall) * RD[i];
+  };
   uint2 *T = tbuf + t_off[job];
   const int cap = (int)(t_off[job + 1] - t_off[job]);
   FsTraceOut r{0, 0, 0, 0, 0, 0, 0.f, 0, 0, 0, 0.f, 0};
@@ -1170,10 +1193,9 @@ __global__ void fs5_trace_kernel(SeqView dna, int M, int maxcodons, const float 
     }
     if (bad || cur < 0 || k < 0 || i < 0) { bad = true; break; }
     if (cur == sM) {
-      const float *cell = P + ((size_t)i * (M + 1) + k) * 8;
-      c = 1; float b = cell[3];
+      c = 1; float b = post(i, k, 3);
 #pragma unroll
-      for (int q = 1; q < 5; q++) if (cell[3 + q] > b) { b = cell[3 + q]; c = q + 1; }
+      for (int q = 1; q < 5; q++) { const float v = post(i, k, 3 + q); if (v > b) { b = v; c = q + 1; } }
     } else c = 0;
     push(cur, k, i, c);
     if ((cur == sN || cur == sC || cur == sJ) && cur == prev) i--;
@@ -1274,7 +1296,7 @@ __global__ void fs5_trace_kernel(SeqView dna, int M, int maxcodons, const float 
         prevs = s;
         if (S) S[zz - z1] = (uint16_t)code;
         // get_postprob (generic_optacc_frameshift.c:425-440): a match state's total posterior (all codon lengths), an insert state's; 0 for D
-        if (SP) SP[zz - z1] = (s == sM) ? P[((size_t)ii * (M + 1) + kk) * 8 + 2] : (s == sI ? P[((size_t)ii * (M + 1) + kk) * 8 + 1] : 0.0f);
+        if (SP) SP[zz - z1] = (s == sM) ? post(ii, kk, 2) : (s == sI ? post(ii, kk, 1) : 0.0f);
       }
       r.aliscore = ali;
     }
@@ -1807,6 +1829,16 @@ int bath::fs5_envelopes_ex(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, cons
   [[maybe_unused]] const int grid = fs_grid(ctx, n);
   if (logsum_mode == BATH_LOGSUM_CONTEXT) logsum_mode = ctx->fs_strict ? BATH_LOGSUM_TABLE_SERIAL : BATH_LOGSUM_TABLE;
   const double cells5 = (double)(foff[(size_t)n] / 8);                          // (L+1) x (M+1) cells of all envelopes
+  // The posterior matrix (32 B per cell) is written only when the caller wants it back (<pp>) or the unfused A/B kernels run: the
+  // pipeline reads posteriors along the optimal-accuracy trace only (O(L + M) cells of (L+1)(M+1)), and fs5_trace_kernel forms those
+  // from the Forward and Backward matrices -- which then stay as they are -- and the rows' normalising factors (4 B per ROW) with the
+  // decoding kernels' own arithmetic, value for value
+  static const bool unfused_env = [] { const char *e = std::getenv("BATH_HIP_FS_UNFUSED"); return e && e[0] == '1'; }();
+  static const bool always_pp = [] { const char *e = std::getenv("BATH_HIP_FS_STORE_PP"); return e && e[0] == '1'; }();          // A/B: the round-4 behaviour
+  const bool store_pp = pp != nullptr || unfused_env || always_pp;
+  DevBuf &b_rowden = ctx->scratch[37];
+  BATH_HIP_TRY(ctx, b_rowden.reserve((size_t)(xoff[(size_t)n] / 5 + 8) * sizeof(float)));
+  float *d_rowden = store_pp ? nullptr : b_rowden.as<float>();
   FsJobs jq[4];
   if ((st = fs_schedule(ctx, dna, 4, jq)) != BATH_OK) return st;
   StageGate gate(ctx->device, StageGate::kEnvelopes);                           // (BATH_HIP_FS_GATE=3: not while another worker's Forward parser has the chip)
@@ -1831,18 +1863,21 @@ int bath::fs5_envelopes_ex(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, cons
     // decoding + optimal-accuracy fill, one walk over the rows (BATH_HIP_FS_UNFUSED=1: the two separate kernels, for A/B runs)
     static const bool unfused = [] { const char *e = std::getenv("BATH_HIP_FS_UNFUSED"); return e && e[0] == '1'; }();
     int mw_nodes = 0;
+    // reads Forward 32 + Backward 12, writes OA 12 B/cell -- and the posteriors, 32 more, only when the caller asked for the matrix
+    const double oa_bytes = cells5 * (store_pp ? 88.0 : 56.0);
     if (!unfused && fs5_decode_oa_mw_shape(M, &mw_nodes) > 0) {        // long models: a block of waves per envelope (bath_fs_decode.hip)
-      const int s3 = ctx->span_begin("fs5_decode_oa_kernel", ctx->stream, cells5, cells5 * 88.0);
+      const int s3 = ctx->span_begin("fs5_decode_oa_kernel", ctx->stream, cells5, oa_bytes);
       if ((st = launch_fs5_decode_oa_mw(ctx, ctx->stream, om, dna, d_bsc, b_f.as<float>(), d_foff, b_fx.as<float>(), d_xoff, b_b.as<float>(), d_boff, b_bx.as<float>(),
-                                        b_cs.as<float>(), b_o.as<float>(), d_osc, (oax || trace) ? b_ox.as<float>() : nullptr, jq[2])) != BATH_OK) return st;
+                                        b_cs.as<float>(), b_o.as<float>(), d_osc, (oax || trace) ? b_ox.as<float>() : nullptr, jq[2], store_pp ? 1 : 0, d_rowden)) != BATH_OK) return st;
       ctx->span_end(s3, ctx->stream);
     } else if (!unfused) {
       if ((st = fs_set_shmem(ctx, fs5_decode_oa_kernel<CC>, oa_shmem)) != BATH_OK) return st;
-      const int s3 = ctx->span_begin("fs5_decode_oa_kernel", ctx->stream, cells5, cells5 * 88.0);   // reads Forward 32 + Backward 12, writes posteriors 32 + OA 12 B/cell
+      const int s3 = ctx->span_begin("fs5_decode_oa_kernel", ctx->stream, cells5, oa_bytes);
       const int oa_grid = (int)std::max<int64_t>(1, std::min<int64_t>((n + 3) / 4, (int64_t)ctx->prop.multiProcessorCount * (CC <= 3 ? BATH_FS_OA_WAVES : 1)));
       hipLaunchKernelGGL((fs5_decode_oa_kernel<CC>), dim3(oa_grid), dim3(256), oa_shmem, ctx->stream, dna->view(), M, om->d_tf, om->d_loop[1], d_bsc, b_f.as<float>(), d_foff,
                          b_fx.as<float>(), d_xoff, b_b.as<float>(), d_boff, b_bx.as<float>(), b_cs.as<float>(), b_o.as<float>(), d_osc,
-                         1.17549435e-38f /* E->J impossible in unihit mode: TSCDELTA = FLT_MIN */, 1.0f, (oax || trace) ? b_ox.as<float>() : nullptr, jq[2]);
+                         1.17549435e-38f /* E->J impossible in unihit mode: TSCDELTA = FLT_MIN */, 1.0f, (oax || trace) ? b_ox.as<float>() : nullptr, jq[2],
+                         store_pp ? 1 : 0, d_rowden);
       ctx->span_end(s3, ctx->stream);
     } else {
     const int s3 = ctx->span_begin("fs5_decode_kernel", ctx->stream, cells5, cells5 * 76.0);     // reads Forward 32 + Backward 12, rewrites 32 B/cell
@@ -1882,7 +1917,8 @@ int bath::fs5_envelopes_ex(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, cons
     hipLaunchKernelGGL(fs5_trace_kernel, dim3((unsigned)((n * kTraceSpread + 63) / 64)), dim3(64), 0, ctx->stream, dna->view(), M, om->maxcodons, om->d_tf, om->d_codons,
                        b_f.as<float>(), d_foff, b_fx.as<float>(), d_xoff, b_o.as<float>(), d_boff, b_ox.as<float>(), b_n2.as<float>(), b_tb.as<uint2>(), d_toff,
                        b_to.as<FsTraceOut>(), om->d_indel, cons, d_steps,
-                       om->d_rsc + (size_t)om->maxcodons * om->pitch, om->pitch, step_pp ? d_step_pp : nullptr, d_cursor);
+                       om->d_rsc + (size_t)om->maxcodons * om->pitch, om->pitch, step_pp ? d_step_pp : nullptr, d_cursor,
+                       store_pp ? nullptr : b_b.as<float>(), d_boff, d_bsc, d_rowden);
     ctx->span_end(s6, ctx->stream);
     BATH_HIP_TRY(ctx, hipGetLastError());
     BATH_HIP_TRY(ctx, hipMemcpyAsync(trace, b_to.p, (size_t)n * sizeof(FsTraceOut), hipMemcpyDeviceToHost, ctx->stream));

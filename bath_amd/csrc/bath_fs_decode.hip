@@ -45,7 +45,8 @@ __global__ __launch_bounds__(64 * kOaMaxWaves) void fs5_decode_oa_mw_kernel(SeqV
                                                                             float *__restrict__ fwd, const int64_t *__restrict__ fwd_off, float *__restrict__ fx, const int64_t *__restrict__ x_off,
                                                                             const float *__restrict__ bck, const int64_t *__restrict__ bck_off, const float *__restrict__ bx,
                                                                             float *__restrict__ colsum /* [n][(M+1)*8 + 8] */, float *__restrict__ oa, float *__restrict__ oasc,
-                                                                            float ej, float ec, float *__restrict__ ox, FsJobs jobs) {
+                                                                            float ej, float ec, float *__restrict__ ox, FsJobs jobs,
+                                                                            int store_pp /* 0: no posterior matrix, see fs5_decode_oa_kernel */, float *__restrict__ rowden) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   float *s_dl = reinterpret_cast<float *>(lds);                 // [(M+2)][8] TSCDELTA, same order as tf
   float *s_pub = s_dl + (size_t)(M + 2) * 8;                    // [2][kOaMaxWaves][8]: {A', B', a_last, b_last, den, wmax, M_last, I_last}
@@ -76,10 +77,10 @@ __global__ __launch_bounds__(64 * kOaMaxWaves) void fs5_decode_oa_mw_kernel(SeqV
     float N0 = 0.f, J0 = 0.f, C0 = 0.f, N1 = 0.f, N2 = 0.f, N3 = 0.f, J1 = 0.f, J2 = 0.f, J3 = 0.f, C1 = 0.f, C2 = 0.f, C3 = 0.f;
     if (wv == 0) { N0 = X[1]; J0 = X[2]; C0 = X[4]; }
     // row 0: posteriors 0, OA cells -inf
-    for (int k = threadIdx.x + 8; k < (M + 1) * 8; k += blockDim.x) F[k] = 0.f;          // (node 0 of row 0 below, after wave 0 has read the row's special states)
+    if (store_pp) for (int k = threadIdx.x + 8; k < (M + 1) * 8; k += blockDim.x) F[k] = 0.f;          // (node 0 of row 0 below, after wave 0 has read the row's special states)
     for (int k = threadIdx.x; k <= M; k += blockDim.x) { O[(size_t)k * 3] = O[(size_t)k * 3 + 1] = O[(size_t)k * 3 + 2] = -INFINITY; }
     if (wv == 0) {
-      if (lane < 8) F[lane] = 0.f;
+      if (store_pp && lane < 8) F[lane] = 0.f;
       if (lane < 5) X[lane] = 0.f;
       if (OX && lane == 0) { OX[0] = -INFINITY; OX[1] = 0.f; OX[2] = -INFINITY; OX[3] = 0.f; OX[4] = -INFINITY; }
     }
@@ -167,8 +168,11 @@ __global__ __launch_bounds__(64 * kOaMaxWaves) void fs5_decode_oa_mw_kernel(SeqV
       denom = (float)(1.0 / (double)denom);
       pn *= denom; pc *= denom; pj *= denom;
       if (wv == 0 && lane == 0) {
+        if (store_pp) {
 #pragma unroll
-        for (int q = 0; q < 8; q++) fr[q] = 0.f;
+          for (int q = 0; q < 8; q++) fr[q] = 0.f;
+        }
+        if (rowden) rowden[x_off[job] / 5 + i] = denom;
         X[i * 5 + 0] = 0.f; X[i * 5 + 3] = 0.f; X[i * 5 + 1] = pn; X[i * 5 + 4] = pc; X[i * 5 + 2] = pj;
         orow[0] = orow[1] = orow[2] = -INFINITY;
       }
@@ -181,8 +185,10 @@ __global__ __launch_bounds__(64 * kOaMaxWaves) void fs5_decode_oa_mw_kernel(SeqV
 #pragma unroll
         for (int q = 0; q < 6; q++) pC[c][q] = eC[c][q] * denom;
         if (node > M) continue;
-        *reinterpret_cast<float4 *>(fr + (size_t)node * 8) = make_float4(0.f, pI[c], pC[c][0], pC[c][1]);
-        *reinterpret_cast<float4 *>(fr + (size_t)node * 8 + 4) = make_float4(pC[c][2], pC[c][3], pC[c][4], pC[c][5]);
+        if (store_pp) {
+          *reinterpret_cast<float4 *>(fr + (size_t)node * 8) = make_float4(0.f, pI[c], pC[c][0], pC[c][1]);
+          *reinterpret_cast<float4 *>(fr + (size_t)node * 8 + 4) = make_float4(pC[c][2], pC[c][3], pC[c][4], pC[c][5]);
+        }
         csum[c][0] += pI[c];
 #pragma unroll
         for (int q = 0; q < 6; q++) csum[c][1 + q] += pC[c][q];
@@ -328,7 +334,7 @@ int fs5_decode_oa_mw_shape(int M, int *nodes_per_lane) {
 
 int launch_fs5_decode_oa_mw(bath_hip_ctx *ctx, hipStream_t stream, const bath_hip_fsprofile *om, const bath_hip_seqs *dna, const float *d_bsc,
                             float *d_fwd, const int64_t *d_foff, float *d_fx, const int64_t *d_xoff, const float *d_bck, const int64_t *d_boff, const float *d_bx,
-                            float *d_colsum, float *d_oa, float *d_osc, float *d_ox, FsJobs jobs) {
+                            float *d_colsum, float *d_oa, float *d_osc, float *d_ox, FsJobs jobs, int store_pp, float *d_rowden) {
   int C = 0;
   const int W = fs5_decode_oa_mw_shape(om->M, &C);
   if (W <= 0) { ctx->set_error("multi-wave optimal-accuracy kernel: no shape for this model"); return BATH_EINVAL; }
@@ -342,7 +348,7 @@ int launch_fs5_decode_oa_mw(bath_hip_ctx *ctx, hipStream_t stream, const bath_hi
   {                                                                                                                                 \
     if (shmem > 64 * 1024) BATH_HIP_TRY(ctx, bath::allow_max_lds((const void *)fs5_decode_oa_mw_kernel<CC>)); \
     hipLaunchKernelGGL((fs5_decode_oa_mw_kernel<CC>), dim3(grid), dim3(64 * W), shmem, stream, dna->view(), M, om->d_tf, om->d_loop[1], d_bsc, d_fwd, d_foff, d_fx, d_xoff,      \
-                       d_bck, d_boff, d_bx, d_colsum, d_oa, d_osc, 1.17549435e-38f /* E->J impossible in unihit mode: TSCDELTA = FLT_MIN */, 1.0f, d_ox, jobs);                  \
+                       d_bck, d_boff, d_bx, d_colsum, d_oa, d_osc, 1.17549435e-38f /* E->J impossible in unihit mode: TSCDELTA = FLT_MIN */, 1.0f, d_ox, jobs, store_pp, d_rowden); \
   }
   if (C == 2) BATH_OA_MW(2) else BATH_OA_MW(3)
 #undef BATH_OA_MW

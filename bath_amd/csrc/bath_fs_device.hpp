@@ -153,7 +153,7 @@ int launch_fs5_bwd_wf(bath_hip_ctx *ctx, hipStream_t stream, const bath_hip_fspr
 int fs5_decode_oa_mw_shape(int M, int *nodes_per_lane);     // waves per envelope (0: the one-wave kernel of bath_frameshift.hip)
 int launch_fs5_decode_oa_mw(bath_hip_ctx *ctx, hipStream_t stream, const bath_hip_fsprofile *om, const bath_hip_seqs *dna, const float *d_bsc,
                             float *d_fwd, const int64_t *d_foff, float *d_fx, const int64_t *d_xoff, const float *d_bck, const int64_t *d_boff, const float *d_bx,
-                            float *d_colsum, float *d_oa, float *d_osc, float *d_ox, FsJobs jobs);
+                            float *d_colsum, float *d_oa, float *d_osc, float *d_ox, FsJobs jobs, int store_pp = 1, float *d_rowden = nullptr);
 
 // ---- multihit recursions in the reference's serial order, chains batched per block (bath_fs_chain.hip)
 int launch_fs3_fwd_chain(bath_hip_ctx *ctx, hipStream_t stream, const bath_hip_fsprofile *om, const bath_hip_seqs *dna, int Cv, float tEL, float tEM,
