@@ -743,6 +743,7 @@ struct StdEnvOut { int32_t i1, k1, i2, k2, ok; float oasc, domcorrection; int32_
 // p7_Decoding + p7_OptimalAccuracy + p7_OATrace + p7_Null2_ByExpectation on one envelope per lane (unihit model).
 // fwd / bck: (L+1) x (M+1) x {M, D, I}; on return bck holds the posteriors and fwd the OA matrix, as in the reference.
 constexpr int kStdTraceSpread = 64;
+constexpr size_t kStdFillSlack = 64 * 16 * 3 * sizeof(float);    // std_envelope_fill_kernel reads the cells of all 64 x C node slots of a row, also past node M
 __global__ void std_envelope_kernel(SeqView sq, int M, const float *__restrict__ tf, const float *__restrict__ rf, float *__restrict__ fwd, float *__restrict__ bck,
                                     const int64_t *__restrict__ dp_off, const float *__restrict__ fx, const float *__restrict__ bx, const int64_t *__restrict__ x_off,
                                     float *__restrict__ ppx_all, float *__restrict__ oax_all, float *__restrict__ em_all /* [n][2*(M+1)] */, StdEnvOut *__restrict__ out,
@@ -989,8 +990,31 @@ __global__ __launch_bounds__(256) void std_envelope_fill_kernel(SeqView sq, int 
   const int lane = threadIdx.x & 63;
   const int64_t wid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  auto allow = [](float tr, float v) { return tr > 0.0f ? v : 0.0f; };
-  for (int64_t t = wid; t < sq.n; t += nw) {
+  // What the row loop needs per node, in registers, so that it has no branch per node (a wave alone on its SIMD issues an
+  // instruction every five cycles or so: with a branch, two compares and two selects per allow() the row of a 459-node model took
+  // 1300 instructions, 3.6 us): the transitions as all-ones / zero masks (allow(tr, v) = v AND mask: exact, v or +0.0), and for
+  // the nodes beyond M limits that turn what is computed for them into the values the guarded code left there (min(x, -inf)).
+  auto band = [](float v, unsigned m) { return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v) & m); };
+  auto vmax = [](float x, float y) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; };      // (no operand is ever NaN: see bath_fs_device.hpp)
+  auto vmin = [](float x, float y) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; };
+  unsigned kBM[C], kMM[C], kIM[C], kDM[C], kMD[C], kDD[C], kMI[C], kII[C], vm[C];
+  float lim[C], npz[C], plim[C];
+  const bool full = lane * C + C <= M, partial = !full && lane * C + 1 <= M;
+#pragma unroll
+  for (int c = 0; c < C; c++) {
+    const int node = lane * C + c + 1;
+    const bool ok = node <= M;
+    const float *tq = tf + (size_t)min(node, M) * 8;
+    auto mk = [&](int q) { return (ok && tq[q] > 0.0f) ? 0xffffffffu : 0u; };
+    kMM[c] = mk(MM); kIM[c] = mk(IM); kDM[c] = mk(DM); kBM[c] = mk(BM); kMD[c] = mk(MD); kDD[c] = mk(DD); kMI[c] = mk(MI); kII[c] = mk(II);
+    vm[c] = ok ? 0xffffffffu : 0u;
+    lim[c] = ok ? INFINITY : -INFINITY;
+    const bool pass = !ok || tq[DD] > 0.0f;                                 // a node that is not there: the identity of the D chain
+    npz[c] = pass ? -INFINITY : 0.0f;
+    plim[c] = pass ? INFINITY : -INFINITY;
+  }
+  for (int64_t t0 = wid; t0 < sq.n; t0 += nw) {
+    const int64_t t = __builtin_amdgcn_readfirstlane((int)t0);              // (the wave's envelope: uniform, so that its pointers are scalars)
     const int L = sq.len[t];
     const uint8_t *dsq = sq.data + sq.off[t] - 1;
     const size_t W = (size_t)(M + 1) * 3;
@@ -999,13 +1023,6 @@ __global__ __launch_bounds__(256) void std_envelope_fill_kernel(SeqView sq, int 
     const float *FX = fx + x_off[t], *BX = bx + x_off[t];
     float *PX = ppx_all + (x_off[t] / 6) * 5, *OX = oax_all + (x_off[t] / 6) * 5;
     const float ploop = 1.0f - 2.0f / ((float)L + 2.0f);
-    float tr[C][8];
-#pragma unroll
-    for (int c = 0; c < C; c++) {
-      const int node = lane * C + c + 1;
-#pragma unroll
-      for (int q = 0; q < 8; q++) tr[c][q] = node <= M ? tf[(size_t)node * 8 + q] : 0.f;
-    }
     float pvM[C], pvI[C], pvD[C], emM[C], emI[C];
 #pragma unroll
     for (int c = 0; c < C; c++) { pvM[c] = pvI[c] = pvD[c] = -INFINITY; emM[c] = emI[c] = 0.f; }
@@ -1016,8 +1033,35 @@ __global__ __launch_bounds__(256) void std_envelope_fill_kernel(SeqView sq, int 
       for (int q = 0; q < 5; q++) PX[q] = 0.f;
       OX[XE] = -INFINITY; OX[XN] = 0.f; OX[XJ] = -INFINITY; OX[XB] = 0.f; OX[XC] = -INFINITY;
     }
+    // Nothing in a row waits for memory: the Forward and Backward cells of row i + 1 are fetched while row i is worked on, and the
+    // special states arrive 64 rows at a time, a lane each (lane l of a chunk: Forward's N, J, C of row r - 1 and its scale factor of
+    // row r, Backward's N, J, C and scale factor of row r), the next 64 in flight.
+    // (a lane reads its C nodes' cells whether they exist or not -- the buffers end in slack for that -- and masks what it read)
+    float fM[C], fI[C], bM[C], bI[C];
+    const size_t lane0 = (size_t)(lane * C + 1) * 3;
+    auto fetch_row = [&](int r) {
+      const float *fq = F + (size_t)r * W + lane0, *bq = Bk + (size_t)r * W + lane0;
+#pragma unroll
+      for (int c = 0; c < C; c++) { fM[c] = fq[3 * c + cM]; fI[c] = fq[3 * c + cI]; bM[c] = bq[3 * c + cM]; bI[c] = bq[3 * c + cI]; }
+    };
+    float xb[8], xn[8];
+    auto fetch_x = [&](int r0, float (&v)[8]) {                             // rows r0 .. r0 + 63, a lane each
+      const int r = min(r0 + lane, L);
+      v[0] = FX[(size_t)(r - 1) * 6 + XN]; v[1] = FX[(size_t)(r - 1) * 6 + XJ]; v[2] = FX[(size_t)(r - 1) * 6 + XC]; v[3] = FX[(size_t)r * 6 + XS];
+      v[4] = BX[(size_t)r * 6 + XN]; v[5] = BX[(size_t)r * 6 + XJ]; v[6] = BX[(size_t)r * 6 + XC]; v[7] = BX[(size_t)r * 6 + XS];
+    };
+    if (L >= 1) { fetch_row(1); fetch_x(1, xb); }
     for (int i = 1; i <= L; i++) {
-      const float totr = scaleproduct * FX[(size_t)i * 6 + XS];
+      const int j = (i - 1) & 63;
+      if (j == 0 && i + 64 <= L) fetch_x(i + 64, xn);
+      float xv[8];
+#pragma unroll
+      for (int q = 0; q < 8; q++) xv[q] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xb[q]), j));
+      if (j == 63) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) xb[q] = xn[q];
+      }
+      const float totr = scaleproduct * xv[3];
       float *frow = F + (size_t)i * W;
       float *brow = Bk + (size_t)i * W;
       // posteriors of this row (p7_Decoding), special states included; they replace the Backward row as in the reference
@@ -1025,42 +1069,36 @@ __global__ __launch_bounds__(256) void std_envelope_fill_kernel(SeqView sq, int 
       float pM[C], pI[C];
 #pragma unroll
       for (int c = 0; c < C; c++) {
-        const int node = lane * C + c + 1;
-        if (node <= M) {
-          pM[c] = frow[(size_t)node * 3 + cM] * (brow[(size_t)node * 3 + cM] * totr);
-          pI[c] = frow[(size_t)node * 3 + cI] * (brow[(size_t)node * 3 + cI] * totr);
-          brow[(size_t)node * 3 + cM] = pM[c]; brow[(size_t)node * 3 + cI] = pI[c]; brow[(size_t)node * 3 + cD] = 0.0f;
-        } else pM[c] = pI[c] = 0.f;
+        pM[c] = band(fM[c] * (bM[c] * totr), vm[c]);
+        pI[c] = band(fI[c] * (bI[c] * totr), vm[c]);
         if (i == 1) { emM[c] = pM[c]; emI[c] = pI[c]; } else { emM[c] = pM[c] + emM[c]; emI[c] = pI[c] + emI[c]; }
       }
-      const float pxN = FX[(size_t)(i - 1) * 6 + XN] * BX[(size_t)i * 6 + XN] * ploop * scaleproduct;
-      const float pxJ = FX[(size_t)(i - 1) * 6 + XJ] * BX[(size_t)i * 6 + XJ] * ploop * scaleproduct;
-      const float pxC = FX[(size_t)(i - 1) * 6 + XC] * BX[(size_t)i * 6 + XC] * ploop * scaleproduct;
+      if (i < L) fetch_row(i + 1);                                          // in flight during the optimal-accuracy part of this row
+      const float pxN = xv[0] * xv[4] * ploop * scaleproduct;
+      const float pxJ = xv[1] * xv[5] * ploop * scaleproduct;
+      const float pxC = xv[2] * xv[6] * ploop * scaleproduct;
       if (i == 1) { sN = pxN; sC = pxC; sJ = pxJ; } else { sN += pxN; sC += pxC; sJ += pxJ; }
-      scaleproduct *= FX[(size_t)i * 6 + XS] / BX[(size_t)i * 6 + XS];
+      scaleproduct *= xv[3] / xv[7];
       // optimal-accuracy row (p7_OptimalAccuracy)
       const float mIn = wave_shr1_f32(pvM[C - 1], -INFINITY), iIn = wave_shr1_f32(pvI[C - 1], -INFINITY), dIn = wave_shr1_f32(pvD[C - 1], -INFINITY);
       float cuM[C], cuI[C], cuD[C];
-      float fc = -INFINITY; bool fpass = true;                              // the lane's composite D-chain function
+      float fc = -INFINITY; unsigned fpass = 0xffffffffu;                   // the lane's composite D-chain function
       float xE = -INFINITY;
 #pragma unroll
       for (int c = 0; c < C; c++) {
-        const int node = lane * C + c + 1;
-        if (node <= M) {
-          const float m1 = c == 0 ? mIn : pvM[c - 1], i1 = c == 0 ? iIn : pvI[c - 1], d1 = c == 0 ? dIn : pvD[c - 1];
-          float sv = allow(tr[c][BM], oxB);
-          sv = fmaxf(sv, allow(tr[c][MM], m1));
-          sv = fmaxf(sv, allow(tr[c][IM], i1));
-          sv = fmaxf(sv, allow(tr[c][DM], d1));
-          sv = sv + pM[c];
-          cuM[c] = sv;
-          xE = fmaxf(xE, sv);
-          cuI[c] = fmaxf(allow(tr[c][MI], pvM[c]), allow(tr[c][II], pvI[c])) + pI[c];
-          const float cst = allow(tr[c][MD], sv);                           // f_node(x) = max(cst, DD ? x : 0)
-          const bool pass = tr[c][DD] > 0.0f;
-          const float g = pass ? cst : fmaxf(cst, 0.0f);
-          if (pass) fc = fmaxf(g, fc); else { fc = g; fpass = false; }      // f_node o (what the lane has so far)
-        } else { cuM[c] = cuI[c] = -INFINITY; }
+        const float m1 = c == 0 ? mIn : pvM[c - 1], i1 = c == 0 ? iIn : pvI[c - 1], d1 = c == 0 ? dIn : pvD[c - 1];
+        float sv = band(oxB, kBM[c]);
+        sv = vmax(sv, band(m1, kMM[c]));
+        sv = vmax(sv, band(i1, kIM[c]));
+        sv = vmax(sv, band(d1, kDM[c]));
+        sv = vmin(sv + pM[c], lim[c]);                                      // (a node beyond M: -inf)
+        cuM[c] = sv;
+        xE = vmax(xE, sv);
+        cuI[c] = vmin(vmax(band(pvM[c], kMI[c]), band(pvI[c], kII[c])) + pI[c], lim[c]);
+        const float cst = vmin(band(sv, kMD[c]), lim[c]);                   // f_node(x) = max(cst, DD ? x : 0); beyond M: the identity (cst = -inf, pass)
+        const float g = vmax(cst, npz[c]);                                  // pass ? cst : max(cst, 0)
+        fc = vmax(g, vmin(fc, plim[c]));                                    // pass ? max(g, fc) : g -- f_node o (what the lane has so far)
+        fpass &= kDD[c] | ~vm[c];
       }
       // inclusive scan of the lanes' functions, then the value entering each lane: D(first node of the lane)
       // by DPP; lanes without a source see the identity function (c = -inf, pass): max and select only, any scan order gives the same
@@ -1073,14 +1111,28 @@ __global__ __launch_bounds__(256) void std_envelope_fill_kernel(SeqView sq, int 
       float din = wave_shr1_f32(sc_c, -INFINITY);                           // prefix over lanes 0..lane-1 applied to D(1) = -inf
 #pragma unroll
       for (int c = 0; c < C; c++) {
-        const int node = lane * C + c + 1;
-        if (node <= M) {
-          cuD[c] = din;
-          xE = fmaxf(xE, din);
-          din = fmaxf(allow(tr[c][MD], cuM[c]), allow(tr[c][DD], din));
-          frow[(size_t)node * 3 + cM] = cuM[c]; frow[(size_t)node * 3 + cD] = cuD[c]; frow[(size_t)node * 3 + cI] = cuI[c];
-        } else cuD[c] = -INFINITY;
+        cuD[c] = vmin(din, lim[c]);
+        xE = vmax(xE, cuD[c]);
+        din = vmax(band(cuM[c], kMD[c]), band(din, kDD[c]));
         pvM[c] = cuM[c]; pvI[c] = cuI[c]; pvD[c] = cuD[c];
+      }
+      // the row's posteriors over Backward's, its OA cells over Forward's: a lane whose C nodes all exist stores them without a test
+      if (full) {
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+          float *bq = brow + (size_t)(lane * C + 1) * 3 + 3 * c, *fq = frow + (size_t)(lane * C + 1) * 3 + 3 * c;
+          bq[cM] = pM[c]; bq[cD] = 0.0f; bq[cI] = pI[c];
+          fq[cM] = cuM[c]; fq[cD] = cuD[c]; fq[cI] = cuI[c];
+        }
+      } else if (partial) {
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+          const int node = lane * C + c + 1;
+          if (node <= M) {
+            brow[(size_t)node * 3 + cM] = pM[c]; brow[(size_t)node * 3 + cI] = pI[c]; brow[(size_t)node * 3 + cD] = 0.0f;
+            frow[(size_t)node * 3 + cM] = cuM[c]; frow[(size_t)node * 3 + cD] = cuD[c]; frow[(size_t)node * 3 + cI] = cuI[c];
+          }
+        }
       }
       xE = wave_max_f32(xE);
       oxJ = fmaxf(oxJ + pxJ, 0.0f);
@@ -1286,7 +1338,7 @@ static int std_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bat
   if ((st = upload_view(ev, exoff, ne)) != BATH_OK) return st;
   const int64_t *d_exoff = b_idx.as<int64_t>() + ne;
   DevBuf &b_f = ctx->scratch[15], &b_b = ctx->scratch[16], &b_dpo = ctx->scratch[20], &b_px = ctx->scratch[18], &b_ox = ctx->scratch[19], &b_em = ctx->scratch[22], &b_out = ctx->scratch[21];
-  BATH_HIP_TRY(ctx, b_f.reserve((size_t)dpoff[(size_t)ne] * 4 + 64)); BATH_HIP_TRY(ctx, b_b.reserve((size_t)dpoff[(size_t)ne] * 4 + 64));
+  BATH_HIP_TRY(ctx, b_f.reserve((size_t)dpoff[(size_t)ne] * 4 + 64 + kStdFillSlack)); BATH_HIP_TRY(ctx, b_b.reserve((size_t)dpoff[(size_t)ne] * 4 + 64 + kStdFillSlack));
   BATH_HIP_TRY(ctx, b_dpo.reserve((size_t)(ne + 1) * 8)); BATH_HIP_TRY(ctx, b_fx.reserve((size_t)exoff[(size_t)ne] * 4 + 64)); BATH_HIP_TRY(ctx, b_bx.reserve((size_t)exoff[(size_t)ne] * 4 + 64));
   BATH_HIP_TRY(ctx, b_px.reserve((size_t)exoff[(size_t)ne] / 6 * 5 * 4 + 64)); BATH_HIP_TRY(ctx, b_ox.reserve((size_t)exoff[(size_t)ne] / 6 * 5 * 4 + 64));
   BATH_HIP_TRY(ctx, b_em.reserve((size_t)ne * 2 * (M + 1) * 4 + 64)); BATH_HIP_TRY(ctx, b_out.reserve((size_t)ne * sizeof(StdEnvOut) + 64));
@@ -1505,7 +1557,7 @@ extern "C" int bath_hip_std_envelopes(bath_hip_ctx *ctx, const bath_hip_oprofile
   DevBuf &b_f = ctx->scratch[15], &b_b = ctx->scratch[16], &b_off = ctx->scratch[20], &b_fx = ctx->scratch[6], &b_bx = ctx->scratch[7], &b_px = ctx->scratch[18],
          &b_ox = ctx->scratch[19], &b_em = ctx->scratch[22], &b_out = ctx->scratch[21], &b_tb = ctx->scratch[10], &b_sc = ctx->scratch[2], &b_n2 = ctx->scratch[23];
   const size_t nx = (size_t)o.x[(size_t)n], ndp = (size_t)o.dp[(size_t)n];
-  BATH_HIP_TRY(ctx, b_f.reserve(ndp * 4 + 64)); BATH_HIP_TRY(ctx, b_b.reserve(ndp * 4 + 64));
+  BATH_HIP_TRY(ctx, b_f.reserve(ndp * 4 + 64 + kStdFillSlack)); BATH_HIP_TRY(ctx, b_b.reserve(ndp * 4 + 64 + kStdFillSlack));
   BATH_HIP_TRY(ctx, b_fx.reserve(nx * 4 + 64)); BATH_HIP_TRY(ctx, b_bx.reserve(nx * 4 + 64));
   BATH_HIP_TRY(ctx, b_px.reserve(nx / 6 * 5 * 4 + 64)); BATH_HIP_TRY(ctx, b_ox.reserve(nx / 6 * 5 * 4 + 64));
   BATH_HIP_TRY(ctx, b_em.reserve((size_t)n * 2 * (M + 1) * 4 + 64)); BATH_HIP_TRY(ctx, b_out.reserve((size_t)n * sizeof(StdEnvOut) + 64));

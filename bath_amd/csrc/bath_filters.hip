@@ -117,8 +117,13 @@ __global__ __launch_bounds__(256) void msv_wave_kernel(SeqView sq, int M, const 
     int xJ = 0;
     int xB = satu8(c.base - tjbm);
     bool overflow = false;
+    const int ph = threadIdx.x & 63;
+    int rbuf = (ph < L) ? (int)s[ph] : 0, rnext = 0;          // residues 64 rows at a time, a lane each, the next 64 in flight (see fwd_wave_kernel)
     for (int i = 0; i < L; i++) {
-      const int x = min((int)s[i], kKp - 1);
+      const int j = i & 63;
+      if (j == 0) { const int q = i + 64 + ph; rnext = (q < L) ? (int)s[q] : 0; }
+      const int x = min(__builtin_amdgcn_readlane(rbuf, j), kKp - 1);
+      if (j == 63) rbuf = rnext;
       const uint8_t *row = rb + (size_t)x * rb_stride;
       int prev = wave_shr1_i32(dp[C - 1], 0);
       int xE = 0;
@@ -210,8 +215,13 @@ __global__ __launch_bounds__(256) void vit_wave_kernel(SeqView sq, int M, const 
     int xJ = -32768, xC = -32768, xE = -32768;
     bool overflow = false;
 
+    const int ph = threadIdx.x & 63;
+    int rbuf = (ph < L) ? (int)s[ph] : 0, rnext = 0;          // residues 64 rows at a time, a lane each, the next 64 in flight (see fwd_wave_kernel)
     for (int i = 1; i <= L; i++) {
-      const int x = min((int)s[i - 1], kKp - 1);
+      const int j = (i - 1) & 63;
+      if (j == 0) { const int q = i - 1 + 64 + ph; rnext = (q < L) ? (int)s[q] : 0; }
+      const int x = min(__builtin_amdgcn_readlane(rbuf, j), kKp - 1);
+      if (j == 63) rbuf = rnext;
       const int16_t *rw = s_rw + (size_t)x * (M + 1);
       const int mIn = wave_shr1_i32(Mp[C - 1], -32768), iIn = wave_shr1_i32(Ip[C - 1], -32768), dIn = wave_shr1_i32(Dp[C - 1], -32768);
       int Mc[C], Ic[C], dcv[C], tdd[C];
@@ -311,6 +321,31 @@ __global__ __launch_bounds__(256) void vit_wave_kernel(SeqView sq, int M, const 
 // ============================================================================================
 struct FwdConsts { float xfE_loop, xfE_move; };
 
+// Emission rows of the wave-per-target Forward / Backward kernels in LDS: [Kp][S] floats, entry node - 1 (S a multiple of 4, 64 C
+// zeros behind the last row), so that a lane's C consecutive nodes are one or two 16-byte reads at 16-byte-aligned addresses that
+// follow the previous lane's: no bank conflicts.  (Indexed by node with a read per node, the lanes of a wave were C x 4 bytes apart:
+// an 8-way conflict at C = 8 -- and the transitions, 32 bytes per node read as two float4, 64-way: they are in registers now.)
+__host__ __device__ constexpr int wave_em_stride(int M) { return (M + 4) & ~3; }          // >= M + 1: entry M is the zero column of node M + 1
+template <int C>
+__device__ __forceinline__ void wave_em_load(const float *row, int lane, float (&e)[C]) {
+  const float *p = row + lane * C;
+  if constexpr (C % 4 == 0) {
+#pragma unroll
+    for (int q = 0; q < C / 4; q++) { const float4 v = *reinterpret_cast<const float4 *>(p + 4 * q); e[4 * q] = v.x; e[4 * q + 1] = v.y; e[4 * q + 2] = v.z; e[4 * q + 3] = v.w; }
+  } else if constexpr (C % 2 == 0) {
+#pragma unroll
+    for (int q = 0; q < C / 2; q++) { const float2 v = *reinterpret_cast<const float2 *>(p + 2 * q); e[2 * q] = v.x; e[2 * q + 1] = v.y; }
+  } else {
+#pragma unroll
+    for (int q = 0; q < C; q++) e[q] = p[q];
+  }
+}
+template <int C>
+__device__ __forceinline__ void wave_em_fill(float *w_rf, const float *g_rf, int M, int src_stride) {
+  const int S = wave_em_stride(M), n = kKp * S + 64 * C;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) { const int x = i / S, k = i - x * S; w_rf[i] = (x < kKp && k < M) ? g_rf[(size_t)x * src_stride + k + 1] : 0.f; }
+}
+
 // GT: the tables of a model too long for the LDS (above ~1100 nodes) are read from global memory (L2-resident) instead
 template <int C, bool GT = false>
 __global__ __launch_bounds__(256) void fwd_wave_kernel(SeqView sq, int M, const float *__restrict__ g_rf, const float *__restrict__ g_tf,
@@ -321,18 +356,25 @@ __global__ __launch_bounds__(256) void fwd_wave_kernel(SeqView sq, int M, const 
                                                        float *__restrict__ dp, const int64_t *__restrict__ dp_off, int unihit,
                                                        const int32_t *__restrict__ cfg_len) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  const float *s_tf = GT ? g_tf : reinterpret_cast<const float *>(lds);          // [(M+1)*8]
-  const float *s_rf = GT ? g_rf : s_tf + (size_t)(M + 1) * 8;                    // [Kp][M+1]
+  const float *s_rf = reinterpret_cast<const float *>(lds);                      // !GT: [Kp][wave_em_stride(M)], entry node - 1
+  const int S = wave_em_stride(M);
   if (ntodo_dev) ntodo = *ntodo_dev;
   if (!GT) {
-    float *w_tf = reinterpret_cast<float *>(lds), *w_rf = w_tf + (size_t)(M + 1) * 8;
-    for (int i = threadIdx.x; i < (M + 1) * 8; i += blockDim.x) w_tf[i] = g_tf[i];
-    for (int i = threadIdx.x; i < kKp * (M + 1); i += blockDim.x) w_rf[i] = g_rf[i];
+    wave_em_fill<C>(reinterpret_cast<float *>(lds), g_rf, M, M + 1);
     __syncthreads();
   }
   const int lane = threadIdx.x & 63;
   const int64_t wid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  // the lane's transitions, once (!GT): MM IM DM BM / MD DD MI II of its C nodes
+  float4 tra[GT ? 1 : C], trb[GT ? 1 : C];
+  if constexpr (!GT) {
+#pragma unroll
+    for (int k = 0; k < C; k++) {
+      const int node = min(lane * C + k + 1, M);
+      tra[k] = *reinterpret_cast<const float4 *>(g_tf + (size_t)node * 8); trb[k] = *reinterpret_cast<const float4 *>(g_tf + (size_t)node * 8 + 4);
+    }
+  }
 
   for (int64_t job = wid; job < ntodo; job += nw) {
     const int64_t sid = todo ? (int64_t)todo[job] : job;
@@ -351,9 +393,20 @@ __global__ __launch_bounds__(256) void fwd_wave_kernel(SeqView sq, int M, const 
     float *xrow = xmx ? xmx + xmx_off[sid] : nullptr;      // (L+1) x {E,N,J,B,C,SCALE}, P7_OMX xmx (impl_sse.h:253-262)
     if (xrow && lane == 0) { xrow[0] = xE; xrow[1] = xN; xrow[2] = xJ; xrow[3] = xB; xrow[4] = xC; xrow[5] = 1.0f; }
 
+    // The residues arrive 64 rows at a time, a lane each, the next 64 in flight: with a load per row every row of a launch of a
+    // few dozen targets (one query's envelopes) waited for its own trip to memory
+    int rbuf = (lane < L) ? (int)s[lane] : 0, rnext = 0;
     for (int i = 1; i <= L; i++) {
-      const int x = min((int)s[i - 1], kKp - 1);
-      const float *rf = s_rf + (size_t)x * (M + 1);
+      const int j = (i - 1) & 63;
+      if (j == 0) { const int q = i - 1 + 64 + lane; rnext = (q < L) ? (int)s[q] : 0; }
+      const int x = min(__builtin_amdgcn_readlane(rbuf, j), kKp - 1);
+      if (j == 63) rbuf = rnext;
+      float em[C];
+      if constexpr (!GT) wave_em_load<C>(s_rf + (size_t)x * S, lane, em);
+      else {
+#pragma unroll
+        for (int k = 0; k < C; k++) em[k] = g_rf[(size_t)x * (M + 1) + min(lane * C + k + 1, M)];
+      }
       const float mIn = wave_shr1_f32(Mp[C - 1], 0.f), iIn = wave_shr1_f32(Ip[C - 1], 0.f), dIn = wave_shr1_f32(Dp[C - 1], 0.f);
       float Mc[C], Ic[C], md[C], tdd[C];
       float sumE = 0.f;
@@ -361,8 +414,9 @@ __global__ __launch_bounds__(256) void fwd_wave_kernel(SeqView sq, int M, const 
       for (int k = 0; k < C; k++) {
         const int node = lane * C + k + 1;
         if (node <= M) {
-          const float4 ta = *reinterpret_cast<const float4 *>(s_tf + (size_t)node * 8);      // MM IM DM BM
-          const float4 tb = *reinterpret_cast<const float4 *>(s_tf + (size_t)node * 8 + 4);  // MD DD MI II
+          float4 ta, tb;                                                                      // MM IM DM BM / MD DD MI II
+          if constexpr (GT) { ta = *reinterpret_cast<const float4 *>(g_tf + (size_t)node * 8); tb = *reinterpret_cast<const float4 *>(g_tf + (size_t)node * 8 + 4); }
+          else { ta = tra[k]; tb = trb[k]; }
           const float m1 = (k == 0) ? mIn : Mp[k - 1];
           const float i1 = (k == 0) ? iIn : Ip[k - 1];
           const float d1 = (k == 0) ? dIn : Dp[k - 1];
@@ -370,7 +424,7 @@ __global__ __launch_bounds__(256) void fwd_wave_kernel(SeqView sq, int M, const 
           sv = sv + m1 * ta.x;
           sv = sv + i1 * ta.y;
           sv = sv + d1 * ta.z;
-          sv = sv * rf[node];
+          sv = sv * em[k];
           Mc[k] = sv;
           sumE += sv;
           md[k] = sv * tb.x;
@@ -440,18 +494,30 @@ __global__ __launch_bounds__(256) void bwd_wave_kernel(SeqView sq, int M, const 
                                                        float *__restrict__ sc, int32_t *__restrict__ status, float *__restrict__ bck_xmx,
                                                        float *__restrict__ dp, const int64_t *__restrict__ dp_off, int unihit) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  const float *s_tf = GT ? g_tf : reinterpret_cast<const float *>(lds);          // [(M+2)*8], node M+1 all zero
-  const float *s_rf = GT ? g_rf : s_tf + (size_t)(M + 2) * 8;                    // [Kp][M+2], column M+1 zero
+  const float *s_tf = g_tf;                                                      // GT: [(M+2)*8], node M+1 all zero (!GT: read once, below)
+  const float *s_rf = GT ? g_rf : reinterpret_cast<const float *>(lds);          // GT: [Kp][M+2], column M+1 zero; !GT: [Kp][wave_em_stride(M)], entry node - 1
+  const int S = wave_em_stride(M);
   if (!GT) {
-    float *w_tf = reinterpret_cast<float *>(lds), *w_rf = w_tf + (size_t)(M + 2) * 8;
-    for (int i = threadIdx.x; i < (M + 2) * 8; i += blockDim.x) w_tf[i] = (i < (M + 1) * 8) ? g_tf[i] : 0.f;
-    for (int i = threadIdx.x; i < kKp * (M + 2); i += blockDim.x) { const int x = i / (M + 2), k = i - x * (M + 2); w_rf[i] = (k <= M) ? g_rf[(size_t)x * (M + 1) + k] : 0.f; }
+    wave_em_fill<C>(reinterpret_cast<float *>(lds), g_rf, M, M + 1);
     __syncthreads();
   }
   // lanes own their nodes in DESCENDING order (logical lane = 63 - physical): the chains towards node M are then upward DPP scans
   const int lane = 63 - (threadIdx.x & 63);
   const int64_t wid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  // the lane's transitions, once (!GT): MD DD MI II and BM of its C nodes (zero beyond node M), MM IM DM of the nodes to their right
+  // (zero from node M on)
+  float4 trb[GT ? 1 : C], trn[GT ? 1 : C]; float trbm[GT ? 1 : C];
+  if constexpr (!GT) {
+#pragma unroll
+    for (int k = 0; k < C; k++) {
+      const int node = lane * C + k + 1;
+      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+      trb[k] = node <= M ? *reinterpret_cast<const float4 *>(g_tf + (size_t)node * 8 + 4) : z;
+      trbm[k] = node <= M ? g_tf[(size_t)node * 8 + 3] : 0.f;
+      trn[k] = node < M ? *reinterpret_cast<const float4 *>(g_tf + (size_t)(node + 1) * 8) : z;
+    }
+  }
   for (int64_t sid = wid; sid < ntodo; sid += nw) {
     const int L = sq.len[sid];
     const uint8_t *s = sq.data + sq.off[sid];
@@ -465,7 +531,7 @@ __global__ __launch_bounds__(256) void bwd_wave_kernel(SeqView sq, int M, const 
     {
       float A = 0.f, B = 1.f;                              // D(k) = xE + D(k+1)*tDD(k)
 #pragma unroll
-      for (int k = C - 1; k >= 0; k--) { const int node = lane * C + k + 1; const float tdd = (node <= M) ? s_tf[(size_t)node * 8 + 5] : 0.f; A = ((node <= M) ? xE : 0.f) + A * tdd; B *= tdd; }
+      for (int k = C - 1; k >= 0; k--) { const int node = lane * C + k + 1; float tdd; if constexpr (GT) tdd = (node <= M) ? s_tf[(size_t)node * 8 + 5] : 0.f; else tdd = trb[k].y; A = ((node <= M) ? xE : 0.f) + A * tdd; B *= tdd; }
       // lanes without a source see the identity map (A = 0, B = 1)
 #define BATH_BWD_STEP(CTRL, MASK) { const float An = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, A), CTRL, MASK, 0xf, false)), \
                                                  Bn = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0x3f800000, __builtin_bit_cast(int, B), CTRL, MASK, 0xf, false)); \
@@ -477,7 +543,8 @@ __global__ __launch_bounds__(256) void bwd_wave_kernel(SeqView sq, int M, const 
       for (int k = C - 1; k >= 0; k--) {
         const int node = lane * C + k + 1;
         if (node <= M) {
-          const float tdd = s_tf[(size_t)node * 8 + 5], tmd = s_tf[(size_t)node * 8 + 4];
+          float tdd, tmd;
+          if constexpr (GT) { tdd = s_tf[(size_t)node * 8 + 5]; tmd = s_tf[(size_t)node * 8 + 4]; } else { tdd = trb[k].y; tmd = trb[k].x; }
           Dn[k] = xE + dnext * tdd;
           Mn[k] = xE + dnext * tmd;
           dnext = Dn[k];
@@ -505,14 +572,29 @@ __global__ __launch_bounds__(256) void bwd_wave_kernel(SeqView sq, int M, const 
       }
     }
     bool own_scales = false;
+    // residue i+1 and Forward's scale factor of row i, 64 rows at a time (a physical lane each, the next 64 in flight): see fwd_wave_kernel
+    const int ph = threadIdx.x & 63;
+    int rbuf = (L - 1 - ph >= 0) ? (int)s[L - 1 - ph] : 0, rnext = 0;
+    float fbuf = (L - 1 - ph >= 0) ? fx[(size_t)(L - 1 - ph) * 6 + 5] : 1.0f, fnext = 1.0f;
     for (int i = L - 1; i >= 0; i--) {
-      const int x = min((int)s[i], kKp - 1);               // residue i+1
-      const float *rf = s_rf + (size_t)x * (M + 2);
+      const int j = (L - 1 - i) & 63;
+      if (j == 0) { const int q = i - 64 - ph; rnext = (q >= 0) ? (int)s[q] : 0; fnext = (q >= 0) ? fx[(size_t)q * 6 + 5] : 1.0f; }
+      const int x = min(__builtin_amdgcn_readlane(rbuf, j), kKp - 1);               // residue i+1
+      const float fs = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fbuf), j));
+      if (j == 63) { rbuf = rnext; fbuf = fnext; }
       // B(i) = sum_k M(i+1,k) * e(k, x_{i+1}) * tBM(k)
       float me[C];                                         // M(i+1,k) * e(k, x_{i+1})
       float b = 0.f;
+      if constexpr (GT) {
+        const float *rf = s_rf + (size_t)x * (M + 2);
 #pragma unroll
-      for (int k = 0; k < C; k++) { const int node = lane * C + k + 1; me[k] = Mn[k] * rf[min(node, M + 1)]; b += me[k] * s_tf[(size_t)min(node, M + 1) * 8 + 3]; }
+        for (int k = 0; k < C; k++) { const int node = lane * C + k + 1; me[k] = Mn[k] * rf[min(node, M + 1)]; b += me[k] * s_tf[(size_t)min(node, M + 1) * 8 + 3]; }
+      } else {
+        float em[C];
+        wave_em_load<C>(s_rf + (size_t)x * S, lane, em);  // (beyond node M + 1: the next row's or the pad's finite numbers, times Mn = 0)
+#pragma unroll
+        for (int k = 0; k < C; k++) { me[k] = Mn[k] * em[k]; b += me[k] * trbm[k]; }
+      }
       xB = wave_sum_f32(b);
       if (i == 0) { xN = (xB * pmove) + (xN * ploop); break; }                                       // :695-740: only N and B are reachable
       xC = xC * ploop;
@@ -530,8 +612,9 @@ __global__ __launch_bounds__(256) void bwd_wave_kernel(SeqView sq, int M, const 
       for (int k = C - 1; k >= 0; k--) {
         const int node = lane * C + k + 1;
         const bool in = node <= M;
-        const float tdm = (node < M) ? s_tf[(size_t)(node + 1) * 8 + 2] : 0.f;
-        tddv[k] = in ? s_tf[(size_t)node * 8 + 5] : 0.f;
+        float tdm;
+        if constexpr (GT) { tdm = (node < M) ? s_tf[(size_t)(node + 1) * 8 + 2] : 0.f; tddv[k] = in ? s_tf[(size_t)node * 8 + 5] : 0.f; }
+        else { tdm = trn[k].z; tddv[k] = trb[k].y; }
         dconst[k] = in ? (mnext[k] * tdm) : 0.f;
         // reference order (:608-612 restated): Dc = mnext*tdm + Dc[k+1]*tdd + xE
         A = in ? ((dconst[k] + A * tddv[k]) + xE) : 0.f; B = in ? B * tddv[k] : 0.f;
@@ -547,16 +630,17 @@ __global__ __launch_bounds__(256) void bwd_wave_kernel(SeqView sq, int M, const 
       for (int k = C - 1; k >= 0; k--) {
         const int node = lane * C + k + 1;
         if (node <= M) {
-          const float *t = s_tf + (size_t)node * 8;               // MD, DD, MI, II leave node k
-          const float *t1 = s_tf + (size_t)(node + 1) * 8;        // MM, IM, DM enter node k+1 (zero at M+1)
-          const float tmm = (node < M) ? t1[0] : 0.f, tim = (node < M) ? t1[1] : 0.f;
-          Ic[k] = In[k] * t[7] + mnext[k] * tim;
+          float tmm, tim, t4, t6, t7;                              // MM, IM enter node k+1 (zero at M+1); MD, MI, II leave node k
+          if constexpr (GT) {
+            const float *t = s_tf + (size_t)node * 8, *t1 = s_tf + (size_t)(node + 1) * 8;
+            tmm = (node < M) ? t1[0] : 0.f; tim = (node < M) ? t1[1] : 0.f; t4 = t[4]; t6 = t[6]; t7 = t[7];
+          } else { tmm = trn[k].x; tim = trn[k].y; t4 = trb[k].x; t6 = trb[k].z; t7 = trb[k].w; }
+          Ic[k] = In[k] * t7 + mnext[k] * tim;
           Dc[k] = (dconst[k] + dnext * tddv[k]) + xE;
-          Mc[k] = ((In[k] * t[6] + mnext[k] * tmm) + xE) + dnext * t[4];
+          Mc[k] = ((In[k] * t6 + mnext[k] * tmm) + xE) + dnext * t4;
           dnext = Dc[k];
         } else { Mc[k] = Ic[k] = Dc[k] = 0.f; dnext = 0.f; }
       }
-      const float fs = fx[(size_t)i * 6 + 5];
       if (xB > 1.0e16f) own_scales = true;
       const float scl = own_scales ? ((xB > 1.0e4f) ? xB : 1.0f) : fs;
       if (scl > 1.0f) {
@@ -718,10 +802,10 @@ int launch_fwd_wave(bath_hip_ctx *ctx, const bath_hip_oprofile *om, SeqView v, c
   if (ntodo == 0) return BATH_OK;
   const int C = columns_per_lane(om->M);
   const int grid = wave_grid(ctx, ntodo);
-  const size_t shmem = ((size_t)(om->M + 1) * 8 + (size_t)kKp * (om->M + 1)) * sizeof(float);
+  const size_t shmem = ((size_t)kKp * wave_em_stride(om->M) + 64 * (size_t)C) * sizeof(float);
   FwdConsts c{om->xf_E[0], om->xf_E[1]};
   if (unihit) { c.xfE_loop = 0.0f; c.xfE_move = 1.0f; }         // p7_oprofile_ReconfigUnihit, p7_oprofile.c:1421-1422
-  if (shmem > kWaveTableLdsMax) {                               // tables stay in global memory
+  if (shmem > kWaveTableLdsMax || C > 16) {                     // tables stay in global memory (beyond 16 nodes per lane the transitions do not fit the registers either)
     BATH_C_SWITCH(C, {
       hipLaunchKernelGGL((fwd_wave_kernel<CC, true>), dim3(grid), dim3(256), 0, ctx->stream, v, om->M, om->d_rf, om->d_tf, om->lt.d_pmove, c, d_todo, ntodo, ntodo_dev, d_sc, d_status, d_xmx, d_xmx_off, d_dp, d_dp_off, unihit, d_cfg_len);
     })
@@ -740,10 +824,10 @@ int launch_bwd_wave(bath_hip_ctx *ctx, const bath_hip_oprofile *om, SeqView v, i
   if (n == 0) return BATH_OK;
   const int C = columns_per_lane(om->M);
   const int grid = wave_grid(ctx, n);
-  const size_t shmem = ((size_t)(om->M + 2) * 8 + (size_t)kKp * (om->M + 2)) * sizeof(float);
+  const size_t shmem = ((size_t)kKp * wave_em_stride(om->M) + 64 * (size_t)C) * sizeof(float);
   FwdConsts c{om->xf_E[0], om->xf_E[1]};
   if (unihit) { c.xfE_loop = 0.0f; c.xfE_move = 1.0f; }
-  if (shmem > kWaveTableLdsMax) {
+  if (shmem > kWaveTableLdsMax || C > 16) {
     BATH_C_SWITCH(C, {
       hipLaunchKernelGGL((bwd_wave_kernel<CC, true>), dim3(grid), dim3(256), 0, ctx->stream, v, om->M, om->d_rfb, om->d_tfb, om->lt.d_pmove, c, n, d_fwd_xmx, d_xmx_off, d_sc, d_status, d_bck_xmx, d_dp, d_dp_off, unihit);
     })

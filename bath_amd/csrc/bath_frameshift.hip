@@ -1706,7 +1706,7 @@ int fs3_regions(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, const bath_hip_
     const int s1 = reuse ? -1 : ctx->span_begin("fs3_fwd_kernel", ctx->stream, cells3, bytes3);
     if (reuse) {
     } else if (MD == 2 && fs_chain_enabled()) {
-      if ((st = launch_fs3_fwd_chain(ctx, ctx->stream, om, dna, Cv, tE, tE, b_sc.as<float>(), b_fx.as<float>(), b_off.as<int64_t>(), jq[0])) != BATH_OK) return st;
+      if ((st = launch_fs3_fwd_chain(ctx, ctx->stream, om, dna, Cv, tE, tE, b_sc.as<float>(), b_fx.as<float>(), b_off.as<int64_t>(), jq[0], 2)) != BATH_OK) return st;
     } else
     hipLaunchKernelGGL((fs3_fwd_kernel<CC, MD>), dim3(grid_dp), dim3(kFsBlock), shmem, ctx->stream, dna->view(), fsdev(om), om->d_loop[0], om->d_move[0], tE, tE, b_sc.as<float>(), b_fx.as<float>(), b_off.as<int64_t>(), jq[0]);
     ctx->span_end(s1, ctx->stream);

@@ -1096,7 +1096,7 @@ static int chain_waves(bath_hip_ctx *ctx, int64_t n, int M, int C, size_t *shmem
   }
 
 int launch_fs3_fwd_chain(bath_hip_ctx *ctx, hipStream_t stream, const bath_hip_fsprofile *om, const bath_hip_seqs *dna, int Cv, float tEL, float tEM,
-                         float *d_sc, float *d_xmx, const int64_t *d_xoff, FsJobs jobs) {
+                         float *d_sc, float *d_xmx, const int64_t *d_xoff, FsJobs jobs, int cu_share) {
   const int M = om->M;
   size_t shmem = 0;
   const int64_t n = dna->n;
@@ -1125,7 +1125,10 @@ int launch_fs3_fwd_chain(bath_hip_ctx *ctx, hipStream_t stream, const bath_hip_f
     BATH_HIP_TRY(ctx, hipGetLastError());
     return BATH_OK;
   }
-  const int W = chain_waves(ctx, dna->n, M, Cv, &shmem);
+  // <cu_share> = 2: the Backward parser of the same windows runs beside this launch (fs3_regions before the branch decision): the
+  // two kernels' blocks do not fit into one CU's LDS together, so each takes half of the CUs with blocks of twice the windows --
+  // with a CU each per kernel, 2 x 164 blocks for the 327 windows of configs[4]'s slice queued on 256 CUs
+  const int W = chain_waves(ctx, dna->n, M, Cv, &shmem, cu_share);
   const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((n + W - 1) / W, (int64_t)ctx->prop.multiProcessorCount));
   BATH_CHAIN_SWITCH(Cv, {
     BATH_HIP_TRY(ctx, bath::allow_max_lds((const void *)fs3_fwd_chain_kernel<CC>));
@@ -1163,7 +1166,7 @@ int launch_fs3_bwd_chain(bath_hip_ctx *ctx, hipStream_t stream, const bath_hip_f
       return BATH_OK;
     }
   }
-  const int W = chain_waves(ctx, dna->n, M, Cv, &shmem, 1, bwd_chain_threads(Cv), chain_compact(Cv) ? (M + 3) * 4 : 0);
+  const int W = chain_waves(ctx, dna->n, M, Cv, &shmem, cu_share, bwd_chain_threads(Cv), chain_compact(Cv) ? (M + 3) * 4 : 0);
   // batches by length (chain_batches); t(w) measured at M = 145 (C = 3): 25.4 us per row pair at one window, 28.5 at 16
   int nbat = 0;
   DevBuf &b_bst = ctx->scratch[48];                                // (its own buffer: Forward's launch may be running on another stream)

@@ -157,7 +157,7 @@ int launch_fs5_decode_oa_mw(bath_hip_ctx *ctx, hipStream_t stream, const bath_hi
 
 // ---- multihit recursions in the reference's serial order, chains batched per block (bath_fs_chain.hip)
 int launch_fs3_fwd_chain(bath_hip_ctx *ctx, hipStream_t stream, const bath_hip_fsprofile *om, const bath_hip_seqs *dna, int Cv, float tEL, float tEM,
-                         float *d_sc, float *d_xmx, const int64_t *d_xoff, FsJobs jobs);
+                         float *d_sc, float *d_xmx, const int64_t *d_xoff, FsJobs jobs, int cu_share = 1);
 int launch_fs3_bwd_chain(bath_hip_ctx *ctx, hipStream_t stream, const bath_hip_fsprofile *om, const bath_hip_seqs *dna, int Cv, float tEL, float tEM,
                          float *d_sc, float *d_xmx, const int64_t *d_xoff, FsJobs jobs, int cu_share = 1 /* 2: the Forward parser runs beside it */);
 int launch_fs5_fwd_chain(bath_hip_ctx *ctx, hipStream_t stream, const bath_hip_fsprofile *om, const bath_hip_seqs *dna, int Cv, float tEL, float tEM, int c5_compat,

@@ -244,8 +244,13 @@ __global__ __launch_bounds__(256) void ssv_bath_kernel(Cand cand, const Counters
     int dp[C];
 #pragma unroll
     for (int k = 0; k < C; k++) dp[k] = 0;
+    const int ph = threadIdx.x & 63;
+    int rbuf = (ph < L) ? (int)s[ph] : 0, rnext = 0;          // residues 64 rows at a time, a lane each, the next 64 in flight (see fwd_wave_kernel)
     for (int i = 1; i <= L; i++) {
-      const int x = min((int)s[i - 1], kKp - 1);
+      const int j = (i - 1) & 63;
+      if (j == 0) { const int q = i - 1 + 64 + ph; rnext = (q < L) ? (int)s[q] : 0; }
+      const int x = min(__builtin_amdgcn_readlane(rbuf, j), kKp - 1);
+      if (j == 63) rbuf = rnext;
       const uint8_t *row = rb + (size_t)x * rb_stride;
       int prev = wave_shr1_i32(dp[C - 1], 0);
       int xE = 0;
@@ -298,6 +303,7 @@ __global__ __launch_bounds__(256) void ssv_bath_kernel(Cand cand, const Counters
         }
         kmin = min(kmin, start); kmax = max(kmax, end);
         i = target_end;
+        { const int base = i & ~63; rbuf = (base + ph < L) ? (int)s[base + ph] : 0; rnext = (base + 64 + ph < L) ? (int)s[base + 64 + ph] : 0; }   // the row loop jumped: refill
       }
     }
     if (lane == 0) { cand.kminmax[2 * c] = kmin; cand.kminmax[2 * c + 1] = kmax; }
