@@ -972,6 +972,183 @@ __global__ void std_envelope_kernel(SeqView sq, int M, const float *__restrict__
   out[t] = r;
 }
 
+// p7_OATrace and what follows it in std_envelope_kernel (alignment score, the columns' posteriors) for an envelope whose matrices
+// std_envelope_fill_kernel left behind, with the WAVE walking instead of one lane.  The walk is a chain of decisions, each on cells
+// whose address the previous decision gives: a lane on its own pays a trip to memory per step (0.8 us; 900 steps for a 459-node
+// model).  Here every lane follows the same state machine on the same (uniform) state and the cells come from look-ahead buffers
+// filled by all 64 lanes at once:
+//   * a match run walks a diagonal: on entering (i, k) lane d fetches what the step from (i - d, k - d) will need -- the three cells
+//     of (i - 1 - d, k - 1 - d), B of that row, the four transitions into node k - d, the residue and the consensus residue of the
+//     cell it leads to -- and the steps take them by v_readlane until the path leaves the diagonal or the 64 are used;
+//   * the C flank is decided 64 rows at a time (a ballot of "stays in C"); the N flank needs no reads at all;
+//   * the E state's choice among the 2 M cells of a row (the reference scans them in its striped order: ties go to the LAST match
+//     cell of the scan, else to the FIRST delete cell) is a lane-parallel scan and two wave maxima over (value, rank);
+//   * the columns' scores and posteriors are gathered a lane per column (prefix counts of the column kinds by ballot), and the
+//     score is summed in the reference's order, first to last column.
+// Same decisions on the same values: the trace is the serial kernel's, state for state (tests/test_hits_gpu.py runs both).
+__global__ __launch_bounds__(64) void std_trace_wave_kernel(SeqView sq, int M, const float *__restrict__ tf, const float *__restrict__ fwd, const float *__restrict__ bck,
+                                                            const int64_t *__restrict__ dp_off, const int64_t *__restrict__ x_off,
+                                                            const float *__restrict__ ppx_all, const float *__restrict__ oax_all, StdEnvOut *__restrict__ out,
+                                                            const uint8_t *__restrict__ cons /* [M+1] or null */, uint8_t *__restrict__ tbuf, const int64_t *__restrict__ t_off,
+                                                            const float *__restrict__ msc /* [Kp][M+1] log-odds */, const float *__restrict__ tsc /* [M][8] log */,
+                                                            const uint8_t *__restrict__ nt /* the DNA block */, const int64_t *__restrict__ nt_base, const int64_t *__restrict__ nt_dir,
+                                                            float *__restrict__ col_pp, int *__restrict__ col_cursor) {
+  enum { XE = 0, XN, XJ, XB, XC, XS };
+  enum { cM = 0, cD = 1, cI = 2 };
+  enum { MM = 0, IM, DM, BM, MD, DD, MI, II };
+  enum { sS = 0, sN, sB, sM, sD, sI, sE, sJ, sC };
+  const int lane = threadIdx.x;
+  const int64_t t = blockIdx.x;
+  const int L = sq.len[t];
+  const uint8_t *dsq = sq.data + sq.off[t] - 1;                              // dsq[1..L]
+  const size_t W = (size_t)(M + 1) * 3;
+  const float *O = fwd + dp_off[t], *P = bck + dp_off[t];
+  const float *PX = ppx_all + (x_off[t] / 6) * 5, *OX = oax_all + (x_off[t] / 6) * 5;
+  StdEnvOut r{-1, -1, -1, -1, 0, 0.f, 0.f, 0, 0, 0.f, 0};
+  {
+    const StdEnvOut pre = out[t];
+    if (!pre.ok) { if (lane == 0) out[t] = r; return; }
+    r.oasc = pre.oasc; r.domcorrection = pre.domcorrection;
+  }
+  auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+  auto rlf = [](float v, int d) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), d)); };
+  auto path = [](float tr, float v) { return tr == 0.0f ? -INFINITY : v; };
+  const int Q = max(2, (M - 1) / 4 + 1);
+  uint8_t *T = tbuf + t_off[t];
+  const int cap = (int)(t_off[t + 1] - t_off[t]);
+  int i = L, k = 0, s0 = sC, steps = 0, ncol = 0, exact = 0;
+  bool bad = false;
+  // the diagonal look-ahead: lane d holds what the match step from (di0 - d, dk0 - d) reads
+  float dM = 0.f, dI = 0.f, dD = 0.f, dXB = 0.f;
+  float4 dT = make_float4(0.f, 0.f, 0.f, 0.f);
+  int dRes = 0, dCons = -1, di0 = -(1 << 20), dk0 = -(1 << 20);
+  while (s0 != sS && !bad) {
+    i = uni(i); k = uni(k); s0 = uni(s0);
+    int s1 = -1;
+    bool from_diag = false; int dd = 0;
+    if (s0 == sC) {
+      const int rr = i - lane;
+      bool stay = false;
+      if (rr >= 1) stay = OX[(size_t)(rr - 1) * 5 + XC] + PX[(size_t)rr * 5 + XC] > OX[(size_t)rr * 5 + XE];
+      const unsigned long long m = __ballot(stay);
+      const int n = (~m == 0ull) ? 64 : (__ffsll((long long)~m) - 1);         // rows i, i-1, ... that stay in C
+      if (n > 0) { i -= n; steps += n; if (steps > 4 * (L + M) + 64) bad = true; continue; }
+      s1 = sE;
+    } else if (s0 == sN) {                                                    // N(i) <- N(i-1) ... <- N(0) <- S: nothing to read
+      steps += i + 1; i = 0; s0 = sS; continue;
+    } else if (s0 == sM) {
+      dd = di0 - i;
+      if (dd < 0 || dd >= 64 || dk0 - k != dd) {
+        const int ii = max(i - 1 - lane, 0), kk = max(k - 1 - lane, 0);
+        const float *pr = O + (size_t)ii * W + (size_t)kk * 3;
+        dM = pr[cM]; dI = pr[cI]; dD = pr[cD]; dXB = OX[(size_t)ii * 5 + XB];
+        dT = *reinterpret_cast<const float4 *>(tf + (size_t)max(k - lane, 0) * 8);
+        dRes = min((int)dsq[max(ii, 1)], kKp - 1); dCons = cons ? (int)cons[kk] : -1;
+        di0 = i; dk0 = k; dd = 0;
+      }
+      dd = uni(dd);
+      const float pm = path(rlf(dT.x, dd), rlf(dM, dd)), pi = path(rlf(dT.y, dd), rlf(dI, dd));
+      const float pd = path(rlf(dT.z, dd), rlf(dD, dd)), pb = path(rlf(dT.w, dd), rlf(dXB, dd));
+      s1 = sM; float b = pm;
+      if (pi > b) { b = pi; s1 = sI; }
+      if (pd > b) { b = pd; s1 = sD; }
+      if (pb > b) { b = pb; s1 = sB; }
+      k--; i--; from_diag = true;
+    } else if (s0 == sD) {
+      const float *tr = tf + (size_t)max(k - 1, 0) * 8, *c = O + (size_t)i * W;
+      const float pm = (k - 1 >= 1) ? path(tr[MD], c[(size_t)(k - 1) * 3 + cM]) : -INFINITY;
+      const float pd = (k - 1 >= 1) ? path(tr[DD], c[(size_t)(k - 1) * 3 + cD]) : -INFINITY;
+      s1 = pm >= pd ? sM : sD; k--;
+    } else if (s0 == sI) {
+      const float *tr = tf + (size_t)k * 8, *pr = O + (size_t)(i - 1) * W;
+      s1 = path(tr[MI], pr[(size_t)k * 3 + cM]) >= path(tr[II], pr[(size_t)k * 3 + cI]) ? sM : sI; i--;
+    } else if (s0 == sJ) {
+      s1 = sJ;                                                                // unihit: E->J impossible, path[1] = -inf (optacc.c:384)
+    } else if (s0 == sE) {
+      // select_e over the reference's striped order q = 0..Q-1: the four match cells rr*Q + q + 1 (>=: a later one takes a tie),
+      // then the four delete cells (>: an earlier one keeps it).  rank: scan position, match cells above all delete cells.
+      const float *c = O + (size_t)i * W;
+      float mx = -INFINITY; int rank = -1;
+      for (int q = lane; q < Q; q += 64) {
+        for (int rr = 0; rr < 4; rr++) { const int kk = rr * Q + q + 1; if (kk <= M) { const float v = c[(size_t)kk * 3 + cM]; const int rk = (1 << 24) + q * 8 + rr; if (v > mx || (v == mx && rk > rank)) { mx = v; rank = rk; } } }
+        for (int rr = 0; rr < 4; rr++) { const int kk = rr * Q + q + 1; if (kk <= M) { const float v = c[(size_t)kk * 3 + cD]; const int rk = (1 << 23) - (q * 8 + 4 + rr); if (v > mx || (v == mx && rk > rank)) { mx = v; rank = rk; } } }
+      }
+      const float best = wave_max_f32(mx);
+      const int brank = wave_max_i32((mx == best) ? rank : -1);
+      if (brank < 0) bad = true;
+      else if (brank >= (1 << 24)) { const int pq = brank - (1 << 24); k = (pq & 7) * Q + (pq >> 3) + 1; s1 = sM; }
+      else { const int pq = (1 << 23) - brank; k = ((pq & 7) - 4) * Q + (pq >> 3) + 1; s1 = sD; }
+    } else if (s0 == sB) {
+      s1 = (OX[(size_t)i * 5 + XN] > OX[(size_t)i * 5 + XJ]) ? sN : sJ;
+    } else bad = true;
+    if (bad || s1 < 0 || i < 0 || k < 0) { bad = true; break; }
+    if (s1 == sM) { if (r.i2 < 0) { r.i2 = i; r.k2 = k; } r.i1 = i; r.k1 = k; }
+    if ((s1 == sM || s1 == sD || s1 == sI) && r.i2 >= 0) {
+      if (ncol < cap && lane == 0) T[ncol] = (uint8_t)s1;
+      ncol++;
+      if (s1 == sM) {
+        r.ncol = ncol;
+        if (cons) {
+          int res, cn;
+          if (from_diag) { res = __builtin_amdgcn_readlane(dRes, dd); cn = __builtin_amdgcn_readlane(dCons, dd); }
+          else { res = min((int)dsq[i], kKp - 1); cn = (int)cons[k]; }
+          if (res == cn) exact++;
+        }
+        r.exact = exact;
+      }
+    }
+    if ((s1 == sN || s1 == sJ || s1 == sC) && s1 == s0) i--;
+    s0 = s1;
+    if (++steps > 4 * (L + M) + 64) bad = true;
+  }
+  if (bad || r.i1 <= 0) { if (lane == 0) out[t] = r; return; }
+  __threadfence();                                                            // lane 0's column bytes, read below by every lane
+  // ---- the columns, first to last match state (column j of the alignment = T[ncol' - 1 - j], ncol' = r.ncol), a lane per
+  // column: its node and residue from prefix counts of the column kinds; p7_pli_computeAliScores_BATH (p7_pipeline.c:781-979)
+  // summed in the reference's order, and the posterior of every column's state (optacc.c, get_postprob)
+  const int nc = r.ncol;
+  if (nc <= cap && nc > 0) {
+    const size_t W1 = (size_t)M + 1;
+    const int64_t base = nt_base[t], dir = nt_dir[t];
+    int pp_off = 0;
+    if (col_pp) { if (lane == 0) pp_off = atomicAdd(col_cursor, nc); pp_off = uni(pp_off); r.pp_off = pp_off; }
+    float total = 0.f;
+    int kbase = r.k1 - 1, ibase = r.i1 - 1, prev_last = sB;
+    for (int jb = 0; jb < nc; jb += 64) {
+      const int j = jb + lane;
+      const bool in = j < nc;
+      const int s = in ? (int)T[nc - 1 - j] : -1;
+      const unsigned long long bMm = __ballot(s == sM), bIm = __ballot(s == sI), bDm = __ballot(s == sD);
+      const unsigned long long upto = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
+      const int kk = kbase + __popcll((bMm | bDm) & upto), ii = ibase + __popcll((bMm | bIm) & upto);
+      int prev = __shfl_up(s, 1, 64);
+      if (lane == 0) prev = prev_last;
+      float sc = 0.f, ppv = 0.f;
+      if (in) {
+        if (s == sM) {
+          int amino = min((int)dsq[ii], kKp - 1);
+          const int64_t c0 = base + dir * (int64_t)(3 * (ii - 1));
+          if (nt[c0] >= 4 || nt[c0 + dir] >= 4 || nt[c0 + 2 * dir] >= 4) amino = 26;
+          sc = msc[(size_t)amino * W1 + kk];
+          if (prev == sI) sc += tsc[(size_t)(kk - 1) * 8 + IM];
+          else if (prev == sD) sc += tsc[(size_t)(kk - 1) * 8 + DM];
+          else if (prev == sM && j < nc - 1) sc += tsc[(size_t)(kk - 1) * 8 + MM];
+          ppv = P[(size_t)ii * W + (size_t)kk * 3 + cM];
+        } else if (s == sI) { sc = tsc[(size_t)kk * 8 + (prev == sI ? II : MI)]; ppv = P[(size_t)ii * W + (size_t)kk * 3 + cI]; }
+        else sc = tsc[(size_t)(kk - 1) * 8 + (prev == sD ? DD : MD)];
+        if (col_pp) col_pp[pp_off + j] = ppv;
+      }
+      const int nin = min(64, nc - jb);
+      if (msc) for (int l = 0; l < nin; l++) total += rlf(sc, l);
+      kbase += __popcll(bMm | bDm); ibase += __popcll(bMm | bIm);
+      prev_last = __builtin_amdgcn_readlane(s, 63);
+    }
+    if (msc) r.aliscore = total;
+  }
+  r.ok = 1;
+  if (lane == 0) out[t] = r;
+}
+
 // The same decoding, optimal-accuracy fill and null2 with a WAVE per envelope: lanes own C consecutive nodes each, rows are
 // walked in order with the previous row in registers (neighbours by shuffle), the row's D chain D(k+1) = max(MD_k ? M_k : 0,
 // DD_k ? D_k : 0) is a wavefront scan over functions x -> pass ? max(c, x) : c (closed under composition), xE a wave max.
@@ -1383,6 +1560,12 @@ static int std_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bat
 #undef BATH_FILL
     BATH_HIP_TRY(ctx, hipGetLastError());
   }
+  const bool lane_trace = [] { const char *e = std::getenv("BATH_HIP_STD_TRACE_LANE"); return e && e[0] == '1'; }();             // A/B and tests: the walk by one lane
+  if (filled && !lane_trace)
+    hipLaunchKernelGGL(std_trace_wave_kernel, dim3((unsigned)ne), dim3(64), 0, ctx->stream, ev.view(), M, om->d_tf, b_f.as<float>(), b_b.as<float>(), b_dpo.as<int64_t>(), d_exoff,
+                       b_px.as<float>(), b_ox.as<float>(), b_out.as<StdEnvOut>(), om->d_cons, b_tb.as<uint8_t>(), b_toff.as<int64_t>(),
+                       om->d_msc, om->d_tsc, dna->d_data, b_toff.as<int64_t>() + ne + 1, b_toff.as<int64_t>() + 2 * ne + 1, d_col_pp, d_col_cursor);
+  else
   hipLaunchKernelGGL(std_envelope_kernel, dim3((unsigned)((ne * kStdTraceSpread + 63) / 64)), dim3(64), 0, ctx->stream, ev.view(), M, om->d_tf, om->d_rf, b_f.as<float>(), b_b.as<float>(), b_dpo.as<int64_t>(),
                      b_fx.as<float>(), b_bx.as<float>(), d_exoff, b_px.as<float>(), b_ox.as<float>(), b_em.as<float>(), b_out.as<StdEnvOut>(),
                      om->d_cons, b_tb.as<uint8_t>(), b_toff.as<int64_t>(), filled,

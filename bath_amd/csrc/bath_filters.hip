@@ -156,6 +156,7 @@ __global__ __launch_bounds__(256) void msv_wave_kernel(SeqView sq, int M, const 
   }
 }
 
+__host__ __device__ constexpr int vit_em_stride(int M) { return (M + 7) & ~7; }
 // ============================================================================================
 // Viterbi filter, wave per target.  int16 semantics of the reference kept exactly: every add
 // saturates to [-32768, 32767] (adds_epi16), special states wrap like int16_t assignments.
@@ -182,14 +183,19 @@ __global__ __launch_bounds__(256) void vit_wave_kernel(SeqView sq, int M, const 
                                                        const float *__restrict__ filtersc, const uint8_t *__restrict__ ssv_scores,
                                                        WindowRec *__restrict__ wins, int *__restrict__ win_count, int win_cap,
                                                        int32_t *__restrict__ kminmax) {
+  // Emission rows in LDS as [Kp][S] int16, entry node - 1, S a multiple of 8 (a lane's C nodes: aligned vector reads that follow the
+  // previous lane's, no bank conflicts; 64 C entries of padding behind the last row); the lane's transitions in registers, read
+  // once (as 16 bytes per node in LDS they were 16 C bytes apart from lane to lane: a 32-way conflict at C = 8).  See fwd_wave_kernel.
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  int16_t *s_tw = reinterpret_cast<int16_t *>(lds);                  // [(M+1)*8]
-  int16_t *s_rw = s_tw + (size_t)(M + 1) * 8;                        // [Kp][M+1]
-  for (int i = threadIdx.x; i < (M + 1) * 8; i += blockDim.x) s_tw[i] = g_tw[i];
-  for (int i = threadIdx.x; i < kKp * (M + 1); i += blockDim.x) s_rw[i] = g_rw[i];
+  int16_t *s_rw = reinterpret_cast<int16_t *>(lds);
+  const int S = vit_em_stride(M);
+  for (int i = threadIdx.x; i < kKp * S + 64 * C; i += blockDim.x) { const int x = i / S, k = i - x * S; s_rw[i] = (x < kKp && k < M) ? g_rw[(size_t)x * (M + 1) + k + 1] : (int16_t)-32768; }
   __syncthreads();
   enum { MM, IM, DM, BM, MD, DD, MI, II };
   const int lane = threadIdx.x & 63;
+  int4 twq[C];
+#pragma unroll
+  for (int k = 0; k < C; k++) twq[k] = *reinterpret_cast<const int4 *>(g_tw + (size_t)min(lane * C + k + 1, M) * 8);
   const int64_t wid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
   const bool do_win = (wins != nullptr);
@@ -222,7 +228,31 @@ __global__ __launch_bounds__(256) void vit_wave_kernel(SeqView sq, int M, const 
       if (j == 0) { const int q = i - 1 + 64 + ph; rnext = (q < L) ? (int)s[q] : 0; }
       const int x = min(__builtin_amdgcn_readlane(rbuf, j), kKp - 1);
       if (j == 63) rbuf = rnext;
-      const int16_t *rw = s_rw + (size_t)x * (M + 1);
+      int em[C];
+      {
+        const int16_t *rw = s_rw + (size_t)x * S + lane * C;
+        if constexpr (C % 8 == 0) {
+#pragma unroll
+          for (int q = 0; q < C / 8; q++) {
+            const int4 v = *reinterpret_cast<const int4 *>(rw + 8 * q);
+            const int w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int h = 0; h < 4; h++) { em[8 * q + 2 * h] = (int16_t)(w[h] & 0xffff); em[8 * q + 2 * h + 1] = w[h] >> 16; }
+          }
+        } else if constexpr (C % 4 == 0) {
+#pragma unroll
+          for (int q = 0; q < C / 4; q++) {
+            const int2 v = *reinterpret_cast<const int2 *>(rw + 4 * q);
+            em[4 * q] = (int16_t)(v.x & 0xffff); em[4 * q + 1] = v.x >> 16; em[4 * q + 2] = (int16_t)(v.y & 0xffff); em[4 * q + 3] = v.y >> 16;
+          }
+        } else if constexpr (C % 2 == 0) {
+#pragma unroll
+          for (int q = 0; q < C / 2; q++) { const int v = *reinterpret_cast<const int *>(rw + 2 * q); em[2 * q] = (int16_t)(v & 0xffff); em[2 * q + 1] = v >> 16; }
+        } else {
+#pragma unroll
+          for (int q = 0; q < C; q++) em[q] = (int)rw[q];
+        }
+      }
       const int mIn = wave_shr1_i32(Mp[C - 1], -32768), iIn = wave_shr1_i32(Ip[C - 1], -32768), dIn = wave_shr1_i32(Dp[C - 1], -32768);
       int Mc[C], Ic[C], dcv[C], tdd[C];
       int xEl = -32768;
@@ -230,7 +260,7 @@ __global__ __launch_bounds__(256) void vit_wave_kernel(SeqView sq, int M, const 
       for (int k = 0; k < C; k++) {
         const int node = lane * C + k + 1;
         if (node <= M) {
-          const int4 tq = *reinterpret_cast<const int4 *>(s_tw + (size_t)node * 8);
+          const int4 tq = twq[k];
           const int tMM = (int16_t)(tq.x & 0xffff), tIM = (int16_t)(tq.x >> 16);
           const int tDM = (int16_t)(tq.y & 0xffff), tBM = (int16_t)(tq.y >> 16);
           const int tMD = (int16_t)(tq.z & 0xffff), tDD = (int16_t)(tq.z >> 16);
@@ -242,7 +272,7 @@ __global__ __launch_bounds__(256) void vit_wave_kernel(SeqView sq, int M, const 
           sv = max(sv, sat16(m1 + tMM));
           sv = max(sv, sat16(i1 + tIM));
           sv = max(sv, sat16(d1 + tDM));
-          sv = sat16(sv + (int)rw[node]);
+          sv = sat16(sv + em[k]);
           Mc[k] = sv;
           xEl = max(xEl, sv);
           dcv[k] = sat16(sv + tMD);
@@ -784,7 +814,7 @@ int launch_vit_wave(bath_hip_ctx *ctx, const bath_hip_oprofile *om, SeqView v, c
   if (ntodo == 0) return BATH_OK;
   const int C = columns_per_lane(om->M);
   const int grid = wave_grid(ctx, ntodo);
-  const size_t shmem = ((size_t)(om->M + 1) * 8 + (size_t)kKp * (om->M + 1)) * sizeof(int16_t);
+  const size_t shmem = ((size_t)kKp * vit_em_stride(om->M) + 64 * (size_t)C) * sizeof(int16_t);
   VitConsts c = vit_consts(om);
   const float *fsc = nullptr; const uint8_t *ssv = nullptr; WindowRec *wins = nullptr; int *wc = nullptr; int cap = 0; int32_t *kmm = nullptr;
   if (wa) { c.invP_vit = wa->invP_vit; c.invP_msv = wa->invP_msv; fsc = wa->d_filtersc; ssv = wa->d_ssv_scores; wins = (WindowRec *)wa->d_wins; wc = wa->d_win_count; cap = wa->win_cap; kmm = wa->d_kminmax; }

@@ -233,6 +233,46 @@ def test_wave_and_lane_envelope_kernels_agree(ctx, monkeypatch):
         assert abs(a[12] - b[12]) <= 1e-4 * max(1.0, abs(b[12]))
 
 
+@pytest.mark.parametrize("hmmfile", ["MET-ct4.bhmm", "PTH2.bhmm", "Caudal_act.bhmm"])
+def test_wave_and_lane_traceback_agree(ctx, monkeypatch, hmmfile):
+    """The optimal-accuracy traceback of an envelope, its alignment score and the posteriors of its columns by the whole wave
+    (std_trace_wave_kernel: look-ahead along the diagonal, the C flank 64 rows at a time, a lane per column afterwards) and by
+    one lane (BATH_HIP_STD_TRACE_LANE=1, the serial restatement of p7_OATrace): every field of every domain and every trace
+    column must be identical, bit for bit -- the two make the same decisions on the same values."""
+    path = ol.GOLDEN + "/" + hmmfile
+    model = ol.Model(path, 0)
+    rng = np.random.default_rng(7)
+    wins = []
+    for i, aa in enumerate(common.emit_from_model(rng, model, 40, flank=6, sharpen=1.3)):      # a soft model: indels and ragged ends
+        nt = np.array(common.revtranslate(rng, aa, model.basic), dtype=np.uint8)
+        w = np.concatenate([rng.integers(0, 4, size=int(rng.integers(3, 400))).astype(np.uint8), nt, rng.integers(0, 4, size=int(rng.integers(0, 300))).astype(np.uint8)])
+        if i % 5 == 0:
+            w[rng.integers(0, len(w), size=3)] = 4 + rng.integers(0, 11, size=3)               # degenerate nucleotides: the X rule of the alignment score
+        wins.append((3 - w[::-1]).astype(np.uint8) if i % 2 and w.max() < 4 else w)
+    out = []
+    for lane in ("0", "1"):
+        monkeypatch.setenv("BATH_HIP_STD_TRACE_LANE", lane)
+        hmm = ba.HMM(path, 0)
+        om = ba.OProfile(ctx, ba.Profile(hmm))
+        pipe = ba.Pipeline(ctx, om, fs_pipe=False, ncbi_table=hmm.ct)
+        _, dm, nskip = pipe.run_hits(ba.SeqBlock(ctx, wins))
+        tr = pipe.traces()
+        out.append((nskip, dm, tr))
+    (na, da, ta), (nb, db, tb) = out
+    assert na == nb and len(da) == len(db) >= 10
+    fields = ("window", "ienv", "jenv", "iali", "jali", "ihmm", "jhmm", "envsc", "oasc", "ali_columns", "pid", "cigar", "domcorrection", "bitscore", "lnP", "reported", "stops", "shifts")
+    kinds = set()
+    for a, b, (t1, st1, k1, i1, c1, pp1), (t2, st2, k2, i2, c2, pp2) in zip(da, db, ta, tb):
+        for f in fields:
+            if hasattr(a, f):
+                va, vb = getattr(a, f), getattr(b, f)
+                assert va == vb or (isinstance(va, float) and np.float32(va).view(np.uint32) == np.float32(vb).view(np.uint32)), (f, va, vb)
+        assert (t1.N, t1.win_start, t1.orf_start) == (t2.N, t2.win_start, t2.orf_start)
+        assert np.array_equal(st1, st2) and np.array_equal(k1, k2) and np.array_equal(i1, i2) and np.array_equal(pp1.view(np.uint32), pp2.view(np.uint32))
+        kinds |= set(int(x) for x in st1)
+    assert ba.T_M in kinds and (hmmfile != "MET-ct4.bhmm" or len(kinds) >= 2)
+
+
 def test_hits_with_a_1024_node_model(ctx, tmp_path):
     """BASELINE config 5 shape: 16 nodes per lane in the wave-per-envelope kernels, 4 lanes per ORF in SSV."""
     path = common.write_synthetic_bhmm(str(tmp_path / "s1024.bhmm"), 1024, seed=1024)
