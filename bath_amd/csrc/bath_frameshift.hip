@@ -1304,6 +1304,283 @@ __global__ void fs5_trace_kernel(SeqView dna, int M, int maxcodons, const float 
   out[job] = r;
 }
 
+// The same trace, correction and columns with the WAVE walking (round 5; fs5_trace_kernel above stays as the one-lane restatement the
+// tests compare with, BATH_HIP_FS_TRACE_LANE=1).  A lane on its own pays a trip to memory for every decision -- two per match step
+// (the optimal-accuracy cells, then the five codon-length posteriors of the cell it chose), one per residue of the correction loop,
+// several per column: ~2 ms for the longest envelope of a pass, at the tail of the pass.  Here all 64 lanes follow the same state
+// machine on uniform state and fill look-ahead buffers together:
+//   * a match run of whole codons walks the slope-3 diagonal: on entering cell (i, k) lane d fetches cell (i - 3d, k - d) -- its
+//     optimal-accuracy cells, B of its row, which transitions into node k - d + 1 exist, and its five codon-length posteriors
+//     (formed like the decoding kernels form them when the matrix was not stored) -- and the steps take them by v_readlane until
+//     a quasi-codon, an insert or a delete leaves the diagonal;
+//   * the C and N flanks are decided / written 64 rows at a time; the E state's first maximum is a lane-parallel scan + a wave
+//     reduction over (value, scan position);
+//   * the correction loop (rescore_isolated_domain_frameshift's walk over the residues, whose nucleotide window also shifts on
+//     iterations that do not advance -- kept as it is) runs serially on chunks of the trace and of the residues held a lane each,
+//     its table look-ups deferred to 64 at a time, its sum in the reference's order;
+//   * the columns are a lane each.
+__global__ __launch_bounds__(64) void fs5_trace_wave_kernel(SeqView dna, int M, int maxcodons, const float *__restrict__ tf, const uint8_t *__restrict__ codons,
+                                 const float *__restrict__ pp, const int64_t *__restrict__ pp_off, const float *__restrict__ px, const int64_t *__restrict__ x_off,
+                                 const float *__restrict__ oa, const int64_t *__restrict__ oa_off, const float *__restrict__ ox,
+                                 const float *__restrict__ null2 /* [n][Kp] */, uint2 *__restrict__ tbuf, const int64_t *__restrict__ t_off, FsTraceOut *__restrict__ out,
+                                 const uint8_t *__restrict__ indel_tab, const uint8_t *__restrict__ cons, uint16_t *__restrict__ steps,
+                                 const float *__restrict__ amino, int pitch, float *__restrict__ step_pp, int *__restrict__ col_cursor,
+                                 const float *__restrict__ bck, const int64_t *__restrict__ bck_off, const float *__restrict__ bcksc, const float *__restrict__ rowden) {
+  const int lane = threadIdx.x;
+  const int64_t job = blockIdx.x;
+  enum { sS = 0, sN, sB, sM, sD, sI, sE, sJ, sC, sT };
+  enum { XE = 0, XN, XJ, XB, XC };
+  const float kTiny = 1.17549435e-38f;
+  const int L = dna.len[job];
+  const uint8_t *dsq = dna.data + dna.off[job] - 1;             // dsq[1..L]
+  const float *P = pp + pp_off[job], *PX = px + x_off[job], *O = oa + oa_off[job], *OX = ox + x_off[job];
+  const float *BK = bck ? bck + bck_off[job] : nullptr, *RD = bck ? rowden + x_off[job] / 5 : nullptr;
+  const float overall = bck ? bcksc[job] : 0.f;
+  auto post = [&](int i, int k, int q) -> float {
+    const float f = P[((size_t)i * (M + 1) + k) * 8 + q];
+    if (!BK) return f;
+    if (q == 1 && k >= M) return 0.f;
+    const float b = BK[((size_t)i * (M + 1) + k) * 3 + (q == 1 ? 1 : 2)];
+    return expf(f + b - overall) * RD[i];
+  };
+  auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+  auto rlf = [](float v, int d) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), d)); };
+  uint2 *T = tbuf + t_off[job];
+  const int cap = (int)(t_off[job + 1] - t_off[job]);
+  FsTraceOut r{0, 0, 0, 0, 0, 0, 0.f, 0, 0, 0, 0.f, 0};
+  auto dl = [&](int node, int s) { return (node >= 1 && node <= M && tf[(size_t)node * 8 + s] != -INFINITY) ? 1.0f : kTiny; };
+  auto OM = [&](int i, int k) { return O[((size_t)i * (M + 1) + k) * 3 + 2]; };
+  auto OI = [&](int i, int k) { return O[((size_t)i * (M + 1) + k) * 3 + 1]; };
+  auto OD = [&](int i, int k) { return O[((size_t)i * (M + 1) + k) * 3 + 0]; };
+  auto entry = [](int st, int k, int i, int c) { return make_uint2((unsigned)st | ((unsigned)c << 8) | ((unsigned)k << 16), (unsigned)i); };
+  int n = 0;
+  auto push = [&](int st, int k, int i, int c) { if (n < cap && lane == 0) T[n] = entry(st, k, i, c); n++; };
+  int i = L, k = 0, c = 0, prev = sC;
+  bool bad = (L < 5);
+  push(sT, k, i, c); push(sC, k, i, c);
+  // the diagonal look-ahead: lane d holds cell (bi0 - 3 d, bk0 - d)
+  float bM = 0.f, bI = 0.f, bD = 0.f, bXB = 0.f, bd0 = 0.f, bd1 = 0.f, bd2 = 0.f, bd3 = 0.f, bp[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  int bi0 = -(1 << 28), bk0 = -(1 << 28);
+  while (!bad && prev != sS) {
+    i = uni(i); k = uni(k); prev = uni(prev); n = uni(n);
+    int cur = -1, dd = -1;
+    if (prev == sC) {
+      // rows i, i-1, ...: lane d decides row i - d; the rows that stay in C are written and skipped together
+      const int rr = i - lane;
+      bool stay = false;
+      if (rr >= 4) {
+        const float p0 = OX[(size_t)(rr - 3) * 5 + XC] + PX[(size_t)rr * 5 + XC];
+        const float p1 = (rr < L) ? OX[(size_t)(rr - 2) * 5 + XC] + PX[(size_t)(rr + 1) * 5 + XC] : kTiny;
+        const float p2 = (rr < L - 1) ? OX[(size_t)(rr - 1) * 5 + XC] + PX[(size_t)(rr + 2) * 5 + XC] : kTiny;
+        const float p3 = OX[(size_t)rr * 5 + XE];
+        float b = p0;
+        if (p1 > b) b = p1;
+        if (p2 > b) b = p2;
+        stay = !(p3 > b);
+      }
+      const unsigned long long m = __ballot(stay);
+      const int ns = (~m == 0ull) ? 64 : (__ffsll((long long)~m) - 1);
+      if (ns > 0) {
+        if (lane < ns && n + lane < cap) T[n + lane] = entry(sC, k, i - lane, 0);
+        n += ns; i -= ns;
+        if (n > cap) bad = true;
+        continue;
+      }
+      cur = sE;
+    } else if (prev == sN) {
+      // N(i) <- N(i-1) ... <- N(1), then S at row 0: one entry per row, nothing to read
+      for (int b0 = 0; b0 < i; b0 += 64) { const int rr = i - b0 - lane; if (rr >= 1 && n + b0 + lane < cap) T[n + b0 + lane] = entry(sN, k, rr, 0); }
+      n += i; i = 0;
+      push(sS, k, 0, 0);
+      if (n > cap) bad = true;
+      prev = sS;
+      continue;
+    } else if (prev == sM) {
+      dd = bk0 - (k - 1);
+      if (dd < 0 || dd >= 64 || bi0 - 3 * dd != i) {
+        bi0 = i; bk0 = k - 1; dd = 0;
+        const int ri = max(i - 3 * lane, 0), rk = max(k - 1 - lane, 0);
+        bM = OM(ri, rk); bI = OI(ri, rk); bD = OD(ri, rk); bXB = OX[(size_t)ri * 5 + XB];
+        bd0 = dl(rk + 1, 0); bd1 = dl(rk + 1, 1); bd2 = dl(rk + 1, 2); bd3 = dl(rk + 1, 3);
+#pragma unroll
+        for (int q = 0; q < 5; q++) bp[q] = post(ri, rk, 3 + q);
+      }
+      dd = uni(dd);
+      const float p0 = rlf(bd0, dd) * rlf(bM, dd), p1 = rlf(bd1, dd) * rlf(bI, dd), p2 = rlf(bd2, dd) * rlf(bD, dd), p3 = rlf(bd3, dd) * rlf(bXB, dd);
+      cur = sM; float b = p0;
+      if (p1 > b) { b = p1; cur = sI; }
+      if (p2 > b) { b = p2; cur = sD; }
+      if (p3 > b) { b = p3; cur = sB; }
+      k--;
+    } else if (prev == sD) {
+      const float p0 = dl(k - 1, 4) * OM(i, max(k - 1, 0)), p1 = dl(k - 1, 5) * OD(i, max(k - 1, 0));
+      cur = p0 >= p1 ? sM : sD; k--;
+    } else if (prev == sI) {
+      const float p0 = dl(k, 6) * OM(max(i - 3, 0), k), p1 = dl(k, 7) * OI(max(i - 3, 0), k);
+      cur = p0 >= p1 ? sM : sI; i -= 3;
+    } else if (prev == sJ) {
+      if (i <= 5) cur = sE;
+      else { const float p0 = OX[(size_t)i * 5 + XJ] + PX[(size_t)i * 5 + XJ], p1 = kTiny * OX[(size_t)i * 5 + XE]; cur = (p1 > p0) ? sE : sJ; }
+    } else if (prev == sE) {
+      // the first maximum of M(i,1), D(i,1), M(i,2), D(i,2), ... (a later cell must be strictly larger)
+      float mx = -INFINITY; int pos = 1 << 30;
+      for (int q = 1 + lane; q <= M; q += 64) {
+        const float m = OM(i, q), d = OD(i, q);
+        if (m > mx) { mx = m; pos = 2 * q; }
+        if (d > mx) { mx = d; pos = 2 * q + 1; }
+      }
+      const float best = wave_max_f32(mx);
+      const int bpos = wave_min_i32((mx == best && best > -INFINITY) ? pos : (1 << 30));
+      if (bpos >= (1 << 30)) bad = true;
+      else { k = bpos >> 1; cur = (bpos & 1) ? sD : sM; }
+    } else if (prev == sB) {
+      cur = (OX[(size_t)i * 5 + XN] > OX[(size_t)i * 5 + XJ]) ? sN : sJ;
+    } else bad = true;
+    if (bad || cur < 0 || k < 0 || i < 0) { bad = true; break; }
+    if (cur == sM) {
+      float v0, v1, v2, v3, v4;
+      if (prev == sM) { v0 = rlf(bp[0], dd); v1 = rlf(bp[1], dd); v2 = rlf(bp[2], dd); v3 = rlf(bp[3], dd); v4 = rlf(bp[4], dd); }
+      else { v0 = post(i, k, 3); v1 = post(i, k, 4); v2 = post(i, k, 5); v3 = post(i, k, 6); v4 = post(i, k, 7); }
+      c = 1; float b = v0;
+      if (v1 > b) { b = v1; c = 2; }
+      if (v2 > b) { b = v2; c = 3; }
+      if (v3 > b) { b = v3; c = 4; }
+      if (v4 > b) { b = v4; c = 5; }
+    } else c = 0;
+    push(cur, k, i, c);
+    if ((cur == sN || cur == sC || cur == sJ) && cur == prev) i--;
+    prev = cur;
+    i -= c;
+    if (n > cap) bad = true;
+  }
+  if (bad) { if (lane == 0) out[job] = r; return; }
+  __threadfence();                                                            // the trace entries, written by lane 0 or a lane each, read below by every lane
+  {
+    // forward order = T[n-1] .. T[0]
+    const float *n2 = null2 + (size_t)job * kKp;
+    // the first and the last match state
+    int z1 = n, z2 = -1;
+    for (int zb = 0; zb < n; zb += 64) {
+      const int z = zb + lane;
+      const bool isM = z < n && (int)(T[n - 1 - z].x & 0xffu) == sM;
+      const unsigned long long m = __ballot(isM);
+      if (m) { if (z1 == n) z1 = zb + __ffsll((long long)m) - 1; z2 = zb + 63 - __clzll((long long)m); }
+    }
+    if (z1 < n && z2 >= 0) {
+      r.ok = 1;
+      const uint2 e1 = T[n - 1 - z1], e2 = T[n - 1 - z2];
+      r.ihmm = (int)(e1.x >> 16); r.jhmm = (int)(e2.x >> 16);
+      r.iali = (int)e1.y - ((int)((e1.x >> 8) & 0xffu) - 1); r.jali = (int)e2.y;
+      // ---- the correction: the reference's loop over the residues, on chunks of the trace and of the residues held a lane each
+      float corr = 0.f;
+      int nshift = 0;
+      {
+        int t = -1, u = -1, v = -1, w = -1, x = -1, pos = 1, z = 0;
+        int zb = 0, pb = 1;                                                   // the chunks: lane l holds entry zb + l, residue pb + l
+        uint2 te = (zb + lane < n) ? T[n - 1 - (zb + lane)] : make_uint2(0u, 0u);
+        int re = (pb + lane <= L) ? (int)dsq[pb + lane] : 0;
+        int pk = 0, pc = 0, npend = 0;                                        // pending look-ups: lane e holds (node, codon index) of the e-th
+        auto flush = [&]() {
+          float sc = 0.f;
+          if (lane < npend) sc = logf(n2[codons[(size_t)pk * maxcodons + pc]]);
+          for (int l = 0; l < npend; l++) { const float q = rlf(sc, l); if (q != -INFINITY) corr += q; }
+          npend = 0;
+        };
+        while (pos <= L && z < n) {
+          pos = uni(pos); z = uni(z);
+          if (z - zb >= 64) { zb = z; te = (zb + lane < n) ? T[n - 1 - (zb + lane)] : make_uint2(0u, 0u); }
+          if (pos - pb >= 64) { pb = pos; re = (pb + lane <= L) ? (int)dsq[pb + lane] : 0; }
+          const int rv = __builtin_amdgcn_readlane(re, pos - pb);
+          x = rv < 4 ? rv : 1367;
+          const unsigned ex = (unsigned)__builtin_amdgcn_readlane((int)te.x, z - zb);
+          const int ei = __builtin_amdgcn_readlane((int)te.y, z - zb);
+          const int s = (int)(ex & 0xffu), cz = (int)((ex >> 8) & 0xffu), kz = (int)(ex >> 16);
+          if (s == sN || s == sC || s == sJ) { if (ei == pos && pos > 2) pos++; z++; }
+          else if (s == sM || s == sI) {
+            if (ei == pos) {
+              int ci, capi;
+              if (s == sI) { ci = x * 341 + w * 85 + v * 21 + 2; capi = 1364; }
+              else {
+                switch (cz) {
+                case 1: ci = x * 341; capi = 1366; break;
+                case 2: ci = x * 341 + w * 85 + 1; capi = 1365; break;
+                case 3: ci = x * 341 + w * 85 + v * 21 + 2; capi = 1364; break;
+                case 4: ci = x * 341 + w * 85 + v * 21 + u * 5 + 3; capi = 1365; break;
+                default: ci = x * 341 + w * 85 + v * 21 + u * 5 + t + 4; capi = 1366; break;
+                }
+                if (cz != 3) nshift++;
+              }
+              if (lane == npend) { pk = kz; pc = min(ci, capi); }
+              if (++npend == 64) flush();
+              z++;
+            }
+            pos++;
+          } else z++;
+          t = u; u = v; v = w; w = x;
+        }
+        flush();
+      }
+      r.nshift = nshift;
+      r.domcorrection = corr;
+      // ---- the columns (p7_alidisplay_fs_Create, p7_pli_computeAliScores_BATH), a lane each; the score summed in column order
+      r.ncol = z2 - z1 + 1;
+      int col_off = 0;
+      if (steps) { if (lane == 0) col_off = atomicAdd(col_cursor, r.ncol); col_off = uni(col_off); }
+      r.col_off = col_off;
+      uint16_t *S = steps ? steps + col_off : nullptr;
+      float *SP = (steps && step_pp) ? step_pp + col_off : nullptr;
+      float ali = 0.f;
+      int nstops = 0, exact = 0;
+      for (int zb = z1; zb <= z2; zb += 64) {
+        const int zz = zb + lane;
+        const bool in = zz <= z2;
+        float colsc = 0.f;
+        bool stop = false, same = false;
+        if (in) {
+          const uint2 e = T[n - 1 - zz];
+          const int s = (int)(e.x & 0xffu), cc0 = (int)((e.x >> 8) & 0xffu), kk = (int)(e.x >> 16), ii = (int)e.y;
+          const int prevs = (zz == z1) ? (int)sB : (int)(T[n - zz].x & 0xffu);
+          const int cc = (s == sM) ? cc0 : (s == sI ? 3 : 0);
+          unsigned code = (unsigned)s;
+          if (s == sI) colsc = tf[(size_t)kk * 8 + (prevs == sI ? 7 : 6)];
+          else if (s == sD) colsc = tf[(size_t)(kk - 1) * 8 + (prevs == sD ? 5 : 4)];
+          if (cc > 0 && ii - cc + 1 >= 1 && ii <= L) {
+            int nn[5] = {0, 0, 0, 0, 0};
+            bool degen = false;
+            for (int q = 0; q < cc; q++) { nn[q] = dsq[ii - cc + 1 + q]; degen |= nn[q] >= 4; }
+            int ci;
+            switch (cc) {
+            case 1: ci = degen ? 1366 : nn[0] * 341; break;
+            case 2: ci = degen ? 1365 : nn[1] * 341 + nn[0] * 85 + 1; break;
+            case 3: ci = degen ? 1364 : nn[2] * 341 + nn[1] * 85 + nn[0] * 21 + 2; break;
+            case 4: ci = degen ? 1365 : nn[3] * 341 + nn[2] * 85 + nn[1] * 21 + nn[0] * 5 + 3; break;
+            default: ci = degen ? 1366 : nn[4] * 341 + nn[3] * 85 + nn[2] * 21 + nn[1] * 5 + nn[0] + 4; break;
+            }
+            const int indel = indel_tab ? indel_tab[(size_t)kk * maxcodons + ci] : 5;
+            stop = (cc == 3) && (indel == 6 || indel == 7 || indel == 8);
+            same = s == sM && cons && codons[(size_t)kk * maxcodons + ci] == cons[kk];
+            code |= (unsigned)cc << 4 | (unsigned)indel << 8;
+            if (s == sM && amino) {
+              colsc = amino[(size_t)codons[(size_t)kk * maxcodons + ci] * pitch + kk];
+              if (prevs == sI) colsc += tf[(size_t)kk * 8 + 1];
+              else if (prevs == sD) colsc += tf[(size_t)kk * 8 + 2];
+              else if (prevs == sM && zz < z2) colsc += tf[(size_t)kk * 8 + 0];
+            }
+          }
+          if (S) S[zz - z1] = (uint16_t)code;
+          if (SP) SP[zz - z1] = (s == sM) ? post(ii, kk, 2) : (s == sI ? post(ii, kk, 1) : 0.0f);
+        }
+        nstops += __popcll(__ballot(stop)); exact += __popcll(__ballot(same));
+        const int nin = min(64, z2 - zb + 1);
+        for (int l = 0; l < nin; l++) ali += rlf(colsc, l);
+      }
+      r.nstops = nstops; r.exact = exact;
+      r.aliscore = ali;
+    }
+  }
+  if (lane == 0) out[job] = r;
+}
+
 __global__ void fs5_null2_kernel(int64_t n, const int32_t *__restrict__ len, int M, int pitch, const float *__restrict__ amino /* rsc + maxcodons*pitch */,
                                  const float *__restrict__ logsum, const float *__restrict__ colsum, float *__restrict__ null2 /* [n][Kp] */) {
   const int64_t job = blockIdx.x;
@@ -1914,7 +2191,15 @@ int bath::fs5_envelopes_ex(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, cons
     int64_t *d_toff = reinterpret_cast<int64_t *>(b_tb.as<char>() + ((size_t)toff[(size_t)n] * sizeof(uint2) + 255) / 256 * 256);
     BATH_HIP_TRY(ctx, hipMemcpyAsync(d_toff, toff.data(), (size_t)(n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
     const int s6 = ctx->span_begin("fs5_trace_kernel", ctx->stream, (double)toff[(size_t)n], 0.0);
+    const bool lane_trace = [] { const char *e = std::getenv("BATH_HIP_FS_TRACE_LANE"); return e && e[0] == '1'; }();      // A/B and tests: the walk by one lane
+    if (lane_trace)
     hipLaunchKernelGGL(fs5_trace_kernel, dim3((unsigned)((n * kTraceSpread + 63) / 64)), dim3(64), 0, ctx->stream, dna->view(), M, om->maxcodons, om->d_tf, om->d_codons,
+                       b_f.as<float>(), d_foff, b_fx.as<float>(), d_xoff, b_o.as<float>(), d_boff, b_ox.as<float>(), b_n2.as<float>(), b_tb.as<uint2>(), d_toff,
+                       b_to.as<FsTraceOut>(), om->d_indel, cons, d_steps,
+                       om->d_rsc + (size_t)om->maxcodons * om->pitch, om->pitch, step_pp ? d_step_pp : nullptr, d_cursor,
+                       store_pp ? nullptr : b_b.as<float>(), d_boff, d_bsc, d_rowden);
+    else
+    hipLaunchKernelGGL(fs5_trace_wave_kernel, dim3((unsigned)n), dim3(64), 0, ctx->stream, dna->view(), M, om->maxcodons, om->d_tf, om->d_codons,
                        b_f.as<float>(), d_foff, b_fx.as<float>(), d_xoff, b_o.as<float>(), d_boff, b_ox.as<float>(), b_n2.as<float>(), b_tb.as<uint2>(), d_toff,
                        b_to.as<FsTraceOut>(), om->d_indel, cons, d_steps,
                        om->d_rsc + (size_t)om->maxcodons * om->pitch, om->pitch, step_pp ? d_step_pp : nullptr, d_cursor,

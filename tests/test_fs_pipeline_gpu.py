@@ -359,3 +359,45 @@ def test_scheduling_switches_do_not_change_the_hits(gpu_ctx, monkeypatch, switch
         out.append((nskip, sorted((d.window, d.fs_window, d.ienv, d.jenv, d.iali, d.jali, d.ihmm, d.jhmm, d.envsc, d.oasc, d.domcorrection, d.bitscore, d.lnP,
                                    d.n_shifted_codons, d.n_stops, d.pid, d.cigar) for d in dm)))
     assert out[0] == out[1] and len(out[0][1]) >= 10 and out[0][0] >= 1        # at least one clustered region went through the ensembles
+
+
+@pytest.mark.parametrize("name", ["Caudal_act.bhmm", "PTH2.bhmm", "2OG-FeII_Oxy_3.bhmm"])
+def test_wave_and_lane_frameshift_traceback_agree(gpu_ctx, monkeypatch, name):
+    """p7_OATrace_Frameshift, the null2 correction over the aligned residues and the alignment columns of an envelope by the whole
+    wave (fs5_trace_wave_kernel: look-ahead along the slope-3 diagonal, flanks 64 rows at a time, a lane per column) and by one lane
+    (BATH_HIP_FS_TRACE_LANE=1, the serial restatement): every field of every domain and every trace column -- state, node,
+    position, codon length, posterior -- must be identical bit for bit; the two make the same decisions on the same values."""
+    rng = np.random.default_rng(131)
+    path = ol.GOLDEN + "/" + name
+    model = ol.Model(path, 0)
+    wins = frameshifted_windows(rng, model, n=36)
+    for q in range(0, len(wins), 7):                                      # degenerate nucleotides: the X rule of the columns' scores
+        wins[q] = wins[q].copy()
+        wins[q][rng.integers(0, len(wins[q]), size=2)] = 4 + rng.integers(0, 11, size=2)
+    hmm = ba.HMM(path, 0)
+    om = ba.OProfile(gpu_ctx, ba.Profile(hmm))
+    om3 = ba.FSOProfile(gpu_ctx, ba.FSProfile(hmm, 3, ncbi_table=hmm.ct))
+    om5 = ba.FSOProfile(gpu_ctx, ba.FSProfile(hmm, 5, ncbi_table=hmm.ct))
+    pipe = ba.Pipeline(gpu_ctx, om, fs_pipe=True, ncbi_table=hmm.ct)
+    out = []
+    for lane in ("0", "1"):
+        monkeypatch.setenv("BATH_HIP_FS_TRACE_LANE", lane)
+        _, fw, dm, nskip = pipe.run_frameshift_domains(om3, om5, ba.SeqBlock(gpu_ctx, wins))
+        out.append((nskip, dm, pipe.traces()))
+    (na, da, ta), (nb, db, tb) = out
+    assert na == nb and len(da) == len(db) >= 10
+    nfs = nshift = 0
+    bits = lambda v: np.float32(v).view(np.uint32)
+    for a, b, (t1, st1, k1, i1, c1, pp1), (t2, st2, k2, i2, c2, pp2) in zip(da, db, ta, tb):
+        ka = (a.window, a.fs_window, a.ienv, a.jenv, a.iali, a.jali, a.ihmm, a.jhmm, a.n_shifted_codons, a.n_stops, a.pid, a.cigar, a.reported)
+        kb = (b.window, b.fs_window, b.ienv, b.jenv, b.iali, b.jali, b.ihmm, b.jhmm, b.n_shifted_codons, b.n_stops, b.pid, b.cigar, b.reported)
+        assert ka == kb
+        for f in ("envsc", "oasc", "domcorrection", "bitscore", "lnP"):
+            assert bits(getattr(a, f)) == bits(getattr(b, f)), (f, getattr(a, f), getattr(b, f))
+        assert (t1.N, t1.win_start, t1.frameshift) == (t2.N, t2.win_start, t2.frameshift)
+        assert np.array_equal(st1, st2) and np.array_equal(k1, k2) and np.array_equal(i1, i2) and np.array_equal(c1, c2)
+        assert np.array_equal(pp1.view(np.uint32), pp2.view(np.uint32))
+        if t1.frameshift:
+            nfs += 1
+            nshift += int((c1[st1 == ba.T_M] != 3).sum())
+    assert nfs >= 5 and nshift >= 3                                       # quasi-codons: where the walk leaves the slope-3 diagonal
