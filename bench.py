@@ -1284,7 +1284,7 @@ def fs_leg(ba, synth, ctx, hmm, om, args, data=None, cpu=None):
                      "frac": env_bytes / (env_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if env_ms > 0 else None,
                      "alone": alone,
                      "note": "5-codon envelope kernels: algorithmic matrix bytes (Forward writes 32, Backward writes 12 + 4 for the B terms, the fused decoding + "
-                             "optimal-accuracy pass reads 44 and writes 44 per cell) / sum of their device times.  Forward and Backward are row-per-lane "
+                             "optimal-accuracy pass reads 44 and writes 12 per cell -- the posterior matrix is not written in pipeline mode, the traceback forms the posteriors it reads) / sum of their device times.  Forward and Backward are row-per-lane "
                              "wavefronts (bath_fs_wavefront.hip): a lane writes its own row, so their stores are 12-32 B pieces of 64 different lines per "
                              "instruction -- bound by memory requests issued, not by bytes (DESIGN.md 4.6)"},
         "mode": "strict (the library's default): every sum along the model in the reference's serial order; scores, special-state rows and matrices "
