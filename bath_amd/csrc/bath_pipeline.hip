@@ -92,7 +92,16 @@ __global__ __launch_bounds__(256, NR <= 76 ? 4 : 1) void ssv_orf_kernel(const ui
     OrfRec rec{0, 0, 0};
     if (live) rec = orfs[t];
     const int L = rec.len_sf & 0x0fffffff;
+#ifdef BATH_SSV_POOL_PROBE
+    // Timing probe (WRONG results; tools/ssv_pool_probe.sh): the residue reads as they would be from a pool written in work-list
+    // order and interleaved per wave -- the 8 bytes of a wave's 64 lanes contiguous (512 B per load instruction), a wave's groups
+    // one after the other -- i.e. with NO over-fetch: what the SSV kernel itself could gain from such a pool, before the pool's cost
+    const uint8_t *s = aa + ((size_t)(tb / TPW) * 8192) % ((size_t)1 << 27) + (size_t)lane * 8;
+#define BATH_SSV_RES(i8) (s + (size_t)(i8) * 64)
+#else
     const uint8_t *s = aa + rec.aa_off;
+#define BATH_SSV_RES(i8) (s + (i8))
+#endif
     const int Lw = wave_max_i32(L);
     s16x2 reg[NR];
 #pragma unroll
@@ -103,10 +112,10 @@ __global__ __launch_bounds__(256, NR <= 76 ? 4 : 1) void ssv_orf_kernel(const ui
     // multiple of 4 rows).  Staging the residues through LDS instead (three global_load_lds_dwordx4 per wave and 32 rows, double
     // buffered) was measured at -2% time and -20% traffic and not kept: most of the excess traffic is 128-byte lines shared by
     // ORFs of different lengths, which no read pattern of this kernel can merge.
-    uint64_t qnext = (0 < L) ? *reinterpret_cast<const uint64_t *>(s) : 0x1d1d1d1d1d1d1d1dull;
+    uint64_t qnext = (0 < L) ? *reinterpret_cast<const uint64_t *>(BATH_SSV_RES(0)) : 0x1d1d1d1d1d1d1d1dull;
     for (int i0 = 0; i0 < Lw; i0 += 8) {
       const uint64_t q = qnext;
-      qnext = (i0 + 8 < L) ? *reinterpret_cast<const uint64_t *>(s + i0 + 8) : 0x1d1d1d1d1d1d1d1dull;
+      qnext = (i0 + 8 < L) ? *reinterpret_cast<const uint64_t *>(BATH_SSV_RES(i0 + 8)) : 0x1d1d1d1d1d1d1d1dull;
       const int nrow = min(8, Lw - i0);                              // wave-uniform
       // the row's overhead is kept to full-rate 32-bit ops: a bit-field extract on the dword holding the residue (no 64-bit
       // shift), a 24-bit multiply for the row offset (v_mul_lo_u32 is quarter rate); bytes inside an ORF are residue codes < 29
