@@ -200,7 +200,7 @@ struct bath_hip_ctx {
   // page-locked staging for small tables a launch uploads (job order, batch starts, offsets): an asynchronous copy from here needs
   // no synchronize before the local it was built in goes away.  One slot per call site; a site is reused by its context only
   // after the stage that used it has synchronized its stream.  [0] fs_schedule, [1]/[2] chain_batches (Forward / Backward), [3] wavefront Backward
-  bath::HostBuf stage[4];
+  bath::HostBuf stage[6];                 // ... [4] / [5]: the standard branch's domain stage, its small uploads / downloads (bath_domaindef.hip: std_domains)
   template <class T> int stage_upload(int slot, void *dst, const T *src, size_t n, hipStream_t s) {
     if (stage[slot].reserve(n * sizeof(T) + 64) != hipSuccess) { set_error("cannot allocate page-locked staging memory"); return BATH_EFAIL; }
     std::memcpy(stage[slot].p, src, n * sizeof(T));

@@ -1383,18 +1383,36 @@ static int std_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bat
     xoff[(size_t)i + 1] = xoff[(size_t)i] + ((int64_t)surv[(size_t)i].n + 1) * 6;
   }
   DevBuf &b_idx = ctx->scratch[0], &b_fx = ctx->scratch[6], &b_bx = ctx->scratch[7], &b_sc = ctx->scratch[2], &b_st = ctx->scratch[3], &b_work = ctx->scratch[4], &b_reg = ctx->scratch[5];
+  // The small transfers of a stage go through page-locked memory (ctx->stage[4] up, [5] down): a hipMemcpyAsync from or to
+  // pageable memory is staged by the runtime and holds the host ~20 us, and one query's domain stage had two dozen of them -- a
+  // fifth of its time on a 12.5 Mb block (configs[3]).  up_begin() sizes the staging area for ALL uploads of a stage (it may move
+  // while nothing is in flight: every stage ends with a synchronize); a sequence view's three arrays travel as ONE copy.
+  size_t up_used = 0;
+  auto up_begin = [&](size_t bytes) -> int { up_used = 0; BATH_HIP_TRY(ctx, ctx->stage[4].reserve(bytes + 1024)); return BATH_OK; };
+  auto up = [&](void *dst, std::initializer_list<std::pair<const void *, size_t>> parts) -> int {
+    char *h = static_cast<char *>(ctx->stage[4].p) + up_used;
+    size_t bytes = 0;
+    for (const auto &q : parts) { std::memcpy(h + bytes, q.first, q.second); bytes += q.second; }
+    up_used += (bytes + 63) & ~(size_t)63;
+    if (up_used > ctx->stage[4].cap) { ctx->set_error("staging area of the domain stage too small"); return BATH_EFAIL; }
+    BATH_HIP_TRY(ctx, hipMemcpyAsync(dst, h, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return BATH_OK;
+  };
+  auto view_bytes = [](int64_t n) { return (size_t)n * 12 + (size_t)(n + 1) * 8 + 256; };
   auto upload_view = [&](bath_hip_seqs &v, const std::vector<int64_t> &xo, int64_t n) -> int {
-    BATH_HIP_TRY(ctx, b_idx.reserve((size_t)n * 12 + (size_t)(n + 1) * 8 + 256));
+    BATH_HIP_TRY(ctx, b_idx.reserve(view_bytes(n)));
     int64_t *d_off = b_idx.as<int64_t>();
     int64_t *d_xo = d_off + n;
     int32_t *d_len = reinterpret_cast<int32_t *>(d_xo + n + 1);
-    BATH_HIP_TRY(ctx, hipMemcpyAsync(d_off, v.h_off.data(), (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
-    BATH_HIP_TRY(ctx, hipMemcpyAsync(d_xo, xo.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-    BATH_HIP_TRY(ctx, hipMemcpyAsync(d_len, v.h_len.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    const int rc = up(d_off, {{v.h_off.data(), (size_t)n * 8}, {xo.data(), (size_t)(n + 1) * 8}, {v.h_len.data(), (size_t)n * 4}});      // contiguous on the device too
+    if (rc != BATH_OK) return rc;
     v.d_data = const_cast<uint8_t *>(d_pool); v.d_off = d_off; v.d_len = d_len;
     return BATH_OK;
   };
+  // downloads: into page-locked memory, then (after the stage's synchronize) a host copy into the vector the code reads
+  auto down_reserve = [&](size_t bytes) -> int { BATH_HIP_TRY(ctx, ctx->stage[5].reserve(bytes + 1024)); return BATH_OK; };
   if ((st = om->ensure_len_tables(view.maxlen)) != BATH_OK) return st;
+  if ((st = up_begin(view_bytes(ns))) != BATH_OK) return st;
   if ((st = upload_view(view, xoff, ns)) != BATH_OK) return st;
   const int64_t *d_xoff = b_idx.as<int64_t>() + ns;
   BATH_HIP_TRY(ctx, b_fx.reserve((size_t)xoff[(size_t)ns] * 4 + 64)); BATH_HIP_TRY(ctx, b_bx.reserve((size_t)xoff[(size_t)ns] * 4 + 64));
@@ -1417,8 +1435,10 @@ static int std_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bat
   }
   BATH_HIP_TRY(ctx, hipGetLastError());
   std::vector<int32_t> regions((size_t)ns * RS);
-  BATH_HIP_TRY(ctx, hipMemcpyAsync(regions.data(), b_reg.p, regions.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if ((st = down_reserve(regions.size() * 4)) != BATH_OK) return st;
+  BATH_HIP_TRY(ctx, hipMemcpyAsync(ctx->stage[5].p, b_reg.p, regions.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
   BATH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  std::memcpy(regions.data(), ctx->stage[5].p, regions.size() * 4);
   view.d_data = nullptr; view.d_off = nullptr; view.d_len = nullptr;
   clk.lap("std:   parsers + regions");
 
@@ -1448,12 +1468,13 @@ static int std_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bat
       mxoff[(size_t)e + 1] = mxoff[(size_t)e] + ((int64_t)Lr + 1) * 6;
       mdpoff[(size_t)e + 1] = mdpoff[(size_t)e] + ((int64_t)Lr + 1) * (M + 1) * 3;
     }
+    if ((st = up_begin(view_bytes(nm) + (size_t)(nm + 1) * 8 + (size_t)nm * 4 + 256)) != BATH_OK) return st;
     if ((st = upload_view(mv, mxoff, nm)) != BATH_OK) return st;
     DevBuf &b_mdpo = ctx->scratch[20], &b_cfg = ctx->scratch[5];
     BATH_HIP_TRY(ctx, b_mdpo.reserve((size_t)(nm + 1) * 8)); BATH_HIP_TRY(ctx, b_cfg.reserve((size_t)nm * 4 + 64));
     BATH_HIP_TRY(ctx, b_fx.reserve((size_t)mxoff[(size_t)nm] * 4 + 64)); BATH_HIP_TRY(ctx, b_sc.reserve((size_t)nm * 8)); BATH_HIP_TRY(ctx, b_st.reserve((size_t)nm * 8));
-    BATH_HIP_TRY(ctx, hipMemcpyAsync(b_mdpo.p, mdpoff.data(), (size_t)(nm + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-    BATH_HIP_TRY(ctx, hipMemcpyAsync(b_cfg.p, cfg.data(), (size_t)nm * 4, hipMemcpyHostToDevice, ctx->stream));
+    if ((st = up(b_mdpo.p, {{mdpoff.data(), (size_t)(nm + 1) * 8}})) != BATH_OK) return st;
+    if ((st = up(b_cfg.p, {{cfg.data(), (size_t)nm * 4}})) != BATH_OK) return st;
     // The matrices, the special-state rows and the regions' residues are for the host (the ensembles' tracebacks): the kernels
     // write them straight into page-locked host memory, the transfer rides along with the computation.  Residues of region e:
     // h_res + roff[e], one row's worth of bytes per residue row (roff = the x-row offsets / 6).
@@ -1512,6 +1533,7 @@ static int std_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bat
     exoff[(size_t)e + 1] = exoff[(size_t)e] + ((int64_t)Ld + 1) * 6;
     dpoff[(size_t)e + 1] = dpoff[(size_t)e] + ((int64_t)Ld + 1) * (M + 1) * 3;
   }
+  if ((st = up_begin(view_bytes(ne) + (size_t)(4 * ne + 2) * 8 + 512)) != BATH_OK) return st;      // the view, the columns' offsets (3 ne + 1), the matrices' (ne + 1)
   if ((st = upload_view(ev, exoff, ne)) != BATH_OK) return st;
   const int64_t *d_exoff = b_idx.as<int64_t>() + ne;
   DevBuf &b_f = ctx->scratch[15], &b_b = ctx->scratch[16], &b_dpo = ctx->scratch[20], &b_px = ctx->scratch[18], &b_ox = ctx->scratch[19], &b_em = ctx->scratch[22], &b_out = ctx->scratch[21];
@@ -1539,9 +1561,9 @@ static int std_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bat
   int *d_col_cursor = reinterpret_cast<int *>(b_tb.as<char>() + tb_cols);
   float *d_col_pp = reinterpret_cast<float *>(b_tb.as<char>() + tb_cols + 256);
   BATH_HIP_TRY(ctx, hipMemsetAsync(d_col_cursor, 0, sizeof(int), ctx->stream));
-  BATH_HIP_TRY(ctx, hipMemcpyAsync(b_toff.p, toff.data(), toff.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+  if ((st = up(b_toff.p, {{toff.data(), toff.size() * 8}})) != BATH_OK) return st;
   BATH_HIP_TRY(ctx, b_sc.reserve((size_t)ne * 8)); BATH_HIP_TRY(ctx, b_st.reserve((size_t)ne * 8));
-  BATH_HIP_TRY(ctx, hipMemcpyAsync(b_dpo.p, dpoff.data(), (size_t)(ne + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+  if ((st = up(b_dpo.p, {{dpoff.data(), (size_t)(ne + 1) * 8}})) != BATH_OK) return st;
   if ((st = launch_fwd_wave(ctx, om, ev.view(), nullptr, ne, b_sc.as<float>(), b_st.as<int32_t>(), nullptr, b_fx.as<float>(), d_exoff, b_f.as<float>(), b_dpo.as<int64_t>(), 1)) != BATH_OK) return st;
   if ((st = launch_bwd_wave(ctx, om, ev.view(), ne, b_fx.as<float>(), d_exoff, b_sc.as<float>() + ne, b_st.as<int32_t>() + ne, b_bx.as<float>(), b_b.as<float>(), b_dpo.as<int64_t>(), 1)) != BATH_OK) return st;
   // decoding + OA fill + null2: a wave per envelope; then the traceback, a lane per envelope.  BATH_HIP_STD_SERIAL=1 (tests) or a
@@ -1577,16 +1599,28 @@ static int std_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bat
   std::vector<uint8_t> tcols((size_t)toff[(size_t)ne]);
   std::vector<float> col_pp;
   {
-    int total = 0;
-    BATH_HIP_TRY(ctx, hipMemcpyAsync(&total, d_col_cursor, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    // what does not depend on the number of columns first (with the count), then the columns' posteriors
+    const size_t o_tc = 64, o_eo = o_tc + ((tcols.size() + 63) & ~(size_t)63), o_sc = o_eo + (((size_t)ne * sizeof(StdEnvOut) + 63) & ~(size_t)63), o_end = o_sc + (size_t)ne * 4;
+    if ((st = down_reserve(o_end)) != BATH_OK) return st;
+    char *h = static_cast<char *>(ctx->stage[5].p);
+    BATH_HIP_TRY(ctx, hipMemcpyAsync(h, d_col_cursor, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    BATH_HIP_TRY(ctx, hipMemcpyAsync(h + o_tc, b_tb.p, tcols.size(), hipMemcpyDeviceToHost, ctx->stream));
+    BATH_HIP_TRY(ctx, hipMemcpyAsync(h + o_eo, b_out.p, (size_t)ne * sizeof(StdEnvOut), hipMemcpyDeviceToHost, ctx->stream));
+    BATH_HIP_TRY(ctx, hipMemcpyAsync(h + o_sc, b_sc.p, (size_t)ne * 4, hipMemcpyDeviceToHost, ctx->stream));
     BATH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    int total = 0;
+    std::memcpy(&total, h, sizeof(int));
+    std::memcpy(tcols.data(), h + o_tc, tcols.size());
+    std::memcpy(eo.data(), h + o_eo, (size_t)ne * sizeof(StdEnvOut));
+    std::memcpy(envsc.data(), h + o_sc, (size_t)ne * 4);
     col_pp.resize((size_t)total);
-    if (total > 0) BATH_HIP_TRY(ctx, hipMemcpyAsync(col_pp.data(), d_col_pp, (size_t)total * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    if (total > 0) {
+      if ((st = down_reserve((size_t)total * sizeof(float))) != BATH_OK) return st;
+      BATH_HIP_TRY(ctx, hipMemcpyAsync(ctx->stage[5].p, d_col_pp, (size_t)total * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+      BATH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+      std::memcpy(col_pp.data(), ctx->stage[5].p, (size_t)total * sizeof(float));
+    }
   }
-  BATH_HIP_TRY(ctx, hipMemcpyAsync(tcols.data(), b_tb.p, tcols.size(), hipMemcpyDeviceToHost, ctx->stream));
-  BATH_HIP_TRY(ctx, hipMemcpyAsync(eo.data(), b_out.p, (size_t)ne * sizeof(StdEnvOut), hipMemcpyDeviceToHost, ctx->stream));
-  BATH_HIP_TRY(ctx, hipMemcpyAsync(envsc.data(), b_sc.p, (size_t)ne * 4, hipMemcpyDeviceToHost, ctx->stream));
-  BATH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   ev.d_data = nullptr; ev.d_off = nullptr; ev.d_len = nullptr;
   clk.lap("std:   envelope kernels");
 
