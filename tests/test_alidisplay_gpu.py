@@ -120,3 +120,45 @@ def test_standard_branch_traces_equal_the_oracles(gpu_ctx, initiator):
         o = omap[(d.window, d.iali, d.jali)]
         b = ba.alidisplay_print(ol.trace_arrays(o.trace_idx), win, hmm, d.iali, d.jali, "w%d" % d.window, gm=gm, ncbi_table=hmm.ct, initiator=initiator)
         assert a == b and " PP\n" in a
+
+
+def test_trace_invariants_on_a_bench_sized_block(gpu_ctx):
+    """Size-independent properties of the exported traces at the bench's shape (200 000 x 1 kb windows with 1 % planted frameshifted
+    domains, ~1000 domains in both branches): every trace runs from a match state at (ihmm, first codon) to a match state at
+    (jhmm, jali); nodes never decrease and advance by one per M / D column; M / I columns advance the nucleotide position by
+    their codon length (3 for I) -- so the columns account for the alignment's whole nucleotide span --; D columns carry no
+    posterior, M / I columns a probability; the shifted-codon count and the column count are the domain record's."""
+    from bath_amd import synth
+    ctx = gpu_ctx
+    ctx.set_fs_strict(True)
+    hmm = ba.HMM(ol.GOLDEN + "/Caudal_act.bhmm", 0)
+    flat, offsets = synth.dna_windows(200_000, 1000, seed=4242, hmm=hmm, frameshift=True)[:2]
+    om = ba.OProfile(ctx, ba.Profile(hmm))
+    om3 = ba.FSOProfile(ctx, ba.FSProfile(hmm, 3, ncbi_table=hmm.ct)); om5 = ba.FSOProfile(ctx, ba.FSProfile(hmm, 5, ncbi_table=hmm.ct))
+    pipe = ba.Pipeline(ctx, om, fs_pipe=True, ncbi_table=hmm.ct)
+    stats, fw, dm, _ = pipe.run_frameshift_domains(om3, om5, ba.SeqBlock(ctx, flat, offsets))
+    traces = pipe.traces()
+    assert len(traces) == len(dm) >= 500
+    n_fs = n_std = n_quasi = 0
+    for d, (t, st, k, i, c, pp) in zip(dm, traces):
+        assert t.N == d.ali_columns == len(st) >= 1
+        assert st[0] == ba.T_M and st[-1] == ba.T_M and k[0] == d.ihmm and k[-1] == d.jhmm
+        isM, isD, isI = st == ba.T_M, st == ba.T_D, st == ba.T_I
+        assert (isM | isD | isI).all()
+        assert (np.diff(k) == (isM | isD)[1:].astype(np.int32)).all()                      # a node per M / D column, none for I
+        step = np.where(isM, c, np.where(isI, 3, 0)).astype(np.int64)
+        assert ((c >= 1) & (c <= 5))[isM].all() and (c[~isM] == 0).all()
+        emit = isM | isI
+        pos = i[emit].astype(np.int64)
+        assert (np.diff(pos) == step[emit][1:]).all()                                      # each emitting column ends its codon's length further on
+        span = abs(d.jali - d.iali) + 1
+        assert step.sum() == span, (d.window, step.sum(), span)
+        assert (pp[isD] == 0).all() and ((pp[emit] >= 0) & (pp[emit] <= 1.0 + 1e-5)).all()
+        if t.frameshift:
+            n_fs += 1
+            assert int((c[isM] != 3).sum()) == d.n_shifted_codons
+            n_quasi += d.n_shifted_codons
+        else:
+            n_std += 1
+            assert (c[isM] == 3).all()
+    assert n_fs >= 300 and n_std >= 100 and n_quasi >= 100
