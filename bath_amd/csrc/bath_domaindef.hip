@@ -1362,6 +1362,245 @@ __global__ __launch_bounds__(256) void std_envelope_fill_kernel(SeqView sq, int 
   }
 }
 
+// The same fill with a BLOCK of four waves per envelope (round 5): models beyond 192 nodes, where a single wave holds 4-16 nodes per
+// lane and a row is hundreds of instructions that one wave issues one every ~5 cycles.  Wave w owns nodes 64 w C + 1 .. 64 (w+1) C
+// (C = 1, 2, 4: up to 1024 nodes), a lane C consecutive nodes as before.  What crosses a wave boundary goes through LDS: the
+// previous row's last cells of wave w - 1 (M, I, D of the node to the left), the waves' composite D-chain functions (wave w applies
+// those of waves 0 .. w - 1 to D(1) = -inf before its own lanes' prefixes) and the waves' row maxima for xE -- which no cell of the
+// next row reads (unihit: B comes from N and J, and J does not read E), so wave 0 folds them into C and the special-state rows one
+// row late.  Two LDS-only barriers per row.  max / select / AND arithmetic as in the one-wave kernel: the same OA matrix,
+// posteriors and special rows bit for bit; only null2's sums over the nodes and the residues associate by wave (as they already
+// differ between the one-wave kernel and the serial one).
+template <int C>
+__global__ __launch_bounds__(256) void std_envelope_fill_mw_kernel(SeqView sq, int M, const float *__restrict__ tf, const float *__restrict__ rf, float *__restrict__ fwd,
+                                                                   float *__restrict__ bck, const int64_t *__restrict__ dp_off, const float *__restrict__ fx,
+                                                                   const float *__restrict__ bx, const int64_t *__restrict__ x_off, float *__restrict__ ppx_all,
+                                                                   float *__restrict__ oax_all, StdEnvOut *__restrict__ out) {
+  enum { XE = 0, XN, XJ, XB, XC, XS };
+  enum { cM = 0, cD = 1, cI = 2 };
+  enum { MM = 0, IM, DM, BM, MD, DD, MI, II };
+  constexpr int NW = 4;
+  __shared__ float s_nbr[2][NW][3];        // [row parity][wave]: M, I, D of the wave's last node
+  __shared__ float s_fc[NW];
+  __shared__ int s_fp[NW];
+  __shared__ float s_xe[2][NW];            // [row parity][wave]: the wave's maximum over the row's M and D cells
+  __shared__ float s_sum[NW][20];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int gl = wv * 64 + lane;                                              // the lane's rank among the block's 256
+  auto lds_barrier = [] { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); };
+  auto band = [](float v, unsigned m) { return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v) & m); };
+  auto vmax = [](float x, float y) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; };
+  auto vmin = [](float x, float y) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; };
+  unsigned kBM[C], kMM[C], kIM[C], kDM[C], kMD[C], kDD[C], kMI[C], kII[C], vm[C];
+  float lim[C], npz[C], plim[C];
+  const bool full = gl * C + C <= M, partial = !full && gl * C + 1 <= M;
+#pragma unroll
+  for (int c = 0; c < C; c++) {
+    const int node = gl * C + c + 1;
+    const bool ok = node <= M;
+    const float *tq = tf + (size_t)min(node, M) * 8;
+    auto mk = [&](int q) { return (ok && tq[q] > 0.0f) ? 0xffffffffu : 0u; };
+    kMM[c] = mk(MM); kIM[c] = mk(IM); kDM[c] = mk(DM); kBM[c] = mk(BM); kMD[c] = mk(MD); kDD[c] = mk(DD); kMI[c] = mk(MI); kII[c] = mk(II);
+    vm[c] = ok ? 0xffffffffu : 0u;
+    lim[c] = ok ? INFINITY : -INFINITY;
+    const bool pass = !ok || tq[DD] > 0.0f;
+    npz[c] = pass ? -INFINITY : 0.0f;
+    plim[c] = pass ? INFINITY : -INFINITY;
+  }
+  for (int64_t t = blockIdx.x; t < sq.n; t += gridDim.x) {
+    const int L = sq.len[t];
+    const uint8_t *dsq = sq.data + sq.off[t] - 1;
+    const size_t W = (size_t)(M + 1) * 3;
+    float *F = fwd + dp_off[t];
+    float *Bk = bck + dp_off[t];
+    const float *FX = fx + x_off[t], *BX = bx + x_off[t];
+    float *PX = ppx_all + (x_off[t] / 6) * 5, *OX = oax_all + (x_off[t] / 6) * 5;
+    const float ploop = 1.0f - 2.0f / ((float)L + 2.0f);
+    float pvM[C], pvI[C], pvD[C], emM[C], emI[C];
+#pragma unroll
+    for (int c = 0; c < C; c++) { pvM[c] = pvI[c] = pvD[c] = -INFINITY; emM[c] = emI[c] = 0.f; }
+    float oxN = 0.f, oxJ = -INFINITY, oxC = -INFINITY, oxB = 0.f, sN = 0.f, sC = 0.f, sJ = 0.f;
+    float scaleproduct = (float)(1.0 / (double)BX[XN]);
+    for (int k = threadIdx.x; k <= M; k += blockDim.x) F[(size_t)k * 3] = F[(size_t)k * 3 + 1] = F[(size_t)k * 3 + 2] = -INFINITY;      // OA row 0
+    if (threadIdx.x == 0) {
+      for (int q = 0; q < 5; q++) PX[q] = 0.f;
+      OX[XE] = -INFINITY; OX[XN] = 0.f; OX[XJ] = -INFINITY; OX[XB] = 0.f; OX[XC] = -INFINITY;
+    }
+    if (lane == 63) { s_nbr[0][wv][0] = s_nbr[0][wv][1] = s_nbr[0][wv][2] = -INFINITY; }          // "row 0" as row 1 reads it
+    float fM[C], fI[C], bM[C], bI[C];
+    const size_t lane0 = (size_t)(gl * C + 1) * 3;
+    auto fetch_row = [&](int r) {
+      const float *fq = F + (size_t)r * W + lane0, *bq = Bk + (size_t)r * W + lane0;
+#pragma unroll
+      for (int c = 0; c < C; c++) { fM[c] = fq[3 * c + cM]; fI[c] = fq[3 * c + cI]; bM[c] = bq[3 * c + cM]; bI[c] = bq[3 * c + cI]; }
+    };
+    float xb[8], xn[8];
+    auto fetch_x = [&](int r0, float (&v)[8]) {                             // rows r0 .. r0 + 63, a lane each (every wave its own copy)
+      const int r = min(r0 + lane, L);
+      v[0] = FX[(size_t)(r - 1) * 6 + XN]; v[1] = FX[(size_t)(r - 1) * 6 + XJ]; v[2] = FX[(size_t)(r - 1) * 6 + XC]; v[3] = FX[(size_t)r * 6 + XS];
+      v[4] = BX[(size_t)r * 6 + XN]; v[5] = BX[(size_t)r * 6 + XJ]; v[6] = BX[(size_t)r * 6 + XC]; v[7] = BX[(size_t)r * 6 + XS];
+    };
+    if (L >= 1) { fetch_row(1); fetch_x(1, xb); }
+    float pxN_prev = 0.f, pxJ_prev = 0.f, pxC_prev = 0.f;
+    // wave 0: C and the special-state rows of row r, once the waves' maxima of that row have crossed the barrier that ended it
+    // (oxN, oxJ, oxB still hold row r's values then: they are advanced at the end of the next row)
+    auto finish_row = [&](int r) {
+      float xE = s_xe[r & 1][0];
+#pragma unroll
+      for (int w = 1; w < NW; w++) xE = vmax(xE, s_xe[r & 1][w]);
+      oxC = fmaxf(oxC + pxC_prev, xE);
+      if (lane == 0) {
+        float *px = PX + (size_t)r * 5, *ox = OX + (size_t)r * 5;
+        px[XE] = 0.f; px[XN] = pxN_prev; px[XJ] = pxJ_prev; px[XB] = 0.f; px[XC] = pxC_prev;
+        ox[XE] = xE; ox[XN] = oxN; ox[XJ] = oxJ; ox[XB] = oxB; ox[XC] = oxC;
+      }
+    };
+    lds_barrier();
+    for (int i = 1; i <= L; i++) {
+      const int par = i & 1;
+      const int j = (i - 1) & 63;
+      if (j == 0 && i + 64 <= L) fetch_x(i + 64, xn);
+      float xv[8];
+#pragma unroll
+      for (int q = 0; q < 8; q++) xv[q] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xb[q]), j));
+      if (j == 63) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) xb[q] = xn[q];
+      }
+      const float totr = scaleproduct * xv[3];
+      float *frow = F + (size_t)i * W;
+      float *brow = Bk + (size_t)i * W;
+      float pM[C], pI[C];
+#pragma unroll
+      for (int c = 0; c < C; c++) {
+        pM[c] = band(fM[c] * (bM[c] * totr), vm[c]);
+        pI[c] = band(fI[c] * (bI[c] * totr), vm[c]);
+        if (i == 1) { emM[c] = pM[c]; emI[c] = pI[c]; } else { emM[c] = pM[c] + emM[c]; emI[c] = pI[c] + emI[c]; }
+      }
+      if (i < L) fetch_row(i + 1);
+      const float pxN = xv[0] * xv[4] * ploop * scaleproduct;
+      const float pxJ = xv[1] * xv[5] * ploop * scaleproduct;
+      const float pxC = xv[2] * xv[6] * ploop * scaleproduct;
+      if (i == 1) { sN = pxN; sC = pxC; sJ = pxJ; } else { sN += pxN; sC += pxC; sJ += pxJ; }
+      scaleproduct *= xv[3] / xv[7];
+      float mIn = wave_shr1_f32(pvM[C - 1], -INFINITY), iIn = wave_shr1_f32(pvI[C - 1], -INFINITY), dIn = wave_shr1_f32(pvD[C - 1], -INFINITY);
+      if (lane == 0 && wv > 0) { mIn = s_nbr[par ^ 1][wv - 1][0]; iIn = s_nbr[par ^ 1][wv - 1][1]; dIn = s_nbr[par ^ 1][wv - 1][2]; }
+      float cuM[C], cuI[C], cuD[C];
+      float fc = -INFINITY; unsigned fpass = 0xffffffffu;
+      float xE = -INFINITY;
+#pragma unroll
+      for (int c = 0; c < C; c++) {
+        const float m1 = c == 0 ? mIn : pvM[c - 1], i1 = c == 0 ? iIn : pvI[c - 1], d1 = c == 0 ? dIn : pvD[c - 1];
+        float sv = band(oxB, kBM[c]);
+        sv = vmax(sv, band(m1, kMM[c]));
+        sv = vmax(sv, band(i1, kIM[c]));
+        sv = vmax(sv, band(d1, kDM[c]));
+        sv = vmin(sv + pM[c], lim[c]);
+        cuM[c] = sv;
+        xE = vmax(xE, sv);
+        cuI[c] = vmin(vmax(band(pvM[c], kMI[c]), band(pvI[c], kII[c])) + pI[c], lim[c]);
+        const float cst = vmin(band(sv, kMD[c]), lim[c]);
+        const float g = vmax(cst, npz[c]);
+        fc = vmax(g, vmin(fc, plim[c]));
+        fpass &= kDD[c] | ~vm[c];
+      }
+      float sc_c = fc; int sc_p = fpass ? 1 : 0;
+#define BATH_OAS_STEP(CTRL, MASK) { const float oc = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp((int)0xff800000, __builtin_bit_cast(int, sc_c), CTRL, MASK, 0xf, false)); \
+                                    const int op = __builtin_amdgcn_update_dpp(1, sc_p, CTRL, MASK, 0xf, false); \
+                                    if (sc_p) { sc_c = fmaxf(sc_c, oc); sc_p = op; } }
+      BATH_OAS_STEP(0x111, 0xf) BATH_OAS_STEP(0x112, 0xf) BATH_OAS_STEP(0x114, 0xf) BATH_OAS_STEP(0x118, 0xf) BATH_OAS_STEP(0x142, 0xa) BATH_OAS_STEP(0x143, 0xc)
+#undef BATH_OAS_STEP
+      if (lane == 63) { s_fc[wv] = sc_c; s_fp[wv] = sc_p; }                   // the wave's composite function
+      if (wv == 0 && i > 1) finish_row(i - 1);                                // (row i - 1's maxima are behind the barrier that ended it)
+      lds_barrier();                                                           // ---- barrier 1: the waves' functions of this row
+      float xin = -INFINITY;                                                   // D entering this wave: the waves before it applied to D(1) = -inf
+      for (int w = 0; w < wv; w++) xin = s_fp[w] ? vmax(s_fc[w], xin) : s_fc[w];
+      const float ec = wave_shr1_f32(sc_c, -INFINITY);                         // exclusive prefix of this wave's lanes (lane 0: the identity)
+      int ep = __builtin_amdgcn_update_dpp(1, sc_p, 0x138, 0xf, 0xf, false);   // wave_shr:1
+      if (lane == 0) ep = 1;
+      float din = ep ? vmax(ec, xin) : ec;
+#pragma unroll
+      for (int c = 0; c < C; c++) {
+        cuD[c] = vmin(din, lim[c]);
+        xE = vmax(xE, cuD[c]);
+        din = vmax(band(cuM[c], kMD[c]), band(din, kDD[c]));
+        pvM[c] = cuM[c]; pvI[c] = cuI[c]; pvD[c] = cuD[c];
+      }
+      if (full) {
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+          float *bq = brow + lane0 + 3 * c, *fq = frow + lane0 + 3 * c;
+          bq[cM] = pM[c]; bq[cD] = 0.0f; bq[cI] = pI[c];
+          fq[cM] = cuM[c]; fq[cD] = cuD[c]; fq[cI] = cuI[c];
+        }
+      } else if (partial) {
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+          const int node = gl * C + c + 1;
+          if (node <= M) {
+            brow[(size_t)node * 3 + cM] = pM[c]; brow[(size_t)node * 3 + cI] = pI[c]; brow[(size_t)node * 3 + cD] = 0.0f;
+            frow[(size_t)node * 3 + cM] = cuM[c]; frow[(size_t)node * 3 + cD] = cuD[c]; frow[(size_t)node * 3 + cI] = cuI[c];
+          }
+        }
+      }
+      if (threadIdx.x == 0) { frow[0] = frow[1] = frow[2] = -INFINITY; }
+      xE = wave_max_f32(xE);
+      if (lane == 63) { s_nbr[par][wv][0] = pvM[C - 1]; s_nbr[par][wv][1] = pvI[C - 1]; s_nbr[par][wv][2] = pvD[C - 1]; s_xe[par][wv] = xE; }
+      // N, J and B of this row (every wave its own copy: none of them reads E); C waits for xE (finish_row, one row late)
+      oxJ = fmaxf(oxJ + pxJ, 0.0f);
+      oxN = oxN + pxN;
+      oxB = fmaxf(oxN, oxJ);
+      pxN_prev = pxN; pxJ_prev = pxJ; pxC_prev = pxC;
+      lds_barrier();                                                           // ---- barrier 2: neighbours and maxima of row i
+    }
+    if (wv == 0 && L >= 1) finish_row(L);
+    // oasc = C(L) lives in wave 0: hand it to everybody with the null2 sums below
+    StdEnvOut r{-1, -1, -1, -1, 0, 0.f, 0.f, 0, 0};
+    if (!isinf(scaleproduct)) {                                             // else eslERANGE: the domain is dropped
+      const float norm = (float)(1.0 / (double)(float)L);
+#pragma unroll
+      for (int c = 0; c < C; c++) { emM[c] *= norm; emI[c] *= norm; }
+      const float xfactor = sN * norm + sC * norm + sJ * norm;
+      float null2[kKp];
+      for (int x = 0; x < 20; x++) {
+        const float *e = rf + (size_t)x * (M + 1);
+        float sv = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; c++) { const int node = gl * C + c + 1; if (node <= M) { sv += emM[c] * e[node]; sv += emI[c]; } }
+        const float ws = wave_sum_f32(sv);
+        if (lane == 0) s_sum[wv][x] = ws;
+      }
+      lds_barrier();
+      for (int x = 0; x < 20; x++) null2[x] = (((s_sum[0][x] + s_sum[1][x]) + s_sum[2][x]) + s_sum[3][x]) + xfactor;
+      lds_barrier();
+      const int mem[6][2] = {{2, 11}, {7, 9}, {3, 13}, {8, 8}, {1, 1}, {-1, -1}};      // B=DN J=IL Z=EQ O=K U=C X=any
+      for (int dx = 0; dx < 6; dx++) {
+        float sum = 0.f; int cnt = 0;
+        if (dx == 5) { for (int y = 0; y < 20; y++) { sum += null2[y]; cnt++; } }
+        else { const int a = min(mem[dx][0], mem[dx][1]), b = max(mem[dx][0], mem[dx][1]); sum += null2[a]; cnt++; if (b != a) { sum += null2[b]; cnt++; } }
+        null2[21 + dx] = sum / (float)cnt;
+      }
+      null2[20] = 1.0f; null2[27] = 1.0f; null2[28] = 1.0f;
+      float corr = 0.f;
+      for (int pos = 1 + (int)threadIdx.x; pos <= L; pos += (int)blockDim.x) {
+        const int x = min((int)dsq[pos], kKp - 1);
+        float v = null2[0];
+#pragma unroll
+        for (int q = 1; q < kKp; q++) v = (x == q) ? null2[q] : v;
+        corr += logf(v);
+      }
+      const float wc = wave_sum_f32(corr);
+      if (lane == 0) s_sum[wv][0] = wc;
+      lds_barrier();
+      r.domcorrection = ((s_sum[0][0] + s_sum[1][0]) + s_sum[2][0]) + s_sum[3][0];
+      r.oasc = oxC;                                                         // (wave 0's: the only reader is thread 0 below)
+      r.ok = 1;
+    }
+    if (threadIdx.x == 0) out[t] = r;
+    lds_barrier();                                                          // the LDS slots are the next envelope's
+  }
+}
+
 }  // namespace
 
 // Domain definition and hit scores for ORFs that passed the Forward filter; appends to ctx->fs_domains.
@@ -1575,6 +1814,17 @@ static int std_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bat
     const unsigned grid = (unsigned)std::min<int64_t>((ne + 3) / 4, (int64_t)ctx->prop.multiProcessorCount * 8);
 #define BATH_FILL(CC) hipLaunchKernelGGL(std_envelope_fill_kernel<CC>, dim3(grid), dim3(256), 0, ctx->stream, ev.view(), M, om->d_tf, om->d_rf, b_f.as<float>(), b_b.as<float>(), \
                                          b_dpo.as<int64_t>(), b_fx.as<float>(), b_bx.as<float>(), d_exoff, b_px.as<float>(), b_ox.as<float>(), b_out.as<StdEnvOut>()); filled = 1
+    // a block of four waves per envelope from 4 nodes per lane on (BATH_HIP_STD_FILL_MW=0: never, =1: for every model)
+    const char *mwe = std::getenv("BATH_HIP_STD_FILL_MW");
+    const bool mw = M <= 1024 && (mwe ? mwe[0] == '1' : c >= 4);
+    if (!(e && e[0] == '1') && mw) {
+      const unsigned mgrid = (unsigned)std::min<int64_t>(ne, (int64_t)ctx->prop.multiProcessorCount * 8);
+#define BATH_FILL_MW(CC) hipLaunchKernelGGL(std_envelope_fill_mw_kernel<CC>, dim3(mgrid), dim3(256), 0, ctx->stream, ev.view(), M, om->d_tf, om->d_rf, b_f.as<float>(), b_b.as<float>(), \
+                                            b_dpo.as<int64_t>(), b_fx.as<float>(), b_bx.as<float>(), d_exoff, b_px.as<float>(), b_ox.as<float>(), b_out.as<StdEnvOut>()); filled = 1
+      const int c4 = (M + 255) / 256;
+      if (c4 <= 1) { BATH_FILL_MW(1); } else if (c4 <= 2) { BATH_FILL_MW(2); } else { BATH_FILL_MW(4); }
+#undef BATH_FILL_MW
+    } else
     if (!(e && e[0] == '1')) {
       if (c <= 1) { BATH_FILL(1); } else if (c <= 2) { BATH_FILL(2); } else if (c <= 3) { BATH_FILL(3); } else if (c <= 4) { BATH_FILL(4); }
       else if (c <= 6) { BATH_FILL(6); } else if (c <= 8) { BATH_FILL(8); } else if (c <= 12) { BATH_FILL(12); } else if (c <= 16) { BATH_FILL(16); }

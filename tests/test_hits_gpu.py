@@ -223,14 +223,20 @@ def test_wave_and_lane_envelope_kernels_agree(ctx, monkeypatch):
         w = np.concatenate([rng.integers(0, 4, size=60).astype(np.uint8), nt, rng.integers(0, 4, size=45).astype(np.uint8)])
         wins.append((3 - w[::-1]).astype(np.uint8) if i % 2 else w)
     out = []
-    for serial in ("0", "1"):
+    # the block-of-four-waves fill (the default from 193 nodes on), the serial kernel, the one-wave fill
+    for serial, mw in (("0", None), ("1", None), ("0", "0")):
         monkeypatch.setenv("BATH_HIP_STD_SERIAL", serial)
+        if mw is None:
+            monkeypatch.delenv("BATH_HIP_STD_FILL_MW", raising=False)
+        else:
+            monkeypatch.setenv("BATH_HIP_STD_FILL_MW", mw)
         _, dm, nskip = gpu_hits(ctx, path, 0, wins)
         out.append((nskip, sorted((d.window, d.ienv, d.jenv, d.iali, d.jali, d.ihmm, d.jhmm, d.envsc, d.oasc, d.ali_columns, d.pid, d.cigar, d.domcorrection) for d in dm)))
-    assert out[0][0] == out[1][0] and len(out[0][1]) == len(out[1][1]) >= 15
-    for a, b in zip(out[0][1], out[1][1]):
-        assert a[:12] == b[:12]
-        assert abs(a[12] - b[12]) <= 1e-4 * max(1.0, abs(b[12]))
+    for other in (1, 2):
+        assert out[0][0] == out[other][0] and len(out[0][1]) == len(out[other][1]) >= 15
+        for a, b in zip(out[0][1], out[other][1]):
+            assert a[:12] == b[:12]
+            assert abs(a[12] - b[12]) <= 1e-4 * max(1.0, abs(b[12]))
 
 
 @pytest.mark.parametrize("hmmfile", ["MET-ct4.bhmm", "PTH2.bhmm", "Caudal_act.bhmm"])
