@@ -169,6 +169,7 @@ struct PipelineSurvivor {
   int32_t n;               // residues
   int32_t win_start = 0;   // windowsq->start on that strand: the ORF's own start, or the DNA window's in the --fs pipeline
   int32_t fs_window = -1;  // index of that DNA window in the frameshift stage's output
+  int64_t fx_off = -1;     // where the cascade's Forward parser left this ORF's special-state rows (floats into ctx->fwd_rows_kept), -1: not kept
 };
 
 }  // namespace bath
@@ -213,6 +214,13 @@ struct bath_hip_ctx {
   int64_t n_records = 0;
   std::vector<bath_orf> orfs;             // bath_hip_translate_orfs output
   std::vector<bath_fs_window> fs_windows; // bath_hip_pipeline_frameshift output
+  // The domain stage of the plain pipeline reads the Forward parser's special-state rows of the ORFs that passed F3 -- the matrix the
+  // reference keeps in pli->oxf between the filter and p7_domaindef (p7_pipeline.c:1741-1771).  keep_fwd_rows: the cascade's Forward
+  // launch writes them (one-lane blocks: the domain stage then copies the survivors' rows instead of running the parser again);
+  // fwd_rows_kept / fwd_rows_off: where, by candidate, until the next cascade call of this context.
+  bool keep_fwd_rows = false;
+  const float *fwd_rows_kept = nullptr;
+  const int64_t *fwd_rows_off = nullptr;
   bool fs_want_regions = false;           // set by the domain stage: the decision stage also runs the Backward parser and the region heuristics
   std::vector<int64_t> fs_keep_xoff;      // the decision stage's Forward parser rows stay on the device (scratch[45]): offsets per DNA window, in floats
   std::vector<int32_t> fs_regions_all;    // ... for every DNA window: 1 + 3*fs_max_regions() ints each (bath_frameshift.hip: fs3_regions)

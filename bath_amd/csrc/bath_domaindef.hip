@@ -623,6 +623,16 @@ namespace {
 constexpr int kStdMaxRegions = 48;       // regions kept per ORF; an ORF with more reports the true count and the call fails loudly (the reference has no cap)
 
 // the residues of each target of a view, to out + xoff[t] / 6 (a block per target)
+// rows of target q: (len[q] + 1) x 6 floats from src + src_off[q] to dst + dst_off[q]
+__global__ void copy_rows_kernel(int64_t n, const int32_t *__restrict__ len, const float *__restrict__ src, const int64_t *__restrict__ src_off,
+                                 float *__restrict__ dst, const int64_t *__restrict__ dst_off) {
+  for (int64_t q = blockIdx.x; q < n; q += gridDim.x) {
+    const float *a = src + src_off[q];
+    float *b = dst + dst_off[q];
+    const int m = (len[q] + 1) * 6;
+    for (int i = threadIdx.x; i < m; i += blockDim.x) b[i] = a[i];
+  }
+}
 __global__ void gather_residues_kernel(SeqView v, const int64_t *__restrict__ xoff, uint8_t *__restrict__ out) {
   for (int64_t t = blockIdx.x; t < v.n; t += gridDim.x) {
     const uint8_t *s = v.data + v.off[t];
@@ -1651,7 +1661,7 @@ static int std_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bat
   // downloads: into page-locked memory, then (after the stage's synchronize) a host copy into the vector the code reads
   auto down_reserve = [&](size_t bytes) -> int { BATH_HIP_TRY(ctx, ctx->stage[5].reserve(bytes + 1024)); return BATH_OK; };
   if ((st = om->ensure_len_tables(view.maxlen)) != BATH_OK) return st;
-  if ((st = up_begin(view_bytes(ns))) != BATH_OK) return st;
+  if ((st = up_begin(view_bytes(ns) + (size_t)ns * 8 + 256)) != BATH_OK) return st;                 // (+ the kept Forward rows' offsets, below)
   if ((st = upload_view(view, xoff, ns)) != BATH_OK) return st;
   const int64_t *d_xoff = b_idx.as<int64_t>() + ns;
   BATH_HIP_TRY(ctx, b_fx.reserve((size_t)xoff[(size_t)ns] * 4 + 64)); BATH_HIP_TRY(ctx, b_bx.reserve((size_t)xoff[(size_t)ns] * 4 + 64));
@@ -1659,7 +1669,20 @@ static int std_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bat
   BATH_HIP_TRY(ctx, b_work.reserve((size_t)xoff[(size_t)ns] / 6 * 3 * 4 + 64));
   const int RS = 1 + 3 * kStdMaxRegions;
   BATH_HIP_TRY(ctx, b_reg.reserve((size_t)ns * RS * 4 + 64));
-  if ((st = launch_fwd_wave(ctx, om, view.view(), nullptr, ns, b_sc.as<float>(), b_st.as<int32_t>(), nullptr, b_fx.as<float>(), d_xoff)) != BATH_OK) return st;
+  // The Forward parser's rows: the reference has them from the filter (pli->oxf, p7_pipeline.c:1741-1771).  When the cascade of this
+  // call kept them (ctx->fwd_rows_kept: a one-lane block through bath_hip_pipeline_hits) the survivors' rows are copied into place;
+  // otherwise (the standard branch of the --fs pipeline, blocks cut into lanes, rows that did not fit) the parser runs again.
+  bool kept = ctx->fwd_rows_kept != nullptr;
+  for (int64_t i = 0; i < ns && kept; i++) kept = surv[(size_t)i].fx_off >= 0;
+  if (kept) {
+    std::vector<int64_t> src((size_t)ns);
+    for (int64_t i = 0; i < ns; i++) src[(size_t)i] = surv[(size_t)i].fx_off;
+    DevBuf &b_src = ctx->scratch[49];
+    BATH_HIP_TRY(ctx, b_src.reserve((size_t)ns * 8 + 64));
+    if ((st = up(b_src.p, {{src.data(), (size_t)ns * 8}})) != BATH_OK) return st;
+    hipLaunchKernelGGL(copy_rows_kernel, dim3((unsigned)std::min<int64_t>(ns, 65535)), dim3(256), 0, ctx->stream, ns, view.d_len, ctx->fwd_rows_kept, b_src.as<int64_t>(), b_fx.as<float>(), d_xoff);
+    BATH_HIP_TRY(ctx, hipGetLastError());
+  } else if ((st = launch_fwd_wave(ctx, om, view.view(), nullptr, ns, b_sc.as<float>(), b_st.as<int32_t>(), nullptr, b_fx.as<float>(), d_xoff)) != BATH_OK) return st;
   if ((st = launch_bwd_wave(ctx, om, view.view(), ns, b_fx.as<float>(), d_xoff, b_sc.as<float>() + ns, b_st.as<int32_t>() + ns, b_bx.as<float>())) != BATH_OK) return st;
   {
     const char *e = std::getenv("BATH_HIP_STD_SERIAL");
@@ -1950,12 +1973,19 @@ extern "C" int bath_hip_pipeline_hits(bath_hip_ctx *ctx, const bath_hip_oprofile
   std::vector<PipelineSurvivor> surv;
   const uint8_t *d_pool = nullptr;
   StageClock clk;
+  // the cascade's Forward parser leaves its special-state rows for the domain stage (BATH_HIP_KEEP_FWD=0: the domain stage runs the
+  // parser again, as it did until round 5)
+  const bool keep = [] { const char *e = std::getenv("BATH_HIP_KEEP_FWD"); return !(e && e[0] == '0'); }();
+  ctx->keep_fwd_rows = keep;
   int st = pipeline_filters_survivors(ctx, om, dna, &prm, &st_local, &surv, &d_pool);
-  if (st != BATH_OK) return st;
+  ctx->keep_fwd_rows = false;
+  if (st != BATH_OK) { ctx->fwd_rows_kept = nullptr; return st; }
   clk.lap("std: cascade + survivors to the host");
   if (stats) *stats = st_local;
   for (PipelineSurvivor &o : surv) o.win_start = o.start;                  // windowsq is the ORF's own stretch of DNA (p7_pipeline.c:1755)
-  if ((st = std_domains(ctx, om, dna, surv, d_pool, DomOpts(prm, E_report), &nclust)) != BATH_OK) return st;
+  st = std_domains(ctx, om, dna, surv, d_pool, DomOpts(prm, E_report), &nclust);
+  ctx->fwd_rows_kept = nullptr; ctx->fwd_rows_off = nullptr;
+  if (st != BATH_OK) return st;
   if (n_clustered_regions) *n_clustered_regions = nclust;
   *domains = ctx->fs_domains.data(); *n_domains = (int64_t)ctx->fs_domains.size();
   return BATH_OK;

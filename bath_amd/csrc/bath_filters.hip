@@ -420,7 +420,7 @@ __global__ __launch_bounds__(256) void fwd_wave_kernel(SeqView sq, int M, const 
     for (int k = 0; k < C; k++) Mp[k] = Ip[k] = Dp[k] = 0.f;
     float xN = 1.f, xE = 0.f, xJ = 0.f, xC = 0.f, xB = pmove;
     float totscale = 0.f;
-    float *xrow = xmx ? xmx + xmx_off[sid] : nullptr;      // (L+1) x {E,N,J,B,C,SCALE}, P7_OMX xmx (impl_sse.h:253-262)
+    float *xrow = (xmx && xmx_off[sid] >= 0) ? xmx + xmx_off[sid] : nullptr;      // (L+1) x {E,N,J,B,C,SCALE}, P7_OMX xmx (impl_sse.h:253-262); a negative offset: not wanted for this target
     if (xrow && lane == 0) { xrow[0] = xE; xrow[1] = xN; xrow[2] = xJ; xrow[3] = xB; xrow[4] = xC; xrow[5] = 1.0f; }
 
     // The residues arrive 64 rows at a time, a lane each, the next 64 in flight: with a load per row every row of a launch of a

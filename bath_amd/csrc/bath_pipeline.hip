@@ -618,6 +618,24 @@ struct FilterState {               // what the frameshift stage reads after the 
 };
 }  // namespace bath
 
+// Where the Forward parser of the cascade leaves the special-state rows of its candidates (ctx->keep_fwd_rows): offsets in work-list
+// order, (len + 1) x 6 floats each, by one wave (a chunk of 64 candidates per step, prefix sums by shuffle); a candidate whose rows
+// would not fit <cap> floats gets -1 and no rows.
+__global__ __launch_bounds__(64) void fwd_keep_offsets_kernel(const int32_t *__restrict__ todo, const int *__restrict__ ntodo_dev, const int32_t *__restrict__ len,
+                                                              int64_t *__restrict__ off, int64_t cap) {
+  const int lane = threadIdx.x, n = *ntodo_dev;
+  int64_t base = 0;
+  for (int j0 = 0; j0 < n; j0 += 64) {
+    const int j = j0 + lane;
+    const int sid = j < n ? todo[j] : -1;
+    const int64_t v = sid >= 0 ? ((int64_t)len[sid] + 1) * 6 : 0;
+    int64_t incl = v;
+    for (int d = 1; d < 64; d <<= 1) { const int64_t u = __shfl_up(incl, d, 64); if (lane >= d) incl += u; }
+    if (sid >= 0) off[sid] = (base + incl <= cap) ? base + incl - v : (int64_t)-1;
+    base += __shfl(incl, 63, 64);
+  }
+}
+
 static int run_filters(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bath_hip_seqs *dna,
                        const bath_pipeline_params *prm, bath_pipeline_stats *stats,
                        const bath_orf_result **results, int64_t *n_results, FilterState *state) {
@@ -834,8 +852,19 @@ static int run_filters(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bat
     hipLaunchKernelGGL(post_vit2_kernel, dim3(64), dim3(256), 0, ctx->stream, W.cand, W.ctr, P, W.todo_vit2, W.todo_fwd);
     BATH_HIP_TRY(ctx, hipGetLastError());
     BATH_HIP_TRY(ctx, hipEventRecord(ev[e++], ctx->stream));
-    // 6. Forward parser, F3/F4
-    if ((st = launch_fwd_wave(ctx, om, cv, W.todo_fwd, cap, W.cand.fwdsc, W.cand.fwd_status, &W.ctr->todo_fwd)) != BATH_OK) return st;
+    // 6. Forward parser, F3/F4 (for the domain stage of a one-lane block it also leaves its special-state rows: ctx->keep_fwd_rows)
+    ctx->fwd_rows_kept = nullptr; ctx->fwd_rows_off = nullptr;
+    float *d_keep = nullptr; int64_t *d_keep_off = nullptr;
+    if (ctx->keep_fwd_rows) {
+      constexpr int64_t kKeepFloats = (int64_t)8 << 20;                        // 32 MB: ~1.4 M residue rows; what does not fit is computed again by the domain stage
+      DevBuf &b_rows = ctx->scratch[38], &b_roff = ctx->scratch[39];
+      BATH_HIP_TRY(ctx, b_rows.reserve((size_t)kKeepFloats * sizeof(float) + 64)); BATH_HIP_TRY(ctx, b_roff.reserve((size_t)cap * sizeof(int64_t) + 64));
+      d_keep = b_rows.as<float>(); d_keep_off = b_roff.as<int64_t>();
+      hipLaunchKernelGGL(fwd_keep_offsets_kernel, dim3(1), dim3(64), 0, ctx->stream, W.todo_fwd, &W.ctr->todo_fwd, W.cand.len, d_keep_off, kKeepFloats);
+      BATH_HIP_TRY(ctx, hipGetLastError());
+    }
+    if ((st = launch_fwd_wave(ctx, om, cv, W.todo_fwd, cap, W.cand.fwdsc, W.cand.fwd_status, &W.ctr->todo_fwd, d_keep, d_keep_off)) != BATH_OK) return st;
+    if (d_keep) { ctx->fwd_rows_kept = d_keep; ctx->fwd_rows_off = d_keep_off; }
     hipLaunchKernelGGL(final_kernel, dim3(dec_blocks), dim3(256), 0, ctx->stream, W.cand, W.ctr, P, W.todo_fwd);
     BATH_HIP_TRY(ctx, hipGetLastError());
     BATH_HIP_TRY(ctx, hipEventRecord(ev[e++], ctx->stream));
@@ -1182,12 +1211,12 @@ float flogsum_host(float a, float b) {               // p7_FLogsum, logsum.c:105
 
 // The frameshift stage needs only the ORFs that passed F4 (a few thousand of the block's 10^5-10^6 MSV survivors) and their
 // hit windows: select them on the device, so that what crosses PCIe is a few hundred KB instead of every candidate array.
-struct FsCandRec { int64_t window, aa_off; double P; int32_t cand, sf, startj, len; float fwdsc, nullsc; };
-__global__ void fs_select_cands_kernel(Cand cand, int nc, FsCandRec *__restrict__ out, int *__restrict__ count) {
+struct FsCandRec { int64_t window, aa_off; double P; int32_t cand, sf, startj, len; float fwdsc, nullsc; int64_t fxoff; };
+__global__ void fs_select_cands_kernel(Cand cand, int nc, FsCandRec *__restrict__ out, int *__restrict__ count, const int64_t *__restrict__ fxoff /* kept Forward rows by candidate, or null */) {
   for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < nc; c += gridDim.x * blockDim.x) {
     if (cand.stage[c] != 4) continue;
     const int slot = atomicAdd(count, 1);
-    out[slot] = FsCandRec{cand.window[c], cand.off[c], cand.P[c], c, cand.sf[c], cand.startj[c], cand.len[c], cand.fwdsc[c], cand.nullsc[c]};
+    out[slot] = FsCandRec{cand.window[c], cand.off[c], cand.P[c], c, cand.sf[c], cand.startj[c], cand.len[c], cand.fwdsc[c], cand.nullsc[c], fxoff ? fxoff[c] : (int64_t)-1};
   }
 }
 __global__ void fs_select_wins_kernel(const WindowRec *__restrict__ wins, int nwins, const int32_t *__restrict__ stage, WindowRec *__restrict__ out, int *__restrict__ count) {
@@ -1234,7 +1263,7 @@ static int select_survivors(bath_hip_ctx *lane, const FilterState &S, bool want_
   WindowRec *d_w = reinterpret_cast<WindowRec *>(b_sel.as<char>() + o_w);
   BATH_HIP_TRY(lane, hipMemsetAsync(d_cnt, 0, 256, lane->stream));
   const int blocks = lane->prop.multiProcessorCount * 4;
-  hipLaunchKernelGGL(fs_select_cands_kernel, dim3(blocks), dim3(256), 0, lane->stream, S.W.cand, nc, d_c, d_cnt);
+  hipLaunchKernelGGL(fs_select_cands_kernel, dim3(blocks), dim3(256), 0, lane->stream, S.W.cand, nc, d_c, d_cnt, lane->fwd_rows_kept ? lane->fwd_rows_off : nullptr);
   if (nwins > 0) hipLaunchKernelGGL(fs_select_wins_kernel, dim3(blocks), dim3(256), 0, lane->stream, S.W.wins, nwins, S.W.cand.stage, d_w, d_cnt + 1);
   BATH_HIP_TRY(lane, hipGetLastError());
   int h_cnt[2] = {0, 0};
@@ -1272,7 +1301,7 @@ static int filters_with_survivors(bath_hip_ctx *ctx, const bath_hip_oprofile *om
   for (size_t k = 0; k < states.size(); k++) {
     const int base = out->nc_total;
     const int64_t dpool = (int64_t)(reinterpret_cast<intptr_t>(states[k].W.pool) - reinterpret_cast<intptr_t>(out->pool));
-    for (FsCandRec q : lsel[k]) { q.cand += base; q.window += first[k]; q.aa_off += dpool; out->sel.push_back(q); }
+    for (FsCandRec q : lsel[k]) { q.cand += base; q.window += first[k]; q.aa_off += dpool; if (states.size() > 1) q.fxoff = -1; out->sel.push_back(q); }
     for (WindowRec w : lwin[k]) { w.cand += base; out->wins.push_back(w); }
     out->nc_total += std::max(states[k].hc.cand_count, 0);
   }
@@ -1292,6 +1321,7 @@ int bath::pipeline_filters_survivors(bath_hip_ctx *ctx, const bath_hip_oprofile 
   for (const FsCandRec &q : sv.sel) {
     PipelineSurvivor o;
     o.window = q.window; o.aa_off = q.aa_off; o.strand = q.sf / 3; o.start = q.sf % 3 + 3 * q.startj + 1; o.n = q.len;
+    o.fx_off = ctx->fwd_rows_kept ? q.fxoff : (int64_t)-1;
     out->push_back(o);
   }
   std::sort(out->begin(), out->end(), [](const PipelineSurvivor &a, const PipelineSurvivor &b) {

@@ -279,6 +279,29 @@ def test_wave_and_lane_traceback_agree(ctx, monkeypatch, hmmfile):
     assert ba.T_M in kinds and (hmmfile != "MET-ct4.bhmm" or len(kinds) >= 2)
 
 
+@pytest.mark.parametrize("hmmfile", ["PTH2.bhmm", "MET-ct4.bhmm"])
+def test_kept_forward_rows_give_the_same_hits(ctx, monkeypatch, hmmfile):
+    """The domain stage reads the Forward parser's special-state rows of the ORFs that passed the Forward filter; the cascade's own
+    Forward launch leaves them (the reference keeps pli->oxf from the filter to p7_domaindef) and the domain stage copies the
+    survivors' rows instead of running the parser again.  BATH_HIP_KEEP_FWD=0 runs it again: every field of every domain must be
+    identical, bit for bit."""
+    path = ol.GOLDEN + "/" + hmmfile
+    model = ol.Model(path, 0)
+    rng = np.random.default_rng(23)
+    wins = []
+    for i, aa in enumerate(common.emit_from_model(rng, model, 30, flank=5, sharpen=1.5)):
+        nt = np.array(common.revtranslate(rng, aa, model.basic), dtype=np.uint8)
+        w = np.concatenate([rng.integers(0, 4, size=int(rng.integers(3, 300))).astype(np.uint8), nt, rng.integers(0, 4, size=int(rng.integers(0, 300))).astype(np.uint8)])
+        wins.append((3 - w[::-1]).astype(np.uint8) if i % 2 else w)
+    out = []
+    for keep in ("1", "0"):
+        monkeypatch.setenv("BATH_HIP_KEEP_FWD", keep)
+        _, dm, nskip = gpu_hits(ctx, path, 0, wins)
+        out.append((nskip, [(d.window, d.ienv, d.jenv, d.iali, d.jali, d.ihmm, d.jhmm, np.float32(d.envsc).view(np.uint32), np.float32(d.oasc).view(np.uint32),
+                             np.float32(d.domcorrection).view(np.uint32), np.float32(d.bitscore).view(np.uint32), d.lnP, d.ali_columns, d.pid, d.cigar, d.reported) for d in dm]))
+    assert out[0] == out[1] and len(out[0][1]) >= 15
+
+
 def test_hits_with_a_1024_node_model(ctx, tmp_path):
     """BASELINE config 5 shape: 16 nodes per lane in the wave-per-envelope kernels, 4 lanes per ORF in SSV."""
     path = common.write_synthetic_bhmm(str(tmp_path / "s1024.bhmm"), 1024, seed=1024)
