@@ -159,6 +159,15 @@ def query_items(n_windows_by_query, world, items_per_rank=2):
     return _items(n_windows_by_query, None, world, items_per_rank)
 
 
+def item_cost(M, n_nt):
+    """Estimated milliseconds of one (query, window group) item of a plain (no --fs) search on an MI355X, for the longest-first deal:
+    a fixed part that grows with the model (the latency chains of a query's cascade and domain stage: ~1 ms + 6.5 us per node) and
+    a throughput part (1.6e-10 ms per node and nucleotide).  Fitted to the items of the 100 Mb x 12-model job measured alone
+    (profiles/r05_c4_items.txt): 2.75 ms at 56 nodes, 4.0 at 152, 5.6 at 238, 7.6 for HALF the genome at 459 nodes -- which
+    residues x (M + 150), the weight the cut uses, puts level with the 152-node model's whole genome."""
+    return 1.0 + 0.0065 * M + 1.6e-10 * M * n_nt
+
+
 def query_items_weighted(n_windows_by_query, costs_by_query, world, items_per_rank=3):
     """[(query, lo, hi)] like query_items, but a query gets groups in proportion to its share of the work: round(share x T) of them,
     at least one, T = max(queries, items_per_rank x world).  With worker contexts running a rank's items side by side the longest

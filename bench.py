@@ -299,7 +299,7 @@ def c4_leg(ba, synth, bdist, ctx, args, cpu):
     all_wins = [bdist.split_targets([len(g)], h.max_length) for h in hmms]
     qcost = [sum(n for _, _, n, _ in w) * (h.M + 150.0) for w, h in zip(all_wins, hmms)]
     items = bdist.query_items_weighted([len(w) for w in all_wins], qcost, 1)
-    owner = bdist.deal([sum(n for _, _, n, _ in all_wins[q][lo:hi]) * (hmms[q].M + 150.0) for q, lo, hi in items], nw)
+    owner = bdist.deal([bdist.item_cost(hmms[q].M, sum(n for _, _, n, _ in all_wins[q][lo:hi])) for q, lo, hi in items], nw)
     workers = []
     for w in range(nw):
         c = ba.Context(0)
@@ -464,13 +464,13 @@ def c4_leg_ranks(ba, synth, bdist, ctx, args, rank, world, dev, on_gpu, sync, to
     n_nt = int(total_mb * 1e6)
     all_wins = [bdist.split_targets([n_nt], h.max_length) for h in hmms]
     items = bdist.query_items_weighted([len(w) for w in all_wins], [sum(n for _, _, n, _ in w) * (h.M + 150.0) for w, h in zip(all_wins, hmms)], world)
-    owner = bdist.deal([sum(n for _, _, n, _ in all_wins[q][lo:hi]) * (hmms[q].M + 150.0) for q, lo, hi in items], world)
+    owner = bdist.deal([bdist.item_cost(hmms[q].M, sum(n for _, _, n, _ in all_wins[q][lo:hi])) for q, lo, hi in items], world)
     mine = [it for it, o in zip(items, owner) if o == rank]
     # A rank's items go to worker contexts of its GPU (host threads, one context each): a query's search is a chain of small launches
     # and host steps that leaves the chip mostly idle, so the items of a rank run side by side like the queries of c4.concurrent_queries
     # (BATH_BENCH_C4_RANK_WORKERS, default 6; 1: one after the other on the rank's main context).
     import threading
-    cost = lambda it: sum(n for _, _, n, _ in all_wins[it[0]][it[1]:it[2]]) * (hmms[it[0]].M + 150.0)
+    cost = lambda it: bdist.item_cost(hmms[it[0]].M, sum(n for _, _, n, _ in all_wins[it[0]][it[1]:it[2]]))
     nwk = max(1, min(int(os.environ.get("BATH_BENCH_C4_RANK_WORKERS", "6")), len(mine)))
     wctx, wjobs = [], []
     if on_gpu:

@@ -13,7 +13,7 @@ n_nt = int(mb * 1e6)
 all_wins = [bdist.split_targets([n_nt], h.max_length) for h in hmms]
 items = bdist.query_items_weighted([len(w) for w in all_wins], [sum(n for _, _, n, _ in w) * (h.M + 150.0) for w, h in zip(all_wins, hmms)], 1)
 g, planted = synth.genome(n_nt, seed=4300, hmms=hmms, genes_per_model=max(4, n_nt // 400_000))
-cost = lambda it: sum(n for _, _, n, _ in all_wins[it[0]][it[1]:it[2]]) * (hmms[it[0]].M + 150.0)
+cost = lambda it: bdist.item_cost(hmms[it[0]].M, sum(n for _, _, n, _ in all_wins[it[0]][it[1]:it[2]]))
 ctx = ba.Context(0)
 def make(c, it):
     q, lo, hi = it
@@ -27,7 +27,7 @@ for it in items:
     ts = []
     for _ in range(3):
         t0 = time.perf_counter(); st, dm, ncl = pipe.run_hits(blk, arrays=True); ts.append((time.perf_counter() - t0) * 1e3)
-    print("item %-16s M %4d windows %4d..%4d alone %6.2f ms  domains %4d clustered %3d  cost %.2e" % (hmms[it[0]].name, hmms[it[0]].M, it[1], it[2], min(ts), len(dm), ncl, cost(it)), flush=True)
+    print("item %-16s M %4d windows %4d..%4d alone %6.2f ms  domains %4d clustered %3d  cost %.2f" % (hmms[it[0]].name, hmms[it[0]].M, it[1], it[2], min(ts), len(dm), ncl, cost(it)), flush=True)
     del pipe, blk
 own = bdist.deal([cost(it) for it in items], nwk)
 wctx = [ba.Context(0) for _ in range(nwk)]
