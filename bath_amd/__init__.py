@@ -20,20 +20,24 @@ import os as _os
 # and a host may run several contexts: with 4 queues, streams that are meant to run side by side end up one behind the other (two worker
 # contexts on whole --fs passes: 53-58 ms per block with 4, 49-51 with 16; nine contexts on configs[3]: 18.0 -> 14.5 ms per database
 # pass; one context alone: no difference).  Set before the first HIP call of the process; a value chosen by the caller is respected.
-def _hip_runtime_loaded():
+def _hip_runtime_initialised():
+    """True only when this process has already made a HIP call that started the runtime (the case in which GPU_MAX_HW_QUEUES comes too
+    late).  A mapped libamdhip64 says nothing -- `import torch` maps it long before any HIP call -- so the question goes to torch, the
+    only way the runtime starts in a Python host before this module: torch.cuda.is_initialized() does not itself touch the GPU."""
+    import sys as _sys
+    t = _sys.modules.get("torch")
     try:
-        with open("/proc/self/maps") as fh:
-            return any("libamdhip64" in line for line in fh)
-    except OSError:
+        return bool(t is not None and t.cuda.is_initialized())
+    except Exception:
         return False
 
 
 HW_QUEUES_SET_BY_IMPORT = "GPU_MAX_HW_QUEUES" not in _os.environ
 if HW_QUEUES_SET_BY_IMPORT:
     # (the variable is inherited by child processes; a host that wants another value sets it before importing this module)
-    if _hip_runtime_loaded():
+    if _hip_runtime_initialised():
         import warnings as _warnings
-        _warnings.warn("bath_amd: the HIP runtime is already loaded in this process, so GPU_MAX_HW_QUEUES=16 may come too late to take effect "
+        _warnings.warn("bath_amd: the HIP runtime is already initialised in this process, so GPU_MAX_HW_QUEUES=16 comes too late to take effect "
                        "(set it in the environment before the first HIP call: several worker contexts share 4 hardware queues otherwise; "
                        "INTEGRATION.md, 'Several contexts on one GPU')", RuntimeWarning, stacklevel=2)
     _os.environ["GPU_MAX_HW_QUEUES"] = "16"
@@ -275,7 +279,7 @@ ABI = {
     "bath_hits_cigars": (C.c_void_p, [_vp, _i64p]),
     "bath_hits_traces": (C.c_int, [_vp, C.POINTER(C.POINTER(DomainTrace)), C.POINTER(C.POINTER(C.c_int8)), C.POINTER(_i32p), C.POINTER(_i32p),
                                    C.POINTER(C.POINTER(C.c_int8)), C.POINTER(_f32p)]),
-    "bath_tophits_add_serialized": (C.c_int, [_vp, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p),
+    "bath_tophits_add_serialized": (C.c_int, [_vp, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p),
                                               C.POINTER(C.c_char_p), C.POINTER(C.c_int64)]),
     "bath_dist_shard_range": (None, [C.c_int64, C.c_int, C.c_int, _i64p, _i64p]),
     "bath_dist_items": (C.c_int64, [_i64p, C.POINTER(C.c_double), C.c_int, C.c_int, C.c_int, C.POINTER(DistItem), C.c_int64]),
@@ -941,7 +945,7 @@ class HitArray:
         recs, pools, shift = [], [], 0
         for h in parts:
             r = h.rec.copy()
-            r["cigar_off"] += shift
+            r["cigar_off"][r["cigar_off"] >= 0] += shift            # -1 = the hit came without a CIGAR: stays -1
             recs.append(r); pools.append(h.pool); shift += len(h.pool)
         return HitArray(np.concatenate(recs) if recs else np.zeros(0, dtype=FS_DOMAIN_DTYPE), b"".join(pools))
 

@@ -103,7 +103,7 @@ extern "C" int bath_hits_deserialize(const uint8_t *buf, int64_t nbytes, bath_hi
   Reader r{buf, nbytes};
   if (r.u32() != kMagic || r.u32() != kVersion) return BATH_EFORMAT;
   const uint64_t n = r.u64();
-  if (n > (uint64_t)nbytes) return BATH_EFORMAT;
+  if (n > (uint64_t)(nbytes - 16) / kHitBase) return BATH_EFORMAT;          // every record has a fixed part: the stream cannot hold more
   bath_hits *H = new bath_hits();
   H->dom.reserve((size_t)n);
   for (uint64_t h = 0; h < n && r.ok; h++) {
@@ -176,13 +176,20 @@ extern "C" int bath_hits_traces(const bath_hits *h, const bath_domain_trace **tr
 }
 
 // p7_tophits_Merge from a byte stream: the hits of another rank join this list (their window indices must already be the
-// search's own: the sender adds its shard's first window to bath_fs_domain.window before serializing, or passes window_shift here)
-extern "C" int bath_tophits_add_serialized(bath_tophits *th, const uint8_t *buf, int64_t nbytes, int64_t window_shift, int64_t seqidx0,
+// search's own: the sender adds its shard's first window to bath_fs_domain.window before serializing, or passes window_shift here).
+// The stream comes from another process: a hit whose shifted window is not one of the <n_seqs> sequences the name / length arrays
+// describe is refused (BATH_EFORMAT) before anything indexes them, and nothing is added.
+extern "C" int bath_tophits_add_serialized(bath_tophits *th, const uint8_t *buf, int64_t nbytes, int64_t window_shift, int64_t n_seqs, int64_t seqidx0,
                                            const char *const *seq_names, const char *const *seq_accs, const char *const *seq_descs, const int64_t *seq_lens) {
+  if (!th || n_seqs < 0) return BATH_EINVAL;
   bath_hits *H = nullptr;
   const int st = bath_hits_deserialize(buf, nbytes, &H);
   if (st != BATH_OK) return st;
-  for (bath_fs_domain &d : H->dom) d.window += window_shift;
+  for (bath_fs_domain &d : H->dom) {
+    if (d.window < 0 || d.window > INT64_MAX - std::max<int64_t>(window_shift, 0)) { delete H; return BATH_EFORMAT; }
+    d.window += window_shift;
+    if (d.window < 0 || d.window >= n_seqs) { delete H; return BATH_EFORMAT; }
+  }
   const int rc = bath_tophits_add(th, H->dom.data(), (int64_t)H->dom.size(), H->cigars.c_str(), seqidx0, seq_names, seq_accs, seq_descs, seq_lens);
   delete H;
   return rc;
@@ -192,6 +199,11 @@ extern "C" int bath_tophits_add_serialized(bath_tophits *th, const uint8_t *buf,
 // Contiguous shares of n units: rank r of <world> gets [lo, hi), the first n % world ranks one unit more (the block queue of
 // bathsearch's threads hands out consecutive blocks; a static cut of the same list)
 extern "C" void bath_dist_shard_range(int64_t n, int rank, int world, int64_t *lo, int64_t *hi) {
+  if (world < 1 || rank < 0 || rank >= world || n < 0) {                    // no such share: an empty range, never a division by zero
+    if (lo) *lo = 0;
+    if (hi) *hi = 0;
+    return;
+  }
   const int64_t base = n / world, extra = n % world;
   const int64_t a = (int64_t)rank * base + std::min<int64_t>(rank, extra);
   if (lo) *lo = a;

@@ -1639,11 +1639,14 @@ static int std_domains(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bat
   size_t up_used = 0;
   auto up_begin = [&](size_t bytes) -> int { up_used = 0; BATH_HIP_TRY(ctx, ctx->stage[4].reserve(bytes + 1024)); return BATH_OK; };
   auto up = [&](void *dst, std::initializer_list<std::pair<const void *, size_t>> parts) -> int {
-    char *h = static_cast<char *>(ctx->stage[4].p) + up_used;
     size_t bytes = 0;
+    for (const auto &q : parts) bytes += q.second;
+    const size_t end = up_used + ((bytes + 63) & ~(size_t)63);
+    if (end > ctx->stage[4].cap) { ctx->set_error("staging area of the domain stage too small"); return BATH_EFAIL; }      // before anything is written
+    char *h = static_cast<char *>(ctx->stage[4].p) + up_used;
+    bytes = 0;
     for (const auto &q : parts) { std::memcpy(h + bytes, q.first, q.second); bytes += q.second; }
-    up_used += (bytes + 63) & ~(size_t)63;
-    if (up_used > ctx->stage[4].cap) { ctx->set_error("staging area of the domain stage too small"); return BATH_EFAIL; }
+    up_used = end;
     BATH_HIP_TRY(ctx, hipMemcpyAsync(dst, h, bytes, hipMemcpyHostToDevice, ctx->stream));
     return BATH_OK;
   };

@@ -521,8 +521,10 @@ const char *bath_hits_cigars(const bath_hits *h, int64_t *nbytes);
 int     bath_hits_traces(const bath_hits *h, const bath_domain_trace **tr, const int8_t **st, const int32_t **k, const int32_t **i,
                          const int8_t **c, const float **pp);                           /* BATH_EINVAL when the stream carried none */
 /* p7_tophits_Merge from a byte stream (bathsearch.c:884-888): the hits of another rank join <th>.  <window_shift> is added to every
- * hit's window index (a rank that searched windows [lo, hi) of the search numbers them from 0); the rest as bath_tophits_add. */
-int     bath_tophits_add_serialized(bath_tophits *th, const uint8_t *buf, int64_t nbytes, int64_t window_shift, int64_t seqidx0,
+ * hit's window index (a rank that searched windows [lo, hi) of the search numbers them from 0); <n_seqs> is the length of the
+ * seq_* arrays: a hit whose shifted window is not in [0, n_seqs) -- a damaged or mismatched stream, a wrong shift -- is refused with
+ * BATH_EFORMAT and nothing is added; the rest as bath_tophits_add. */
+int     bath_tophits_add_serialized(bath_tophits *th, const uint8_t *buf, int64_t nbytes, int64_t window_shift, int64_t n_seqs, int64_t seqidx0,
                                     const char *const *seq_names, const char *const *seq_accs, const char *const *seq_descs, const int64_t *seq_lens);
 
 /* Division of the work, the same on every rank without communication.

@@ -79,6 +79,14 @@ int main(void)
   CHECK(bath_hits_deserialize(b2, n1, &H) == BATH_EFORMAT && bath_hits_stream_size(b2, n1) == -1);
   b2[0] = 'X';
   CHECK(bath_hits_deserialize(b2, n1, &H) == BATH_EFORMAT);
+  { /* a header that claims more hits than the bytes behind it could hold is refused before anything is reserved */
+    uint8_t hdr[24]; memcpy(hdr, b1, 16); memset(hdr + 16, 0, 8);
+    hdr[8] = 0x7f; hdr[15] = 24;
+    CHECK(bath_hits_deserialize(hdr, 24, &H) == BATH_EFORMAT && H == NULL);
+    memset(hdr + 8, 0, 8); hdr[15] = 24;                                                             /* n = 24 <= nbytes, the old bound */
+    CHECK(bath_hits_deserialize(hdr, 24, &H) == BATH_EFORMAT && H == NULL);
+  }
+  { int64_t lo = 7, hi = 7; bath_dist_shard_range(10, 0, 0, &lo, &hi); CHECK(lo == 0 && hi == 0); } /* world 0: an empty share, no SIGFPE */
 
   /* ---- 3. a remote rank's hits join the hit list */
   const char *names[4] = { "chr1", "chr2", "chr3", "chr4" };
@@ -90,7 +98,10 @@ int main(void)
   uint8_t *br = malloc((size_t) nr);
   bath_hits_serialize(rem, 2, cigars, NULL, NULL, NULL, NULL, NULL, NULL, br, nr);
   bath_tophits *th = bath_tophits_create();
-  CHECK(bath_tophits_add_serialized(th, br, nr, 2 /* ... and owns windows [2, 4) of the search */, 0, names, NULL, NULL, lens) == BATH_OK);
+  /* a stream whose windows fall outside the search's sequences (a wrong shift, a mismatched stream) is refused whole */
+  CHECK(bath_tophits_add_serialized(th, br, nr, 3, 4, 0, names, NULL, NULL, lens) == BATH_EFORMAT && bath_tophits_count(th) == 0);
+  CHECK(bath_tophits_add_serialized(th, br, nr, -1, 4, 0, names, NULL, NULL, lens) == BATH_EFORMAT && bath_tophits_count(th) == 0);
+  CHECK(bath_tophits_add_serialized(th, br, nr, 2 /* ... and owns windows [2, 4) of the search */, 4, 0, names, NULL, NULL, lens) == BATH_OK);
   CHECK(bath_tophits_count(th) == 2 && bath_tophits_finalize(th, 20000, 100, 10.0) == BATH_OK && bath_tophits_reported(th) == 2);
   char tbl[4096];
   const int64_t nt = bath_tophits_tabular_targets(th, "query", "-", 134, 1, 1, 0, tbl, sizeof tbl - 1);

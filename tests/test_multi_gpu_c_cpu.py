@@ -55,3 +55,39 @@ def test_python_hit_arrays_travel_as_the_c_stream():
     assert p == len(b) and h2.to_bytes() == b and h2.pool == b"30M\0" + b"12M3I9M\0"
     both = ba.HitArray.concat([h2, h])
     assert both.to_bytes() == ba.HitArray.from_bytes(both.to_bytes())[0].to_bytes() and len(both) == 4
+
+
+def test_concat_keeps_absent_cigars_absent():
+    """A hit shipped without a CIGAR comes back with cigar_off == -1 (bath_hits_deserialize); behind another part's pool it must stay
+    -1, not become an offset into that pool (an absent CIGAR would silently turn into the previous part's terminating NUL)."""
+    d = ba.FsDomain(); d.window = 1; d.reported = 1; d.iali = 10; d.jali = 100; d.cigar = "30M"
+    e = ba.FsDomain(); e.window = 2; e.reported = 1; e.iali = 50; e.jali = 90; e.cigar = "7M1F5M"
+    with_cig = ba.HitArray.from_domains([d, e])
+    bare = ba.HitArray(with_cig.rec.copy(), b"")                                     # the same records, no pool: serialized without CIGARs
+    bare2, _ = ba.HitArray.from_bytes(bare.to_bytes())
+    assert list(bare2.rec["cigar_off"]) == [-1, -1]
+    both = ba.HitArray.concat([with_cig, bare2, with_cig])
+    assert list(both.rec["cigar_off"]) == [0, 4, -1, -1, 11, 15] and both.pool == with_cig.pool * 2
+    again, _ = ba.HitArray.from_bytes(both.to_bytes())                                # ... and the mixed array travels
+    assert list(again.rec["cigar_off"]) == [0, 4, -1, -1, 11, 15] and again.pool == both.pool
+
+
+def test_remote_hits_outside_the_search_are_refused():
+    """bath_tophits_add_serialized checks every shifted window against the number of sequences before anything indexes the name and
+    length arrays (a damaged stream or a wrong shift must be an error code, not an out-of-bounds read)."""
+    import ctypes as C
+    d = ba.FsDomain(); d.window = 3; d.reported = 1; d.iali = 10; d.jali = 100; d.lnP = -40.0; d.bitscore = 50.0; d.cigar = "30M"
+    b = ba.HitArray.from_domains([d]).to_bytes()
+    names = (C.c_char_p * 4)(b"a", b"b", b"c", b"d")
+    lens = (C.c_int64 * 4)(1000, 1000, 1000, 1000)
+    L = ba.lib()
+    th = L.bath_tophits_create()
+    EFORMAT = L.bath_hits_deserialize(b"XXXX" + b[4:], len(b), C.byref(C.c_void_p()))
+    assert EFORMAT != ba.OK
+    assert L.bath_tophits_add_serialized(th, b, len(b), 1, 4, 0, names, None, None, lens) == EFORMAT      # 3 + 1 = 4: past the end
+    assert L.bath_tophits_add_serialized(th, b, len(b), -4, 4, 0, names, None, None, lens) == EFORMAT     # negative
+    assert L.bath_tophits_count(th) == 0
+    assert L.bath_tophits_add_serialized(th, b, len(b), 0, 4, 0, names, None, None, lens) == ba.OK and L.bath_tophits_count(th) == 1
+    L.bath_tophits_destroy(th)
+    lo, hi = bd.shard_range(10, 0, 0)                                                # world 0: an empty share, no SIGFPE
+    assert (lo, hi) == (0, 0)

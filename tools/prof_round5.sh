@@ -13,7 +13,7 @@ python3 bench.py --steps 5 --warmup 1 > $OUT/bench_plain.json 2> $OUT/bench_plai
 BATH_HIP_TIMING=1 python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-c45 --no-streamed --no-concurrent --no-one-part > /dev/null 2> $OUT/bench_stage_laps.txt
 # 1a: the cascade alone: every ssv_orf_kernel launch is a half-block launch of a timed step
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats0 -o bench0 -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-fs --no-streamed --no-concurrent --no-one-part --no-c45 > $OUT/bench_under_prof_cascade.log 2>&1
-grep '^{"metric"' $OUT/bench_under_prof_cascade.log > $OUT/bench_under_prof_cascade.json
+grep '^{"metric"' $OUT/bench_under_prof_cascade.log | tail -1 > $OUT/bench_under_prof_cascade.json   # stdout's compact line is the last one (stderr carries the full record)
 find $OUT/stats0 -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats_cascade.csv \;
 rm -rf $OUT/stats0
 # 1b: the whole default command (all legs: cascade, streamed, --fs strict + fast, c4, c5)
