@@ -73,32 +73,52 @@ def reduce_stats(stats, device="cpu"):
     return dict(zip(STAT_FIELDS, [int(v) for v in vals.cpu()]))
 
 
+def exchange_bytes(by_dest, device="cpu"):
+    """Variable-length exchange of bytes objects: {destination rank: payload} on every rank -> {source rank: payload} on every rank
+    (only non-empty payloads travel; a rank's payload to itself does not leave the process).  The byte counts go in ONE all-gather;
+    then every send and every receive of the exchange is posted at once (batch_isend_irecv: a grouped launch under RCCL), so the
+    streams of N - 1 ranks to one receiver move side by side, each on its own xGMI link, instead of one rank after the other."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return {0: by_dest[0]} if by_dest.get(0) else {}
+    world, rank = dist.get_world_size(), dist.get_rank()
+    mine = np.zeros(world, dtype=np.int64)
+    for d, payload in by_dest.items():
+        if not 0 <= int(d) < world:
+            raise ValueError("exchange_bytes: no rank %r in a world of %d" % (d, world))
+        mine[int(d)] = len(payload)
+    counts = [torch.zeros(world, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(counts, torch.from_numpy(mine).to(device))
+    counts = torch.stack(counts).cpu().numpy()                      # counts[src][dst]
+    ops, bufs, keep = [], {}, []
+    for src in range(world):
+        k = int(counts[src][rank])
+        if src != rank and k:
+            bufs[src] = torch.empty(k, dtype=torch.uint8, device=device)
+            ops.append(dist.P2POp(dist.irecv, bufs[src], src))
+    for d, payload in by_dest.items():
+        if int(d) != rank and len(payload):
+            t = torch.frombuffer(bytearray(payload), dtype=torch.uint8).to(device)
+            keep.append(t)
+            ops.append(dist.P2POp(dist.isend, t, int(d)))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    out = {src: bytes(b.cpu().numpy().tobytes()) for src, b in bufs.items()}
+    if by_dest.get(rank):
+        out[rank] = by_dest[rank]
+    return out
+
+
 def gather_bytes(data, dst=0, device="cpu"):
     """Variable-length gather of one bytes object per rank ON RANK <dst> ONLY (p7_tophits_Merge's direction: workers -> master):
-    every rank sends its length, then its payload, point to point; nothing is replicated to the other ranks.
-    Returns the list of payloads on rank <dst>, None elsewhere."""
+    every rank's byte count in one all-gather, then every payload point to point with all the receives posted at once
+    (exchange_bytes); nothing is replicated to the other ranks.  Returns the list of payloads on rank <dst>, None elsewhere."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return [data]
-    world, rank = dist.get_world_size(), dist.get_rank()
-    n = torch.tensor([len(data)], dtype=torch.int64, device=device)
-    if rank == dst:
-        counts = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
-        dist.gather(n, counts, dst=dst)
-        out = []
-        for r in range(world):
-            if r == dst:
-                out.append(data)
-                continue
-            k = int(counts[r].item())
-            buf = torch.empty(max(k, 1), dtype=torch.uint8, device=device)
-            if k:
-                dist.recv(buf[:k], src=r)
-            out.append(bytes(buf[:k].cpu().numpy().tobytes()))
-        return out
-    dist.gather(n, None, dst=dst)
-    if len(data):
-        dist.send(torch.frombuffer(bytearray(data), dtype=torch.uint8).to(device), dst=dst)
-    return None
+    got = exchange_bytes({dst: data}, device)
+    if dist.get_rank() != dst:
+        return None
+    return [got.get(r, b"") for r in range(dist.get_world_size())]
 
 
 def gather_results(res, window_offset, dst=0, device="cpu"):
@@ -161,11 +181,12 @@ def query_items(n_windows_by_query, world, items_per_rank=2):
 
 def item_cost(M, n_nt):
     """Estimated milliseconds of one (query, window group) item of a plain (no --fs) search on an MI355X, for the longest-first deal:
-    a fixed part that grows with the model (the latency chains of a query's cascade and domain stage: ~1 ms + 6.5 us per node) and
-    a throughput part (1.6e-10 ms per node and nucleotide).  Fitted to the items of the 100 Mb x 12-model job measured alone
-    (profiles/r05_c4_items.txt): 2.75 ms at 56 nodes, 4.0 at 152, 5.6 at 238, 7.6 for HALF the genome at 459 nodes -- which
-    residues x (M + 150), the weight the cut uses, puts level with the 152-node model's whole genome."""
-    return 1.0 + 0.0065 * M + 1.6e-10 * M * n_nt
+    a fixed part that grows with the model (the latency chains of a query's cascade and domain stage: 1.5 ms + 9 us per node) and a
+    throughput part, 7.5e-11 ms per node and nucleotide (the cascade's rate: 2 strands x 0.75 ORF residues per nt x M cells at 2e13
+    cells/s).  The throughput term is fixed from the cascade's measured rate, the other two are a least-squares fit to the 13 items
+    of the 100 Mb x 12-model job measured alone (profiles/r05_c4_items.txt: 2.75 ms at 56 nodes ... 7.6 ms for HALF the genome at
+    459 nodes): within 13 % of every item but one (tests/test_dist_cpu.py pins the ordering)."""
+    return 1.5 + 0.009 * M + 7.5e-11 * M * n_nt
 
 
 def query_items_weighted(n_windows_by_query, costs_by_query, world, items_per_rank=3):
@@ -241,6 +262,51 @@ def gather_query_hits(by_query, dst=0, device="cpu"):
             h, p = HitArray.from_bytes(part, p + 4)
             got.setdefault(q, []).append(h)
     return {q: HitArray.concat(v) for q, v in got.items()}
+
+
+def query_owner(query, world):
+    """The rank that finishes <query> (its hit list merged, E-values, duplicates, sorting, the table's text): q mod N, so that the
+    serial end of a multi-query job is spread over the ranks instead of sitting on rank 0."""
+    return int(query) % int(world)
+
+
+def exchange_query_hits(by_query, device="cpu"):
+    """p7_tophits_Merge per query ON THE QUERY'S OWNER: {query: HitArray} of every rank -> {query: HitArray} (the union over the
+    ranks, CIGAR offsets rebased) for the queries this rank owns (query_owner).  One exchange_bytes for all queries."""
+    from . import HitArray
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    by_dest = {}
+    for q in sorted(by_query):
+        by_dest.setdefault(query_owner(q, world), bytearray()).extend(int(q).to_bytes(4, "little") + by_query[q].to_bytes())
+    parts = exchange_bytes({d: bytes(b) for d, b in by_dest.items()}, device)
+    got = {}
+    for src in sorted(parts):                                      # rank order: the merged list does not depend on arrival order
+        part, p = parts[src], 0
+        while p < len(part):
+            q = int.from_bytes(part[p : p + 4], "little")
+            h, p = HitArray.from_bytes(part, p + 4)
+            got.setdefault(q, []).append(h)
+    return {q: HitArray.concat(v) for q, v in got.items()}
+
+
+def gather_query_tables(tables, dst=0, device="cpu"):
+    """The finished queries travel to the rank that prints: {query: (reported hits, table text)} of every owner -> the same dict
+    for all queries on rank <dst> (None elsewhere).  What moves is the table's text, not the hits."""
+    blob = bytearray()
+    for q in sorted(tables):
+        n, text = tables[q]
+        t = text.encode()
+        blob += int(q).to_bytes(4, "little") + int(n).to_bytes(8, "little") + len(t).to_bytes(8, "little") + t
+    parts = gather_bytes(bytes(blob), dst, device)
+    if parts is None:
+        return None
+    out = {}
+    for part in parts:
+        p = 0
+        while p < len(part):
+            q = int.from_bytes(part[p : p + 4], "little"); n = int.from_bytes(part[p + 4 : p + 12], "little"); k = int.from_bytes(part[p + 12 : p + 20], "little")
+            out[q] = (n, part[p + 20 : p + 20 + k].decode()); p += 20 + k
+    return out
 
 
 def reduce_query_stats(stats_by_query, n_queries, device="cpu"):

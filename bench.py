@@ -302,7 +302,7 @@ def c4_leg(ba, synth, bdist, ctx, args, cpu):
     owner = bdist.deal([bdist.item_cost(hmms[q].M, sum(n for _, _, n, _ in all_wins[q][lo:hi])) for q, lo, hi in items], nw)
     workers = []
     for w in range(nw):
-        c = ba.Context(0)
+        c = ba.Context(GPU)
         jobs = []
         for (q, lo, hi), o in zip(items, owner):
             if o != w:
@@ -421,6 +421,20 @@ def c5_leg(ba, synth, bdist, ctx, args, cpu):
                                                          "mismatches": {k: {"gpu": a, "cpu": b} for k, (a, b) in parity.items() if a != b}, "cpu_seconds": cpu["c5_seconds"], **(c5_hits or {})}}
 
 
+def domain_records(domains):
+    """A hit list as a sorted list of tuples -- every field that reaches the output, floats by their bits, the CIGAR string -- so that
+    two searches can be compared record for record (fs_window, the index of the DNA window inside ONE pass, is local and left out)."""
+    return sorted((int(d.window), int(d.strand), int(d.ienv), int(d.jenv), int(d.iali), int(d.jali), int(d.ihmm), int(d.jhmm), fbits(d.envsc), fbits(d.bitscore),
+                   float(d.lnP), int(d.reported), int(d.n_shifted_codons), int(d.n_stops), d.cigar) for d in domains)
+
+
+def records_diff(a, b, limit=3):
+    """(equal, a few records only one side has) of two domain_records lists."""
+    sa, sb = set(a), set(b)
+    return a == b, {"n_ranks_search": len(a), "single_rank_search": len(b), "only_in_ranks_search": [list(map(str, x)) for x in sorted(sa - sb)[:limit]],
+                    "only_in_single_rank_search": [list(map(str, x)) for x in sorted(sb - sa)[:limit]]}
+
+
 def finish_query(ba, hmm, domains, wins, nres, genome_len):
     """Rank 0's end of a query (bathsearch.c:868-921): window coordinates -> target coordinates, E-values with the whole search's
     residue count, duplicates of the window overlaps removed, sorted, thresholded; returns (reported hits, --tblout text)."""
@@ -451,8 +465,9 @@ def finish_query_arrays(ba, hmm, hits, wins, nres, genome_len):
 
 def c4_leg_ranks(ba, synth, bdist, ctx, args, rank, world, dev, on_gpu, sync, total_mb):
     """BASELINE configs[3] over N ranks: the 12-model database is broadcast once; (query, window group) pairs are dealt to the
-    ranks (dist.query_items / dist.deal); per query the hits and the counters are gathered on rank 0, which finishes every query
-    like the single-rank search (dist.gather_query_domains, finish_query).  Strong scaling of ONE job: <total_mb> Mb x 12 queries."""
+    ranks (dist.query_items_weighted / dist.deal); per query the hits travel to the query's owner rank (q mod N), which finishes it
+    like the single-rank search (dist.exchange_query_hits, finish_query_arrays), the counters are all-reduced, and the finished
+    tables are gathered on rank 0 (dist.gather_query_tables).  Strong scaling of ONE job: <total_mb> Mb x 12 queries."""
     import hashlib
     blob = open(DB, "rb").read() if rank == 0 else b""
     blob = bdist.broadcast_bytes(blob, 0, dev)                          # the whole database, once (1 MB over xGMI)
@@ -477,7 +492,7 @@ def c4_leg_ranks(ba, synth, bdist, ctx, args, rank, world, dev, on_gpu, sync, to
         g, planted = synth.genome(n_nt, seed=4300, hmms=hmms, genes_per_model=max(4, n_nt // 400_000))
         wown = bdist.deal([cost(it) for it in mine], nwk)
         for w in range(nwk):
-            c = ctx if nwk == 1 else ba.Context(dev.index or 0)
+            c = ctx if nwk == 1 else ba.Context(GPU)
             jobs = []
             for (q, lo, hi), o in zip(mine, wown):
                 if o != w:
@@ -538,16 +553,21 @@ def c4_leg_ranks(ba, synth, bdist, ctx, args, rank, world, dev, on_gpu, sync, to
                 acc["nres"] += 2 * sum(n - c for _, _, n, c in all_wins[q][lo:hi])
         busy += time.perf_counter() - tb
         tg = time.perf_counter()
-        gathered = bdist.gather_query_hits({q: ba.HitArray.concat(v) for q, v in by_q.items()}, 0, dev)
+        # p7_tophits_Merge per query on the query's OWNER (q mod N), p7_pipeline_Merge for all queries in one all-reduce
+        owned = bdist.exchange_query_hits({q: ba.HitArray.concat(v) for q, v in by_q.items()}, dev)
         merged = bdist.reduce_query_stats(st_q, len(hmms), dev)
         t_gather += time.perf_counter() - tg
-        tables = []
-        if rank == 0:
-            tf = time.perf_counter()
-            # every query finished on rank 0, inside the timed region; the twelve hit lists are independent and the work is the
-            # library's (sort, duplicates, thresholds, the table's text): a few threads, as bathsearch's output stage could
-            tables = list(finish_pool.map(lambda q: finish_query_arrays(ba, hmms[q], gathered.get(q), all_wins[q], merged[q]["nres"], n_nt), range(len(hmms))))
-            t_finish += time.perf_counter() - tf
+        tf = time.perf_counter()
+        # every query finished on its owner, inside the timed region (bathsearch.c:868-921: E-values with the whole search's residue
+        # count, duplicates of the window overlaps, sort, thresholds, the table's text); a rank's queries are independent and the
+        # work is the library's: a few threads, as bathsearch's output stage could.  Only the finished tables travel to rank 0.
+        my_q = [q for q in range(len(hmms)) if bdist.query_owner(q, world) == rank]
+        done = dict(zip(my_q, finish_pool.map(lambda q: finish_query_arrays(ba, hmms[q], owned.get(q), all_wins[q], merged[q]["nres"], n_nt), my_q)))
+        t_finish += time.perf_counter() - tf
+        tg = time.perf_counter()
+        got_tables = bdist.gather_query_tables(done, 0, dev)
+        t_gather += time.perf_counter() - tg
+        tables = [got_tables[q] for q in range(len(hmms))] if rank == 0 else []
     sync()
     dt = bdist.max_over_ranks((time.perf_counter() - t0) / steps, dev)
     busy_all = bdist.gather_floats(busy / steps * 1e3, 0, dev)
@@ -559,9 +579,10 @@ def c4_leg_ranks(ba, synth, bdist, ctx, args, rank, world, dev, on_gpu, sync, to
     if rank != 0:
         return None
     out = {"workload": "tRNA-proteins.bhmm (12 query models, broadcast once) vs ONE %.0f Mb synthetic genome: (query, window group) pairs dealt to %d rank(s), "
-                       "hits and counters gathered per query on rank 0 and every query finished there (strong scaling)" % (total_mb, world),
+                       "a query's hits merged and finished on its owner rank (q mod N), counters all-reduced, tables gathered on rank 0 (strong scaling)" % (total_mb, world),
            "n_gpus": world, "scaling": "strong", "items": len(items), "items_per_rank": [owner.count(r) for r in range(world)], "worker_contexts_per_rank": nwk,
            "ms_per_database_pass": dt * 1e3, "rank_busy_ms": busy_all, "rank0_gather_ms": t_gather / steps * 1e3, "rank0_finish_ms": t_finish / steps * 1e3,
+           "queries_finished_on": "their owner rank (q mod N); the finished tables travel to rank 0", "queries_owned_by_rank0": len(my_q),
            "residues_per_s": sum(m["nres"] for m in merged) / dt, "hits": int(sum(t[0] for t in tables)), "hits_per_query": [t[0] for t in tables],
            "tables_sha1": hashlib.sha1("".join(t[1] for t in tables).encode()).hexdigest()[:16]}
     if on_gpu and world > 1:
@@ -574,6 +595,8 @@ def c4_leg_ranks(ba, synth, bdist, ctx, args, rank, world, dev, on_gpu, sync, to
             st, dm, _ = pipe.run_hits(blk)
             solo.append(finish_query(ba, hmm, dm, all_wins[q], st.nres, n_nt))
         out["tables_equal_to_single_rank_search"] = [a[1] for a in solo] == [b[1] for b in tables]
+        out["single_rank_hits_per_query"] = [a[0] for a in solo]
+        out["queries_whose_tables_differ"] = [q for q, (a, b) in enumerate(zip(solo, tables)) if a[1] != b[1]]
     return out
 
 
@@ -613,11 +636,25 @@ def c5_leg_ranks(ba, synth, bdist, ctx, args, rank, world, dev, on_gpu, sync, to
     dt = bdist.max_over_ranks((time.perf_counter() - t0) / steps, dev)
     if rank != 0:
         return None
-    return {"workload": "synthetic %d-node model --fs vs ONE %.0f Mb synthetic genome, %d windows of %d nt with context in contiguous shards over %d rank(s); "
-                        "domains gathered on rank 0 inside the timed region (strong scaling)" % (C5_M, total_mb, len(wins), bdist.BLOCK_LENGTH, world),
-            "n_gpus": world, "scaling": "strong", "ms_per_pass": dt * 1e3, "residues_per_s": merged["nres"] / dt, "mode": "strict (the library's default)",
-            "domains_gathered": len(gathered), "reported": int(sum(d.reported for d in gathered)),
-            "windows_of_gathered_domains_are_global": bool(all(0 <= d.window < len(wins) for d in gathered))}
+    out = {"workload": "synthetic %d-node model --fs vs ONE %.0f Mb synthetic genome, %d windows of %d nt with context in contiguous shards over %d rank(s); "
+                       "domains gathered on rank 0 inside the timed region (strong scaling)" % (C5_M, total_mb, len(wins), bdist.BLOCK_LENGTH, world),
+           "n_gpus": world, "scaling": "strong", "ms_per_pass": dt * 1e3, "residues_per_s": merged["nres"] / dt, "mode": "strict (the library's default)",
+           "domains_gathered": len(gathered), "reported": int(sum(d.reported for d in gathered)),
+           "windows_of_gathered_domains_are_global": bool(all(0 <= d.window < len(wins) for d in gathered))}
+    if on_gpu and world > 1:
+        # the same search on rank 0 alone, outside the timed region (bathsearch.c:868-921: what the merge of the workers must give):
+        # every gathered domain and every counter equal to the single-rank pass's
+        del blk
+        g, _ = synth.genome(n_nt, seed=4400, hmms=[hmm], genes_per_model=max(8, n_nt // 400_000), frameshift=True)
+        whole = ba.SeqBlock(ctx, [g[s_:s_ + n] for _, s_, n, _ in wins]); whole.set_context([c for _, _, _, c in wins])
+        del g
+        s_stats, _, s_dm, _ = pipe.run_frameshift_domains(om3, om5, whole)
+        same, diff = records_diff(domain_records(gathered), domain_records(s_dm))
+        cdiff = {f: (merged[f], int(getattr(s_stats, f))) for f in COUNTERS if merged[f] != int(getattr(s_stats, f))}
+        out["domains_equal_to_single_rank_search"] = bool(same)
+        out["counters_equal_to_single_rank_search"] = not cdiff
+        out["single_rank_check"] = {**diff, "counter_mismatches": {k: {"ranks": a, "single": b} for k, (a, b) in cdiff.items()}}
+    return out
 
 
 def c5_size_sweep(ba, synth, bdist, ctx, sizes_mb):
@@ -647,6 +684,9 @@ def c5_size_sweep(ba, synth, bdist, ctx, sizes_mb):
                     "chain_kernels_ms": {k: round(kt[k][0], 1) for k in ("fs3_fwd_kernel", "fs_bwd_kernel<3>") if k in kt}})
         del blk
     return out
+
+
+GPU = 0          # the device this rank's contexts live on (main() sets it: LOCAL_RANK, or 0 under BATH_BENCH_SHARE_DEVICE=1)
 
 
 # ------------------------------------------------------------------------------------------------ launcher
@@ -748,11 +788,23 @@ def main():
     on_gpu = torch.cuda.is_available() and not args.plumbing_only
     if not on_gpu and not args.plumbing_only:
         raise SystemExit("bench.py needs an MI355X: the backend has no CPU path")
+    # Which GPU a rank computes on, and where the collectives' tensors live.  Default: rank r on GPU r, RCCL ("nccl") on device tensors.
+    # BATH_BENCH_SHARE_DEVICE=1 puts every rank's context on GPU 0 and BATH_BENCH_BACKEND=gloo moves the collectives to CPU tensors:
+    # the N-rank legs then run with REAL kernels on a one-GPU box (RCCL refuses two ranks on one device), which is how
+    # tests/test_nrank_gpu.py checks the N-rank search against the single-rank search record for record.
+    global GPU
+    share_device = os.environ.get("BATH_BENCH_SHARE_DEVICE") == "1"
+    backend = os.environ.get("BATH_BENCH_BACKEND") or ("nccl" if on_gpu else "gloo")
+    if backend not in ("nccl", "gloo"):
+        raise SystemExit("BATH_BENCH_BACKEND must be nccl or gloo")
+    if on_gpu and share_device and backend == "nccl" and world > 1:
+        raise SystemExit("BATH_BENCH_SHARE_DEVICE=1 needs BATH_BENCH_BACKEND=gloo: RCCL does not run two ranks on one device")
+    GPU = 0 if share_device else local_rank
     if on_gpu:
-        torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank) if on_gpu else torch.device("cpu")
+        torch.cuda.set_device(GPU)
+    dev = torch.device("cuda", GPU) if (on_gpu and backend == "nccl") else torch.device("cpu")
     if world > 1:
-        if on_gpu:
+        if backend == "nccl" and on_gpu:
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group("gloo")
@@ -777,7 +829,7 @@ def main():
 
     stage_ms, stage_launches = {}, {}
     if on_gpu:
-        ctx = ba.Context(local_rank)
+        ctx = ba.Context(GPU)
         om = ba.OProfile(ctx, ba.Profile(hmm))
         dna = ba.SeqBlock(ctx, flat, offsets)
         pipe = ba.Pipeline(ctx, om, fs_pipe=False, ncbi_table=hmm.ct)
@@ -816,6 +868,18 @@ def main():
         ms_with_results = 0.0
     merged = bdist.reduce_stats(stats, dev)
     hits = bdist.gather_results(res, lo, 0, dev)
+    strong_check = None
+    if on_gpu and world > 1 and args.scaling == "strong" and rank == 0:
+        # one block over N ranks must be the block on one rank (p7_pipeline_Merge, p7_tophits_Merge: bathsearch.c:884-893): rank 0 runs
+        # the WHOLE block alone, outside the timed region, and compares the reduced counters and the gathered records with its own
+        full, _, _ = synth.dna_windows(args.windows, args.length, seed=42, hmm=hmm0)
+        whole = ba.SeqBlock(ctx, full, np.arange(args.windows + 1, dtype=np.int64) * args.length)
+        s_stats, s_res = pipe.run(whole, want_results=True, copy=False)
+        cdiff = {f: (merged[f], int(getattr(s_stats, f))) for f in COUNTERS if merged[f] != int(getattr(s_stats, f))}
+        key = lambda r: sorted(zip(*([r[f].tolist() for f in ("window", "strand", "frame", "start", "end", "stage")] + [np.ascontiguousarray(r["usc"]).view(np.uint32).tolist()])))
+        strong_check = {"counters_equal_to_single_rank": not cdiff, "records_equal_to_single_rank": key(hits) == key(s_res),
+                        "counter_mismatches": {k: {"ranks": a, "single": b} for k, (a, b) in cdiff.items()}}
+        del whole, full
 
     out = None
     if rank == 0:
@@ -843,6 +907,8 @@ def main():
         }
         if args.plumbing_only:
             out["plumbing_only"] = True
+        if strong_check is not None:
+            out["strong_scaling_check"] = strong_check
     if rank == 0 and on_gpu:
         out["stage_ms"] = {k: float(np.mean(v)) for k, v in stage_ms.items()}
         # dominant kernel: ssv_orf_kernel.  A large block runs as <lanes> concurrent parts (bath_hip_pipeline_filters), so a
@@ -982,6 +1048,8 @@ def compact_line(out):
     if cb:
         c["cpu_baseline"] = {"value": _r(cb["value"]), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
                              "sample": "%s (SSE2 restatement of impl_sse)" % cb.get("sample", "").split(",")[0]}
+    if "strong_scaling_check" in out:
+        c["strong_check"] = {k: out["strong_scaling_check"][k] for k in ("counters_equal_to_single_rank", "records_equal_to_single_rank")}
     if "parity_full_block" in out:
         c["parity_full_block"] = out["parity_full_block"]
     fs = out.get("fs")
@@ -995,7 +1063,8 @@ def compact_line(out):
                    "fast_ms": _r(g(fs, "fast", "ms_per_pass")), "domains": fs.get("domains"),
                    "fast_identical": g(fs, "fast", "domains_identical_to_strict_mode")}
         if fs.get("n_gpus"):
-            c["fs"]["n_gpus"] = fs.get("n_gpus")
+            c["fs"] = {"ms_per_pass": _r(fs.get("ms_per_pass")), "residues_per_s": _r(fs.get("residues_per_s")), "n_gpus": fs.get("n_gpus"),
+                       "domains_equal": fs.get("domains_equal_to_single_rank_search"), "counters_equal": fs.get("counters_equal_to_single_rank_search")}
     c4 = out.get("c4")
     if c4:
         c["c4"] = {"ms_per_database_pass": _r(c4.get("ms_per_database_pass")), "concurrent_queries_ms": _r(g(c4, "concurrent_queries", "ms_per_database_pass")),
@@ -1003,13 +1072,17 @@ def compact_line(out):
                    "hits_equal": g(c4, "concurrent_queries", "hits_equal_to_serial_loop"), "parity_ok": g(c4, "parity_check", "all_equal")}
         if c4.get("n_gpus"):
             c["c4"].update({"n_gpus": c4.get("n_gpus"), "tables_equal": c4.get("tables_equal_to_single_rank_search")})
+            for k in ("concurrent_queries_ms", "full_job_ms", "hits_equal", "parity_ok"):       # the N = 1 leg's keys
+                if c["c4"].get(k) is None:
+                    c["c4"].pop(k, None)
     c5 = out.get("c5")
     if c5:
         sw = c5.get("size_sweep") or []
         c["c5"] = {"ms_per_pass": _r(c5.get("ms_per_pass")), "fast_ms": _r(g(c5, "fast", "ms_per_pass")),
                    "sweep_mb_ms": [[int(x["genome_mb"]), _r(x["ms_per_pass"])] for x in sw], "parity_ok": g(c5, "parity_check", "all_equal")}
         if c5.get("n_gpus"):
-            c["c5"]["n_gpus"] = c5.get("n_gpus")
+            c["c5"] = {"ms_per_pass": _r(c5.get("ms_per_pass")), "n_gpus": c5.get("n_gpus"), "domains_equal": c5.get("domains_equal_to_single_rank_search"),
+                       "counters_equal": c5.get("counters_equal_to_single_rank_search")}
     c["detail"] = "full record: stderr + gpurun_out/bench_detail.json"
     return c
 
@@ -1045,7 +1118,7 @@ def concurrent_leg(ba, hmm, flat, offsets, args, stats_one, ms_one, workers=3, m
     if main_ctx is not None:
         main_ctx.trim()                                         # (see fs_concurrent_leg)
     for _ in range(workers):
-        c = ba.Context(0)
+        c = ba.Context(GPU)
         o = ba.OProfile(c, ba.Profile(hmm))
         d = ba.SeqBlock(c, flat, offsets)
         p = ba.Pipeline(c, o, fs_pipe=False, ncbi_table=hmm.ct)
@@ -1155,11 +1228,23 @@ def fs_leg_ranks(ba, synth, bdist, dist, ctx, hmm, om, args, rank, world, dev, o
     dt = bdist.max_over_ranks((time.perf_counter() - t0) / steps, dev)
     if rank != 0:
         return None
-    return {"workload": "Caudal_act.bhmm --fs vs %d x %d nt windows in total, sharded over %d GPUs (strong scaling); domains gathered on rank 0 inside the timed region"
-                        % (args.fs_windows, args.length, world),
-            "ms_per_pass": dt * 1e3, "residues_per_s": merged["nres"] / dt, "scaling": "strong", "n_gpus": world,
-            "domains_gathered": len(gathered), "windows_of_gathered_domains_are_global": bool(all(0 <= d.window < args.fs_windows for d in gathered)),
-            "mode": "strict (the library's default)"}
+    out = {"workload": "Caudal_act.bhmm --fs vs %d x %d nt windows in total, sharded over %d GPUs (strong scaling); domains gathered on rank 0 inside the timed region"
+                       % (args.fs_windows, args.length, world),
+           "ms_per_pass": dt * 1e3, "residues_per_s": merged["nres"] / dt, "scaling": "strong", "n_gpus": world,
+           "domains_gathered": len(gathered), "windows_of_gathered_domains_are_global": bool(all(0 <= d.window < args.fs_windows for d in gathered)),
+           "mode": "strict (the library's default)"}
+    if on_gpu and world > 1:
+        # the same block on rank 0 alone, outside the timed region: the merged search must be the single-rank search, record for record
+        del dna
+        flat, offsets, _ = synth.dna_windows(args.fs_windows, args.length, seed=4242, hmm=hmm, frameshift=True)
+        whole = ba.SeqBlock(ctx, flat, offsets)
+        s_stats, _, s_dm, _ = pipe.run_frameshift_domains(om3, om5, whole)
+        same, diff = records_diff(domain_records(gathered), domain_records(s_dm))
+        cdiff = {f: (merged[f], int(getattr(s_stats, f))) for f in COUNTERS if merged[f] != int(getattr(s_stats, f))}
+        out["domains_equal_to_single_rank_search"] = bool(same)
+        out["counters_equal_to_single_rank_search"] = not cdiff
+        out["single_rank_check"] = {**diff, "counter_mismatches": {k: {"ranks": a, "single": b} for k, (a, b) in cdiff.items()}}
+    return out
 
 
 def fs_concurrent_leg(ba, hmm, flat, offsets, strict_keys, one_ms, workers=2, passes=6, main_ctx=None):
@@ -1171,7 +1256,7 @@ def fs_concurrent_leg(ba, hmm, flat, offsets, strict_keys, one_ms, workers=2, pa
     if main_ctx is not None:
         main_ctx.trim()                                         # the idle main context gives its lanes' and side contexts' streams back (hardware queues)
     for _ in range(workers):
-        c = ba.Context(0)
+        c = ba.Context(GPU)
         o = ba.OProfile(c, ba.Profile(hmm))
         o3 = ba.FSOProfile(c, ba.FSProfile(hmm, 3, ncbi_table=hmm.ct))
         o5 = ba.FSOProfile(c, ba.FSProfile(hmm, 5, ncbi_table=hmm.ct))

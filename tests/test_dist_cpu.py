@@ -231,3 +231,126 @@ def test_weighted_items_cut_the_heavy_queries_and_cover_every_window():
         assert groups[3] == max(groups) and groups[3] >= 2 and groups[11] == 1        # the 459-node model is cut, the 56-node one never
         assert len(items) <= max(12, 3 * world) + 6
     assert query_items_weighted([1, 1], [5.0, 1.0], 8) == [(0, 0, 1), (1, 0, 1)]      # never more groups than windows
+
+
+def _fabricated_hits(ba, items, owner, rank=None):
+    """{query: [FsDomain]} of the items <rank> owns (all items when rank is None): one hit per window, a duplicate pair at every
+    group boundary (the overlap of two windows finds a hit twice: p7_tophits_RemoveDuplicates must drop one copy whoever found it)."""
+    by_q = {}
+    for (qq, lo, hi), o in zip(items, owner):
+        if rank is not None and o != rank:
+            continue
+        for w in range(lo, hi):
+            d = ba.FsDomain()
+            d.window, d.reported = 0, 1
+            d.iali = d.ienv = 1000 * w + 17 * qq + 1
+            d.jali = d.jenv = d.iali + 299
+            d.ihmm, d.jhmm = 1, 100
+            d.lnP, d.bitscore = -30.0 - 0.25 * w - qq, 40.0 + 0.5 * w + qq
+            d.cigar = "%dM" % (100 + w)
+            by_q.setdefault(qq, []).append(d)
+        if lo > 0:                                              # the copy of the previous group's last hit
+            d = ba.FsDomain()
+            w = lo - 1
+            d.window, d.reported = 0, 1
+            d.iali = d.ienv = 1000 * w + 17 * qq + 1
+            d.jali = d.jenv = d.iali + 299
+            d.ihmm, d.jhmm = 1, 100
+            d.lnP, d.bitscore = -30.0 - 0.25 * w - qq, 40.0 + 0.5 * w + qq
+            d.cigar = "%dM" % (100 + w)
+            by_q.setdefault(qq, []).append(d)
+    return by_q
+
+
+def _finish(ba, hits, nres):
+    th = ba.TopHits()
+    th.add_arrays(hits if hits is not None else ba.HitArray(np.zeros(0, dtype=ba.FS_DOMAIN_DTYPE), b""), ["genome"], [10 ** 6])
+    th.finalize(int(nres), 300)
+    return th.reported(), th.tblout("q", "", 100, show_cigar=True, show_header=False)
+
+
+def _owner_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    import bath_amd as ba
+    from bath_amd import dist as bd
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    nwin = [7, 2, 9, 4, 5]
+    items = bd.query_items(nwin, world, items_per_rank=3)
+    owner = bd.deal([(hi - lo) * (qq + 1.0) for qq, lo, hi in items], world)
+    mine = {k: ba.HitArray.from_domains(v) for k, v in _fabricated_hits(ba, items, owner, rank).items()}
+    st_q = {}
+    for (qq, lo, hi), o in zip(items, owner):
+        if o == rank:
+            st_q.setdefault(qq, dict.fromkeys(bd.STAT_FIELDS, 0))["nres"] += 2000 * (hi - lo)
+    owned = bd.exchange_query_hits(mine)                        # a query's hits on its owner (q mod N) ...
+    merged = bd.reduce_query_stats(st_q, len(nwin))
+    my_q = [qq for qq in range(len(nwin)) if bd.query_owner(qq, world) == rank]
+    assert sorted(owned) == [qq for qq in my_q if qq in owned] and all(qq in my_q for qq in owned)
+    done = {qq: _finish(ba, owned.get(qq), merged[qq]["nres"]) for qq in my_q}          # ... finished there ...
+    tables = bd.gather_query_tables(done, 0)                    # ... and only the tables travel to rank 0
+    # exchange_bytes on its own: every rank sends rank-dependent payloads to every other rank (and nothing to itself)
+    got = bd.exchange_bytes({d: bytes([rank]) * (3 * d + rank + 1) for d in range(world) if d != rank})
+    q.put((rank, items, owner, tables, {s: (len(b), set(b)) for s, b in got.items()}, [m["nres"] for m in merged]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_queries_finished_on_their_owner_give_the_single_process_tables(world):
+    """configs[3]'s end of a job with the serial tail spread: per query the hits of all ranks meet on the owner rank (q mod N), the
+    owner finishes the query (bath_tophits_finalize: E-values, duplicates of window overlaps, order, thresholds) and ships the
+    table; rank 0's tables must be those of ONE process finishing every query from all hits (bathsearch.c:868-921)."""
+    import bath_amd as ba
+    from bath_amd import dist as bd
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_owner_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    items, owner = outs[0][1], outs[0][2]
+    assert all(o[1] == items and o[2] == owner for o in outs)
+    assert all(o[3] is None for o in outs[1:])
+    tables = outs[0][3]
+    nwin = [7, 2, 9, 4, 5]
+    nres = [2000 * n for n in nwin]
+    assert outs[0][5] == nres
+    everything = _fabricated_hits(ba, items, owner)
+    for qq in range(len(nwin)):
+        want = _finish(ba, ba.HitArray.from_domains(everything[qq]), nres[qq])
+        assert tables[qq] == want, qq
+        assert want[0] == nwin[qq]                              # the duplicates at the group boundaries are gone, whoever found them
+    for o in outs:                                              # the raw exchange: from every other rank, the right length and content
+        rank = o[0]
+        assert o[4] == {s_: (3 * rank + s_ + 1, {s_}) for s_ in range(world) if s_ != rank}
+
+
+def test_item_cost_orders_the_database_as_measured():
+    """dist.item_cost (the longest-first deal's estimate) against the item times measured alone on an MI355X for the 100 Mb x 12-model
+    job (profiles/r05_c4_items.txt: model length, share of the genome, milliseconds): every pair of items whose measured times differ
+    by more than 15 % is ordered the same way by the estimate, the estimate is within 15 % of every measured time but one, and the
+    deal it leads to is balanced."""
+    from bath_amd.dist import item_cost, deal
+    measured = [(78, 1.0, 3.80), (152, 1.0, 4.02), (116, 1.0, 3.16), (459, 0.5, 7.69), (459, 0.5, 7.52), (238, 1.0, 5.58), (131, 1.0, 3.70),
+                (121, 1.0, 3.29), (185, 1.0, 4.10), (192, 1.0, 4.32), (247, 1.0, 4.93), (136, 1.0, 3.53), (56, 1.0, 2.75)]
+    n_nt = 100_000_000
+    est = [item_cost(m, int(share * n_nt)) for m, share, _ in measured]
+    for a in range(len(measured)):
+        for b in range(len(measured)):
+            if 0 not in (a, b) and measured[a][2] > 1.15 * measured[b][2]:      # (item 0 is the measurement's outlier, below)
+                assert est[a] > est[b], (measured[a], measured[b], est[a], est[b])
+    off = [abs(e - t) / t for e, (_, _, t) in zip(est, measured)]
+    assert sorted(off)[-2] < 0.15, off                          # (the 78-node model's 3.80 ms is the outlier of the measurement)
+    assert est.index(max(est)) in (3, 4)                        # the halves of the 459-node model lead the longest-first deal
+    for world in (2, 4, 8):
+        own = deal(est, world)
+        assert own == deal(list(est), world)
+        load = [sum(c for c, o in zip(est, own) if o == r) for r in range(world)]
+        assert max(load) <= sum(est) / world + max(est) and max(load) - min(load) <= max(est)
