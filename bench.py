@@ -445,7 +445,7 @@ def finish_query(ba, hmm, domains, wins, nres, genome_len):
     th = ba.TopHits()
     th.add(domains, ["genome"], [genome_len])
     th.finalize(int(nres), hmm.max_length)
-    return sum(1 for d, _, fl in th.hits() if d.reported), th.tblout(hmm.name, hmm.acc, hmm.M, show_cigar=True, show_header=False)
+    return th.reported(), th.tblout(hmm.name, hmm.acc, hmm.M, show_cigar=True, show_header=False)      # (reported: duplicates of window overlaps not counted)
 
 
 def finish_query_arrays(ba, hmm, hits, wins, nres, genome_len):
