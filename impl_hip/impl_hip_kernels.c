@@ -25,6 +25,11 @@
 #include <string.h>
 #include <math.h>
 
+#include "easel.h"
+#include "esl_alphabet.h"      /* esl_abc_FAvgScVec */
+#include "esl_random.h"        /* esl_random, esl_rnd_FChoose */
+#include "esl_vectorops.h"     /* esl_vec_FNorm, esl_vec_FLogNorm */
+
 #include "hmmer.h"
 
 #define IH_KP 29

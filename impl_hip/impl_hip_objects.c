@@ -11,6 +11,9 @@
 #include <string.h>
 #include <math.h>
 
+#include "easel.h"
+#include "esl_alphabet.h"
+
 #include "hmmer.h"
 
 #define IH_KP 29               /* the amino alphabet of every BATH profile (abc->Kp) */
