@@ -143,6 +143,59 @@ def fs_cpu_sample(flat, length, k):
             "counters": {f: int(getattr(pli, f)) for f in COUNTERS}}
 
 
+_FS_CPU_JOB = None          # (model path, list of DNA windows, their contexts): inherited by the forked workers of fs_cpu_baseline
+
+
+def fs_cpu_worker(span):
+    """The oracle's whole --fs pipeline -- the cascade on the SSE2 striped kernels (oracle/sse), then the scalar restatement of
+    generic_*_frameshift.c: DNA windows, 3-codon parsers, regions, 5-codon Forward / Backward / decoding / optimal accuracy /
+    null2, traceback, hits -- over windows [lo, hi) of the job (a forked worker: no GPU state)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as ol
+    path, seqs, ctxs = _FS_CPU_JOB
+    lo, hi = span
+    L_ = ol.lib()
+    L_.bo_pipeline_use_sse(1)
+    model = ol.Model(path, 0)
+    model.fs(3); model.fs(5)                                     # profile construction is not part of the scoring loop
+    t0 = time.perf_counter()
+    pli, ofw, _, odm, _, _ = model.run_pipeline_fsdom(seqs[lo:hi], contexts=None if ctxs is None else ctxs[lo:hi])
+    dt = time.perf_counter() - t0
+    L_.bo_pipeline_use_sse(0)
+    return dt, int(pli.nres), len(ofw), len(odm)
+
+
+def fs_cpu_baseline(path, seqs, ctxs, what, probe=None, budget_s=12.0):
+    """cpu_baseline of an --fs leg, BEFORE any GPU initialisation: every usable core scores its own slice of <seqs> through the
+    oracle's --fs pipeline (fs_cpu_worker); the sample is sized from a one-thread probe so that the whole thing takes about
+    <budget_s> seconds.  kind "port": the cascade is the SSE2 restatement of impl_sse, the frameshift stages are the SCALAR
+    restatement of generic_*_frameshift.c (the reference's impl_sse/fwdback_fs.c runs them striped in probability space: the
+    reference on these cores would be faster than this figure by that factor)."""
+    import multiprocessing as mp
+    global _FS_CPU_JOB
+    _FS_CPU_JOB = (path, seqs, ctxs)
+    cores = usable_cores()
+    n = len(seqs)
+    probe = min(n, probe or max(1, n // 50))
+    dt1, nres1, _, _ = fs_cpu_worker((0, probe))
+    per = dt1 / probe
+    covered = int(min(n, max(cores, budget_s * cores / max(per, 1e-9) * 0.8)))
+    cores = min(cores, covered)
+    bounds = [covered * c // cores for c in range(cores + 1)]
+    t0 = time.perf_counter()
+    with mp.get_context("fork").Pool(cores) as pool:
+        outs = pool.map(fs_cpu_worker, [(bounds[c], bounds[c + 1]) for c in range(cores)])
+    wall = time.perf_counter() - t0
+    busy = max(o[0] for o in outs)
+    _FS_CPU_JOB = None
+    return {"value": sum(o[1] for o in outs) / busy, "unit": "residues/s", "cores": cores, "kind": "port",
+            "label": "the oracle's --fs pipeline: SSE2 restatement of impl_sse's cascade + SCALAR restatement of generic_*_frameshift.c for every frameshift "
+                     "stage (the reference runs those striped in probability space, impl_sse/fwdback_fs.c; it cannot be built here)",
+            "sample": "%d of %d %s, %d processes, %.1f s scoring (%.1f s wall); %d DNA windows, %d domains"
+                      % (covered, n, what, cores, busy, wall, sum(o[2] for o in outs), sum(o[3] for o in outs)),
+            "one_thread": {"value": nres1 / dt1, "sample": "%d %s, %.1f s" % (probe, what, dt1)}}
+
+
 def fs_parity_check(ba, ctx, pipe, om3, om5, flat, length, cpu):
     """The GPU's strict --fs pass over the windows the oracle scored: DNA windows with their Forward scores bitwise; the domains of
     the frameshift branch with exact coordinates and bitwise envelope scores; the standard branch's (fp32 odds-ratio arithmetic,
@@ -249,6 +302,10 @@ def c45_cpu_samples(args):
     out["c5_hits"] = sorted(hit_key(w, o) + (fbits(o.envsc),) for w, (a, b) in enumerate(per_d) for o in odm[a:b])
     out["c5_seconds"] = time.perf_counter() - t0
     L_.bo_pipeline_use_sse(0)
+    # cpu_baseline of the configs[4] leg: genome windows (262 kb + context each) through the oracle's --fs pipeline, one per core and pass
+    all_wins = bdist.split_targets([len(g5)], hmm5.max_length)
+    out["c5_baseline"] = fs_cpu_baseline(c5_model_path(), [g5[s_:s_ + n] for _, s_, n, _ in all_wins], [c for _, _, _, c in all_wins],
+                                         "genome windows of %d nt + context (both strands)" % bdist.BLOCK_LENGTH, probe=1, budget_s=10.0)
     return out
 
 
@@ -413,6 +470,7 @@ def c5_leg(ba, synth, bdist, ctx, args, cpu):
                         "windows of %d nt with context, %d planted frameshifted genes" % (C5_M, C5_M, args.c5_mb, len(wins), bdist.BLOCK_LENGTH, len(planted)),
             "ms_per_pass": dt * 1e3, "residues_per_s": stats.nres / dt, "mode": "strict (bit-identical frameshift recursions)",
             "fast": {"ms_per_pass": dtf * 1e3, "residues_per_s": stats.nres / dtf},
+            "cpu_baseline": (cpu or {}).get("c5_baseline"),
             **summary, "kernels_ms": {k: round(v["ms"], 3) for k, v in sorted(kt.items(), key=lambda kv: -kv[1]["ms"])},
             "cascade": {"ms": cms, "residues_per_s": cst.nres / (cms * 1e-3), "gcells_per_s": (cst.cells_msv + cst.cells_vit + cst.cells_fwd) / (cms * 1e-3) / 1e9,
                         "stage_ms": stage, "ssv_tcells_per_s": cst.cells_msv / (ssv_ms * 1e-3) / 1e12, "ssv_frac_of_packed_issue_peak": cst.cells_msv / (ssv_ms * 1e-3) / 1e12 / 44.4},
@@ -780,6 +838,9 @@ def main():
             fs_data = synth.dna_windows(args.fs_windows, args.length, seed=4242, hmm=hmm0, frameshift=True)
             if not args.no_cpu_baseline and args.fs_parity_windows > 0:
                 fs_cpu = fs_cpu_sample(fs_data[0], args.length, min(args.fs_parity_windows, args.fs_windows))
+                nw = min(args.fs_windows, 400_000)
+                fs_cpu["baseline"] = fs_cpu_baseline(MODEL, [fs_data[0][i * args.length:(i + 1) * args.length] for i in range(nw)], None,
+                                                     "windows x %d nt of the fs block (both strands)" % args.length, probe=2000)
 
     import torch
     import torch.distributed as dist
@@ -1062,6 +1123,8 @@ def compact_line(out):
                    "two_workers_ms_per_block": _r(g(fs, "concurrent_blocks", "ms_per_block")),
                    "fast_ms": _r(g(fs, "fast", "ms_per_pass")), "domains": fs.get("domains"),
                    "fast_identical": g(fs, "fast", "domains_identical_to_strict_mode")}
+        if fs.get("cpu_baseline"):
+            c["fs"]["cpu_baseline"] = {"value": _r(g(fs, "cpu_baseline", "value")), "cores": g(fs, "cpu_baseline", "cores"), "kind": "port: SSE2 cascade + scalar generic fs"}
         if fs.get("n_gpus"):
             c["fs"] = {"ms_per_pass": _r(fs.get("ms_per_pass")), "residues_per_s": _r(fs.get("residues_per_s")), "n_gpus": fs.get("n_gpus"),
                        "domains_equal": fs.get("domains_equal_to_single_rank_search"), "counters_equal": fs.get("counters_equal_to_single_rank_search")}
@@ -1080,6 +1143,8 @@ def compact_line(out):
         sw = c5.get("size_sweep") or []
         c["c5"] = {"ms_per_pass": _r(c5.get("ms_per_pass")), "fast_ms": _r(g(c5, "fast", "ms_per_pass")),
                    "sweep_mb_ms": [[int(x["genome_mb"]), _r(x["ms_per_pass"])] for x in sw], "parity_ok": g(c5, "parity_check", "all_equal")}
+        if c5.get("cpu_baseline"):
+            c["c5"]["cpu_baseline"] = {"value": _r(g(c5, "cpu_baseline", "value")), "cores": g(c5, "cpu_baseline", "cores")}
         if c5.get("n_gpus"):
             c["c5"] = {"ms_per_pass": _r(c5.get("ms_per_pass")), "n_gpus": c5.get("n_gpus"), "domains_equal": c5.get("domains_equal_to_single_rank_search"),
                        "counters_equal": c5.get("counters_equal_to_single_rank_search")}
@@ -1382,7 +1447,7 @@ def fs_leg(ba, synth, ctx, hmm, om, args, data=None, cpu=None):
                     "and in-frame stops (0.002), both strands: cascade (F4) -> DNA windows -> 3-codon parsers -> regions -> 5-codon "
                     "Forward/Backward/decoding/optimal accuracy/null2 -> traceback -> hits" % (hmm.M, args.fs_windows, args.length),
         "ms_per_pass": dt * 1e3, "residues_per_s": stats.nres / dt, "steps": steps,
-        "parity_check": parity, "concurrent_blocks": conc,
+        "parity_check": parity, "concurrent_blocks": conc, "cpu_baseline": (cpu or {}).get("baseline"),
         **summary,
         "kernels": kt,
         "roofline": {"bound": "hbm", "binding_resource": "memory requests issued (a lane writes its own row: 64 pieces per store instruction)", "kernels": env, "cells": env_cells, "bytes_per_cell": env_bytes / env_cells if env_cells else None,
