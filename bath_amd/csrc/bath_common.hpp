@@ -193,15 +193,16 @@ struct bath_hip_ctx {
   int fs_serial = -1;                   // envelopes' Backward after Forward on one stream instead of beside it (timing probes); -1: BATH_HIP_FS_SERIAL decides
   uint64_t tabs_uid = 0;                // whose SSV score table sits in scratch[8] (bath_pipeline.hip: uploaded once per profile, not per call)
   const void *tabs_ptr = nullptr;
+  uint64_t fsw_pad_uid = 0;             // whose window padding fractions sit in scratch[52] (bath_fs_windows.hip)
   int orf_tables_id = -1;               // the NCBI table whose codon tables sit in scratch[28] (bath_orfs.hip: built and uploaded once per context and table)
   std::string err;
   void set_error(const std::string &m) { err = m; }
   // scratch owned by the context (reused across calls)
-  bath::DevBuf scratch[50];
+  bath::DevBuf scratch[56];             // [50]-[52]: the device-side DNA-window builder (bath_fs_windows.hip)
   // page-locked staging for small tables a launch uploads (job order, batch starts, offsets): an asynchronous copy from here needs
   // no synchronize before the local it was built in goes away.  One slot per call site; a site is reused by its context only
   // after the stage that used it has synchronized its stream.  [0] fs_schedule, [1]/[2] chain_batches (Forward / Backward), [3] wavefront Backward
-  bath::HostBuf stage[6];                 // ... [4] / [5]: the standard branch's domain stage, its small uploads / downloads (bath_domaindef.hip: std_domains)
+  bath::HostBuf stage[8];                 // ... [4] / [5]: the standard branch's domain stage, its small uploads / downloads (bath_domaindef.hip: std_domains)
   template <class T> int stage_upload(int slot, void *dst, const T *src, size_t n, hipStream_t s) {
     if (stage[slot].reserve(n * sizeof(T) + 64) != hipSuccess) { set_error("cannot allocate page-locked staging memory"); return BATH_EFAIL; }
     std::memcpy(stage[slot].p, src, n * sizeof(T));

@@ -75,6 +75,41 @@ struct FsWinDev {                  // one DNA window / envelope, device view
   int32_t seq_n, start, len, strand, kmin, kmax;   // start: 1-based on the strand being read
 };
 int fs_gather_view(bath_hip_ctx *ctx, const bath_hip_seqs *dna, std::vector<FsWinDev> &regs, const uint8_t *d_comp, bath_hip_seqs *view, const FsWinDev **d_desc_out);
+
+// ---- the DNA windows of the frameshift stage built on the device (bath_fs_windows.hip)
+struct WindowRec;                  // bath_kernels.hpp
+struct FsCandRec { int64_t window, aa_off; double P; int32_t cand, sf, startj, len; float fwdsc, nullsc; int64_t fxoff; };   // an ORF that passed F4, as a cascade lane leaves it
+struct FsLaneSurv {                // one cascade lane's F4 survivors and their hit windows, in the lane's device memory
+  const FsCandRec *d_c; const WindowRec *d_w;
+  int32_t n_c, n_w, cand_base;     // counts; what makes the lane's candidate ids the block's
+  int64_t first_window, dpool;     // ... its sequence indices the block's, its pool offsets relative to the first lane's pool
+};
+struct FsOrfDev {                  // an ORF that passed F4, in the order esl_gencode emits them per (sequence, strand)
+  int64_t w, aa_off; double P;
+  int32_t cand, strand, start, end, n; float fwd_null;
+  int32_t wb, we;                  // its hit windows, a range of the ordered hit-window list
+  int32_t dw_n, dw_len, dw_k;      // the DNA window it asks for (start on the strand, length; node of its best hit window)
+  int32_t kmin, kmax;              // first / last model node over its hit windows
+  int32_t g0, g1;                  // its (sequence, strand) group, a range of the ordered ORF list
+  int32_t pad_;
+};
+struct FsWinBuild {                // fs_build_windows_device's result: host copies (page-locked, valid until the next build) and device arrays
+  int32_t n_orfs = 0, nw = 0, maxlen = 0;
+  int64_t pool_bytes = 0, total = 0;
+  const int64_t *h_voff = nullptr; const int32_t *h_vlen = nullptr;   // [nw] the windows' pool offsets and lengths: valid when the build returns
+  const FsOrfDev *h_orfs = nullptr;         // [n_orfs]  } in flight when the build returns: valid after the next synchronize of
+  const int32_t *h_grp = nullptr;           // [2 nw]    } the context's stream (fs_decide_device); a window's group = a range of h_orfs
+  bath_fs_window *d_out = nullptr;          // the records on the device (fs_decide_device completes them)
+  const FsWinDev *d_desc = nullptr;         // the gather kernel's descriptors
+  const int64_t *d_voff = nullptr; const int32_t *d_vlen = nullptr;   // the view's off[] / len[]
+};
+bool fs_windows_on_device();       // false under BATH_HIP_FS_WINDOWS_HOST=1 (A/B: the host path of rounds 1-5)
+// BATH_OK; BATH_ENORESULT: an input this path does not take (the caller runs the host path); an error
+int fs_build_windows_device(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bath_hip_fsprofile *om_fs3, const bath_hip_seqs *dna,
+                            const bath_pipeline_params *prm, const FsLaneSurv *lanes, int nlanes, int nc_total, FsWinBuild *out);
+// after the parsers: scores -> P-values -> branch on the device, the completed records into h_out[nw]
+int fs_decide_device(bath_hip_ctx *ctx, const bath_hip_fsprofile *om_fs3, const bath_pipeline_params *prm, const FsWinBuild &B, const float *d_bias,
+                     const float *d_fsc, bath_fs_window *h_out);
 float flogsum_host(float a, float b);                          // p7_FLogsum with its table, on the host
 
 // ---- frameshift helpers for the pipeline (bath_frameshift.hip)

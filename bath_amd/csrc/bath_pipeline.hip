@@ -1202,6 +1202,24 @@ int fs_gather_view(bath_hip_ctx *ctx, const bath_hip_seqs *dna, std::vector<FsWi
   return BATH_OK;
 }
 
+// the same for windows built on the device (bath_fs_windows.hip): descriptors with their pool offsets, the view's off[] and
+// len[] are already there; only the pool is reserved and the copy kernel launched
+int fs_gather_view_built(bath_hip_ctx *ctx, const bath_hip_seqs *dna, const FsWinBuild &B, const uint8_t *d_comp, bath_hip_seqs *view, const FsWinDev **d_desc_out) {
+  const int nw = B.nw;
+  DevBuf &b_pool = ctx->scratch[29];
+  BATH_HIP_TRY(ctx, b_pool.reserve((size_t)B.pool_bytes + 256));
+  BATH_HIP_TRY(ctx, hipMemsetAsync(b_pool.p, 0x1d, (size_t)B.pool_bytes + 256, ctx->stream));
+  hipLaunchKernelGGL(fs_window_gather_kernel, dim3((unsigned)std::max(1, std::min(nw, 65535))), dim3(256), 0, ctx->stream, dna->d_data, B.d_desc, nw, d_comp, b_pool.as<uint8_t>());
+  BATH_HIP_TRY(ctx, hipGetLastError());
+  view->ctx = ctx; view->n = nw; view->d_data = b_pool.as<uint8_t>(); view->is_part = true;
+  view->h_off.resize((size_t)nw); view->h_len.resize((size_t)nw);
+  for (int i = 0; i < nw; i++) { view->h_off[(size_t)i] = B.h_voff[i]; view->h_len[(size_t)i] = B.h_vlen[i]; }
+  view->maxlen = B.maxlen; view->total = B.total; view->total_aligned = B.pool_bytes;
+  view->d_off = const_cast<int64_t *>(B.d_voff); view->d_len = const_cast<int32_t *>(B.d_vlen);
+  if (d_desc_out) *d_desc_out = B.d_desc;
+  return BATH_OK;
+}
+
 float flogsum_host(float a, float b) {               // p7_FLogsum, logsum.c:105-111 (table of logsum.c:89)
   // (a function-local static with an initialiser: built once, thread-safe -- worker contexts and the window threads call this concurrently)
   static const std::vector<float> tbl = [] { std::vector<float> t(16000); for (int i = 0; i < 16000; i++) t[i] = (float)std::log(1. + std::exp((double)-i / 1000.f)); return t; }();
@@ -1211,7 +1229,7 @@ float flogsum_host(float a, float b) {               // p7_FLogsum, logsum.c:105
 
 // The frameshift stage needs only the ORFs that passed F4 (a few thousand of the block's 10^5-10^6 MSV survivors) and their
 // hit windows: select them on the device, so that what crosses PCIe is a few hundred KB instead of every candidate array.
-struct FsCandRec { int64_t window, aa_off; double P; int32_t cand, sf, startj, len; float fwdsc, nullsc; int64_t fxoff; };
+// (FsCandRec: bath_launch.hpp)
 __global__ void fs_select_cands_kernel(Cand cand, int nc, FsCandRec *__restrict__ out, int *__restrict__ count, const int64_t *__restrict__ fxoff /* kept Forward rows by candidate, or null */) {
   for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < nc; c += gridDim.x * blockDim.x) {
     if (cand.stage[c] != 4) continue;
@@ -1248,10 +1266,29 @@ struct SurvivorSet {
   int nc_total = 0;
   const uint8_t *pool = nullptr;
   FilterState S0;                    // the first lane's state: the model-dependent tables any lane holds alike
+  // device_only: the lists stayed in the lanes' device memory (counts known, nothing copied): what bath_fs_windows.hip reads;
+  // survivors_to_host() completes sel / wins from them when the host path must run after all
+  bool on_device = false;
+  std::vector<FsLaneSurv> lanes;
+  std::vector<bath_hip_ctx *> lane_ctx;
+  int n_states = 0;
 };
 
-static int select_survivors(bath_hip_ctx *lane, const FilterState &S, bool want_wins, std::vector<FsCandRec> *sel, std::vector<WindowRec> *wins) {
+static int fetch_survivors(bath_hip_ctx *lane, const FsLaneSurv &ls, std::vector<FsCandRec> *sel, std::vector<WindowRec> *wins) {
+  sel->resize((size_t)ls.n_c); wins->resize((size_t)ls.n_w);
+  if (ls.n_c) BATH_HIP_TRY(lane, hipMemcpyAsync(sel->data(), ls.d_c, sel->size() * sizeof(FsCandRec), hipMemcpyDeviceToHost, lane->stream));
+  if (ls.n_w) BATH_HIP_TRY(lane, hipMemcpyAsync(wins->data(), ls.d_w, wins->size() * sizeof(WindowRec), hipMemcpyDeviceToHost, lane->stream));
+  BATH_HIP_TRY(lane, hipStreamSynchronize(lane->stream));
+  // the kernels append in completion order: candidate order makes what follows deterministic
+  std::sort(sel->begin(), sel->end(), [](const FsCandRec &a, const FsCandRec &b) { return a.cand < b.cand; });
+  std::stable_sort(wins->begin(), wins->end(), [](const WindowRec &a, const WindowRec &b) { return a.cand != b.cand ? a.cand < b.cand : a.n < b.n; });
+  return BATH_OK;
+}
+
+static int select_survivors(bath_hip_ctx *lane, const FilterState &S, bool want_wins, std::vector<FsCandRec> *sel, std::vector<WindowRec> *wins,
+                            FsLaneSurv *dev = nullptr /* non-null: leave the lists on the device, report where */) {
   sel->clear(); wins->clear();
+  if (dev) *dev = FsLaneSurv{};
   const int nc = S.hc.cand_count;
   if (nc <= 0) return BATH_OK;
   const int nwins = want_wins ? std::min(S.hc.win_count, S.W.win_cap) : 0;
@@ -1269,42 +1306,70 @@ static int select_survivors(bath_hip_ctx *lane, const FilterState &S, bool want_
   int h_cnt[2] = {0, 0};
   BATH_HIP_TRY(lane, hipMemcpyAsync(h_cnt, d_cnt, sizeof h_cnt, hipMemcpyDeviceToHost, lane->stream));
   BATH_HIP_TRY(lane, hipStreamSynchronize(lane->stream));
-  sel->resize((size_t)h_cnt[0]); wins->resize((size_t)h_cnt[1]);
-  if (h_cnt[0]) BATH_HIP_TRY(lane, hipMemcpyAsync(sel->data(), d_c, sel->size() * sizeof(FsCandRec), hipMemcpyDeviceToHost, lane->stream));
-  if (h_cnt[1]) BATH_HIP_TRY(lane, hipMemcpyAsync(wins->data(), d_w, wins->size() * sizeof(WindowRec), hipMemcpyDeviceToHost, lane->stream));
-  BATH_HIP_TRY(lane, hipStreamSynchronize(lane->stream));
-  // the kernels append in completion order: candidate order makes what follows deterministic
-  std::sort(sel->begin(), sel->end(), [](const FsCandRec &a, const FsCandRec &b) { return a.cand < b.cand; });
-  std::stable_sort(wins->begin(), wins->end(), [](const WindowRec &a, const WindowRec &b) { return a.cand != b.cand ? a.cand < b.cand : a.n < b.n; });
+  FsLaneSurv ls{};
+  ls.d_c = d_c; ls.d_w = d_w; ls.n_c = h_cnt[0]; ls.n_w = h_cnt[1];
+  if (dev) { *dev = ls; return BATH_OK; }
+  return fetch_survivors(lane, ls, sel, wins);
+}
+
+static void merge_lane_lists(SurvivorSet *out, const std::vector<std::vector<FsCandRec>> &lsel, const std::vector<std::vector<WindowRec>> &lwin) {
+  out->sel.clear(); out->wins.clear();
+  for (size_t k = 0; k < (size_t)out->n_states; k++) {
+    const FsLaneSurv &ls = out->lanes[k];
+    for (FsCandRec q : lsel[k]) { q.cand += ls.cand_base; q.window += ls.first_window; q.aa_off += ls.dpool; if (out->n_states > 1) q.fxoff = -1; out->sel.push_back(q); }
+    for (WindowRec w : lwin[k]) { w.cand += ls.cand_base; out->wins.push_back(w); }
+  }
+}
+
+// the host path after a device-only cascade (an input bath_fs_windows.hip does not take): the lanes' lists come over after all
+static int survivors_to_host(SurvivorSet *sv) {
+  if (!sv->on_device) return BATH_OK;
+  std::vector<std::vector<FsCandRec>> lsel((size_t)sv->n_states);
+  std::vector<std::vector<WindowRec>> lwin((size_t)sv->n_states);
+  for (size_t k = 0; k < (size_t)sv->n_states; k++) {
+    const int st = fetch_survivors(sv->lane_ctx[k], sv->lanes[k], &lsel[k], &lwin[k]);
+    if (st != BATH_OK) return st;
+  }
+  merge_lane_lists(sv, lsel, lwin);
+  sv->on_device = false;
   return BATH_OK;
 }
 
 static int filters_with_survivors(bath_hip_ctx *ctx, const bath_hip_oprofile *om, const bath_hip_seqs *dna, const bath_pipeline_params *prm,
-                                  bath_pipeline_stats *stats, const bath_orf_result **results, int64_t *n_results, bool want_wins, SurvivorSet *out) {
+                                  bath_pipeline_stats *stats, const bath_orf_result **results, int64_t *n_results, bool want_wins, SurvivorSet *out,
+                                  bool device_only = false) {
   std::vector<FilterState> states;
   const size_t nl = (size_t)std::max(1, pipeline_lane_count(dna));
   std::vector<std::vector<FsCandRec>> lsel(nl);
   std::vector<std::vector<WindowRec>> lwin(nl);
   std::vector<int64_t> first(nl, 0);
+  std::vector<FsLaneSurv> ldev(nl);
+  std::vector<bath_hip_ctx *> lctx(nl, nullptr);
   StageGate gate(prm->fs_pipe ? ctx->device : -1, StageGate::kCascade);      // (BATH_HIP_FS_GATE=3: not while another worker's Forward parser has the chip)
   int st = run_filters_lanes(ctx, om, dna, prm, stats, results, n_results, &states,
                              [&](int k, bath_hip_ctx *lane, const bath_hip_seqs *part, const FilterState &S) {
                                if ((size_t)k >= nl) { lane->set_error("more pipeline lanes than the survivor merge was sized for"); return (int)BATH_EFAIL; }
                                first[(size_t)k] = part->is_part ? part->first_window : 0;
-                               return select_survivors(lane, S, want_wins, &lsel[(size_t)k], &lwin[(size_t)k]);
+                               lctx[(size_t)k] = lane;
+                               return select_survivors(lane, S, want_wins, &lsel[(size_t)k], &lwin[(size_t)k], device_only ? &ldev[(size_t)k] : nullptr);
                              });
   gate.release();
   if (st != BATH_OK) return st;
   out->sel.clear(); out->wins.clear(); out->nc_total = 0;
   out->S0 = states.empty() ? FilterState{} : states[0];
   out->pool = out->S0.W.pool;
+  out->n_states = (int)states.size();
+  out->lanes.assign(ldev.begin(), ldev.begin() + (ptrdiff_t)states.size());
+  out->lane_ctx.assign(lctx.begin(), lctx.begin() + (ptrdiff_t)states.size());
   for (size_t k = 0; k < states.size(); k++) {
-    const int base = out->nc_total;
-    const int64_t dpool = (int64_t)(reinterpret_cast<intptr_t>(states[k].W.pool) - reinterpret_cast<intptr_t>(out->pool));
-    for (FsCandRec q : lsel[k]) { q.cand += base; q.window += first[k]; q.aa_off += dpool; if (states.size() > 1) q.fxoff = -1; out->sel.push_back(q); }
-    for (WindowRec w : lwin[k]) { w.cand += base; out->wins.push_back(w); }
+    FsLaneSurv &ls = out->lanes[k];
+    ls.cand_base = out->nc_total;
+    ls.first_window = first[k];
+    ls.dpool = (int64_t)(reinterpret_cast<intptr_t>(states[k].W.pool) - reinterpret_cast<intptr_t>(out->pool));
     out->nc_total += std::max(states[k].hc.cand_count, 0);
   }
+  out->on_device = device_only;
+  if (!device_only) merge_lane_lists(out, lsel, lwin);                     // (the lanes fetched and ordered their lists as they finished)
   return BATH_OK;
 }
 
@@ -1345,14 +1410,33 @@ extern "C" int bath_hip_pipeline_frameshift(bath_hip_ctx *ctx, const bath_hip_op
   bath_pipeline_stats st_local{};
   StageClock clk;
   SurvivorSet sv;
-  int st = filters_with_survivors(ctx, om, dna, &prm, &st_local, results, n_results, true, &sv);
+  const bool try_device = fs_windows_on_device();
+  int st = filters_with_survivors(ctx, om, dna, &prm, &st_local, results, n_results, true, &sv, try_device);
   if (st != BATH_OK) return st;
-  clk.lap("fs:   cascade + F4 survivors and their windows to the host");
+  clk.lap("fs:   cascade + F4 survivors selected");
   const FilterState &S = sv.S0;
   const int nc = sv.nc_total;
   const int M = om->M;
   const double kLn2 = 0.69314718055994529;
 
+  // ---- p7_pli_BuildDNAWindows + the per-window ORF summary of p7_pli_Frameshift: on the device (bath_fs_windows.hip), from the
+  // lists the cascade's lanes left there; the host path below is the A/B twin (BATH_HIP_FS_WINDOWS_HOST=1) and the fallback
+  std::vector<bath_fs_window> out;
+  std::vector<FsWinDev> dev;
+  std::vector<PipelineSurvivor> std_all;                                      // the ORFs the standard branch would take (:1479-1487) ...
+  std::vector<int32_t> std_begin;                                            // ... of window i: [std_begin[i], std_begin[i+1])
+  FsWinBuild B;
+  bool built = false;
+  if (try_device) {
+    st = fs_build_windows_device(ctx, om, om_fs3, dna, &prm, sv.lanes.data(), sv.n_states, nc, &B);
+    if (st == BATH_OK) {
+      built = true;
+      out.assign((size_t)B.nw, bath_fs_window{});                           // (the records arrive completed, after the branch decision)
+      clk.lap("fs:   DNA windows (device)");
+    } else if (st != BATH_ENORESULT) return st;
+    else if ((st = survivors_to_host(&sv)) != BATH_OK) return st;
+  }
+  if (!built) {
   // ---- the ORFs that passed F4, grouped by (sequence, strand) in the order esl_gencode emits a strand's ORFs: when the closing
   // stop codon is read; ORFs still open at the end of the sequence follow, frame by frame.  Each ORF's hit windows are a range
   // of <h_wins> (sorted by candidate, then start).
@@ -1382,13 +1466,9 @@ extern "C" int bath_hip_pipeline_frameshift(bath_hip_ctx *ctx, const bath_hip_op
     return (a.start - 1) % 3 < (b.start - 1) % 3;
   });
 
-  // ---- p7_pli_BuildDNAWindows + the per-window ORF summary of p7_pli_Frameshift
+  // ---- p7_pli_BuildDNAWindows + the per-window ORF summary of p7_pli_Frameshift (host path)
   // The groups (sequence, strand) are independent: host threads take contiguous runs of groups and their outputs are joined in
   // order (the GPU waits for this step: 1.6 -> 1.2 ms for the bench block's 8 k ORFs, the sort of the ORFs included).
-  std::vector<bath_fs_window> out;
-  std::vector<FsWinDev> dev;
-  std::vector<PipelineSurvivor> std_all;                                      // the ORFs the standard branch would take (:1479-1487) ...
-  std::vector<int32_t> std_begin;                                            // ... of window i: [std_begin[i], std_begin[i+1])
   std::vector<size_t> gstart;                                                // first ORF of every group, and the end
   for (size_t g0 = 0; g0 < orfs_all.size();) {
     gstart.push_back(g0);
@@ -1502,8 +1582,9 @@ extern "C" int bath_hip_pipeline_frameshift(bath_hip_ctx *ctx, const bath_hip_op
     std_all.insert(std_all.end(), P.std_all.begin(), P.std_all.end());
   }
   std_begin.push_back((int32_t)std_all.size());
-  const int nw = (int)out.size();
   clk.lap("fs:   DNA windows (host)");
+  }   // !built
+  const int nw = (int)out.size();
   int64_t pos_fwd = 0;
   ctx->fs_std_orfs.clear();
   ctx->fs_std_pool = sv.pool;
@@ -1513,7 +1594,9 @@ extern "C" int bath_hip_pipeline_frameshift(bath_hip_ctx *ctx, const bath_hip_op
     DevBuf &b_out = ctx->scratch[31];
     bath_hip_seqs view;
     const FsWinDev *d_desc = nullptr;
-    if ((st = fs_gather_view(ctx, dna, dev, S.tt.comp, &view, &d_desc)) != BATH_OK) return st;
+    if (built) st = fs_gather_view_built(ctx, dna, B, S.tt.comp, &view, &d_desc);      // descriptors, offsets and lengths are already on the device
+    else st = fs_gather_view(ctx, dna, dev, S.tt.comp, &view, &d_desc);
+    if (st != BATH_OK) return st;
     BATH_HIP_TRY(ctx, b_out.reserve((size_t)nw * 6 * sizeof(float) + 64));
     // the bias filter (a lane per window and pass, serial over the window) and the Forward parser are independent: the bias
     // kernel goes to the side stream, behind the gather
@@ -1539,6 +1622,35 @@ extern "C" int bath_hip_pipeline_frameshift(bath_hip_ctx *ctx, const bath_hip_op
     st = fs3_forward_scores(ctx, om_fs3, &view, h_fsc.data());
     view.d_data = nullptr; view.d_off = nullptr; view.d_len = nullptr;     // borrowed pointers: nothing for a destructor to free
     if (st != BATH_OK) return st;
+    if (built) {
+      // ---- scores -> P-values -> branch on the device (fsw_decide_kernel); the host reads the completed records once and keeps the
+      // bookkeeping: pos_past_fwd, and the ORFs of the windows that take the standard branch (:1479-1487), from the ordered ORF list
+      if ((st = fs_join(ctx)) != BATH_OK) return st;                          // the bias kernel's side stream
+      if ((st = fs_decide_device(ctx, om_fs3, &prm, B, b_out.as<float>(), ctx->scratch[12].as<float>(), out.data())) != BATH_OK) return st;
+      clk.lap("fs:   gather + bias + 3-codon Forward + branch decision (device)");
+      for (int i = 0; i < nw; i++) {
+        const bath_fs_window &r = out[(size_t)i];
+        if (r.branch == 1) { pos_fwd += r.length; continue; }
+        if (r.branch != 2) continue;
+        const int n_seq = dna->h_len[(size_t)r.window];
+        const int64_t dstart = r.strand ? n_seq : 1;
+        const int64_t wstart = r.strand ? dstart - ((int64_t)r.n + r.length) : dstart + r.n - 1;
+        const int64_t wend = r.strand ? dstart - r.n + 1 : wstart + r.length - 1;
+        for (int32_t z = B.h_grp[2 * i]; z < B.h_grp[2 * i + 1]; z++) {
+          const FsOrfDev &o = B.h_orfs[z];
+          int64_t os, oe;
+          if (r.strand) { const int64_t rs = (int64_t)n_seq - o.start + 1, re = (int64_t)n_seq - o.end + 1; os = dstart - (n_seq - re + 1) + 1; oe = dstart - (n_seq - rs + 1) + 1; }
+          else { os = dstart + o.start - 1; oe = dstart + o.end - 1; }
+          if (!(os >= wstart && oe <= wend) || o.P > prm.F3) continue;        // :1405, :1483
+          if (aligned[(size_t)o.cand]) continue;                               // oxf_holder[i] == NULL: an overlapping window already took the ORF (:1485)
+          aligned[(size_t)o.cand] = 1;
+          pos_fwd += (int64_t)o.n * 3;
+          PipelineSurvivor ps;
+          ps.window = r.window; ps.aa_off = o.aa_off; ps.strand = r.strand; ps.start = o.start; ps.n = o.n; ps.win_start = r.n; ps.fs_window = i;
+          ctx->fs_std_orfs.push_back(ps);
+        }
+      }
+    } else {
     BATH_HIP_TRY(ctx, hipMemcpyAsync(h_bias.data(), b_out.p, h_bias.size() * sizeof(float), hipMemcpyDeviceToHost, ctx->side_stream));
     BATH_HIP_TRY(ctx, hipStreamSynchronize(ctx->side_stream));
     BATH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1581,8 +1693,9 @@ extern "C" int bath_hip_pipeline_frameshift(bath_hip_ctx *ctx, const bath_hip_op
         }
       }
     }
+    }   // host decision
   }
-  clk.lap("fs:   branch decision (host)");
+  clk.lap("fs:   branch decision");
   st_local.pos_past_fwd = pos_fwd;                                         // in the fs pipeline only this stage counts it (:1468, :1490)
   if (stats) *stats = st_local;
   ctx->fs_windows = out;
