@@ -198,11 +198,11 @@ struct bath_hip_ctx {
   std::string err;
   void set_error(const std::string &m) { err = m; }
   // scratch owned by the context (reused across calls)
-  bath::DevBuf scratch[56];             // [50]-[52]: the device-side DNA-window builder (bath_fs_windows.hip)
+  bath::DevBuf scratch[60];             // [50]-[52]: the device-side DNA-window builder (bath_fs_windows.hip)
   // page-locked staging for small tables a launch uploads (job order, batch starts, offsets): an asynchronous copy from here needs
   // no synchronize before the local it was built in goes away.  One slot per call site; a site is reused by its context only
   // after the stage that used it has synchronized its stream.  [0] fs_schedule, [1]/[2] chain_batches (Forward / Backward), [3] wavefront Backward
-  bath::HostBuf stage[8];                 // ... [4] / [5]: the standard branch's domain stage, its small uploads / downloads (bath_domaindef.hip: std_domains)
+  bath::HostBuf stage[12];                // ... [4] / [5]: the standard branch's domain stage, its small uploads / downloads (bath_domaindef.hip: std_domains)
   template <class T> int stage_upload(int slot, void *dst, const T *src, size_t n, hipStream_t s) {
     if (stage[slot].reserve(n * sizeof(T) + 64) != hipSuccess) { set_error("cannot allocate page-locked staging memory"); return BATH_EFAIL; }
     std::memcpy(stage[slot].p, src, n * sizeof(T));
@@ -223,6 +223,14 @@ struct bath_hip_ctx {
   const float *fwd_rows_kept = nullptr;
   const int64_t *fwd_rows_off = nullptr;
   bool fs_want_regions = false;           // set by the domain stage: the decision stage also runs the Backward parser and the region heuristics
+  // Speculative Backward (bath_frameshift.hip: fs3_backward_spec): the 3-codon Backward parser of the LONGEST DNA windows runs beside the
+  // Forward parser of all of them, before the branch is known -- the two parsers of a window do not read each other, and the pass lasts
+  // as long as its longest window's Forward, then Backward, then regions' Forward.  fs_spec_rows[w] >= 0: window w's special-state rows
+  // lie at that offset (floats) of scratch[53]; the domain stage runs the parser for the other frameshift-branch windows only.
+  hipStream_t spec_stream = nullptr;
+  hipEvent_t ev_spec = nullptr;
+  bool fs_spec_valid = false;
+  std::vector<int64_t> fs_spec_rows;
   std::vector<int64_t> fs_keep_xoff;      // the decision stage's Forward parser rows stay on the device (scratch[45]): offsets per DNA window, in floats
   std::vector<int32_t> fs_regions_all;    // ... for every DNA window: 1 + 3*fs_max_regions() ints each (bath_frameshift.hip: fs3_regions)
   std::vector<bath_fs_domain> fs_domains; // bath_hip_pipeline_frameshift_domains output

@@ -1784,7 +1784,8 @@ static int fs_schedule(bath_hip_ctx *ctx, const bath_hip_seqs *dna, int k, FsJob
 }  // namespace bath
 
 static int fs3_parser(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, const bath_hip_seqs *dna, int logsum_mode, float *sc, float *xmx,
-                      const int64_t *xmx_off, bool backward, DevBuf *keep = nullptr /* the rows stay in this device buffer instead of going to <xmx> */) {
+                      const int64_t *xmx_off, bool backward, DevBuf *keep = nullptr /* the rows stay in this device buffer instead of going to <xmx> */,
+                      const std::function<int()> *after_launch = nullptr /* runs between the kernel's launch and the wait for it */) {
   if (!ctx || !om || !dna || om->codon_lengths != 3) { if (ctx) ctx->set_error("fs3 parser needs a 3-codon profile"); return BATH_EINVAL; }
   BATH_HIP_TRY(ctx, hipSetDevice(ctx->device));
   if (logsum_mode == BATH_LOGSUM_CONTEXT) logsum_mode = ctx->fs_strict ? BATH_LOGSUM_TABLE_SERIAL : BATH_LOGSUM_TABLE;
@@ -1827,6 +1828,7 @@ static int fs3_parser(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, const bat
   }))
   ctx->span_end(sp, ctx->stream);
   BATH_HIP_TRY(ctx, hipGetLastError());
+  if (after_launch && *after_launch && (st = (*after_launch)()) != BATH_OK) return st;
   BATH_HIP_TRY(ctx, hipMemcpyAsync(sc, b_sc.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
   if (xmx) BATH_HIP_TRY(ctx, hipMemcpyAsync(xmx, d_x, (size_t)xmx_off[n] * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
   BATH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1920,6 +1922,12 @@ int fs_max_regions() { return kMaxRegions; }
 // row chain: run Backward on the context's side stream while Forward runs on the main one.
 int fs_fork(bath_hip_ctx *ctx) {
   if (!ctx->side_stream) {
+    static const bool lowprio = [] { const char *e = std::getenv("BATH_HIP_FS_SIDE_LOWPRIO"); return e && e[0] == '1'; }();   // (probe)
+    if (lowprio) {
+      int lo = 0, hi = 0;
+      BATH_HIP_TRY(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));
+      BATH_HIP_TRY(ctx, hipStreamCreateWithPriority(&ctx->side_stream, hipStreamNonBlocking, lo));
+    } else
     BATH_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
     BATH_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
     BATH_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
@@ -1931,6 +1939,80 @@ int fs_fork(bath_hip_ctx *ctx) {
 int fs_join(bath_hip_ctx *ctx) {
   BATH_HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->side_stream));
   BATH_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+  return BATH_OK;
+}
+
+// rows of the selected windows from one buffer into another: (len + 1) x 5 floats each, a block per window
+__global__ void fs_rows_copy_kernel(int n, const int32_t *__restrict__ len, const int64_t *__restrict__ src_off /* -1: nothing to copy */, const float *__restrict__ src,
+                                    const int64_t *__restrict__ dst_off, float *__restrict__ dst) {
+  const int w = blockIdx.x;
+  if (w >= n || src_off[w] < 0) return;
+  const int cnt = (len[w] + 1) * 5;
+  const float *a = src + src_off[w];
+  float *b = dst + dst_off[w];
+  for (int i = threadIdx.x; i < cnt; i += blockDim.x) b[i] = a[i];
+}
+
+// Speculative Backward (strict mode, a host with ONE context at work): the 3-codon Backward parser of the <k> longest windows of
+// <dna> on the context's speculation stream, beside whatever follows on the main stream -- the Forward parser of all windows.
+// The pass is a chain of stages each as long as its longest window (Forward 9.4 ms, then Backward 14.2 ms on the bench block);
+// the two parsers of a window do not read each other, only the DECISION to run Backward reads Forward's score (p7_pipeline.c:1464-1470).
+// Rows go to scratch[53] at the offsets fs_spec_rows records; fs3_regions (the domain stage) waits for the stream, runs the parser
+// for the frameshift-branch windows that were not among the <k>, and takes the others' rows from here.  What the speculation computes
+// for windows that turn out to take the standard branch is thrown away: CU time nothing else of this context could use, which is
+// why a host running several worker contexts does not speculate (bath_pipeline.hip).
+int fs3_backward_spec(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, const bath_hip_seqs *dna, int k) {
+  ctx->fs_spec_valid = false;
+  const int64_t n = dna->n;
+  if (n == 0 || k <= 0 || !ctx->fs_strict || !fs_chain_enabled() || om->codon_lengths != 3) return BATH_OK;
+  int st = om->ensure_len(dna->maxlen / 3 + 1);
+  if (st != BATH_OK) return st;
+  if (!ctx->spec_stream) {
+    BATH_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->spec_stream, hipStreamNonBlocking));
+    BATH_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_spec, hipEventDisableTiming));
+  }
+  std::vector<int32_t> order((size_t)n);
+  for (int64_t i = 0; i < n; i++) order[(size_t)i] = (int32_t)i;
+  std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return dna->h_len[(size_t)a] > dna->h_len[(size_t)b]; });
+  k = (int)std::min<int64_t>(k, n);
+  order.resize((size_t)k);
+  // rows of the chosen windows back to back; every other window: -1
+  ctx->fs_spec_rows.assign((size_t)n, -1);
+  std::vector<int64_t> xoff((size_t)n, 0);
+  int64_t tot = 0;
+  for (int32_t w : order) { ctx->fs_spec_rows[(size_t)w] = tot; xoff[(size_t)w] = tot; tot += ((int64_t)dna->h_len[(size_t)w] + 1) * 5; }
+  DevBuf &b_rows = ctx->scratch[53], &b_aux = ctx->scratch[54];
+  BATH_HIP_TRY(ctx, b_rows.reserve((size_t)tot * sizeof(float) + 64));
+  // aux: job counter (256 B), order list, per-window row offsets, scores
+  const size_t o_ord = 256, o_xoff = o_ord + (((size_t)k * 4 + 255) & ~(size_t)255), o_sc = o_xoff + (((size_t)n * 8 + 255) & ~(size_t)255);
+  BATH_HIP_TRY(ctx, b_aux.reserve(o_sc + (size_t)n * 4 + 64));
+  hipStream_t s = ctx->spec_stream;
+  // (the windows' pool was gathered on ctx->stream BEFORE the Forward parser's launch, and the side stream was forked behind the
+  // gather: ev_fork is that point, so the speculation does not wait for Forward)
+  BATH_HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_fork, 0));
+  BATH_HIP_TRY(ctx, hipMemsetAsync(b_aux.p, 0, 256, s));
+  if (ctx->stage[8].reserve((size_t)k * 4 + (size_t)n * 8 + 64) != hipSuccess) { ctx->set_error("cannot allocate page-locked staging memory"); return BATH_EFAIL; }
+  char *hs = static_cast<char *>(ctx->stage[8].p);
+  std::memcpy(hs, order.data(), (size_t)k * 4);
+  std::memcpy(hs + (size_t)k * 4, xoff.data(), (size_t)n * 8);
+  BATH_HIP_TRY(ctx, hipMemcpyAsync(b_aux.as<char>() + o_ord, hs, (size_t)k * 4, hipMemcpyHostToDevice, s));
+  BATH_HIP_TRY(ctx, hipMemcpyAsync(b_aux.as<char>() + o_xoff, hs + (size_t)k * 4, (size_t)n * 8, hipMemcpyHostToDevice, s));
+  // the launcher sizes its blocks and batches from a block's host arrays: a shadow of <dna> that holds the chosen windows only
+  // (the kernel addresses windows by their index in <dna> through the order list; n = the length of that list)
+  bath_hip_seqs shadow;
+  shadow.ctx = ctx; shadow.is_part = true; shadow.n = k; shadow.d_data = dna->d_data; shadow.d_off = dna->d_off; shadow.d_len = dna->d_len;
+  shadow.h_len.resize((size_t)k);
+  shadow.maxlen = 0; shadow.total = 0;
+  for (int i = 0; i < k; i++) { const int32_t L = dna->h_len[(size_t)order[(size_t)i]]; shadow.h_len[(size_t)i] = L; shadow.maxlen = std::max(shadow.maxlen, L); shadow.total += L; }
+  const FsJobs jq{reinterpret_cast<const int32_t *>(b_aux.as<char>() + o_ord), b_aux.as<unsigned>()};
+  const float tE = (float)-0.69314718055994529;
+  const int sp = ctx->span_begin("fs_bwd_kernel<3> (speculative)", s, (double)(tot / 5) * om->M, (double)(tot / 5) * 21.0);
+  st = launch_fs3_bwd_chain(ctx, s, om, &shadow, fs_columns(om->M), tE, tE, reinterpret_cast<float *>(b_aux.as<char>() + o_sc), b_rows.as<float>(),
+                            reinterpret_cast<const int64_t *>(b_aux.as<char>() + o_xoff), jq, 4, 57, 9);
+  ctx->span_end(sp, s);
+  shadow.d_data = nullptr; shadow.d_off = nullptr; shadow.d_len = nullptr;   // borrowed
+  if (st != BATH_OK) return st;
+  ctx->fs_spec_valid = true;
   return BATH_OK;
 }
 
@@ -1973,7 +2055,42 @@ int fs3_regions(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, const bath_hip_
   BATH_HIP_TRY(ctx, b_sc.reserve((size_t)n * 2 * sizeof(float)));
   FsJobs jq[2];
   if ((st = fs_schedule(ctx, dna, 2, jq)) != BATH_OK) return st;
+  // Speculative rows (fs3_backward_spec): window q of <dna> is window kept[q] of the decision stage's block; when its Backward rows are
+  // already in scratch[53] the parser below skips it (a job list of the OTHER windows, longest first; the launcher sees a shadow of
+  // <dna> that holds only those) and a copy kernel puts the rows where the region heuristics read them
+  const bool spec = reuse && ctx->fs_spec_valid && ctx->fs_strict && fs_chain_enabled();
+  std::vector<int64_t> spec_src;
+  bath_hip_seqs rest;
+  const bath_hip_seqs *bwd_dna = dna;
+  int64_t n_rest = n;
+  if (spec) {
+    spec_src.assign((size_t)n, -1);
+    std::vector<int32_t> ord;
+    for (int64_t q = 0; q < n; q++) {
+      const int64_t at = ctx->fs_spec_rows[(size_t)kept[q]];
+      if (at >= 0) spec_src[(size_t)q] = at; else ord.push_back((int32_t)q);
+    }
+    std::stable_sort(ord.begin(), ord.end(), [&](int32_t a, int32_t b) { return dna->h_len[(size_t)a] > dna->h_len[(size_t)b]; });
+    n_rest = (int64_t)ord.size();
+    DevBuf &b_sp = ctx->scratch[55];                                          // counter, the rest's job list, the speculative rows' offsets
+    const size_t o_ord = 256, o_src = o_ord + (((size_t)std::max<int64_t>(n_rest, 1) * 4 + 255) & ~(size_t)255);
+    BATH_HIP_TRY(ctx, b_sp.reserve(o_src + (size_t)n * 8 + 64));
+    BATH_HIP_TRY(ctx, hipMemsetAsync(b_sp.p, 0, 256, ctx->stream));
+    if (ctx->stage[10].reserve((size_t)n_rest * 4 + (size_t)n * 8 + 64) != hipSuccess) { ctx->set_error("cannot allocate page-locked staging memory"); return BATH_EFAIL; }
+    char *hs = static_cast<char *>(ctx->stage[10].p);
+    if (n_rest) std::memcpy(hs, ord.data(), (size_t)n_rest * 4);
+    std::memcpy(hs + (size_t)n_rest * 4, spec_src.data(), (size_t)n * 8);
+    if (n_rest) BATH_HIP_TRY(ctx, hipMemcpyAsync(b_sp.as<char>() + o_ord, hs, (size_t)n_rest * 4, hipMemcpyHostToDevice, ctx->stream));
+    BATH_HIP_TRY(ctx, hipMemcpyAsync(b_sp.as<char>() + o_src, hs + (size_t)n_rest * 4, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    jq[1] = FsJobs{reinterpret_cast<const int32_t *>(b_sp.as<char>() + o_ord), b_sp.as<unsigned>()};
+    rest.ctx = ctx; rest.is_part = true; rest.n = n_rest; rest.d_data = dna->d_data; rest.d_off = dna->d_off; rest.d_len = dna->d_len;
+    rest.h_len.resize((size_t)n_rest); rest.maxlen = 0; rest.total = 0;
+    for (int64_t i = 0; i < n_rest; i++) { const int32_t L = dna->h_len[(size_t)ord[(size_t)i]]; rest.h_len[(size_t)i] = L; rest.maxlen = std::max(rest.maxlen, L); rest.total += L; }
+    bwd_dna = &rest;
+  }
+  struct Borrowed { bath_hip_seqs &v; ~Borrowed() { v.d_data = nullptr; v.d_off = nullptr; v.d_len = nullptr; } } rest_guard{rest};
   const int mode = ctx->fs_strict ? BATH_LOGSUM_TABLE_SERIAL : BATH_LOGSUM_TABLE;
+  static const int spec_share = [] { const char *e = std::getenv("BATH_HIP_FS_SPEC_SHARE"); return e ? std::max(1, std::atoi(e)) : 2; }();   // (probe) CUs each parser's launch is sized for: all / this
   StageGate gate((mode == BATH_LOGSUM_TABLE_SERIAL && fs_chain_enabled()) ? ctx->device : -1, reuse ? StageGate::kBwdChain : StageGate::kFwdChain);   // held until the synchronize below
   if ((st = fs_fork(ctx)) != BATH_OK) return st;
   const double cells3 = (double)(xoff[(size_t)n] / 5) * om->M;                // rows x nodes; algorithmic HBM bytes: 1 B/nt in + 20 B/row out
@@ -1983,19 +2100,27 @@ int fs3_regions(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, const bath_hip_
     const int s1 = reuse ? -1 : ctx->span_begin("fs3_fwd_kernel", ctx->stream, cells3, bytes3);
     if (reuse) {
     } else if (MD == 2 && fs_chain_enabled()) {
-      if ((st = launch_fs3_fwd_chain(ctx, ctx->stream, om, dna, Cv, tE, tE, b_sc.as<float>(), b_fx.as<float>(), b_off.as<int64_t>(), jq[0], 2)) != BATH_OK) return st;
+      if ((st = launch_fs3_fwd_chain(ctx, ctx->stream, om, dna, Cv, tE, tE, b_sc.as<float>(), b_fx.as<float>(), b_off.as<int64_t>(), jq[0], spec_share)) != BATH_OK) return st;
     } else
     hipLaunchKernelGGL((fs3_fwd_kernel<CC, MD>), dim3(grid_dp), dim3(kFsBlock), shmem, ctx->stream, dna->view(), fsdev(om), om->d_loop[0], om->d_move[0], tE, tE, b_sc.as<float>(), b_fx.as<float>(), b_off.as<int64_t>(), jq[0]);
     ctx->span_end(s1, ctx->stream);
     if ((st = fs_set_shmem(ctx, fs_bwd_kernel<CC, 3, MD>, shmem)) != BATH_OK) return st;
     const int s2 = ctx->span_begin("fs_bwd_kernel<3>", ctx->side_stream, cells3, bytes3);
     if (MD == 2 && fs_chain_enabled()) {
-      if ((st = launch_fs3_bwd_chain(ctx, ctx->side_stream, om, dna, Cv, tE, tE, b_sc.as<float>() + n, b_bx.as<float>(), b_off.as<int64_t>(), jq[1], reuse ? 1 : 2)) != BATH_OK) return st;
+      if (n_rest > 0 && (st = launch_fs3_bwd_chain(ctx, ctx->side_stream, om, bwd_dna, Cv, tE, tE, b_sc.as<float>() + n, b_bx.as<float>(), b_off.as<int64_t>(), jq[1], reuse ? 1 : spec_share)) != BATH_OK) return st;
     } else
     hipLaunchKernelGGL((fs_bwd_kernel<CC, 3, MD>), dim3(grid_dp), dim3(kFsBlock), shmem, ctx->side_stream, dna->view(), fsdev(om), om->d_loop[0], om->d_move[0], tE, tE, b_sc.as<float>() + n, (float *)nullptr, (const int64_t *)nullptr, b_bx.as<float>(), b_off.as<int64_t>(), jq[1]);
     ctx->span_end(s2, ctx->side_stream);
   }))
   if ((st = fs_join(ctx)) != BATH_OK) return st;
+  if (spec) {                                                                  // the speculative rows of this call's windows into place
+    BATH_HIP_TRY(ctx, hipEventRecord(ctx->ev_spec, ctx->spec_stream));
+    BATH_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_spec, 0));
+    const size_t o_src = 256 + (((size_t)std::max<int64_t>(n_rest, 1) * 4 + 255) & ~(size_t)255);
+    hipLaunchKernelGGL(fs_rows_copy_kernel, dim3((unsigned)n), dim3(256), 0, ctx->stream, (int)n, dna->d_len, reinterpret_cast<const int64_t *>(ctx->scratch[55].as<char>() + o_src),
+                       ctx->scratch[53].as<float>(), b_off.as<int64_t>(), b_bx.as<float>());
+    BATH_HIP_TRY(ctx, hipGetLastError());
+  }
   const int s3 = ctx->span_begin("fs_regions_kernel", ctx->stream, (double)(xoff[(size_t)n] / 5), (double)(xoff[(size_t)n] / 5) * 52.0);
   hipLaunchKernelGGL(fs_regions_kernel, dim3((unsigned)n), dim3(64), 0, ctx->stream, n, dna->d_len, d_fx, b_bx.as<float>(), b_off.as<int64_t>(), d_fxoff, om->d_logsum, loop,
                      b_work.as<float>(), b_reg.as<int32_t>());
@@ -2010,15 +2135,15 @@ int fs3_regions(bath_hip_ctx *ctx, const bath_hip_fsprofile *om, const bath_hip_
 
 namespace bath {
 // used by the pipeline's frameshift stage (bath_pipeline.hip)
-int fs3_forward_scores(bath_hip_ctx *ctx, const bath_hip_fsprofile *om3, const bath_hip_seqs *dna, float *sc) {
+int fs3_forward_scores(bath_hip_ctx *ctx, const bath_hip_fsprofile *om3, const bath_hip_seqs *dna, float *sc, const std::function<int()> *after_launch) {
   ctx->fs_keep_xoff.clear();
   const int mode = ctx->fs_strict ? BATH_LOGSUM_TABLE_SERIAL : BATH_LOGSUM_TABLE;
-  if (!ctx->fs_want_regions) return fs3_parser(ctx, om3, dna, mode, sc, nullptr, nullptr, false);
+  if (!ctx->fs_want_regions) return fs3_parser(ctx, om3, dna, mode, sc, nullptr, nullptr, false, nullptr, after_launch);
   // the domain stage follows: the special-state rows of every window stay on the device (20 B per nucleotide), so that the
   // windows that take the frameshift branch need the Backward parser only
   std::vector<int64_t> xoff((size_t)dna->n + 1, 0);
   for (int64_t i = 0; i < dna->n; i++) xoff[(size_t)i + 1] = xoff[(size_t)i] + ((int64_t)dna->h_len[(size_t)i] + 1) * 5;
-  const int st = fs3_parser(ctx, om3, dna, mode, sc, nullptr, xoff.data(), false, &ctx->scratch[45]);
+  const int st = fs3_parser(ctx, om3, dna, mode, sc, nullptr, xoff.data(), false, &ctx->scratch[45], after_launch);
   if (st == BATH_OK) ctx->fs_keep_xoff = std::move(xoff);
   return st;
 }

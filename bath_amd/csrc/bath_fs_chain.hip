@@ -1139,7 +1139,9 @@ int launch_fs3_fwd_chain(bath_hip_ctx *ctx, hipStream_t stream, const bath_hip_f
 }
 
 int launch_fs3_bwd_chain(bath_hip_ctx *ctx, hipStream_t stream, const bath_hip_fsprofile *om, const bath_hip_seqs *dna, int Cv, float tEL, float tEM,
-                         float *d_sc, float *d_xmx, const int64_t *d_xoff, FsJobs jobs, int cu_share) {
+                         float *d_sc, float *d_xmx, const int64_t *d_xoff, FsJobs jobs, int cu_share, int bst_slot, int stage_slot) {
+  // <bst_slot>, <stage_slot>: where the launch keeps its batch starts (device scratch, page-locked staging).  A second launch that
+  // may run while the first is still pulling batches (the speculative Backward of the longest windows) brings its own.
   const int M = om->M;
   size_t shmem = 0;
   // half a wave per window when the model fits 32 lanes x 6 nodes and the windows would otherwise take more than half the chip:
@@ -1151,8 +1153,8 @@ int launch_fs3_bwd_chain(bath_hip_ctx *ctx, hipStream_t stream, const bath_hip_f
     if (half_env != 0 && CH <= 6 && (half_env == 1 || n > (int64_t)ctx->prop.multiProcessorCount * 8)) {
       const size_t hs = (size_t)(kLogsumTbl + (M + 2) * 8 + 32 * 2 * (CH * 32 + 1) + 64 + 16) * sizeof(float);
       int nbat = 0;
-      DevBuf &b_bst = ctx->scratch[48];
-      const int stb = chain_batches(ctx, stream, dna, 0.128 * M + 6.6 + 0.5 * CH, 0.03 * CH, 32, b_bst, 2, &nbat, cu_share);
+      DevBuf &b_bst = ctx->scratch[bst_slot];
+      const int stb = chain_batches(ctx, stream, dna, 0.128 * M + 6.6 + 0.5 * CH, 0.03 * CH, 32, b_bst, stage_slot, &nbat, cu_share);
       if (stb != BATH_OK) return stb;
       const int hgrid = std::max(1, std::min(nbat, (int)ctx->prop.multiProcessorCount));
       FsDev dev{om->M, om->pitch, om->maxcodons, om->d_rsc, om->d_tf, om->d_tb, om->d_logsum};
@@ -1169,8 +1171,8 @@ int launch_fs3_bwd_chain(bath_hip_ctx *ctx, hipStream_t stream, const bath_hip_f
   const int W = chain_waves(ctx, dna->n, M, Cv, &shmem, cu_share, bwd_chain_threads(Cv), chain_compact(Cv) ? (M + 3) * 4 : 0);
   // batches by length (chain_batches); t(w) measured at M = 145 (C = 3): 25.4 us per row pair at one window, 28.5 at 16
   int nbat = 0;
-  DevBuf &b_bst = ctx->scratch[48];                                // (its own buffer: Forward's launch may be running on another stream)
-  const int stb = chain_batches(ctx, stream, dna, 0.128 * M + 6.6, 0.067 * Cv, W, b_bst, 2, &nbat, cu_share);
+  DevBuf &b_bst = ctx->scratch[bst_slot];                          // (its own buffer: Forward's launch may be running on another stream)
+  const int stb = chain_batches(ctx, stream, dna, 0.128 * M + 6.6, 0.067 * Cv, W, b_bst, stage_slot, &nbat, cu_share);
   if (stb != BATH_OK) return stb;
   const int grid = std::max(1, std::min(nbat, (int)ctx->prop.multiProcessorCount));
   FsDev dev{om->M, om->pitch, om->maxcodons, om->d_rsc, om->d_tf, om->d_tb, om->d_logsum};

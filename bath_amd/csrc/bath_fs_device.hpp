@@ -159,7 +159,8 @@ int launch_fs5_decode_oa_mw(bath_hip_ctx *ctx, hipStream_t stream, const bath_hi
 int launch_fs3_fwd_chain(bath_hip_ctx *ctx, hipStream_t stream, const bath_hip_fsprofile *om, const bath_hip_seqs *dna, int Cv, float tEL, float tEM,
                          float *d_sc, float *d_xmx, const int64_t *d_xoff, FsJobs jobs, int cu_share = 1);
 int launch_fs3_bwd_chain(bath_hip_ctx *ctx, hipStream_t stream, const bath_hip_fsprofile *om, const bath_hip_seqs *dna, int Cv, float tEL, float tEM,
-                         float *d_sc, float *d_xmx, const int64_t *d_xoff, FsJobs jobs, int cu_share = 1 /* 2: the Forward parser runs beside it */);
+                         float *d_sc, float *d_xmx, const int64_t *d_xoff, FsJobs jobs, int cu_share = 1 /* 2: the Forward parser runs beside it */,
+                         int bst_slot = 48, int stage_slot = 2 /* scratch / staging slots of the launch's batch starts */);
 int launch_fs5_fwd_chain(bath_hip_ctx *ctx, hipStream_t stream, const bath_hip_fsprofile *om, const bath_hip_seqs *dna, int Cv, float tEL, float tEM, int c5_compat,
                          float *d_sc, float *d_fwd, const int64_t *d_foff, float *d_xmx, const int64_t *d_xoff, int cfg_len, FsJobs jobs, int *d_done);
 inline bool fs_chain_enabled() { static const bool off = [] { const char *e = std::getenv("BATH_HIP_FS_HANDOFF"); return e && e[0] == '1'; }(); return !off; }   // BATH_HIP_FS_HANDOFF=1: the 64-step lane hand-off kernels, for A/B runs

@@ -1,5 +1,6 @@
 // bath_launch.hpp -- host-side launchers shared between bath_filters.hip and bath_pipeline.hip.
 #pragma once
+#include <functional>
 #include <utility>
 
 #include "bath_common.hpp"
@@ -115,11 +116,13 @@ float flogsum_host(float a, float b);                          // p7_FLogsum wit
 // ---- frameshift helpers for the pipeline (bath_frameshift.hip)
 int fs_fork(bath_hip_ctx *ctx);   // the context's side stream waits for what the main stream holds so far
 int fs_join(bath_hip_ctx *ctx);   // ... and the main stream for the side stream
-int fs3_forward_scores(bath_hip_ctx *ctx, const bath_hip_fsprofile *om3, const bath_hip_seqs *dna, float *sc);   // table log-sum, host array out
+int fs3_forward_scores(bath_hip_ctx *ctx, const bath_hip_fsprofile *om3, const bath_hip_seqs *dna, float *sc,
+                       const std::function<int()> *after_launch = nullptr);   // table log-sum, host array out; <after_launch> runs between the launch and the wait
 const float *fsprofile_evparam(const bath_hip_fsprofile *om);
 int fs_max_regions();
 int fs3_regions(bath_hip_ctx *ctx, const bath_hip_fsprofile *om3, const bath_hip_seqs *dna, float loop, int32_t *regions_out, float *fwd_sc_out = nullptr, const int32_t *kept = nullptr);   // parsers + domain decoding + region heuristics (+ the Forward scores)
 int fsprofile_codon_lengths(const bath_hip_fsprofile *om);
+int fs3_backward_spec(bath_hip_ctx *ctx, const bath_hip_fsprofile *om3, const bath_hip_seqs *dna, int k);   // speculative Backward of the k longest windows, on ctx->spec_stream
 struct FsHostTables { int M, max_length, maxcodons; const float *tsc; const uint8_t *codons; const float *evparam; };
 const FsHostTables fsprofile_host(const bath_hip_fsprofile *om);
 struct FsTraceOut {               // what the pipeline keeps of an envelope's OA trace

@@ -1206,7 +1206,7 @@ int fs_gather_view(bath_hip_ctx *ctx, const bath_hip_seqs *dna, std::vector<FsWi
 // len[] are already there; only the pool is reserved and the copy kernel launched
 int fs_gather_view_built(bath_hip_ctx *ctx, const bath_hip_seqs *dna, const FsWinBuild &B, const uint8_t *d_comp, bath_hip_seqs *view, const FsWinDev **d_desc_out) {
   const int nw = B.nw;
-  DevBuf &b_pool = ctx->scratch[29];
+  DevBuf &b_pool = ctx->scratch[56];                                          // its own pool: the speculative Backward reads it while the domain stage gathers into scratch[29]
   BATH_HIP_TRY(ctx, b_pool.reserve((size_t)B.pool_bytes + 256));
   BATH_HIP_TRY(ctx, hipMemsetAsync(b_pool.p, 0x1d, (size_t)B.pool_bytes + 256, ctx->stream));
   hipLaunchKernelGGL(fs_window_gather_kernel, dim3((unsigned)std::max(1, std::min(nw, 65535))), dim3(256), 0, ctx->stream, dna->d_data, B.d_desc, nw, d_comp, b_pool.as<uint8_t>());
@@ -1405,6 +1405,8 @@ extern "C" int bath_hip_pipeline_frameshift(bath_hip_ctx *ctx, const bath_hip_op
   if (fsprofile_codon_lengths(om_fs3) != 3) { ctx->set_error("the frameshift stage needs the 3-codon frameshift profile"); return BATH_EINVAL; }
   *fs_windows = nullptr; *n_fs_windows = 0;
   ctx->fs_windows.clear();
+  if (ctx->spec_stream) BATH_HIP_TRY(ctx, hipStreamSynchronize(ctx->spec_stream));   // (a speculative Backward of the previous call that nothing waited for)
+  ctx->fs_spec_valid = false;
   bath_pipeline_params prm = *prm_in;
   prm.fs_pipe = 1;
   bath_pipeline_stats st_local{};
@@ -1608,7 +1610,9 @@ extern "C" int bath_hip_pipeline_frameshift(bath_hip_ctx *ctx, const bath_hip_op
     std::vector<float> h_fsc((size_t)nw);
     ctx->fs_regions_all.clear();
     ctx->fs_keep_xoff.clear();
-    if (ctx->fs_want_regions && nw <= (int64_t)ctx->prop.multiProcessorCount * 16) {
+    static const bool spec_all = [] { const char *e = std::getenv("BATH_HIP_FS_SPEC_ALL"); return e && e[0] == '1'; }();   // (probe: both parsers side by side whatever the count)
+    static const bool spec_force = [] { const char *e = std::getenv("BATH_HIP_FS_SPEC_FORCE"); return e && e[0] == '1'; }();   // tests: the speculative path for a handful of windows
+    if (ctx->fs_want_regions && !spec_force && (spec_all || nw <= (int64_t)ctx->prop.multiProcessorCount * 16)) {
       // The domain stage follows: its Backward parser, domain decoding and region heuristics run here, for every window,
       // next to the Forward parser whose score decides the branch.  These kernels are bound by the row chain of the longest
       // window as long as every window has a wave of its own (16 waves per CU), so up to that many windows the ones that will
@@ -1618,8 +1622,23 @@ extern "C" int bath_hip_pipeline_frameshift(bath_hip_ctx *ctx, const bath_hip_op
       ctx->fs_regions_all.assign((size_t)nw * (size_t)(1 + 3 * fs_max_regions()), 0);
       const float pmove = (2.0f + 1.0f) / (100.0f + 2.0f + 1.0f);              // p7_fs_ReconfigLength(L = 100, nj = 1): the saved length (p7_domaindef.c:318)
       st = fs3_regions(ctx, om_fs3, &view, (float)std::log((double)(1.0f - pmove)), ctx->fs_regions_all.data(), h_fsc.data());
-    } else
-    st = fs3_forward_scores(ctx, om_fs3, &view, h_fsc.data());
+    } else {
+      // more windows than both parsers can run side by side for: Forward for all of them, and -- when the domain stage follows, the
+      // windows were built on the device (their pool is not the one that stage gathers into) and this context is the host's only one
+      // at work -- the Backward parser of the LONGEST windows speculatively beside it (fs3_backward_spec).
+      // BATH_HIP_FS_SPEC_K: how many.  DEFAULT 0 = OFF: measured on the bench block (profiles/r06_fs_spec_probe.txt), the speculation
+      // does not pay -- the Forward launch is batched so that all of its 238 blocks end together (chain_batches), so it holds 238 of the
+      // 256 CUs for its whole 9.4 ms and the speculative blocks beyond the 18 free CUs start when Forward ENDS, later than the domain
+      // stage would have started them; launched first instead, they push Forward's blocks into a second round (21.4 -> 25.6-30.8 ms for
+      // 12.9-9.3 ms of Backward saved).  Kept, tested (BATH_HIP_FS_SPEC_FORCE=1 with a handful of windows), off.
+      static const int spec_k = [] { const char *e = std::getenv("BATH_HIP_FS_SPEC_K"); return e ? std::atoi(e) : 0; }();
+      const int k = spec_k;
+      // launched AFTER Forward's kernel (the hook): Forward's blocks take their CUs first, the speculation gets the ones that are left
+      // and the ones Forward's short batches give back -- launched first it delays Forward by more than it saves (measured)
+      const std::function<int()> spec = [&]() -> int { return fs3_backward_spec(ctx, om_fs3, &view, k); };
+      const bool speculate = ctx->fs_want_regions && built && k > 0 && host_contexts() <= 1;
+      st = fs3_forward_scores(ctx, om_fs3, &view, h_fsc.data(), speculate ? &spec : nullptr);
+    }
     view.d_data = nullptr; view.d_off = nullptr; view.d_len = nullptr;     // borrowed pointers: nothing for a destructor to free
     if (st != BATH_OK) return st;
     if (built) {

@@ -162,6 +162,8 @@ extern "C" void bath_hip_finalize(bath_hip_ctx *ctx) {
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
   if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
   if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
+  if (ctx->spec_stream) { (void)hipStreamSynchronize(ctx->spec_stream); (void)hipStreamDestroy(ctx->spec_stream); }
+  if (ctx->ev_spec) (void)hipEventDestroy(ctx->ev_spec);
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -188,6 +190,11 @@ extern "C" int bath_hip_trim(bath_hip_ctx *ctx) {
     if (ctx->ev_fork) { (void)hipEventDestroy(ctx->ev_fork); ctx->ev_fork = nullptr; }
     if (ctx->ev_join) { (void)hipEventDestroy(ctx->ev_join); ctx->ev_join = nullptr; }
   }
+  if (ctx->spec_stream) {
+    (void)hipStreamSynchronize(ctx->spec_stream); (void)hipStreamDestroy(ctx->spec_stream); ctx->spec_stream = nullptr;
+    if (ctx->ev_spec) { (void)hipEventDestroy(ctx->ev_spec); ctx->ev_spec = nullptr; }
+  }
+  ctx->fs_spec_valid = false; ctx->fs_spec_rows.clear();
   ctx->fs_std_orfs.clear(); ctx->fs_std_pool = nullptr; ctx->fs_keep_xoff.clear(); ctx->fs_regions_all.clear();
   ctx->d_records = nullptr; ctx->n_records = 0;
   return BATH_OK;
