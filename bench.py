@@ -992,7 +992,7 @@ def main():
         k1_ms = float(np.mean([o["ssv_f1"] for o in one])) if one else float("nan")
         tc1 = stats.cells_msv / (k1_ms * 1e-3) / 1e12 if one else float("nan")
         traffic = None
-        pmc = next((f for f in (os.path.join(ROOT, "profiles", r + "_ssv_orf_pmc.json") for r in ("r05", "r04", "r03", "r02")) if os.path.exists(f)), "")
+        pmc = next((f for f in (os.path.join(ROOT, "profiles", r + "_ssv_orf_pmc.json") for r in ("r06", "r05", "r04", "r03", "r02")) if os.path.exists(f)), "")
         if os.path.exists(pmc):
             try:
                 traffic = json.load(open(pmc)).get("hbm_bytes_per_launch_full_block") / lanes
