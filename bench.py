@@ -165,7 +165,7 @@ def fs_cpu_worker(span):
     return dt, int(pli.nres), len(ofw), len(odm)
 
 
-def fs_cpu_baseline(path, seqs, ctxs, what, probe=None, budget_s=12.0):
+def fs_cpu_baseline(path, seqs, ctxs, what, probe=None, budget_s=12.0, min_per_s=0.0):
     """cpu_baseline of an --fs leg, BEFORE any GPU initialisation: every usable core scores its own slice of <seqs> through the
     oracle's --fs pipeline (fs_cpu_worker); the sample is sized from a one-thread probe so that the whole thing takes about
     <budget_s> seconds.  kind "port": the cascade is the SSE2 restatement of impl_sse, the frameshift stages are the SCALAR
@@ -178,7 +178,7 @@ def fs_cpu_baseline(path, seqs, ctxs, what, probe=None, budget_s=12.0):
     n = len(seqs)
     probe = min(n, probe or max(1, n // 50))
     dt1, nres1, _, _ = fs_cpu_worker((0, probe))
-    per = dt1 / probe
+    per = max(dt1 / probe, min_per_s)            # (min_per_s: a floor for jobs whose first units are not typical -- a genome window without a gene costs nothing)
     covered = int(min(n, max(cores, budget_s * cores / max(per, 1e-9) * 0.8)))
     cores = min(cores, covered)
     bounds = [covered * c // cores for c in range(cores + 1)]
@@ -305,7 +305,7 @@ def c45_cpu_samples(args):
     # cpu_baseline of the configs[4] leg: genome windows (262 kb + context each) through the oracle's --fs pipeline, one per core and pass
     all_wins = bdist.split_targets([len(g5)], hmm5.max_length)
     out["c5_baseline"] = fs_cpu_baseline(c5_model_path(), [g5[s_:s_ + n] for _, s_, n, _ in all_wins], [c for _, _, _, c in all_wins],
-                                         "genome windows of %d nt + context (both strands)" % bdist.BLOCK_LENGTH, probe=1, budget_s=10.0)
+                                         "genome windows of %d nt + context (both strands)" % bdist.BLOCK_LENGTH, probe=1, budget_s=10.0, min_per_s=0.5)
     return out
 
 
