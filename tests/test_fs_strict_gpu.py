@@ -217,3 +217,27 @@ def test_clusters_envelopes_beside_the_first_batch_fresh_process(beside):
         env["BATH_HIP_FS_CLUSTERS_BESIDE"] = beside
     r = subprocess.run([sys.executable, "-c", BESIDE_SCRIPT.format(root=root)], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "beside ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+def _rerun(env_extra, select):
+    """Runs a selection of this module's tests in a FRESH process with extra environment (the switches are read once per process)."""
+    import os, subprocess, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, **env_extra)
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.join(here, "test_fs_strict_gpu.py"), os.path.join(here, "test_fs_pipeline_gpu.py"), "-k", select],
+                       env=env, capture_output=True, text=True, timeout=1500, cwd=os.path.dirname(here))
+    assert r.returncode == 0 and " passed" in r.stdout, (r.stdout[-3000:], r.stderr[-2000:])
+
+
+def test_host_window_path_agrees_with_the_oracle_too():
+    """The DNA windows are built and the branch decided on the device by default (bath_fs_windows.hip); the host path of rounds 1-5
+    (p7_pli_BuildDNAWindows restated in C++, bath_pipeline.hip) stays as the fallback for blocks the device path does not take and as
+    the A/B twin: BATH_HIP_FS_WINDOWS_HOST=1 runs the strict pipeline tests and the window-level tests through it."""
+    _rerun({"BATH_HIP_FS_WINDOWS_HOST": "1"}, "strict_pipeline_is_exact or planted_frameshifted or cascade_lanes or recorded_fs")
+
+
+def test_speculative_backward_rows_are_the_parsers_rows():
+    """fs3_backward_spec (off by default: profiles/r06_fs_spec_probe.txt): the Backward parser of the K longest DNA windows beside the
+    Forward parser of all of them, its rows copied into place for the domain stage, which runs the parser for the other windows only.
+    Forced for a handful of windows (BATH_HIP_FS_SPEC_FORCE=1, K = 5): every strict pipeline test must still hold bit for bit."""
+    _rerun({"BATH_HIP_FS_SPEC_FORCE": "1", "BATH_HIP_FS_SPEC_K": "5"}, "strict_pipeline_is_exact or planted_frameshifted or cascade_lanes or recorded_fs")
