@@ -147,30 +147,33 @@ _FS_CPU_JOB = None          # (model path, list of DNA windows, their contexts):
 
 
 def fs_cpu_worker(span):
-    """The oracle's whole --fs pipeline -- the cascade on the SSE2 striped kernels (oracle/sse), then the scalar restatement of
-    generic_*_frameshift.c: DNA windows, 3-codon parsers, regions, 5-codon Forward / Backward / decoding / optimal accuracy /
-    null2, traceback, hits -- over windows [lo, hi) of the job (a forked worker: no GPU state)."""
+    """The oracle's whole --fs pipeline -- the cascade and the 3-codon Forward parser of every DNA window on the SSE2 striped kernels
+    (oracle/sse: sse_filters.c, sse_fs.c), the stages behind the branch decision on the scalar restatement of
+    generic_*_frameshift.c (Backward parser, regions, 5-codon Forward / Backward / decoding / optimal accuracy / null2, traceback,
+    hits) -- over windows [lo, hi) of the job (a forked worker: no GPU state)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as ol
     path, seqs, ctxs = _FS_CPU_JOB
     lo, hi = span
     L_ = ol.lib()
     L_.bo_pipeline_use_sse(1)
+    L_.bo_fs_use_sse(1)                                          # the 3-codon Forward parser of every DNA window: striped, probability space (oracle/sse/sse_fs.c)
     model = ol.Model(path, 0)
     model.fs(3); model.fs(5)                                     # profile construction is not part of the scoring loop
     t0 = time.perf_counter()
     pli, ofw, _, odm, _, _ = model.run_pipeline_fsdom(seqs[lo:hi], contexts=None if ctxs is None else ctxs[lo:hi])
     dt = time.perf_counter() - t0
     L_.bo_pipeline_use_sse(0)
+    L_.bo_fs_use_sse(0)
     return dt, int(pli.nres), len(ofw), len(odm)
 
 
 def fs_cpu_baseline(path, seqs, ctxs, what, probe=None, budget_s=12.0, min_per_s=0.0):
     """cpu_baseline of an --fs leg, BEFORE any GPU initialisation: every usable core scores its own slice of <seqs> through the
     oracle's --fs pipeline (fs_cpu_worker); the sample is sized from a one-thread probe so that the whole thing takes about
-    <budget_s> seconds.  kind "port": the cascade is the SSE2 restatement of impl_sse, the frameshift stages are the SCALAR
-    restatement of generic_*_frameshift.c (the reference's impl_sse/fwdback_fs.c runs them striped in probability space: the
-    reference on these cores would be faster than this figure by that factor)."""
+    <budget_s> seconds.  kind "port": the cascade and the per-window 3-codon Forward parser are SSE2 striped restatements of impl_sse
+    (fwdback_fs.c:97-533 in probability space); the stages that only frameshift-branch windows reach are the SCALAR restatement of
+    generic_*_frameshift.c (the reference runs those striped too: it would be faster than this figure on those windows)."""
     import multiprocessing as mp
     global _FS_CPU_JOB
     _FS_CPU_JOB = (path, seqs, ctxs)
@@ -189,8 +192,9 @@ def fs_cpu_baseline(path, seqs, ctxs, what, probe=None, budget_s=12.0, min_per_s
     busy = max(o[0] for o in outs)
     _FS_CPU_JOB = None
     return {"value": sum(o[1] for o in outs) / busy, "unit": "residues/s", "cores": cores, "kind": "port",
-            "label": "the oracle's --fs pipeline: SSE2 restatement of impl_sse's cascade + SCALAR restatement of generic_*_frameshift.c for every frameshift "
-                     "stage (the reference runs those striped in probability space, impl_sse/fwdback_fs.c; it cannot be built here)",
+            "label": "the oracle's --fs pipeline: SSE2 striped restatements of impl_sse's cascade and of p7_ForwardParser_Frameshift_3Codons (probability space, "
+                     "every DNA window) + SCALAR restatement of generic_*_frameshift.c for the stages behind the branch decision (the reference runs those "
+                     "striped too, impl_sse/fwdback_fs.c; it cannot be built here)",
             "sample": "%d of %d %s, %d processes, %.1f s scoring (%.1f s wall); %d DNA windows, %d domains"
                       % (covered, n, what, cores, busy, wall, sum(o[2] for o in outs), sum(o[3] for o in outs)),
             "one_thread": {"value": nres1 / dt1, "sample": "%d %s, %.1f s" % (probe, what, dt1)}}
@@ -1124,7 +1128,7 @@ def compact_line(out):
                    "fast_ms": _r(g(fs, "fast", "ms_per_pass")), "domains": fs.get("domains"),
                    "fast_identical": g(fs, "fast", "domains_identical_to_strict_mode")}
         if fs.get("cpu_baseline"):
-            c["fs"]["cpu_baseline"] = {"value": _r(g(fs, "cpu_baseline", "value")), "cores": g(fs, "cpu_baseline", "cores"), "kind": "port: SSE2 cascade + scalar generic fs"}
+            c["fs"]["cpu_baseline"] = {"value": _r(g(fs, "cpu_baseline", "value")), "cores": g(fs, "cpu_baseline", "cores"), "kind": "port: SSE2 cascade + SSE2 fs3 Forward + scalar generic fs"}
         if fs.get("n_gpus"):
             c["fs"] = {"ms_per_pass": _r(fs.get("ms_per_pass")), "residues_per_s": _r(fs.get("residues_per_s")), "n_gpus": fs.get("n_gpus"),
                        "domains_equal": fs.get("domains_equal_to_single_rank_search"), "counters_equal": fs.get("counters_equal_to_single_rank_search")}

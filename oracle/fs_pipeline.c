@@ -145,7 +145,7 @@ int bo_pli_frameshift(bo_pipeline *pli, bo_oprofile *om, bo_fs_profile *gm3, bo_
     bo_fs_profile_reconfig_length(gm3, L / 3);
     bo_gmx *gx = bo_gmx_create(gm3->M, L + 1, L, 3);
     float fsc = -INFINITY;
-    bo_gforward_parser_fs3(wdsq, L, gm3, gx, &fsc);
+    bo_k_gforward_parser_fs3(wdsq, L, gm3, gx, &fsc);
     bo_gmx_free(gx);
     float seqscore = (float)((fsc - filtersc) / LOG2C);
     double P_fs = bo_exp_surv(seqscore, gm3->evparam[BO_FTAUFS3], gm3->evparam[BO_FLAMBDA]);

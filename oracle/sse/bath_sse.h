@@ -10,6 +10,7 @@
  *   bs_vitfilter      <- p7_ViterbiFilter impl_sse/vitfilter.c:83-248    8 x int16 stripes, lazy-F D->D
  *   bs_vitfilter_bath <- p7_ViterbiFilter_BATH vitfilter.c:286-465       the same + hit windows
  *   bs_forward_parser <- p7_ForwardParser impl_sse/fwdback.c:132,256-463 4 x fp32 stripes, odds ratios, sparse rescaling
+ *   bs_fs3_forward_parser <- p7_ForwardParser_Frameshift_3Codons impl_sse/fwdback_fs.c:97-533 (sse_fs.c)
  *
  * Validated against the scalar oracle (tests/test_sse_cpu.py): integer filters bit-exact (score and status), Forward
  * within 1e-5 relative (fp32 sums in striped order).  Striping: node k (1..M) lives in vector q = (k-1) % Q,
@@ -49,5 +50,19 @@ int bs_forward_parser(const uint8_t *dsq, int L, bs_oprofile *so, float *ret_sc)
 
 /* the oracle's cascade (oracle/pipeline.c) with these kernels in place of the scalar ones: 0 scalar, 1 SSE2 striped */
 void bo_pipeline_use_sse(int on);
+
+/* ---- the frameshift stage (sse_fs.c): p7_ForwardParser_Frameshift_3Codons, impl_sse/fwdback_fs.c:97-533, striped in probability space */
+typedef struct {
+  int M, Q, ncodons;
+  const bo_fs_profile *gm;   /* the special-state transitions are read from here at call time (they follow the length configuration) */
+  __m128 *rfv;               /* [338][Q]  emission odds ratios of every codon / quasi-codon row */
+  __m128 *tfv;               /* [Q][7] {BM, MM, IM, DM of node k-1; MD, MI, II of node k} then [Q] DD */
+  __m128 *rows;              /* four rows of {M, D, I} and three rows of IVX */
+} bs_fsprofile;
+bs_fsprofile *bs_fsprofile_create(const bo_fs_profile *gm3);
+void          bs_fsprofile_free(bs_fsprofile *so);
+int bs_fs3_forward_parser(const uint8_t *dsq, int L, bs_fsprofile *so, float *xmx_log /* (L+1) x 5, log space, or NULL */, float *ret_sc);
+/* the oracle's --fs pipeline (fs_pipeline.c, fs_domaindef.c) with the striped Forward parser in place of the scalar log-space one */
+void bo_fs_use_sse(int on);
 
 #endif

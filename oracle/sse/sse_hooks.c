@@ -33,3 +33,16 @@ int bo_k_forward_parser(const uint8_t *dsq, int L, const bo_oprofile *om, float 
 {
   return use_sse ? bs_forward_parser(dsq, L, striped(om), ret_sc) : bo_forward_parser(dsq, L, om, NULL, ret_sc);
 }
+
+/* ---- the frameshift stage: the 3-codon Forward parser of a DNA window */
+static int fs_use_sse = 0;
+static __thread bs_fsprofile *fs_cached = NULL;
+
+void bo_fs_use_sse(int on) { fs_use_sse = on; }
+
+int bo_k_gforward_parser_fs3(const uint8_t *dsq, int L, const bo_fs_profile *gm3, bo_gmx *gx, float *ret_sc)
+{
+  if (!fs_use_sse) return bo_gforward_parser_fs3(dsq, L, gm3, gx, ret_sc);
+  if (!fs_cached || fs_cached->gm != gm3 || fs_cached->M != gm3->M) { bs_fsprofile_free(fs_cached); fs_cached = bs_fsprofile_create(gm3); }
+  return bs_fs3_forward_parser(dsq, L, fs_cached, gx ? gx->xmx : NULL, ret_sc);
+}

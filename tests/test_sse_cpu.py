@@ -114,3 +114,93 @@ def test_cascade_on_striped_kernels_equals_scalar_cascade():
     assert out[0][0] == out[1][0] and out[0][1] == out[1][1] and out[0][0][5] >= 10
     for a, b in zip(out[0][2], out[1][2]):
         assert (np.isinf(a) and np.isinf(b)) or abs(a - b) <= 1e-5 * max(1.0, abs(a))
+
+
+@pytest.mark.parametrize("name,idx", [("Caudal_act.bhmm", 0), ("PTH2.bhmm", 0), ("AMP_N.bhmm", 0), ("tRNA-proteins.bhmm", 3)])
+def test_fs3_forward_parser_striped_probability_space(name, idx):
+    """oracle/sse/sse_fs.c -- the SSE2 striped, probability-space restatement of p7_ForwardParser_Frameshift_3Codons
+    (impl_sse/fwdback_fs.c:97-533) that the --fs cpu_baseline legs run -- against the scalar log-space oracle
+    (generic_fwdback_frameshift.c:451-622 restated) on DNA windows with planted frameshifted genes, random DNA, degenerate
+    nucleotides and very short windows.  Tolerances are the reference's own between its SSE and generic parsers
+    (fwdback_fs.c:3189-3191): with the oracle on EXACT log-sums the scores agree to 1e-4 relative (+1e-3 nats near zero) and so do
+    all five special-state rows; against the TABLE log-sum (what the pipeline's oracle runs) within 1e-2 nats + 1e-4 relative per
+    window -- the table's own distance from exact arithmetic (a truncating 0.001-nat table is biased; the reference allows 1.0)."""
+    L_ = ol.lib()
+    model = ol.Model(ol.GOLDEN + "/" + name, idx)
+    gm3 = model.fs(3)
+    L_.bs_fsprofile_create.restype = C.c_void_p
+    L_.bs_fs3_forward_parser.restype = C.c_int
+    L_.bs_fs3_forward_parser.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]
+    L_.bs_fsprofile_free.argtypes = [C.c_void_p]
+    so = L_.bs_fsprofile_create(gm3)
+    assert so
+    rng = np.random.default_rng(11 + idx)
+    wins = []
+    for aa in common.emit_from_model(rng, model, 10, flank=8):                     # genes with a deleted and an inserted nucleotide
+        nt = list(common.revtranslate(rng, aa, model.basic))
+        del nt[int(rng.integers(5, len(nt) - 5))]
+        nt.insert(int(rng.integers(5, len(nt) - 5)), int(rng.integers(0, 4)))
+        wins.append(np.array(nt, dtype=np.uint8))
+    wins += [w for w in common.random_dna(rng, 6, 700)]
+    deg = common.random_dna(rng, 1, 300)[0].copy(); deg[50:60] = 15; deg[120] = 4      # N runs and an ambiguity code
+    wins += [deg, common.random_dna(rng, 1, 3)[0], common.random_dna(rng, 1, 7)[0], common.random_dna(rng, 1, 2500)[0]]
+    f, g = C.c_float(), C.c_float()
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+    worst_exact = worst_table = 0.0
+    for w in wins:
+        L = len(w)
+        d = ol.u8(ol.dsq_from(w))
+        L_.bo_fs_profile_reconfig_length(gm3, L // 3)
+        rows = np.zeros((L + 1) * 5, np.float32)
+        st = L_.bs_fs3_forward_parser(C.cast(d, C.c_void_p), L, so, rows.ctypes.data, C.byref(g))
+        gx = L_.bo_gmx_create(model.M, L + 1, L, 3)
+        for exact in (1, 0):
+            L_.bo_flogsum_set_exact(exact)
+            so_st = L_.bo_gforward_parser_fs3(d, L, gm3, gx, C.byref(f))
+            assert so_st == 0
+            if exact:
+                orow = np.ctypeslib.as_array(gx.contents.xmx, shape=((L + 1) * 5,)).copy()
+        L_.bo_flogsum_set_exact(0)
+        table_sc = f.value
+        L_.bo_flogsum_set_exact(1); L_.bo_gforward_parser_fs3(d, L, gm3, gx, C.byref(f)); L_.bo_flogsum_set_exact(0)
+        exact_sc = f.value
+        L_.bo_gmx_free(gx)
+        if not np.isfinite(exact_sc):
+            assert st == ERANGE or not np.isfinite(g.value)
+            continue
+        assert st == 0
+        assert abs(g.value - exact_sc) <= 1e-3 + 1e-4 * abs(exact_sc), (L, g.value, exact_sc)
+        assert abs(g.value - table_sc) <= 1e-2 + 1e-4 * abs(table_sc), (L, g.value, table_sc)
+        worst_exact = max(worst_exact, abs(g.value - exact_sc)); worst_table = max(worst_table, abs(g.value - table_sc))
+        fin = np.isfinite(orow) & (orow > -60.0)                                       # (values far below the scale are flushed in odds-ratio space)
+        assert np.all(np.abs(rows[fin] - orow[fin]) <= 2e-3 + 2e-4 * np.abs(orow[fin])), (L, float(np.abs(rows[fin] - orow[fin]).max()))
+        assert np.all(rows[~np.isfinite(orow)] < -50.0) or np.all(~np.isfinite(rows[~np.isfinite(orow)]))
+    L_.bs_fsprofile_free(so)
+    print("fs3 striped vs scalar: worst |delta| %.2e nats (exact log-sums), %.2e (table)" % (worst_exact, worst_table))
+
+
+def test_fs_pipeline_on_the_striped_parser_finds_the_same_windows():
+    """The oracle's --fs pipeline with the striped parser in place (bo_fs_use_sse: what the fs / c5 cpu_baseline legs time): same DNA
+    windows, Forward scores within the tolerance above, the same branch for every window whose decision is not within that tolerance
+    of flipping."""
+    L_ = ol.lib()
+    model = ol.Model(ol.GOLDEN + "/Caudal_act.bhmm", 0)
+    rng = np.random.default_rng(3)
+    wins = list(common.random_dna(rng, 40, 1000))
+    for aa in common.emit_from_model(rng, model, 20, flank=10):
+        nt = list(common.revtranslate(rng, aa, model.basic))
+        del nt[int(rng.integers(10, len(nt) - 10))]
+        wins.append(np.array(nt, dtype=np.uint8))
+    pli0, _, _, fw0, pw0 = model.run_pipeline_fs(wins)
+    L_.bo_fs_use_sse(1)
+    try:
+        pli1, _, _, fw1, pw1 = model.run_pipeline_fs(wins)
+    finally:
+        L_.bo_fs_use_sse(0)
+    assert pw0 == pw1 and len(fw0) == len(fw1) >= 5
+    flips = 0
+    for a, b in zip(fw0, fw1):
+        assert (a.strand, a.n, a.length, a.orf_cnt) == (b.strand, b.n, b.length, b.orf_cnt)
+        assert abs(a.fwdsc - b.fwdsc) <= 1e-2 + 1e-4 * abs(a.fwdsc)
+        flips += a.branch != b.branch
+    assert flips <= 1
