@@ -13,6 +13,7 @@ ap.add_argument("--workers", type=str, default="1,2,3")
 ap.add_argument("--passes", type=int, default=4, help="passes per worker")
 ap.add_argument("--windows", type=int, default=1_000_000)
 ap.add_argument("--distinct", action="store_true", help="every worker its own block (another seed) instead of copies of one block")
+ap.add_argument("--stagger-ms", type=float, default=0.0, help="worker w starts its passes w x this many ms after worker 0 (are workers better off out of step?)")
 ap.add_argument("--json", action="store_true", help="one JSON line at the end: {workers: {ms_per_block, domains_equal}} (bench.py reads it)")
 args = ap.parse_args()
 if os.environ.get("PROBE_TORCH") == "1":                        # what bench.py's process has done before its fs leg
@@ -60,6 +61,8 @@ for W in [int(x) for x in args.workers.split(",")]:
 
     def work(w):
         ctx, om, om3, om5, dna, pipe, seed = objs[w]
+        if args.stagger_ms > 0 and w > 0:
+            time.sleep(w * args.stagger_ms * 1e-3)
         for _ in range(args.passes):
             _, _, dm, _ = pipe.run_frameshift_domains(om3, om5, dna, arrays=True)
         ctx.synchronize()
