@@ -147,17 +147,16 @@ _FS_CPU_JOB = None          # (model path, list of DNA windows, their contexts):
 
 
 def fs_cpu_worker(span):
-    """The oracle's whole --fs pipeline -- the cascade and the 3-codon Forward parser of every DNA window on the SSE2 striped kernels
-    (oracle/sse: sse_filters.c, sse_fs.c), the stages behind the branch decision on the scalar restatement of
-    generic_*_frameshift.c (Backward parser, regions, 5-codon Forward / Backward / decoding / optimal accuracy / null2, traceback,
-    hits) -- over windows [lo, hi) of the job (a forked worker: no GPU state)."""
+    """The oracle's whole --fs pipeline -- the cascade and both 3-codon parsers on the SSE2 striped kernels (oracle/sse: sse_filters.c,
+    sse_fs.c), the envelope stage on the scalar restatement of generic_*_frameshift.c (5-codon Forward / Backward / decoding / optimal
+    accuracy / null2, traceback, hits) -- over windows [lo, hi) of the job (a forked worker: no GPU state)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as ol
     path, seqs, ctxs = _FS_CPU_JOB
     lo, hi = span
     L_ = ol.lib()
     L_.bo_pipeline_use_sse(1)
-    L_.bo_fs_use_sse(1)                                          # the 3-codon Forward parser of every DNA window: striped, probability space (oracle/sse/sse_fs.c)
+    L_.bo_fs_use_sse(1)                                          # both 3-codon parsers: striped, probability space (oracle/sse/sse_fs.c)
     model = ol.Model(path, 0)
     model.fs(3); model.fs(5)                                     # profile construction is not part of the scoring loop
     t0 = time.perf_counter()
@@ -171,9 +170,9 @@ def fs_cpu_worker(span):
 def fs_cpu_baseline(path, seqs, ctxs, what, probe=None, budget_s=12.0, min_per_s=0.0):
     """cpu_baseline of an --fs leg, BEFORE any GPU initialisation: every usable core scores its own slice of <seqs> through the
     oracle's --fs pipeline (fs_cpu_worker); the sample is sized from a one-thread probe so that the whole thing takes about
-    <budget_s> seconds.  kind "port": the cascade and the per-window 3-codon Forward parser are SSE2 striped restatements of impl_sse
-    (fwdback_fs.c:97-533 in probability space); the stages that only frameshift-branch windows reach are the SCALAR restatement of
-    generic_*_frameshift.c (the reference runs those striped too: it would be faster than this figure on those windows)."""
+    <budget_s> seconds.  kind "port": the cascade and the 3-codon parsers are SSE2 striped restatements of impl_sse (fwdback_fs.c:97-533,
+    :565-1050 in probability space); the 5-codon envelope stage is the SCALAR restatement of generic_*_frameshift.c (the reference runs
+    that striped too: it would be faster than this figure on the envelopes)."""
     import multiprocessing as mp
     global _FS_CPU_JOB
     _FS_CPU_JOB = (path, seqs, ctxs)
@@ -192,9 +191,9 @@ def fs_cpu_baseline(path, seqs, ctxs, what, probe=None, budget_s=12.0, min_per_s
     busy = max(o[0] for o in outs)
     _FS_CPU_JOB = None
     return {"value": sum(o[1] for o in outs) / busy, "unit": "residues/s", "cores": cores, "kind": "port",
-            "label": "the oracle's --fs pipeline: SSE2 striped restatements of impl_sse's cascade and of p7_ForwardParser_Frameshift_3Codons (probability space, "
-                     "every DNA window) + SCALAR restatement of generic_*_frameshift.c for the stages behind the branch decision (the reference runs those "
-                     "striped too, impl_sse/fwdback_fs.c; it cannot be built here)",
+            "label": "the oracle's --fs pipeline: SSE2 striped restatements of impl_sse's cascade and of the 3-codon frameshift parsers (probability space) + "
+                     "SCALAR restatement of generic_*_frameshift.c for the 5-codon envelope stage (the reference runs that striped too, "
+                     "impl_sse/fwdback_fs.c:2054-; it cannot be built here)",
             "sample": "%d of %d %s, %d processes, %.1f s scoring (%.1f s wall); %d DNA windows, %d domains"
                       % (covered, n, what, cores, busy, wall, sum(o[2] for o in outs), sum(o[3] for o in outs)),
             "one_thread": {"value": nres1 / dt1, "sample": "%d %s, %.1f s" % (probe, what, dt1)}}
@@ -1128,7 +1127,7 @@ def compact_line(out):
                    "fast_ms": _r(g(fs, "fast", "ms_per_pass")), "domains": fs.get("domains"),
                    "fast_identical": g(fs, "fast", "domains_identical_to_strict_mode")}
         if fs.get("cpu_baseline"):
-            c["fs"]["cpu_baseline"] = {"value": _r(g(fs, "cpu_baseline", "value")), "cores": g(fs, "cpu_baseline", "cores"), "kind": "port: SSE2 cascade + SSE2 fs3 Forward + scalar generic fs"}
+            c["fs"]["cpu_baseline"] = {"value": _r(g(fs, "cpu_baseline", "value")), "cores": g(fs, "cpu_baseline", "cores"), "kind": "port: SSE2 cascade + SSE2 fs3 parsers + scalar fs5 envelopes"}
         if fs.get("n_gpus"):
             c["fs"] = {"ms_per_pass": _r(fs.get("ms_per_pass")), "residues_per_s": _r(fs.get("residues_per_s")), "n_gpus": fs.get("n_gpus"),
                        "domains_equal": fs.get("domains_equal_to_single_rank_search"), "counters_equal": fs.get("counters_equal_to_single_rank_search")}

@@ -276,6 +276,7 @@ int bo_gforward_parser_fs3(const uint8_t *dsq, int L, const bo_fs_profile *gm3, 
 int bo_gbackward_parser_fs3(const uint8_t *dsq, int L, const bo_fs_profile *gm3, bo_gmx *gx, float *ret_sc);           /* :1422 */
 /* ... through the kernel hook (oracle/sse/sse_hooks.c): the scalar log-space parser, or the SSE2 striped probability-space one (bo_fs_use_sse) */
 int bo_k_gforward_parser_fs3(const uint8_t *dsq, int L, const bo_fs_profile *gm3, bo_gmx *gx, float *ret_sc);
+int bo_k_gbackward_parser_fs3(const uint8_t *dsq, int L, const bo_fs_profile *gm3, bo_gmx *gx, float *ret_sc);
 int bo_gdecoding_fs(const bo_fs_profile *gm5, bo_gmx *fwd /* in: Forward; out: posteriors */, const bo_gmx *bck);       /* generic_decoding_frameshift.c:36 */
 int bo_goptacc_fs(const bo_fs_profile *gm5, const bo_gmx *pp, bo_gmx *oa, float *ret_e);                               /* generic_optacc_frameshift.c:53 */
 int bo_gnull2_fs(const bo_fs_profile *gm5, bo_gmx *pp /* row 0 is clobbered, as in the reference */, float *null2 /* Kp */);                                    /* generic_null2_frameshift.c:46 */

@@ -369,7 +369,7 @@ int bo_domaindef_fs(bo_pipeline *pli, bo_fs_profile *gm3, bo_fs_profile *gm5, bo
   float fsc, bsc;
   bo_fs_profile_reconfig_length(gm3, L / 3);
   bo_k_gforward_parser_fs3(wdsq, L, gm3, fx, &fsc);
-  if (bo_gbackward_parser_fs3(wdsq, L, gm3, bx, &bsc) == BO_ERANGE) { bo_gmx_free(fx); bo_gmx_free(bx); return BO_OK; }   /* p7_pipeline.c:1471 */
+  if (bo_k_gbackward_parser_fs3(wdsq, L, gm3, bx, &bsc) == BO_ERANGE) { bo_gmx_free(fx); bo_gmx_free(bx); return BO_OK; }   /* p7_pipeline.c:1471 */
   float *btot = calloc((size_t) L + 2, sizeof(float)), *etot = calloc((size_t) L + 2, sizeof(float)), *mocc = calloc((size_t) L + 2, sizeof(float));
   bo_fs_profile_reconfig_multihit(gm5, 100);                      /* the configuration bathsearch.c:797 starts with */
   bo_gdomain_decoding_fs(gm5, fx, bx, btot, etot, mocc);

@@ -62,6 +62,7 @@ typedef struct {
 bs_fsprofile *bs_fsprofile_create(const bo_fs_profile *gm3);
 void          bs_fsprofile_free(bs_fsprofile *so);
 int bs_fs3_forward_parser(const uint8_t *dsq, int L, bs_fsprofile *so, float *xmx_log /* (L+1) x 5, log space, or NULL */, float *ret_sc);
+int bs_fs3_backward_parser(const uint8_t *dsq, int L, bs_fsprofile *so, float *xmx_log /* (L+1) x 5, log space, or NULL */, float *ret_sc);   /* fwdback_fs.c:565 */
 /* the oracle's --fs pipeline (fs_pipeline.c, fs_domaindef.c) with the striped Forward parser in place of the scalar log-space one */
 void bo_fs_use_sse(int on);
 

@@ -46,3 +46,10 @@ int bo_k_gforward_parser_fs3(const uint8_t *dsq, int L, const bo_fs_profile *gm3
   if (!fs_cached || fs_cached->gm != gm3 || fs_cached->M != gm3->M) { bs_fsprofile_free(fs_cached); fs_cached = bs_fsprofile_create(gm3); }
   return bs_fs3_forward_parser(dsq, L, fs_cached, gx ? gx->xmx : NULL, ret_sc);
 }
+
+int bo_k_gbackward_parser_fs3(const uint8_t *dsq, int L, const bo_fs_profile *gm3, bo_gmx *gx, float *ret_sc)
+{
+  if (!fs_use_sse) return bo_gbackward_parser_fs3(dsq, L, gm3, gx, ret_sc);
+  if (!fs_cached || fs_cached->gm != gm3 || fs_cached->M != gm3->M) { bs_fsprofile_free(fs_cached); fs_cached = bs_fsprofile_create(gm3); }
+  return bs_fs3_backward_parser(dsq, L, fs_cached, gx ? gx->xmx : NULL, ret_sc);
+}

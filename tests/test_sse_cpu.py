@@ -132,6 +132,8 @@ def test_fs3_forward_parser_striped_probability_space(name, idx):
     L_.bs_fs3_forward_parser.restype = C.c_int
     L_.bs_fs3_forward_parser.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]
     L_.bs_fsprofile_free.argtypes = [C.c_void_p]
+    L_.bs_fs3_backward_parser.restype = C.c_int
+    L_.bs_fs3_backward_parser.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]
     so = L_.bs_fsprofile_create(gm3)
     assert so
     rng = np.random.default_rng(11 + idx)
@@ -164,7 +166,23 @@ def test_fs3_forward_parser_striped_probability_space(name, idx):
         table_sc = f.value
         L_.bo_flogsum_set_exact(1); L_.bo_gforward_parser_fs3(d, L, gm3, gx, C.byref(f)); L_.bo_flogsum_set_exact(0)
         exact_sc = f.value
+        # ... and the Backward parser: score (= Forward's, up to the arithmetic) and rows against the exact-log-sum oracle
+        L_.bo_flogsum_set_exact(1)
+        b_st = L_.bo_gbackward_parser_fs3(d, L, gm3, gx, C.byref(f))
+        L_.bo_flogsum_set_exact(0)
+        b_exact = f.value
+        brow_o = np.ctypeslib.as_array(gx.contents.xmx, shape=((L + 1) * 5,)).copy()
         L_.bo_gmx_free(gx)
+        brow = np.zeros((L + 1) * 5, np.float32)
+        h = C.c_float()
+        bst = L_.bs_fs3_backward_parser(C.cast(d, C.c_void_p), L, so, brow.ctypes.data, C.byref(h))
+        if b_st == 0 and np.isfinite(b_exact):
+            assert bst == 0 and abs(h.value - b_exact) <= 1e-3 + 1e-4 * abs(b_exact), (L, h.value, b_exact)
+            assert abs(h.value - g.value) <= 2e-3 + 2e-4 * abs(g.value) or not np.isfinite(exact_sc)        # Forward == Backward
+            o2, s2 = brow_o.reshape(L + 1, 5), brow.reshape(L + 1, 5)
+            top = np.where(np.isfinite(o2), o2, -np.inf).max(axis=1, keepdims=True)
+            live = np.isfinite(o2) & (o2 > top - 40.0)                                   # within 40 nats of the row's largest value: what a posterior can see
+            assert np.all(np.abs(s2[live] - o2[live]) <= 2e-3 + 2e-4 * np.abs(o2[live])), (L, float(np.abs(s2[live] - o2[live]).max()))
         if not np.isfinite(exact_sc):
             assert st == ERANGE or not np.isfinite(g.value)
             continue
@@ -204,3 +222,14 @@ def test_fs_pipeline_on_the_striped_parser_finds_the_same_windows():
         assert abs(a.fwdsc - b.fwdsc) <= 1e-2 + 1e-4 * abs(a.fwdsc)
         flips += a.branch != b.branch
     assert flips <= 1
+    # ... and through domain definition (both parsers striped, their rows read by the log-space domain decoding): the same domains
+    _, _, _, dm0, pd0, sk0 = model.run_pipeline_fsdom(wins)
+    L_.bo_fs_use_sse(1)
+    try:
+        _, _, _, dm1, pd1, sk1 = model.run_pipeline_fsdom(wins)
+    finally:
+        L_.bo_fs_use_sse(0)
+    key = lambda d: (d.ienv, d.jenv, d.iali, d.jali, d.ihmm, d.jhmm)
+    assert len(dm0) == len(dm1) >= 3 and sk0 == sk1
+    assert sum(key(a) == key(b) for a, b in zip(dm0, dm1)) >= len(dm0) - 1          # (an envelope end may move where a posterior sits on a threshold)
+    assert all(abs(a.bitscore - b.bitscore) <= 0.05 for a, b in zip(dm0, dm1) if key(a) == key(b))
