@@ -91,3 +91,61 @@ def test_remote_hits_outside_the_search_are_refused():
     L.bath_tophits_destroy(th)
     lo, hi = bd.shard_range(10, 0, 0)                                                # world 0: an empty share, no SIGFPE
     assert (lo, hi) == (0, 0)
+
+
+def test_damaged_hit_streams_never_crash_the_reader():
+    """A stream that crossed a process boundary is untrusted input: 3000 random corruptions of a valid stream (bytes flipped, the
+    stream cut, counts and sizes overwritten, garbage appended) through bath_hits_stream_size / bath_hits_deserialize /
+    bath_tophits_add_serialized.  Every call must return -- OK with a self-consistent result, or an error code -- and nothing may be
+    added to the hit list by a call that reports an error.  (tools/san_cpu.sh runs this under ASan + UBSan.)"""
+    import ctypes as C
+    import numpy as np
+    rng = np.random.default_rng(99)
+    doms = []
+    for w in range(6):
+        d = ba.FsDomain(); d.window = w % 4; d.reported = 1; d.iali = 10 + w; d.jali = 100 + w; d.lnP = -30.0 - w; d.bitscore = 40.0 + w
+        d.cigar = "%dM%dI%dM" % (10 + w, 1 + w % 3, 20 + w)
+        doms.append(d)
+    good = ba.HitArray.from_domains(doms).to_bytes()
+    L = ba.lib()
+    names = (C.c_char_p * 4)(b"a", b"b", b"c", b"d")
+    lens = (C.c_int64 * 4)(1000, 1000, 1000, 1000)
+    n_ok = n_err = 0
+    for trial in range(3000):
+        b = bytearray(good)
+        kind = trial % 6
+        if kind == 0:
+            for _ in range(int(rng.integers(1, 6))):
+                b[int(rng.integers(0, len(b)))] = int(rng.integers(0, 256))
+        elif kind == 1:
+            b = b[:int(rng.integers(0, len(b)))]
+        elif kind == 2:
+            b[8:16] = int(rng.integers(0, 2 ** 40)).to_bytes(8, "big")                      # the hit count
+        elif kind == 3:
+            p = 16
+            b[p:p + 4] = int(rng.integers(0, 2 ** 31)).to_bytes(4, "big")                   # the first record's size
+        elif kind == 4:
+            b += bytes(rng.integers(0, 256, size=int(rng.integers(1, 40)), dtype=np.uint8))
+        else:
+            p = int(rng.integers(16, len(b) - 4)); b[p:p + 4] = b"\\xff\\xff\\xff\\xff"
+        raw = bytes(b)
+        buf = (C.c_uint8 * max(len(raw), 1)).from_buffer_copy(raw if raw else b"\\0")       # an exact-size heap copy: an overrun is ASan's to catch
+        size = L.bath_hits_stream_size(C.addressof(buf), len(raw))
+        assert size == -1 or 16 <= size <= len(raw)
+        h = C.c_void_p()
+        st = L.bath_hits_deserialize(C.addressof(buf), len(raw), C.byref(h))
+        if st == ba.OK:
+            assert h.value and 0 <= L.bath_hits_count(h) <= 6 + 40
+            L.bath_hits_destroy(h)
+        else:
+            assert not h.value
+        th = L.bath_tophits_create()
+        st2 = L.bath_tophits_add_serialized(th, C.addressof(buf), len(raw), 0, 4, 0, names, None, None, lens)
+        if st2 == ba.OK:
+            n_ok += 1
+            assert L.bath_tophits_count(th) <= 6 + 40
+        else:
+            n_err += 1
+            assert L.bath_tophits_count(th) == 0
+        L.bath_tophits_destroy(th)
+    assert n_err > 1500 and n_ok > 0                                     # most corruptions are caught; flips inside float fields are still valid streams

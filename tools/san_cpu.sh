@@ -35,6 +35,6 @@ print("NOT REPORTED")
 PY
   echo "# 2. the CPU-tier tests that reach host code, against the instrumented library"
   python3 -m pytest tests/test_abi_cpu.py tests/test_tophits_cpu.py tests/test_multi_gpu_c_cpu.py tests/test_ensemble_cpu.py tests/test_alidisplay_cpu.py \
-      tests/test_options_cpu.py tests/test_easel_pieces_cpu.py tests/test_dist_cpu.py -q -p no:cacheprovider 2>&1 | tail -15
+      tests/test_options_cpu.py tests/test_easel_pieces_cpu.py tests/test_dist_cpu.py tests/test_sse_cpu.py -q -p no:cacheprovider 2>&1 | tail -15
 } > "$OUT" 2>&1
 cat "$OUT"
