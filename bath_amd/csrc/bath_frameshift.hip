@@ -1769,9 +1769,8 @@ static int upload_offsets(bath_hip_ctx *ctx, DevBuf &buf, const int64_t *off, in
 // queued on ctx->stream; jobs[i] is what launch i passes to its kernel
 static int fs_schedule(bath_hip_ctx *ctx, const bath_hip_seqs *dna, int k, FsJobs *jobs) {
   const int64_t n = dna->n;
-  std::vector<int32_t> order((size_t)n);
-  for (int64_t i = 0; i < n; i++) order[(size_t)i] = (int32_t)i;
-  std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return dna->h_len[(size_t)a] > dna->h_len[(size_t)b]; });
+  std::vector<int32_t> order;
+  fs_order_by_length_desc(dna->h_len.data(), n, &order);
   if (k > 64) { ctx->set_error("fs_schedule: more than 64 job counters"); return BATH_EINVAL; }
   DevBuf &b = ctx->scratch[40];                                    // its own slot: the cascade's local-composition terms live in 36
   BATH_HIP_TRY(ctx, b.reserve(256 + (size_t)n * sizeof(int32_t) + 64));

@@ -1030,8 +1030,8 @@ __global__ __launch_bounds__(THREADS) void fs5_fwd_chain_kernel(SeqView dna, FsD
 // bst[b] .. bst[b+1]-1 of the list sorted by decreasing length.  BATH_HIP_FS_BATCH=w: uniform batches of w (A/B runs).
 static int chain_batches(bath_hip_ctx *ctx, hipStream_t stream, const bath_hip_seqs *dna, double t0, double dt, int wmax, DevBuf &buf, int stage_slot, int *nbat_out, int cu_share = 1) {
   const int64_t n = dna->n;
-  std::vector<int> ls(dna->h_len.begin(), dna->h_len.begin() + n);
-  std::sort(ls.begin(), ls.end(), [](int a, int b) { return a > b; });
+  std::vector<int32_t> ls;
+  fs_order_by_length_desc(dna->h_len.data(), n, nullptr, &ls);
   const int cus = std::max(1, (int)ctx->prop.multiProcessorCount / cu_share);      // <cu_share>: another chain kernel runs beside this one (blocks of the two do not share a CU's LDS)
   std::vector<int32_t> bst;
   auto batches = [&](double T, std::vector<int32_t> *out) -> int64_t {

@@ -38,6 +38,8 @@ namespace bath {
 namespace {
 
 constexpr int kMaxOrfs = 32768, kMaxHitWins = 65536, kMaxGroup = 1024;
+// BATH_HIP_FSW_MAX_GROUP=g (tests): groups of more than g ORFs send the block to the host path, so that the fallback runs on small inputs
+static int max_group() { static const int g = [] { const char *e = std::getenv("BATH_HIP_FSW_MAX_GROUP"); return e ? std::max(1, std::min(std::atoi(e), kMaxGroup)) : kMaxGroup; }(); return g; }
 struct Key { uint64_t hi, lo; };
 __device__ __forceinline__ bool key_less(const Key &a, const Key &b) { return a.hi < b.hi || (a.hi == b.hi && a.lo < b.lo); }
 
@@ -165,7 +167,7 @@ struct DnaWinDev { int32_t n, k, length; };
 
 // per ORF: the bounds of its (sequence, strand) group, and its window's place in the group's list ordered by start
 // (p7_hmmwindow_SortByStart; equal starts keep the ORFs' order)
-__global__ void fsw_group_kernel(FsOrfDev *__restrict__ orfs, int n, DnaWinDev *__restrict__ sorted, int *__restrict__ flags) {
+__global__ void fsw_group_kernel(FsOrfDev *__restrict__ orfs, int n, DnaWinDev *__restrict__ sorted, int *__restrict__ flags, int group_cap) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= n) return;
   const int64_t w = orfs[s].w;
@@ -173,7 +175,7 @@ __global__ void fsw_group_kernel(FsOrfDev *__restrict__ orfs, int n, DnaWinDev *
   int g0 = s, g1 = s + 1;
   while (g0 > 0 && orfs[g0 - 1].w == w && orfs[g0 - 1].strand == strand && s - g0 <= kMaxGroup) g0--;
   while (g1 < n && orfs[g1].w == w && orfs[g1].strand == strand && g1 - s <= kMaxGroup) g1++;
-  if (g1 - g0 > kMaxGroup) { atomicOr(flags, 1); return; }             // the host path takes such a block
+  if (g1 - g0 > group_cap) { atomicOr(flags, 1); return; }             // the host path takes such a block
   const int32_t my_n = orfs[s].dw_n;
   int r = 0;
   for (int b = g0; b < g1; b++) { const int32_t bn = orfs[b].dw_n; r += (bn < my_n || (bn == my_n && b < s)) ? 1 : 0; }
@@ -413,7 +415,7 @@ int fs_build_windows_device(bath_hip_ctx *ctx, const bath_hip_oprofile *om, cons
     hipLaunchKernelGGL(fsw_hits2_kernel, dim3(gh), dim3(T), 0, s, d_win, nhw, d_slot, d_best, d_orf);
   }
   hipLaunchKernelGGL(fsw_orf_kernel, dim3(gn), dim3(T), 0, s, d_orf, n, d_win, dna->d_len, p);
-  hipLaunchKernelGGL(fsw_group_kernel, dim3(gn), dim3(T), 0, s, d_orf, n, d_wl, d_hdr + 1);
+  hipLaunchKernelGGL(fsw_group_kernel, dim3(gn), dim3(T), 0, s, d_orf, n, d_wl, d_hdr + 1, max_group());
   hipLaunchKernelGGL(fsw_fuse_kernel, dim3(gn), dim3(T), 0, s, d_orf, n, d_wl, d_cnt, om->max_length);
   hipLaunchKernelGGL(fsw_scan_kernel, dim3(1), dim3(1024), 0, s, d_cnt, n, d_base, d_hdr);
   hipLaunchKernelGGL(fsw_summary_kernel, dim3(gn), dim3(T), 0, s, d_orf, n, d_wl, d_cnt, d_base, dna->d_off, dna->d_len, p, d_out, d_desc, d_grp);

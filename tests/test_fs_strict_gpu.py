@@ -241,3 +241,10 @@ def test_speculative_backward_rows_are_the_parsers_rows():
     Forward parser of all of them, its rows copied into place for the domain stage, which runs the parser for the other windows only.
     Forced for a handful of windows (BATH_HIP_FS_SPEC_FORCE=1, K = 5): every strict pipeline test must still hold bit for bit."""
     _rerun({"BATH_HIP_FS_SPEC_FORCE": "1", "BATH_HIP_FS_SPEC_K": "5"}, "strict_pipeline_is_exact or planted_frameshifted or cascade_lanes or recorded_fs")
+
+
+def test_blocks_the_device_window_path_refuses_fall_back_to_the_host_path():
+    """bath_fs_windows.hip hands a block back (BATH_ENORESULT) when a (sequence, strand) group has more ORFs than it serialises in one
+    thread; the pipeline then fetches the survivors and runs the host path.  BATH_HIP_FSW_MAX_GROUP=1 makes every input with two
+    surviving ORFs on one strand such a block: the strict pipeline tests must hold through the fallback."""
+    _rerun({"BATH_HIP_FSW_MAX_GROUP": "1"}, "strict_pipeline_is_exact or planted_frameshifted or cascade_lanes or recorded_fs")
