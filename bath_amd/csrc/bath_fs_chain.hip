@@ -43,6 +43,29 @@ constexpr int bwd_chain_threads(int C) { return chain_compact(C) ? 512 : chain_t
 // host memory over PCIe) have been acknowledged.  This barrier waits for the LDS operations alone.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// While the chain wave runs alone, the waves 1..3 of the block -- one on each of the CU's other SIMDs -- do not park at the barrier
+// but poll a word of LDS between sleeps (kChainAwakeWaves; the block is launched with at least four waves for this, whatever the
+// number of windows it holds).  A CU whose other SIMDs hold only parked waves issues the chain's dependent instructions 5-30 %
+// slower, by an amount that differs from block to block and from launch to launch (tools/lsbench7.hip: 198-267 clocks per Forward
+// node, median 213, beside parked waves; 199-203 beside pollers that sleep 64 clocks per poll; 226-231 beside waves that spin on
+// the VALU).  The word counts row pairs: the chain wave stores the pair's number when its serial part is done.
+#ifndef BATH_CHAIN_KEEPALIVE
+#define BATH_CHAIN_KEEPALIVE 1
+#endif
+constexpr int kChainAwakeWaves = BATH_CHAIN_KEEPALIVE ? 4 : 1;   // the chain wave and its pollers
+__device__ __forceinline__ void chain_keepalive(const int *flag, int pair) {
+#if BATH_CHAIN_KEEPALIVE
+  const volatile int *f = flag;
+  while (*f != pair) __builtin_amdgcn_s_sleep(1);
+#endif
+}
+__device__ __forceinline__ void chain_done(int *flag, int pair) {
+#if BATH_CHAIN_KEEPALIVE
+  *reinterpret_cast<volatile int *>(flag) = pair;
+#endif
+}
+__device__ __forceinline__ bool chain_poller(int wv) { return wv >= 1 && wv < kChainAwakeWaves; }
+
 // staged rows: [wave][row of the pair][stride]; stride odd, so that the chain lanes (one row each) read different banks
 __host__ __device__ inline int fs_chain_stride(int C) { return C * 64 + 1; }
 
@@ -59,6 +82,19 @@ __host__ __device__ inline int fs_chain_stride(int C) { return C * 64 + 1; }
 //   tp        LDS byte address of {tMD, tDD}(k+1)
 //   set A     M_k, tMD(k), tDD(k) on entry; the asm covers TWO nodes and leaves set A for node k+2
 // ---------------------------------------------------------------------------------------------------------------------------
+// nodes per trip of the chain loops (pairs of nodes repeated)
+#ifndef BATH_CHAIN_UNROLL
+#define BATH_CHAIN_UNROLL 16
+#endif
+#if BATH_CHAIN_UNROLL == 8
+#define BATH_CHAIN_REPEAT(P) P P P P
+#elif BATH_CHAIN_UNROLL == 4
+#define BATH_CHAIN_REPEAT(P) P P
+#elif BATH_CHAIN_UNROLL == 16
+#define BATH_CHAIN_REPEAT(P) P P P P P P P P
+#else
+#define BATH_CHAIN_REPEAT(P) P
+#endif
 #define BATH_LS_INDEX(a, x, y)                      \
   "v_sub_f32 " a ", " x ", " y "\n\t"               \
   "v_min_f32_e64 " a ", |" a "|, %[c15]\n\t"        \
@@ -96,10 +132,23 @@ struct FwdChainRegs { float e, d, Mk, tx, ty; unsigned st, tp; };
 __device__ __forceinline__ void fwd_chain_nodes(FwdChainRegs &r, int n, unsigned tbl, float c15) {
   float Mn, ux, uy, a1, a2, u, w, mx1, mxd, x;
   int k = 0;
+  // (sixteen nodes per trip: the chain's dependency runs through the loop's own instructions -- the counter, the branch, the waits
+  // either side of the asm block are issued in order between a node's last add and the next node's first subtraction: ~25 clocks
+  // per node at two nodes per trip.  M = 1024, clocks per node at 2 / 16 nodes per trip: Forward 224 -> 200, B sum 120 -> 92,
+  // D chain 250 -> 212; profiles/r06_chain_loops_ab.txt)
+#define BATH_FWD_PAIR BATH_FWD_NODE("%[Mk]", "%[tx]", "%[ty]", "%[Mn]", "%[ux]", "%[uy]") BATH_FWD_NODE("%[Mn]", "%[ux]", "%[uy]", "%[Mk]", "%[tx]", "%[ty]")
+  for (; k + BATH_CHAIN_UNROLL <= n; k += BATH_CHAIN_UNROLL)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\t"
+                 BATH_CHAIN_REPEAT(BATH_FWD_PAIR)
+                 "s_waitcnt lgkmcnt(0)"
+                 : [e] "+v"(r.e), [d] "+v"(r.d), [Mk] "+v"(r.Mk), [tx] "+v"(r.tx), [ty] "+v"(r.ty), [st] "+v"(r.st), [tp] "+v"(r.tp),
+                   [Mn] "=&v"(Mn), [ux] "=&v"(ux), [uy] "=&v"(uy), [a1] "=&v"(a1), [a2] "=&v"(a2), [u] "=&v"(u), [w] "=&v"(w),
+                   [mx1] "=&v"(mx1), [mxd] "=&v"(mxd), [x] "=&v"(x)
+                 : [tbl] "s"(tbl), [c15] "s"(c15)
+                 : "memory");
   for (; k + 2 <= n; k += 2)
     asm volatile("s_waitcnt lgkmcnt(0)\n\t"
-                 BATH_FWD_NODE("%[Mk]", "%[tx]", "%[ty]", "%[Mn]", "%[ux]", "%[uy]")
-                 BATH_FWD_NODE("%[Mn]", "%[ux]", "%[uy]", "%[Mk]", "%[tx]", "%[ty]")
+                 BATH_FWD_PAIR
                  "s_waitcnt lgkmcnt(0)"
                  : [e] "+v"(r.e), [d] "+v"(r.d), [Mk] "+v"(r.Mk), [tx] "+v"(r.tx), [ty] "+v"(r.ty), [st] "+v"(r.st), [tp] "+v"(r.tp),
                    [Mn] "=&v"(Mn), [ux] "=&v"(ux), [uy] "=&v"(uy), [a1] "=&v"(a1), [a2] "=&v"(a2), [u] "=&v"(u), [w] "=&v"(w),
@@ -143,6 +192,13 @@ __device__ __forceinline__ float bwd_bsum_nodes(float b, float v, float sN, floa
   float vn, a1, mx;
   int k = 0;
 #define BATH_BSUM_PAIR(TS, TS2)                                                                                                          \
+  for (; k + BATH_CHAIN_UNROLL <= n; k += BATH_CHAIN_UNROLL)                                                                            \
+    asm volatile("s_waitcnt lgkmcnt(0)\n\t"                                                                                             \
+                 BATH_CHAIN_REPEAT(BATH_BSUM_NODE("%[v]", "%[vn]", TS, TS2) BATH_BSUM_NODE("%[vn]", "%[v]", TS, TS2))                    \
+                 "s_waitcnt lgkmcnt(0)"                                                                                                 \
+                 : [b] "+v"(b), [v] "+v"(v), [sN] "+v"(sN), [tN] "+v"(tN), [st] "+v"(st), [tp] "+v"(tp), [vn] "=&v"(vn), [a1] "=&v"(a1), [mx] "=&v"(mx) \
+                 : [tbl] "s"(tbl), [c15] "s"(c15)                                                                                       \
+                 : "memory");                                                                                                           \
   for (; k + 2 <= n; k += 2)                                                                                                            \
     asm volatile("s_waitcnt lgkmcnt(0)\n\t"                                                                                             \
                  BATH_BSUM_NODE("%[v]", "%[vn]", TS, TS2)                                                                               \
@@ -194,6 +250,17 @@ __device__ __forceinline__ void bwd_d_nodes(BwdChainRegs &r, float xE, unsigned 
   float ivq, ux, uy, u, bs, p1, p2, a1, mx1, x;
   int k = 0;
 #define BATH_BWD_D_PAIR(NTS)                                                                                                             \
+  for (; k + BATH_CHAIN_UNROLL <= n; k += BATH_CHAIN_UNROLL)                                                                            \
+    asm volatile("s_waitcnt lgkmcnt(0)\n\t"                                                                                             \
+                 BATH_CHAIN_REPEAT(BATH_BWD_D_NODE("%[ivn]", "%[tx]", "%[ty]", "%[ivq]", "%[ux]", "%[uy]", NTS)                          \
+                                   BATH_BWD_D_NODE("%[ivk]", "%[ux]", "%[uy]", "%[ivk]", "%[tx]", "%[ty]", NTS)                          \
+                                   "v_mov_b32 %[ivn], %[ivq]\n\t")                                                                      \
+                 "s_waitcnt lgkmcnt(0)"                                                                                                 \
+                 : [dn] "+v"(r.dn), [ivn] "+v"(r.ivn), [ivk] "+v"(r.ivk), [tx] "+v"(r.tx), [ty] "+v"(r.ty), [st] "+v"(r.st), [tp] "+v"(r.tp), \
+                   [ivq] "=&v"(ivq), [ux] "=&v"(ux), [uy] "=&v"(uy), [u] "=&v"(u), [bs] "=&v"(bs), [p1] "=&v"(p1), [p2] "=&v"(p2),       \
+                   [a1] "=&v"(a1), [mx1] "=&v"(mx1), [x] "=&v"(x)                                                                       \
+                 : [xE] "v"(xE), [mid] "s"(mid), [tbl] "s"(tbl), [c15] "s"(c15)                                                         \
+                 : "memory");                                                                                                           \
   for (; k + 2 <= n; k += 2)                                                                                                            \
     asm volatile("s_waitcnt lgkmcnt(0)\n\t"                                                                                             \
                  BATH_BWD_D_NODE("%[ivn]", "%[tx]", "%[ty]", "%[ivq]", "%[ux]", "%[uy]", NTS)                                           \
@@ -229,16 +296,18 @@ __device__ __forceinline__ unsigned lds_addr(const void *p) { return (unsigned)(
 // ---------------------------------------------------------------------------------------------------------------------------
 template <int C>
 __global__ __launch_bounds__(chain_threads(C)) void fs3_fwd_chain_kernel(SeqView dna, FsDev p, const float *__restrict__ loop_tab, const float *__restrict__ move_tab,
-                                                             float tEL, float tEM, float *__restrict__ sc, float *__restrict__ xmx, const int64_t *__restrict__ xmx_off, FsJobs jobs) {
+                                                             float tEL, float tEM, float *__restrict__ sc, float *__restrict__ xmx, const int64_t *__restrict__ xmx_off, FsJobs jobs,
+                                                             int W /* windows per block: the block has max(W, kChainAwakeWaves) waves */) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   float *s_tbl = reinterpret_cast<float *>(lds);
   float *s_tf = s_tbl + kLogsumTbl;
   const int M = p.M;
-  const int W = blockDim.x >> 6;
   const int stride = fs_chain_stride(C);
   float *s_stage = s_tf + (M + 2) * 8;                          // [W][2][stride]
   float *s_e = s_stage + (size_t)W * 2 * stride;                // [W][2] E(i) of the pair's rows
-  int *s_ctl = reinterpret_cast<int *>(s_e + 2 * kChainMaxWaves);   // [0]: first job of the block's batch
+  int *s_ctl = reinterpret_cast<int *>(s_e + 2 * kChainMaxWaves);   // [0]: first job of the block's batch; [4]: the row pair whose serial part is done
+  if (threadIdx.x == 0) s_ctl[4] = 0;
+  int pair = 0;
   fs_load_logsum_table(s_tbl, p.logsum);
   for (int i = threadIdx.x; i < (M + 2) * 8; i += blockDim.x) s_tf[i] = p.tf[i];
   __syncthreads();
@@ -252,7 +321,7 @@ __global__ __launch_bounds__(chain_threads(C)) void fs3_fwd_chain_kernel(SeqView
     __syncthreads();
     const int64_t base = s_ctl[0];
     if (base >= dna.n) break;
-    const int64_t job = (base + wv < dna.n) ? (int64_t)jobs.order[base + wv] : (int64_t)-1;
+    const int64_t job = (wv < W && base + wv < dna.n) ? (int64_t)jobs.order[base + wv] : (int64_t)-1;
     const int Lmax = dna.len[jobs.order[base]];                 // the batch's longest window (the list is sorted by length)
     const int L = job >= 0 ? dna.len[job] : 0;
     const uint8_t *d = job >= 0 ? dna.data + dna.off[job] : dna.data;
@@ -269,6 +338,8 @@ __global__ __launch_bounds__(chain_threads(C)) void fs3_fwd_chain_kernel(SeqView
       for (int i = 0; i < 2; i++) { xo[i * 5 + 0] = -INFINITY; xo[i * 5 + 1] = 0.f; xo[i * 5 + 2] = -INFINITY; xo[i * 5 + 3] = tNM; xo[i * 5 + 4] = -INFINITY; }
     auto nuc = [&](int i) -> int { return (i >= 1 && i <= L) ? ((d[i - 1] < 4) ? (int)d[i - 1] : 338) : 338; };   // x_i; 338 = p7P_MAXCODONS3 (degenerate / outside)
     for (int i = 2; i <= Lmax; i += 2) {
+      ++pair;
+      if (wv >= W) { lds_barrier(); chain_keepalive(s_ctl + 4, pair); lds_barrier(); continue; }   // a poller without a window
       const bool actA = job >= 0 && L >= 3 && i <= L, actB = job >= 0 && L >= 3 && i + 1 <= L;
       // ---- emission rows of the pair: codon lengths 2, 3, 4 ending at x_i (row A) and x_{i+1} (row B)
       const int xa = nuc(i), wa = nuc(i - 1), va = nuc(i - 2), ua = nuc(i - 3), xb = nuc(i + 1);
@@ -332,6 +403,7 @@ __global__ __launch_bounds__(chain_threads(C)) void fs3_fwd_chain_kernel(SeqView
         ech = r.e; dch = r.d;
         s_e[lane] = ech;
       }
+      if (wv == 0) chain_done(s_ctl + 4, pair); else if (chain_poller(wv)) chain_keepalive(s_ctl + 4, pair);
       lds_barrier();
       // ---- 3. D and E back to the window's wave; special states of both rows (:592-603)
       float DA[C], DB[C];
@@ -391,7 +463,9 @@ __global__ __launch_bounds__(1024) void fs3_fwd_chain_half_kernel(SeqView dna, F
   constexpr int stride = CH * 32 + 1;
   float *s_stage = s_tf + (M + 2) * 8;                          // [W][2][stride]
   float *s_b = s_stage + (size_t)W * 2 * stride;                // [W][2] B(i) of the pair's rows, from the chain lanes
-  int *s_ctl = reinterpret_cast<int *>(s_b + 2 * W);
+  int *s_ctl = reinterpret_cast<int *>(s_b + 2 * W);         // [0]: the block's batch; [4]: the row pair whose serial part is done
+  if (threadIdx.x == 0) s_ctl[4] = 0;
+  int pair = 0;
   fs_load_logsum_table(s_tbl, p.logsum);
   for (int i = threadIdx.x; i < (M + 2) * 8; i += blockDim.x) s_tf[i] = p.tf[i];
   __syncthreads();
@@ -437,7 +511,8 @@ __global__ __launch_bounds__(1024) void fs3_fwd_chain_half_kernel(SeqView dna, F
     auto nuc = [&](int i) -> int { return (i >= 1 && i <= L) ? ((d[i - 1] < 4) ? (int)d[i - 1] : 338) : 338; };
     __syncthreads();
     for (int i = 2; i <= Lmax; i += 2) {
-      if (wave_idle) { lds_barrier(); lds_barrier(); continue; }
+      ++pair;
+      if (wave_idle) { lds_barrier(); if (chain_poller(wv)) chain_keepalive(s_ctl + 4, pair); lds_barrier(); continue; }
       const bool actB = job >= 0 && L >= 3 && i + 1 <= L;
       const float B2 = s_b[win * 2 + 0], B1 = s_b[win * 2 + 1];   // B(i-2), B(i-1): the previous pair's rows
       const int xa = nuc(i), wa = nuc(i - 1), va = nuc(i - 2), ua = nuc(i - 3), xb = nuc(i + 1);
@@ -508,7 +583,8 @@ __global__ __launch_bounds__(1024) void fs3_fwd_chain_half_kernel(SeqView dna, F
           if (i + 1 <= cL) { cfin3 = cfin2; cfin2 = cfin1; cfin1 = cB; }
           if (i == cL || i + 1 == cL) sc[cjob] = LS(cfin1, LS(cfin2 + ctNL, cfin3 + ctNL)) + ctNM;
         }
-      }
+        chain_done(s_ctl + 4, pair);
+      } else if (chain_poller(wv)) chain_keepalive(s_ctl + 4, pair);
       lds_barrier();
       float DA[CH], DB[CH];
 #pragma unroll
@@ -545,17 +621,19 @@ __global__ __launch_bounds__(1024) void fs3_fwd_chain_half_kernel(SeqView dna, F
 template <int C>
 __global__ __launch_bounds__(bwd_chain_threads(C)) void fs3_bwd_chain_kernel(SeqView dna, FsDev p, const float *__restrict__ loop_tab, const float *__restrict__ move_tab,
                                                              float tEL, float tEM, float *__restrict__ sc, float *__restrict__ xmx, const int64_t *__restrict__ xmx_off, FsJobs jobs,
-                                                             const int32_t *__restrict__ bstart /* batches of the sorted list, chain_batches */, int nb) {
+                                                             const int32_t *__restrict__ bstart /* batches of the sorted list, chain_batches */, int nb,
+                                                             int W /* windows per block: the block has max(W, kChainAwakeWaves) waves */) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   constexpr bool kCompact = chain_compact(C);
   float *s_tbl = reinterpret_cast<float *>(lds);
   float *s_tb = s_tbl + kLogsumTbl;                             // kCompact: [(M + 3)][4] = {tDD(k), tDM(k), tBM(k-1), -}; else tb's [(M + 2)][8]
   const int M = p.M;
-  const int W = blockDim.x >> 6;
   const int stride = fs_chain_stride(C);
   float *s_stage = s_tb + (kCompact ? (M + 3) * 4 : (M + 2) * 8);   // [W][2][stride]: ivx(i,k) in, D(i,k) out
   float *s_e = s_stage + (size_t)W * 2 * stride;                // [W][2] E(i) of the pair's rows
-  int *s_ctl = reinterpret_cast<int *>(s_e + 2 * kChainMaxWaves);   // [0]: first job of the block's batch
+  int *s_ctl = reinterpret_cast<int *>(s_e + 2 * kChainMaxWaves);   // [0]: first job of the block's batch; [4]: the row pair whose serial part is done
+  if (threadIdx.x == 0) s_ctl[4] = 0;
+  int pair = 0;
   fs_load_logsum_table(s_tbl, p.logsum);
   if constexpr (kCompact) {
     for (int k = threadIdx.x; k < M + 3; k += blockDim.x) {
@@ -574,6 +652,9 @@ __global__ __launch_bounds__(bwd_chain_threads(C)) void fs3_bwd_chain_kernel(Seq
   // Lanes own their nodes in DESCENDING order (logical lane = 63 - physical lane), as in fs_bwd_kernel: "the lane holding the
   // next nodes" is then the physical lane below and the neighbour move is the same wave_shr1
   const int ll = 63 - lane;
+#ifdef BATH_CHAIN_CLOCK
+  long long dbgb_cyc = 0, dbgd_cyc = 0, dbgb_n = 0;
+#endif
 #define LS(a, b) flogsum<false>((a), (b), s_tbl)
   for (;;) {                                                    // batches dealt longest first, on request (see fs3_fwd_chain_half_kernel)
     if (threadIdx.x == 0) s_ctl[0] = (int)atomicAdd(jobs.counter, 1u);
@@ -607,7 +688,8 @@ __global__ __launch_bounds__(bwd_chain_threads(C)) void fs3_bwd_chain_kernel(Seq
     auto nuc = [&](int i) -> int { return (i >= 1 && i <= L) ? ((d[i - 1] < 4) ? (int)d[i - 1] : 338) : 338; };
     const int npairs = Lmax / 2 + 1;                            // rows Lmax .. 0 of the longest window
     for (int q = 0; q < npairs; q++) {
-      if (wave_idle) { lds_barrier(); lds_barrier(); continue; }
+      ++pair;
+      if (wave_idle) { lds_barrier(); if (chain_poller(wv)) chain_keepalive(s_ctl + 4, pair); lds_barrier(); continue; }
       const int iA = L - 2 * q, iB = iA - 1;                    // this window's rows of the pair; avail = 2q and 2q + 1 for every window
       const bool mainA = 2 * q >= 5, mainB = 2 * q + 1 >= 5;
       // codons that START at x_{i+1}: x = x_{i+1}, w = x_{i+2}, v = x_{i+3}, u = x_{i+4}; the last base is the most significant digit (:1539-1550)
@@ -637,8 +719,14 @@ __global__ __launch_bounds__(bwd_chain_threads(C)) void fs3_bwd_chain_kernel(Seq
         float *st = s_stage + (size_t)lane * stride;
         const int avail = 2 * q + cs, irow = cL - avail;
         // (the terms are read two nodes ahead of the chain: the slots M+1, M+2 of the row and of the transitions are inside the block's LDS)
+#ifdef BATH_CHAIN_CLOCK
+        const long long bc0 = clock64();
+#endif
         const float b = bwd_bsum_nodes<kCompact>(st[1] + *TBM(1), st[2] + *TBM(2), st[3], *TBM(3), lds_addr(st + 2), lds_addr(TBM(2)),
                                                  M - 1, lds_addr(s_tbl), 15.999f);
+#ifdef BATH_CHAIN_CLOCK
+        dbgb_cyc += clock64() - bc0; dbgb_n += M;
+#endif
         // N, J, C of row i+3: the other slot's row of two pairs ago (slot 0) or of the previous pair (slot 1)
         const float pN1 = __shfl_xor(hN1, 1, 64), pN2 = __shfl_xor(hN2, 1, 64), pJ1 = __shfl_xor(hJ1, 1, 64), pJ2 = __shfl_xor(hJ2, 1, 64);
         const float pC1 = __shfl_xor(hC1, 1, 64), pC2 = __shfl_xor(hC2, 1, 64);
@@ -651,7 +739,13 @@ __global__ __launch_bounds__(bwd_chain_threads(C)) void fs3_bwd_chain_kernel(Seq
         // D(i,k) = LS(LS(E, D(i,k+1) + tDD), ivx(i,k+1) + tDM); the rows L-3, L-4 pair E with the ivx term first (:1524-1526).
         // Log-sum is symmetric, so both are LS(LS(E, p1), p2) with the operands swapped: no branch in the loop
         BwdChainRegs r{-INFINITY, -INFINITY, st[M], TDD(M)[0], TDD(M)[1], lds_addr(st + M - 1), lds_addr(TDD(M - 1))};   // ivx(i,M), tDD(M), tDM(M)
+#ifdef BATH_CHAIN_CLOCK
+        const long long dc0 = clock64();
+#endif
         bwd_d_nodes<kCompact>(r, xE, __builtin_amdgcn_ballot_w64(mid), M, lds_addr(s_tbl), 15.999f);
+#ifdef BATH_CHAIN_CLOCK
+        dbgd_cyc += clock64() - dc0;
+#endif
         s_e[lane] = xE;
         const float partnerN = __shfl_xor(xN, 1, 64);
         if (clive && irow >= 0) {
@@ -667,6 +761,7 @@ __global__ __launch_bounds__(bwd_chain_threads(C)) void fs3_bwd_chain_kernel(Seq
         }
         hN2 = hN1; hN1 = xN; hJ2 = hJ1; hJ1 = xJ; hC2 = hC1; hC1 = xC;
       }
+      if (wv == 0) chain_done(s_ctl + 4, pair); else if (chain_poller(wv)) chain_keepalive(s_ctl + 4, pair);
       lds_barrier();
       // ---- 3. the cells of both rows (:1574-1600)
       const float EA = s_e[wv * 2 + 0], EB = s_e[wv * 2 + 1];
@@ -697,6 +792,9 @@ __global__ __launch_bounds__(bwd_chain_threads(C)) void fs3_bwd_chain_kernel(Seq
         for (int c = 0; c < C; c++) { R4[c] = R2[c]; R3[c] = R1[c]; R2[c] = MA[c]; R1[c] = MB[c]; J3[c] = J1[c]; J2[c] = IA[c]; J1[c] = IB[c]; }
       }
     }
+#ifdef BATH_CHAIN_CLOCK
+    if (wv == 0 && lane == 0 && blockIdx.x == 0 && dbgb_n > 0) printf("bwd chain: B sum %.1f ticks per node, D chain %.1f ticks per node (%lld nodes)\n", (double)dbgb_cyc / dbgb_n, (double)dbgd_cyc / dbgb_n, dbgb_n);
+#endif
     if (job >= 0 && !live && lane == 0) sc[job] = -INFINITY;
     __syncthreads();
   }
@@ -729,7 +827,9 @@ __global__ __launch_bounds__(1024) void fs3_bwd_chain_half_kernel(SeqView dna, F
   const int ll = 31 - hl;                                       // nodes in descending order: the lane holding the next nodes is the physical lane below
 #define LS(a, b) flogsum<false>((a), (b), s_tbl)
   auto shr1 = [&](float v) { const float r = wave_shr1(v, -INFINITY); return hl == 0 ? -INFINITY : r; };   // the neighbour move stays inside the half wave
-  int *s_ctl = reinterpret_cast<int *>(s_e + 2 * W);
+  int *s_ctl = reinterpret_cast<int *>(s_e + 2 * W);         // [0]: the block's batch; [4]: the row pair whose serial part is done
+  if (threadIdx.x == 0) s_ctl[4] = 0;
+  int pair = 0;
   for (;;) {                                                    // batches dealt longest first, on request (see fs3_fwd_chain_half_kernel)
     if (threadIdx.x == 0) s_ctl[0] = (int)atomicAdd(jobs.counter, 1u);
     __syncthreads();
@@ -761,7 +861,8 @@ __global__ __launch_bounds__(1024) void fs3_bwd_chain_half_kernel(SeqView dna, F
     auto nuc = [&](int i) -> int { return (i >= 1 && i <= L) ? ((d[i - 1] < 4) ? (int)d[i - 1] : 338) : 338; };
     const int npairs = Lmax / 2 + 1;
     for (int q = 0; q < npairs; q++) {
-      if (wave_idle) { lds_barrier(); lds_barrier(); continue; }
+      ++pair;
+      if (wave_idle) { lds_barrier(); if (chain_poller(wv)) chain_keepalive(s_ctl + 4, pair); lds_barrier(); continue; }
       const int iA = L - 2 * q, iB = iA - 1;
       const bool mainA = 2 * q >= 5, mainB = 2 * q + 1 >= 5;
       const int x0 = nuc(iA), x1 = nuc(iA + 1), x2 = nuc(iA + 2), x3 = nuc(iA + 3), x4 = nuc(iA + 4);
@@ -816,6 +917,7 @@ __global__ __launch_bounds__(1024) void fs3_bwd_chain_half_kernel(SeqView dna, F
         }
         hN2 = hN1; hN1 = xN; hJ2 = hJ1; hJ1 = xJ; hC2 = hC1; hC1 = xC;
       }
+      if (wv == 0) chain_done(s_ctl + 4, pair); else if (chain_poller(wv)) chain_keepalive(s_ctl + 4, pair);
       lds_barrier();
       // ---- 3. the cells of both rows (:1574-1600)
       const float EA = s_e[win * 2 + 0], EB = s_e[win * 2 + 1];
@@ -858,16 +960,18 @@ __global__ __launch_bounds__(1024) void fs3_bwd_chain_half_kernel(SeqView dna, F
 template <int C, int THREADS>
 __global__ __launch_bounds__(THREADS) void fs5_fwd_chain_kernel(SeqView dna, FsDev p, const float *__restrict__ loop_tab, const float *__restrict__ move_tab,
                                                              float tEL, float tEM, int c5_compat, float *__restrict__ sc, float *__restrict__ fwd, const int64_t *__restrict__ fwd_off,
-                                                             float *__restrict__ xmx, const int64_t *__restrict__ xmx_off, int cfg_len, FsJobs jobs, int *__restrict__ done) {
+                                                             float *__restrict__ xmx, const int64_t *__restrict__ xmx_off, int cfg_len, FsJobs jobs, int *__restrict__ done,
+                                                             int W /* windows per block: the block has max(W, kChainAwakeWaves) waves */) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   float *s_tbl = reinterpret_cast<float *>(lds);
   float *s_tf = s_tbl + kLogsumTbl;
   const int M = p.M;
-  const int W = blockDim.x >> 6;
   const int stride = fs_chain_stride(C);
   float *s_stage = s_tf + (M + 2) * 8;                          // [W][2][stride]; row 0 of each pair of slots is used
   float *s_e = s_stage + (size_t)W * 2 * stride;
-  int *s_ctl = reinterpret_cast<int *>(s_e + 2 * kChainMaxWaves);
+  int *s_ctl = reinterpret_cast<int *>(s_e + 2 * kChainMaxWaves);   // [0]: first job of the block's batch; [4]: the row whose serial part is done
+  if (threadIdx.x == 0) s_ctl[4] = 0;
+  int pair = 0;
   fs_load_logsum_table(s_tbl, p.logsum);
   for (int i = threadIdx.x; i < (M + 2) * 8; i += blockDim.x) s_tf[i] = p.tf[i];
   __syncthreads();
@@ -878,7 +982,7 @@ __global__ __launch_bounds__(THREADS) void fs5_fwd_chain_kernel(SeqView dna, FsD
     __syncthreads();
     const int64_t base = s_ctl[0];
     if (base >= dna.n) break;
-    const int64_t job = (base + wv < dna.n) ? (int64_t)jobs.order[base + wv] : (int64_t)-1;
+    const int64_t job = (wv < W && base + wv < dna.n) ? (int64_t)jobs.order[base + wv] : (int64_t)-1;
     const int Lmax = dna.len[jobs.order[base]];
     const int L = job >= 0 ? dna.len[job] : 0;
     const bool live = job >= 0 && L >= 5;
@@ -916,6 +1020,8 @@ __global__ __launch_bounds__(THREADS) void fs5_fwd_chain_kernel(SeqView dna, FsD
     };
     load_emissions(1);
     for (int i = 1; i <= Lmax; i++) {
+      ++pair;
+      if (wv >= W) { lds_barrier(); chain_keepalive(s_ctl + 4, pair); lds_barrier(); continue; }   // a poller without a window
       const bool act = live && i <= L;
       const float mIn = wave_shr1(Mr0[C - 1], -INFINITY), iIn = wave_shr1(Ir0[C - 1], -INFINITY), dIn = wave_shr1(Dr1[C - 1], -INFINITY);
       float Mc[C], Ic[C], ivc[C];
@@ -981,6 +1087,7 @@ __global__ __launch_bounds__(THREADS) void fs5_fwd_chain_kernel(SeqView dna, FsD
         ech = (i >= 5) ? LS(LS(Mn, dch), ech) : LS(Mn, LS(dch, ech));
         s_e[lane] = ech;
       }
+      if (wv == 0) chain_done(s_ctl + 4, pair); else if (chain_poller(wv)) chain_keepalive(s_ctl + 4, pair);
       lds_barrier();
       float Dc[C];
 #pragma unroll
@@ -1132,7 +1239,7 @@ int launch_fs3_fwd_chain(bath_hip_ctx *ctx, hipStream_t stream, const bath_hip_f
   const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((n + W - 1) / W, (int64_t)ctx->prop.multiProcessorCount));
   BATH_CHAIN_SWITCH(Cv, {
     BATH_HIP_TRY(ctx, bath::allow_max_lds((const void *)fs3_fwd_chain_kernel<CC>));
-    hipLaunchKernelGGL((fs3_fwd_chain_kernel<CC>), dim3(grid), dim3(64 * W), shmem, stream, dna->view(), dev, om->d_loop[0], om->d_move[0], tEL, tEM, d_sc, d_xmx, d_xoff, jobs);
+    hipLaunchKernelGGL((fs3_fwd_chain_kernel<CC>), dim3(grid), dim3(64 * std::max(W, kChainAwakeWaves)), shmem, stream, dna->view(), dev, om->d_loop[0], om->d_move[0], tEL, tEM, d_sc, d_xmx, d_xoff, jobs, W);
   })
   BATH_HIP_TRY(ctx, hipGetLastError());
   return BATH_OK;
@@ -1178,8 +1285,8 @@ int launch_fs3_bwd_chain(bath_hip_ctx *ctx, hipStream_t stream, const bath_hip_f
   FsDev dev{om->M, om->pitch, om->maxcodons, om->d_rsc, om->d_tf, om->d_tb, om->d_logsum};
   BATH_CHAIN_SWITCH(Cv, {
     BATH_HIP_TRY(ctx, bath::allow_max_lds((const void *)fs3_bwd_chain_kernel<CC>));
-    hipLaunchKernelGGL((fs3_bwd_chain_kernel<CC>), dim3(grid), dim3(64 * W), shmem, stream, dna->view(), dev, om->d_loop[0], om->d_move[0], tEL, tEM, d_sc, d_xmx, d_xoff, jobs,
-                       b_bst.as<int32_t>(), nbat);
+    hipLaunchKernelGGL((fs3_bwd_chain_kernel<CC>), dim3(grid), dim3(64 * std::max(W, kChainAwakeWaves)), shmem, stream, dna->view(), dev, om->d_loop[0], om->d_move[0], tEL, tEM, d_sc, d_xmx, d_xoff, jobs,
+                       b_bst.as<int32_t>(), nbat, W);
   })
   BATH_HIP_TRY(ctx, hipGetLastError());
   return BATH_OK;
@@ -1205,12 +1312,12 @@ int launch_fs5_fwd_chain(bath_hip_ctx *ctx, hipStream_t stream, const bath_hip_f
   BATH_CHAIN_SWITCH(Cv, {
     if (64 * W <= 256) {
       BATH_HIP_TRY(ctx, bath::allow_max_lds((const void *)fs5_fwd_chain_kernel<CC, 256>));
-      hipLaunchKernelGGL((fs5_fwd_chain_kernel<CC, 256>), dim3(grid), dim3(64 * W), shmem, stream, dna->view(), dev, om->d_loop[0], om->d_move[0], tEL, tEM, c5_compat, d_sc, d_fwd, d_foff,
-                         d_xmx, d_xoff, cfg_len, jobs, d_done);
+      hipLaunchKernelGGL((fs5_fwd_chain_kernel<CC, 256>), dim3(grid), dim3(64 * std::max(W, kChainAwakeWaves)), shmem, stream, dna->view(), dev, om->d_loop[0], om->d_move[0], tEL, tEM, c5_compat, d_sc, d_fwd, d_foff,
+                         d_xmx, d_xoff, cfg_len, jobs, d_done, W);
     } else {
       BATH_HIP_TRY(ctx, bath::allow_max_lds((const void *)fs5_fwd_chain_kernel<CC, chain_threads(CC)>));
-      hipLaunchKernelGGL((fs5_fwd_chain_kernel<CC, chain_threads(CC)>), dim3(grid), dim3(64 * W), shmem, stream, dna->view(), dev, om->d_loop[0], om->d_move[0], tEL, tEM, c5_compat, d_sc, d_fwd, d_foff,
-                         d_xmx, d_xoff, cfg_len, jobs, d_done);
+      hipLaunchKernelGGL((fs5_fwd_chain_kernel<CC, chain_threads(CC)>), dim3(grid), dim3(64 * std::max(W, kChainAwakeWaves)), shmem, stream, dna->view(), dev, om->d_loop[0], om->d_move[0], tEL, tEM, c5_compat, d_sc, d_fwd, d_foff,
+                         d_xmx, d_xoff, cfg_len, jobs, d_done, W);
     }
   })
   BATH_HIP_TRY(ctx, hipGetLastError());
