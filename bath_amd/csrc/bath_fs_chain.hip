@@ -103,7 +103,7 @@ __host__ __device__ inline int fs_chain_stride(int C) { return C * 64 + 1; }
   "v_lshl_add_u32 " a ", " a ", 2, %[tbl]\n\t"      \
   "ds_read_b32 " a ", " a "\n\t"
 
-#define BATH_FWD_NODE(MK, TX, TY, MN, UX, UY)                                                                 \
+#define BATH_FWD_NODE_TS(MK, TX, TY, MN, UX, UY, TS)                                                          \
   BATH_LS_INDEX("%[a1]", "%[d]", "%[e]")                        /* L1: LS(D_k, E) */                          \
   "s_waitcnt lgkmcnt(1)\n\t"                                    /* the loads of this node's M, tMD, tDD */    \
   "v_add_f32 %[u], " MK ", " TX "\n\t"                                                                        \
@@ -122,13 +122,17 @@ __host__ __device__ inline int fs_chain_stride(int C) { return C * 64 + 1; }
   "s_waitcnt lgkmcnt(4)\n\t"                                    /* W, L2 */                                   \
   "v_add_f32 %[d], %[mxd], %[a2]\n\t"                                                                         \
   "v_add_u32 %[st], 4, %[st]\n\t"                                                                             \
-  "v_add_u32 %[tp], 32, %[tp]\n\t"                                                                            \
+  "v_add_u32 %[tp], " TS ", %[tp]\n\t"                                                                        \
   "s_waitcnt lgkmcnt(3)\n\t"                                    /* L3 */                                      \
   "v_add_f32 %[e], %[mx1], %[a1]\n\t"
+
+// (TS: bytes per node of the transition table the chain reads: 32 for tf's rows of eight, 8 for the compact {tMD, tDD} pairs)
+#define BATH_FWD_NODE(MK, TX, TY, MN, UX, UY) BATH_FWD_NODE_TS(MK, TX, TY, MN, UX, UY, BATH_FWD_TS)
 
 struct FwdChainRegs { float e, d, Mk, tx, ty; unsigned st, tp; };
 
 // <n> nodes of a Forward chain from the state in <r>; on return r.Mk, r.tx, r.ty belong to the node after the last one
+#define BATH_FWD_TS "32"
 __device__ __forceinline__ void fwd_chain_nodes(FwdChainRegs &r, int n, unsigned tbl, float c15) {
   float Mn, ux, uy, a1, a2, u, w, mx1, mxd, x;
   int k = 0;
@@ -168,6 +172,51 @@ __device__ __forceinline__ void fwd_chain_nodes(FwdChainRegs &r, int n, unsigned
   }
 }
 
+#undef BATH_FWD_TS
+#undef BATH_FWD_PAIR
+// the same over compact transitions: r.tp walks over pairs {tMD(k), tDD(k)}
+#define BATH_FWD_TS "8"
+__device__ __forceinline__ void fwd_chain_nodes_compact(FwdChainRegs &r, int n, unsigned tbl, float c15) {
+  float Mn, ux, uy, a1, a2, u, w, mx1, mxd, x;
+  int k = 0;
+  // (sixteen nodes per trip: the chain's dependency runs through the loop's own instructions -- the counter, the branch, the waits
+  // either side of the asm block are issued in order between a node's last add and the next node's first subtraction: ~25 clocks
+  // per node at two nodes per trip.  M = 1024, clocks per node at 2 / 16 nodes per trip: Forward 224 -> 200, B sum 120 -> 92,
+  // D chain 250 -> 212; profiles/r06_chain_loops_ab.txt)
+#define BATH_FWD_PAIR BATH_FWD_NODE("%[Mk]", "%[tx]", "%[ty]", "%[Mn]", "%[ux]", "%[uy]") BATH_FWD_NODE("%[Mn]", "%[ux]", "%[uy]", "%[Mk]", "%[tx]", "%[ty]")
+  for (; k + BATH_CHAIN_UNROLL <= n; k += BATH_CHAIN_UNROLL)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\t"
+                 BATH_CHAIN_REPEAT(BATH_FWD_PAIR)
+                 "s_waitcnt lgkmcnt(0)"
+                 : [e] "+v"(r.e), [d] "+v"(r.d), [Mk] "+v"(r.Mk), [tx] "+v"(r.tx), [ty] "+v"(r.ty), [st] "+v"(r.st), [tp] "+v"(r.tp),
+                   [Mn] "=&v"(Mn), [ux] "=&v"(ux), [uy] "=&v"(uy), [a1] "=&v"(a1), [a2] "=&v"(a2), [u] "=&v"(u), [w] "=&v"(w),
+                   [mx1] "=&v"(mx1), [mxd] "=&v"(mxd), [x] "=&v"(x)
+                 : [tbl] "s"(tbl), [c15] "s"(c15)
+                 : "memory");
+  for (; k + 2 <= n; k += 2)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\t"
+                 BATH_FWD_PAIR
+                 "s_waitcnt lgkmcnt(0)"
+                 : [e] "+v"(r.e), [d] "+v"(r.d), [Mk] "+v"(r.Mk), [tx] "+v"(r.tx), [ty] "+v"(r.ty), [st] "+v"(r.st), [tp] "+v"(r.tp),
+                   [Mn] "=&v"(Mn), [ux] "=&v"(ux), [uy] "=&v"(uy), [a1] "=&v"(a1), [a2] "=&v"(a2), [u] "=&v"(u), [w] "=&v"(w),
+                   [mx1] "=&v"(mx1), [mxd] "=&v"(mxd), [x] "=&v"(x)
+                 : [tbl] "s"(tbl), [c15] "s"(c15)
+                 : "memory");
+  if (k < n) {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\t"
+                 BATH_FWD_NODE("%[Mk]", "%[tx]", "%[ty]", "%[Mn]", "%[ux]", "%[uy]")
+                 "s_waitcnt lgkmcnt(0)"
+                 : [e] "+v"(r.e), [d] "+v"(r.d), [st] "+v"(r.st), [tp] "+v"(r.tp),
+                   [Mn] "=&v"(Mn), [ux] "=&v"(ux), [uy] "=&v"(uy), [a1] "=&v"(a1), [a2] "=&v"(a2), [u] "=&v"(u), [w] "=&v"(w),
+                   [mx1] "=&v"(mx1), [mxd] "=&v"(mxd), [x] "=&v"(x)
+                 : [Mk] "v"(r.Mk), [tx] "v"(r.tx), [ty] "v"(r.ty), [tbl] "s"(tbl), [c15] "s"(c15)
+                 : "memory");
+    r.Mk = Mn; r.tx = ux; r.ty = uy;
+  }
+}
+
+#undef BATH_FWD_TS
+#undef BATH_FWD_PAIR
 // ---- the Backward chains the same way.  B(i) = LS over the nodes, ascending, of ivx(i,k) + tBM(k-1): one log-sum per node,
 // the term of node k+1 added up and the raw values of node k+2 loaded behind the look-up.
 //   b       B so far (in/out);  v: the term of this node;  sN, tN: ivx and tBM of the NEXT node, loaded by the node before
@@ -439,6 +488,237 @@ __global__ __launch_bounds__(chain_threads(C)) void fs3_fwd_chain_kernel(SeqView
 #ifdef BATH_CHAIN_CLOCK
     if (wv == 0 && lane == 0 && blockIdx.x == 0 && dbg_n > 0) printf("fwd chain: %.1f clock64 ticks per node, %.1f ns per node (%lld nodes)\n", (double)dbg_cyc / dbg_n, (double)dbg_wall / dbg_n * 10.0, dbg_n);
 #endif
+    __syncthreads();                                            // s_ctl is rewritten at the top
+  }
+#undef LS
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The same for LONG models (12 or 16 nodes per lane) with the rows' history in global memory instead of registers.
+// fs3_fwd_chain_kernel<16> keeps ten rows of history, six new rows and the emission scores in 460 registers per lane: a CU's
+// register file holds four such windows, and a chain wave that could carry 64 rows carries 8.  Here a window's wave keeps
+// nothing from one row pair to the next: what a pair leaves (M, I, D, IVX of both rows, <hist>: two records of eight rows per
+// window slot, the pair's and the one before) is read back where the next pairs need it, four nodes at a time, so that
+// registers and LDS hold EIGHT windows per block of 512 threads.
+// A lane owns the nodes in STRIPES of four: its g-th group is the nodes (g * 64 + lane) * 4 + 1 .. + 4, so that everything a wave
+// touches per group is contiguous -- 1 KB of a history row per load or store, 256 consecutive emission scores per codon row, the
+// stage row's slots -- and the transitions, kept as six arrays by kind (tMM, tIM, tDM, tBM, tMI, tII at node k in slot k - 1),
+// are read as one float4 per lane without LDS bank conflicts (with a lane owning C consecutive nodes of tf's rows of eight, the
+// kernel above reads them 64 lanes to a bank: its parallel part is 33 k clocks of LDS time per pair at four windows).  The rows
+// i-1, i-2 "at node k-1" are the same vectors moved on by one node: the lane below's last element (DPP), lane 0 taking lane
+// 63's of the group before.  Every log-sum has the operands and the order of the kernel above.
+// Traffic: 72 KB per window and row pair at M = 1024 (ten rows in, eight out) against a pair's ~100 us: ~5 GB/s per CU.
+// ---------------------------------------------------------------------------------------------------------------------------
+constexpr int kChainHistRows = 8;                                // MA IA DA MB IB DB ivA ivB
+__host__ __device__ inline int fs_chain_hist_pitch(int C) { return C * 64; }   // floats per row
+__host__ __device__ inline size_t fs_chain_mem_fixed_lds(int M, int C) {       // everything but the stage rows
+  return (size_t)(kLogsumTbl + 6 * C * 64 + (M + 3) * 2 + 2 * kChainMaxWaves + 16) * sizeof(float);
+}
+template <int C>
+__global__ __launch_bounds__(512) void fs3_fwd_chain_mem_kernel(SeqView dna, FsDev p, const float *__restrict__ loop_tab, const float *__restrict__ move_tab,
+                                                                 float tEL, float tEM, float *__restrict__ sc, float *__restrict__ xmx, const int64_t *__restrict__ xmx_off, FsJobs jobs,
+                                                                 int W /* windows per block: the block has max(W, kChainAwakeWaves) waves */,
+                                                                 float *__restrict__ hist /* [blocks][W][2][kChainHistRows][fs_chain_hist_pitch(C)] */) {
+  static_assert(C % 4 == 0, "groups of four nodes");
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  constexpr int HP = C * 64, G = C / 4;
+  float *s_tbl = reinterpret_cast<float *>(lds);
+  float *s_t6 = s_tbl + kLogsumTbl;                             // [6][HP]: tMM(k-1), tIM(k-1), tDM(k-1), tBM(k-1), tMI(k), tII(k) of node k in slot k - 1
+  float *s_tc = s_t6 + 6 * HP;                                  // [(M + 3)][2] = {tMD(k), tDD(k)}: the chain's
+  const int M = p.M;
+  const int stride = fs_chain_stride(C);
+  float *s_stage = s_tc + (M + 3) * 2;                          // [W][2][stride]
+  float *s_e = s_stage + (size_t)W * 2 * stride;                // [W][2] E(i) of the pair's rows
+  int *s_ctl = reinterpret_cast<int *>(s_e + 2 * kChainMaxWaves);   // [0]: first job of the block's batch; [4]: the row pair whose serial part is done
+  if (threadIdx.x == 0) s_ctl[4] = 0;
+  int pair = 0;
+#ifdef BATH_CHAIN_CLOCK
+  long long dbg_t[5] = {0, 0, 0, 0, 0}, dbg_n = 0;
+#endif
+  fs_load_logsum_table(s_tbl, p.logsum);
+  for (int n = threadIdx.x; n < HP; n += blockDim.x) {
+    const int nd = imin(n + 1, M + 1);                          // (the nodes past the model's end read row M + 1, as the kernel above does)
+    s_t6[0 * HP + n] = p.tf[nd * 8 + 0]; s_t6[1 * HP + n] = p.tf[nd * 8 + 1]; s_t6[2 * HP + n] = p.tf[nd * 8 + 2]; s_t6[3 * HP + n] = p.tf[nd * 8 + 3];
+    s_t6[4 * HP + n] = p.tf[nd * 8 + 6]; s_t6[5 * HP + n] = p.tf[nd * 8 + 7];
+  }
+  for (int k = threadIdx.x; k < M + 3; k += blockDim.x) { const int kk = imin(k, M + 1); s_tc[k * 2] = p.tf[kk * 8 + 4]; s_tc[k * 2 + 1] = p.tf[kk * 8 + 5]; }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float *const rec0 = hist + ((size_t)blockIdx.x * W + imin(wv, W - 1)) * 2 * kChainHistRows * HP;   // row a of record r: rec0 + (r * 8 + a) * HP, node k in slot k - 1
+#define LS(a, b) flogsum<false>((a), (b), s_tbl)
+  const float4 ninf4 = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+  auto ld4 = [&](const float *row, int g, bool on) -> float4 { float4 v = ninf4; if (on) v = reinterpret_cast<const float4 *>(row)[g * 64 + lane]; return v; };
+  auto st4 = [&](float *row, int g, const float4 &v) { reinterpret_cast<float4 *>(row)[g * 64 + lane] = v; };
+  auto el = [](const float4 &v, int j) -> float { return j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w)); };
+  // a row's vector moved on by one node: the lane below's last element comes first; lane 0 takes <c63>, lane 63's last element of the group before
+  auto moved = [&](const float4 &v, float &c63) -> float4 {
+    float first = wave_shr1(v.w, -INFINITY);
+    if (lane == 0) first = c63;
+    c63 = __shfl(v.w, 63, 64);
+    return make_float4(first, v.x, v.y, v.z);
+  };
+  for (;;) {
+    if (threadIdx.x == 0) s_ctl[0] = (int)atomicAdd(jobs.counter, (unsigned)W);
+    __syncthreads();
+    const int64_t base = s_ctl[0];
+    if (base >= dna.n) break;
+    const int64_t job = (wv < W && base + wv < dna.n) ? (int64_t)jobs.order[base + wv] : (int64_t)-1;
+    const int Lmax = dna.len[jobs.order[base]];                 // the batch's longest window (the list is sorted by length)
+    const int L = job >= 0 ? dna.len[job] : 0;
+    const uint8_t *d = job >= 0 ? dna.data + dna.off[job] : dna.data;
+    float *xo = (xmx && job >= 0) ? xmx + xmx_off[job] : nullptr;
+    const int Lc = L / 3;
+    const float tNL = loop_tab[Lc], tNM = move_tab[Lc], tJL = tNL, tJM = tNM, tCL = tNL, tCM = tNM;
+    float N1 = 0.f, N2 = 0.f, N3 = 0.f, J1 = -INFINITY, J2 = -INFINITY, J3 = -INFINITY, C1 = -INFINITY, C2 = -INFINITY, C3 = -INFINITY;
+    float B1 = tNM, B2 = tNM;                                   // B(i-1), B(i-2)
+    if (xo && lane == 0 && L >= 3)
+      for (int i = 0; i < 2; i++) { xo[i * 5 + 0] = -INFINITY; xo[i * 5 + 1] = 0.f; xo[i * 5 + 2] = -INFINITY; xo[i * 5 + 3] = tNM; xo[i * 5 + 4] = -INFINITY; }
+    auto nuc = [&](int i) -> int { return (i >= 1 && i <= L) ? ((d[i - 1] < 4) ? (int)d[i - 1] : 338) : 338; };
+    int np = 0;                                                 // pairs this window has stored: record np & 1 takes the next one
+    for (int i = 2; i <= Lmax; i += 2) {
+      ++pair;
+      if (wv >= W) { lds_barrier(); chain_keepalive(s_ctl + 4, pair); lds_barrier(); continue; }   // a poller without a window
+      const bool actA = job >= 0 && L >= 3 && i <= L, actB = job >= 0 && L >= 3 && i + 1 <= L;
+      const int xa = nuc(i), wa = nuc(i - 1), va = nuc(i - 2), ua = nuc(i - 3), xb = nuc(i + 1);
+      const float *qa2 = p.rsc + (size_t)imin(xa * 84 + wa * 21, 337) * p.pitch;
+      const float *qa3 = p.rsc + (size_t)imin(xa * 84 + wa * 21 + va * 5 + 1, 336) * p.pitch;
+      const float *qa4 = p.rsc + (size_t)imin(xa * 84 + wa * 21 + va * 5 + ua + 2, 337) * p.pitch;
+      const float *qb2 = p.rsc + (size_t)imin(xb * 84 + xa * 21, 337) * p.pitch;
+      const float *qb3 = p.rsc + (size_t)imin(xb * 84 + xa * 21 + wa * 5 + 1, 336) * p.pitch;
+      const float *qb4 = p.rsc + (size_t)imin(xb * 84 + xa * 21 + wa * 5 + va + 2, 337) * p.pitch;
+      // the records: <prev> holds the rows i-2 (its A rows) and i-1 (its B rows), <cur> -- until this pair overwrites it -- the rows
+      // i-4 and i-3.  A window that has stored no pair (one pair) yet reads -inf instead (every row before row 2 is -inf).
+      const bool h1 = np >= 1, h2 = np >= 2;
+#ifdef BATH_CHAIN_CLOCK
+      const long long t0 = clock64();
+#endif
+      __threadfence_block();                                    // the previous pairs' rows, stored by other lanes of this wave, before they are read
+      float *const cur = rec0 + (size_t)(np & 1) * kChainHistRows * HP;
+      const float *const prev = rec0 + (size_t)((np + 1) & 1) * kChainHistRows * HP;
+      // ---- 1. everything of both rows that is parallel over the nodes, four nodes at a time; the rows and the emission scores of
+      //         the next group are loaded while this one is computed
+      struct Group { float4 m2, i2, d2, m1, i1, d1, iv2, iv1, m3, i3; float e[4][6]; };
+      auto load_group = [&](int g, Group &q) {
+        q.m2 = ld4(prev + 0 * HP, g, h1); q.i2 = ld4(prev + 1 * HP, g, h1); q.d2 = ld4(prev + 2 * HP, g, h1);       // row i-2
+        q.m1 = ld4(prev + 3 * HP, g, h1); q.i1 = ld4(prev + 4 * HP, g, h1); q.d1 = ld4(prev + 5 * HP, g, h1);       // row i-1
+        q.iv2 = ld4(prev + 6 * HP, g, h1); q.iv1 = ld4(prev + 7 * HP, g, h1);                                       // IVX of rows i-2, i-1
+        q.m3 = ld4(cur + 3 * HP, g, h2); q.i3 = ld4(cur + 4 * HP, g, h2);                                           // row i-3
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+          const int ne = imin((g * 64 + lane) * 4 + c + 1, M);
+          q.e[c][0] = qa2[ne]; q.e[c][1] = qa3[ne]; q.e[c][2] = qa4[ne]; q.e[c][3] = qb2[ne]; q.e[c][4] = qb3[ne]; q.e[c][5] = qb4[ne];
+        }
+      };
+      Group gc, gn;
+      load_group(0, gc);
+      float km2 = -INFINITY, ki2 = -INFINITY, kd2 = -INFINITY, km1 = -INFINITY, ki1 = -INFINITY, kd1 = -INFINITY;   // lane 63's last elements of the group before (node 0: -inf)
+#pragma unroll 1
+      for (int g = 0; g < G; g++) {
+        const int n0 = (g * 64 + lane) * 4;                     // the group's first node is n0 + 1
+        if (g + 1 < G) load_group(g + 1, gn);
+        const float4 m2 = gc.m2, i2 = gc.i2, iv2 = gc.iv2, iv1 = gc.iv1, m3 = gc.m3, i3 = gc.i3;
+        const float4 m2s = moved(gc.m2, km2), i2s = moved(gc.i2, ki2), d2s = moved(gc.d2, kd2);
+        const float4 m1s = moved(gc.m1, km1), i1s = moved(gc.i1, ki1), d1s = moved(gc.d1, kd1);
+        const float4 tmm = reinterpret_cast<const float4 *>(s_t6 + 0 * HP)[g * 64 + lane], tim = reinterpret_cast<const float4 *>(s_t6 + 1 * HP)[g * 64 + lane];
+        const float4 tdm = reinterpret_cast<const float4 *>(s_t6 + 2 * HP)[g * 64 + lane], tbm = reinterpret_cast<const float4 *>(s_t6 + 3 * HP)[g * 64 + lane];
+        const float4 tmi = reinterpret_cast<const float4 *>(s_t6 + 4 * HP)[g * 64 + lane], tii = reinterpret_cast<const float4 *>(s_t6 + 5 * HP)[g * 64 + lane];
+        float oMA[4], oIA[4], oVA[4], oMB[4], oIB[4], oVB[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+          const int node = n0 + c + 1;
+          const bool in = node <= M;
+          const float ea2 = in ? gc.e[c][0] : -INFINITY, ea3 = in ? gc.e[c][1] : -INFINITY, ea4 = in ? gc.e[c][2] : -INFINITY;
+          const float eb2 = in ? gc.e[c][3] : -INFINITY, eb3 = in ? gc.e[c][4] : -INFINITY, eb4 = in ? gc.e[c][5] : -INFINITY;
+          // row A = i: from row i-2 and B(i-2) (:562-569)
+          const float a = LS(el(m2s, c) + el(tmm, c), LS(el(i2s, c) + el(tim, c), LS(el(d2s, c) + el(tdm, c), B2 + el(tbm, c))));
+          oVA[c] = a;
+          float mv = a + ea2;
+          mv = LS(mv, el(iv1, c) + ea3); mv = LS(mv, el(iv2, c) + ea4);      // :571-574
+          oMA[c] = mv;
+          const float insA = LS(el(m3, c) + el(tmi, c), el(i3, c) + el(tii, c));
+          oIA[c] = (i > 2 && node < M) ? insA : -INFINITY;
+          // row B = i+1: from row i-1 and B(i-1); its 3- and 4-nucleotide codons start in rows i and i-1
+          const float b = LS(el(m1s, c) + el(tmm, c), LS(el(i1s, c) + el(tim, c), LS(el(d1s, c) + el(tdm, c), B1 + el(tbm, c))));
+          oVB[c] = b;
+          float mw = b + eb2;
+          mw = LS(mw, a + eb3); mw = LS(mw, el(iv1, c) + eb4);
+          oMB[c] = mw;
+          const float insB = LS(el(m2, c) + el(tmi, c), el(i2, c) + el(tii, c));
+          oIB[c] = (node < M) ? insB : -INFINITY;
+          s_stage[((size_t)wv * 2 + 0) * stride + node] = mv; s_stage[((size_t)wv * 2 + 1) * stride + node] = mw;
+        }
+        if (actB) {                                             // both rows exist: the pair becomes history (M and I of row i-3 were read above)
+          st4(cur + 0 * HP, g, make_float4(oMA[0], oMA[1], oMA[2], oMA[3])); st4(cur + 1 * HP, g, make_float4(oIA[0], oIA[1], oIA[2], oIA[3]));
+          st4(cur + 6 * HP, g, make_float4(oVA[0], oVA[1], oVA[2], oVA[3]));
+          st4(cur + 3 * HP, g, make_float4(oMB[0], oMB[1], oMB[2], oMB[3])); st4(cur + 4 * HP, g, make_float4(oIB[0], oIB[1], oIB[2], oIB[3]));
+          st4(cur + 7 * HP, g, make_float4(oVB[0], oVB[1], oVB[2], oVB[3]));
+        }
+        gc = gn;
+      }
+#ifdef BATH_CHAIN_CLOCK
+      const long long t1 = clock64();
+#endif
+      lds_barrier();
+#ifdef BATH_CHAIN_CLOCK
+      const long long t2 = clock64();
+#endif
+      // ---- 2. the serial part, a lane per row (as in fs3_fwd_chain_kernel; the transitions are the compact pairs)
+      if (wv == 0 && lane < 2 * W) {
+        float *st = s_stage + (size_t)lane * stride;
+        FwdChainRegs r{-INFINITY, -INFINITY, st[1], s_tc[1 * 2], s_tc[1 * 2 + 1], lds_addr(st + 1), lds_addr(s_tc + 2 * 2)};   // tMD(k), tDD(k)
+        fwd_chain_nodes_compact(r, M, lds_addr(s_tbl), 15.999f);
+        s_e[lane] = r.e;
+      }
+      if (wv == 0) chain_done(s_ctl + 4, pair); else if (chain_poller(wv)) chain_keepalive(s_ctl + 4, pair);
+#ifdef BATH_CHAIN_CLOCK
+      const long long t3 = clock64();
+#endif
+      lds_barrier();
+#ifdef BATH_CHAIN_CLOCK
+      const long long t4 = clock64();
+#endif
+      // ---- 3. D of both rows into the pair's record; special states of both rows (:592-603)
+      if (actB) {
+#pragma unroll 1
+        for (int g = 0; g < G; g++) {
+          const int n0 = (g * 64 + lane) * 4;
+          float da[4], db[4];
+#pragma unroll
+          for (int c = 0; c < 4; c++) {
+            const int node = n0 + c + 1, ne = imin(node, M);
+            const float x = s_stage[((size_t)wv * 2 + 0) * stride + ne], y = s_stage[((size_t)wv * 2 + 1) * stride + ne];
+            da[c] = (node <= M) ? x : -INFINITY; db[c] = (node <= M) ? y : -INFINITY;
+          }
+          st4(cur + 2 * HP, g, make_float4(da[0], da[1], da[2], da[3])); st4(cur + 5 * HP, g, make_float4(db[0], db[1], db[2], db[3]));
+        }
+      }
+      const float EA = s_e[wv * 2 + 0], EB = s_e[wv * 2 + 1];
+      float NA, JA, CA;
+      if (i == 2) { NA = 0.f; JA = EA + tEL; CA = EA + tEM; }
+      else { NA = N3 + tNL; JA = LS(J3 + tJL, EA + tEL); CA = LS(C3 + tCL, EA + tEM); }
+      const float BA = LS(NA + tNM, JA + tJM);
+      const float NB = N2 + tNL, JB = LS(J2 + tJL, EB + tEL), CB = LS(C2 + tCL, EB + tEM);
+      const float BB = LS(NB + tNM, JB + tJM);
+      if (xo && lane == 0) {
+        if (actA) { float *r = xo + (size_t)i * 5; r[0] = EA; r[1] = NA; r[2] = JA; r[3] = BA; r[4] = CA; }
+        if (actB) { float *r = xo + (size_t)(i + 1) * 5; r[0] = EB; r[1] = NB; r[2] = JB; r[3] = BB; r[4] = CB; }
+      }
+      if (actB) {                                               // both rows exist: the rings move by two
+        N3 = N1; N2 = NA; N1 = NB; J3 = J1; J2 = JA; J1 = JB; C3 = C1; C2 = CA; C1 = CB; B2 = BA; B1 = BB;
+        np++;
+      } else if (actA) {                                        // the window's last row: only C(L), C(L-1), C(L-2) are still needed
+        C3 = C2; C2 = C1; C1 = CA;
+      }
+#ifdef BATH_CHAIN_CLOCK
+      dbg_t[0] += t1 - t0; dbg_t[1] += t2 - t1; dbg_t[2] += t3 - t2; dbg_t[3] += t4 - t3; dbg_t[4] += clock64() - t4; dbg_n++;
+#endif
+    }
+#ifdef BATH_CHAIN_CLOCK
+    if (lane == 0 && blockIdx.x == 0 && (wv == 0 || wv == W - 1) && dbg_n > 0)
+      printf("fwd mem wave %d: per pair, clocks: parallel part %.0f, wait %.0f, chain (wave 0) or poll %.0f, wait %.0f, D rows + special states %.0f\n", wv,
+             (double)dbg_t[0] / dbg_n, (double)dbg_t[1] / dbg_n, (double)dbg_t[2] / dbg_n, (double)dbg_t[3] / dbg_n, (double)dbg_t[4] / dbg_n);
+#endif
+    if (job >= 0 && lane == 0) sc[job] = (L >= 3) ? LS(C1, LS(C2 + tCL, C3 + tCL)) + tCM : -INFINITY;
     __syncthreads();                                            // s_ctl is rewritten at the top
   }
 #undef LS
@@ -1236,6 +1516,31 @@ int launch_fs3_fwd_chain(bath_hip_ctx *ctx, hipStream_t stream, const bath_hip_f
   // two kernels' blocks do not fit into one CU's LDS together, so each takes half of the CUs with blocks of twice the windows --
   // with a CU each per kernel, 2 x 164 blocks for the 327 windows of configs[4]'s slice queued on 256 CUs
   const int W = chain_waves(ctx, dna->n, M, Cv, &shmem, cu_share);
+  // Long models with more windows than a round and a half of such blocks (configs[4] at 500 Mb and more): the kernel that keeps the
+  // rows' history in global memory carries twice the windows per CU (BATH_HIP_FS_FWD_MEM=1 / =0: always, with full blocks / never).
+  // M = 1024, windows of 8000 nt, ms: 1308 windows 811 -> 476, 2616 windows 1218 -> 945; configs[4] at 1 Gb 2.61 -> 2.12 s
+  static const int mem_env = [] { const char *e = std::getenv("BATH_HIP_FS_FWD_MEM"); return e ? std::atoi(e) : -1; }();
+  if ((Cv == 12 || Cv == 16) && mem_env != 0) {
+    const int64_t slots = std::max<int64_t>(1, (int64_t)ctx->prop.multiProcessorCount / std::max(1, cu_share));
+    const size_t fixed = fs_chain_mem_fixed_lds(M, Cv);
+    int Wm = 8;
+    while (Wm > 1 && fixed + (size_t)Wm * 2 * fs_chain_stride(Cv) * sizeof(float) > 160 * 1024) Wm >>= 1;
+    if (mem_env != 1) while (Wm > 1 && (int64_t)(Wm / 2) * slots >= n) Wm >>= 1;
+    if (Wm > W && (mem_env == 1 || 2 * n > 3 * slots * W)) {     // (a pair takes 119 us here against 101: not before the other kernel needs a round and a half)
+      const size_t ms = fixed + (size_t)Wm * 2 * fs_chain_stride(Cv) * sizeof(float);
+      const int mgrid = (int)std::max<int64_t>(1, std::min<int64_t>((n + Wm - 1) / Wm, (int64_t)ctx->prop.multiProcessorCount));
+      DevBuf &b_hist = ctx->scratch[58];
+      BATH_HIP_TRY(ctx, b_hist.reserve((size_t)mgrid * Wm * 2 * kChainHistRows * fs_chain_hist_pitch(Cv) * sizeof(float)));
+#define BATH_MEM(C_)                                                                                                               \
+      case C_: BATH_HIP_TRY(ctx, bath::allow_max_lds((const void *)fs3_fwd_chain_mem_kernel<C_>));                                  \
+               hipLaunchKernelGGL((fs3_fwd_chain_mem_kernel<C_>), dim3(mgrid), dim3(64 * std::max(Wm, kChainAwakeWaves)), ms, stream, dna->view(), dev, om->d_loop[0], om->d_move[0], tEL, tEM, \
+                                  d_sc, d_xmx, d_xoff, jobs, Wm, b_hist.as<float>()); break;
+      switch (Cv) { BATH_MEM(12) BATH_MEM(16) }
+#undef BATH_MEM
+      BATH_HIP_TRY(ctx, hipGetLastError());
+      return BATH_OK;
+    }
+  }
   const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((n + W - 1) / W, (int64_t)ctx->prop.multiProcessorCount));
   BATH_CHAIN_SWITCH(Cv, {
     BATH_HIP_TRY(ctx, bath::allow_max_lds((const void *)fs3_fwd_chain_kernel<CC>));

@@ -150,3 +150,33 @@ def test_fs3_chain_kernel_variants_are_bit_identical(switches, n_model, n_random
     r = subprocess.run([sys.executable, "-c", HALF_SCRIPT.format(root=ROOT, seed=5 + len(switches), n_model=n_model, n_random=n_random, hi=hi)],
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "half-wave ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+MEM_SCRIPT = r"""
+import sys, os
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import numpy as np
+import bath_amd as ba, oracle_lib as ol, common
+from test_fs_chain_gpu import mixed_windows, check_fs3
+path = common.write_synthetic_bhmm({path!r}, {M}, seed={M})
+ctx = ba.Context(0)
+model = ol.Model(path); hmm = ba.HMM(path)
+om3 = ba.FSOProfile(ctx, ba.FSProfile(hmm, 3))
+rng = np.random.default_rng({M})
+wins = mixed_windows(rng, model, 14, 50, lo=15, hi=520)
+wins += [rng.integers(0, 4, size=L).astype(np.uint8) for L in (15, 16, 17, 18, 19, 20)]
+check_fs3(ctx, model, om3, wins, "history in memory")
+print("mem kernel ok", len(wins))
+"""
+
+
+@pytest.mark.parametrize("M", [700, 1000, 1024])
+def test_fs3_forward_chain_with_the_history_in_memory_is_bit_identical(tmp_path, M):
+    """fs3_fwd_chain_mem_kernel (long models, eight windows per block, the rows' history in global memory: what configs[4] takes from
+    250 Mb on) forced onto ~80 windows of 15..520 nt with BATH_HIP_FS_FWD_MEM=1: 12 and 16 nodes per lane (1000: node slots past the
+    model's end), batches whose windows end at different rows, windows too short for a codon.  Scores and special-state rows against
+    the oracle, bit for bit."""
+    env = dict(os.environ, BATH_HIP_FS_FWD_MEM="1")
+    r = subprocess.run([sys.executable, "-c", MEM_SCRIPT.format(root=ROOT, path=str(tmp_path / ("s%d.bhmm" % M)), M=M)],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "mem kernel ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
