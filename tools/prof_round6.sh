@@ -57,6 +57,11 @@ for n in 2 3; do
   cp gpurun_out/bench_detail.json $OUT/nrank_${n}_detail.json
 done
 python3 tools/chain_long_probe.py > $OUT/chain_long_probe.txt 2>&1
+# 6: the chain kernels of long models: the Forward kernel with the rows' history in memory against the register kernel; configs[4]'s
+#    pass at 250 Mb kernel by kernel; the whole GPU tier
+bash tools/fwd_mem_probe.sh > $OUT/fwd_mem_probe.txt 2>&1
+bash tools/c5_timeline.sh 250 > $OUT/c5_timeline_250mb.txt 2>&1
+python3 -m pytest tests -m gpu -x -q > $OUT/gputest_all.log 2>&1
 python3 tools/pmc_summary.py $OUT/pmc_by_kernel.json $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq1 $OUT/pmc_sq2 $OUT/pmc_grbm > $OUT/pmc_summary.txt
 rm -rf $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq1 $OUT/pmc_sq2 $OUT/pmc_grbm
 tail -1 $OUT/bench_under_prof.log | cut -c1-300
