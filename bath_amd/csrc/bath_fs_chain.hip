@@ -898,20 +898,26 @@ __global__ __launch_bounds__(1024) void fs3_fwd_chain_half_kernel(SeqView dna, F
 //      (:1596-1599), leaving D(i,k) in place of ivx(i,k);
 //   3. window waves: M(i,k), I(i,k) from D(i,k+1), ivx(i,k+1), I(i+3,k), E(i).
 // ---------------------------------------------------------------------------------------------------------------------------
-template <int C>
-__global__ __launch_bounds__(bwd_chain_threads(C)) void fs3_bwd_chain_kernel(SeqView dna, FsDev p, const float *__restrict__ loop_tab, const float *__restrict__ move_tab,
+// WPW: waves per window.  Long models take two (C nodes per lane, 128 lanes) when a block holds up to four windows: a window's
+// parallel part is a chain of dependent log-sums per node that one wave walks through alone on its SIMD -- 17 us of a 147 us row pair
+// at M = 1024 with 16 nodes per lane and 87 spilled registers; two waves of 8 nodes per lane on two SIMDs (193 registers, no spills)
+// make it 11 us: 147 -> 141 us per pair (profiles/r06_bwd_wpw_probe.txt).  The one value that crosses the waves (ivx of the first
+// node of the wave above) goes through LDS.
+template <int C, int WPW = 1, int MAXT = 1024>
+__global__ __launch_bounds__(WPW == 1 ? bwd_chain_threads(C) : MAXT) void fs3_bwd_chain_kernel(SeqView dna, FsDev p, const float *__restrict__ loop_tab, const float *__restrict__ move_tab,
                                                              float tEL, float tEM, float *__restrict__ sc, float *__restrict__ xmx, const int64_t *__restrict__ xmx_off, FsJobs jobs,
                                                              const int32_t *__restrict__ bstart /* batches of the sorted list, chain_batches */, int nb,
                                                              int W /* windows per block: the block has max(W, kChainAwakeWaves) waves */) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  constexpr bool kCompact = chain_compact(C);
+  constexpr bool kCompact = chain_compact(C * WPW);
   float *s_tbl = reinterpret_cast<float *>(lds);
   float *s_tb = s_tbl + kLogsumTbl;                             // kCompact: [(M + 3)][4] = {tDD(k), tDM(k), tBM(k-1), -}; else tb's [(M + 2)][8]
   const int M = p.M;
-  const int stride = fs_chain_stride(C);
+  const int stride = fs_chain_stride(C * WPW);
   float *s_stage = s_tb + (kCompact ? (M + 3) * 4 : (M + 2) * 8);   // [W][2][stride]: ivx(i,k) in, D(i,k) out
   float *s_e = s_stage + (size_t)W * 2 * stride;                // [W][2] E(i) of the pair's rows
   int *s_ctl = reinterpret_cast<int *>(s_e + 2 * kChainMaxWaves);   // [0]: first job of the block's batch; [4]: the row pair whose serial part is done
+  float *s_xch = reinterpret_cast<float *>(s_ctl + 16);          // [waves][2]: ivx of both rows at the first (lowest) node of each wave, for the wave above
   if (threadIdx.x == 0) s_ctl[4] = 0;
   int pair = 0;
   fs_load_logsum_table(s_tbl, p.logsum);
@@ -931,7 +937,8 @@ __global__ __launch_bounds__(bwd_chain_threads(C)) void fs3_bwd_chain_kernel(Seq
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   // Lanes own their nodes in DESCENDING order (logical lane = 63 - physical lane), as in fs_bwd_kernel: "the lane holding the
   // next nodes" is then the physical lane below and the neighbour move is the same wave_shr1
-  const int ll = 63 - lane;
+  const int win = wv / WPW, half = wv % WPW;                    // the wave's window slot; its place among the window's waves (0: the highest nodes)
+  const int ll = 64 * WPW - 1 - (half * 64 + lane);
 #ifdef BATH_CHAIN_CLOCK
   long long dbgb_cyc = 0, dbgd_cyc = 0, dbgb_n = 0;
 #endif
@@ -943,12 +950,12 @@ __global__ __launch_bounds__(bwd_chain_threads(C)) void fs3_bwd_chain_kernel(Seq
     if (bb >= nb) break;
     const int64_t base = bstart[bb];
     const int cnt = bstart[bb + 1] - bstart[bb];                // windows of this batch (<= W): the longest windows come in smaller batches
-    const int64_t job = (wv < cnt) ? (int64_t)jobs.order[base + wv] : (int64_t)-1;
+    const int64_t job = (win < cnt) ? (int64_t)jobs.order[base + win] : (int64_t)-1;
     const int Lmax = dna.len[jobs.order[base]];
     const int L = job >= 0 ? dna.len[job] : 0;
     const bool live = job >= 0 && L >= 5;                       // shorter windows report -inf (fs_bwd_kernel does)
     const uint8_t *d = job >= 0 ? dna.data + dna.off[job] : dna.data;
-    const bool wave_idle = wv != 0 && wv >= cnt;                // no window in this wave's slot: it only keeps the barriers
+    const bool wave_idle = wv != 0 && win >= cnt;               // no window in this wave's slot: it only keeps the barriers
     // ---- the chain wave's lanes: lane c serves slot (c & 1) of window (c >> 1)
     const int cw = lane >> 1, cs = lane & 1;
     const bool chain_lane = (wv == 0) && (lane < 2 * W);
@@ -991,8 +998,9 @@ __global__ __launch_bounds__(bwd_chain_threads(C)) void fs3_bwd_chain_kernel(Seq
         const float a = mainA ? LS(sa2, LS(sa3, sa4)) : LS(LS(sa2, sa3), sa4);       // :1552-1553; the rows near the end add their codons left to right (:1483, :1517-1518)
         const float b = mainB ? LS(sb2, LS(sb3, sb4)) : LS(LS(sb2, sb3), sb4);
         ivA[c] = in ? a : -INFINITY; ivB[c] = in ? b : -INFINITY;
-        s_stage[((size_t)wv * 2 + 0) * stride + node] = ivA[c]; s_stage[((size_t)wv * 2 + 1) * stride + node] = ivB[c];
+        s_stage[((size_t)win * 2 + 0) * stride + node] = ivA[c]; s_stage[((size_t)win * 2 + 1) * stride + node] = ivB[c];
       }
+      if (WPW > 1 && half < WPW - 1 && lane == 63) { s_xch[wv * 2 + 0] = ivA[0]; s_xch[wv * 2 + 1] = ivB[0]; }   // for lane 0 of the wave below (read after the barriers)
       lds_barrier();
       // ---- 2. the serial part
       if (chain_lane) {
@@ -1044,8 +1052,9 @@ __global__ __launch_bounds__(bwd_chain_threads(C)) void fs3_bwd_chain_kernel(Seq
       if (wv == 0) chain_done(s_ctl + 4, pair); else if (chain_poller(wv)) chain_keepalive(s_ctl + 4, pair);
       lds_barrier();
       // ---- 3. the cells of both rows (:1574-1600)
-      const float EA = s_e[wv * 2 + 0], EB = s_e[wv * 2 + 1];
-      const float ivNextA = wave_shr1(ivA[0], -INFINITY), ivNextB = wave_shr1(ivB[0], -INFINITY);
+      const float EA = s_e[win * 2 + 0], EB = s_e[win * 2 + 1];
+      float ivNextA = wave_shr1(ivA[0], -INFINITY), ivNextB = wave_shr1(ivB[0], -INFINITY);
+      if (WPW > 1 && half > 0 && lane == 0) { ivNextA = s_xch[(wv - 1) * 2 + 0]; ivNextB = s_xch[(wv - 1) * 2 + 1]; }
       float MA[C], IA[C], MB[C], IB[C];
 #pragma unroll
       for (int c = C - 1; c >= 0; c--) {
@@ -1053,8 +1062,8 @@ __global__ __launch_bounds__(bwd_chain_threads(C)) void fs3_bwd_chain_kernel(Seq
         const bool in = node <= M;
         const float4 t0 = *reinterpret_cast<const float4 *>(wt + nd * 8);              // tMD tMI tMM tDD
         const float tii = wt[nd * 8 + 5], tim = wt[nd * 8 + 6];
-        const float dnA = (node < M) ? s_stage[((size_t)wv * 2 + 0) * stride + node + 1] : -INFINITY;
-        const float dnB = (node < M) ? s_stage[((size_t)wv * 2 + 1) * stride + node + 1] : -INFINITY;
+        const float dnA = (node < M) ? s_stage[((size_t)win * 2 + 0) * stride + node + 1] : -INFINITY;
+        const float dnB = (node < M) ? s_stage[((size_t)win * 2 + 1) * stride + node + 1] : -INFINITY;
         const float inA = (c == C - 1) ? ivNextA : ivA[c + 1], inB = (c == C - 1) ? ivNextB : ivB[c + 1];
         float mvA, ivoA, mvB, ivoB;
         // row A: avail = 2q
@@ -1075,7 +1084,7 @@ __global__ __launch_bounds__(bwd_chain_threads(C)) void fs3_bwd_chain_kernel(Seq
 #ifdef BATH_CHAIN_CLOCK
     if (wv == 0 && lane == 0 && blockIdx.x == 0 && dbgb_n > 0) printf("bwd chain: B sum %.1f ticks per node, D chain %.1f ticks per node (%lld nodes)\n", (double)dbgb_cyc / dbgb_n, (double)dbgd_cyc / dbgb_n, dbgb_n);
 #endif
-    if (job >= 0 && !live && lane == 0) sc[job] = -INFINITY;
+    if (job >= 0 && !live && lane == 0 && half == 0) sc[job] = -INFINITY;
     __syncthreads();
   }
 #undef LS
@@ -1451,7 +1460,7 @@ static int chain_batches(bath_hip_ctx *ctx, hipStream_t stream, const bath_hip_s
 
 static int chain_waves(bath_hip_ctx *ctx, int64_t n, int M, int C, size_t *shmem_out, int cu_share = 1, int threads = 0, int trans_floats = 0) {
   // as many windows per block as LDS holds next to the table and the transitions ...
-  const size_t fixed = (size_t)(kLogsumTbl + (trans_floats ? trans_floats : (M + 2) * 8) + 2 * kChainMaxWaves + 16) * sizeof(float);
+  const size_t fixed = (size_t)(kLogsumTbl + (trans_floats ? trans_floats : (M + 2) * 8) + 2 * kChainMaxWaves + 16 + 2 * kChainMaxWaves) * sizeof(float);   // ... E values, control words, the waves' hand-over
   int W = (threads ? threads : chain_threads(C)) / 64;
   while (W > 1 && fixed + (size_t)W * 2 * fs_chain_stride(C) * sizeof(float) > 160 * 1024) W >>= 1;
   // ... but no more than it takes to give every block a CU of its own: the waves of a block go through the parallel part of a
@@ -1588,6 +1597,20 @@ int launch_fs3_bwd_chain(bath_hip_ctx *ctx, hipStream_t stream, const bath_hip_f
   if (stb != BATH_OK) return stb;
   const int grid = std::max(1, std::min(nbat, (int)ctx->prop.multiProcessorCount));
   FsDev dev{om->M, om->pitch, om->maxcodons, om->d_rsc, om->d_tf, om->d_tb, om->d_logsum};
+  // long models: two waves per window (BATH_HIP_FS_BWD_WPW=1: one, for A/B runs)
+  static const int wpw_env = [] { const char *e = std::getenv("BATH_HIP_FS_BWD_WPW"); return e ? std::atoi(e) : 2; }();
+  if (chain_compact(Cv) && wpw_env == 2 && W <= 4 && (Cv == 12 || Cv == 16 || Cv == 20)) {
+    // (up to four windows per block: eight waves of 256 registers.  Eight windows would be sixteen waves of 128 registers: 86 spilled at
+    // 8 nodes per lane, and no faster than one wave per window -- 157 us per row pair either way at M = 1024)
+#define BATH_BWD2(C_, T_)                                                                                                          \
+    case 2 * C_: BATH_HIP_TRY(ctx, bath::allow_max_lds((const void *)fs3_bwd_chain_kernel<C_, 2, T_>));                              \
+                 hipLaunchKernelGGL((fs3_bwd_chain_kernel<C_, 2, T_>), dim3(grid), dim3(64 * std::max(2 * W, kChainAwakeWaves)), shmem, stream, dna->view(), dev, om->d_loop[0], om->d_move[0], tEL, tEM, \
+                                    d_sc, d_xmx, d_xoff, jobs, b_bst.as<int32_t>(), nbat, W); break;
+    switch (Cv) { BATH_BWD2(6, 512) BATH_BWD2(8, 512) BATH_BWD2(10, 512) }
+#undef BATH_BWD2
+    BATH_HIP_TRY(ctx, hipGetLastError());
+    return BATH_OK;
+  }
   BATH_CHAIN_SWITCH(Cv, {
     BATH_HIP_TRY(ctx, bath::allow_max_lds((const void *)fs3_bwd_chain_kernel<CC>));
     hipLaunchKernelGGL((fs3_bwd_chain_kernel<CC>), dim3(grid), dim3(64 * std::max(W, kChainAwakeWaves)), shmem, stream, dna->view(), dev, om->d_loop[0], om->d_move[0], tEL, tEM, d_sc, d_xmx, d_xoff, jobs,
