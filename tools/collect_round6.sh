@@ -12,7 +12,7 @@ cp $S/kernel_stats_fs_strict.csv $D/r06_fs_strict_kernel_stats.csv
 cp $S/kernel_stats_fs_fast.csv $D/r06_fs_fast_kernel_stats.csv
 cp $S/kernel_stats_c4_c5.csv $D/r06_c4_c5_kernel_stats.csv
 cp $S/gputest_all.log $D/r06_gputest_all.log
-for f in fs_pass_timeline fs_concurrent_timeline fs_workers c4_query_timeline_RtcB c4_query_timeline_PTH2 c4_items chain_long_probe fs_windows_ab fs_host_threads pmc_summary fwd_mem_probe c5_timeline_250mb; do
+for f in fs_pass_timeline fs_concurrent_timeline fs_workers c4_query_timeline_RtcB c4_query_timeline_PTH2 c4_items chain_long_probe fs_windows_ab fs_host_threads pmc_summary fwd_mem_probe c5_timeline_250mb bwd_wpw_probe; do
   grep -v "amdgpu.ids\|simple_timer" $S/$f.txt > $D/r06_$f.txt
 done
 cp $S/pmc_by_kernel.json $D/r06_pmc_by_kernel_200k_windows.json
