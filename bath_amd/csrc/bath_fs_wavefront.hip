@@ -478,21 +478,33 @@ __global__ __launch_bounds__(W == 1 ? kWfBlock : 64 * W) void fs5_bwd_wf_kernel(
 template <bool EXACT>
 __global__ __launch_bounds__(kFsBlock) void fs5_bwd_x_kernel(SeqView dna, int M, const float *__restrict__ logsum_g, const float *__restrict__ loop_tab, const float *__restrict__ move_tab,
                                                              float *__restrict__ xmx, const int64_t *__restrict__ xmx_off, const float *__restrict__ terms, const int64_t *__restrict__ term_off,
-                                                             float *__restrict__ sc, FsJobs jobs, int RW /* rows the sweep had in flight: 64 x its waves per envelope */) {
+                                                             float *__restrict__ sc, FsJobs jobs, int RW /* rows the sweep had in flight: 64 x its waves per envelope */,
+                                                             int team /* 1: the waves of a block share one envelope (few long envelopes: a row group of 64 each in turn) */) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   float *s_tbl = reinterpret_cast<float *>(lds);
+  __shared__ int s_job;
   fs_load_logsum_table(s_tbl, logsum_g);
   __syncthreads();
-  const int lane = threadIdx.x & 63;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = team ? (int)(blockDim.x >> 6) : 1;
   const int Mp = fs_wf_period(M, RW);
 #define LS(a, b) flogsum<EXACT>((a), (b), s_tbl)
-  for (int64_t job = fs_next_job(jobs, dna.n, lane); job >= 0; job = fs_next_job(jobs, dna.n, lane)) {
+  // the next envelope: of the wave, or (team) of the block -- B(i) of different rows are independent sums, so the block's waves take the
+  // row groups in turn and wave 0 runs the N / J chain once they are all in place (M = 1024, 257 envelopes of ~3 kb: a wave per envelope
+  // is 8.8 ms on 33 CUs)
+  auto next_job = [&]() -> int64_t {
+    if (!team) return fs_next_job(jobs, dna.n, lane);
+    __syncthreads();                                                    // the previous envelope's N / J chain has read what the waves stored
+    if (threadIdx.x == 0) { const unsigned q = atomicAdd(jobs.counter, 1u); s_job = (int64_t)q < dna.n ? (int)jobs.order[q] : -1; }
+    __syncthreads();
+    return (int64_t)s_job;
+  };
+  for (int64_t job = next_job(); job >= 0; job = next_job()) {
     const int L = dna.len[job];
-    if (L < 5) { if (lane == 0) sc[job] = -INFINITY; continue; }
+    if (L < 5) { if (threadIdx.x == 0 || (!team && lane == 0)) sc[job] = -INFINITY; continue; }
     float *xo = xmx + xmx_off[job];
     const float *tm = terms + term_off[job];
     const float tNL = loop_tab[L / 3], tNM = move_tab[L / 3], tJL = tNL, tJM = tNM;
-    for (int g0 = 0; g0 <= L; g0 += 64) {                               // 64 rows at a time: the rows a wave of the sweep owned in one round
+    for (int g0 = team ? 64 * wv : 0; g0 <= L; g0 += 64 * nw) {         // 64 rows at a time: the rows a wave of the sweep owned in one round
       const int j = g0 + lane;                                          // this lane's row: i = L - j
       const int pr = g0 / RW, gl = (g0 % RW) + lane;                    // its round and its place in the sweep's pipeline
       float b = -INFINITY;
@@ -515,7 +527,8 @@ __global__ __launch_bounds__(kFsBlock) void fs5_bwd_x_kernel(SeqView dna, int M,
       }
       if (j <= L) xo[(size_t)(L - j) * 5 + 3] = (j == 0) ? -INFINITY : b;   // row L: no codon starts there, B(L) = -inf
     }
-    __threadfence_block();
+    if (team) { __syncthreads(); if (wv != 0) continue; }               // (the barrier is also the fence: the other waves' B(i) are in place)
+    else __threadfence_block();
     float nfin = -INFINITY;                                             // N of the chain's last row (i = 0, 1 or 2)
     if (lane < 3) {
       float n = -INFINITY, jj = -INFINITY;
@@ -648,12 +661,16 @@ int launch_fs5_bwd_wf(bath_hip_ctx *ctx, hipStream_t stream, const bath_hip_fspr
   BATH_WF_DISPATCH(fs5_bwd_wf_kernel, dna->view(), dev, om->d_loop[1], om->d_move[1], d_bck, d_boff, d_xmx, d_xoff, terms_scratch.as<float>(), toff_scratch.as<int64_t>(), g.ring_g, jobs_sweep, dbg);
   BATH_HIP_TRY(ctx, hipGetLastError());
   const int xwaves = kFsBlock / 64;
-  const int xgrid = (int)std::max<int64_t>(1, std::min<int64_t>((n + xwaves - 1) / xwaves, (int64_t)ctx->prop.multiProcessorCount * 2));
+  // few envelopes (a wave each would leave most CUs without a block): a block per envelope, its waves sharing the rows
+  static const int team_env = [] { const char *e = std::getenv("BATH_HIP_FS_BWDX_TEAM"); return e ? std::atoi(e) : -1; }();
+  const int team = team_env >= 0 ? (team_env != 0) : (n <= (int64_t)ctx->prop.multiProcessorCount * 2 ? 1 : 0);
+  const int xgrid = team ? (int)std::max<int64_t>(1, std::min<int64_t>(n, (int64_t)ctx->prop.multiProcessorCount * 2))
+                         : (int)std::max<int64_t>(1, std::min<int64_t>((n + xwaves - 1) / xwaves, (int64_t)ctx->prop.multiProcessorCount * 2));
   const size_t xshmem = (size_t)kLogsumTbl * sizeof(float);
   if (exact) hipLaunchKernelGGL((fs5_bwd_x_kernel<true>), dim3(xgrid), dim3(kFsBlock), xshmem, stream, dna->view(), M, om->d_logsum, om->d_loop[1], om->d_move[1], d_xmx, d_xoff,
-                                terms_scratch.as<float>(), toff_scratch.as<int64_t>(), d_sc, jobs_x, RW);
+                                terms_scratch.as<float>(), toff_scratch.as<int64_t>(), d_sc, jobs_x, RW, team);
   else hipLaunchKernelGGL((fs5_bwd_x_kernel<false>), dim3(xgrid), dim3(kFsBlock), xshmem, stream, dna->view(), M, om->d_logsum, om->d_loop[1], om->d_move[1], d_xmx, d_xoff,
-                          terms_scratch.as<float>(), toff_scratch.as<int64_t>(), d_sc, jobs_x, RW);
+                          terms_scratch.as<float>(), toff_scratch.as<int64_t>(), d_sc, jobs_x, RW, team);
   BATH_HIP_TRY(ctx, hipGetLastError());
   return BATH_OK;
 }
