@@ -248,3 +248,10 @@ def test_blocks_the_device_window_path_refuses_fall_back_to_the_host_path():
     thread; the pipeline then fetches the survivors and runs the host path.  BATH_HIP_FSW_MAX_GROUP=1 makes every input with two
     surviving ORFs on one strand such a block: the strict pipeline tests must hold through the fallback."""
     _rerun({"BATH_HIP_FSW_MAX_GROUP": "1"}, "strict_pipeline_is_exact or planted_frameshifted or cascade_lanes or recorded_fs")
+
+
+def test_envelope_b_sums_by_a_wave_per_envelope_too():
+    """fs5_bwd_x_kernel adds up B(i) of an envelope's rows with the waves of a block sharing ONE envelope when a launch has few envelopes
+    (every test input) and with a wave per envelope otherwise (the bench block's thousands).  BATH_HIP_FS_BWDX_TEAM=0 runs the strict
+    pipeline tests through the wave-per-envelope form."""
+    _rerun({"BATH_HIP_FS_BWDX_TEAM": "0"}, "strict_pipeline_is_exact or planted_frameshifted or recorded_fs")
