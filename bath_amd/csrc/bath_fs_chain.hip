@@ -272,11 +272,18 @@ __device__ __forceinline__ float bwd_bsum_nodes(float b, float v, float sN, floa
 // (<mid>, a lane mask) take them in the other order (:1524-1526).  Two dependent look-ups per node; the loads of node k-1 sit
 // behind the first, the address arithmetic behind the second; D(i,k) is stored over ivx(i,k), which was read a node ahead.
 //   dn   D(i,k+1) (in/out);  IVN: ivx(i,k+1);  set A = {ivx(i,k), tDD(k), tDM(k)};  st at slot k-1, tp at s_tb[(k-1) * 8 + 3]
-#define BATH_BWD_D_NODE(IVN, TX, TY, IVQ, UX, UY, NTS)                                 \
+// (H: the node's first instructions -- BATH_BWD_D_HEAD_MID selects the order per lane; BATH_BWD_D_HEAD_PLAIN is the order of every row
+// but L-3 and L-4, without the two selects, one of which sits on the dependent path: all pairs of a block but the second and third)
+#define BATH_BWD_D_HEAD_MID(IVN, TX, TY)                                               \
   "v_add_f32 %[u], %[dn], " TX "\n\t"                                                  \
   "v_add_f32 %[bs], " IVN ", " TY "\n\t"                                               \
   "v_cndmask_b32_e64 %[p1], %[u], %[bs], %[mid]\n\t"                                   \
-  "v_cndmask_b32_e64 %[p2], %[bs], %[u], %[mid]\n\t"                                   \
+  "v_cndmask_b32_e64 %[p2], %[bs], %[u], %[mid]\n\t"
+#define BATH_BWD_D_HEAD_PLAIN(IVN, TX, TY)                                             \
+  "v_add_f32 %[p1], %[dn], " TX "\n\t"                                                 \
+  "v_add_f32 %[p2], " IVN ", " TY "\n\t"
+#define BATH_BWD_D_NODE(H, IVN, TX, TY, IVQ, UX, UY, NTS)                              \
+  H(IVN, TX, TY)                                                                       \
   BATH_LS_INDEX("%[a1]", "%[xE]", "%[p1]")                                             \
   "ds_read_b32 " IVQ ", %[st]\n\t"                                                     \
   "ds_read_b32 " UX ", %[tp]\n\t"                                                      \
@@ -298,11 +305,11 @@ template <bool COMPACT = false>
 __device__ __forceinline__ void bwd_d_nodes(BwdChainRegs &r, float xE, unsigned long long mid, int n, unsigned tbl, float c15) {
   float ivq, ux, uy, u, bs, p1, p2, a1, mx1, x;
   int k = 0;
-#define BATH_BWD_D_PAIR(NTS)                                                                                                             \
+#define BATH_BWD_D_PAIR(NTS, H)                                                                                                          \
   for (; k + BATH_CHAIN_UNROLL <= n; k += BATH_CHAIN_UNROLL)                                                                            \
     asm volatile("s_waitcnt lgkmcnt(0)\n\t"                                                                                             \
-                 BATH_CHAIN_REPEAT(BATH_BWD_D_NODE("%[ivn]", "%[tx]", "%[ty]", "%[ivq]", "%[ux]", "%[uy]", NTS)                          \
-                                   BATH_BWD_D_NODE("%[ivk]", "%[ux]", "%[uy]", "%[ivk]", "%[tx]", "%[ty]", NTS)                          \
+                 BATH_CHAIN_REPEAT(BATH_BWD_D_NODE(H, "%[ivn]", "%[tx]", "%[ty]", "%[ivq]", "%[ux]", "%[uy]", NTS)                          \
+                                   BATH_BWD_D_NODE(H, "%[ivk]", "%[ux]", "%[uy]", "%[ivk]", "%[tx]", "%[ty]", NTS)                          \
                                    "v_mov_b32 %[ivn], %[ivq]\n\t")                                                                      \
                  "s_waitcnt lgkmcnt(0)"                                                                                                 \
                  : [dn] "+v"(r.dn), [ivn] "+v"(r.ivn), [ivk] "+v"(r.ivk), [tx] "+v"(r.tx), [ty] "+v"(r.ty), [st] "+v"(r.st), [tp] "+v"(r.tp), \
@@ -312,8 +319,8 @@ __device__ __forceinline__ void bwd_d_nodes(BwdChainRegs &r, float xE, unsigned 
                  : "memory");                                                                                                           \
   for (; k + 2 <= n; k += 2)                                                                                                            \
     asm volatile("s_waitcnt lgkmcnt(0)\n\t"                                                                                             \
-                 BATH_BWD_D_NODE("%[ivn]", "%[tx]", "%[ty]", "%[ivq]", "%[ux]", "%[uy]", NTS)                                           \
-                 BATH_BWD_D_NODE("%[ivk]", "%[ux]", "%[uy]", "%[ivk]", "%[tx]", "%[ty]", NTS)                                           \
+                 BATH_BWD_D_NODE(H, "%[ivn]", "%[tx]", "%[ty]", "%[ivq]", "%[ux]", "%[uy]", NTS)                                           \
+                 BATH_BWD_D_NODE(H, "%[ivk]", "%[ux]", "%[uy]", "%[ivk]", "%[tx]", "%[ty]", NTS)                                           \
                  "v_mov_b32 %[ivn], %[ivq]\n\t"                                                                                         \
                  "s_waitcnt lgkmcnt(0)"                                                                                                 \
                  : [dn] "+v"(r.dn), [ivn] "+v"(r.ivn), [ivk] "+v"(r.ivk), [tx] "+v"(r.tx), [ty] "+v"(r.ty), [st] "+v"(r.st), [tp] "+v"(r.tp), \
@@ -323,7 +330,7 @@ __device__ __forceinline__ void bwd_d_nodes(BwdChainRegs &r, float xE, unsigned 
                  : "memory");                                                                                                           \
   if (k < n) {                                                                                                                          \
     asm volatile("s_waitcnt lgkmcnt(0)\n\t"                                                                                             \
-                 BATH_BWD_D_NODE("%[ivn]", "%[tx]", "%[ty]", "%[ivq]", "%[ux]", "%[uy]", NTS)                                           \
+                 BATH_BWD_D_NODE(H, "%[ivn]", "%[tx]", "%[ty]", "%[ivq]", "%[ux]", "%[uy]", NTS)                                           \
                  "s_waitcnt lgkmcnt(0)"                                                                                                 \
                  : [dn] "+v"(r.dn), [st] "+v"(r.st), [tp] "+v"(r.tp),                                                                   \
                    [ivq] "=&v"(ivq), [ux] "=&v"(ux), [uy] "=&v"(uy), [u] "=&v"(u), [bs] "=&v"(bs), [p1] "=&v"(p1), [p2] "=&v"(p2),       \
@@ -332,7 +339,8 @@ __device__ __forceinline__ void bwd_d_nodes(BwdChainRegs &r, float xE, unsigned 
                  : "memory");                                                                                                           \
     r.ivn = r.ivk; r.ivk = ivq; r.tx = ux; r.ty = uy;                                                                                   \
   }
-  if constexpr (COMPACT) { BATH_BWD_D_PAIR("-16") } else { BATH_BWD_D_PAIR("-32") }
+  if (mid == 0) { if constexpr (COMPACT) { BATH_BWD_D_PAIR("-16", BATH_BWD_D_HEAD_PLAIN) } else { BATH_BWD_D_PAIR("-32", BATH_BWD_D_HEAD_PLAIN) } }
+  else { if constexpr (COMPACT) { BATH_BWD_D_PAIR("-16", BATH_BWD_D_HEAD_MID) } else { BATH_BWD_D_PAIR("-32", BATH_BWD_D_HEAD_MID) } }
 #undef BATH_BWD_D_PAIR
 }
 
