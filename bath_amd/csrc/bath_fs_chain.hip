@@ -1545,7 +1545,8 @@ int launch_fs3_fwd_chain(bath_hip_ctx *ctx, hipStream_t stream, const bath_hip_f
     if (mem_env != 1) while (Wm > 1 && (int64_t)(Wm / 2) * slots >= n) Wm >>= 1;
     if (Wm > W && (mem_env == 1 || 2 * n > 3 * slots * W)) {     // (a pair takes 119 us here against 101: not before the other kernel needs a round and a half)
       const size_t ms = fixed + (size_t)Wm * 2 * fs_chain_stride(Cv) * sizeof(float);
-      const int mgrid = (int)std::max<int64_t>(1, std::min<int64_t>((n + Wm - 1) / Wm, (int64_t)ctx->prop.multiProcessorCount));
+      static const int grid_env = [] { const char *e = std::getenv("BATH_HIP_FS_FWD_MEM_GRID"); return e ? std::atoi(e) : 0; }();   // tests: few blocks, several batches each
+      const int mgrid = (int)std::max<int64_t>(1, std::min<int64_t>((n + Wm - 1) / Wm, grid_env > 0 ? (int64_t)grid_env : (int64_t)ctx->prop.multiProcessorCount));
       DevBuf &b_hist = ctx->scratch[58];
       BATH_HIP_TRY(ctx, b_hist.reserve((size_t)mgrid * Wm * 2 * kChainHistRows * fs_chain_hist_pitch(Cv) * sizeof(float)));
 #define BATH_MEM(C_)                                                                                                               \

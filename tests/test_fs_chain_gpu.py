@@ -170,14 +170,15 @@ print("mem kernel ok", len(wins))
 """
 
 
-@pytest.mark.parametrize("M,extra", [(700, {}), (1000, {}), (1024, {}), (1024, {"BATH_HIP_FS_BWD_WPW": "1"})])
+@pytest.mark.parametrize("M,extra", [(700, {}), (1000, {}), (1024, {}), (1024, {"BATH_HIP_FS_BWD_WPW": "1"}), (1024, {"BATH_HIP_FS_FWD_MEM_GRID": "3"})])
 def test_fs3_forward_chain_with_the_history_in_memory_is_bit_identical(tmp_path, M, extra):
     """fs3_fwd_chain_mem_kernel (long models, eight windows per block, the rows' history in global memory: what configs[4] takes from
     250 Mb on) forced onto ~80 windows of 15..520 nt with BATH_HIP_FS_FWD_MEM=1: 12 and 16 nodes per lane (1000: node slots past the
     model's end), batches whose windows end at different rows, windows too short for a codon.  Scores and special-state rows against
     the oracle, bit for bit.  The script checks the Backward parser on the same windows: the long models' kernel with two waves per
     window (the default up to four windows per block), and with BATH_HIP_FS_BWD_WPW=1 the one-wave instantiation that blocks of eight
-    windows take."""
+    windows take.  BATH_HIP_FS_FWD_MEM_GRID=3: three blocks for the ten batches, so that a block's history records are reused by the
+    windows of its next batches (configs[4] at 1 Gb: 330 batches on 256 blocks)."""
     env = dict(os.environ, BATH_HIP_FS_FWD_MEM="1", **extra)
     r = subprocess.run([sys.executable, "-c", MEM_SCRIPT.format(root=ROOT, path=str(tmp_path / ("s%d.bhmm" % M)), M=M)],
                        env=env, capture_output=True, text=True, timeout=900)
