@@ -512,7 +512,7 @@ __global__ __launch_bounds__(chain_threads(C)) void fs3_fwd_chain_kernel(SeqView
 // touches per group is contiguous -- 1 KB of a history row per load or store, 256 consecutive emission scores per codon row, the
 // stage row's slots -- and the transitions, kept as six arrays by kind (tMM, tIM, tDM, tBM, tMI, tII at node k in slot k - 1),
 // are read as one float4 per lane without LDS bank conflicts (with a lane owning C consecutive nodes of tf's rows of eight, the
-// kernel above reads them 64 lanes to a bank: its parallel part is 33 k clocks of LDS time per pair at four windows).  The rows
+// kernel above reads them 64 lanes to a bank).  The rows
 // i-1, i-2 "at node k-1" are the same vectors moved on by one node: the lane below's last element (DPP), lane 0 taking lane
 // 63's of the group before.  Every log-sum has the operands and the order of the kernel above.
 // Traffic: 72 KB per window and row pair at M = 1024 (ten rows in, eight out) against a pair's ~100 us: ~5 GB/s per CU.
